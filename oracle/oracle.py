@@ -1,0 +1,244 @@
+"""ctypes adapter for the CPU oracle (oracle/vgx_oracle.c) — TEST INFRASTRUCTURE ONLY.
+
+Only tests/, ``__graft_entry__.smoke()`` and ``bench.py``'s cpu_baseline leg import this module; the
+product package ``vgsim_amd`` never does.  ``run_direct`` / ``run_tau`` take a host model object
+(``vgsim_amd.BirthDeathModel``: parameters and state in numpy arrays named as in the reference), run
+the C restatement in place on those arrays and leave the model exactly as the reference's
+``SimulatePopulation`` / ``SimulatePopulation_tau`` would (event log, counters, state).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB = os.path.join(HERE, "libvgx_oracle.so")
+
+LOG_LIBM, LOG_PORTABLE = 0, 1
+
+_F = C.POINTER(C.c_double)
+_I = C.POINTER(C.c_int64)
+_U = C.POINTER(C.c_uint64)
+
+_FIELDS = [
+    ("sites", C.c_int64), ("hapNum", C.c_int64), ("popNum", C.c_int64), ("susNum", C.c_int64),
+    ("user_seed", C.c_int64),
+    ("bRate", _F), ("dRate", _F), ("sRate", _F), ("mRate", _F), ("hapMutType", _F), ("susceptibility", _F),
+    ("suscType", _I), ("suscepTransition", _F), ("sizes", _I),
+    ("contactDensity", _F), ("contactDensityBeforeLockdown", _F), ("contactDensityAfterLockdown", _F),
+    ("startLD", _F), ("endLD", _F), ("samplingMultiplier", _F), ("migrationRates", _F),
+    ("susceptible", _I), ("infectious", _I), ("initial_susceptible", _I), ("initial_infectious", _I),
+    ("totalSusceptible", _I), ("totalInfectious", _I), ("lockdownON", _I),
+    ("tmRate", _F), ("eventHapPopRate", _F), ("tEventHapPopRate", _F), ("hapPopRate", _F),
+    ("susceptHapPopRate", _F), ("suscepCumulTransition", _F), ("immuneSourcePopRate", _F),
+    ("infectPopRate", _F), ("immunePopRate", _F), ("popRate", _F), ("migPopRate", _F), ("actualSizes", _F),
+    ("maxEffectiveBirthMigration", _F), ("effectiveMigration", _F),
+    ("first_simulation", C.c_int64), ("globalInfectious", C.c_int64),
+    ("bCounter", C.c_int64), ("dCounter", C.c_int64), ("sCounter", C.c_int64), ("mCounter", C.c_int64),
+    ("iCounter", C.c_int64), ("swapLockdown", C.c_int64), ("migPlus", C.c_int64), ("migNonPlus", C.c_int64),
+    ("good_attempt", C.c_int64),
+    ("currentTime", C.c_double), ("totalRate", C.c_double), ("totalMigrationRate", C.c_double),
+    ("rn", C.c_double), ("tau_l", C.c_double),
+    ("ev_size", C.c_int64), ("ev_ptr", C.c_int64), ("ev_times", _F), ("ev_types", _I), ("ev_haplotypes", _I),
+    ("ev_populations", _I), ("ev_newHaplotypes", _I), ("ev_newPopulations", _I),
+    ("mev_size", C.c_int64), ("mev_ptr", C.c_int64), ("mev_num", _I), ("mev_times", _F), ("mev_types", _I),
+    ("mev_haplotypes", _I), ("mev_populations", _I), ("mev_newHaplotypes", _I), ("mev_newPopulations", _I),
+    ("loc_cap", C.c_int64), ("loc_n", C.c_int64), ("loc_states", _I), ("loc_populations", _I), ("loc_times", _F),
+    ("infectiousAuxTau", _F), ("susceptibleAuxTau", _F), ("infectiousDelta", _I), ("susceptibleDelta", _I),
+    ("sparse", C.c_int64), ("log_mode", C.c_int64), ("iterations_done", C.c_int64), ("error", C.c_int64),
+    ("occ", _U),
+]
+
+
+class VgoModel(C.Structure):
+    _fields_ = _FIELDS
+
+
+class VgoPcg64(C.Structure):
+    _fields_ = [("state_hi", C.c_uint64), ("state_lo", C.c_uint64), ("inc_hi", C.c_uint64), ("inc_lo", C.c_uint64)]
+
+
+def build(force=False):
+    """Compile the oracle with gcc (oracle/Makefile)."""
+    if force or not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(os.path.join(HERE, "vgx_oracle.c")):
+        subprocess.check_call(["make", "-s", "-C", HERE])
+    return LIB
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(LIB)
+        for fn in (L.vgo_simulate_direct, L.vgo_simulate_tau):
+            fn.argtypes = [C.POINTER(VgoModel), C.c_int64, C.c_int64, C.c_float, C.c_int64]
+            fn.restype = C.c_int
+        L.vgo_update_all_rates.argtypes = [C.POINTER(VgoModel)]
+        L.vgo_update_all_rates.restype = None
+        L.vgo_prop_num.argtypes = [C.POINTER(VgoModel)]
+        L.vgo_prop_num.restype = C.c_int64
+        L.vgo_pcg64_seed.argtypes = [C.POINTER(VgoPcg64), C.c_uint64, C.c_uint32]
+        L.vgo_pcg64_double.argtypes = [C.POINTER(VgoPcg64)]
+        L.vgo_pcg64_double.restype = C.c_double
+        L.vgo_pcg64_next64.argtypes = [C.POINTER(VgoPcg64)]
+        L.vgo_pcg64_next64.restype = C.c_uint64
+        L.vgo_pcg64_advance.argtypes = [C.POINTER(VgoPcg64), C.c_uint64, C.c_uint64]
+        L.vgo_poisson.argtypes = [C.POINTER(VgoPcg64), C.c_double]
+        L.vgo_poisson.restype = C.c_int64
+        L.vgo_portable_log.argtypes = [C.c_double]
+        L.vgo_portable_log.restype = C.c_double
+        _lib = L
+    return _lib
+
+
+def _ptr(a):
+    if a.dtype == np.float64:
+        return a.ctypes.data_as(_F)
+    if a.dtype == np.int64:
+        return a.ctypes.data_as(_I)
+    if a.dtype == np.uint64:
+        return a.ctypes.data_as(_U)
+    raise TypeError(a.dtype)
+
+
+class OracleState:
+    """The reference's rate caches (pyx:150-155, 182-199), kept beside a host model between calls so
+    tests can inspect them; allocated lazily, owned by Python."""
+
+    def __init__(self, model, record_multievents=False, loc_cap=1 << 16):
+        H, P, S = model.hapNum, model.popNum, model.susNum
+        z = np.zeros
+        self.tmRate = z(H)
+        self.eventHapPopRate = z((P, H, 4))
+        self.tEventHapPopRate = z((P, H))
+        self.hapPopRate = z((P, H))
+        self.susceptHapPopRate = z((P, H, S))
+        self.suscepCumulTransition = z(S)
+        self.immuneSourcePopRate = z((P, S))
+        self.infectPopRate, self.immunePopRate, self.popRate = z(P), z(P), z(P)
+        self.migPopRate, self.maxEffectiveBirthMigration = z(P), z(P)
+        self.effectiveMigration = z((P, P))
+        self.infectiousAuxTau = z((P, H))
+        self.susceptibleAuxTau = z((P, S))
+        self.infectiousDelta = z((P, H), dtype=np.int64)
+        self.susceptibleDelta = z((P, S), dtype=np.int64)
+        self.occ = z((P, (H + 63) // 64), dtype=np.uint64)
+        self.loc_states = z(loc_cap, dtype=np.int64)
+        self.loc_populations = z(loc_cap, dtype=np.int64)
+        self.loc_times = z(loc_cap)
+        self.record_multievents = record_multievents
+        self.mev = None          # dict of dense multievent arrays (reference layout) when recorded
+        self.mev_ptr = 0
+        self.iterations_done = 0
+
+
+def _struct(model, st, sparse, log_mode):
+    m = VgoModel()
+    m.sites, m.hapNum, m.popNum, m.susNum = model.sites, model.hapNum, model.popNum, model.susNum
+    m.user_seed = model.user_seed
+    for name in ("bRate", "dRate", "sRate", "mRate", "hapMutType", "susceptibility", "suscType",
+                 "suscepTransition", "sizes", "contactDensity", "contactDensityBeforeLockdown",
+                 "contactDensityAfterLockdown", "startLD", "endLD", "samplingMultiplier", "migrationRates",
+                 "susceptible", "infectious", "initial_susceptible", "initial_infectious", "totalSusceptible",
+                 "totalInfectious", "lockdownON", "actualSizes"):
+        a = getattr(model, name)
+        assert a.flags["C_CONTIGUOUS"], name
+        setattr(m, name, _ptr(a))
+    for name in ("tmRate", "eventHapPopRate", "tEventHapPopRate", "hapPopRate", "susceptHapPopRate",
+                 "suscepCumulTransition", "immuneSourcePopRate", "infectPopRate", "immunePopRate", "popRate",
+                 "migPopRate", "maxEffectiveBirthMigration", "effectiveMigration", "infectiousAuxTau",
+                 "susceptibleAuxTau", "infectiousDelta", "susceptibleDelta", "occ", "loc_states",
+                 "loc_populations", "loc_times"):
+        setattr(m, name, _ptr(getattr(st, name)))
+    m.loc_cap, m.loc_n = len(st.loc_states), 0
+    m.first_simulation = int(model.first_simulation)
+    m.globalInfectious = int(model.globalInfectious)
+    for c in model.COUNTERS + ("good_attempt",):
+        setattr(m, c, int(getattr(model, c)))
+    m.currentTime, m.totalRate, m.totalMigrationRate = model.currentTime, model.totalRate, model.totalMigrationRate
+    m.tau_l = model.tau_l
+    ev = model.events
+    m.ev_size, m.ev_ptr = ev.size, ev.ptr
+    m.ev_times = _ptr(ev.times)
+    m.ev_types, m.ev_haplotypes, m.ev_populations = _ptr(ev.types), _ptr(ev.haplotypes), _ptr(ev.populations)
+    m.ev_newHaplotypes, m.ev_newPopulations = _ptr(ev.newHaplotypes), _ptr(ev.newPopulations)
+    m.sparse, m.log_mode = int(sparse), int(log_mode)
+    m.iterations_done = 0
+    return m
+
+
+def _absorb(model, st, m):
+    model.first_simulation = bool(m.first_simulation)
+    model.globalInfectious = m.globalInfectious
+    for c in model.COUNTERS + ("good_attempt",):
+        setattr(model, c, getattr(m, c))
+    model.currentTime, model.totalRate, model.totalMigrationRate = m.currentTime, m.totalRate, m.totalMigrationRate
+    model.tau_l = m.tau_l
+    model.events.ptr = m.ev_ptr
+    for k in range(m.loc_n):
+        model.loc.AddLockdown(st.loc_states[k], st.loc_populations[k], st.loc_times[k])
+    st.iterations_done = m.iterations_done
+
+
+def get_state(model):
+    st = getattr(model, "_oracle_state", None)
+    if st is None:
+        st = model._oracle_state = OracleState(model)
+    return st
+
+
+def run_direct(model, iterations, sample_size, time, attempts, sparse=False, log_mode=LOG_LIBM):
+    """The oracle's SimulatePopulation (pyx:396-429) on a host model; returns the error code."""
+    st = get_state(model)
+    model.events.CreateEvents(iterations)  # PrepareParameters pyx:434
+    m = _struct(model, st, sparse, log_mode)
+    rc = lib().vgo_simulate_direct(C.byref(m), iterations, sample_size, float(time), attempts)
+    _absorb(model, st, m)
+    return rc
+
+
+def run_tau(model, iterations, sample_size, time, attempts, record_multievents=False, log_mode=LOG_LIBM):
+    """The oracle's SimulatePopulation_tau (pyx:2293-2346); multievents in the reference's dense layout
+    (propNum rows per step, zeros included) when ``record_multievents``."""
+    st = get_state(model)
+    model.events.CreateEvents(iterations)  # pyx:2298 -> pyx:434
+    model.events.CreateEvents(iterations)  # pyx:2306
+    m = _struct(model, st, False, log_mode)
+    prop = lib().vgo_prop_num(C.byref(m))
+    m.mev_ptr = st.mev_ptr
+    if record_multievents:
+        cap = st.mev_ptr + iterations * prop  # multievents.CreateEvents(iterations*propNum), ev:136-152
+        old = st.mev
+        st.mev = {k: np.zeros(cap, dtype=(float if k == "times" else np.int64))
+                  for k in ("num", "times", "types", "haplotypes", "populations", "newHaplotypes", "newPopulations")}
+        if old is not None:
+            for k in st.mev:
+                st.mev[k][:st.mev_ptr] = old[k][:st.mev_ptr]
+        m.mev_size = cap
+        m.mev_num, m.mev_times, m.mev_types = _ptr(st.mev["num"]), _ptr(st.mev["times"]), _ptr(st.mev["types"])
+        m.mev_haplotypes, m.mev_populations = _ptr(st.mev["haplotypes"]), _ptr(st.mev["populations"])
+        m.mev_newHaplotypes, m.mev_newPopulations = _ptr(st.mev["newHaplotypes"]), _ptr(st.mev["newPopulations"])
+    rc = lib().vgo_simulate_tau(C.byref(m), iterations, sample_size, float(time), attempts)
+    st.mev_ptr = m.mev_ptr
+    _absorb(model, st, m)
+    return rc
+
+
+def update_all_rates(model, sparse=False):
+    st = get_state(model)
+    m = _struct(model, st, sparse, LOG_LIBM)
+    lib().vgo_update_all_rates(C.byref(m))
+    model.totalRate, model.totalMigrationRate = m.totalRate, m.totalMigrationRate
+    return st
+
+
+def pcg64_stream(seed, attempt, n):
+    g = VgoPcg64()
+    lib().vgo_pcg64_seed(C.byref(g), seed, attempt)
+    state = (g.state_hi << 64) | g.state_lo
+    inc = (g.inc_hi << 64) | g.inc_lo
+    return state, inc, np.array([lib().vgo_pcg64_double(C.byref(g)) for _ in range(n)])

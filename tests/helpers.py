@@ -1,0 +1,96 @@
+"""Shared helpers for the parity tests (test infrastructure)."""
+import contextlib
+import hashlib
+import io
+import json
+import math
+import os
+
+import numpy as np
+
+import models
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load_golden(name):
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    meta = json.loads(str(z["meta"]))
+    return meta, z
+
+
+def quiet():
+    return contextlib.redirect_stdout(io.StringIO())
+
+
+def libm_matches_fixture_host():
+    """The time row of the fixtures was produced with glibc 2.35's log() on the development container.
+    A host whose libm rounds differently (e.g. another ifunc variant) can differ in the last bit, so the
+    bit-exact time assertion is made only where this known-answer probe holds; elsewhere the documented
+    tolerance applies.  First event of golden model 1: -ln(u)/rate with attempt 2's first uniform."""
+    return -math.log(0.44016044650747377) / 5.799996 == 0.14148560919448125
+
+
+def run_case_oracle(oracle, name, sparse=False, log_mode=0):
+    """Drive a case of tests/models.py through this repo's Simulator object + the CPU oracle."""
+    from vgsim_amd import Simulator
+    with quiet():
+        sim, phases = models.build(Simulator, name)
+    m = sim.simulation
+    for setup, kw in phases:
+        setup(sim)
+        kw = dict(kw)
+        it = kw.pop("iterations")
+        ss = kw.pop("sample_size", None)
+        ss = it if ss is None else ss
+        tm = kw.pop("epidemic_time", -1)
+        at = kw.pop("attempts", 200)
+        method = kw.pop("method", "direct")
+        if method == "direct":
+            rc = oracle.run_direct(m, it, ss, tm, at, sparse=sparse, log_mode=log_mode)
+        else:
+            rc = oracle.run_tau(m, it, ss, tm, at, log_mode=log_mode)
+        assert rc == 0, "oracle error code %d" % rc
+    return sim
+
+
+def chain_of(model):
+    return model.events.as_array()
+
+
+def check_against_golden(model, name, exact_time=True, rtol_time=1e-12):
+    """Compare a finished host model with the fixture recorded from the reference."""
+    meta, z = load_golden(name)
+    st = meta["stats"]
+    chain = chain_of(model)
+    ptr = st["ptr"]
+    assert model.events.ptr == ptr
+    assert chain.shape[1] == meta["size"]
+    for k in ("sCounter", "bCounter", "dCounter", "mCounter", "migPlus", "migNonPlus", "iCounter", "good_attempt"):
+        if k in st:
+            assert getattr(model, k) == st[k], k
+    if "times" in z:
+        ints = z["ints"].astype(np.int64)
+        assert np.array_equal(chain[1:].astype(np.int64), ints), "integer rows differ"
+        ref_t = z["times"]
+    else:
+        head, tail = z["head"], z["tail"]
+        assert np.array_equal(chain[1:, :256], head[1:]) and np.array_equal(chain[1:, ptr - tail.shape[1]:ptr], tail[1:])
+        ref_t = None
+    if exact_time:
+        assert hashlib.sha256(np.ascontiguousarray(chain).tobytes()).hexdigest() == meta["sha256_chain"]
+        assert model.currentTime == st["currentTime"]
+    else:
+        # documented tolerance for the float row when log() is not the fixture host's libm
+        if ref_t is not None:
+            np.testing.assert_allclose(chain[0], ref_t, rtol=rtol_time, atol=0)
+        else:
+            np.testing.assert_allclose(chain[0, :256], z["head"][0], rtol=rtol_time, atol=0)
+            np.testing.assert_allclose(chain[0, ptr - z["tail"].shape[1]:ptr], z["tail"][0], rtol=rtol_time, atol=0)
+        assert abs(model.currentTime - st["currentTime"]) <= rtol_time * abs(st["currentTime"])
+    assert np.array_equal(model.susceptible, z["susceptible"])
+    nz = z["infectious_nz"]
+    inf = np.zeros_like(model.infectious)
+    if len(nz):
+        inf[nz[:, 0], nz[:, 1]] = nz[:, 2]
+    assert np.array_equal(model.infectious, inf)

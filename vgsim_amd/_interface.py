@@ -1,0 +1,151 @@
+"""``Simulator``: the caller-facing facade, same constructor, setters and ``simulate`` signature as the
+reference's ``src/_interface.py:9-883`` (delegation to ``self.simulation``; ``simulate`` = if:799-829).
+
+Only the forward-simulation surface is provided; genealogy, plotting and file writers are outside the
+accelerated path ("out of scope") and raise ``NotImplementedError``.
+"""
+import sys
+import time
+from random import randrange
+
+from ._model import BirthDeathModel
+
+
+class Simulator:
+    def __init__(self, number_of_sites=0, populations_number=1, number_of_susceptible_groups=1, seed=None,
+                 sampling_probability=False, memory_optimization=False, genome_length=int(1e6),
+                 recombination_probability=0.0):
+        if seed == None:  # noqa: E711 (reference semantics, if:40)
+            seed = int(randrange(sys.maxsize))
+        print('User seed:', seed)
+        self.simulation = BirthDeathModel(
+            number_of_sites=number_of_sites, populations_number=populations_number,
+            number_of_susceptible_groups=number_of_susceptible_groups, seed=seed,
+            sampling_probability=sampling_probability, memory_optimization=memory_optimization,
+            genome_length=genome_length, recombination_probability=recombination_probability)
+
+    # read-only properties (if:130-156)
+    seed = property(lambda self: self.simulation.seed)
+    sampling_probability = property(lambda self: self.simulation.sampling_probability)
+    memory_optimization = property(lambda self: self.simulation.memory_optimization)
+    number_of_sites = property(lambda self: self.simulation.number_of_sites)
+    haplotypes_number = property(lambda self: self.simulation.haplotypes_number)
+    populations_number = property(lambda self: self.simulation.populations_number)
+    number_of_susceptible_groups = property(lambda self: self.simulation.number_of_susceptible_groups)
+    initial_haplotype = property(lambda self: self.simulation.initial_haplotype)
+    step_haplotype = property(lambda self: self.simulation.step_haplotype)
+    genome_length = property(lambda self: self.simulation.genome_length)
+    coinfection_parameters = property(lambda self: self.simulation.coinfection_parameters)
+    transmission_rate = property(lambda self: self.simulation.transmission_rate)
+    recovery_rate = property(lambda self: self.simulation.recovery_rate)
+    sampling_rate = property(lambda self: self.simulation.sampling_rate)
+    mutation_rate = property(lambda self: self.simulation.mutation_rate)
+    mutation_probabilities = property(lambda self: self.simulation.mutation_probabilities)
+    mutation_position = property(lambda self: self.simulation.mutation_position)
+    susceptibility_type = property(lambda self: self.simulation.susceptibility_type)
+    susceptibility = property(lambda self: self.simulation.susceptibility)
+    immunity_transition = property(lambda self: self.simulation.immunity_transition)
+    population_size = property(lambda self: self.simulation.population_size)
+    contact_density = property(lambda self: self.simulation.contact_density)
+    npi = property(lambda self: self.simulation.npi)
+    sampling_multiplier = property(lambda self: self.simulation.sampling_multiplier)
+    migration_probability = property(lambda self: self.simulation.migration_probability)
+    susceptible = property(lambda self: self.simulation.susceptible)
+    infectious = property(lambda self: self.simulation.infectious)
+
+    # setters (if:158-470): same names, argument order and defaults
+    def set_initial_haplotype(self, amount):
+        self.simulation.set_initial_haplotype(amount)
+
+    def set_step_haplotype(self, amount):
+        self.simulation.set_step_haplotype(amount)
+
+    def set_genome_length(self, genome_length):
+        self.simulation.set_genome_length(genome_length)
+
+    def set_coinfection_parameters(self, recombination):
+        self.simulation.set_coinfection_parameters(recombination)
+
+    def set_transmission_rate(self, rate, haplotype=None):
+        self.simulation.set_transmission_rate(rate, haplotype)
+
+    def set_recovery_rate(self, rate, haplotype=None):
+        self.simulation.set_recovery_rate(rate, haplotype)
+
+    def set_sampling_rate(self, rate, haplotype=None):
+        self.simulation.set_sampling_rate(rate, haplotype)
+
+    def set_mutation_rate(self, rate, haplotype=None, mutation=None):
+        self.simulation.set_mutation_rate(rate, haplotype, mutation)
+
+    def set_mutation_probabilities(self, probabilities, haplotype=None, mutation=None):
+        self.simulation.set_mutation_probabilities(probabilities, haplotype, mutation)
+
+    def set_mutation_position(self, mutation, position):
+        self.simulation.set_mutation_position(mutation, position)
+
+    def set_susceptibility_type(self, susceptibility_type, haplotype=None):
+        self.simulation.set_susceptibility_type(susceptibility_type, haplotype)
+
+    def set_susceptibility(self, rate, haplotype=None, susceptibility_type=None):
+        self.simulation.set_susceptibility(rate, haplotype, susceptibility_type)
+
+    def set_immunity_transition(self, rate, source=None, target=None):
+        self.simulation.set_immunity_transition(rate, source, target)
+
+    def set_population_size(self, size, population=None):
+        self.simulation.set_population_size(size, population)
+
+    def set_contact_density(self, value, population=None):
+        self.simulation.set_contact_density(value, population)
+
+    def set_npi(self, parameters, population=None):
+        self.simulation.set_npi(parameters, population)
+
+    def set_sampling_multiplier(self, multiplier, population=None):
+        self.simulation.set_sampling_multiplier(multiplier, population)
+
+    def set_migration_probability(self, probability, source=None, target=None):
+        self.simulation.set_migration_probability(probability, source, target)
+
+    def set_total_migration_probability(self, total_probability):
+        self.simulation.set_total_migration_probability(total_probability)
+
+    def set_susceptible(self, amount, source_type, target_type, population=None):
+        self.simulation.set_susceptible(amount, source_type, target_type, population)
+
+    def set_infectious(self, amount, source_type, target_haplotype, population=None):
+        self.simulation.set_infectious(amount, source_type, target_haplotype, population)
+
+    # the drop-in boundary (if:799-829)
+    def simulate(self, iterations=1000, sample_size=None, epidemic_time=-1, method='direct', attempts=200):
+        if sample_size is None:
+            sample_size = iterations
+        if epidemic_time is None:
+            epidemic_time = -1
+        start_time = time.time()
+        if method == 'direct':
+            self.simulation.SimulatePopulation(iterations, sample_size, epidemic_time, attempts)
+            self.simulation.Stats(time.time() - start_time)
+        elif method == 'tau':
+            self.simulation.SimulatePopulation_tau(iterations, sample_size, epidemic_time, attempts)
+            self.simulation.Stats(time.time() - start_time)
+        else:
+            print("Unknown method. Choose between 'direct' and 'tau'.")
+
+    def genealogy(self, seed=None):
+        self.simulation.GetGenealogy(seed)
+
+    def export_chain_events(self, file_name="chain_events"):
+        self.simulation.export_chain_events(file_name)
+
+    def get_proportion(self):
+        return self.simulation.get_proportion()
+
+    def print_counters(self):
+        self.simulation.PrintCounters()
+
+    def citation(self):
+        print("VGsim: scalable viral genealogy simulator for global pandemic")
+        print("Vladimir Shchur, Vadim Spirin, Dmitry Sirotkin, EvgeniBurovski, Nicola De Maio, Russell Corbett-Detig")
+        print("medRxiv 2021.04.21.21255891; doi: https://doi.org/10.1101/2021.04.21.21255891")
