@@ -1,0 +1,154 @@
+/*
+ * vgx.h — C ABI of the MI355X-native forward epidemic simulation engine (libvgx.so).
+ *
+ * This is the drop-in boundary for ONE path of Genomics-HSE/VGsim: the two native entry points that
+ * `Simulator.simulate` calls on its engine object (reference src/_interface.py:821-829):
+ *     BirthDeathModel.SimulatePopulation      (src/_BirthDeath.pyx:396-429, direct Gillespie)
+ *     BirthDeathModel.SimulatePopulation_tau  (src/_BirthDeath.pyx:2293-2346, Poisson tau-leaping)
+ * plus what the caller needs to hand the model over and read the results back.  Plain pointers and
+ * sizes only; every array is a C-contiguous host buffer with the reference's own name, dtype and shape
+ * (numpy arrays of the reference's `cdef class BirthDeathModel`, pyx:47-68).  A binding for the
+ * reference (ctypes, or `cdef extern` from Cython) is shown in INTEGRATION.md.
+ *
+ * One engine = one model shape and `n_replicates` independent trajectories of it (replicate = one
+ * seeded run; the classic API uses 1).  Engines are independent; calls on one engine must not overlap.
+ * Every function returns VGX_OK (0) or an error code; vgx_last_error() gives the message.
+ */
+#ifndef VGX_H
+#define VGX_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct vgx_engine vgx_engine;
+
+enum {
+    VGX_OK = 0,
+    VGX_ERR_ARG = 1,            /* bad argument / unsupported configuration */
+    VGX_ERR_HIP = 2,            /* HIP runtime failure (no device, out of memory, launch failure) */
+    VGX_ERR_ZERO_WEIGHT = 3,    /* fastChoose hit a zero weight: the reference prints and exits (fast_choose.pxi:5-13) */
+    VGX_ERR_CAPACITY = 4,       /* occupancy list / lockdown log / multievent buffer capacity exceeded */
+    VGX_ERR_LOOP_GUARD = 5,     /* iteration guard tripped (would be an endless loop upstream) */
+    VGX_ERR_CLASSES = 6         /* more distinct per-haplotype rate rows than the engine supports */
+};
+
+/* Event types: src/events.pxi:2-8 */
+enum { VGX_BIRTH = 0, VGX_DEATH = 1, VGX_SAMPLING = 2, VGX_MUTATION = 3, VGX_SUSCCHANGE = 4,
+       VGX_MIGRATION = 5, VGX_MULTITYPE = 6 };
+
+/* pyx:84-90: hapNum must equal 4^sites */
+typedef struct vgx_dims {
+    int64_t sites, hapNum, popNum, susNum;
+} vgx_dims;
+
+/* Model parameters (borrowed, copied by vgx_set_params).  Names, dtypes, shapes: pyx:157-204. */
+typedef struct vgx_params {
+    const double *bRate, *dRate, *sRate;         /* [H]            pyx:158-160 */
+    const double *mRate;                         /* [H][sites]     pyx:161 */
+    const double *hapMutType;                    /* [H][sites][3]  pyx:163 */
+    const double *susceptibility;                /* [H][S]         pyx:162 */
+    const int64_t *suscType;                     /* [H]            pyx:157 */
+    const double *suscepTransition;              /* [S][S]         pyx:196 */
+    const int64_t *sizes;                        /* [P]            pyx:173 */
+    const double *contactDensityBeforeLockdown;  /* [P]            pyx:190 */
+    const double *contactDensityAfterLockdown;   /* [P]            pyx:191 */
+    const double *startLD, *endLD;               /* [P]            pyx:192-193 */
+    const double *samplingMultiplier;            /* [P]            pyx:194 */
+    const double *migrationRates;                /* [P][P]         pyx:198 (diagonal ignored: recomputed, pyx:290-295) */
+} vgx_params;
+
+/* Compartment state and scalars that persist between simulate() calls (pyx:34-38, 47-49).
+ * In vgx_set_state the arrays are read; in vgx_get_state they are written (any may be NULL = skip). */
+typedef struct vgx_state {
+    int64_t *susceptible;          /* [P][S] */
+    int64_t *infectious;           /* [P][H] */
+    int64_t *initial_susceptible;  /* [P][S]  snapshot used by Restart (pyx:714-738) */
+    int64_t *initial_infectious;   /* [P][H] */
+    int64_t *totalSusceptible, *totalInfectious, *lockdownON; /* [P] */
+    double *contactDensity;        /* [P]  current value (flips with lockdowns, pyx:698-710) */
+    int64_t first_simulation;      /* pyx:34, 435-448 */
+    int64_t globalInfectious;
+    int64_t bCounter, dCounter, sCounter, mCounter, iCounter, swapLockdown, migPlus, migNonPlus;
+    int64_t good_attempt;
+    double currentTime, totalRate, totalMigrationRate, tau_l;
+    int64_t ev_ptr, ev_size;       /* event-log position/capacity as maintained by Events.CreateEvents (events.pxi:52-68) */
+} vgx_state;
+
+/* Options of one simulate call beyond the reference's four arguments. */
+typedef struct vgx_run_opts {
+    int64_t record_events;   /* 1: keep the event log (default for the classic API); 0: counters/trajectories only */
+    int64_t max_loop_factor; /* loop guard: at most max_loop_factor*iterations + 2^20 loop iterations (0 = 1024) */
+    int64_t traj_points;     /* >0: bin totalInfectious/totalSusceptible[P] at this many uniform time points */
+    double traj_t0, traj_t1; /* time window of the trajectory grid */
+    int64_t reserved[4];
+} vgx_run_opts;
+
+/* Per-replicate results of the last simulate call. */
+typedef struct vgx_counters {
+    int64_t ev_ptr;                /* events.ptr after the call */
+    int64_t ev_first_new;          /* first log index written by this call (0 if a Restart rewound the log) */
+    int64_t loop_iterations;       /* loop iterations incl. rejected migrations (each draws 2 uniforms) */
+    int64_t restarts;
+    int64_t lockdown_records;
+    int64_t error;                 /* VGX_* code raised inside the kernel for this replicate */
+    int64_t multievent_rows;       /* tau: rows appended to the multievent log by this call */
+    int64_t reserved[5];
+} vgx_counters;
+
+/* ---- lifecycle ------------------------------------------------------------------------------ */
+int vgx_create(const vgx_dims *dims, int64_t n_replicates, int device, vgx_engine **out);
+void vgx_destroy(vgx_engine *e);
+const char *vgx_last_error(const vgx_engine *e);   /* e may be NULL: message of the last failed vgx_create */
+int vgx_device_count(void);
+
+/* ---- model hand-over ------------------------------------------------------------------------ */
+int vgx_set_params(vgx_engine *e, const vgx_params *p);
+/* The same state is given to every replicate; replicates differ by their seed only. */
+int vgx_set_state(vgx_engine *e, const vgx_state *s);
+int vgx_get_state(vgx_engine *e, int64_t replicate, vgx_state *out);
+/* user_seed of each replicate: the RNG of attempt k is PCG64(SeedSequence(seed, spawn_key=(k,))),
+ * the stream RndmWrapper(seed=(user_seed, k)) creates at pyx:403 / pyx:2310. */
+int vgx_set_seeds(vgx_engine *e, const int64_t *seeds /* [n_replicates] */);
+
+/* ---- the hot path --------------------------------------------------------------------------- */
+/* Replaces BirthDeathModel.SimulatePopulation(iterations, sample_size, float time, attempts), pyx:396. */
+int vgx_simulate_direct(vgx_engine *e, int64_t iterations, int64_t sample_size, float time, int64_t attempts,
+                        const vgx_run_opts *opts /* may be NULL */);
+/* Replaces BirthDeathModel.SimulatePopulation_tau(iterations, sample_size, float time, attempts), pyx:2293. */
+int vgx_simulate_tau(vgx_engine *e, int64_t iterations, int64_t sample_size, float time, int64_t attempts,
+                     const vgx_run_opts *opts /* may be NULL */);
+
+/* ---- results -------------------------------------------------------------------------------- */
+int vgx_get_counters(vgx_engine *e, int64_t replicate, vgx_counters *out);
+/* Copies log rows [first, first+count) into the caller's Events arrays (events.pxi:26-29). */
+int vgx_get_events(vgx_engine *e, int64_t replicate, int64_t first, int64_t count, double *times,
+                   int64_t *types, int64_t *haplotypes, int64_t *populations, int64_t *newHaplotypes,
+                   int64_t *newPopulations);
+/* Lockdown switches recorded by the last call (models.pxi:52-66): up to `cap` rows, returns the count in *n. */
+int vgx_get_lockdowns(vgx_engine *e, int64_t replicate, int64_t cap, int64_t *states, int64_t *populations,
+                      double *times, int64_t *n);
+/* Tau multievents of the last call (events.pxi:105-152), rows with num > 0 only. */
+int vgx_get_multievents(vgx_engine *e, int64_t replicate, int64_t cap, int64_t *num, double *times, int64_t *types,
+                        int64_t *haplotypes, int64_t *populations, int64_t *newHaplotypes,
+                        int64_t *newPopulations, int64_t *n);
+/* Summary trajectories of the last call: out[replicate][point][population][0=infectious,1=susceptible], f64.
+ * `out` is a host pointer, or a device pointer when out_is_device != 0 (e.g. a torch tensor for an RCCL gather). */
+int vgx_get_trajectories(vgx_engine *e, double *out, int out_is_device);
+
+/* ---- measurement ---------------------------------------------------------------------------- */
+/* Device time of the last simulate call's kernels, from HIP events on the engine's stream (ms). */
+double vgx_last_kernel_ms(const vgx_engine *e);
+/* Number of kernel launches timed by the last simulate call. */
+int64_t vgx_last_kernel_launches(const vgx_engine *e);
+/* Bytes of device memory held by the engine. */
+int64_t vgx_device_bytes(const vgx_engine *e);
+/* Standalone streaming kernels over the engine's resident state (roofline measurement):
+ * dense propensity rebuild + scan of every (replicate, population) row. Returns device ms in *ms. */
+int vgx_bench_propensity_scan(vgx_engine *e, int64_t repeats, double *ms, int64_t *bytes_per_launch);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VGX_H */

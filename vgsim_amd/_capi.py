@@ -1,0 +1,244 @@
+"""ctypes binding of libvgx.so (C ABI in ``include/vgx.h``): the only way the Python host layer reaches
+the HIP kernels.  There is no CPU fallback: a missing library or a missing GPU raises ``RuntimeError``.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libvgx.so")
+
+_F = C.POINTER(C.c_double)
+_I = C.POINTER(C.c_int64)
+
+VGX_OK = 0
+
+
+class VgxDims(C.Structure):
+    _fields_ = [("sites", C.c_int64), ("hapNum", C.c_int64), ("popNum", C.c_int64), ("susNum", C.c_int64)]
+
+
+class VgxParams(C.Structure):
+    _fields_ = [("bRate", _F), ("dRate", _F), ("sRate", _F), ("mRate", _F), ("hapMutType", _F),
+                ("susceptibility", _F), ("suscType", _I), ("suscepTransition", _F), ("sizes", _I),
+                ("contactDensityBeforeLockdown", _F), ("contactDensityAfterLockdown", _F), ("startLD", _F),
+                ("endLD", _F), ("samplingMultiplier", _F), ("migrationRates", _F)]
+
+
+class VgxState(C.Structure):
+    _fields_ = [("susceptible", _I), ("infectious", _I), ("initial_susceptible", _I), ("initial_infectious", _I),
+                ("totalSusceptible", _I), ("totalInfectious", _I), ("lockdownON", _I), ("contactDensity", _F),
+                ("first_simulation", C.c_int64), ("globalInfectious", C.c_int64),
+                ("bCounter", C.c_int64), ("dCounter", C.c_int64), ("sCounter", C.c_int64), ("mCounter", C.c_int64),
+                ("iCounter", C.c_int64), ("swapLockdown", C.c_int64), ("migPlus", C.c_int64), ("migNonPlus", C.c_int64),
+                ("good_attempt", C.c_int64),
+                ("currentTime", C.c_double), ("totalRate", C.c_double), ("totalMigrationRate", C.c_double),
+                ("tau_l", C.c_double), ("ev_ptr", C.c_int64), ("ev_size", C.c_int64)]
+
+
+class VgxRunOpts(C.Structure):
+    _fields_ = [("record_events", C.c_int64), ("max_loop_factor", C.c_int64), ("traj_points", C.c_int64),
+                ("traj_t0", C.c_double), ("traj_t1", C.c_double), ("reserved", C.c_int64 * 4)]
+
+
+class VgxCounters(C.Structure):
+    _fields_ = [("ev_ptr", C.c_int64), ("ev_first_new", C.c_int64), ("loop_iterations", C.c_int64),
+                ("restarts", C.c_int64), ("lockdown_records", C.c_int64), ("error", C.c_int64),
+                ("multievent_rows", C.c_int64), ("reserved", C.c_int64 * 5)]
+
+
+# every entry point include/vgx.h declares: (restype, argtypes)
+_H = C.c_void_p
+SIGNATURES = {
+    "vgx_create": (C.c_int, [C.POINTER(VgxDims), C.c_int64, C.c_int, C.POINTER(_H)]),
+    "vgx_destroy": (None, [_H]),
+    "vgx_last_error": (C.c_char_p, [_H]),
+    "vgx_device_count": (C.c_int, []),
+    "vgx_set_params": (C.c_int, [_H, C.POINTER(VgxParams)]),
+    "vgx_set_state": (C.c_int, [_H, C.POINTER(VgxState)]),
+    "vgx_get_state": (C.c_int, [_H, C.c_int64, C.POINTER(VgxState)]),
+    "vgx_set_seeds": (C.c_int, [_H, _I]),
+    "vgx_simulate_direct": (C.c_int, [_H, C.c_int64, C.c_int64, C.c_float, C.c_int64, C.POINTER(VgxRunOpts)]),
+    "vgx_simulate_tau": (C.c_int, [_H, C.c_int64, C.c_int64, C.c_float, C.c_int64, C.POINTER(VgxRunOpts)]),
+    "vgx_get_counters": (C.c_int, [_H, C.c_int64, C.POINTER(VgxCounters)]),
+    "vgx_get_events": (C.c_int, [_H, C.c_int64, C.c_int64, C.c_int64, _F, _I, _I, _I, _I, _I]),
+    "vgx_get_lockdowns": (C.c_int, [_H, C.c_int64, C.c_int64, _I, _I, _F, _I]),
+    "vgx_get_multievents": (C.c_int, [_H, C.c_int64, C.c_int64, _I, _F, _I, _I, _I, _I, _I, _I]),
+    "vgx_get_trajectories": (C.c_int, [_H, C.c_void_p, C.c_int]),
+    "vgx_last_kernel_ms": (C.c_double, [_H]),
+    "vgx_last_kernel_launches": (C.c_int64, [_H]),
+    "vgx_device_bytes": (C.c_int64, [_H]),
+    "vgx_bench_propensity_scan": (C.c_int, [_H, C.c_int64, _F, _I]),
+}
+
+_lib = None
+
+
+def load_library():
+    """Load libvgx.so and bind every symbol of include/vgx.h; raises if the HIP extension is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "vgsim_amd: the HIP extension %s is not built (run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C vgsim_amd/csrc`). There is no CPU fallback." % LIB_PATH)
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def _p(a):
+    if a is None:
+        return None
+    assert a.flags["C_CONTIGUOUS"]
+    if a.dtype == np.float64:
+        return a.ctypes.data_as(_F)
+    if a.dtype == np.int64:
+        return a.ctypes.data_as(_I)
+    raise TypeError(a.dtype)
+
+
+class VgxError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("libvgx error %d: %s" % (code, msg))
+        self.code = code
+
+
+class HipEngine:
+    """One libvgx engine: a model shape and ``n_replicates`` independent seeded trajectories on one GPU."""
+
+    def __init__(self, sites, hapNum, popNum, susNum, n_replicates=1, device=0):
+        self.lib = load_library()
+        self.dims = VgxDims(sites, hapNum, popNum, susNum)
+        self.R = int(n_replicates)
+        self.handle = _H()
+        rc = self.lib.vgx_create(C.byref(self.dims), self.R, int(device), C.byref(self.handle))
+        if rc != VGX_OK:
+            self.handle = None
+            raise VgxError(rc, self.lib.vgx_last_error(None).decode())
+        self.P, self.H, self.S = popNum, hapNum, susNum
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.vgx_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != VGX_OK:
+            raise VgxError(rc, self.lib.vgx_last_error(self.handle).decode())
+
+    # ---------------------------------------------------------------- hand-over
+    def set_params(self, m):
+        p = VgxParams()
+        for name, _ in VgxParams._fields_:
+            a = getattr(m, name)
+            setattr(p, name, _p(np.ascontiguousarray(a)))
+        self._keep = [getattr(m, n) for n, _ in VgxParams._fields_]
+        self._check(self.lib.vgx_set_params(self.handle, C.byref(p)))
+
+    def _state_struct(self, m):
+        s = VgxState()
+        for name in ("susceptible", "infectious", "initial_susceptible", "initial_infectious", "totalSusceptible",
+                     "totalInfectious", "lockdownON", "contactDensity"):
+            setattr(s, name, _p(getattr(m, name)))
+        return s
+
+    def set_state(self, m):
+        s = self._state_struct(m)
+        s.first_simulation = int(m.first_simulation)
+        s.globalInfectious = int(m.globalInfectious)
+        for c in m.COUNTERS + ("good_attempt",):
+            setattr(s, c, int(getattr(m, c)))
+        s.currentTime, s.totalRate, s.totalMigrationRate, s.tau_l = m.currentTime, m.totalRate, m.totalMigrationRate, m.tau_l
+        s.ev_ptr, s.ev_size = m.events.ptr, m.events.size
+        self._check(self.lib.vgx_set_state(self.handle, C.byref(s)))
+
+    def get_state(self, m, replicate=0):
+        s = self._state_struct(m)
+        self._check(self.lib.vgx_get_state(self.handle, replicate, C.byref(s)))
+        m.first_simulation = bool(s.first_simulation)
+        m.globalInfectious = s.globalInfectious
+        for c in m.COUNTERS + ("good_attempt",):
+            setattr(m, c, getattr(s, c))
+        m.currentTime, m.totalRate, m.totalMigrationRate, m.tau_l = s.currentTime, s.totalRate, s.totalMigrationRate, s.tau_l
+
+    def set_seeds(self, seeds):
+        a = np.ascontiguousarray(np.asarray(seeds, dtype=np.int64))
+        assert a.shape == (self.R,)
+        self._check(self.lib.vgx_set_seeds(self.handle, _p(a)))
+
+    def counters(self, replicate=0):
+        c = VgxCounters()
+        self._check(self.lib.vgx_get_counters(self.handle, replicate, C.byref(c)))
+        return c
+
+    def fetch_events(self, events, replicate, first, count):
+        """Copy device log rows [first, first+count) into a host ``Events`` object at the same indices."""
+        if count <= 0:
+            return
+        sl = slice(first, first + count)
+        bufs = [np.zeros(count, dtype=np.float64)] + [np.zeros(count, dtype=np.int64) for _ in range(5)]
+        self._check(self.lib.vgx_get_events(self.handle, replicate, first, count, *[_p(b) for b in bufs]))
+        events.times[sl] = bufs[0]
+        for name, b in zip(events.COLUMNS, bufs[1:]):
+            getattr(events, name)[sl] = b
+
+    def lockdowns(self, replicate=0, cap=4096):
+        st, pp = np.zeros(cap, dtype=np.int64), np.zeros(cap, dtype=np.int64)
+        tt = np.zeros(cap, dtype=np.float64)
+        n = C.c_int64(0)
+        self._check(self.lib.vgx_get_lockdowns(self.handle, replicate, cap, _p(st), _p(pp), _p(tt), C.byref(n)))
+        k = min(n.value, cap)
+        return st[:k], pp[:k], tt[:k]
+
+    # ---------------------------------------------------------------- the hot path for one host model
+    def simulate_direct(self, m, iterations, sample_size, time, attempts, opts=None):
+        """``BirthDeathModel.SimulatePopulation`` (pyx:396-429) for a host model object: upload, run the
+        persistent kernel, read the model back exactly as the reference would leave it."""
+        self.set_params(m)
+        self.set_state(m)
+        self.set_seeds([m.user_seed] * self.R)
+        rc = self.lib.vgx_simulate_direct(self.handle, iterations, sample_size, float(time), attempts,
+                                          C.byref(opts) if opts is not None else None)
+        self._check(rc)
+        self._absorb(m)
+
+    def simulate_tau(self, m, iterations, sample_size, time, attempts, opts=None):
+        """``BirthDeathModel.SimulatePopulation_tau`` (pyx:2293-2346)."""
+        self.set_params(m)
+        self.set_state(m)
+        self.set_seeds([m.user_seed] * self.R)
+        rc = self.lib.vgx_simulate_tau(self.handle, iterations, sample_size, float(time), attempts,
+                                       C.byref(opts) if opts is not None else None)
+        self._check(rc)
+        self._absorb(m)
+
+    def _absorb(self, m, replicate=0):
+        self.get_state(m, replicate)
+        c = self.counters(replicate)
+        first = c.ev_first_new
+        self.fetch_events(m.events, replicate, first, c.ev_ptr - first)
+        m.events.ptr = c.ev_ptr
+        st, pp, tt = self.lockdowns(replicate)
+        for k in range(len(st)):
+            m.loc.AddLockdown(st[k], pp[k], tt[k])
+        self.last_counters = c
+
+    @property
+    def last_kernel_ms(self):
+        return self.lib.vgx_last_kernel_ms(self.handle)
+
+    @property
+    def device_bytes(self):
+        return self.lib.vgx_device_bytes(self.handle)

@@ -1,0 +1,715 @@
+// vgx_api.hip — host side of libvgx.so: the C ABI of include/vgx.h.
+//
+// Owns device memory (hipMalloc), one HIP stream and a pair of HIP events per engine; converts between
+// the reference's dense host arrays (BirthDeathModel fields, src/_BirthDeath.pyx:47-68) and the engine's
+// HBM layout (vgx_dev.h); does the parameter-only parts of UpdateAllRates (pyx:284-297, 340-344) and the
+// first-call part of PrepareParameters (pyx:435-448) on the host, in the reference's operation order
+// (this file is compiled with -ffp-contract=off as well); launches the kernels.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+#include <algorithm>
+#include <string>
+#include <unordered_map>
+#include <vector>
+#include "../../include/vgx.h"
+#include "vgx_dev.h"
+
+extern "C" __global__ void vgx_direct_kernel(VgxDirectArgs a);
+extern "C" __global__ void vgx_init_reps_kernel(VgxDevRep r, int P, int S, int64_t R, const int32_t *s_nocc,
+                                                const int32_t *s_hap, const int32_t *s_cls, const int64_t *s_cnt,
+                                                int64_t s_cap, const int64_t *s_sus, const double *s_cd,
+                                                const int64_t *s_tot);
+
+static std::string g_create_error;
+
+struct HostState {
+    std::vector<int64_t> susceptible, infectious, initial_susceptible, initial_infectious;
+    std::vector<int64_t> totalSusceptible, totalInfectious, lockdownON;
+    std::vector<double> contactDensity;
+    int64_t first_simulation = 0, globalInfectious = 0;
+    int64_t bCounter = 0, dCounter = 0, sCounter = 0, mCounter = 0, iCounter = 0, swapLockdown = 0, migPlus = 0,
+            migNonPlus = 0, good_attempt = 0;
+    double currentTime = 0, totalRate = 0, totalMigrationRate = 0, tau_l = 0.01;
+    int64_t ev_ptr = 0, ev_size = 0;
+};
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+};
+
+struct vgx_engine {
+    vgx_dims d{};
+    int64_t R = 1;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::string err;
+    bool have_params = false, have_state = false, dev_state_valid = false;
+    int C = 0, CB = 0;
+    // host copies of what the host needs again
+    std::vector<int32_t> cls;
+    std::vector<int64_t> sizes, seeds;
+    std::vector<double> suscepCumul, mig, actualSizes;
+    HostState hs;
+    // device
+    std::vector<DevBuf *> all;
+    DevBuf p_cls, p_suscType, p_mRate, p_hapMutType, p_bRate, p_susc, p_cd, p_cs, p_ctm, p_cbidx, p_cbb, p_cbsig,
+        p_sizes, p_cdBefore, p_cdAfter, p_startLD, p_endLD, p_sampMult, p_actualSizes, p_mig, p_suscTrans,
+        p_suscCumul;
+    DevBuf r_popD, r_popI, r_sus, r_immSrc, r_birthC, r_xC, r_effMig, r_nocc, r_lhap, r_lcls, r_lcnt, r_sc, r_seeds,
+        r_evtime, r_evcols, r_locrec, r_loctime, r_traj;
+    DevBuf i_nocc, i_hap, i_cls, i_cnt, i_sus;          // initial state (Restart)
+    DevBuf s_nocc, s_hap, s_cls, s_cnt, s_sus, s_cd, s_tot;  // state at the start of the call
+    VgxDevParams dp{};
+    VgxDevRep dr{};
+    int64_t cap = 0, evcap = 0, ev_base = 0, ev_ptr0 = 0, traj_points = 0;
+    int64_t last_ev_size = 0;
+    std::vector<VgxRepScalars> sc_host;
+    bool sc_host_valid = false;
+    float last_ms = 0.f;
+    int64_t last_launches = 0;
+    size_t dev_bytes = 0;
+};
+
+#define HIPCHECK(e_, call)                                                                             \
+    do {                                                                                               \
+        hipError_t err__ = (call);                                                                     \
+        if (err__ != hipSuccess) {                                                                     \
+            (e_)->err = std::string(#call) + ": " + hipGetErrorString(err__);                          \
+            return VGX_ERR_HIP;                                                                        \
+        }                                                                                              \
+    } while (0)
+
+static int fail(vgx_engine *e, int code, const std::string &msg) {
+    e->err = msg;
+    return code;
+}
+
+static int ensure(vgx_engine *e, DevBuf &b, size_t bytes) {
+    if (bytes == 0) bytes = 8;
+    if (b.bytes >= bytes) return VGX_OK;
+    if (b.p) {
+        HIPCHECK(e, hipFree(b.p));
+        e->dev_bytes -= b.bytes;
+        b.p = nullptr;
+        b.bytes = 0;
+    }
+    HIPCHECK(e, hipMalloc(&b.p, bytes));
+    b.bytes = bytes;
+    e->dev_bytes += bytes;
+    if (std::find(e->all.begin(), e->all.end(), &b) == e->all.end()) e->all.push_back(&b);
+    return VGX_OK;
+}
+
+template <typename T>
+static int upload(vgx_engine *e, DevBuf &b, const T *src, size_t n) {
+    int rc = ensure(e, b, n * sizeof(T));
+    if (rc) return rc;
+    if (n) HIPCHECK(e, hipMemcpyAsync(b.p, src, n * sizeof(T), hipMemcpyHostToDevice, e->stream));
+    return VGX_OK;
+}
+
+extern "C" int vgx_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" int vgx_create(const vgx_dims *dims, int64_t n_replicates, int device, vgx_engine **out) {
+    if (!dims || !out || n_replicates < 1) { g_create_error = "vgx_create: bad argument"; return VGX_ERR_ARG; }
+    int64_t h = 1;
+    for (int64_t s = 0; s < dims->sites; s++) h *= 4;
+    if (dims->sites < 0 || dims->sites > 15 || dims->hapNum != h || dims->popNum < 1 || dims->susNum < 1) {
+        g_create_error = "vgx_create: hapNum must equal 4^sites (sites <= 15), popNum >= 1, susNum >= 1";
+        return VGX_ERR_ARG;
+    }
+    int n = 0;
+    hipError_t he = hipGetDeviceCount(&n);
+    if (he != hipSuccess || n == 0) {
+        g_create_error = std::string("vgx_create: no HIP device available (") + hipGetErrorString(he) +
+                         "); this engine has no CPU fallback";
+        return VGX_ERR_HIP;
+    }
+    if (device < 0 || device >= n) { g_create_error = "vgx_create: device index out of range"; return VGX_ERR_ARG; }
+    vgx_engine *e = new vgx_engine();
+    e->d = *dims;
+    e->R = n_replicates;
+    e->device = device;
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&e->stream) != hipSuccess ||
+        hipEventCreate(&e->ev0) != hipSuccess || hipEventCreate(&e->ev1) != hipSuccess) {
+        g_create_error = "vgx_create: could not create stream/events";
+        delete e;
+        return VGX_ERR_HIP;
+    }
+    e->seeds.assign((size_t)n_replicates, 0);
+    *out = e;
+    return VGX_OK;
+}
+
+extern "C" void vgx_destroy(vgx_engine *e) {
+    if (!e) return;
+    hipSetDevice(e->device);
+    hipStreamSynchronize(e->stream);
+    for (DevBuf *b : e->all)
+        if (b->p) hipFree(b->p);
+    if (e->ev0) hipEventDestroy(e->ev0);
+    if (e->ev1) hipEventDestroy(e->ev1);
+    if (e->stream) hipStreamDestroy(e->stream);
+    delete e;
+}
+
+extern "C" const char *vgx_last_error(const vgx_engine *e) { return e ? e->err.c_str() : g_create_error.c_str(); }
+extern "C" double vgx_last_kernel_ms(const vgx_engine *e) { return e ? (double)e->last_ms : 0.0; }
+extern "C" int64_t vgx_last_kernel_launches(const vgx_engine *e) { return e ? e->last_launches : 0; }
+extern "C" int64_t vgx_device_bytes(const vgx_engine *e) { return e ? (int64_t)e->dev_bytes : 0; }
+
+extern "C" int vgx_set_seeds(vgx_engine *e, const int64_t *seeds) {
+    if (!e || !seeds) return VGX_ERR_ARG;
+    for (int64_t r = 0; r < e->R; r++) {
+        if (seeds[r] < 0) return fail(e, VGX_ERR_ARG, "vgx_set_seeds: seeds must be >= 0");
+        e->seeds[(size_t)r] = seeds[r];
+    }
+    return VGX_OK;
+}
+
+extern "C" int vgx_set_params(vgx_engine *e, const vgx_params *p) {
+    if (!e || !p) return VGX_ERR_ARG;
+    HIPCHECK(e, hipSetDevice(e->device));
+    const int64_t H = e->d.hapNum, P = e->d.popNum, S = e->d.susNum, sites = e->d.sites;
+    if (!p->bRate || !p->dRate || !p->sRate || !p->susceptibility || !p->suscType || !p->suscepTransition ||
+        !p->sizes || !p->contactDensityBeforeLockdown || !p->contactDensityAfterLockdown || !p->startLD ||
+        !p->endLD || !p->samplingMultiplier || !p->migrationRates || (sites > 0 && (!p->mRate || !p->hapMutType)))
+        return fail(e, VGX_ERR_ARG, "vgx_set_params: null parameter array");
+    for (int64_t h = 0; h < H; h++)
+        if (p->suscType[h] < 0 || p->suscType[h] >= S) return fail(e, VGX_ERR_ARG, "vgx_set_params: suscType out of range");
+
+    // ---- classes of identical per-haplotype rate rows ----
+    std::vector<double> tm((size_t)H);
+    for (int64_t h = 0; h < H; h++) {  // tmRate, pyx:306-308
+        double t = 0;
+        for (int64_t s = 0; s < sites; s++) t += p->mRate[h * sites + s];
+        tm[(size_t)h] = t;
+    }
+    std::unordered_map<std::string, int> fullmap, birthmap;
+    std::vector<double> c_d, c_s, c_tm, cb_b, cb_sig;
+    std::vector<int32_t> c_bidx;
+    e->cls.assign((size_t)H, 0);
+    std::string key;
+    for (int64_t h = 0; h < H; h++) {
+        key.assign((const char *)&p->bRate[h], 8);
+        key.append((const char *)&p->susceptibility[h * S], (size_t)S * 8);
+        auto bi = birthmap.find(key);
+        int cb;
+        if (bi == birthmap.end()) {
+            cb = (int)cb_b.size();
+            birthmap.emplace(key, cb);
+            cb_b.push_back(p->bRate[h]);
+            for (int64_t s = 0; s < S; s++) cb_sig.push_back(p->susceptibility[h * S + s]);
+        } else {
+            cb = bi->second;
+        }
+        key.append((const char *)&p->dRate[h], 8);
+        key.append((const char *)&p->sRate[h], 8);
+        key.append((const char *)&tm[(size_t)h], 8);
+        auto fi = fullmap.find(key);
+        int c;
+        if (fi == fullmap.end()) {
+            c = (int)c_d.size();
+            fullmap.emplace(key, c);
+            c_d.push_back(p->dRate[h]);
+            c_s.push_back(p->sRate[h]);
+            c_tm.push_back(tm[(size_t)h]);
+            c_bidx.push_back(cb);
+            if (c_d.size() > VGX_MAX_CLASSES)
+                return fail(e, VGX_ERR_CLASSES,
+                            "vgx_set_params: more than " + std::to_string(VGX_MAX_CLASSES) +
+                                " distinct per-haplotype rate rows (bRate, susceptibility, dRate, sRate, sum of mRate)");
+        } else {
+            c = fi->second;
+        }
+        e->cls[(size_t)h] = c;
+    }
+    e->C = (int)c_d.size();
+    e->CB = (int)cb_b.size();
+
+    // ---- parameter-only parts of UpdateAllRates, in the reference's order ----
+    e->suscepCumul.assign((size_t)S, 0.0);
+    for (int64_t s1 = 0; s1 < S; s1++) {  // pyx:284-287
+        double v = 0;
+        for (int64_t s2 = 0; s2 < S; s2++) v += p->suscepTransition[s1 * S + s2];
+        e->suscepCumul[(size_t)s1] = v;
+    }
+    e->mig.assign(p->migrationRates, p->migrationRates + P * P);
+    e->actualSizes.assign((size_t)P, 0.0);
+    e->sizes.assign(p->sizes, p->sizes + P);
+    for (int64_t p1 = 0; p1 < P; p1++) {  // pyx:289-297
+        e->mig[(size_t)(p1 * P + p1)] = 1.0;
+        double a = 0.0;
+        for (int64_t p2 = 0; p2 < P; p2++) {
+            if (p1 == p2) continue;
+            e->mig[(size_t)(p1 * P + p1)] -= e->mig[(size_t)(p1 * P + p2)];
+            a += e->mig[(size_t)(p2 * P + p1)] * (double)p->sizes[p2];
+        }
+        // NB: the reference reads migrationRates[pn2, pn1] for pn2 != pn1 only, so the not-yet-rewritten
+        // diagonals of later rows never enter (pyx:296)
+        a += e->mig[(size_t)(p1 * P + p1)] * (double)p->sizes[p1];
+        e->actualSizes[(size_t)p1] = a;
+    }
+    double maxEffectiveBirth = 0.0;  // pyx:340-344
+    for (int64_t h = 0; h < H; h++)
+        for (int64_t s = 0; s < S; s++) {
+            double v = p->bRate[h] * p->susceptibility[h * S + s];
+            if (v > maxEffectiveBirth) maxEffectiveBirth = v;
+        }
+
+    int rc = 0;
+    rc |= upload(e, e->p_cls, e->cls.data(), (size_t)H);
+    rc |= upload(e, e->p_suscType, p->suscType, (size_t)H);
+    rc |= upload(e, e->p_mRate, p->mRate, (size_t)(H * sites));
+    rc |= upload(e, e->p_hapMutType, p->hapMutType, (size_t)(H * sites * 3));
+    rc |= upload(e, e->p_bRate, p->bRate, (size_t)H);
+    rc |= upload(e, e->p_susc, p->susceptibility, (size_t)(H * S));
+    rc |= upload(e, e->p_cd, c_d.data(), c_d.size());
+    rc |= upload(e, e->p_cs, c_s.data(), c_s.size());
+    rc |= upload(e, e->p_ctm, c_tm.data(), c_tm.size());
+    rc |= upload(e, e->p_cbidx, c_bidx.data(), c_bidx.size());
+    rc |= upload(e, e->p_cbb, cb_b.data(), cb_b.size());
+    rc |= upload(e, e->p_cbsig, cb_sig.data(), cb_sig.size());
+    rc |= upload(e, e->p_sizes, p->sizes, (size_t)P);
+    rc |= upload(e, e->p_cdBefore, p->contactDensityBeforeLockdown, (size_t)P);
+    rc |= upload(e, e->p_cdAfter, p->contactDensityAfterLockdown, (size_t)P);
+    rc |= upload(e, e->p_startLD, p->startLD, (size_t)P);
+    rc |= upload(e, e->p_endLD, p->endLD, (size_t)P);
+    rc |= upload(e, e->p_sampMult, p->samplingMultiplier, (size_t)P);
+    rc |= upload(e, e->p_actualSizes, e->actualSizes.data(), (size_t)P);
+    rc |= upload(e, e->p_mig, e->mig.data(), (size_t)(P * P));
+    rc |= upload(e, e->p_suscTrans, p->suscepTransition, (size_t)(S * S));
+    rc |= upload(e, e->p_suscCumul, e->suscepCumul.data(), (size_t)S);
+    if (rc) return VGX_ERR_HIP;
+    HIPCHECK(e, hipStreamSynchronize(e->stream));  // the sources are caller/stack memory
+
+    VgxDevParams &d = e->dp;
+    d.H = (int32_t)H; d.P = (int32_t)P; d.S = (int32_t)S; d.sites = (int32_t)sites; d.C = e->C; d.CB = e->CB;
+    d.cls = (const int32_t *)e->p_cls.p; d.suscType = (const int64_t *)e->p_suscType.p;
+    d.mRate = (const double *)e->p_mRate.p; d.hapMutType = (const double *)e->p_hapMutType.p;
+    d.bRate = (const double *)e->p_bRate.p; d.susc = (const double *)e->p_susc.p;
+    d.c_d = (const double *)e->p_cd.p; d.c_s = (const double *)e->p_cs.p; d.c_tm = (const double *)e->p_ctm.p;
+    d.c_bidx = (const int32_t *)e->p_cbidx.p; d.cb_b = (const double *)e->p_cbb.p;
+    d.cb_sigma = (const double *)e->p_cbsig.p;
+    d.sizes = (const int64_t *)e->p_sizes.p; d.cdBefore = (const double *)e->p_cdBefore.p;
+    d.cdAfter = (const double *)e->p_cdAfter.p; d.startLD = (const double *)e->p_startLD.p;
+    d.endLD = (const double *)e->p_endLD.p; d.sampMult = (const double *)e->p_sampMult.p;
+    d.actualSizes = (const double *)e->p_actualSizes.p; d.mig = (const double *)e->p_mig.p;
+    d.suscepTransition = (const double *)e->p_suscTrans.p; d.suscepCumul = (const double *)e->p_suscCumul.p;
+    d.maxEffectiveBirth = maxEffectiveBirth;
+    e->have_params = true;
+    e->dev_state_valid = false;  // class ids in the occupancy lists refer to the old parameter rows
+    return VGX_OK;
+}
+
+extern "C" int vgx_set_state(vgx_engine *e, const vgx_state *s) {
+    if (!e || !s) return VGX_ERR_ARG;
+    const int64_t H = e->d.hapNum, P = e->d.popNum, S = e->d.susNum;
+    if (!s->susceptible || !s->infectious || !s->lockdownON || !s->contactDensity)
+        return fail(e, VGX_ERR_ARG, "vgx_set_state: susceptible, infectious, lockdownON and contactDensity are required");
+    HostState &h = e->hs;
+    h.susceptible.assign(s->susceptible, s->susceptible + P * S);
+    h.infectious.assign(s->infectious, s->infectious + P * H);
+    if (s->initial_susceptible) h.initial_susceptible.assign(s->initial_susceptible, s->initial_susceptible + P * S);
+    else h.initial_susceptible.assign((size_t)(P * S), 0);
+    if (s->initial_infectious) h.initial_infectious.assign(s->initial_infectious, s->initial_infectious + P * H);
+    else h.initial_infectious.assign((size_t)(P * H), 0);
+    h.lockdownON.assign(s->lockdownON, s->lockdownON + P);
+    h.contactDensity.assign(s->contactDensity, s->contactDensity + P);
+    h.totalSusceptible.assign((size_t)P, 0);
+    h.totalInfectious.assign((size_t)P, 0);
+    if (s->totalSusceptible) h.totalSusceptible.assign(s->totalSusceptible, s->totalSusceptible + P);
+    if (s->totalInfectious) h.totalInfectious.assign(s->totalInfectious, s->totalInfectious + P);
+    h.first_simulation = s->first_simulation;
+    h.globalInfectious = s->globalInfectious;
+    h.bCounter = s->bCounter; h.dCounter = s->dCounter; h.sCounter = s->sCounter; h.mCounter = s->mCounter;
+    h.iCounter = s->iCounter; h.swapLockdown = s->swapLockdown; h.migPlus = s->migPlus; h.migNonPlus = s->migNonPlus;
+    h.good_attempt = s->good_attempt;
+    h.currentTime = s->currentTime; h.totalRate = s->totalRate; h.totalMigrationRate = s->totalMigrationRate;
+    h.tau_l = s->tau_l;
+    h.ev_ptr = s->ev_ptr; h.ev_size = s->ev_size;
+    e->have_state = true;
+    e->dev_state_valid = false;
+    return VGX_OK;
+}
+
+// dense [P][H] -> ordered occupancy lists
+static void build_lists(const vgx_engine *e, const std::vector<int64_t> &dense, std::vector<int32_t> &nocc,
+                        std::vector<int32_t> &hap, std::vector<int32_t> &cl, std::vector<int64_t> &cnt, int64_t &cap) {
+    const int64_t H = e->d.hapNum, P = e->d.popNum;
+    nocc.assign((size_t)P, 0);
+    int64_t mx = 0;
+    for (int64_t pn = 0; pn < P; pn++) {
+        int64_t n = 0;
+        for (int64_t h = 0; h < H; h++) n += dense[(size_t)(pn * H + h)] != 0;
+        nocc[(size_t)pn] = (int32_t)n;
+        mx = std::max(mx, n);
+    }
+    cap = std::max<int64_t>(mx, 1);
+    hap.assign((size_t)(P * cap), 0);
+    cl.assign((size_t)(P * cap), 0);
+    cnt.assign((size_t)(P * cap), 0);
+    for (int64_t pn = 0; pn < P; pn++) {
+        int64_t k = 0;
+        for (int64_t h = 0; h < H; h++) {
+            int64_t v = dense[(size_t)(pn * H + h)];
+            if (v != 0) {
+                hap[(size_t)(pn * cap + k)] = (int32_t)h;
+                cl[(size_t)(pn * cap + k)] = e->cls[(size_t)h];
+                cnt[(size_t)(pn * cap + k)] = v;
+                k++;
+            }
+        }
+    }
+}
+
+static size_t lds_bytes_for(const vgx_engine *e) {
+    const size_t P = (size_t)e->d.popNum, S = (size_t)e->d.susNum;
+    return (7 * P + P * S + (size_t)e->C) * 8 + (3 * P + P * S) * 8;
+}
+
+// PrepareParameters' first-call part (pyx:435-448) + FirstInfection (pyx:234-242) on the host state
+static void prepare_first(vgx_engine *e) {
+    HostState &h = e->hs;
+    const int64_t H = e->d.hapNum, P = e->d.popNum, S = e->d.susNum;
+    if (!h.first_simulation) {
+        if (h.globalInfectious == 0) {
+            for (int64_t sn = 0; sn < S; sn++) {
+                if (h.susceptible[(size_t)sn] == 0) continue;
+                h.susceptible[(size_t)sn] -= 1;
+                h.totalSusceptible[0] -= 1;
+                h.infectious[0] += 1;
+                h.totalInfectious[0] += 1;
+                h.globalInfectious += 1;
+                break;
+            }
+        }
+        h.globalInfectious = 0;
+        for (int64_t pn = 0; pn < P; pn++) {
+            h.totalSusceptible[(size_t)pn] = 0;
+            for (int64_t sn = 0; sn < S; sn++) {
+                h.initial_susceptible[(size_t)(pn * S + sn)] = h.susceptible[(size_t)(pn * S + sn)];
+                h.totalSusceptible[(size_t)pn] += h.susceptible[(size_t)(pn * S + sn)];
+            }
+            h.totalInfectious[(size_t)pn] = 0;
+            for (int64_t hn = 0; hn < H; hn++) {
+                int64_t v = h.infectious[(size_t)(pn * H + hn)];
+                h.initial_infectious[(size_t)(pn * H + hn)] = v;
+                h.totalInfectious[(size_t)pn] += v;
+                h.globalInfectious += v;
+            }
+        }
+        h.first_simulation = 1;
+    }
+}
+
+static int init_device_state(vgx_engine *e, int64_t traj_points) {
+    HostState &h = e->hs;
+    const int64_t H = e->d.hapNum, P = e->d.popNum, S = e->d.susNum, R = e->R;
+    std::vector<int32_t> nocc, hap, cl, i_nocc, i_hap, i_cl;
+    std::vector<int64_t> cnt, i_cnt;
+    int64_t s_cap = 1, i_cap = 1;
+    build_lists(e, h.infectious, nocc, hap, cl, cnt, s_cap);
+    build_lists(e, h.initial_infectious, i_nocc, i_hap, i_cl, i_cnt, i_cap);
+
+    // list capacity per (replicate, population): worst case H when it fits the memory budget
+    size_t free_b = 0, total_b = 0;
+    HIPCHECK(e, hipMemGetInfo(&free_b, &total_b));
+    int64_t need = std::max<int64_t>(std::max(s_cap, i_cap), 1);
+    int64_t budget = (int64_t)((double)(free_b + e->r_lhap.bytes + e->r_lcls.bytes + e->r_lcnt.bytes) * 0.55 / (double)(R * P * 16));
+    int64_t cap = std::min<int64_t>(H, std::max<int64_t>(budget, 64));
+    cap = std::max(cap, std::min<int64_t>(H, need + 64));
+    if (cap < need) return fail(e, VGX_ERR_CAPACITY, "occupancy lists do not fit device memory");
+    e->cap = cap;
+
+    int rc = 0;
+    rc |= ensure(e, e->r_popD, (size_t)(R * PD_COUNT * P) * 8);
+    rc |= ensure(e, e->r_popI, (size_t)(R * PI_COUNT * P) * 8);
+    rc |= ensure(e, e->r_sus, (size_t)(R * P * S) * 8);
+    rc |= ensure(e, e->r_immSrc, (size_t)(R * P * S) * 8);
+    rc |= ensure(e, e->r_birthC, (size_t)(R * P * e->CB) * 8);
+    rc |= ensure(e, e->r_xC, (size_t)(R * P * e->CB * S) * 8);
+    rc |= ensure(e, e->r_effMig, (size_t)(R * P * P) * 8);
+    rc |= ensure(e, e->r_nocc, (size_t)(R * P) * 4);
+    rc |= ensure(e, e->r_lhap, (size_t)(R * P * cap) * 4);
+    rc |= ensure(e, e->r_lcls, (size_t)(R * P * cap) * 4);
+    rc |= ensure(e, e->r_lcnt, (size_t)(R * P * cap) * 8);
+    rc |= ensure(e, e->r_sc, (size_t)R * sizeof(VgxRepScalars));
+    rc |= ensure(e, e->r_locrec, (size_t)(R * VGX_LOC_CAP * 2) * 4);
+    rc |= ensure(e, e->r_loctime, (size_t)(R * VGX_LOC_CAP) * 8);
+    if (rc) return rc;
+    HIPCHECK(e, hipMemsetAsync(e->r_effMig.p, 0, (size_t)(R * P * P) * 8, e->stream));
+    HIPCHECK(e, hipMemsetAsync(e->r_popD.p, 0, (size_t)(R * PD_COUNT * P) * 8, e->stream));
+    HIPCHECK(e, hipMemsetAsync(e->r_immSrc.p, 0, (size_t)(R * P * S) * 8, e->stream));
+
+    rc |= upload(e, e->s_nocc, nocc.data(), nocc.size());
+    rc |= upload(e, e->s_hap, hap.data(), hap.size());
+    rc |= upload(e, e->s_cls, cl.data(), cl.size());
+    rc |= upload(e, e->s_cnt, cnt.data(), cnt.size());
+    rc |= upload(e, e->s_sus, h.susceptible.data(), h.susceptible.size());
+    rc |= upload(e, e->s_cd, h.contactDensity.data(), h.contactDensity.size());
+    std::vector<int64_t> tot((size_t)(3 * P));
+    for (int64_t pn = 0; pn < P; pn++) {
+        tot[(size_t)pn] = h.totalSusceptible[(size_t)pn];
+        tot[(size_t)(P + pn)] = h.totalInfectious[(size_t)pn];
+        tot[(size_t)(2 * P + pn)] = h.lockdownON[(size_t)pn];
+    }
+    rc |= upload(e, e->s_tot, tot.data(), tot.size());
+    rc |= upload(e, e->i_nocc, i_nocc.data(), i_nocc.size());
+    rc |= upload(e, e->i_hap, i_hap.data(), i_hap.size());
+    rc |= upload(e, e->i_cls, i_cl.data(), i_cl.size());
+    rc |= upload(e, e->i_cnt, i_cnt.data(), i_cnt.size());
+    rc |= upload(e, e->i_sus, h.initial_susceptible.data(), h.initial_susceptible.size());
+    rc |= upload(e, e->r_seeds, e->seeds.data(), e->seeds.size());
+    if (rc) return VGX_ERR_HIP;
+
+    e->sc_host.assign((size_t)R, VgxRepScalars{});
+    for (int64_t r = 0; r < R; r++) {
+        VgxRepScalars &s = e->sc_host[(size_t)r];
+        s.currentTime = h.currentTime; s.totalRate = h.totalRate; s.totalMig = h.totalMigrationRate; s.tau_l = h.tau_l;
+        s.globalInfectious = h.globalInfectious;
+        s.bCounter = h.bCounter; s.dCounter = h.dCounter; s.sCounter = h.sCounter; s.mCounter = h.mCounter;
+        s.iCounter = h.iCounter; s.swapLockdown = h.swapLockdown; s.migPlus = h.migPlus; s.migNonPlus = h.migNonPlus;
+        s.good_attempt = h.good_attempt;
+        s.ev_ptr = h.ev_ptr;
+    }
+    HIPCHECK(e, hipMemcpyAsync(e->r_sc.p, e->sc_host.data(), (size_t)R * sizeof(VgxRepScalars), hipMemcpyHostToDevice, e->stream));
+
+    VgxDevRep &d = e->dr;
+    d.popD = (double *)e->r_popD.p; d.popI = (int64_t *)e->r_popI.p; d.sus = (int64_t *)e->r_sus.p;
+    d.immSrc = (double *)e->r_immSrc.p; d.birthC = (double *)e->r_birthC.p; d.xC = (double *)e->r_xC.p;
+    d.effMig = (double *)e->r_effMig.p; d.nocc = (int32_t *)e->r_nocc.p; d.lhap = (int32_t *)e->r_lhap.p;
+    d.lcls = (int32_t *)e->r_lcls.p; d.lcnt = (int64_t *)e->r_lcnt.p; d.cap = cap;
+    d.i_nocc = (const int32_t *)e->i_nocc.p; d.i_hap = (const int32_t *)e->i_hap.p;
+    d.i_cls = (const int32_t *)e->i_cls.p; d.i_cnt = (const int64_t *)e->i_cnt.p; d.i_cap = i_cap;
+    d.i_sus = (const int64_t *)e->i_sus.p;
+    d.sc = (VgxRepScalars *)e->r_sc.p; d.seeds = (const int64_t *)e->r_seeds.p;
+    d.loc_rec = (int32_t *)e->r_locrec.p; d.loc_time = (double *)e->r_loctime.p;
+
+    hipLaunchKernelGGL(vgx_init_reps_kernel, dim3((unsigned)R), dim3(VGX_WAVE), 0, e->stream, d, (int)P, (int)S, R,
+                       (const int32_t *)e->s_nocc.p, (const int32_t *)e->s_hap.p, (const int32_t *)e->s_cls.p,
+                       (const int64_t *)e->s_cnt.p, s_cap, (const int64_t *)e->s_sus.p, (const double *)e->s_cd.p,
+                       (const int64_t *)e->s_tot.p);
+    HIPCHECK(e, hipGetLastError());
+    HIPCHECK(e, hipStreamSynchronize(e->stream));  // host vectors above go out of scope
+    e->dev_state_valid = true;
+    (void)traj_points;
+    return VGX_OK;
+}
+
+extern "C" int vgx_simulate_direct(vgx_engine *e, int64_t iterations, int64_t sample_size, float time,
+                                   int64_t attempts, const vgx_run_opts *opts) {
+    if (!e) return VGX_ERR_ARG;
+    if (!e->have_params || !e->have_state) return fail(e, VGX_ERR_ARG, "vgx_simulate_direct: set params and state first");
+    if (iterations < 0 || attempts < 0) return fail(e, VGX_ERR_ARG, "vgx_simulate_direct: negative iterations/attempts");
+    HIPCHECK(e, hipSetDevice(e->device));
+    const int64_t P = e->d.popNum, R = e->R;
+    vgx_run_opts o{};
+    o.record_events = 1;
+    if (opts) o = *opts;
+    if (o.max_loop_factor <= 0) o.max_loop_factor = 1024;
+    size_t lds = lds_bytes_for(e);
+    if (lds > 160 * 1024) return fail(e, VGX_ERR_ARG, "vgx_simulate_direct: population block does not fit the 160 KiB LDS");
+
+    HostState &h = e->hs;
+    if (!e->dev_state_valid) {
+        prepare_first(e);
+        int rc = init_device_state(e, o.traj_points);
+        if (rc) return rc;
+    }
+    // events.ptr / events.size as maintained by the caller's Events.CreateEvents (events.pxi:52-68)
+    const int64_t ev_ptr0 = h.ev_ptr, ev_size = h.ev_size;
+    if (ev_size < ev_ptr0) return fail(e, VGX_ERR_ARG, "vgx_simulate_direct: ev_size < ev_ptr");
+    // a Restart (pyx:414-415) rewinds the log to 0, so the device log must then cover [0, ev_size)
+    const bool may_restart = ev_ptr0 <= 100 && iterations > 100;
+    e->ev_base = may_restart ? 0 : ev_ptr0;
+    e->ev_ptr0 = ev_ptr0;
+    int64_t evcap = o.record_events ? std::max<int64_t>(ev_size - e->ev_base, 1) : 1;
+    int rc = 0;
+    rc |= ensure(e, e->r_evtime, (size_t)(R * evcap) * 8);
+    rc |= ensure(e, e->r_evcols, (size_t)(R * evcap * 5) * 4);
+    if (o.traj_points > 0) rc |= ensure(e, e->r_traj, (size_t)(R * o.traj_points * P * 2) * 8);
+    if (rc) return rc;
+    e->evcap = evcap;
+    e->traj_points = o.traj_points;
+    e->last_ev_size = ev_size;
+
+    VgxDirectArgs a{};
+    a.p = e->dp;
+    a.r = e->dr;
+    a.r.ev_time = (double *)e->r_evtime.p;
+    a.r.ev_cols = (int32_t *)e->r_evcols.p;
+    a.r.evcap = evcap;
+    a.r.ev_base = e->ev_base;
+    a.r.traj = o.traj_points > 0 ? (double *)e->r_traj.p : nullptr;
+    a.r.traj_points = o.traj_points;
+    a.r.traj_t0 = o.traj_t0;
+    a.r.traj_dt = o.traj_points > 1 ? (o.traj_t1 - o.traj_t0) / (double)(o.traj_points - 1) : 0.0;
+    a.n_replicates = R;
+    a.iterations = iterations; a.sample_size = sample_size; a.attempts = attempts; a.time = time;
+    a.ev_size = ev_size;
+    a.max_loop = o.max_loop_factor * std::max<int64_t>(iterations, 1) + (1 << 20);
+    a.record_events = o.record_events ? 1 : 0;
+    a.lds_bytes = (int32_t)lds;
+
+    HIPCHECK(e, hipFuncSetAttribute((const void *)vgx_direct_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIPCHECK(e, hipEventRecord(e->ev0, e->stream));
+    hipLaunchKernelGGL(vgx_direct_kernel, dim3((unsigned)R), dim3(VGX_WAVE), lds, e->stream, a);
+    HIPCHECK(e, hipGetLastError());
+    HIPCHECK(e, hipEventRecord(e->ev1, e->stream));
+    HIPCHECK(e, hipStreamSynchronize(e->stream));
+    HIPCHECK(e, hipEventElapsedTime(&e->last_ms, e->ev0, e->ev1));
+    e->last_launches = 1;
+
+    e->sc_host.resize((size_t)R);
+    HIPCHECK(e, hipMemcpy(e->sc_host.data(), e->r_sc.p, (size_t)R * sizeof(VgxRepScalars), hipMemcpyDeviceToHost));
+    e->sc_host_valid = true;
+    // the caller's next simulate continues from where replicate 0 stopped unless it sets a new state
+    h.ev_ptr = e->sc_host[0].ev_ptr;
+    for (int64_t r = 0; r < R; r++) {
+        int64_t er = e->sc_host[(size_t)r].error;
+        if (er) {
+            const char *what = er == VGX_ERR_ZERO_WEIGHT ? "zero weight sampled (fastChoose alert)"
+                               : er == VGX_ERR_CAPACITY  ? "capacity exceeded (occupancy list / event or lockdown log)"
+                               : er == VGX_ERR_LOOP_GUARD ? "loop guard tripped"
+                                                          : "kernel error";
+            return fail(e, (int)er, std::string("vgx_simulate_direct: replicate ") + std::to_string(r) + ": " + what);
+        }
+    }
+    return VGX_OK;
+}
+
+extern "C" int vgx_simulate_tau(vgx_engine *e, int64_t, int64_t, float, int64_t, const vgx_run_opts *) {
+    if (!e) return VGX_ERR_ARG;
+    return fail(e, VGX_ERR_ARG, "vgx_simulate_tau: not built into this library yet");
+}
+
+extern "C" int vgx_get_counters(vgx_engine *e, int64_t replicate, vgx_counters *out) {
+    if (!e || !out || replicate < 0 || replicate >= e->R) return VGX_ERR_ARG;
+    if (!e->sc_host_valid) return fail(e, VGX_ERR_ARG, "vgx_get_counters: no simulate call yet");
+    const VgxRepScalars &s = e->sc_host[(size_t)replicate];
+    memset(out, 0, sizeof(*out));
+    out->ev_ptr = s.ev_ptr;
+    out->ev_first_new = s.restarts > 0 ? 0 : e->ev_ptr0;
+    out->loop_iterations = s.loop_iterations;
+    out->restarts = s.restarts;
+    out->lockdown_records = s.loc_n;
+    out->error = s.error;
+    out->multievent_rows = s.mev_rows;
+    return VGX_OK;
+}
+
+extern "C" int vgx_get_events(vgx_engine *e, int64_t replicate, int64_t first, int64_t count, double *times,
+                              int64_t *types, int64_t *haplotypes, int64_t *populations, int64_t *newHaplotypes,
+                              int64_t *newPopulations) {
+    if (!e || replicate < 0 || replicate >= e->R || first < 0 || count < 0) return VGX_ERR_ARG;
+    if (count == 0) return VGX_OK;
+    HIPCHECK(e, hipSetDevice(e->device));
+    int64_t slot0 = first - e->ev_base;
+    if (slot0 < 0 || slot0 + count > e->evcap) return fail(e, VGX_ERR_ARG, "vgx_get_events: range outside the device log of the last call");
+    std::vector<int32_t> cols((size_t)count * 5);
+    HIPCHECK(e, hipMemcpy(cols.data(), (int32_t *)e->r_evcols.p + (replicate * e->evcap + slot0) * 5, (size_t)count * 20, hipMemcpyDeviceToHost));
+    if (times) HIPCHECK(e, hipMemcpy(times, (double *)e->r_evtime.p + replicate * e->evcap + slot0, (size_t)count * 8, hipMemcpyDeviceToHost));
+    int64_t *dst[5] = {types, haplotypes, populations, newHaplotypes, newPopulations};
+    for (int c = 0; c < 5; c++)
+        if (dst[c])
+            for (int64_t i = 0; i < count; i++) dst[c][i] = cols[(size_t)(i * 5 + c)];
+    return VGX_OK;
+}
+
+extern "C" int vgx_get_lockdowns(vgx_engine *e, int64_t replicate, int64_t cap, int64_t *states, int64_t *populations,
+                                 double *times, int64_t *n) {
+    if (!e || !n || replicate < 0 || replicate >= e->R) return VGX_ERR_ARG;
+    if (!e->sc_host_valid) return fail(e, VGX_ERR_ARG, "vgx_get_lockdowns: no simulate call yet");
+    HIPCHECK(e, hipSetDevice(e->device));
+    int64_t cnt = std::min<int64_t>(e->sc_host[(size_t)replicate].loc_n, VGX_LOC_CAP);
+    *n = cnt;
+    cnt = std::min(cnt, cap);
+    if (cnt <= 0) return VGX_OK;
+    std::vector<int32_t> rec((size_t)cnt * 2);
+    std::vector<double> tt((size_t)cnt);
+    HIPCHECK(e, hipMemcpy(rec.data(), (int32_t *)e->r_locrec.p + replicate * VGX_LOC_CAP * 2, (size_t)cnt * 8, hipMemcpyDeviceToHost));
+    HIPCHECK(e, hipMemcpy(tt.data(), (double *)e->r_loctime.p + replicate * VGX_LOC_CAP, (size_t)cnt * 8, hipMemcpyDeviceToHost));
+    for (int64_t i = 0; i < cnt; i++) {
+        if (states) states[i] = rec[(size_t)(i * 2)];
+        if (populations) populations[i] = rec[(size_t)(i * 2 + 1)];
+        if (times) times[i] = tt[(size_t)i];
+    }
+    return VGX_OK;
+}
+
+extern "C" int vgx_get_multievents(vgx_engine *e, int64_t, int64_t, int64_t *, double *, int64_t *, int64_t *, int64_t *,
+                                   int64_t *, int64_t *, int64_t *n) {
+    if (!e || !n) return VGX_ERR_ARG;
+    *n = 0;
+    return VGX_OK;
+}
+
+extern "C" int vgx_get_trajectories(vgx_engine *e, double *out, int out_is_device) {
+    if (!e || !out) return VGX_ERR_ARG;
+    if (e->traj_points <= 0) return fail(e, VGX_ERR_ARG, "vgx_get_trajectories: the last call recorded none");
+    HIPCHECK(e, hipSetDevice(e->device));
+    size_t bytes = (size_t)(e->R * e->traj_points * e->d.popNum * 2) * 8;
+    HIPCHECK(e, hipMemcpy(out, e->r_traj.p, bytes, out_is_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost));
+    return VGX_OK;
+}
+
+extern "C" int vgx_get_state(vgx_engine *e, int64_t replicate, vgx_state *out) {
+    if (!e || !out || replicate < 0 || replicate >= e->R) return VGX_ERR_ARG;
+    if (!e->dev_state_valid || !e->sc_host_valid) return fail(e, VGX_ERR_ARG, "vgx_get_state: no device state");
+    HIPCHECK(e, hipSetDevice(e->device));
+    const int64_t H = e->d.hapNum, P = e->d.popNum, S = e->d.susNum, cap = e->cap;
+    const VgxRepScalars &s = e->sc_host[(size_t)replicate];
+    std::vector<int64_t> popI((size_t)(PI_COUNT * P));
+    std::vector<double> popD((size_t)(PD_COUNT * P));
+    HIPCHECK(e, hipMemcpy(popI.data(), (int64_t *)e->r_popI.p + replicate * PI_COUNT * P, popI.size() * 8, hipMemcpyDeviceToHost));
+    HIPCHECK(e, hipMemcpy(popD.data(), (double *)e->r_popD.p + replicate * PD_COUNT * P, popD.size() * 8, hipMemcpyDeviceToHost));
+    if (out->susceptible)
+        HIPCHECK(e, hipMemcpy(out->susceptible, (int64_t *)e->r_sus.p + replicate * P * S, (size_t)(P * S) * 8, hipMemcpyDeviceToHost));
+    if (out->infectious) {
+        std::vector<int32_t> nocc((size_t)P);
+        HIPCHECK(e, hipMemcpy(nocc.data(), (int32_t *)e->r_nocc.p + replicate * P, (size_t)P * 4, hipMemcpyDeviceToHost));
+        memset(out->infectious, 0, (size_t)(P * H) * 8);
+        std::vector<int32_t> hap;
+        std::vector<int64_t> cnt;
+        for (int64_t pn = 0; pn < P; pn++) {
+            int64_t n = nocc[(size_t)pn];
+            if (n <= 0) continue;
+            hap.resize((size_t)n);
+            cnt.resize((size_t)n);
+            HIPCHECK(e, hipMemcpy(hap.data(), (int32_t *)e->r_lhap.p + (replicate * P + pn) * cap, (size_t)n * 4, hipMemcpyDeviceToHost));
+            HIPCHECK(e, hipMemcpy(cnt.data(), (int64_t *)e->r_lcnt.p + (replicate * P + pn) * cap, (size_t)n * 8, hipMemcpyDeviceToHost));
+            for (int64_t k = 0; k < n; k++) out->infectious[pn * H + hap[(size_t)k]] = cnt[(size_t)k];
+        }
+    }
+    HostState &h = e->hs;
+    if (out->initial_susceptible) memcpy(out->initial_susceptible, h.initial_susceptible.data(), (size_t)(P * S) * 8);
+    if (out->initial_infectious) memcpy(out->initial_infectious, h.initial_infectious.data(), (size_t)(P * H) * 8);
+    for (int64_t pn = 0; pn < P; pn++) {
+        if (out->totalSusceptible) out->totalSusceptible[pn] = popI[(size_t)(PI_TOTSUS * P + pn)];
+        if (out->totalInfectious) out->totalInfectious[pn] = popI[(size_t)(PI_TOTINF * P + pn)];
+        if (out->lockdownON) out->lockdownON[pn] = popI[(size_t)(PI_LOCK * P + pn)];
+        if (out->contactDensity) out->contactDensity[pn] = popD[(size_t)(PD_CD * P + pn)];
+    }
+    out->first_simulation = h.first_simulation;
+    out->globalInfectious = s.globalInfectious;
+    out->bCounter = s.bCounter; out->dCounter = s.dCounter; out->sCounter = s.sCounter; out->mCounter = s.mCounter;
+    out->iCounter = s.iCounter; out->swapLockdown = s.swapLockdown; out->migPlus = s.migPlus;
+    out->migNonPlus = s.migNonPlus; out->good_attempt = s.good_attempt;
+    out->currentTime = s.currentTime; out->totalRate = s.totalRate; out->totalMigrationRate = s.totalMig;
+    out->tau_l = s.tau_l;
+    out->ev_ptr = s.ev_ptr; out->ev_size = e->last_ev_size;
+    return VGX_OK;
+}
+
+extern "C" int vgx_bench_propensity_scan(vgx_engine *e, int64_t, double *, int64_t *) {
+    if (!e) return VGX_ERR_ARG;
+    return fail(e, VGX_ERR_ARG, "vgx_bench_propensity_scan: not built into this library yet");
+}

@@ -1,0 +1,106 @@
+// vgx_dev.h — structures shared by the host side of libvgx (vgx_api.hip) and the gfx950 kernels.
+//
+// HBM layout.  Parameters are one read-only copy shared by all replicates.  Each
+// replicate (= one seeded trajectory) owns:
+//   * a population block: per-population rate caches and counters, [field][P], loaded into LDS by the
+//     replicate's wavefront for the whole run;
+//   * per population an ORDERED OCCUPANCY LIST of the haplotypes present there: struct-of-arrays
+//     (hap int32, class int32, count int64), sorted by haplotype index, contiguous -> the per-event
+//     propensity pass of population pi is one coalesced stream of nocc[pi]*16 bytes instead of the
+//     reference's H*(84+16S)-byte dense row (pyx:516-528), and visits haplotypes in the reference's
+//     summation order, so sums and scans stay bit-identical;
+//   * the event log (f64 time + 5 x int32 per event) and a small lockdown log.
+#pragma once
+#include <stdint.h>
+
+#define VGX_WAVE 64
+#define VGX_MAX_CLASSES 1024   // distinct per-haplotype rate rows (full classes) supported by the direct kernel
+#define VGX_LOC_CAP 4096       // lockdown switches recorded per replicate and call
+
+// fields of the per-replicate f64 population block
+enum { PD_POPRATE = 0, PD_INFECT, PD_IMMUNE, PD_MIG, PD_MAXEBM, PD_CD, PD_COUNT };
+// fields of the per-replicate i64 population block
+enum { PI_TOTSUS = 0, PI_TOTINF, PI_LOCK, PI_COUNT };
+
+struct VgxDevParams {
+    int32_t H, P, S, sites, C, CB;
+    const int32_t *cls;         // [H] full rate class of a haplotype
+    const int64_t *suscType;    // [H]
+    const double *mRate;        // [H][sites]
+    const double *hapMutType;   // [H][sites][3]
+    const double *bRate;        // [H]
+    const double *susc;         // [H][S]
+    const double *c_d, *c_s, *c_tm;  // [C] recovery, sampling, total mutation rate of a class
+    const int32_t *c_bidx;      // [C] -> birth class
+    const double *cb_b;         // [CB] transmission rate of a birth class
+    const double *cb_sigma;     // [CB][S] susceptibility row of a birth class
+    const int64_t *sizes;       // [P]
+    const double *cdBefore, *cdAfter, *startLD, *endLD, *sampMult, *actualSizes;  // [P]
+    const double *mig;          // [P][P] migrationRates with the recomputed diagonal (pyx:290-295)
+    const double *suscepTransition;  // [S][S]
+    const double *suscepCumul;  // [S]
+    double maxEffectiveBirth;   // pyx:340-344
+};
+
+struct VgxRepScalars {
+    double currentTime, totalRate, totalMig, tau_l;
+    int64_t globalInfectious;
+    int64_t bCounter, dCounter, sCounter, mCounter, iCounter, swapLockdown, migPlus, migNonPlus;
+    int64_t good_attempt;
+    int64_t ev_ptr;          // absolute events.ptr
+    int64_t loop_iterations;
+    int64_t restarts;
+    int64_t loc_n;
+    int64_t error;
+    int64_t mev_rows;
+    int64_t traj_next;       // next trajectory grid point to emit
+    int64_t pad[3];
+};
+
+struct VgxDevRep {
+    double *popD;        // [R][PD_COUNT][P]
+    int64_t *popI;       // [R][PI_COUNT][P]
+    int64_t *sus;        // [R][P][S]
+    double *immSrc;      // [R][P][S]   immuneSourcePopRate
+    double *birthC;      // [R][P][CB]  eventHapPopRate[.,.,0] per birth class, as of the last infect-update of the population
+    double *xC;          // [R][P][CB][S] susceptHapPopRate per birth class, same staleness
+    double *effMig;      // [R][P][P]
+    int32_t *nocc;       // [R][P]
+    int32_t *lhap;       // [R][P][cap]
+    int32_t *lcls;       // [R][P][cap]
+    int64_t *lcnt;       // [R][P][cap]
+    int64_t cap;
+    // initial state for Restart (pyx:714-738), one copy shared by the replicates
+    const int32_t *i_nocc;   // [P]
+    const int32_t *i_hap;    // [P][i_cap]
+    const int32_t *i_cls;
+    const int64_t *i_cnt;
+    int64_t i_cap;
+    const int64_t *i_sus;    // [P][S]
+    VgxRepScalars *sc;       // [R]
+    const int64_t *seeds;    // [R]
+    // event log
+    double *ev_time;         // [R][evcap]
+    int32_t *ev_cols;        // [R][evcap][5]  type, haplotype, population, newHaplotype, newPopulation
+    int64_t evcap;
+    int64_t ev_base;         // absolute index of log slot 0
+    // lockdown log
+    int32_t *loc_rec;        // [R][VGX_LOC_CAP][2]  state, population
+    double *loc_time;        // [R][VGX_LOC_CAP]
+    // trajectories
+    double *traj;            // [R][T][P][2] or null
+    int64_t traj_points;
+    double traj_t0, traj_dt;
+};
+
+struct VgxDirectArgs {
+    VgxDevParams p;
+    VgxDevRep r;
+    int64_t n_replicates;
+    int64_t iterations, sample_size, attempts;
+    float time;
+    int64_t ev_size;         // absolute events.size
+    int64_t max_loop;
+    int32_t record_events;
+    int32_t lds_bytes;
+};
