@@ -1,0 +1,178 @@
+#!/usr/bin/env python3
+"""bench.py — BASELINE.json's metric on its config-3 workload: simulated events/sec, direct Gillespie,
+65 536 haplotypes (8 sites) x 64 populations, replicate ensemble, on N MI355X of one node.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...)
+
+One "step" = one pass of the hot path over one batch: `--replicates` independent seeded trajectories per GPU,
+`--events` recorded events each, from the single index case (the only initial condition the reference API can
+express), parameters of SURVEY.md §8(d) config 3.  Weak scaling: per-GPU work is fixed, replicates are sharded
+one wavefront each, no data-path collective; the only collective is one RCCL gather of the summary
+trajectories per step.  The JSON line also carries the roofline of the dominant kernel (device time from HIP
+events on the engine's stream) and the CPU baseline (the oracle = op-for-op port of the reference's dense
+algorithm, timed on this host, rank 0, N=1 only).
+"""
+import argparse
+import contextlib
+import io
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+SITES, POPS, SUS = 8, 64, 1           # BASELINE.json configs[2]: 4^8 = 65 536 haplotypes x 64 populations
+HBM_PEAK_GBS = 8000.0                 # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def make_simulator(seed):
+    from vgsim_amd import Simulator
+    with contextlib.redirect_stdout(io.StringIO()):
+        s = Simulator(number_of_sites=SITES, populations_number=POPS, number_of_susceptible_groups=SUS, seed=seed)
+    s.set_transmission_rate(2.5)
+    s.set_recovery_rate(0.9)
+    s.set_sampling_rate(0.1)
+    s.set_mutation_rate(0.01)
+    s.set_total_migration_probability(0.01)
+    s.set_population_size(10 ** 7)
+    return s
+
+
+def cpu_baseline(seconds_target=15.0):
+    """The oracle (oracle/vgx_oracle.c, dense = the reference's own O(H*S*P)-per-event algorithm) on the same
+    workload, one host core, bounded sample."""
+    from oracle import oracle
+    oracle.build()
+    sim = make_simulator(2020)
+    m = sim.simulation
+    t0 = time.time()
+    oracle.run_direct(m, 101, 10 ** 12, -1, 200)      # includes PrepareParameters/UpdateAllRates and Restarts
+    t1 = time.time()
+    n1 = m.events.ptr
+    per_event = max((t1 - t0) / max(n1, 1), 1e-6)
+    n2 = int(max(50, min(5000, seconds_target / per_event)))
+    t2 = time.time()
+    oracle.run_direct(m, n2, 10 ** 12, -1, 200)       # continues the same trajectory
+    t3 = time.time()
+    done = m.events.ptr - n1
+    return {"value": done / max(t3 - t2, 1e-9), "unit": "events/s", "cores": 1, "kind": "port",
+            "sample": "%d events of one config-3 trajectory (seed 2020) after a %d-event start, oracle in the "
+                      "reference's dense mode, %.1f s" % (done, n1, t3 - t2)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--replicates", type=int, default=4096, help="replicates per GPU and step")
+    ap.add_argument("--events", type=int, default=100000, help="recorded events per replicate and step")
+    ap.add_argument("--traj-points", type=int, default=1001)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the engine has no CPU fallback)")
+    torch.cuda.set_device(local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    from vgsim_amd.ensemble import Ensemble
+    sim = make_simulator(2020)
+    ens = Ensemble(sim, a.replicates, device=local)
+    R, N = a.replicates, a.events
+    H = 4 ** SITES
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    def step(i):
+        # distinct seeds per (step, rank, replicate): results do not depend on the GPU count
+        seeds = 2020 + (i * world + rank) * R + np.arange(R, dtype=np.int64)
+        res = ens.simulate(N, sample_size=10 ** 12, traj_points=a.traj_points, traj_window=(0.0, 12.0), seeds=seeds)
+        gathered = ens.gather_trajectories(dst=0) if world > 1 else None
+        return res, gathered
+
+    for i in range(a.warmup):
+        step(i)
+    sync()
+    t0 = time.perf_counter()
+    events = 0
+    kernel_ms = 0.0
+    occ_entries = 0
+    for i in range(a.steps):
+        res, _ = step(a.warmup + i)
+        events += res.total_events
+        kernel_ms += res.kernel_ms
+    sync()
+    elapsed = time.perf_counter() - t0
+
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        e = torch.tensor([float(events)], dtype=torch.float64, device="cuda")
+        dist.all_reduce(e, op=dist.ReduceOp.SUM)
+        elapsed, total_events = float(t.item()), float(e.item())
+    else:
+        total_events = float(events)
+
+    if rank == 0:
+        value = total_events / elapsed
+        # ---- roofline of the dominant kernel (vgx_direct_kernel), this rank ----
+        # Algorithmic bytes per recorded event of THIS engine's layout: the chosen population's
+        # occupancy-list stream (16 B/entry, read once and kept in registers), the migration row (8P), the
+        # event record (28 B) and the count write-back (8 B).  Mean list length measured from final state.
+        st = ens.replicate_state(0)
+        nocc_mean = float((st.infectious != 0).sum(axis=1).mean())
+        bytes_per_event = 16.0 * max(nocc_mean, 1.0) + 8.0 * POPS + 28.0 + 8.0
+        ev_per_launch = events / max(a.steps, 1)
+        launch_s = (kernel_ms / max(a.steps, 1)) * 1e-3
+        achieved = ev_per_launch * bytes_per_event / launch_s / 1e9
+        dense_bytes = H * (84 + 16 * SUS) + 16 * POPS + 48   # the reference's dense layout
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_direct_c3.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "simulated events/sec (direct Gillespie)", "value": value, "unit": "events/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / max(a.steps, 1),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "BASELINE config 3: 65536 haplotypes (8 sites) x 64 populations x 1 susceptibility "
+                                   "group, direct Gillespie, bit-exact mode (PCG64 stream, reference summation order), "
+                                   "index-case start, b=2.5 d=0.9 s=0.1 m=0.01/site, total migration 0.01, N=1e7",
+                       "replicates_per_gpu": R, "events_per_replicate": N, "parallelism": "replicates x%d" % world,
+                       "trajectory_points": a.traj_points},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "vgx_direct_kernel", "kernel_ms_per_launch": kernel_ms / max(a.steps, 1),
+                         "bytes_per_event": bytes_per_event, "mean_occupancy_list_len": nocc_mean,
+                         "note": "persistent sequential event loop: latency/issue-bound, not bandwidth-bound; the "
+                                 "reference's dense layout would need %.3g B/event = %.3g GB/s at this event rate"
+                                 % (dense_bytes, ev_per_launch * dense_bytes / launch_s / 1e9)},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line), flush=True)
+    ens.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -76,9 +76,11 @@ def check_against_golden(model, name, exact_time=True, rtol_time=1e-12):
     for k in ("sCounter", "bCounter", "dCounter", "mCounter", "migPlus", "migNonPlus", "iCounter", "good_attempt"):
         if k in st:
             assert getattr(model, k) == st[k], k
+    # rows at and beyond events.ptr are leftovers of failed attempts (Restart only rewinds ptr, pyx:715);
+    # they are compared only in the exact (sha256) branch below
     if "times" in z:
         ints = z["ints"].astype(np.int64)
-        assert np.array_equal(chain[1:].astype(np.int64), ints), "integer rows differ"
+        assert np.array_equal(chain[1:, :ptr].astype(np.int64), ints[:, :ptr]), "integer rows differ"
         ref_t = z["times"]
     else:
         head, tail = z["head"], z["tail"]
@@ -90,7 +92,7 @@ def check_against_golden(model, name, exact_time=True, rtol_time=1e-12):
     else:
         # documented tolerance for the float row when log() is not the fixture host's libm
         if ref_t is not None:
-            np.testing.assert_allclose(chain[0], ref_t, rtol=rtol_time, atol=0)
+            np.testing.assert_allclose(chain[0, :ptr], ref_t[:ptr], rtol=rtol_time, atol=0)
         else:
             np.testing.assert_allclose(chain[0, :256], z["head"][0], rtol=rtol_time, atol=0)
             np.testing.assert_allclose(chain[0, ptr - z["tail"].shape[1]:ptr], z["tail"][0], rtol=rtol_time, atol=0)

@@ -7,7 +7,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libvgx.so")
+LIB_PATH = os.environ.get("VGX_LIBRARY", os.path.join(HERE, "libvgx.so"))  # VGX_LIBRARY: diagnostic builds only
 
 _F = C.POINTER(C.c_double)
 _I = C.POINTER(C.c_int64)
@@ -69,6 +69,7 @@ SIGNATURES = {
     "vgx_last_kernel_ms": (C.c_double, [_H]),
     "vgx_last_kernel_launches": (C.c_int64, [_H]),
     "vgx_device_bytes": (C.c_int64, [_H]),
+    "vgx_get_profile": (C.c_int, [_H, C.c_int64, _I]),
     "vgx_bench_propensity_scan": (C.c_int, [_H, C.c_int64, _F, _I]),
 }
 

@@ -15,11 +15,13 @@
 #include "../../include/vgx.h"
 #include "vgx_dev.h"
 
-extern "C" __global__ void vgx_direct_kernel(VgxDirectArgs a);
-extern "C" __global__ void vgx_init_reps_kernel(VgxDevRep r, int P, int S, int64_t R, const int32_t *s_nocc,
-                                                const int32_t *s_hap, const int32_t *s_cls, const int64_t *s_cnt,
-                                                int64_t s_cap, const int64_t *s_sus, const double *s_cd,
-                                                const int64_t *s_tot);
+// launchers defined next to their kernels (vgx_direct.hip)
+extern "C" hipError_t vgxi_launch_direct(const VgxDirectArgs *a, size_t lds, hipStream_t stream);
+extern "C" size_t vgxi_direct_lds_bytes(int P, int S, int C, int CB);
+extern "C" hipError_t vgxi_launch_init_reps(const VgxDevRep *r, int P, int S, int64_t R, const int32_t *s_nocc,
+                                            const int32_t *s_hap, const int32_t *s_cls, const int64_t *s_cnt,
+                                            int64_t s_cap, const int64_t *s_sus, const double *s_cd,
+                                            const int64_t *s_tot, hipStream_t stream);
 
 static std::string g_create_error;
 
@@ -55,11 +57,11 @@ struct vgx_engine {
     HostState hs;
     // device
     std::vector<DevBuf *> all;
-    DevBuf p_cls, p_suscType, p_mRate, p_hapMutType, p_bRate, p_susc, p_cd, p_cs, p_ctm, p_cbidx, p_cbb, p_cbsig,
+    DevBuf p_cls, p_suscType, p_mRate, p_hapMutType, p_bRate, p_susc, p_cd, p_cs, p_ctm, p_cbidx, p_cstype, p_cbb, p_cbsig,
         p_sizes, p_cdBefore, p_cdAfter, p_startLD, p_endLD, p_sampMult, p_actualSizes, p_mig, p_suscTrans,
         p_suscCumul;
     DevBuf r_popD, r_popI, r_sus, r_immSrc, r_birthC, r_xC, r_effMig, r_nocc, r_lhap, r_lcls, r_lcnt, r_sc, r_seeds,
-        r_evtime, r_evcols, r_locrec, r_loctime, r_traj;
+        r_evtime, r_evcols, r_locrec, r_loctime, r_traj, r_prof;
     DevBuf i_nocc, i_hap, i_cls, i_cnt, i_sus;          // initial state (Restart)
     DevBuf s_nocc, s_hap, s_cls, s_cnt, s_sus, s_cd, s_tot;  // state at the start of the call
     VgxDevParams dp{};
@@ -150,13 +152,13 @@ extern "C" int vgx_create(const vgx_dims *dims, int64_t n_replicates, int device
 
 extern "C" void vgx_destroy(vgx_engine *e) {
     if (!e) return;
-    hipSetDevice(e->device);
-    hipStreamSynchronize(e->stream);
+    (void)hipSetDevice(e->device);
+    (void)hipStreamSynchronize(e->stream);
     for (DevBuf *b : e->all)
-        if (b->p) hipFree(b->p);
-    if (e->ev0) hipEventDestroy(e->ev0);
-    if (e->ev1) hipEventDestroy(e->ev1);
-    if (e->stream) hipStreamDestroy(e->stream);
+        if (b->p) (void)hipFree(b->p);
+    if (e->ev0) (void)hipEventDestroy(e->ev0);
+    if (e->ev1) (void)hipEventDestroy(e->ev1);
+    if (e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
 }
 
@@ -194,7 +196,7 @@ extern "C" int vgx_set_params(vgx_engine *e, const vgx_params *p) {
     }
     std::unordered_map<std::string, int> fullmap, birthmap;
     std::vector<double> c_d, c_s, c_tm, cb_b, cb_sig;
-    std::vector<int32_t> c_bidx;
+    std::vector<int32_t> c_bidx, c_stype;
     e->cls.assign((size_t)H, 0);
     std::string key;
     for (int64_t h = 0; h < H; h++) {
@@ -213,6 +215,7 @@ extern "C" int vgx_set_params(vgx_engine *e, const vgx_params *p) {
         key.append((const char *)&p->dRate[h], 8);
         key.append((const char *)&p->sRate[h], 8);
         key.append((const char *)&tm[(size_t)h], 8);
+        key.append((const char *)&p->suscType[h], 8);
         auto fi = fullmap.find(key);
         int c;
         if (fi == fullmap.end()) {
@@ -222,10 +225,11 @@ extern "C" int vgx_set_params(vgx_engine *e, const vgx_params *p) {
             c_s.push_back(p->sRate[h]);
             c_tm.push_back(tm[(size_t)h]);
             c_bidx.push_back(cb);
+            c_stype.push_back((int32_t)p->suscType[h]);
             if (c_d.size() > VGX_MAX_CLASSES)
                 return fail(e, VGX_ERR_CLASSES,
                             "vgx_set_params: more than " + std::to_string(VGX_MAX_CLASSES) +
-                                " distinct per-haplotype rate rows (bRate, susceptibility, dRate, sRate, sum of mRate)");
+                                " distinct per-haplotype rate rows (bRate, susceptibility, dRate, sRate, sum of mRate, suscType)");
         } else {
             c = fi->second;
         }
@@ -275,6 +279,7 @@ extern "C" int vgx_set_params(vgx_engine *e, const vgx_params *p) {
     rc |= upload(e, e->p_cs, c_s.data(), c_s.size());
     rc |= upload(e, e->p_ctm, c_tm.data(), c_tm.size());
     rc |= upload(e, e->p_cbidx, c_bidx.data(), c_bidx.size());
+    rc |= upload(e, e->p_cstype, c_stype.data(), c_stype.size());
     rc |= upload(e, e->p_cbb, cb_b.data(), cb_b.size());
     rc |= upload(e, e->p_cbsig, cb_sig.data(), cb_sig.size());
     rc |= upload(e, e->p_sizes, p->sizes, (size_t)P);
@@ -296,7 +301,8 @@ extern "C" int vgx_set_params(vgx_engine *e, const vgx_params *p) {
     d.mRate = (const double *)e->p_mRate.p; d.hapMutType = (const double *)e->p_hapMutType.p;
     d.bRate = (const double *)e->p_bRate.p; d.susc = (const double *)e->p_susc.p;
     d.c_d = (const double *)e->p_cd.p; d.c_s = (const double *)e->p_cs.p; d.c_tm = (const double *)e->p_ctm.p;
-    d.c_bidx = (const int32_t *)e->p_cbidx.p; d.cb_b = (const double *)e->p_cbb.p;
+    d.c_bidx = (const int32_t *)e->p_cbidx.p; d.c_stype = (const int32_t *)e->p_cstype.p;
+    d.cb_b = (const double *)e->p_cbb.p;
     d.cb_sigma = (const double *)e->p_cbsig.p;
     d.sizes = (const int64_t *)e->p_sizes.p; d.cdBefore = (const double *)e->p_cdBefore.p;
     d.cdAfter = (const double *)e->p_cdAfter.p; d.startLD = (const double *)e->p_startLD.p;
@@ -371,8 +377,7 @@ static void build_lists(const vgx_engine *e, const std::vector<int64_t> &dense, 
 }
 
 static size_t lds_bytes_for(const vgx_engine *e) {
-    const size_t P = (size_t)e->d.popNum, S = (size_t)e->d.susNum;
-    return (7 * P + P * S + (size_t)e->C) * 8 + (3 * P + P * S) * 8;
+    return vgxi_direct_lds_bytes((int)e->d.popNum, (int)e->d.susNum, e->C, e->CB);
 }
 
 // PrepareParameters' first-call part (pyx:435-448) + FirstInfection (pyx:234-242) on the host state
@@ -444,6 +449,7 @@ static int init_device_state(vgx_engine *e, int64_t traj_points) {
     rc |= ensure(e, e->r_sc, (size_t)R * sizeof(VgxRepScalars));
     rc |= ensure(e, e->r_locrec, (size_t)(R * VGX_LOC_CAP * 2) * 4);
     rc |= ensure(e, e->r_loctime, (size_t)(R * VGX_LOC_CAP) * 8);
+    rc |= ensure(e, e->r_prof, (size_t)(R * VGX_PROF_SLOTS) * 8);
     if (rc) return rc;
     HIPCHECK(e, hipMemsetAsync(e->r_effMig.p, 0, (size_t)(R * P * P) * 8, e->stream));
     HIPCHECK(e, hipMemsetAsync(e->r_popD.p, 0, (size_t)(R * PD_COUNT * P) * 8, e->stream));
@@ -492,12 +498,13 @@ static int init_device_state(vgx_engine *e, int64_t traj_points) {
     d.i_sus = (const int64_t *)e->i_sus.p;
     d.sc = (VgxRepScalars *)e->r_sc.p; d.seeds = (const int64_t *)e->r_seeds.p;
     d.loc_rec = (int32_t *)e->r_locrec.p; d.loc_time = (double *)e->r_loctime.p;
+    d.prof = (unsigned long long *)e->r_prof.p;
+    HIPCHECK(e, hipMemsetAsync(e->r_prof.p, 0, (size_t)(R * VGX_PROF_SLOTS) * 8, e->stream));
 
-    hipLaunchKernelGGL(vgx_init_reps_kernel, dim3((unsigned)R), dim3(VGX_WAVE), 0, e->stream, d, (int)P, (int)S, R,
-                       (const int32_t *)e->s_nocc.p, (const int32_t *)e->s_hap.p, (const int32_t *)e->s_cls.p,
-                       (const int64_t *)e->s_cnt.p, s_cap, (const int64_t *)e->s_sus.p, (const double *)e->s_cd.p,
-                       (const int64_t *)e->s_tot.p);
-    HIPCHECK(e, hipGetLastError());
+    HIPCHECK(e, vgxi_launch_init_reps(&d, (int)P, (int)S, R, (const int32_t *)e->s_nocc.p, (const int32_t *)e->s_hap.p,
+                                      (const int32_t *)e->s_cls.p, (const int64_t *)e->s_cnt.p, s_cap,
+                                      (const int64_t *)e->s_sus.p, (const double *)e->s_cd.p,
+                                      (const int64_t *)e->s_tot.p, e->stream));
     HIPCHECK(e, hipStreamSynchronize(e->stream));  // host vectors above go out of scope
     e->dev_state_valid = true;
     (void)traj_points;
@@ -516,7 +523,9 @@ extern "C" int vgx_simulate_direct(vgx_engine *e, int64_t iterations, int64_t sa
     if (opts) o = *opts;
     if (o.max_loop_factor <= 0) o.max_loop_factor = 1024;
     size_t lds = lds_bytes_for(e);
-    if (lds > 160 * 1024) return fail(e, VGX_ERR_ARG, "vgx_simulate_direct: population block does not fit the 160 KiB LDS");
+    if (lds > 160 * 1024)
+        return fail(e, VGX_ERR_ARG, "vgx_simulate_direct: the population/class tables need " + std::to_string(lds) +
+                                        " bytes of LDS per wavefront (limit 163840): too many populations x rate classes");
 
     HostState &h = e->hs;
     if (!e->dev_state_valid) {
@@ -559,10 +568,8 @@ extern "C" int vgx_simulate_direct(vgx_engine *e, int64_t iterations, int64_t sa
     a.record_events = o.record_events ? 1 : 0;
     a.lds_bytes = (int32_t)lds;
 
-    HIPCHECK(e, hipFuncSetAttribute((const void *)vgx_direct_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     HIPCHECK(e, hipEventRecord(e->ev0, e->stream));
-    hipLaunchKernelGGL(vgx_direct_kernel, dim3((unsigned)R), dim3(VGX_WAVE), lds, e->stream, a);
-    HIPCHECK(e, hipGetLastError());
+    HIPCHECK(e, vgxi_launch_direct(&a, lds, e->stream));
     HIPCHECK(e, hipEventRecord(e->ev1, e->stream));
     HIPCHECK(e, hipStreamSynchronize(e->stream));
     HIPCHECK(e, hipEventElapsedTime(&e->last_ms, e->ev0, e->ev1));
@@ -706,6 +713,13 @@ extern "C" int vgx_get_state(vgx_engine *e, int64_t replicate, vgx_state *out) {
     out->currentTime = s.currentTime; out->totalRate = s.totalRate; out->totalMigrationRate = s.totalMig;
     out->tau_l = s.tau_l;
     out->ev_ptr = s.ev_ptr; out->ev_size = e->last_ev_size;
+    return VGX_OK;
+}
+
+extern "C" int vgx_get_profile(vgx_engine *e, int64_t replicate, int64_t *out16) {
+    if (!e || !out16 || replicate < 0 || replicate >= e->R || !e->r_prof.p) return VGX_ERR_ARG;
+    HIPCHECK(e, hipSetDevice(e->device));
+    HIPCHECK(e, hipMemcpy(out16, (unsigned long long *)e->r_prof.p + replicate * VGX_PROF_SLOTS, VGX_PROF_SLOTS * 8, hipMemcpyDeviceToHost));
     return VGX_OK;
 }
 

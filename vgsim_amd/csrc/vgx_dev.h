@@ -16,6 +16,7 @@
 #define VGX_WAVE 64
 #define VGX_MAX_CLASSES 1024   // distinct per-haplotype rate rows (full classes) supported by the direct kernel
 #define VGX_LOC_CAP 4096       // lockdown switches recorded per replicate and call
+#define VGX_PROF_SLOTS 16       // in-kernel phase stamps of the diagnostic (-DVGX_PROFILE) build
 
 // fields of the per-replicate f64 population block
 enum { PD_POPRATE = 0, PD_INFECT, PD_IMMUNE, PD_MIG, PD_MAXEBM, PD_CD, PD_COUNT };
@@ -32,6 +33,7 @@ struct VgxDevParams {
     const double *susc;         // [H][S]
     const double *c_d, *c_s, *c_tm;  // [C] recovery, sampling, total mutation rate of a class
     const int32_t *c_bidx;      // [C] -> birth class
+    const int32_t *c_stype;     // [C] suscType of the class
     const double *cb_b;         // [CB] transmission rate of a birth class
     const double *cb_sigma;     // [CB][S] susceptibility row of a birth class
     const int64_t *sizes;       // [P]
@@ -91,6 +93,7 @@ struct VgxDevRep {
     double *traj;            // [R][T][P][2] or null
     int64_t traj_points;
     double traj_t0, traj_dt;
+    unsigned long long *prof; // [R][VGX_PROF_SLOTS] cycle sums of the diagnostic build (else untouched)
 };
 
 struct VgxDirectArgs {

@@ -8,87 +8,75 @@
 //
 // Execution model: ONE 64-lane wavefront per replicate (workgroup = 1 wave, grid = replicates), alive for
 // the whole simulate call.  The trajectory itself is sequential (event k+1 depends on event k), so the
-// wave exploits the parallelism INSIDE an event: lanes map to populations (P-wide arrays live in LDS),
-// to the entries of the chosen population's ordered occupancy list (coalesced 16 B/entry stream from
-// HBM/L2), and to the terms of the transmission sum.  Everything that the reference sums left-to-right
-// is summed left-to-right here too (seq_sum / seq_scan: a lane-ordered chain of f64 adds), with no FMA
-// contraction (-ffp-contract=off), so every rate, every comparison and the recycled random number are
-// bit-identical to the reference's; only haplotypes with a non-zero count are visited, which is exact
-// because x + 0.0 == x and a zero weight can never stop a scan.
-//
-// Per-haplotype rates are factored through CLASSES of identical parameter rows (bRate, susceptibility
-// row, dRate, sRate, sum of mRate): BirthRate (pyx:382-392) depends on the haplotype only through its
-// class, so it is evaluated once per class and population instead of once per haplotype — same
-// operations on the same operands, hence the same bits.
+// wave exploits the parallelism INSIDE an event: lanes map to populations (all P-wide arrays and the
+// per-class tables live in LDS for the whole run), to the entries of the chosen population's ordered
+// occupancy list (one coalesced 16 B/entry stream from HBM/L2 per event, kept in registers between the
+// selection scan and the rate refresh), and to the terms of the transmission sum.  Everything the
+// reference sums left-to-right is summed left-to-right here too (vgx_wave.h: seq_sum / seq_scan), with
+// no FMA contraction (-ffp-contract=off), so every rate, every comparison and the recycled random
+// number are bit-identical to the reference's.  Three restructurings keep that property:
+//   * only haplotypes with a non-zero count are visited: x + 0.0 == x and a zero weight can never stop a
+//     scan;
+//   * per-haplotype rates are factored through CLASSES of identical parameter rows (bRate, susceptibility
+//     row, dRate, sRate, sum of mRate, suscType): BirthRate (pyx:382-392) depends on the haplotype only
+//     through its class, so it is evaluated once per class — same operations on the same operands;
+//   * the running prefix sums of popRate / migPopRate that fastChoose would recompute (fast_choose.pxi:25)
+//     are kept (they ARE the partial sums of the totalRate / totalMigrationRate loops, pyx:537-546) and
+//     refreshed from the changed population onwards, so population selection is one compare + ballot.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "vgx_dev.h"
 #include "vgx_rng.h"
+#include "vgx_wave.h"
 
-#define LANES VGX_WAVE
+#define LANES VGX_LANES
+
+// In-kernel stamps (diagnostic build only, -DVGX_PROFILE: tools/profile_phases.py): cycles per phase of the
+// event loop, summed per replicate into the debug buffer r.prof.  No stamp executes in the product build.
+#ifdef VGX_PROFILE
+#define PROF(i)                                                       \
+    do {                                                              \
+        unsigned long long prof_t1 = __builtin_readcyclecounter();    \
+        c.prof_acc[i] += prof_t1 - c.prof_t0;                         \
+        c.prof_t0 = prof_t1;                                          \
+    } while (0)
+#else
+#define PROF(i)
+#endif
 
 enum { ERR_ZERO_WEIGHT = 3, ERR_CAPACITY = 4, ERR_LOOP_GUARD = 5 };
 enum { EV_BIRTH = 0, EV_DEATH, EV_SAMPLING, EV_MUTATION, EV_SUSCCHANGE, EV_MIGRATION };
 
-// compiler-level ordering of cross-lane traffic through LDS / global memory inside the wave.  The
-// hardware executes one wave's LDS and vector-memory instructions in issue order, so no wait is needed.
-#define WSYNC()                                                  \
-    do {                                                         \
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");   \
-        __builtin_amdgcn_wave_barrier();                         \
-    } while (0)
-
-static __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
-
-static __device__ __forceinline__ double bcast(double v, int k) {  // value of lane k (k wave-uniform)
-    int lo = __builtin_amdgcn_readlane(__double2loint(v), k);
-    int hi = __builtin_amdgcn_readlane(__double2hiint(v), k);
-    return __hiloint2double(hi, lo);
-}
-static __device__ __forceinline__ int64_t bcast_i64(int64_t v, int k) {
-    int lo = __builtin_amdgcn_readlane((int)(uint32_t)v, k);
-    int hi = __builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)v >> 32), k);
-    return (int64_t)(((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo);
-}
-
-// acc + v[0] + v[1] + ... + v[n-1], added strictly in lane order (the reference's loop order).
-static __device__ __forceinline__ double seq_sum(double v, int n, double acc) {
-
-    for (int k = 0; k < n; ++k) acc += bcast(v, k);
-    return acc;
-}
-// lane L gets carry + v[0] + ... + v[min(L, n-1)] with the same rounding sequence as the serial loop:
-// adding +0.0 after lane L's own term is exact.
-static __device__ __forceinline__ double seq_scan(double v, int n, double carry, int lane) {
-    double acc = carry;
-
-    for (int k = 0; k < n; ++k) {
-        double wk = bcast(v, k);
-        acc += (k <= lane) ? wk : 0.0;
-    }
-    return acc;
-}
-// inclusive integer scan across the wave (order-free: int64 addition is associative)
-static __device__ __forceinline__ int64_t iscan(int64_t v, int lane) {
-#pragma unroll
-    for (int d = 1; d < LANES; d <<= 1) {
-        int64_t o = __shfl_up(v, d);
-        if (lane >= d) v += o;
-    }
-    return v;
-}
+// the occupancy-list tile of one population held in registers (lane k <-> entry k) while it has <= 64 entries
+struct Tile {
+    bool valid;
+    int pi, n;
+    int hap, cls;
+    int64_t cnt;
+};
 
 struct Ctx {
-    // dims
     int P, S, H, C, CB, sites, lane;
-    // parameters
     const VgxDevParams *p;
-    // LDS
-    double *popRate, *infectPopRate, *immunePopRate, *migPopRate, *maxEBM, *cd, *as, *immSrc, *tE;
-    int64_t *totalSus, *totalInf, *lockON, *sus;
-    // global, this replicate
-    double *birthC, *xC, *effMig;
-    int32_t *nocc, *lhap, *lcls;
+    // ---- LDS, f64 ----
+    double *popRate, *infect, *immune, *migRate, *maxEBM, *cd, *as, *cum, *cumMig, *sampMult, *ldStart, *ldEnd;  // [P]
+    double *immSrc;    // [P][S]  immuneSourcePopRate
+    double *birthC;    // [P][CB] eventHapPopRate[.,.,0] per birth class as of the population's last infect-update
+    double *xC;        // [P][CB][S] susceptHapPopRate per birth class, same staleness
+    double *tE;        // [C] tEventHapPopRate per class for the population being processed
+    double *c_d, *c_s, *c_tm;  // [C]
+    double *cb_b;      // [CB]
+    double *cb_sigma;  // [CB][S]
+    double *cumul;     // [S] suscepCumulTransition
+    double *trans;     // [S][S]
+    // ---- LDS, i64 / i32 ----
+    int64_t *totalSus, *totalInf, *lockON;  // [P]
+    int64_t *sus;      // [P][S]
+    int32_t *nocc;     // [P]
+    int32_t *c_bidx, *c_stype;  // [C]
+    // ---- global, this replicate ----
+    double *effMig;
+    int32_t *lhap, *lcls;
     int64_t *lcnt;
     int64_t cap;
     double *ev_time;
@@ -100,12 +88,16 @@ struct Ctx {
     double traj_t0, traj_dt;
     int64_t evcap, ev_base;
     int record_events;
-    // scalars
+    // ---- wave-uniform scalars ----
     double currentTime, totalRate, totalMig, rn;
     int64_t gI;
     int64_t bC, dC, sC, mC, iC, swapLD, migPlus, migNon;
     int64_t ev_ptr, ev_size, loc_n;
     int error;
+    bool has_mig;  // some maxEffectiveBirthMigration > 0
+#ifdef VGX_PROFILE
+    unsigned long long prof_t0, prof_acc[VGX_PROF_SLOTS];
+#endif
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -139,40 +131,48 @@ static __device__ __forceinline__ int choose_serial_i64(Ctx &c, LoadW w, int n, 
     return i;
 }
 
-// fastChoose over a P-sized f64 array held in LDS: lane-ordered prefix sums, one ballot per 64 entries.
-static __device__ int choose_lds(Ctx &c, const double *w, int n, double tw, double &rn) {
+// fastChoose over a P-sized f64 array whose serial prefix sums are cached in `cum`
+// (cum[k] == the reference's running `total` at index k, bit for bit).
+static __device__ int choose_prefix(Ctx &c, const double *w, const double *cum, int n, double tw, double &rn) {
     const int lane = c.lane;
     double r = tw * rn;
-    double carry = 0.0;
     for (int base = 0; base < n; base += LANES) {
         int k = base + lane;
-        int nn = min(LANES, n - base);
-        double wk = (k < n) ? w[k] : 0.0;
-        double pre = seq_scan(wk, nn, carry, lane);
+        double pre = (k < n) ? cum[k] : 0.0;
         unsigned long long hit = __ballot((k < n) && !(pre < r));
         if (hit) {
-            int j = __ffsll((long long)hit) - 1;
-            double total = bcast(pre, j), wi = bcast(wk, j);
+            int j = base + __ffsll((long long)hit) - 1;
+            double total = cum[j], wi = w[j];
             if (wi == 0.0) c.error = ERR_ZERO_WEIGHT;
             rn = (r - (total - wi)) / wi;
-            return base + j;
+            return j;
         }
-        carry = bcast(pre, LANES - 1);
     }
-    // ran to the end: the reference loop clamps at n-1 (fast_choose.pxi:26)
-    double wi = w[n - 1];
+    double wi = w[n - 1], total = cum[n - 1];  // clamp at n-1 (fast_choose.pxi:26)
     if (wi == 0.0) c.error = ERR_ZERO_WEIGHT;
-    rn = (r - (carry - wi)) / wi;
+    rn = (r - (total - wi)) / wi;
     return n - 1;
 }
 
 // ------------------------------------------------------------------------------------------------
-// Occupancy list of a population: ordered (hap, class, count) entries.
+// Occupancy list of a population: ordered (hap, class, count) entries in global memory.
 static __device__ __forceinline__ int32_t *LH(Ctx &c, int pi) { return c.lhap + (int64_t)pi * c.cap; }
 static __device__ __forceinline__ int32_t *LC(Ctx &c, int pi) { return c.lcls + (int64_t)pi * c.cap; }
 static __device__ __forceinline__ int64_t *LN(Ctx &c, int pi) { return c.lcnt + (int64_t)pi * c.cap; }
 
-// first index whose haplotype is >= target (n if none); *found tells whether it is the target itself
+static __device__ __forceinline__ void tile_load(Ctx &c, Tile &t, int pi) {
+    t.pi = pi;
+    t.n = c.nocc[pi];
+    t.valid = t.n <= LANES;
+    t.hap = 0; t.cls = 0; t.cnt = 0;
+    if (t.valid && c.lane < t.n) {
+        t.hap = LH(c, pi)[c.lane];
+        t.cls = LC(c, pi)[c.lane];
+        t.cnt = LN(c, pi)[c.lane];
+    }
+}
+
+// first index whose haplotype is >= target (n if none); found tells whether it is the target itself
 static __device__ int list_lower_bound(Ctx &c, int pi, int target, bool &found) {
     const int n = c.nocc[pi];
     const int32_t *lh = LH(c, pi);
@@ -251,14 +251,13 @@ static __device__ void list_add(Ctx &c, int pi, int hap, int64_t delta) {
 // ------------------------------------------------------------------------------------------------
 // BirthRate per class (pyx:382-392): ps += susceptHapPopRate * m * m * cd / as over (sn, pn), in order.
 static __device__ void birth_update(Ctx &c, int pi) {
-    const VgxDevParams &p = *c.p;
     const int P = c.P, S = c.S, lane = c.lane;
-    const double *mrow = p.mig + (int64_t)pi * P;
+    const double *mrow = c.p->mig + (int64_t)pi * P;
     for (int cb = 0; cb < c.CB; ++cb) {
         double ps = 0.0;
         for (int sn = 0; sn < S; ++sn) {
-            double x = (double)c.sus[pi * S + sn] * p.cb_sigma[cb * S + sn];
-            if (lane == 0) c.xC[((int64_t)pi * c.CB + cb) * S + sn] = x;
+            double x = (double)c.sus[pi * S + sn] * c.cb_sigma[cb * S + sn];
+            if (lane == 0) c.xC[(pi * c.CB + cb) * S + sn] = x;
             for (int base = 0; base < P; base += LANES) {
                 int pn = base + lane;
                 double t = 0.0;
@@ -269,27 +268,30 @@ static __device__ void birth_update(Ctx &c, int pi) {
                 ps = seq_sum(t, min(LANES, P - base), ps);
             }
         }
-        if (lane == 0) c.birthC[(int64_t)pi * c.CB + cb] = p.cb_b[cb] * ps;
+        if (lane == 0) c.birthC[pi * c.CB + cb] = c.cb_b[cb] * ps;
     }
     WSYNC();
 }
 
 // tEventHapPopRate per class (pyx:522-526) from the cached birth rates of population pi
 static __device__ void tE_fill(Ctx &c, int pi) {
-    const VgxDevParams &p = *c.p;
-    const double mult = p.sampMult[pi];
+    const double mult = c.sampMult[pi];
     for (int base = 0; base < c.C; base += LANES) {
         int k = base + c.lane;
         if (k < c.C) {
-            double b = c.birthC[(int64_t)pi * c.CB + p.c_bidx[k]];
-            c.tE[k] = ((b + p.c_d[k]) + p.c_s[k] * mult) + p.c_tm[k];
+            double b = c.birthC[pi * c.CB + c.c_bidx[k]];
+            c.tE[k] = ((b + c.c_d[k]) + c.c_s[k] * mult) + c.c_tm[k];
         }
     }
     WSYNC();
 }
 
 // infectPopRate[pi] = sum over occupied haplotypes, in haplotype order, of tEvent * infectious (pyx:519-528)
-static __device__ double row_sum(Ctx &c, int pi) {
+static __device__ double row_sum(Ctx &c, int pi, const Tile &t) {
+    if (t.valid && t.pi == pi) {
+        double w = (c.lane < t.n) ? c.tE[t.cls] * (double)t.cnt : 0.0;
+        return seq_sum(w, t.n, 0.0);
+    }
     const int n = c.nocc[pi];
     const int32_t *lc = LC(c, pi);
     const int64_t *ln = LN(c, pi);
@@ -304,26 +306,26 @@ static __device__ double row_sum(Ctx &c, int pi) {
 }
 
 // fastChoose(hapPopRate[pi], infectPopRate[pi], rn) over the occupied entries; returns the list index
-static __device__ int row_select(Ctx &c, int pi, double tw, double &rn, double &w_sel) {
-    const int n = c.nocc[pi];
+static __device__ int row_select(Ctx &c, int pi, const Tile &t, double tw, double &rn) {
+    const int lane = c.lane;
+    const int n = t.valid ? t.n : c.nocc[pi];
     const int32_t *lc = LC(c, pi);
     const int64_t *ln = LN(c, pi);
-    const int lane = c.lane;
     double r = tw * rn;
     double carry = 0.0;
     for (int base = 0; base < n; base += LANES) {
         int k = base + lane;
         int nn = min(LANES, n - base);
         double w = 0.0;
-        if (k < n) w = c.tE[lc[k]] * (double)ln[k];
-        double pre = seq_scan(w, nn, carry, lane);
+        if (t.valid) w = (k < n) ? c.tE[t.cls] * (double)t.cnt : 0.0;
+        else if (k < n) w = c.tE[lc[k]] * (double)ln[k];
+        double pre = seq_scan(w, nn, carry);
         unsigned long long hit = __ballot((k < n) && !(pre < r));
         if (hit) {
             int j = __ffsll((long long)hit) - 1;
-            double total = bcast(pre, j);
-            w_sel = bcast(w, j);
-            if (w_sel == 0.0) c.error = ERR_ZERO_WEIGHT;
-            rn = (r - (total - w_sel)) / w_sel;
+            double total = bcast(pre, j), wi = bcast(w, j);
+            if (wi == 0.0) c.error = ERR_ZERO_WEIGHT;
+            rn = (r - (total - wi)) / wi;
             return base + j;
         }
         carry = bcast(pre, LANES - 1);
@@ -331,118 +333,134 @@ static __device__ int row_select(Ctx &c, int pi, double tw, double &rn, double &
     // nothing reached r: the dense loop runs on to index H-1 (fast_choose.pxi:26); that is a valid pick
     // only if haplotype H-1 is occupied, otherwise the reference reports a zero weight
     if (n > 0 && LH(c, pi)[n - 1] == c.H - 1) {
-        w_sel = c.tE[lc[n - 1]] * (double)ln[n - 1];
-        rn = (r - (carry - w_sel)) / w_sel;
+        double wi = c.tE[lc[n - 1]] * (double)ln[n - 1];
+        rn = (r - (carry - wi)) / wi;
         return n - 1;
     }
     c.error = ERR_ZERO_WEIGHT;
-    w_sel = 1.0;
     return 0;
 }
 
-// UpdateRates (pyx:516-546)
-static __device__ void update_rates(Ctx &c, int pi, bool infect, bool immune, bool migration) {
+// totalRate and the prefix sums of popRate from population `from` onwards (pyx:537-539)
+static __device__ void refresh_cum(Ctx &c, int from) {
     const int P = c.P, lane = c.lane;
-    if (infect) {
-        birth_update(c, pi);
-        tE_fill(c, pi);
-        double v = row_sum(c, pi);
-        if (lane == 0) c.infectPopRate[pi] = v;
-    }
-    if (immune) {
-        double v = 0.0;
-        for (int sn = 0; sn < c.S; ++sn) v += c.immSrc[pi * c.S + sn];
-        if (lane == 0) c.immunePopRate[pi] = v;
+    int base0 = (from / LANES) * LANES;
+    double carry = (base0 > 0) ? c.cum[base0 - 1] : 0.0;
+    for (int base = base0; base < P; base += LANES) {
+        int pn = base + lane;
+        int k0 = (base == base0) ? ((from - base0) & ~7) : 0;  // first chain step actually executed
+        double w = 0.0;
+        if (pn < P && pn >= base + k0) w = c.popRate[pn];
+        if (base == base0 && k0 > 0) carry = c.cum[base + k0 - 1];
+        double pre = seq_scan(w, min(LANES, P - base), carry, k0);
+        if (pn < P && pn >= base + k0) c.cum[pn] = pre;
+        carry = bcast(pre, LANES - 1);
     }
     WSYNC();
-    if (infect || immune) {
-        if (lane == 0) c.popRate[pi] = c.infectPopRate[pi] + c.immunePopRate[pi];
-        WSYNC();
-        double tr = 0.0;
-        for (int base = 0; base < P; base += LANES) {
-            int pn = base + lane;
-            double w = (pn < P) ? c.popRate[pn] : 0.0;
-            tr = seq_sum(w, min(LANES, P - base), tr);
-        }
-        c.totalRate = tr;
-    }
-    if (migration) {
-        double tm = 0.0;
-        for (int base = 0; base < P; base += LANES) {
-            int pn = base + lane;
-            double w = 0.0;
-            if (pn < P) {
-                w = c.maxEBM[pn] * (double)c.totalSus[pn] * (double)(c.gI - c.totalInf[pn]);
-                c.migPopRate[pn] = w;
-            }
-            tm = seq_sum(w, min(LANES, P - base), tm);
-        }
-        c.totalMig = tm;
-        WSYNC();
-    }
+    c.totalRate = c.cum[P - 1];
 }
 
-// UpdateAllRates (pyx:279-351).  suscepCumulTransition, the migration diagonal, actualSizes and
-// maxEffectiveBirth depend on parameters only and are computed on the host (vgx_api.hip), in the same order.
-static __device__ void update_all_rates(Ctx &c) {
-    const VgxDevParams &p = *c.p;
-    const int P = c.P, S = c.S, lane = c.lane;
-    double tr = 0.0;
-    for (int pn = 0; pn < P; ++pn) {
-        birth_update(c, pn);
-        tE_fill(c, pn);
-        double inf = row_sum(c, pn);
-        double imm = 0.0;
-        for (int sn = 0; sn < S; ++sn) {
-            double v = p.suscepCumul[sn] * (double)c.sus[pn * S + sn];
-            if (lane == 0) c.immSrc[pn * S + sn] = v;
-            imm += v;
-        }
-        double pr = inf + imm;
-        if (lane == 0) { c.infectPopRate[pn] = inf; c.immunePopRate[pn] = imm; c.popRate[pn] = pr; }
-        tr += pr;
+// migPopRate, its prefix sums and totalMigrationRate (pyx:541-546)
+static __device__ void refresh_mig(Ctx &c) {
+    const int P = c.P, lane = c.lane;
+    if (!c.has_mig) {  // every maxEffectiveBirthMigration is +0.0: all products and sums are +0.0
+        for (int pn = lane; pn < P; pn += LANES) { c.migRate[pn] = 0.0; c.cumMig[pn] = 0.0; }
+        c.totalMig = 0.0;
+        WSYNC();
+        return;
     }
-    c.totalRate = tr;
-    WSYNC();
-    // effectiveMigration[pn1, pn2] (pyx:327-338): lane <-> target pn2, serial over sources and the inner sum
-    for (int base = 0; base < P; base += LANES) {
-        int pn2 = base + lane;
-        double mx = 0.0;
-        if (pn2 < P) {
-            const double *m2 = p.mig + (int64_t)pn2 * P;
-            for (int pn1 = 0; pn1 < P; ++pn1) {
-                if (pn1 == pn2) continue;
-                const double *m1 = p.mig + (int64_t)pn1 * P;
-                double e = 0.0;
-                for (int pn3 = 0; pn3 < P; ++pn3) e += m1[pn3] * m2[pn3] * c.cd[pn3] / c.as[pn3];
-                c.effMig[(int64_t)pn1 * P + pn2] = e;
-                if (e > mx) mx = e;
-            }
-            c.maxEBM[pn2] = mx * p.maxEffectiveBirth;
-        }
-    }
-    WSYNC();
-    double tm = 0.0;
+    double carry = 0.0;
     for (int base = 0; base < P; base += LANES) {
         int pn = base + lane;
         double w = 0.0;
         if (pn < P) {
             w = c.maxEBM[pn] * (double)c.totalSus[pn] * (double)(c.gI - c.totalInf[pn]);
-            c.migPopRate[pn] = w;
+            c.migRate[pn] = w;
         }
-        tm = seq_sum(w, min(LANES, P - base), tm);
+        double pre = seq_scan(w, min(LANES, P - base), carry);
+        if (pn < P) c.cumMig[pn] = pre;
+        carry = bcast(pre, LANES - 1);
     }
-    c.totalMig = tm;
+    c.totalMig = carry;
     WSYNC();
 }
 
-static __device__ void add_event(Ctx &c, int type, int hap, int pop, int nh, int np) {  // events.pxi:37-44
+// ------------------------------------------------------------------------------------------------
+// Deferred work of one loop iteration.  Event handlers only change compartments and describe what has to
+// be refreshed; the kernel body then runs the (large) list and rate routines from ONE call site each.
+struct UpdReq {      // UpdateRates(pi, infect, immune, migration) (pyx:516) or, with full, UpdateAllRates (pyx:279)
+    bool any, infect, immune, migration, full;
+    int lo, hi;      // populations [lo, hi)
+};
+struct ListOp { int pi, hap; int64_t delta; };
+struct EvRec { int type, hap, pop, nh, np; };  // type < 0: nothing to log (rejected migration)
+
+// UpdateRates for populations [lo, hi) / UpdateAllRates.  suscepCumulTransition, the migration diagonal,
+// actualSizes and maxEffectiveBirth depend on parameters only and come from the host (vgx_api.hip).
+static __device__ __forceinline__ void update(Ctx &c, const UpdReq &q, const Tile &t) {
+    const VgxDevParams &p = *c.p;
+    const int P = c.P, S = c.S, lane = c.lane;
+    for (int pn = q.lo; pn < q.hi; ++pn) {
+        if (q.infect) {
+            birth_update(c, pn);
+            PROF(8);
+            tE_fill(c, pn);
+            PROF(9);
+            double v = row_sum(c, pn, t);
+            if (lane == 0) c.infect[pn] = v;
+            PROF(10);
+        }
+        if (q.full) {  // pyx:320-323
+            for (int sn = lane; sn < S; sn += LANES) c.immSrc[pn * S + sn] = c.cumul[sn] * (double)c.sus[pn * S + sn];
+            WSYNC();
+        }
+        if (q.immune) {
+            double v = 0.0;
+            for (int sn = 0; sn < S; ++sn) v += c.immSrc[pn * S + sn];
+            if (lane == 0) c.immune[pn] = v;
+        }
+        WSYNC();
+        if (lane == 0) c.popRate[pn] = c.infect[pn] + c.immune[pn];
+    }
+    WSYNC();
+    PROF(11);
+    if (q.infect || q.immune) refresh_cum(c, q.lo);
+    PROF(12);
+    if (q.full) {
+        // effectiveMigration[pn1, pn2] (pyx:327-338): lane <-> target pn2, serial over sources and the inner sum
+        bool any = false;
+        for (int base = 0; base < P; base += LANES) {
+            int pn2 = base + lane;
+            double mx = 0.0;
+            if (pn2 < P) {
+                const double *m2 = p.mig + (int64_t)pn2 * P;
+                for (int pn1 = 0; pn1 < P; ++pn1) {
+                    if (pn1 == pn2) continue;
+                    const double *m1 = p.mig + (int64_t)pn1 * P;
+                    double e = 0.0;
+                    for (int pn3 = 0; pn3 < P; ++pn3) e += m1[pn3] * m2[pn3] * c.cd[pn3] / c.as[pn3];
+                    c.effMig[(int64_t)pn1 * P + pn2] = e;
+                    if (e > mx) mx = e;
+                }
+                c.maxEBM[pn2] = mx * p.maxEffectiveBirth;
+            }
+            any = any || (__ballot(pn2 < P && mx * p.maxEffectiveBirth != 0.0) != 0ull);
+        }
+        c.has_mig = any;
+        WSYNC();
+        PROF(13);
+    }
+    if (q.migration) refresh_mig(c);
+    PROF(14);
+}
+
+static __device__ __forceinline__ void add_event(Ctx &c, const EvRec &e) {  // events.pxi:37-44
     if (c.record_events) {
         int64_t slot = c.ev_ptr - c.ev_base;
         if (slot >= 0 && slot < c.evcap) {
             int lane = c.lane;
             if (lane < 5) {
-                int v = lane == 0 ? type : lane == 1 ? hap : lane == 2 ? pop : lane == 3 ? nh : np;
+                int v = lane == 0 ? e.type : lane == 1 ? e.hap : lane == 2 ? e.pop : lane == 3 ? e.nh : e.np;
                 c.ev_cols[slot * 5 + lane] = v;
             } else if (lane == 5) {
                 c.ev_time[slot] = c.currentTime;
@@ -454,33 +472,37 @@ static __device__ void add_event(Ctx &c, int type, int hap, int pop, int nh, int
     c.ev_ptr += 1;
 }
 
-static __device__ void check_lockdown(Ctx &c, int pi) {  // pyx:698-710
+// CheckLockdown (pyx:698-710) for populations [lo, hi): applies the switches and logs them; returns whether
+// any happened.  UpdateAllRates is a pure function of the state, so running it once after the last switch
+// (the caller does) leaves exactly what the reference's call after every switch leaves.
+static __device__ __forceinline__ bool check_lockdowns(Ctx &c, int lo, int hi) {
     const VgxDevParams &p = *c.p;
-    for (int pass = 0; pass < 2; ++pass) {
-        bool flip;
-        if (pass == 0) flip = ((double)c.totalInf[pi] > p.startLD[pi] * (double)p.sizes[pi]) && c.lockON[pi] == 0;
-        else flip = ((double)c.totalInf[pi] < p.endLD[pi] * (double)p.sizes[pi]) && c.lockON[pi] == 1;
-        if (flip) {
-            WSYNC();
-            if (c.lane == 0) {
-                c.cd[pi] = pass == 0 ? p.cdAfter[pi] : p.cdBefore[pi];
-                c.lockON[pi] = pass == 0 ? 1 : 0;
-            }
-            c.swapLD += 1;
-            WSYNC();
-            update_all_rates(c);
-            if (c.loc_n < VGX_LOC_CAP) {
+    bool any = false;
+    for (int pi = lo; pi < hi; ++pi) {
+        for (int pass = 0; pass < 2; ++pass) {
+            bool flip;
+            if (pass == 0) flip = ((double)c.totalInf[pi] > c.ldStart[pi]) && c.lockON[pi] == 0;
+            else flip = ((double)c.totalInf[pi] < c.ldEnd[pi]) && c.lockON[pi] == 1;
+            if (flip) {
+                WSYNC();
                 if (c.lane == 0) {
-                    c.loc_rec[c.loc_n * 2 + 0] = pass == 0 ? 1 : 0;
-                    c.loc_rec[c.loc_n * 2 + 1] = pi;
-                    c.loc_time[c.loc_n] = c.currentTime;
+                    c.cd[pi] = pass == 0 ? p.cdAfter[pi] : p.cdBefore[pi];
+                    c.lockON[pi] = pass == 0 ? 1 : 0;
+                    if (c.loc_n < VGX_LOC_CAP) {
+                        c.loc_rec[c.loc_n * 2 + 0] = pass == 0 ? 1 : 0;
+                        c.loc_rec[c.loc_n * 2 + 1] = pi;
+                        c.loc_time[c.loc_n] = c.currentTime;
+                    }
                 }
-            } else {
-                c.error = ERR_CAPACITY;
+                if (c.loc_n >= VGX_LOC_CAP) c.error = ERR_CAPACITY;
+                c.swapLD += 1;
+                c.loc_n += 1;
+                any = true;
+                WSYNC();
             }
-            c.loc_n += 1;
         }
     }
+    return any;
 }
 
 static __device__ __forceinline__ int mutate(const Ctx &c, int hi, int s, int DS) {  // pyx:2420-2427
@@ -490,19 +512,19 @@ static __device__ __forceinline__ int mutate(const Ctx &c, int hi, int s, int DS
     return hi + (DS - AS) * digit4;
 }
 
-// NewInfections / NewRecoveries on the population counters (pyx:246-260); the list is updated by the caller
-static __device__ __forceinline__ void counters_infect(Ctx &c, int pi, int si, int64_t num) {
+// NewInfections on the population counters (pyx:246-251); the list is updated by the caller
+static __device__ __forceinline__ void counters_infect(Ctx &c, int pi, int si) {
     if (c.lane == 0) {
-        c.sus[pi * c.S + si] -= num;
-        c.totalSus[pi] -= num;
-        c.totalInf[pi] += num;
+        c.sus[pi * c.S + si] -= 1;
+        c.totalSus[pi] -= 1;
+        c.totalInf[pi] += 1;
     }
-    c.gI += num;
+    c.gI += 1;
     WSYNC();
 }
 
 // summary trajectories: emit the state for every grid point passed by the time step (state before the event)
-static __device__ void traj_emit(Ctx &c, double t_new, bool final_fill) {
+static __device__ __forceinline__ void traj_emit(Ctx &c, double t_new, bool final_fill) {
     while (c.traj_next < c.traj_points) {
         double tg = c.traj_t0 + (double)c.traj_next * c.traj_dt;
         if (!final_fill && !(tg < t_new)) break;
@@ -519,194 +541,187 @@ static __device__ void traj_emit(Ctx &c, double t_new, bool final_fill) {
 }
 
 // ------------------------------------------------------------------------------------------------
-static __device__ void immunity_transition(Ctx &c, int pi) {  // pyx:550-564
-    const VgxDevParams &p = *c.p;
-    const int S = c.S;
-    int ssi = choose_serial(c, [&](int i) { return c.immSrc[pi * S + i]; }, S, c.immunePopRate[pi], c.rn);
-    int tsi = choose_serial(c, [&](int i) { return p.suscepTransition[ssi * S + i]; }, S, p.suscepCumul[ssi], c.rn);
-    WSYNC();
-    if (c.lane == 0) {
-        c.sus[pi * S + ssi] -= 1;
-        c.sus[pi * S + tsi] += 1;
-        c.immSrc[pi * S + ssi] = (double)c.sus[pi * S + ssi] * p.suscepCumul[ssi];
-        c.immSrc[pi * S + tsi] = (double)c.sus[pi * S + tsi] * p.suscepCumul[tsi];
-    }
-    WSYNC();
-    update_rates(c, pi, false, true, false);
-    c.iC += 1;
-    add_event(c, EV_SUSCCHANGE, ssi, pi, tsi, 0);
-}
-
-static __device__ void birth(Ctx &c, int pi, int k, int hi, int cb) {  // pyx:568-605 (recombination off)
-    const VgxDevParams &p = *c.p;
-    const int S = c.S;
-    const double *x = c.xC + ((int64_t)pi * c.CB + cb) * S;
-    double ws = 0.0;
-    for (int sn = 0; sn < S; ++sn) ws += x[sn];
-    int si = choose_serial(c, [&](int i) { return x[i]; }, S, ws, c.rn);
-    counters_infect(c, pi, si, 1);
-    if (c.lane == 0) LN(c, pi)[k] += 1;
-    add_event(c, EV_BIRTH, hi, pi, si, c.H);
-    if (c.lane == 0) c.immSrc[pi * S + si] = p.suscepCumul[si] * (double)c.sus[pi * S + si];
-    WSYNC();
-    update_rates(c, pi, true, true, true);
-    c.bC += 1;
-}
-
-static __device__ void death(Ctx &c, int pi, int k, int hi, bool sampling) {  // pyx:616-635
-    const VgxDevParams &p = *c.p;
-    const int S = c.S;
-    int st = (int)p.suscType[hi];
-    if (c.lane == 0) {
-        c.sus[pi * S + st] += 1;
-        c.totalSus[pi] += 1;
-        c.totalInf[pi] -= 1;
-    }
-    c.gI -= 1;
-    int64_t left = LN(c, pi)[k] - 1;
-    if (left == 0) {
-        list_remove_at(c, pi, k);
-    } else {
-        if (c.lane == 0) LN(c, pi)[k] = left;
-    }
-    WSYNC();
-    if (c.lane == 0) c.immSrc[pi * S + st] = (double)c.sus[pi * S + st] * p.suscepCumul[st];
-    WSYNC();
-    update_rates(c, pi, true, true, true);
-    if (sampling) {
-        c.sC += 1;
-        add_event(c, EV_SAMPLING, hi, pi, st, 0);
-    } else {
-        c.dC += 1;
-        add_event(c, EV_DEATH, hi, pi, st, 0);
-    }
-}
-
-static __device__ void mutation(Ctx &c, int pi, int k, int hi, int cls) {  // pyx:640-667
-    const VgxDevParams &p = *c.p;
-    const int sites = c.sites;
-    const double *mr = p.mRate + (int64_t)hi * sites;
-    int mi = choose_serial(c, [&](int i) { return mr[i]; }, sites, p.c_tm[cls], c.rn);
-    const double *hm = p.hapMutType + ((int64_t)hi * sites + mi) * 3;
-    int DS = choose_serial(c, [&](int i) { return hm[i]; }, 3, hm[0] + hm[1] + hm[2], c.rn);
-    int nhi = mutate(c, hi, mi, DS);
-    list_add(c, pi, nhi, +1);
-    if (c.error) return;
-    list_add(c, pi, hi, -1);
-    update_rates(c, pi, true, false, false);
-    c.mC += 1;
-    add_event(c, EV_MUTATION, hi, pi, nhi, 0);
-}
-
-static __device__ int generate_migration(Ctx &c) {  // pyx:672-694
+// One GenerateEvent (pyx:483-512): selects and applies the event, fills the deferred work.
+static __device__ __forceinline__ int generate_event(Ctx &c, double u, Tile &t, UpdReq &q, ListOp &op0, ListOp &op1,
+                                                     int &n_ops, EvRec &ev) {
     const VgxDevParams &p = *c.p;
     const int P = c.P, S = c.S, lane = c.lane;
-    int tpi = choose_lds(c, c.migPopRate, P, c.totalMig, c.rn);
-    // fastChoose_skip(totalInfectious, globalInfectious - totalInfectious[tpi], rn, skip=tpi), fast_choose.pxi:36-52
-    int spi;
-    {
-        double r = (double)(c.gI - c.totalInf[tpi]) * c.rn;
-        int start = (tpi == 0) ? 1 : 0;
-        int64_t carry = 0;
-        spi = -1;
-        int64_t total = 0;
-        for (int base = 0; base < P && spi < 0; base += LANES) {
-            int k = base + lane;
-            int64_t w = (k < P && k != tpi && k >= start) ? c.totalInf[k] : 0;
-            int64_t pre = iscan(w, lane) + carry;
-            unsigned long long hit = __ballot(k < P && k != tpi && k >= start && !((double)pre < r));
-            if (hit) {
-                int j = __ffsll((long long)hit) - 1;
-                spi = base + j;
-                total = bcast_i64(pre, j);
-            }
-            carry = bcast_i64(pre, LANES - 1);
-        }
-        if (spi < 0) { spi = P - 1; total = carry; }  // clamp at n-1 (may equal skip only then)
-        if (start >= P) { spi = P - 1; total = 0; }
-        int64_t wi = c.totalInf[spi];
-        if (wi == 0) c.error = ERR_ZERO_WEIGHT;
-        c.rn = (r - (double)(total - wi)) / (double)wi;
-    }
-    // fastChoose(infectious[spi], totalInfectious[spi], rn): int64 weights over the occupancy list
-    int hi;
-    {
-        const int n = c.nocc[spi];
-        const int64_t *ln = LN(c, spi);
-        double r = (double)c.totalInf[spi] * c.rn;
-        int64_t carry = 0, total = 0, wi = 0;
-        int kk = -1;
-        for (int base = 0; base < n && kk < 0; base += LANES) {
-            int k = base + lane;
-            int64_t w = (k < n) ? ln[k] : 0;
-            int64_t pre = iscan(w, lane) + carry;
-            unsigned long long hit = __ballot(k < n && !((double)pre < r));
-            if (hit) {
-                int j = __ffsll((long long)hit) - 1;
-                kk = base + j;
-                total = bcast_i64(pre, j);
-                wi = bcast_i64(w, j);
-            }
-            carry = bcast_i64(pre, LANES - 1);
-        }
-        if (kk < 0) {
-            if (n > 0 && LH(c, spi)[n - 1] == c.H - 1) { kk = n - 1; total = carry; wi = ln[n - 1]; }
-            else { c.error = ERR_ZERO_WEIGHT; return tpi; }
-        }
-        hi = LH(c, spi)[kk];
-        c.rn = (r - (double)(total - wi)) / (double)wi;
-    }
-    int si = choose_serial_i64(c, [&](int i) { return c.sus[tpi * S + i]; }, S, c.totalSus[tpi], c.rn);
-    double p_accept = c.effMig[(int64_t)spi * P + tpi] * p.bRate[hi] * p.susc[(int64_t)hi * S + si] / c.maxEBM[tpi];
-    if (c.rn < p_accept) {
-        counters_infect(c, tpi, si, 1);
-        list_add(c, tpi, hi, +1);
-        update_rates(c, tpi, true, true, true);
-        c.migPlus += 1;
-        add_event(c, EV_MIGRATION, hi, spi, si, tpi);
-    } else {
-        c.migNon += 1;
-    }
-    return tpi;
-}
-
-static __device__ int generate_event(Ctx &c, double u) {  // pyx:483-512
-    const VgxDevParams &p = *c.p;
     int pi;
     c.rn = u;
     double choose = c.rn * (c.totalRate + c.totalMig);
     if (c.totalRate > choose) {
         c.rn = choose / c.totalRate;
-        pi = choose_lds(c, c.popRate, c.P, c.totalRate, c.rn);
+        pi = choose_prefix(c, c.popRate, c.cum, P, c.totalRate, c.rn);
         choose = c.rn * c.popRate[pi];
-        if (c.immunePopRate[pi] > choose) {
-            c.rn = choose / c.immunePopRate[pi];
-            immunity_transition(c, pi);
+        q.lo = pi; q.hi = pi + 1; q.any = true;
+        PROF(2);
+        if (c.immune[pi] > choose) {
+            // ---- ImmunityTransition (pyx:550-564) ----
+            c.rn = choose / c.immune[pi];
+            int ssi = choose_serial(c, [&](int i) { return c.immSrc[pi * S + i]; }, S, c.immune[pi], c.rn);
+            int tsi = choose_serial(c, [&](int i) { return c.trans[ssi * S + i]; }, S, c.cumul[ssi], c.rn);
+            WSYNC();
+            if (lane == 0) {
+                c.sus[pi * S + ssi] -= 1;
+                c.sus[pi * S + tsi] += 1;
+                c.immSrc[pi * S + ssi] = (double)c.sus[pi * S + ssi] * c.cumul[ssi];
+                c.immSrc[pi * S + tsi] = (double)c.sus[pi * S + tsi] * c.cumul[tsi];
+            }
+            WSYNC();
+            q.immune = true;
+            c.iC += 1;
+            ev.type = EV_SUSCCHANGE; ev.hap = ssi; ev.pop = pi; ev.nh = tsi; ev.np = 0;
         } else {
-            c.rn = (choose - c.immunePopRate[pi]) / c.infectPopRate[pi];
+            c.rn = (choose - c.immune[pi]) / c.infect[pi];
+            tile_load(c, t, pi);
             tE_fill(c, pi);  // from the cached per-class birth rates: the same values UpdateRates stored
-            double w_sel;
-            int k = row_select(c, pi, c.infectPopRate[pi], c.rn, w_sel);
+            PROF(3);
+            int k = row_select(c, pi, t, c.infect[pi], c.rn);
+            PROF(4);
             if (c.error) return pi;
-            int hi = LH(c, pi)[k];
-            int cls = LC(c, pi)[k];
-            int cb = p.c_bidx[cls];
-            double e0 = c.birthC[(int64_t)pi * c.CB + cb], e1 = p.c_d[cls], e2 = p.c_s[cls] * p.sampMult[pi], e3 = p.c_tm[cls];
+            int hi, cls;
+            if (t.valid) { hi = __builtin_amdgcn_readlane(t.hap, k); cls = __builtin_amdgcn_readlane(t.cls, k); }
+            else { hi = LH(c, pi)[k]; cls = LC(c, pi)[k]; }
+            int cb = c.c_bidx[cls];
+            double e0 = c.birthC[pi * c.CB + cb], e1 = c.c_d[cls], e2 = c.c_s[cls] * c.sampMult[pi], e3 = c.c_tm[cls];
             double tEv = c.tE[cls];
             int ei = choose_serial(c, [&](int i) { return i == 0 ? e0 : i == 1 ? e1 : i == 2 ? e2 : e3; }, 4, tEv, c.rn);
-            if (ei == 0) birth(c, pi, k, hi, cb);
-            else if (ei == 1) death(c, pi, k, hi, false);
-            else if (ei == 2) death(c, pi, k, hi, true);
-            else mutation(c, pi, k, hi, cls);
+            q.infect = true;
+            if (ei == 0) {
+                // ---- Birth (pyx:568-605, recombination off) ----
+                const double *x = c.xC + (pi * c.CB + cb) * S;
+                double ws = 0.0;
+                for (int sn = 0; sn < S; ++sn) ws += x[sn];
+                int si = choose_serial(c, [&](int i) { return x[i]; }, S, ws, c.rn);
+                counters_infect(c, pi, si);
+                if (t.valid) {
+                    if (lane == k) { t.cnt += 1; LN(c, pi)[k] = t.cnt; }
+                } else if (lane == 0) {
+                    LN(c, pi)[k] += 1;
+                }
+                if (lane == 0) c.immSrc[pi * S + si] = c.cumul[si] * (double)c.sus[pi * S + si];
+                WSYNC();
+                q.immune = true; q.migration = true;
+                c.bC += 1;
+                ev.type = EV_BIRTH; ev.hap = hi; ev.pop = pi; ev.nh = si; ev.np = c.H;
+            } else if (ei == 1 || ei == 2) {
+                // ---- Death / Sampling (pyx:616-635) ----
+                int st = c.c_stype[cls];
+                if (lane == 0) {
+                    c.sus[pi * S + st] += 1;
+                    c.totalSus[pi] += 1;
+                    c.totalInf[pi] -= 1;
+                }
+                c.gI -= 1;
+                int64_t left = (t.valid ? bcast_i64(t.cnt, k) : LN(c, pi)[k]) - 1;
+                if (left == 0) {
+                    op0.pi = pi; op0.hap = hi; op0.delta = -1; n_ops = 1;
+                    t.valid = false;
+                } else if (t.valid) {
+                    if (lane == k) { t.cnt = left; LN(c, pi)[k] = left; }
+                } else if (lane == 0) {
+                    LN(c, pi)[k] = left;
+                }
+                WSYNC();
+                if (lane == 0) c.immSrc[pi * S + st] = (double)c.sus[pi * S + st] * c.cumul[st];
+                WSYNC();
+                q.immune = true; q.migration = true;
+                if (ei == 2) { c.sC += 1; ev.type = EV_SAMPLING; } else { c.dC += 1; ev.type = EV_DEATH; }
+                ev.hap = hi; ev.pop = pi; ev.nh = st; ev.np = 0;
+            } else {
+                // ---- Mutation (pyx:640-667) ----
+                const int sites = c.sites;
+                const double *mr = p.mRate + (int64_t)hi * sites;
+                int mi = choose_serial(c, [&](int i) { return mr[i]; }, sites, c.c_tm[cls], c.rn);
+                const double *hm = p.hapMutType + ((int64_t)hi * sites + mi) * 3;
+                int DS = choose_serial(c, [&](int i) { return hm[i]; }, 3, hm[0] + hm[1] + hm[2], c.rn);
+                int nhi = mutate(c, hi, mi, DS);
+                t.valid = false;
+                op0.pi = pi; op0.hap = nhi; op0.delta = +1;
+                op1.pi = pi; op1.hap = hi; op1.delta = -1;
+                n_ops = 2;
+                c.mC += 1;
+                ev.type = EV_MUTATION; ev.hap = hi; ev.pop = pi; ev.nh = nhi; ev.np = 0;
+            }
         }
     } else {
+        // ---- GenerateMigration (pyx:672-694) ----
         c.rn = (choose - c.totalRate) / c.totalMig;
-        pi = generate_migration(c);
+        int tpi = choose_prefix(c, c.migRate, c.cumMig, P, c.totalMig, c.rn);
+        pi = tpi;
+        // fastChoose_skip(totalInfectious, globalInfectious - totalInfectious[tpi], rn, skip=tpi), fast_choose.pxi:36-52
+        int spi;
+        {
+            double r = (double)(c.gI - c.totalInf[tpi]) * c.rn;
+            int start = (tpi == 0) ? 1 : 0;
+            int64_t carry = 0;
+            spi = -1;
+            int64_t total = 0;
+            for (int base = 0; base < P && spi < 0; base += LANES) {
+                int k = base + lane;
+                int64_t w = (k < P && k != tpi && k >= start) ? c.totalInf[k] : 0;
+                int64_t pre = iscan(w, lane) + carry;
+                unsigned long long hit = __ballot(k < P && k != tpi && k >= start && !((double)pre < r));
+                if (hit) {
+                    int j = __ffsll((long long)hit) - 1;
+                    spi = base + j;
+                    total = bcast_i64(pre, j);
+                }
+                carry = bcast_i64(pre, LANES - 1);
+            }
+            if (spi < 0) { spi = P - 1; total = carry; }  // clamp at n-1 (may equal skip only then)
+            int64_t wi = c.totalInf[spi];
+            if (wi == 0) c.error = ERR_ZERO_WEIGHT;
+            c.rn = (r - (double)(total - wi)) / (double)wi;
+        }
+        // fastChoose(infectious[spi], totalInfectious[spi], rn): int64 weights over the occupancy list
+        int hi = 0;
+        {
+            const int n = c.nocc[spi];
+            const int64_t *ln = LN(c, spi);
+            double r = (double)c.totalInf[spi] * c.rn;
+            int64_t carry = 0, total = 0, wi = 1;
+            int kk = -1;
+            for (int base = 0; base < n && kk < 0; base += LANES) {
+                int k = base + lane;
+                int64_t w = (k < n) ? ln[k] : 0;
+                int64_t pre = iscan(w, lane) + carry;
+                unsigned long long hit = __ballot(k < n && !((double)pre < r));
+                if (hit) {
+                    int j = __ffsll((long long)hit) - 1;
+                    kk = base + j;
+                    total = bcast_i64(pre, j);
+                    wi = bcast_i64(w, j);
+                }
+                carry = bcast_i64(pre, LANES - 1);
+            }
+            if (kk < 0) {
+                if (n > 0 && LH(c, spi)[n - 1] == c.H - 1) { kk = n - 1; total = carry; wi = ln[n - 1]; }
+                else { c.error = ERR_ZERO_WEIGHT; kk = 0; }
+            }
+            if (!c.error) hi = LH(c, spi)[kk];
+            c.rn = (r - (double)(total - wi)) / (double)wi;
+        }
+        if (c.error) return pi;
+        int si = choose_serial_i64(c, [&](int i) { return c.sus[tpi * S + i]; }, S, c.totalSus[tpi], c.rn);
+        double p_accept = c.effMig[(int64_t)spi * P + tpi] * p.bRate[hi] * p.susc[(int64_t)hi * S + si] / c.maxEBM[tpi];
+        if (c.rn < p_accept) {
+            counters_infect(c, tpi, si);
+            op0.pi = tpi; op0.hap = hi; op0.delta = +1; n_ops = 1;
+            q.any = true; q.lo = tpi; q.hi = tpi + 1; q.infect = true; q.immune = true; q.migration = true;
+            c.migPlus += 1;
+            ev.type = EV_MIGRATION; ev.hap = hi; ev.pop = spi; ev.nh = si; ev.np = tpi;
+        } else {
+            c.migNon += 1;
+        }
     }
+    PROF(5);
     return pi;
 }
 
-static __device__ void restart(Ctx &c, const VgxDevRep &r) {  // pyx:714-738
+// Restart (pyx:714-738): compartments back to the initial snapshot; the caller re-checks lockdowns and
+// rebuilds all rates.
+static __device__ __forceinline__ void restart_state(Ctx &c, const VgxDevRep &r) {
     const int P = c.P, S = c.S, lane = c.lane;
     c.ev_ptr = 0;
     c.bC = c.dC = c.sC = c.mC = c.iC = 0;
@@ -739,8 +754,6 @@ static __device__ void restart(Ctx &c, const VgxDevRep &r) {  // pyx:714-738
     }
     c.gI = g;
     WSYNC();
-    for (int pn = 0; pn < P; ++pn) check_lockdown(c, pn);
-    update_all_rates(c);
 }
 
 extern "C" __global__ void __launch_bounds__(LANES) vgx_direct_kernel(VgxDirectArgs a) {
@@ -749,50 +762,62 @@ extern "C" __global__ void __launch_bounds__(LANES) vgx_direct_kernel(VgxDirectA
     const int lane = threadIdx.x;
     const VgxDevParams &p = a.p;
     const VgxDevRep &r = a.r;
-    const int P = p.P, S = p.S;
+    const int P = p.P, S = p.S, C = p.C, CB = p.CB;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     Ctx c;
-    c.P = P; c.S = S; c.H = p.H; c.C = p.C; c.CB = p.CB; c.sites = p.sites; c.lane = lane;
+    c.P = P; c.S = S; c.H = p.H; c.C = C; c.CB = CB; c.sites = p.sites; c.lane = lane;
     c.p = &a.p;
+    // LDS carve: keep in step with vgxi_direct_lds_bytes()
     double *ld = (double *)smem;
-    c.popRate = ld; ld += P;
-    c.infectPopRate = ld; ld += P;
-    c.immunePopRate = ld; ld += P;
-    c.migPopRate = ld; ld += P;
-    c.maxEBM = ld; ld += P;
-    c.cd = ld; ld += P;
-    c.as = ld; ld += P;
+    c.popRate = ld; ld += P;   c.infect = ld; ld += P;   c.immune = ld; ld += P;   c.migRate = ld; ld += P;
+    c.maxEBM = ld; ld += P;    c.cd = ld; ld += P;       c.as = ld; ld += P;       c.cum = ld; ld += P;
+    c.cumMig = ld; ld += P;    c.sampMult = ld; ld += P; c.ldStart = ld; ld += P;  c.ldEnd = ld; ld += P;
     c.immSrc = ld; ld += P * S;
-    c.tE = ld; ld += p.C;
+    c.birthC = ld; ld += P * CB;
+    c.xC = ld; ld += P * CB * S;
+    c.tE = ld; ld += C;   c.c_d = ld; ld += C;   c.c_s = ld; ld += C;   c.c_tm = ld; ld += C;
+    c.cb_b = ld; ld += CB;
+    c.cb_sigma = ld; ld += CB * S;
+    c.cumul = ld; ld += S;
+    c.trans = ld; ld += S * S;
     int64_t *li = (int64_t *)ld;
-    c.totalSus = li; li += P;
-    c.totalInf = li; li += P;
-    c.lockON = li; li += P;
+    c.totalSus = li; li += P;   c.totalInf = li; li += P;   c.lockON = li; li += P;
     c.sus = li; li += P * S;
+    int32_t *l4 = (int32_t *)li;
+    c.nocc = l4; l4 += P;
+    c.c_bidx = l4; l4 += C;
+    c.c_stype = l4; l4 += C;
 
     double *gD = r.popD + (int64_t)rep * PD_COUNT * P;
     int64_t *gI = r.popI + (int64_t)rep * PI_COUNT * P;
+    int32_t *gN = r.nocc + (int64_t)rep * P;
     for (int pn = lane; pn < P; pn += LANES) {
-        c.popRate[pn] = gD[PD_POPRATE * P + pn];
-        c.infectPopRate[pn] = gD[PD_INFECT * P + pn];
-        c.immunePopRate[pn] = gD[PD_IMMUNE * P + pn];
-        c.migPopRate[pn] = gD[PD_MIG * P + pn];
-        c.maxEBM[pn] = gD[PD_MAXEBM * P + pn];
+        c.popRate[pn] = 0.0; c.infect[pn] = 0.0; c.immune[pn] = 0.0; c.migRate[pn] = 0.0; c.maxEBM[pn] = 0.0;
+        c.cum[pn] = 0.0; c.cumMig[pn] = 0.0;
         c.cd[pn] = gD[PD_CD * P + pn];
         c.as[pn] = p.actualSizes[pn];
+        c.sampMult[pn] = p.sampMult[pn];
+        c.ldStart[pn] = p.startLD[pn] * (double)p.sizes[pn];
+        c.ldEnd[pn] = p.endLD[pn] * (double)p.sizes[pn];
         c.totalSus[pn] = gI[PI_TOTSUS * P + pn];
         c.totalInf[pn] = gI[PI_TOTINF * P + pn];
         c.lockON[pn] = gI[PI_LOCK * P + pn];
+        c.nocc[pn] = gN[pn];
     }
-    for (int i = lane; i < P * S; i += LANES) {
-        c.sus[i] = r.sus[(int64_t)rep * P * S + i];
-        c.immSrc[i] = r.immSrc[(int64_t)rep * P * S + i];
+    for (int i = lane; i < P * S; i += LANES) { c.sus[i] = r.sus[(int64_t)rep * P * S + i]; c.immSrc[i] = 0.0; }
+    for (int i = lane; i < P * CB; i += LANES) c.birthC[i] = 0.0;
+    for (int i = lane; i < P * CB * S; i += LANES) c.xC[i] = 0.0;
+    for (int i = lane; i < C; i += LANES) {
+        c.tE[i] = 0.0; c.c_d[i] = p.c_d[i]; c.c_s[i] = p.c_s[i]; c.c_tm[i] = p.c_tm[i];
+        c.c_bidx[i] = p.c_bidx[i]; c.c_stype[i] = p.c_stype[i];
     }
-    c.birthC = r.birthC + (int64_t)rep * P * p.CB;
-    c.xC = r.xC + (int64_t)rep * P * p.CB * S;
+    for (int i = lane; i < CB; i += LANES) c.cb_b[i] = p.cb_b[i];
+    for (int i = lane; i < CB * S; i += LANES) c.cb_sigma[i] = p.cb_sigma[i];
+    for (int i = lane; i < S; i += LANES) c.cumul[i] = p.suscepCumul[i];
+    for (int i = lane; i < S * S; i += LANES) c.trans[i] = p.suscepTransition[i];
+
     c.effMig = r.effMig + (int64_t)rep * P * P;
-    c.nocc = r.nocc + (int64_t)rep * P;
     c.cap = r.cap;
     c.lhap = r.lhap + (int64_t)rep * P * r.cap;
     c.lcls = r.lcls + (int64_t)rep * P * r.cap;
@@ -812,43 +837,104 @@ extern "C" __global__ void __launch_bounds__(LANES) vgx_direct_kernel(VgxDirectA
     c.swapLD = sc->swapLockdown; c.migPlus = sc->migPlus; c.migNon = sc->migNonPlus;
     c.ev_ptr = sc->ev_ptr; c.ev_size = a.ev_size; c.loc_n = 0; c.error = 0;
     c.traj_next = 0;
+    c.has_mig = true;
     WSYNC();
-
-    // PrepareParameters tail (pyx:449-451); FirstInfection and the initial snapshot were done by the host
-    for (int pn = 0; pn < P; ++pn) check_lockdown(c, pn);
-    update_all_rates(c);
 
     const double tlimit = (double)a.time;
     const bool has_tlimit = !(a.time == -1.0f);
     const int64_t seed = r.seeds[rep];
     int64_t loops = 0, restarts = 0, good_attempt = sc->good_attempt;
-    for (int64_t att = 0; att < a.attempts; ++att) {  // pyx:402-418
-        VgxPcg64 g;
-        vgx_pcg64_seed(g, (uint64_t)seed, (uint32_t)att);
-        if (c.totalRate + c.totalMig != 0.0 && c.gI != 0) {
-            while (c.ev_ptr < c.ev_size && (a.sample_size == -1 || c.sC <= a.sample_size) &&
-                   (!has_tlimit || c.currentTime < tlimit)) {
-                if (loops >= a.max_loop) { c.error = ERR_LOOP_GUARD; break; }
+    int64_t att = 0;
+    VgxPcg64 g;
+    g.sh = g.sl = g.ih = g.il = 0;
+
+    // The reference's control flow (pyx:399-418) as one loop with one call site per large routine:
+    //   rebuild : [CheckLockdown for all populations] + UpdateAllRates   (PrepareParameters tail, Restart tail)
+    //   event   : SampleTime, GenerateEvent -> list ops -> UpdateRates -> extinction test -> CheckLockdown(pi)
+    //             -> UpdateAllRates if a lockdown switched
+    bool rebuild = true;       // start of the call / after a Restart
+    bool attempt_open = false; // RNG seeded and first-iteration guard (pyx:404) passed for attempt `att`
+    bool finished = false;
+#ifdef VGX_PROFILE
+    for (int i = 0; i < VGX_PROF_SLOTS; ++i) c.prof_acc[i] = 0;
+    c.prof_t0 = __builtin_readcyclecounter();
+#endif
+    while (!finished && !c.error) {
+        PROF(0);
+        Tile t;
+        t.valid = false; t.pi = -1; t.n = 0; t.hap = 0; t.cls = 0; t.cnt = 0;
+        UpdReq q;
+        q.any = false; q.infect = false; q.immune = false; q.migration = false; q.full = false; q.lo = 0; q.hi = 0;
+        ListOp op0, op1;
+        op0.pi = 0; op0.hap = 0; op0.delta = 0; op1 = op0;
+        int n_ops = 0;
+        EvRec ev;
+        ev.type = -1; ev.hap = 0; ev.pop = 0; ev.nh = 0; ev.np = 0;
+        int lk_lo = 0, lk_hi = 0;
+        bool end_attempt = false;
+
+        if (rebuild) {
+            lk_lo = 0; lk_hi = P;
+        } else {
+            if (!attempt_open) {
+                if (att >= a.attempts) { finished = true; continue; }
+                vgx_pcg64_seed(g, (uint64_t)seed, (uint32_t)att);
+                attempt_open = true;
+                if (!(c.totalRate + c.totalMig != 0.0 && c.gI != 0)) end_attempt = true;  // pyx:404
+            }
+            if (!end_attempt && !(c.ev_ptr < c.ev_size && (a.sample_size == -1 || c.sC <= a.sample_size) &&
+                                  (!has_tlimit || c.currentTime < tlimit)))
+                end_attempt = true;  // pyx:405-407
+            if (!end_attempt) {
+                if (loops >= a.max_loop) { c.error = ERR_LOOP_GUARD; continue; }
                 loops += 1;
                 double u1 = vgx_pcg64_double(g);
                 double t_new = c.currentTime + (-vgx_log(u1) / (c.totalRate + c.totalMig));  // SampleTime pyx:476-478
                 if (c.traj) traj_emit(c, t_new, false);
                 c.currentTime = t_new;
                 double u2 = vgx_pcg64_double(g);
-                int pi = generate_event(c, u2);
-                if (c.error) break;
-                if (c.totalRate == 0.0 || c.gI == 0) break;
-                check_lockdown(c, pi);
-                if (c.error) break;
+                PROF(1);
+                int pi = generate_event(c, u2, t, q, op0, op1, n_ops, ev);
+                if (c.error) continue;
+                lk_lo = pi; lk_hi = pi + 1;
             }
         }
-        if (c.error) break;
+
+        if (!end_attempt) {
+            for (int i = 0; i < n_ops; ++i) {  // the one call site of the list routines
+                list_add(c, i == 0 ? op0.pi : op1.pi, i == 0 ? op0.hap : op1.hap, i == 0 ? op0.delta : op1.delta);
+                if (c.error) break;
+            }
+            if (c.error) continue;
+            PROF(6);
+            if (ev.type >= 0) add_event(c, ev);
+            PROF(7);
+            for (int round = 0; round < 2; ++round) {  // the one call site of the rate routines
+                if (round == 1) {
+                    if (!rebuild && (c.totalRate == 0.0 || c.gI == 0)) { end_attempt = true; break; }  // pyx:410-411
+                    bool switched = check_lockdowns(c, lk_lo, lk_hi);  // pyx:412 / pyx:449-450 / pyx:736-737
+                    if (!switched && !rebuild) break;
+                    q.any = true; q.full = true; q.infect = true; q.immune = true; q.migration = true;
+                    q.lo = 0; q.hi = P;
+                    t.valid = false;
+                }
+                if (q.any) update(c, q, t);
+            }
+            PROF(15);
+            rebuild = false;
+            if (!end_attempt) continue;
+        }
+
+        // end of an attempt (pyx:414-418)
+        attempt_open = false;
         if (c.ev_ptr <= 100 && a.iterations > 100) {
-            restart(c, r);
+            restart_state(c, r);
             restarts += 1;
+            att += 1;
+            rebuild = true;  // CheckLockdown for all + UpdateAllRates, also after the last attempt
         } else {
             good_attempt = att + 1;
-            break;
+            finished = true;
         }
     }
     if (c.traj) traj_emit(c, 0.0, true);
@@ -856,19 +942,24 @@ extern "C" __global__ void __launch_bounds__(LANES) vgx_direct_kernel(VgxDirectA
     WSYNC();
     for (int pn = lane; pn < P; pn += LANES) {
         gD[PD_POPRATE * P + pn] = c.popRate[pn];
-        gD[PD_INFECT * P + pn] = c.infectPopRate[pn];
-        gD[PD_IMMUNE * P + pn] = c.immunePopRate[pn];
-        gD[PD_MIG * P + pn] = c.migPopRate[pn];
+        gD[PD_INFECT * P + pn] = c.infect[pn];
+        gD[PD_IMMUNE * P + pn] = c.immune[pn];
+        gD[PD_MIG * P + pn] = c.migRate[pn];
         gD[PD_MAXEBM * P + pn] = c.maxEBM[pn];
         gD[PD_CD * P + pn] = c.cd[pn];
         gI[PI_TOTSUS * P + pn] = c.totalSus[pn];
         gI[PI_TOTINF * P + pn] = c.totalInf[pn];
         gI[PI_LOCK * P + pn] = c.lockON[pn];
+        gN[pn] = c.nocc[pn];
     }
     for (int i = lane; i < P * S; i += LANES) {
         r.sus[(int64_t)rep * P * S + i] = c.sus[i];
         r.immSrc[(int64_t)rep * P * S + i] = c.immSrc[i];
     }
+#ifdef VGX_PROFILE
+    if (lane == 0 && r.prof)
+        for (int i = 0; i < VGX_PROF_SLOTS; ++i) r.prof[(int64_t)rep * VGX_PROF_SLOTS + i] = c.prof_acc[i];
+#endif
     if (lane == 0) {
         sc->currentTime = c.currentTime; sc->totalRate = c.totalRate; sc->totalMig = c.totalMig;
         sc->globalInfectious = c.gI;
@@ -906,4 +997,30 @@ extern "C" __global__ void __launch_bounds__(LANES) vgx_init_reps_kernel(
         r.popI[(rep * PI_COUNT + PI_LOCK) * P + pn] = s_tot[2 * P + pn];
     }
     for (int i = lane; i < P * S; i += LANES) r.sus[rep * P * S + i] = s_sus[i];
+}
+
+// ---- host-side launchers (this translation unit owns its kernels; no relocatable device code needed) ----
+extern "C" __attribute__((visibility("hidden"))) size_t vgxi_direct_lds_bytes(int P, int S, int C, int CB) {
+    size_t f64 = 12 * (size_t)P + (size_t)P * S + (size_t)P * CB + (size_t)P * CB * S + 4 * (size_t)C + CB +
+                 (size_t)CB * S + S + (size_t)S * S;
+    size_t i64 = 3 * (size_t)P + (size_t)P * S;
+    size_t i32 = (size_t)P + 2 * (size_t)C;
+    return (f64 + i64) * 8 + ((i32 * 4 + 15) / 16) * 16;
+}
+
+extern "C" __attribute__((visibility("hidden"))) hipError_t vgxi_launch_direct(const VgxDirectArgs *a, size_t lds,
+                                                                              hipStream_t stream) {
+    hipError_t err = hipFuncSetAttribute((const void *)vgx_direct_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (err != hipSuccess) return err;
+    hipLaunchKernelGGL(vgx_direct_kernel, dim3((unsigned)a->n_replicates), dim3(LANES), lds, stream, *a);
+    return hipGetLastError();
+}
+
+extern "C" __attribute__((visibility("hidden"))) hipError_t vgxi_launch_init_reps(
+    const VgxDevRep *r, int P, int S, int64_t R, const int32_t *s_nocc, const int32_t *s_hap, const int32_t *s_cls,
+    const int64_t *s_cnt, int64_t s_cap, const int64_t *s_sus, const double *s_cd, const int64_t *s_tot,
+    hipStream_t stream) {
+    hipLaunchKernelGGL(vgx_init_reps_kernel, dim3((unsigned)R), dim3(LANES), 0, stream, *r, P, S, R, s_nocc, s_hap,
+                       s_cls, s_cnt, s_cap, s_sus, s_cd, s_tot);
+    return hipGetLastError();
 }

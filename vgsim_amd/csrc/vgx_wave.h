@@ -1,0 +1,90 @@
+// vgx_wave.h — wavefront-level primitives of the gfx950 kernels (64-lane waves, one wave per workgroup).
+//
+// seq_sum / seq_scan add f64 values held one-per-lane STRICTLY IN LANE ORDER, i.e. with the rounding
+// sequence of the reference's serial loops (fast_choose.pxi:25-28, src/_BirthDeath.pyx:519-528, 537-546).
+// Each step is {v_readlane lo, v_readlane hi, v_add_f64}; the scan additionally narrows EXEC to lanes >= k
+// before the add, so lane L stops accumulating after its own term and ends with the serial prefix
+// w[0]+...+w[L] (no compare/select instructions on the dependent chain).  Two SGPR pairs (vcc and
+// s[10:11]) alternate so that the VALU-writes-SGPR -> VALU-reads-SGPR distance of gfx940+ (2 wait states)
+// is always covered by the next step's lane reads.  The blocks must be reached with all 64 lanes active
+// (wave-uniform control flow); EXEC is restored to all-ones at the end of every block.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define VGX_LANES 64
+
+// compiler-level ordering of cross-lane traffic through LDS / global memory inside one wave; the hardware
+// executes a wave's LDS and vector-memory instructions in issue order.
+#define WSYNC()                                                  \
+    do {                                                         \
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");   \
+        __builtin_amdgcn_wave_barrier();                         \
+    } while (0)
+
+static __device__ __forceinline__ double bcast(double v, int k) {  // value of lane k (k wave-uniform)
+    int lo = __builtin_amdgcn_readlane(__double2loint(v), k);
+    int hi = __builtin_amdgcn_readlane(__double2hiint(v), k);
+    return __hiloint2double(hi, lo);
+}
+static __device__ __forceinline__ int64_t bcast_i64(int64_t v, int k) {
+    int lo = __builtin_amdgcn_readlane((int)(uint32_t)v, k);
+    int hi = __builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)v >> 32), k);
+    return (int64_t)(((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo);
+}
+
+// ---- 8 chain steps per asm block; lanes K = B+0 .. B+7 -------------------------------------------
+#define VGX_RLA(K) "v_readlane_b32 vcc_lo, %1, " K "\n\tv_readlane_b32 vcc_hi, %2, " K "\n\t"
+#define VGX_RLB(K) "v_readlane_b32 s10, %1, " K "\n\tv_readlane_b32 s11, %2, " K "\n\t"
+#define VGX_ADDA "v_add_f64 %0, %0, vcc\n\t"
+#define VGX_ADDB "v_add_f64 %0, %0, s[10:11]\n\t"
+#define VGX_EX(K) "s_lshl_b64 exec, -1, " K "\n\t"
+
+#define VGX_SUM8(B)                                                                                   \
+    "s_nop 1\n\t" VGX_RLA(#B "+0") VGX_RLB(#B "+1") VGX_ADDA VGX_RLA(#B "+2") VGX_ADDB VGX_RLB(#B "+3")  \
+        VGX_ADDA VGX_RLA(#B "+4") VGX_ADDB VGX_RLB(#B "+5") VGX_ADDA VGX_RLA(#B "+6") VGX_ADDB           \
+            VGX_RLB(#B "+7") VGX_ADDA "s_nop 1\n\t" VGX_ADDB
+
+#define VGX_SCAN8(B)                                                                                  \
+    "s_nop 1\n\t" VGX_RLA(#B "+0") VGX_RLB(#B "+1") VGX_EX(#B "+0") VGX_ADDA VGX_RLA(#B "+2")            \
+        VGX_EX(#B "+1") VGX_ADDB VGX_RLB(#B "+3") VGX_EX(#B "+2") VGX_ADDA VGX_RLA(#B "+4")              \
+            VGX_EX(#B "+3") VGX_ADDB VGX_RLB(#B "+5") VGX_EX(#B "+4") VGX_ADDA VGX_RLA(#B "+6")          \
+                VGX_EX(#B "+5") VGX_ADDB VGX_RLB(#B "+7") VGX_EX(#B "+6") VGX_ADDA "s_nop 0\n\t"         \
+                    VGX_EX(#B "+7") VGX_ADDB "s_mov_b64 exec, -1\n\t"
+
+#define VGX_SUM_GROUP(B) \
+    if (n > B) asm volatile(VGX_SUM8(B) : "+v"(acc) : "v"(lo), "v"(hi) : "vcc", "s10", "s11");
+#define VGX_SCAN_GROUP(B) \
+    if (n > B && k0 < B + 8) asm volatile(VGX_SCAN8(B) : "+v"(acc) : "v"(lo), "v"(hi) : "vcc", "scc", "s10", "s11");
+
+// acc + v[0] + v[1] + ... + v[n-1] in lane order.  Lanes >= n MUST hold +0.0 (steps run in groups of 8).
+// Real functions (register arguments only) so that the unrolled chains exist once in the code object.
+static __device__ __forceinline__ double seq_sum(double v, int n, double acc) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    n = __builtin_amdgcn_readfirstlane(n);
+    VGX_SUM_GROUP(0) VGX_SUM_GROUP(8) VGX_SUM_GROUP(16) VGX_SUM_GROUP(24)
+    VGX_SUM_GROUP(32) VGX_SUM_GROUP(40) VGX_SUM_GROUP(48) VGX_SUM_GROUP(56)
+    return acc;
+}
+
+// lane L (k0 <= L < n) gets carry + v[k0'] + ... + v[L] with k0' = k0 rounded down to a multiple of 8:
+// lanes in [k0', k0) and lanes >= n MUST hold +0.0.  Lanes >= n-1 end with the total.
+static __device__ __forceinline__ double seq_scan(double v, int n, double carry, int k0 = 0) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    n = __builtin_amdgcn_readfirstlane(n);
+    k0 = __builtin_amdgcn_readfirstlane(k0);
+    double acc = carry;
+    VGX_SCAN_GROUP(0) VGX_SCAN_GROUP(8) VGX_SCAN_GROUP(16) VGX_SCAN_GROUP(24)
+    VGX_SCAN_GROUP(32) VGX_SCAN_GROUP(40) VGX_SCAN_GROUP(48) VGX_SCAN_GROUP(56)
+    return acc;
+}
+
+// inclusive integer scan across the wave (order-free: int64 addition is associative)
+static __device__ __forceinline__ int64_t iscan(int64_t v, int lane) {
+#pragma unroll
+    for (int d = 1; d < VGX_LANES; d <<= 1) {
+        int64_t o = __shfl_up(v, d);
+        if (lane >= d) v += o;
+    }
+    return v;
+}

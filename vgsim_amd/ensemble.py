@@ -1,0 +1,136 @@
+"""Replicate ensembles: many independent seeded trajectories of one model on one GPU, one GPU per process.
+
+The reference has no notion of an ensemble (users start separate ``Simulator`` processes by hand, SURVEY.md
+§8e); this is the data-parallel axis the engine shards: replicate r of rank k runs on GPU k as its own
+persistent wavefront, nothing is exchanged while simulating, and the only collective is one gather of the
+fixed-shape summary trajectories ``[replicates, points, populations, 2]`` to rank 0 (RCCL over xGMI when the
+process group uses the ``nccl`` backend, gloo on CPU in the tests).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _capi
+
+
+class EnsembleResult:
+    """Per-replicate outcome of one ensemble call (numpy arrays of length n_replicates)."""
+
+    def __init__(self, R):
+        z = lambda: np.zeros(R, dtype=np.int64)  # noqa: E731
+        self.events = z()           # events.ptr
+        self.loop_iterations = z()  # incl. rejected migrations
+        self.restarts = z()
+        self.kernel_ms = 0.0
+
+    @property
+    def total_events(self):
+        return int(self.events.sum())
+
+
+class Ensemble:
+    def __init__(self, simulator, n_replicates, seeds=None, device=0):
+        """``simulator``: a configured ``vgsim_amd.Simulator`` (or its ``.simulation`` model) giving parameters
+        and the common start state; ``seeds``: one user seed per replicate (default seed, seed+1, ...)."""
+        self.model = getattr(simulator, "simulation", simulator)
+        m = self.model
+        m._check_supported()
+        self.R = int(n_replicates)
+        self.engine = _capi.HipEngine(m.sites, m.hapNum, m.popNum, m.susNum, n_replicates=self.R, device=device)
+        self.seeds = np.arange(m.user_seed, m.user_seed + self.R, dtype=np.int64) if seeds is None \
+            else np.ascontiguousarray(seeds, dtype=np.int64)
+        assert self.seeds.shape == (self.R,)
+        self.traj_shape = None
+
+    def close(self):
+        self.engine.close()
+
+    def simulate(self, iterations, sample_size=None, epidemic_time=-1, attempts=200, record_events=False,
+                 traj_points=0, traj_window=(0.0, 1.0), seeds=None):
+        """Direct Gillespie for every replicate from the model's current state (``SimulatePopulation`` semantics
+        per replicate, pyx:396-429).  Returns an :class:`EnsembleResult`."""
+        m, eng = self.model, self.engine
+        if seeds is not None:
+            self.seeds = np.ascontiguousarray(seeds, dtype=np.int64)
+        if sample_size is None:
+            sample_size = iterations
+        if epidemic_time is None:
+            epidemic_time = -1
+        # Events.CreateEvents bookkeeping on a scratch copy of the counters (the host model keeps its own log)
+        ptr, size = m.events.ptr, m.events.size
+        size = size + iterations if ptr == 0 else max(size, ptr + iterations)
+        eng.set_params(m)
+        saved = (m.events.ptr, m.events.size)
+        m.events.size = size
+        try:
+            eng.set_state(m)
+        finally:
+            m.events.ptr, m.events.size = saved
+        eng.set_seeds(self.seeds)
+        o = _capi.VgxRunOpts()
+        o.record_events = 1 if record_events else 0
+        o.traj_points = int(traj_points)
+        o.traj_t0, o.traj_t1 = float(traj_window[0]), float(traj_window[1])
+        rc = eng.lib.vgx_simulate_direct(eng.handle, int(iterations), int(sample_size), float(np.float32(epidemic_time)),
+                                         int(attempts), C.byref(o))
+        eng._check(rc)
+        res = EnsembleResult(self.R)
+        for r in range(self.R):
+            c = eng.counters(r)
+            res.events[r], res.loop_iterations[r], res.restarts[r] = c.ev_ptr, c.loop_iterations, c.restarts
+        res.kernel_ms = eng.last_kernel_ms
+        self.traj_shape = (self.R, int(traj_points), m.popNum, 2) if traj_points > 0 else None
+        return res
+
+    def replicate_state(self, replicate):
+        """A host model object holding the state (compartments, counters, times) of one replicate."""
+        import copy
+        m = copy.copy(self.model)
+        for name in ("susceptible", "infectious", "initial_susceptible", "initial_infectious", "totalSusceptible",
+                     "totalInfectious", "lockdownON", "contactDensity"):
+            setattr(m, name, getattr(self.model, name).copy())
+        self.engine.get_state(m, replicate)
+        return m
+
+    def replicate_events(self, replicate):
+        """(6, n) float64 event chain of one replicate (needs ``record_events=True``)."""
+        from ._model import Events
+        c = self.engine.counters(replicate)
+        ev = Events()
+        ev.CreateEvents(max(int(c.ev_ptr), 1))
+        self.engine.fetch_events(ev, replicate, c.ev_first_new, c.ev_ptr - c.ev_first_new)
+        ev.ptr = c.ev_ptr
+        return ev.as_array()[:, :c.ev_ptr]
+
+    def trajectories(self, out=None):
+        """Summary trajectories of the last call, ``[R, T, P, 2]`` float64 (infectious, susceptible per population).
+        ``out`` may be a CUDA torch tensor (filled on the device, no host round trip) or None (numpy)."""
+        if self.traj_shape is None:
+            raise RuntimeError("the last simulate() call did not record trajectories (traj_points=0)")
+        eng = self.engine
+        if out is None:
+            a = np.empty(self.traj_shape, dtype=np.float64)
+            eng._check(eng.lib.vgx_get_trajectories(eng.handle, a.ctypes.data_as(C.c_void_p), 0))
+            return a
+        assert tuple(out.shape) == self.traj_shape and out.is_contiguous() and str(out.dtype) == "torch.float64"
+        eng._check(eng.lib.vgx_get_trajectories(eng.handle, C.c_void_p(out.data_ptr()), 1 if out.is_cuda else 0))
+        return out
+
+    def gather_trajectories(self, dst=0):
+        """One collective for the whole ensemble: every rank's ``[R, T, P, 2]`` block to rank ``dst``
+        (``torch.distributed.gather``; backend nccl = RCCL over xGMI, gloo on CPU).  Returns the stacked
+        ``[world, R, T, P, 2]`` tensor on ``dst`` and None elsewhere."""
+        import torch
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()):
+            return torch.from_numpy(self.trajectories())[None]
+        backend = dist.get_backend()
+        if backend == "nccl":
+            dev = torch.device("cuda", torch.cuda.current_device())
+            mine = self.trajectories(torch.empty(self.traj_shape, dtype=torch.float64, device=dev))
+        else:
+            mine = torch.from_numpy(self.trajectories())
+        world, rank = dist.get_world_size(), dist.get_rank()
+        bufs = [torch.empty_like(mine) for _ in range(world)] if rank == dst else None
+        dist.gather(mine, bufs, dst=dst)
+        return torch.stack(bufs) if rank == dst else None
