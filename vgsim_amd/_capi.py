@@ -223,14 +223,39 @@ class HipEngine:
         rc = self.lib.vgx_simulate_tau(self.handle, iterations, sample_size, float(time), attempts,
                                        C.byref(opts) if opts is not None else None)
         self._check(rc)
-        self._absorb(m)
+        mev_base = 0 if False else m.multievents.ptr
+        self._absorb(m, tau=True, mev_base=mev_base)
 
-    def _absorb(self, m, replicate=0):
+    def multievents(self, replicate=0):
+        """Rows (num > 0 only) of the last tau call: dict of arrays num, times, types, haplotypes, ..."""
+        n = C.c_int64(0)
+        self._check(self.lib.vgx_get_multievents(self.handle, replicate, 0, None, None, None, None, None, None, None, C.byref(n)))
+        k = n.value
+        cols = {name: np.zeros(k, dtype=np.int64) for name in ("num", "types", "haplotypes", "populations", "newHaplotypes", "newPopulations")}
+        times = np.zeros(k, dtype=np.float64)
+        if k:
+            self._check(self.lib.vgx_get_multievents(self.handle, replicate, k, _p(cols["num"]), _p(times), _p(cols["types"]),
+                                                     _p(cols["haplotypes"]), _p(cols["populations"]), _p(cols["newHaplotypes"]),
+                                                     _p(cols["newPopulations"]), C.byref(n)))
+        cols["times"] = times
+        return cols
+
+    def _absorb(self, m, replicate=0, tau=False, mev_base=0):
         self.get_state(m, replicate)
         c = self.counters(replicate)
         first = c.ev_first_new
         self.fetch_events(m.events, replicate, first, c.ev_ptr - first)
         m.events.ptr = c.ev_ptr
+        if tau:
+            rows = self.multievents(replicate)
+            if c.restarts > 0:  # Restart rewinds multievents.ptr too (pyx:716)
+                m.multievents.ptr = 0
+                mev_base = 0
+            # MULTITYPE records carry the [start, end) range of their rows (pyx:2325), here within the sparse log
+            m.events.haplotypes[first:c.ev_ptr] += mev_base
+            m.events.populations[first:c.ev_ptr] += mev_base
+            m.multievents.extend(rows.pop("times"), **rows)
+            self.last_events_drawn = c.reserved[0]
         st, pp, tt = self.lockdowns(replicate)
         for k in range(len(st)):
             m.loc.AddLockdown(st[k], pp[k], tt[k])

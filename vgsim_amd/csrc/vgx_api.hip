@@ -23,6 +23,10 @@ extern "C" hipError_t vgxi_launch_init_reps(const VgxDevRep *r, int P, int S, in
                                             int64_t s_cap, const int64_t *s_sus, const double *s_cd,
                                             const int64_t *s_tot, hipStream_t stream);
 
+#define TAU_DECL(name) extern "C" hipError_t vgxi_##name(const VgxTauArgs *a, hipStream_t s);
+TAU_DECL(tau_prep) TAU_DECL(tau_drift) TAU_DECL(tau_choose) TAU_DECL(tau_draw) TAU_DECL(tau_suscep_draw)
+TAU_DECL(tau_check) TAU_DECL(tau_decide) TAU_DECL(tau_commit) TAU_DECL(tau_finish)
+
 static std::string g_create_error;
 
 struct HostState {
@@ -62,6 +66,18 @@ struct vgx_engine {
         p_suscCumul;
     DevBuf r_popD, r_popI, r_sus, r_immSrc, r_birthC, r_xC, r_effMig, r_nocc, r_lhap, r_lcls, r_lcnt, r_sc, r_seeds,
         r_evtime, r_evcols, r_locrec, r_loctime, r_traj, r_prof;
+    // tau-leaping (dense compartments)
+    DevBuf t_I, t_S, t_dChk, t_dApp, t_dSi, t_dTot, t_totInf, t_gI, t_cd, t_lock, t_F, t_eff, t_Aeff, t_Gout, t_dS,
+        t_taubits, t_tau, t_time, t_flags, t_counters, t_cnttry, t_mev, t_mevn, t_mevbase, t_locn;
+    bool last_was_tau = false;
+    struct TauStep { double time; int64_t m0, m1; };
+    std::vector<std::vector<TauStep>> tau_log;      // [R] MULTITYPE records of the last tau call
+    std::vector<std::vector<double>> tau_loc_time;  // [R] lockdown log of the last tau call
+    std::vector<std::vector<int64_t>> tau_loc_state, tau_loc_pop;
+    std::vector<int64_t> tau_ev_ptr0;
+    std::vector<VgxRepScalars> tau_sc;
+    std::vector<double> h_startLD, h_endLD, h_cdBefore, h_cdAfter;
+    bool h_has_mig = false;
     DevBuf i_nocc, i_hap, i_cls, i_cnt, i_sus;          // initial state (Restart)
     DevBuf s_nocc, s_hap, s_cls, s_cnt, s_sus, s_cd, s_tot;  // state at the start of the call
     VgxDevParams dp{};
@@ -248,6 +264,15 @@ extern "C" int vgx_set_params(vgx_engine *e, const vgx_params *p) {
     e->mig.assign(p->migrationRates, p->migrationRates + P * P);
     e->actualSizes.assign((size_t)P, 0.0);
     e->sizes.assign(p->sizes, p->sizes + P);
+    e->h_startLD.assign(p->startLD, p->startLD + P);
+    e->h_endLD.assign(p->endLD, p->endLD + P);
+    e->h_cdBefore.assign(p->contactDensityBeforeLockdown, p->contactDensityBeforeLockdown + P);
+    e->h_cdAfter.assign(p->contactDensityAfterLockdown, p->contactDensityAfterLockdown + P);
+    e->h_has_mig = false;
+    for (int64_t i = 0; i < P; i++)
+        for (int64_t j = 0; j < P; j++)
+            if (i != j && p->migrationRates[i * P + j] != 0.0) e->h_has_mig = true;
+    if (S > 64) return fail(e, VGX_ERR_ARG, "vgx_set_params: at most 64 susceptibility groups are supported");
     for (int64_t p1 = 0; p1 < P; p1++) {  // pyx:289-297
         e->mig[(size_t)(p1 * P + p1)] = 1.0;
         double a = 0.0;
@@ -511,9 +536,18 @@ static int init_device_state(vgx_engine *e, int64_t traj_points) {
     return VGX_OK;
 }
 
+static int direct_core(vgx_engine *e, int64_t iterations, int64_t sample_size, float time, int64_t attempts,
+                       const vgx_run_opts *opts);
+
 extern "C" int vgx_simulate_direct(vgx_engine *e, int64_t iterations, int64_t sample_size, float time,
                                    int64_t attempts, const vgx_run_opts *opts) {
     if (!e) return VGX_ERR_ARG;
+    e->last_was_tau = false;
+    return direct_core(e, iterations, sample_size, time, attempts, opts);
+}
+
+static int direct_core(vgx_engine *e, int64_t iterations, int64_t sample_size, float time, int64_t attempts,
+                       const vgx_run_opts *opts) {
     if (!e->have_params || !e->have_state) return fail(e, VGX_ERR_ARG, "vgx_simulate_direct: set params and state first");
     if (iterations < 0 || attempts < 0) return fail(e, VGX_ERR_ARG, "vgx_simulate_direct: negative iterations/attempts");
     HIPCHECK(e, hipSetDevice(e->device));
@@ -593,9 +627,315 @@ extern "C" int vgx_simulate_direct(vgx_engine *e, int64_t iterations, int64_t sa
     return VGX_OK;
 }
 
-extern "C" int vgx_simulate_tau(vgx_engine *e, int64_t, int64_t, float, int64_t, const vgx_run_opts *) {
+// ------------------------------------------------------------------------------------------------
+// SimulatePopulation_tau (pyx:2293-2346): the step loop runs on the host, the steps on the device.
+template <typename T>
+static int dl(vgx_engine *e, std::vector<T> &dst, const DevBuf &b, size_t n) {
+    dst.resize(n);
+    HIPCHECK(e, hipMemcpy(dst.data(), b.p, n * sizeof(T), hipMemcpyDeviceToHost));
+    return VGX_OK;
+}
+template <typename T>
+static int ul(vgx_engine *e, const DevBuf &b, const std::vector<T> &src) {
+    HIPCHECK(e, hipMemcpy(b.p, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
+    return VGX_OK;
+}
+
+extern "C" int vgx_simulate_tau(vgx_engine *e, int64_t iterations, int64_t sample_size, float time, int64_t attempts,
+                                const vgx_run_opts *opts) {
     if (!e) return VGX_ERR_ARG;
-    return fail(e, VGX_ERR_ARG, "vgx_simulate_tau: not built into this library yet");
+    if (!e->have_params || !e->have_state) return fail(e, VGX_ERR_ARG, "vgx_simulate_tau: set params and state first");
+    HIPCHECK(e, hipSetDevice(e->device));
+    const int64_t H = e->d.hapNum, P = e->d.popNum, S = e->d.susNum, R = e->R;
+    vgx_run_opts o{};
+    o.record_events = 1;
+    if (opts) o = *opts;
+    HostState &h = e->hs;
+    const int64_t ev_ptr_start = h.ev_ptr, ev_size = h.ev_size;
+
+    // PrepareParameters (pyx:2298): first-call snapshot on the host, then CheckLockdown for every population and
+    // UpdateAllRates through the direct kernel run with zero attempts (it stops after that preparation).
+    e->dev_state_valid = false;
+    vgx_run_opts po{};
+    po.record_events = 0;
+    int rc = direct_core(e, 0, -1, -1.0f, 0, &po);
+    if (rc) return rc;
+    const VgxRepScalars prep = e->sc_host[0];
+    std::vector<double> popD((size_t)(PD_COUNT * P));
+    std::vector<int64_t> popI((size_t)(PI_COUNT * P));
+    HIPCHECK(e, hipMemcpy(popD.data(), e->r_popD.p, popD.size() * 8, hipMemcpyDeviceToHost));
+    HIPCHECK(e, hipMemcpy(popI.data(), e->r_popI.p, popI.size() * 8, hipMemcpyDeviceToHost));
+    for (int64_t pn = 0; pn < P; pn++) {
+        h.contactDensity[(size_t)pn] = popD[(size_t)(PD_CD * P + pn)];
+        h.lockdownON[(size_t)pn] = popI[(size_t)(PI_LOCK * P + pn)];
+    }
+    h.swapLockdown = prep.swapLockdown;
+    h.totalRate = prep.totalRate;
+    h.totalMigrationRate = prep.totalMig;
+    e->tau_loc_time.assign((size_t)R, {});
+    e->tau_loc_state.assign((size_t)R, {});
+    e->tau_loc_pop.assign((size_t)R, {});
+    {
+        int64_t n = std::min<int64_t>(prep.loc_n, VGX_LOC_CAP);
+        std::vector<int32_t> rec((size_t)n * 2);
+        std::vector<double> tt((size_t)n);
+        if (n > 0) {
+            HIPCHECK(e, hipMemcpy(rec.data(), e->r_locrec.p, (size_t)n * 8, hipMemcpyDeviceToHost));
+            HIPCHECK(e, hipMemcpy(tt.data(), e->r_loctime.p, (size_t)n * 8, hipMemcpyDeviceToHost));
+        }
+        for (int64_t r = 0; r < R; r++)
+            for (int64_t i = 0; i < n; i++) {
+                e->tau_loc_state[(size_t)r].push_back(rec[(size_t)(i * 2)]);
+                e->tau_loc_pop[(size_t)r].push_back(rec[(size_t)(i * 2 + 1)]);
+                e->tau_loc_time[(size_t)r].push_back(tt[(size_t)i]);
+            }
+    }
+    e->dev_state_valid = false;  // the occupancy lists are not maintained by the tau path
+    const bool start_ok = (prep.totalRate + prep.totalMig != 0.0) && h.globalInfectious != 0;
+
+    // ---- device arrays ----
+    const int64_t mev_cap = o.record_events ? std::max<int64_t>(1, std::min<int64_t>((int64_t)1 << 24, iterations * 8192)) : 0;
+    const size_t nF = 8;  // int32 flag arrays
+    rc = 0;
+    rc |= ensure(e, e->t_I, (size_t)(R * P * H) * 8);
+    rc |= ensure(e, e->t_S, (size_t)(R * P * S) * 8);
+    rc |= ensure(e, e->t_dChk, (size_t)(R * P * H) * 8);
+    rc |= ensure(e, e->t_dApp, (size_t)(R * P * H) * 8);
+    rc |= ensure(e, e->t_dSi, (size_t)(R * P * S) * 8);
+    rc |= ensure(e, e->t_dTot, (size_t)(R * P) * 8);
+    rc |= ensure(e, e->t_totInf, (size_t)(R * P) * 8);
+    rc |= ensure(e, e->t_gI, (size_t)R * 8);
+    rc |= ensure(e, e->t_cd, (size_t)(R * P) * 8);
+    rc |= ensure(e, e->t_lock, (size_t)(R * P) * 4);
+    rc |= ensure(e, e->t_F, (size_t)(R * P) * 8);
+    rc |= ensure(e, e->t_eff, (size_t)(R * P * P) * 8);
+    rc |= ensure(e, e->t_Aeff, (size_t)(R * P * P) * 8);
+    rc |= ensure(e, e->t_Gout, (size_t)(R * P * e->CB) * 8);
+    rc |= ensure(e, e->t_dS, (size_t)(R * P * S) * 8);
+    rc |= ensure(e, e->t_taubits, (size_t)R * 8);
+    rc |= ensure(e, e->t_tau, (size_t)R * 8);
+    rc |= ensure(e, e->t_time, (size_t)R * 8);
+    rc |= ensure(e, e->t_flags, (size_t)R * nF * 4);
+    rc |= ensure(e, e->t_counters, (size_t)R * 8 * 8);
+    rc |= ensure(e, e->t_cnttry, (size_t)R * 8 * 8);
+    rc |= ensure(e, e->t_mev, (size_t)(R * std::max<int64_t>(mev_cap, 1) * 6) * 8);
+    rc |= ensure(e, e->t_mevn, (size_t)R * 8);
+    rc |= ensure(e, e->t_mevbase, (size_t)R * 8);
+    rc |= ensure(e, e->t_locn, (size_t)R * 8);
+    rc |= upload(e, e->r_seeds, e->seeds.data(), e->seeds.size());
+    if (rc) return VGX_ERR_HIP;
+    HIPCHECK(e, hipMemset(e->t_dChk.p, 0, (size_t)(R * P * H) * 8));
+    HIPCHECK(e, hipMemset(e->t_dApp.p, 0, (size_t)(R * P * H) * 8));
+    HIPCHECK(e, hipMemset(e->t_dSi.p, 0, (size_t)(R * P * S) * 8));
+    HIPCHECK(e, hipMemset(e->t_dTot.p, 0, (size_t)(R * P) * 8));
+    HIPCHECK(e, hipMemset(e->t_counters.p, 0, (size_t)R * 64));
+    HIPCHECK(e, hipMemset(e->t_cnttry.p, 0, (size_t)R * 64));
+    HIPCHECK(e, hipMemset(e->t_mevn.p, 0, (size_t)R * 8));
+    HIPCHECK(e, hipMemset(e->t_mevbase.p, 0, (size_t)R * 8));
+    HIPCHECK(e, hipMemset(e->t_locn.p, 0, (size_t)R * 8));
+    HIPCHECK(e, hipMemset(e->t_flags.p, 0, (size_t)R * nF * 4));
+    std::vector<int32_t> lock32((size_t)P);
+    for (int64_t pn = 0; pn < P; pn++) lock32[(size_t)pn] = (int32_t)h.lockdownON[(size_t)pn];
+    auto upload_state = [&](int64_t r, const std::vector<int64_t> &inf, const std::vector<int64_t> &sus) -> int {
+        std::vector<int64_t> tot((size_t)P, 0);
+        for (int64_t pn = 0; pn < P; pn++)
+            for (int64_t hn = 0; hn < H; hn++) tot[(size_t)pn] += inf[(size_t)(pn * H + hn)];
+        HIPCHECK(e, hipMemcpy((int64_t *)e->t_I.p + r * P * H, inf.data(), (size_t)(P * H) * 8, hipMemcpyHostToDevice));
+        HIPCHECK(e, hipMemcpy((int64_t *)e->t_S.p + r * P * S, sus.data(), (size_t)(P * S) * 8, hipMemcpyHostToDevice));
+        HIPCHECK(e, hipMemcpy((int64_t *)e->t_totInf.p + r * P, tot.data(), (size_t)P * 8, hipMemcpyHostToDevice));
+        return VGX_OK;
+    };
+    for (int64_t r = 0; r < R; r++) {
+        rc = upload_state(r, h.infectious, h.susceptible);
+        if (rc) return rc;
+        HIPCHECK(e, hipMemcpy((double *)e->t_cd.p + r * P, h.contactDensity.data(), (size_t)P * 8, hipMemcpyHostToDevice));
+        HIPCHECK(e, hipMemcpy((int32_t *)e->t_lock.p + r * P, lock32.data(), (size_t)P * 4, hipMemcpyHostToDevice));
+    }
+
+    VgxTauArgs a{};
+    a.p = e->dp;
+    a.R = R;
+    a.I = (int64_t *)e->t_I.p; a.S = (int64_t *)e->t_S.p; a.dChk = (int64_t *)e->t_dChk.p; a.dApp = (int64_t *)e->t_dApp.p;
+    a.dSi = (int64_t *)e->t_dSi.p; a.dTot = (int64_t *)e->t_dTot.p; a.totInf = (int64_t *)e->t_totInf.p;
+    a.gI = (int64_t *)e->t_gI.p; a.cd = (double *)e->t_cd.p; a.lockON = (int32_t *)e->t_lock.p; a.F = (double *)e->t_F.p;
+    a.effMig = (double *)e->t_eff.p; a.Aeff = (double *)e->t_Aeff.p; a.Gout = (double *)e->t_Gout.p;
+    a.dS = (double *)e->t_dS.p; a.tau_bits = (unsigned long long *)e->t_taubits.p; a.tau = (double *)e->t_tau.p;
+    a.time_now = (double *)e->t_time.p;
+    int32_t *fl = (int32_t *)e->t_flags.p;
+    a.active = fl; a.ok = fl + R; a.accepted = fl + 2 * R; a.deciding = fl + 3 * R; a.retry = fl + 4 * R;
+    a.step = fl + 5 * R; a.error = fl + 6 * R; a.attempt = fl + 7 * R;
+    a.seeds = (const int64_t *)e->r_seeds.p;
+    a.has_mig = e->h_has_mig ? 1 : 0;
+    a.counters = (int64_t *)e->t_counters.p; a.cnt_try = (int64_t *)e->t_cnttry.p;
+    a.mev = (int64_t *)e->t_mev.p; a.mev_cap = mev_cap;
+    a.mev_n = (unsigned long long *)e->t_mevn.p; a.mev_base = (unsigned long long *)e->t_mevbase.p;
+    a.loc_n = (unsigned long long *)e->t_locn.p; a.loc_rec = (int32_t *)e->r_locrec.p; a.loc_time = (double *)e->r_loctime.p;
+
+    // ---- per-replicate host bookkeeping ----
+    std::vector<double> tnow((size_t)R, h.currentTime), tau_h;
+    std::vector<int64_t> ev_ptr((size_t)R, ev_ptr_start), att((size_t)R, 0), good((size_t)R, h.good_attempt), gI((size_t)R, h.globalInfectious);
+    std::vector<int64_t> base_cnt = {h.bCounter, h.dCounter, h.sCounter, h.mCounter, h.iCounter, h.migPlus, h.swapLockdown, 0};
+    std::vector<std::vector<int64_t>> cnt0((size_t)R, base_cnt);  // counters before this call / after a restart
+    std::vector<int64_t> cnt((size_t)R * 8, 0);
+    std::vector<int32_t> running((size_t)R, 0), finished((size_t)R, 0), step_h((size_t)R, 0), att32((size_t)R, 0), acc_h, err_h;
+    std::vector<int64_t> restarts((size_t)R, 0), steps_done((size_t)R, 0);
+    e->tau_log.assign((size_t)R, {});
+    e->tau_ev_ptr0.assign((size_t)R, ev_ptr_start);
+    std::vector<unsigned long long> mevn((size_t)R, 0);
+    for (int64_t r = 0; r < R; r++) running[(size_t)r] = (attempts > 0 && start_ok) ? 1 : 0;
+    std::vector<int32_t> fresh((size_t)R, 1);  // attempt just opened: the pyx:2311 guard applies
+    float ms_total = 0.f;
+    int64_t launches = 0;
+    const bool has_tl = !(time == -1.0f);
+    auto sC_of = [&](int64_t r) { return cnt0[(size_t)r][2] + cnt[(size_t)r * 8 + 2]; };
+    int64_t guard = 0;
+    while (true) {
+        // loop condition (pyx:2312) / end of attempt (pyx:2331-2335)
+        bool any = false;
+        for (int64_t r = 0; r < R; r++) {
+            if (finished[(size_t)r]) continue;
+            if (attempts <= 0) { finished[(size_t)r] = 1; continue; }
+            bool go = running[(size_t)r] && ev_ptr[(size_t)r] < ev_size && (sample_size == -1 || sC_of(r) < sample_size) &&
+                      (!has_tl || tnow[(size_t)r] < (double)time) && (fresh[(size_t)r] || gI[(size_t)r] != 0);
+            fresh[(size_t)r] = 0;
+            if (go) { any = true; continue; }
+            running[(size_t)r] = 0;
+            if (ev_ptr[(size_t)r] <= 100 && iterations > 100) {  // Restart (pyx:714-738)
+                restarts[(size_t)r] += 1;
+                rc = upload_state(r, h.initial_infectious, h.initial_susceptible);
+                if (rc) return rc;
+                HIPCHECK(e, hipMemset((int64_t *)e->t_counters.p + r * 8, 0, 64));
+                HIPCHECK(e, hipMemset((unsigned long long *)e->t_mevn.p + r, 0, 8));
+                HIPCHECK(e, hipMemset((unsigned long long *)e->t_mevbase.p + r, 0, 8));
+                for (int i = 0; i < 8; i++) cnt[(size_t)r * 8 + i] = 0;
+                cnt0[(size_t)r] = {0, 0, 0, 0, 0, 0, base_cnt[6], 0};
+                tnow[(size_t)r] = 0.0;
+                ev_ptr[(size_t)r] = 0;
+                e->tau_ev_ptr0[(size_t)r] = 0;
+                e->tau_log[(size_t)r].clear();
+                int64_t g0 = 0;
+                for (int64_t i = 0; i < P * H; i++) g0 += h.initial_infectious[(size_t)i];
+                gI[(size_t)r] = g0;
+                att[(size_t)r] += 1;
+                if (att[(size_t)r] < attempts) {
+                    running[(size_t)r] = (g0 != 0) ? 1 : 0;
+                    fresh[(size_t)r] = 1;
+                    if (running[(size_t)r]) any = true;
+                    else r -= 1;  // re-evaluate: the attempt ends at once
+                } else {
+                    finished[(size_t)r] = 1;
+                }
+            } else {
+                good[(size_t)r] = att[(size_t)r] + 1;
+                finished[(size_t)r] = 1;
+            }
+        }
+        if (!any) break;
+        if (++guard > (int64_t)4 * (iterations + 16) * std::max<int64_t>(attempts, 1)) return fail(e, VGX_ERR_LOOP_GUARD, "vgx_simulate_tau: step loop guard");
+        for (int64_t r = 0; r < R; r++) att32[(size_t)r] = (int32_t)att[(size_t)r];
+        HIPCHECK(e, hipMemcpy(a.active, running.data(), (size_t)R * 4, hipMemcpyHostToDevice));
+        HIPCHECK(e, hipMemcpy(a.step, step_h.data(), (size_t)R * 4, hipMemcpyHostToDevice));
+        HIPCHECK(e, hipMemcpy(a.attempt, att32.data(), (size_t)R * 4, hipMemcpyHostToDevice));
+        HIPCHECK(e, hipMemcpy(a.time_now, tnow.data(), (size_t)R * 8, hipMemcpyHostToDevice));
+        HIPCHECK(e, hipEventRecord(e->ev0, e->stream));
+        HIPCHECK(e, vgxi_tau_prep(&a, e->stream));
+        HIPCHECK(e, vgxi_tau_drift(&a, e->stream));
+        HIPCHECK(e, vgxi_tau_choose(&a, e->stream));
+        launches += 3;
+        for (int tries = 0;; tries++) {
+            HIPCHECK(e, vgxi_tau_draw(&a, e->stream));
+            HIPCHECK(e, vgxi_tau_suscep_draw(&a, e->stream));
+            HIPCHECK(e, vgxi_tau_check(&a, e->stream));
+            HIPCHECK(e, vgxi_tau_decide(&a, e->stream));
+            HIPCHECK(e, vgxi_tau_commit(&a, e->stream));
+            launches += 5;
+            HIPCHECK(e, hipStreamSynchronize(e->stream));
+            acc_h.resize((size_t)R);
+            HIPCHECK(e, hipMemcpy(acc_h.data(), a.accepted, (size_t)R * 4, hipMemcpyDeviceToHost));
+            bool all = true;
+            for (int64_t r = 0; r < R; r++)
+                if (running[(size_t)r] && !acc_h[(size_t)r]) all = false;
+            if (all) break;
+            if (tries > 300) return fail(e, VGX_ERR_LOOP_GUARD, "vgx_simulate_tau: tau halving did not converge");
+        }
+        HIPCHECK(e, vgxi_tau_finish(&a, e->stream));
+        launches += 1;
+        HIPCHECK(e, hipEventRecord(e->ev1, e->stream));
+        HIPCHECK(e, hipStreamSynchronize(e->stream));
+        float ms = 0.f;
+        HIPCHECK(e, hipEventElapsedTime(&ms, e->ev0, e->ev1));
+        ms_total += ms;
+        tau_h.resize((size_t)R);
+        err_h.resize((size_t)R);
+        std::vector<int64_t> gI_d((size_t)R);
+        HIPCHECK(e, hipMemcpy(tau_h.data(), a.tau, (size_t)R * 8, hipMemcpyDeviceToHost));
+        HIPCHECK(e, hipMemcpy(err_h.data(), a.error, (size_t)R * 4, hipMemcpyDeviceToHost));
+        HIPCHECK(e, hipMemcpy(gI_d.data(), a.gI, (size_t)R * 8, hipMemcpyDeviceToHost));
+        HIPCHECK(e, hipMemcpy(cnt.data(), a.counters, (size_t)R * 64, hipMemcpyDeviceToHost));
+        HIPCHECK(e, hipMemcpy(mevn.data(), a.mev_n, (size_t)R * 8, hipMemcpyDeviceToHost));
+        std::vector<unsigned long long> mevb((size_t)R);
+        HIPCHECK(e, hipMemcpy(mevb.data(), a.mev_base, (size_t)R * 8, hipMemcpyDeviceToHost));
+        for (int64_t r = 0; r < R; r++) {
+            if (!running[(size_t)r]) continue;
+            if (err_h[(size_t)r]) return fail(e, VGX_ERR_LOOP_GUARD, "vgx_simulate_tau: replicate " + std::to_string(r) + ": tau underflow in the halving loop");
+            if (mev_cap > 0 && (int64_t)mevn[(size_t)r] > mev_cap)
+                return fail(e, VGX_ERR_CAPACITY, "vgx_simulate_tau: multievent buffer full (pass record_events=0 for large runs)");
+            tnow[(size_t)r] += tau_h[(size_t)r];                       // pyx:2322
+            e->tau_log[(size_t)r].push_back({tnow[(size_t)r], (int64_t)mevb[(size_t)r], (int64_t)mevn[(size_t)r]});  // pyx:2325
+            mevb[(size_t)r] = mevn[(size_t)r];
+            ev_ptr[(size_t)r] += 1;
+            step_h[(size_t)r] += 1;
+            steps_done[(size_t)r] += 1;
+            gI[(size_t)r] = gI_d[(size_t)r];
+        }
+        HIPCHECK(e, hipMemcpy(a.mev_base, mevb.data(), (size_t)R * 8, hipMemcpyHostToDevice));
+    }
+
+    // ---- results ----
+    std::vector<unsigned long long> locn((size_t)R);
+    HIPCHECK(e, hipMemcpy(locn.data(), a.loc_n, (size_t)R * 8, hipMemcpyDeviceToHost));
+    for (int64_t r = 0; r < R; r++) {
+        int64_t n = std::min<int64_t>((int64_t)locn[(size_t)r], VGX_LOC_CAP);
+        if (n <= 0) continue;
+        std::vector<int32_t> rec((size_t)n * 2);
+        std::vector<double> tt((size_t)n);
+        HIPCHECK(e, hipMemcpy(rec.data(), (int32_t *)e->r_locrec.p + r * VGX_LOC_CAP * 2, (size_t)n * 8, hipMemcpyDeviceToHost));
+        HIPCHECK(e, hipMemcpy(tt.data(), (double *)e->r_loctime.p + r * VGX_LOC_CAP, (size_t)n * 8, hipMemcpyDeviceToHost));
+        for (int64_t i = 0; i < n; i++) {
+            e->tau_loc_state[(size_t)r].push_back(rec[(size_t)(i * 2)]);
+            e->tau_loc_pop[(size_t)r].push_back(rec[(size_t)(i * 2 + 1)]);
+            e->tau_loc_time[(size_t)r].push_back(tt[(size_t)i]);
+        }
+    }
+    e->tau_sc.assign((size_t)R, VgxRepScalars{});
+    for (int64_t r = 0; r < R; r++) {
+        VgxRepScalars &s = e->tau_sc[(size_t)r];
+        const std::vector<int64_t> &c0 = cnt0[(size_t)r];
+        const int64_t *c = &cnt[(size_t)r * 8];
+        s.currentTime = tnow[(size_t)r]; s.totalRate = h.totalRate; s.totalMig = h.totalMigrationRate;
+        s.tau_l = tau_h.empty() ? h.tau_l : tau_h[(size_t)r];
+        s.globalInfectious = gI[(size_t)r];
+        s.bCounter = c0[0] + c[0]; s.dCounter = c0[1] + c[1]; s.sCounter = c0[2] + c[2]; s.mCounter = c0[3] + c[3];
+        s.iCounter = c0[4] + c[4]; s.migPlus = c0[5] + c[5]; s.migNonPlus = h.migNonPlus;
+        s.swapLockdown = c0[6] + c[6];
+        s.good_attempt = good[(size_t)r];
+        s.ev_ptr = ev_ptr[(size_t)r];
+        s.loop_iterations = steps_done[(size_t)r];
+        s.restarts = restarts[(size_t)r];
+        s.loc_n = (int64_t)e->tau_loc_time[(size_t)r].size();
+        s.mev_rows = (int64_t)mevn[(size_t)r];
+        s.traj_next = c[7];  // events drawn (sum of multiplicities), reported through vgx_counters.reserved[0]
+        if (restarts[(size_t)r] > 0) s.migNonPlus = 0;
+    }
+    e->sc_host = e->tau_sc;
+    e->sc_host_valid = true;
+    e->last_was_tau = true;
+    e->last_ms = ms_total;
+    e->last_launches = launches;
+    e->last_ev_size = ev_size;
+    e->ev_ptr0 = ev_ptr_start;
+    h.ev_ptr = ev_ptr[0];
+    return VGX_OK;
 }
 
 extern "C" int vgx_get_counters(vgx_engine *e, int64_t replicate, vgx_counters *out) {
@@ -605,6 +945,7 @@ extern "C" int vgx_get_counters(vgx_engine *e, int64_t replicate, vgx_counters *
     memset(out, 0, sizeof(*out));
     out->ev_ptr = s.ev_ptr;
     out->ev_first_new = s.restarts > 0 ? 0 : e->ev_ptr0;
+    if (e->last_was_tau) out->reserved[0] = s.traj_next;  // tau: events drawn (sum of channel multiplicities)
     out->loop_iterations = s.loop_iterations;
     out->restarts = s.restarts;
     out->lockdown_records = s.loc_n;
@@ -619,6 +960,21 @@ extern "C" int vgx_get_events(vgx_engine *e, int64_t replicate, int64_t first, i
     if (!e || replicate < 0 || replicate >= e->R || first < 0 || count < 0) return VGX_ERR_ARG;
     if (count == 0) return VGX_OK;
     HIPCHECK(e, hipSetDevice(e->device));
+    if (e->last_was_tau) {  // MULTITYPE records (pyx:2325): [start, end) of the step's multievent rows
+        const auto &lg = e->tau_log[(size_t)replicate];
+        int64_t i0 = first - e->tau_ev_ptr0[(size_t)replicate];
+        if (i0 < 0 || i0 + count > (int64_t)lg.size()) return fail(e, VGX_ERR_ARG, "vgx_get_events: range outside the last tau call");
+        for (int64_t i = 0; i < count; i++) {
+            const auto &st = lg[(size_t)(i0 + i)];
+            if (times) times[i] = st.time;
+            if (types) types[i] = VGX_MULTITYPE;
+            if (haplotypes) haplotypes[i] = st.m0;
+            if (populations) populations[i] = st.m1;
+            if (newHaplotypes) newHaplotypes[i] = 0;
+            if (newPopulations) newPopulations[i] = 0;
+        }
+        return VGX_OK;
+    }
     int64_t slot0 = first - e->ev_base;
     if (slot0 < 0 || slot0 + count > e->evcap) return fail(e, VGX_ERR_ARG, "vgx_get_events: range outside the device log of the last call");
     std::vector<int32_t> cols((size_t)count * 5);
@@ -636,6 +992,16 @@ extern "C" int vgx_get_lockdowns(vgx_engine *e, int64_t replicate, int64_t cap, 
     if (!e || !n || replicate < 0 || replicate >= e->R) return VGX_ERR_ARG;
     if (!e->sc_host_valid) return fail(e, VGX_ERR_ARG, "vgx_get_lockdowns: no simulate call yet");
     HIPCHECK(e, hipSetDevice(e->device));
+    if (e->last_was_tau) {
+        const auto &tt = e->tau_loc_time[(size_t)replicate];
+        *n = (int64_t)tt.size();
+        for (int64_t i = 0; i < std::min<int64_t>(*n, cap); i++) {
+            if (states) states[i] = e->tau_loc_state[(size_t)replicate][(size_t)i];
+            if (populations) populations[i] = e->tau_loc_pop[(size_t)replicate][(size_t)i];
+            if (times) times[i] = tt[(size_t)i];
+        }
+        return VGX_OK;
+    }
     int64_t cnt = std::min<int64_t>(e->sc_host[(size_t)replicate].loc_n, VGX_LOC_CAP);
     *n = cnt;
     cnt = std::min(cnt, cap);
@@ -652,10 +1018,32 @@ extern "C" int vgx_get_lockdowns(vgx_engine *e, int64_t replicate, int64_t cap, 
     return VGX_OK;
 }
 
-extern "C" int vgx_get_multievents(vgx_engine *e, int64_t, int64_t, int64_t *, double *, int64_t *, int64_t *, int64_t *,
-                                   int64_t *, int64_t *, int64_t *n) {
-    if (!e || !n) return VGX_ERR_ARG;
+extern "C" int vgx_get_multievents(vgx_engine *e, int64_t replicate, int64_t cap, int64_t *num, double *times,
+                                   int64_t *types, int64_t *haplotypes, int64_t *populations, int64_t *newHaplotypes,
+                                   int64_t *newPopulations, int64_t *n) {
+    if (!e || !n || replicate < 0 || replicate >= e->R) return VGX_ERR_ARG;
     *n = 0;
+    if (!e->last_was_tau) return VGX_OK;
+    HIPCHECK(e, hipSetDevice(e->device));
+    const auto &lg = e->tau_log[(size_t)replicate];
+    int64_t rows = lg.empty() ? 0 : lg.back().m1;
+    *n = rows;
+    rows = std::min(rows, cap);
+    if (rows <= 0) return VGX_OK;
+    int64_t mev_cap = (int64_t)(e->t_mev.bytes / 48 / (size_t)e->R);
+    std::vector<int64_t> buf((size_t)rows * 6);
+    HIPCHECK(e, hipMemcpy(buf.data(), (int64_t *)e->t_mev.p + replicate * mev_cap * 6, (size_t)rows * 48, hipMemcpyDeviceToHost));
+    size_t st = 0;
+    for (int64_t i = 0; i < rows; i++) {
+        while (st + 1 < lg.size() && i >= lg[st].m1) st++;
+        if (num) num[i] = buf[(size_t)(i * 6)];
+        if (times) times[i] = lg[st].time;
+        if (types) types[i] = buf[(size_t)(i * 6 + 1)];
+        if (haplotypes) haplotypes[i] = buf[(size_t)(i * 6 + 2)];
+        if (populations) populations[i] = buf[(size_t)(i * 6 + 3)];
+        if (newHaplotypes) newHaplotypes[i] = buf[(size_t)(i * 6 + 4)];
+        if (newPopulations) newPopulations[i] = buf[(size_t)(i * 6 + 5)];
+    }
     return VGX_OK;
 }
 
@@ -670,6 +1058,43 @@ extern "C" int vgx_get_trajectories(vgx_engine *e, double *out, int out_is_devic
 
 extern "C" int vgx_get_state(vgx_engine *e, int64_t replicate, vgx_state *out) {
     if (!e || !out || replicate < 0 || replicate >= e->R) return VGX_ERR_ARG;
+    if (e->last_was_tau && e->sc_host_valid) {
+        HIPCHECK(e, hipSetDevice(e->device));
+        const int64_t H = e->d.hapNum, P = e->d.popNum, S = e->d.susNum;
+        const VgxRepScalars &s = e->sc_host[(size_t)replicate];
+        HostState &h = e->hs;
+        if (out->susceptible) HIPCHECK(e, hipMemcpy(out->susceptible, (int64_t *)e->t_S.p + replicate * P * S, (size_t)(P * S) * 8, hipMemcpyDeviceToHost));
+        if (out->infectious) HIPCHECK(e, hipMemcpy(out->infectious, (int64_t *)e->t_I.p + replicate * P * H, (size_t)(P * H) * 8, hipMemcpyDeviceToHost));
+        if (out->initial_susceptible) memcpy(out->initial_susceptible, h.initial_susceptible.data(), (size_t)(P * S) * 8);
+        if (out->initial_infectious) memcpy(out->initial_infectious, h.initial_infectious.data(), (size_t)(P * H) * 8);
+        std::vector<int64_t> tot((size_t)P);
+        std::vector<double> cd((size_t)P);
+        std::vector<int32_t> lk((size_t)P);
+        HIPCHECK(e, hipMemcpy(tot.data(), (int64_t *)e->t_totInf.p + replicate * P, (size_t)P * 8, hipMemcpyDeviceToHost));
+        HIPCHECK(e, hipMemcpy(cd.data(), (double *)e->t_cd.p + replicate * P, (size_t)P * 8, hipMemcpyDeviceToHost));
+        HIPCHECK(e, hipMemcpy(lk.data(), (int32_t *)e->t_lock.p + replicate * P, (size_t)P * 4, hipMemcpyDeviceToHost));
+        std::vector<int64_t> sus((size_t)(P * S));
+        HIPCHECK(e, hipMemcpy(sus.data(), (int64_t *)e->t_S.p + replicate * P * S, (size_t)(P * S) * 8, hipMemcpyDeviceToHost));
+        for (int64_t pn = 0; pn < P; pn++) {
+            if (out->totalInfectious) out->totalInfectious[pn] = tot[(size_t)pn];
+            if (out->totalSusceptible) {
+                int64_t t = 0;
+                for (int64_t sn = 0; sn < S; sn++) t += sus[(size_t)(pn * S + sn)];
+                out->totalSusceptible[pn] = t;
+            }
+            if (out->lockdownON) out->lockdownON[pn] = lk[(size_t)pn];
+            if (out->contactDensity) out->contactDensity[pn] = cd[(size_t)pn];
+        }
+        out->first_simulation = h.first_simulation;
+        out->globalInfectious = s.globalInfectious;
+        out->bCounter = s.bCounter; out->dCounter = s.dCounter; out->sCounter = s.sCounter; out->mCounter = s.mCounter;
+        out->iCounter = s.iCounter; out->swapLockdown = s.swapLockdown; out->migPlus = s.migPlus;
+        out->migNonPlus = s.migNonPlus; out->good_attempt = s.good_attempt;
+        out->currentTime = s.currentTime; out->totalRate = s.totalRate; out->totalMigrationRate = s.totalMig;
+        out->tau_l = s.tau_l;
+        out->ev_ptr = s.ev_ptr; out->ev_size = e->last_ev_size;
+        return VGX_OK;
+    }
     if (!e->dev_state_valid || !e->sc_host_valid) return fail(e, VGX_ERR_ARG, "vgx_get_state: no device state");
     HIPCHECK(e, hipSetDevice(e->device));
     const int64_t H = e->d.hapNum, P = e->d.popNum, S = e->d.susNum, cap = e->cap;

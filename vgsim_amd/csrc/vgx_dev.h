@@ -107,3 +107,40 @@ struct VgxDirectArgs {
     int32_t record_events;
     int32_t lds_bytes;
 };
+
+// Tau-leaping (vgx_tau.hip): dense compartment arrays per replicate, [R][P][H] / [R][P][S].
+struct VgxTauArgs {
+    VgxDevParams p;
+    int64_t R;
+    int64_t *I;          // [R][P][H] infectious
+    int64_t *S;          // [R][P][S] susceptible
+    int64_t *dChk;       // [R][P][H] infectious deltas as the reference's bounds check books them (pyx:2473)
+    int64_t *dApp;       // [R][P][H] infectious deltas as UpdateCompartmentCounts_tau applies them (pyx:2548)
+    int64_t *dSi;        // [R][P][S] susceptible deltas
+    int64_t *dTot;       // [R][P]    delta of totalInfectious
+    int64_t *totInf;     // [R][P]
+    int64_t *gI;         // [R]
+    double *cd;          // [R][P] contact density
+    int32_t *lockON;     // [R][P]
+    double *F;           // [R][P]     sum_spn m[pn,spn]^2 cd[spn]/as[spn]
+    double *effMig;      // [R][P][P]
+    double *Aeff;        // [R][P][P]  effMig[tpn][spn] * m[spn][spn]
+    double *Gout;        // [R][P][CB] out-migration weight of a source population per birth class
+    double *dS;          // [R][P][S]  drift of the susceptible compartments
+    unsigned long long *tau_bits;  // [R] running minimum of the tau candidates (bit pattern)
+    double *tau;         // [R]
+    double *time_now;    // [R]
+    int32_t *active, *ok, *accepted, *deciding, *retry, *step, *error;  // [R]
+    int32_t *attempt;    // [R]
+    const int64_t *seeds;  // [R]
+    int32_t has_mig;
+    int64_t *counters;   // [R][8]: births, recoveries, samples, mutations, immunity, migrations, lockdown switches, events drawn
+    int64_t *cnt_try;    // [R][8] tallies of the retry being validated
+    int64_t *mev;        // [R][mev_cap][6]  num, type, hap, pop, newHap, newPop (rows with num > 0 only)
+    int64_t mev_cap;
+    unsigned long long *mev_n;     // [R]
+    unsigned long long *mev_base;  // [R] rows of the steps already accepted
+    unsigned long long *loc_n;     // [R]
+    int32_t *loc_rec;    // [R][VGX_LOC_CAP][2]
+    double *loc_time;    // [R][VGX_LOC_CAP]
+};

@@ -1,0 +1,551 @@
+// vgx_tau.hip — Poisson tau-leaping kernels for gfx950 (MI355X).
+//
+// Replaces the body of BirthDeathModel.SimulatePopulation_tau (reference src/_BirthDeath.pyx:2293-2346):
+// Propensities pyx:2351-2417, ChooseTau pyx:2432-2450, GenerateEvents_tau pyx:2454-2529 (+DrawEventsNum
+// pyx:2531), UpdateCompartmentCounts_tau pyx:2536-2593.
+//
+// The reference materialises one propensity and one event count per channel (propNum of them, pyx:2301:
+// 3.8e8 at 65 536 x 64, 7.7e10 at 2^20 x 256) and draws them one after the other from one PCG64 stream.
+// Here one thread owns one compartment (population pn, haplotype hn) and evaluates its channels in
+// registers; nothing per-channel is stored:
+//   * every channel out of (pn, hn) has a propensity proportional to infectious[pn, hn], so empty
+//     compartments draw nothing (exactly like random_poisson(lam=0), which consumes no random numbers);
+//   * the (P-1)*S migration channels out of a compartment are drawn as ONE Poisson with the summed rate and
+//     then split multinomially over (target population, susceptibility group): the same joint law as
+//     independent Poissons per channel;
+//   * draws come from Philox4x32-10 keyed by (seed, attempt) with the counter (compartment, step, retry):
+//     every compartment owns an independent, reproducible stream, whatever the launch geometry;
+//   * one pass books both the deltas the reference's bounds check inspects and the deltas it applies
+//     (they differ for migrants, pyx:2473 vs pyx:2548); the state is only touched by the commit kernel;
+//   * net drifts (infectiousAuxTau / susceptibleAuxTau, the input of ChooseTau) are evaluated per
+//     compartment by gathering the incoming mutation and migration terms; tau_l is a grid-wide minimum.
+// Arithmetic is f64 with the reference's formulas but not its summation order: the tau path is checked
+// distributionally (tests/test_hip_tau.py), as BASELINE.json asks.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "vgx_dev.h"
+#include "vgx_rng.h"
+
+#define TB 256  // threads per block of the compartment kernels
+
+struct TauRng {
+    uint32_t ctr[4];
+    uint32_t key[2];
+    uint32_t buf[4];
+    int have;
+    __device__ void init(uint64_t seed, uint32_t attempt, uint64_t cell, uint32_t step, uint32_t retry) {
+        key[0] = (uint32_t)seed ^ (attempt * 0x9E3779B9u);
+        key[1] = (uint32_t)(seed >> 32) ^ 0x85EBCA6Bu;
+        ctr[0] = (uint32_t)cell;
+        ctr[1] = (uint32_t)(cell >> 32);
+        ctr[2] = step;
+        ctr[3] = retry << 20;  // low 20 bits: block counter of this stream
+        have = 0;
+    }
+    __device__ double uniform() {  // (0,1): 52 random bits + half an ulp, never 0
+        if (have < 2) {
+            vgx_philox4x32(ctr, key, buf);
+            ctr[3] += 1;
+            have = 4;
+        }
+        uint64_t x = ((uint64_t)buf[have - 1] << 32) | buf[have - 2];
+        have -= 2;
+        return ((double)(x >> 12) + 0.5) * (1.0 / 4503599627370496.0);
+    }
+};
+
+// log Gamma for PTRS (Stirling series with upward recurrence below 7, as in numpy's random_loggam)
+static __device__ double tau_loggam(double x) {
+    const double a[10] = {8.333333333333333e-02, -2.777777777777778e-03, 7.936507936507937e-04,
+                          -5.952380952380952e-04, 8.417508417508418e-04, -1.917526917526918e-03,
+                          6.410256410256410e-03, -2.955065359477124e-02, 1.796443723688307e-01,
+                          -1.39243221690590e+00};
+    if (x == 1.0 || x == 2.0) return 0.0;
+    int n = x < 7.0 ? (int)(7 - x) : 0;
+    double x0 = x + n;
+    double x2 = (1.0 / x0) * (1.0 / x0);
+    double gl0 = a[9];
+    for (int k = 8; k >= 0; k--) gl0 = gl0 * x2 + a[k];
+    double gl = gl0 / x0 + 0.5 * 1.8378770664093453e+00 + (x0 - 0.5) * log(x0) - x0;
+    for (int k = 1; k <= n; k++) { gl -= log(x0 - 1.0); x0 -= 1.0; }
+    return gl;
+}
+
+// Poisson(lam): multiplication method below 10, PTRS (Hoermann 1993) from 10 on — numpy's random_poisson,
+// the sampler pyx:2532 calls, with a counter-based uniform source.
+static __device__ int64_t tau_poisson(TauRng &g, double lam) {
+    if (!(lam > 0.0)) return 0;
+    if (lam < 10.0) {
+        double enlam = exp(-lam), prod = 1.0;
+        int64_t X = 0;
+        while (true) {
+            prod *= g.uniform();
+            if (prod > enlam) X += 1;
+            else return X;
+        }
+    }
+    double slam = sqrt(lam), loglam = log(lam);
+    double b = 0.931 + 2.53 * slam, a = -0.059 + 0.02483 * b;
+    double invalpha = 1.1239 + 1.1328 / (b - 3.4), vr = 0.9277 - 3.6224 / (b - 2);
+    while (true) {
+        double U = g.uniform() - 0.5, V = g.uniform();
+        double us = 0.5 - fabs(U);
+        int64_t k = (int64_t)floor((2 * a / us + b) * U + lam + 0.43);
+        if (us >= 0.07 && V <= vr) return k;
+        if (k < 0 || (us < 0.013 && V > us)) continue;
+        if ((log(V) + log(invalpha) - log(a / (us * us) + b)) <= (-lam + k * loglam - tau_loggam((double)k + 1))) return k;
+    }
+}
+
+static __device__ __forceinline__ int tau_mutate(int sites, int hi, int s, int DS) {  // pyx:2420-2427
+    int digit4 = 1 << (2 * (sites - s - 1));
+    int AS = (hi / digit4) % 4;
+    if (DS >= AS) DS += 1;
+    return hi + (DS - AS) * digit4;
+}
+
+static __device__ __forceinline__ void atomic_min_pos_double(unsigned long long *addr, double v) {
+    // for non-negative doubles the bit patterns order like the values
+    atomicMin(addr, (unsigned long long)__double_as_longlong(v));
+}
+
+// ------------------------------------------------------------------------------------------------
+// Per-step, per-replicate preparation: transmission factor F[pn] = sum_spn m[pn,spn]^2 cd[spn]/as[spn]
+// (pyx:2412-2414), effectiveMigration (pyx:327-338) under the current contact densities,
+// Aeff[tpn][spn] = effMig[tpn,spn] * m[spn,spn] (pyx:2366-2367), and the out-migration weight of a source
+// population per birth class Gout[spn][cb] = sum_{tpn != spn, sn} effMig[tpn,spn] S[tpn,sn] sigma_cb[sn].
+extern "C" __global__ void __launch_bounds__(TB) vgx_tau_prep_kernel(VgxTauArgs a) {
+    const int rep = blockIdx.x;
+    const VgxDevParams &p = a.p;
+    const int P = p.P, S = p.S, CB = p.CB;
+    if (!a.active[rep]) return;
+    const double *cd = a.cd + (int64_t)rep * P;
+    double *F = a.F + (int64_t)rep * P;
+    double *eff = a.effMig + (int64_t)rep * P * P;
+    double *Aeff = a.Aeff + (int64_t)rep * P * P;
+    double *Gout = a.Gout + (int64_t)rep * P * CB;
+    const int64_t *Sus = a.S + (int64_t)rep * P * S;
+    for (int pn = threadIdx.x; pn < P; pn += TB) {
+        double f = 0.0;
+        for (int q = 0; q < P; ++q) {
+            double m = p.mig[(int64_t)pn * P + q];
+            f += m * m * cd[q] / p.actualSizes[q];
+        }
+        F[pn] = f;
+    }
+    for (int idx = threadIdx.x; idx < P * P; idx += TB) {
+        int t = idx / P, s = idx % P;  // eff[t][s]
+        double e = 0.0;
+        if (t != s)
+            for (int q = 0; q < P; ++q) e += p.mig[(int64_t)t * P + q] * p.mig[(int64_t)s * P + q] * cd[q] / p.actualSizes[q];
+        eff[idx] = e;
+        Aeff[idx] = e * p.mig[(int64_t)s * P + s];
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < P * CB; idx += TB) {
+        int spn = idx / CB, cb = idx % CB;
+        double g = 0.0;
+        for (int t = 0; t < P; ++t) {
+            if (t == spn) continue;
+            double e = eff[(int64_t)t * P + spn];
+            for (int sn = 0; sn < S; ++sn) g += e * (double)Sus[t * S + sn] * p.cb_sigma[cb * S + sn];
+        }
+        Gout[idx] = g;
+    }
+    if (threadIdx.x == 0) {
+        a.tau_bits[rep] = (unsigned long long)__double_as_longlong(1.0);  // tau_l starts at 1.0 (pyx:2437)
+        a.ok[rep] = 1;
+    }
+    for (int i = threadIdx.x; i < P * S; i += TB) a.dS[(int64_t)rep * P * S + i] = 0.0;
+}
+
+// Net drift of every infectious compartment and its tau candidate (Propensities + ChooseTau); partial
+// sums of the susceptible drift.  grid = (ceil(H/TB), P, R).
+extern "C" __global__ void __launch_bounds__(TB) vgx_tau_drift_kernel(VgxTauArgs a) {
+    const int rep = blockIdx.z, pn = blockIdx.y;
+    if (!a.active[rep]) return;
+    const VgxDevParams &p = a.p;
+    const int P = p.P, S = p.S, H = p.H, sites = p.sites;
+    const int hn = blockIdx.x * TB + threadIdx.x;
+    const int64_t *I = a.I + (int64_t)rep * P * H;
+    const int64_t *Sus = a.S + (int64_t)rep * P * S + (int64_t)pn * S;
+    __shared__ double sdS[64];      // S <= 64 susceptibility groups
+    __shared__ unsigned long long smin;
+    if (threadIdx.x < 64) sdS[threadIdx.x] = 0.0;
+    if (threadIdx.x == 0) smin = (unsigned long long)__double_as_longlong(1.0);
+    __syncthreads();
+    if (hn < H) {
+        const int c = p.cls[hn];
+        const int cb = p.c_bidx[c];
+        const double Ih = (double)I[(int64_t)pn * H + hn];
+        const double b = p.cb_b[cb];
+        double drift = 0.0;
+        // recovery and sampling (pyx:2386-2395)
+        double rec = p.c_d[c] * Ih, samp = p.c_s[c] * Ih * p.sampMult[pn];
+        drift -= rec;
+        drift -= samp;
+        if (rec + samp != 0.0) atomicAdd(&sdS[p.c_stype[c]], rec + samp);
+        // outgoing mutation (pyx:2398-2404): sum_i w_i / sum w == 1
+        drift -= p.c_tm[c] * Ih;
+        // incoming mutation: sources differ from hn in exactly one site
+        for (int s = 0; s < sites; ++s) {
+            int digit4 = 1 << (2 * (sites - s - 1));
+            int AS = (hn / digit4) % 4;
+            for (int al = 0; al < 4; ++al) {
+                if (al == AS) continue;
+                int src = hn + (al - AS) * digit4;
+                int64_t Is = I[(int64_t)pn * H + src];
+                if (Is == 0) continue;
+                int i = AS - (AS > al ? 1 : 0);  // derived-state index of `AS` in the source's numbering
+                const double *hm = p.hapMutType + ((int64_t)src * sites + s) * 3;
+                drift += p.mRate[(int64_t)src * sites + s] * hm[i] / (hm[0] + hm[1] + hm[2]) * (double)Is;
+            }
+        }
+        // transmission (pyx:2407-2417) and incoming migration (pyx:2360-2370)
+        double migI = 0.0;
+        const double *Arow = a.Aeff + ((int64_t)rep * P + pn) * P;
+        if (a.has_mig)
+            for (int spn = 0; spn < P; ++spn) {
+                if (spn == pn) continue;
+                double A = Arow[spn];
+                if (A != 0.0) migI += A * (double)I[(int64_t)spn * H + hn];
+            }
+        const double F = a.F[(int64_t)rep * P + pn];
+        for (int sn = 0; sn < S; ++sn) {
+            double sig = p.cb_sigma[cb * S + sn];
+            double base = b * sig * (double)Sus[sn];
+            double v = base * Ih * F + base * migI;
+            drift += v;
+            if (v != 0.0) atomicAdd(&sdS[sn], -v);
+        }
+        if (fabs(drift) >= 1e-8) {  // pyx:2440-2444, epsilon*X in single precision
+            float eps = 0.03f;
+            double v = (double)(eps * (float)I[(int64_t)pn * H + hn]) / 2.0;
+            double cand = (v > 1.0 ? v : 1.0) / fabs(drift);
+            atomic_min_pos_double(&smin, cand);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < S && sdS[threadIdx.x] != 0.0) atomicAdd(&a.dS[((int64_t)rep * P + pn) * S + threadIdx.x], sdS[threadIdx.x]);
+    if (threadIdx.x == 0) atomicMin(&a.tau_bits[rep], smin);
+}
+
+// Susceptible compartments: immunity-transition drift (pyx:2374-2381), tau candidates (pyx:2445-2450),
+// final tau_l; clears the per-step accumulators.  grid = R, block = 64.
+extern "C" __global__ void __launch_bounds__(64) vgx_tau_choose_kernel(VgxTauArgs a) {
+    const int rep = blockIdx.x;
+    if (!a.active[rep]) return;
+    const VgxDevParams &p = a.p;
+    const int P = p.P, S = p.S;
+    const int64_t *Sus = a.S + (int64_t)rep * P * S;
+    double *dS = a.dS + (int64_t)rep * P * S;
+    double best = 1.0;
+    for (int idx = threadIdx.x; idx < P * S; idx += 64) {
+        int pn = idx / S, sn = idx % S;
+        double d = dS[idx];
+        for (int o = 0; o < S; ++o) {
+            if (o == sn) continue;
+            d += p.suscepTransition[o * S + sn] * (double)Sus[pn * S + o];
+            d -= p.suscepTransition[sn * S + o] * (double)Sus[pn * S + sn];
+        }
+        if (fabs(d) >= 1e-8) {
+            float eps = 0.03f;
+            double v = (double)(eps * (float)Sus[idx]) / 2.0;
+            double cand = (v > 1.0 ? v : 1.0) / fabs(d);
+            if (cand < best) best = cand;
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        double other = __shfl_down(best, o);
+        if (other < best) best = other;
+    }
+    if (threadIdx.x == 0) {
+        double t = __longlong_as_double((long long)a.tau_bits[rep]);
+        a.tau[rep] = t < best ? t : best;
+        a.retry[rep] = 0;
+        a.accepted[rep] = 0;
+    }
+}
+
+// A multievent row (events.pxi:116-125) of the step being drawn; rows of a rejected retry are discarded by
+// rewinding mev_n (vgx_tau_decide_kernel).
+static __device__ __forceinline__ void tau_row(const VgxTauArgs &a, int rep, int64_t num, int type, int hap, int pop,
+                                               int nh, int np) {
+    if (a.mev_cap <= 0) return;
+    unsigned long long slot = atomicAdd(&a.mev_n[rep], 1ull);
+    if ((int64_t)slot < a.mev_cap) {
+        int64_t *row = a.mev + ((int64_t)rep * a.mev_cap + (int64_t)slot) * 6;
+        row[0] = num; row[1] = type; row[2] = hap; row[3] = pop; row[4] = nh; row[5] = np;
+    }
+}
+
+// GenerateEvents_tau for one compartment (pn, hn): draws all its channels once and books
+//   dChk : the infectious deltas the reference's bounds check looks at (pyx:2473: a migrant is booked on its
+//          SOURCE compartment there),
+//   dApp : the infectious deltas UpdateCompartmentCounts_tau applies (pyx:2548: the migrant infects the
+//          TARGET population),
+//   dS   : the susceptible deltas (identical in both), the tentative counters and multievent rows.
+// The compartment arrays themselves are not touched, so every thread sees the pre-step state.
+static __device__ __forceinline__ void tau_cell(const VgxTauArgs &a, int rep, int pn, int hn, double tau, int64_t *cnt) {
+    const VgxDevParams &p = a.p;
+    const int P = p.P, S = p.S, H = p.H, sites = p.sites;
+    const int64_t *I = a.I + (int64_t)rep * P * H;
+    int64_t *dC = a.dChk + (int64_t)rep * P * H;
+    int64_t *dA = a.dApp + (int64_t)rep * P * H;
+    const int64_t *Sus = a.S + (int64_t)rep * P * S;
+    int64_t *dS = a.dSi + (int64_t)rep * P * S;
+    const int64_t Icell = I[(int64_t)pn * H + hn];
+    if (Icell == 0) return;
+    const double Ih = (double)Icell;
+    const int c = p.cls[hn];
+    const int cb = p.c_bidx[c];
+    const int st = p.c_stype[c];
+    TauRng g;
+    g.init((uint64_t)a.seeds[rep], (uint32_t)a.attempt[rep], (uint64_t)pn * (uint64_t)H + (uint64_t)hn, (uint32_t)a.step[rep],
+           (uint32_t)a.retry[rep]);
+    int64_t own = 0, migrants = 0;
+    // ---- migration out of (pn, hn): one Poisson, multinomial split (pyx:2464-2474 / 2541-2550) ----
+    if (a.has_mig) {
+        double G = a.Gout[((int64_t)rep * P + pn) * p.CB + cb];
+        double lam = G * Ih * p.cb_b[cb] * p.mig[(int64_t)pn * P + pn] * tau;
+        int64_t M = tau_poisson(g, lam);
+        const double *eff = a.effMig + (int64_t)rep * P * P;
+        for (int64_t k = 0; k < M; ++k) {
+            double u = g.uniform() * G, acc = 0.0;
+            int tp = -1, ts = 0;
+            for (int t = 0; t < P && tp < 0; ++t) {
+                if (t == pn) continue;
+                double e = eff[(int64_t)t * P + pn];
+                if (e == 0.0) continue;
+                for (int sn = 0; sn < S; ++sn) {
+                    acc += e * (double)Sus[t * S + sn] * p.cb_sigma[cb * S + sn];
+                    if (u < acc) { tp = t; ts = sn; break; }
+                }
+            }
+            if (tp < 0) {  // rounding at the upper end: last channel with a non-zero weight
+                for (int t = P - 1; t >= 0 && tp < 0; --t) {
+                    if (t == pn) continue;
+                    for (int sn = S - 1; sn >= 0; --sn)
+                        if (eff[(int64_t)t * P + pn] * (double)Sus[t * S + sn] * p.cb_sigma[cb * S + sn] > 0.0) { tp = t; ts = sn; break; }
+                }
+            }
+            if (tp < 0) continue;
+            migrants += 1;
+            atomicAdd((unsigned long long *)&dA[(int64_t)tp * H + hn], 1ull);
+            atomicAdd((unsigned long long *)&dS[tp * S + ts], (unsigned long long)(-1ll));
+            atomicAdd((unsigned long long *)&a.dTot[(int64_t)rep * P + tp], 1ull);
+            cnt[5] += 1;
+            tau_row(a, rep, 1, 5, hn, pn, ts, tp);
+        }
+    }
+    // ---- recovery, sampling (pyx:2492-2503 / 2567-2576) ----
+    int64_t rec = tau_poisson(g, p.c_d[c] * Ih * tau);
+    int64_t samp = tau_poisson(g, p.c_s[c] * Ih * p.sampMult[pn] * tau);
+    if (rec) { cnt[1] += rec; tau_row(a, rep, rec, 1, hn, pn, st, 0); }
+    if (samp) { cnt[2] += samp; tau_row(a, rep, samp, 2, hn, pn, st, 0); }
+    own -= rec + samp;
+    // ---- mutations (pyx:2506-2512 / 2579-2586) ----
+    for (int s = 0; s < sites; ++s) {
+        const double *hm = p.hapMutType + ((int64_t)hn * sites + s) * 3;
+        double wsum = hm[0] + hm[1] + hm[2];
+        double mr = p.mRate[(int64_t)hn * sites + s];
+        for (int i = 0; i < 3; ++i) {
+            int64_t k = tau_poisson(g, mr * hm[i] / wsum * Ih * tau);
+            if (k == 0) continue;
+            int nh = tau_mutate(sites, hn, s, i);
+            own -= k;
+            atomicAdd((unsigned long long *)&dC[(int64_t)pn * H + nh], (unsigned long long)k);
+            atomicAdd((unsigned long long *)&dA[(int64_t)pn * H + nh], (unsigned long long)k);
+            cnt[3] += k;
+            tau_row(a, rep, k, 3, hn, pn, nh, 0);
+        }
+    }
+    // ---- transmission (pyx:2515-2520 / 2589-2593) ----
+    const double F = a.F[(int64_t)rep * P + pn];
+    int64_t births = 0;
+    for (int sn = 0; sn < S; ++sn) {
+        double lam = p.cb_b[cb] * p.cb_sigma[cb * S + sn] * (double)Sus[pn * S + sn] * Ih * F * tau;
+        int64_t k = tau_poisson(g, lam);
+        if (k == 0) continue;
+        births += k;
+        atomicAdd((unsigned long long *)&dS[pn * S + sn], (unsigned long long)(-k));
+        cnt[0] += k;
+        tau_row(a, rep, k, 0, hn, pn, sn, 0);
+    }
+    own += births;
+    if (own + migrants != 0) atomicAdd((unsigned long long *)&dC[(int64_t)pn * H + hn], (unsigned long long)(own + migrants));
+    if (own != 0) atomicAdd((unsigned long long *)&dA[(int64_t)pn * H + hn], (unsigned long long)own);
+    if (rec + samp != 0) atomicAdd((unsigned long long *)&dS[pn * S + st], (unsigned long long)(rec + samp));
+    int64_t dt = births - rec - samp;
+    if (dt != 0) atomicAdd((unsigned long long *)&a.dTot[(int64_t)rep * P + pn], (unsigned long long)dt);
+}
+
+// grid = (ceil(H/TB), P, R); dChk/dApp/dSi/dTot are zero on entry
+extern "C" __global__ void __launch_bounds__(TB) vgx_tau_draw_kernel(VgxTauArgs a) {
+    const int rep = blockIdx.z, pn = blockIdx.y;
+    if (!a.active[rep] || a.accepted[rep]) return;
+    const int hn = blockIdx.x * TB + threadIdx.x;
+    int64_t cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (hn < a.p.H) tau_cell(a, rep, pn, hn, a.tau[rep], cnt);
+    __shared__ unsigned long long sc[8];
+    if (threadIdx.x < 8) sc[threadIdx.x] = 0;
+    __syncthreads();
+    for (int i = 0; i < 6; ++i)
+        if (cnt[i]) atomicAdd(&sc[i], (unsigned long long)cnt[i]);
+    __syncthreads();
+    if (threadIdx.x < 6 && sc[threadIdx.x]) atomicAdd((unsigned long long *)&a.cnt_try[(int64_t)rep * 8 + threadIdx.x], sc[threadIdx.x]);
+}
+
+// Immunity transitions (pyx:2479-2487 / 2554-2562): P*S*S slots per replicate, one thread each.
+extern "C" __global__ void __launch_bounds__(TB) vgx_tau_suscep_draw_kernel(VgxTauArgs a) {
+    const int rep = blockIdx.y;
+    if (!a.active[rep] || a.accepted[rep]) return;
+    const VgxDevParams &p = a.p;
+    const int P = p.P, S = p.S;
+    const int idx = blockIdx.x * TB + threadIdx.x;
+    if (idx >= P * S * S) return;
+    int pn = idx / (S * S), rest = idx % (S * S), ssn = rest / S, tsn = rest % S;
+    if (ssn == tsn) return;
+    const int64_t *Sus = a.S + (int64_t)rep * P * S;
+    int64_t *dS = a.dSi + (int64_t)rep * P * S;
+    double lam = p.suscepTransition[ssn * S + tsn] * (double)Sus[pn * S + ssn] * a.tau[rep];
+    if (!(lam > 0.0)) return;
+    TauRng g;
+    g.init((uint64_t)a.seeds[rep], (uint32_t)a.attempt[rep], ((uint64_t)1 << 62) + (uint64_t)idx, (uint32_t)a.step[rep], (uint32_t)a.retry[rep]);
+    int64_t k = tau_poisson(g, lam);
+    if (k == 0) return;
+    atomicAdd((unsigned long long *)&dS[pn * S + tsn], (unsigned long long)k);
+    atomicAdd((unsigned long long *)&dS[pn * S + ssn], (unsigned long long)(-k));
+    atomicAdd((unsigned long long *)&a.cnt_try[(int64_t)rep * 8 + 4], (unsigned long long)k);
+    tau_row(a, rep, k, 4, ssn, pn, tsn, 0);
+}
+
+// Bounds check of GenerateEvents_tau (pyx:2522-2528).  grid = (ceil(H/TB), P, R).
+extern "C" __global__ void __launch_bounds__(TB) vgx_tau_check_kernel(VgxTauArgs a) {
+    const int rep = blockIdx.z, pn = blockIdx.y;
+    if (!a.active[rep] || a.accepted[rep]) return;
+    const VgxDevParams &p = a.p;
+    const int P = p.P, S = p.S, H = p.H;
+    const int hn = blockIdx.x * TB + threadIdx.x;
+    bool bad = false;
+    if (hn < H) {
+        int64_t d = a.dChk[(int64_t)rep * P * H + (int64_t)pn * H + hn];
+        if (d != 0) {
+            int64_t v = d + a.I[(int64_t)rep * P * H + (int64_t)pn * H + hn];
+            bad = v < 0 || v > p.sizes[pn];
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x < S) {
+        int64_t v = a.dSi[((int64_t)rep * P + pn) * S + threadIdx.x] + a.S[((int64_t)rep * P + pn) * S + threadIdx.x];
+        if (v < 0 || v > p.sizes[pn]) bad = true;
+    }
+    if (__any(bad)) {
+        if ((threadIdx.x & 63) == 0) a.ok[rep] = 0;
+    }
+}
+
+// After the check of one retry: accept, or halve tau and discard the tentative tallies (pyx:2316-2321).
+// grid = R, block = 64.  `deciding` marks the replicates whose deltas the commit kernel must now handle.
+extern "C" __global__ void __launch_bounds__(64) vgx_tau_decide_kernel(VgxTauArgs a) {
+    const int rep = blockIdx.x;
+    if (threadIdx.x != 0) return;
+    a.deciding[rep] = 0;
+    if (!a.active[rep] || a.accepted[rep]) return;
+    a.deciding[rep] = 1;
+    if (a.ok[rep]) {
+        a.accepted[rep] = 1;
+        for (int i = 0; i < 6; ++i) { a.counters[(int64_t)rep * 8 + i] += a.cnt_try[(int64_t)rep * 8 + i]; }
+        int64_t drawn = 0;
+        for (int i = 0; i < 6; ++i) { drawn += a.cnt_try[(int64_t)rep * 8 + i]; a.cnt_try[(int64_t)rep * 8 + i] = 0; }
+        a.counters[(int64_t)rep * 8 + 7] += drawn;  // total events drawn (throughput metric)
+    } else {
+        a.tau[rep] *= 0.5;
+        a.retry[rep] += 1;
+        a.ok[rep] = 1;
+        for (int i = 0; i < 6; ++i) a.cnt_try[(int64_t)rep * 8 + i] = 0;
+        a.mev_n[rep] = a.mev_base[rep];
+        if (a.retry[rep] > 200) { a.accepted[rep] = 1; a.error[rep] = 5; }  // loop guard (tau underflow)
+    }
+}
+
+// UpdateCompartmentCounts_tau for accepted replicates (I += dApp, S += dS, totals), clearing of the delta
+// arrays for both accepted and rejected ones.  grid = (ceil(H/TB), P, R).
+extern "C" __global__ void __launch_bounds__(TB) vgx_tau_commit_kernel(VgxTauArgs a) {
+    const int rep = blockIdx.z, pn = blockIdx.y;
+    if (!a.deciding[rep]) return;
+    const int P = a.p.P, S = a.p.S, H = a.p.H;
+    const bool acc = a.accepted[rep] && !a.error[rep];
+    const int hn = blockIdx.x * TB + threadIdx.x;
+    if (hn < H) {
+        int64_t off = (int64_t)rep * P * H + (int64_t)pn * H + hn;
+        int64_t dA = a.dApp[off];
+        if (dA != 0) { if (acc) a.I[off] += dA; a.dApp[off] = 0; }
+        if (a.dChk[off] != 0) a.dChk[off] = 0;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < S) {
+        int64_t off = ((int64_t)rep * P + pn) * S + threadIdx.x;
+        if (acc) a.S[off] += a.dSi[off];
+        a.dSi[off] = 0;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        int64_t off = (int64_t)rep * P + pn;
+        if (acc) a.totInf[off] += a.dTot[off];
+        a.dTot[off] = 0;
+    }
+}
+
+// End of a step (pyx:2322-2329): globalInfectious, CheckLockdown for every population (contact density
+// only: the step kernels rebuild what they need from it).  grid = R, block = 64.
+extern "C" __global__ void __launch_bounds__(64) vgx_tau_finish_kernel(VgxTauArgs a) {
+    const int rep = blockIdx.x;
+    if (!a.active[rep]) return;
+    const VgxDevParams &p = a.p;
+    const int P = p.P;
+    const int lane = threadIdx.x;
+    long long part = 0;
+    for (int pn = lane; pn < P; pn += 64) part += a.totInf[(int64_t)rep * P + pn];
+    for (int o = 32; o > 0; o >>= 1) part += __shfl_down(part, o);
+    long long g = __shfl(part, 0);
+    if (g != 0) {  // pyx:2326-2329: no lockdown check after extinction
+        for (int pn = lane; pn < P; pn += 64) {
+            int64_t ti = a.totInf[(int64_t)rep * P + pn];
+            int32_t *lock = a.lockON + (int64_t)rep * P + pn;
+            double *cd = a.cd + (int64_t)rep * P + pn;
+            for (int pass = 0; pass < 2; ++pass) {
+                bool flip = pass == 0 ? ((double)ti > p.startLD[pn] * (double)p.sizes[pn] && *lock == 0)
+                                      : ((double)ti < p.endLD[pn] * (double)p.sizes[pn] && *lock == 1);
+                if (flip) {
+                    *cd = pass == 0 ? p.cdAfter[pn] : p.cdBefore[pn];
+                    *lock = pass == 0 ? 1 : 0;
+                    unsigned long long slot = atomicAdd(&a.loc_n[rep], 1ull);
+                    if (slot < VGX_LOC_CAP) {
+                        a.loc_rec[((int64_t)rep * VGX_LOC_CAP + slot) * 2 + 0] = pass == 0 ? 1 : 0;
+                        a.loc_rec[((int64_t)rep * VGX_LOC_CAP + slot) * 2 + 1] = pn;
+                        a.loc_time[(int64_t)rep * VGX_LOC_CAP + slot] = a.time_now[rep] + a.tau[rep];
+                    }
+                    atomicAdd((unsigned long long *)&a.counters[(int64_t)rep * 8 + 6], 1ull);  // swapLockdown
+                }
+            }
+        }
+    }
+    if (lane == 0) a.gI[rep] = g;
+}
+
+// ---- launchers -----------------------------------------------------------------------------------
+#define TAU_LAUNCH(name, grid, block)                                                            \
+    extern "C" __attribute__((visibility("hidden"))) hipError_t vgxi_##name(const VgxTauArgs *a, \
+                                                                           hipStream_t s) {      \
+        hipLaunchKernelGGL(vgx_##name##_kernel, grid, block, 0, s, *a);                          \
+        return hipGetLastError();                                                                \
+    }
+#define CELL_GRID dim3((unsigned)((a->p.H + TB - 1) / TB), (unsigned)a->p.P, (unsigned)a->R)
+#define SUS_GRID dim3((unsigned)((a->p.P * a->p.S * a->p.S + TB - 1) / TB), (unsigned)a->R)
+TAU_LAUNCH(tau_prep, dim3((unsigned)a->R), dim3(TB))
+TAU_LAUNCH(tau_drift, CELL_GRID, dim3(TB))
+TAU_LAUNCH(tau_choose, dim3((unsigned)a->R), dim3(64))
+TAU_LAUNCH(tau_draw, CELL_GRID, dim3(TB))
+TAU_LAUNCH(tau_suscep_draw, SUS_GRID, dim3(TB))
+TAU_LAUNCH(tau_check, CELL_GRID, dim3(TB))
+TAU_LAUNCH(tau_decide, dim3((unsigned)a->R), dim3(64))
+TAU_LAUNCH(tau_commit, CELL_GRID, dim3(TB))
+TAU_LAUNCH(tau_finish, dim3((unsigned)a->R), dim3(64))
