@@ -147,9 +147,6 @@ int64_t vgx_device_bytes(const vgx_engine *e);
 /* Diagnostic build only (libvgx built with -DVGX_PROFILE): 16 per-phase shader-cycle sums of the last direct
  * call for one replicate (phase list: tools/profile_phases.py); all zeros in the product build. */
 int vgx_get_profile(vgx_engine *e, int64_t replicate, int64_t *out16);
-/* Standalone streaming kernels over the engine's resident state (roofline measurement):
- * dense propensity rebuild + scan of every (replicate, population) row. Returns device ms in *ms. */
-int vgx_bench_propensity_scan(vgx_engine *e, int64_t repeats, double *ms, int64_t *bytes_per_launch);
 
 #ifdef __cplusplus
 }

@@ -70,7 +70,6 @@ SIGNATURES = {
     "vgx_last_kernel_launches": (C.c_int64, [_H]),
     "vgx_device_bytes": (C.c_int64, [_H]),
     "vgx_get_profile": (C.c_int, [_H, C.c_int64, _I]),
-    "vgx_bench_propensity_scan": (C.c_int, [_H, C.c_int64, _F, _I]),
 }
 
 _lib = None

@@ -1147,8 +1147,3 @@ extern "C" int vgx_get_profile(vgx_engine *e, int64_t replicate, int64_t *out16)
     HIPCHECK(e, hipMemcpy(out16, (unsigned long long *)e->r_prof.p + replicate * VGX_PROF_SLOTS, VGX_PROF_SLOTS * 8, hipMemcpyDeviceToHost));
     return VGX_OK;
 }
-
-extern "C" int vgx_bench_propensity_scan(vgx_engine *e, int64_t, double *, int64_t *) {
-    if (!e) return VGX_ERR_ARG;
-    return fail(e, VGX_ERR_ARG, "vgx_bench_propensity_scan: not built into this library yet");
-}
