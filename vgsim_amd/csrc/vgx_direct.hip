@@ -46,6 +46,8 @@
 
 enum { ERR_ZERO_WEIGHT = 3, ERR_CAPACITY = 4, ERR_LOOP_GUARD = 5 };
 enum { EV_BIRTH = 0, EV_DEATH, EV_SAMPLING, EV_MUTATION, EV_SUSCCHANGE, EV_MIGRATION };
+enum { CNT_B = 0, CNT_D, CNT_S, CNT_M, CNT_I, CNT_SWAP, CNT_MIGP, CNT_MIGN };
+#define BUMP(i) do { if (c.lane == 0) c.cnt[i] += 1; } while (0)
 
 // the occupancy-list tile of one population held in registers (lane k <-> entry k) while it has <= 64 entries
 struct Tile {
@@ -53,7 +55,49 @@ struct Tile {
     int pi, n;
     int hap, cls;
     int64_t cnt;
+    double mrow0;  // migrationRates[pi][lane], fetched together with the tile (first 64 populations)
 };
+
+// 64 PCG64 outputs per refill: lane k jumps the stream k+1 steps ahead (state*a^(k+1) + inc*(a^k+...+1), exact
+// 128-bit arithmetic), so the uniforms are the reference's, in order.  Even lanes hold -log(u) for SampleTime
+// (pyx:477), odd lanes the uniform of GenerateEvent (pyx:488): 32 loop iterations per refill, and the logarithm
+// is evaluated 32-wide instead of once per iteration on one lane.
+struct RngBatch {
+    uint64_t Ah, Al, Gh, Gl;   // per lane: a^(lane+1), sum_{j<=lane} a^j
+    uint64_t sh, sl, ih, il;   // stream position before the batch; increment
+    double val;
+    int pos;                   // iterations consumed from the current batch (32 = empty)
+};
+static __device__ __forceinline__ void rng_init_lane(RngBatch &g, int lane) {
+    const uint64_t MH = 0x2360ED051FC65DA4ull, ML = 0x4385DF649FCCF645ull;
+    uint64_t Ah = MH, Al = ML, Gh = 0, Gl = 1;
+    for (int j = 1; j < LANES; ++j) {
+        uint64_t nh, nl, gh, gl;
+        vgx_mul128(Ah, Al, MH, ML, nh, nl);
+        vgx_mul128(Gh, Gl, MH, ML, gh, gl);
+        vgx_add128(gh, gl, 0, 1);
+        if (j <= lane) { Ah = nh; Al = nl; Gh = gh; Gl = gl; }
+    }
+    g.Ah = Ah; g.Al = Al; g.Gh = Gh; g.Gl = Gl;
+    g.pos = 32;
+}
+static __device__ __forceinline__ void rng_seed(RngBatch &g, uint64_t seed, uint32_t attempt) {
+    VgxPcg64 s;
+    vgx_pcg64_seed(s, seed, attempt);
+    g.sh = s.sh; g.sl = s.sl; g.ih = s.ih; g.il = s.il;
+    g.pos = 32;
+}
+static __device__ __forceinline__ void rng_refill(RngBatch &g, int lane) {
+    uint64_t h, l, ch, cl;
+    vgx_mul128(g.Ah, g.Al, g.sh, g.sl, h, l);
+    vgx_mul128(g.Gh, g.Gl, g.ih, g.il, ch, cl);
+    vgx_add128(h, l, ch, cl);
+    double u = vgx_pcg64_output_double(h, l);
+    g.val = (lane & 1) ? u : -vgx_log(u);
+    g.sh = (uint64_t)bcast_i64((int64_t)h, LANES - 1);
+    g.sl = (uint64_t)bcast_i64((int64_t)l, LANES - 1);
+    g.pos = 0;
+}
 
 struct Ctx {
     int P, S, H, C, CB, sites, lane;
@@ -91,10 +135,11 @@ struct Ctx {
     // ---- wave-uniform scalars ----
     double currentTime, totalRate, totalMig, rn;
     int64_t gI;
-    int64_t bC, dC, sC, mC, iC, swapLD, migPlus, migNon;
+    int64_t *cnt;      // LDS [8]: bCounter, dCounter, sCounter, mCounter, iCounter, swapLockdown, migPlus, migNonPlus
     int64_t ev_ptr, ev_size, loc_n;
     int error;
     bool has_mig;  // some maxEffectiveBirthMigration > 0
+    bool ld_any;   // some population can switch its lockdown state at all
 #ifdef VGX_PROFILE
     unsigned long long prof_t0, prof_acc[VGX_PROF_SLOTS];
 #endif
@@ -165,6 +210,7 @@ static __device__ __forceinline__ void tile_load(Ctx &c, Tile &t, int pi) {
     t.n = c.nocc[pi];
     t.valid = t.n <= LANES;
     t.hap = 0; t.cls = 0; t.cnt = 0;
+    t.mrow0 = (c.lane < c.P) ? c.p->mig[(int64_t)pi * c.P + c.lane] : 0.0;
     if (t.valid && c.lane < t.n) {
         t.hap = LH(c, pi)[c.lane];
         t.cls = LC(c, pi)[c.lane];
@@ -250,9 +296,10 @@ static __device__ void list_add(Ctx &c, int pi, int hap, int64_t delta) {
 
 // ------------------------------------------------------------------------------------------------
 // BirthRate per class (pyx:382-392): ps += susceptHapPopRate * m * m * cd / as over (sn, pn), in order.
-static __device__ void birth_update(Ctx &c, int pi) {
+static __device__ void birth_update(Ctx &c, int pi, const Tile &t) {
     const int P = c.P, S = c.S, lane = c.lane;
     const double *mrow = c.p->mig + (int64_t)pi * P;
+    const bool pref = (t.pi == pi);
     for (int cb = 0; cb < c.CB; ++cb) {
         double ps = 0.0;
         for (int sn = 0; sn < S; ++sn) {
@@ -260,12 +307,12 @@ static __device__ void birth_update(Ctx &c, int pi) {
             if (lane == 0) c.xC[(pi * c.CB + cb) * S + sn] = x;
             for (int base = 0; base < P; base += LANES) {
                 int pn = base + lane;
-                double t = 0.0;
+                double tv = 0.0;
                 if (pn < P) {
-                    double m = mrow[pn];
-                    t = x * m * m * c.cd[pn] / c.as[pn];
+                    double m = (pref && base == 0) ? t.mrow0 : mrow[pn];
+                    tv = x * m * m * c.cd[pn] / c.as[pn];
                 }
-                ps = seq_sum(t, min(LANES, P - base), ps);
+                ps = seq_sum(tv, min(LANES, P - base), ps);
             }
         }
         if (lane == 0) c.birthC[pi * c.CB + cb] = c.cb_b[cb] * ps;
@@ -402,7 +449,7 @@ static __device__ __forceinline__ void update(Ctx &c, const UpdReq &q, const Til
     const int P = c.P, S = c.S, lane = c.lane;
     for (int pn = q.lo; pn < q.hi; ++pn) {
         if (q.infect) {
-            birth_update(c, pn);
+            birth_update(c, pn, t);
             PROF(8);
             tE_fill(c, pn);
             PROF(9);
@@ -495,7 +542,7 @@ static __device__ __forceinline__ bool check_lockdowns(Ctx &c, int lo, int hi) {
                     }
                 }
                 if (c.loc_n >= VGX_LOC_CAP) c.error = ERR_CAPACITY;
-                c.swapLD += 1;
+                BUMP(CNT_SWAP);
                 c.loc_n += 1;
                 any = true;
                 WSYNC();
@@ -569,7 +616,7 @@ static __device__ __forceinline__ int generate_event(Ctx &c, double u, Tile &t, 
             }
             WSYNC();
             q.immune = true;
-            c.iC += 1;
+            BUMP(CNT_I);
             ev.type = EV_SUSCCHANGE; ev.hap = ssi; ev.pop = pi; ev.nh = tsi; ev.np = 0;
         } else {
             c.rn = (choose - c.immune[pi]) / c.infect[pi];
@@ -602,7 +649,7 @@ static __device__ __forceinline__ int generate_event(Ctx &c, double u, Tile &t, 
                 if (lane == 0) c.immSrc[pi * S + si] = c.cumul[si] * (double)c.sus[pi * S + si];
                 WSYNC();
                 q.immune = true; q.migration = true;
-                c.bC += 1;
+                BUMP(CNT_B);
                 ev.type = EV_BIRTH; ev.hap = hi; ev.pop = pi; ev.nh = si; ev.np = c.H;
             } else if (ei == 1 || ei == 2) {
                 // ---- Death / Sampling (pyx:616-635) ----
@@ -626,7 +673,7 @@ static __device__ __forceinline__ int generate_event(Ctx &c, double u, Tile &t, 
                 if (lane == 0) c.immSrc[pi * S + st] = (double)c.sus[pi * S + st] * c.cumul[st];
                 WSYNC();
                 q.immune = true; q.migration = true;
-                if (ei == 2) { c.sC += 1; ev.type = EV_SAMPLING; } else { c.dC += 1; ev.type = EV_DEATH; }
+                if (ei == 2) { BUMP(CNT_S); ev.type = EV_SAMPLING; } else { BUMP(CNT_D); ev.type = EV_DEATH; }
                 ev.hap = hi; ev.pop = pi; ev.nh = st; ev.np = 0;
             } else {
                 // ---- Mutation (pyx:640-667) ----
@@ -640,7 +687,7 @@ static __device__ __forceinline__ int generate_event(Ctx &c, double u, Tile &t, 
                 op0.pi = pi; op0.hap = nhi; op0.delta = +1;
                 op1.pi = pi; op1.hap = hi; op1.delta = -1;
                 n_ops = 2;
-                c.mC += 1;
+                BUMP(CNT_M);
                 ev.type = EV_MUTATION; ev.hap = hi; ev.pop = pi; ev.nh = nhi; ev.np = 0;
             }
         }
@@ -709,10 +756,10 @@ static __device__ __forceinline__ int generate_event(Ctx &c, double u, Tile &t, 
             counters_infect(c, tpi, si);
             op0.pi = tpi; op0.hap = hi; op0.delta = +1; n_ops = 1;
             q.any = true; q.lo = tpi; q.hi = tpi + 1; q.infect = true; q.immune = true; q.migration = true;
-            c.migPlus += 1;
+            BUMP(CNT_MIGP);
             ev.type = EV_MIGRATION; ev.hap = hi; ev.pop = spi; ev.nh = si; ev.np = tpi;
         } else {
-            c.migNon += 1;
+            BUMP(CNT_MIGN);
         }
     }
     PROF(5);
@@ -724,8 +771,7 @@ static __device__ __forceinline__ int generate_event(Ctx &c, double u, Tile &t, 
 static __device__ __forceinline__ void restart_state(Ctx &c, const VgxDevRep &r) {
     const int P = c.P, S = c.S, lane = c.lane;
     c.ev_ptr = 0;
-    c.bC = c.dC = c.sC = c.mC = c.iC = 0;
-    c.migPlus = c.migNon = 0;
+    if (lane < 8 && lane != CNT_SWAP) c.cnt[lane] = 0;  // swapLockdown survives a Restart (pyx:714-738)
     c.currentTime = 0.0;
     c.traj_next = 0;
     int64_t g = 0;
@@ -784,6 +830,7 @@ extern "C" __global__ void __launch_bounds__(LANES) vgx_direct_kernel(VgxDirectA
     int64_t *li = (int64_t *)ld;
     c.totalSus = li; li += P;   c.totalInf = li; li += P;   c.lockON = li; li += P;
     c.sus = li; li += P * S;
+    c.cnt = li; li += 8;
     int32_t *l4 = (int32_t *)li;
     c.nocc = l4; l4 += P;
     c.c_bidx = l4; l4 += C;
@@ -833,20 +880,35 @@ extern "C" __global__ void __launch_bounds__(LANES) vgx_direct_kernel(VgxDirectA
     VgxRepScalars *sc = r.sc + rep;
     c.currentTime = sc->currentTime; c.totalRate = 0.0; c.totalMig = 0.0; c.rn = 0.0;
     c.gI = sc->globalInfectious;
-    c.bC = sc->bCounter; c.dC = sc->dCounter; c.sC = sc->sCounter; c.mC = sc->mCounter; c.iC = sc->iCounter;
-    c.swapLD = sc->swapLockdown; c.migPlus = sc->migPlus; c.migNon = sc->migNonPlus;
+    if (lane == 0) {
+        c.cnt[CNT_B] = sc->bCounter; c.cnt[CNT_D] = sc->dCounter; c.cnt[CNT_S] = sc->sCounter; c.cnt[CNT_M] = sc->mCounter;
+        c.cnt[CNT_I] = sc->iCounter; c.cnt[CNT_SWAP] = sc->swapLockdown; c.cnt[CNT_MIGP] = sc->migPlus;
+        c.cnt[CNT_MIGN] = sc->migNonPlus;
+    }
     c.ev_ptr = sc->ev_ptr; c.ev_size = a.ev_size; c.loc_n = 0; c.error = 0;
     c.traj_next = 0;
     c.has_mig = true;
     WSYNC();
+    {   // a population can switch on only if its threshold lies below its size (S + I of a population is conserved,
+        // so totalInfectious[pn] <= sizes[pn]) and off only if it is on
+        bool possible = false;
+        for (int base = 0; base < P; base += LANES) {
+            int pn = base + lane;
+            bool pp = pn < P && (c.ldStart[pn] < (double)p.sizes[pn] || c.lockON[pn] != 0);
+            possible = possible || (__ballot(pp) != 0ull);
+        }
+        c.ld_any = possible;
+    }
 
     const double tlimit = (double)a.time;
     const bool has_tlimit = !(a.time == -1.0f);
     const int64_t seed = r.seeds[rep];
     int64_t loops = 0, restarts = 0, good_attempt = sc->good_attempt;
     int64_t att = 0;
-    VgxPcg64 g;
+    RngBatch g;
+    rng_init_lane(g, lane);
     g.sh = g.sl = g.ih = g.il = 0;
+    g.val = 0.0;
 
     // The reference's control flow (pyx:399-418) as one loop with one call site per large routine:
     //   rebuild : [CheckLockdown for all populations] + UpdateAllRates   (PrepareParameters tail, Restart tail)
@@ -862,7 +924,7 @@ extern "C" __global__ void __launch_bounds__(LANES) vgx_direct_kernel(VgxDirectA
     while (!finished && !c.error) {
         PROF(0);
         Tile t;
-        t.valid = false; t.pi = -1; t.n = 0; t.hap = 0; t.cls = 0; t.cnt = 0;
+        t.valid = false; t.pi = -1; t.n = 0; t.hap = 0; t.cls = 0; t.cnt = 0; t.mrow0 = 0.0;
         UpdReq q;
         q.any = false; q.infect = false; q.immune = false; q.migration = false; q.full = false; q.lo = 0; q.hi = 0;
         ListOp op0, op1;
@@ -878,21 +940,22 @@ extern "C" __global__ void __launch_bounds__(LANES) vgx_direct_kernel(VgxDirectA
         } else {
             if (!attempt_open) {
                 if (att >= a.attempts) { finished = true; continue; }
-                vgx_pcg64_seed(g, (uint64_t)seed, (uint32_t)att);
+                rng_seed(g, (uint64_t)seed, (uint32_t)att);
                 attempt_open = true;
                 if (!(c.totalRate + c.totalMig != 0.0 && c.gI != 0)) end_attempt = true;  // pyx:404
             }
-            if (!end_attempt && !(c.ev_ptr < c.ev_size && (a.sample_size == -1 || c.sC <= a.sample_size) &&
+            if (!end_attempt && !(c.ev_ptr < c.ev_size && (a.sample_size == -1 || c.cnt[CNT_S] <= a.sample_size) &&
                                   (!has_tlimit || c.currentTime < tlimit)))
                 end_attempt = true;  // pyx:405-407
             if (!end_attempt) {
                 if (loops >= a.max_loop) { c.error = ERR_LOOP_GUARD; continue; }
                 loops += 1;
-                double u1 = vgx_pcg64_double(g);
-                double t_new = c.currentTime + (-vgx_log(u1) / (c.totalRate + c.totalMig));  // SampleTime pyx:476-478
+                if (g.pos == 32) rng_refill(g, lane);
+                double nlog = bcast(g.val, 2 * g.pos), u2 = bcast(g.val, 2 * g.pos + 1);
+                g.pos += 1;
+                double t_new = c.currentTime + (nlog / (c.totalRate + c.totalMig));  // SampleTime pyx:476-478
                 if (c.traj) traj_emit(c, t_new, false);
                 c.currentTime = t_new;
-                double u2 = vgx_pcg64_double(g);
                 PROF(1);
                 int pi = generate_event(c, u2, t, q, op0, op1, n_ops, ev);
                 if (c.error) continue;
@@ -912,7 +975,7 @@ extern "C" __global__ void __launch_bounds__(LANES) vgx_direct_kernel(VgxDirectA
             for (int round = 0; round < 2; ++round) {  // the one call site of the rate routines
                 if (round == 1) {
                     if (!rebuild && (c.totalRate == 0.0 || c.gI == 0)) { end_attempt = true; break; }  // pyx:410-411
-                    bool switched = check_lockdowns(c, lk_lo, lk_hi);  // pyx:412 / pyx:449-450 / pyx:736-737
+                    bool switched = c.ld_any && check_lockdowns(c, lk_lo, lk_hi);  // pyx:412 / pyx:449-450 / pyx:736-737
                     if (!switched && !rebuild) break;
                     q.any = true; q.full = true; q.infect = true; q.immune = true; q.migration = true;
                     q.lo = 0; q.hi = P;
@@ -963,8 +1026,9 @@ extern "C" __global__ void __launch_bounds__(LANES) vgx_direct_kernel(VgxDirectA
     if (lane == 0) {
         sc->currentTime = c.currentTime; sc->totalRate = c.totalRate; sc->totalMig = c.totalMig;
         sc->globalInfectious = c.gI;
-        sc->bCounter = c.bC; sc->dCounter = c.dC; sc->sCounter = c.sC; sc->mCounter = c.mC; sc->iCounter = c.iC;
-        sc->swapLockdown = c.swapLD; sc->migPlus = c.migPlus; sc->migNonPlus = c.migNon;
+        sc->bCounter = c.cnt[CNT_B]; sc->dCounter = c.cnt[CNT_D]; sc->sCounter = c.cnt[CNT_S]; sc->mCounter = c.cnt[CNT_M];
+        sc->iCounter = c.cnt[CNT_I]; sc->swapLockdown = c.cnt[CNT_SWAP]; sc->migPlus = c.cnt[CNT_MIGP];
+        sc->migNonPlus = c.cnt[CNT_MIGN];
         sc->good_attempt = good_attempt;
         sc->ev_ptr = c.ev_ptr; sc->loop_iterations = loops; sc->restarts = restarts;
         sc->loc_n = c.loc_n; sc->error = c.error; sc->traj_next = c.traj_next;
@@ -1003,7 +1067,7 @@ extern "C" __global__ void __launch_bounds__(LANES) vgx_init_reps_kernel(
 extern "C" __attribute__((visibility("hidden"))) size_t vgxi_direct_lds_bytes(int P, int S, int C, int CB) {
     size_t f64 = 12 * (size_t)P + (size_t)P * S + (size_t)P * CB + (size_t)P * CB * S + 4 * (size_t)C + CB +
                  (size_t)CB * S + S + (size_t)S * S;
-    size_t i64 = 3 * (size_t)P + (size_t)P * S;
+    size_t i64 = 3 * (size_t)P + (size_t)P * S + 8;
     size_t i32 = (size_t)P + 2 * (size_t)C;
     return (f64 + i64) * 8 + ((i32 * 4 + 15) / 16) * 16;
 }

@@ -98,6 +98,23 @@ VGX_HD double vgx_pcg64_double(VgxPcg64 &g) {
     return (double)(vgx_pcg64_next(g) >> 11) * (1.0 / 9007199254740992.0);
 }
 
+// 128-bit helpers (mod 2^128)
+VGX_HD void vgx_mul128(uint64_t ah, uint64_t al, uint64_t bh, uint64_t bl, uint64_t &rh, uint64_t &rl) {
+    rl = al * bl;
+    rh = vgx_mulhi64(al, bl) + ah * bl + al * bh;
+}
+VGX_HD void vgx_add128(uint64_t &ah, uint64_t &al, uint64_t bh, uint64_t bl) {
+    uint64_t nl = al + bl;
+    ah = ah + bh + (nl < al ? 1u : 0u);
+    al = nl;
+}
+VGX_HD double vgx_pcg64_output_double(uint64_t sh, uint64_t sl) {  // XSL-RR of a state, as a double in [0,1)
+    uint64_t x = sh ^ sl;
+    unsigned rot = (unsigned)(sh >> 58);
+    uint64_t o = (x >> rot) | (x << ((64u - rot) & 63u));
+    return (double)(o >> 11) * (1.0 / 9007199254740992.0);
+}
+
 // ---- Philox4x32-10 -------------------------------------------------------------------------------
 struct VgxPhilox { uint32_t c[4]; uint32_t k[2]; };
 VGX_HD void vgx_philox_round(uint32_t c[4], uint32_t k0, uint32_t k1) {

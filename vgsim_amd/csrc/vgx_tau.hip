@@ -286,7 +286,9 @@ static __device__ __forceinline__ void tau_row(const VgxTauArgs &a, int rep, int
 //          TARGET population),
 //   dS   : the susceptible deltas (identical in both), the tentative counters and multievent rows.
 // The compartment arrays themselves are not touched, so every thread sees the pre-step state.
-static __device__ __forceinline__ void tau_cell(const VgxTauArgs &a, int rep, int pn, int hn, double tau, int64_t *cnt) {
+static __device__ __forceinline__ void tau_cell(const VgxTauArgs &a, int rep, int pn, int hn, double tau, int64_t *cnt,
+                                                unsigned long long *sS /* LDS [S]: this population's susceptible deltas */,
+                                                unsigned long long *sTot /* LDS: delta of totalInfectious[pn] */) {
     const VgxDevParams &p = a.p;
     const int P = p.P, S = p.S, H = p.H, sites = p.sites;
     const int64_t *I = a.I + (int64_t)rep * P * H;
@@ -368,16 +370,16 @@ static __device__ __forceinline__ void tau_cell(const VgxTauArgs &a, int rep, in
         int64_t k = tau_poisson(g, lam);
         if (k == 0) continue;
         births += k;
-        atomicAdd((unsigned long long *)&dS[pn * S + sn], (unsigned long long)(-k));
+        atomicAdd(&sS[sn], (unsigned long long)(-k));
         cnt[0] += k;
         tau_row(a, rep, k, 0, hn, pn, sn, 0);
     }
     own += births;
     if (own + migrants != 0) atomicAdd((unsigned long long *)&dC[(int64_t)pn * H + hn], (unsigned long long)(own + migrants));
     if (own != 0) atomicAdd((unsigned long long *)&dA[(int64_t)pn * H + hn], (unsigned long long)own);
-    if (rec + samp != 0) atomicAdd((unsigned long long *)&dS[pn * S + st], (unsigned long long)(rec + samp));
+    if (rec + samp != 0) atomicAdd(&sS[st], (unsigned long long)(rec + samp));
     int64_t dt = births - rec - samp;
-    if (dt != 0) atomicAdd((unsigned long long *)&a.dTot[(int64_t)rep * P + pn], (unsigned long long)dt);
+    if (dt != 0) atomicAdd(sTot, (unsigned long long)dt);
 }
 
 // grid = (ceil(H/TB), P, R); dChk/dApp/dSi/dTot are zero on entry
@@ -386,14 +388,21 @@ extern "C" __global__ void __launch_bounds__(TB) vgx_tau_draw_kernel(VgxTauArgs 
     if (!a.active[rep] || a.accepted[rep]) return;
     const int hn = blockIdx.x * TB + threadIdx.x;
     int64_t cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (hn < a.p.H) tau_cell(a, rep, pn, hn, a.tau[rep], cnt);
-    __shared__ unsigned long long sc[8];
+    // per-block accumulation of everything that all compartments of a population add to (one global atomic per
+    // block instead of one per compartment: the susceptible deltas of a population are a single address)
+    __shared__ unsigned long long sc[8], sS[64], sTot;
     if (threadIdx.x < 8) sc[threadIdx.x] = 0;
+    if (threadIdx.x < 64) sS[threadIdx.x] = 0;
+    if (threadIdx.x == 0) sTot = 0;
     __syncthreads();
+    if (hn < a.p.H) tau_cell(a, rep, pn, hn, a.tau[rep], cnt, sS, &sTot);
     for (int i = 0; i < 6; ++i)
         if (cnt[i]) atomicAdd(&sc[i], (unsigned long long)cnt[i]);
     __syncthreads();
     if (threadIdx.x < 6 && sc[threadIdx.x]) atomicAdd((unsigned long long *)&a.cnt_try[(int64_t)rep * 8 + threadIdx.x], sc[threadIdx.x]);
+    if (threadIdx.x < a.p.S && sS[threadIdx.x])
+        atomicAdd((unsigned long long *)&a.dSi[((int64_t)rep * a.p.P + pn) * a.p.S + threadIdx.x], sS[threadIdx.x]);
+    if (threadIdx.x == 0 && sTot) atomicAdd((unsigned long long *)&a.dTot[(int64_t)rep * a.p.P + pn], sTot);
 }
 
 // Immunity transitions (pyx:2479-2487 / 2554-2562): P*S*S slots per replicate, one thread each.
