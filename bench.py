@@ -146,7 +146,10 @@ def main():
         pmc = os.path.join(ROOT, "profiles", "pmc_direct_c3.json")
         if os.path.exists(pmc):
             try:
-                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+                d = json.load(open(pmc))
+                c = d.get("config", {})
+                if c.get("replicates_per_gpu") == R and c.get("events_per_replicate") == N and c.get("trajectory_points") == a.traj_points:
+                    traffic = d.get("hbm_bytes_per_launch")   # PMC passes are separate runs of this same command
             except Exception:
                 traffic = None
         line = {

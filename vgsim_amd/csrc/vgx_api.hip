@@ -68,7 +68,7 @@ struct vgx_engine {
         r_evtime, r_evcols, r_locrec, r_loctime, r_traj, r_prof;
     // tau-leaping (dense compartments)
     DevBuf t_I, t_S, t_dChk, t_dApp, t_dSi, t_dTot, t_totInf, t_gI, t_cd, t_lock, t_F, t_eff, t_Aeff, t_Gout, t_dS,
-        t_taubits, t_tau, t_time, t_flags, t_counters, t_cnttry, t_mev, t_mevn, t_mevbase, t_locn;
+        t_taubits, t_tau, t_time, t_flags, t_counters, t_cnttry, t_mev, t_mevn, t_mevbase, t_locn, t_mutcum, t_migcdf, t_migIn;
     bool last_was_tau = false;
     struct TauStep { double time; int64_t m0, m1; };
     std::vector<std::vector<TauStep>> tau_log;      // [R] MULTITYPE records of the last tau call
@@ -77,7 +77,8 @@ struct vgx_engine {
     std::vector<int64_t> tau_ev_ptr0;
     std::vector<VgxRepScalars> tau_sc;
     std::vector<double> h_startLD, h_endLD, h_cdBefore, h_cdAfter;
-    bool h_has_mig = false;
+    bool h_has_mig = false, h_mut_uniform = false;
+    double h_mutp[16][3] = {}, h_mut_total = 0.0;
     DevBuf i_nocc, i_hap, i_cls, i_cnt, i_sus;          // initial state (Restart)
     DevBuf s_nocc, s_hap, s_cls, s_cnt, s_sus, s_cd, s_tot;  // state at the start of the call
     VgxDevParams dp{};
@@ -273,6 +274,20 @@ extern "C" int vgx_set_params(vgx_engine *e, const vgx_params *p) {
         for (int64_t j = 0; j < P; j++)
             if (i != j && p->migrationRates[i * P + j] != 0.0) e->h_has_mig = true;
     if (S > 64) return fail(e, VGX_ERR_ARG, "vgx_set_params: at most 64 susceptibility groups are supported");
+    // uniform mutation model (every haplotype has the same mRate / hapMutType rows): table for the tau kernels
+    e->h_mut_uniform = true;
+    for (int64_t h = 1; h < H && e->h_mut_uniform; h++)
+        if (memcmp(p->mRate + h * sites, p->mRate, (size_t)sites * 8) != 0 ||
+            memcmp(p->hapMutType + h * sites * 3, p->hapMutType, (size_t)sites * 24) != 0)
+            e->h_mut_uniform = false;
+    e->h_mut_total = 0.0;
+    for (int64_t s2 = 0; s2 < sites && s2 < 16; s2++) {
+        const double *hm = p->hapMutType + s2 * 3;
+        for (int i = 0; i < 3; i++) {
+            e->h_mutp[s2][i] = sites > 0 ? p->mRate[s2] * hm[i] / (hm[0] + hm[1] + hm[2]) : 0.0;
+            e->h_mut_total += e->h_mutp[s2][i];
+        }
+    }
     for (int64_t p1 = 0; p1 < P; p1++) {  // pyx:289-297
         e->mig[(size_t)(p1 * P + p1)] = 1.0;
         double a = 0.0;
@@ -628,6 +643,8 @@ static int direct_core(vgx_engine *e, int64_t iterations, int64_t sample_size, f
 }
 
 // ------------------------------------------------------------------------------------------------
+static bool sites_ok16(const vgx_engine *e) { return e->d.sites <= 16; }
+
 // SimulatePopulation_tau (pyx:2293-2346): the step loop runs on the host, the steps on the device.
 template <typename T>
 static int dl(vgx_engine *e, std::vector<T> &dst, const DevBuf &b, size_t n) {
@@ -691,11 +708,14 @@ extern "C" int vgx_simulate_tau(vgx_engine *e, int64_t iterations, int64_t sampl
             }
     }
     e->dev_state_valid = false;  // the occupancy lists are not maintained by the tau path
+    for (int64_t pn = 0; pn < P; pn++)
+        if (e->sizes[(size_t)pn] >= ((int64_t)1 << 31)) return fail(e, VGX_ERR_ARG, "vgx_simulate_tau: population sizes must be below 2^31");
     const bool start_ok = (prep.totalRate + prep.totalMig != 0.0) && h.globalInfectious != 0;
 
     // ---- device arrays ----
     const int64_t mev_cap = o.record_events ? std::max<int64_t>(1, std::min<int64_t>((int64_t)1 << 24, iterations * 8192)) : 0;
-    const size_t nF = 8;  // int32 flag arrays
+    const size_t nF = 9;  // int32 flag arrays
+    const int64_t Ppad = (P + 31) / 32 * 32;
     rc = 0;
     rc |= ensure(e, e->t_I, (size_t)(R * P * H) * 8);
     rc |= ensure(e, e->t_S, (size_t)(R * P * S) * 8);
@@ -709,7 +729,7 @@ extern "C" int vgx_simulate_tau(vgx_engine *e, int64_t iterations, int64_t sampl
     rc |= ensure(e, e->t_lock, (size_t)(R * P) * 4);
     rc |= ensure(e, e->t_F, (size_t)(R * P) * 8);
     rc |= ensure(e, e->t_eff, (size_t)(R * P * P) * 8);
-    rc |= ensure(e, e->t_Aeff, (size_t)(R * P * P) * 8);
+    rc |= ensure(e, e->t_Aeff, (size_t)(R * P * Ppad) * 8);
     rc |= ensure(e, e->t_Gout, (size_t)(R * P * e->CB) * 8);
     rc |= ensure(e, e->t_dS, (size_t)(R * P * S) * 8);
     rc |= ensure(e, e->t_taubits, (size_t)R * 8);
@@ -722,6 +742,16 @@ extern "C" int vgx_simulate_tau(vgx_engine *e, int64_t iterations, int64_t sampl
     rc |= ensure(e, e->t_mevn, (size_t)R * 8);
     rc |= ensure(e, e->t_mevbase, (size_t)R * 8);
     rc |= ensure(e, e->t_locn, (size_t)R * 8);
+    if (e->h_has_mig) rc |= ensure(e, e->t_migIn, (size_t)(R * P * H) * 8);
+    rc |= ensure(e, e->t_migcdf, (size_t)(R * P * e->CB * P * S) * 8);
+    {
+        std::vector<double> cum;
+        double acc = 0.0;
+        for (int64_t s2 = 0; s2 < e->d.sites && s2 < 16; s2++)
+            for (int i = 0; i < 3; i++) { acc += e->h_mutp[s2][i]; cum.push_back(acc); }
+        if (cum.empty()) cum.push_back(0.0);
+        rc |= upload(e, e->t_mutcum, cum.data(), cum.size());
+    }
     rc |= upload(e, e->r_seeds, e->seeds.data(), e->seeds.size());
     if (rc) return VGX_ERR_HIP;
     HIPCHECK(e, hipMemset(e->t_dChk.p, 0, (size_t)(R * P * H) * 8));
@@ -763,9 +793,20 @@ extern "C" int vgx_simulate_tau(vgx_engine *e, int64_t iterations, int64_t sampl
     a.time_now = (double *)e->t_time.p;
     int32_t *fl = (int32_t *)e->t_flags.p;
     a.active = fl; a.ok = fl + R; a.accepted = fl + 2 * R; a.deciding = fl + 3 * R; a.retry = fl + 4 * R;
-    a.step = fl + 5 * R; a.error = fl + 6 * R; a.attempt = fl + 7 * R;
+    a.step = fl + 5 * R; a.error = fl + 6 * R; a.attempt = fl + 7 * R; a.eff_dirty = fl + 8 * R;
+    a.Ppad = (int32_t)Ppad;
+    {
+        std::vector<int32_t> ones((size_t)R, 1);
+        HIPCHECK(e, hipMemcpy(a.eff_dirty, ones.data(), (size_t)R * 4, hipMemcpyHostToDevice));
+    }
     a.seeds = (const int64_t *)e->r_seeds.p;
     a.has_mig = e->h_has_mig ? 1 : 0;
+    a.mut_uniform = (e->h_mut_uniform && sites_ok16(e)) ? 1 : 0;
+    memcpy(a.mutp, e->h_mutp, sizeof(a.mutp));
+    a.mut_total = e->h_mut_total;
+    a.mutcum = (const double *)e->t_mutcum.p;
+    a.migcdf = (double *)e->t_migcdf.p;
+    a.migIn = (double *)e->t_migIn.p;
     a.counters = (int64_t *)e->t_counters.p; a.cnt_try = (int64_t *)e->t_cnttry.p;
     a.mev = (int64_t *)e->t_mev.p; a.mev_cap = mev_cap;
     a.mev_n = (unsigned long long *)e->t_mevn.p; a.mev_base = (unsigned long long *)e->t_mevbase.p;

@@ -124,7 +124,10 @@ struct VgxTauArgs {
     int32_t *lockON;     // [R][P]
     double *F;           // [R][P]     sum_spn m[pn,spn]^2 cd[spn]/as[spn]
     double *effMig;      // [R][P][P]
-    double *Aeff;        // [R][P][P]  effMig[tpn][spn] * m[spn][spn]
+    double *Aeff;        // [R][P][Ppad] TRANSPOSED: [spn][tpn] = effMig[tpn][spn] * m[spn][spn], rows zero-padded
+    int32_t Ppad;        // P rounded up to a multiple of 32
+    int32_t *eff_dirty;  // [R] contact densities changed since effMig/Aeff/F were computed
+    double *migIn;       // [R][P][H]  sum_spn Aeff[tpn][spn] * I[spn][hn] (drift of incoming migration)
     double *Gout;        // [R][P][CB] out-migration weight of a source population per birth class
     double *dS;          // [R][P][S]  drift of the susceptible compartments
     unsigned long long *tau_bits;  // [R] running minimum of the tau candidates (bit pattern)
@@ -134,6 +137,11 @@ struct VgxTauArgs {
     int32_t *attempt;    // [R]
     const int64_t *seeds;  // [R]
     int32_t has_mig;
+    int32_t mut_uniform;     // every haplotype has the same mRate / hapMutType rows: use mutp[][] below
+    double mutp[16][3];      // mRate[s] * w[s][i] / (w[s][0]+w[s][1]+w[s][2]) of the uniform mutation model
+    double mut_total;        // sum of mutp
+    const double *mutcum;    // [3*sites] running sums of mutp (device)
+    double *migcdf;          // [R][P][CB][P*S] running sums of the out-migration channel weights
     int64_t *counters;   // [R][8]: births, recoveries, samples, mutations, immunity, migrations, lockdown switches, events drawn
     int64_t *cnt_try;    // [R][8] tallies of the retry being validated
     int64_t *mev;        // [R][mev_cap][6]  num, type, hap, pop, newHap, newPop (rows with num > 0 only)

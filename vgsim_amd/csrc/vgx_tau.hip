@@ -26,30 +26,39 @@
 #include "vgx_dev.h"
 #include "vgx_rng.h"
 
+// The tau path is validated distributionally (different random streams anyway), so FMA contraction is allowed
+// here, unlike in the bit-exact direct kernel (the library is built with -ffp-contract=off).
+#pragma clang fp contract(fast)
+
 #define TB 256  // threads per block of the compartment kernels
 
 struct TauRng {
-    uint32_t ctr[4];
-    uint32_t key[2];
-    uint32_t buf[4];
-    int have;
+    uint32_t c0, c1, c2, c3, k0, k1;
+    uint64_t spare;
+    bool have;
     __device__ void init(uint64_t seed, uint32_t attempt, uint64_t cell, uint32_t step, uint32_t retry) {
-        key[0] = (uint32_t)seed ^ (attempt * 0x9E3779B9u);
-        key[1] = (uint32_t)(seed >> 32) ^ 0x85EBCA6Bu;
-        ctr[0] = (uint32_t)cell;
-        ctr[1] = (uint32_t)(cell >> 32);
-        ctr[2] = step;
-        ctr[3] = retry << 20;  // low 20 bits: block counter of this stream
-        have = 0;
+        k0 = (uint32_t)seed ^ (attempt * 0x9E3779B9u);
+        k1 = (uint32_t)(seed >> 32) ^ 0x85EBCA6Bu;
+        c0 = (uint32_t)cell;
+        c1 = (uint32_t)(cell >> 32);
+        c2 = step;
+        c3 = retry << 20;  // low 20 bits: block counter of this stream
+        have = false;
+        spare = 0;
     }
     __device__ double uniform() {  // (0,1): 52 random bits + half an ulp, never 0
-        if (have < 2) {
-            vgx_philox4x32(ctr, key, buf);
-            ctr[3] += 1;
-            have = 4;
+        uint64_t x;
+        if (have) {
+            x = spare;
+            have = false;
+        } else {
+            uint32_t ctr[4] = {c0, c1, c2, c3}, key[2] = {k0, k1}, out[4];
+            vgx_philox4x32(ctr, key, out);
+            c3 += 1;
+            x = ((uint64_t)out[1] << 32) | out[0];
+            spare = ((uint64_t)out[3] << 32) | out[2];
+            have = true;
         }
-        uint64_t x = ((uint64_t)buf[have - 1] << 32) | buf[have - 2];
-        have -= 2;
         return ((double)(x >> 12) + 0.5) * (1.0 / 4503599627370496.0);
     }
 };
@@ -71,18 +80,21 @@ static __device__ double tau_loggam(double x) {
     return gl;
 }
 
-// Poisson(lam): multiplication method below 10, PTRS (Hoermann 1993) from 10 on — numpy's random_poisson,
-// the sampler pyx:2532 calls, with a counter-based uniform source.
+// Poisson(lam).  The reference's sampler (numpy random_poisson, pyx:2532) uses the multiplication method below 10
+// and PTRS (Hoermann 1993) from 10 on; here the small-mean branch is inversion by sequential search (one uniform
+// per draw instead of k+1: same law, no random numbers inside the divergent loop), the large-mean branch PTRS.
 static __device__ int64_t tau_poisson(TauRng &g, double lam) {
     if (!(lam > 0.0)) return 0;
     if (lam < 10.0) {
-        double enlam = exp(-lam), prod = 1.0;
+        double u = g.uniform();
+        double pk = exp(-lam), F = pk;
         int64_t X = 0;
-        while (true) {
-            prod *= g.uniform();
-            if (prod > enlam) X += 1;
-            else return X;
+        while (u > F && X < 200) {
+            X += 1;
+            pk *= lam / (double)X;
+            F += pk;
         }
+        return X;
     }
     double slam = sqrt(lam), loglam = log(lam);
     double b = 0.931 + 2.53 * slam, a = -0.059 + 0.02483 * b;
@@ -117,113 +129,178 @@ static __device__ __forceinline__ void atomic_min_pos_double(unsigned long long 
 extern "C" __global__ void __launch_bounds__(TB) vgx_tau_prep_kernel(VgxTauArgs a) {
     const int rep = blockIdx.x;
     const VgxDevParams &p = a.p;
-    const int P = p.P, S = p.S, CB = p.CB;
+    const int P = p.P, S = p.S, CB = p.CB, Pp = a.Ppad;
     if (!a.active[rep]) return;
     const double *cd = a.cd + (int64_t)rep * P;
     double *F = a.F + (int64_t)rep * P;
     double *eff = a.effMig + (int64_t)rep * P * P;
-    double *Aeff = a.Aeff + (int64_t)rep * P * P;
+    double *AeffT = a.Aeff + (int64_t)rep * P * Pp;   // [spn][tpn], rows padded to Pp with zeros
     double *Gout = a.Gout + (int64_t)rep * P * CB;
     const int64_t *Sus = a.S + (int64_t)rep * P * S;
-    for (int pn = threadIdx.x; pn < P; pn += TB) {
-        double f = 0.0;
-        for (int q = 0; q < P; ++q) {
-            double m = p.mig[(int64_t)pn * P + q];
-            f += m * m * cd[q] / p.actualSizes[q];
+    if (a.eff_dirty[rep]) {  // contact densities changed (start of the call / lockdown switch)
+        for (int pn = threadIdx.x; pn < P; pn += TB) {
+            double f = 0.0;
+            for (int q = 0; q < P; ++q) {
+                double m = p.mig[(int64_t)pn * P + q];
+                f += m * m * cd[q] / p.actualSizes[q];
+            }
+            F[pn] = f;
         }
-        F[pn] = f;
-    }
-    for (int idx = threadIdx.x; idx < P * P; idx += TB) {
-        int t = idx / P, s = idx % P;  // eff[t][s]
-        double e = 0.0;
-        if (t != s)
-            for (int q = 0; q < P; ++q) e += p.mig[(int64_t)t * P + q] * p.mig[(int64_t)s * P + q] * cd[q] / p.actualSizes[q];
-        eff[idx] = e;
-        Aeff[idx] = e * p.mig[(int64_t)s * P + s];
+        for (int idx = threadIdx.x; idx < P * P; idx += TB) {
+            int t = idx / P, s = idx % P;  // eff[t][s]
+            double e = 0.0;
+            if (t != s && a.has_mig)
+                for (int q = 0; q < P; ++q) e += p.mig[(int64_t)t * P + q] * p.mig[(int64_t)s * P + q] * cd[q] / p.actualSizes[q];
+            eff[idx] = e;
+            AeffT[(int64_t)s * Pp + t] = e * p.mig[(int64_t)s * P + s];
+        }
+        for (int idx = threadIdx.x; idx < P * (Pp - P); idx += TB) AeffT[(int64_t)(idx / (Pp - P)) * Pp + P + idx % (Pp - P)] = 0.0;
     }
     __syncthreads();
     for (int idx = threadIdx.x; idx < P * CB; idx += TB) {
         int spn = idx / CB, cb = idx % CB;
         double g = 0.0;
-        for (int t = 0; t < P; ++t) {
-            if (t == spn) continue;
-            double e = eff[(int64_t)t * P + spn];
-            for (int sn = 0; sn < S; ++sn) g += e * (double)Sus[t * S + sn] * p.cb_sigma[cb * S + sn];
-        }
+        if (a.has_mig)
+            for (int t = 0; t < P; ++t) {
+                if (t == spn) continue;
+                double e = eff[(int64_t)t * P + spn];
+                for (int sn = 0; sn < S; ++sn) g += e * (double)Sus[t * S + sn] * p.cb_sigma[cb * S + sn];
+            }
         Gout[idx] = g;
+        // cumulative weights over (tpn, sn) of the out-migration channels of (spn, cb): target lookup by bisection
+        double *cdf = a.migcdf + (((int64_t)rep * P + spn) * CB + cb) * (int64_t)P * S;
+        double acc = 0.0;
+        for (int t = 0; t < P; ++t)
+            for (int sn = 0; sn < S; ++sn) {
+                if (t != spn && a.has_mig) acc += eff[(int64_t)t * P + spn] * (double)Sus[t * S + sn] * p.cb_sigma[cb * S + sn];
+                cdf[t * S + sn] = acc;
+            }
     }
     if (threadIdx.x == 0) {
         a.tau_bits[rep] = (unsigned long long)__double_as_longlong(1.0);  // tau_l starts at 1.0 (pyx:2437)
         a.ok[rep] = 1;
+        a.eff_dirty[rep] = 0;
     }
     for (int i = threadIdx.x; i < P * S; i += TB) a.dS[(int64_t)rep * P * S + i] = 0.0;
 }
 
+// Incoming-migration term of the drift, migIn[tpn][hn] = sum_spn Aeff[tpn][spn] * I[spn][hn] (pyx:2366-2369):
+// a [P x P] x [P x H] product.  Block = 4 waves, lane <-> haplotype of a 64-wide tile, persistent over tiles.
+// The tile I[:, h0:h0+64] of ALL source populations is staged once in LDS (int32, coalesced 512-B global reads);
+// each wave keeps 8 target populations in registers, reads I[spn][lane] once per source population from LDS and
+// the 8 coefficients of the transposed, padded matrix as ONE wave-uniform scalar load (the pointers are
+// __restrict__ kernel arguments and the only store goes to migIn, so the loads are provably read-only).
+#define TH 64
+#define TPW 8
+extern "C" __global__ void __launch_bounds__(TB) vgx_tau_migin_kernel(const double *__restrict__ AeffT_all,
+                                                                      const int64_t *__restrict__ I_all,
+                                                                      double *__restrict__ migIn_all,
+                                                                      const int32_t *__restrict__ active, int P, int Pp,
+                                                                      int H) {
+    const int rep = blockIdx.y;
+    if (!active[rep]) return;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t *__restrict__ I = I_all + (int64_t)rep * P * H;
+    const double *__restrict__ AeffT = AeffT_all + (int64_t)rep * P * Pp;
+    double *__restrict__ out = migIn_all + (int64_t)rep * P * H;
+    extern __shared__ __attribute__((aligned(16))) unsigned char tsm[];
+    int32_t *It = (int32_t *)tsm;  // [P][TH]
+    const int ntiles = (H + TH - 1) / TH;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int h0 = tile * TH;
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < P * TH; idx += TB) {
+            int spn = idx >> 6, h = idx & 63;
+            It[idx] = (h0 + h < H) ? (int32_t)I[(int64_t)spn * H + h0 + h] : 0;
+        }
+        __syncthreads();
+        for (int tp0 = wave * TPW; tp0 < P; tp0 += 4 * TPW) {
+            double acc[TPW];
+#pragma unroll
+            for (int j = 0; j < TPW; ++j) acc[j] = 0.0;
+#pragma unroll 4
+            for (int spn = 0; spn < P; ++spn) {
+                double x = (double)It[spn * TH + lane];
+                const double *__restrict__ arow = AeffT + (int64_t)spn * Pp + tp0;  // 8 consecutive wave-uniform coefficients
+#pragma unroll
+                for (int j = 0; j < TPW; ++j) acc[j] += arow[j] * x;
+            }
+            if (h0 + lane < H) {
+#pragma unroll
+                for (int j = 0; j < TPW; ++j)
+                    if (tp0 + j < P) out[(int64_t)(tp0 + j) * H + h0 + lane] = acc[j];
+            }
+        }
+    }
+}
+
 // Net drift of every infectious compartment and its tau candidate (Propensities + ChooseTau); partial
-// sums of the susceptible drift.  grid = (ceil(H/TB), P, R).
+// sums of the susceptible drift.  Thread <-> compartment, grid = (ceil(H/TB), P, R); every gather of a
+// neighbouring haplotype is coalesced across the lanes (neighbours of consecutive haplotypes are consecutive).
 extern "C" __global__ void __launch_bounds__(TB) vgx_tau_drift_kernel(VgxTauArgs a) {
     const int rep = blockIdx.z, pn = blockIdx.y;
     if (!a.active[rep]) return;
     const VgxDevParams &p = a.p;
     const int P = p.P, S = p.S, H = p.H, sites = p.sites;
     const int hn = blockIdx.x * TB + threadIdx.x;
-    const int64_t *I = a.I + (int64_t)rep * P * H;
+    const int lane = threadIdx.x & 63;
+    const int64_t *I = a.I + (int64_t)rep * P * H + (int64_t)pn * H;
     const int64_t *Sus = a.S + (int64_t)rep * P * S + (int64_t)pn * S;
     __shared__ double sdS[64];      // S <= 64 susceptibility groups
     __shared__ unsigned long long smin;
     if (threadIdx.x < 64) sdS[threadIdx.x] = 0.0;
     if (threadIdx.x == 0) smin = (unsigned long long)__double_as_longlong(1.0);
     __syncthreads();
-    if (hn < H) {
-        const int c = p.cls[hn];
-        const int cb = p.c_bidx[c];
-        const double Ih = (double)I[(int64_t)pn * H + hn];
-        const double b = p.cb_b[cb];
-        double drift = 0.0;
-        // recovery and sampling (pyx:2386-2395)
-        double rec = p.c_d[c] * Ih, samp = p.c_s[c] * Ih * p.sampMult[pn];
-        drift -= rec;
-        drift -= samp;
-        if (rec + samp != 0.0) atomicAdd(&sdS[p.c_stype[c]], rec + samp);
-        // outgoing mutation (pyx:2398-2404): sum_i w_i / sum w == 1
-        drift -= p.c_tm[c] * Ih;
-        // incoming mutation: sources differ from hn in exactly one site
-        for (int s = 0; s < sites; ++s) {
-            int digit4 = 1 << (2 * (sites - s - 1));
-            int AS = (hn / digit4) % 4;
-            for (int al = 0; al < 4; ++al) {
-                if (al == AS) continue;
-                int src = hn + (al - AS) * digit4;
-                int64_t Is = I[(int64_t)pn * H + src];
-                if (Is == 0) continue;
-                int i = AS - (AS > al ? 1 : 0);  // derived-state index of `AS` in the source's numbering
+    const bool live = hn < H;
+    const int hh = live ? hn : H - 1;
+    const int c = p.cls[hh];
+    const int cb = p.c_bidx[c];
+    const int64_t Icell = live ? I[hh] : 0;
+    const double Ih = (double)Icell;
+    double drift = 0.0;
+    // recovery and sampling (pyx:2386-2395), outgoing mutation (pyx:2398-2404: sum_i w_i / sum w == 1)
+    const double rec = p.c_d[c] * Ih, samp = p.c_s[c] * Ih * p.sampMult[pn];
+    drift -= rec;
+    drift -= samp;
+    drift -= p.c_tm[c] * Ih;
+    // incoming mutation: sources differ from hn in exactly one site
+    for (int s = 0; s < sites; ++s) {
+        const int sh = 2 * (sites - s - 1);
+        const int AS = (hh >> sh) & 3;
+        for (int al = 0; al < 4; ++al) {
+            if (al == AS) continue;
+            const int src = hh + ((al - AS) << sh);
+            const int64_t Is = live ? I[src] : 0;
+            if (Is == 0) continue;
+            const int i = AS - (AS > al ? 1 : 0);  // derived-state index of `AS` in the source's numbering
+            double rate;
+            if (a.mut_uniform) rate = a.mutcum[s * 3 + i] - (s * 3 + i > 0 ? a.mutcum[s * 3 + i - 1] : 0.0);
+            else {
                 const double *hm = p.hapMutType + ((int64_t)src * sites + s) * 3;
-                drift += p.mRate[(int64_t)src * sites + s] * hm[i] / (hm[0] + hm[1] + hm[2]) * (double)Is;
+                rate = p.mRate[(int64_t)src * sites + s] * hm[i] / (hm[0] + hm[1] + hm[2]);
             }
+            drift += rate * (double)Is;
         }
-        // transmission (pyx:2407-2417) and incoming migration (pyx:2360-2370)
-        double migI = 0.0;
-        const double *Arow = a.Aeff + ((int64_t)rep * P + pn) * P;
-        if (a.has_mig)
-            for (int spn = 0; spn < P; ++spn) {
-                if (spn == pn) continue;
-                double A = Arow[spn];
-                if (A != 0.0) migI += A * (double)I[(int64_t)spn * H + hn];
-            }
-        const double F = a.F[(int64_t)rep * P + pn];
-        for (int sn = 0; sn < S; ++sn) {
-            double sig = p.cb_sigma[cb * S + sn];
-            double base = b * sig * (double)Sus[sn];
-            double v = base * Ih * F + base * migI;
-            drift += v;
-            if (v != 0.0) atomicAdd(&sdS[sn], -v);
-        }
-        if (fabs(drift) >= 1e-8) {  // pyx:2440-2444, epsilon*X in single precision
-            float eps = 0.03f;
-            double v = (double)(eps * (float)I[(int64_t)pn * H + hn]) / 2.0;
-            double cand = (v > 1.0 ? v : 1.0) / fabs(drift);
-            atomic_min_pos_double(&smin, cand);
-        }
+    }
+    // transmission (pyx:2407-2417) and incoming migration (pyx:2360-2370)
+    const double migI = (a.has_mig && live) ? a.migIn[((int64_t)rep * P + pn) * H + hh] : 0.0;
+    const double F = a.F[(int64_t)rep * P + pn];
+    const double b = p.cb_b[cb];
+    const double to_st = live ? rec + samp : 0.0;
+    for (int sn = 0; sn < S; ++sn) {
+        double base = b * p.cb_sigma[cb * S + sn] * (double)Sus[sn];
+        double v = live ? base * Ih * F + base * migI : 0.0;
+        drift += v;
+        double red = -v + ((int)p.c_stype[c] == sn ? to_st : 0.0);   // susceptible drift of (pn, sn)
+        for (int o = 32; o > 0; o >>= 1) red += __shfl_down(red, o);
+        if (lane == 0 && red != 0.0) atomicAdd(&sdS[sn], red);
+    }
+    if (live && fabs(drift) >= 1e-8) {  // pyx:2440-2444, epsilon*X in single precision
+        float eps = 0.03f;
+        double v = (double)(eps * (float)Icell) / 2.0;
+        double cand = (v > 1.0 ? v : 1.0) / fabs(drift);
+        atomic_min_pos_double(&smin, cand);
     }
     __syncthreads();
     if (threadIdx.x < S && sdS[threadIdx.x] != 0.0) atomicAdd(&a.dS[((int64_t)rep * P + pn) * S + threadIdx.x], sdS[threadIdx.x]);
@@ -279,12 +356,15 @@ static __device__ __forceinline__ void tau_row(const VgxTauArgs &a, int rep, int
     }
 }
 
-// GenerateEvents_tau for one compartment (pn, hn): draws all its channels once and books
+// GenerateEvents_tau for one compartment (pn, hn).  All channels out of a compartment are independent Poisson
+// variables, so their sum is Poisson with the summed rate and, given the sum, the channel of each event is
+// multinomial: ONE draw per compartment, then a split (same joint law as pyx:2464-2520, ~5x fewer draws).
+// Books
 //   dChk : the infectious deltas the reference's bounds check looks at (pyx:2473: a migrant is booked on its
 //          SOURCE compartment there),
 //   dApp : the infectious deltas UpdateCompartmentCounts_tau applies (pyx:2548: the migrant infects the
 //          TARGET population),
-//   dS   : the susceptible deltas (identical in both), the tentative counters and multievent rows.
+//   the susceptible deltas (identical in both), the tentative counters and multievent rows.
 // The compartment arrays themselves are not touched, so every thread sees the pre-step state.
 static __device__ __forceinline__ void tau_cell(const VgxTauArgs &a, int rep, int pn, int hn, double tau, int64_t *cnt,
                                                 unsigned long long *sS /* LDS [S]: this population's susceptible deltas */,
@@ -302,35 +382,101 @@ static __device__ __forceinline__ void tau_cell(const VgxTauArgs &a, int rep, in
     const int c = p.cls[hn];
     const int cb = p.c_bidx[c];
     const int st = p.c_stype[c];
+    // ---- channel rates per unit time ----
+    const double G = a.has_mig ? a.Gout[((int64_t)rep * P + pn) * p.CB + cb] : 0.0;
+    const double r_mig = G * Ih * p.cb_b[cb] * p.mig[(int64_t)pn * P + pn];          // pyx:2366-2367 summed over (tpn, sn)
+    const double r_rec = p.c_d[c] * Ih;                                              // pyx:2386
+    const double r_samp = p.c_s[c] * Ih * p.sampMult[pn];                            // pyx:2392
+    const double r_mut = (a.mut_uniform ? a.mut_total : p.c_tm[c]) * Ih;             // pyx:2400-2401 summed over (s, i)
+    const double Fb = p.cb_b[cb] * Ih * a.F[(int64_t)rep * P + pn];
+    double r_tr = 0.0;                                                               // pyx:2412-2414 summed over sn
+    for (int sn = 0; sn < S; ++sn) r_tr += Fb * p.cb_sigma[cb * S + sn] * (double)Sus[pn * S + sn];
+    const double r_all = r_mig + r_rec + r_samp + r_mut + r_tr;
     TauRng g;
     g.init((uint64_t)a.seeds[rep], (uint32_t)a.attempt[rep], (uint64_t)pn * (uint64_t)H + (uint64_t)hn, (uint32_t)a.step[rep],
            (uint32_t)a.retry[rep]);
-    int64_t own = 0, migrants = 0;
-    // ---- migration out of (pn, hn): one Poisson, multinomial split (pyx:2464-2474 / 2541-2550) ----
-    if (a.has_mig) {
-        double G = a.Gout[((int64_t)rep * P + pn) * p.CB + cb];
-        double lam = G * Ih * p.cb_b[cb] * p.mig[(int64_t)pn * P + pn] * tau;
-        int64_t M = tau_poisson(g, lam);
-        const double *eff = a.effMig + (int64_t)rep * P * P;
-        for (int64_t k = 0; k < M; ++k) {
-            double u = g.uniform() * G, acc = 0.0;
-            int tp = -1, ts = 0;
-            for (int t = 0; t < P && tp < 0; ++t) {
-                if (t == pn) continue;
-                double e = eff[(int64_t)t * P + pn];
-                if (e == 0.0) continue;
-                for (int sn = 0; sn < S; ++sn) {
-                    acc += e * (double)Sus[t * S + sn] * p.cb_sigma[cb * S + sn];
-                    if (u < acc) { tp = t; ts = sn; break; }
-                }
+    const int64_t N = tau_poisson(g, r_all * tau);
+    if (N == 0) return;
+    int64_t own = 0, migrants = 0, rec = 0, samp = 0, births = 0;
+    for (int64_t ev = 0; ev < N; ++ev) {
+        double u = g.uniform() * r_all;
+        if (u < r_rec) { rec += 1; continue; }
+        u -= r_rec;
+        if (u < r_samp) { samp += 1; continue; }
+        u -= r_samp;
+        if (u < r_tr || (r_mut == 0.0 && r_mig == 0.0)) {
+            // transmission to susceptibility group sn (pyx:2515-2520 / 2589-2593)
+            double acc = 0.0;
+            int sn_hit = -1;
+            for (int sn = 0; sn < S; ++sn) {
+                double w = Fb * p.cb_sigma[cb * S + sn] * (double)Sus[pn * S + sn];
+                acc += w;
+                if (w > 0.0) sn_hit = sn;          // last positive channel so far: fallback at the upper end
+                if (u < acc) break;
             }
-            if (tp < 0) {  // rounding at the upper end: last channel with a non-zero weight
-                for (int t = P - 1; t >= 0 && tp < 0; --t) {
-                    if (t == pn) continue;
-                    for (int sn = S - 1; sn >= 0; --sn)
-                        if (eff[(int64_t)t * P + pn] * (double)Sus[t * S + sn] * p.cb_sigma[cb * S + sn] > 0.0) { tp = t; ts = sn; break; }
+            if (sn_hit < 0) continue;
+            births += 1;
+            atomicAdd(&sS[sn_hit], (unsigned long long)(-1ll));
+            cnt[0] += 1;
+            tau_row(a, rep, 1, 0, hn, pn, sn_hit, 0);
+            continue;
+        }
+        u -= r_tr;
+        if (u < r_mut || r_mig == 0.0) {
+            // mutation (pyx:2506-2512 / 2579-2586): site and derived state
+            double uu = (r_mut > 0.0 ? u / r_mut : 0.0), acc = 0.0;
+            int ss = -1, ii = 0;
+            if (a.mut_uniform) {
+                uu *= a.mut_total;
+                const int nch = 3 * sites;
+                int lo = 0, hi = nch - 1;
+                while (lo < hi) {
+                    int mid = (lo + hi) >> 1;
+                    if (a.mutcum[mid] > uu) hi = mid; else lo = mid + 1;
                 }
+                while (lo > 0 && a.mutcum[lo] == a.mutcum[lo - 1]) lo -= 1;
+                if (nch > 0 && a.mutcum[nch - 1] > 0.0) { ss = lo / 3; ii = lo % 3; }
+            } else {
+                uu *= p.c_tm[c];
+                for (int s = 0; s < sites && ss < 0; ++s) {
+                    const double *hm = p.hapMutType + ((int64_t)hn * sites + s) * 3;
+                    double wsum = hm[0] + hm[1] + hm[2], mr = p.mRate[(int64_t)hn * sites + s];
+                    for (int i = 0; i < 3; ++i) {
+                        acc += mr * hm[i] / wsum;
+                        if (uu < acc) { ss = s; ii = i; break; }
+                    }
+                }
+                if (ss < 0)
+                    for (int s = sites - 1; s >= 0 && ss < 0; --s) {
+                        const double *hm = p.hapMutType + ((int64_t)hn * sites + s) * 3;
+                        for (int i = 2; i >= 0; --i)
+                            if (p.mRate[(int64_t)hn * sites + s] * hm[i] > 0.0) { ss = s; ii = i; break; }
+                    }
             }
+            if (ss < 0) continue;
+            int nh = tau_mutate(sites, hn, ss, ii);
+            own -= 1;
+            atomicAdd((unsigned long long *)&dC[(int64_t)pn * H + nh], 1ull);
+            atomicAdd((unsigned long long *)&dA[(int64_t)pn * H + nh], 1ull);
+            cnt[3] += 1;
+            tau_row(a, rep, 1, 3, hn, pn, nh, 0);
+            continue;
+        }
+        u -= r_mut;
+        {
+            // migration (pyx:2464-2474 / 2541-2550): target population and susceptibility group, by bisection in
+            // the cumulative channel weights of this source population and birth class
+            const double *cdf = a.migcdf + (((int64_t)rep * P + pn) * p.CB + cb) * (int64_t)P * S;
+            const int nch = P * S;
+            double uu = (u / r_mig) * cdf[nch - 1];
+            int lo = 0, hi = nch - 1;
+            while (lo < hi) {               // first channel with cdf > uu
+                int mid = (lo + hi) >> 1;
+                if (cdf[mid] > uu) hi = mid; else lo = mid + 1;
+            }
+            while (lo > 0 && cdf[lo] == cdf[lo - 1]) lo -= 1;   // a zero-weight channel can only be hit by rounding
+            int tp = lo / S, ts = lo % S;
+            if (tp == pn || !(cdf[nch - 1] > 0.0)) tp = -1;
             if (tp < 0) continue;
             migrants += 1;
             atomicAdd((unsigned long long *)&dA[(int64_t)tp * H + hn], 1ull);
@@ -340,41 +486,9 @@ static __device__ __forceinline__ void tau_cell(const VgxTauArgs &a, int rep, in
             tau_row(a, rep, 1, 5, hn, pn, ts, tp);
         }
     }
-    // ---- recovery, sampling (pyx:2492-2503 / 2567-2576) ----
-    int64_t rec = tau_poisson(g, p.c_d[c] * Ih * tau);
-    int64_t samp = tau_poisson(g, p.c_s[c] * Ih * p.sampMult[pn] * tau);
     if (rec) { cnt[1] += rec; tau_row(a, rep, rec, 1, hn, pn, st, 0); }
     if (samp) { cnt[2] += samp; tau_row(a, rep, samp, 2, hn, pn, st, 0); }
-    own -= rec + samp;
-    // ---- mutations (pyx:2506-2512 / 2579-2586) ----
-    for (int s = 0; s < sites; ++s) {
-        const double *hm = p.hapMutType + ((int64_t)hn * sites + s) * 3;
-        double wsum = hm[0] + hm[1] + hm[2];
-        double mr = p.mRate[(int64_t)hn * sites + s];
-        for (int i = 0; i < 3; ++i) {
-            int64_t k = tau_poisson(g, mr * hm[i] / wsum * Ih * tau);
-            if (k == 0) continue;
-            int nh = tau_mutate(sites, hn, s, i);
-            own -= k;
-            atomicAdd((unsigned long long *)&dC[(int64_t)pn * H + nh], (unsigned long long)k);
-            atomicAdd((unsigned long long *)&dA[(int64_t)pn * H + nh], (unsigned long long)k);
-            cnt[3] += k;
-            tau_row(a, rep, k, 3, hn, pn, nh, 0);
-        }
-    }
-    // ---- transmission (pyx:2515-2520 / 2589-2593) ----
-    const double F = a.F[(int64_t)rep * P + pn];
-    int64_t births = 0;
-    for (int sn = 0; sn < S; ++sn) {
-        double lam = p.cb_b[cb] * p.cb_sigma[cb * S + sn] * (double)Sus[pn * S + sn] * Ih * F * tau;
-        int64_t k = tau_poisson(g, lam);
-        if (k == 0) continue;
-        births += k;
-        atomicAdd(&sS[sn], (unsigned long long)(-k));
-        cnt[0] += k;
-        tau_row(a, rep, k, 0, hn, pn, sn, 0);
-    }
-    own += births;
+    own += births - rec - samp;
     if (own + migrants != 0) atomicAdd((unsigned long long *)&dC[(int64_t)pn * H + hn], (unsigned long long)(own + migrants));
     if (own != 0) atomicAdd((unsigned long long *)&dA[(int64_t)pn * H + hn], (unsigned long long)own);
     if (rec + samp != 0) atomicAdd(&sS[st], (unsigned long long)(rec + samp));
@@ -533,6 +647,7 @@ extern "C" __global__ void __launch_bounds__(64) vgx_tau_finish_kernel(VgxTauArg
                         a.loc_time[(int64_t)rep * VGX_LOC_CAP + slot] = a.time_now[rep] + a.tau[rep];
                     }
                     atomicAdd((unsigned long long *)&a.counters[(int64_t)rep * 8 + 6], 1ull);  // swapLockdown
+                    a.eff_dirty[rep] = 1;
                 }
             }
         }
@@ -550,7 +665,21 @@ extern "C" __global__ void __launch_bounds__(64) vgx_tau_finish_kernel(VgxTauArg
 #define CELL_GRID dim3((unsigned)((a->p.H + TB - 1) / TB), (unsigned)a->p.P, (unsigned)a->R)
 #define SUS_GRID dim3((unsigned)((a->p.P * a->p.S * a->p.S + TB - 1) / TB), (unsigned)a->R)
 TAU_LAUNCH(tau_prep, dim3((unsigned)a->R), dim3(TB))
-TAU_LAUNCH(tau_drift, CELL_GRID, dim3(TB))
+extern "C" __attribute__((visibility("hidden"))) hipError_t vgxi_tau_drift(const VgxTauArgs *a, hipStream_t s) {
+    if (a->has_mig) {
+        size_t lds = (size_t)a->p.P * TH * 4;
+        hipError_t err = hipFuncSetAttribute((const void *)vgx_tau_migin_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (err != hipSuccess) return err;
+        int ntiles = (a->p.H + TH - 1) / TH;
+        int gx = ntiles < 2048 ? ntiles : 2048;
+        hipLaunchKernelGGL(vgx_tau_migin_kernel, dim3((unsigned)gx, (unsigned)a->R), dim3(TB), lds, s, a->Aeff, a->I, a->migIn,
+                           a->active, a->p.P, a->Ppad, a->p.H);
+        err = hipGetLastError();
+        if (err != hipSuccess) return err;
+    }
+    hipLaunchKernelGGL(vgx_tau_drift_kernel, CELL_GRID, dim3(TB), 0, s, *a);
+    return hipGetLastError();
+}
 TAU_LAUNCH(tau_choose, dim3((unsigned)a->R), dim3(64))
 TAU_LAUNCH(tau_draw, CELL_GRID, dim3(TB))
 TAU_LAUNCH(tau_suscep_draw, SUS_GRID, dim3(TB))
