@@ -41,7 +41,7 @@ def make_simulator(seed):
     return s
 
 
-def cpu_baseline(seconds_target=15.0):
+def cpu_baseline(seconds_target=45.0):
     """The oracle (oracle/vgx_oracle.c, dense = the reference's own O(H*S*P)-per-event algorithm) on the same
     workload, one host core, bounded sample."""
     from oracle import oracle
@@ -63,6 +63,46 @@ def cpu_baseline(seconds_target=15.0):
                       "reference's dense mode, %.1f s" % (done, n1, t3 - t2)}
 
 
+def tau_leg(device, steps=3, per_cell=3):
+    """Tau-leaping on BASELINE config 4 (2^20 haplotypes x 256 populations, migration), dense ("spread")
+    occupancy written straight into the model's arrays; the reference cannot even construct this shape
+    (SURVEY.md §0.8).  Reports events drawn per second of device time and the step's HBM roofline against the
+    fused-minimum traffic 16*P*H bytes/step."""
+    import ctypes as C
+    import numpy as np
+    from vgsim_amd import Simulator, _capi
+    sites, P = 10, 256
+    with contextlib.redirect_stdout(io.StringIO()):
+        s = Simulator(number_of_sites=sites, populations_number=P, seed=2020)
+    s.set_transmission_rate(2.5); s.set_recovery_rate(0.9); s.set_sampling_rate(0.1); s.set_mutation_rate(0.01)
+    s.set_total_migration_probability(0.01); s.set_population_size(10 ** 7)
+    m = s.simulation
+    H = m.hapNum
+    m.infectious[:] = per_cell
+    m.susceptible[:, 0] -= per_cell * H
+    eng = _capi.HipEngine(m.sites, m.hapNum, m.popNum, m.susNum, n_replicates=1, device=device)
+    m.events.CreateEvents(steps)
+    m.events.ptr = 1            # not the first call of the model: capacity = ptr + iterations (events.pxi:61-68)
+    m.events.CreateEvents(steps)
+    eng.set_params(m); eng.set_state(m); eng.set_seeds(np.array([2020], dtype=np.int64))
+    o = _capi.VgxRunOpts(); o.record_events = 0
+    eng._check(eng.lib.vgx_simulate_tau(eng.handle, steps, 10 ** 15, -1.0, 1, C.byref(o)))
+    c = eng.counters(0)
+    ms = eng.last_kernel_ms
+    n = max(int(c.loop_iterations), 1)
+    fused = 16.0 * P * H * n
+    out = {"workload": "BASELINE config 4: 1048576 haplotypes (10 sites) x 256 populations, total migration 0.01, "
+                       "dense occupancy (%d infected per compartment), Poisson tau-leaping" % per_cell,
+           "steps": n, "ms_per_step": ms / n, "events_drawn": int(c.reserved[0]),
+           "value": c.reserved[0] / (ms * 1e-3), "unit": "events/s (device time)",
+           "roofline": {"bound": "hbm", "achieved": fused / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": fused / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                        "note": "all step kernels together (prep, migin, drift, draw x retries, check, commit); "
+                                "algorithmic bytes = 16*P*H per step (read+write infectious once)"}}
+    eng.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -72,6 +112,7 @@ def main():
     ap.add_argument("--events", type=int, default=100000, help="recorded events per replicate and step")
     ap.add_argument("--traj-points", type=int, default=1001)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-tau", action="store_true", help="skip the tau-leap (config 4) leg")
     a = ap.parse_args()
 
     import numpy as np
@@ -171,8 +212,15 @@ def main():
         }
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(line), flush=True)
     ens.close()
+    ens = None
+    if rank == 0:
+        if world == 1 and not a.no_tau:
+            try:
+                line["tau_leap"] = tau_leg(local)
+            except Exception as ex:  # never lose the headline line
+                line["tau_leap"] = {"error": repr(ex)}
+        print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
 

@@ -255,6 +255,28 @@ CASES["c3_s5_p16"] = (_ctor(number_of_sites=5, populations_number=16, number_of_
 CASES["c3_s6_p8_spread"] = (_ctor(number_of_sites=6, populations_number=8, number_of_susceptible_groups=1, seed=2022),
                             [(_c3_spread_warm, _direct(4000)), (_c3_spread_timed, _direct(2000, sample_size=10 ** 9))])
 
+def _p70(s):  # more than one 64-lane tile of populations; lockdowns in several demes; 2 susceptibility groups
+    s.set_transmission_rate(2.2)
+    s.set_transmission_rate(3.0, haplotype=2)
+    s.set_recovery_rate(0.8)
+    s.set_sampling_rate(0.05)
+    s.set_mutation_rate(0.2)
+    s.set_susceptibility_type(1)
+    s.set_susceptibility(0.5, susceptibility_type=1)
+    s.set_immunity_transition(0.05, source=1, target=0)
+    s.set_population_size(50000)
+    s.set_population_size(20000, population=69)
+    s.set_total_migration_probability(0.08)
+    s.set_contact_density(1.5, population=65)
+    for pn in (0, 3, 64, 69):
+        s.set_npi([0.3, 0.004, 0.001], population=pn)
+    s.set_sampling_multiplier(3.0, population=66)
+
+
+CASES["p70"] = (_ctor(number_of_sites=1, populations_number=70, number_of_susceptible_groups=2, seed=99),
+                [(_p70, _direct(15000))])
+CASES["big_seed"] = (_ctor(number_of_sites=1, seed=2 ** 40 + 12345), [(_g2, _direct(3000))])   # two-word SeedSequence entropy
+
 # cases whose full (6,N) chain is committed; the others commit head/tail columns + sha256 + counters
 FULL_CHAIN_LIMIT = 20000
 
