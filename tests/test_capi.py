@@ -60,8 +60,10 @@ def test_no_gpu_fails_loudly():
 
 
 def test_product_never_imports_oracle():
+    """oracle/ is test infrastructure: nothing under vgsim_amd/ may import, load or link it."""
+    pat = re.compile(r"(^\s*(from|import)\s+oracle\b)|libvgx_oracle|vgx_oracle\.|oracle/", re.M)
     for dirpath, _, files in os.walk(os.path.join(ROOT, "vgsim_amd")):
         for f in files:
-            if f.endswith((".py", ".hip", ".h", ".cpp")):
+            if f.endswith((".py", ".hip", ".h", ".cpp", "Makefile")):
                 text = open(os.path.join(dirpath, f)).read()
-                assert "oracle" not in text.replace("no CPU fallback", "").lower() or f == "__never__", (dirpath, f)
+                assert not pat.search(text), (dirpath, f)

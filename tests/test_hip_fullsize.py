@@ -1,0 +1,57 @@
+"""Parity at BASELINE.json's full config-3 size (65 536 haplotypes x 64 populations).  The dense oracle would
+need ~6 ms per event there, so the check uses (a) the oracle's occupied-only mode, which tests/test_oracle_golden.py
+proves bit-identical to the dense reference order, on one replicate, and (b) size-independent invariants on a
+whole ensemble: host conservation per population, counters vs compartments, event-type bookkeeping."""
+import contextlib
+import io
+
+import numpy as np
+import pytest
+
+import helpers
+
+pytestmark = pytest.mark.gpu
+
+
+def c3(seed, mut=0.01):
+    from vgsim_amd import Simulator
+    with contextlib.redirect_stdout(io.StringIO()):
+        s = Simulator(number_of_sites=8, populations_number=64, number_of_susceptible_groups=1, seed=seed)
+    s.set_transmission_rate(2.5); s.set_recovery_rate(0.9); s.set_sampling_rate(0.1)
+    s.set_mutation_rate(mut); s.set_total_migration_probability(0.01); s.set_population_size(10 ** 7)
+    return s
+
+
+@pytest.mark.parametrize("seed,mut,n", [(2020, 0.01, 40000), (2021, 0.4, 12000)])
+def test_config3_bit_exact_vs_sparse_oracle(oracle_mod, seed, mut, n):
+    hip = c3(seed, mut)
+    with helpers.quiet():
+        hip.simulate(n, sample_size=10 ** 9)
+    ref = c3(seed, mut).simulation
+    assert oracle_mod.run_direct(ref, n, 10 ** 9, -1, 200, sparse=True, log_mode=oracle_mod.LOG_PORTABLE) == 0
+    helpers.assert_models_equal(hip.simulation, ref, "config3 seed %d" % seed)
+    assert (hip.simulation.infectious != 0).sum() > (50 if mut < 0.1 else 1000)   # the lists are really exercised
+
+
+def test_config3_ensemble_invariants():
+    from vgsim_amd.ensemble import Ensemble
+    sim = c3(7)
+    R, N = 256, 20000
+    ens = Ensemble(sim, R)
+    res = ens.simulate(N, sample_size=10 ** 12, record_events=True)
+    assert (res.events == N).all() or (res.events <= N).all()
+    sizes = sim.simulation.sizes
+    for r in (0, 17, 255):
+        st = ens.replicate_state(r)
+        assert np.array_equal(st.susceptible.sum(axis=1) + st.infectious.sum(axis=1), sizes)      # hosts conserved per deme
+        assert st.globalInfectious == st.infectious.sum() and np.array_equal(st.totalInfectious, st.infectious.sum(axis=1))
+        chain = ens.replicate_events(r)
+        hist = np.bincount(chain[1].astype(int), minlength=7)
+        assert (hist[0], hist[1], hist[2], hist[3], hist[5]) == (st.bCounter, st.dCounter, st.sCounter, st.mCounter, st.migPlus)
+        assert 1 + st.bCounter + st.migPlus - st.dCounter - st.sCounter == st.globalInfectious    # index case + births - removals
+        assert (np.diff(chain[0]) >= 0).all() and chain[0, -1] == st.currentTime
+        # every loop iteration either records an event or is a rejected migration; failed attempts add theirs
+        assert res.loop_iterations[r] >= res.events[r] + st.migNonPlus
+        if res.restarts[r] == 0:
+            assert res.loop_iterations[r] == res.events[r] + st.migNonPlus
+    ens.close()

@@ -24,7 +24,7 @@ extern "C" hipError_t vgxi_launch_init_reps(const VgxDevRep *r, int P, int S, in
                                             const int64_t *s_tot, hipStream_t stream);
 
 #define TAU_DECL(name) extern "C" hipError_t vgxi_##name(const VgxTauArgs *a, hipStream_t s);
-TAU_DECL(tau_prep) TAU_DECL(tau_drift) TAU_DECL(tau_choose) TAU_DECL(tau_draw) TAU_DECL(tau_suscep_draw)
+TAU_DECL(tau_eff) TAU_DECL(tau_scatter) TAU_DECL(tau_prep) TAU_DECL(tau_drift) TAU_DECL(tau_choose) TAU_DECL(tau_draw) TAU_DECL(tau_suscep_draw)
 TAU_DECL(tau_check) TAU_DECL(tau_decide) TAU_DECL(tau_commit) TAU_DECL(tau_finish)
 
 static std::string g_create_error;
@@ -68,8 +68,9 @@ struct vgx_engine {
         r_evtime, r_evcols, r_locrec, r_loctime, r_traj, r_prof;
     // tau-leaping (dense compartments)
     DevBuf t_I, t_S, t_dChk, t_dApp, t_dSi, t_dTot, t_totInf, t_gI, t_cd, t_lock, t_F, t_eff, t_Aeff, t_Gout, t_dS,
-        t_taubits, t_tau, t_time, t_flags, t_counters, t_cnttry, t_mev, t_mevn, t_mevbase, t_locn, t_mutcum, t_migcdf, t_migIn;
+        t_taubits, t_tau, t_time, t_flags, t_counters, t_cnttry, t_mev, t_mevn, t_mevbase, t_locn, t_mutcum, t_migcdf, t_migIn, t_inc, t_incn;
     bool last_was_tau = false;
+    int64_t tau_mev_cap = 0;
     struct TauStep { double time; int64_t m0, m1; };
     std::vector<std::vector<TauStep>> tau_log;      // [R] MULTITYPE records of the last tau call
     std::vector<std::vector<double>> tau_loc_time;  // [R] lockdown log of the last tau call
@@ -710,6 +711,7 @@ extern "C" int vgx_simulate_tau(vgx_engine *e, int64_t iterations, int64_t sampl
     e->dev_state_valid = false;  // the occupancy lists are not maintained by the tau path
     for (int64_t pn = 0; pn < P; pn++)
         if (e->sizes[(size_t)pn] >= ((int64_t)1 << 31)) return fail(e, VGX_ERR_ARG, "vgx_simulate_tau: population sizes must be below 2^31");
+    if (e->C > 256 && (e->CB > 16 || S > 64)) return fail(e, VGX_ERR_CLASSES, "vgx_simulate_tau: more than 16 transmission classes together with more than 256 rate classes is not supported");
     const bool start_ok = (prep.totalRate + prep.totalMig != 0.0) && h.globalInfectious != 0;
 
     // ---- device arrays ----
@@ -743,6 +745,9 @@ extern "C" int vgx_simulate_tau(vgx_engine *e, int64_t iterations, int64_t sampl
     rc |= ensure(e, e->t_mevbase, (size_t)R * 8);
     rc |= ensure(e, e->t_locn, (size_t)R * 8);
     if (e->h_has_mig) rc |= ensure(e, e->t_migIn, (size_t)(R * P * H) * 8);
+    const int64_t inc_cap = std::max<int64_t>((int64_t)1 << 22, P * H / 8) / VGX_INC_SHARDS * VGX_INC_SHARDS;
+    rc |= ensure(e, e->t_inc, (size_t)(R * inc_cap) * 8);
+    rc |= ensure(e, e->t_incn, (size_t)R * VGX_INC_SHARDS * 8);
     rc |= ensure(e, e->t_migcdf, (size_t)(R * P * e->CB * P * S) * 8);
     {
         std::vector<double> cum;
@@ -754,8 +759,7 @@ extern "C" int vgx_simulate_tau(vgx_engine *e, int64_t iterations, int64_t sampl
     }
     rc |= upload(e, e->r_seeds, e->seeds.data(), e->seeds.size());
     if (rc) return VGX_ERR_HIP;
-    HIPCHECK(e, hipMemset(e->t_dChk.p, 0, (size_t)(R * P * H) * 8));
-    HIPCHECK(e, hipMemset(e->t_dApp.p, 0, (size_t)(R * P * H) * 8));
+    HIPCHECK(e, hipMemset(e->t_incn.p, 0, (size_t)R * VGX_INC_SHARDS * 8));
     HIPCHECK(e, hipMemset(e->t_dSi.p, 0, (size_t)(R * P * S) * 8));
     HIPCHECK(e, hipMemset(e->t_dTot.p, 0, (size_t)(R * P) * 8));
     HIPCHECK(e, hipMemset(e->t_counters.p, 0, (size_t)R * 64));
@@ -807,8 +811,10 @@ extern "C" int vgx_simulate_tau(vgx_engine *e, int64_t iterations, int64_t sampl
     a.mutcum = (const double *)e->t_mutcum.p;
     a.migcdf = (double *)e->t_migcdf.p;
     a.migIn = (double *)e->t_migIn.p;
+    a.inc = (int64_t *)e->t_inc.p; a.inc_cap = inc_cap; a.inc_n = (unsigned long long *)e->t_incn.p;
     a.counters = (int64_t *)e->t_counters.p; a.cnt_try = (int64_t *)e->t_cnttry.p;
     a.mev = (int64_t *)e->t_mev.p; a.mev_cap = mev_cap;
+    e->tau_mev_cap = mev_cap;
     a.mev_n = (unsigned long long *)e->t_mevn.p; a.mev_base = (unsigned long long *)e->t_mevbase.p;
     a.loc_n = (unsigned long long *)e->t_locn.p; a.loc_rec = (int32_t *)e->r_locrec.p; a.loc_time = (double *)e->r_loctime.p;
 
@@ -879,17 +885,19 @@ extern "C" int vgx_simulate_tau(vgx_engine *e, int64_t iterations, int64_t sampl
         HIPCHECK(e, hipMemcpy(a.attempt, att32.data(), (size_t)R * 4, hipMemcpyHostToDevice));
         HIPCHECK(e, hipMemcpy(a.time_now, tnow.data(), (size_t)R * 8, hipMemcpyHostToDevice));
         HIPCHECK(e, hipEventRecord(e->ev0, e->stream));
+        HIPCHECK(e, vgxi_tau_eff(&a, e->stream));
         HIPCHECK(e, vgxi_tau_prep(&a, e->stream));
         HIPCHECK(e, vgxi_tau_drift(&a, e->stream));
         HIPCHECK(e, vgxi_tau_choose(&a, e->stream));
-        launches += 3;
+        launches += 4;
         for (int tries = 0;; tries++) {
             HIPCHECK(e, vgxi_tau_draw(&a, e->stream));
             HIPCHECK(e, vgxi_tau_suscep_draw(&a, e->stream));
+            HIPCHECK(e, vgxi_tau_scatter(&a, e->stream));
             HIPCHECK(e, vgxi_tau_check(&a, e->stream));
             HIPCHECK(e, vgxi_tau_decide(&a, e->stream));
             HIPCHECK(e, vgxi_tau_commit(&a, e->stream));
-            launches += 5;
+            launches += 6;
             HIPCHECK(e, hipStreamSynchronize(e->stream));
             acc_h.resize((size_t)R);
             HIPCHECK(e, hipMemcpy(acc_h.data(), a.accepted, (size_t)R * 4, hipMemcpyDeviceToHost));
@@ -918,6 +926,7 @@ extern "C" int vgx_simulate_tau(vgx_engine *e, int64_t iterations, int64_t sampl
         HIPCHECK(e, hipMemcpy(mevb.data(), a.mev_base, (size_t)R * 8, hipMemcpyDeviceToHost));
         for (int64_t r = 0; r < R; r++) {
             if (!running[(size_t)r]) continue;
+            if (err_h[(size_t)r] == VGX_ERR_CAPACITY) return fail(e, VGX_ERR_CAPACITY, "vgx_simulate_tau: replicate " + std::to_string(r) + ": list of cross-compartment events full");
             if (err_h[(size_t)r]) return fail(e, VGX_ERR_LOOP_GUARD, "vgx_simulate_tau: replicate " + std::to_string(r) + ": tau underflow in the halving loop");
             if (mev_cap > 0 && (int64_t)mevn[(size_t)r] > mev_cap)
                 return fail(e, VGX_ERR_CAPACITY, "vgx_simulate_tau: multievent buffer full (pass record_events=0 for large runs)");
@@ -1071,7 +1080,8 @@ extern "C" int vgx_get_multievents(vgx_engine *e, int64_t replicate, int64_t cap
     *n = rows;
     rows = std::min(rows, cap);
     if (rows <= 0) return VGX_OK;
-    int64_t mev_cap = (int64_t)(e->t_mev.bytes / 48 / (size_t)e->R);
+    const int64_t mev_cap = e->tau_mev_cap;
+    if (mev_cap <= 0) return VGX_OK;  // the call did not record multievents
     std::vector<int64_t> buf((size_t)rows * 6);
     HIPCHECK(e, hipMemcpy(buf.data(), (int64_t *)e->t_mev.p + replicate * mev_cap * 6, (size_t)rows * 48, hipMemcpyDeviceToHost));
     size_t st = 0;

@@ -16,6 +16,7 @@
 #define VGX_WAVE 64
 #define VGX_MAX_CLASSES 1024   // distinct per-haplotype rate rows (full classes) supported by the direct kernel
 #define VGX_LOC_CAP 4096       // lockdown switches recorded per replicate and call
+#define VGX_INC_SHARDS 4096     // shards of the tau kernels' cross-compartment event list
 #define VGX_PROF_SLOTS 16       // in-kernel phase stamps of the diagnostic (-DVGX_PROFILE) build
 
 // fields of the per-replicate f64 population block
@@ -116,6 +117,9 @@ struct VgxTauArgs {
     int64_t *S;          // [R][P][S] susceptible
     int64_t *dChk;       // [R][P][H] infectious deltas as the reference's bounds check books them (pyx:2473)
     int64_t *dApp;       // [R][P][H] infectious deltas as UpdateCompartmentCounts_tau applies them (pyx:2548)
+    int64_t *inc;        // [R][inc_cap] individuals entering another compartment: cell index | (applied-only << 62)
+    int64_t inc_cap;
+    unsigned long long *inc_n;  // [R][VGX_INC_SHARDS]
     int64_t *dSi;        // [R][P][S] susceptible deltas
     int64_t *dTot;       // [R][P]    delta of totalInfectious
     int64_t *totInf;     // [R][P]

@@ -122,6 +122,35 @@ static __device__ __forceinline__ void atomic_min_pos_double(unsigned long long 
 }
 
 // ------------------------------------------------------------------------------------------------
+// effectiveMigration (pyx:327-338), its transposed/padded product with the diagonal, and the transmission factor,
+// rebuilt only when the contact densities changed (start of the call, lockdown switch).  grid = (P, R): one block
+// per row t.
+extern "C" __global__ void __launch_bounds__(TB) vgx_tau_eff_kernel(VgxTauArgs a) {
+    const int rep = blockIdx.y, t = blockIdx.x;
+    const VgxDevParams &p = a.p;
+    const int P = p.P, Pp = a.Ppad;
+    if (!a.active[rep] || !a.eff_dirty[rep]) return;
+    const double *cd = a.cd + (int64_t)rep * P;
+    double *eff = a.effMig + (int64_t)rep * P * P;
+    double *AeffT = a.Aeff + (int64_t)rep * P * Pp;   // [spn][tpn], rows padded to Pp with zeros
+    for (int s = threadIdx.x; s < P; s += TB) {
+        double e = 0.0;
+        if (t != s && a.has_mig)
+            for (int q = 0; q < P; ++q) e += p.mig[(int64_t)t * P + q] * p.mig[(int64_t)s * P + q] * cd[q] / p.actualSizes[q];
+        eff[(int64_t)t * P + s] = e;
+        AeffT[(int64_t)s * Pp + t] = e * p.mig[(int64_t)s * P + s];
+    }
+    for (int k = threadIdx.x; k < Pp - P; k += TB) AeffT[(int64_t)t * Pp + P + k] = 0.0;
+    if (threadIdx.x == 0) {
+        double f = 0.0;
+        for (int q = 0; q < P; ++q) {
+            double m = p.mig[(int64_t)t * P + q];
+            f += m * m * cd[q] / p.actualSizes[q];
+        }
+        a.F[(int64_t)rep * P + t] = f;
+    }
+}
+
 // Per-step, per-replicate preparation: transmission factor F[pn] = sum_spn m[pn,spn]^2 cd[spn]/as[spn]
 // (pyx:2412-2414), effectiveMigration (pyx:327-338) under the current contact densities,
 // Aeff[tpn][spn] = effMig[tpn,spn] * m[spn,spn] (pyx:2366-2367), and the out-migration weight of a source
@@ -129,33 +158,11 @@ static __device__ __forceinline__ void atomic_min_pos_double(unsigned long long 
 extern "C" __global__ void __launch_bounds__(TB) vgx_tau_prep_kernel(VgxTauArgs a) {
     const int rep = blockIdx.x;
     const VgxDevParams &p = a.p;
-    const int P = p.P, S = p.S, CB = p.CB, Pp = a.Ppad;
+    const int P = p.P, S = p.S, CB = p.CB;
     if (!a.active[rep]) return;
-    const double *cd = a.cd + (int64_t)rep * P;
-    double *F = a.F + (int64_t)rep * P;
     double *eff = a.effMig + (int64_t)rep * P * P;
-    double *AeffT = a.Aeff + (int64_t)rep * P * Pp;   // [spn][tpn], rows padded to Pp with zeros
     double *Gout = a.Gout + (int64_t)rep * P * CB;
     const int64_t *Sus = a.S + (int64_t)rep * P * S;
-    if (a.eff_dirty[rep]) {  // contact densities changed (start of the call / lockdown switch)
-        for (int pn = threadIdx.x; pn < P; pn += TB) {
-            double f = 0.0;
-            for (int q = 0; q < P; ++q) {
-                double m = p.mig[(int64_t)pn * P + q];
-                f += m * m * cd[q] / p.actualSizes[q];
-            }
-            F[pn] = f;
-        }
-        for (int idx = threadIdx.x; idx < P * P; idx += TB) {
-            int t = idx / P, s = idx % P;  // eff[t][s]
-            double e = 0.0;
-            if (t != s && a.has_mig)
-                for (int q = 0; q < P; ++q) e += p.mig[(int64_t)t * P + q] * p.mig[(int64_t)s * P + q] * cd[q] / p.actualSizes[q];
-            eff[idx] = e;
-            AeffT[(int64_t)s * Pp + t] = e * p.mig[(int64_t)s * P + s];
-        }
-        for (int idx = threadIdx.x; idx < P * (Pp - P); idx += TB) AeffT[(int64_t)(idx / (Pp - P)) * Pp + P + idx % (Pp - P)] = 0.0;
-    }
     __syncthreads();
     for (int idx = threadIdx.x; idx < P * CB; idx += TB) {
         int spn = idx / CB, cb = idx % CB;
@@ -242,66 +249,86 @@ extern "C" __global__ void __launch_bounds__(TB) vgx_tau_drift_kernel(VgxTauArgs
     const int rep = blockIdx.z, pn = blockIdx.y;
     if (!a.active[rep]) return;
     const VgxDevParams &p = a.p;
-    const int P = p.P, S = p.S, H = p.H, sites = p.sites;
-    const int hn = blockIdx.x * TB + threadIdx.x;
+    const int P = p.P, S = p.S, H = p.H, sites = p.sites, C = p.C, CB = p.CB;
     const int lane = threadIdx.x & 63;
     const int64_t *I = a.I + (int64_t)rep * P * H + (int64_t)pn * H;
     const int64_t *Sus = a.S + (int64_t)rep * P * S + (int64_t)pn * S;
     __shared__ double sdS[64];      // S <= 64 susceptibility groups
     __shared__ unsigned long long smin;
+    // class tables and this population's per-class factors in LDS when they are small (else global)
+    __shared__ double l_cd[256], l_cs[256], l_ctm[256], l_base[16 * 64], l_mutp[48];
+    __shared__ int32_t l_bidx[256], l_stype[256];
+    const bool useL = C <= 256 && CB <= 16;
     if (threadIdx.x < 64) sdS[threadIdx.x] = 0.0;
     if (threadIdx.x == 0) smin = (unsigned long long)__double_as_longlong(1.0);
+    if (useL) {
+        for (int i = threadIdx.x; i < C; i += TB) {
+            l_cd[i] = p.c_d[i]; l_cs[i] = p.c_s[i] * p.sampMult[pn]; l_ctm[i] = p.c_tm[i];
+            l_bidx[i] = p.c_bidx[i]; l_stype[i] = p.c_stype[i];
+        }
+        for (int i = threadIdx.x; i < CB * S; i += TB) l_base[i] = p.cb_b[i / S] * p.cb_sigma[i] * (double)Sus[i % S];
+    }
+    for (int i = threadIdx.x; i < 3 * sites && i < 48; i += TB) l_mutp[i] = a.mutcum[i] - (i > 0 ? a.mutcum[i - 1] : 0.0);
     __syncthreads();
-    const bool live = hn < H;
-    const int hh = live ? hn : H - 1;
-    const int c = p.cls[hh];
-    const int cb = p.c_bidx[c];
-    const int64_t Icell = live ? I[hh] : 0;
-    const double Ih = (double)Icell;
-    double drift = 0.0;
-    // recovery and sampling (pyx:2386-2395), outgoing mutation (pyx:2398-2404: sum_i w_i / sum w == 1)
-    const double rec = p.c_d[c] * Ih, samp = p.c_s[c] * Ih * p.sampMult[pn];
-    drift -= rec;
-    drift -= samp;
-    drift -= p.c_tm[c] * Ih;
-    // incoming mutation: sources differ from hn in exactly one site
-    for (int s = 0; s < sites; ++s) {
-        const int sh = 2 * (sites - s - 1);
-        const int AS = (hh >> sh) & 3;
-        for (int al = 0; al < 4; ++al) {
-            if (al == AS) continue;
-            const int src = hh + ((al - AS) << sh);
-            const int64_t Is = live ? I[src] : 0;
-            if (Is == 0) continue;
-            const int i = AS - (AS > al ? 1 : 0);  // derived-state index of `AS` in the source's numbering
-            double rate;
-            if (a.mut_uniform) rate = a.mutcum[s * 3 + i] - (s * 3 + i > 0 ? a.mutcum[s * 3 + i - 1] : 0.0);
-            else {
-                const double *hm = p.hapMutType + ((int64_t)src * sites + s) * 3;
-                rate = p.mRate[(int64_t)src * sites + s] * hm[i] / (hm[0] + hm[1] + hm[2]);
+    const double F = a.F[(int64_t)rep * P + pn];
+    double cand_min = 1.0;
+    for (int hn = blockIdx.x * TB + threadIdx.x; hn - (int)threadIdx.x < H; hn += gridDim.x * TB) {
+        const bool live = hn < H;
+        const int hh = live ? hn : H - 1;
+        const int c = p.cls[hh];
+        const int cb = useL ? l_bidx[c] : p.c_bidx[c];
+        const int st = useL ? l_stype[c] : p.c_stype[c];
+        const int64_t Icell = live ? I[hh] : 0;
+        const double Ih = (double)Icell;
+        double drift = 0.0;
+        // recovery and sampling (pyx:2386-2395), outgoing mutation (pyx:2398-2404: sum_i w_i / sum w == 1)
+        const double rec = (useL ? l_cd[c] : p.c_d[c]) * Ih;
+        const double samp = useL ? l_cs[c] * Ih : p.c_s[c] * Ih * p.sampMult[pn];
+        drift -= rec;
+        drift -= samp;
+        drift -= (useL ? l_ctm[c] : p.c_tm[c]) * Ih;
+        // incoming mutation: sources differ from hn in exactly one site
+        for (int s = 0; s < sites; ++s) {
+            const int sh = 2 * (sites - s - 1);
+            const int AS = (hh >> sh) & 3;
+            for (int al = 0; al < 4; ++al) {
+                if (al == AS) continue;
+                const int src = hh + ((al - AS) << sh);
+                const int64_t Is = live ? I[src] : 0;
+                if (Is == 0) continue;
+                const int i = AS - (AS > al ? 1 : 0);  // derived-state index of `AS` in the source's numbering
+                double rate;
+                if (a.mut_uniform) rate = l_mutp[s * 3 + i];
+                else {
+                    const double *hm = p.hapMutType + ((int64_t)src * sites + s) * 3;
+                    rate = p.mRate[(int64_t)src * sites + s] * hm[i] / (hm[0] + hm[1] + hm[2]);
+                }
+                drift += rate * (double)Is;
             }
-            drift += rate * (double)Is;
+        }
+        // transmission (pyx:2407-2417) and incoming migration (pyx:2360-2370)
+        const double migI = (a.has_mig && live) ? a.migIn[((int64_t)rep * P + pn) * H + hh] : 0.0;
+        const double to_st = live ? rec + samp : 0.0;
+        for (int sn = 0; sn < S; ++sn) {
+            double base = useL ? l_base[cb * S + sn] : p.cb_b[cb] * p.cb_sigma[cb * S + sn] * (double)Sus[sn];
+            double v = live ? base * Ih * F + base * migI : 0.0;
+            drift += v;
+            double red = -v + (st == sn ? to_st : 0.0);   // susceptible drift of (pn, sn)
+            for (int o = 32; o > 0; o >>= 1) red += __shfl_down(red, o);
+            if (lane == 0 && red != 0.0) atomicAdd(&sdS[sn], red);
+        }
+        if (live && fabs(drift) >= 1e-8) {  // pyx:2440-2444, epsilon*X in single precision
+            float eps = 0.03f;
+            double v = (double)(eps * (float)Icell) / 2.0;
+            double cand = (v > 1.0 ? v : 1.0) / fabs(drift);
+            if (cand < cand_min) cand_min = cand;
         }
     }
-    // transmission (pyx:2407-2417) and incoming migration (pyx:2360-2370)
-    const double migI = (a.has_mig && live) ? a.migIn[((int64_t)rep * P + pn) * H + hh] : 0.0;
-    const double F = a.F[(int64_t)rep * P + pn];
-    const double b = p.cb_b[cb];
-    const double to_st = live ? rec + samp : 0.0;
-    for (int sn = 0; sn < S; ++sn) {
-        double base = b * p.cb_sigma[cb * S + sn] * (double)Sus[sn];
-        double v = live ? base * Ih * F + base * migI : 0.0;
-        drift += v;
-        double red = -v + ((int)p.c_stype[c] == sn ? to_st : 0.0);   // susceptible drift of (pn, sn)
-        for (int o = 32; o > 0; o >>= 1) red += __shfl_down(red, o);
-        if (lane == 0 && red != 0.0) atomicAdd(&sdS[sn], red);
+    for (int o = 32; o > 0; o >>= 1) {
+        double other = __shfl_down(cand_min, o);
+        if (other < cand_min) cand_min = other;
     }
-    if (live && fabs(drift) >= 1e-8) {  // pyx:2440-2444, epsilon*X in single precision
-        float eps = 0.03f;
-        double v = (double)(eps * (float)Icell) / 2.0;
-        double cand = (v > 1.0 ? v : 1.0) / fabs(drift);
-        atomic_min_pos_double(&smin, cand);
-    }
+    if (lane == 0) atomic_min_pos_double(&smin, cand_min);
     __syncthreads();
     if (threadIdx.x < S && sdS[threadIdx.x] != 0.0) atomicAdd(&a.dS[((int64_t)rep * P + pn) * S + threadIdx.x], sdS[threadIdx.x]);
     if (threadIdx.x == 0) atomicMin(&a.tau_bits[rep], smin);
@@ -356,17 +383,45 @@ static __device__ __forceinline__ void tau_row(const VgxTauArgs &a, int rep, int
     }
 }
 
+// One individual entering compartment `cell` from another compartment (a mutant: booked in both delta arrays; a
+// migrant: applied only, pyx:2473 vs pyx:2548).  Appended to the replicate's list; vgx_tau_scatter_kernel adds them
+// after the draw kernel, when every compartment has stored its own deltas.
+// The list is sharded by thread block (VGX_INC_SHARDS counters) so that appends do not serialise on one address.
+static __device__ __forceinline__ void tau_incoming(const VgxTauArgs &a, int rep, int64_t cell, bool applied_only) {
+    const int shard = (int)((blockIdx.x + gridDim.x * blockIdx.y) & (VGX_INC_SHARDS - 1));
+    const int64_t scap = a.inc_cap / VGX_INC_SHARDS;
+    unsigned long long slot = atomicAdd(&a.inc_n[(int64_t)rep * VGX_INC_SHARDS + shard], 1ull);
+    if ((int64_t)slot < scap)
+        a.inc[(int64_t)rep * a.inc_cap + (int64_t)shard * scap + (int64_t)slot] = cell | (applied_only ? ((int64_t)1 << 62) : 0);
+}
+
+// Per-block tables of the draw kernel (a block works on ONE population): class parameters, this population's
+// transmission / migration weights per birth class and the bisection tables, staged in LDS when they fit
+// (else the pointers refer to the global arrays).
+struct TauTab {
+    const double *c_d, *c_s, *c_tm;      // [C]
+    const int32_t *c_bidx, *c_stype;     // [C]
+    const double *rtr;                   // [CB]   transmission rate per infected of the class: sum_sn wtr
+    const double *wtr;                   // [CB][S] b * sigma[sn] * S[pn][sn] * F[pn]
+    const double *rmig;                  // [CB]   out-migration rate per infected: Gout * b * m[pn][pn]
+    const double *mutcum;                // [3*sites] running sums of the uniform mutation model
+    const double *cdf;                   // [CB][P*S] running sums of the out-migration channel weights of pn
+};
+
 // GenerateEvents_tau for one compartment (pn, hn).  All channels out of a compartment are independent Poisson
 // variables, so their sum is Poisson with the summed rate and, given the sum, the channel of each event is
-// multinomial: ONE draw per compartment, then a split (same joint law as pyx:2464-2520, ~5x fewer draws).
-// Books
+// multinomial: ONE draw per compartment, then a split (same joint law as pyx:2464-2520, ~5x fewer draws).  The
+// split first only counts the frequent kinds (recovery, sampling, transmission) and the number of mutants and
+// migrants; their targets are then chosen by bisection in a second, short loop, so the rare, expensive branches
+// are not executed by the whole wavefront on every event.  Books
 //   dChk : the infectious deltas the reference's bounds check looks at (pyx:2473: a migrant is booked on its
 //          SOURCE compartment there),
 //   dApp : the infectious deltas UpdateCompartmentCounts_tau applies (pyx:2548: the migrant infects the
 //          TARGET population),
 //   the susceptible deltas (identical in both), the tentative counters and multievent rows.
 // The compartment arrays themselves are not touched, so every thread sees the pre-step state.
-static __device__ __forceinline__ void tau_cell(const VgxTauArgs &a, int rep, int pn, int hn, double tau, int64_t *cnt,
+static __device__ __forceinline__ void tau_cell(const VgxTauArgs &a, const TauTab &T, int rep, int pn, int hn, double tau,
+                                                int64_t *cnt,
                                                 unsigned long long *sS /* LDS [S]: this population's susceptible deltas */,
                                                 unsigned long long *sTot /* LDS: delta of totalInfectious[pn] */) {
     const VgxDevParams &p = a.p;
@@ -374,149 +429,205 @@ static __device__ __forceinline__ void tau_cell(const VgxTauArgs &a, int rep, in
     const int64_t *I = a.I + (int64_t)rep * P * H;
     int64_t *dC = a.dChk + (int64_t)rep * P * H;
     int64_t *dA = a.dApp + (int64_t)rep * P * H;
-    const int64_t *Sus = a.S + (int64_t)rep * P * S;
     int64_t *dS = a.dSi + (int64_t)rep * P * S;
     const int64_t Icell = I[(int64_t)pn * H + hn];
+    // every compartment stores its own deltas (plain, coalesced), so the arrays need no clearing pass;
+    // deltas INTO other compartments (mutants, migrants) go through the append list and are scattered afterwards
+    dC[(int64_t)pn * H + hn] = 0;
+    dA[(int64_t)pn * H + hn] = 0;
     if (Icell == 0) return;
     const double Ih = (double)Icell;
     const int c = p.cls[hn];
-    const int cb = p.c_bidx[c];
-    const int st = p.c_stype[c];
+    const int cb = T.c_bidx[c];
+    const int st = T.c_stype[c];
     // ---- channel rates per unit time ----
-    const double G = a.has_mig ? a.Gout[((int64_t)rep * P + pn) * p.CB + cb] : 0.0;
-    const double r_mig = G * Ih * p.cb_b[cb] * p.mig[(int64_t)pn * P + pn];          // pyx:2366-2367 summed over (tpn, sn)
-    const double r_rec = p.c_d[c] * Ih;                                              // pyx:2386
-    const double r_samp = p.c_s[c] * Ih * p.sampMult[pn];                            // pyx:2392
-    const double r_mut = (a.mut_uniform ? a.mut_total : p.c_tm[c]) * Ih;             // pyx:2400-2401 summed over (s, i)
-    const double Fb = p.cb_b[cb] * Ih * a.F[(int64_t)rep * P + pn];
-    double r_tr = 0.0;                                                               // pyx:2412-2414 summed over sn
-    for (int sn = 0; sn < S; ++sn) r_tr += Fb * p.cb_sigma[cb * S + sn] * (double)Sus[pn * S + sn];
+    const double r_rec = T.c_d[c] * Ih;                                              // pyx:2386
+    const double r_samp = T.c_s[c] * Ih * p.sampMult[pn];                            // pyx:2392
+    const double r_tr = T.rtr[cb] * Ih;                                              // pyx:2412-2414 summed over sn
+    const double r_mut = (a.mut_uniform ? a.mut_total : T.c_tm[c]) * Ih;             // pyx:2400-2401 summed over (s, i)
+    const double r_mig = T.rmig[cb] * Ih;                                            // pyx:2366-2367 summed over (tpn, sn)
     const double r_all = r_mig + r_rec + r_samp + r_mut + r_tr;
     TauRng g;
     g.init((uint64_t)a.seeds[rep], (uint32_t)a.attempt[rep], (uint64_t)pn * (uint64_t)H + (uint64_t)hn, (uint32_t)a.step[rep],
            (uint32_t)a.retry[rep]);
     const int64_t N = tau_poisson(g, r_all * tau);
     if (N == 0) return;
-    int64_t own = 0, migrants = 0, rec = 0, samp = 0, births = 0;
+    int64_t rec = 0, samp = 0, births = 0, n_mut = 0, n_mig = 0;
+    const double t1 = r_rec, t2 = t1 + r_samp, t3 = t2 + r_tr, t4 = t3 + r_mut;
     for (int64_t ev = 0; ev < N; ++ev) {
         double u = g.uniform() * r_all;
-        if (u < r_rec) { rec += 1; continue; }
-        u -= r_rec;
-        if (u < r_samp) { samp += 1; continue; }
-        u -= r_samp;
-        if (u < r_tr || (r_mut == 0.0 && r_mig == 0.0)) {
+        if (u < t1) rec += 1;
+        else if (u < t2) samp += 1;
+        else if (u < t3 || (r_mut == 0.0 && r_mig == 0.0)) {
             // transmission to susceptibility group sn (pyx:2515-2520 / 2589-2593)
-            double acc = 0.0;
+            double uu = (u - t2) / Ih, acc = 0.0;
             int sn_hit = -1;
             for (int sn = 0; sn < S; ++sn) {
-                double w = Fb * p.cb_sigma[cb * S + sn] * (double)Sus[pn * S + sn];
+                double w = T.wtr[cb * S + sn];
                 acc += w;
                 if (w > 0.0) sn_hit = sn;          // last positive channel so far: fallback at the upper end
-                if (u < acc) break;
+                if (uu < acc) break;
             }
             if (sn_hit < 0) continue;
             births += 1;
             atomicAdd(&sS[sn_hit], (unsigned long long)(-1ll));
-            cnt[0] += 1;
             tau_row(a, rep, 1, 0, hn, pn, sn_hit, 0);
-            continue;
-        }
-        u -= r_tr;
-        if (u < r_mut || r_mig == 0.0) {
-            // mutation (pyx:2506-2512 / 2579-2586): site and derived state
-            double uu = (r_mut > 0.0 ? u / r_mut : 0.0), acc = 0.0;
-            int ss = -1, ii = 0;
-            if (a.mut_uniform) {
-                uu *= a.mut_total;
-                const int nch = 3 * sites;
-                int lo = 0, hi = nch - 1;
-                while (lo < hi) {
-                    int mid = (lo + hi) >> 1;
-                    if (a.mutcum[mid] > uu) hi = mid; else lo = mid + 1;
-                }
-                while (lo > 0 && a.mutcum[lo] == a.mutcum[lo - 1]) lo -= 1;
-                if (nch > 0 && a.mutcum[nch - 1] > 0.0) { ss = lo / 3; ii = lo % 3; }
-            } else {
-                uu *= p.c_tm[c];
-                for (int s = 0; s < sites && ss < 0; ++s) {
-                    const double *hm = p.hapMutType + ((int64_t)hn * sites + s) * 3;
-                    double wsum = hm[0] + hm[1] + hm[2], mr = p.mRate[(int64_t)hn * sites + s];
-                    for (int i = 0; i < 3; ++i) {
-                        acc += mr * hm[i] / wsum;
-                        if (uu < acc) { ss = s; ii = i; break; }
-                    }
-                }
-                if (ss < 0)
-                    for (int s = sites - 1; s >= 0 && ss < 0; --s) {
-                        const double *hm = p.hapMutType + ((int64_t)hn * sites + s) * 3;
-                        for (int i = 2; i >= 0; --i)
-                            if (p.mRate[(int64_t)hn * sites + s] * hm[i] > 0.0) { ss = s; ii = i; break; }
-                    }
-            }
-            if (ss < 0) continue;
-            int nh = tau_mutate(sites, hn, ss, ii);
-            own -= 1;
-            atomicAdd((unsigned long long *)&dC[(int64_t)pn * H + nh], 1ull);
-            atomicAdd((unsigned long long *)&dA[(int64_t)pn * H + nh], 1ull);
-            cnt[3] += 1;
-            tau_row(a, rep, 1, 3, hn, pn, nh, 0);
-            continue;
-        }
-        u -= r_mut;
-        {
-            // migration (pyx:2464-2474 / 2541-2550): target population and susceptibility group, by bisection in
-            // the cumulative channel weights of this source population and birth class
-            const double *cdf = a.migcdf + (((int64_t)rep * P + pn) * p.CB + cb) * (int64_t)P * S;
-            const int nch = P * S;
-            double uu = (u / r_mig) * cdf[nch - 1];
-            int lo = 0, hi = nch - 1;
-            while (lo < hi) {               // first channel with cdf > uu
-                int mid = (lo + hi) >> 1;
-                if (cdf[mid] > uu) hi = mid; else lo = mid + 1;
-            }
-            while (lo > 0 && cdf[lo] == cdf[lo - 1]) lo -= 1;   // a zero-weight channel can only be hit by rounding
-            int tp = lo / S, ts = lo % S;
-            if (tp == pn || !(cdf[nch - 1] > 0.0)) tp = -1;
-            if (tp < 0) continue;
-            migrants += 1;
-            atomicAdd((unsigned long long *)&dA[(int64_t)tp * H + hn], 1ull);
-            atomicAdd((unsigned long long *)&dS[tp * S + ts], (unsigned long long)(-1ll));
-            atomicAdd((unsigned long long *)&a.dTot[(int64_t)rep * P + tp], 1ull);
-            cnt[5] += 1;
-            tau_row(a, rep, 1, 5, hn, pn, ts, tp);
-        }
+        } else if (u < t4 || r_mig == 0.0) n_mut += 1;
+        else n_mig += 1;
     }
-    if (rec) { cnt[1] += rec; tau_row(a, rep, rec, 1, hn, pn, st, 0); }
-    if (samp) { cnt[2] += samp; tau_row(a, rep, samp, 2, hn, pn, st, 0); }
-    own += births - rec - samp;
-    if (own + migrants != 0) atomicAdd((unsigned long long *)&dC[(int64_t)pn * H + hn], (unsigned long long)(own + migrants));
-    if (own != 0) atomicAdd((unsigned long long *)&dA[(int64_t)pn * H + hn], (unsigned long long)own);
+    // ---- mutants (pyx:2506-2512 / 2579-2586): site and derived state ----
+    int64_t mut_done = 0;
+    for (int64_t k = 0; k < n_mut; ++k) {
+        int ss = -1, ii = 0;
+        if (a.mut_uniform) {
+            const int nch = 3 * sites;
+            double uu = g.uniform() * T.mutcum[nch - 1];
+            int lo = 0, hi = nch - 1;
+            while (lo < hi) {
+                int mid = (lo + hi) >> 1;
+                if (T.mutcum[mid] > uu) hi = mid; else lo = mid + 1;
+            }
+            while (lo > 0 && T.mutcum[lo] == T.mutcum[lo - 1]) lo -= 1;   // a zero-weight channel can only be hit by rounding
+            if (T.mutcum[nch - 1] > 0.0) { ss = lo / 3; ii = lo % 3; }
+        } else {
+            double uu = g.uniform() * T.c_tm[c], acc = 0.0;
+            for (int s = 0; s < sites && ss < 0; ++s) {
+                const double *hm = p.hapMutType + ((int64_t)hn * sites + s) * 3;
+                double wsum = hm[0] + hm[1] + hm[2], mr = p.mRate[(int64_t)hn * sites + s];
+                for (int i = 0; i < 3; ++i) {
+                    acc += mr * hm[i] / wsum;
+                    if (uu < acc) { ss = s; ii = i; break; }
+                }
+            }
+            if (ss < 0)
+                for (int s = sites - 1; s >= 0 && ss < 0; --s) {
+                    const double *hm = p.hapMutType + ((int64_t)hn * sites + s) * 3;
+                    for (int i = 2; i >= 0; --i)
+                        if (p.mRate[(int64_t)hn * sites + s] * hm[i] > 0.0) { ss = s; ii = i; break; }
+                }
+        }
+        if (ss < 0) continue;
+        int nh = tau_mutate(sites, hn, ss, ii);
+        mut_done += 1;
+        tau_incoming(a, rep, (int64_t)pn * H + nh, false);
+        tau_row(a, rep, 1, 3, hn, pn, nh, 0);
+    }
+    // ---- migrants (pyx:2464-2474 / 2541-2550): target population and susceptibility group, by bisection in the
+    // cumulative channel weights of this source population and birth class ----
+    int64_t migrants = 0;
+    for (int64_t k = 0; k < n_mig; ++k) {
+        const double *cdf = T.cdf + (int64_t)cb * P * S;
+        const int nch = P * S;
+        double uu = g.uniform() * cdf[nch - 1];
+        int lo = 0, hi = nch - 1;
+        while (lo < hi) {               // first channel with cdf > uu
+            int mid = (lo + hi) >> 1;
+            if (cdf[mid] > uu) hi = mid; else lo = mid + 1;
+        }
+        while (lo > 0 && cdf[lo] == cdf[lo - 1]) lo -= 1;
+        int tp = lo / S, ts = lo % S;
+        if (tp == pn || !(cdf[nch - 1] > 0.0)) continue;
+        migrants += 1;
+        tau_incoming(a, rep, (int64_t)tp * H + hn, true);
+        atomicAdd((unsigned long long *)&dS[tp * S + ts], (unsigned long long)(-1ll));
+        atomicAdd((unsigned long long *)&a.dTot[(int64_t)rep * P + tp], 1ull);
+        tau_row(a, rep, 1, 5, hn, pn, ts, tp);
+    }
+    cnt[0] += births; cnt[1] += rec; cnt[2] += samp; cnt[3] += mut_done; cnt[5] += migrants;
+    if (rec) tau_row(a, rep, rec, 1, hn, pn, st, 0);
+    if (samp) tau_row(a, rep, samp, 2, hn, pn, st, 0);
+    const int64_t own = births - rec - samp - mut_done;
+    dC[(int64_t)pn * H + hn] = own + migrants;
+    dA[(int64_t)pn * H + hn] = own;
     if (rec + samp != 0) atomicAdd(&sS[st], (unsigned long long)(rec + samp));
     int64_t dt = births - rec - samp;
     if (dt != 0) atomicAdd(sTot, (unsigned long long)dt);
 }
 
-// grid = (ceil(H/TB), P, R); dChk/dApp/dSi/dTot are zero on entry
+// LDS budget of the draw kernel's tables (doubles, then int32); 0 = tables stay in global memory
+static __host__ __device__ inline size_t tau_tab_lds_bytes(int C, int CB, int S, int P, bool &cdf_in_lds) {
+    cdf_in_lds = false;
+    if (C > 256 || CB > 16) return 0;
+    size_t dbl = 3 * (size_t)C + 2 * (size_t)CB + (size_t)CB * S + 48;
+    if ((size_t)CB * P * S <= 4096) { cdf_in_lds = true; dbl += (size_t)CB * P * S; }
+    return dbl * 8 + 2 * (size_t)C * 4;
+}
+
+// grid = (ceil(H/TB), P, R); dSi/dTot are zero on entry
 extern "C" __global__ void __launch_bounds__(TB) vgx_tau_draw_kernel(VgxTauArgs a) {
     const int rep = blockIdx.z, pn = blockIdx.y;
     if (!a.active[rep] || a.accepted[rep]) return;
+    const VgxDevParams &p = a.p;
+    const int P = p.P, S = p.S, C = p.C, CB = p.CB;
     const int hn = blockIdx.x * TB + threadIdx.x;
-    int64_t cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
     // per-block accumulation of everything that all compartments of a population add to (one global atomic per
     // block instead of one per compartment: the susceptible deltas of a population are a single address)
     __shared__ unsigned long long sc[8], sS[64], sTot;
+    __shared__ double g_rtr[16], g_rmig[16], g_wtr[16 * 64];   // fallback storage when the class tables stay global
     if (threadIdx.x < 8) sc[threadIdx.x] = 0;
     if (threadIdx.x < 64) sS[threadIdx.x] = 0;
     if (threadIdx.x == 0) sTot = 0;
+    bool cdfL;
+    const bool useL = tau_tab_lds_bytes(C, CB, S, P, cdfL) != 0;
+    TauTab T;
+    const double F = a.F[(int64_t)rep * P + pn];
+    const int64_t *Sus = a.S + (int64_t)rep * P * S + (int64_t)pn * S;
+    const double *gcdf = a.migcdf + ((int64_t)rep * P + pn) * CB * (int64_t)P * S;
+    if (useL) {
+        double *d = (double *)dsm;
+        double *l_cd = d; d += C;
+        double *l_cs = d; d += C;
+        double *l_ctm = d; d += C;
+        double *l_rtr = d; d += CB;
+        double *l_rmig = d; d += CB;
+        double *l_wtr = d; d += CB * S;
+        double *l_mut = d; d += 48;
+        double *l_cdf = d; if (cdfL) d += CB * P * S;
+        int32_t *l_bidx = (int32_t *)d;
+        int32_t *l_stype = l_bidx + C;
+        for (int i = threadIdx.x; i < C; i += TB) {
+            l_cd[i] = p.c_d[i]; l_cs[i] = p.c_s[i]; l_ctm[i] = p.c_tm[i]; l_bidx[i] = p.c_bidx[i]; l_stype[i] = p.c_stype[i];
+        }
+        for (int i = threadIdx.x; i < CB * S; i += TB) l_wtr[i] = p.cb_b[i / S] * p.cb_sigma[i] * (double)Sus[i % S] * F;
+        for (int i = threadIdx.x; i < 3 * p.sites && i < 48; i += TB) l_mut[i] = a.mutcum[i];
+        if (cdfL)
+            for (int i = threadIdx.x; i < CB * P * S; i += TB) l_cdf[i] = gcdf[i];
+        __syncthreads();
+        for (int cb = threadIdx.x; cb < CB; cb += TB) {
+            double r = 0.0;
+            for (int sn = 0; sn < S; ++sn) r += l_wtr[cb * S + sn];
+            l_rtr[cb] = r;
+            l_rmig[cb] = a.has_mig ? a.Gout[((int64_t)rep * P + pn) * CB + cb] * p.cb_b[cb] * p.mig[(int64_t)pn * P + pn] : 0.0;
+        }
+        T.c_d = l_cd; T.c_s = l_cs; T.c_tm = l_ctm; T.c_bidx = l_bidx; T.c_stype = l_stype;
+        T.rtr = l_rtr; T.wtr = l_wtr; T.rmig = l_rmig; T.mutcum = l_mut; T.cdf = cdfL ? l_cdf : gcdf;
+    } else {
+        // many classes: parameters stay in global memory; the per-population weights of up to 16 birth classes
+        // are still prepared once per block (more birth classes are rejected by the host)
+        for (int i = threadIdx.x; i < CB * S && i < 16 * 64; i += TB) g_wtr[i] = p.cb_b[i / S] * p.cb_sigma[i] * (double)Sus[i % S] * F;
+        __syncthreads();
+        for (int cb = threadIdx.x; cb < CB && cb < 16; cb += TB) {
+            double r = 0.0;
+            for (int sn = 0; sn < S; ++sn) r += g_wtr[cb * S + sn];
+            g_rtr[cb] = r;
+            g_rmig[cb] = a.has_mig ? a.Gout[((int64_t)rep * P + pn) * CB + cb] * p.cb_b[cb] * p.mig[(int64_t)pn * P + pn] : 0.0;
+        }
+        T.c_d = p.c_d; T.c_s = p.c_s; T.c_tm = p.c_tm; T.c_bidx = p.c_bidx; T.c_stype = p.c_stype;
+        T.rtr = g_rtr; T.wtr = g_wtr; T.rmig = g_rmig; T.mutcum = a.mutcum; T.cdf = gcdf;
+    }
     __syncthreads();
-    if (hn < a.p.H) tau_cell(a, rep, pn, hn, a.tau[rep], cnt, sS, &sTot);
+    int64_t cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const double tau = a.tau[rep];
+    for (int h = hn; h < p.H; h += gridDim.x * TB)   // persistent over haplotype tiles: the table staging is amortised
+        tau_cell(a, T, rep, pn, h, tau, cnt, sS, &sTot);
     for (int i = 0; i < 6; ++i)
         if (cnt[i]) atomicAdd(&sc[i], (unsigned long long)cnt[i]);
     __syncthreads();
     if (threadIdx.x < 6 && sc[threadIdx.x]) atomicAdd((unsigned long long *)&a.cnt_try[(int64_t)rep * 8 + threadIdx.x], sc[threadIdx.x]);
-    if (threadIdx.x < a.p.S && sS[threadIdx.x])
-        atomicAdd((unsigned long long *)&a.dSi[((int64_t)rep * a.p.P + pn) * a.p.S + threadIdx.x], sS[threadIdx.x]);
-    if (threadIdx.x == 0 && sTot) atomicAdd((unsigned long long *)&a.dTot[(int64_t)rep * a.p.P + pn], sTot);
+    if (threadIdx.x < S && sS[threadIdx.x])
+        atomicAdd((unsigned long long *)&a.dSi[((int64_t)rep * P + pn) * S + threadIdx.x], sS[threadIdx.x]);
+    if (threadIdx.x == 0 && sTot) atomicAdd((unsigned long long *)&a.dTot[(int64_t)rep * P + pn], sTot);
 }
 
 // Immunity transitions (pyx:2479-2487 / 2554-2562): P*S*S slots per replicate, one thread each.
@@ -541,6 +652,29 @@ extern "C" __global__ void __launch_bounds__(TB) vgx_tau_suscep_draw_kernel(VgxT
     atomicAdd((unsigned long long *)&dS[pn * S + ssn], (unsigned long long)(-k));
     atomicAdd((unsigned long long *)&a.cnt_try[(int64_t)rep * 8 + 4], (unsigned long long)k);
     tau_row(a, rep, k, 4, ssn, pn, tsn, 0);
+}
+
+// Adds the appended incoming individuals to the delta arrays and empties the list.  grid = (VGX_INC_SHARDS, R).
+extern "C" __global__ void __launch_bounds__(64) vgx_tau_scatter_kernel(VgxTauArgs a) {
+    const int rep = blockIdx.y, shard = blockIdx.x;
+    if (!a.active[rep] || a.accepted[rep]) return;
+    const int64_t PH = (int64_t)a.p.P * a.p.H;
+    const int64_t scap = a.inc_cap / VGX_INC_SHARDS;
+    unsigned long long *cntp = &a.inc_n[(int64_t)rep * VGX_INC_SHARDS + shard];
+    unsigned long long n = *cntp;
+    if ((int64_t)n > scap) {  // shard overflow: the step cannot be validated
+        if (threadIdx.x == 0) a.error[rep] = 4;
+        n = (unsigned long long)scap;
+    }
+    const int64_t *lst = a.inc + (int64_t)rep * a.inc_cap + (int64_t)shard * scap;
+    for (unsigned long long i = threadIdx.x; i < n; i += 64) {
+        int64_t e = lst[i];
+        int64_t cell = e & (((int64_t)1 << 62) - 1);
+        atomicAdd((unsigned long long *)&a.dApp[(int64_t)rep * PH + cell], 1ull);
+        if (!(e >> 62)) atomicAdd((unsigned long long *)&a.dChk[(int64_t)rep * PH + cell], 1ull);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) *cntp = 0;
 }
 
 // Bounds check of GenerateEvents_tau (pyx:2522-2528).  grid = (ceil(H/TB), P, R).
@@ -591,8 +725,9 @@ extern "C" __global__ void __launch_bounds__(64) vgx_tau_decide_kernel(VgxTauArg
     }
 }
 
-// UpdateCompartmentCounts_tau for accepted replicates (I += dApp, S += dS, totals), clearing of the delta
-// arrays for both accepted and rejected ones.  grid = (ceil(H/TB), P, R).
+// UpdateCompartmentCounts_tau for accepted replicates (I += dApp, S += dS, totals); the small per-population
+// accumulators are cleared for accepted and rejected ones alike (the [P][H] delta arrays are overwritten by the
+// next draw).  grid = (ceil(H/TB), P, R).
 extern "C" __global__ void __launch_bounds__(TB) vgx_tau_commit_kernel(VgxTauArgs a) {
     const int rep = blockIdx.z, pn = blockIdx.y;
     if (!a.deciding[rep]) return;
@@ -601,9 +736,10 @@ extern "C" __global__ void __launch_bounds__(TB) vgx_tau_commit_kernel(VgxTauArg
     const int hn = blockIdx.x * TB + threadIdx.x;
     if (hn < H) {
         int64_t off = (int64_t)rep * P * H + (int64_t)pn * H + hn;
-        int64_t dA = a.dApp[off];
-        if (dA != 0) { if (acc) a.I[off] += dA; a.dApp[off] = 0; }
-        if (a.dChk[off] != 0) a.dChk[off] = 0;
+        if (acc) {
+            int64_t dA = a.dApp[off];
+            if (dA != 0) a.I[off] += dA;
+        }
     }
     if (blockIdx.x == 0 && threadIdx.x < S) {
         int64_t off = ((int64_t)rep * P + pn) * S + threadIdx.x;
@@ -664,6 +800,7 @@ extern "C" __global__ void __launch_bounds__(64) vgx_tau_finish_kernel(VgxTauArg
     }
 #define CELL_GRID dim3((unsigned)((a->p.H + TB - 1) / TB), (unsigned)a->p.P, (unsigned)a->R)
 #define SUS_GRID dim3((unsigned)((a->p.P * a->p.S * a->p.S + TB - 1) / TB), (unsigned)a->R)
+TAU_LAUNCH(tau_eff, dim3((unsigned)a->p.P, (unsigned)a->R), dim3(TB))
 TAU_LAUNCH(tau_prep, dim3((unsigned)a->R), dim3(TB))
 extern "C" __attribute__((visibility("hidden"))) hipError_t vgxi_tau_drift(const VgxTauArgs *a, hipStream_t s) {
     if (a->has_mig) {
@@ -677,12 +814,24 @@ extern "C" __attribute__((visibility("hidden"))) hipError_t vgxi_tau_drift(const
         err = hipGetLastError();
         if (err != hipSuccess) return err;
     }
-    hipLaunchKernelGGL(vgx_tau_drift_kernel, CELL_GRID, dim3(TB), 0, s, *a);
+    unsigned tiles = (unsigned)((a->p.H + TB - 1) / TB);
+    unsigned gx = tiles < 32u ? tiles : 32u;
+    hipLaunchKernelGGL(vgx_tau_drift_kernel, dim3(gx, (unsigned)a->p.P, (unsigned)a->R), dim3(TB), 0, s, *a);
     return hipGetLastError();
 }
 TAU_LAUNCH(tau_choose, dim3((unsigned)a->R), dim3(64))
-TAU_LAUNCH(tau_draw, CELL_GRID, dim3(TB))
+extern "C" __attribute__((visibility("hidden"))) hipError_t vgxi_tau_draw(const VgxTauArgs *a, hipStream_t s) {
+    bool cdfL;
+    size_t lds = tau_tab_lds_bytes(a->p.C, a->p.CB, a->p.S, a->p.P, cdfL);
+    hipError_t err = hipFuncSetAttribute((const void *)vgx_tau_draw_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds ? lds : 16));
+    if (err != hipSuccess) return err;
+    unsigned tiles = (unsigned)((a->p.H + TB - 1) / TB);
+    unsigned gx = tiles < 32u ? tiles : 32u;   // blocks per (population, replicate); each loops over its tiles
+    hipLaunchKernelGGL(vgx_tau_draw_kernel, dim3(gx, (unsigned)a->p.P, (unsigned)a->R), dim3(TB), lds ? lds : 16, s, *a);
+    return hipGetLastError();
+}
 TAU_LAUNCH(tau_suscep_draw, SUS_GRID, dim3(TB))
+TAU_LAUNCH(tau_scatter, dim3((unsigned)VGX_INC_SHARDS, (unsigned)a->R), dim3(64))
 TAU_LAUNCH(tau_check, CELL_GRID, dim3(TB))
 TAU_LAUNCH(tau_decide, dim3((unsigned)a->R), dim3(64))
 TAU_LAUNCH(tau_commit, CELL_GRID, dim3(TB))
