@@ -802,37 +802,43 @@ static __device__ __forceinline__ void restart_state(Ctx &c, const VgxDevRep &r)
     WSYNC();
 }
 
-extern "C" __global__ void __launch_bounds__(LANES) vgx_direct_kernel(VgxDirectArgs a) {
+// Kernel body, specialised on the LDS stride of the per-population arrays (PT: 64 when popNum <= 64, so every
+// LDS address is a compile-time constant; 0 = runtime stride), on the number of susceptibility groups (ST: 1 or 0 =
+// runtime) and on a single rate class (ONE): the common shapes lose their address arithmetic and inner loops.
+template <int PT, int ST, int ONE>
+static __device__ __forceinline__ void direct_body(const VgxDirectArgs &a) {
     const int rep = blockIdx.x;
     if (rep >= a.n_replicates) return;
     const int lane = threadIdx.x;
     const VgxDevParams &p = a.p;
     const VgxDevRep &r = a.r;
-    const int P = p.P, S = p.S, C = p.C, CB = p.CB;
+    const int P = p.P, S = ST ? ST : p.S, C = ONE ? 1 : p.C, CB = ONE ? 1 : p.CB;
+    const int PL = PT ? PT : P;   // LDS stride of the [P] arrays
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     Ctx c;
     c.P = P; c.S = S; c.H = p.H; c.C = C; c.CB = CB; c.sites = p.sites; c.lane = lane;
     c.p = &a.p;
-    // LDS carve: keep in step with vgxi_direct_lds_bytes()
+    // LDS carve: keep in step with vgxi_direct_lds_bytes().  Arrays whose size depends only on (PL, S) first.
     double *ld = (double *)smem;
-    c.popRate = ld; ld += P;   c.infect = ld; ld += P;   c.immune = ld; ld += P;   c.migRate = ld; ld += P;
-    c.maxEBM = ld; ld += P;    c.cd = ld; ld += P;       c.as = ld; ld += P;       c.cum = ld; ld += P;
-    c.cumMig = ld; ld += P;    c.sampMult = ld; ld += P; c.ldStart = ld; ld += P;  c.ldEnd = ld; ld += P;
-    c.immSrc = ld; ld += P * S;
-    c.birthC = ld; ld += P * CB;
-    c.xC = ld; ld += P * CB * S;
-    c.tE = ld; ld += C;   c.c_d = ld; ld += C;   c.c_s = ld; ld += C;   c.c_tm = ld; ld += C;
-    c.cb_b = ld; ld += CB;
-    c.cb_sigma = ld; ld += CB * S;
+    c.popRate = ld; ld += PL;   c.infect = ld; ld += PL;   c.immune = ld; ld += PL;   c.migRate = ld; ld += PL;
+    c.maxEBM = ld; ld += PL;    c.cd = ld; ld += PL;       c.as = ld; ld += PL;       c.cum = ld; ld += PL;
+    c.cumMig = ld; ld += PL;    c.sampMult = ld; ld += PL; c.ldStart = ld; ld += PL;  c.ldEnd = ld; ld += PL;
+    c.immSrc = ld; ld += PL * S;
     c.cumul = ld; ld += S;
     c.trans = ld; ld += S * S;
     int64_t *li = (int64_t *)ld;
-    c.totalSus = li; li += P;   c.totalInf = li; li += P;   c.lockON = li; li += P;
-    c.sus = li; li += P * S;
+    c.totalSus = li; li += PL;   c.totalInf = li; li += PL;   c.lockON = li; li += PL;
+    c.sus = li; li += PL * S;
     c.cnt = li; li += 8;
-    int32_t *l4 = (int32_t *)li;
-    c.nocc = l4; l4 += P;
+    c.nocc = (int32_t *)li; li += (PL + 1) / 2;
+    ld = (double *)li;
+    c.birthC = ld; ld += PL * CB;
+    c.xC = ld; ld += PL * CB * S;
+    c.tE = ld; ld += C;   c.c_d = ld; ld += C;   c.c_s = ld; ld += C;   c.c_tm = ld; ld += C;
+    c.cb_b = ld; ld += CB;
+    c.cb_sigma = ld; ld += CB * S;
+    int32_t *l4 = (int32_t *)ld;
     c.c_bidx = l4; l4 += C;
     c.c_stype = l4; l4 += C;
 
@@ -1035,6 +1041,12 @@ extern "C" __global__ void __launch_bounds__(LANES) vgx_direct_kernel(VgxDirectA
     }
 }
 
+extern "C" __global__ void __launch_bounds__(LANES) vgx_direct_kernel(VgxDirectArgs a) { direct_body<0, 0, 0>(a); }
+// popNum <= 64: constant LDS addresses
+extern "C" __global__ void __launch_bounds__(LANES) vgx_direct_kernel_p64(VgxDirectArgs a) { direct_body<64, 0, 0>(a); }
+// popNum <= 64, one susceptibility group, one rate class (e.g. BASELINE configs 2 and 3)
+extern "C" __global__ void __launch_bounds__(LANES) vgx_direct_kernel_p64s1c1(VgxDirectArgs a) { direct_body<64, 1, 1>(a); }
+
 // Gives every replicate the same start state (the host model's state at the beginning of the call):
 // occupancy lists, susceptible counts, contact densities, population totals and lockdown flags.
 extern "C" __global__ void __launch_bounds__(LANES) vgx_init_reps_kernel(
@@ -1065,18 +1077,21 @@ extern "C" __global__ void __launch_bounds__(LANES) vgx_init_reps_kernel(
 
 // ---- host-side launchers (this translation unit owns its kernels; no relocatable device code needed) ----
 extern "C" __attribute__((visibility("hidden"))) size_t vgxi_direct_lds_bytes(int P, int S, int C, int CB) {
-    size_t f64 = 12 * (size_t)P + (size_t)P * S + (size_t)P * CB + (size_t)P * CB * S + 4 * (size_t)C + CB +
-                 (size_t)CB * S + S + (size_t)S * S;
-    size_t i64 = 3 * (size_t)P + (size_t)P * S + 8;
-    size_t i32 = (size_t)P + 2 * (size_t)C;
-    return (f64 + i64) * 8 + ((i32 * 4 + 15) / 16) * 16;
+    size_t PL = P <= 64 ? 64 : (size_t)P;
+    size_t f64 = 12 * PL + PL * S + S + (size_t)S * S;
+    size_t i64 = 3 * PL + PL * S + 8 + (PL + 1) / 2;
+    size_t f64b = PL * CB + PL * CB * S + 4 * (size_t)C + CB + (size_t)CB * S;
+    size_t i32 = 2 * (size_t)C;
+    return (f64 + i64 + f64b) * 8 + ((i32 * 4 + 15) / 16) * 16;
 }
 
 extern "C" __attribute__((visibility("hidden"))) hipError_t vgxi_launch_direct(const VgxDirectArgs *a, size_t lds,
                                                                               hipStream_t stream) {
-    hipError_t err = hipFuncSetAttribute((const void *)vgx_direct_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    void (*k)(VgxDirectArgs) = vgx_direct_kernel;
+    if (a->p.P <= 64) k = (a->p.S == 1 && a->p.C == 1 && a->p.CB == 1) ? vgx_direct_kernel_p64s1c1 : vgx_direct_kernel_p64;
+    hipError_t err = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (err != hipSuccess) return err;
-    hipLaunchKernelGGL(vgx_direct_kernel, dim3((unsigned)a->n_replicates), dim3(LANES), lds, stream, *a);
+    hipLaunchKernelGGL(k, dim3((unsigned)a->n_replicates), dim3(LANES), lds, stream, *a);
     return hipGetLastError();
 }
 
