@@ -103,3 +103,39 @@ def test_multievent_rows_account_for_counters():
     assert hip.mCounter == direct[3] + by_type[3]
     assert hip.iCounter == direct[4] + by_type[4]
     assert hip.migPlus == direct[5] + by_type[5]
+
+
+def test_tau_ensemble_replicates_equal_single_runs():
+    """Replicate r of a tau ensemble is the run a single engine makes with that seed: the Philox streams are keyed
+    by (seed, attempt, compartment, step, retry) and all accumulation is integer, so equality is exact."""
+    from vgsim_amd import Simulator
+    from vgsim_amd.ensemble import Ensemble
+    ctor, phases = models.CASES["tau_b"]
+    seeds = np.array([7, 8, 1234, 99], dtype=np.int64)
+
+    def warm(seed):
+        with helpers.quiet():
+            sim = Simulator(**dict(ctor, seed=int(seed)))
+            phases[0][0](sim)
+        return sim
+
+    # common start state: a direct warm-up with seed 7, then tau with different seeds
+    base = warm(7)
+    with helpers.quiet():
+        base.simulate(2000)
+    ens = Ensemble(base, len(seeds), seeds=seeds)
+    res = ens.simulate_tau(60, sample_size=10 ** 12)
+    for r, seed in enumerate(seeds):
+        one = warm(7)
+        with helpers.quiet():
+            one.simulate(2000)
+            one.simulation.user_seed = int(seed)      # same start state, replicate's seed for the tau phase
+            one.simulate(60, sample_size=10 ** 12, method="tau")
+        st = ens.replicate_state(r)
+        m = one.simulation
+        assert np.array_equal(st.infectious, m.infectious) and np.array_equal(st.susceptible, m.susceptible), r
+        assert (st.bCounter, st.dCounter, st.sCounter, st.mCounter, st.iCounter, st.migPlus) == \
+               (m.bCounter, m.dCounter, m.sCounter, m.mCounter, m.iCounter, m.migPlus)
+        assert st.currentTime == m.currentTime and res.events[r] == m.events.ptr
+    assert len({int(ens.replicate_state(r).bCounter) for r in range(len(seeds))}) > 1   # the seeds really differ
+    ens.close()

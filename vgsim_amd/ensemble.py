@@ -82,6 +82,43 @@ class Ensemble:
         self.traj_shape = (self.R, int(traj_points), m.popNum, 2) if traj_points > 0 else None
         return res
 
+    def simulate_tau(self, iterations, sample_size=None, epidemic_time=-1, attempts=200, record_events=False, seeds=None):
+        """Poisson tau-leaping for every replicate from the model's current state (``SimulatePopulation_tau``
+        semantics per replicate, pyx:2293-2346).  ``EnsembleResult.events`` counts MULTITYPE records (steps);
+        ``events_drawn`` the sum of the drawn channel multiplicities."""
+        m, eng = self.model, self.engine
+        if seeds is not None:
+            self.seeds = np.ascontiguousarray(seeds, dtype=np.int64)
+        if sample_size is None:
+            sample_size = iterations
+        if epidemic_time is None:
+            epidemic_time = -1
+        ptr, size = m.events.ptr, m.events.size
+        for _ in range(2):  # CreateEvents is called twice on the tau path (pyx:2298 -> pyx:434, pyx:2306)
+            size = size + iterations if ptr == 0 else max(size, ptr + iterations)
+        eng.set_params(m)
+        saved = (m.events.ptr, m.events.size)
+        m.events.size = size
+        try:
+            eng.set_state(m)
+        finally:
+            m.events.ptr, m.events.size = saved
+        eng.set_seeds(self.seeds)
+        o = _capi.VgxRunOpts()
+        o.record_events = 1 if record_events else 0
+        rc = eng.lib.vgx_simulate_tau(eng.handle, int(iterations), int(sample_size), float(np.float32(epidemic_time)),
+                                      int(attempts), C.byref(o))
+        eng._check(rc)
+        res = EnsembleResult(self.R)
+        res.events_drawn = np.zeros(self.R, dtype=np.int64)
+        for r in range(self.R):
+            c = eng.counters(r)
+            res.events[r], res.loop_iterations[r], res.restarts[r] = c.ev_ptr, c.loop_iterations, c.restarts
+            res.events_drawn[r] = c.reserved[0]
+        res.kernel_ms = eng.last_kernel_ms
+        self.traj_shape = None
+        return res
+
     def replicate_state(self, replicate):
         """A host model object holding the state (compartments, counters, times) of one replicate."""
         import copy
