@@ -9,6 +9,7 @@
 #include <stdint.h>
 #include <string.h>
 #include <algorithm>
+#include <cmath>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -672,28 +673,38 @@ extern "C" int vgx_simulate_tau(vgx_engine *e, int64_t iterations, int64_t sampl
     const int64_t ev_ptr_start = h.ev_ptr, ev_size = h.ev_size;
 
     // PrepareParameters (pyx:2298): first-call snapshot on the host, then CheckLockdown for every population and
-    // UpdateAllRates through the direct kernel run with zero attempts (it stops after that preparation).
+    // UpdateAllRates.  The tau steps never read the direct path's rate caches; what the driver needs from
+    // UpdateAllRates is only whether totalRate + totalMigrationRate is non-zero (pyx:2311).  For moderately
+    // occupied states the direct kernel does that preparation exactly (run with zero attempts); for densely
+    // occupied large states (its exact, lane-ordered row sums would take seconds) the lockdown switches and the
+    // non-zero test are done on the host and totalRate is reported as NaN (the reference leaves a stale value).
     e->dev_state_valid = false;
-    vgx_run_opts po{};
-    po.record_events = 0;
-    int rc = direct_core(e, 0, -1, -1.0f, 0, &po);
-    if (rc) return rc;
-    const VgxRepScalars prep = e->sc_host[0];
-    std::vector<double> popD((size_t)(PD_COUNT * P));
-    std::vector<int64_t> popI((size_t)(PI_COUNT * P));
-    HIPCHECK(e, hipMemcpy(popD.data(), e->r_popD.p, popD.size() * 8, hipMemcpyDeviceToHost));
-    HIPCHECK(e, hipMemcpy(popI.data(), e->r_popI.p, popI.size() * 8, hipMemcpyDeviceToHost));
-    for (int64_t pn = 0; pn < P; pn++) {
-        h.contactDensity[(size_t)pn] = popD[(size_t)(PD_CD * P + pn)];
-        h.lockdownON[(size_t)pn] = popI[(size_t)(PI_LOCK * P + pn)];
-    }
-    h.swapLockdown = prep.swapLockdown;
-    h.totalRate = prep.totalRate;
-    h.totalMigrationRate = prep.totalMig;
     e->tau_loc_time.assign((size_t)R, {});
     e->tau_loc_state.assign((size_t)R, {});
     e->tau_loc_pop.assign((size_t)R, {});
-    {
+    prepare_first(e);
+    int64_t occupied = 0;
+    for (int64_t i = 0; i < P * H; i++) occupied += h.infectious[(size_t)i] != 0;
+    bool rates_nonzero = false;
+    int rc = 0;
+    if (occupied <= ((int64_t)1 << 18)) {
+        vgx_run_opts po{};
+        po.record_events = 0;
+        rc = direct_core(e, 0, -1, -1.0f, 0, &po);
+        if (rc) return rc;
+        const VgxRepScalars prep = e->sc_host[0];
+        std::vector<double> popD((size_t)(PD_COUNT * P));
+        std::vector<int64_t> popI((size_t)(PI_COUNT * P));
+        HIPCHECK(e, hipMemcpy(popD.data(), e->r_popD.p, popD.size() * 8, hipMemcpyDeviceToHost));
+        HIPCHECK(e, hipMemcpy(popI.data(), e->r_popI.p, popI.size() * 8, hipMemcpyDeviceToHost));
+        for (int64_t pn = 0; pn < P; pn++) {
+            h.contactDensity[(size_t)pn] = popD[(size_t)(PD_CD * P + pn)];
+            h.lockdownON[(size_t)pn] = popI[(size_t)(PI_LOCK * P + pn)];
+        }
+        h.swapLockdown = prep.swapLockdown;
+        h.totalRate = prep.totalRate;
+        h.totalMigrationRate = prep.totalMig;
+        rates_nonzero = prep.totalRate + prep.totalMig != 0.0;
         int64_t n = std::min<int64_t>(prep.loc_n, VGX_LOC_CAP);
         std::vector<int32_t> rec((size_t)n * 2);
         std::vector<double> tt((size_t)n);
@@ -707,18 +718,43 @@ extern "C" int vgx_simulate_tau(vgx_engine *e, int64_t iterations, int64_t sampl
                 e->tau_loc_pop[(size_t)r].push_back(rec[(size_t)(i * 2 + 1)]);
                 e->tau_loc_time[(size_t)r].push_back(tt[(size_t)i]);
             }
+    } else {
+        for (int64_t pn = 0; pn < P; pn++) {  // CheckLockdown (pyx:698-710) on the host totals
+            for (int pass = 0; pass < 2; pass++) {
+                double ti = (double)h.totalInfectious[(size_t)pn], sz = (double)e->sizes[(size_t)pn];
+                bool flip = pass == 0 ? (ti > e->h_startLD[(size_t)pn] * sz && h.lockdownON[(size_t)pn] == 0)
+                                      : (ti < e->h_endLD[(size_t)pn] * sz && h.lockdownON[(size_t)pn] == 1);
+                if (!flip) continue;
+                h.contactDensity[(size_t)pn] = pass == 0 ? e->h_cdAfter[(size_t)pn] : e->h_cdBefore[(size_t)pn];
+                h.lockdownON[(size_t)pn] = pass == 0 ? 1 : 0;
+                h.swapLockdown += 1;
+                for (int64_t r = 0; r < R; r++) {
+                    e->tau_loc_state[(size_t)r].push_back(pass == 0 ? 1 : 0);
+                    e->tau_loc_pop[(size_t)r].push_back(pn);
+                    e->tau_loc_time[(size_t)r].push_back(h.currentTime);
+                }
+            }
+        }
+        rates_nonzero = h.globalInfectious != 0;   // an infected host always has a positive total event rate unless every rate is 0
+        for (int64_t pn = 0; pn < P && !rates_nonzero; pn++)
+            for (int64_t sn = 0; sn < S; sn++)
+                if (e->suscepCumul[(size_t)sn] * (double)h.susceptible[(size_t)(pn * S + sn)] != 0.0) rates_nonzero = true;
+        h.totalRate = std::nan("");
+        h.totalMigrationRate = std::nan("");
     }
     e->dev_state_valid = false;  // the occupancy lists are not maintained by the tau path
     for (int64_t pn = 0; pn < P; pn++)
         if (e->sizes[(size_t)pn] >= ((int64_t)1 << 31)) return fail(e, VGX_ERR_ARG, "vgx_simulate_tau: population sizes must be below 2^31");
     if (e->C > 256 && (e->CB > 16 || S > 64)) return fail(e, VGX_ERR_CLASSES, "vgx_simulate_tau: more than 16 transmission classes together with more than 256 rate classes is not supported");
-    const bool start_ok = (prep.totalRate + prep.totalMig != 0.0) && h.globalInfectious != 0;
+    const bool start_ok = rates_nonzero && h.globalInfectious != 0;
 
     // ---- device arrays ----
     const int64_t mev_cap = o.record_events ? std::max<int64_t>(1, std::min<int64_t>((int64_t)1 << 24, iterations * 8192)) : 0;
     const size_t nF = 9;  // int32 flag arrays
     const int64_t Ppad = (P + 31) / 32 * 32;
     rc = 0;
+    rc |= ensure(e, e->r_locrec, (size_t)(R * VGX_LOC_CAP * 2) * 4);
+    rc |= ensure(e, e->r_loctime, (size_t)(R * VGX_LOC_CAP) * 8);
     rc |= ensure(e, e->t_I, (size_t)(R * P * H) * 8);
     rc |= ensure(e, e->t_S, (size_t)(R * P * S) * 8);
     rc |= ensure(e, e->t_dChk, (size_t)(R * P * H) * 8);

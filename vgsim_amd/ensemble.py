@@ -168,6 +168,9 @@ class Ensemble:
         else:
             mine = torch.from_numpy(self.trajectories())
         world, rank = dist.get_world_size(), dist.get_rank()
-        bufs = [torch.empty_like(mine) for _ in range(world)] if rank == dst else None
-        dist.gather(mine, bufs, dst=dst)
-        return torch.stack(bufs) if rank == dst else None
+        if rank == dst:   # gather straight into the rows of the result: no second copy of [world, R, T, P, 2]
+            out = torch.empty((world,) + tuple(mine.shape), dtype=mine.dtype, device=mine.device)
+            dist.gather(mine, list(out.unbind(0)), dst=dst)
+            return out
+        dist.gather(mine, None, dst=dst)
+        return None
