@@ -63,7 +63,85 @@ def cpu_baseline(seconds_target=45.0):
                       "reference's dense mode, %.1f s" % (done, n1, t3 - t2)}
 
 
-def tau_leg(device, steps=3, per_cell=3):
+def spread_leg(device, mode="exact", replicates=1024, events=20000, occupied=4096):
+    """Config 3 at *spread* occupancy: every population starts with `occupied` distinct
+    haplotypes (1-3 infected each, written straight into the model's arrays — the reference's own
+    set_infectious is broken, pyx:1596).  Here the per-event work is the stream over the chosen population's
+    occupancy list, so the kernel is priced against HBM with the same byte formula as the headline leg."""
+    import numpy as np
+    from vgsim_amd.ensemble import Ensemble
+    sim = make_simulator(2020)
+    m = sim.simulation
+    H = m.hapNum
+    rng = np.random.default_rng(2020)
+    for pn in range(POPS):
+        haps = rng.choice(H, size=occupied, replace=False)
+        m.infectious[pn, haps] = rng.integers(1, 4, size=occupied)
+        m.susceptible[pn, 0] -= int(m.infectious[pn].sum())
+    ens = Ensemble(sim, replicates, device=device)
+    seeds = 5000 + np.arange(replicates, dtype=np.int64)
+    best = None
+    for it in range(2):   # first launch is the warm-up
+        res = ens.simulate(events, sample_size=10 ** 12, record_events=True, traj_points=0, seeds=seeds + it * replicates,
+                           mode=mode)
+        best = res
+    st = ens.replicate_state(0)
+    nocc = float((st.infectious != 0).sum(axis=1).mean())
+    ms = best.kernel_ms
+    ev = best.total_events
+    # exact: the whole list of the chosen population is streamed (16 B/entry); fast: tile sums + one tile
+    bpe = (16.0 * nocc if mode == "exact" else 8.0 * (nocc / 64.0) + 16.0 * 64) + 8.0 * POPS + 28.0 + 8.0
+    out = {"workload": "BASELINE config 3, spread occupancy: %d occupied haplotypes per population at start "
+                       "(mean %.0f at the end), %d replicates x %d events, %s mode" % (occupied, nocc, replicates, events, mode),
+           "value": ev / (ms * 1e-3), "unit": "events/s (device time)", "kernel_ms_per_launch": ms,
+           "roofline": {"bound": "hbm", "achieved": ev * bpe / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": ev * bpe / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                        "bytes_per_event": bpe, "mean_occupancy_list_len": nocc}}
+    ens.close()
+    return out
+
+
+def fast_leg(device, replicates, events, traj_points):
+    """The headline workload (natural occupancy) in FAST mode, device time of one launch after a warm-up."""
+    import numpy as np
+    from vgsim_amd.ensemble import Ensemble
+    ens = Ensemble(make_simulator(2020), replicates, device=device)
+    res = None
+    for it in range(2):
+        res = ens.simulate(events, sample_size=10 ** 12, record_events=True, traj_points=traj_points,
+                           traj_window=(0.0, 12.0), seeds=2020 + it * replicates + np.arange(replicates, dtype=np.int64),
+                           mode="fast")
+    out = {"workload": "headline workload in FAST mode (order-free sums, same PCG64 stream)",
+           "value": res.total_events / (res.kernel_ms * 1e-3), "unit": "events/s (device time)",
+           "kernel_ms_per_launch": res.kernel_ms}
+    ens.close()
+    return out
+
+
+def c2_leg(device, replicates=16384, events=100000):
+    """BASELINE config 2 (H=1, P=1, S=1, N=1e6): latency-bound — one dependent chain per event; reported as
+    events/s per replicate and replicates in flight."""
+    import numpy as np
+    from vgsim_amd import Simulator
+    from vgsim_amd.ensemble import Ensemble
+    with contextlib.redirect_stdout(io.StringIO()):
+        s = Simulator(number_of_sites=0, populations_number=1, number_of_susceptible_groups=1, seed=2020)
+    s.set_transmission_rate(4.0); s.set_recovery_rate(1.5); s.set_sampling_rate(0.3)
+    ens = Ensemble(s, replicates, device=device)
+    res = None
+    for it in range(2):
+        res = ens.simulate(events, sample_size=10 ** 12, record_events=True,
+                           seeds=2020 + it * replicates + np.arange(replicates, dtype=np.int64))
+    ms = res.kernel_ms
+    out = {"workload": "BASELINE config 2: 1 haplotype x 1 population, b=4.0 d=1.5 s=0.3, N=1e6",
+           "replicates_in_flight": replicates, "events_per_replicate": events,
+           "value": res.total_events / (ms * 1e-3), "unit": "events/s (device time)",
+           "events_per_s_per_replicate": res.total_events / (ms * 1e-3) / replicates, "kernel_ms_per_launch": ms}
+    ens.close()
+    return out
+
+
+def tau_leg(device, steps=20, per_cell=3):
     """Tau-leaping on BASELINE config 4 (2^20 haplotypes x 256 populations, migration), dense ("spread")
     occupancy written straight into the model's arrays; the reference cannot even construct this shape
     (SURVEY.md §0.8).  Reports events drawn per second of device time and the step's HBM roofline against the
@@ -113,6 +191,7 @@ def main():
     ap.add_argument("--traj-points", type=int, default=1001)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-tau", action="store_true", help="skip the tau-leap (config 4) leg")
+    ap.add_argument("--no-extra", action="store_true", help="skip the spread-occupancy and config-2 legs")
     a = ap.parse_args()
 
     import numpy as np
@@ -143,7 +222,8 @@ def main():
     def step(i):
         # distinct seeds per (step, rank, replicate): results do not depend on the GPU count
         seeds = 2020 + (i * world + rank) * R + np.arange(R, dtype=np.int64)
-        res = ens.simulate(N, sample_size=10 ** 12, traj_points=a.traj_points, traj_window=(0.0, 12.0), seeds=seeds)
+        res = ens.simulate(N, sample_size=10 ** 12, record_events=True, traj_points=a.traj_points,
+                           traj_window=(0.0, 12.0), seeds=seeds)
         gathered = ens.gather_trajectories(dst=0) if world > 1 else None
         return res, gathered
 
@@ -210,6 +290,15 @@ def main():
                                  "reference's dense layout would need %.3g B/event = %.3g GB/s at this event rate"
                                  % (dense_bytes, ev_per_launch * dense_bytes / launch_s / 1e9)},
         }
+        # event log: resident in HBM per replicate (28 B/event); D2H through vgx_get_events on a sample
+        t_d = time.perf_counter()
+        nrep = min(R, 32)
+        got = 0
+        for r in range(nrep):
+            got += ens.replicate_events(r).shape[1]
+        t_d = time.perf_counter() - t_d
+        line["event_log"] = {"device_bytes_per_event": 28, "d2h_sample_replicates": nrep, "d2h_events": got,
+                             "d2h_s": t_d, "note": "copy-out widens to the reference's (6,N) float64 layout on the host"}
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
     ens.close()
@@ -220,6 +309,16 @@ def main():
                 line["tau_leap"] = tau_leg(local)
             except Exception as ex:  # never lose the headline line
                 line["tau_leap"] = {"error": repr(ex)}
+        if world == 1 and not a.no_extra:
+            legs = (("fast_mode", lambda d: fast_leg(d, R, N, a.traj_points)),
+                    ("spread_occupancy", lambda d: spread_leg(d, "exact")),
+                    ("spread_occupancy_fast", lambda d: spread_leg(d, "fast", replicates=4096)),
+                    ("config2", c2_leg))
+            for name, fn in legs:
+                try:
+                    line[name] = fn(local)
+                except Exception as ex:
+                    line[name] = {"error": repr(ex)}
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -82,7 +82,11 @@ typedef struct vgx_run_opts {
     int64_t max_loop_factor; /* loop guard: at most max_loop_factor*iterations + 2^20 loop iterations (0 = 1024) */
     int64_t traj_points;     /* >0: bin totalInfectious/totalSusceptible[P] at this many uniform time points */
     double traj_t0, traj_t1; /* time window of the trajectory grid */
-    int64_t reserved[4];
+    int64_t mode;            /* direct path: 0 = EXACT (the reference's floating-point summation order, bit-exact log);
+                                1 = FAST (order-free sums: class-aggregated infection rate, integer prefix search,
+                                factored BirthRate, tree scans; same random stream and event semantics; needs one
+                                rate class).  Ignored by vgx_simulate_tau. */
+    int64_t reserved[3];
 } vgx_run_opts;
 
 /* Per-replicate results of the last simulate call. */

@@ -105,13 +105,17 @@ def check_against_golden(model, name, exact_time=True, rtol_time=1e-12):
     assert np.array_equal(model.infectious, inf)
 
 
-def run_case_hip(name, phases_limit=None):
-    """Drive a case through the product path: Simulator -> BirthDeathModel -> ctypes -> libvgx.so -> HIP."""
+def run_case_hip(name, phases_limit=None, mode=None):
+    """Drive a case through the product path: Simulator -> BirthDeathModel -> ctypes -> libvgx.so -> HIP.
+    ``mode='fast'`` runs the direct phases in the engine's FAST mode."""
     from vgsim_amd import Simulator
     with quiet():
         sim, phases = models.build(Simulator, name)
         for setup, kw in phases[:phases_limit]:
             setup(sim)
+            kw = dict(kw)
+            if mode is not None and kw.get("method", "direct") == "direct":
+                kw["mode"] = mode
             sim.simulate(**kw)
     return sim
 

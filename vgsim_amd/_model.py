@@ -664,13 +664,23 @@ class BirthDeathModel:
             self._engine = HipEngine(self.sites, self.hapNum, self.popNum, self.susNum, n_replicates=1)
         return self._engine
 
-    def SimulatePopulation(self, iterations, sample_size, time, attempts):
-        """pyx:396-429: direct Gillespie on the GPU (one persistent wavefront per trajectory)."""
+    def SimulatePopulation(self, iterations, sample_size, time, attempts, mode='exact'):
+        """pyx:396-429: direct Gillespie on the GPU (one persistent wavefront per trajectory).  ``mode``:
+        'exact' = the reference's floating-point summation order (bit-exact log); 'fast' = order-free sums
+        (same random stream and event semantics, needs one rate class; include/vgx.h vgx_run_opts.mode)."""
         self._check_supported()
+        if mode not in ('exact', 'fast'):
+            raise ValueError("mode must be 'exact' or 'fast'")
         self.events.CreateEvents(iterations)
         self.CheckSizes()
         time = float(np.float32(time))  # `float time` in the reference signature
-        self._get_engine().simulate_direct(self, iterations, sample_size, time, attempts)
+        opts = None
+        if mode == 'fast':
+            from . import _capi
+            opts = _capi.VgxRunOpts()
+            opts.record_events = 1
+            opts.mode = 1
+        self._get_engine().simulate_direct(self, iterations, sample_size, time, attempts, opts)
         self._print_termination(sample_size, time)
 
     def SimulatePopulation_tau(self, iterations, sample_size, time, attempts):

@@ -65,7 +65,7 @@ struct vgx_engine {
     DevBuf p_cls, p_suscType, p_mRate, p_hapMutType, p_bRate, p_susc, p_cd, p_cs, p_ctm, p_cbidx, p_cstype, p_cbb, p_cbsig,
         p_sizes, p_cdBefore, p_cdAfter, p_startLD, p_endLD, p_sampMult, p_actualSizes, p_mig, p_suscTrans,
         p_suscCumul;
-    DevBuf r_popD, r_popI, r_sus, r_immSrc, r_birthC, r_xC, r_effMig, r_nocc, r_lhap, r_lcls, r_lcnt, r_sc, r_seeds,
+    DevBuf r_popD, r_popI, r_sus, r_immSrc, r_birthC, r_xC, r_effMig, r_nocc, r_lhap, r_lcls, r_lcnt, r_ltsum, r_sc, r_seeds,
         r_evtime, r_evcols, r_locrec, r_loctime, r_traj, r_prof;
     // tau-leaping (dense compartments)
     DevBuf t_I, t_S, t_dChk, t_dApp, t_dSi, t_dTot, t_totInf, t_gI, t_cd, t_lock, t_F, t_eff, t_Aeff, t_Gout, t_dS,
@@ -488,6 +488,8 @@ static int init_device_state(vgx_engine *e, int64_t traj_points) {
     rc |= ensure(e, e->r_lhap, (size_t)(R * P * cap) * 4);
     rc |= ensure(e, e->r_lcls, (size_t)(R * P * cap) * 4);
     rc |= ensure(e, e->r_lcnt, (size_t)(R * P * cap) * 8);
+    const int64_t capT = cap / 64 + 1;
+    rc |= ensure(e, e->r_ltsum, (size_t)(R * P * capT) * 8);
     rc |= ensure(e, e->r_sc, (size_t)R * sizeof(VgxRepScalars));
     rc |= ensure(e, e->r_locrec, (size_t)(R * VGX_LOC_CAP * 2) * 4);
     rc |= ensure(e, e->r_loctime, (size_t)(R * VGX_LOC_CAP) * 8);
@@ -535,6 +537,8 @@ static int init_device_state(vgx_engine *e, int64_t traj_points) {
     d.immSrc = (double *)e->r_immSrc.p; d.birthC = (double *)e->r_birthC.p; d.xC = (double *)e->r_xC.p;
     d.effMig = (double *)e->r_effMig.p; d.nocc = (int32_t *)e->r_nocc.p; d.lhap = (int32_t *)e->r_lhap.p;
     d.lcls = (int32_t *)e->r_lcls.p; d.lcnt = (int64_t *)e->r_lcnt.p; d.cap = cap;
+    d.ltsum = (int64_t *)e->r_ltsum.p; d.capT = capT;
+    HIPCHECK(e, hipMemsetAsync(e->r_ltsum.p, 0, (size_t)(R * P * capT) * 8, e->stream));
     d.i_nocc = (const int32_t *)e->i_nocc.p; d.i_hap = (const int32_t *)e->i_hap.p;
     d.i_cls = (const int32_t *)e->i_cls.p; d.i_cnt = (const int64_t *)e->i_cnt.p; d.i_cap = i_cap;
     d.i_sus = (const int64_t *)e->i_sus.p;
@@ -573,6 +577,10 @@ static int direct_core(vgx_engine *e, int64_t iterations, int64_t sample_size, f
     o.record_events = 1;
     if (opts) o = *opts;
     if (o.max_loop_factor <= 0) o.max_loop_factor = 1024;
+    if (o.mode != 0 && o.mode != 1) return fail(e, VGX_ERR_ARG, "vgx_simulate_direct: mode must be 0 (exact) or 1 (fast)");
+    if (o.mode == 1 && !(e->C == 1 && e->CB == 1))
+        return fail(e, VGX_ERR_CLASSES, "vgx_simulate_direct: fast mode needs one rate class (identical bRate, dRate, sRate, "
+                                        "mutation total, susceptibility row and suscType for all haplotypes)");
     size_t lds = lds_bytes_for(e);
     if (lds > 160 * 1024)
         return fail(e, VGX_ERR_ARG, "vgx_simulate_direct: the population/class tables need " + std::to_string(lds) +
@@ -617,6 +625,7 @@ static int direct_core(vgx_engine *e, int64_t iterations, int64_t sample_size, f
     a.ev_size = ev_size;
     a.max_loop = o.max_loop_factor * std::max<int64_t>(iterations, 1) + (1 << 20);
     a.record_events = o.record_events ? 1 : 0;
+    a.fast = o.mode == 1 ? 1 : 0;
     a.lds_bytes = (int32_t)lds;
 
     HIPCHECK(e, hipEventRecord(e->ev0, e->stream));

@@ -73,6 +73,8 @@ struct VgxDevRep {
     int32_t *lcls;       // [R][P][cap]
     int64_t *lcnt;       // [R][P][cap]
     int64_t cap;
+    int64_t *ltsum;      // [R][P][capT] sum of the counts of every 64-entry tile of the list (0 beyond the list)
+    int64_t capT;        // cap / 64 + 1
     // initial state for Restart (pyx:714-738), one copy shared by the replicates
     const int32_t *i_nocc;   // [P]
     const int32_t *i_hap;    // [P][i_cap]
@@ -107,6 +109,8 @@ struct VgxDirectArgs {
     int64_t max_loop;
     int32_t record_events;
     int32_t lds_bytes;
+    int32_t fast;            // 0: reference summation order (bit-exact); 1: order-free sums (vgx_run_opts.mode)
+    int32_t pad_;
 };
 
 // Tau-leaping (vgx_tau.hip): dense compartment arrays per replicate, [R][P][H] / [R][P][S].

@@ -103,7 +103,7 @@ struct Ctx {
     int P, S, H, C, CB, sites, lane;
     const VgxDevParams *p;
     // ---- LDS, f64 ----
-    double *popRate, *infect, *immune, *migRate, *maxEBM, *cd, *as, *cum, *cumMig, *sampMult, *ldStart, *ldEnd;  // [P]
+    double *popRate, *infect, *immune, *migRate, *maxEBM, *cd, *as, *cum, *cumMig, *sampMult;  // [P]
     double *immSrc;    // [P][S]  immuneSourcePopRate
     double *birthC;    // [P][CB] eventHapPopRate[.,.,0] per birth class as of the population's last infect-update
     double *xC;        // [P][CB][S] susceptHapPopRate per birth class, same staleness
@@ -111,6 +111,7 @@ struct Ctx {
     double *c_d, *c_s, *c_tm;  // [C]
     double *cb_b;      // [CB]
     double *cb_sigma;  // [CB][S]
+    double *kmig;      // [P] FAST mode: sum_pn m[pi][pn]^2 * cd[pn] / as[pn], constant between lockdown switches
     double *cumul;     // [S] suscepCumulTransition
     double *trans;     // [S][S]
     // ---- LDS, i64 / i32 ----
@@ -123,6 +124,8 @@ struct Ctx {
     int32_t *lhap, *lcls;
     int64_t *lcnt;
     int64_t cap;
+    int64_t *ltsum;    // per 64-entry tile of each list: sum of its counts
+    int64_t capT;
     double *ev_time;
     int32_t *ev_cols;
     int32_t *loc_rec;
@@ -138,6 +141,7 @@ struct Ctx {
     int64_t *cnt;      // LDS [8]: bCounter, dCounter, sCounter, mCounter, iCounter, swapLockdown, migPlus, migNonPlus
     int64_t ev_ptr, ev_size, loc_n;
     int error;
+    int fast;      // compile-time constant of the instantiation: order-free sums instead of the reference's order
     bool has_mig;  // some maxEffectiveBirthMigration > 0
     bool ld_any;   // some population can switch its lockdown state at all
 #ifdef VGX_PROFILE
@@ -178,7 +182,7 @@ static __device__ __forceinline__ int choose_serial_i64(Ctx &c, LoadW w, int n, 
 
 // fastChoose over a P-sized f64 array whose serial prefix sums are cached in `cum`
 // (cum[k] == the reference's running `total` at index k, bit for bit).
-static __device__ int choose_prefix(Ctx &c, const double *w, const double *cum, int n, double tw, double &rn) {
+static __device__ __forceinline__ int choose_prefix(Ctx &c, const double *w, const double *cum, int n, double tw, double &rn) {
     const int lane = c.lane;
     double r = tw * rn;
     for (int base = 0; base < n; base += LANES) {
@@ -204,6 +208,7 @@ static __device__ int choose_prefix(Ctx &c, const double *w, const double *cum, 
 static __device__ __forceinline__ int32_t *LH(Ctx &c, int pi) { return c.lhap + (int64_t)pi * c.cap; }
 static __device__ __forceinline__ int32_t *LC(Ctx &c, int pi) { return c.lcls + (int64_t)pi * c.cap; }
 static __device__ __forceinline__ int64_t *LN(Ctx &c, int pi) { return c.lcnt + (int64_t)pi * c.cap; }
+static __device__ __forceinline__ int64_t *LT(Ctx &c, int pi) { return c.ltsum + (int64_t)pi * c.capT; }
 
 static __device__ __forceinline__ void tile_load(Ctx &c, Tile &t, int pi) {
     t.pi = pi;
@@ -218,58 +223,113 @@ static __device__ __forceinline__ void tile_load(Ctx &c, Tile &t, int pi) {
     }
 }
 
-// first index whose haplotype is >= target (n if none); found tells whether it is the target itself
-static __device__ int list_lower_bound(Ctx &c, int pi, int target, bool &found) {
+// first index whose haplotype is >= target (n if none); found tells whether it is the target itself.
+// Two levels: the first haplotypes of the 64-entry tiles (one strided load per 64 tiles), then one tile.
+static __device__ __forceinline__ int list_lower_bound(Ctx &c, int pi, int target, bool &found) {
     const int n = c.nocc[pi];
     const int32_t *lh = LH(c, pi);
-    for (int base = 0; base < n; base += LANES) {
-        int k = base + c.lane;
-        int h = (k < n) ? lh[k] : 0x7fffffff;
-        unsigned long long ge = __ballot(h >= target);
-        if (ge) {
-            int j = __ffsll((long long)ge) - 1;
-            int hj = __builtin_amdgcn_readlane(h, j);
-            found = (hj == target);
-            return base + j;
+    int tile = 0;  // last tile whose first haplotype is <= target (tile 0 if there is none)
+    if (n > LANES) {
+        const int nt = (n + LANES - 1) / LANES;
+        for (int tb = 0; tb < nt; tb += LANES) {
+            int j = tb + c.lane;
+            int h0 = (j < nt) ? lh[(int64_t)j * LANES] : 0x7fffffff;
+            int nle = __popcll(__ballot(h0 <= target));
+            if (nle > 0) tile = tb + nle - 1;
+            if (nle < LANES) break;
         }
     }
-    found = false;
-    return n;
+    const int base = tile * LANES;
+    int k = base + c.lane;
+    int h = (k < n) ? lh[k] : 0x7fffffff;
+    unsigned long long ge = __ballot(h >= target);
+    if (ge) {
+        int j = __ffsll((long long)ge) - 1;
+        int hj = __builtin_amdgcn_readlane(h, j);
+        found = (hj == target);
+        return base + j;
+    }
+    found = false;  // the whole tile is below the target and the next tile starts above it
+    return min(n, base + LANES);
 }
 
-static __device__ void list_insert_at(Ctx &c, int pi, int pos, int hap, int cls, int64_t cnt) {
+#define VGX_SHIFT_U 4   // 64-entry chunks moved per step of a list shift (loads of a step are in flight together)
+
+static __device__ __forceinline__ void list_insert_at(Ctx &c, int pi, int pos, int hap, int cls, int64_t cnt) {
     int n = c.nocc[pi];
     if (n >= c.cap) { c.error = ERR_CAPACITY; return; }
     int32_t *lh = LH(c, pi), *lc = LC(c, pi);
-    int64_t *ln = LN(c, pi);
-    // shift [pos, n) one slot up, highest chunk first; each chunk is read completely before it is written
-    for (int hi = n; hi > pos; hi -= LANES) {
-        int lo = max(pos, hi - LANES);
-        int k = lo + c.lane;
-        bool ok = k < hi;
-        int h = 0, cl = 0;
-        int64_t ct = 0;
-        if (ok) { h = lh[k]; cl = lc[k]; ct = ln[k]; }
+    int64_t *ln = LN(c, pi), *lt = LT(c, pi);
+    // tile sums: tile j gains the entry entering from below (the new one for pos's tile) and loses its last entry
+    {
+        const int jp = pos / LANES, jl = n / LANES;
+        for (int tb = jp; tb <= jl; tb += LANES) {
+            int j = tb + c.lane;
+            if (j <= jl) {
+                int64_t in = (j == jp) ? cnt : ln[(int64_t)j * LANES - 1];
+                int kout = j * LANES + LANES - 1;
+                int64_t out = (kout < n) ? ln[kout] : 0;
+                lt[j] += in - out;
+            }
+        }
         WSYNC();
-        if (ok) { lh[k + 1] = h; lc[k + 1] = cl; ln[k + 1] = ct; }
+    }
+    // shift [pos, n) one slot up, highest block first; each block is read completely before it is written
+    for (int hi = n; hi > pos; hi -= VGX_SHIFT_U * LANES) {
+        int lo = max(pos, hi - VGX_SHIFT_U * LANES);
+        int h[VGX_SHIFT_U], cl[VGX_SHIFT_U];
+        int64_t ct[VGX_SHIFT_U];
+#pragma unroll
+        for (int u = 0; u < VGX_SHIFT_U; ++u) {
+            int k = lo + u * LANES + c.lane;
+            h[u] = 0; cl[u] = 0; ct[u] = 0;
+            if (k < hi) { h[u] = lh[k]; cl[u] = lc[k]; ct[u] = ln[k]; }
+        }
+        WSYNC();
+#pragma unroll
+        for (int u = 0; u < VGX_SHIFT_U; ++u) {
+            int k = lo + u * LANES + c.lane;
+            if (k < hi) { lh[k + 1] = h[u]; lc[k + 1] = cl[u]; ln[k + 1] = ct[u]; }
+        }
         WSYNC();
     }
     if (c.lane == 0) { lh[pos] = hap; lc[pos] = cls; ln[pos] = cnt; c.nocc[pi] = n + 1; }
     WSYNC();
 }
 
-static __device__ void list_remove_at(Ctx &c, int pi, int pos) {
+static __device__ __forceinline__ void list_remove_at(Ctx &c, int pi, int pos) {
     int n = c.nocc[pi];
     int32_t *lh = LH(c, pi), *lc = LC(c, pi);
-    int64_t *ln = LN(c, pi);
-    for (int lo = pos + 1; lo < n; lo += LANES) {
-        int k = lo + c.lane;
-        bool ok = k < n;
-        int h = 0, cl = 0;
-        int64_t ct = 0;
-        if (ok) { h = lh[k]; cl = lc[k]; ct = ln[k]; }
+    int64_t *ln = LN(c, pi), *lt = LT(c, pi);
+    // tile sums: tile j loses its first entry (the removed one for pos's tile) and gains the first of the next tile
+    {
+        const int jp = pos / LANES, jl = (n - 1) / LANES;
+        for (int tb = jp; tb <= jl; tb += LANES) {
+            int j = tb + c.lane;
+            if (j <= jl) {
+                int64_t out = (j == jp) ? ln[pos] : ln[(int64_t)j * LANES];
+                int kin = j * LANES + LANES;
+                int64_t in = (kin < n) ? ln[kin] : 0;
+                lt[j] += in - out;
+            }
+        }
         WSYNC();
-        if (ok) { lh[k - 1] = h; lc[k - 1] = cl; ln[k - 1] = ct; }
+    }
+    for (int lo = pos + 1; lo < n; lo += VGX_SHIFT_U * LANES) {
+        int h[VGX_SHIFT_U], cl[VGX_SHIFT_U];
+        int64_t ct[VGX_SHIFT_U];
+#pragma unroll
+        for (int u = 0; u < VGX_SHIFT_U; ++u) {
+            int k = lo + u * LANES + c.lane;
+            h[u] = 0; cl[u] = 0; ct[u] = 0;
+            if (k < n) { h[u] = lh[k]; cl[u] = lc[k]; ct[u] = ln[k]; }
+        }
+        WSYNC();
+#pragma unroll
+        for (int u = 0; u < VGX_SHIFT_U; ++u) {
+            int k = lo + u * LANES + c.lane;
+            if (k < n) { lh[k - 1] = h[u]; lc[k - 1] = cl[u]; ln[k - 1] = ct[u]; }
+        }
         WSYNC();
     }
     if (c.lane == 0) c.nocc[pi] = n - 1;
@@ -277,7 +337,7 @@ static __device__ void list_remove_at(Ctx &c, int pi, int pos) {
 }
 
 // infectious[pi, hap] += delta (delta = +1 / -1), keeping the list ordered and free of zero counts
-static __device__ void list_add(Ctx &c, int pi, int hap, int64_t delta) {
+static __device__ __forceinline__ void list_add(Ctx &c, int pi, int hap, int64_t delta) {
     bool found;
     int pos = list_lower_bound(c, pi, hap, found);
     if (found) {
@@ -286,7 +346,7 @@ static __device__ void list_add(Ctx &c, int pi, int hap, int64_t delta) {
         if (v == 0) {
             list_remove_at(c, pi, pos);
         } else {
-            if (c.lane == 0) ln[pos] = v;
+            if (c.lane == 0) { ln[pos] = v; LT(c, pi)[pos / LANES] += delta; }
             WSYNC();
         }
     } else {
@@ -296,7 +356,7 @@ static __device__ void list_add(Ctx &c, int pi, int hap, int64_t delta) {
 
 // ------------------------------------------------------------------------------------------------
 // BirthRate per class (pyx:382-392): ps += susceptHapPopRate * m * m * cd / as over (sn, pn), in order.
-static __device__ void birth_update(Ctx &c, int pi, const Tile &t) {
+static __device__ __forceinline__ void birth_update(Ctx &c, int pi, const Tile &t) {
     const int P = c.P, S = c.S, lane = c.lane;
     const double *mrow = c.p->mig + (int64_t)pi * P;
     const bool pref = (t.pi == pi);
@@ -305,6 +365,10 @@ static __device__ void birth_update(Ctx &c, int pi, const Tile &t) {
         for (int sn = 0; sn < S; ++sn) {
             double x = (double)c.sus[pi * S + sn] * c.cb_sigma[cb * S + sn];
             if (lane == 0) c.xC[(pi * c.CB + cb) * S + sn] = x;
+            if (c.fast) {  // factored: the sum over pn is constant between lockdown switches
+                ps += x * c.kmig[pi];
+                continue;
+            }
             for (int base = 0; base < P; base += LANES) {
                 int pn = base + lane;
                 double tv = 0.0;
@@ -321,7 +385,7 @@ static __device__ void birth_update(Ctx &c, int pi, const Tile &t) {
 }
 
 // tEventHapPopRate per class (pyx:522-526) from the cached birth rates of population pi
-static __device__ void tE_fill(Ctx &c, int pi) {
+static __device__ __forceinline__ void tE_fill(Ctx &c, int pi) {
     const double mult = c.sampMult[pi];
     for (int base = 0; base < c.C; base += LANES) {
         int k = base + c.lane;
@@ -334,7 +398,8 @@ static __device__ void tE_fill(Ctx &c, int pi) {
 }
 
 // infectPopRate[pi] = sum over occupied haplotypes, in haplotype order, of tEvent * infectious (pyx:519-528)
-static __device__ double row_sum(Ctx &c, int pi, const Tile &t) {
+static __device__ __forceinline__ double row_sum(Ctx &c, int pi, const Tile &t) {
+    if (c.fast) return c.tE[0] * (double)c.totalInf[pi];  // one rate class: sum_h tE * infectious[pi, h]
     if (t.valid && t.pi == pi) {
         double w = (c.lane < t.n) ? c.tE[t.cls] * (double)t.cnt : 0.0;
         return seq_sum(w, t.n, 0.0);
@@ -352,8 +417,70 @@ static __device__ double row_sum(Ctx &c, int pi, const Tile &t) {
     return acc;
 }
 
+// fastChoose(infectious[pi], tw = totalInfectious[pi], rn) (fast_choose.pxi:18-31, int64 weights) over the occupancy
+// list: integer prefix sums are order-free, so the tile sums give the tile and one tile scan gives the entry.
+// Returns the list index and recycles rn like the reference.
+static __device__ __forceinline__ int count_select(Ctx &c, int pi, const Tile &t, int64_t tw, double &rn) {
+    const int lane = c.lane;
+    const double r = (double)tw * rn;
+    const bool reg = t.valid && t.pi == pi;
+    const int n = reg ? t.n : c.nocc[pi];
+    const int64_t *ln = LN(c, pi);
+    int64_t before = 0;
+    int base = 0;
+    bool none = false;
+    if (!reg && n > LANES) {
+        const int nt = (n + LANES - 1) / LANES;
+        const int64_t *lt = LT(c, pi);
+        int jt = -1;
+        int64_t carry = 0;
+        for (int tb = 0; tb < nt && jt < 0; tb += LANES) {
+            int j = tb + lane;
+            int64_t w = (j < nt) ? lt[j] : 0;
+            int64_t pre = iscan(w, lane) + carry;
+            unsigned long long hit = __ballot(j < nt && !((double)pre < r));
+            if (hit) {
+                int q = __ffsll((long long)hit) - 1;
+                jt = tb + q;
+                before = bcast_i64(pre, q) - bcast_i64(w, q);
+            }
+            carry = bcast_i64(pre, LANES - 1);
+        }
+        if (jt < 0) { none = true; before = carry; } else base = jt * LANES;
+    }
+    int q = -1;
+    int64_t total = before, wi = 0;
+    if (!none) {
+        int k = base + lane;
+        int64_t w = reg ? ((lane < n) ? t.cnt : 0) : ((k < n) ? ln[k] : 0);
+        int64_t pre = iscan(w, lane) + before;
+        unsigned long long hit = __ballot(k < n && !((double)pre < r));
+        if (hit) {
+            q = __ffsll((long long)hit) - 1;
+            total = bcast_i64(pre, q);
+            wi = bcast_i64(w, q);
+        } else {
+            total = bcast_i64(pre, LANES - 1);
+        }
+    }
+    if (q < 0) {
+        // nothing reached r: the dense loop runs on to index H-1 (fast_choose.pxi:26); that is a valid pick only if
+        // haplotype H-1 is occupied, otherwise the reference reports a zero weight
+        if (n > 0 && LH(c, pi)[n - 1] == c.H - 1) {
+            wi = ln[n - 1];
+            rn = (r - (double)(total - wi)) / (double)wi;
+            return n - 1;
+        }
+        c.error = ERR_ZERO_WEIGHT;
+        return 0;
+    }
+    rn = (r - (double)(total - wi)) / (double)wi;
+    return base + q;
+}
+
 // fastChoose(hapPopRate[pi], infectPopRate[pi], rn) over the occupied entries; returns the list index
-static __device__ int row_select(Ctx &c, int pi, const Tile &t, double tw, double &rn) {
+static __device__ __forceinline__ int row_select(Ctx &c, int pi, const Tile &t, double tw, double &rn) {
+    if (c.fast) return count_select(c, pi, t, c.totalInf[pi], rn);  // one rate class: weights tE * count
     const int lane = c.lane;
     const int n = t.valid ? t.n : c.nocc[pi];
     const int32_t *lc = LC(c, pi);
@@ -389,8 +516,20 @@ static __device__ int row_select(Ctx &c, int pi, const Tile &t, double tw, doubl
 }
 
 // totalRate and the prefix sums of popRate from population `from` onwards (pyx:537-539)
-static __device__ void refresh_cum(Ctx &c, int from) {
+static __device__ __forceinline__ void refresh_cum(Ctx &c, int from) {
     const int P = c.P, lane = c.lane;
+    if (c.fast) {
+        double carry = 0.0;
+        for (int base = 0; base < P; base += LANES) {
+            int pn = base + lane;
+            double pre = fscan(pn < P ? c.popRate[pn] : 0.0) + carry;
+            if (pn < P) c.cum[pn] = pre;
+            carry = bcast(pre, LANES - 1);
+        }
+        c.totalRate = carry;
+        WSYNC();
+        return;
+    }
     int base0 = (from / LANES) * LANES;
     double carry = (base0 > 0) ? c.cum[base0 - 1] : 0.0;
     for (int base = base0; base < P; base += LANES) {
@@ -408,8 +547,25 @@ static __device__ void refresh_cum(Ctx &c, int from) {
 }
 
 // migPopRate, its prefix sums and totalMigrationRate (pyx:541-546)
-static __device__ void refresh_mig(Ctx &c) {
+static __device__ __forceinline__ void refresh_mig(Ctx &c) {
     const int P = c.P, lane = c.lane;
+    if (c.fast && c.has_mig) {
+        double carry = 0.0;
+        for (int base = 0; base < P; base += LANES) {
+            int pn = base + lane;
+            double w = 0.0;
+            if (pn < P) {
+                w = c.maxEBM[pn] * (double)c.totalSus[pn] * (double)(c.gI - c.totalInf[pn]);
+                c.migRate[pn] = w;
+            }
+            double pre = fscan(w) + carry;
+            if (pn < P) c.cumMig[pn] = pre;
+            carry = bcast(pre, LANES - 1);
+        }
+        c.totalMig = carry;
+        WSYNC();
+        return;
+    }
     if (!c.has_mig) {  // every maxEffectiveBirthMigration is +0.0: all products and sums are +0.0
         for (int pn = lane; pn < P; pn += LANES) { c.migRate[pn] = 0.0; c.cumMig[pn] = 0.0; }
         c.totalMig = 0.0;
@@ -447,6 +603,20 @@ struct EvRec { int type, hap, pop, nh, np; };  // type < 0: nothing to log (reje
 static __device__ __forceinline__ void update(Ctx &c, const UpdReq &q, const Tile &t) {
     const VgxDevParams &p = *c.p;
     const int P = c.P, S = c.S, lane = c.lane;
+    if (c.fast && q.full) {  // kmig[pi] = sum_pn m[pi][pn]^2 * cd[pn] / as[pn]
+        for (int pi = 0; pi < P; ++pi) {
+            const double *mrow = p.mig + (int64_t)pi * P;
+            double acc = 0.0;
+            for (int base = 0; base < P; base += LANES) {
+                int pn = base + lane;
+                double tv = 0.0;
+                if (pn < P) { double m = mrow[pn]; tv = m * m * c.cd[pn] / c.as[pn]; }
+                acc += bcast(fscan(tv), LANES - 1);
+            }
+            if (lane == 0) c.kmig[pi] = acc;
+        }
+        WSYNC();
+    }
     for (int pn = q.lo; pn < q.hi; ++pn) {
         if (q.infect) {
             birth_update(c, pn, t);
@@ -528,8 +698,9 @@ static __device__ __forceinline__ bool check_lockdowns(Ctx &c, int lo, int hi) {
     for (int pi = lo; pi < hi; ++pi) {
         for (int pass = 0; pass < 2; ++pass) {
             bool flip;
-            if (pass == 0) flip = ((double)c.totalInf[pi] > c.ldStart[pi]) && c.lockON[pi] == 0;
-            else flip = ((double)c.totalInf[pi] < c.ldEnd[pi]) && c.lockON[pi] == 1;
+            // thresholds startLD * sizes / endLD * sizes (pyx:699, 705) from the read-only parameters (scalar loads)
+            if (pass == 0) flip = ((double)c.totalInf[pi] > p.startLD[pi] * (double)p.sizes[pi]) && c.lockON[pi] == 0;
+            else flip = ((double)c.totalInf[pi] < p.endLD[pi] * (double)p.sizes[pi]) && c.lockON[pi] == 1;
             if (flip) {
                 WSYNC();
                 if (c.lane == 0) {
@@ -646,7 +817,7 @@ static __device__ __forceinline__ int generate_event(Ctx &c, double u, Tile &t, 
                 } else if (lane == 0) {
                     LN(c, pi)[k] += 1;
                 }
-                if (lane == 0) c.immSrc[pi * S + si] = c.cumul[si] * (double)c.sus[pi * S + si];
+                if (lane == 0) { LT(c, pi)[k / LANES] += 1; c.immSrc[pi * S + si] = c.cumul[si] * (double)c.sus[pi * S + si]; }
                 WSYNC();
                 q.immune = true; q.migration = true;
                 BUMP(CNT_B);
@@ -664,10 +835,13 @@ static __device__ __forceinline__ int generate_event(Ctx &c, double u, Tile &t, 
                 if (left == 0) {
                     op0.pi = pi; op0.hap = hi; op0.delta = -1; n_ops = 1;
                     t.valid = false;
-                } else if (t.valid) {
-                    if (lane == k) { t.cnt = left; LN(c, pi)[k] = left; }
-                } else if (lane == 0) {
-                    LN(c, pi)[k] = left;
+                } else {
+                    if (t.valid) {
+                        if (lane == k) { t.cnt = left; LN(c, pi)[k] = left; }
+                    } else if (lane == 0) {
+                        LN(c, pi)[k] = left;
+                    }
+                    if (lane == 0) LT(c, pi)[k / LANES] -= 1;
                 }
                 WSYNC();
                 if (lane == 0) c.immSrc[pi * S + st] = (double)c.sus[pi * S + st] * c.cumul[st];
@@ -724,30 +898,8 @@ static __device__ __forceinline__ int generate_event(Ctx &c, double u, Tile &t, 
         // fastChoose(infectious[spi], totalInfectious[spi], rn): int64 weights over the occupancy list
         int hi = 0;
         {
-            const int n = c.nocc[spi];
-            const int64_t *ln = LN(c, spi);
-            double r = (double)c.totalInf[spi] * c.rn;
-            int64_t carry = 0, total = 0, wi = 1;
-            int kk = -1;
-            for (int base = 0; base < n && kk < 0; base += LANES) {
-                int k = base + lane;
-                int64_t w = (k < n) ? ln[k] : 0;
-                int64_t pre = iscan(w, lane) + carry;
-                unsigned long long hit = __ballot(k < n && !((double)pre < r));
-                if (hit) {
-                    int j = __ffsll((long long)hit) - 1;
-                    kk = base + j;
-                    total = bcast_i64(pre, j);
-                    wi = bcast_i64(w, j);
-                }
-                carry = bcast_i64(pre, LANES - 1);
-            }
-            if (kk < 0) {
-                if (n > 0 && LH(c, spi)[n - 1] == c.H - 1) { kk = n - 1; total = carry; wi = ln[n - 1]; }
-                else { c.error = ERR_ZERO_WEIGHT; kk = 0; }
-            }
+            int kk = count_select(c, spi, t, c.totalInf[spi], c.rn);  // t is not valid here (no tile loaded yet)
             if (!c.error) hi = LH(c, spi)[kk];
-            c.rn = (r - (double)(total - wi)) / (double)wi;
         }
         if (c.error) return pi;
         int si = choose_serial_i64(c, [&](int i) { return c.sus[tpi * S + i]; }, S, c.totalSus[tpi], c.rn);
@@ -783,6 +935,7 @@ static __device__ __forceinline__ void restart_state(Ctx &c, const VgxDevRep &r)
             ts += v;
         }
         int n = r.i_nocc[pn];
+        const int n_old = c.nocc[pn];
         int64_t ti = 0;
         for (int base = 0; base < n; base += LANES) {
             int k = base + lane;
@@ -793,8 +946,12 @@ static __device__ __forceinline__ void restart_state(Ctx &c, const VgxDevRep &r)
                 LC(c, pn)[k] = r.i_cls[(int64_t)pn * r.i_cap + k];
                 LN(c, pn)[k] = ct;
             }
-            ti += bcast_i64(iscan(ct, lane), LANES - 1);
+            int64_t tsum = bcast_i64(iscan(ct, lane), LANES - 1);
+            if (lane == 0) LT(c, pn)[base / LANES] = tsum;
+            ti += tsum;
         }
+        for (int j = (n + LANES - 1) / LANES + lane; j <= n_old / LANES && j < c.capT; j += LANES) LT(c, pn)[j] = 0;
+        WSYNC();
         if (lane == 0) { c.nocc[pn] = n; c.totalSus[pn] = ts; c.totalInf[pn] = ti; }
         g += ti;
     }
@@ -805,7 +962,7 @@ static __device__ __forceinline__ void restart_state(Ctx &c, const VgxDevRep &r)
 // Kernel body, specialised on the LDS stride of the per-population arrays (PT: 64 when popNum <= 64, so every
 // LDS address is a compile-time constant; 0 = runtime stride), on the number of susceptibility groups (ST: 1 or 0 =
 // runtime) and on a single rate class (ONE): the common shapes lose their address arithmetic and inner loops.
-template <int PT, int ST, int ONE>
+template <int PT, int ST, int ONE, int FAST>
 static __device__ __forceinline__ void direct_body(const VgxDirectArgs &a) {
     const int rep = blockIdx.x;
     if (rep >= a.n_replicates) return;
@@ -818,12 +975,14 @@ static __device__ __forceinline__ void direct_body(const VgxDirectArgs &a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     Ctx c;
     c.P = P; c.S = S; c.H = p.H; c.C = C; c.CB = CB; c.sites = p.sites; c.lane = lane;
+    c.fast = FAST;
     c.p = &a.p;
     // LDS carve: keep in step with vgxi_direct_lds_bytes().  Arrays whose size depends only on (PL, S) first.
     double *ld = (double *)smem;
     c.popRate = ld; ld += PL;   c.infect = ld; ld += PL;   c.immune = ld; ld += PL;   c.migRate = ld; ld += PL;
     c.maxEBM = ld; ld += PL;    c.cd = ld; ld += PL;       c.as = ld; ld += PL;       c.cum = ld; ld += PL;
-    c.cumMig = ld; ld += PL;    c.sampMult = ld; ld += PL; c.ldStart = ld; ld += PL;  c.ldEnd = ld; ld += PL;
+    c.cumMig = ld; ld += PL;    c.sampMult = ld; ld += PL;
+    c.kmig = ld; ld += PL;
     c.immSrc = ld; ld += PL * S;
     c.cumul = ld; ld += S;
     c.trans = ld; ld += S * S;
@@ -847,12 +1006,10 @@ static __device__ __forceinline__ void direct_body(const VgxDirectArgs &a) {
     int32_t *gN = r.nocc + (int64_t)rep * P;
     for (int pn = lane; pn < P; pn += LANES) {
         c.popRate[pn] = 0.0; c.infect[pn] = 0.0; c.immune[pn] = 0.0; c.migRate[pn] = 0.0; c.maxEBM[pn] = 0.0;
-        c.cum[pn] = 0.0; c.cumMig[pn] = 0.0;
+        c.cum[pn] = 0.0; c.cumMig[pn] = 0.0; c.kmig[pn] = 0.0;
         c.cd[pn] = gD[PD_CD * P + pn];
         c.as[pn] = p.actualSizes[pn];
         c.sampMult[pn] = p.sampMult[pn];
-        c.ldStart[pn] = p.startLD[pn] * (double)p.sizes[pn];
-        c.ldEnd[pn] = p.endLD[pn] * (double)p.sizes[pn];
         c.totalSus[pn] = gI[PI_TOTSUS * P + pn];
         c.totalInf[pn] = gI[PI_TOTINF * P + pn];
         c.lockON[pn] = gI[PI_LOCK * P + pn];
@@ -875,6 +1032,8 @@ static __device__ __forceinline__ void direct_body(const VgxDirectArgs &a) {
     c.lhap = r.lhap + (int64_t)rep * P * r.cap;
     c.lcls = r.lcls + (int64_t)rep * P * r.cap;
     c.lcnt = r.lcnt + (int64_t)rep * P * r.cap;
+    c.capT = r.capT;
+    c.ltsum = r.ltsum + (int64_t)rep * P * r.capT;
     c.evcap = r.evcap; c.ev_base = r.ev_base;
     c.ev_time = r.ev_time + (int64_t)rep * r.evcap;
     c.ev_cols = r.ev_cols + (int64_t)rep * r.evcap * 5;
@@ -900,7 +1059,7 @@ static __device__ __forceinline__ void direct_body(const VgxDirectArgs &a) {
         bool possible = false;
         for (int base = 0; base < P; base += LANES) {
             int pn = base + lane;
-            bool pp = pn < P && (c.ldStart[pn] < (double)p.sizes[pn] || c.lockON[pn] != 0);
+            bool pp = pn < P && (p.startLD[pn] * (double)p.sizes[pn] < (double)p.sizes[pn] || c.lockON[pn] != 0);
             possible = possible || (__ballot(pp) != 0ull);
         }
         c.ld_any = possible;
@@ -1041,11 +1200,14 @@ static __device__ __forceinline__ void direct_body(const VgxDirectArgs &a) {
     }
 }
 
-extern "C" __global__ void __launch_bounds__(LANES) vgx_direct_kernel(VgxDirectArgs a) { direct_body<0, 0, 0>(a); }
+extern "C" __global__ void __launch_bounds__(LANES) vgx_direct_kernel(VgxDirectArgs a) { direct_body<0, 0, 0, 0>(a); }
 // popNum <= 64: constant LDS addresses
-extern "C" __global__ void __launch_bounds__(LANES) vgx_direct_kernel_p64(VgxDirectArgs a) { direct_body<64, 0, 0>(a); }
+extern "C" __global__ void __launch_bounds__(LANES) vgx_direct_kernel_p64(VgxDirectArgs a) { direct_body<64, 0, 0, 0>(a); }
 // popNum <= 64, one susceptibility group, one rate class (e.g. BASELINE configs 2 and 3)
-extern "C" __global__ void __launch_bounds__(LANES) vgx_direct_kernel_p64s1c1(VgxDirectArgs a) { direct_body<64, 1, 1>(a); }
+extern "C" __global__ void __launch_bounds__(LANES) vgx_direct_kernel_p64s1c1(VgxDirectArgs a) { direct_body<64, 1, 1, 0>(a); }
+// FAST mode (vgx_run_opts.mode = 1, one rate class): order-free sums, same random stream and event semantics
+extern "C" __global__ void __launch_bounds__(LANES) vgx_direct_fast_kernel(VgxDirectArgs a) { direct_body<0, 0, 1, 1>(a); }
+extern "C" __global__ void __launch_bounds__(LANES) vgx_direct_fast_kernel_p64s1(VgxDirectArgs a) { direct_body<64, 1, 1, 1>(a); }
 
 // Gives every replicate the same start state (the host model's state at the beginning of the call):
 // occupancy lists, susceptible counts, contact densities, population totals and lockdown flags.
@@ -1059,10 +1221,18 @@ extern "C" __global__ void __launch_bounds__(LANES) vgx_init_reps_kernel(
         int n = s_nocc[pn];
         int32_t *lh = r.lhap + (rep * P + pn) * r.cap, *lc = r.lcls + (rep * P + pn) * r.cap;
         int64_t *ln = r.lcnt + (rep * P + pn) * r.cap;
-        for (int k = lane; k < n; k += LANES) {
-            lh[k] = s_hap[(int64_t)pn * s_cap + k];
-            lc[k] = s_cls[(int64_t)pn * s_cap + k];
-            ln[k] = s_cnt[(int64_t)pn * s_cap + k];
+        int64_t *lt = r.ltsum + (rep * P + pn) * r.capT;   // zero-filled by the host beyond the list
+        for (int base = 0; base < n; base += LANES) {
+            int k = base + lane;
+            int64_t ct = 0;
+            if (k < n) {
+                ct = s_cnt[(int64_t)pn * s_cap + k];
+                lh[k] = s_hap[(int64_t)pn * s_cap + k];
+                lc[k] = s_cls[(int64_t)pn * s_cap + k];
+                ln[k] = ct;
+            }
+            int64_t tsum = bcast_i64(iscan(ct, lane), LANES - 1);
+            if (lane == 0) lt[base / LANES] = tsum;
         }
     }
     for (int pn = lane; pn < P; pn += LANES) {
@@ -1078,7 +1248,7 @@ extern "C" __global__ void __launch_bounds__(LANES) vgx_init_reps_kernel(
 // ---- host-side launchers (this translation unit owns its kernels; no relocatable device code needed) ----
 extern "C" __attribute__((visibility("hidden"))) size_t vgxi_direct_lds_bytes(int P, int S, int C, int CB) {
     size_t PL = P <= 64 ? 64 : (size_t)P;
-    size_t f64 = 12 * PL + PL * S + S + (size_t)S * S;
+    size_t f64 = 11 * PL + PL * S + S + (size_t)S * S;
     size_t i64 = 3 * PL + PL * S + 8 + (PL + 1) / 2;
     size_t f64b = PL * CB + PL * CB * S + 4 * (size_t)C + CB + (size_t)CB * S;
     size_t i32 = 2 * (size_t)C;
@@ -1088,7 +1258,12 @@ extern "C" __attribute__((visibility("hidden"))) size_t vgxi_direct_lds_bytes(in
 extern "C" __attribute__((visibility("hidden"))) hipError_t vgxi_launch_direct(const VgxDirectArgs *a, size_t lds,
                                                                               hipStream_t stream) {
     void (*k)(VgxDirectArgs) = vgx_direct_kernel;
-    if (a->p.P <= 64) k = (a->p.S == 1 && a->p.C == 1 && a->p.CB == 1) ? vgx_direct_kernel_p64s1c1 : vgx_direct_kernel_p64;
+    if (a->fast) {
+        if (!(a->p.C == 1 && a->p.CB == 1)) return hipErrorInvalidValue;  // checked by the caller
+        k = (a->p.P <= 64 && a->p.S == 1) ? vgx_direct_fast_kernel_p64s1 : vgx_direct_fast_kernel;
+    } else if (a->p.P <= 64) {
+        k = (a->p.S == 1 && a->p.C == 1 && a->p.CB == 1) ? vgx_direct_kernel_p64s1c1 : vgx_direct_kernel_p64;
+    }
     hipError_t err = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (err != hipSuccess) return err;
     hipLaunchKernelGGL(k, dim3((unsigned)a->n_replicates), dim3(LANES), lds, stream, *a);

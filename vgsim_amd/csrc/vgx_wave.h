@@ -79,12 +79,47 @@ static __device__ __forceinline__ double seq_scan(double v, int n, double carry,
     return acc;
 }
 
-// inclusive integer scan across the wave (order-free: int64 addition is associative)
-static __device__ __forceinline__ int64_t iscan(int64_t v, int lane) {
-#pragma unroll
-    for (int d = 1; d < VGX_LANES; d <<= 1) {
-        int64_t o = __shfl_up(v, d);
-        if (lane >= d) v += o;
+// ---- order-free wave scans on the DPP network (no LDS traffic) ----------------------------------------------
+// Inclusive prefix over the 64 lanes in 6 steps: row_shr 1/2/4/8 inside each row of 16 lanes (lanes without a
+// source receive 0), then row_bcast:15 into rows 1 and 3 and row_bcast:31 into rows 2 and 3 (the gfx9 scan).
+#define VGX_DPP_SHR(v, d) __builtin_amdgcn_update_dpp(0, (v), 0x110 + (d), 0xf, 0xf, true)
+#define VGX_DPP_BC15(v) __builtin_amdgcn_update_dpp(0, (v), 0x142, 0xa, 0xf, false)
+#define VGX_DPP_BC31(v) __builtin_amdgcn_update_dpp(0, (v), 0x143, 0xc, 0xf, false)
+#define VGX_SCAN_STEPS(STEP) STEP(VGX_DPP_SHR, 1) STEP(VGX_DPP_SHR, 2) STEP(VGX_DPP_SHR, 4) STEP(VGX_DPP_SHR, 8)
+#define VGX_I64_STEP(F, D)                                                                  \
+    {                                                                                       \
+        int lo = F((int)(uint32_t)v, D), hi = F((int)(uint32_t)((uint64_t)v >> 32), D);      \
+        v += (int64_t)(((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo);                      \
     }
+#define VGX_I64_STEP0(F)                                                                    \
+    {                                                                                       \
+        int lo = F((int)(uint32_t)v), hi = F((int)(uint32_t)((uint64_t)v >> 32));           \
+        v += (int64_t)(((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo);                      \
+    }
+#define VGX_F64_STEP(F, D)                                                                  \
+    {                                                                                       \
+        int lo = F(__double2loint(v), D), hi = F(__double2hiint(v), D);                     \
+        v += __hiloint2double(hi, lo);                                                      \
+    }
+#define VGX_F64_STEP0(F)                                                                    \
+    {                                                                                       \
+        int lo = F(__double2loint(v)), hi = F(__double2hiint(v));                           \
+        v += __hiloint2double(hi, lo);                                                      \
+    }
+
+// inclusive integer scan across the wave (int64 addition is associative: any order is exact)
+static __device__ __forceinline__ int64_t iscan(int64_t v, int lane) {
+    (void)lane;
+    VGX_SCAN_STEPS(VGX_I64_STEP)
+    VGX_I64_STEP0(VGX_DPP_BC15)
+    VGX_I64_STEP0(VGX_DPP_BC31)
+    return v;
+}
+
+// inclusive f64 scan across the wave in tree order (FAST mode only: NOT the reference's rounding sequence)
+static __device__ __forceinline__ double fscan(double v) {
+    VGX_SCAN_STEPS(VGX_F64_STEP)
+    VGX_F64_STEP0(VGX_DPP_BC15)
+    VGX_F64_STEP0(VGX_DPP_BC31)
     return v;
 }

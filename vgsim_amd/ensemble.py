@@ -46,9 +46,12 @@ class Ensemble:
         self.engine.close()
 
     def simulate(self, iterations, sample_size=None, epidemic_time=-1, attempts=200, record_events=False,
-                 traj_points=0, traj_window=(0.0, 1.0), seeds=None):
+                 traj_points=0, traj_window=(0.0, 1.0), seeds=None, mode='exact'):
         """Direct Gillespie for every replicate from the model's current state (``SimulatePopulation`` semantics
-        per replicate, pyx:396-429).  Returns an :class:`EnsembleResult`."""
+        per replicate, pyx:396-429).  ``mode``: 'exact' (reference summation order, bit-exact) or 'fast'
+        (order-free sums, one rate class).  Returns an :class:`EnsembleResult`."""
+        if mode not in ('exact', 'fast'):
+            raise ValueError("mode must be 'exact' or 'fast'")
         m, eng = self.model, self.engine
         if seeds is not None:
             self.seeds = np.ascontiguousarray(seeds, dtype=np.int64)
@@ -71,6 +74,7 @@ class Ensemble:
         o.record_events = 1 if record_events else 0
         o.traj_points = int(traj_points)
         o.traj_t0, o.traj_t1 = float(traj_window[0]), float(traj_window[1])
+        o.mode = 1 if mode == 'fast' else 0
         rc = eng.lib.vgx_simulate_direct(eng.handle, int(iterations), int(sample_size), float(np.float32(epidemic_time)),
                                          int(attempts), C.byref(o))
         eng._check(rc)
