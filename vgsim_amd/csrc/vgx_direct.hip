@@ -143,6 +143,7 @@ struct Ctx {
     int error;
     int fast;      // compile-time constant of the instantiation: order-free sums instead of the reference's order
     bool has_mig;  // some maxEffectiveBirthMigration > 0
+    bool mig_cum_ok;  // cumMig[] matches migRate[]
     bool ld_any;   // some population can switch its lockdown state at all
 #ifdef VGX_PROFILE
     unsigned long long prof_t0, prof_acc[VGX_PROF_SLOTS];
@@ -260,8 +261,9 @@ static __device__ __forceinline__ void list_insert_at(Ctx &c, int pi, int pos, i
     if (n >= c.cap) { c.error = ERR_CAPACITY; return; }
     int32_t *lh = LH(c, pi), *lc = LC(c, pi);
     int64_t *ln = LN(c, pi), *lt = LT(c, pi);
-    // tile sums: tile j gains the entry entering from below (the new one for pos's tile) and loses its last entry
-    {
+    // tile sums (kept while a list is longer than one tile): tile j gains the entry entering from below (the new
+    // one for pos's tile) and loses its last entry
+    if (n > LANES) {
         const int jp = pos / LANES, jl = n / LANES;
         for (int tb = jp; tb <= jl; tb += LANES) {
             int j = tb + c.lane;
@@ -295,6 +297,11 @@ static __device__ __forceinline__ void list_insert_at(Ctx &c, int pi, int pos, i
     }
     if (c.lane == 0) { lh[pos] = hap; lc[pos] = cls; ln[pos] = cnt; c.nocc[pi] = n + 1; }
     WSYNC();
+    if (n == LANES) {  // the list outgrows one tile: start its tile sums
+        int64_t s0 = bcast_i64(iscan(ln[c.lane], c.lane), LANES - 1);
+        if (c.lane == 0) { lt[0] = s0; lt[1] = ln[LANES]; }
+        WSYNC();
+    }
 }
 
 static __device__ __forceinline__ void list_remove_at(Ctx &c, int pi, int pos) {
@@ -302,7 +309,7 @@ static __device__ __forceinline__ void list_remove_at(Ctx &c, int pi, int pos) {
     int32_t *lh = LH(c, pi), *lc = LC(c, pi);
     int64_t *ln = LN(c, pi), *lt = LT(c, pi);
     // tile sums: tile j loses its first entry (the removed one for pos's tile) and gains the first of the next tile
-    {
+    if (n > LANES) {
         const int jp = pos / LANES, jl = (n - 1) / LANES;
         for (int tb = jp; tb <= jl; tb += LANES) {
             int j = tb + c.lane;
@@ -346,7 +353,7 @@ static __device__ __forceinline__ void list_add(Ctx &c, int pi, int hap, int64_t
         if (v == 0) {
             list_remove_at(c, pi, pos);
         } else {
-            if (c.lane == 0) { ln[pos] = v; LT(c, pi)[pos / LANES] += delta; }
+            if (c.lane == 0) { ln[pos] = v; if (c.nocc[pi] > LANES) LT(c, pi)[pos / LANES] += delta; }
             WSYNC();
         }
     } else {
@@ -563,16 +570,20 @@ static __device__ __forceinline__ void refresh_mig(Ctx &c) {
             carry = bcast(pre, LANES - 1);
         }
         c.totalMig = carry;
+        c.mig_cum_ok = true;
         WSYNC();
         return;
     }
     if (!c.has_mig) {  // every maxEffectiveBirthMigration is +0.0: all products and sums are +0.0
         for (int pn = lane; pn < P; pn += LANES) { c.migRate[pn] = 0.0; c.cumMig[pn] = 0.0; }
         c.totalMig = 0.0;
+        c.mig_cum_ok = true;
         WSYNC();
         return;
     }
-    double carry = 0.0;
+    // totalMigrationRate only: the prefix sums GenerateMigration's fastChoose needs (same additions, same order)
+    // are produced by mig_scan() when a migration is actually drawn
+    double acc = 0.0;
     for (int base = 0; base < P; base += LANES) {
         int pn = base + lane;
         double w = 0.0;
@@ -580,11 +591,25 @@ static __device__ __forceinline__ void refresh_mig(Ctx &c) {
             w = c.maxEBM[pn] * (double)c.totalSus[pn] * (double)(c.gI - c.totalInf[pn]);
             c.migRate[pn] = w;
         }
+        acc = seq_sum(w, min(LANES, P - base), acc);
+    }
+    c.totalMig = acc;
+    c.mig_cum_ok = false;
+    WSYNC();
+}
+
+// running totals of migPopRate (pyx:541-546 / fast_choose.pxi:25) for the population choice of a migration
+static __device__ __forceinline__ void mig_scan(Ctx &c) {
+    const int P = c.P, lane = c.lane;
+    double carry = 0.0;
+    for (int base = 0; base < P; base += LANES) {
+        int pn = base + lane;
+        double w = (pn < P) ? c.migRate[pn] : 0.0;
         double pre = seq_scan(w, min(LANES, P - base), carry);
         if (pn < P) c.cumMig[pn] = pre;
         carry = bcast(pre, LANES - 1);
     }
-    c.totalMig = carry;
+    c.mig_cum_ok = true;
     WSYNC();
 }
 
@@ -817,7 +842,7 @@ static __device__ __forceinline__ int generate_event(Ctx &c, double u, Tile &t, 
                 } else if (lane == 0) {
                     LN(c, pi)[k] += 1;
                 }
-                if (lane == 0) { LT(c, pi)[k / LANES] += 1; c.immSrc[pi * S + si] = c.cumul[si] * (double)c.sus[pi * S + si]; }
+                if (lane == 0) { if (!t.valid) LT(c, pi)[k / LANES] += 1; c.immSrc[pi * S + si] = c.cumul[si] * (double)c.sus[pi * S + si]; }
                 WSYNC();
                 q.immune = true; q.migration = true;
                 BUMP(CNT_B);
@@ -841,7 +866,7 @@ static __device__ __forceinline__ int generate_event(Ctx &c, double u, Tile &t, 
                     } else if (lane == 0) {
                         LN(c, pi)[k] = left;
                     }
-                    if (lane == 0) LT(c, pi)[k / LANES] -= 1;
+                    if (lane == 0 && !t.valid) LT(c, pi)[k / LANES] -= 1;
                 }
                 WSYNC();
                 if (lane == 0) c.immSrc[pi * S + st] = (double)c.sus[pi * S + st] * c.cumul[st];
@@ -868,6 +893,7 @@ static __device__ __forceinline__ int generate_event(Ctx &c, double u, Tile &t, 
     } else {
         // ---- GenerateMigration (pyx:672-694) ----
         c.rn = (choose - c.totalRate) / c.totalMig;
+        if (!c.mig_cum_ok) mig_scan(c);
         int tpi = choose_prefix(c, c.migRate, c.cumMig, P, c.totalMig, c.rn);
         pi = tpi;
         // fastChoose_skip(totalInfectious, globalInfectious - totalInfectious[tpi], rn, skip=tpi), fast_choose.pxi:36-52
@@ -1053,6 +1079,7 @@ static __device__ __forceinline__ void direct_body(const VgxDirectArgs &a) {
     c.ev_ptr = sc->ev_ptr; c.ev_size = a.ev_size; c.loc_n = 0; c.error = 0;
     c.traj_next = 0;
     c.has_mig = true;
+    c.mig_cum_ok = false;
     WSYNC();
     {   // a population can switch on only if its threshold lies below its size (S + I of a population is conserved,
         // so totalInfectious[pn] <= sizes[pn]) and off only if it is on

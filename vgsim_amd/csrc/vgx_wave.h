@@ -2,7 +2,8 @@
 //
 // seq_sum / seq_scan add f64 values held one-per-lane STRICTLY IN LANE ORDER, i.e. with the rounding
 // sequence of the reference's serial loops (fast_choose.pxi:25-28, src/_BirthDeath.pyx:519-528, 537-546).
-// Each step is {v_readlane lo, v_readlane hi, v_add_f64}; the scan additionally narrows EXEC to lanes >= k
+// seq_sum: one v_fmac_f64 (DPP row_newbcast) per step, see below.  seq_scan: each step is
+// {v_readlane lo, v_readlane hi, v_add_f64}; the scan additionally narrows EXEC to lanes >= k
 // before the add, so lane L stops accumulating after its own term and ends with the serial prefix
 // w[0]+...+w[L] (no compare/select instructions on the dependent chain).  Two SGPR pairs (vcc and
 // s[10:11]) alternate so that the VALU-writes-SGPR -> VALU-reads-SGPR distance of gfx940+ (2 wait states)
@@ -40,11 +41,6 @@ static __device__ __forceinline__ int64_t bcast_i64(int64_t v, int k) {
 #define VGX_ADDB "v_add_f64 %0, %0, s[10:11]\n\t"
 #define VGX_EX(K) "s_lshl_b64 exec, -1, " K "\n\t"
 
-#define VGX_SUM8(B)                                                                                   \
-    "s_nop 1\n\t" VGX_RLA(#B "+0") VGX_RLB(#B "+1") VGX_ADDA VGX_RLA(#B "+2") VGX_ADDB VGX_RLB(#B "+3")  \
-        VGX_ADDA VGX_RLA(#B "+4") VGX_ADDB VGX_RLB(#B "+5") VGX_ADDA VGX_RLA(#B "+6") VGX_ADDB           \
-            VGX_RLB(#B "+7") VGX_ADDA "s_nop 1\n\t" VGX_ADDB
-
 #define VGX_SCAN8(B)                                                                                  \
     "s_nop 1\n\t" VGX_RLA(#B "+0") VGX_RLB(#B "+1") VGX_EX(#B "+0") VGX_ADDA VGX_RLA(#B "+2")            \
         VGX_EX(#B "+1") VGX_ADDB VGX_RLB(#B "+3") VGX_EX(#B "+2") VGX_ADDA VGX_RLA(#B "+4")              \
@@ -52,19 +48,40 @@ static __device__ __forceinline__ int64_t bcast_i64(int64_t v, int k) {
                 VGX_EX(#B "+5") VGX_ADDB VGX_RLB(#B "+7") VGX_EX(#B "+6") VGX_ADDA "s_nop 0\n\t"         \
                     VGX_EX(#B "+7") VGX_ADDB "s_mov_b64 exec, -1\n\t"
 
-#define VGX_SUM_GROUP(B) \
-    if (n > B) asm volatile(VGX_SUM8(B) : "+v"(acc) : "v"(lo), "v"(hi) : "vcc", "s10", "s11");
 #define VGX_SCAN_GROUP(B) \
     if (n > B && k0 < B + 8) asm volatile(VGX_SCAN8(B) : "+v"(acc) : "v"(lo), "v"(hi) : "vcc", "scc", "s10", "s11");
 
-// acc + v[0] + v[1] + ... + v[n-1] in lane order.  Lanes >= n MUST hold +0.0 (steps run in groups of 8).
-// Real functions (register arguments only) so that the unrolled chains exist once in the code object.
+// ---- seq_sum: ONE VALU instruction per chain step ------------------------------------------------------------
+// v_fmac_f64 with a DPP source (gfx90a+ "DP ALU DPP", row_newbcast only): acc = fma(v[lane k of the row], 1.0, acc),
+// which rounds exactly like acc + v[k].  row_newbcast:k broadcasts inside a row of 16 lanes, so the chain runs row
+// by row: row_mask enables only the lanes of the current row (they all hold the same running sum), and between
+// rows the sum moves on with row_bcast:15.  The result is made wave-uniform at the end.
+#define VGX_FM(K, RM) "v_fmac_f64_dpp %0, %1, %2 row_newbcast:" #K " row_mask:" #RM " bank_mask:0xf\n\t"
+#define VGX_FSUM8_LO(RM) "s_nop 1\n\t" VGX_FM(0, RM) VGX_FM(1, RM) VGX_FM(2, RM) VGX_FM(3, RM) VGX_FM(4, RM) VGX_FM(5, RM) VGX_FM(6, RM) VGX_FM(7, RM)
+#define VGX_FSUM8_HI(RM) "s_nop 1\n\t" VGX_FM(8, RM) VGX_FM(9, RM) VGX_FM(10, RM) VGX_FM(11, RM) VGX_FM(12, RM) VGX_FM(13, RM) VGX_FM(14, RM) VGX_FM(15, RM)
+#define VGX_FSUM_ROW(R, RM, RMNEXT)                                                                       \
+    if (n > 16 * R) {                                                                                     \
+        asm volatile(VGX_FSUM8_LO(RM) : "+v"(acc) : "v"(v), "v"(one));                                     \
+        if (n > 16 * R + 8) asm volatile(VGX_FSUM8_HI(RM) : "+v"(acc) : "v"(v), "v"(one));                 \
+        if (R < 3 && n > 16 * R + 16) {                                                                   \
+            int alo = __double2loint(acc), ahi = __double2hiint(acc);                                     \
+            alo = __builtin_amdgcn_update_dpp(alo, alo, 0x142, RMNEXT, 0xf, false);                       \
+            ahi = __builtin_amdgcn_update_dpp(ahi, ahi, 0x142, RMNEXT, 0xf, false);                       \
+            acc = __hiloint2double(ahi, alo);                                                             \
+        }                                                                                                 \
+    }
+
+// acc + v[0] + v[1] + ... + v[n-1] in lane order (wave-uniform result).  Lanes >= n MUST hold +0.0 (steps run in
+// groups of 8); acc must be wave-uniform; all 64 lanes active.
 static __device__ __forceinline__ double seq_sum(double v, int n, double acc) {
-    int lo = __double2loint(v), hi = __double2hiint(v);
     n = __builtin_amdgcn_readfirstlane(n);
-    VGX_SUM_GROUP(0) VGX_SUM_GROUP(8) VGX_SUM_GROUP(16) VGX_SUM_GROUP(24)
-    VGX_SUM_GROUP(32) VGX_SUM_GROUP(40) VGX_SUM_GROUP(48) VGX_SUM_GROUP(56)
-    return acc;
+    if (n <= 0) return acc;
+    const double one = 1.0;
+    VGX_FSUM_ROW(0, 0x1, 0x2) VGX_FSUM_ROW(1, 0x2, 0x4) VGX_FSUM_ROW(2, 0x4, 0x8) VGX_FSUM_ROW(3, 0x8, 0x0)
+    int src = ((n - 1) >> 4) << 4;   // a lane of the last row that ran
+    int lo = __builtin_amdgcn_readlane(__double2loint(acc), src);
+    int hi = __builtin_amdgcn_readlane(__double2hiint(acc), src);
+    return __hiloint2double(hi, lo);
 }
 
 // lane L (k0 <= L < n) gets carry + v[k0'] + ... + v[L] with k0' = k0 rounded down to a multiple of 8:
