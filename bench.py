@@ -311,7 +311,7 @@ def main():
                 line["tau_leap"] = {"error": repr(ex)}
         if world == 1 and not a.no_extra:
             legs = (("fast_mode", lambda d: fast_leg(d, R, N, a.traj_points)),
-                    ("spread_occupancy", lambda d: spread_leg(d, "exact")),
+                    ("spread_occupancy", lambda d: spread_leg(d, "exact", replicates=4096, events=5000)),
                     ("spread_occupancy_fast", lambda d: spread_leg(d, "fast", replicates=4096)),
                     ("config2", c2_leg))
             for name, fn in legs:

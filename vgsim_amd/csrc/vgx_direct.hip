@@ -418,7 +418,7 @@ static __device__ __forceinline__ double row_sum(Ctx &c, int pi, const Tile &t) 
     for (int base = 0; base < n; base += LANES) {
         int k = base + c.lane;
         double w = 0.0;
-        if (k < n) w = c.tE[lc[k]] * (double)ln[k];
+        if (k < n) w = c.tE[c.C == 1 ? 0 : lc[k]] * (double)ln[k];
         acc = seq_sum(w, min(LANES, n - base), acc);
     }
     return acc;
@@ -492,16 +492,38 @@ static __device__ __forceinline__ int row_select(Ctx &c, int pi, const Tile &t, 
     const int n = t.valid ? t.n : c.nocc[pi];
     const int32_t *lc = LC(c, pi);
     const int64_t *ln = LN(c, pi);
-    double r = tw * rn;
-    double carry = 0.0;
-    for (int base = 0; base < n; base += LANES) {
-        int k = base + lane;
-        int nn = min(LANES, n - base);
-        double w = 0.0;
-        if (t.valid) w = (k < n) ? c.tE[t.cls] * (double)t.cnt : 0.0;
-        else if (k < n) w = c.tE[lc[k]] * (double)ln[k];
-        double pre = seq_scan(w, nn, carry);
-        unsigned long long hit = __ballot((k < n) && !(pre < r));
+    const double r = tw * rn;
+    double carry = 0.0, w = 0.0;
+    int base = 0, k0 = 0, nn = n;
+    bool inside = true;   // the running sum reaches r inside lanes [k0, nn) of the chunk at `base`
+    if (t.valid) {
+        w = (lane < n) ? c.tE[t.cls] * (double)t.cnt : 0.0;
+    } else {
+        // long list: the running sum advances one row of 16 entries at a time (one fmac per entry, vgx_wave.h);
+        // the row in which it first reaches r is then scanned lane by lane below — same additions, same order
+        inside = false;
+        while (base < n) {
+            int k = base + lane;
+            nn = min(LANES, n - base);
+            w = (k < n) ? c.tE[c.C == 1 ? 0 : lc[k]] * (double)ln[k] : 0.0;
+            for (int row = 0; row < 4 && 16 * row < nn; ++row) {
+                double before = carry;
+                carry = row_chain(w, row, min(16, nn - 16 * row), carry);
+                if (!(carry < r)) {
+                    inside = true;
+                    k0 = 16 * row;
+                    nn = min(nn, 16 * row + 16);
+                    carry = before;
+                    break;
+                }
+            }
+            if (inside) break;
+            base += LANES;
+        }
+    }
+    if (inside) {
+        double pre = seq_scan(w, nn, carry, k0);
+        unsigned long long hit = __ballot(lane >= k0 && lane < nn && !(pre < r));
         if (hit) {
             int j = __ffsll((long long)hit) - 1;
             double total = bcast(pre, j), wi = bcast(w, j);
@@ -509,12 +531,12 @@ static __device__ __forceinline__ int row_select(Ctx &c, int pi, const Tile &t, 
             rn = (r - (total - wi)) / wi;
             return base + j;
         }
-        carry = bcast(pre, LANES - 1);
+        carry = nn > 0 ? bcast(pre, nn - 1) : 0.0;  // register tile whose total stays below r
     }
     // nothing reached r: the dense loop runs on to index H-1 (fast_choose.pxi:26); that is a valid pick
     // only if haplotype H-1 is occupied, otherwise the reference reports a zero weight
     if (n > 0 && LH(c, pi)[n - 1] == c.H - 1) {
-        double wi = c.tE[lc[n - 1]] * (double)ln[n - 1];
+        double wi = c.tE[c.C == 1 ? 0 : lc[n - 1]] * (double)ln[n - 1];
         rn = (r - (carry - wi)) / wi;
         return n - 1;
     }

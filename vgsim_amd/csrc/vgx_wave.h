@@ -71,6 +71,21 @@ static __device__ __forceinline__ int64_t bcast_i64(int64_t v, int k) {
         }                                                                                                 \
     }
 
+// One row (16 lanes, R = 0..3) of the chain: acc + v[16R] + ... + v[16R + m - 1], wave-uniform in and out
+// (m = entries of the row that count, 1..16; lanes beyond MUST hold +0.0).
+#define VGX_ROW_CASE(R, RM)                                                                  \
+    if (row == R) {                                                                          \
+        asm volatile(VGX_FSUM8_LO(RM) : "+v"(acc) : "v"(v), "v"(one));                        \
+        if (m > 8) asm volatile(VGX_FSUM8_HI(RM) : "+v"(acc) : "v"(v), "v"(one));             \
+    }
+static __device__ __forceinline__ double row_chain(double v, int row, int m, double acc) {
+    const double one = 1.0;
+    VGX_ROW_CASE(0, 0x1) VGX_ROW_CASE(1, 0x2) VGX_ROW_CASE(2, 0x4) VGX_ROW_CASE(3, 0x8)
+    int lo = __builtin_amdgcn_readlane(__double2loint(acc), row * 16);
+    int hi = __builtin_amdgcn_readlane(__double2hiint(acc), row * 16);
+    return __hiloint2double(hi, lo);
+}
+
 // acc + v[0] + v[1] + ... + v[n-1] in lane order (wave-uniform result).  Lanes >= n MUST hold +0.0 (steps run in
 // groups of 8); acc must be wave-uniform; all 64 lanes active.
 static __device__ __forceinline__ double seq_sum(double v, int n, double acc) {
