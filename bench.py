@@ -28,6 +28,18 @@ SITES, POPS, SUS = 8, 64, 1           # BASELINE.json configs[2]: 4^8 = 65 536 h
 HBM_PEAK_GBS = 8000.0                 # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
+def pmc_traffic(leg, config):
+    """HBM bytes per launch from the committed PMC passes (profiles/pmc_direct_c3.json: separate rocprofv3 --pmc runs of
+    this same command, corrected as MI355X_MICROARCH.md prescribes), or None when the configuration differs."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "pmc_direct_c3.json")))[leg]
+        if all(d["config"].get(k) == v for k, v in config.items()):
+            return d["hbm_bytes_per_launch"]
+    except Exception:
+        pass
+    return None
+
+
 def make_simulator(seed):
     from vgsim_amd import Simulator
     with contextlib.redirect_stdout(io.StringIO()):
@@ -89,13 +101,16 @@ def spread_leg(device, mode="exact", replicates=1024, events=20000, occupied=409
     nocc = float((st.infectious != 0).sum(axis=1).mean())
     ms = best.kernel_ms
     ev = best.total_events
-    # exact: the whole list of the chosen population is streamed (16 B/entry); fast: tile sums + one tile
-    bpe = (16.0 * nocc if mode == "exact" else 8.0 * (nocc / 64.0) + 16.0 * 64) + 8.0 * POPS + 28.0 + 8.0
+    # exact, one rate class: counts (8 B/entry) of the whole list for the rate refresh + of the entries up to the hit
+    # (half the list on average) for the selection; fast: tile sums + one tile
+    bpe = (12.0 * nocc if mode == "exact" else 8.0 * (nocc / 64.0) + 16.0 * 64) + 8.0 * POPS + 28.0 + 8.0
+    traffic = pmc_traffic("spread_occupancy", {"replicates_per_gpu": replicates, "events_per_replicate": events,
+                                                "occupied": occupied, "mode": mode})
     out = {"workload": "BASELINE config 3, spread occupancy: %d occupied haplotypes per population at start "
                        "(mean %.0f at the end), %d replicates x %d events, %s mode" % (occupied, nocc, replicates, events, mode),
            "value": ev / (ms * 1e-3), "unit": "events/s (device time)", "kernel_ms_per_launch": ms,
            "roofline": {"bound": "hbm", "achieved": ev * bpe / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": ev * bpe / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                        "frac": ev * bpe / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
                         "bytes_per_event": bpe, "mean_occupancy_list_len": nocc}}
     ens.close()
     return out
@@ -141,7 +156,7 @@ def c2_leg(device, replicates=16384, events=100000):
     return out
 
 
-def tau_leg(device, steps=20, per_cell=3):
+def tau_leg(device, steps=20, per_cell=3, seed=2020):
     """Tau-leaping on BASELINE config 4 (2^20 haplotypes x 256 populations, migration), dense ("spread")
     occupancy written straight into the model's arrays; the reference cannot even construct this shape
     (SURVEY.md §0.8).  Reports events drawn per second of device time and the step's HBM roofline against the
@@ -162,7 +177,7 @@ def tau_leg(device, steps=20, per_cell=3):
     m.events.CreateEvents(steps)
     m.events.ptr = 1            # not the first call of the model: capacity = ptr + iterations (events.pxi:61-68)
     m.events.CreateEvents(steps)
-    eng.set_params(m); eng.set_state(m); eng.set_seeds(np.array([2020], dtype=np.int64))
+    eng.set_params(m); eng.set_state(m); eng.set_seeds(np.array([seed], dtype=np.int64))
     o = _capi.VgxRunOpts(); o.record_events = 0
     eng._check(eng.lib.vgx_simulate_tau(eng.handle, steps, 10 ** 15, -1.0, 1, C.byref(o)))
     c = eng.counters(0)
@@ -191,7 +206,9 @@ def main():
     ap.add_argument("--traj-points", type=int, default=1001)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-tau", action="store_true", help="skip the tau-leap (config 4) leg")
-    ap.add_argument("--no-extra", action="store_true", help="skip the spread-occupancy and config-2 legs")
+    ap.add_argument("--no-extra", action="store_true", help="skip the FAST-mode, spread-occupancy and config-2 legs")
+    ap.add_argument("--only", default="", help="development/profiling: run only this extra leg (fast_mode, spread_occupancy, "
+                                               "spread_occupancy_fast, config2, tau_leap) and print its JSON")
     a = ap.parse_args()
 
     import numpy as np
@@ -208,10 +225,17 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
     from vgsim_amd.ensemble import Ensemble
-    sim = make_simulator(2020)
-    ens = Ensemble(sim, a.replicates, device=local)
     R, N = a.replicates, a.events
     H = 4 ** SITES
+    extra_legs = (("fast_mode", lambda d: fast_leg(d, R, N, a.traj_points)),
+                  ("spread_occupancy", lambda d: spread_leg(d, "exact", replicates=4096, events=5000)),
+                  ("spread_occupancy_fast", lambda d: spread_leg(d, "fast", replicates=4096)),
+                  ("config2", c2_leg), ("tau_leap", tau_leg))
+    if a.only:
+        print(json.dumps({a.only: dict(extra_legs)[a.only](local)}), flush=True)
+        return
+    sim = make_simulator(2020)
+    ens = Ensemble(sim, a.replicates, device=local)
 
     def sync():
         torch.cuda.synchronize()
@@ -263,16 +287,8 @@ def main():
         launch_s = (kernel_ms / max(a.steps, 1)) * 1e-3
         achieved = ev_per_launch * bytes_per_event / launch_s / 1e9
         dense_bytes = H * (84 + 16 * SUS) + 16 * POPS + 48   # the reference's dense layout
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_direct_c3.json")
-        if os.path.exists(pmc):
-            try:
-                d = json.load(open(pmc))
-                c = d.get("config", {})
-                if c.get("replicates_per_gpu") == R and c.get("events_per_replicate") == N and c.get("trajectory_points") == a.traj_points:
-                    traffic = d.get("hbm_bytes_per_launch")   # PMC passes are separate runs of this same command
-            except Exception:
-                traffic = None
+        traffic = pmc_traffic("headline", {"replicates_per_gpu": R, "events_per_replicate": N, "trajectory_points": a.traj_points})
+        li = float(res.loop_iterations.sum()) / max(float(res.events.sum()), 1.0)
         line = {
             "metric": "simulated events/sec (direct Gillespie)", "value": value, "unit": "events/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / max(a.steps, 1),
@@ -281,10 +297,10 @@ def main():
                                    "group, direct Gillespie, bit-exact mode (PCG64 stream, reference summation order), "
                                    "index-case start, b=2.5 d=0.9 s=0.1 m=0.01/site, total migration 0.01, N=1e7",
                        "replicates_per_gpu": R, "events_per_replicate": N, "parallelism": "replicates x%d" % world,
-                       "trajectory_points": a.traj_points},
+                       "trajectory_points": a.traj_points, "loop_iterations_per_event": li},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "vgx_direct_kernel", "kernel_ms_per_launch": kernel_ms / max(a.steps, 1),
+                         "kernel": "vgx_direct_kernel_p64s1c1", "kernel_ms_per_launch": kernel_ms / max(a.steps, 1),
                          "bytes_per_event": bytes_per_event, "mean_occupancy_list_len": nocc_mean,
                          "note": "persistent sequential event loop: latency/issue-bound, not bandwidth-bound; the "
                                  "reference's dense layout would need %.3g B/event = %.3g GB/s at this event rate"
@@ -303,18 +319,32 @@ def main():
             line["cpu_baseline"] = cpu_baseline()
     ens.close()
     ens = None
+    # tau-leaping leg (BASELINE config 4): one independent replicate per GPU (replicas only, no collective on the path)
+    tau = None
+    if not a.no_tau:
+        try:
+            tau = tau_leg(local, seed=2020 + rank)
+        except Exception as ex:  # never lose the headline line
+            tau = {"error": repr(ex)}
+        if world > 1:
+            ok = 0.0 if "error" in tau else 1.0
+            v = torch.tensor([ok, tau.get("events_drawn", 0.0) * ok, tau.get("ms_per_step", 0.0) * tau.get("steps", 0) * ok],
+                             dtype=torch.float64, device="cuda")
+            tot = v.clone()
+            dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+            mx = v.clone()
+            dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+            if rank == 0 and "error" not in tau:
+                tau["ranks_ok"] = int(tot[0].item())
+                tau["events_drawn"] = int(tot[1].item())
+                tau["value"] = tot[1].item() / max(mx[2].item() * 1e-3, 1e-12)   # all ranks' events / slowest rank's device time
+                tau["unit"] = "events/s (device time, %d replicas)" % world
+                tau.pop("roofline", None)
     if rank == 0:
-        if world == 1 and not a.no_tau:
-            try:
-                line["tau_leap"] = tau_leg(local)
-            except Exception as ex:  # never lose the headline line
-                line["tau_leap"] = {"error": repr(ex)}
+        if tau is not None:
+            line["tau_leap"] = tau
         if world == 1 and not a.no_extra:
-            legs = (("fast_mode", lambda d: fast_leg(d, R, N, a.traj_points)),
-                    ("spread_occupancy", lambda d: spread_leg(d, "exact", replicates=4096, events=5000)),
-                    ("spread_occupancy_fast", lambda d: spread_leg(d, "fast", replicates=4096)),
-                    ("config2", c2_leg))
-            for name, fn in legs:
+            for name, fn in extra_legs[:4]:
                 try:
                     line[name] = fn(local)
                 except Exception as ex:

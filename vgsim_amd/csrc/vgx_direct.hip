@@ -404,6 +404,40 @@ static __device__ __forceinline__ void tE_fill(Ctx &c, int pi) {
     WSYNC();
 }
 
+// A long occupancy list is read 64 entries at a time with the loads of the next VGX_STREAM_DEPTH chunks already in
+// flight (the serial sum of one chunk is much shorter than an HBM round trip).
+#define VGX_STREAM_DEPTH 4
+struct ListStream {
+    const int32_t *lc;
+    const int64_t *ln;
+    int64_t cnt[VGX_STREAM_DEPTH];
+    int cls[VGX_STREAM_DEPTH];
+};
+static __device__ __forceinline__ void stream_load(Ctx &c, ListStream &ls, int slot, int base, int n) {
+    int k = base + c.lane;
+    ls.cnt[slot] = 0;
+    ls.cls[slot] = 0;
+    if (k < n) {
+        ls.cnt[slot] = ls.ln[k];
+        if (c.C != 1) ls.cls[slot] = ls.lc[k];
+    }
+}
+static __device__ __forceinline__ void stream_open(Ctx &c, ListStream &ls, int pi, int n) {
+    ls.lc = LC(c, pi);
+    ls.ln = LN(c, pi);
+#pragma unroll
+    for (int d = 0; d < VGX_STREAM_DEPTH; ++d) stream_load(c, ls, d, d * LANES, n);
+}
+// weight tEvent * infectious of entry base + lane (0.0 beyond the list); refills the freed slot
+static __device__ __forceinline__ double stream_next(Ctx &c, ListStream &ls, int base, int n) {
+    int64_t cn = ls.cnt[0];
+    int cl = ls.cls[0];
+#pragma unroll
+    for (int d = 0; d + 1 < VGX_STREAM_DEPTH; ++d) { ls.cnt[d] = ls.cnt[d + 1]; ls.cls[d] = ls.cls[d + 1]; }
+    stream_load(c, ls, VGX_STREAM_DEPTH - 1, base + VGX_STREAM_DEPTH * LANES, n);
+    return (base + c.lane < n) ? c.tE[cl] * (double)cn : 0.0;
+}
+
 // infectPopRate[pi] = sum over occupied haplotypes, in haplotype order, of tEvent * infectious (pyx:519-528)
 static __device__ __forceinline__ double row_sum(Ctx &c, int pi, const Tile &t) {
     if (c.fast) return c.tE[0] * (double)c.totalInf[pi];  // one rate class: sum_h tE * infectious[pi, h]
@@ -412,13 +446,11 @@ static __device__ __forceinline__ double row_sum(Ctx &c, int pi, const Tile &t) 
         return seq_sum(w, t.n, 0.0);
     }
     const int n = c.nocc[pi];
-    const int32_t *lc = LC(c, pi);
-    const int64_t *ln = LN(c, pi);
+    ListStream ls;
+    stream_open(c, ls, pi, n);
     double acc = 0.0;
     for (int base = 0; base < n; base += LANES) {
-        int k = base + c.lane;
-        double w = 0.0;
-        if (k < n) w = c.tE[c.C == 1 ? 0 : lc[k]] * (double)ln[k];
+        double w = stream_next(c, ls, base, n);
         acc = seq_sum(w, min(LANES, n - base), acc);
     }
     return acc;
@@ -502,10 +534,11 @@ static __device__ __forceinline__ int row_select(Ctx &c, int pi, const Tile &t, 
         // long list: the running sum advances one row of 16 entries at a time (one fmac per entry, vgx_wave.h);
         // the row in which it first reaches r is then scanned lane by lane below — same additions, same order
         inside = false;
+        ListStream ls;
+        stream_open(c, ls, pi, n);
         while (base < n) {
-            int k = base + lane;
             nn = min(LANES, n - base);
-            w = (k < n) ? c.tE[c.C == 1 ? 0 : lc[k]] * (double)ln[k] : 0.0;
+            w = stream_next(c, ls, base, n);
             for (int row = 0; row < 4 && 16 * row < nn; ++row) {
                 double before = carry;
                 carry = row_chain(w, row, min(16, nn - 16 * row), carry);
