@@ -84,8 +84,8 @@ typedef struct vgx_run_opts {
     double traj_t0, traj_t1; /* time window of the trajectory grid */
     int64_t mode;            /* direct path: 0 = EXACT (the reference's floating-point summation order, bit-exact log);
                                 1 = FAST (order-free sums: class-aggregated infection rate, integer prefix search,
-                                factored BirthRate, tree scans; same random stream and event semantics; needs one
-                                rate class).  Ignored by vgx_simulate_tau. */
+                                factored BirthRate, tree scans; same random stream and event semantics, identical
+                                integer columns on the same seed).  Ignored by vgx_simulate_tau. */
     int64_t reserved[3];
 } vgx_run_opts;
 

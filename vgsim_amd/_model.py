@@ -667,7 +667,7 @@ class BirthDeathModel:
     def SimulatePopulation(self, iterations, sample_size, time, attempts, mode='exact'):
         """pyx:396-429: direct Gillespie on the GPU (one persistent wavefront per trajectory).  ``mode``:
         'exact' = the reference's floating-point summation order (bit-exact log); 'fast' = order-free sums
-        (same random stream and event semantics, needs one rate class; include/vgx.h vgx_run_opts.mode)."""
+        (same random stream and event semantics; include/vgx.h vgx_run_opts.mode)."""
         self._check_supported()
         if mode not in ('exact', 'fast'):
             raise ValueError("mode must be 'exact' or 'fast'")

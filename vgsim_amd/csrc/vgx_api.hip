@@ -578,9 +578,6 @@ static int direct_core(vgx_engine *e, int64_t iterations, int64_t sample_size, f
     if (opts) o = *opts;
     if (o.max_loop_factor <= 0) o.max_loop_factor = 1024;
     if (o.mode != 0 && o.mode != 1) return fail(e, VGX_ERR_ARG, "vgx_simulate_direct: mode must be 0 (exact) or 1 (fast)");
-    if (o.mode == 1 && !(e->C == 1 && e->CB == 1))
-        return fail(e, VGX_ERR_CLASSES, "vgx_simulate_direct: fast mode needs one rate class (identical bRate, dRate, sRate, "
-                                        "mutation total, susceptibility row and suscType for all haplotypes)");
     size_t lds = lds_bytes_for(e);
     if (lds > 160 * 1024)
         return fail(e, VGX_ERR_ARG, "vgx_simulate_direct: the population/class tables need " + std::to_string(lds) +

@@ -440,7 +440,20 @@ static __device__ __forceinline__ double stream_next(Ctx &c, ListStream &ls, int
 
 // infectPopRate[pi] = sum over occupied haplotypes, in haplotype order, of tEvent * infectious (pyx:519-528)
 static __device__ __forceinline__ double row_sum(Ctx &c, int pi, const Tile &t) {
-    if (c.fast) return c.tE[0] * (double)c.totalInf[pi];  // one rate class: sum_h tE * infectious[pi, h]
+    if (c.fast) {
+        if (c.C == 1) return c.tE[0] * (double)c.totalInf[pi];  // one rate class: sum_h tE * infectious[pi, h]
+        // several classes: tree sums over the lanes, chunk after chunk (order-free; haplotype order is kept)
+        if (t.valid && t.pi == pi) {
+            double w = (c.lane < t.n) ? c.tE[t.cls] * (double)t.cnt : 0.0;
+            return bcast(fscan(w), LANES - 1);
+        }
+        const int n = c.nocc[pi];
+        ListStream ls;
+        stream_open(c, ls, pi, n);
+        double acc = 0.0;
+        for (int base = 0; base < n; base += LANES) acc += bcast(fscan(stream_next(c, ls, base, n)), LANES - 1);
+        return acc;
+    }
     if (t.valid && t.pi == pi) {
         double w = (c.lane < t.n) ? c.tE[t.cls] * (double)t.cnt : 0.0;
         return seq_sum(w, t.n, 0.0);
@@ -519,7 +532,7 @@ static __device__ __forceinline__ int count_select(Ctx &c, int pi, const Tile &t
 
 // fastChoose(hapPopRate[pi], infectPopRate[pi], rn) over the occupied entries; returns the list index
 static __device__ __forceinline__ int row_select(Ctx &c, int pi, const Tile &t, double tw, double &rn) {
-    if (c.fast) return count_select(c, pi, t, c.totalInf[pi], rn);  // one rate class: weights tE * count
+    if (c.fast && c.C == 1) return count_select(c, pi, t, c.totalInf[pi], rn);  // one rate class: weights tE * count
     const int lane = c.lane;
     const int n = t.valid ? t.n : c.nocc[pi];
     const int32_t *lc = LC(c, pi);
@@ -527,6 +540,31 @@ static __device__ __forceinline__ int row_select(Ctx &c, int pi, const Tile &t, 
     const double r = tw * rn;
     double carry = 0.0, w = 0.0;
     int base = 0, k0 = 0, nn = n;
+    if (c.fast) {  // several classes: tree prefix sums chunk by chunk, first entry whose prefix reaches r
+        ListStream ls;
+        if (!t.valid) stream_open(c, ls, pi, n);
+        for (; base < n; base += LANES) {
+            w = t.valid ? ((lane < n) ? c.tE[t.cls] * (double)t.cnt : 0.0) : stream_next(c, ls, base, n);
+            double pre = fscan(w) + carry;
+            unsigned long long hit = __ballot(base + lane < n && !(pre < r));
+            if (hit) {
+                int j = __ffsll((long long)hit) - 1;
+                double total = bcast(pre, j), wi = bcast(w, j);
+                if (wi == 0.0) c.error = ERR_ZERO_WEIGHT;
+                rn = (r - (total - wi)) / wi;
+                return base + j;
+            }
+            carry = bcast(pre, LANES - 1);
+        }
+        // rounding left the total below r: the last occupied entry (the reference clamps at the end of the array)
+        if (n > 0) {
+            double wi = c.tE[t.valid ? __builtin_amdgcn_readlane(t.cls, n - 1) : lc[n - 1]] * (double)(t.valid ? bcast_i64(t.cnt, n - 1) : ln[n - 1]);
+            rn = (r - (carry - wi)) / wi;
+            return n - 1;
+        }
+        c.error = ERR_ZERO_WEIGHT;
+        return 0;
+    }
     bool inside = true;   // the running sum reaches r inside lanes [k0, nn) of the chunk at `base`
     if (t.valid) {
         w = (lane < n) ? c.tE[t.cls] * (double)t.cnt : 0.0;
@@ -1287,8 +1325,8 @@ extern "C" __global__ void __launch_bounds__(LANES) vgx_direct_kernel(VgxDirectA
 extern "C" __global__ void __launch_bounds__(LANES) vgx_direct_kernel_p64(VgxDirectArgs a) { direct_body<64, 0, 0, 0>(a); }
 // popNum <= 64, one susceptibility group, one rate class (e.g. BASELINE configs 2 and 3)
 extern "C" __global__ void __launch_bounds__(LANES) vgx_direct_kernel_p64s1c1(VgxDirectArgs a) { direct_body<64, 1, 1, 0>(a); }
-// FAST mode (vgx_run_opts.mode = 1, one rate class): order-free sums, same random stream and event semantics
-extern "C" __global__ void __launch_bounds__(LANES) vgx_direct_fast_kernel(VgxDirectArgs a) { direct_body<0, 0, 1, 1>(a); }
+// FAST mode (vgx_run_opts.mode = 1): order-free sums, same random stream and event semantics
+extern "C" __global__ void __launch_bounds__(LANES) vgx_direct_fast_kernel(VgxDirectArgs a) { direct_body<0, 0, 0, 1>(a); }
 extern "C" __global__ void __launch_bounds__(LANES) vgx_direct_fast_kernel_p64s1(VgxDirectArgs a) { direct_body<64, 1, 1, 1>(a); }
 
 // Gives every replicate the same start state (the host model's state at the beginning of the call):
@@ -1341,8 +1379,7 @@ extern "C" __attribute__((visibility("hidden"))) hipError_t vgxi_launch_direct(c
                                                                               hipStream_t stream) {
     void (*k)(VgxDirectArgs) = vgx_direct_kernel;
     if (a->fast) {
-        if (!(a->p.C == 1 && a->p.CB == 1)) return hipErrorInvalidValue;  // checked by the caller
-        k = (a->p.P <= 64 && a->p.S == 1) ? vgx_direct_fast_kernel_p64s1 : vgx_direct_fast_kernel;
+        k = (a->p.P <= 64 && a->p.S == 1 && a->p.C == 1 && a->p.CB == 1) ? vgx_direct_fast_kernel_p64s1 : vgx_direct_fast_kernel;
     } else if (a->p.P <= 64) {
         k = (a->p.S == 1 && a->p.C == 1 && a->p.CB == 1) ? vgx_direct_kernel_p64s1c1 : vgx_direct_kernel_p64;
     }

@@ -49,7 +49,7 @@ class Ensemble:
                  traj_points=0, traj_window=(0.0, 1.0), seeds=None, mode='exact'):
         """Direct Gillespie for every replicate from the model's current state (``SimulatePopulation`` semantics
         per replicate, pyx:396-429).  ``mode``: 'exact' (reference summation order, bit-exact) or 'fast'
-        (order-free sums, one rate class).  Returns an :class:`EnsembleResult`."""
+        (order-free sums).  Returns an :class:`EnsembleResult`."""
         if mode not in ('exact', 'fast'):
             raise ValueError("mode must be 'exact' or 'fast'")
         m, eng = self.model, self.engine
