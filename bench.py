@@ -116,6 +116,33 @@ def spread_leg(device, mode="exact", replicates=1024, events=20000, occupied=409
     return out
 
 
+def genealogy_leg(device, events=300000):
+    """the backward pass (GetGenealogy, pyx:743-1000) over one config-3 chain produced on the
+    device — libvgx's host code against the oracle's literal restatement of the reference (dense per-compartment
+    vectors), same chain, same seed, identical trees."""
+    import copy
+    import numpy as np
+    from vgsim_amd import _capi
+    from oracle import oracle
+    oracle.build()
+    sim = make_simulator(2020)
+    with contextlib.redirect_stdout(io.StringIO()):
+        sim.simulate(events, sample_size=10 ** 12)
+    m = sim.simulation
+    m2 = copy.copy(m)
+    m2.infectious = m.infectious.copy()
+    m2.events = copy.deepcopy(m.events)
+    t0 = time.perf_counter()
+    out = _capi.get_genealogy(m, 7)
+    t1 = time.perf_counter()
+    ref = oracle.run_genealogy(m2, 7)
+    t2 = time.perf_counter()
+    same = bool(np.array_equal(out["tree"], ref["tree"]) and np.array_equal(out["times"], ref["times"]))
+    return {"workload": "backward pass over one config-3 chain (host code)", "events": int(m.events.ptr), "samples": int(m.sCounter),
+            "value": m.events.ptr / (t1 - t0), "unit": "events/s (one host core)", "seconds": t1 - t0,
+            "oracle_events_per_s": m.events.ptr / (t2 - t1), "oracle_seconds": t2 - t1, "identical_to_oracle": same}
+
+
 def fast_leg(device, replicates, events, traj_points):
     """The headline workload (natural occupancy) in FAST mode, device time of one launch after a warm-up."""
     import numpy as np
@@ -208,7 +235,7 @@ def main():
     ap.add_argument("--no-tau", action="store_true", help="skip the tau-leap (config 4) leg")
     ap.add_argument("--no-extra", action="store_true", help="skip the FAST-mode, spread-occupancy and config-2 legs")
     ap.add_argument("--only", default="", help="development/profiling: run only this extra leg (fast_mode, spread_occupancy, "
-                                               "spread_occupancy_fast, config2, tau_leap) and print its JSON")
+                                               "spread_occupancy_fast, config2, genealogy, tau_leap) and print its JSON")
     a = ap.parse_args()
 
     import numpy as np
@@ -230,7 +257,7 @@ def main():
     extra_legs = (("fast_mode", lambda d: fast_leg(d, R, N, a.traj_points)),
                   ("spread_occupancy", lambda d: spread_leg(d, "exact", replicates=4096, events=5000)),
                   ("spread_occupancy_fast", lambda d: spread_leg(d, "fast", replicates=4096)),
-                  ("config2", c2_leg), ("tau_leap", tau_leg))
+                  ("config2", c2_leg), ("genealogy", genealogy_leg), ("tau_leap", tau_leg))
     if a.only:
         print(json.dumps({a.only: dict(extra_legs)[a.only](local)}), flush=True)
         return
@@ -344,7 +371,7 @@ def main():
         if tau is not None:
             line["tau_leap"] = tau
         if world == 1 and not a.no_extra:
-            for name, fn in extra_legs[:4]:
+            for name, fn in extra_legs[:5]:
                 try:
                     line[name] = fn(local)
                 except Exception as ex:

@@ -98,7 +98,8 @@ typedef struct vgx_counters {
     int64_t lockdown_records;
     int64_t error;                 /* VGX_* code raised inside the kernel for this replicate */
     int64_t multievent_rows;       /* tau: rows appended to the multievent log by this call */
-    int64_t reserved[5];
+    int64_t reserved[5];           /* [0] tau: events drawn; direct: [1] index of the last attempt that drew random
+                                      numbers (-1 none), [2] its loop iterations (2 uniforms each) */
 } vgx_counters;
 
 /* ---- lifecycle ------------------------------------------------------------------------------ */
@@ -140,6 +141,37 @@ int vgx_get_multievents(vgx_engine *e, int64_t replicate, int64_t cap, int64_t *
 /* Summary trajectories of the last call: out[replicate][point][population][0=infectious,1=susceptible], f64.
  * `out` is a host pointer, or a device pointer when out_is_device != 0 (e.g. a torch tensor for an RCCL gather). */
 int vgx_get_trajectories(vgx_engine *e, double *out, int out_is_device);
+
+/* ---- backward pass ------------------------------------------------------------------------- */
+/* Replaces BirthDeathModel.GetGenealogy(seed) (pyx:743-1000) with its recorders Mutations / Migrations
+ * (models.pxi:1-48): one backward walk over the event log that coalesces the sampled lineages.  Host code (no
+ * device, no engine handle needed).  `infectious` is walked back in place exactly as the reference does. */
+typedef struct vgx_genealogy_io {
+    int64_t popNum, hapNum;
+    int64_t sCounter;                      /* number of samples; the tree has 2*sCounter-1 nodes */
+    /* event log (events.pxi:24-68) */
+    int64_t ev_ptr;
+    const double *ev_times;
+    const int64_t *ev_types, *ev_haplotypes, *ev_populations, *ev_newHaplotypes, *ev_newPopulations;
+    /* multievent rows (events.pxi:105-152) referenced by MULTITYPE events as [haplotypes, populations); may be NULL */
+    int64_t mev_rows;
+    const int64_t *mev_num; const double *mev_times;
+    const int64_t *mev_types, *mev_haplotypes, *mev_populations, *mev_newHaplotypes, *mev_newPopulations;
+    int64_t *infectious;                   /* [P][H], state at the end of the simulation (in/out) */
+    /* PCG64 position of the reference's self.seed: state hi, lo, increment hi, lo + numpy's buffered 32-bit half */
+    uint64_t rng_state[4];
+    int64_t rng_has_uint32;
+    uint64_t rng_uinteger;
+    /* outputs, caller-allocated */
+    int64_t *tree, *tree_pop; double *times;            /* [2*sCounter-1]: parent (-1 = root), population, time */
+    int64_t mut_cap, mut_n; int64_t *mut_node, *mut_AS, *mut_DS, *mut_site; double *mut_time;
+    int64_t mig_cap, mig_n; int64_t *mig_node, *mig_old, *mig_new; double *mig_time;
+    int64_t nodes_used;
+} vgx_genealogy_io;
+int vgx_get_genealogy(vgx_genealogy_io *io, char *errbuf, int64_t errcap);
+/* (state, inc) of PCG64(SeedSequence(seed, spawn_key=(attempt,))) after `draws` outputs: where the reference's
+ * self.seed stands when GetGenealogy(seed=None) continues the simulation's stream (pyx:766-767). */
+void vgx_rng_position(int64_t seed, int64_t attempt, int64_t draws, uint64_t out[4]);
 
 /* ---- measurement ---------------------------------------------------------------------------- */
 /* Device time of the last simulate call's kernels, from HIP events on the engine's stream (ms). */

@@ -48,6 +48,7 @@ _FIELDS = [
     ("infectiousAuxTau", _F), ("susceptibleAuxTau", _F), ("infectiousDelta", _I), ("susceptibleDelta", _I),
     ("sparse", C.c_int64), ("log_mode", C.c_int64), ("iterations_done", C.c_int64), ("error", C.c_int64),
     ("occ", _U),
+    ("rng_state_hi", C.c_uint64), ("rng_state_lo", C.c_uint64), ("rng_inc_hi", C.c_uint64), ("rng_inc_lo", C.c_uint64),
 ]
 
 
@@ -91,6 +92,10 @@ def lib():
         L.vgo_poisson.restype = C.c_int64
         L.vgo_portable_log.argtypes = [C.c_double]
         L.vgo_portable_log.restype = C.c_double
+        L.vgo_get_genealogy.argtypes = [C.POINTER(VgoGenealogy)]
+        L.vgo_get_genealogy.restype = C.c_int
+        L.vgo_hypergeometric.argtypes = [C.POINTER(VgoGenRng), C.c_int64, C.c_int64, C.c_int64]
+        L.vgo_hypergeometric.restype = C.c_int64
         _lib = L
     return _lib
 
@@ -182,6 +187,7 @@ def _absorb(model, st, m):
     for k in range(m.loc_n):
         model.loc.AddLockdown(st.loc_states[k], st.loc_populations[k], st.loc_times[k])
     st.iterations_done = m.iterations_done
+    st.rng_final = (m.rng_state_hi, m.rng_state_lo, m.rng_inc_hi, m.rng_inc_lo)
 
 
 def get_state(model):
@@ -234,6 +240,74 @@ def update_all_rates(model, sparse=False):
     lib().vgo_update_all_rates(C.byref(m))
     model.totalRate, model.totalMigrationRate = m.totalRate, m.totalMigrationRate
     return st
+
+
+class VgoGenRng(C.Structure):
+    _fields_ = [("g", VgoPcg64), ("has_uint32", C.c_int64), ("uinteger", C.c_uint64)]
+
+
+class VgoGenealogy(C.Structure):
+    _fields_ = [("popNum", C.c_int64), ("hapNum", C.c_int64), ("sCounter", C.c_int64), ("ev_ptr", C.c_int64),
+                ("ev_times", _F), ("ev_types", _I), ("ev_haplotypes", _I), ("ev_populations", _I),
+                ("ev_newHaplotypes", _I), ("ev_newPopulations", _I),
+                ("mev_num", _I), ("mev_times", _F), ("mev_types", _I), ("mev_haplotypes", _I), ("mev_populations", _I),
+                ("mev_newHaplotypes", _I), ("mev_newPopulations", _I),
+                ("infectious", _I), ("infectiousDelta", _I), ("rng", VgoGenRng),
+                ("tree", _I), ("tree_pop", _I), ("times", _F),
+                ("mut_cap", C.c_int64), ("mut_n", C.c_int64), ("mut_node", _I), ("mut_AS", _I), ("mut_DS", _I),
+                ("mut_site", _I), ("mut_time", _F),
+                ("mig_cap", C.c_int64), ("mig_n", C.c_int64), ("mig_node", _I), ("mig_old", _I), ("mig_new", _I),
+                ("mig_time", _F), ("nodes_used", C.c_int64)]
+
+
+def run_genealogy(model, seed=None):
+    """The oracle's GetGenealogy (pyx:743-1000) on a host model whose forward phases were run by this oracle.
+    ``seed=None`` continues the simulation's random stream (pyx:766-767).  Walks ``model.infectious`` back in place like
+    the reference; returns a dict with tree, tree_pop, times, mut_* and mig_* arrays."""
+    st = get_state(model)
+    ev = model.events
+    g = VgoGenealogy()
+    g.popNum, g.hapNum, g.sCounter, g.ev_ptr = model.popNum, model.hapNum, int(model.sCounter), ev.ptr
+    g.ev_times, g.ev_types, g.ev_haplotypes = _ptr(ev.times), _ptr(ev.types), _ptr(ev.haplotypes)
+    g.ev_populations, g.ev_newHaplotypes, g.ev_newPopulations = _ptr(ev.populations), _ptr(ev.newHaplotypes), _ptr(ev.newPopulations)
+    n_mut = int((ev.types[:ev.ptr] == 3).sum())
+    n_mig = int((ev.types[:ev.ptr] == 5).sum())
+    if st.mev is not None:
+        mv = st.mev
+        g.mev_num, g.mev_times, g.mev_types = _ptr(mv["num"]), _ptr(mv["times"]), _ptr(mv["types"])
+        g.mev_haplotypes, g.mev_populations = _ptr(mv["haplotypes"]), _ptr(mv["populations"])
+        g.mev_newHaplotypes, g.mev_newPopulations = _ptr(mv["newHaplotypes"]), _ptr(mv["newPopulations"])
+        n_mut += int(mv["num"][:st.mev_ptr][mv["types"][:st.mev_ptr] == 3].sum())
+        n_mig += int(mv["num"][:st.mev_ptr][mv["types"][:st.mev_ptr] == 5].sum())
+    assert model.infectious.flags["C_CONTIGUOUS"]
+    g.infectious, g.infectiousDelta = _ptr(model.infectious), _ptr(st.infectiousDelta)
+    if seed is None:
+        g.rng.g.state_hi, g.rng.g.state_lo, g.rng.g.inc_hi, g.rng.g.inc_lo = st.rng_final
+    else:
+        lib().vgo_pcg64_seed(C.byref(g.rng.g), int(seed), 0)
+    nodes = 2 * int(model.sCounter) - 1
+    out = {"tree": np.zeros(max(nodes, 1), dtype=np.int64), "tree_pop": np.zeros(max(nodes, 1), dtype=np.int64),
+           "times": np.zeros(max(nodes, 1))}
+    g.tree, g.tree_pop, g.times = _ptr(out["tree"]), _ptr(out["tree_pop"]), _ptr(out["times"])
+    g.mut_cap, g.mig_cap = n_mut + 1, n_mig + nodes + 1
+    for k in ("mut_node", "mut_AS", "mut_DS", "mut_site"):
+        out[k] = np.zeros(g.mut_cap, dtype=np.int64)
+        setattr(g, k, _ptr(out[k]))
+    out["mut_time"] = np.zeros(g.mut_cap)
+    g.mut_time = _ptr(out["mut_time"])
+    for k in ("mig_node", "mig_old", "mig_new"):
+        out[k] = np.zeros(g.mig_cap, dtype=np.int64)
+        setattr(g, k, _ptr(out[k]))
+    out["mig_time"] = np.zeros(g.mig_cap)
+    g.mig_time = _ptr(out["mig_time"])
+    rc = lib().vgo_get_genealogy(C.byref(g))
+    for k in list(out):
+        if k.startswith("mut_"):
+            out[k] = out[k][:g.mut_n]
+        elif k.startswith("mig_"):
+            out[k] = out[k][:g.mig_n]
+    out["rc"], out["nodes_used"] = rc, g.nodes_used
+    return out
 
 
 def pcg64_stream(seed, attempt, n):

@@ -798,6 +798,7 @@ int vgo_simulate_direct(vgo_model *m, int64_t iterations, int64_t sample_size, f
             break;
         }
     }
+    m->rng_state_hi = r.g.state_hi; m->rng_state_lo = r.g.state_lo; m->rng_inc_hi = r.g.inc_hi; m->rng_inc_lo = r.g.inc_lo;
     return (int)m->error;
 }
 
@@ -1084,5 +1085,6 @@ out:
     free(A.pMigr); free(A.eMigr); free(A.pSuscep); free(A.eSuscep); free(A.pRec); free(A.eRec);
     free(A.pSamp); free(A.eSamp); free(A.pMut); free(A.eMut); free(A.pTrans); free(A.eTrans);
     m->sparse = sparse_saved;
+    m->rng_state_hi = r.g.state_hi; m->rng_state_lo = r.g.state_lo; m->rng_inc_hi = r.g.inc_hi; m->rng_inc_lo = r.g.inc_lo;
     return (int)m->error;
 }

@@ -95,6 +95,8 @@ typedef struct vgo_model {
     int64_t iterations_done; /* loop iterations incl. rejected migrations (diagnostic) */
     int64_t error;
     uint64_t *occ;      /* [P][ceil(H/64)] occupancy bitmap, used when sparse (caller allocates) */
+    /* PCG64 (state, inc) of self.seed when the simulate call returns: GetGenealogy(seed=None) draws on from here */
+    uint64_t rng_state_hi, rng_state_lo, rng_inc_hi, rng_inc_lo;
 } vgo_model;
 
 /* pyx:396-429.  `time` is a C float exactly as in the reference signature. */
@@ -114,6 +116,28 @@ uint64_t vgo_pcg64_next64(vgo_pcg64 *g);
 void vgo_pcg64_advance(vgo_pcg64 *g, uint64_t delta_hi, uint64_t delta_lo);
 int64_t vgo_poisson(vgo_pcg64 *g, double lam); /* numpy random_poisson restated */
 double vgo_portable_log(double x);
+
+/* ---- backward pass: GetGenealogy (pyx:743-1000), vgx_oracle_genealogy.c ---- */
+typedef struct { vgo_pcg64 g; int64_t has_uint32; uint64_t uinteger; } vgo_gen_rng; /* numpy bitgen front end on PCG64 */
+int64_t vgo_hypergeometric(vgo_gen_rng *r, int64_t good, int64_t bad, int64_t sample); /* numpy random_hypergeometric */
+typedef struct vgo_genealogy {
+    int64_t popNum, hapNum, sCounter;
+    /* event chain (ev:24-68) and, for MULTITYPE events, the multievent rows they refer to (ev:105-152) */
+    int64_t ev_ptr;
+    const double *ev_times;
+    const int64_t *ev_types, *ev_haplotypes, *ev_populations, *ev_newHaplotypes, *ev_newPopulations;
+    const int64_t *mev_num; const double *mev_times;
+    const int64_t *mev_types, *mev_haplotypes, *mev_populations, *mev_newHaplotypes, *mev_newPopulations;
+    int64_t *infectious;       /* [P][H] state at the end of the simulation; walked back in place like upstream */
+    int64_t *infectiousDelta;  /* [P][H] scratch */
+    vgo_gen_rng rng;           /* in: stream position; out: position after the pass */
+    /* outputs, caller-allocated */
+    int64_t *tree, *tree_pop; double *times;           /* [2*sCounter-1] */
+    int64_t mut_cap, mut_n; int64_t *mut_node, *mut_AS, *mut_DS, *mut_site; double *mut_time;
+    int64_t mig_cap, mig_n; int64_t *mig_node, *mig_old, *mig_new; double *mig_time;
+    int64_t nodes_used;
+} vgo_genealogy;
+int vgo_get_genealogy(vgo_genealogy *G);
 
 #ifdef __cplusplus
 }

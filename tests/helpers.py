@@ -38,7 +38,7 @@ def libm_matches_fixture_host():
 _LIBM_OK = None
 
 
-def run_case_oracle(oracle, name, sparse=False, log_mode=0):
+def run_case_oracle(oracle, name, sparse=False, log_mode=0, record_multievents=False):
     """Drive a case of tests/models.py through this repo's Simulator object + the CPU oracle."""
     from vgsim_amd import Simulator
     with quiet():
@@ -56,7 +56,7 @@ def run_case_oracle(oracle, name, sparse=False, log_mode=0):
         if method == "direct":
             rc = oracle.run_direct(m, it, ss, tm, at, sparse=sparse, log_mode=log_mode)
         else:
-            rc = oracle.run_tau(m, it, ss, tm, at, log_mode=log_mode)
+            rc = oracle.run_tau(m, it, ss, tm, at, record_multievents=record_multievents, log_mode=log_mode)
         assert rc == 0, "oracle error code %d" % rc
     return sim
 

@@ -49,6 +49,20 @@ class VgxCounters(C.Structure):
                 ("multievent_rows", C.c_int64), ("reserved", C.c_int64 * 5)]
 
 
+class VgxGenealogyIO(C.Structure):
+    _fields_ = [("popNum", C.c_int64), ("hapNum", C.c_int64), ("sCounter", C.c_int64), ("ev_ptr", C.c_int64),
+                ("ev_times", _F), ("ev_types", _I), ("ev_haplotypes", _I), ("ev_populations", _I),
+                ("ev_newHaplotypes", _I), ("ev_newPopulations", _I),
+                ("mev_rows", C.c_int64), ("mev_num", _I), ("mev_times", _F), ("mev_types", _I), ("mev_haplotypes", _I),
+                ("mev_populations", _I), ("mev_newHaplotypes", _I), ("mev_newPopulations", _I),
+                ("infectious", _I), ("rng_state", C.c_uint64 * 4), ("rng_has_uint32", C.c_int64), ("rng_uinteger", C.c_uint64),
+                ("tree", _I), ("tree_pop", _I), ("times", _F),
+                ("mut_cap", C.c_int64), ("mut_n", C.c_int64), ("mut_node", _I), ("mut_AS", _I), ("mut_DS", _I),
+                ("mut_site", _I), ("mut_time", _F),
+                ("mig_cap", C.c_int64), ("mig_n", C.c_int64), ("mig_node", _I), ("mig_old", _I), ("mig_new", _I),
+                ("mig_time", _F), ("nodes_used", C.c_int64)]
+
+
 # every entry point include/vgx.h declares: (restype, argtypes)
 _H = C.c_void_p
 SIGNATURES = {
@@ -71,6 +85,8 @@ SIGNATURES = {
     "vgx_last_kernel_launches": (C.c_int64, [_H]),
     "vgx_device_bytes": (C.c_int64, [_H]),
     "vgx_get_profile": (C.c_int, [_H, C.c_int64, _I]),
+    "vgx_get_genealogy": (C.c_int, [C.POINTER(VgxGenealogyIO), C.c_char_p, C.c_int64]),
+    "vgx_rng_position": (None, [C.c_int64, C.c_int64, C.c_int64, C.POINTER(C.c_uint64 * 4)]),
 }
 
 _lib = None
@@ -248,6 +264,8 @@ class HipEngine:
         m.events.ptr = c.ev_ptr
         if tau:
             rows = self.multievents(replicate)
+            rows = canonical_multievents(rows, m.events.haplotypes[first:c.ev_ptr], m.events.populations[first:c.ev_ptr],
+                                         m.sites, m.susNum)
             if c.restarts > 0:  # Restart rewinds multievents.ptr too (pyx:716)
                 m.multievents.ptr = 0
                 mev_base = 0
@@ -268,3 +286,119 @@ class HipEngine:
     @property
     def device_bytes(self):
         return self.lib.vgx_device_bytes(self.handle)
+
+
+def canonical_multievents(rows, starts, ends, sites, susNum):
+    """Rows of one tau call in the reference's order and granularity.  The device appends a step's rows in whatever
+    order its threads get there (and one row per drawn transmission / mutant / migrant); the reference writes one row
+    per channel in a fixed order (UpdateCompartmentCounts_tau, pyx:2540-2593: all migrations by (source, target,
+    group, haplotype); then per population the immunity transitions, then per haplotype recovery, sampling, mutations
+    by (site, derived state), transmissions by group).  Sorting each step's rows by that key and merging equal channels
+    gives the reference's rows with ``num > 0`` — what the backward pass (pyx:873-994) walks — independent of
+    scheduling.  ``starts`` / ``ends`` (the MULTITYPE events' row ranges, relative to this call) are updated in place."""
+    n = len(rows["times"])
+    if n == 0:
+        return rows
+    num, typ, hap = rows["num"], rows["types"], rows["haplotypes"]
+    pop, nh, npop = rows["populations"], rows["newHaplotypes"], rows["newPopulations"]
+    step = np.searchsorted(np.asarray(ends), np.arange(n), side="right")
+    mig = typ == 5
+    k1 = np.where(mig, 0, 1)
+    k2 = pop.copy()                                  # source population / population
+    k3 = np.where(mig, npop, np.where(typ == 4, 0, 1))
+    k4 = np.where(mig, nh, hap)                      # migration: group; else source group / haplotype
+    k5 = np.zeros(n, dtype=np.int64)
+    k5[mig] = hap[mig]
+    k5[typ == 4] = nh[typ == 4]
+    k5[typ == 1] = 0
+    k5[typ == 2] = 1
+    mu = typ == 3
+    if mu.any():
+        d = np.abs(nh[mu] - hap[mu])
+        low = np.zeros(d.shape, dtype=np.int64)      # digit position from the least significant end
+        t = d.copy()
+        while (t >= 4).any():
+            big = t >= 4
+            t[big] //= 4
+            low[big] += 1
+        digit4 = 4 ** low
+        AS, DS = (hap[mu] // digit4) % 4, (nh[mu] // digit4) % 4
+        k5[mu] = 2 + (sites - 1 - low) * 3 + np.where(DS > AS, DS - 1, DS)
+    k5[typ == 0] = 2 + 3 * sites + nh[typ == 0]
+    order = np.lexsort((k5, k4, k3, k2, k1, step))
+    key = np.stack([step, k1, k2, k3, k4, k5])[:, order]
+    first = np.ones(n, dtype=bool)
+    first[1:] = (key[:, 1:] != key[:, :-1]).any(axis=0)
+    idx = np.nonzero(first)[0]
+    out = {c: rows[c][order][idx] for c in ("types", "haplotypes", "populations", "newHaplotypes", "newPopulations")}
+    out["num"] = np.add.reduceat(num[order], idx)
+    out["times"] = rows["times"][order][idx]
+    per_step = np.bincount(key[0, idx], minlength=len(starts))
+    e = np.cumsum(per_step)
+    starts[:] = e - per_step
+    ends[:] = e
+    return out
+
+
+def get_genealogy(m, seed=None, rng_position=None, rng_raw=None):
+    """``BirthDeathModel.GetGenealogy(seed)`` (pyx:743-1000) on a host model: the backward pass over ``m.events`` (and
+    ``m.multievents`` for tau chains) in libvgx's host code.  ``seed``: reseeds the stream as the reference does
+    (``RndmWrapper(seed=(seed, 0))``, pyx:766-767); ``None`` continues from ``rng_position`` = (attempt, draws) of the
+    simulation's stream, or from ``rng_raw`` = the raw generator state a previous pass returned (``out["rng_raw"]``).
+    Walks ``m.infectious`` back in place; returns a dict of arrays."""
+    lib = load_library()
+    ev, mv = m.events, m.multievents
+    io = VgxGenealogyIO()
+    io.popNum, io.hapNum, io.sCounter, io.ev_ptr = m.popNum, m.hapNum, int(m.sCounter), int(ev.ptr)
+    io.ev_times, io.ev_types, io.ev_haplotypes = _p(ev.times), _p(ev.types), _p(ev.haplotypes)
+    io.ev_populations, io.ev_newHaplotypes, io.ev_newPopulations = _p(ev.populations), _p(ev.newHaplotypes), _p(ev.newPopulations)
+    types = ev.types[:ev.ptr]
+    n_mut, n_mig = int((types == 3).sum()), int((types == 5).sum())
+    if mv.ptr > 0:
+        io.mev_rows = int(mv.ptr)
+        io.mev_num, io.mev_times, io.mev_types = _p(mv.num), _p(mv.times), _p(mv.types)
+        io.mev_haplotypes, io.mev_populations = _p(mv.haplotypes), _p(mv.populations)
+        io.mev_newHaplotypes, io.mev_newPopulations = _p(mv.newHaplotypes), _p(mv.newPopulations)
+        n_mut += int(mv.num[:mv.ptr][mv.types[:mv.ptr] == 3].sum())
+        n_mig += int(mv.num[:mv.ptr][mv.types[:mv.ptr] == 5].sum())
+    if not m.infectious.flags["C_CONTIGUOUS"]:
+        raise ValueError("infectious must be C-contiguous")
+    io.infectious = _p(m.infectious)
+    pos = (C.c_uint64 * 4)()
+    if seed is not None:
+        lib.vgx_rng_position(int(seed), 0, 0, C.byref(pos))
+    elif rng_raw is not None:
+        for i in range(4):
+            pos[i] = rng_raw[i]
+        io.rng_has_uint32, io.rng_uinteger = int(rng_raw[4]), int(rng_raw[5])
+    else:
+        att, draws = rng_position if rng_position is not None else (0, 0)
+        lib.vgx_rng_position(int(m.user_seed), int(att), int(draws), C.byref(pos))
+    for i in range(4):
+        io.rng_state[i] = pos[i]
+    nodes = max(2 * int(m.sCounter) - 1, 1)
+    out = {"tree": np.zeros(nodes, dtype=np.int64), "tree_pop": np.zeros(nodes, dtype=np.int64), "times": np.zeros(nodes)}
+    io.tree, io.tree_pop, io.times = _p(out["tree"]), _p(out["tree_pop"]), _p(out["times"])
+    io.mut_cap, io.mig_cap = n_mut + 1, n_mig + nodes + 1
+    for k in ("mut_node", "mut_AS", "mut_DS", "mut_site"):
+        out[k] = np.zeros(io.mut_cap, dtype=np.int64)
+        setattr(io, k, _p(out[k]))
+    out["mut_time"] = np.zeros(io.mut_cap)
+    io.mut_time = _p(out["mut_time"])
+    for k in ("mig_node", "mig_old", "mig_new"):
+        out[k] = np.zeros(io.mig_cap, dtype=np.int64)
+        setattr(io, k, _p(out[k]))
+    out["mig_time"] = np.zeros(io.mig_cap)
+    io.mig_time = _p(out["mig_time"])
+    err = C.create_string_buffer(512)
+    rc = lib.vgx_get_genealogy(C.byref(io), err, 512)
+    if rc != 0:
+        raise RuntimeError(err.value.decode() or "vgx_get_genealogy failed (%d)" % rc)
+    for k in list(out):
+        if k.startswith("mut_"):
+            out[k] = out[k][:io.mut_n]
+        elif k.startswith("mig_"):
+            out[k] = out[k][:io.mig_n]
+    out["nodes_used"] = int(io.nodes_used)
+    out["rng_raw"] = tuple(int(io.rng_state[i]) for i in range(4)) + (int(io.rng_has_uint32), int(io.rng_uinteger))
+    return out

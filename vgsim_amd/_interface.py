@@ -136,6 +136,27 @@ class Simulator:
     def genealogy(self, seed=None):
         self.simulation.GetGenealogy(seed)
 
+    def get_tree(self):
+        return self.simulation.get_tree()
+
+    def output_sample_data(self, output_print=False):  # if:536-553 (prints when output_print is False, as upstream)
+        time, pop, hap = self.simulation.output_sample_data()
+        if output_print:
+            return time, pop, hap
+        else:
+            print(time)
+            print(pop)
+            print(hap)
+
+    def export_migrations(self, file_template=None, file_path=None):  # if:524-534
+        self.simulation.export_migrations(file_template, file_path)
+
+    def print_mutations(self):
+        self.simulation.print_mutations()
+
+    def print_migrations(self):
+        self.simulation.print_migrations()
+
     def export_chain_events(self, file_name="chain_events"):
         self.simulation.export_chain_events(file_name)
 

@@ -88,6 +88,26 @@ class Lockdowns:
         self.times.append(float(time))
 
 
+class Mutations:
+    """models.pxi:1-32 (filled by the backward pass)."""
+
+    def __init__(self):
+        self.nodeId, self.AS, self.DS, self.site, self.time = [], [], [], [], []
+
+    def get_mutation(self, id_mut):
+        return self.nodeId[id_mut], self.DS[id_mut], self.AS[id_mut], self.site[id_mut], self.time[id_mut]
+
+
+class Migrations:
+    """models.pxi:35-51."""
+
+    def __init__(self):
+        self.nodeId, self.time, self.oldPop, self.newPop = [], [], [], []
+
+    def get_migration(self, id_mig):
+        return self.nodeId[id_mig], self.time[id_mig], self.oldPop[id_mig], self.newPop[id_mig]
+
+
 class BirthDeathModel:
     COUNTERS = ("bCounter", "dCounter", "sCounter", "mCounter", "iCounter", "swapLockdown", "migPlus",
                 "migNonPlus")
@@ -180,6 +200,13 @@ class BirthDeathModel:
         self.migrationRates = np.zeros((P, P), dtype=float)
 
         self._engine = None  # HIP engine handle, created lazily at the first simulate call
+        # backward pass (pyx:770-774 allocates the real arrays; a 1-element tree means "not simulated", pyx:1950)
+        self.tree = np.zeros(1, dtype=np.int64)
+        self.tree_pop = np.zeros(1, dtype=np.int64)
+        self.times = np.zeros(1, dtype=float)
+        self.mut, self.mig = Mutations(), Migrations()
+        self._rng_position = None   # (attempt, uniforms drawn) of the last direct simulate call's random stream
+        self._rng_raw = None        # raw generator state after the last genealogy pass
 
     # ------------------------------------------------------------------ haplotype patterns (pyx:1187-1267)
     def calculate_indexes(self, indexes_list, edge):
@@ -680,7 +707,11 @@ class BirthDeathModel:
             opts = _capi.VgxRunOpts()
             opts.record_events = 1
             opts.mode = 1
-        self._get_engine().simulate_direct(self, iterations, sample_size, time, attempts, opts)
+        eng = self._get_engine()
+        eng.simulate_direct(self, iterations, sample_size, time, attempts, opts)
+        c = eng.last_counters
+        self._rng_position = (int(c.reserved[1]), 2 * int(c.reserved[2])) if c.reserved[1] >= 0 else None
+        self._rng_raw = None
         self._print_termination(sample_size, time)
 
     def SimulatePopulation_tau(self, iterations, sample_size, time, attempts):
@@ -691,6 +722,7 @@ class BirthDeathModel:
         self.CheckSizes()
         time = float(np.float32(time))
         self._get_engine().simulate_tau(self, iterations, sample_size, time, attempts)
+        self._rng_position, self._rng_raw = None, None
         self._print_termination(sample_size, time)
 
     # ------------------------------------------------------------------ reporting (pyx:2048-2068, 2284, 2607-2613, 1849-1851)
@@ -725,6 +757,67 @@ class BirthDeathModel:
     def export_chain_events(self, name_file):
         np.save(name_file, self.events.as_array())
 
+    # ------------------------------------------------------------------ backward pass (pyx:743-1000, models.pxi:1-48)
     def GetGenealogy(self, seed):
-        raise NotImplementedError('GetGenealogy (pyx:743-1000) consumes the event log this engine produces but is '
-                                  'outside the accelerated path (SURVEY.md §8f rank 1).')
+        """pyx:743-1000: coalesces the sampled lineages backwards over the event log (libvgx host code,
+        ``vgx_get_genealogy``).  ``seed`` reseeds the random stream like the reference (``RndmWrapper(seed=(seed, 0))``);
+        ``None`` continues the stream of the last direct ``simulate`` call (after a tau call, whose device stream is
+        Philox, it starts at the beginning of stream ``(user_seed, 0)``)."""
+        if self.sCounter < 2:
+            print("Less than two cases were sampled...")
+            print("_________________________________")
+            sys.exit(0)
+        from . import _capi
+        out = _capi.get_genealogy(self, seed, rng_position=self._rng_position,
+                                  rng_raw=self._rng_raw if seed is None else None)
+        self._rng_raw = out["rng_raw"]
+        self.tree, self.tree_pop, self.times = out["tree"], out["tree_pop"], out["times"]
+        self.mut, self.mig = Mutations(), Migrations()
+        self.mut.nodeId, self.mut.AS, self.mut.DS = out["mut_node"].tolist(), out["mut_AS"].tolist(), out["mut_DS"].tolist()
+        self.mut.site, self.mut.time = out["mut_site"].tolist(), out["mut_time"].tolist()
+        self.mig.nodeId, self.mig.time = out["mig_node"].tolist(), out["mig_time"].tolist()
+        self.mig.oldPop, self.mig.newPop = out["mig_old"].tolist(), out["mig_new"].tolist()
+
+    def _need_tree(self):
+        if self.tree.shape[0] == 1:
+            print('Genealogy was not simulated. Use VGsim.genealogy() method to simulate it.')
+            sys.exit(1)
+
+    def get_tree(self):  # pyx:1949-1953
+        self._need_tree()
+        return self.tree, self.times
+
+    def output_tree_mutations(self):  # pyx:1725-1742
+        self._need_tree()
+        mut = [list(self.mut.nodeId), list(self.mut.AS), list(self.mut.site), list(self.mut.DS), list(self.mut.time)]
+        times_dict = {self.events.times[i]: i for i in range(len(self.events.times))}
+        populations = {}
+        for time in self.times:
+            populations[time] = self.events.populations[times_dict[time]]
+        return self.tree, self.times, mut, populations
+
+    def export_migrations(self, name_file, file_path):  # pyx:1744-1754
+        self._need_tree()
+        path = (file_path + '/' + name_file + '.tsv') if file_path is not None else (name_file + '.tsv')
+        with open(path, 'w') as f_mig:
+            f_mig.write("Node\tTime\tOld_population\tNew_population\n")
+            for i in range(len(self.mig.nodeId)):
+                f_mig.write(str(self.mig.nodeId[i]) + '\t' + str(self.mig.time[i]) + '\t' + str(self.mig.oldPop[i]) + '\t' +
+                            str(self.mig.newPop[i]) + "\n")
+
+    def output_sample_data(self):  # pyx:1756-1763
+        time, pop, hap = [], [], []
+        for i in range(self.events.ptr):
+            if self.events.types[i] == SAMPLING:
+                time.append(self.events.times[i])
+                pop.append(self.events.populations[i])
+                hap.append(self.events.haplotypes[i])
+        return time, pop, hap
+
+    def print_mutations(self):  # pyx:1177-1179
+        for i in range(len(self.mut.nodeId)):
+            print(self.mut.get_mutation(i))
+
+    def print_migrations(self):  # pyx:1182-1184
+        for i in range(len(self.mig.nodeId)):
+            print(self.mig.get_migration(i))

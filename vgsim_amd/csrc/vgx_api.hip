@@ -1043,6 +1043,8 @@ extern "C" int vgx_get_counters(vgx_engine *e, int64_t replicate, vgx_counters *
     out->lockdown_records = s.loc_n;
     out->error = s.error;
     out->multievent_rows = s.mev_rows;
+    if (!e->last_was_tau) { out->reserved[1] = s.last_attempt; out->reserved[2] = s.last_attempt_loops; }
+    else out->reserved[1] = -1;
     return VGX_OK;
 }
 

@@ -57,7 +57,9 @@ struct VgxRepScalars {
     int64_t error;
     int64_t mev_rows;
     int64_t traj_next;       // next trajectory grid point to emit
-    int64_t pad[3];
+    int64_t last_attempt;        // index of the last attempt that drew random numbers (-1: none)
+    int64_t last_attempt_loops;  // loop iterations of that attempt (2 uniforms each)
+    int64_t pad[1];
 };
 
 struct VgxDevRep {

@@ -1189,6 +1189,7 @@ static __device__ __forceinline__ void direct_body(const VgxDirectArgs &a) {
     const bool has_tlimit = !(a.time == -1.0f);
     const int64_t seed = r.seeds[rep];
     int64_t loops = 0, restarts = 0, good_attempt = sc->good_attempt;
+    int64_t last_att = -1, last_att_loops = 0;
     int64_t att = 0;
     RngBatch g;
     rng_init_lane(g, lane);
@@ -1227,6 +1228,7 @@ static __device__ __forceinline__ void direct_body(const VgxDirectArgs &a) {
                 if (att >= a.attempts) { finished = true; continue; }
                 rng_seed(g, (uint64_t)seed, (uint32_t)att);
                 attempt_open = true;
+                last_att = att; last_att_loops = 0;
                 if (!(c.totalRate + c.totalMig != 0.0 && c.gI != 0)) end_attempt = true;  // pyx:404
             }
             if (!end_attempt && !(c.ev_ptr < c.ev_size && (a.sample_size == -1 || c.cnt[CNT_S] <= a.sample_size) &&
@@ -1235,6 +1237,7 @@ static __device__ __forceinline__ void direct_body(const VgxDirectArgs &a) {
             if (!end_attempt) {
                 if (loops >= a.max_loop) { c.error = ERR_LOOP_GUARD; continue; }
                 loops += 1;
+                last_att_loops += 1;
                 if (g.pos == 32) rng_refill(g, lane);
                 double nlog = bcast(g.val, 2 * g.pos), u2 = bcast(g.val, 2 * g.pos + 1);
                 g.pos += 1;
@@ -1317,6 +1320,7 @@ static __device__ __forceinline__ void direct_body(const VgxDirectArgs &a) {
         sc->good_attempt = good_attempt;
         sc->ev_ptr = c.ev_ptr; sc->loop_iterations = loops; sc->restarts = restarts;
         sc->loc_n = c.loc_n; sc->error = c.error; sc->traj_next = c.traj_next;
+        sc->last_attempt = last_att; sc->last_attempt_loops = last_att_loops;
     }
 }
 
