@@ -148,3 +148,19 @@ def assert_models_equal(got, want, what=""):
     assert np.array_equal(got.contactDensity, want.contactDensity), what + " contactDensity"
     assert got.loc.states == want.loc.states and got.loc.populationsId == want.loc.populationsId, what + " lockdown log"
     assert got.loc.times == want.loc.times, what + " lockdown times"
+
+
+def sparse_multievents(m, st):
+    """Give a host model driven by the oracle the engine's multievent layout (rows with num > 0 only; MULTITYPE
+    events carry [start, end) of their rows) derived from the oracle's dense reference layout."""
+    if st.mev is None:
+        return
+    mv, n = st.mev, st.mev_ptr
+    keep = np.nonzero(mv["num"][:n] > 0)[0]
+    newpos = np.concatenate(([0], np.cumsum(mv["num"][:n] > 0)))
+    ev = m.events
+    multi = np.nonzero(ev.types[:ev.ptr] == 6)[0]
+    ev.haplotypes[multi] = newpos[ev.haplotypes[multi]]
+    ev.populations[multi] = newpos[ev.populations[multi]]
+    m.multievents.ptr = 0
+    m.multievents.extend(mv["times"][keep], **{k: mv[k][keep] for k in m.multievents.COLUMNS})

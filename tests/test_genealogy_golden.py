@@ -52,22 +52,6 @@ def _product_genealogy(m, seed, rng_raw=None):
     return _capi.get_genealogy(m, seed, rng_raw=rng_raw)
 
 
-def _sparse_multievents(m, st):
-    """The engine's multievent layout (rows with num > 0 only, MULTITYPE events carry [start, end) of their rows)
-    derived from the oracle's dense reference layout."""
-    if st.mev is None:
-        return
-    mv, n = st.mev, st.mev_ptr
-    keep = np.nonzero(mv["num"][:n] > 0)[0]
-    newpos = np.concatenate(([0], np.cumsum(mv["num"][:n] > 0)))
-    ev = m.events
-    multi = np.nonzero(ev.types[:ev.ptr] == 6)[0]
-    ev.haplotypes[multi] = newpos[ev.haplotypes[multi]]
-    ev.populations[multi] = newpos[ev.populations[multi]]
-    m.multievents.ptr = 0
-    m.multievents.extend(mv["times"][keep], **{k: mv[k][keep] for k in m.multievents.COLUMNS})
-
-
 @pytest.mark.parametrize("path", GOLD, ids=[os.path.basename(p)[10:-4] for p in GOLD])
 def test_product_genealogy_matches_reference(oracle_mod, path):
     """The shipped backward pass (libvgx host code, called through the C ABI; needs no GPU) on the same chains."""
@@ -75,7 +59,7 @@ def test_product_genealogy_matches_reference(oracle_mod, path):
     sim = helpers.run_case_oracle(oracle_mod, meta["case"], record_multievents=True)
     m = sim.simulation
     st = oracle_mod.get_state(m)
-    _sparse_multievents(m, st)
+    helpers.sparse_multievents(m, st)
     raw = None
     if meta["genealogy_seed"] is None:   # continue where the forward run's generator stands
         raw = tuple(st.rng_final) + (0, 0)

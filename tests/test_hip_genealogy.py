@@ -64,3 +64,31 @@ def test_tau_pipeline_structure_and_reproducibility(name):
         runs.append((m.tree.copy(), m.times.copy(), list(m.mut.nodeId), list(m.mig.nodeId), mv.num[:mv.ptr].copy()))
     for a, b in zip(runs[0], runs[1]):
         assert np.array_equal(a, b)
+
+
+def test_ensemble_replicate_genealogy_equals_single_run():
+    """Genealogy of replicate r of an ensemble == genealogy of a single run with that replicate's seed."""
+    from vgsim_amd import Simulator
+    from vgsim_amd.ensemble import Ensemble
+    import models
+    with helpers.quiet():
+        sim, phases = models.build(Simulator, "c3_s5_p16")
+        phases[0][0](sim)
+    R = 8
+    ens = Ensemble(sim, R, seeds=np.arange(500, 500 + R))
+    ens.simulate(6000, sample_size=10 ** 9, record_events=True)
+    for r in (0, 5):
+        with helpers.quiet():
+            one, ph = models.build(Simulator, "c3_s5_p16")
+            ph[0][0](one)
+            one.simulation.user_seed = 500 + r
+            one.simulate(6000, sample_size=10 ** 9)
+        if one.simulation.sCounter < 2:
+            continue
+        for gseed in (None, 31):
+            got = ens.genealogy(r, gseed)
+            with helpers.quiet():
+                one.genealogy(gseed)
+            assert np.array_equal(got["tree"], one.simulation.tree) and np.array_equal(got["times"], one.simulation.times)
+            break   # the single-run model's infectious array has been walked back: one pass per model
+    ens.close()

@@ -139,6 +139,12 @@ class Simulator:
     def get_tree(self):
         return self.simulation.get_tree()
 
+    def get_data_susceptible(self, population, susceptibility_type, step_num):  # if:599-617
+        return self.simulation.get_data_susceptible(population, susceptibility_type, step_num)
+
+    def get_data_infectious(self, population, haplotype, step_num):  # if:619-637
+        return self.simulation.get_data_infectious(population, haplotype, step_num)
+
     def output_sample_data(self, output_print=False):  # if:536-553 (prints when output_print is False, as upstream)
         time, pop, hap = self.simulation.output_sample_data()
         if output_print:

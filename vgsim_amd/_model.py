@@ -814,6 +814,83 @@ class BirthDeathModel:
                 hap.append(self.events.haplotypes[i])
         return time, pop, hap
 
+    # ------------------------------------------------------------------ log replays (pyx:1967-2045)
+    def _replay(self, step_num, delta_of, sample_of=None, start=0.0):
+        """Shared engine of get_data_infectious / get_data_susceptible: the reference walks the log once per query in
+        interpreted loops; here every event's bin is found with one searchsorted and the per-bin sums with bincount.
+        Bins the walk never reaches stay 0 exactly as upstream (Data[point+1] is only written when `point` advances)."""
+        ev, mv = self.events, self.multievents
+        n = ev.ptr
+        time_points = [i * self.currentTime / step_num for i in range(step_num + 1)]
+        tp = np.asarray(time_points, dtype=float)
+        bins = np.minimum(np.searchsorted(tp, ev.times[:n], side="left"), step_num)
+        # `point` only ever increases (a later event with a smaller time — a chain continued after a Restart — stays in
+        # the bin reached so far)
+        bins = np.maximum.accumulate(bins) if n else bins
+        cols = {k: getattr(ev, k)[:n] for k in ("types", "haplotypes", "populations", "newHaplotypes", "newPopulations")}
+        d = delta_of(cols, np.ones(n, dtype=np.int64)).astype(float)
+        data = np.bincount(bins, weights=d, minlength=step_num + 1)
+        samp = np.bincount(bins, weights=sample_of(cols, np.ones(n, dtype=np.int64)).astype(float), minlength=step_num + 1) \
+            if sample_of else None
+        multi = np.nonzero(cols["types"] == MULTITYPE)[0]
+        if len(multi) and mv.ptr:
+            lo, hi = cols["haplotypes"][multi], cols["populations"][multi]
+            cnt = np.maximum(hi - lo, 0)
+            rows = np.repeat(lo, cnt) + (np.arange(cnt.sum()) - np.repeat(np.cumsum(cnt) - cnt, cnt))
+            rbin = np.repeat(bins[multi], cnt)
+            rc = {k: getattr(mv, k)[rows] for k in ("types", "haplotypes", "populations", "newHaplotypes", "newPopulations")}
+            rc["_rows"] = True
+            num = mv.num[rows]
+            data += np.bincount(rbin, weights=delta_of(rc, num).astype(float), minlength=step_num + 1)
+            if sample_of:
+                samp += np.bincount(rbin, weights=sample_of(rc, num).astype(float), minlength=step_num + 1)
+        last = int(bins[-1]) if n else 0
+        out = np.zeros(step_num + 1)
+        out[:last + 1] = start + np.cumsum(data[:last + 1])
+        out_s = None
+        if sample_of:
+            out_s = np.zeros(step_num + 1)
+            out_s[:last + 1] = np.cumsum(samp[:last + 1])
+        return out, out_s, time_points
+
+    def _lockdowns_of(self, pop):
+        return [[self.loc.states[i], self.loc.times[i]] for i in range(len(self.loc.times)) if self.loc.populationsId[i] == pop]
+
+    def get_data_infectious(self, pop, hap, step_num):
+        """pyx:1967-2006, including its operator precedence (pyx:1982: recoveries and samplings of every compartment
+        decrement the series)."""
+        def delta(c, num):
+            t = c["types"]
+            here = (c["populations"] == pop) & (c["haplotypes"] == hap)
+            a = (t == BIRTH) & here
+            b = ~a & ((t == DEATH) | (t == SAMPLING) | ((t == MUTATION) & here))
+            c3 = ~a & ~b & (t == MUTATION) & (c["newHaplotypes"] == hap) & (c["populations"] == pop)
+            d4 = ~a & ~b & ~c3 & (t == MIGRATION) & (c["newPopulations"] == pop) & (c["haplotypes"] == hap)
+            return num * (a.astype(np.int64) - b + c3 + d4)
+
+        def sample(c, num):
+            t = c["types"]
+            a = (t == BIRTH) & (c["populations"] == pop) & (c["haplotypes"] == hap)
+            return num * (~a & (t == SAMPLING))
+
+        data, samp, tp = self._replay(step_num, delta, sample, start=float(self.initial_infectious[pop, hap]))
+        return data, samp, tp, self._lockdowns_of(pop)
+
+    def get_data_susceptible(self, pop, sus, step_num):
+        """pyx:2008-2045."""
+        def delta(c, num):
+            t = c["types"]
+            a = (t == BIRTH) & (c["populations"] == pop) & (c["newHaplotypes"] == sus)
+            b = ~a & ((t == DEATH) | (t == SAMPLING) | (t == SUSCCHANGE)) & (c["populations"] == pop) & (c["newHaplotypes"] == sus)
+            c3 = ~a & ~b & (t == SUSCCHANGE) & (c["haplotypes"] == sus) & (c["populations"] == pop)
+            # single events test newHaplotypes == sus (pyx:2023), multievent rows haplotypes == sus (pyx:2037)
+            grp = c["haplotypes"] if c.get("_rows") else c["newHaplotypes"]
+            d4 = ~a & ~b & ~c3 & (t == MIGRATION) & (c["newPopulations"] == pop) & (grp == sus)
+            return num * (-a.astype(np.int64) + b - c3 - d4)
+
+        data, _, tp = self._replay(step_num, delta, None, start=float(self.initial_susceptible[pop, sus]))
+        return data, tp, self._lockdowns_of(pop)
+
     def print_mutations(self):  # pyx:1177-1179
         for i in range(len(self.mut.nodeId)):
             print(self.mut.get_mutation(i))

@@ -143,6 +143,24 @@ class Ensemble:
         ev.ptr = c.ev_ptr
         return ev.as_array()[:, :c.ev_ptr]
 
+    def genealogy(self, replicate, seed):
+        """Backward pass (``GetGenealogy``, pyx:743-1000) over the recorded chain of one replicate of the last direct
+        ``simulate(record_events=True)`` call; returns the dict of ``_capi.get_genealogy`` (tree, times, mut_*, mig_*)."""
+        from ._model import Events
+        m = self.replicate_state(replicate)
+        chain = self.replicate_events(replicate)
+        ev = Events()
+        ev.CreateEvents(max(chain.shape[1], 1))
+        ev.times[:chain.shape[1]] = chain[0]
+        for k, name in enumerate(("types", "haplotypes", "populations", "newHaplotypes", "newPopulations")):
+            getattr(ev, name)[:chain.shape[1]] = chain[k + 1].astype(np.int64)
+        ev.ptr = chain.shape[1]
+        m.events = ev
+        c = self.engine.counters(replicate)
+        pos = (int(c.reserved[1]), 2 * int(c.reserved[2])) if c.reserved[1] >= 0 else None
+        m.user_seed = int(self.seeds[replicate])
+        return _capi.get_genealogy(m, seed, rng_position=pos)
+
     def trajectories(self, out=None):
         """Summary trajectories of the last call, ``[R, T, P, 2]`` float64 (infectious, susceptible per population).
         ``out`` may be a CUDA torch tensor (filled on the device, no host round trip) or None (numpy)."""
