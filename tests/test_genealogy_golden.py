@@ -120,3 +120,17 @@ def test_rng_position_matches_numpy():
         out = (C.c_uint64 * 4)()
         lib.vgx_rng_position(seed, att, draws, C.byref(out))
         assert (int(out[0]) << 64 | int(out[1])) == st["state"] and (int(out[2]) << 64 | int(out[3])) == st["inc"]
+
+
+def test_chain_round_trip_feeds_the_backward_pass(oracle_mod, tmp_path):
+    """export_chain_events -> set_chain_events -> genealogy gives the tree of the original log."""
+    meta, z = load([p for p in GOLD if "c3_s5_p16_seed15" in p][0])
+    sim = helpers.run_case_oracle(oracle_mod, meta["case"])
+    sim.export_chain_events(str(tmp_path / "chain"))
+    final_inf = sim.simulation.infectious.copy()
+    sim.simulation.events.ptr = 0
+    sim.set_chain_events(str(tmp_path / "chain"))
+    assert np.array_equal(sim.simulation.infectious, final_inf)
+    sim.genealogy(15)
+    tree, times = sim.get_tree()
+    assert np.array_equal(tree, z["tree"]) and np.array_equal(times, z["times"])

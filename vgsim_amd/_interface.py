@@ -166,6 +166,9 @@ class Simulator:
     def export_chain_events(self, file_name="chain_events"):
         self.simulation.export_chain_events(file_name)
 
+    def set_chain_events(self, file_name):
+        self.simulation.set_chain_events(file_name)
+
     def get_proportion(self):
         return self.simulation.get_proportion()
 

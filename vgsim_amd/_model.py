@@ -757,6 +757,24 @@ class BirthDeathModel:
     def export_chain_events(self, name_file):
         np.save(name_file, self.events.as_array())
 
+    def set_chain_events(self, name_file):
+        """pyx:1705-1719 made to work: loads a ``(6, N)`` float64 chain written by ``export_chain_events`` into the
+        event log (upstream assigns the float rows to typed int64 views and sets ``self.ptr`` instead of
+        ``events.ptr``).  The counters a later ``genealogy()`` needs (``sCounter``) are recounted from the chain."""
+        tokens = np.load(name_file + '.npy')
+        if tokens.ndim != 2 or tokens.shape[0] != 6:
+            raise ValueError('Incorrect chain of events: a (6, N) array is expected.')
+        n = tokens.shape[1]
+        while n > 0 and not tokens[:, n - 1].any():   # unused capacity of the exporting log (events.size > events.ptr)
+            n -= 1
+        self.events = Events()
+        self.events.CreateEvents(max(n, 1))
+        self.events.times[:n] = tokens[0, :n]
+        for k, name in enumerate(("types", "haplotypes", "populations", "newHaplotypes", "newPopulations")):
+            getattr(self.events, name)[:n] = tokens[k + 1, :n].astype(np.int64)
+        self.events.ptr = n
+        self.sCounter = int((self.events.types[:n] == SAMPLING).sum())
+
     # ------------------------------------------------------------------ backward pass (pyx:743-1000, models.pxi:1-48)
     def GetGenealogy(self, seed):
         """pyx:743-1000: coalesces the sampled lineages backwards over the event log (libvgx host code,
