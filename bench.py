@@ -70,9 +70,21 @@ def cpu_baseline(seconds_target=45.0):
     oracle.run_direct(m, n2, 10 ** 12, -1, 200)       # continues the same trajectory
     t3 = time.time()
     done = m.events.ptr - n1
-    return {"value": done / max(t3 - t2, 1e-9), "unit": "events/s", "cores": 1, "kind": "port",
-            "sample": "%d events of one config-3 trajectory (seed 2020) after a %d-event start, oracle in the "
-                      "reference's dense mode, %.1f s" % (done, n1, t3 - t2)}
+    out = {"value": done / max(t3 - t2, 1e-9), "unit": "events/s", "cores": 1, "kind": "port",
+           "sample": "%d events of one config-3 trajectory (seed 2020) after a %d-event start, oracle in the "
+                     "reference's dense mode, %.1f s" % (done, n1, t3 - t2)}
+    # backward pass (GetGenealogy) of the oracle on a 300 000-event chain of the same model (forward run in the oracle's
+    # occupied-haplotypes-only mode, which is bit-identical to the dense one)
+    sim2 = make_simulator(2020)
+    m2 = sim2.simulation
+    oracle.run_direct(m2, 300000, 10 ** 12, -1, 200, sparse=True)
+    if m2.sCounter >= 2:
+        t4 = time.time()
+        oracle.run_genealogy(m2, 7)
+        t5 = time.time()
+        out["genealogy"] = {"value": m2.events.ptr / max(t5 - t4, 1e-9), "unit": "events/s", "events": int(m2.events.ptr),
+                            "samples": int(m2.sCounter), "seconds": t5 - t4}
+    return out
 
 
 def spread_leg(device, mode="exact", replicates=1024, events=20000, occupied=4096):
@@ -118,29 +130,18 @@ def spread_leg(device, mode="exact", replicates=1024, events=20000, occupied=409
 
 def genealogy_leg(device, events=300000):
     """the backward pass (GetGenealogy, pyx:743-1000) over one config-3 chain produced on the
-    device — libvgx's host code against the oracle's literal restatement of the reference (dense per-compartment
-    vectors), same chain, same seed, identical trees."""
-    import copy
-    import numpy as np
+    device, in libvgx's host code (one core).  The oracle's literal restatement is timed in the cpu_baseline leg."""
     from vgsim_amd import _capi
-    from oracle import oracle
-    oracle.build()
     sim = make_simulator(2020)
     with contextlib.redirect_stdout(io.StringIO()):
         sim.simulate(events, sample_size=10 ** 12)
     m = sim.simulation
-    m2 = copy.copy(m)
-    m2.infectious = m.infectious.copy()
-    m2.events = copy.deepcopy(m.events)
     t0 = time.perf_counter()
     out = _capi.get_genealogy(m, 7)
     t1 = time.perf_counter()
-    ref = oracle.run_genealogy(m2, 7)
-    t2 = time.perf_counter()
-    same = bool(np.array_equal(out["tree"], ref["tree"]) and np.array_equal(out["times"], ref["times"]))
     return {"workload": "backward pass over one config-3 chain (host code)", "events": int(m.events.ptr), "samples": int(m.sCounter),
-            "value": m.events.ptr / (t1 - t0), "unit": "events/s (one host core)", "seconds": t1 - t0,
-            "oracle_events_per_s": m.events.ptr / (t2 - t1), "oracle_seconds": t2 - t1, "identical_to_oracle": same}
+            "tree_nodes": int(out["nodes_used"]), "value": m.events.ptr / (t1 - t0), "unit": "events/s (one host core)",
+            "seconds": t1 - t0}
 
 
 def fast_leg(device, replicates, events, traj_points):
