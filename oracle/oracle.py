@@ -13,7 +13,7 @@ import subprocess
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB = os.path.join(HERE, "libvgx_oracle.so")
+LIB = os.environ.get("VGX_ORACLE_LIBRARY") or os.path.join(HERE, "libvgx_oracle.so")
 
 LOG_LIBM, LOG_PORTABLE = 0, 1
 
@@ -62,8 +62,11 @@ class VgoPcg64(C.Structure):
 
 def build(force=False):
     """Compile the oracle with gcc (oracle/Makefile)."""
-    if force or not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(os.path.join(HERE, "vgx_oracle.c")):
-        subprocess.check_call(["make", "-s", "-C", HERE])
+    if os.environ.get("VGX_ORACLE_LIBRARY"):   # e.g. the AddressSanitizer build (make -C oracle asan)
+        return LIB
+    if force:
+        subprocess.check_call(["make", "-s", "-C", HERE, "clean"])
+    subprocess.check_call(["make", "-s", "-C", HERE])   # a no-op when the library is newer than its sources
     return LIB
 
 

@@ -87,6 +87,7 @@ static __device__ int64_t tau_poisson(TauRng &g, double lam) {
     if (!(lam > 0.0)) return 0;
     if (lam < 10.0) {
         double u = g.uniform();
+        if (u <= 1.0 - lam) return 0;   // exp(-lam) >= 1 - lam: the search below would stop at 0 (most compartments)
         double pk = exp(-lam), F = pk;
         int64_t X = 0;
         while (u > F && X < 200) {
