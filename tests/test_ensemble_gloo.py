@@ -41,6 +41,21 @@ WORKER = textwrap.dedent("""
         print("GATHER_OK")
     else:
         assert got is None
+    # asynchronous form used by bench.py: the transfer of step i overlaps step i+1; a preallocated result is reused
+    out = torch.empty((world, R, T, P, 2), dtype=torch.float64) if rank == 0 else None
+    pend = None
+    for it in range(3):
+        block = (np.arange(R * T * P * 2, dtype=np.float64).reshape(R, T, P, 2) + 1000.0 * rank + 7.0 * it)
+        ens.trajectories = lambda out=None, b=block: b.copy()
+        if pend is not None:
+            res = pend.wait()
+            if rank == 0:
+                assert res is out and np.array_equal(res[1].numpy(), np.arange(R * T * P * 2, dtype=np.float64).reshape(R, T, P, 2) + 1000.0 + 7.0 * (it - 1))
+        pend = ens.gather_trajectories(dst=0, out=out, async_op=True)
+    res = pend.wait()
+    if rank == 0:
+        assert np.array_equal(res[0].numpy(), np.arange(R * T * P * 2, dtype=np.float64).reshape(R, T, P, 2) + 14.0)
+        print("ASYNC_OK")
     # seed partition used by bench.py: disjoint and independent of the world size
     step, seeds = 0, 2020 + (0 * world + rank) * R + np.arange(R)
     allseeds = [torch.zeros(R, dtype=torch.int64) for _ in range(world)]
@@ -61,4 +76,4 @@ def test_gather_world_size_2(tmp_path):
         procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     outs = [p.communicate(timeout=240)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
-    assert "GATHER_OK" in outs[0]
+    assert "GATHER_OK" in outs[0] and "ASYNC_OK" in outs[0]

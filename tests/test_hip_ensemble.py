@@ -77,3 +77,44 @@ def test_ensemble_without_log_counts_the_same(oracle_mod):
     b = ens.simulate(5000, sample_size=10 ** 9, record_events=False)
     assert np.array_equal(a.events, b.events) and np.array_equal(a.loop_iterations, b.loop_iterations)
     ens.close()
+
+
+def test_rccl_gather_single_rank(tmp_path):
+    """The collective of the ensemble layer on the real backend (nccl = RCCL), world_size 1 on this GPU: synchronous
+    and asynchronous gather into a preallocated result, straight from device memory."""
+    import os
+    import subprocess
+    import sys
+    import textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "w.py"
+    script.write_text(textwrap.dedent("""
+        import os, sys, io, contextlib
+        import numpy as np, torch, torch.distributed as dist
+        sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
+        import models
+        from vgsim_amd import Simulator
+        from vgsim_amd.ensemble import Ensemble
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        with contextlib.redirect_stdout(io.StringIO()):
+            sim, ph = models.build(Simulator, "c3_s5_p16")
+            ph[0][0](sim)
+        ens = Ensemble(sim, 16)
+        ens.simulate(2000, sample_size=10 ** 9, traj_points=17, traj_window=(0.0, 5.0))
+        want = ens.trajectories()
+        got = ens.gather_trajectories(dst=0)
+        assert got.is_cuda and got.shape == (1,) + want.shape and np.array_equal(got[0].cpu().numpy(), want)
+        out = torch.empty((1,) + want.shape, dtype=torch.float64, device="cuda")
+        pend = ens.gather_trajectories(dst=0, out=out, async_op=True)
+        ens.simulate(2000, sample_size=10 ** 9, traj_points=17, traj_window=(0.0, 5.0), seeds=np.arange(900, 916))
+        res = pend.wait()
+        torch.cuda.synchronize()
+        assert res is out and np.array_equal(res[0].cpu().numpy(), want)      # the first call's trajectories
+        assert not np.array_equal(ens.trajectories(), want)
+        dist.destroy_process_group()
+        print("RCCL_OK")
+    """) % (root, root))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    assert p.returncode == 0 and b"RCCL_OK" in p.stdout, p.stdout.decode()[-3000:]

@@ -470,7 +470,7 @@ static int init_device_state(vgx_engine *e, int64_t traj_points) {
     size_t free_b = 0, total_b = 0;
     HIPCHECK(e, hipMemGetInfo(&free_b, &total_b));
     int64_t need = std::max<int64_t>(std::max(s_cap, i_cap), 1);
-    int64_t budget = (int64_t)((double)(free_b + e->r_lhap.bytes + e->r_lcls.bytes + e->r_lcnt.bytes) * 0.55 / (double)(R * P * 16));
+    int64_t budget = (int64_t)((double)(free_b + e->r_lhap.bytes + e->r_lcls.bytes + e->r_lcnt.bytes) * 0.45 / (double)(R * P * 16));
     int64_t cap = std::min<int64_t>(H, std::max<int64_t>(budget, 64));
     cap = std::max(cap, std::min<int64_t>(H, need + 64));
     if (cap < need) return fail(e, VGX_ERR_CAPACITY, "occupancy lists do not fit device memory");

@@ -175,14 +175,18 @@ class Ensemble:
         eng._check(eng.lib.vgx_get_trajectories(eng.handle, C.c_void_p(out.data_ptr()), 1 if out.is_cuda else 0))
         return out
 
-    def gather_trajectories(self, dst=0):
+    def gather_trajectories(self, dst=0, out=None, async_op=False):
         """One collective for the whole ensemble: every rank's ``[R, T, P, 2]`` block to rank ``dst``
         (``torch.distributed.gather``; backend nccl = RCCL over xGMI, gloo on CPU).  Returns the stacked
-        ``[world, R, T, P, 2]`` tensor on ``dst`` and None elsewhere."""
+        ``[world, R, T, P, 2]`` tensor on ``dst`` and None elsewhere; ``out`` may be a preallocated result tensor on
+        ``dst``.  With ``async_op=True`` the trajectories are first copied out of the engine (so the next ``simulate``
+        may overwrite them) and a :class:`PendingGather` is returned: the transfer overlaps the next step and
+        ``.wait()`` gives the result."""
         import torch
         import torch.distributed as dist
         if not (dist.is_available() and dist.is_initialized()):
-            return torch.from_numpy(self.trajectories())[None]
+            res = torch.from_numpy(self.trajectories())[None]
+            return PendingGather(None, res, None) if async_op else res
         backend = dist.get_backend()
         if backend == "nccl":
             dev = torch.device("cuda", torch.cuda.current_device())
@@ -191,8 +195,25 @@ class Ensemble:
             mine = torch.from_numpy(self.trajectories())
         world, rank = dist.get_world_size(), dist.get_rank()
         if rank == dst:   # gather straight into the rows of the result: no second copy of [world, R, T, P, 2]
-            out = torch.empty((world,) + tuple(mine.shape), dtype=mine.dtype, device=mine.device)
-            dist.gather(mine, list(out.unbind(0)), dst=dst)
-            return out
-        dist.gather(mine, None, dst=dst)
-        return None
+            if out is None:
+                out = torch.empty((world,) + tuple(mine.shape), dtype=mine.dtype, device=mine.device)
+            assert tuple(out.shape) == (world,) + tuple(mine.shape) and out.is_contiguous()
+            work = dist.gather(mine, list(out.unbind(0)), dst=dst, async_op=async_op)
+        else:
+            out = None
+            work = dist.gather(mine, None, dst=dst, async_op=async_op)
+        return PendingGather(work, out, mine) if async_op else out
+
+
+class PendingGather:
+    """Handle of an asynchronous trajectory gather: keeps the send/receive buffers alive until ``wait()``."""
+
+    def __init__(self, work, result, keep):
+        self.work, self.result, self.keep = work, result, keep
+
+    def wait(self):
+        if self.work is not None:
+            self.work.wait()
+            self.work = None
+        self.keep = None
+        return self.result
