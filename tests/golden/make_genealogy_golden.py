@@ -48,6 +48,14 @@ def run(name, gseed):
         times = np.asarray(times).astype(np.float64).copy()
         _, _, mut, _ = m.output_tree_mutations()
         m.export_migrations("_gen_mig_%s" % name, "/tmp")
+        # the reference's text writers (src/IO.py:144-255) on the same genealogy
+        sim.export_newick("_gen_%s" % name, "/tmp")
+        sim.export_mutations("_gen_mut_%s" % name, "/tmp")
+    texts = {}
+    for key, fn in (("newick", "/tmp/_gen_%s_tree.nwk" % name), ("sample_population", "/tmp/_gen_%s_sample_population.tsv" % name),
+                    ("mutations_tsv", "/tmp/_gen_mut_%s.tsv" % name)):
+        texts[key] = open(fn).read()
+        os.remove(fn)
     rows = [l.split("\t") for l in open("/tmp/_gen_mig_%s.tsv" % name).read().splitlines()[1:]]
     os.remove("/tmp/_gen_mig_%s.tsv" % name)
     mig_node = np.array([int(r[0]) for r in rows], dtype=np.int64)
@@ -58,7 +66,7 @@ def run(name, gseed):
     tag = "%s_seed%s" % (name, "None" if gseed is None else gseed)
     nz = np.argwhere(inf_before != 0)
     nz2 = np.argwhere(inf_after != 0)
-    meta = dict(case=name, genealogy_seed=gseed, sCounter=int((len(tree) + 1) // 2), events=int(chain.shape[1]))
+    meta = dict(case=name, genealogy_seed=gseed, sCounter=int((len(tree) + 1) // 2), events=int(chain.shape[1]), **texts)
     np.savez_compressed(
         os.path.join(HERE, "genealogy_" + tag + ".npz"), meta=json.dumps(meta), tree=tree, times=times,
         mut_node=np.array(mut[0], dtype=np.int64), mut_AS=np.array(mut[1], dtype=np.int64),

@@ -134,3 +134,24 @@ def test_chain_round_trip_feeds_the_backward_pass(oracle_mod, tmp_path):
     sim.genealogy(15)
     tree, times = sim.get_tree()
     assert np.array_equal(tree, z["tree"]) and np.array_equal(times, z["times"])
+
+
+@pytest.mark.parametrize("path", GOLD, ids=[os.path.basename(p)[10:-4] for p in GOLD])
+def test_text_writers_match_reference(oracle_mod, path, tmp_path):
+    """export_newick / export_mutations (src/IO.py:144-255) on the genealogy of every fixture: same bytes as the
+    reference wrote.  (Tau chains: the sample-population table is skipped — upstream looks the population up in the
+    MULTITYPE event's row-index field, which depends on the multievent layout.)"""
+    meta, z = load(path)
+    sim = helpers.run_case_oracle(oracle_mod, meta["case"], record_multievents=True)
+    m = sim.simulation
+    tau = bool((m.events.types[:m.events.ptr] == 6).any())
+    out = oracle_mod.run_genealogy(m, meta["genealogy_seed"])
+    m.tree, m.times, m.tree_pop = out["tree"], out["times"], out["tree_pop"]
+    m.mut.nodeId, m.mut.AS, m.mut.DS = out["mut_node"].tolist(), out["mut_AS"].tolist(), out["mut_DS"].tolist()
+    m.mut.site, m.mut.time = out["mut_site"].tolist(), out["mut_time"].tolist()
+    sim.export_newick("t", str(tmp_path))
+    sim.export_mutations("m", str(tmp_path))
+    assert open(tmp_path / "t_tree.nwk").read() == meta["newick"]
+    assert open(tmp_path / "m.tsv").read() == meta["mutations_tsv"]
+    if not tau:
+        assert open(tmp_path / "t_sample_population.tsv").read() == meta["sample_population"]

@@ -154,6 +154,16 @@ class Simulator:
             print(pop)
             print(hap)
 
+    def export_newick(self, file_template=None, file_path=None):  # if:498-509
+        from ._writers import write_newick
+        pruferSeq, times, mut, populations = self.simulation.output_tree_mutations()
+        write_newick(pruferSeq, times, populations, file_template, file_path)
+
+    def export_mutations(self, file_template=None, file_path=None):  # if:511-522
+        from ._writers import write_mutations
+        pruferSeq, times, mut, populations = self.simulation.output_tree_mutations()
+        write_mutations(mut, len(pruferSeq), file_template, file_path)
+
     def export_migrations(self, file_template=None, file_path=None):  # if:524-534
         self.simulation.export_migrations(file_template, file_path)
 
