@@ -110,6 +110,24 @@ static __device__ int64_t tau_poisson(TauRng &g, double lam) {
     }
 }
 
+// First draw of a compartment: the uniform of the small-mean branch comes from a 32-bit word that four neighbouring
+// compartments share one Philox block for (resolution 2^-32: irrelevant for a search that ends after a few terms);
+// the compartment's own stream is only started when more random numbers are needed.
+static __device__ int64_t tau_poisson_first(TauRng &g, double lam, uint32_t word) {
+    if (!(lam > 0.0)) return 0;
+    if (lam >= 10.0) return tau_poisson(g, lam);
+    double u = ((double)word + 0.5) * (1.0 / 4294967296.0);
+    if (u <= 1.0 - lam) return 0;   // exp(-lam) >= 1 - lam: the search would stop at 0 (most compartments)
+    double pk = exp(-lam), F = pk;
+    int64_t X = 0;
+    while (u > F && X < 200) {
+        X += 1;
+        pk *= lam / (double)X;
+        F += pk;
+    }
+    return X;
+}
+
 static __device__ __forceinline__ int tau_mutate(int sites, int hi, int s, int DS) {  // pyx:2420-2427
     int digit4 = 1 << (2 * (sites - s - 1));
     int AS = (hi / digit4) % 4;
@@ -199,8 +217,11 @@ extern "C" __global__ void __launch_bounds__(TB) vgx_tau_prep_kernel(VgxTauArgs 
 // the 8 coefficients of the transposed, padded matrix as ONE wave-uniform scalar load (the pointers are
 // __restrict__ kernel arguments and the only store goes to migIn, so the loads are provably read-only).
 #define TH 64
-#define TPW 8
-extern "C" __global__ void __launch_bounds__(TB) vgx_tau_migin_kernel(const double *__restrict__ AeffT_all,
+#define TPW 16
+#ifndef MIGIN_TB
+#define MIGIN_TB 1024   // waves of a block share one LDS tile of infectious counts: more waves per tile hide the scalar loads
+#endif
+extern "C" __global__ void __launch_bounds__(MIGIN_TB) vgx_tau_migin_kernel(const double *__restrict__ AeffT_all,
                                                                       const int64_t *__restrict__ I_all,
                                                                       double *__restrict__ migIn_all,
                                                                       const int32_t *__restrict__ active, int P, int Pp,
@@ -218,12 +239,12 @@ extern "C" __global__ void __launch_bounds__(TB) vgx_tau_migin_kernel(const doub
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int h0 = tile * TH;
         __syncthreads();
-        for (int idx = threadIdx.x; idx < P * TH; idx += TB) {
+        for (int idx = threadIdx.x; idx < P * TH; idx += MIGIN_TB) {
             int spn = idx >> 6, h = idx & 63;
             It[idx] = (h0 + h < H) ? (int32_t)I[(int64_t)spn * H + h0 + h] : 0;
         }
         __syncthreads();
-        for (int tp0 = wave * TPW; tp0 < P; tp0 += 4 * TPW) {
+        for (int tp0 = wave * TPW; tp0 < P; tp0 += (MIGIN_TB / 64) * TPW) {
             double acc[TPW];
 #pragma unroll
             for (int j = 0; j < TPW; ++j) acc[j] = 0.0;
@@ -258,7 +279,7 @@ extern "C" __global__ void __launch_bounds__(TB) vgx_tau_drift_kernel(VgxTauArgs
     __shared__ unsigned long long smin;
     // class tables and this population's per-class factors in LDS when they are small (else global)
     __shared__ double l_cd[256], l_cs[256], l_ctm[256], l_base[16 * 64], l_mutp[48];
-    __shared__ int32_t l_bidx[256], l_stype[256];
+    __shared__ int32_t l_bidx[256], l_stype[256], l_site_flat[16];
     const bool useL = C <= 256 && CB <= 16;
     if (threadIdx.x < 64) sdS[threadIdx.x] = 0.0;
     if (threadIdx.x == 0) smin = (unsigned long long)__double_as_longlong(1.0);
@@ -269,7 +290,9 @@ extern "C" __global__ void __launch_bounds__(TB) vgx_tau_drift_kernel(VgxTauArgs
         }
         for (int i = threadIdx.x; i < CB * S; i += TB) l_base[i] = p.cb_b[i / S] * p.cb_sigma[i] * (double)Sus[i % S];
     }
-    for (int i = threadIdx.x; i < 3 * sites && i < 48; i += TB) l_mutp[i] = a.mutcum[i] - (i > 0 ? a.mutcum[i - 1] : 0.0);
+    for (int i = threadIdx.x; i < 3 * sites && i < 48; i += TB) l_mutp[i] = a.mutp[i / 3][i % 3];
+    for (int i = threadIdx.x; i < sites && i < 16; i += TB)
+        l_site_flat[i] = (a.mutp[i][0] == a.mutp[i][1] && a.mutp[i][1] == a.mutp[i][2]) ? 1 : 0;
     __syncthreads();
     const double F = a.F[(int64_t)rep * P + pn];
     double cand_min = 1.0;
@@ -292,6 +315,17 @@ extern "C" __global__ void __launch_bounds__(TB) vgx_tau_drift_kernel(VgxTauArgs
         for (int s = 0; s < sites; ++s) {
             const int sh = 2 * (sites - s - 1);
             const int AS = (hh >> sh) & 3;
+            if (a.mut_uniform && l_site_flat[s]) {
+                // the three derived states of this site are equally likely for every source: add the three
+                // neighbouring counts as integers, convert and scale once
+                const int b0 = hh & ~(3 << sh);
+                int64_t nb = 0;
+                if (live) {
+                    nb = I[b0] + I[b0 + (1 << sh)] + I[b0 + (2 << sh)] + I[b0 + (3 << sh)] - Icell;
+                }
+                drift += l_mutp[s * 3] * (double)nb;
+                continue;
+            }
             for (int al = 0; al < 4; ++al) {
                 if (al == AS) continue;
                 const int src = hh + ((al - AS) << sh);
@@ -422,20 +456,18 @@ struct TauTab {
 //   the susceptible deltas (identical in both), the tentative counters and multievent rows.
 // The compartment arrays themselves are not touched, so every thread sees the pre-step state.
 static __device__ __forceinline__ void tau_cell(const VgxTauArgs &a, const TauTab &T, int rep, int pn, int hn, double tau,
+                                                uint32_t first_word, int64_t Icell, int64_t &ownChk, int64_t &ownApp,
                                                 int64_t *cnt,
                                                 unsigned long long *sS /* LDS [S]: this population's susceptible deltas */,
                                                 unsigned long long *sTot /* LDS: delta of totalInfectious[pn] */) {
     const VgxDevParams &p = a.p;
     const int P = p.P, S = p.S, H = p.H, sites = p.sites;
-    const int64_t *I = a.I + (int64_t)rep * P * H;
-    int64_t *dC = a.dChk + (int64_t)rep * P * H;
-    int64_t *dA = a.dApp + (int64_t)rep * P * H;
     int64_t *dS = a.dSi + (int64_t)rep * P * S;
-    const int64_t Icell = I[(int64_t)pn * H + hn];
-    // every compartment stores its own deltas (plain, coalesced), so the arrays need no clearing pass;
-    // deltas INTO other compartments (mutants, migrants) go through the append list and are scattered afterwards
-    dC[(int64_t)pn * H + hn] = 0;
-    dA[(int64_t)pn * H + hn] = 0;
+    // every compartment's own deltas are returned to the caller, which stores them for four neighbouring
+    // compartments at once (plain, coalesced: the arrays need no clearing pass); deltas INTO other compartments
+    // (mutants, migrants) go through the append list and are scattered afterwards
+    ownChk = 0;
+    ownApp = 0;
     if (Icell == 0) return;
     const double Ih = (double)Icell;
     const int c = p.cls[hn];
@@ -451,7 +483,7 @@ static __device__ __forceinline__ void tau_cell(const VgxTauArgs &a, const TauTa
     TauRng g;
     g.init((uint64_t)a.seeds[rep], (uint32_t)a.attempt[rep], (uint64_t)pn * (uint64_t)H + (uint64_t)hn, (uint32_t)a.step[rep],
            (uint32_t)a.retry[rep]);
-    const int64_t N = tau_poisson(g, r_all * tau);
+    const int64_t N = tau_poisson_first(g, r_all * tau, first_word);
     if (N == 0) return;
     int64_t rec = 0, samp = 0, births = 0, n_mut = 0, n_mig = 0;
     const double t1 = r_rec, t2 = t1 + r_samp, t3 = t2 + r_tr, t4 = t3 + r_mut;
@@ -538,8 +570,8 @@ static __device__ __forceinline__ void tau_cell(const VgxTauArgs &a, const TauTa
     if (rec) tau_row(a, rep, rec, 1, hn, pn, st, 0);
     if (samp) tau_row(a, rep, samp, 2, hn, pn, st, 0);
     const int64_t own = births - rec - samp - mut_done;
-    dC[(int64_t)pn * H + hn] = own + migrants;
-    dA[(int64_t)pn * H + hn] = own;
+    ownChk = own + migrants;
+    ownApp = own;
     if (rec + samp != 0) atomicAdd(&sS[st], (unsigned long long)(rec + samp));
     int64_t dt = births - rec - samp;
     if (dt != 0) atomicAdd(sTot, (unsigned long long)dt);
@@ -620,8 +652,43 @@ extern "C" __global__ void __launch_bounds__(TB) vgx_tau_draw_kernel(VgxTauArgs 
     __syncthreads();
     int64_t cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const double tau = a.tau[rep];
-    for (int h = hn; h < p.H; h += gridDim.x * TB)   // persistent over haplotype tiles: the table staging is amortised
-        tau_cell(a, T, rep, pn, h, tau, cnt, sS, &sTot);
+    // a thread works on four neighbouring haplotypes at a time (32 B loads and stores); their first uniforms are the
+    // four words of ONE Philox block keyed like the compartment streams, counter (group index, step, retry | 0xFFFFF)
+    const int H = p.H;
+    const int64_t *Irow = a.I + ((int64_t)rep * P + pn) * H;
+    int64_t *dCrow = a.dChk + ((int64_t)rep * P + pn) * H, *dArow = a.dApp + ((int64_t)rep * P + pn) * H;
+    const uint32_t key[2] = {(uint32_t)a.seeds[rep] ^ ((uint32_t)a.attempt[rep] * 0x9E3779B9u),
+                             (uint32_t)((uint64_t)a.seeds[rep] >> 32) ^ 0x85EBCA6Bu};
+    const int groups = (H + 3) / 4;
+    for (int q = hn; q < groups; q += gridDim.x * TB) {   // persistent over tiles: the table staging is amortised
+        const int h0 = q * 4;
+        const uint64_t gidx = (uint64_t)pn * (uint64_t)groups + (uint64_t)q;
+        const uint32_t ctr[4] = {(uint32_t)gidx, (uint32_t)(gidx >> 32), (uint32_t)a.step[rep], ((uint32_t)a.retry[rep] << 20) | 0xFFFFFu};
+        uint32_t w[4];
+        vgx_philox4x32(ctr, key, w);
+        int64_t Iv[4] = {0, 0, 0, 0}, oc[4], oa[4];
+        if (h0 + 3 < H) {
+            const longlong2 *src = (const longlong2 *)(Irow + h0);
+            longlong2 x = src[0], y = src[1];
+            Iv[0] = x.x; Iv[1] = x.y; Iv[2] = y.x; Iv[3] = y.y;
+        } else {
+            for (int j = 0; j < 4; ++j)
+                if (h0 + j < H) Iv[j] = Irow[h0 + j];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            oc[j] = 0; oa[j] = 0;
+            if (h0 + j < H) tau_cell(a, T, rep, pn, h0 + j, tau, w[j], Iv[j], oc[j], oa[j], cnt, sS, &sTot);
+        }
+        if (h0 + 3 < H) {
+            longlong2 *dc = (longlong2 *)(dCrow + h0), *da = (longlong2 *)(dArow + h0);
+            dc[0] = make_longlong2(oc[0], oc[1]); dc[1] = make_longlong2(oc[2], oc[3]);
+            da[0] = make_longlong2(oa[0], oa[1]); da[1] = make_longlong2(oa[2], oa[3]);
+        } else {
+            for (int j = 0; j < 4; ++j)
+                if (h0 + j < H) { dCrow[h0 + j] = oc[j]; dArow[h0 + j] = oa[j]; }
+        }
+    }
     for (int i = 0; i < 6; ++i)
         if (cnt[i]) atomicAdd(&sc[i], (unsigned long long)cnt[i]);
     __syncthreads();
@@ -810,7 +877,7 @@ extern "C" __attribute__((visibility("hidden"))) hipError_t vgxi_tau_drift(const
         if (err != hipSuccess) return err;
         int ntiles = (a->p.H + TH - 1) / TH;
         int gx = ntiles < 2048 ? ntiles : 2048;
-        hipLaunchKernelGGL(vgx_tau_migin_kernel, dim3((unsigned)gx, (unsigned)a->R), dim3(TB), lds, s, a->Aeff, a->I, a->migIn,
+        hipLaunchKernelGGL(vgx_tau_migin_kernel, dim3((unsigned)gx, (unsigned)a->R), dim3(MIGIN_TB), lds, s, a->Aeff, a->I, a->migIn,
                            a->active, a->p.P, a->Ppad, a->p.H);
         err = hipGetLastError();
         if (err != hipSuccess) return err;
@@ -827,7 +894,7 @@ extern "C" __attribute__((visibility("hidden"))) hipError_t vgxi_tau_draw(const 
     hipError_t err = hipFuncSetAttribute((const void *)vgx_tau_draw_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds ? lds : 16));
     if (err != hipSuccess) return err;
     unsigned tiles = (unsigned)((a->p.H + TB - 1) / TB);
-    unsigned gx = tiles < 32u ? tiles : 32u;   // blocks per (population, replicate); each loops over its tiles
+    unsigned gx = (tiles + 3u) / 4u < 32u ? (tiles + 3u) / 4u : 32u;   // blocks per (population, replicate); each loops over its tiles of 4*TB haplotypes
     hipLaunchKernelGGL(vgx_tau_draw_kernel, dim3(gx, (unsigned)a->p.P, (unsigned)a->R), dim3(TB), lds ? lds : 16, s, *a);
     return hipGetLastError();
 }
