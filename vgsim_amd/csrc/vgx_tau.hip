@@ -110,24 +110,6 @@ static __device__ int64_t tau_poisson(TauRng &g, double lam) {
     }
 }
 
-// First draw of a compartment: the uniform of the small-mean branch comes from a 32-bit word that four neighbouring
-// compartments share one Philox block for (resolution 2^-32: irrelevant for a search that ends after a few terms);
-// the compartment's own stream is only started when more random numbers are needed.
-static __device__ int64_t tau_poisson_first(TauRng &g, double lam, uint32_t word) {
-    if (!(lam > 0.0)) return 0;
-    if (lam >= 10.0) return tau_poisson(g, lam);
-    double u = ((double)word + 0.5) * (1.0 / 4294967296.0);
-    if (u <= 1.0 - lam) return 0;   // exp(-lam) >= 1 - lam: the search would stop at 0 (most compartments)
-    double pk = exp(-lam), F = pk;
-    int64_t X = 0;
-    while (u > F && X < 200) {
-        X += 1;
-        pk *= lam / (double)X;
-        F += pk;
-    }
-    return X;
-}
-
 static __device__ __forceinline__ int tau_mutate(int sites, int hi, int s, int DS) {  // pyx:2420-2427
     int digit4 = 1 << (2 * (sites - s - 1));
     int AS = (hi / digit4) % 4;
@@ -441,6 +423,7 @@ struct TauTab {
     const double *rmig;                  // [CB]   out-migration rate per infected: Gout * b * m[pn][pn]
     const double *mutcum;                // [3*sites] running sums of the uniform mutation model
     const double *cdf;                   // [CB][P*S] running sums of the out-migration channel weights of pn
+    const double *r1;                    // [C] total event rate per infected of the class in this population, or null
 };
 
 // GenerateEvents_tau for one compartment (pn, hn).  All channels out of a compartment are independent Poisson
@@ -455,22 +438,43 @@ struct TauTab {
 //          TARGET population),
 //   the susceptible deltas (identical in both), the tentative counters and multievent rows.
 // The compartment arrays themselves are not touched, so every thread sees the pre-step state.
-static __device__ __forceinline__ void tau_cell(const VgxTauArgs &a, const TauTab &T, int rep, int pn, int hn, double tau,
-                                                uint32_t first_word, int64_t Icell, int64_t &ownChk, int64_t &ownApp,
-                                                int64_t *cnt,
-                                                unsigned long long *sS /* LDS [S]: this population's susceptible deltas */,
-                                                unsigned long long *sTot /* LDS: delta of totalInfectious[pn] */) {
+// Can compartment (pn, hn) draw any event in this step?  For most compartments the class's total rate and the shared
+// 32-bit word say no at once; the others are queued and tau_cell_events makes the draw (inversion with the same word
+// below a mean of 10, PTRS on the compartment's own stream from 10 on).
+static __device__ __forceinline__ int tau_cell_count(const VgxTauArgs &a, const TauTab &T, int pn, int hn, double tau,
+                                                     uint32_t first_word, int64_t Icell) {
+    const VgxDevParams &p = a.p;
+    if (Icell == 0) return 0;
+    const double Ih = (double)Icell;
+    const int c = (p.C == 1) ? 0 : p.cls[hn];
+    double rate;
+    if (T.r1) {
+        rate = T.r1[c];
+    } else {
+        const int cb = T.c_bidx[c];
+        rate = T.rmig[cb] + T.c_d[c] + T.c_s[c] * p.sampMult[pn] + (a.mut_uniform ? a.mut_total : T.c_tm[c]) + T.rtr[cb];
+    }
+    const double lam = rate * Ih * tau;
+    if (!(lam > 0.0)) return 0;
+    if (lam >= 10.0) return 1;
+    const double u = ((double)first_word + 0.5) * (1.0 / 4294967296.0);
+    return (u <= 1.0 - lam) ? 0 : 1;   // exp(-lam) >= 1 - lam: the inversion search of tau_cell_events would stop at 0
+}
+
+static __device__ __forceinline__ void tau_cell_events(const VgxTauArgs &a, const TauTab &T, int rep, int pn, int hn, double tau,
+                                                       int64_t Icell, uint32_t first_word, int64_t &ownChk, int64_t &ownApp, int64_t *cnt,
+                                                       unsigned long long *sS /* LDS [S]: this population's susceptible deltas */,
+                                                       unsigned long long *sTot /* LDS: delta of totalInfectious[pn] */) {
     const VgxDevParams &p = a.p;
     const int P = p.P, S = p.S, H = p.H, sites = p.sites;
     int64_t *dS = a.dSi + (int64_t)rep * P * S;
-    // every compartment's own deltas are returned to the caller, which stores them for four neighbouring
-    // compartments at once (plain, coalesced: the arrays need no clearing pass); deltas INTO other compartments
-    // (mutants, migrants) go through the append list and are scattered afterwards
     ownChk = 0;
     ownApp = 0;
-    if (Icell == 0) return;
     const double Ih = (double)Icell;
-    const int c = p.cls[hn];
+    const int c = (p.C == 1) ? 0 : p.cls[hn];
+    TauRng g;
+    g.init((uint64_t)a.seeds[rep], (uint32_t)a.attempt[rep], (uint64_t)pn * (uint64_t)H + (uint64_t)hn, (uint32_t)a.step[rep],
+           (uint32_t)a.retry[rep]);
     const int cb = T.c_bidx[c];
     const int st = T.c_stype[c];
     // ---- channel rates per unit time ----
@@ -480,11 +484,23 @@ static __device__ __forceinline__ void tau_cell(const VgxTauArgs &a, const TauTa
     const double r_mut = (a.mut_uniform ? a.mut_total : T.c_tm[c]) * Ih;             // pyx:2400-2401 summed over (s, i)
     const double r_mig = T.rmig[cb] * Ih;                                            // pyx:2366-2367 summed over (tpn, sn)
     const double r_all = r_mig + r_rec + r_samp + r_mut + r_tr;
-    TauRng g;
-    g.init((uint64_t)a.seeds[rep], (uint32_t)a.attempt[rep], (uint64_t)pn * (uint64_t)H + (uint64_t)hn, (uint32_t)a.step[rep],
-           (uint32_t)a.retry[rep]);
-    const int64_t N = tau_poisson_first(g, r_all * tau, first_word);
-    if (N == 0) return;
+    int64_t N;
+    {
+        const double lam = r_all * tau;
+        if (lam >= 10.0) {
+            N = tau_poisson(g, lam);
+        } else {   // inversion by sequential search with the shared word (same law as numpy's sampler below 10)
+            const double u = ((double)first_word + 0.5) * (1.0 / 4294967296.0);
+            double pk = exp(-lam), F = pk;
+            N = 0;
+            while (u > F && N < 200) {
+                N += 1;
+                pk *= lam / (double)N;
+                F += pk;
+            }
+        }
+        if (N == 0) return;
+    }
     int64_t rec = 0, samp = 0, births = 0, n_mut = 0, n_mig = 0;
     const double t1 = r_rec, t2 = t1 + r_samp, t3 = t2 + r_tr, t4 = t3 + r_mut;
     for (int64_t ev = 0; ev < N; ++ev) {
@@ -581,7 +597,7 @@ static __device__ __forceinline__ void tau_cell(const VgxTauArgs &a, const TauTa
 static __host__ __device__ inline size_t tau_tab_lds_bytes(int C, int CB, int S, int P, bool &cdf_in_lds) {
     cdf_in_lds = false;
     if (C > 256 || CB > 16) return 0;
-    size_t dbl = 3 * (size_t)C + 2 * (size_t)CB + (size_t)CB * S + 48;
+    size_t dbl = 4 * (size_t)C + 2 * (size_t)CB + (size_t)CB * S + 48;
     if ((size_t)CB * P * S <= 4096) { cdf_in_lds = true; dbl += (size_t)CB * P * S; }
     return dbl * 8 + 2 * (size_t)C * 4;
 }
@@ -592,7 +608,6 @@ extern "C" __global__ void __launch_bounds__(TB) vgx_tau_draw_kernel(VgxTauArgs 
     if (!a.active[rep] || a.accepted[rep]) return;
     const VgxDevParams &p = a.p;
     const int P = p.P, S = p.S, C = p.C, CB = p.CB;
-    const int hn = blockIdx.x * TB + threadIdx.x;
     extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
     // per-block accumulation of everything that all compartments of a population add to (one global atomic per
     // block instead of one per compartment: the susceptible deltas of a population are a single address)
@@ -616,6 +631,7 @@ extern "C" __global__ void __launch_bounds__(TB) vgx_tau_draw_kernel(VgxTauArgs 
         double *l_rmig = d; d += CB;
         double *l_wtr = d; d += CB * S;
         double *l_mut = d; d += 48;
+        double *l_r1 = d; d += C;
         double *l_cdf = d; if (cdfL) d += CB * P * S;
         int32_t *l_bidx = (int32_t *)d;
         int32_t *l_stype = l_bidx + C;
@@ -633,8 +649,13 @@ extern "C" __global__ void __launch_bounds__(TB) vgx_tau_draw_kernel(VgxTauArgs 
             l_rtr[cb] = r;
             l_rmig[cb] = a.has_mig ? a.Gout[((int64_t)rep * P + pn) * CB + cb] * p.cb_b[cb] * p.mig[(int64_t)pn * P + pn] : 0.0;
         }
+        __syncthreads();
+        for (int i = threadIdx.x; i < C; i += TB) {   // same terms as r_all in tau_cell, per infected
+            int cb = l_bidx[i];
+            l_r1[i] = l_rmig[cb] + l_cd[i] + l_cs[i] * p.sampMult[pn] + (a.mut_uniform ? a.mut_total : l_ctm[i]) + l_rtr[cb];
+        }
         T.c_d = l_cd; T.c_s = l_cs; T.c_tm = l_ctm; T.c_bidx = l_bidx; T.c_stype = l_stype;
-        T.rtr = l_rtr; T.wtr = l_wtr; T.rmig = l_rmig; T.mutcum = l_mut; T.cdf = cdfL ? l_cdf : gcdf;
+        T.rtr = l_rtr; T.wtr = l_wtr; T.rmig = l_rmig; T.mutcum = l_mut; T.cdf = cdfL ? l_cdf : gcdf; T.r1 = l_r1;
     } else {
         // many classes: parameters stay in global memory; the per-population weights of up to 16 birth classes
         // are still prepared once per block (more birth classes are rejected by the host)
@@ -647,48 +668,96 @@ extern "C" __global__ void __launch_bounds__(TB) vgx_tau_draw_kernel(VgxTauArgs 
             g_rmig[cb] = a.has_mig ? a.Gout[((int64_t)rep * P + pn) * CB + cb] * p.cb_b[cb] * p.mig[(int64_t)pn * P + pn] : 0.0;
         }
         T.c_d = p.c_d; T.c_s = p.c_s; T.c_tm = p.c_tm; T.c_bidx = p.c_bidx; T.c_stype = p.c_stype;
-        T.rtr = g_rtr; T.wtr = g_wtr; T.rmig = g_rmig; T.mutcum = a.mutcum; T.cdf = gcdf;
+        T.rtr = g_rtr; T.wtr = g_wtr; T.rmig = g_rmig; T.mutcum = a.mutcum; T.cdf = gcdf; T.r1 = nullptr;
     }
     __syncthreads();
     int64_t cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const double tau = a.tau[rep];
-    // a thread works on four neighbouring haplotypes at a time (32 B loads and stores); their first uniforms are the
-    // four words of ONE Philox block keyed like the compartment streams, counter (group index, step, retry | 0xFFFFF)
+    // Phase A: a thread looks at four neighbouring haplotypes (32 B loads and stores); their first uniforms are the
+    // four words of ONE Philox block keyed like the compartment streams, counter (group index, step, retry | 0xFFFFF).
+    // The few compartments that drew events are queued in LDS.  Phase B: the queue is worked off with all lanes busy
+    // (one queued compartment per thread), instead of one divergent lane per wavefront.
     const int H = p.H;
     const int64_t *Irow = a.I + ((int64_t)rep * P + pn) * H;
     int64_t *dCrow = a.dChk + ((int64_t)rep * P + pn) * H, *dArow = a.dApp + ((int64_t)rep * P + pn) * H;
     const uint32_t key[2] = {(uint32_t)a.seeds[rep] ^ ((uint32_t)a.attempt[rep] * 0x9E3779B9u),
                              (uint32_t)((uint64_t)a.seeds[rep] >> 32) ^ 0x85EBCA6Bu};
-    const int groups = (H + 3) / 4;
-    for (int q = hn; q < groups; q += gridDim.x * TB) {   // persistent over tiles: the table staging is amortised
-        const int h0 = q * 4;
-        const uint64_t gidx = (uint64_t)pn * (uint64_t)groups + (uint64_t)q;
-        const uint32_t ctr[4] = {(uint32_t)gidx, (uint32_t)(gidx >> 32), (uint32_t)a.step[rep], ((uint32_t)a.retry[rep] << 20) | 0xFFFFFu};
-        uint32_t w[4];
-        vgx_philox4x32(ctr, key, w);
-        int64_t Iv[4] = {0, 0, 0, 0}, oc[4], oa[4];
-        if (h0 + 3 < H) {
-            const longlong2 *src = (const longlong2 *)(Irow + h0);
-            longlong2 x = src[0], y = src[1];
-            Iv[0] = x.x; Iv[1] = x.y; Iv[2] = y.x; Iv[3] = y.y;
-        } else {
-            for (int j = 0; j < 4; ++j)
-                if (h0 + j < H) Iv[j] = Irow[h0 + j];
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            oc[j] = 0; oa[j] = 0;
-            if (h0 + j < H) tau_cell(a, T, rep, pn, h0 + j, tau, w[j], Iv[j], oc[j], oa[j], cnt, sS, &sTot);
-        }
-        if (h0 + 3 < H) {
-            longlong2 *dc = (longlong2 *)(dCrow + h0), *da = (longlong2 *)(dArow + h0);
-            dc[0] = make_longlong2(oc[0], oc[1]); dc[1] = make_longlong2(oc[2], oc[3]);
-            da[0] = make_longlong2(oa[0], oa[1]); da[1] = make_longlong2(oa[2], oa[3]);
-        } else {
-            for (int j = 0; j < 4; ++j)
-                if (h0 + j < H) { dCrow[h0 + j] = oc[j]; dArow[h0 + j] = oa[j]; }
-        }
+    const int groups = ((H + 255) / 256) * 64;   // 4 haplotypes per thread, 256 per wavefront chunk
+    const uint32_t ctr_step = (uint32_t)a.step[rep], ctr_retry = ((uint32_t)a.retry[rep] << 20) | 0xFFFFFu;   // loop invariants
+    // Phase A (every tile): the quick test; all four own deltas are stored as zero and the few compartments that may
+    // draw events are queued in LDS.  Phase B (when the queue holds a few wavefronts' worth, and at the end): the queue
+    // is worked off with all lanes busy and the queued compartments' deltas are stored again.
+    enum { QCAP = 8 * TB, QGO = QCAP - 4 * TB };
+    __shared__ int q_n, q_h[QCAP], q_w[QCAP];
+    if (threadIdx.x == 0) q_n = 0;
+    __syncthreads();
+    const int L = threadIdx.x & 63;
+    const int wave_off = (int)(threadIdx.x & ~63u) * 4;
+    // the loads of the next tile are issued before this tile is worked on
+    longlong2 nx = make_longlong2(0, 0), ny = make_longlong2(0, 0);
+    {
+        const int chunk = blockIdx.x * TB * 4 + wave_off;
+        if (chunk + 256 <= H) { nx = *(const longlong2 *)(Irow + chunk + 2 * L); ny = *(const longlong2 *)(Irow + chunk + 128 + 2 * L); }
     }
+    for (int q0 = blockIdx.x * TB; q0 < groups; q0 += gridDim.x * TB) {   // persistent over tiles: the table staging is amortised
+        const int q = q0 + threadIdx.x;
+        // the 256 haplotypes of a wavefront's chunk are split so that every 16-byte load/store instruction of the wave
+        // covers one contiguous KiB: thread (lane L) owns haplotypes chunk + {2L, 2L+1, 128+2L, 129+2L}
+        const int chunk = q0 * 4 + wave_off;
+        const longlong2 x = nx, y = ny;
+        {
+            const int nchunk = (q0 + gridDim.x * TB) * 4 + wave_off;
+            if (nchunk + 256 <= H) { nx = *(const longlong2 *)(Irow + nchunk + 2 * L); ny = *(const longlong2 *)(Irow + nchunk + 128 + 2 * L); }
+        }
+        if (chunk < H) {
+            int hh[4] = {chunk + 2 * L, chunk + 2 * L + 1, chunk + 128 + 2 * L, chunk + 129 + 2 * L};
+            const bool full = chunk + 256 <= H;
+            const uint64_t gidx = (uint64_t)pn * (uint64_t)groups + (uint64_t)q;
+            const uint32_t ctr[4] = {(uint32_t)gidx, (uint32_t)(gidx >> 32), ctr_step, ctr_retry};
+            uint32_t w[4];
+            vgx_philox4x32(ctr, key, w);
+            int64_t Iv[4] = {0, 0, 0, 0};
+            if (full) {
+                Iv[0] = x.x; Iv[1] = x.y; Iv[2] = y.x; Iv[3] = y.y;
+            } else {
+                for (int j = 0; j < 4; ++j)
+                    if (hh[j] < H) Iv[j] = Irow[hh[j]];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (hh[j] < H && tau_cell_count(a, T, pn, hh[j], tau, w[j], Iv[j])) {
+                    int slot = atomicAdd(&q_n, 1);
+                    q_h[slot] = hh[j];
+                    q_w[slot] = (int)w[j];
+                }
+            }
+            if (full) {
+                const longlong2 z = make_longlong2(0, 0);
+                *(longlong2 *)(dCrow + hh[0]) = z; *(longlong2 *)(dCrow + hh[2]) = z;
+                *(longlong2 *)(dArow + hh[0]) = z; *(longlong2 *)(dArow + hh[2]) = z;
+            } else {
+                for (int j = 0; j < 4; ++j)
+                    if (hh[j] < H) { dCrow[hh[j]] = 0; dArow[hh[j]] = 0; }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // LDS only: queue length visible to everyone
+        const int nq = q_n;
+        const bool last = q0 + (int)(gridDim.x * TB) >= groups;
+        if (nq >= QGO || (last && nq > 0)) {   // block-uniform
+            __syncthreads();   // the zero stores above are complete before queued compartments are stored again
+            for (int k = threadIdx.x; k < nq; k += TB) {
+                const int h = q_h[k];
+                int64_t oc, oa;
+                tau_cell_events(a, T, rep, pn, h, tau, Irow[h], (uint32_t)q_w[k], oc, oa, cnt, sS, &sTot);
+                if (oc != 0) dCrow[h] = oc;
+                if (oa != 0) dArow[h] = oa;
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) q_n = 0;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+    __syncthreads();
     for (int i = 0; i < 6; ++i)
         if (cnt[i]) atomicAdd(&sc[i], (unsigned long long)cnt[i]);
     __syncthreads();
