@@ -519,7 +519,7 @@ static __device__ __forceinline__ void tau_cell_events(const VgxTauArgs &a, cons
             }
             if (sn_hit < 0) continue;
             births += 1;
-            atomicAdd(&sS[sn_hit], (unsigned long long)(-1ll));
+            if (sn_hit < 4) cnt[8 + sn_hit] -= 1; else atomicAdd(&sS[sn_hit], (unsigned long long)(-1ll));
             tau_row(a, rep, 1, 0, hn, pn, sn_hit, 0);
         } else if (u < t4 || r_mig == 0.0) n_mut += 1;
         else n_mig += 1;
@@ -588,9 +588,9 @@ static __device__ __forceinline__ void tau_cell_events(const VgxTauArgs &a, cons
     const int64_t own = births - rec - samp - mut_done;
     ownChk = own + migrants;
     ownApp = own;
-    if (rec + samp != 0) atomicAdd(&sS[st], (unsigned long long)(rec + samp));
+    if (rec + samp != 0) { if (st < 4) cnt[8 + st] += rec + samp; else atomicAdd(&sS[st], (unsigned long long)(rec + samp)); }
     int64_t dt = births - rec - samp;
-    if (dt != 0) atomicAdd(sTot, (unsigned long long)dt);
+    cnt[6] += dt;   // delta of totalInfectious[pn], added to the block's total at the end
 }
 
 // LDS budget of the draw kernel's tables (doubles, then int32); 0 = tables stay in global memory
@@ -671,7 +671,9 @@ extern "C" __global__ void __launch_bounds__(TB) vgx_tau_draw_kernel(VgxTauArgs 
         T.rtr = g_rtr; T.wtr = g_wtr; T.rmig = g_rmig; T.mutcum = a.mutcum; T.cdf = gcdf; T.r1 = nullptr;
     }
     __syncthreads();
-    int64_t cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    // per-thread tallies: [0..5] event counters, [6] delta of totalInfectious[pn], [8..11] susceptible deltas of the first
+    // four groups (all compartments of a population add to the same few addresses: no atomics per event)
+    int64_t cnt[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     const double tau = a.tau[rep];
     // Phase A: a thread looks at four neighbouring haplotypes (32 B loads and stores); their first uniforms are the
     // four words of ONE Philox block keyed like the compartment streams, counter (group index, step, retry | 0xFFFFF).
@@ -758,8 +760,16 @@ extern "C" __global__ void __launch_bounds__(TB) vgx_tau_draw_kernel(VgxTauArgs 
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
     __syncthreads();
-    for (int i = 0; i < 6; ++i)
-        if (cnt[i]) atomicAdd(&sc[i], (unsigned long long)cnt[i]);
+    for (int i = 0; i < 12; ++i) {   // wave-level sums first, then one LDS atomic per wave and tally
+        if (i == 7) continue;
+        long long v = cnt[i];
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+        if ((threadIdx.x & 63) == 0 && v != 0) {
+            if (i < 6) atomicAdd(&sc[i], (unsigned long long)v);
+            else if (i == 6) atomicAdd(&sTot, (unsigned long long)v);
+            else atomicAdd(&sS[i - 8], (unsigned long long)v);
+        }
+    }
     __syncthreads();
     if (threadIdx.x < 6 && sc[threadIdx.x]) atomicAdd((unsigned long long *)&a.cnt_try[(int64_t)rep * 8 + threadIdx.x], sc[threadIdx.x]);
     if (threadIdx.x < S && sS[threadIdx.x])
