@@ -2,13 +2,11 @@
 //
 // seq_sum / seq_scan add f64 values held one-per-lane STRICTLY IN LANE ORDER, i.e. with the rounding
 // sequence of the reference's serial loops (fast_choose.pxi:25-28, src/_BirthDeath.pyx:519-528, 537-546).
-// seq_sum: one v_fmac_f64 (DPP row_newbcast) per step, see below.  seq_scan: each step is
-// {v_readlane lo, v_readlane hi, v_add_f64}; the scan additionally narrows EXEC to lanes >= k
+// Both are chains of v_fmac_f64 with a DPP row_newbcast source (acc = fma(w[k], 1.0, acc) rounds exactly like
+// acc + w[k]), one VALU instruction per step; the scan additionally narrows EXEC to lanes >= k
 // before the add, so lane L stops accumulating after its own term and ends with the serial prefix
-// w[0]+...+w[L] (no compare/select instructions on the dependent chain).  Two SGPR pairs (vcc and
-// s[10:11]) alternate so that the VALU-writes-SGPR -> VALU-reads-SGPR distance of gfx940+ (2 wait states)
-// is always covered by the next step's lane reads.  The blocks must be reached with all 64 lanes active
-// (wave-uniform control flow); EXEC is restored to all-ones at the end of every block.
+// w[0]+...+w[L] (no compare/select instructions on the dependent chain).  The blocks must be reached with all 64
+// lanes active (wave-uniform control flow); EXEC is restored to all-ones at the end of every block.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -33,23 +31,6 @@ static __device__ __forceinline__ int64_t bcast_i64(int64_t v, int k) {
     int hi = __builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)v >> 32), k);
     return (int64_t)(((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo);
 }
-
-// ---- 8 chain steps per asm block; lanes K = B+0 .. B+7 -------------------------------------------
-#define VGX_RLA(K) "v_readlane_b32 vcc_lo, %1, " K "\n\tv_readlane_b32 vcc_hi, %2, " K "\n\t"
-#define VGX_RLB(K) "v_readlane_b32 s10, %1, " K "\n\tv_readlane_b32 s11, %2, " K "\n\t"
-#define VGX_ADDA "v_add_f64 %0, %0, vcc\n\t"
-#define VGX_ADDB "v_add_f64 %0, %0, s[10:11]\n\t"
-#define VGX_EX(K) "s_lshl_b64 exec, -1, " K "\n\t"
-
-#define VGX_SCAN8(B)                                                                                  \
-    "s_nop 1\n\t" VGX_RLA(#B "+0") VGX_RLB(#B "+1") VGX_EX(#B "+0") VGX_ADDA VGX_RLA(#B "+2")            \
-        VGX_EX(#B "+1") VGX_ADDB VGX_RLB(#B "+3") VGX_EX(#B "+2") VGX_ADDA VGX_RLA(#B "+4")              \
-            VGX_EX(#B "+3") VGX_ADDB VGX_RLB(#B "+5") VGX_EX(#B "+4") VGX_ADDA VGX_RLA(#B "+6")          \
-                VGX_EX(#B "+5") VGX_ADDB VGX_RLB(#B "+7") VGX_EX(#B "+6") VGX_ADDA "s_nop 0\n\t"         \
-                    VGX_EX(#B "+7") VGX_ADDB "s_mov_b64 exec, -1\n\t"
-
-#define VGX_SCAN_GROUP(B) \
-    if (n > B && k0 < B + 8) asm volatile(VGX_SCAN8(B) : "+v"(acc) : "v"(lo), "v"(hi) : "vcc", "scc", "s10", "s11");
 
 // ---- seq_sum: ONE VALU instruction per chain step ------------------------------------------------------------
 // v_fmac_f64 with a DPP source (gfx90a+ "DP ALU DPP", row_newbcast only): acc = fma(v[lane k of the row], 1.0, acc),
@@ -99,16 +80,41 @@ static __device__ __forceinline__ double seq_sum(double v, int n, double acc) {
     return __hiloint2double(hi, lo);
 }
 
+// ---- seq_scan: the same fmac chain with EXEC narrowed to lanes >= k before step k ---------------------------------
+// All lanes of a row run the identical chain; narrowing EXEC (s_lshl_b64 exec, -1, k) before step k makes lane L stop
+// after its own term, so it ends with the serial prefix w[0] + ... + w[L].  A DPP instruction needs 5 wait states after
+// an EXEC write (s_nop 4); other waves of the SIMD issue meanwhile, so at >= 3 waves/SIMD a step costs one VALU slot
+// (measured, tools/scan_dpp_test.hip: 3.8 ns per step and SIMD against 6.9 ns for the 2 x v_readlane + v_add_f64 step
+// used before, bit-identical results).
+#define VGX_FX(K, LANE, RM) "s_lshl_b64 exec, -1, " #LANE "\n\ts_nop 4\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:" #K " row_mask:" #RM " bank_mask:0xf\n\t"
+#define VGX_FSCAN8_LO(B, RM) "s_nop 1\n\t" VGX_FX(0, B+0, RM) VGX_FX(1, B+1, RM) VGX_FX(2, B+2, RM) VGX_FX(3, B+3, RM) \
+    VGX_FX(4, B+4, RM) VGX_FX(5, B+5, RM) VGX_FX(6, B+6, RM) VGX_FX(7, B+7, RM) "s_mov_b64 exec, -1\n\t"
+#define VGX_FSCAN8_HI(B, RM) "s_nop 1\n\t" VGX_FX(8, B+8, RM) VGX_FX(9, B+9, RM) VGX_FX(10, B+10, RM) VGX_FX(11, B+11, RM) \
+    VGX_FX(12, B+12, RM) VGX_FX(13, B+13, RM) VGX_FX(14, B+14, RM) VGX_FX(15, B+15, RM) "s_mov_b64 exec, -1\n\t"
+#define VGX_FSCAN_ROW(R, B, RM, RMNEXT)                                                                     \
+    if (n > B && k0 < B + 8) asm volatile(VGX_FSCAN8_LO(B, RM) : "+v"(acc) : "v"(v), "v"(one) : "scc");      \
+    if (n > B + 8 && k0 < B + 16) asm volatile(VGX_FSCAN8_HI(B, RM) : "+v"(acc) : "v"(v), "v"(one) : "scc"); \
+    if (R < 3 && n > B + 16) {                                                                              \
+        int alo = __double2loint(acc), ahi = __double2hiint(acc);                                           \
+        alo = __builtin_amdgcn_update_dpp(alo, alo, 0x142, RMNEXT, 0xf, false);                             \
+        ahi = __builtin_amdgcn_update_dpp(ahi, ahi, 0x142, RMNEXT, 0xf, false);                             \
+        acc = __hiloint2double(ahi, alo);                                                                   \
+    }
+
 // lane L (k0 <= L < n) gets carry + v[k0'] + ... + v[L] with k0' = k0 rounded down to a multiple of 8:
-// lanes in [k0', k0) and lanes >= n MUST hold +0.0.  Lanes >= n-1 end with the total.
+// lanes in [k0', k0) and lanes >= n MUST hold +0.0.  Lanes >= n-1 end with the total.  carry must be wave-uniform;
+// all 64 lanes active.
 static __device__ __forceinline__ double seq_scan(double v, int n, double carry, int k0 = 0) {
-    int lo = __double2loint(v), hi = __double2hiint(v);
     n = __builtin_amdgcn_readfirstlane(n);
     k0 = __builtin_amdgcn_readfirstlane(k0);
     double acc = carry;
-    VGX_SCAN_GROUP(0) VGX_SCAN_GROUP(8) VGX_SCAN_GROUP(16) VGX_SCAN_GROUP(24)
-    VGX_SCAN_GROUP(32) VGX_SCAN_GROUP(40) VGX_SCAN_GROUP(48) VGX_SCAN_GROUP(56)
-    return acc;
+    if (n <= 0) return acc;
+    const double one = 1.0;
+    VGX_FSCAN_ROW(0, 0, 0x1, 0x2) VGX_FSCAN_ROW(1, 16, 0x2, 0x4) VGX_FSCAN_ROW(2, 32, 0x4, 0x8) VGX_FSCAN_ROW(3, 48, 0x8, 0x0)
+    // rows after the last one that ran still hold the carry: give every lane >= n the total
+    int tlo = __builtin_amdgcn_readlane(__double2loint(acc), n - 1);
+    int thi = __builtin_amdgcn_readlane(__double2hiint(acc), n - 1);
+    return ((int)__lane_id() >= n) ? __hiloint2double(thi, tlo) : acc;
 }
 
 // ---- order-free wave scans on the DPP network (no LDS traffic) ----------------------------------------------
