@@ -127,6 +127,8 @@ int vgx_simulate_tau(vgx_engine *e, int64_t iterations, int64_t sample_size, flo
 
 /* ---- results -------------------------------------------------------------------------------- */
 int vgx_get_counters(vgx_engine *e, int64_t replicate, vgx_counters *out);
+/* All replicates at once: out[replicate][4] = ev_ptr, loop_iterations, restarts, tau events drawn. */
+int vgx_get_counters_all(vgx_engine *e, int64_t *out);
 /* Copies log rows [first, first+count) into the caller's Events arrays (events.pxi:26-29). */
 int vgx_get_events(vgx_engine *e, int64_t replicate, int64_t first, int64_t count, double *times,
                    int64_t *types, int64_t *haplotypes, int64_t *populations, int64_t *newHaplotypes,

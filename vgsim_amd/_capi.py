@@ -77,6 +77,7 @@ SIGNATURES = {
     "vgx_simulate_direct": (C.c_int, [_H, C.c_int64, C.c_int64, C.c_float, C.c_int64, C.POINTER(VgxRunOpts)]),
     "vgx_simulate_tau": (C.c_int, [_H, C.c_int64, C.c_int64, C.c_float, C.c_int64, C.POINTER(VgxRunOpts)]),
     "vgx_get_counters": (C.c_int, [_H, C.c_int64, C.POINTER(VgxCounters)]),
+    "vgx_get_counters_all": (C.c_int, [_H, _I]),
     "vgx_get_events": (C.c_int, [_H, C.c_int64, C.c_int64, C.c_int64, _F, _I, _I, _I, _I, _I]),
     "vgx_get_lockdowns": (C.c_int, [_H, C.c_int64, C.c_int64, _I, _I, _F, _I]),
     "vgx_get_multievents": (C.c_int, [_H, C.c_int64, C.c_int64, _I, _F, _I, _I, _I, _I, _I, _I]),
@@ -255,6 +256,12 @@ class HipEngine:
                                                      _p(cols["newPopulations"]), C.byref(n)))
         cols["times"] = times
         return cols
+
+    def counters_all(self):
+        """``[R, 4]`` int64: ev_ptr, loop_iterations, restarts, tau events drawn of every replicate."""
+        out = np.zeros((self.R, 4), dtype=np.int64)
+        self._check(self.lib.vgx_get_counters_all(self.handle, _p(out)))
+        return out
 
     def _absorb(self, m, replicate=0, tau=False, mev_base=0):
         self.get_state(m, replicate)

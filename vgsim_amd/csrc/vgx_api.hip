@@ -1048,6 +1048,19 @@ extern "C" int vgx_get_counters(vgx_engine *e, int64_t replicate, vgx_counters *
     return VGX_OK;
 }
 
+extern "C" int vgx_get_counters_all(vgx_engine *e, int64_t *out /* [R][4]: ev_ptr, loop_iterations, restarts, tau events drawn */) {
+    if (!e || !out) return VGX_ERR_ARG;
+    if (!e->sc_host_valid) return fail(e, VGX_ERR_ARG, "vgx_get_counters_all: no simulate call yet");
+    for (int64_t r = 0; r < e->R; r++) {
+        const VgxRepScalars &s = e->sc_host[(size_t)r];
+        out[r * 4 + 0] = s.ev_ptr;
+        out[r * 4 + 1] = s.loop_iterations;
+        out[r * 4 + 2] = s.restarts;
+        out[r * 4 + 3] = e->last_was_tau ? s.traj_next : 0;
+    }
+    return VGX_OK;
+}
+
 extern "C" int vgx_get_events(vgx_engine *e, int64_t replicate, int64_t first, int64_t count, double *times,
                               int64_t *types, int64_t *haplotypes, int64_t *populations, int64_t *newHaplotypes,
                               int64_t *newPopulations) {

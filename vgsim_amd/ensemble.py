@@ -79,9 +79,8 @@ class Ensemble:
                                          int(attempts), C.byref(o))
         eng._check(rc)
         res = EnsembleResult(self.R)
-        for r in range(self.R):
-            c = eng.counters(r)
-            res.events[r], res.loop_iterations[r], res.restarts[r] = c.ev_ptr, c.loop_iterations, c.restarts
+        call = eng.counters_all()
+        res.events[:], res.loop_iterations[:], res.restarts[:] = call[:, 0], call[:, 1], call[:, 2]
         res.kernel_ms = eng.last_kernel_ms
         self.traj_shape = (self.R, int(traj_points), m.popNum, 2) if traj_points > 0 else None
         return res
@@ -114,11 +113,9 @@ class Ensemble:
                                       int(attempts), C.byref(o))
         eng._check(rc)
         res = EnsembleResult(self.R)
-        res.events_drawn = np.zeros(self.R, dtype=np.int64)
-        for r in range(self.R):
-            c = eng.counters(r)
-            res.events[r], res.loop_iterations[r], res.restarts[r] = c.ev_ptr, c.loop_iterations, c.restarts
-            res.events_drawn[r] = c.reserved[0]
+        call = eng.counters_all()
+        res.events[:], res.loop_iterations[:], res.restarts[:] = call[:, 0], call[:, 1], call[:, 2]
+        res.events_drawn = call[:, 3].copy()
         res.kernel_ms = eng.last_kernel_ms
         self.traj_shape = None
         return res
