@@ -761,10 +761,10 @@ extern "C" int vgx_simulate_tau(vgx_engine *e, int64_t iterations, int64_t sampl
     rc = 0;
     rc |= ensure(e, e->r_locrec, (size_t)(R * VGX_LOC_CAP * 2) * 4);
     rc |= ensure(e, e->r_loctime, (size_t)(R * VGX_LOC_CAP) * 8);
-    rc |= ensure(e, e->t_I, (size_t)(R * P * H) * 8);
+    rc |= ensure(e, e->t_I, (size_t)(R * P * H) * 4);
     rc |= ensure(e, e->t_S, (size_t)(R * P * S) * 8);
-    rc |= ensure(e, e->t_dChk, (size_t)(R * P * H) * 8);
-    rc |= ensure(e, e->t_dApp, (size_t)(R * P * H) * 8);
+    rc |= ensure(e, e->t_dChk, (size_t)(R * P * H) * 4);
+    rc |= ensure(e, e->t_dApp, (size_t)(R * P * H) * 4);
     rc |= ensure(e, e->t_dSi, (size_t)(R * P * S) * 8);
     rc |= ensure(e, e->t_dTot, (size_t)(R * P) * 8);
     rc |= ensure(e, e->t_totInf, (size_t)(R * P) * 8);
@@ -814,9 +814,14 @@ extern "C" int vgx_simulate_tau(vgx_engine *e, int64_t iterations, int64_t sampl
     for (int64_t pn = 0; pn < P; pn++) lock32[(size_t)pn] = (int32_t)h.lockdownON[(size_t)pn];
     auto upload_state = [&](int64_t r, const std::vector<int64_t> &inf, const std::vector<int64_t> &sus) -> int {
         std::vector<int64_t> tot((size_t)P, 0);
+        std::vector<int32_t> inf32((size_t)(P * H));   // device layout: 4 bytes per compartment (sizes < 2^31, checked above)
         for (int64_t pn = 0; pn < P; pn++)
-            for (int64_t hn = 0; hn < H; hn++) tot[(size_t)pn] += inf[(size_t)(pn * H + hn)];
-        HIPCHECK(e, hipMemcpy((int64_t *)e->t_I.p + r * P * H, inf.data(), (size_t)(P * H) * 8, hipMemcpyHostToDevice));
+            for (int64_t hn = 0; hn < H; hn++) {
+                int64_t v = inf[(size_t)(pn * H + hn)];
+                tot[(size_t)pn] += v;
+                inf32[(size_t)(pn * H + hn)] = (int32_t)v;
+            }
+        HIPCHECK(e, hipMemcpy((int32_t *)e->t_I.p + r * P * H, inf32.data(), (size_t)(P * H) * 4, hipMemcpyHostToDevice));
         HIPCHECK(e, hipMemcpy((int64_t *)e->t_S.p + r * P * S, sus.data(), (size_t)(P * S) * 8, hipMemcpyHostToDevice));
         HIPCHECK(e, hipMemcpy((int64_t *)e->t_totInf.p + r * P, tot.data(), (size_t)P * 8, hipMemcpyHostToDevice));
         return VGX_OK;
@@ -831,7 +836,7 @@ extern "C" int vgx_simulate_tau(vgx_engine *e, int64_t iterations, int64_t sampl
     VgxTauArgs a{};
     a.p = e->dp;
     a.R = R;
-    a.I = (int64_t *)e->t_I.p; a.S = (int64_t *)e->t_S.p; a.dChk = (int64_t *)e->t_dChk.p; a.dApp = (int64_t *)e->t_dApp.p;
+    a.I = (int32_t *)e->t_I.p; a.S = (int64_t *)e->t_S.p; a.dChk = (int32_t *)e->t_dChk.p; a.dApp = (int32_t *)e->t_dApp.p;
     a.dSi = (int64_t *)e->t_dSi.p; a.dTot = (int64_t *)e->t_dTot.p; a.totInf = (int64_t *)e->t_totInf.p;
     a.gI = (int64_t *)e->t_gI.p; a.cd = (double *)e->t_cd.p; a.lockON = (int32_t *)e->t_lock.p; a.F = (double *)e->t_F.p;
     a.effMig = (double *)e->t_eff.p; a.Aeff = (double *)e->t_Aeff.p; a.Gout = (double *)e->t_Gout.p;
@@ -1172,7 +1177,11 @@ extern "C" int vgx_get_state(vgx_engine *e, int64_t replicate, vgx_state *out) {
         const VgxRepScalars &s = e->sc_host[(size_t)replicate];
         HostState &h = e->hs;
         if (out->susceptible) HIPCHECK(e, hipMemcpy(out->susceptible, (int64_t *)e->t_S.p + replicate * P * S, (size_t)(P * S) * 8, hipMemcpyDeviceToHost));
-        if (out->infectious) HIPCHECK(e, hipMemcpy(out->infectious, (int64_t *)e->t_I.p + replicate * P * H, (size_t)(P * H) * 8, hipMemcpyDeviceToHost));
+        if (out->infectious) {
+            std::vector<int32_t> inf32((size_t)(P * H));
+            HIPCHECK(e, hipMemcpy(inf32.data(), (int32_t *)e->t_I.p + replicate * P * H, (size_t)(P * H) * 4, hipMemcpyDeviceToHost));
+            for (int64_t i = 0; i < P * H; i++) out->infectious[i] = inf32[(size_t)i];
+        }
         if (out->initial_susceptible) memcpy(out->initial_susceptible, h.initial_susceptible.data(), (size_t)(P * S) * 8);
         if (out->initial_infectious) memcpy(out->initial_infectious, h.initial_infectious.data(), (size_t)(P * H) * 8);
         std::vector<int64_t> tot((size_t)P);

@@ -119,10 +119,10 @@ struct VgxDirectArgs {
 struct VgxTauArgs {
     VgxDevParams p;
     int64_t R;
-    int64_t *I;          // [R][P][H] infectious
+    int32_t *I;          // [R][P][H] infectious (tau population sizes are < 2^31: 4 bytes per compartment)
     int64_t *S;          // [R][P][S] susceptible
-    int64_t *dChk;       // [R][P][H] infectious deltas as the reference's bounds check books them (pyx:2473)
-    int64_t *dApp;       // [R][P][H] infectious deltas as UpdateCompartmentCounts_tau applies them (pyx:2548)
+    int32_t *dChk;       // [R][P][H] infectious deltas as the reference's bounds check books them (pyx:2473)
+    int32_t *dApp;       // [R][P][H] infectious deltas as UpdateCompartmentCounts_tau applies them (pyx:2548)
     int64_t *inc;        // [R][inc_cap] individuals entering another compartment: cell index | (applied-only << 62)
     int64_t inc_cap;
     unsigned long long *inc_n;  // [R][VGX_INC_SHARDS]

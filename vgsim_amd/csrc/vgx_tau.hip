@@ -204,7 +204,7 @@ extern "C" __global__ void __launch_bounds__(TB) vgx_tau_prep_kernel(VgxTauArgs 
 #define MIGIN_TB 1024   // waves of a block share one LDS tile of infectious counts: more waves per tile hide the scalar loads
 #endif
 extern "C" __global__ void __launch_bounds__(MIGIN_TB) vgx_tau_migin_kernel(const double *__restrict__ AeffT_all,
-                                                                      const int64_t *__restrict__ I_all,
+                                                                      const int32_t *__restrict__ I_all,
                                                                       double *__restrict__ migIn_all,
                                                                       const int32_t *__restrict__ active, int P, int Pp,
                                                                       int H) {
@@ -212,7 +212,7 @@ extern "C" __global__ void __launch_bounds__(MIGIN_TB) vgx_tau_migin_kernel(cons
     if (!active[rep]) return;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int64_t *__restrict__ I = I_all + (int64_t)rep * P * H;
+    const int32_t *__restrict__ I = I_all + (int64_t)rep * P * H;
     const double *__restrict__ AeffT = AeffT_all + (int64_t)rep * P * Pp;
     double *__restrict__ out = migIn_all + (int64_t)rep * P * H;
     extern __shared__ __attribute__((aligned(16))) unsigned char tsm[];
@@ -223,7 +223,7 @@ extern "C" __global__ void __launch_bounds__(MIGIN_TB) vgx_tau_migin_kernel(cons
         __syncthreads();
         for (int idx = threadIdx.x; idx < P * TH; idx += MIGIN_TB) {
             int spn = idx >> 6, h = idx & 63;
-            It[idx] = (h0 + h < H) ? (int32_t)I[(int64_t)spn * H + h0 + h] : 0;
+            It[idx] = (h0 + h < H) ? I[(int64_t)spn * H + h0 + h] : 0;
         }
         __syncthreads();
         for (int tp0 = wave * TPW; tp0 < P; tp0 += (MIGIN_TB / 64) * TPW) {
@@ -255,7 +255,7 @@ extern "C" __global__ void __launch_bounds__(TB) vgx_tau_drift_kernel(VgxTauArgs
     const VgxDevParams &p = a.p;
     const int P = p.P, S = p.S, H = p.H, sites = p.sites, C = p.C, CB = p.CB;
     const int lane = threadIdx.x & 63;
-    const int64_t *I = a.I + (int64_t)rep * P * H + (int64_t)pn * H;
+    const int32_t *I = a.I + (int64_t)rep * P * H + (int64_t)pn * H;
     const int64_t *Sus = a.S + (int64_t)rep * P * S + (int64_t)pn * S;
     __shared__ double sdS[64];      // S <= 64 susceptibility groups
     __shared__ unsigned long long smin;
@@ -303,7 +303,7 @@ extern "C" __global__ void __launch_bounds__(TB) vgx_tau_drift_kernel(VgxTauArgs
                 const int b0 = hh & ~(3 << sh);
                 int64_t nb = 0;
                 if (live) {
-                    nb = I[b0] + I[b0 + (1 << sh)] + I[b0 + (2 << sh)] + I[b0 + (3 << sh)] - Icell;
+                    nb = (int64_t)I[b0] + (int64_t)I[b0 + (1 << sh)] + (int64_t)I[b0 + (2 << sh)] + (int64_t)I[b0 + (3 << sh)] - Icell;
                 }
                 drift += l_mutp[s * 3] * (double)nb;
                 continue;
@@ -680,8 +680,8 @@ extern "C" __global__ void __launch_bounds__(TB) vgx_tau_draw_kernel(VgxTauArgs 
     // The few compartments that drew events are queued in LDS.  Phase B: the queue is worked off with all lanes busy
     // (one queued compartment per thread), instead of one divergent lane per wavefront.
     const int H = p.H;
-    const int64_t *Irow = a.I + ((int64_t)rep * P + pn) * H;
-    int64_t *dCrow = a.dChk + ((int64_t)rep * P + pn) * H, *dArow = a.dApp + ((int64_t)rep * P + pn) * H;
+    const int32_t *Irow = a.I + ((int64_t)rep * P + pn) * H;
+    int32_t *dCrow = a.dChk + ((int64_t)rep * P + pn) * H, *dArow = a.dApp + ((int64_t)rep * P + pn) * H;
     const uint32_t key[2] = {(uint32_t)a.seeds[rep] ^ ((uint32_t)a.attempt[rep] * 0x9E3779B9u),
                              (uint32_t)((uint64_t)a.seeds[rep] >> 32) ^ 0x85EBCA6Bu};
     const int groups = ((H + 255) / 256) * 64;   // 4 haplotypes per thread, 256 per wavefront chunk
@@ -695,51 +695,51 @@ extern "C" __global__ void __launch_bounds__(TB) vgx_tau_draw_kernel(VgxTauArgs 
     __syncthreads();
     const int L = threadIdx.x & 63;
     const int wave_off = (int)(threadIdx.x & ~63u) * 4;
-    // the loads of the next tile are issued before this tile is worked on
-    longlong2 nx = make_longlong2(0, 0), ny = make_longlong2(0, 0);
+    // the load of the next tile is issued before this tile is worked on
+    int4 nx = make_int4(0, 0, 0, 0);
     {
         const int chunk = blockIdx.x * TB * 4 + wave_off;
-        if (chunk + 256 <= H) { nx = *(const longlong2 *)(Irow + chunk + 2 * L); ny = *(const longlong2 *)(Irow + chunk + 128 + 2 * L); }
+        if (chunk + 256 <= H) nx = *(const int4 *)(Irow + chunk + 4 * L);
     }
     for (int q0 = blockIdx.x * TB; q0 < groups; q0 += gridDim.x * TB) {   // persistent over tiles: the table staging is amortised
         const int q = q0 + threadIdx.x;
-        // the 256 haplotypes of a wavefront's chunk are split so that every 16-byte load/store instruction of the wave
-        // covers one contiguous KiB: thread (lane L) owns haplotypes chunk + {2L, 2L+1, 128+2L, 129+2L}
+        // a thread owns four consecutive haplotypes (16 bytes of counts): every load/store instruction of the wave covers
+        // one contiguous KiB
         const int chunk = q0 * 4 + wave_off;
-        const longlong2 x = nx, y = ny;
+        const int4 x = nx;
         {
             const int nchunk = (q0 + gridDim.x * TB) * 4 + wave_off;
-            if (nchunk + 256 <= H) { nx = *(const longlong2 *)(Irow + nchunk + 2 * L); ny = *(const longlong2 *)(Irow + nchunk + 128 + 2 * L); }
+            if (nchunk + 256 <= H) nx = *(const int4 *)(Irow + nchunk + 4 * L);
         }
         if (chunk < H) {
-            int hh[4] = {chunk + 2 * L, chunk + 2 * L + 1, chunk + 128 + 2 * L, chunk + 129 + 2 * L};
+            const int h0 = chunk + 4 * L;
             const bool full = chunk + 256 <= H;
             const uint64_t gidx = (uint64_t)pn * (uint64_t)groups + (uint64_t)q;
             const uint32_t ctr[4] = {(uint32_t)gidx, (uint32_t)(gidx >> 32), ctr_step, ctr_retry};
             uint32_t w[4];
             vgx_philox4x32(ctr, key, w);
-            int64_t Iv[4] = {0, 0, 0, 0};
+            int Iv[4] = {0, 0, 0, 0};
             if (full) {
-                Iv[0] = x.x; Iv[1] = x.y; Iv[2] = y.x; Iv[3] = y.y;
+                Iv[0] = x.x; Iv[1] = x.y; Iv[2] = x.z; Iv[3] = x.w;
             } else {
                 for (int j = 0; j < 4; ++j)
-                    if (hh[j] < H) Iv[j] = Irow[hh[j]];
+                    if (h0 + j < H) Iv[j] = Irow[h0 + j];
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                if (hh[j] < H && tau_cell_count(a, T, pn, hh[j], tau, w[j], Iv[j])) {
+                if (h0 + j < H && tau_cell_count(a, T, pn, h0 + j, tau, w[j], (int64_t)Iv[j])) {
                     int slot = atomicAdd(&q_n, 1);
-                    q_h[slot] = hh[j];
+                    q_h[slot] = h0 + j;
                     q_w[slot] = (int)w[j];
                 }
             }
             if (full) {
-                const longlong2 z = make_longlong2(0, 0);
-                *(longlong2 *)(dCrow + hh[0]) = z; *(longlong2 *)(dCrow + hh[2]) = z;
-                *(longlong2 *)(dArow + hh[0]) = z; *(longlong2 *)(dArow + hh[2]) = z;
+                const int4 z = make_int4(0, 0, 0, 0);
+                *(int4 *)(dCrow + h0) = z;
+                *(int4 *)(dArow + h0) = z;
             } else {
                 for (int j = 0; j < 4; ++j)
-                    if (hh[j] < H) { dCrow[hh[j]] = 0; dArow[hh[j]] = 0; }
+                    if (h0 + j < H) { dCrow[h0 + j] = 0; dArow[h0 + j] = 0; }
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // LDS only: queue length visible to everyone
@@ -750,9 +750,9 @@ extern "C" __global__ void __launch_bounds__(TB) vgx_tau_draw_kernel(VgxTauArgs 
             for (int k = threadIdx.x; k < nq; k += TB) {
                 const int h = q_h[k];
                 int64_t oc, oa;
-                tau_cell_events(a, T, rep, pn, h, tau, Irow[h], (uint32_t)q_w[k], oc, oa, cnt, sS, &sTot);
-                if (oc != 0) dCrow[h] = oc;
-                if (oa != 0) dArow[h] = oa;
+                tau_cell_events(a, T, rep, pn, h, tau, (int64_t)Irow[h], (uint32_t)q_w[k], oc, oa, cnt, sS, &sTot);
+                if (oc != 0) dCrow[h] = (int32_t)oc;
+                if (oa != 0) dArow[h] = (int32_t)oa;
             }
             __syncthreads();
             if (threadIdx.x == 0) q_n = 0;
@@ -817,8 +817,8 @@ extern "C" __global__ void __launch_bounds__(64) vgx_tau_scatter_kernel(VgxTauAr
     for (unsigned long long i = threadIdx.x; i < n; i += 64) {
         int64_t e = lst[i];
         int64_t cell = e & (((int64_t)1 << 62) - 1);
-        atomicAdd((unsigned long long *)&a.dApp[(int64_t)rep * PH + cell], 1ull);
-        if (!(e >> 62)) atomicAdd((unsigned long long *)&a.dChk[(int64_t)rep * PH + cell], 1ull);
+        atomicAdd(&a.dApp[(int64_t)rep * PH + cell], 1);
+        if (!(e >> 62)) atomicAdd(&a.dChk[(int64_t)rep * PH + cell], 1);
     }
     __syncthreads();
     if (threadIdx.x == 0) *cntp = 0;
@@ -835,7 +835,7 @@ extern "C" __global__ void __launch_bounds__(TB) vgx_tau_check_kernel(VgxTauArgs
     if (hn < H) {
         int64_t d = a.dChk[(int64_t)rep * P * H + (int64_t)pn * H + hn];
         if (d != 0) {
-            int64_t v = d + a.I[(int64_t)rep * P * H + (int64_t)pn * H + hn];
+            int64_t v = d + (int64_t)a.I[(int64_t)rep * P * H + (int64_t)pn * H + hn];
             bad = v < 0 || v > p.sizes[pn];
         }
     }
@@ -884,7 +884,7 @@ extern "C" __global__ void __launch_bounds__(TB) vgx_tau_commit_kernel(VgxTauArg
     if (hn < H) {
         int64_t off = (int64_t)rep * P * H + (int64_t)pn * H + hn;
         if (acc) {
-            int64_t dA = a.dApp[off];
+            int32_t dA = a.dApp[off];
             if (dA != 0) a.I[off] += dA;
         }
     }
