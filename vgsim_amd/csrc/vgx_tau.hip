@@ -830,13 +830,20 @@ extern "C" __global__ void __launch_bounds__(TB) vgx_tau_check_kernel(VgxTauArgs
     if (!a.active[rep] || a.accepted[rep]) return;
     const VgxDevParams &p = a.p;
     const int P = p.P, S = p.S, H = p.H;
-    const int hn = blockIdx.x * TB + threadIdx.x;
+    const int h0 = (blockIdx.x * TB + threadIdx.x) * 4;   // four compartments per thread (16-byte loads)
     bool bad = false;
-    if (hn < H) {
-        int64_t d = a.dChk[(int64_t)rep * P * H + (int64_t)pn * H + hn];
-        if (d != 0) {
-            int64_t v = d + (int64_t)a.I[(int64_t)rep * P * H + (int64_t)pn * H + hn];
-            bad = v < 0 || v > p.sizes[pn];
+    if (h0 < H) {
+        const int64_t off = (int64_t)rep * P * H + (int64_t)pn * H + h0;
+        int d[4] = {0, 0, 0, 0};
+        const bool full = h0 + 3 < H && (H & 3) == 0;
+        if (full) { int4 x = *(const int4 *)(a.dChk + off); d[0] = x.x; d[1] = x.y; d[2] = x.z; d[3] = x.w; }
+        else for (int j = 0; j < 4; ++j) if (h0 + j < H) d[j] = a.dChk[off + j];
+        if (d[0] | d[1] | d[2] | d[3]) {
+            for (int j = 0; j < 4; ++j)
+                if (d[j] != 0) {
+                    int64_t v = (int64_t)d[j] + (int64_t)a.I[off + j];
+                    bad = bad || v < 0 || v > p.sizes[pn];
+                }
         }
     }
     if (blockIdx.x == 0 && threadIdx.x < S) {
@@ -880,12 +887,19 @@ extern "C" __global__ void __launch_bounds__(TB) vgx_tau_commit_kernel(VgxTauArg
     if (!a.deciding[rep]) return;
     const int P = a.p.P, S = a.p.S, H = a.p.H;
     const bool acc = a.accepted[rep] && !a.error[rep];
-    const int hn = blockIdx.x * TB + threadIdx.x;
-    if (hn < H) {
-        int64_t off = (int64_t)rep * P * H + (int64_t)pn * H + hn;
-        if (acc) {
-            int32_t dA = a.dApp[off];
-            if (dA != 0) a.I[off] += dA;
+    const int h0 = (blockIdx.x * TB + threadIdx.x) * 4;   // four compartments per thread
+    if (h0 < H && acc) {
+        const int64_t off = (int64_t)rep * P * H + (int64_t)pn * H + h0;
+        if (h0 + 3 < H && (H & 3) == 0) {
+            int4 x = *(const int4 *)(a.dApp + off);
+            if (x.x | x.y | x.z | x.w) {
+                int4 v = *(const int4 *)(a.I + off);
+                v.x += x.x; v.y += x.y; v.z += x.z; v.w += x.w;
+                *(int4 *)(a.I + off) = v;
+            }
+        } else {
+            for (int j = 0; j < 4; ++j)
+                if (h0 + j < H) { int32_t dA = a.dApp[off + j]; if (dA != 0) a.I[off + j] += dA; }
         }
     }
     if (blockIdx.x == 0 && threadIdx.x < S) {
@@ -945,7 +959,7 @@ extern "C" __global__ void __launch_bounds__(64) vgx_tau_finish_kernel(VgxTauArg
         hipLaunchKernelGGL(vgx_##name##_kernel, grid, block, 0, s, *a);                          \
         return hipGetLastError();                                                                \
     }
-#define CELL_GRID dim3((unsigned)((a->p.H + TB - 1) / TB), (unsigned)a->p.P, (unsigned)a->R)
+#define CELL_GRID dim3((unsigned)((a->p.H + 4 * TB - 1) / (4 * TB)), (unsigned)a->p.P, (unsigned)a->R)   /* 4 compartments per thread */
 #define SUS_GRID dim3((unsigned)((a->p.P * a->p.S * a->p.S + TB - 1) / TB), (unsigned)a->R)
 TAU_LAUNCH(tau_eff, dim3((unsigned)a->p.P, (unsigned)a->R), dim3(TB))
 TAU_LAUNCH(tau_prep, dim3((unsigned)a->R), dim3(TB))
