@@ -300,11 +300,10 @@ extern "C" __global__ void __launch_bounds__(TB) vgx_tau_drift_kernel(VgxTauArgs
             if (a.mut_uniform && l_site_flat[s]) {
                 // the three derived states of this site are equally likely for every source: add the three
                 // neighbouring counts as integers, convert and scale once
-                const int b0 = hh & ~(3 << sh);
-                int64_t nb = 0;
-                if (live) {
-                    nb = (int64_t)I[b0] + (int64_t)I[b0 + (1 << sh)] + (int64_t)I[b0 + (2 << sh)] + (int64_t)I[b0 + (3 << sh)] - Icell;
-                }
+                // the other three alleles of this site are hh with the site's two bits XORed by 1, 2, 3; their sum stays
+                // below the population size (< 2^31)
+                int nb = 0;
+                if (live) nb = I[hh ^ (1 << sh)] + I[hh ^ (2 << sh)] + I[hh ^ (3 << sh)];
                 drift += l_mutp[s * 3] * (double)nb;
                 continue;
             }
