@@ -53,12 +53,12 @@ def make_simulator(seed):
     return s
 
 
-def cpu_baseline(seconds_target=45.0):
-    """The oracle (oracle/vgx_oracle.c, dense = the reference's own O(H*S*P)-per-event algorithm) on the same
-    workload, one host core, bounded sample."""
+def cpu_sample(seed, seconds_target):
+    """One bounded sample of the config-3 workload on the oracle (dense = the reference's own O(H*S*P)-per-event
+    algorithm), one core: (events, seconds, start-up events)."""
     from oracle import oracle
     oracle.build()
-    sim = make_simulator(2020)
+    sim = make_simulator(seed)
     m = sim.simulation
     t0 = time.time()
     oracle.run_direct(m, 101, 10 ** 12, -1, 200)      # includes PrepareParameters/UpdateAllRates and Restarts
@@ -69,10 +69,31 @@ def cpu_baseline(seconds_target=45.0):
     t2 = time.time()
     oracle.run_direct(m, n2, 10 ** 12, -1, 200)       # continues the same trajectory
     t3 = time.time()
-    done = m.events.ptr - n1
-    out = {"value": done / max(t3 - t2, 1e-9), "unit": "events/s", "cores": 1, "kind": "port",
+    return m.events.ptr - n1, t3 - t2, n1
+
+
+def cpu_baseline(seconds_target=45.0):
+    """The oracle (oracle/vgx_oracle.c) on the same workload: one host core (the headline baseline) and, beside it,
+    one independent seeded process per available core (a CPU user's way to run an ensemble)."""
+    import subprocess
+    from oracle import oracle
+    oracle.build()
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = max(1, min(cores, 64))
+    # the per-core processes start first (plain interpreters: nothing of this process' GPU state is inherited)
+    code = ("import sys; sys.path.insert(0, %r); import bench; "
+            "d, t, n = bench.cpu_sample(int(sys.argv[1]), %f); print(d, t)" % (ROOT, seconds_target * 0.6))
+    procs = [subprocess.Popen([sys.executable, "-c", code, str(3000 + k)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)
+             for k in range(cores)] if cores > 1 else []
+    outs = [pr.communicate()[0].decode().split() for pr in procs]
+    rates = [float(o[0]) / max(float(o[1]), 1e-9) for o in outs if len(o) == 2]
+    done, secs, n1 = cpu_sample(2020, seconds_target)
+    out = {"value": done / max(secs, 1e-9), "unit": "events/s", "cores": 1, "kind": "port",
            "sample": "%d events of one config-3 trajectory (seed 2020) after a %d-event start, oracle in the "
-                     "reference's dense mode, %.1f s" % (done, n1, t3 - t2)}
+                     "reference's dense mode, %.1f s" % (done, n1, secs)}
+    if rates:
+        out["all_cores"] = {"value": sum(rates), "unit": "events/s", "cores": len(rates),
+                            "sample": "one independent process per available core, same workload, seeds 3000.."}
     # backward pass (GetGenealogy) of the oracle on a 300 000-event chain of the same model (forward run in the oracle's
     # occupied-haplotypes-only mode, which is bit-identical to the dense one)
     sim2 = make_simulator(2020)
