@@ -55,3 +55,37 @@ def test_config3_ensemble_invariants():
         if res.restarts[r] == 0:
             assert res.loop_iterations[r] == res.events[r] + st.migNonPlus
     ens.close()
+
+
+def test_config3_spread_occupancy_exact_oracle_and_fast():
+    """4096 occupied haplotypes per population (lists of 64 tiles: tile sums, two-level lower bound, row-wise running
+    sums, chunked tree scans): EXACT is bit-identical to the oracle's occupied-only mode, FAST has the same integer
+    columns and compartments."""
+    from vgsim_amd import _capi
+    from oracle import oracle as oracle_mod
+    oracle_mod.build()
+
+    def spread(seed):
+        s = c3(seed)
+        m = s.simulation
+        rng = np.random.default_rng(99)
+        for pn in range(64):
+            haps = rng.choice(m.hapNum, size=4096, replace=False)
+            m.infectious[pn, haps] = rng.integers(1, 4, size=4096)
+            m.susceptible[pn, 0] -= int(m.infectious[pn].sum())
+        return s
+
+    n = 3000
+    ex = spread(11)
+    with helpers.quiet():
+        ex.simulate(n, sample_size=10 ** 9)
+    ref = spread(11).simulation
+    assert oracle_mod.run_direct(ref, n, 10 ** 9, -1, 200, sparse=True, log_mode=oracle_mod.LOG_PORTABLE) == 0
+    helpers.assert_models_equal(ex.simulation, ref, "config3 spread")
+    fa = spread(11)
+    with helpers.quiet():
+        fa.simulate(n, sample_size=10 ** 9, mode="fast")
+    a, b = helpers.chain_of(fa.simulation), helpers.chain_of(ex.simulation)
+    assert np.array_equal(a[1:, :n], b[1:, :n])
+    np.testing.assert_allclose(a[0, :n], b[0, :n], rtol=1e-9, atol=0.0)
+    assert np.array_equal(fa.simulation.infectious, ex.simulation.infectious)
