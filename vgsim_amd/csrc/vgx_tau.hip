@@ -403,12 +403,40 @@ static __device__ __forceinline__ void tau_row(const VgxTauArgs &a, int rep, int
 // migrant: applied only, pyx:2473 vs pyx:2548).  Appended to the replicate's list; vgx_tau_scatter_kernel adds them
 // after the draw kernel, when every compartment has stored its own deltas.
 // The list is sharded by thread block (VGX_INC_SHARDS counters) so that appends do not serialise on one address.
-static __device__ __forceinline__ void tau_incoming(const VgxTauArgs &a, int rep, int64_t cell, bool applied_only) {
+#define VGX_INC_STAGE 512   // entries staged in LDS per thread block before one reservation in the global list
+struct IncStage { int n; int64_t e[VGX_INC_STAGE]; unsigned long long base; };
+
+static __device__ __forceinline__ void tau_incoming_global(const VgxTauArgs &a, int rep, int64_t entry) {
     const int shard = (int)((blockIdx.x + gridDim.x * blockIdx.y) & (VGX_INC_SHARDS - 1));
     const int64_t scap = a.inc_cap / VGX_INC_SHARDS;
     unsigned long long slot = atomicAdd(&a.inc_n[(int64_t)rep * VGX_INC_SHARDS + shard], 1ull);
-    if ((int64_t)slot < scap)
-        a.inc[(int64_t)rep * a.inc_cap + (int64_t)shard * scap + (int64_t)slot] = cell | (applied_only ? ((int64_t)1 << 62) : 0);
+    if ((int64_t)slot < scap) a.inc[(int64_t)rep * a.inc_cap + (int64_t)shard * scap + (int64_t)slot] = entry;
+}
+// Appends go to the block's LDS stage (an LDS atomic instead of a returning global atomic per mutant / migrant in the
+// divergent part of the kernel); tau_incoming_flush moves the stage to the global list with one reservation.
+static __device__ __forceinline__ void tau_incoming(const VgxTauArgs &a, IncStage *st, int rep, int64_t cell, bool applied_only) {
+    const int64_t entry = cell | (applied_only ? ((int64_t)1 << 62) : 0);
+    int slot = atomicAdd(&st->n, 1);
+    if (slot < VGX_INC_STAGE) st->e[slot] = entry;
+    else tau_incoming_global(a, rep, entry);
+}
+// block-uniform call
+static __device__ __forceinline__ void tau_incoming_flush(const VgxTauArgs &a, IncStage *st, int rep) {
+    __syncthreads();
+    const int n = st->n < VGX_INC_STAGE ? st->n : VGX_INC_STAGE;
+    if (n > 0) {
+        const int shard = (int)((blockIdx.x + gridDim.x * blockIdx.y) & (VGX_INC_SHARDS - 1));
+        const int64_t scap = a.inc_cap / VGX_INC_SHARDS;
+        if (threadIdx.x == 0) st->base = atomicAdd(&a.inc_n[(int64_t)rep * VGX_INC_SHARDS + shard], (unsigned long long)n);
+        __syncthreads();
+        const unsigned long long base = st->base;
+        int64_t *dst = a.inc + (int64_t)rep * a.inc_cap + (int64_t)shard * scap;
+        for (int i = threadIdx.x; i < n; i += blockDim.x)
+            if ((int64_t)(base + i) < scap) dst[base + i] = st->e[i];   // a full shard is detected by the scatter kernel
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) st->n = 0;
+    __syncthreads();
 }
 
 // Per-block tables of the draw kernel (a block works on ONE population): class parameters, this population's
@@ -462,6 +490,7 @@ static __device__ __forceinline__ int tau_cell_count(const VgxTauArgs &a, const 
 
 static __device__ __forceinline__ void tau_cell_events(const VgxTauArgs &a, const TauTab &T, int rep, int pn, int hn, double tau,
                                                        int64_t Icell, uint32_t first_word, int64_t &ownChk, int64_t &ownApp, int64_t *cnt,
+                                                       IncStage *stage,
                                                        unsigned long long *sS /* LDS [S]: this population's susceptible deltas */,
                                                        unsigned long long *sTot /* LDS: delta of totalInfectious[pn] */) {
     const VgxDevParams &p = a.p;
@@ -557,7 +586,7 @@ static __device__ __forceinline__ void tau_cell_events(const VgxTauArgs &a, cons
         if (ss < 0) continue;
         int nh = tau_mutate(sites, hn, ss, ii);
         mut_done += 1;
-        tau_incoming(a, rep, (int64_t)pn * H + nh, false);
+        tau_incoming(a, stage, rep, (int64_t)pn * H + nh, false);
         tau_row(a, rep, 1, 3, hn, pn, nh, 0);
     }
     // ---- migrants (pyx:2464-2474 / 2541-2550): target population and susceptibility group, by bisection in the
@@ -576,7 +605,7 @@ static __device__ __forceinline__ void tau_cell_events(const VgxTauArgs &a, cons
         int tp = lo / S, ts = lo % S;
         if (tp == pn || !(cdf[nch - 1] > 0.0)) continue;
         migrants += 1;
-        tau_incoming(a, rep, (int64_t)tp * H + hn, true);
+        tau_incoming(a, stage, rep, (int64_t)tp * H + hn, true);
         atomicAdd((unsigned long long *)&dS[tp * S + ts], (unsigned long long)(-1ll));
         atomicAdd((unsigned long long *)&a.dTot[(int64_t)rep * P + tp], 1ull);
         tau_row(a, rep, 1, 5, hn, pn, ts, tp);
@@ -690,7 +719,8 @@ extern "C" __global__ void __launch_bounds__(TB) vgx_tau_draw_kernel(VgxTauArgs 
     // is worked off with all lanes busy and the queued compartments' deltas are stored again.
     enum { QCAP = 8 * TB, QGO = QCAP - 4 * TB };
     __shared__ int q_n, q_h[QCAP], q_w[QCAP];
-    if (threadIdx.x == 0) q_n = 0;
+    __shared__ IncStage stage;
+    if (threadIdx.x == 0) { q_n = 0; stage.n = 0; }
     __syncthreads();
     const int L = threadIdx.x & 63;
     const int wave_off = (int)(threadIdx.x & ~63u) * 4;
@@ -749,12 +779,13 @@ extern "C" __global__ void __launch_bounds__(TB) vgx_tau_draw_kernel(VgxTauArgs 
             for (int k = threadIdx.x; k < nq; k += TB) {
                 const int h = q_h[k];
                 int64_t oc, oa;
-                tau_cell_events(a, T, rep, pn, h, tau, (int64_t)Irow[h], (uint32_t)q_w[k], oc, oa, cnt, sS, &sTot);
+                tau_cell_events(a, T, rep, pn, h, tau, (int64_t)Irow[h], (uint32_t)q_w[k], oc, oa, cnt, &stage, sS, &sTot);
                 if (oc != 0) dCrow[h] = (int32_t)oc;
                 if (oa != 0) dArow[h] = (int32_t)oa;
             }
             __syncthreads();
             if (threadIdx.x == 0) q_n = 0;
+            tau_incoming_flush(a, &stage, rep);   // at most QCAP queued compartments per round; overflow goes straight to the list
         }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
