@@ -1,0 +1,95 @@
+"""Seeded random models (GPU): shapes, rate heterogeneity, mutation weights, susceptibility groups, immunity
+transitions, migration matrices, sampling multipliers and lockdown thresholds drawn at random through the public
+setters; the HIP engine must reproduce the oracle bit for bit in EXACT mode and on the integer columns in FAST mode.
+Finds the corner cases hand-written models miss (empty populations, zero rates, single-group models, populations
+beyond one 64-lane tile)."""
+import numpy as np
+import pytest
+
+import helpers
+
+pytestmark = pytest.mark.gpu
+
+
+def build(seed):
+    from vgsim_amd import Simulator
+    rng = np.random.default_rng(seed)
+    sites = int(rng.integers(0, 4))
+    P = int(rng.choice([1, 2, 3, 5, 9, 66]))
+    S = int(rng.integers(1, 4))
+    with helpers.quiet():
+        s = Simulator(number_of_sites=sites, populations_number=P, number_of_susceptible_groups=S, seed=int(rng.integers(0, 2 ** 31)))
+    H = 4 ** sites
+    s.set_transmission_rate(float(rng.uniform(1.5, 4.0)))
+    s.set_recovery_rate(float(rng.uniform(0.3, 1.2)))
+    s.set_sampling_rate(float(rng.uniform(0.01, 0.4)))
+    for _ in range(int(rng.integers(0, 4))):          # a few haplotypes with their own rates -> several rate classes
+        h = int(rng.integers(0, H))
+        s.set_transmission_rate(float(rng.uniform(0.5, 5.0)), haplotype=h)
+        if rng.random() < 0.5:
+            s.set_recovery_rate(float(rng.uniform(0.2, 1.5)), haplotype=h)
+    if sites:
+        s.set_mutation_rate(float(rng.choice([0.0, 0.01, 0.2, 0.8])))
+        if rng.random() < 0.5:
+            s.set_mutation_rate(float(rng.uniform(0.0, 0.5)), mutation=int(rng.integers(0, sites)))
+        if rng.random() < 0.5:
+            w = [int(x) for x in rng.integers(0, 4, size=4)]
+            if sum(w) - max(w) > 0 and all(sum(w) - w[i] > 0 for i in range(4)):
+                s.set_mutation_probabilities(w)
+    for g in range(1, S):
+        s.set_susceptibility(float(rng.uniform(0.0, 1.0)), susceptibility_type=g)
+        if rng.random() < 0.7:
+            s.set_immunity_transition(float(rng.uniform(0.0, 0.1)), source=g, target=int(rng.integers(0, S)))
+    if S > 1:
+        s.set_susceptibility_type(int(rng.integers(0, S)))
+        for _ in range(2):
+            s.set_susceptibility_type(int(rng.integers(0, S)), haplotype=int(rng.integers(0, H)))
+    s.set_population_size(int(rng.integers(2000, 200000)))
+    if P > 1:
+        s.set_population_size(int(rng.integers(500, 5000)), population=int(rng.integers(0, P)))
+        s.set_total_migration_probability(float(rng.uniform(0.0, 0.3)))
+        if rng.random() < 0.5:
+            a, b = (int(x) for x in rng.choice(P, size=2, replace=False))
+            s.set_migration_probability(float(rng.uniform(0.0, 0.002)), source=a, target=b)
+        s.set_contact_density(float(rng.uniform(0.5, 2.0)), population=int(rng.integers(0, P)))
+        s.set_sampling_multiplier(float(rng.uniform(0.5, 3.0)), population=int(rng.integers(0, P)))
+    for _ in range(int(rng.integers(0, 3))):
+        start = float(rng.uniform(0.001, 0.05))
+        s.set_npi([float(rng.uniform(0.0, 0.8)), start, float(rng.uniform(0.0, start))], population=int(rng.integers(0, P)))
+    return s, int(rng.integers(300, 4000))
+
+
+def drive_oracle(oracle_mod, sim, n):
+    rc = oracle_mod.run_direct(sim.simulation, n, 10 ** 9, -1, 200, log_mode=oracle_mod.LOG_PORTABLE)
+    return rc
+
+
+@pytest.mark.parametrize("seed", list(range(int(__import__("os").environ.get("VGX_FUZZ_SEEDS", "40")))))
+def test_random_model(oracle_mod, seed):
+    hip, n = build(seed)
+    ref, _ = build(seed)
+    fast, _ = build(seed)
+    rc = drive_oracle(oracle_mod, ref, n)
+    if rc != 0:   # zero-weight abort of the reference (fast_choose.pxi:5-13): the engine must report it too
+        with pytest.raises(RuntimeError):
+            with helpers.quiet():
+                hip.simulate(n, sample_size=10 ** 9)
+        return
+    with helpers.quiet():
+        hip.simulate(n, sample_size=10 ** 9)
+        fast.simulate(n, sample_size=10 ** 9, mode="fast")
+    helpers.assert_models_equal(hip.simulation, ref.simulation, "fuzz %d" % seed)
+    ptr = ref.simulation.events.ptr
+    a, b = helpers.chain_of(fast.simulation), helpers.chain_of(ref.simulation)
+    assert fast.simulation.events.ptr == ptr
+    assert np.array_equal(a[1:, :ptr], b[1:, :ptr]), "fast: " + helpers.describe_first_diff(a[1:], b[1:], ptr)
+    np.testing.assert_allclose(a[0, :ptr], b[0, :ptr], rtol=1e-9, atol=0.0)
+    assert np.array_equal(fast.simulation.infectious, ref.simulation.infectious)
+    # the backward pass continues the simulation's stream from the position the kernel reports
+    if ref.simulation.sCounter >= 2:
+        want = oracle_mod.run_genealogy(ref.simulation, None)
+        if want["rc"] == 0:   # several roots (lineages that never coalesce) are outside what the pass defines
+            with helpers.quiet():
+                hip.genealogy(None)
+            assert np.array_equal(hip.simulation.tree, want["tree"]) and np.array_equal(hip.simulation.times, want["times"])
+            assert hip.simulation.mig.nodeId == want["mig_node"].tolist() and hip.simulation.mut.nodeId == want["mut_node"].tolist()
