@@ -94,6 +94,16 @@ def cpu_baseline(seconds_target=45.0):
     if rates:
         out["all_cores"] = {"value": sum(rates), "unit": "events/s", "cores": len(rates),
                             "sample": "one independent process per available core, same workload, seeds 3000.."}
+    # one trajectory of config 2 (H = P = 1: the regime where a CPU core is at its best)
+    from vgsim_amd import Simulator
+    with contextlib.redirect_stdout(io.StringIO()):
+        c2 = Simulator(number_of_sites=0, populations_number=1, number_of_susceptible_groups=1, seed=2020)
+    c2.set_transmission_rate(4.0); c2.set_recovery_rate(1.5); c2.set_sampling_rate(0.3)
+    t6 = time.time()
+    oracle.run_direct(c2.simulation, 1000000, 10 ** 12, -1, 200)
+    t7 = time.time()
+    out["config2"] = {"value": c2.simulation.events.ptr / max(t7 - t6, 1e-9), "unit": "events/s", "cores": 1,
+                      "events": int(c2.simulation.events.ptr)}
     # backward pass (GetGenealogy) of the oracle on a 300 000-event chain of the same model (forward run in the oracle's
     # occupied-haplotypes-only mode, which is bit-identical to the dense one)
     sim2 = make_simulator(2020)
@@ -165,6 +175,25 @@ def genealogy_leg(device, events=300000):
             "seconds": t1 - t0}
 
 
+def single_leg(device):
+    """One trajectory at a time (the classic API): latency of the sequential event loop on one wavefront."""
+    import numpy as np
+    from vgsim_amd import Simulator
+    from vgsim_amd.ensemble import Ensemble
+    out = {"workload": "a single replicate (one wavefront): events/s of device time"}
+    with contextlib.redirect_stdout(io.StringIO()):
+        c2 = Simulator(number_of_sites=0, populations_number=1, number_of_susceptible_groups=1, seed=2020)
+    c2.set_transmission_rate(4.0); c2.set_recovery_rate(1.5); c2.set_sampling_rate(0.3)
+    for name, sim, n in (("config3", make_simulator(2020), 100000), ("config2", c2, 200000)):
+        ens = Ensemble(sim, 1, device=device)
+        res = None
+        for it in range(2):
+            res = ens.simulate(n, sample_size=10 ** 12, record_events=True, seeds=np.array([2020 + it], dtype=np.int64))
+        out[name] = res.total_events / (res.kernel_ms * 1e-3)
+        ens.close()
+    return out
+
+
 def fast_leg(device, replicates, events, traj_points):
     """The headline workload (natural occupancy) in FAST mode, device time of one launch after a warm-up."""
     import numpy as np
@@ -182,26 +211,30 @@ def fast_leg(device, replicates, events, traj_points):
     return out
 
 
-def c2_leg(device, replicates=16384, events=100000):
+def c2_leg(device):
     """BASELINE config 2 (H=1, P=1, S=1, N=1e6): latency-bound — one dependent chain per event; reported as
-    events/s per replicate and replicates in flight."""
+    events/s per replicate and replicates in flight, for the wavefront-per-replicate kernel and for the
+    lane-per-replicate kernel (vgx_lanes.hip) that the engine picks for minimal models in very large ensembles."""
     import numpy as np
     from vgsim_amd import Simulator
     from vgsim_amd.ensemble import Ensemble
     with contextlib.redirect_stdout(io.StringIO()):
         s = Simulator(number_of_sites=0, populations_number=1, number_of_susceptible_groups=1, seed=2020)
     s.set_transmission_rate(4.0); s.set_recovery_rate(1.5); s.set_sampling_rate(0.3)
-    ens = Ensemble(s, replicates, device=device)
-    res = None
-    for it in range(2):
-        res = ens.simulate(events, sample_size=10 ** 12, record_events=True,
-                           seeds=2020 + it * replicates + np.arange(replicates, dtype=np.int64))
-    ms = res.kernel_ms
-    out = {"workload": "BASELINE config 2: 1 haplotype x 1 population, b=4.0 d=1.5 s=0.3, N=1e6",
-           "replicates_in_flight": replicates, "events_per_replicate": events,
-           "value": res.total_events / (ms * 1e-3), "unit": "events/s (device time)",
-           "events_per_s_per_replicate": res.total_events / (ms * 1e-3) / replicates, "kernel_ms_per_launch": ms}
-    ens.close()
+    out = {"workload": "BASELINE config 2: 1 haplotype x 1 population, b=4.0 d=1.5 s=0.3, N=1e6"}
+    for key, kernel, replicates, events in (("wave", "wave", 16384, 100000), ("lane", "auto", 262144, 10000)):
+        ens = Ensemble(s, replicates, device=device)
+        res = None
+        for it in range(2):
+            res = ens.simulate(events, sample_size=10 ** 12, record_events=True, kernel=kernel,
+                               seeds=2020 + it * replicates + np.arange(replicates, dtype=np.int64))
+        ms = res.kernel_ms
+        out[key] = {"replicates_in_flight": replicates, "events_per_replicate": events,
+                    "value": res.total_events / (ms * 1e-3), "unit": "events/s (device time)",
+                    "events_per_s_per_replicate": res.total_events / (ms * 1e-3) / replicates, "kernel_ms_per_launch": ms}
+        ens.close()
+    out["value"] = max(out["wave"]["value"], out["lane"]["value"])
+    out["unit"] = "events/s (device time)"
     return out
 
 
@@ -279,7 +312,7 @@ def main():
     extra_legs = (("fast_mode", lambda d: fast_leg(d, R, N, a.traj_points)),
                   ("spread_occupancy", lambda d: spread_leg(d, "exact", replicates=4096, events=5000)),
                   ("spread_occupancy_fast", lambda d: spread_leg(d, "fast", replicates=4096)),
-                  ("config2", c2_leg), ("genealogy", genealogy_leg), ("tau_leap", tau_leg))
+                  ("config2", c2_leg), ("genealogy", genealogy_leg), ("single_trajectory", single_leg), ("tau_leap", tau_leg))
     if a.only:
         print(json.dumps({a.only: dict(extra_legs)[a.only](local)}), flush=True)
         return
@@ -409,7 +442,7 @@ def main():
         if tau is not None:
             line["tau_leap"] = tau
         if world == 1 and not a.no_extra:
-            for name, fn in extra_legs[:5]:
+            for name, fn in extra_legs[:6]:
                 try:
                     line[name] = fn(local)
                 except Exception as ex:

@@ -86,7 +86,9 @@ typedef struct vgx_run_opts {
                                 1 = FAST (order-free sums: class-aggregated infection rate, integer prefix search,
                                 factored BirthRate, tree scans; same random stream and event semantics, identical
                                 integer columns on the same seed).  Ignored by vgx_simulate_tau. */
-    int64_t reserved[3];
+    int64_t kernel;          /* direct path: 0 = automatic, 1 = one replicate per wavefront (vgx_direct.hip), 2 = one replicate
+                                per lane (vgx_lanes.hip; small models: popNum <= 16, popNum*hapNum <= 1024, susNum <= 8, EXACT) */
+    int64_t reserved[2];
 } vgx_run_opts;
 
 /* Per-replicate results of the last simulate call. */

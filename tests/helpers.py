@@ -105,7 +105,7 @@ def check_against_golden(model, name, exact_time=True, rtol_time=1e-12):
     assert np.array_equal(model.infectious, inf)
 
 
-def run_case_hip(name, phases_limit=None, mode=None):
+def run_case_hip(name, phases_limit=None, mode=None, kernel=None):
     """Drive a case through the product path: Simulator -> BirthDeathModel -> ctypes -> libvgx.so -> HIP.
     ``mode='fast'`` runs the direct phases in the engine's FAST mode."""
     from vgsim_amd import Simulator
@@ -116,6 +116,8 @@ def run_case_hip(name, phases_limit=None, mode=None):
             kw = dict(kw)
             if mode is not None and kw.get("method", "direct") == "direct":
                 kw["mode"] = mode
+            if kernel is not None and kw.get("method", "direct") == "direct":
+                kw["kernel"] = kernel
             sim.simulate(**kw)
     return sim
 

@@ -79,6 +79,12 @@ def test_random_model(oracle_mod, seed):
         hip.simulate(n, sample_size=10 ** 9)
         fast.simulate(n, sample_size=10 ** 9, mode="fast")
     helpers.assert_models_equal(hip.simulation, ref.simulation, "fuzz %d" % seed)
+    m0 = ref.simulation
+    if m0.popNum <= 16 and m0.popNum * m0.hapNum <= 1024:   # the one-replicate-per-lane kernel on the same model
+        lane, _ = build(seed)
+        with helpers.quiet():
+            lane.simulate(n, sample_size=10 ** 9, kernel="lane")
+        helpers.assert_models_equal(lane.simulation, ref.simulation, "fuzz %d (lane kernel)" % seed)
     ptr = ref.simulation.events.ptr
     a, b = helpers.chain_of(fast.simulation), helpers.chain_of(ref.simulation)
     assert fast.simulation.events.ptr == ptr

@@ -39,8 +39,8 @@ class VgxState(C.Structure):
 
 class VgxRunOpts(C.Structure):
     _fields_ = [("record_events", C.c_int64), ("max_loop_factor", C.c_int64), ("traj_points", C.c_int64),
-                ("traj_t0", C.c_double), ("traj_t1", C.c_double), ("mode", C.c_int64),
-                ("reserved", C.c_int64 * 3)]
+                ("traj_t0", C.c_double), ("traj_t1", C.c_double), ("mode", C.c_int64), ("kernel", C.c_int64),
+                ("reserved", C.c_int64 * 2)]
 
 
 class VgxCounters(C.Structure):

@@ -118,14 +118,15 @@ class Simulator:
         self.simulation.set_infectious(amount, source_type, target_haplotype, population)
 
     # the drop-in boundary (if:799-829)
-    def simulate(self, iterations=1000, sample_size=None, epidemic_time=-1, method='direct', attempts=200, mode='exact'):
+    def simulate(self, iterations=1000, sample_size=None, epidemic_time=-1, method='direct', attempts=200, mode='exact',
+                 kernel='auto'):
         if sample_size is None:
             sample_size = iterations
         if epidemic_time is None:
             epidemic_time = -1
         start_time = time.time()
         if method == 'direct':
-            self.simulation.SimulatePopulation(iterations, sample_size, epidemic_time, attempts, mode=mode)
+            self.simulation.SimulatePopulation(iterations, sample_size, epidemic_time, attempts, mode=mode, kernel=kernel)
             self.simulation.Stats(time.time() - start_time)
         elif method == 'tau':
             self.simulation.SimulatePopulation_tau(iterations, sample_size, epidemic_time, attempts)

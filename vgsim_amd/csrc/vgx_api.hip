@@ -18,6 +18,7 @@
 
 // launchers defined next to their kernels (vgx_direct.hip)
 extern "C" hipError_t vgxi_launch_direct(const VgxDirectArgs *a, size_t lds, hipStream_t stream);
+extern "C" hipError_t vgxi_launch_lanes(const VgxDirectArgs *a, const VgxLaneWs *w, hipStream_t stream);
 extern "C" size_t vgxi_direct_lds_bytes(int P, int S, int C, int CB);
 extern "C" hipError_t vgxi_launch_init_reps(const VgxDevRep *r, int P, int S, int64_t R, const int32_t *s_nocc,
                                             const int32_t *s_hap, const int32_t *s_cls, const int64_t *s_cnt,
@@ -65,7 +66,7 @@ struct vgx_engine {
     DevBuf p_cls, p_suscType, p_mRate, p_hapMutType, p_bRate, p_susc, p_cd, p_cs, p_ctm, p_cbidx, p_cstype, p_cbb, p_cbsig,
         p_sizes, p_cdBefore, p_cdAfter, p_startLD, p_endLD, p_sampMult, p_actualSizes, p_mig, p_suscTrans,
         p_suscCumul;
-    DevBuf r_popD, r_popI, r_sus, r_immSrc, r_birthC, r_xC, r_effMig, r_nocc, r_lhap, r_lcls, r_lcnt, r_ltsum, r_sc, r_seeds,
+    DevBuf r_popD, r_popI, r_sus, r_immSrc, r_birthC, r_xC, r_effMig, r_nocc, r_lhap, r_lcls, r_lcnt, r_ltsum, r_lanews, r_sc, r_seeds,
         r_evtime, r_evcols, r_locrec, r_loctime, r_traj, r_prof;
     // tau-leaping (dense compartments)
     DevBuf t_I, t_S, t_dChk, t_dApp, t_dSi, t_dTot, t_totInf, t_gI, t_cd, t_lock, t_F, t_eff, t_Aeff, t_Gout, t_dS,
@@ -86,6 +87,7 @@ struct vgx_engine {
     VgxDevParams dp{};
     VgxDevRep dr{};
     int64_t cap = 0, evcap = 0, ev_base = 0, ev_ptr0 = 0, traj_points = 0;
+    bool last_used_lanes = false;
     int64_t last_ev_size = 0;
     std::vector<VgxRepScalars> sc_host;
     bool sc_host_valid = false;
@@ -625,8 +627,34 @@ static int direct_core(vgx_engine *e, int64_t iterations, int64_t sample_size, f
     a.fast = o.mode == 1 ? 1 : 0;
     a.lds_bytes = (int32_t)lds;
 
+    // Kernel choice: small models run one replicate per LANE (vgx_lanes.hip: the reference's serial loops, dense state);
+    // everything else one replicate per wavefront.  opts.kernel: 0 = automatic, 1 = wavefront, 2 = lane.
+    const int64_t H = e->d.hapNum, S = e->d.susNum;
+    const bool lane_ok = o.mode == 0 && P * H <= 1024 && P <= 16 && S <= 8 && H <= e->cap;
+    if (o.kernel == 2 && !lane_ok)
+        return fail(e, VGX_ERR_ARG, "vgx_simulate_direct: the lane-per-replicate kernel needs exact mode, popNum <= 16, "
+                                    "popNum * hapNum <= 1024 and susNum <= 8");
+    // measured (tools/probe_lanes.py): the lane kernel only wins for minimal models in very large ensembles (config 2 at
+    // 262 144 replicates: 2.4e9 vs 7.0e8 events/s); its state lives in HBM/L2, so every other shape is latency-bound
+    const bool use_lanes = o.kernel == 2 || (o.kernel == 0 && lane_ok && P * H * S <= 4 && R >= 65536);
+    VgxLaneWs ws{};
+    if (use_lanes) {
+        const int64_t PH = P * H;
+        const int64_t n_i = PH + P * S + 3 * P, n_d = P + 3 * PH + PH * S + P * S + 5 * P + P * P;
+        int rcw = ensure(e, e->r_lanews, (size_t)((n_i + n_d) * R) * 8);
+        if (rcw) return rcw;
+        int64_t *wi = (int64_t *)e->r_lanews.p;
+        ws.inf = wi; wi += PH * R; ws.sus = wi; wi += P * S * R; ws.totS = wi; wi += P * R; ws.totI = wi; wi += P * R; ws.lock = wi; wi += P * R;
+        double *wd = (double *)wi;
+        ws.cd = wd; wd += P * R; ws.birth = wd; wd += PH * R; ws.tE = wd; wd += PH * R; ws.hpr = wd; wd += PH * R;
+        ws.shpr = wd; wd += PH * S * R; ws.immSrc = wd; wd += P * S * R; ws.infP = wd; wd += P * R; ws.immP = wd; wd += P * R;
+        ws.popR = wd; wd += P * R; ws.migR = wd; wd += P * R; ws.maxEBM = wd; wd += P * R; ws.effMig = wd; wd += P * P * R;
+    }
+    e->last_used_lanes = use_lanes;
+
     HIPCHECK(e, hipEventRecord(e->ev0, e->stream));
-    HIPCHECK(e, vgxi_launch_direct(&a, lds, e->stream));
+    if (use_lanes) HIPCHECK(e, vgxi_launch_lanes(&a, &ws, e->stream));
+    else HIPCHECK(e, vgxi_launch_direct(&a, lds, e->stream));
     HIPCHECK(e, hipEventRecord(e->ev1, e->stream));
     HIPCHECK(e, hipStreamSynchronize(e->stream));
     HIPCHECK(e, hipEventElapsedTime(&e->last_ms, e->ev0, e->ev1));

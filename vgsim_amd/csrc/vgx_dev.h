@@ -115,6 +115,13 @@ struct VgxDirectArgs {
     int32_t pad_;
 };
 
+// Dense per-replicate state of the lane-per-replicate kernel (vgx_lanes.hip): element i of replicate r at [i * R + r].
+struct VgxLaneWs {
+    int64_t *inf, *sus, *totS, *totI, *lock;    // [P*H], [P*S], [P], [P], [P]
+    double *cd, *birth, *tE, *hpr, *shpr, *immSrc, *infP, *immP, *popR, *migR, *maxEBM, *effMig;
+    // [P], [P*H], [P*H], [P*H], [P*H*S], [P*S], [P] x 5, [P*P]
+};
+
 // Tau-leaping (vgx_tau.hip): dense compartment arrays per replicate, [R][P][H] / [R][P][S].
 struct VgxTauArgs {
     VgxDevParams p;

@@ -46,7 +46,7 @@ class Ensemble:
         self.engine.close()
 
     def simulate(self, iterations, sample_size=None, epidemic_time=-1, attempts=200, record_events=False,
-                 traj_points=0, traj_window=(0.0, 1.0), seeds=None, mode='exact'):
+                 traj_points=0, traj_window=(0.0, 1.0), seeds=None, mode='exact', kernel='auto'):
         """Direct Gillespie for every replicate from the model's current state (``SimulatePopulation`` semantics
         per replicate, pyx:396-429).  ``mode``: 'exact' (reference summation order, bit-exact) or 'fast'
         (order-free sums).  Returns an :class:`EnsembleResult`."""
@@ -75,6 +75,7 @@ class Ensemble:
         o.traj_points = int(traj_points)
         o.traj_t0, o.traj_t1 = float(traj_window[0]), float(traj_window[1])
         o.mode = 1 if mode == 'fast' else 0
+        o.kernel = {'auto': 0, 'wave': 1, 'lane': 2}[kernel]
         rc = eng.lib.vgx_simulate_direct(eng.handle, int(iterations), int(sample_size), float(np.float32(epidemic_time)),
                                          int(attempts), C.byref(o))
         eng._check(rc)
