@@ -363,19 +363,13 @@ __device__ void traj_emit(Lane &L, double t_new, bool final_fill) {
 
 }  // namespace
 
-extern "C" __global__ void __launch_bounds__(64) vgx_lanes_kernel(VgxDirectArgs a, VgxLaneWs w) {
-    const int64_t rep = (int64_t)blockIdx.x * 64 + threadIdx.x;
-    if (rep >= a.n_replicates) return;
+// Body shared by the two kernels below: `L` already knows where this lane's dense state lives.
+static __device__ __forceinline__ void lanes_body(const VgxDirectArgs &a, Lane &L, const int64_t rep) {
     const VgxDevParams &p = a.p;
     const VgxDevRep &r = a.r;
-    Lane L;
     L.p = &a.p;
     L.H = p.H; L.P = p.P; L.S = p.S; L.sites = p.sites;
-    L.R = a.n_replicates; L.rep = rep;
     const int H = L.H, P = L.P, S = L.S;
-    L.inf = w.inf; L.sus = w.sus; L.totS = w.totS; L.totI = w.totI; L.lock = w.lock;
-    L.cd = w.cd; L.birth = w.birth; L.tE = w.tE; L.hpr = w.hpr; L.shpr = w.shpr; L.immSrc = w.immSrc;
-    L.infP = w.infP; L.immP = w.immP; L.popR = w.popR; L.migR = w.migR; L.maxEBM = w.maxEBM; L.effMig = w.effMig;
 
     // ---- start state from the wave kernel's layout ----
     double *gD = r.popD + rep * PD_COUNT * P;
@@ -510,9 +504,49 @@ extern "C" __global__ void __launch_bounds__(64) vgx_lanes_kernel(VgxDirectArgs 
     sc->last_attempt = last_att; sc->last_attempt_loops = last_att_loops;
 }
 
+// state in HBM, interleaved across all replicates
+extern "C" __global__ void __launch_bounds__(64) vgx_lanes_kernel(VgxDirectArgs a, VgxLaneWs w) {
+    const int64_t rep = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (rep >= a.n_replicates) return;
+    Lane L;
+    L.R = a.n_replicates; L.rep = rep;
+    L.inf = w.inf; L.sus = w.sus; L.totS = w.totS; L.totI = w.totI; L.lock = w.lock;
+    L.cd = w.cd; L.birth = w.birth; L.tE = w.tE; L.hpr = w.hpr; L.shpr = w.shpr; L.immSrc = w.immSrc;
+    L.infP = w.infP; L.immP = w.immP; L.popR = w.popR; L.migR = w.migR; L.maxEBM = w.maxEBM; L.effMig = w.effMig;
+    lanes_body(a, L, rep);
+}
+
+// state in LDS (minimal models: the whole dense state of 64 replicates fits), interleaved across the 64 lanes
+extern "C" __global__ void __launch_bounds__(64) vgx_lanes_lds_kernel(VgxDirectArgs a) {
+    const int64_t rep = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lsm[];
+    if (rep >= a.n_replicates) return;   // no barrier in this kernel: lanes are independent
+    const int64_t P = a.p.P, H = a.p.H, S = a.p.S, PH = P * H;
+    Lane L;
+    L.R = 64; L.rep = threadIdx.x;
+    int64_t *wi = (int64_t *)lsm;
+    L.inf = wi; wi += PH * 64; L.sus = wi; wi += P * S * 64; L.totS = wi; wi += P * 64; L.totI = wi; wi += P * 64; L.lock = wi; wi += P * 64;
+    double *wd = (double *)wi;
+    L.cd = wd; wd += P * 64; L.birth = wd; wd += PH * 64; L.tE = wd; wd += PH * 64; L.hpr = wd; wd += PH * 64;
+    L.shpr = wd; wd += PH * S * 64; L.immSrc = wd; wd += P * S * 64; L.infP = wd; wd += P * 64; L.immP = wd; wd += P * 64;
+    L.popR = wd; wd += P * 64; L.migR = wd; wd += P * 64; L.maxEBM = wd; wd += P * 64; L.effMig = wd; wd += P * P * 64;
+    lanes_body(a, L, rep);
+}
+
 // ---- host-side launcher ----
+extern "C" __attribute__((visibility("hidden"))) size_t vgxi_lanes_elems(int64_t P, int64_t H, int64_t S) {
+    const int64_t PH = P * H;
+    return (size_t)((PH + P * S + 3 * P) + (P + 3 * PH + PH * S + P * S + 5 * P + P * P));   // 8-byte elements per replicate
+}
 extern "C" __attribute__((visibility("hidden"))) hipError_t vgxi_launch_lanes(const VgxDirectArgs *a, const VgxLaneWs *w, hipStream_t stream) {
     const unsigned blocks = (unsigned)((a->n_replicates + 63) / 64);
-    hipLaunchKernelGGL(vgx_lanes_kernel, dim3(blocks), dim3(64), 0, stream, *a, *w);
+    const size_t lds = vgxi_lanes_elems(a->p.P, a->p.H, a->p.S) * 64 * 8;
+    if (lds <= 40 * 1024) {   // four or more blocks per CU keep their state in LDS
+        hipError_t err = hipFuncSetAttribute((const void *)vgx_lanes_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (err != hipSuccess) return err;
+        hipLaunchKernelGGL(vgx_lanes_lds_kernel, dim3(blocks), dim3(64), lds, stream, *a);
+    } else {
+        hipLaunchKernelGGL(vgx_lanes_kernel, dim3(blocks), dim3(64), 0, stream, *a, *w);
+    }
     return hipGetLastError();
 }
