@@ -1,23 +1,26 @@
 """``Simulator``: the caller-facing facade, same constructor, setters and ``simulate`` signature as the
 reference's ``src/_interface.py:9-883`` (delegation to ``self.simulation``; ``simulate`` = if:799-829).
 
-Only the forward-simulation surface is provided; genealogy, plotting and file writers are outside the
-accelerated path ("out of scope") and raise ``NotImplementedError``.
+Every method of the reference's facade is present with its name, argument order and defaults; ``simulate`` takes two
+extra keywords (``mode``, ``kernel``).  The matplotlib helpers (if:639-797) live in ``_plots.py`` and import matplotlib
+only when called.
 """
 import sys
 import time
 from random import randrange
 
 from ._model import BirthDeathModel
+from ._plots import PlotMixin
 
 
-class Simulator:
+class Simulator(PlotMixin):
     def __init__(self, number_of_sites=0, populations_number=1, number_of_susceptible_groups=1, seed=None,
                  sampling_probability=False, memory_optimization=False, genome_length=int(1e6),
                  recombination_probability=0.0):
         if seed == None:  # noqa: E711 (reference semantics, if:40)
             seed = int(randrange(sys.maxsize))
         print('User seed:', seed)
+        self.fig = None
         self.simulation = BirthDeathModel(
             number_of_sites=number_of_sites, populations_number=populations_number,
             number_of_susceptible_groups=number_of_susceptible_groups, seed=seed,
@@ -135,7 +138,9 @@ class Simulator:
             print("Unknown method. Choose between 'direct' and 'tau'.")
 
     def genealogy(self, seed=None):
+        start_time = time.time()
         self.simulation.GetGenealogy(seed)
+        print(f"Getting genealogy time: {time.time() - start_time}")
 
     def get_tree(self):
         return self.simulation.get_tree()
@@ -168,6 +173,33 @@ class Simulator:
     def export_migrations(self, file_template=None, file_path=None):  # if:524-534
         self.simulation.export_migrations(file_template, file_path)
 
+    def print_basic_parameters(self):  # if:49-53
+        self.simulation.print_basic_parameters()
+
+    def print_populations(self, population=True, susceptibles=True, infectious=True, migration=True):  # if:55-72
+        self.simulation.print_populations(population=population, susceptibles=susceptibles, infectious=infectious,
+                                          migration=migration)
+
+    def print_immunity_model(self, immunity=True, transition=True):  # if:74-84
+        self.simulation.print_immunity_model(immunity, transition)
+
+    def print_all(self, basic_parameters=False, population=False, susceptible=False, infectious=False, migration=False,
+                  immunity_model=False, immunity=False, transition=False):
+        """if:92-126 (upstream passes an undefined name ``susceptibles`` to print_populations; ``susceptible`` is meant)."""
+        if basic_parameters:
+            self.simulation.print_basic_parameters()
+        if population or susceptible or infectious or migration:
+            self.simulation.print_populations(population=population, susceptibles=susceptible, infectious=infectious,
+                                              migration=migration)
+        if immunity or transition:
+            self.simulation.print_immunity_model(immunity=immunity, transition=transition)
+
+    def get_indexes_from_haplotype(self, haplotype):
+        """if:129-130 (upstream calls an undefined ``create_list_for_cycles``): haplotype numbers matching a pattern
+        such as ``'A*'``, an int, a list of those, or all for ``None``."""
+        import numpy as np
+        return np.array(sorted(self.simulation.calculate_indexes(haplotype, self.simulation.hapNum)))
+
     def print_mutations(self):
         self.simulation.print_mutations()
 
@@ -179,6 +211,46 @@ class Simulator:
 
     def set_chain_events(self, file_name):
         self.simulation.set_chain_events(file_name)
+
+    def export_settings(self, file_template="parameters"):  # if:569-574
+        self.simulation.export_settings(file_template)
+
+    def set_settings(self, file_template):  # if:478-482
+        self.simulation.set_settings(file_template)
+
+    def export_state(self, file_template="parameters"):
+        """if:576-581 (upstream calls undefined ``output_chain_events``/``output_settings``): the event chain as
+        ``<template>.npy`` plus the settings directory ``<template>/``."""
+        self.export_chain_events(file_template)
+        self.export_settings(file_template)
+
+    def set_state(self, file_template):  # if:484-489
+        self.set_chain_events(file_template)
+        self.set_settings(file_template)
+
+    def output_epidemiology_timelines(self, step=1000, output_file=False):  # if:555-567
+        if output_file:
+            self.simulation.output_epidemiology_timelines(step, output_file)
+        else:
+            return self.simulation.output_epidemiology_timelines(step, output_file)
+
+    def export_ts(self):  # if:583-584
+        return self.simulation.export_ts()
+
+    def print_recomb(self, left, right):
+        self.simulation.print_recomb(left, right)
+
+    def print_chain(self):
+        self.simulation.print_chain()
+
+    def print_tree(self):
+        self.simulation.print_tree()
+
+    def debug(self):
+        self.simulation.Debug()
+
+    def print_propensities(self):
+        self.simulation.PrintPropensities()
 
     def get_proportion(self):
         return self.simulation.get_proportion()

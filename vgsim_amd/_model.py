@@ -15,6 +15,8 @@ import sys
 
 import numpy as np
 
+from ._report import Reporting
+
 BIRTH, DEATH, SAMPLING, MUTATION, SUSCCHANGE, MIGRATION, MULTITYPE = range(7)  # events.pxi:2-8
 
 
@@ -108,7 +110,21 @@ class Migrations:
         return self.nodeId[id_mig], self.time[id_mig], self.oldPop[id_mig], self.newPop[id_mig]
 
 
-class BirthDeathModel:
+class Recombination:
+    """models.pxi:69-89: forward record of recombinant infections (filled by ``Birth``, pyx:593)."""
+
+    def __init__(self):
+        self.idevents, self.his, self.hi2s, self.nhis, self.posRecombs = [], [], [], [], []
+
+    def AddRecombination_forward(self, Id, hi, hi2, posRecomb, nhi):
+        self.idevents.append(int(Id))
+        self.his.append(int(hi))
+        self.hi2s.append(int(hi2))
+        self.nhis.append(int(nhi))
+        self.posRecombs.append(int(posRecomb))
+
+
+class BirthDeathModel(Reporting):
     COUNTERS = ("bCounter", "dCounter", "sCounter", "mCounter", "iCounter", "swapLockdown", "migPlus",
                 "migNonPlus")
 
@@ -167,6 +183,7 @@ class BirthDeathModel:
         self.events = Events()
         self.multievents = MultiEvents()
         self.loc = Lockdowns()
+        self.rec = Recombination()
 
         H, P, S = self.hapNum, self.popNum, self.susNum
         # parameters and their defaults: pyx:157-204
@@ -198,6 +215,10 @@ class BirthDeathModel:
         self.samplingMultiplier = np.ones(P, dtype=float)
         self.suscepTransition = np.zeros((S, S), dtype=float)
         self.migrationRates = np.zeros((P, P), dtype=float)
+        # haplotype <-> program-number tables (pyx:105-125): the identity without memory_optimization
+        self.currentHapNum = self.hapNum
+        self.hapToNum = np.arange(H, dtype=np.int64)
+        self.numToHap = np.arange(H, dtype=np.int64)
 
         self._engine = None  # HIP engine handle, created lazily at the first simulate call
         # backward pass (pyx:770-774 allocates the real arrays; a 1-element tree means "not simulated", pyx:1950)
@@ -805,6 +826,39 @@ class BirthDeathModel:
             print('Genealogy was not simulated. Use VGsim.genealogy() method to simulate it.')
             sys.exit(1)
 
+    def export_ts(self):
+        """pyx:1909-1947: the genealogy as a tskit tree sequence (one tree over ``[0, genome_length)``; nodes, edges,
+        migrations, sites and mutations in tskit's time direction, time 0 = the latest sample).  Needs tskit."""
+        self._need_tree()
+        try:
+            import tskit
+        except ImportError as e:
+            raise ImportError('export_ts needs the tskit package, which is not installed.') from e
+        tc = tskit.TableCollection()
+        tc.sequence_length = self.genome_length
+        t0 = self.times[0]
+        for i in range(len(self.mig.nodeId)):
+            node, t, old, new = self.mig.get_migration(i)
+            tc.migrations.add_row(0.0, 1.0, node, old, new, t0 - t)
+        for _ in range(self.popNum):
+            tc.populations.add_row(None)
+        n_nodes = 2 * self.sCounter - 1
+        is_leaf = [1] * n_nodes
+        for i in range(n_nodes - 1):
+            tc.edges.add_row(0.0, self.genome_length, self.tree[i], i)
+            is_leaf[self.tree[i]] = 0
+        for i in range(n_nodes):
+            tc.nodes.add_row(is_leaf[i], t0 - self.times[i], self.tree_pop[i])
+        for pos in self.sitesPosition:
+            pos = pos + 1 if pos == 0 else pos - 1 if pos == self.genome_length else pos
+            tc.sites.add_row(pos, 'A')
+        allele = ['A', 'T', 'C', 'G']
+        for i in range(len(self.mut.nodeId)):
+            node, DS, AS, site, t = self.mut.get_mutation(i)
+            tc.mutations.add_row(site=site, node=node, derived_state=allele[DS], time=t0 - t)
+        tc.sort()
+        return tc.tree_sequence()
+
     def get_tree(self):  # pyx:1949-1953
         self._need_tree()
         return self.tree, self.times
@@ -914,9 +968,11 @@ class BirthDeathModel:
         return data, tp, self._lockdowns_of(pop)
 
     def print_mutations(self):  # pyx:1177-1179
+        print('nodeId\tDS\tAS\tsite\ttime')
         for i in range(len(self.mut.nodeId)):
             print(self.mut.get_mutation(i))
 
     def print_migrations(self):  # pyx:1182-1184
+        print('nodeId\ttime\tsource population\ttarget population')
         for i in range(len(self.mig.nodeId)):
             print(self.mig.get_migration(i))
