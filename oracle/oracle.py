@@ -49,6 +49,9 @@ _FIELDS = [
     ("sparse", C.c_int64), ("log_mode", C.c_int64), ("iterations_done", C.c_int64), ("error", C.c_int64),
     ("occ", _U),
     ("rng_state_hi", C.c_uint64), ("rng_state_lo", C.c_uint64), ("rng_inc_hi", C.c_uint64), ("rng_inc_lo", C.c_uint64),
+    ("recombination", C.c_double), ("genome_length", C.c_int64), ("sitesPosition", _I),
+    ("rec_cap", C.c_int64), ("rec_n", C.c_int64), ("rec_idevents", _I), ("rec_his", _I), ("rec_hi2s", _I),
+    ("rec_nhis", _I), ("rec_posRecombs", _I),
 ]
 
 
@@ -176,6 +179,15 @@ def _struct(model, st, sparse, log_mode):
     m.ev_newHaplotypes, m.ev_newPopulations = _ptr(ev.newHaplotypes), _ptr(ev.newPopulations)
     m.sparse, m.log_mode = int(sparse), int(log_mode)
     m.iterations_done = 0
+    m.recombination = float(model.recombination)
+    m.genome_length = int(model.genome_length)
+    st.sitesPosition = np.ascontiguousarray(model.sitesPosition, dtype=np.int64)
+    m.sitesPosition = _ptr(st.sitesPosition)
+    cap = (ev.size + 25000) if model.recombination else 0   # failed attempts (<= 100 events each) keep their records
+    st.rec = {k: np.zeros(cap, dtype=np.int64) for k in ("idevents", "his", "hi2s", "nhis", "posRecombs")}
+    m.rec_cap, m.rec_n = cap, 0
+    for k, a in st.rec.items():
+        setattr(m, "rec_" + k, _ptr(a))
     return m
 
 
@@ -190,6 +202,8 @@ def _absorb(model, st, m):
     for k in range(m.loc_n):
         model.loc.AddLockdown(st.loc_states[k], st.loc_populations[k], st.loc_times[k])
     st.iterations_done = m.iterations_done
+    for k in range(min(m.rec_n, m.rec_cap)):   # failed attempts' records stay, like upstream (Restart keeps `rec`)
+        model.rec.AddRecombination_forward(*(st.rec[c][k] for c in ("idevents", "his", "hi2s", "nhis", "posRecombs")))
     st.rng_final = (m.rng_state_hi, m.rng_state_lo, m.rng_inc_hi, m.rng_inc_lo)
 
 

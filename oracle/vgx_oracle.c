@@ -595,14 +595,55 @@ static void ImmunityTransition(vgo_model *m, int64_t pi) { /* pyx:550-564 */
     AddEvent(m, m->currentTime, VGO_SUSCCHANGE, ssi, pi, tsi, 0);
 }
 
-static void Birth(vgo_model *m, int64_t pi, int64_t hi) { /* pyx:568-605, recombination branch (575-596) out of scope */
-    double ws = 0.0;
+/* Python-semantics float modulo for non-negative operands (Cython emits __Pyx_mod_double for `%` on C doubles
+ * under cdivision=False; for x >= 0, y > 0 that is fmod). */
+static inline double py_mod_nonneg(double x, double y) { return fmod(x, y); }
+
+static void Birth(vgo_model *m, int64_t pi, int64_t hi) { /* pyx:568-605 */
+    double ws = 0.0, hs = 0.0;
     for (int64_t sn = 0; sn < S_; sn++) ws += IDX3(m->susceptHapPopRate, pi, hi, sn, H_, S_);
     choice_t c = choose_f64(m, &IDX3(m->susceptHapPopRate, pi, hi, 0, H_, S_), S_, ws, m->rn);
     int64_t si = c.i;
     m->rn = c.rn;
-    NewInfections(m, pi, si, hi, 1);
-    AddEvent(m, m->currentTime, VGO_BIRTH, hi, pi, si, H_);
+    if (m->rn < m->recombination && m->totalInfectious[pi] > 1) { /* pyx:575-596 */
+        m->rn = m->rn / m->recombination;
+        /* birthInf[hn] = eventHapPopRate[pi, hn, 0] * infectious[pi, hn] with one host of hi set aside; the
+         * reference fills a scratch vector of hapNum doubles (pyx:579-581), restated here without the vector:
+         * the same products, summed and scanned in the same order */
+        double *birthInf = (double *)malloc((size_t)H_ * sizeof(double));
+        IDX2(m->infectious, pi, hi, H_) -= 1;
+        for (int64_t hn = 0; hn < H_; hn++) {
+            birthInf[hn] = IDX3(m->eventHapPopRate, pi, hn, 0, H_, 4) * (double)IDX2(m->infectious, pi, hn, H_);
+            hs += birthInf[hn];
+        }
+        IDX2(m->infectious, pi, hi, H_) += 1;
+        c = choose_f64(m, birthInf, H_, hs, m->rn);
+        free(birthInf);
+        int64_t hi2 = c.i;
+        m->rn = c.rn;
+        int64_t posRecomb = (int64_t)((double)m->genome_length * m->rn);
+        int64_t nhi = 0;
+        for (int64_t s = 0; s < m->sites; s++) {
+            /* `4**(sites-s-1)` is a C double (Cython 3, cpow=False); `*` binds before `%` (pyx:589/591), so every
+             * site but the last contributes (4^k * floor(h / 4^k)) % 4 == 0 */
+            double p4 = pow(4.0, (double)(m->sites - s - 1));
+            int64_t parent = m->sitesPosition[s] < posRecomb ? hi : hi2;
+            nhi += (int64_t)py_mod_nonneg(p4 * floor((double)parent / p4), 4.0);
+        }
+        if (m->rec_n < m->rec_cap) {
+            m->rec_idevents[m->rec_n] = m->ev_ptr;
+            m->rec_his[m->rec_n] = hi;
+            m->rec_hi2s[m->rec_n] = hi2;
+            m->rec_nhis[m->rec_n] = nhi;
+            m->rec_posRecombs[m->rec_n] = posRecomb;
+        }
+        m->rec_n += 1;
+        NewInfections(m, pi, si, nhi, 1);
+        AddEvent(m, m->currentTime, VGO_BIRTH, hi, pi, si, hi2);
+    } else {
+        NewInfections(m, pi, si, hi, 1);
+        AddEvent(m, m->currentTime, VGO_BIRTH, hi, pi, si, H_);
+    }
     IDX2(m->immuneSourcePopRate, pi, si, S_) = m->suscepCumulTransition[si] * (double)IDX2(m->susceptible, pi, si, S_);
     UpdateRates(m, pi, 1, 1, 1);
     m->bCounter += 1;

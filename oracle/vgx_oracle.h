@@ -18,8 +18,8 @@
  *     checkout, so for that one mapping: PARITY UNPINNED.
  *
  * All arrays are caller-owned, C-contiguous (numpy in the tests); the oracle allocates nothing except
- * small scratch vectors.  memory_optimization (hapToNum/numToHap) and recombination are out of scope
- * (SURVEY.md §8f): numToHap is the identity and recombination must be 0.
+ * small scratch vectors.  memory_optimization (hapToNum/numToHap) is not restated: upstream's table code corrupts
+ * the state, numToHap is the identity here.
  */
 #ifndef VGX_ORACLE_H
 #define VGX_ORACLE_H
@@ -97,6 +97,12 @@ typedef struct vgo_model {
     uint64_t *occ;      /* [P][ceil(H/64)] occupancy bitmap, used when sparse (caller allocates) */
     /* PCG64 (state, inc) of self.seed when the simulate call returns: GetGenealogy(seed=None) draws on from here */
     uint64_t rng_state_hi, rng_state_lo, rng_inc_hi, rng_inc_lo;
+    /* ---- recombination (pyx:93-102, 575-596; recorder md:69-89) ---- */
+    double recombination;                     /* recombination_probability; 0 = branch never taken */
+    int64_t genome_length;
+    int64_t *sitesPosition;                   /* [sites] */
+    int64_t rec_cap, rec_n;                   /* forward records; never cleared by Restart (pyx:714-738) */
+    int64_t *rec_idevents, *rec_his, *rec_hi2s, *rec_nhis, *rec_posRecombs;
 } vgo_model;
 
 /* pyx:396-429.  `time` is a C float exactly as in the reference signature. */

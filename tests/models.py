@@ -277,6 +277,37 @@ CASES["p70"] = (_ctor(number_of_sites=1, populations_number=70, number_of_suscep
                 [(_p70, _direct(15000))])
 CASES["big_seed"] = (_ctor(number_of_sites=1, seed=2 ** 40 + 12345), [(_g2, _direct(3000))])   # two-word SeedSequence entropy
 
+
+
+# ---------------------------------------------------------------- recombination branch of Birth (pyx:575-596)
+def _recomb(s):
+    s.set_mutation_rate(0.3)
+    s.set_sampling_rate(0.1)
+    s.set_transmission_rate(3.0, haplotype='T**')
+    s.set_susceptibility(0.5, susceptibility_type=1)
+    s.set_immunity_transition(0.05, source=1, target=0)
+    s.set_susceptibility_type(1)
+    s.set_migration_probability(0.02)
+
+
+def _recomb_positions(s):  # sites inside the genome: the breakpoint falls on either side of the last site
+    s.set_mutation_rate(0.2)
+    s.set_sampling_rate(0.05)
+    s.set_transmission_rate(2.6, haplotype='*G*')
+    s.set_total_migration_probability(0.05)
+    s.set_mutation_position(1, 300000)
+    s.set_mutation_position(2, 600000)
+
+
+CASES["recomb_a"] = (_ctor(number_of_sites=3, populations_number=2, number_of_susceptible_groups=2, seed=2020,
+                           recombination_probability=0.3), [(_recomb, _direct(8000))])
+CASES["recomb_pos"] = (_ctor(number_of_sites=3, populations_number=3, number_of_susceptible_groups=1, seed=7,
+                             recombination_probability=0.15), [(_recomb_positions, _direct(6000))])
+CASES["recomb_restart"] = (_ctor(number_of_sites=2, populations_number=1, number_of_susceptible_groups=1, seed=2,
+                                 recombination_probability=0.5),
+                           [(lambda s: s.set_transmission_rate(1.3), _direct(3000))])
+RECOMBINATION_CASES = ("recomb_a", "recomb_pos", "recomb_restart")
+
 # cases whose full (6,N) chain is committed; the others commit head/tail columns + sha256 + counters
 FULL_CHAIN_LIMIT = 20000
 

@@ -8,8 +8,8 @@ compartment state live in numpy arrays with the reference's names; the two hot e
 engine through the C ABI in ``include/vgx.h`` (``vgsim_amd/_capi.py``).  There is no CPU fallback:
 without ``libvgx.so`` and a GPU the simulate calls raise.
 
-Out of scope here: memory_optimization (sparse haplotype table, pyx:105-125),
-recombination (pyx:575-596), genealogy and the output writers.
+``memory_optimization=True`` runs the same (natively sparse) engine and only maintains the haplotype table
+(``_refresh_haplotype_table``).
 """
 import sys
 
@@ -216,9 +216,14 @@ class BirthDeathModel(Reporting):
         self.suscepTransition = np.zeros((S, S), dtype=float)
         self.migrationRates = np.zeros((P, P), dtype=float)
         # haplotype <-> program-number tables (pyx:105-125): the identity without memory_optimization
-        self.currentHapNum = self.hapNum
-        self.hapToNum = np.arange(H, dtype=np.int64)
-        self.numToHap = np.arange(H, dtype=np.int64)
+        if self._memory_optimization:
+            self.currentHapNum = 0
+            self.hapToNum = np.zeros(H, dtype=np.int64)
+            self.numToHap = np.zeros(self.maxHapNum, dtype=np.int64)
+        else:
+            self.currentHapNum = self.hapNum
+            self.hapToNum = np.arange(H, dtype=np.int64)
+            self.numToHap = np.arange(H, dtype=np.int64)
 
         self._engine = None  # HIP engine handle, created lazily at the first simulate call
         # backward pass (pyx:770-774 allocates the real arrays; a 1-element tree means "not simulated", pyx:1950)
@@ -652,11 +657,32 @@ class BirthDeathModel(Reporting):
 
     # ------------------------------------------------------------------ hot-path entry points
     def _check_supported(self):
-        if self._memory_optimization:
-            raise NotImplementedError('memory_optimization=True (sparse haplotype table, pyx:105-125) is outside '
-                                      'the accelerated path; the engine keeps haplotype occupancy sparse on its own.')
         if self.recombination != 0:
             raise NotImplementedError('recombination_probability > 0 (pyx:575-596) is outside the accelerated path.')
+
+    def _refresh_haplotype_table(self):
+        """``memory_optimization=True`` (pyx:105-125, 264-274, 355-377, 651-660).  The engine's state is sparse in the
+        haplotype dimension whatever the flag says (ordered occupancy lists), and the reference's table
+        keeps program numbers in haplotype order (sorted insert, pyx:365-375), i.e. the scan order of the plain
+        layout: the trajectory is that of ``memory_optimization=False``.  What remains of the option is its
+        bookkeeping, rebuilt here after every simulate call: ``numToHap`` = the haplotypes seen so far in ascending
+        order, ``hapToNum`` its inverse, ``maxHapNum`` grown in ``addMemoryNum`` steps like ``AddMemory``."""
+        if not self._memory_optimization:
+            return
+        seen = [self.numToHap[:self.currentHapNum], np.nonzero(self.initial_infectious.any(axis=0))[0],
+                np.nonzero(self.infectious.any(axis=0))[0]]
+        n = self.events.ptr
+        seen.append(self.events.newHaplotypes[:n][self.events.types[:n] == MUTATION])
+        mv = self.multievents
+        seen.append(mv.newHaplotypes[:mv.ptr][mv.types[:mv.ptr] == MUTATION])
+        haps = np.unique(np.concatenate([np.asarray(a, dtype=np.int64) for a in seen]))
+        self.currentHapNum = len(haps)
+        while self.maxHapNum < self.currentHapNum:
+            self.maxHapNum = min(self.hapNum, self.maxHapNum + max(self.addMemoryNum, 1))
+        self.numToHap = np.zeros(self.maxHapNum, dtype=np.int64)
+        self.numToHap[:len(haps)] = haps
+        self.hapToNum = np.zeros(self.hapNum, dtype=np.int64)
+        self.hapToNum[haps] = np.arange(len(haps))
 
     def _compute_actual_sizes(self):
         """pyx:289-297 on the host, only for the CheckSizes printout (the engine computes its own)."""
@@ -737,6 +763,7 @@ class BirthDeathModel(Reporting):
         c = eng.last_counters
         self._rng_position = (int(c.reserved[1]), 2 * int(c.reserved[2])) if c.reserved[1] >= 0 else None
         self._rng_raw = None
+        self._refresh_haplotype_table()
         self._print_termination(sample_size, time)
 
     def SimulatePopulation_tau(self, iterations, sample_size, time, attempts):
@@ -748,6 +775,7 @@ class BirthDeathModel(Reporting):
         time = float(np.float32(time))
         self._get_engine().simulate_tau(self, iterations, sample_size, time, attempts)
         self._rng_position, self._rng_raw = None, None
+        self._refresh_haplotype_table()
         self._print_termination(sample_size, time)
 
     # ------------------------------------------------------------------ reporting (pyx:2048-2068, 2284, 2607-2613, 1849-1851)
