@@ -112,6 +112,12 @@ int vgx_device_count(void);
 
 /* ---- model hand-over ------------------------------------------------------------------------ */
 int vgx_set_params(vgx_engine *e, const vgx_params *p);
+/* Recombination branch of Birth (pyx:575-596): `recombination_probability` (pyx:93, set_coinfection_parameters
+ * pyx:1422-1426), `genome_length` (pyx:1409-1417) and sitesPosition[sites] (pyx:98-101, set_mutation_position
+ * pyx:1516-1524).  Optional: without this call the probability is 0 and the branch is never taken.  With a non-zero
+ * probability direct runs use the lane-per-replicate kernel. */
+int vgx_set_recombination(vgx_engine *e, double recombination_probability, int64_t genome_length,
+                          const int64_t *sitesPosition /* [sites], may be NULL when the probability is 0 */);
 /* The same state is given to every replicate; replicates differ by their seed only. */
 int vgx_set_state(vgx_engine *e, const vgx_state *s);
 int vgx_get_state(vgx_engine *e, int64_t replicate, vgx_state *out);
@@ -138,6 +144,11 @@ int vgx_get_events(vgx_engine *e, int64_t replicate, int64_t first, int64_t coun
 /* Lockdown switches recorded by the last call (models.pxi:52-66): up to `cap` rows, returns the count in *n. */
 int vgx_get_lockdowns(vgx_engine *e, int64_t replicate, int64_t cap, int64_t *states, int64_t *populations,
                       double *times, int64_t *n);
+/* Forward recombination records of the last direct call (Recombination.AddRecombination_forward, models.pxi:82-89):
+ * event index, parent haplotypes hi and hi2, recombinant haplotype, breakpoint.  Like upstream, records of failed
+ * attempts stay in the list (Restart does not clear `rec`, pyx:714-738). */
+int vgx_get_recombinations(vgx_engine *e, int64_t replicate, int64_t cap, int64_t *idevents, int64_t *his,
+                           int64_t *hi2s, int64_t *nhis, int64_t *posRecombs, int64_t *n);
 /* Tau multievents of the last call (events.pxi:105-152), rows with num > 0 only. */
 int vgx_get_multievents(vgx_engine *e, int64_t replicate, int64_t cap, int64_t *num, double *times, int64_t *types,
                         int64_t *haplotypes, int64_t *populations, int64_t *newHaplotypes,

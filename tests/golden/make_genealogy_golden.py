@@ -28,6 +28,30 @@ import VGsim  # noqa: E402  (the reference build)
 # (case of tests/models.py, genealogy seed or None = continue the simulation's stream)
 GENEALOGY_CASES = [("g1_short", 11), ("g7_short", 12), ("g9_short", 13), ("g9_short", None), ("stress_h64", 14),
                    ("c3_s5_p16", 15), ("continuation", 16), ("p70", 17), ("tau_a", 18), ("tau_b", 19), ("tau_c", 20)]
+# Chains with recombinant births (pyx:575-596): the BIRTH record names the parent haplotype while the new host carries
+# the recombinant one (pyx:595-596), so upstream's backward pass loses lineages and returns a FOREST (node times left
+# at 0, several roots); its writers then fail (KeyError in output_tree_mutations).  Recorded: that forest as get_tree
+# returns it, and the number of mutation records print_mutations lists.
+FOREST_CASES = [("recomb_a", 21), ("recomb_pos", 22)]
+
+
+def run_forest(name, gseed):
+    with contextlib.redirect_stdout(io.StringIO()):
+        sim, phases = models.build(VGsim.Simulator, name)
+        for setup, kw in phases:
+            setup(sim)
+            sim.simulate(**kw)
+        sim.genealogy(gseed)
+        tree, times = sim.simulation.get_tree()
+        tree, times = np.asarray(tree).astype(np.int64).copy(), np.asarray(times).astype(np.float64).copy()
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        sim.print_mutations()
+    n_mut = len(buf.getvalue().splitlines()) - 1
+    meta = dict(case=name, genealogy_seed=gseed, mutations=n_mut, unset_times=int((times == 0).sum()))
+    np.savez_compressed(os.path.join(HERE, "forest_%s_seed%d.npz" % (name, gseed)), meta=json.dumps(meta), tree=tree, times=times)
+    print("%-28s nodes=%d unset=%d mutations=%d" % (name, len(tree), meta["unset_times"], n_mut))
+
 
 
 def run(name, gseed):
@@ -83,3 +107,7 @@ if __name__ == "__main__":
         if want and name not in want:
             continue
         run(name, gseed)
+    for name, gseed in FOREST_CASES:
+        if want and name not in want:
+            continue
+        run_forest(name, gseed)

@@ -150,6 +150,8 @@ def assert_models_equal(got, want, what=""):
     assert np.array_equal(got.contactDensity, want.contactDensity), what + " contactDensity"
     assert got.loc.states == want.loc.states and got.loc.populationsId == want.loc.populationsId, what + " lockdown log"
     assert got.loc.times == want.loc.times, what + " lockdown times"
+    for k in ("idevents", "his", "hi2s", "nhis", "posRecombs"):   # forward recombination records (models.pxi:69-89)
+        assert getattr(got.rec, k) == getattr(want.rec, k), "%s rec.%s" % (what, k)
 
 
 def sparse_multievents(m, st):

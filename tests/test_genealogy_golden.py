@@ -155,3 +155,21 @@ def test_text_writers_match_reference(oracle_mod, path, tmp_path):
     assert open(tmp_path / "m.tsv").read() == meta["mutations_tsv"]
     if not tau:
         assert open(tmp_path / "t_sample_population.tsv").read() == meta["sample_population"]
+
+
+@pytest.mark.parametrize("name,gseed", [("recomb_a", 21), ("recomb_pos", 22)])
+def test_recombinant_chain_gives_upstreams_forest_and_the_product_says_so(oracle_mod, name, gseed):
+    """A recombinant BIRTH is logged under the parent haplotype although the new host carries the recombinant one
+    (pyx:595-596), so the backward pass loses lineages: the reference returns a forest with unset node times
+    (fixture recorded from it), the literal oracle reproduces that forest bit for bit and reports the condition,
+    and the shipped pass raises instead of handing back a broken tree."""
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "forest_%s_seed%d.npz" % (name, gseed)))
+    meta = json.loads(str(z["meta"]))
+    m = helpers.run_case_oracle(oracle_mod, name).simulation
+    out = oracle_mod.run_genealogy(m, gseed)
+    assert out["rc"] != 0
+    assert np.array_equal(out["tree"], z["tree"]) and np.array_equal(out["times"], z["times"])
+    assert len(out["mut_node"]) == meta["mutations"] and int((out["times"] == 0).sum()) == meta["unset_times"] > 0
+    m = helpers.run_case_oracle(oracle_mod, name).simulation
+    with pytest.raises(RuntimeError, match="never coalesced"):
+        _product_genealogy(m, gseed)

@@ -15,7 +15,8 @@ pytestmark = pytest.mark.gpu
 
 # every direct case of the parity suite: one rate class (class-aggregated rate + integer prefix search) and several
 # classes (tree scans over the occupancy list in haplotype order)
-DIRECT = [n for n, (_, ph) in models.CASES.items() if all(kw.get("method", "direct") == "direct" for _, kw in ph)]
+DIRECT = [n for n, (_, ph) in models.CASES.items() if all(kw.get("method", "direct") == "direct" for _, kw in ph)
+          and n not in models.RECOMBINATION_CASES]   # recombination runs in exact mode only (lane kernel)
 RTOL_TIME = 1e-9
 
 

@@ -37,3 +37,37 @@ def test_lane_kernel_bit_exact_vs_oracle(oracle_mod, name):
     hip = helpers.run_case_hip(name, kernel="lane").simulation
     ref = helpers.run_case_oracle(oracle_mod, name, log_mode=oracle_mod.LOG_PORTABLE).simulation
     helpers.assert_models_equal(hip, ref, name)
+
+
+def test_recombination_is_refused_by_the_wave_kernel_and_fast_mode():
+    from vgsim_amd._capi import VgxError
+    with helpers.quiet():
+        sim, phases = models.build(__import__("vgsim_amd").Simulator, "recomb_a")
+        phases[0][0](sim)
+    for kw in (dict(kernel="wave"), dict(mode="fast")):
+        with pytest.raises(VgxError), helpers.quiet():
+            sim.simulate(100, **kw)
+    assert len(helpers.run_case_hip("recomb_a").simulation.rec.his) > 1000
+
+
+def test_memory_optimization_flag_changes_bookkeeping_only():
+    """The engine is sparse in the haplotype dimension by construction: ``memory_optimization=True`` yields the chain of
+    the plain layout and maintains the reference's haplotype table (sorted program numbers, pyx:355-377)."""
+    from vgsim_amd import Simulator
+
+    def run(flag):
+        with helpers.quiet():
+            s = Simulator(4, 2, 1, seed=11, memory_optimization=flag)
+            s.set_mutation_rate(0.2)
+            s.set_migration_probability(0.01)
+            s.simulate(4000)
+            s.simulate(300, method="tau", sample_size=10 ** 9)
+        return s.simulation
+    a, b = run(False), run(True)
+    assert np.array_equal(a.events.as_array(), b.events.as_array()) and np.array_equal(a.infectious, b.infectious)
+    n = b.currentHapNum
+    seen = np.unique(np.concatenate(([0], b.events.newHaplotypes[:b.events.ptr][b.events.types[:b.events.ptr] == 3],
+                                     b.multievents.newHaplotypes[:b.multievents.ptr][b.multievents.types[:b.multievents.ptr] == 3])))
+    assert n == len(seen) < 256 and np.array_equal(b.numToHap[:n], seen)
+    assert np.array_equal(b.hapToNum[seen], np.arange(n)) and n <= b.maxHapNum <= 256 and len(b.numToHap) == b.maxHapNum
+    assert a.currentHapNum == 256 and np.array_equal(a.numToHap, np.arange(256))

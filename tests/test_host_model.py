@@ -146,12 +146,16 @@ def test_events_capacity_rule():
     assert ev.as_array().shape == (6, 22)
 
 
+def test_memory_optimization_table_starts_empty():
+    m = make(number_of_sites=3, memory_optimization=True).simulation   # pyx:105-121
+    assert (m.maxHapNum, m.addMemoryNum, m.currentHapNum, len(m.numToHap), len(m.hapToNum)) == (4, 4, 0, 4, 64)
+    m = make(number_of_sites=3).simulation
+    assert m.currentHapNum == 64 and list(m.numToHap[:3]) == [0, 1, 2]
+
+
 def test_unsupported_paths_raise():
-    s = make(number_of_sites=2, memory_optimization=True)
-    with pytest.raises(NotImplementedError):
-        s.simulate(10)
-    s = make(recombination_probability=0.5)
-    with pytest.raises(NotImplementedError):
+    s = make(number_of_sites=1, recombination_probability=0.5)   # upstream has no scratch vector for sites < 2 (pyx:98-102)
+    with pytest.raises(ValueError):
         s.simulate(10)
     with pytest.raises(SystemExit):   # "Less than two cases were sampled..." (pyx:762-765)
         make().genealogy()

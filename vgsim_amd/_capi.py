@@ -71,6 +71,8 @@ SIGNATURES = {
     "vgx_last_error": (C.c_char_p, [_H]),
     "vgx_device_count": (C.c_int, []),
     "vgx_set_params": (C.c_int, [_H, C.POINTER(VgxParams)]),
+    "vgx_set_recombination": (C.c_int, [_H, C.c_double, C.c_int64, _I]),
+    "vgx_get_recombinations": (C.c_int, [_H, C.c_int64, C.c_int64, _I, _I, _I, _I, _I, _I]),
     "vgx_set_state": (C.c_int, [_H, C.POINTER(VgxState)]),
     "vgx_get_state": (C.c_int, [_H, C.c_int64, C.POINTER(VgxState)]),
     "vgx_set_seeds": (C.c_int, [_H, _I]),
@@ -164,6 +166,18 @@ class HipEngine:
             setattr(p, name, _p(np.ascontiguousarray(a)))
         self._keep = [getattr(m, n) for n, _ in VgxParams._fields_]
         self._check(self.lib.vgx_set_params(self.handle, C.byref(p)))
+        pos = np.ascontiguousarray(getattr(m, "sitesPosition", np.zeros(0)), dtype=np.int64)
+        self._check(self.lib.vgx_set_recombination(self.handle, float(getattr(m, "recombination", 0.0)),
+                                                   int(getattr(m, "genome_length", 0)), _p(pos) if len(pos) else None))
+
+    def recombinations(self, replicate=0):
+        """Forward recombination records of the last direct call: (idevents, his, hi2s, nhis, posRecombs)."""
+        n = C.c_int64(0)
+        self._check(self.lib.vgx_get_recombinations(self.handle, replicate, 0, None, None, None, None, None, C.byref(n)))
+        cols = [np.zeros(n.value, dtype=np.int64) for _ in range(5)]
+        if n.value:
+            self._check(self.lib.vgx_get_recombinations(self.handle, replicate, n.value, *[_p(c) for c in cols], C.byref(n)))
+        return cols
 
     def _state_struct(self, m):
         s = VgxState()
@@ -284,6 +298,9 @@ class HipEngine:
         st, pp, tt = self.lockdowns(replicate)
         for k in range(len(st)):
             m.loc.AddLockdown(st[k], pp[k], tt[k])
+        if not tau and getattr(m, "recombination", 0.0) and hasattr(m, "rec"):
+            for row in zip(*self.recombinations(replicate)):
+                m.rec.AddRecombination_forward(*row)
         self.last_counters = c
 
     @property

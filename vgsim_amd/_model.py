@@ -657,8 +657,10 @@ class BirthDeathModel(Reporting):
 
     # ------------------------------------------------------------------ hot-path entry points
     def _check_supported(self):
-        if self.recombination != 0:
-            raise NotImplementedError('recombination_probability > 0 (pyx:575-596) is outside the accelerated path.')
+        if self.recombination != 0 and self.sites < 2:
+            # upstream allocates the scratch vector of the recombination branch only for sites > 1 (pyx:98-102) and
+            # crashes in Birth otherwise
+            raise ValueError('Incorrect value of recombination probability. Recombination needs at least two sites.')
 
     def _refresh_haplotype_table(self):
         """``memory_optimization=True`` (pyx:105-125, 264-274, 355-377, 651-660).  The engine's state is sparse in the

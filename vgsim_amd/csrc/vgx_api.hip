@@ -18,6 +18,7 @@
 
 // launchers defined next to their kernels (vgx_direct.hip)
 extern "C" hipError_t vgxi_launch_direct(const VgxDirectArgs *a, size_t lds, hipStream_t stream);
+extern "C" int vgxi_tau_inc_shards(int64_t H, int64_t P);
 extern "C" hipError_t vgxi_launch_lanes(const VgxDirectArgs *a, const VgxLaneWs *w, hipStream_t stream);
 extern "C" size_t vgxi_direct_lds_bytes(int P, int S, int C, int CB);
 extern "C" hipError_t vgxi_launch_init_reps(const VgxDevRep *r, int P, int S, int64_t R, const int32_t *s_nocc,
@@ -65,7 +66,10 @@ struct vgx_engine {
     std::vector<DevBuf *> all;
     DevBuf p_cls, p_suscType, p_mRate, p_hapMutType, p_bRate, p_susc, p_cd, p_cs, p_ctm, p_cbidx, p_cstype, p_cbb, p_cbsig,
         p_sizes, p_cdBefore, p_cdAfter, p_startLD, p_endLD, p_sampMult, p_actualSizes, p_mig, p_suscTrans,
-        p_suscCumul;
+        p_suscCumul, p_sitesPos;
+    double recombination = 0.0;          // pyx:93, 1422-1426
+    int64_t genome_length = 1000000, rec_cap = 0;
+    DevBuf r_rec;
     DevBuf r_popD, r_popI, r_sus, r_immSrc, r_birthC, r_xC, r_effMig, r_nocc, r_lhap, r_lcls, r_lcnt, r_ltsum, r_lanews, r_sc, r_seeds,
         r_evtime, r_evcols, r_locrec, r_loctime, r_traj, r_prof;
     // tau-leaping (dense compartments)
@@ -354,8 +358,52 @@ extern "C" int vgx_set_params(vgx_engine *e, const vgx_params *p) {
     d.actualSizes = (const double *)e->p_actualSizes.p; d.mig = (const double *)e->p_mig.p;
     d.suscepTransition = (const double *)e->p_suscTrans.p; d.suscepCumul = (const double *)e->p_suscCumul.p;
     d.maxEffectiveBirth = maxEffectiveBirth;
+    d.recombination = e->recombination; d.genome_length = e->genome_length;
+    d.sitesPosition = (const int64_t *)e->p_sitesPos.p;
     e->have_params = true;
     e->dev_state_valid = false;  // class ids in the occupancy lists refer to the old parameter rows
+    return VGX_OK;
+}
+
+extern "C" int vgx_set_recombination(vgx_engine *e, double recombination_probability, int64_t genome_length,
+                                     const int64_t *sitesPosition) {
+    if (!e) return VGX_ERR_ARG;
+    const int64_t sites = e->d.sites;
+    if (!(recombination_probability >= 0.0 && recombination_probability <= 1.0) || genome_length < 0)
+        return fail(e, VGX_ERR_ARG, "vgx_set_recombination: probability outside [0, 1] or negative genome length");
+    if (recombination_probability != 0.0 && (sites < 2 || !sitesPosition))
+        return fail(e, VGX_ERR_ARG, "vgx_set_recombination: recombination needs at least two sites and their positions "
+                                    "(the reference allocates its scratch vector only then, pyx:98-102)");
+    HIPCHECK(e, hipSetDevice(e->device));
+    e->recombination = recombination_probability;
+    e->genome_length = genome_length;
+    if (sites > 0 && sitesPosition) {
+        int rc = upload(e, e->p_sitesPos, sitesPosition, (size_t)sites);
+        if (rc) return rc;
+        HIPCHECK(e, hipStreamSynchronize(e->stream));
+    }
+    e->dp.recombination = e->recombination; e->dp.genome_length = e->genome_length;
+    e->dp.sitesPosition = (const int64_t *)e->p_sitesPos.p;
+    return VGX_OK;
+}
+
+extern "C" int vgx_get_recombinations(vgx_engine *e, int64_t replicate, int64_t cap, int64_t *idevents, int64_t *his,
+                                      int64_t *hi2s, int64_t *nhis, int64_t *posRecombs, int64_t *n) {
+    if (!e || !n || replicate < 0 || replicate >= e->R) return VGX_ERR_ARG;
+    if (!e->sc_host_valid) return fail(e, VGX_ERR_ARG, "vgx_get_recombinations: no simulate call yet");
+    *n = 0;
+    if (e->last_was_tau || !e->last_used_lanes || e->rec_cap == 0) return VGX_OK;
+    HIPCHECK(e, hipSetDevice(e->device));
+    int64_t cnt = std::min<int64_t>(e->sc_host[(size_t)replicate].rec_n, e->rec_cap);
+    *n = cnt;
+    cnt = std::min(cnt, cap);
+    if (cnt <= 0) return VGX_OK;
+    std::vector<int64_t> rec((size_t)cnt * 5);
+    HIPCHECK(e, hipMemcpy(rec.data(), (int64_t *)e->r_rec.p + replicate * e->rec_cap * 5, (size_t)cnt * 40, hipMemcpyDeviceToHost));
+    int64_t *dst[5] = {idevents, his, hi2s, nhis, posRecombs};
+    for (int c = 0; c < 5; c++)
+        if (dst[c])
+            for (int64_t i = 0; i < cnt; i++) dst[c][i] = rec[(size_t)(i * 5 + c)];
     return VGX_OK;
 }
 
@@ -630,14 +678,31 @@ static int direct_core(vgx_engine *e, int64_t iterations, int64_t sample_size, f
     // Kernel choice: small models run one replicate per LANE (vgx_lanes.hip: the reference's serial loops, dense state);
     // everything else one replicate per wavefront.  opts.kernel: 0 = automatic, 1 = wavefront, 2 = lane.
     const int64_t H = e->d.hapNum, S = e->d.susNum;
-    const bool lane_ok = o.mode == 0 && P * H <= 1024 && P <= 16 && S <= 8 && H <= e->cap;
+    // Recombination (pyx:575-596) is implemented by the lane kernel only: serial, dense state, any shape whose dense
+    // arrays fit (upstream's recombinants carry a single site, so the option has no large-haplotype-space use).
+    const bool recomb = e->recombination != 0.0;
+    const bool lane_ok = o.mode == 0 && (recomb ? P * H * std::max<int64_t>(S, 1) <= (1 << 24)
+                                                : (P * H <= 1024 && P <= 16 && S <= 8 && H <= e->cap));
+    if (recomb && (o.kernel == 1 || !lane_ok))
+        return fail(e, VGX_ERR_ARG, "vgx_simulate_direct: recombination runs on the lane-per-replicate kernel in exact "
+                                    "mode (popNum * hapNum * susNum <= 2^24)");
     if (o.kernel == 2 && !lane_ok)
         return fail(e, VGX_ERR_ARG, "vgx_simulate_direct: the lane-per-replicate kernel needs exact mode, popNum <= 16, "
                                     "popNum * hapNum <= 1024 and susNum <= 8");
     // measured (tools/probe_lanes.py): the lane kernel only wins for minimal models in very large ensembles (config 2 at
     // 262 144 replicates: 2.4e9 vs 7.0e8 events/s); its state lives in HBM/L2, so every other shape is latency-bound
-    const bool use_lanes = o.kernel == 2 || (o.kernel == 0 && lane_ok && P * H * S <= 4 && R >= 65536);
+    const bool use_lanes = recomb || o.kernel == 2 || (o.kernel == 0 && lane_ok && P * H * S <= 4 && R >= 65536);
     VgxLaneWs ws{};
+    a.r.rec = nullptr; a.r.rec_cap = 0;
+    e->rec_cap = 0;
+    if (recomb) {
+        // every recorded event can be a recombinant birth; failed attempts (<= 100 events each) keep their records
+        const int64_t rec_cap = evcap + 101 * std::max<int64_t>(attempts, 1);
+        int rcr = ensure(e, e->r_rec, (size_t)(R * rec_cap * 5) * 8);
+        if (rcr) return rcr;
+        a.r.rec = (int64_t *)e->r_rec.p; a.r.rec_cap = rec_cap;
+        e->rec_cap = rec_cap;
+    }
     if (use_lanes) {
         const int64_t PH = P * H;
         const int64_t n_i = PH + P * S + 3 * P, n_d = P + 3 * PH + PH * S + P * S + 5 * P + P * P;
@@ -886,7 +951,7 @@ extern "C" int vgx_simulate_tau(vgx_engine *e, int64_t iterations, int64_t sampl
     a.mutcum = (const double *)e->t_mutcum.p;
     a.migcdf = (double *)e->t_migcdf.p;
     a.migIn = (double *)e->t_migIn.p;
-    a.inc = (int64_t *)e->t_inc.p; a.inc_cap = inc_cap; a.inc_n = (unsigned long long *)e->t_incn.p;
+    a.inc = (int64_t *)e->t_inc.p; a.inc_cap = inc_cap; a.inc_shards = vgxi_tau_inc_shards(H, P); a.inc_n = (unsigned long long *)e->t_incn.p;
     a.counters = (int64_t *)e->t_counters.p; a.cnt_try = (int64_t *)e->t_cnttry.p;
     a.mev = (int64_t *)e->t_mev.p; a.mev_cap = mev_cap;
     e->tau_mev_cap = mev_cap;

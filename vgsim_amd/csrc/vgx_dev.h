@@ -43,6 +43,10 @@ struct VgxDevParams {
     const double *suscepTransition;  // [S][S]
     const double *suscepCumul;  // [S]
     double maxEffectiveBirth;   // pyx:340-344
+    // recombination branch of Birth (pyx:575-596); recombination == 0: never taken
+    double recombination;
+    int64_t genome_length;
+    const int64_t *sitesPosition;  // [sites]
 };
 
 struct VgxRepScalars {
@@ -59,7 +63,7 @@ struct VgxRepScalars {
     int64_t traj_next;       // next trajectory grid point to emit
     int64_t last_attempt;        // index of the last attempt that drew random numbers (-1: none)
     int64_t last_attempt_loops;  // loop iterations of that attempt (2 uniforms each)
-    int64_t pad[1];
+    int64_t rec_n;               // recombination records written so far (kept across Restarts like upstream's `rec`)
 };
 
 struct VgxDevRep {
@@ -98,6 +102,9 @@ struct VgxDevRep {
     double *traj;            // [R][T][P][2] or null
     int64_t traj_points;
     double traj_t0, traj_dt;
+    // forward recombination records (models.pxi:69-89): idevent, hi, hi2, nhi, posRecomb
+    int64_t *rec;            // [R][rec_cap][5] or null
+    int64_t rec_cap;
     unsigned long long *prof; // [R][VGX_PROF_SLOTS] cycle sums of the diagnostic build (else untouched)
 };
 
@@ -132,6 +139,7 @@ struct VgxTauArgs {
     int32_t *dApp;       // [R][P][H] infectious deltas as UpdateCompartmentCounts_tau applies them (pyx:2548)
     int64_t *inc;        // [R][inc_cap] individuals entering another compartment: cell index | (applied-only << 62)
     int64_t inc_cap;
+    int32_t inc_shards;  // shards in use: a power of two <= VGX_INC_SHARDS matched to the draw kernel's grid; inc_cap / inc_shards entries each
     unsigned long long *inc_n;  // [R][VGX_INC_SHARDS]
     int64_t *dSi;        // [R][P][S] susceptible deltas
     int64_t *dTot;       // [R][P]    delta of totalInfectious

@@ -38,6 +38,7 @@ struct Lane {
     // logs
     double *ev_time; int32_t *ev_cols; int64_t evcap, ev_base; int record_events;
     int32_t *loc_rec; double *loc_time;
+    int64_t *rec; int64_t rec_cap, rec_n;
     double *traj; int64_t traj_points, traj_next; double traj_t0, traj_dt;
 };
 
@@ -230,6 +231,46 @@ __device__ __forceinline__ int mutate(const Lane &L, int hi, int s, int DS) {  /
     return hi + (DS - AS) * digit4;
 }
 
+// Recombination branch of Birth (pyx:575-596).  birthInf[hn] = eventHapPopRate[pi, hn, 0] * infectious[pi, hn] with one
+// host of `hi` set aside (pyx:578-582) is not stored: the same products are formed again for the scan, in the same order.
+__device__ __noinline__ void recombinant_birth(Lane &L, int pi, int hi, int si) {
+    const VgxDevParams &p = *L.p;
+    const int H = L.H;
+    L.rn = L.rn / p.recombination;
+    double hs = 0.0;
+    for (int hn = 0; hn < H; ++hn)
+        hs += AT(L.birth, pi * H + hn) * (double)(AT(L.inf, pi * H + hn) - (hn == hi ? 1 : 0));
+    // fastChoose(birthInf, hs, rn), fast_choose.pxi:18-31
+    double r = hs * L.rn;
+    int i = 0;
+    double wi = AT(L.birth, pi * H) * (double)(AT(L.inf, pi * H) - (hi == 0 ? 1 : 0));
+    double total = wi;
+    while (total < r && i < H - 1) {
+        i += 1;
+        wi = AT(L.birth, pi * H + i) * (double)(AT(L.inf, pi * H + i) - (i == hi ? 1 : 0));
+        total += wi;
+    }
+    if (wi == 0.0) { L.error = ERR_ZERO_WEIGHT; return; }
+    L.rn = (r - (total - wi)) / wi;
+    const int hi2 = i;
+    const int64_t posRecomb = (int64_t)((double)p.genome_length * L.rn);
+    // pyx:586-591 as written: `4**k * floor(h / 4**k) % 4` is (4^k * floor(h / 4^k)) % 4, which is 0 for every site but
+    // the last (k = 0), where it is h % 4 -- the recombinant carries only the last site of one parent
+    int nhi = 0;
+    if (L.sites > 0) nhi = (p.sitesPosition[L.sites - 1] < posRecomb ? hi : hi2) % 4;
+    if (L.rec) {
+        if (L.rec_n < L.rec_cap) {
+            int64_t *o = L.rec + L.rec_n * 5;
+            o[0] = L.ev_ptr; o[1] = hi; o[2] = hi2; o[3] = nhi; o[4] = posRecomb;
+        } else {
+            L.error = ERR_CAPACITY;
+        }
+    }
+    L.rec_n += 1;
+    new_infection(L, pi, si, nhi);
+    add_event(L, EV_BIRTH, hi, pi, si, hi2);
+}
+
 // GenerateEvent (pyx:483-512); returns the population whose lockdown state has to be checked
 __device__ int generate_event(Lane &L, double u) {
     const VgxDevParams &p = *L.p;
@@ -270,12 +311,16 @@ __device__ int generate_event(Lane &L, double u) {
                 ei = i;
             }
             if (ei == 0) {
-                // Birth (pyx:568-605, recombination off)
+                // Birth (pyx:568-605)
                 double ws = 0.0;
                 for (int sn = 0; sn < S; ++sn) ws += AT(L.shpr, (pi * H + hi) * S + sn);
                 int si = choose_lane_f64(L, L.shpr, (pi * H + hi) * S, S, ws);
-                new_infection(L, pi, si, hi);
-                add_event(L, EV_BIRTH, hi, pi, si, H);
+                if (p.recombination != 0.0 && L.rn < p.recombination && AT(L.totI, pi) > 1) {
+                    recombinant_birth(L, pi, hi, si);
+                } else {
+                    new_infection(L, pi, si, hi);
+                    add_event(L, EV_BIRTH, hi, pi, si, H);
+                }
                 AT(L.immSrc, pi * S + si) = p.suscepCumul[si] * (double)AT(L.sus, pi * S + si);
                 update_rates(L, pi, true, true, true);
                 L.cB += 1;
@@ -398,6 +443,7 @@ static __device__ __forceinline__ void lanes_body(const VgxDirectArgs &a, Lane &
     L.ev_cols = r.ev_cols + rep * r.evcap * 5;
     L.loc_rec = r.loc_rec + rep * VGX_LOC_CAP * 2;
     L.loc_time = r.loc_time + rep * VGX_LOC_CAP;
+    L.rec = r.rec ? r.rec + rep * r.rec_cap * 5 : nullptr; L.rec_cap = r.rec_cap; L.rec_n = 0;
     L.traj_points = r.traj_points; L.traj_t0 = r.traj_t0; L.traj_dt = r.traj_dt; L.traj_next = 0;
     L.traj = r.traj ? r.traj + rep * r.traj_points * P * 2 : nullptr;
 
@@ -502,6 +548,7 @@ static __device__ __forceinline__ void lanes_body(const VgxDirectArgs &a, Lane &
     sc->ev_ptr = L.ev_ptr; sc->loop_iterations = loops; sc->restarts = restarts;
     sc->loc_n = L.loc_n; sc->error = L.error; sc->traj_next = L.traj_next;
     sc->last_attempt = last_att; sc->last_attempt_loops = last_att_loops;
+    sc->rec_n = L.rec_n;
 }
 
 // state in HBM, interleaved across all replicates

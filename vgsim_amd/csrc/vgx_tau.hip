@@ -407,8 +407,8 @@ static __device__ __forceinline__ void tau_row(const VgxTauArgs &a, int rep, int
 struct IncStage { int n; int64_t e[VGX_INC_STAGE]; unsigned long long base; };
 
 static __device__ __forceinline__ void tau_incoming_global(const VgxTauArgs &a, int rep, int64_t entry) {
-    const int shard = (int)((blockIdx.x + gridDim.x * blockIdx.y) & (VGX_INC_SHARDS - 1));
-    const int64_t scap = a.inc_cap / VGX_INC_SHARDS;
+    const int shard = (int)((blockIdx.x + gridDim.x * blockIdx.y) & (a.inc_shards - 1));
+    const int64_t scap = a.inc_cap / a.inc_shards;
     unsigned long long slot = atomicAdd(&a.inc_n[(int64_t)rep * VGX_INC_SHARDS + shard], 1ull);
     if ((int64_t)slot < scap) a.inc[(int64_t)rep * a.inc_cap + (int64_t)shard * scap + (int64_t)slot] = entry;
 }
@@ -425,8 +425,8 @@ static __device__ __forceinline__ void tau_incoming_flush(const VgxTauArgs &a, I
     __syncthreads();
     const int n = st->n < VGX_INC_STAGE ? st->n : VGX_INC_STAGE;
     if (n > 0) {
-        const int shard = (int)((blockIdx.x + gridDim.x * blockIdx.y) & (VGX_INC_SHARDS - 1));
-        const int64_t scap = a.inc_cap / VGX_INC_SHARDS;
+        const int shard = (int)((blockIdx.x + gridDim.x * blockIdx.y) & (a.inc_shards - 1));
+        const int64_t scap = a.inc_cap / a.inc_shards;
         if (threadIdx.x == 0) st->base = atomicAdd(&a.inc_n[(int64_t)rep * VGX_INC_SHARDS + shard], (unsigned long long)n);
         __syncthreads();
         const unsigned long long base = st->base;
@@ -831,27 +831,26 @@ extern "C" __global__ void __launch_bounds__(TB) vgx_tau_suscep_draw_kernel(VgxT
     tau_row(a, rep, k, 4, ssn, pn, tsn, 0);
 }
 
-// Adds the appended incoming individuals to the delta arrays and empties the list.  grid = (VGX_INC_SHARDS, R).
+// Adds the appended incoming individuals to the delta arrays.  grid = (inc_shards, R, VGX_INC_SHARDS / inc_shards):
+// the blocks of one shard take interleaved 64-entry slices of it, so a few long shards (small models with large
+// epidemics) are worked off by as many wavefronts as many short ones.  vgx_tau_decide_kernel empties the list.
 extern "C" __global__ void __launch_bounds__(64) vgx_tau_scatter_kernel(VgxTauArgs a) {
     const int rep = blockIdx.y, shard = blockIdx.x;
     if (!a.active[rep] || a.accepted[rep]) return;
     const int64_t PH = (int64_t)a.p.P * a.p.H;
-    const int64_t scap = a.inc_cap / VGX_INC_SHARDS;
-    unsigned long long *cntp = &a.inc_n[(int64_t)rep * VGX_INC_SHARDS + shard];
-    unsigned long long n = *cntp;
+    const int64_t scap = a.inc_cap / a.inc_shards;
+    unsigned long long n = a.inc_n[(int64_t)rep * VGX_INC_SHARDS + shard];
     if ((int64_t)n > scap) {  // shard overflow: the step cannot be validated
-        if (threadIdx.x == 0) a.error[rep] = 4;
+        if (threadIdx.x == 0 && blockIdx.z == 0) a.error[rep] = 4;
         n = (unsigned long long)scap;
     }
     const int64_t *lst = a.inc + (int64_t)rep * a.inc_cap + (int64_t)shard * scap;
-    for (unsigned long long i = threadIdx.x; i < n; i += 64) {
+    for (unsigned long long i = (unsigned long long)blockIdx.z * 64 + threadIdx.x; i < n; i += (unsigned long long)gridDim.z * 64) {
         int64_t e = lst[i];
         int64_t cell = e & (((int64_t)1 << 62) - 1);
         atomicAdd(&a.dApp[(int64_t)rep * PH + cell], 1);
         if (!(e >> 62)) atomicAdd(&a.dChk[(int64_t)rep * PH + cell], 1);
     }
-    __syncthreads();
-    if (threadIdx.x == 0) *cntp = 0;
 }
 
 // Bounds check of GenerateEvents_tau (pyx:2522-2528).  grid = (ceil(H/TB), P, R).
@@ -889,9 +888,13 @@ extern "C" __global__ void __launch_bounds__(TB) vgx_tau_check_kernel(VgxTauArgs
 // grid = R, block = 64.  `deciding` marks the replicates whose deltas the commit kernel must now handle.
 extern "C" __global__ void __launch_bounds__(64) vgx_tau_decide_kernel(VgxTauArgs a) {
     const int rep = blockIdx.x;
+    const bool live = a.active[rep] && !a.accepted[rep];
+    __syncthreads();
+    if (live)   // the cross-compartment list of this draw has been applied by vgx_tau_scatter_kernel
+        for (int i = threadIdx.x; i < a.inc_shards; i += 64) a.inc_n[(int64_t)rep * VGX_INC_SHARDS + i] = 0;
     if (threadIdx.x != 0) return;
     a.deciding[rep] = 0;
-    if (!a.active[rep] || a.accepted[rep]) return;
+    if (!live) return;
     a.deciding[rep] = 1;
     if (a.ok[rep]) {
         a.accepted[rep] = 1;
@@ -1022,7 +1025,16 @@ extern "C" __attribute__((visibility("hidden"))) hipError_t vgxi_tau_draw(const 
     return hipGetLastError();
 }
 TAU_LAUNCH(tau_suscep_draw, SUS_GRID, dim3(TB))
-TAU_LAUNCH(tau_scatter, dim3((unsigned)VGX_INC_SHARDS, (unsigned)a->R), dim3(64))
+TAU_LAUNCH(tau_scatter, dim3((unsigned)a->inc_shards, (unsigned)a->R, (unsigned)(VGX_INC_SHARDS / a->inc_shards)), dim3(64))
+// Number of thread blocks per replicate of the draw kernel: the cross-compartment list gets one shard per block (a
+// power of two, at most VGX_INC_SHARDS), so that its whole capacity is usable whatever the grid size.
+extern "C" __attribute__((visibility("hidden"))) int vgxi_tau_inc_shards(int64_t H, int64_t P) {
+    unsigned tiles = (unsigned)((H + TB - 1) / TB);
+    int64_t blocks = (int64_t)((tiles + 3u) / 4u < 32u ? (tiles + 3u) / 4u : 32u) * P;
+    int sh = 1;
+    while (sh * 2 <= blocks && sh * 2 <= VGX_INC_SHARDS) sh *= 2;
+    return sh;
+}
 TAU_LAUNCH(tau_check, CELL_GRID, dim3(TB))
 TAU_LAUNCH(tau_decide, dim3((unsigned)a->R), dim3(64))
 TAU_LAUNCH(tau_commit, CELL_GRID, dim3(TB))
