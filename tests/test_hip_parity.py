@@ -61,13 +61,16 @@ def test_memory_optimization_flag_changes_bookkeeping_only():
             s.set_mutation_rate(0.2)
             s.set_migration_probability(0.01)
             s.simulate(4000)
+            after_direct.append(s.simulation.currentHapNum)
             s.simulate(300, method="tau", sample_size=10 ** 9)
         return s.simulation
+    after_direct = []
     a, b = run(False), run(True)
+    assert after_direct[0] == 256 and 1 < after_direct[1] < 256     # the table grows with the haplotypes seen
     assert np.array_equal(a.events.as_array(), b.events.as_array()) and np.array_equal(a.infectious, b.infectious)
     n = b.currentHapNum
     seen = np.unique(np.concatenate(([0], b.events.newHaplotypes[:b.events.ptr][b.events.types[:b.events.ptr] == 3],
                                      b.multievents.newHaplotypes[:b.multievents.ptr][b.multievents.types[:b.multievents.ptr] == 3])))
-    assert n == len(seen) < 256 and np.array_equal(b.numToHap[:n], seen)
+    assert after_direct[1] <= n == len(seen) <= 256 and np.array_equal(b.numToHap[:n], seen)
     assert np.array_equal(b.hapToNum[seen], np.arange(n)) and n <= b.maxHapNum <= 256 and len(b.numToHap) == b.maxHapNum
     assert a.currentHapNum == 256 and np.array_equal(a.numToHap, np.arange(256))
