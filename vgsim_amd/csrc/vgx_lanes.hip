@@ -233,7 +233,7 @@ __device__ __forceinline__ int mutate(const Lane &L, int hi, int s, int DS) {  /
 
 // Recombination branch of Birth (pyx:575-596).  birthInf[hn] = eventHapPopRate[pi, hn, 0] * infectious[pi, hn] with one
 // host of `hi` set aside (pyx:578-582) is not stored: the same products are formed again for the scan, in the same order.
-__device__ __noinline__ void recombinant_birth(Lane &L, int pi, int hi, int si) {
+__device__ __forceinline__ void recombinant_birth(Lane &L, int pi, int hi, int si) {
     const VgxDevParams &p = *L.p;
     const int H = L.H;
     L.rn = L.rn / p.recombination;
@@ -271,7 +271,9 @@ __device__ __noinline__ void recombinant_birth(Lane &L, int pi, int hi, int si) 
     add_event(L, EV_BIRTH, hi, pi, si, hi2);
 }
 
-// GenerateEvent (pyx:483-512); returns the population whose lockdown state has to be checked
+// GenerateEvent (pyx:483-512); returns the population whose lockdown state has to be checked.  RECOMB: the build with the
+// recombination branch of Birth (the default kernels do not carry it: same code as before, same registers).
+template <bool RECOMB>
 __device__ int generate_event(Lane &L, double u) {
     const VgxDevParams &p = *L.p;
     const int P = L.P, H = L.H, S = L.S;
@@ -315,7 +317,7 @@ __device__ int generate_event(Lane &L, double u) {
                 double ws = 0.0;
                 for (int sn = 0; sn < S; ++sn) ws += AT(L.shpr, (pi * H + hi) * S + sn);
                 int si = choose_lane_f64(L, L.shpr, (pi * H + hi) * S, S, ws);
-                if (p.recombination != 0.0 && L.rn < p.recombination && AT(L.totI, pi) > 1) {
+                if (RECOMB && L.rn < p.recombination && AT(L.totI, pi) > 1) {
                     recombinant_birth(L, pi, hi, si);
                 } else {
                     new_infection(L, pi, si, hi);
@@ -409,6 +411,7 @@ __device__ void traj_emit(Lane &L, double t_new, bool final_fill) {
 }  // namespace
 
 // Body shared by the two kernels below: `L` already knows where this lane's dense state lives.
+template <bool RECOMB>
 static __device__ __forceinline__ void lanes_body(const VgxDirectArgs &a, Lane &L, const int64_t rep) {
     const VgxDevParams &p = a.p;
     const VgxDevRep &r = a.r;
@@ -443,7 +446,7 @@ static __device__ __forceinline__ void lanes_body(const VgxDirectArgs &a, Lane &
     L.ev_cols = r.ev_cols + rep * r.evcap * 5;
     L.loc_rec = r.loc_rec + rep * VGX_LOC_CAP * 2;
     L.loc_time = r.loc_time + rep * VGX_LOC_CAP;
-    L.rec = r.rec ? r.rec + rep * r.rec_cap * 5 : nullptr; L.rec_cap = r.rec_cap; L.rec_n = 0;
+    L.rec = (RECOMB && r.rec) ? r.rec + rep * r.rec_cap * 5 : nullptr; L.rec_cap = r.rec_cap; L.rec_n = 0;
     L.traj_points = r.traj_points; L.traj_t0 = r.traj_t0; L.traj_dt = r.traj_dt; L.traj_next = 0;
     L.traj = r.traj ? r.traj + rep * r.traj_points * P * 2 : nullptr;
 
@@ -470,7 +473,7 @@ static __device__ __forceinline__ void lanes_body(const VgxDirectArgs &a, Lane &
                 if (L.traj) traj_emit(L, t_new, false);
                 L.currentTime = t_new;
                 double u2 = vgx_pcg64_double(g);
-                int pi = generate_event(L, u2);
+                int pi = generate_event<RECOMB>(L, u2);
                 if (L.error) break;
                 if (L.totalRate == 0.0 || L.gI == 0) break;   // pyx:410-411
                 if (check_lockdowns(L, pi, pi + 1)) update_all_rates(L);   // pyx:412
@@ -552,7 +555,8 @@ static __device__ __forceinline__ void lanes_body(const VgxDirectArgs &a, Lane &
 }
 
 // state in HBM, interleaved across all replicates
-extern "C" __global__ void __launch_bounds__(64) vgx_lanes_kernel(VgxDirectArgs a, VgxLaneWs w) {
+template <bool RECOMB>
+static __device__ __forceinline__ void lanes_hbm(const VgxDirectArgs &a, const VgxLaneWs &w) {
     const int64_t rep = (int64_t)blockIdx.x * 64 + threadIdx.x;
     if (rep >= a.n_replicates) return;
     Lane L;
@@ -560,13 +564,15 @@ extern "C" __global__ void __launch_bounds__(64) vgx_lanes_kernel(VgxDirectArgs 
     L.inf = w.inf; L.sus = w.sus; L.totS = w.totS; L.totI = w.totI; L.lock = w.lock;
     L.cd = w.cd; L.birth = w.birth; L.tE = w.tE; L.hpr = w.hpr; L.shpr = w.shpr; L.immSrc = w.immSrc;
     L.infP = w.infP; L.immP = w.immP; L.popR = w.popR; L.migR = w.migR; L.maxEBM = w.maxEBM; L.effMig = w.effMig;
-    lanes_body(a, L, rep);
+    lanes_body<RECOMB>(a, L, rep);
 }
+extern "C" __global__ void __launch_bounds__(64) vgx_lanes_kernel(VgxDirectArgs a, VgxLaneWs w) { lanes_hbm<false>(a, w); }
+extern "C" __global__ void __launch_bounds__(64) vgx_lanes_recomb_kernel(VgxDirectArgs a, VgxLaneWs w) { lanes_hbm<true>(a, w); }
 
 // state in LDS (minimal models: the whole dense state of 64 replicates fits), interleaved across the 64 lanes
-extern "C" __global__ void __launch_bounds__(64) vgx_lanes_lds_kernel(VgxDirectArgs a) {
+template <bool RECOMB>
+static __device__ __forceinline__ void lanes_lds(const VgxDirectArgs &a, unsigned char *lsm) {
     const int64_t rep = (int64_t)blockIdx.x * 64 + threadIdx.x;
-    extern __shared__ __attribute__((aligned(16))) unsigned char lsm[];
     if (rep >= a.n_replicates) return;   // no barrier in this kernel: lanes are independent
     const int64_t P = a.p.P, H = a.p.H, S = a.p.S, PH = P * H;
     Lane L;
@@ -577,7 +583,15 @@ extern "C" __global__ void __launch_bounds__(64) vgx_lanes_lds_kernel(VgxDirectA
     L.cd = wd; wd += P * 64; L.birth = wd; wd += PH * 64; L.tE = wd; wd += PH * 64; L.hpr = wd; wd += PH * 64;
     L.shpr = wd; wd += PH * S * 64; L.immSrc = wd; wd += P * S * 64; L.infP = wd; wd += P * 64; L.immP = wd; wd += P * 64;
     L.popR = wd; wd += P * 64; L.migR = wd; wd += P * 64; L.maxEBM = wd; wd += P * 64; L.effMig = wd; wd += P * P * 64;
-    lanes_body(a, L, rep);
+    lanes_body<RECOMB>(a, L, rep);
+}
+extern "C" __global__ void __launch_bounds__(64) vgx_lanes_lds_kernel(VgxDirectArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lsm[];
+    lanes_lds<false>(a, lsm);
+}
+extern "C" __global__ void __launch_bounds__(64) vgx_lanes_lds_recomb_kernel(VgxDirectArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lsm[];
+    lanes_lds<true>(a, lsm);
 }
 
 // ---- host-side launcher ----
@@ -588,12 +602,16 @@ extern "C" __attribute__((visibility("hidden"))) size_t vgxi_lanes_elems(int64_t
 extern "C" __attribute__((visibility("hidden"))) hipError_t vgxi_launch_lanes(const VgxDirectArgs *a, const VgxLaneWs *w, hipStream_t stream) {
     const unsigned blocks = (unsigned)((a->n_replicates + 63) / 64);
     const size_t lds = vgxi_lanes_elems(a->p.P, a->p.H, a->p.S) * 64 * 8;
+    const bool recomb = a->p.recombination != 0.0;
     if (lds <= 40 * 1024) {   // four or more blocks per CU keep their state in LDS
-        hipError_t err = hipFuncSetAttribute((const void *)vgx_lanes_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        const void *fn = recomb ? (const void *)vgx_lanes_lds_recomb_kernel : (const void *)vgx_lanes_lds_kernel;
+        hipError_t err = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (err != hipSuccess) return err;
-        hipLaunchKernelGGL(vgx_lanes_lds_kernel, dim3(blocks), dim3(64), lds, stream, *a);
+        if (recomb) hipLaunchKernelGGL(vgx_lanes_lds_recomb_kernel, dim3(blocks), dim3(64), lds, stream, *a);
+        else hipLaunchKernelGGL(vgx_lanes_lds_kernel, dim3(blocks), dim3(64), lds, stream, *a);
     } else {
-        hipLaunchKernelGGL(vgx_lanes_kernel, dim3(blocks), dim3(64), 0, stream, *a, *w);
+        if (recomb) hipLaunchKernelGGL(vgx_lanes_recomb_kernel, dim3(blocks), dim3(64), 0, stream, *a, *w);
+        else hipLaunchKernelGGL(vgx_lanes_kernel, dim3(blocks), dim3(64), 0, stream, *a, *w);
     }
     return hipGetLastError();
 }
