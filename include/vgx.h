@@ -88,7 +88,8 @@ typedef struct vgx_run_opts {
                                 integer columns on the same seed).  Ignored by vgx_simulate_tau. */
     int64_t kernel;          /* direct path: 0 = automatic, 1 = one replicate per wavefront (vgx_direct.hip), 2 = one replicate
                                 per lane (vgx_lanes.hip; small models: popNum <= 16, popNum*hapNum <= 1024, susNum <= 8, EXACT) */
-    int64_t reserved[2];
+    int64_t reserved[2];     /* [0] tau path: 1 = run every try of the halving loop (pyx:2316-2321) instead of starting at the
+                                first try that is not certain to be rejected (same accepted steps either way) */
 } vgx_run_opts;
 
 /* Per-replicate results of the last simulate call. */
@@ -101,7 +102,8 @@ typedef struct vgx_counters {
     int64_t error;                 /* VGX_* code raised inside the kernel for this replicate */
     int64_t multievent_rows;       /* tau: rows appended to the multievent log by this call */
     int64_t reserved[5];           /* [0] tau: events drawn; direct: [1] index of the last attempt that drew random
-                                      numbers (-1 none), [2] its loop iterations (2 uniforms each) */
+                                      numbers (-1 none), [2] its loop iterations (2 uniforms each); [3] tau: tries of the
+                                      halving loop left out as certain rejections */
 } vgx_counters;
 
 /* ---- lifecycle ------------------------------------------------------------------------------ */

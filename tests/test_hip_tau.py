@@ -139,3 +139,48 @@ def test_tau_ensemble_replicates_equal_single_runs():
         assert st.currentTime == m.currentTime and res.events[r] == m.events.ptr
     assert len({int(ens.replicate_state(r).bCounter) for r in range(len(seeds))}) > 1   # the seeds really differ
     ens.close()
+
+
+def test_halving_sieve_leaves_the_accepted_steps_untouched():
+    """Many sparsely filled compartments: the first tries of every step are certain rejections.  The sieve
+    (vgx_tau_sieve_kernel) starts the halving loop later; since a try's random streams are keyed by its index, the
+    steps that get accepted are bit for bit those of the full loop (vgx_run_opts.reserved[0] = 1)."""
+    import ctypes as C
+    from vgsim_amd import Simulator, _capi
+
+    def run(full_loop):
+        with helpers.quiet():
+            s = Simulator(number_of_sites=9, populations_number=16, seed=31)
+        s.set_transmission_rate(2.5); s.set_recovery_rate(0.9); s.set_sampling_rate(0.1); s.set_mutation_rate(0.01)
+        s.set_total_migration_probability(0.01); s.set_population_size(10 ** 8)
+        m = s.simulation
+        m.infectious[:] = 3
+        m.susceptible[:, 0] -= 3 * m.hapNum
+        m.totalInfectious[:] = 3 * m.hapNum
+        m.totalSusceptible[:] = m.susceptible.sum(axis=1)
+        m.globalInfectious = int(m.totalInfectious.sum())
+        m.first_simulation = True
+        m.initial_infectious[:] = m.infectious
+        m.initial_susceptible[:] = m.susceptible
+        eng = _capi.HipEngine(m.sites, m.hapNum, m.popNum, m.susNum, n_replicates=1)
+        m.events.CreateEvents(12)
+        m.events.ptr = 1
+        m.events.CreateEvents(12)
+        eng.set_params(m); eng.set_state(m); eng.set_seeds(np.array([31], dtype=np.int64))
+        o = _capi.VgxRunOpts(); o.record_events = 0      # hundreds of thousands of multievent rows per step
+        o.reserved[0] = 1 if full_loop else 0
+        eng._check(eng.lib.vgx_simulate_tau(eng.handle, 12, 10 ** 15, -1.0, 1, C.byref(o)))
+        eng.get_state(m, 0)
+        c = eng.counters(0)
+        out = (m, int(c.reserved[3]), int(c.reserved[0]), int(c.ev_ptr))
+        eng.close()
+        return out
+    a, skipped_a, drawn_a, ptr_a = run(True)
+    b, skipped_b, drawn_b, ptr_b = run(False)
+    assert skipped_a == 0 and skipped_b >= 3           # certain rejections left out
+    assert ptr_a == ptr_b == 13 and drawn_a == drawn_b > 0
+    assert a.currentTime == b.currentTime > 0
+    assert np.array_equal(a.infectious, b.infectious) and np.array_equal(a.susceptible, b.susceptible)
+    assert not np.array_equal(a.infectious, a.initial_infectious)
+    for k in a.COUNTERS:
+        assert getattr(a, k) == getattr(b, k), k

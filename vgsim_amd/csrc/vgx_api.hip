@@ -19,6 +19,7 @@
 // launchers defined next to their kernels (vgx_direct.hip)
 extern "C" hipError_t vgxi_launch_direct(const VgxDirectArgs *a, size_t lds, hipStream_t stream);
 extern "C" int vgxi_tau_inc_shards(int64_t H, int64_t P);
+extern "C" hipError_t vgxi_tau_sieve(const VgxTauArgs *a, hipStream_t s);
 extern "C" hipError_t vgxi_launch_lanes(const VgxDirectArgs *a, const VgxLaneWs *w, hipStream_t stream);
 extern "C" size_t vgxi_direct_lds_bytes(int P, int S, int C, int CB);
 extern "C" hipError_t vgxi_launch_init_reps(const VgxDevRep *r, int P, int S, int64_t R, const int32_t *s_nocc,
@@ -74,7 +75,8 @@ struct vgx_engine {
         r_evtime, r_evcols, r_locrec, r_loctime, r_traj, r_prof;
     // tau-leaping (dense compartments)
     DevBuf t_I, t_S, t_dChk, t_dApp, t_dSi, t_dTot, t_totInf, t_gI, t_cd, t_lock, t_F, t_eff, t_Aeff, t_Gout, t_dS,
-        t_taubits, t_tau, t_time, t_flags, t_counters, t_cnttry, t_mev, t_mevn, t_mevbase, t_locn, t_mutcum, t_migcdf, t_migIn, t_inc, t_incn;
+        t_taubits, t_tau, t_time, t_flags, t_counters, t_cnttry, t_mev, t_mevn, t_mevbase, t_locn, t_mutcum, t_migcdf, t_migIn, t_inc, t_incn, t_sieve, t_sieveskip;
+    std::vector<int64_t> tau_sieve_skipped;   // [R] tries left out by the sieve in the last tau call
     bool last_was_tau = false;
     int64_t tau_mev_cap = 0;
     struct TauStep { double time; int64_t m0, m1; };
@@ -874,6 +876,8 @@ extern "C" int vgx_simulate_tau(vgx_engine *e, int64_t iterations, int64_t sampl
     rc |= ensure(e, e->t_time, (size_t)R * 8);
     rc |= ensure(e, e->t_flags, (size_t)R * nF * 4);
     rc |= ensure(e, e->t_counters, (size_t)R * 8 * 8);
+    rc |= ensure(e, e->t_sieve, (size_t)R * VGX_SIEVE_K * 8);
+    rc |= ensure(e, e->t_sieveskip, (size_t)R * 8);
     rc |= ensure(e, e->t_cnttry, (size_t)R * 8 * 8);
     rc |= ensure(e, e->t_mev, (size_t)(R * std::max<int64_t>(mev_cap, 1) * 6) * 8);
     rc |= ensure(e, e->t_mevn, (size_t)R * 8);
@@ -898,6 +902,8 @@ extern "C" int vgx_simulate_tau(vgx_engine *e, int64_t iterations, int64_t sampl
     HIPCHECK(e, hipMemset(e->t_dSi.p, 0, (size_t)(R * P * S) * 8));
     HIPCHECK(e, hipMemset(e->t_dTot.p, 0, (size_t)(R * P) * 8));
     HIPCHECK(e, hipMemset(e->t_counters.p, 0, (size_t)R * 64));
+    HIPCHECK(e, hipMemset(e->t_sieve.p, 0, (size_t)R * VGX_SIEVE_K * 8));
+    HIPCHECK(e, hipMemset(e->t_sieveskip.p, 0, (size_t)R * 8));
     HIPCHECK(e, hipMemset(e->t_cnttry.p, 0, (size_t)R * 64));
     HIPCHECK(e, hipMemset(e->t_mevn.p, 0, (size_t)R * 8));
     HIPCHECK(e, hipMemset(e->t_mevbase.p, 0, (size_t)R * 8));
@@ -953,6 +959,8 @@ extern "C" int vgx_simulate_tau(vgx_engine *e, int64_t iterations, int64_t sampl
     a.migIn = (double *)e->t_migIn.p;
     a.inc = (int64_t *)e->t_inc.p; a.inc_cap = inc_cap; a.inc_shards = vgxi_tau_inc_shards(H, P); a.inc_n = (unsigned long long *)e->t_incn.p;
     a.counters = (int64_t *)e->t_counters.p; a.cnt_try = (int64_t *)e->t_cnttry.p;
+    a.sieve = (double *)e->t_sieve.p; a.sieve_skipped = (int64_t *)e->t_sieveskip.p;
+    a.sieve_on = o.reserved[0] == 1 ? 0 : 1;   // vgx_run_opts.reserved[0] = 1: run every try of the halving loop
     a.mev = (int64_t *)e->t_mev.p; a.mev_cap = mev_cap;
     e->tau_mev_cap = mev_cap;
     a.mev_n = (unsigned long long *)e->t_mevn.p; a.mev_base = (unsigned long long *)e->t_mevbase.p;
@@ -1030,6 +1038,7 @@ extern "C" int vgx_simulate_tau(vgx_engine *e, int64_t iterations, int64_t sampl
         HIPCHECK(e, vgxi_tau_drift(&a, e->stream));
         HIPCHECK(e, vgxi_tau_choose(&a, e->stream));
         launches += 4;
+        if (a.sieve_on) { HIPCHECK(e, vgxi_tau_sieve(&a, e->stream)); launches += 2; }
         for (int tries = 0;; tries++) {
             HIPCHECK(e, vgxi_tau_draw(&a, e->stream));
             HIPCHECK(e, vgxi_tau_suscep_draw(&a, e->stream));
@@ -1117,6 +1126,8 @@ extern "C" int vgx_simulate_tau(vgx_engine *e, int64_t iterations, int64_t sampl
         s.traj_next = c[7];  // events drawn (sum of multiplicities), reported through vgx_counters.reserved[0]
         if (restarts[(size_t)r] > 0) s.migNonPlus = 0;
     }
+    e->tau_sieve_skipped.assign((size_t)R, 0);
+    HIPCHECK(e, hipMemcpy(e->tau_sieve_skipped.data(), a.sieve_skipped, (size_t)R * 8, hipMemcpyDeviceToHost));
     e->sc_host = e->tau_sc;
     e->sc_host_valid = true;
     e->last_was_tau = true;
@@ -1136,6 +1147,7 @@ extern "C" int vgx_get_counters(vgx_engine *e, int64_t replicate, vgx_counters *
     out->ev_ptr = s.ev_ptr;
     out->ev_first_new = s.restarts > 0 ? 0 : e->ev_ptr0;
     if (e->last_was_tau) out->reserved[0] = s.traj_next;  // tau: events drawn (sum of channel multiplicities)
+    if (e->last_was_tau && (size_t)replicate < e->tau_sieve_skipped.size()) out->reserved[3] = e->tau_sieve_skipped[(size_t)replicate];
     out->loop_iterations = s.loop_iterations;
     out->restarts = s.restarts;
     out->lockdown_records = s.loc_n;

@@ -17,6 +17,7 @@
 #define VGX_MAX_CLASSES 1024   // distinct per-haplotype rate rows (full classes) supported by the direct kernel
 #define VGX_LOC_CAP 4096       // lockdown switches recorded per replicate and call
 #define VGX_INC_SHARDS 4096     // shards of the tau kernels' cross-compartment event list
+#define VGX_SIEVE_K 16          // halvings the tau sieve looks ahead
 #define VGX_PROF_SLOTS 16       // in-kernel phase stamps of the diagnostic (-DVGX_PROFILE) build
 
 // fields of the per-replicate f64 population block
@@ -176,4 +177,9 @@ struct VgxTauArgs {
     unsigned long long *loc_n;     // [R]
     int32_t *loc_rec;    // [R][VGX_LOC_CAP][2]
     double *loc_time;    // [R][VGX_LOC_CAP]
+    // sieve of the halving loop (vgx_tau_sieve_kernel): lower bounds on the expected number of compartments that fail
+    // the bounds check at tau * 2^-k, k = 0..VGX_SIEVE_K-1
+    double *sieve;       // [R][VGX_SIEVE_K]
+    int64_t *sieve_skipped;  // [R] tries skipped so far in this call
+    int32_t sieve_on;
 };

@@ -387,6 +387,106 @@ extern "C" __global__ void __launch_bounds__(64) vgx_tau_choose_kernel(VgxTauArg
     }
 }
 
+
+// ---- sieve of the halving loop -----------------------------------------------------------------------------------------
+// The reference redraws the whole step with tau/2 whenever one compartment fails the bounds check (pyx:2316-2321).  With
+// many sparsely filled compartments the first tries are certain to fail: at config 4 (2.7e8 compartments of 3 hosts) the
+// expected number of failing compartments is 1.6e6 at the chosen tau and still 500 three halvings later.  A try's random
+// streams are keyed by the try index (Philox counter word `retry`), so leaving out a try that would have been rejected
+// changes nothing at all in what is finally accepted.  This kernel computes, for tau * 2^-k (k < VGX_SIEVE_K), a LOWER
+// bound E_k on the expected number of failing compartments; vgx_tau_sieve_pick_kernel then starts the loop at the first k
+// with E_k <= VGX_SIEVE_MIN_FAILS (treating compartments as independent, a skipped try would have been accepted with
+// probability < exp(-VGX_SIEVE_MIN_FAILS)).
+//
+// Bound for compartment c with X hosts (all channels are independent Poisson variables):
+//   fails if   no transmission and no out-migration of c (both are booked as + on c by the check, pyx:2473, 2517),
+//              no mutant arrives, and recoveries + samplings >= X + 1.
+//   P(no transmission, no out-migration) = exp(-(r_tr + r_mig) X tau)
+//   P(no mutant arrives) >= exp(-(|drift_c| + r_dec X) tau) >= exp(-m_c - r_dec X tau),  m_c = max(eps X / 2, 1):
+//              transmission + incoming mutation <= drift_c + decrements, and ChooseTau made |drift_c| tau <= m_c
+//   P(Poisson(mu) >= n) >= exp(-mu) mu^n / n!,   mu = (r_rec + r_samp) X tau,  n = X + 1
+// Evaluated in single precision (the threshold has orders of magnitude of slack).  grid = (gx, P, R).
+#define VGX_SIEVE_MIN_FAILS 32.0
+#define VGX_SIEVE_XMAX 64
+extern "C" __global__ void __launch_bounds__(TB) vgx_tau_sieve_kernel(VgxTauArgs a) {
+    const int rep = blockIdx.z, pn = blockIdx.y;
+    if (!a.active[rep]) return;
+    const VgxDevParams &p = a.p;
+    const int P = p.P, S = p.S, C = p.C, H = p.H;
+    if (C > 256) return;   // no table space: E stays 0 and nothing is skipped
+    __shared__ float s_all[256], s_dec[256], s_lf[VGX_SIEVE_XMAX + 2];
+    __shared__ double s_E[VGX_SIEVE_K];
+    const double F = a.F[(int64_t)rep * P + pn];
+    const int64_t *Sus = a.S + (int64_t)rep * P * S + (int64_t)pn * S;
+    for (int i = threadIdx.x; i < C; i += TB) {
+        const int cb = p.c_bidx[i];
+        double rtr = 0.0;
+        for (int sn = 0; sn < S; ++sn) rtr += p.cb_b[cb] * p.cb_sigma[cb * S + sn] * (double)Sus[sn] * F;
+        const double rmig = a.has_mig ? a.Gout[((int64_t)rep * P + pn) * p.CB + cb] * p.cb_b[cb] * p.mig[(int64_t)pn * P + pn] : 0.0;
+        const double dec = p.c_d[i] + p.c_s[i] * p.sampMult[pn];
+        s_dec[i] = (float)dec;
+        s_all[i] = (float)((rmig + dec + (a.mut_uniform ? a.mut_total : p.c_tm[i]) + rtr) * 1.000001);   // rounded up
+    }
+    for (int i = threadIdx.x; i < VGX_SIEVE_XMAX + 2; i += TB) s_lf[i] = (float)(lgamma((double)i + 1.0) * 1.000001);
+    if (threadIdx.x < VGX_SIEVE_K) s_E[threadIdx.x] = 0.0;
+    __syncthreads();
+    const float tau0 = (float)a.tau[rep];
+    float acc[VGX_SIEVE_K];
+#pragma unroll
+    for (int k = 0; k < VGX_SIEVE_K; ++k) acc[k] = 0.f;
+    const int32_t *Irow = a.I + ((int64_t)rep * P + pn) * H;
+    for (int h0 = (blockIdx.x * TB + threadIdx.x) * 4; h0 < H; h0 += gridDim.x * TB * 4) {
+        int Iv[4] = {0, 0, 0, 0};
+        if (h0 + 3 < H && (H & 3) == 0) { const int4 x = *(const int4 *)(Irow + h0); Iv[0] = x.x; Iv[1] = x.y; Iv[2] = x.z; Iv[3] = x.w; }
+        else for (int j = 0; j < 4; ++j) if (h0 + j < H) Iv[j] = Irow[h0 + j];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int X = Iv[j];
+            if (X <= 0 || X > VGX_SIEVE_XMAX) continue;
+            const int c = (C == 1) ? 0 : p.cls[h0 + j];
+            const float Xf = (float)X, n = Xf + 1.0f;
+            const float mu0 = s_dec[c] * Xf * tau0;
+            if (!(mu0 > 0.f)) continue;
+            const float m = fmaxf(0.0151f * Xf, 1.0f);
+            const float A = -m + n * (__logf(mu0) - 1e-6f) - s_lf[X + 1];
+            const float B = (s_all[c] * Xf * tau0 + mu0);
+            const float nl2 = n * 0.69314724f;   // ln 2 rounded up
+            float sc = 1.0f, Ak = A;
+#pragma unroll
+            for (int k = 0; k < VGX_SIEVE_K; ++k) {
+                acc[k] += __expf(Ak - B * sc);
+                Ak -= nl2;
+                sc *= 0.5f;
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < VGX_SIEVE_K; ++k) {
+        float v = acc[k];
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+        if ((threadIdx.x & 63) == 0 && v > 0.f) atomicAdd(&s_E[k], (double)v);
+    }
+    __syncthreads();
+    if (threadIdx.x < VGX_SIEVE_K && s_E[threadIdx.x] > 0.0) atomicAdd(&a.sieve[(int64_t)rep * VGX_SIEVE_K + threadIdx.x], s_E[threadIdx.x] * 0.99);
+}
+
+// Starts the halving loop of the step at the first try that is not certain to fail.  grid = R, one thread.
+extern "C" __global__ void __launch_bounds__(64) vgx_tau_sieve_pick_kernel(VgxTauArgs a) {
+    const int rep = blockIdx.x;
+    if (threadIdx.x != 0 || !a.active[rep]) return;
+    double *E = a.sieve + (int64_t)rep * VGX_SIEVE_K;
+    int k0 = 0;
+    while (k0 < VGX_SIEVE_K && E[k0] > VGX_SIEVE_MIN_FAILS) k0 += 1;
+    for (int k = 0; k < VGX_SIEVE_K; ++k) E[k] = 0.0;
+    if (k0 > 0) {
+        double t = a.tau[rep];
+        for (int k = 0; k < k0; ++k) t *= 0.5;   // the halvings the skipped tries would have made (pyx:2319)
+        a.tau[rep] = t;
+        a.retry[rep] = k0;
+        a.sieve_skipped[rep] += k0;
+    }
+}
+
 // A multievent row (events.pxi:116-125) of the step being drawn; rows of a rejected retry are discarded by
 // rewinding mev_n (vgx_tau_decide_kernel).
 static __device__ __forceinline__ void tau_row(const VgxTauArgs &a, int rep, int64_t num, int type, int hap, int pop,
@@ -1025,6 +1125,13 @@ extern "C" __attribute__((visibility("hidden"))) hipError_t vgxi_tau_draw(const 
     return hipGetLastError();
 }
 TAU_LAUNCH(tau_suscep_draw, SUS_GRID, dim3(TB))
+extern "C" __attribute__((visibility("hidden"))) hipError_t vgxi_tau_sieve(const VgxTauArgs *a, hipStream_t s) {
+    unsigned tiles = (unsigned)((a->p.H + 4 * TB - 1) / (4 * TB));
+    unsigned gx = tiles < 64u ? tiles : 64u;
+    hipLaunchKernelGGL(vgx_tau_sieve_kernel, dim3(gx, (unsigned)a->p.P, (unsigned)a->R), dim3(TB), 0, s, *a);
+    hipLaunchKernelGGL(vgx_tau_sieve_pick_kernel, dim3((unsigned)a->R), dim3(64), 0, s, *a);
+    return hipGetLastError();
+}
 TAU_LAUNCH(tau_scatter, dim3((unsigned)a->inc_shards, (unsigned)a->R, (unsigned)(VGX_INC_SHARDS / a->inc_shards)), dim3(64))
 // Number of thread blocks per replicate of the draw kernel: the cross-compartment list gets one shard per block (a
 // power of two, at most VGX_INC_SHARDS), so that its whole capacity is usable whatever the grid size.
