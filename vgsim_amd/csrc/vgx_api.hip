@@ -899,6 +899,8 @@ extern "C" int vgx_simulate_tau(vgx_engine *e, int64_t iterations, int64_t sampl
     rc |= upload(e, e->r_seeds, e->seeds.data(), e->seeds.size());
     if (rc) return VGX_ERR_HIP;
     HIPCHECK(e, hipMemset(e->t_incn.p, 0, (size_t)R * VGX_INC_SHARDS * 8));
+    HIPCHECK(e, hipMemset(e->t_dChk.p, 0, (size_t)(R * P * H) * 4));   // the step kernels keep both delta arrays zero between tries
+    HIPCHECK(e, hipMemset(e->t_dApp.p, 0, (size_t)(R * P * H) * 4));
     HIPCHECK(e, hipMemset(e->t_dSi.p, 0, (size_t)(R * P * S) * 8));
     HIPCHECK(e, hipMemset(e->t_dTot.p, 0, (size_t)(R * P) * 8));
     HIPCHECK(e, hipMemset(e->t_counters.p, 0, (size_t)R * 64));

@@ -814,9 +814,10 @@ extern "C" __global__ void __launch_bounds__(TB) vgx_tau_draw_kernel(VgxTauArgs 
                              (uint32_t)((uint64_t)a.seeds[rep] >> 32) ^ 0x85EBCA6Bu};
     const int groups = ((H + 255) / 256) * 64;   // 4 haplotypes per thread, 256 per wavefront chunk
     const uint32_t ctr_step = (uint32_t)a.step[rep], ctr_retry = ((uint32_t)a.retry[rep] << 20) | 0xFFFFFu;   // loop invariants
-    // Phase A (every tile): the quick test; all four own deltas are stored as zero and the few compartments that may
-    // draw events are queued in LDS.  Phase B (when the queue holds a few wavefronts' worth, and at the end): the queue
-    // is worked off with all lanes busy and the queued compartments' deltas are stored again.
+    // Phase A (every tile): the quick test; the few compartments that may draw events are queued in LDS.  Phase B (when
+    // the queue holds a few wavefronts' worth, and at the end): the queue is worked off with all lanes busy and the queued
+    // compartments' deltas are stored.  Both delta arrays are all zero on entry: the check kernel clears the entries of
+    // dChk it finds set, the commit kernel those of dApp, so a try costs no 8-bytes-per-compartment zero fill.
     enum { QCAP = 8 * TB, QGO = QCAP - 4 * TB };
     __shared__ int q_n, q_h[QCAP], q_w[QCAP];
     __shared__ IncStage stage;
@@ -862,20 +863,12 @@ extern "C" __global__ void __launch_bounds__(TB) vgx_tau_draw_kernel(VgxTauArgs 
                     q_w[slot] = (int)w[j];
                 }
             }
-            if (full) {
-                const int4 z = make_int4(0, 0, 0, 0);
-                *(int4 *)(dCrow + h0) = z;
-                *(int4 *)(dArow + h0) = z;
-            } else {
-                for (int j = 0; j < 4; ++j)
-                    if (h0 + j < H) { dCrow[h0 + j] = 0; dArow[h0 + j] = 0; }
-            }
         }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // LDS only: queue length visible to everyone
         const int nq = q_n;
         const bool last = q0 + (int)(gridDim.x * TB) >= groups;
         if (nq >= QGO || (last && nq > 0)) {   // block-uniform
-            __syncthreads();   // the zero stores above are complete before queued compartments are stored again
+            __syncthreads();
             for (int k = threadIdx.x; k < nq; k += TB) {
                 const int h = q_h[k];
                 int64_t oc, oa;
@@ -972,6 +965,7 @@ extern "C" __global__ void __launch_bounds__(TB) vgx_tau_check_kernel(VgxTauArgs
                 if (d[j] != 0) {
                     int64_t v = (int64_t)d[j] + (int64_t)a.I[off + j];
                     bad = bad || v < 0 || v > p.sizes[pn];
+                    a.dChk[off + j] = 0;   // nobody reads it after this kernel: zero again for the next try
                 }
         }
     }
@@ -1013,26 +1007,28 @@ extern "C" __global__ void __launch_bounds__(64) vgx_tau_decide_kernel(VgxTauArg
 }
 
 // UpdateCompartmentCounts_tau for accepted replicates (I += dApp, S += dS, totals); the small per-population
-// accumulators are cleared for accepted and rejected ones alike (the [P][H] delta arrays are overwritten by the
-// next draw).  grid = (ceil(H/TB), P, R).
+// accumulators are cleared for accepted and rejected ones alike, and so are the entries of dApp that the try set.  grid = (ceil(H/TB), P, R).
 extern "C" __global__ void __launch_bounds__(TB) vgx_tau_commit_kernel(VgxTauArgs a) {
     const int rep = blockIdx.z, pn = blockIdx.y;
     if (!a.deciding[rep]) return;
     const int P = a.p.P, S = a.p.S, H = a.p.H;
     const bool acc = a.accepted[rep] && !a.error[rep];
     const int h0 = (blockIdx.x * TB + threadIdx.x) * 4;   // four compartments per thread
-    if (h0 < H && acc) {
+    if (h0 < H) {   // rejected tries too: their entries of dApp are cleared
         const int64_t off = (int64_t)rep * P * H + (int64_t)pn * H + h0;
         if (h0 + 3 < H && (H & 3) == 0) {
             int4 x = *(const int4 *)(a.dApp + off);
             if (x.x | x.y | x.z | x.w) {
-                int4 v = *(const int4 *)(a.I + off);
-                v.x += x.x; v.y += x.y; v.z += x.z; v.w += x.w;
-                *(int4 *)(a.I + off) = v;
+                if (acc) {
+                    int4 v = *(const int4 *)(a.I + off);
+                    v.x += x.x; v.y += x.y; v.z += x.z; v.w += x.w;
+                    *(int4 *)(a.I + off) = v;
+                }
+                *(int4 *)(a.dApp + off) = make_int4(0, 0, 0, 0);
             }
         } else {
             for (int j = 0; j < 4; ++j)
-                if (h0 + j < H) { int32_t dA = a.dApp[off + j]; if (dA != 0) a.I[off + j] += dA; }
+                if (h0 + j < H) { int32_t dA = a.dApp[off + j]; if (dA != 0) { if (acc) a.I[off + j] += dA; a.dApp[off + j] = 0; } }
         }
     }
     if (blockIdx.x == 0 && threadIdx.x < S) {
