@@ -155,8 +155,43 @@ def spread_leg(device, mode="exact", replicates=1024, events=20000, occupied=409
            "roofline": {"bound": "hbm", "achieved": ev * bpe / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": ev * bpe / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
                         "bytes_per_event": bpe, "mean_occupancy_list_len": nocc}}
+    if mode == "exact":
+        # per event: the refreshed population's whole list (pyx:519-528), on average half of the selected population's
+        # list (fast_choose.pxi:22-25), the popRate and migPopRate totals (pyx:537-546)
+        steps = 1.5 * nocc + 2.0 * POPS
+        out["chain_bound"] = {"bound": "dependent f64 additions in the reference's order (one v_fmac_f64 per term)",
+                              "steps_per_event": steps, "achieved": ev * steps / (ms * 1e-3), "peak": CHAIN_STEPS_PER_S,
+                              "unit": "chain steps/s", "frac": ev * steps / (ms * 1e-3) / CHAIN_STEPS_PER_S}
     ens.close()
     return out
+
+
+def c4_direct_leg(device, replicates=1024, events=20000):
+    """Direct Gillespie at BASELINE config 4's shape (2^20 haplotypes x 256 populations, migration), index-case start: the
+    general instantiation of the wave kernel (populations in tiles of 64, 37 KB of LDS tables per wavefront)."""
+    import numpy as np
+    from vgsim_amd import Simulator
+    from vgsim_amd.ensemble import Ensemble
+    with contextlib.redirect_stdout(io.StringIO()):
+        s = Simulator(number_of_sites=10, populations_number=256, seed=2020)
+    s.set_transmission_rate(2.5); s.set_recovery_rate(0.9); s.set_sampling_rate(0.1); s.set_mutation_rate(0.01)
+    s.set_total_migration_probability(0.01); s.set_population_size(10 ** 7)
+    ens = Ensemble(s, replicates, device=device)
+    res = None
+    for it in range(2):
+        res = ens.simulate(events, sample_size=10 ** 12, record_events=True,
+                           seeds=2020 + it * replicates + np.arange(replicates, dtype=np.int64))
+    out = {"workload": "direct Gillespie at config 4's shape: 1048576 haplotypes x 256 populations, %d replicates x %d events, "
+                       "exact mode, index-case start" % (replicates, events),
+           "value": res.total_events / (res.kernel_ms * 1e-3), "unit": "events/s (device time)", "kernel_ms_per_launch": res.kernel_ms}
+    ens.close()
+    return out
+
+
+# Sequential f64 additions in the reference's order run as a chain of dependent v_fmac_f64 (DPP) steps, one term per
+# step; measured issue rate of that chain: 1.9 ns per step and SIMD at >= 4 waves/SIMD (profiles/r01_microbench_chain.txt),
+# 1024 SIMDs.  This is the bound of the exact mode on long occupancy lists (DESIGN.md 4.1), reported beside the HBM one.
+CHAIN_STEPS_PER_S = 1024 / 1.9e-9
 
 
 def genealogy_leg(device, events=300000):
@@ -290,7 +325,7 @@ def main():
     ap.add_argument("--no-tau", action="store_true", help="skip the tau-leap (config 4) leg")
     ap.add_argument("--no-extra", action="store_true", help="skip the FAST-mode, spread-occupancy and config-2 legs")
     ap.add_argument("--only", default="", help="development/profiling: run only this extra leg (fast_mode, spread_occupancy, "
-                                               "spread_occupancy_fast, config2, genealogy, tau_leap) and print its JSON")
+                                               "spread_occupancy_fast, config2, genealogy, single_trajectory, direct_config4_shape, tau_leap) and print its JSON")
     a = ap.parse_args()
 
     import numpy as np
@@ -312,7 +347,8 @@ def main():
     extra_legs = (("fast_mode", lambda d: fast_leg(d, R, N, a.traj_points)),
                   ("spread_occupancy", lambda d: spread_leg(d, "exact", replicates=4096, events=5000)),
                   ("spread_occupancy_fast", lambda d: spread_leg(d, "fast", replicates=4096)),
-                  ("config2", c2_leg), ("genealogy", genealogy_leg), ("single_trajectory", single_leg), ("tau_leap", tau_leg))
+                  ("config2", c2_leg), ("genealogy", genealogy_leg), ("single_trajectory", single_leg),
+                  ("direct_config4_shape", c4_direct_leg), ("tau_leap", tau_leg))
     if a.only:
         print(json.dumps({a.only: dict(extra_legs)[a.only](local)}), flush=True)
         return
@@ -442,7 +478,7 @@ def main():
         if tau is not None:
             line["tau_leap"] = tau
         if world == 1 and not a.no_extra:
-            for name, fn in extra_legs[:6]:
+            for name, fn in extra_legs[:7]:
                 try:
                     line[name] = fn(local)
                 except Exception as ex:
