@@ -75,7 +75,7 @@ struct vgx_engine {
         r_evtime, r_evcols, r_locrec, r_loctime, r_traj, r_prof;
     // tau-leaping (dense compartments)
     DevBuf t_I, t_S, t_dChk, t_dApp, t_dSi, t_dTot, t_totInf, t_gI, t_cd, t_lock, t_F, t_eff, t_Aeff, t_Gout, t_dS,
-        t_taubits, t_tau, t_time, t_flags, t_counters, t_cnttry, t_mev, t_mevn, t_mevbase, t_locn, t_mutcum, t_migcdf, t_migIn, t_inc, t_incn, t_sieve, t_sieveskip;
+        t_taubits, t_tau, t_time, t_flags, t_counters, t_cnttry, t_mev, t_mevn, t_mevbase, t_locn, t_mutcum, t_migcdf, t_migIn, t_mutHi, t_inc, t_incn, t_sieve, t_sieveskip;
     std::vector<int64_t> tau_sieve_skipped;   // [R] tries left out by the sieve in the last tau call
     bool last_was_tau = false;
     int64_t tau_mev_cap = 0;
@@ -884,6 +884,7 @@ extern "C" int vgx_simulate_tau(vgx_engine *e, int64_t iterations, int64_t sampl
     rc |= ensure(e, e->t_mevbase, (size_t)R * 8);
     rc |= ensure(e, e->t_locn, (size_t)R * 8);
     if (e->h_has_mig) rc |= ensure(e, e->t_migIn, (size_t)(R * P * H) * 8);
+    rc |= ensure(e, e->t_mutHi, (size_t)(e->d.sites > 6 ? R * P * H : 1) * 8);   // tiled drift, first pass (vgx_tau_muthigh_kernel)
     const int64_t inc_cap = std::max<int64_t>((int64_t)1 << 22, P * H / 8) / VGX_INC_SHARDS * VGX_INC_SHARDS;
     rc |= ensure(e, e->t_inc, (size_t)(R * inc_cap) * 8);
     rc |= ensure(e, e->t_incn, (size_t)R * VGX_INC_SHARDS * 8);
@@ -959,6 +960,7 @@ extern "C" int vgx_simulate_tau(vgx_engine *e, int64_t iterations, int64_t sampl
     a.mutcum = (const double *)e->t_mutcum.p;
     a.migcdf = (double *)e->t_migcdf.p;
     a.migIn = (double *)e->t_migIn.p;
+    a.mutHi = (double *)e->t_mutHi.p;
     a.inc = (int64_t *)e->t_inc.p; a.inc_cap = inc_cap; a.inc_shards = vgxi_tau_inc_shards(H, P); a.inc_n = (unsigned long long *)e->t_incn.p;
     a.counters = (int64_t *)e->t_counters.p; a.cnt_try = (int64_t *)e->t_cnttry.p;
     a.sieve = (double *)e->t_sieve.p; a.sieve_skipped = (int64_t *)e->t_sieveskip.p;

@@ -154,6 +154,7 @@ struct VgxTauArgs {
     int32_t Ppad;        // P rounded up to a multiple of 32
     int32_t *eff_dirty;  // [R] contact densities changed since effMig/Aeff/F were computed
     double *migIn;       // [R][P][H]  sum_spn Aeff[tpn][spn] * I[spn][hn] (drift of incoming migration)
+    double *mutHi;       // [R][P][H]  incoming mutation drift through the high sites (tiled drift, sites > 6), or null
     double *Gout;        // [R][P][CB] out-migration weight of a source population per birth class
     double *dS;          // [R][P][S]  drift of the susceptible compartments
     unsigned long long *tau_bits;  // [R] running minimum of the tau candidates (bit pattern)

@@ -350,6 +350,172 @@ extern "C" __global__ void __launch_bounds__(TB) vgx_tau_drift_kernel(VgxTauArgs
     if (threadIdx.x == 0) atomicMin(&a.tau_bits[rep], smin);
 }
 
+// ---- tiled drift (uniform mutation model, 1 <= sites <= 6 + VGX_DRIFT_HIGH_MAX) ------------------------------------------
+// The gathers of the kernel above read every neighbouring 1 KiB chunk from HBM again (PMC at config 4: 17.7 GB per step for
+// 1 GiB of counts).  Haplotype numbers are base-4 digit strings, so the single-site neighbours of a haplotype differ from it
+// in one two-bit group: with the low VGX_DRIFT_LOW sites (4096 consecutive haplotypes) of a population in LDS all their
+// neighbours are local, and the remaining high sites are handled by a first pass over tiles that hold ALL values of the high
+// digits for a short run of the low ones.  Each pass reads the counts once.
+#define VGX_DRIFT_LOW 6        // sites whose neighbours lie inside a 4096-haplotype tile
+#define VGX_DRIFT_HIGH_MAX 4   // high sites of the first pass: up to 4^4 rows
+#define VGX_MUTHIGH_CELLS 8192 // compartments per tile of the first pass (32 KB of LDS: 256 rows x 32 columns = one 128-byte line per row)
+static __host__ __device__ inline bool tau_drift_tiled_ok(int sites, int mut_uniform) {
+    return mut_uniform && sites >= 1 && sites <= VGX_DRIFT_LOW + VGX_DRIFT_HIGH_MAX;
+}
+// rate with which a source that differs from `h` at site s (allele `al` there instead of h's `AS`) mutates into h
+static __device__ __forceinline__ double tau_mutp_in(const double *l_mutp, int s, int AS, int al) {
+    const int i = AS - (AS > al ? 1 : 0);   // derived-state index of AS in the source's numbering
+    return l_mutp[s * 3 + i];
+}
+
+// Pass 1: out[pn][h] = incoming mutation drift through the high sites.  Tile = rows (all 4^nh values of the high digits)
+// x CH consecutive values of the low part; grid = (ceil(4^low_sites / CH), P, R), dynamic LDS = rows * CH * 4 bytes.
+extern "C" __global__ void __launch_bounds__(TB) vgx_tau_muthigh_kernel(VgxTauArgs a) {
+    const int rep = blockIdx.z, pn = blockIdx.y;
+    if (!a.active[rep]) return;
+    const VgxDevParams &p = a.p;
+    const int P = p.P, H = p.H, sites = p.sites;
+    const int nh = sites - VGX_DRIFT_LOW, rows = 1 << (2 * nh), CH = VGX_MUTHIGH_CELLS / rows < 4096 ? VGX_MUTHIGH_CELLS / rows : 4096;
+    const int lowbits = 2 * VGX_DRIFT_LOW;
+    extern __shared__ __attribute__((aligned(16))) unsigned char hsm[];
+    int32_t *tile = (int32_t *)hsm;   // [rows][CH]
+    __shared__ double l_mutp[48];
+    for (int i = threadIdx.x; i < 3 * sites && i < 48; i += TB) l_mutp[i] = a.mutp[i / 3][i % 3];
+    const int32_t *I = a.I + ((int64_t)rep * P + pn) * H;
+    double *out = a.mutHi + ((int64_t)rep * P + pn) * H;
+    const int c0 = blockIdx.x * CH;
+    for (int idx = threadIdx.x; idx < rows * CH; idx += TB) {
+        const int row = idx / CH, col = idx - row * CH;
+        tile[idx] = I[(row << lowbits) | (c0 + col)];
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < rows * CH; idx += TB) {
+        const int row = idx / CH, col = idx - row * CH;
+        double d = 0.0;
+        for (int s = 0; s < nh; ++s) {   // site s of the haplotype <-> two-bit group nh - 1 - s of `row`
+            const int sh = 2 * (nh - 1 - s);
+            const int AS = (row >> sh) & 3;
+            if (l_mutp[s * 3] == l_mutp[s * 3 + 1] && l_mutp[s * 3 + 1] == l_mutp[s * 3 + 2]) {
+                // equally likely derived states: the three neighbouring counts are added as integers (their sum stays
+                // below the population size) and scaled once
+                d += l_mutp[s * 3] * (double)(tile[(row ^ (1 << sh)) * CH + col] + tile[(row ^ (2 << sh)) * CH + col] +
+                                              tile[(row ^ (3 << sh)) * CH + col]);
+                continue;
+            }
+            for (int x = 1; x < 4; ++x) {
+                const int nb = tile[(row ^ (x << sh)) * CH + col];
+                if (nb != 0) d += tau_mutp_in(l_mutp, s, AS, AS ^ x) * (double)nb;
+            }
+        }
+        out[(row << lowbits) | (c0 + col)] = d;
+    }
+}
+
+// Pass 2: the drift kernel proper on tiles of 4^min(sites, VGX_DRIFT_LOW) consecutive haplotypes held in LDS.
+// grid = (ceil(H / tile), P, R).
+extern "C" __global__ void __launch_bounds__(TB) vgx_tau_drift_tiled_kernel(VgxTauArgs a) {
+    const int rep = blockIdx.z, pn = blockIdx.y;
+    if (!a.active[rep]) return;
+    const VgxDevParams &p = a.p;
+    const int P = p.P, S = p.S, H = p.H, sites = p.sites, C = p.C, CB = p.CB;
+    const int lane = threadIdx.x & 63;
+    const int low = sites < VGX_DRIFT_LOW ? sites : VGX_DRIFT_LOW, nh = sites - low;
+    const int TS = 1 << (2 * low);   // tile size (<= 4096 haplotypes)
+    const int64_t rowoff = ((int64_t)rep * P + pn) * H;
+    const int32_t *I = a.I + rowoff;
+    const int64_t *Sus = a.S + (int64_t)rep * P * S + (int64_t)pn * S;
+    __shared__ int32_t tile[4096];
+    __shared__ double sdS[64];
+    __shared__ unsigned long long smin;
+    __shared__ double l_cd[256], l_cs[256], l_ctm[256], l_base[16 * 64], l_mutp[48];
+    __shared__ int32_t l_bidx[256], l_stype[256];
+    const bool useL = C <= 256 && CB <= 16;
+    if (threadIdx.x < 64) sdS[threadIdx.x] = 0.0;
+    if (threadIdx.x == 0) smin = (unsigned long long)__double_as_longlong(1.0);
+    if (useL) {
+        for (int i = threadIdx.x; i < C; i += TB) {
+            l_cd[i] = p.c_d[i]; l_cs[i] = p.c_s[i] * p.sampMult[pn]; l_ctm[i] = p.c_tm[i];
+            l_bidx[i] = p.c_bidx[i]; l_stype[i] = p.c_stype[i];
+        }
+        for (int i = threadIdx.x; i < CB * S; i += TB) l_base[i] = p.cb_b[i / S] * p.cb_sigma[i] * (double)Sus[i % S];
+    }
+    for (int i = threadIdx.x; i < 3 * sites && i < 48; i += TB) l_mutp[i] = a.mutp[i / 3][i % 3];
+    const int h0 = blockIdx.x * TS;
+    for (int i = threadIdx.x * 4; i < TS; i += TB * 4) {
+        if (TS >= 4) *(int4 *)(tile + i) = *(const int4 *)(I + h0 + i);
+        else for (int j = 0; j < TS; ++j) tile[j] = I[h0 + j];
+    }
+    __syncthreads();
+    const double F = a.F[(int64_t)rep * P + pn];
+    double cand_min = 1.0;
+    // a thread takes four consecutive compartments at a time (32-byte loads of the two f64 inputs); its contributions to
+    // the susceptible drift of the first four groups are summed in registers and reduced once at the end
+    double redS[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int t0 = threadIdx.x * 4; t0 < TS; t0 += TB * 4) {
+        double mh[4] = {0.0, 0.0, 0.0, 0.0}, mg[4] = {0.0, 0.0, 0.0, 0.0};
+        if (nh > 0) { const double4 v = *(const double4 *)(a.mutHi + rowoff + h0 + t0); mh[0] = v.x; mh[1] = v.y; mh[2] = v.z; mh[3] = v.w; }
+        if (a.has_mig) { const double4 v = *(const double4 *)(a.migIn + rowoff + h0 + t0); mg[0] = v.x; mg[1] = v.y; mg[2] = v.z; mg[3] = v.w; }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int tt = t0 + j;
+            const int hh = h0 + tt;
+            const int c = (C == 1) ? 0 : p.cls[hh];
+            const int cb = useL ? l_bidx[c] : p.c_bidx[c];
+            const int st = useL ? l_stype[c] : p.c_stype[c];
+            const int32_t Icell = tile[tt];
+            const double Ih = (double)Icell;
+            double drift = 0.0;
+            const double rec = (useL ? l_cd[c] : p.c_d[c]) * Ih;
+            const double samp = useL ? l_cs[c] * Ih : p.c_s[c] * Ih * p.sampMult[pn];
+            drift -= rec;
+            drift -= samp;
+            drift -= (useL ? l_ctm[c] : p.c_tm[c]) * Ih;
+            // incoming mutation through the low sites: neighbours inside the tile (site s <-> two-bit group sites - 1 - s)
+            for (int s = nh; s < sites; ++s) {
+                const int sh = 2 * (sites - s - 1);
+                const int AS = (tt >> sh) & 3;
+                if (l_mutp[s * 3] == l_mutp[s * 3 + 1] && l_mutp[s * 3 + 1] == l_mutp[s * 3 + 2]) {
+                    drift += l_mutp[s * 3] * (double)(tile[tt ^ (1 << sh)] + tile[tt ^ (2 << sh)] + tile[tt ^ (3 << sh)]);
+                    continue;
+                }
+                for (int x = 1; x < 4; ++x) {
+                    const int nb = tile[tt ^ (x << sh)];
+                    if (nb != 0) drift += tau_mutp_in(l_mutp, s, AS, AS ^ x) * (double)nb;
+                }
+            }
+            drift += mh[j];   // ... and through the high sites (pass 1)
+            const double to_st = rec + samp;
+            for (int sn = 0; sn < S; ++sn) {
+                const double base = useL ? l_base[cb * S + sn] : p.cb_b[cb] * p.cb_sigma[cb * S + sn] * (double)Sus[sn];
+                const double v = base * Ih * F + base * mg[j];
+                drift += v;
+                const double red = -v + (st == sn ? to_st : 0.0);   // susceptible drift of (pn, sn)
+                if (sn < 4) redS[sn] += red;
+                else if (red != 0.0) atomicAdd(&sdS[sn], red);
+            }
+            if (fabs(drift) >= 1e-8) {  // pyx:2440-2444, epsilon*X in single precision
+                float eps = 0.03f;
+                double v = (double)(eps * (float)Icell) / 2.0;
+                double cand = (v > 1.0 ? v : 1.0) / fabs(drift);
+                if (cand < cand_min) cand_min = cand;
+            }
+        }
+    }
+    for (int sn = 0; sn < 4 && sn < S; ++sn) {
+        double red = redS[sn];
+        for (int o = 32; o > 0; o >>= 1) red += __shfl_down(red, o);
+        if (lane == 0 && red != 0.0) atomicAdd(&sdS[sn], red);
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        double other = __shfl_down(cand_min, o);
+        if (other < cand_min) cand_min = other;
+    }
+    if (lane == 0) atomic_min_pos_double(&smin, cand_min);
+    __syncthreads();
+    if (threadIdx.x < S && sdS[threadIdx.x] != 0.0) atomicAdd(&a.dS[((int64_t)rep * P + pn) * S + threadIdx.x], sdS[threadIdx.x]);
+    if (threadIdx.x == 0) atomicMin(&a.tau_bits[rep], smin);
+}
+
 // Susceptible compartments: immunity-transition drift (pyx:2374-2381), tau candidates (pyx:2445-2450),
 // final tau_l; clears the per-step accumulators.  grid = R, block = 64.
 extern "C" __global__ void __launch_bounds__(64) vgx_tau_choose_kernel(VgxTauArgs a) {
@@ -1106,6 +1272,18 @@ extern "C" __attribute__((visibility("hidden"))) hipError_t vgxi_tau_drift(const
     }
     unsigned tiles = (unsigned)((a->p.H + TB - 1) / TB);
     unsigned gx = tiles < 32u ? tiles : 32u;
+    if (tau_drift_tiled_ok(a->p.sites, a->mut_uniform) && a->mutHi) {
+        const int sites = a->p.sites, low = sites < VGX_DRIFT_LOW ? sites : VGX_DRIFT_LOW, nh = sites - low;
+        if (nh > 0) {
+            const int rows = 1 << (2 * nh), CH = VGX_MUTHIGH_CELLS / rows < 4096 ? VGX_MUTHIGH_CELLS / rows : 4096;
+            const size_t lds = (size_t)rows * CH * 4;
+            hipError_t err = hipFuncSetAttribute((const void *)vgx_tau_muthigh_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (err != hipSuccess) return err;
+            hipLaunchKernelGGL(vgx_tau_muthigh_kernel, dim3((unsigned)((1 << (2 * low)) / CH), (unsigned)a->p.P, (unsigned)a->R), dim3(TB), lds, s, *a);
+        }
+        hipLaunchKernelGGL(vgx_tau_drift_tiled_kernel, dim3((unsigned)(a->p.H >> (2 * low)), (unsigned)a->p.P, (unsigned)a->R), dim3(TB), 0, s, *a);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(vgx_tau_drift_kernel, dim3(gx, (unsigned)a->p.P, (unsigned)a->R), dim3(TB), 0, s, *a);
     return hipGetLastError();
 }
