@@ -31,6 +31,9 @@
 #pragma clang fp contract(fast)
 
 #define TB 256  // threads per block of the compartment kernels
+#ifndef VGX_DRAW_GX
+#define VGX_DRAW_GX 32u   // thread blocks of the draw kernel per (population, replicate)
+#endif
 
 struct TauRng {
     uint32_t c0, c1, c2, c3, k0, k1;
@@ -1294,7 +1297,7 @@ extern "C" __attribute__((visibility("hidden"))) hipError_t vgxi_tau_draw(const 
     hipError_t err = hipFuncSetAttribute((const void *)vgx_tau_draw_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds ? lds : 16));
     if (err != hipSuccess) return err;
     unsigned tiles = (unsigned)((a->p.H + TB - 1) / TB);
-    unsigned gx = (tiles + 3u) / 4u < 32u ? (tiles + 3u) / 4u : 32u;   // blocks per (population, replicate); each loops over its tiles of 4*TB haplotypes
+    unsigned gx = (tiles + 3u) / 4u < VGX_DRAW_GX ? (tiles + 3u) / 4u : VGX_DRAW_GX;   // blocks per (population, replicate); each loops over its tiles of 4*TB haplotypes
     hipLaunchKernelGGL(vgx_tau_draw_kernel, dim3(gx, (unsigned)a->p.P, (unsigned)a->R), dim3(TB), lds ? lds : 16, s, *a);
     return hipGetLastError();
 }
@@ -1311,7 +1314,7 @@ TAU_LAUNCH(tau_scatter, dim3((unsigned)a->inc_shards, (unsigned)a->R, (unsigned)
 // power of two, at most VGX_INC_SHARDS), so that its whole capacity is usable whatever the grid size.
 extern "C" __attribute__((visibility("hidden"))) int vgxi_tau_inc_shards(int64_t H, int64_t P) {
     unsigned tiles = (unsigned)((H + TB - 1) / TB);
-    int64_t blocks = (int64_t)((tiles + 3u) / 4u < 32u ? (tiles + 3u) / 4u : 32u) * P;
+    int64_t blocks = (int64_t)((tiles + 3u) / 4u < VGX_DRAW_GX ? (tiles + 3u) / 4u : VGX_DRAW_GX) * P;
     int sh = 1;
     while (sh * 2 <= blocks && sh * 2 <= VGX_INC_SHARDS) sh *= 2;
     return sh;
