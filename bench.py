@@ -301,14 +301,22 @@ def tau_leg(device, steps=20, per_cell=3, seed=2020):
     ms = eng.last_kernel_ms
     n = max(int(c.loop_iterations), 1)
     fused = 16.0 * P * H * n
+    traffic = None
+    try:   # HBM bytes per step from the committed PMC passes of this same leg (profiles/pmc_tau_c4.json)
+        d = json.load(open(os.path.join(ROOT, "profiles", "pmc_tau_c4.json")))
+        if d["config"] == {"steps": steps, "per_cell": per_cell}:
+            traffic = d["hbm_bytes_per_step"]
+    except Exception:
+        pass
     out = {"workload": "BASELINE config 4: 1048576 haplotypes (10 sites) x 256 populations, total migration 0.01, "
                        "dense occupancy (%d infected per compartment), Poisson tau-leaping" % per_cell,
            "steps": n, "ms_per_step": ms / n, "events_drawn": int(c.reserved[0]),
            "value": c.reserved[0] / (ms * 1e-3), "unit": "events/s (device time)",
            "roofline": {"bound": "hbm", "achieved": fused / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": fused / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
-                        "note": "all step kernels together (prep, migin, drift, draw x retries, check, commit); "
-                                "algorithmic bytes = 16*P*H per step (read+write infectious once)"}}
+                        "frac": fused / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
+                        "note": "all step kernels together (prep, migin, drift, sieve, draw x tries, check, commit); "
+                                "algorithmic bytes = 16*P*H per step (read+write infectious once, one try); traffic = "
+                                "PMC bytes per step (about four tries of the reference's halving loop per step)"}}
     eng.close()
     return out
 
