@@ -207,3 +207,20 @@ def test_command_line_builds_the_model_from_the_example_files():
     assert (sim.simulation.hapNum, sim.simulation.popNum, sim.simulation.sRate[0]) == (1, 1, 0.1)
     _, out = quiet(cmd.main, ["-c"])
     assert "VGsim" in out
+
+
+def test_plot_helpers(tmp_path):
+    matplotlib = pytest.importorskip("matplotlib")
+    matplotlib.use("Agg")
+    sim, _ = quiet(Simulator, 2, 2, 2, seed=3)
+    fill_chain(sim)
+    sim.simulation.loc.AddLockdown(True, 0, 1.2)
+    sim.simulation.loc.AddLockdown(False, 0, 2.2)
+    sim.add_plot_infectious(0, 0, step_num=3)
+    sim.add_plot_infectious(0, 'A*', step_num=3, label_infectious="inf", label_samples="smp")
+    sim.add_plot_susceptible(1, 1, step_num=3)
+    sim.add_legend()
+    sim.add_title("trajectories")
+    out = tmp_path / "p.png"
+    sim.plot(str(out))
+    assert out.stat().st_size > 1000 and sim.fig is None

@@ -254,7 +254,7 @@ class HipEngine:
         rc = self.lib.vgx_simulate_tau(self.handle, iterations, sample_size, float(time), attempts,
                                        C.byref(opts) if opts is not None else None)
         self._check(rc)
-        mev_base = 0 if False else m.multievents.ptr
+        mev_base = m.multievents.ptr   # rows of earlier tau calls stay in the log
         self._absorb(m, tau=True, mev_base=mev_base)
 
     def multievents(self, replicate=0):

@@ -41,7 +41,7 @@ class PlotMixin:
             for hi in sorted(self.simulation.calculate_indexes(haplotype, self.simulation.hapNum)):
                 self.plot_infectious(population, hi, step_num, label_infectious, label_samples)
         else:
-            print("#TODO")
+            print("Incorrect type of haplotype. Type should be int or str.")   # upstream prints "#TODO" (if:663)
 
     def plot_infectious(self, population, haplotype, step_num, label_infectious, label_samples):
         infections, sample, time_points, lockdowns = self.simulation.get_data_infectious(population, haplotype, step_num)
@@ -51,13 +51,13 @@ class PlotMixin:
         elif isinstance(label_infectious, str):
             self.ax_2.plot(time_points, infections, label=label_infectious)
         else:
-            print("#TODO")
+            print("Incorrect type of label. Type should be str or None.")   # upstream prints "#TODO"
         if label_samples is None:
             self.ax.plot(time_points, sample, "--", label='Samples ' + name)
         elif isinstance(label_samples, str):
             self.ax.plot(time_points, sample, "--", label=label_samples)
         else:
-            print("#TODO")
+            print("Incorrect type of label. Type should be str or None.")   # upstream prints "#TODO"
         if len(lockdowns) != 0:
             _shade_lockdowns(_plt(), time_points, infections, lockdowns)
 
@@ -69,7 +69,7 @@ class PlotMixin:
         elif isinstance(label_susceptible, str):
             self.ax_2.plot(time_points, susceptible, label=label_susceptible)
         else:
-            print("#TODO")
+            print("Incorrect type of label. Type should be str or None.")   # upstream prints "#TODO"
         if len(lockdowns) != 0:
             _shade_lockdowns(_plt(), time_points, susceptible, lockdowns)
 
