@@ -308,6 +308,52 @@ CASES["recomb_restart"] = (_ctor(number_of_sites=2, populations_number=1, number
                            [(lambda s: s.set_transmission_rate(1.3), _direct(3000))])
 RECOMBINATION_CASES = ("recomb_a", "recomb_pos", "recomb_restart")
 
+
+# ---------------------------------------------------------------- the reference's command-line example model
+def _cmd_example(s):
+    """testing/cmd_example/example.{rt,pp,mg,su,st} (copied as data to tests/golden/cmd_example/) applied the way
+    VGsim_cmd.py:113-142 does.  The files are parsed with plain string operations here so that the same setter calls
+    reach the reference when the goldens are recorded and this repository's Simulator in the tests."""
+    import os
+    d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cmd_example")
+
+    def rows(name, skip):
+        with open(os.path.join(d, name)) as f:
+            return [ln.rstrip().split(" ") for ln in f.read().splitlines()[skip:] if ln.strip() and ln[0] != "#"]
+    for i, r in enumerate(rows("example.rt", 2)):
+        s.set_transmission_rate(float(r[1]), i)
+        s.set_recovery_rate(float(r[2]), i)
+        s.set_sampling_rate(float(r[3]), i)
+        for j, mut in enumerate(r[4:]):
+            a = [float(v) for v in mut.split(",")]
+            s.set_mutation_rate(a[0], i, j)
+            allele = (i >> (2 * (len(r) - 5 - j))) & 3
+            probs = a[1:]
+            probs.insert(allele, 0.0)
+            s.set_mutation_probabilities(probs, i, j)
+    pp = rows("example.pp", 2)
+    mg = rows("example.mg", 1)
+    for i, r in enumerate(pp):
+        s.set_population_size(int(r[1]), i)
+        s.set_contact_density(float(r[2]), i)
+        s.set_npi([float(v) for v in r[3].split(",")], i)
+        s.set_sampling_multiplier(float(r[4]), i)
+        for j in range(len(pp)):
+            if i != j:
+                s.set_migration_probability(float(mg[i][j]), i, j)
+    for i, r in enumerate(rows("example.su", 2)):
+        for j, v in enumerate(r[2:]):
+            s.set_susceptibility(float(v), i, j)
+        s.set_susceptibility_type(int(r[1]), i)
+    for i, r in enumerate(rows("example.st", 1)):
+        for j, v in enumerate(r):
+            if i != j:
+                s.set_immunity_transition(float(v), i, j)
+
+
+CASES["cmd_example"] = (_ctor(number_of_sites=2, populations_number=3, number_of_susceptible_groups=3, seed=17),
+                        [(_cmd_example, _direct(12000))])
+
 # cases whose full (6,N) chain is committed; the others commit head/tail columns + sha256 + counters
 FULL_CHAIN_LIMIT = 20000
 

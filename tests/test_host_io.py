@@ -224,3 +224,17 @@ def test_plot_helpers(tmp_path):
     out = tmp_path / "p.png"
     sim.plot(str(out))
     assert out.stat().st_size > 1000 and sim.fig is None
+
+
+def test_readers_and_the_setter_sequence_build_the_golden_model():
+    """The `cmd_example` parity case (tests/models.py) parses the example files by hand; the shipped readers + the
+    command line's setter sequence must build the identical model."""
+    import models
+    from vgsim_amd import cmd
+    (a, _), _ = quiet(cmd.build_simulator, cmd.parser().parse_args(
+        ["-seed", "17", "-rt", os.path.join(D, "example.rt"), "-pm", os.path.join(D, "example.pp"), os.path.join(D, "example.mg"),
+         "-su", os.path.join(D, "example.su"), "-st", os.path.join(D, "example.st")]))
+    (b, phases), _ = quiet(models.build, Simulator, "cmd_example")
+    phases[0][0](b)
+    for k in PARAMS:
+        assert np.array_equal(getattr(a.simulation, k), getattr(b.simulation, k)), k
