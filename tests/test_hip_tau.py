@@ -184,3 +184,37 @@ def test_halving_sieve_leaves_the_accepted_steps_untouched():
     assert not np.array_equal(a.infectious, a.initial_infectious)
     for k in a.COUNTERS:
         assert getattr(a, k) == getattr(b, k), k
+
+
+@pytest.mark.parametrize("sites,weights", [(7, None), (8, [1.0, 2.0, 0.5, 1.5]), (9, None), (10, None)])
+def test_tiled_drift_leap_length_matches_oracle(oracle_mod, sites, weights):
+    """The two-pass tiled drift (high sites over row tiles, low sites in an LDS tile) for 1-4 high sites, flat and unequal
+    derived-state weights: the first accepted leap after a bit-exact direct warm-up has the oracle's length."""
+    from vgsim_amd import Simulator
+
+    def run(engine):
+        with helpers.quiet():
+            s = Simulator(number_of_sites=sites, populations_number=2, seed=3)
+            s.set_transmission_rate(2.5); s.set_recovery_rate(0.9); s.set_sampling_rate(0.1); s.set_mutation_rate(0.3)
+            if weights is not None:
+                s.set_mutation_probabilities(weights)
+            s.set_migration_probability(0.01)
+            m = s.simulation
+            if engine == "hip":
+                s.simulate(3000)
+                s.simulate(2, sample_size=10 ** 9, method="tau")
+            else:
+                assert oracle_mod.run_direct(m, 3000, 3000, -1, 200, log_mode=oracle_mod.LOG_PORTABLE) == 0
+                assert oracle_mod.run_tau(m, 2, 10 ** 9, -1, 200, log_mode=oracle_mod.LOG_PORTABLE) == 0
+        return m
+    hip, ref = run("hip"), run("oracle")
+    assert np.array_equal(hip.events.as_array()[:, :3000], ref.events.as_array()[:, :3000])
+    assert hip.events.types[3000] == 6 and ref.events.types[3000] == 6
+    assert len(np.nonzero(hip.infectious.sum(axis=0))[0]) > 50          # mutants spread over many haplotypes
+    dt_hip = hip.events.times[3000] - hip.events.times[2999]
+    dt_ref = ref.events.times[3000] - ref.events.times[2999]
+    # the accepted leap is the chosen tau after however many halvings each side's own random draws needed (pyx:2316-2321):
+    # equal up to a power of two
+    k = np.log2(dt_ref / dt_hip)
+    assert abs(k - round(k)) < 1e-8 and abs(round(k)) <= 12, (dt_hip, dt_ref)
+    assert dt_hip * 2.0 ** round(k) == pytest.approx(dt_ref, rel=1e-9)
