@@ -75,7 +75,7 @@ struct vgx_engine {
         r_evtime, r_evcols, r_locrec, r_loctime, r_traj, r_prof;
     // tau-leaping (dense compartments)
     DevBuf t_I, t_S, t_dChk, t_dApp, t_dSi, t_dTot, t_totInf, t_gI, t_cd, t_lock, t_F, t_eff, t_Aeff, t_Gout, t_dS,
-        t_taubits, t_tau, t_time, t_flags, t_counters, t_cnttry, t_mev, t_mevn, t_mevbase, t_locn, t_mutcum, t_migcdf, t_migIn, t_mutHi, t_inc, t_incn, t_sieve, t_sieveskip;
+        t_taubits, t_tau, t_time, t_flags, t_counters, t_cnttry, t_mev, t_mevn, t_mevbase, t_locn, t_mutcum, t_migcdf, t_migIn, t_mutHi, t_colT, t_colTW, t_inc, t_incn, t_sieve, t_sieveskip;
     std::vector<int64_t> tau_sieve_skipped;   // [R] tries left out by the sieve in the last tau call
     bool last_was_tau = false;
     int64_t tau_mev_cap = 0;
@@ -86,7 +86,8 @@ struct vgx_engine {
     std::vector<int64_t> tau_ev_ptr0;
     std::vector<VgxRepScalars> tau_sc;
     std::vector<double> h_startLD, h_endLD, h_cdBefore, h_cdAfter;
-    bool h_has_mig = false, h_mut_uniform = false;
+    bool h_has_mig = false, h_mut_uniform = false, h_mig_uniform = false;
+    double h_mig_b = 0.0, h_mig_d = 1.0;
     double h_mutp[16][3] = {}, h_mut_total = 0.0;
     DevBuf i_nocc, i_hap, i_cls, i_cnt, i_sus;          // initial state (Restart)
     DevBuf s_nocc, s_hap, s_cls, s_cnt, s_sus, s_cd, s_tot;  // state at the start of the call
@@ -340,6 +341,14 @@ extern "C" int vgx_set_params(vgx_engine *e, const vgx_params *p) {
     rc |= upload(e, e->p_sampMult, p->samplingMultiplier, (size_t)P);
     rc |= upload(e, e->p_actualSizes, e->actualSizes.data(), (size_t)P);
     rc |= upload(e, e->p_mig, e->mig.data(), (size_t)(P * P));
+    // uniform migration: one common off-diagonal probability and (hence) one common recomputed diagonal
+    e->h_mig_uniform = e->h_has_mig && P >= 2 && P <= 1024;
+    for (int64_t i = 0; i < P && e->h_mig_uniform; i++)
+        for (int64_t j = 0; j < P; j++) {
+            const double v = e->mig[(size_t)(i * P + j)];
+            if (v != (i == j ? e->mig[0] : e->mig[1])) { e->h_mig_uniform = false; break; }
+        }
+    if (e->h_mig_uniform) { e->h_mig_d = e->mig[0]; e->h_mig_b = e->mig[1]; }
     rc |= upload(e, e->p_suscTrans, p->suscepTransition, (size_t)(S * S));
     rc |= upload(e, e->p_suscCumul, e->suscepCumul.data(), (size_t)S);
     if (rc) return VGX_ERR_HIP;
@@ -883,7 +892,8 @@ extern "C" int vgx_simulate_tau(vgx_engine *e, int64_t iterations, int64_t sampl
     rc |= ensure(e, e->t_mevn, (size_t)R * 8);
     rc |= ensure(e, e->t_mevbase, (size_t)R * 8);
     rc |= ensure(e, e->t_locn, (size_t)R * 8);
-    if (e->h_has_mig) rc |= ensure(e, e->t_migIn, (size_t)(R * P * H) * 8);
+    if (e->h_has_mig && !e->h_mig_uniform) rc |= ensure(e, e->t_migIn, (size_t)(R * P * H) * 8);
+    if (e->h_mig_uniform) { rc |= ensure(e, e->t_colT, (size_t)(R * H) * 8); rc |= ensure(e, e->t_colTW, (size_t)(R * H) * 8); }
     rc |= ensure(e, e->t_mutHi, (size_t)(e->d.sites > 6 ? R * P * H : 1) * 8);   // tiled drift, first pass (vgx_tau_muthigh_kernel)
     const int64_t inc_cap = std::max<int64_t>((int64_t)1 << 22, P * H / 8) / VGX_INC_SHARDS * VGX_INC_SHARDS;
     rc |= ensure(e, e->t_inc, (size_t)(R * inc_cap) * 8);
@@ -961,6 +971,8 @@ extern "C" int vgx_simulate_tau(vgx_engine *e, int64_t iterations, int64_t sampl
     a.migcdf = (double *)e->t_migcdf.p;
     a.migIn = (double *)e->t_migIn.p;
     a.mutHi = (double *)e->t_mutHi.p;
+    a.mig_uniform = e->h_mig_uniform ? 1 : 0; a.mig_b = e->h_mig_b; a.mig_d = e->h_mig_d;
+    a.colT = (double *)e->t_colT.p; a.colTW = (double *)e->t_colTW.p;
     a.inc = (int64_t *)e->t_inc.p; a.inc_cap = inc_cap; a.inc_shards = vgxi_tau_inc_shards(H, P); a.inc_n = (unsigned long long *)e->t_incn.p;
     a.counters = (int64_t *)e->t_counters.p; a.cnt_try = (int64_t *)e->t_cnttry.p;
     a.sieve = (double *)e->t_sieve.p; a.sieve_skipped = (int64_t *)e->t_sieveskip.p;

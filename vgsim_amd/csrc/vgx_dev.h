@@ -155,6 +155,13 @@ struct VgxTauArgs {
     int32_t *eff_dirty;  // [R] contact densities changed since effMig/Aeff/F were computed
     double *migIn;       // [R][P][H]  sum_spn Aeff[tpn][spn] * I[spn][hn] (drift of incoming migration)
     double *mutHi;       // [R][P][H]  incoming mutation drift through the high sites (tiled drift, sites > 6), or null
+    // uniform migration (every off-diagonal migration probability equal to mig_b, hence every diagonal equal to mig_d):
+    // effMig[t][s] = b^2 W + (d b - b^2)(w_t + w_s), w = cd / actualSizes, W = sum w, so the incoming migration pressure
+    // needs only the two column sums below instead of the [P x P] x [P x H] product
+    int32_t mig_uniform;
+    double mig_b, mig_d;
+    double *colT;        // [R][H] sum_spn I[spn][h]
+    double *colTW;       // [R][H] sum_spn w[spn] I[spn][h]
     double *Gout;        // [R][P][CB] out-migration weight of a source population per birth class
     double *dS;          // [R][P][S]  drift of the susceptible compartments
     unsigned long long *tau_bits;  // [R] running minimum of the tau candidates (bit pattern)

@@ -249,6 +249,67 @@ extern "C" __global__ void __launch_bounds__(MIGIN_TB) vgx_tau_migin_kernel(cons
     }
 }
 
+
+// ---- uniform migration -----------------------------------------------------------------------------------------------------
+// With one common off-diagonal migration probability b (diagonal d = 1 - (P-1) b; what set_migration_probability(p) and
+// set_total_migration_probability produce) effectiveMigration (pyx:327-338) has the closed form
+//     effMig[t][s] = sum_q m[t][q] m[s][q] w[q] = b^2 W + (d b - b^2)(w[t] + w[s]),   w = cd / actualSizes,  W = sum_q w[q],
+// so the incoming migration pressure sum_{s != t} effMig[t][s] m[s][s] I[s][h] (pyx:2366-2367) is
+//     d { (b^2 W + (d b - b^2) w[t]) (T[h] - I[t][h]) + (d b - b^2) (TW[h] - w[t] I[t][h]) }
+// with the two column sums T = sum_s I[s][h], TW = sum_s w[s] I[s][h]: O(P H) work and no [P][H] f64 array, instead of
+// the [P x P] x [P x H] product of vgx_tau_migin_kernel.
+#define VGX_MIGU_PMAX 1024
+struct MigU { double c1, c2, wt; };
+// block-uniform (all threads of the block call it); s_part: 16 doubles of shared scratch; ends with a barrier
+static __device__ __forceinline__ MigU tau_migu_setup(const VgxTauArgs &a, int rep, int pn, double *s_part) {
+    const VgxDevParams &p = a.p;
+    const int P = p.P;
+    double part = 0.0;
+    for (int q = threadIdx.x; q < P; q += blockDim.x) part += a.cd[(int64_t)rep * P + q] / p.actualSizes[q];
+    for (int o = 32; o > 0; o >>= 1) part += __shfl_down(part, o);
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = part;
+    __syncthreads();
+    double W = 0.0;
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) W += s_part[i];
+    MigU u;
+    const double b = a.mig_b, d = a.mig_d, g = d * b - b * b;
+    u.wt = a.cd[(int64_t)rep * P + pn] / p.actualSizes[pn];
+    u.c1 = d * (b * b * W + g * u.wt);
+    u.c2 = d * g;
+    __syncthreads();
+    return u;
+}
+static __device__ __forceinline__ double tau_migu(const MigU &u, double T, double TW, double Ih) {
+    return u.c1 * (T - Ih) + u.c2 * (TW - u.wt * Ih);
+}
+
+// Column sums over the populations.  grid = (ceil(H / (4 TB)), R).
+extern "C" __global__ void __launch_bounds__(TB) vgx_tau_colsum_kernel(VgxTauArgs a) {
+    const int rep = blockIdx.y;
+    if (!a.active[rep]) return;
+    const VgxDevParams &p = a.p;
+    const int P = p.P, H = p.H;
+    __shared__ double s_w[VGX_MIGU_PMAX];
+    for (int q = threadIdx.x; q < P; q += TB) s_w[q] = a.cd[(int64_t)rep * P + q] / p.actualSizes[q];
+    __syncthreads();
+    const int h0 = (blockIdx.x * TB + threadIdx.x) * 4;
+    if (h0 >= H) return;
+    const int32_t *I = a.I + (int64_t)rep * P * H;
+    long long t[4] = {0, 0, 0, 0};
+    double tw[4] = {0.0, 0.0, 0.0, 0.0};
+    const bool full = h0 + 3 < H && (H & 3) == 0;
+    for (int q = 0; q < P; ++q) {
+        int x[4] = {0, 0, 0, 0};
+        if (full) { const int4 v = *(const int4 *)(I + (int64_t)q * H + h0); x[0] = v.x; x[1] = v.y; x[2] = v.z; x[3] = v.w; }
+        else for (int j = 0; j < 4; ++j) if (h0 + j < H) x[j] = I[(int64_t)q * H + h0 + j];
+        const double w = s_w[q];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { t[j] += x[j]; tw[j] += w * (double)x[j]; }
+    }
+    for (int j = 0; j < 4; ++j)
+        if (h0 + j < H) { a.colT[(int64_t)rep * H + h0 + j] = (double)t[j]; a.colTW[(int64_t)rep * H + h0 + j] = tw[j]; }
+}
+
 // Net drift of every infectious compartment and its tau candidate (Propensities + ChooseTau); partial
 // sums of the susceptible drift.  Thread <-> compartment, grid = (ceil(H/TB), P, R); every gather of a
 // neighbouring haplotype is coalesced across the lanes (neighbours of consecutive haplotypes are consecutive).
@@ -280,6 +341,9 @@ extern "C" __global__ void __launch_bounds__(TB) vgx_tau_drift_kernel(VgxTauArgs
         l_site_flat[i] = (a.mutp[i][0] == a.mutp[i][1] && a.mutp[i][1] == a.mutp[i][2]) ? 1 : 0;
     __syncthreads();
     const double F = a.F[(int64_t)rep * P + pn];
+    __shared__ double s_wu[16];
+    MigU mu = {0.0, 0.0, 0.0};
+    if (a.has_mig && a.mig_uniform) mu = tau_migu_setup(a, rep, pn, s_wu);
     double cand_min = 1.0;
     for (int hn = blockIdx.x * TB + threadIdx.x; hn - (int)threadIdx.x < H; hn += gridDim.x * TB) {
         const bool live = hn < H;
@@ -326,7 +390,10 @@ extern "C" __global__ void __launch_bounds__(TB) vgx_tau_drift_kernel(VgxTauArgs
             }
         }
         // transmission (pyx:2407-2417) and incoming migration (pyx:2360-2370)
-        const double migI = (a.has_mig && live) ? a.migIn[((int64_t)rep * P + pn) * H + hh] : 0.0;
+        double migI = 0.0;
+        if (a.has_mig && live)
+            migI = a.mig_uniform ? tau_migu(mu, a.colT[(int64_t)rep * H + hh], a.colTW[(int64_t)rep * H + hh], Ih)
+                                 : a.migIn[((int64_t)rep * P + pn) * H + hh];
         const double to_st = live ? rec + samp : 0.0;
         for (int sn = 0; sn < S; ++sn) {
             double base = useL ? l_base[cb * S + sn] : p.cb_b[cb] * p.cb_sigma[cb * S + sn] * (double)Sus[sn];
@@ -450,6 +517,9 @@ extern "C" __global__ void __launch_bounds__(TB) vgx_tau_drift_tiled_kernel(VgxT
     }
     __syncthreads();
     const double F = a.F[(int64_t)rep * P + pn];
+    __shared__ double s_wu[16];
+    MigU mu = {0.0, 0.0, 0.0};
+    if (a.has_mig && a.mig_uniform) mu = tau_migu_setup(a, rep, pn, s_wu);
     double cand_min = 1.0;
     // a thread takes four consecutive compartments at a time (32-byte loads of the two f64 inputs); its contributions to
     // the susceptible drift of the first four groups are summed in registers and reduced once at the end
@@ -457,7 +527,14 @@ extern "C" __global__ void __launch_bounds__(TB) vgx_tau_drift_tiled_kernel(VgxT
     for (int t0 = threadIdx.x * 4; t0 < TS; t0 += TB * 4) {
         double mh[4] = {0.0, 0.0, 0.0, 0.0}, mg[4] = {0.0, 0.0, 0.0, 0.0};
         if (nh > 0) { const double4 v = *(const double4 *)(a.mutHi + rowoff + h0 + t0); mh[0] = v.x; mh[1] = v.y; mh[2] = v.z; mh[3] = v.w; }
-        if (a.has_mig) { const double4 v = *(const double4 *)(a.migIn + rowoff + h0 + t0); mg[0] = v.x; mg[1] = v.y; mg[2] = v.z; mg[3] = v.w; }
+        if (a.has_mig && a.mig_uniform) {   // the two column sums are shared by all populations: they stay in the caches
+            const double4 v = *(const double4 *)(a.colT + (int64_t)rep * H + h0 + t0);
+            const double4 u = *(const double4 *)(a.colTW + (int64_t)rep * H + h0 + t0);
+            mg[0] = tau_migu(mu, v.x, u.x, (double)tile[t0]); mg[1] = tau_migu(mu, v.y, u.y, (double)tile[t0 + 1]);
+            mg[2] = tau_migu(mu, v.z, u.z, (double)tile[t0 + 2]); mg[3] = tau_migu(mu, v.w, u.w, (double)tile[t0 + 3]);
+        } else if (a.has_mig) {
+            const double4 v = *(const double4 *)(a.migIn + rowoff + h0 + t0); mg[0] = v.x; mg[1] = v.y; mg[2] = v.z; mg[3] = v.w;
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int tt = t0 + j;
@@ -1262,7 +1339,11 @@ extern "C" __global__ void __launch_bounds__(64) vgx_tau_finish_kernel(VgxTauArg
 TAU_LAUNCH(tau_eff, dim3((unsigned)a->p.P, (unsigned)a->R), dim3(TB))
 TAU_LAUNCH(tau_prep, dim3((unsigned)a->R), dim3(TB))
 extern "C" __attribute__((visibility("hidden"))) hipError_t vgxi_tau_drift(const VgxTauArgs *a, hipStream_t s) {
-    if (a->has_mig) {
+    if (a->has_mig && a->mig_uniform) {
+        hipLaunchKernelGGL(vgx_tau_colsum_kernel, dim3((unsigned)((a->p.H + 4 * TB - 1) / (4 * TB)), (unsigned)a->R), dim3(TB), 0, s, *a);
+        hipError_t err = hipGetLastError();
+        if (err != hipSuccess) return err;
+    } else if (a->has_mig) {
         size_t lds = (size_t)a->p.P * TH * 4;
         hipError_t err = hipFuncSetAttribute((const void *)vgx_tau_migin_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (err != hipSuccess) return err;
