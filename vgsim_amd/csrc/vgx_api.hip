@@ -971,6 +971,15 @@ extern "C" int vgx_simulate_tau(vgx_engine *e, int64_t iterations, int64_t sampl
     a.migcdf = (double *)e->t_migcdf.p;
     a.migIn = (double *)e->t_migIn.p;
     a.mutHi = (double *)e->t_mutHi.p;
+    {   // high sites (the first sites - 6) all with one rate and equally likely derived states?
+        const int nh = (int)e->d.sites - 6;
+        bool same = a.mut_uniform && nh > 0 && nh <= 4;
+        for (int s2 = 0; s2 < nh && same; s2++)
+            for (int i = 0; i < 3; i++)
+                if (e->h_mutp[s2][i] != e->h_mutp[0][0]) same = false;
+        a.mutHi_int = same ? 1 : 0;
+        a.mutHi_rate = same ? e->h_mutp[0][0] : 0.0;
+    }
     a.mig_uniform = e->h_mig_uniform ? 1 : 0; a.mig_b = e->h_mig_b; a.mig_d = e->h_mig_d;
     a.colT = (double *)e->t_colT.p; a.colTW = (double *)e->t_colTW.p;
     a.inc = (int64_t *)e->t_inc.p; a.inc_cap = inc_cap; a.inc_shards = vgxi_tau_inc_shards(H, P); a.inc_n = (unsigned long long *)e->t_incn.p;

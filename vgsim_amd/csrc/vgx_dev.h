@@ -155,6 +155,8 @@ struct VgxTauArgs {
     int32_t *eff_dirty;  // [R] contact densities changed since effMig/Aeff/F were computed
     double *migIn;       // [R][P][H]  sum_spn Aeff[tpn][spn] * I[spn][hn] (drift of incoming migration)
     double *mutHi;       // [R][P][H]  incoming mutation drift through the high sites (tiled drift, sites > 6), or null
+    int32_t mutHi_int;   // all high sites share one rate and equally likely derived states: mutHi holds int32 neighbour sums
+    double mutHi_rate;   // ... to be scaled by this rate
     // uniform migration (every off-diagonal migration probability equal to mig_b, hence every diagonal equal to mig_d):
     // effMig[t][s] = b^2 W + (d b - b^2)(w_t + w_s), w = cd / actualSizes, W = sum w, so the incoming migration pressure
     // needs only the two column sums below instead of the [P x P] x [P x H] product

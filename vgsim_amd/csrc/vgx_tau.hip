@@ -459,6 +459,19 @@ extern "C" __global__ void __launch_bounds__(TB) vgx_tau_muthigh_kernel(VgxTauAr
         tile[idx] = I[(row << lowbits) | (c0 + col)];
     }
     __syncthreads();
+    if (a.mutHi_int) {   // one rate for every high site and derived state: the neighbour counts are summed as integers
+        int32_t *outi = (int32_t *)a.mutHi + ((int64_t)rep * P + pn) * H;
+        for (int idx = threadIdx.x; idx < rows * CH; idx += TB) {
+            const int row = idx / CH, col = idx - row * CH;
+            int sum = 0;
+            for (int s = 0; s < nh; ++s) {
+                const int sh = 2 * s;
+                sum += tile[(row ^ (1 << sh)) * CH + col] + tile[(row ^ (2 << sh)) * CH + col] + tile[(row ^ (3 << sh)) * CH + col];
+            }
+            outi[(row << lowbits) | (c0 + col)] = sum;
+        }
+        return;
+    }
     for (int idx = threadIdx.x; idx < rows * CH; idx += TB) {
         const int row = idx / CH, col = idx - row * CH;
         double d = 0.0;
@@ -526,7 +539,12 @@ extern "C" __global__ void __launch_bounds__(TB) vgx_tau_drift_tiled_kernel(VgxT
     double redS[4] = {0.0, 0.0, 0.0, 0.0};
     for (int t0 = threadIdx.x * 4; t0 < TS; t0 += TB * 4) {
         double mh[4] = {0.0, 0.0, 0.0, 0.0}, mg[4] = {0.0, 0.0, 0.0, 0.0};
-        if (nh > 0) { const double4 v = *(const double4 *)(a.mutHi + rowoff + h0 + t0); mh[0] = v.x; mh[1] = v.y; mh[2] = v.z; mh[3] = v.w; }
+        if (nh > 0 && a.mutHi_int) {
+            const int4 v = *(const int4 *)((const int32_t *)a.mutHi + rowoff + h0 + t0);
+            mh[0] = a.mutHi_rate * (double)v.x; mh[1] = a.mutHi_rate * (double)v.y; mh[2] = a.mutHi_rate * (double)v.z; mh[3] = a.mutHi_rate * (double)v.w;
+        } else if (nh > 0) {
+            const double4 v = *(const double4 *)(a.mutHi + rowoff + h0 + t0); mh[0] = v.x; mh[1] = v.y; mh[2] = v.z; mh[3] = v.w;
+        }
         if (a.has_mig && a.mig_uniform) {   // the two column sums are shared by all populations: they stay in the caches
             const double4 v = *(const double4 *)(a.colT + (int64_t)rep * H + h0 + t0);
             const double4 u = *(const double4 *)(a.colTW + (int64_t)rep * H + h0 + t0);
