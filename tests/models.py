@@ -246,7 +246,10 @@ CASES["time_stop"] = (_ctor(number_of_sites=1, populations_number=2, seed=9),
 CASES["extinct"] = (_ctor(seed=3), [(lambda s: s.set_transmission_rate(0.5), _direct(50, attempts=3))])
 CASES["extinct_restart"] = (_ctor(seed=3), [(lambda s: s.set_transmission_rate(0.5), _direct(1000, attempts=3))])
 for _name, (_sites, _P, _S, _seed, _nd, _nt) in {"tau_a": (0, 1, 1, 7, 2000, 200), "tau_b": (2, 3, 2, 7, 2000, 200),
-                                                  "tau_c": (1, 2, 3, 5, 3000, 150)}.items():
+                                                  "tau_c": (1, 2, 3, 5, 3000, 150),
+                                                  # a long warm-up: thousands of hosts per compartment, hundreds of events per
+                                                  # compartment and leap (the engine's per-channel kernel for large compartments)
+                                                  "tau_d": (1, 2, 1, 11, 30000, 40)}.items():
     CASES[_name] = (_ctor(number_of_sites=_sites, populations_number=_P, number_of_susceptible_groups=_S, seed=_seed),
                     [(_tau_common(_P, _S), _direct(_nd)),
                      (_nothing, dict(iterations=_nt, sample_size=10 ** 12, method='tau'))])

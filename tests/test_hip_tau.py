@@ -54,10 +54,10 @@ def test_first_leap_length_matches_oracle(oracle_mod, name):
     assert dt_hip == pytest.approx(dt_ref, rel=1e-9)
 
 
-@pytest.mark.parametrize("name", ["tau_a", "tau_b", "tau_c"])
+@pytest.mark.parametrize("name", ["tau_a", "tau_b", "tau_c", "tau_d"])
 def test_tau_moments_match_oracle(oracle_mod, name):
     ctor, _ = models.CASES[name]
-    keys = ("bCounter", "dCounter", "sCounter", "currentTime")
+    keys = ("bCounter", "dCounter", "sCounter", "mCounter", "migPlus", "currentTime")
     diffs = {k: [] for k in keys + ("infected",)}
     means = {k: [] for k in keys + ("infected",)}
     for i in range(N_SEEDS):

@@ -29,7 +29,7 @@ extern "C" hipError_t vgxi_launch_init_reps(const VgxDevRep *r, int P, int S, in
 
 #define TAU_DECL(name) extern "C" hipError_t vgxi_##name(const VgxTauArgs *a, hipStream_t s);
 TAU_DECL(tau_eff) TAU_DECL(tau_scatter) TAU_DECL(tau_prep) TAU_DECL(tau_drift) TAU_DECL(tau_choose) TAU_DECL(tau_draw) TAU_DECL(tau_suscep_draw)
-TAU_DECL(tau_check) TAU_DECL(tau_decide) TAU_DECL(tau_commit) TAU_DECL(tau_finish)
+TAU_DECL(tau_check) TAU_DECL(tau_decide) TAU_DECL(tau_commit) TAU_DECL(tau_finish) TAU_DECL(tau_draw_big)
 
 static std::string g_create_error;
 
@@ -75,7 +75,7 @@ struct vgx_engine {
         r_evtime, r_evcols, r_locrec, r_loctime, r_traj, r_prof;
     // tau-leaping (dense compartments)
     DevBuf t_I, t_S, t_dChk, t_dApp, t_dSi, t_dTot, t_totInf, t_gI, t_cd, t_lock, t_F, t_eff, t_Aeff, t_Gout, t_dS,
-        t_taubits, t_tau, t_time, t_flags, t_counters, t_cnttry, t_mev, t_mevn, t_mevbase, t_locn, t_mutcum, t_migcdf, t_migIn, t_mutHi, t_colT, t_colTW, t_inc, t_incn, t_sieve, t_sieveskip;
+        t_taubits, t_tau, t_time, t_flags, t_counters, t_cnttry, t_mev, t_mevn, t_mevbase, t_locn, t_mutcum, t_migcdf, t_migIn, t_mutHi, t_colT, t_colTW, t_inc, t_incn, t_sieve, t_sieveskip, t_big, t_bign;
     std::vector<int64_t> tau_sieve_skipped;   // [R] tries left out by the sieve in the last tau call
     bool last_was_tau = false;
     int64_t tau_mev_cap = 0;
@@ -860,7 +860,7 @@ extern "C" int vgx_simulate_tau(vgx_engine *e, int64_t iterations, int64_t sampl
 
     // ---- device arrays ----
     const int64_t mev_cap = o.record_events ? std::max<int64_t>(1, std::min<int64_t>((int64_t)1 << 24, iterations * 8192)) : 0;
-    const size_t nF = 9;  // int32 flag arrays
+    const size_t nF = 10;  // int32 flag arrays
     const int64_t Ppad = (P + 31) / 32 * 32;
     rc = 0;
     rc |= ensure(e, e->r_locrec, (size_t)(R * VGX_LOC_CAP * 2) * 4);
@@ -885,6 +885,9 @@ extern "C" int vgx_simulate_tau(vgx_engine *e, int64_t iterations, int64_t sampl
     rc |= ensure(e, e->t_time, (size_t)R * 8);
     rc |= ensure(e, e->t_flags, (size_t)R * nF * 4);
     rc |= ensure(e, e->t_counters, (size_t)R * 8 * 8);
+    const int64_t big_cap = std::min<int64_t>(P * H, (int64_t)1 << 20);
+    rc |= ensure(e, e->t_big, (size_t)(R * big_cap) * 8);
+    rc |= ensure(e, e->t_bign, (size_t)R * 8);
     rc |= ensure(e, e->t_sieve, (size_t)R * VGX_SIEVE_K * 8);
     rc |= ensure(e, e->t_sieveskip, (size_t)R * 8);
     rc |= ensure(e, e->t_cnttry, (size_t)R * 8 * 8);
@@ -895,7 +898,7 @@ extern "C" int vgx_simulate_tau(vgx_engine *e, int64_t iterations, int64_t sampl
     if (e->h_has_mig && !e->h_mig_uniform) rc |= ensure(e, e->t_migIn, (size_t)(R * P * H) * 8);
     if (e->h_mig_uniform) { rc |= ensure(e, e->t_colT, (size_t)(R * H) * 8); rc |= ensure(e, e->t_colTW, (size_t)(R * H) * 8); }
     rc |= ensure(e, e->t_mutHi, (size_t)(e->d.sites > 6 ? R * P * H : 1) * 8);   // tiled drift, first pass (vgx_tau_muthigh_kernel)
-    const int64_t inc_cap = std::max<int64_t>((int64_t)1 << 22, P * H / 8) / VGX_INC_SHARDS * VGX_INC_SHARDS;
+    int64_t inc_cap = std::max<int64_t>((int64_t)1 << 22, P * H / 8) / VGX_INC_SHARDS * VGX_INC_SHARDS;   // grown on demand
     rc |= ensure(e, e->t_inc, (size_t)(R * inc_cap) * 8);
     rc |= ensure(e, e->t_incn, (size_t)R * VGX_INC_SHARDS * 8);
     rc |= ensure(e, e->t_migcdf, (size_t)(R * P * e->CB * P * S) * 8);
@@ -915,6 +918,7 @@ extern "C" int vgx_simulate_tau(vgx_engine *e, int64_t iterations, int64_t sampl
     HIPCHECK(e, hipMemset(e->t_dSi.p, 0, (size_t)(R * P * S) * 8));
     HIPCHECK(e, hipMemset(e->t_dTot.p, 0, (size_t)(R * P) * 8));
     HIPCHECK(e, hipMemset(e->t_counters.p, 0, (size_t)R * 64));
+    HIPCHECK(e, hipMemset(e->t_bign.p, 0, (size_t)R * 8));
     HIPCHECK(e, hipMemset(e->t_sieve.p, 0, (size_t)R * VGX_SIEVE_K * 8));
     HIPCHECK(e, hipMemset(e->t_sieveskip.p, 0, (size_t)R * 8));
     HIPCHECK(e, hipMemset(e->t_cnttry.p, 0, (size_t)R * 64));
@@ -956,7 +960,7 @@ extern "C" int vgx_simulate_tau(vgx_engine *e, int64_t iterations, int64_t sampl
     a.time_now = (double *)e->t_time.p;
     int32_t *fl = (int32_t *)e->t_flags.p;
     a.active = fl; a.ok = fl + R; a.accepted = fl + 2 * R; a.deciding = fl + 3 * R; a.retry = fl + 4 * R;
-    a.step = fl + 5 * R; a.error = fl + 6 * R; a.attempt = fl + 7 * R; a.eff_dirty = fl + 8 * R;
+    a.step = fl + 5 * R; a.error = fl + 6 * R; a.attempt = fl + 7 * R; a.eff_dirty = fl + 8 * R; a.grow = fl + 9 * R;
     a.Ppad = (int32_t)Ppad;
     {
         std::vector<int32_t> ones((size_t)R, 1);
@@ -984,6 +988,7 @@ extern "C" int vgx_simulate_tau(vgx_engine *e, int64_t iterations, int64_t sampl
     a.colT = (double *)e->t_colT.p; a.colTW = (double *)e->t_colTW.p;
     a.inc = (int64_t *)e->t_inc.p; a.inc_cap = inc_cap; a.inc_shards = vgxi_tau_inc_shards(H, P); a.inc_n = (unsigned long long *)e->t_incn.p;
     a.counters = (int64_t *)e->t_counters.p; a.cnt_try = (int64_t *)e->t_cnttry.p;
+    a.big = (int64_t *)e->t_big.p; a.big_cap = big_cap; a.big_n = (unsigned long long *)e->t_bign.p;
     a.sieve = (double *)e->t_sieve.p; a.sieve_skipped = (int64_t *)e->t_sieveskip.p;
     a.sieve_on = o.reserved[0] == 1 ? 0 : 1;   // vgx_run_opts.reserved[0] = 1: run every try of the halving loop
     a.mev = (int64_t *)e->t_mev.p; a.mev_cap = mev_cap;
@@ -1066,12 +1071,13 @@ extern "C" int vgx_simulate_tau(vgx_engine *e, int64_t iterations, int64_t sampl
         if (a.sieve_on) { HIPCHECK(e, vgxi_tau_sieve(&a, e->stream)); launches += 2; }
         for (int tries = 0;; tries++) {
             HIPCHECK(e, vgxi_tau_draw(&a, e->stream));
+            HIPCHECK(e, vgxi_tau_draw_big(&a, e->stream));
             HIPCHECK(e, vgxi_tau_suscep_draw(&a, e->stream));
             HIPCHECK(e, vgxi_tau_scatter(&a, e->stream));
             HIPCHECK(e, vgxi_tau_check(&a, e->stream));
             HIPCHECK(e, vgxi_tau_decide(&a, e->stream));
             HIPCHECK(e, vgxi_tau_commit(&a, e->stream));
-            launches += 6;
+            launches += 7;
             HIPCHECK(e, hipStreamSynchronize(e->stream));
             acc_h.resize((size_t)R);
             HIPCHECK(e, hipMemcpy(acc_h.data(), a.accepted, (size_t)R * 4, hipMemcpyDeviceToHost));
@@ -1079,6 +1085,20 @@ extern "C" int vgx_simulate_tau(vgx_engine *e, int64_t iterations, int64_t sampl
             for (int64_t r = 0; r < R; r++)
                 if (running[(size_t)r] && !acc_h[(size_t)r]) all = false;
             if (all) break;
+            // a try that overflowed the list of individuals entering other compartments was discarded by the decide
+            // kernel without touching tau or the try index: double the list (it is empty now) and run the same try again
+            std::vector<int32_t> grow_h((size_t)R);
+            HIPCHECK(e, hipMemcpy(grow_h.data(), a.grow, (size_t)R * 4, hipMemcpyDeviceToHost));
+            if (std::any_of(grow_h.begin(), grow_h.end(), [](int32_t g) { return g != 0; })) {
+                if (inc_cap > ((int64_t)1 << 33) / std::max<int64_t>(R, 1))
+                    return fail(e, VGX_ERR_CAPACITY, "vgx_simulate_tau: more than 2^33 individuals change compartment in one leap");
+                inc_cap *= 2;
+                int rcg = ensure(e, e->t_inc, (size_t)(R * inc_cap) * 8);
+                if (rcg) return rcg;
+                a.inc = (int64_t *)e->t_inc.p;
+                a.inc_cap = inc_cap;
+                HIPCHECK(e, hipMemset(a.grow, 0, (size_t)R * 4));
+            }
             if (tries > 300) return fail(e, VGX_ERR_LOOP_GUARD, "vgx_simulate_tau: tau halving did not converge");
         }
         HIPCHECK(e, vgxi_tau_finish(&a, e->stream));

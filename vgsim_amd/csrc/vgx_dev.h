@@ -170,6 +170,11 @@ struct VgxTauArgs {
     double *tau;         // [R]
     double *time_now;    // [R]
     int32_t *active, *ok, *accepted, *deciding, *retry, *step, *error;  // [R]
+    // compartments expecting many events in the current try (vgx_tau_draw_big_kernel)
+    int64_t *big;        // [R][big_cap] pn * H + hn
+    int64_t big_cap;
+    unsigned long long *big_n;  // [R]
+    int32_t *grow;       // [R] the try overflowed the cross-compartment list: the host enlarges it and the SAME try runs again
     int32_t *attempt;    // [R]
     const int64_t *seeds;  // [R]
     int32_t has_mig;

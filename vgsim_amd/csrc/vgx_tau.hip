@@ -768,6 +768,7 @@ static __device__ __forceinline__ void tau_row(const VgxTauArgs &a, int rep, int
 // after the draw kernel, when every compartment has stored its own deltas.
 // The list is sharded by thread block (VGX_INC_SHARDS counters) so that appends do not serialise on one address.
 #define VGX_INC_STAGE 512   // entries staged in LDS per thread block before one reservation in the global list
+#define VGX_TAU_BIG 256.0   // expected events of a compartment per leap from which every channel is drawn on its own
 struct IncStage { int n; int64_t e[VGX_INC_STAGE]; unsigned long long base; };
 
 static __device__ __forceinline__ void tau_incoming_global(const VgxTauArgs &a, int rep, int64_t entry) {
@@ -778,11 +779,19 @@ static __device__ __forceinline__ void tau_incoming_global(const VgxTauArgs &a, 
 }
 // Appends go to the block's LDS stage (an LDS atomic instead of a returning global atomic per mutant / migrant in the
 // divergent part of the kernel); tau_incoming_flush moves the stage to the global list with one reservation.
-static __device__ __forceinline__ void tau_incoming(const VgxTauArgs &a, IncStage *st, int rep, int64_t cell, bool applied_only) {
-    const int64_t entry = cell | (applied_only ? ((int64_t)1 << 62) : 0);
-    int slot = atomicAdd(&st->n, 1);
-    if (slot < VGX_INC_STAGE) st->e[slot] = entry;
-    else tau_incoming_global(a, rep, entry);
+// List entry: compartment (bits 0-37), multiplicity (bits 38-61), applied-only flag (bit 62).
+#define VGX_INC_CELL_BITS 38
+#define VGX_INC_MAXMULT ((int64_t)((1 << 24) - 1))
+static __device__ __forceinline__ void tau_incoming(const VgxTauArgs &a, IncStage *st, int rep, int64_t cell, bool applied_only,
+                                                    int64_t count = 1) {
+    while (count > 0) {
+        const int64_t k = count < VGX_INC_MAXMULT ? count : VGX_INC_MAXMULT;
+        const int64_t entry = cell | (k << VGX_INC_CELL_BITS) | (applied_only ? ((int64_t)1 << 62) : 0);
+        int slot = atomicAdd(&st->n, 1);
+        if (slot < VGX_INC_STAGE) st->e[slot] = entry;
+        else tau_incoming_global(a, rep, entry);
+        count -= k;
+    }
 }
 // block-uniform call
 static __device__ __forceinline__ void tau_incoming_flush(const VgxTauArgs &a, IncStage *st, int rep) {
@@ -832,7 +841,7 @@ struct TauTab {
 // Can compartment (pn, hn) draw any event in this step?  For most compartments the class's total rate and the shared
 // 32-bit word say no at once; the others are queued and tau_cell_events makes the draw (inversion with the same word
 // below a mean of 10, PTRS on the compartment's own stream from 10 on).
-static __device__ __forceinline__ int tau_cell_count(const VgxTauArgs &a, const TauTab &T, int pn, int hn, double tau,
+static __device__ __forceinline__ int tau_cell_count(const VgxTauArgs &a, const TauTab &T, int rep, int pn, int hn, double tau,
                                                      uint32_t first_word, int64_t Icell) {
     const VgxDevParams &p = a.p;
     if (Icell == 0) return 0;
@@ -847,6 +856,11 @@ static __device__ __forceinline__ int tau_cell_count(const VgxTauArgs &a, const 
     }
     const double lam = rate * Ih * tau;
     if (!(lam > 0.0)) return 0;
+    if (lam >= VGX_TAU_BIG) {   // many events: one wavefront draws its channels one by one (vgx_tau_draw_big_kernel)
+        const unsigned long long slot = atomicAdd(&a.big_n[rep], 1ull);
+        if ((int64_t)slot < a.big_cap) { a.big[(int64_t)rep * a.big_cap + (int64_t)slot] = (int64_t)pn * p.H + hn; return 0; }
+        return 1;               // list full: the compartment takes the event-by-event path below (slow, same law)
+    }
     if (lam >= 10.0) return 1;
     const double u = ((double)first_word + 0.5) * (1.0 / 4294967296.0);
     return (u <= 1.0 - lam) ? 0 : 1;   // exp(-lam) >= 1 - lam: the inversion search of tau_cell_events would stop at 0
@@ -1121,7 +1135,7 @@ extern "C" __global__ void __launch_bounds__(TB) vgx_tau_draw_kernel(VgxTauArgs 
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                if (h0 + j < H && tau_cell_count(a, T, pn, h0 + j, tau, w[j], (int64_t)Iv[j])) {
+                if (h0 + j < H && tau_cell_count(a, T, rep, pn, h0 + j, tau, w[j], (int64_t)Iv[j])) {
                     int slot = atomicAdd(&q_n, 1);
                     q_h[slot] = h0 + j;
                     q_w[slot] = (int)w[j];
@@ -1164,6 +1178,112 @@ extern "C" __global__ void __launch_bounds__(TB) vgx_tau_draw_kernel(VgxTauArgs 
     if (threadIdx.x == 0 && sTot) atomicAdd((unsigned long long *)&a.dTot[(int64_t)rep * P + pn], sTot);
 }
 
+
+// Compartments that expect many events in this leap (>= VGX_TAU_BIG; the draw kernel's quick test lists them): every channel
+// gets its own Poisson draw, as in the reference (pyx:2464-2520), with the channels of one compartment spread over the
+// lanes of a wavefront.  The single draw + split of tau_cell_events walks through the events one by one, which a
+// compartment with 10^5 hosts would do for tens of thousands of events on one lane (natural epidemics: most hosts carry a
+// few haplotypes); the joint law of the channel counts is the same (Poisson splitting).  A channel's stream is keyed by
+// (compartment, channel), so the result does not depend on the lane mapping.  grid = (VGX_BIG_BLOCKS, R), 4 waves a block.
+#define VGX_BIG_BLOCKS 256
+extern "C" __global__ void __launch_bounds__(TB) vgx_tau_draw_big_kernel(VgxTauArgs a) {
+    const int rep = blockIdx.y;
+    if (!a.active[rep] || a.accepted[rep]) return;
+    const VgxDevParams &p = a.p;
+    const int P = p.P, S = p.S, H = p.H, sites = p.sites, CB = p.CB;
+    const int lane = threadIdx.x & 63;
+    unsigned long long n = a.big_n[rep];
+    if ((int64_t)n > a.big_cap) n = (unsigned long long)a.big_cap;
+    const double tau = a.tau[rep];
+    int64_t *dS = a.dSi + (int64_t)rep * P * S;
+    for (unsigned long long e = (unsigned long long)blockIdx.x * (TB / 64) + (threadIdx.x >> 6); e < n; e += (unsigned long long)gridDim.x * (TB / 64)) {
+        const int64_t cell = a.big[(int64_t)rep * a.big_cap + (int64_t)e];
+        const int pn = (int)(cell / H), hn = (int)(cell - (int64_t)pn * H);
+        const double Ih = (double)a.I[(int64_t)rep * P * H + cell];
+        const int c = (p.C == 1) ? 0 : p.cls[hn];
+        const int cb = p.c_bidx[c], st = p.c_stype[c];
+        const double F = a.F[(int64_t)rep * P + pn];
+        const int64_t *Sus = a.S + (int64_t)rep * P * S + (int64_t)pn * S;
+        const double *cdf = a.migcdf + (((int64_t)rep * P + pn) * CB + cb) * (int64_t)P * S;
+        const double r_mig = a.has_mig ? a.Gout[((int64_t)rep * P + pn) * CB + cb] * p.cb_b[cb] * p.mig[(int64_t)pn * P + pn] * Ih : 0.0;
+        const int n_mut = 3 * sites, n_mig = (r_mig > 0.0) ? P * S : 0, nchan = 2 + S + n_mut + n_mig;
+        int64_t births = 0, rec = 0, samp = 0, mut_done = 0, migrants = 0;
+        for (int ch = lane; ch < nchan; ch += 64) {
+            TauRng g;
+            g.init((uint64_t)a.seeds[rep], (uint32_t)a.attempt[rep], (uint64_t)cell | ((uint64_t)(ch + 1) << 40), (uint32_t)a.step[rep],
+                   (uint32_t)a.retry[rep]);
+            if (ch == 0) {
+                rec = tau_poisson(g, p.c_d[c] * Ih * tau);                                   // pyx:2386
+                if (rec) tau_row(a, rep, rec, 1, hn, pn, st, 0);
+            } else if (ch == 1) {
+                samp = tau_poisson(g, p.c_s[c] * Ih * p.sampMult[pn] * tau);                 // pyx:2392
+                if (samp) tau_row(a, rep, samp, 2, hn, pn, st, 0);
+            } else if (ch < 2 + S) {                                                         // pyx:2412-2414
+                const int sn = ch - 2;
+                const int64_t k = tau_poisson(g, p.cb_b[cb] * p.cb_sigma[cb * S + sn] * (double)Sus[sn] * F * Ih * tau);
+                if (k) {
+                    births += k;
+                    atomicAdd((unsigned long long *)&dS[pn * S + sn], (unsigned long long)(-k));
+                    tau_row(a, rep, k, 0, hn, pn, sn, 0);
+                }
+            } else if (ch < 2 + S + n_mut) {                                                 // pyx:2400-2401
+                const int m = ch - 2 - S, ss = m / 3, ii = m % 3;
+                double rate;
+                if (a.mut_uniform) rate = a.mutp[ss][ii];
+                else {
+                    const double *hm = p.hapMutType + ((int64_t)hn * sites + ss) * 3;
+                    rate = p.mRate[(int64_t)hn * sites + ss] * hm[ii] / (hm[0] + hm[1] + hm[2]);
+                }
+                const int64_t k = tau_poisson(g, rate * Ih * tau);
+                if (k) {
+                    const int nh = tau_mutate(sites, hn, ss, ii);
+                    mut_done += k;
+                    int64_t left = k;
+                    while (left > 0) {
+                        const int64_t kk = left < VGX_INC_MAXMULT ? left : VGX_INC_MAXMULT;
+                        tau_incoming_global(a, rep, ((int64_t)pn * H + nh) | (kk << VGX_INC_CELL_BITS));
+                        left -= kk;
+                    }
+                    tau_row(a, rep, k, 3, hn, pn, nh, 0);
+                }
+            } else {                                                                         // pyx:2366-2367
+                const int j = ch - 2 - S - n_mut, tp = j / S, ts = j % S;
+                const double wj = cdf[j] - (j > 0 ? cdf[j - 1] : 0.0);
+                const int64_t k = (wj > 0.0 && tp != pn) ? tau_poisson(g, wj / cdf[P * S - 1] * r_mig * tau) : 0;
+                if (k) {
+                    migrants += k;
+                    int64_t left = k;
+                    while (left > 0) {
+                        const int64_t kk = left < VGX_INC_MAXMULT ? left : VGX_INC_MAXMULT;
+                        tau_incoming_global(a, rep, ((int64_t)tp * H + hn) | (kk << VGX_INC_CELL_BITS) | ((int64_t)1 << 62));
+                        left -= kk;
+                    }
+                    atomicAdd((unsigned long long *)&dS[tp * S + ts], (unsigned long long)(-k));
+                    atomicAdd((unsigned long long *)&a.dTot[(int64_t)rep * P + tp], (unsigned long long)k);
+                    tau_row(a, rep, k, 5, hn, pn, ts, tp);
+                }
+            }
+        }
+        long long v[5] = {births, rec, samp, mut_done, migrants};
+        for (int i = 0; i < 5; ++i)
+            for (int o = 32; o > 0; o >>= 1) v[i] += __shfl_down(v[i], o);
+        if (lane == 0) {
+            const int64_t own = v[0] - v[1] - v[2] - v[3];
+            const int64_t off = (int64_t)rep * P * H + cell;
+            if (own + v[4] != 0) a.dChk[off] = (int32_t)(own + v[4]);   // pyx:2473: migrants are booked on their source here
+            if (own != 0) a.dApp[off] = (int32_t)own;
+            unsigned long long *ct = (unsigned long long *)&a.cnt_try[(int64_t)rep * 8];
+            if (v[0]) atomicAdd(&ct[0], (unsigned long long)v[0]);
+            if (v[1]) atomicAdd(&ct[1], (unsigned long long)v[1]);
+            if (v[2]) atomicAdd(&ct[2], (unsigned long long)v[2]);
+            if (v[3]) atomicAdd(&ct[3], (unsigned long long)v[3]);
+            if (v[4]) atomicAdd(&ct[5], (unsigned long long)v[4]);
+            if (v[1] + v[2]) atomicAdd((unsigned long long *)&dS[pn * S + st], (unsigned long long)(v[1] + v[2]));
+            if (v[0] - v[1] - v[2]) atomicAdd((unsigned long long *)&a.dTot[(int64_t)rep * P + pn], (unsigned long long)(v[0] - v[1] - v[2]));
+        }
+    }
+}
+
 // Immunity transitions (pyx:2479-2487 / 2554-2562): P*S*S slots per replicate, one thread each.
 extern "C" __global__ void __launch_bounds__(TB) vgx_tau_suscep_draw_kernel(VgxTauArgs a) {
     const int rep = blockIdx.y;
@@ -1204,9 +1324,10 @@ extern "C" __global__ void __launch_bounds__(64) vgx_tau_scatter_kernel(VgxTauAr
     const int64_t *lst = a.inc + (int64_t)rep * a.inc_cap + (int64_t)shard * scap;
     for (unsigned long long i = (unsigned long long)blockIdx.z * 64 + threadIdx.x; i < n; i += (unsigned long long)gridDim.z * 64) {
         int64_t e = lst[i];
-        int64_t cell = e & (((int64_t)1 << 62) - 1);
-        atomicAdd(&a.dApp[(int64_t)rep * PH + cell], 1);
-        if (!(e >> 62)) atomicAdd(&a.dChk[(int64_t)rep * PH + cell], 1);
+        int64_t cell = e & (((int64_t)1 << VGX_INC_CELL_BITS) - 1);
+        int k = (int)((e >> VGX_INC_CELL_BITS) & VGX_INC_MAXMULT);
+        atomicAdd(&a.dApp[(int64_t)rep * PH + cell], k);
+        if (!(e >> 62)) atomicAdd(&a.dChk[(int64_t)rep * PH + cell], k);
     }
 }
 
@@ -1248,12 +1369,25 @@ extern "C" __global__ void __launch_bounds__(64) vgx_tau_decide_kernel(VgxTauArg
     const int rep = blockIdx.x;
     const bool live = a.active[rep] && !a.accepted[rep];
     __syncthreads();
-    if (live)   // the cross-compartment list of this draw has been applied by vgx_tau_scatter_kernel
+    if (live) {  // the cross-compartment list of this draw has been applied by vgx_tau_scatter_kernel
         for (int i = threadIdx.x; i < a.inc_shards; i += 64) a.inc_n[(int64_t)rep * VGX_INC_SHARDS + i] = 0;
+        if (threadIdx.x == 0) a.big_n[rep] = 0;
+    }
     if (threadIdx.x != 0) return;
     a.deciding[rep] = 0;
     if (!live) return;
     a.deciding[rep] = 1;
+    if (a.error[rep] == 4) {
+        // the cross-compartment list overflowed (vgx_tau_scatter_kernel): nothing of this try counts.  It is discarded like a
+        // rejected one but tau and the try index stay, so that the same draws are made again once the host has enlarged
+        // the list (the streams are keyed by the try index).
+        a.error[rep] = 0;
+        a.grow[rep] = 1;
+        a.ok[rep] = 1;
+        for (int i = 0; i < 6; ++i) a.cnt_try[(int64_t)rep * 8 + i] = 0;
+        a.mev_n[rep] = a.mev_base[rep];
+        return;
+    }
     if (a.ok[rep]) {
         a.accepted[rep] = 1;
         for (int i = 0; i < 6; ++i) { a.counters[(int64_t)rep * 8 + i] += a.cnt_try[(int64_t)rep * 8 + i]; }
@@ -1401,6 +1535,7 @@ extern "C" __attribute__((visibility("hidden"))) hipError_t vgxi_tau_draw(const 
     return hipGetLastError();
 }
 TAU_LAUNCH(tau_suscep_draw, SUS_GRID, dim3(TB))
+TAU_LAUNCH(tau_draw_big, dim3(VGX_BIG_BLOCKS, (unsigned)a->R), dim3(TB))
 extern "C" __attribute__((visibility("hidden"))) hipError_t vgxi_tau_sieve(const VgxTauArgs *a, hipStream_t s) {
     unsigned tiles = (unsigned)((a->p.H + 4 * TB - 1) / (4 * TB));
     unsigned gx = tiles < 64u ? tiles : 64u;
