@@ -222,3 +222,31 @@ def test_tiled_drift_leap_length_matches_oracle(oracle_mod, sites, weights, asym
     k = np.log2(dt_ref / dt_hip)
     assert abs(k - round(k)) < 1e-8 and abs(round(k)) <= 12, (dt_hip, dt_ref)
     assert dt_hip * 2.0 ** round(k) == pytest.approx(dt_ref, rel=1e-9)
+
+
+def test_cross_compartment_list_grows_on_demand():
+    """Four million compartments of 40 hosts with a high mutation rate: far more mutants per leap than the initial
+    capacity of the cross-compartment list (4M entries).  The overflowing try is discarded, the list doubled and the same
+    try run again; hosts are conserved and every mutant is accounted for."""
+    import ctypes as C
+    from vgsim_amd import Simulator, _capi
+    with helpers.quiet():
+        s = Simulator(number_of_sites=9, populations_number=16, seed=5)
+    s.set_transmission_rate(2.5); s.set_recovery_rate(0.9); s.set_sampling_rate(0.1); s.set_mutation_rate(0.5)
+    s.set_population_size(2 * 10 ** 9)
+    m = s.simulation
+    m.infectious[:] = 40
+    m.susceptible[:, 0] -= 40 * m.hapNum
+    eng = _capi.HipEngine(m.sites, m.hapNum, m.popNum, m.susNum, n_replicates=1)
+    m.events.CreateEvents(2); m.events.ptr = 1; m.events.CreateEvents(2)
+    eng.set_params(m); eng.set_state(m); eng.set_seeds(np.array([5], dtype=np.int64))
+    o = _capi.VgxRunOpts(); o.record_events = 0
+    before = int(m.infectious.sum()) + 1          # + the index case the first call adds (pyx:435-448)
+    eng._check(eng.lib.vgx_simulate_tau(eng.handle, 2, 10 ** 15, -1.0, 1, C.byref(o)))
+    eng.get_state(m, 0)
+    c = eng.counters(0)
+    eng.close()
+    assert c.loop_iterations == 2 and m.mCounter > 2 * 4194304        # more mutants per leap than the list held
+    assert (m.infectious >= 0).all()
+    assert int(m.infectious.sum()) == before + m.bCounter - m.dCounter - m.sCounter
+    assert int(m.susceptible.sum() + m.infectious.sum()) == int(m.sizes.sum())
