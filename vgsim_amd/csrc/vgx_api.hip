@@ -75,7 +75,7 @@ struct vgx_engine {
         r_evtime, r_evcols, r_locrec, r_loctime, r_traj, r_prof;
     // tau-leaping (dense compartments)
     DevBuf t_I, t_S, t_dChk, t_dApp, t_dSi, t_dTot, t_totInf, t_gI, t_cd, t_lock, t_F, t_eff, t_Aeff, t_Gout, t_dS,
-        t_taubits, t_tau, t_time, t_flags, t_counters, t_cnttry, t_mev, t_mevn, t_mevbase, t_locn, t_mutcum, t_migcdf, t_migIn, t_mutHi, t_colT, t_colTW, t_inc, t_incn, t_sieve, t_sieveskip, t_big, t_bign;
+        t_taubits, t_tau, t_time, t_flags, t_counters, t_cnttry, t_mev, t_mevn, t_mevbase, t_locn, t_mutcum, t_migcdf, t_migIn, t_mutHi, t_colT, t_colTW, t_inc, t_incn, t_sieve, t_sieveskip, t_big, t_bign, t_res;
     std::vector<int64_t> tau_sieve_skipped;   // [R] tries left out by the sieve in the last tau call
     bool last_was_tau = false;
     int64_t tau_mev_cap = 0;
@@ -888,6 +888,7 @@ extern "C" int vgx_simulate_tau(vgx_engine *e, int64_t iterations, int64_t sampl
     const int64_t big_cap = std::min<int64_t>(P * H, (int64_t)1 << 20);
     rc |= ensure(e, e->t_big, (size_t)(R * big_cap) * 8);
     rc |= ensure(e, e->t_bign, (size_t)R * 8);
+    rc |= ensure(e, e->t_res, (size_t)R * 16 * 8);
     rc |= ensure(e, e->t_sieve, (size_t)R * VGX_SIEVE_K * 8);
     rc |= ensure(e, e->t_sieveskip, (size_t)R * 8);
     rc |= ensure(e, e->t_cnttry, (size_t)R * 8 * 8);
@@ -959,8 +960,8 @@ extern "C" int vgx_simulate_tau(vgx_engine *e, int64_t iterations, int64_t sampl
     a.dS = (double *)e->t_dS.p; a.tau_bits = (unsigned long long *)e->t_taubits.p; a.tau = (double *)e->t_tau.p;
     a.time_now = (double *)e->t_time.p;
     int32_t *fl = (int32_t *)e->t_flags.p;
-    a.active = fl; a.ok = fl + R; a.accepted = fl + 2 * R; a.deciding = fl + 3 * R; a.retry = fl + 4 * R;
-    a.step = fl + 5 * R; a.error = fl + 6 * R; a.attempt = fl + 7 * R; a.eff_dirty = fl + 8 * R; a.grow = fl + 9 * R;
+    a.active = fl; a.ok = fl + R; a.accepted = fl + 2 * R; a.grow = fl + 3 * R; a.retry = fl + 4 * R;   // accepted, grow: one copy per try
+    a.step = fl + 5 * R; a.error = fl + 6 * R; a.attempt = fl + 7 * R; a.eff_dirty = fl + 8 * R; a.deciding = fl + 9 * R;
     a.Ppad = (int32_t)Ppad;
     {
         std::vector<int32_t> ones((size_t)R, 1);
@@ -989,6 +990,7 @@ extern "C" int vgx_simulate_tau(vgx_engine *e, int64_t iterations, int64_t sampl
     a.inc = (int64_t *)e->t_inc.p; a.inc_cap = inc_cap; a.inc_shards = vgxi_tau_inc_shards(H, P); a.inc_n = (unsigned long long *)e->t_incn.p;
     a.counters = (int64_t *)e->t_counters.p; a.cnt_try = (int64_t *)e->t_cnttry.p;
     a.big = (int64_t *)e->t_big.p; a.big_cap = big_cap; a.big_n = (unsigned long long *)e->t_bign.p;
+    a.res = (int64_t *)e->t_res.p;
     a.sieve = (double *)e->t_sieve.p; a.sieve_skipped = (int64_t *)e->t_sieveskip.p;
     a.sieve_on = o.reserved[0] == 1 ? 0 : 1;   // vgx_run_opts.reserved[0] = 1: run every try of the halving loop
     a.mev = (int64_t *)e->t_mev.p; a.mev_cap = mev_cap;
@@ -1011,6 +1013,8 @@ extern "C" int vgx_simulate_tau(vgx_engine *e, int64_t iterations, int64_t sampl
     std::vector<int32_t> fresh((size_t)R, 1);  // attempt just opened: the pyx:2311 guard applies
     float ms_total = 0.f;
     int64_t launches = 0;
+    std::vector<int32_t> dev_active, dev_step, dev_att;   // what the device holds (empty: nothing uploaded yet)
+    std::vector<double> dev_time;
     const bool has_tl = !(time == -1.0f);
     auto sC_of = [&](int64_t r) { return cnt0[(size_t)r][2] + cnt[(size_t)r * 8 + 2]; };
     int64_t guard = 0;
@@ -1057,11 +1061,13 @@ extern "C" int vgx_simulate_tau(vgx_engine *e, int64_t iterations, int64_t sampl
         }
         if (!any) break;
         if (++guard > (int64_t)4 * (iterations + 16) * std::max<int64_t>(attempts, 1)) return fail(e, VGX_ERR_LOOP_GUARD, "vgx_simulate_tau: step loop guard");
+        // the device keeps step and time itself (vgx_tau_finish_kernel advances them exactly as the host does below): only
+        // what an attempt's end or a Restart changed is uploaded
         for (int64_t r = 0; r < R; r++) att32[(size_t)r] = (int32_t)att[(size_t)r];
-        HIPCHECK(e, hipMemcpy(a.active, running.data(), (size_t)R * 4, hipMemcpyHostToDevice));
-        HIPCHECK(e, hipMemcpy(a.step, step_h.data(), (size_t)R * 4, hipMemcpyHostToDevice));
-        HIPCHECK(e, hipMemcpy(a.attempt, att32.data(), (size_t)R * 4, hipMemcpyHostToDevice));
-        HIPCHECK(e, hipMemcpy(a.time_now, tnow.data(), (size_t)R * 8, hipMemcpyHostToDevice));
+        if (running != dev_active) { HIPCHECK(e, hipMemcpy(a.active, running.data(), (size_t)R * 4, hipMemcpyHostToDevice)); dev_active = running; }
+        if (step_h != dev_step) { HIPCHECK(e, hipMemcpy(a.step, step_h.data(), (size_t)R * 4, hipMemcpyHostToDevice)); dev_step = step_h; }
+        if (att32 != dev_att) { HIPCHECK(e, hipMemcpy(a.attempt, att32.data(), (size_t)R * 4, hipMemcpyHostToDevice)); dev_att = att32; }
+        if (tnow != dev_time) { HIPCHECK(e, hipMemcpy(a.time_now, tnow.data(), (size_t)R * 8, hipMemcpyHostToDevice)); dev_time = tnow; }
         HIPCHECK(e, hipEventRecord(e->ev0, e->stream));
         HIPCHECK(e, vgxi_tau_eff(&a, e->stream));
         HIPCHECK(e, vgxi_tau_prep(&a, e->stream));
@@ -1079,17 +1085,15 @@ extern "C" int vgx_simulate_tau(vgx_engine *e, int64_t iterations, int64_t sampl
             HIPCHECK(e, vgxi_tau_commit(&a, e->stream));
             launches += 7;
             HIPCHECK(e, hipStreamSynchronize(e->stream));
-            acc_h.resize((size_t)R);
-            HIPCHECK(e, hipMemcpy(acc_h.data(), a.accepted, (size_t)R * 4, hipMemcpyDeviceToHost));
+            acc_h.resize((size_t)R * 2);   // accepted[R], grow[R]
+            HIPCHECK(e, hipMemcpy(acc_h.data(), a.accepted, (size_t)R * 8, hipMemcpyDeviceToHost));
             bool all = true;
             for (int64_t r = 0; r < R; r++)
                 if (running[(size_t)r] && !acc_h[(size_t)r]) all = false;
             if (all) break;
             // a try that overflowed the list of individuals entering other compartments was discarded by the decide
             // kernel without touching tau or the try index: double the list (it is empty now) and run the same try again
-            std::vector<int32_t> grow_h((size_t)R);
-            HIPCHECK(e, hipMemcpy(grow_h.data(), a.grow, (size_t)R * 4, hipMemcpyDeviceToHost));
-            if (std::any_of(grow_h.begin(), grow_h.end(), [](int32_t g) { return g != 0; })) {
+            if (std::any_of(acc_h.begin() + R, acc_h.end(), [](int32_t g) { return g != 0; })) {
                 if (inc_cap > ((int64_t)1 << 33) / std::max<int64_t>(R, 1))
                     return fail(e, VGX_ERR_CAPACITY, "vgx_simulate_tau: more than 2^33 individuals change compartment in one leap");
                 inc_cap *= 2;
@@ -1110,14 +1114,19 @@ extern "C" int vgx_simulate_tau(vgx_engine *e, int64_t iterations, int64_t sampl
         ms_total += ms;
         tau_h.resize((size_t)R);
         err_h.resize((size_t)R);
-        std::vector<int64_t> gI_d((size_t)R);
-        HIPCHECK(e, hipMemcpy(tau_h.data(), a.tau, (size_t)R * 8, hipMemcpyDeviceToHost));
-        HIPCHECK(e, hipMemcpy(err_h.data(), a.error, (size_t)R * 4, hipMemcpyDeviceToHost));
-        HIPCHECK(e, hipMemcpy(gI_d.data(), a.gI, (size_t)R * 8, hipMemcpyDeviceToHost));
-        HIPCHECK(e, hipMemcpy(cnt.data(), a.counters, (size_t)R * 64, hipMemcpyDeviceToHost));
-        HIPCHECK(e, hipMemcpy(mevn.data(), a.mev_n, (size_t)R * 8, hipMemcpyDeviceToHost));
+        std::vector<int64_t> gI_d((size_t)R), res_h((size_t)R * 16);
         std::vector<unsigned long long> mevb((size_t)R);
-        HIPCHECK(e, hipMemcpy(mevb.data(), a.mev_base, (size_t)R * 8, hipMemcpyDeviceToHost));
+        HIPCHECK(e, hipMemcpy(res_h.data(), a.res, (size_t)R * 16 * 8, hipMemcpyDeviceToHost));   // packed by the finish kernel
+        for (int64_t r = 0; r < R; r++) {
+            if (!running[(size_t)r]) continue;
+            const int64_t *o = &res_h[(size_t)r * 16];
+            memcpy(&tau_h[(size_t)r], &o[0], 8);
+            gI_d[(size_t)r] = o[1];
+            for (int i = 0; i < 8; i++) cnt[(size_t)r * 8 + i] = o[2 + i];
+            mevb[(size_t)r] = (unsigned long long)o[10];
+            mevn[(size_t)r] = (unsigned long long)o[11];
+            err_h[(size_t)r] = (int32_t)o[12];
+        }
         for (int64_t r = 0; r < R; r++) {
             if (!running[(size_t)r]) continue;
             if (err_h[(size_t)r] == VGX_ERR_CAPACITY) return fail(e, VGX_ERR_CAPACITY, "vgx_simulate_tau: replicate " + std::to_string(r) + ": list of cross-compartment events full");
@@ -1126,13 +1135,13 @@ extern "C" int vgx_simulate_tau(vgx_engine *e, int64_t iterations, int64_t sampl
                 return fail(e, VGX_ERR_CAPACITY, "vgx_simulate_tau: multievent buffer full (pass record_events=0 for large runs)");
             tnow[(size_t)r] += tau_h[(size_t)r];                       // pyx:2322
             e->tau_log[(size_t)r].push_back({tnow[(size_t)r], (int64_t)mevb[(size_t)r], (int64_t)mevn[(size_t)r]});  // pyx:2325
-            mevb[(size_t)r] = mevn[(size_t)r];
             ev_ptr[(size_t)r] += 1;
             step_h[(size_t)r] += 1;
             steps_done[(size_t)r] += 1;
             gI[(size_t)r] = gI_d[(size_t)r];
+            dev_time[(size_t)r] = tnow[(size_t)r];   // the finish kernel made the same two updates on the device
+            dev_step[(size_t)r] = step_h[(size_t)r];
         }
-        HIPCHECK(e, hipMemcpy(a.mev_base, mevb.data(), (size_t)R * 8, hipMemcpyHostToDevice));
     }
 
     // ---- results ----

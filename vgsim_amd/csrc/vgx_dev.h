@@ -174,6 +174,8 @@ struct VgxTauArgs {
     int64_t *big;        // [R][big_cap] pn * H + hn
     int64_t big_cap;
     unsigned long long *big_n;  // [R]
+    int64_t *res;        // [R][16] what the host reads after a step, packed by vgx_tau_finish_kernel: tau (bits),
+                         // globalInfectious, counters[8], multievent row range of the step, error
     int32_t *grow;       // [R] the try overflowed the cross-compartment list: the host enlarges it and the SAME try runs again
     int32_t *attempt;    // [R]
     const int64_t *seeds;  // [R]

@@ -1476,7 +1476,21 @@ extern "C" __global__ void __launch_bounds__(64) vgx_tau_finish_kernel(VgxTauArg
             }
         }
     }
-    if (lane == 0) a.gI[rep] = g;
+    __syncthreads();   // the lockdown records above use time_now + tau
+    if (lane == 0) {
+        a.gI[rep] = g;
+        // one packed record per replicate for the host, and the bookkeeping it used to upload before every step
+        int64_t *o = a.res + (int64_t)rep * 16;
+        o[0] = __double_as_longlong(a.tau[rep]);
+        o[1] = g;
+        for (int i = 0; i < 8; ++i) o[2 + i] = a.counters[(int64_t)rep * 8 + i];
+        o[10] = (int64_t)a.mev_base[rep];        // multievent rows of this step: [o[10], o[11])
+        o[11] = (int64_t)a.mev_n[rep];
+        o[12] = a.error[rep];
+        a.mev_base[rep] = a.mev_n[rep];          // rows of the accepted step stay (pyx:2325)
+        a.time_now[rep] += a.tau[rep];           // pyx:2322
+        a.step[rep] += 1;
+    }
 }
 
 // ---- launchers -----------------------------------------------------------------------------------
