@@ -992,7 +992,8 @@ extern "C" int vgx_simulate_tau(vgx_engine *e, int64_t iterations, int64_t sampl
     a.big = (int64_t *)e->t_big.p; a.big_cap = big_cap; a.big_n = (unsigned long long *)e->t_bign.p;
     a.res = (int64_t *)e->t_res.p;
     a.sieve = (double *)e->t_sieve.p; a.sieve_skipped = (int64_t *)e->t_sieveskip.p;
-    a.sieve_on = o.reserved[0] == 1 ? 0 : 1;   // vgx_run_opts.reserved[0] = 1: run every try of the halving loop
+    // vgx_run_opts.reserved[0] = 1: run every try of the halving loop; with few compartments no try is ever a certain rejection
+    a.sieve_on = (o.reserved[0] == 1 || P * H < 32768) ? 0 : 1;
     a.mev = (int64_t *)e->t_mev.p; a.mev_cap = mev_cap;
     e->tau_mev_cap = mev_cap;
     a.mev_n = (unsigned long long *)e->t_mevn.p; a.mev_base = (unsigned long long *)e->t_mevbase.p;

@@ -768,7 +768,7 @@ static __device__ __forceinline__ void tau_row(const VgxTauArgs &a, int rep, int
 // after the draw kernel, when every compartment has stored its own deltas.
 // The list is sharded by thread block (VGX_INC_SHARDS counters) so that appends do not serialise on one address.
 #define VGX_INC_STAGE 512   // entries staged in LDS per thread block before one reservation in the global list
-#define VGX_TAU_BIG 256.0   // expected events of a compartment per leap from which every channel is drawn on its own
+#define VGX_TAU_BIG 64.0    // expected events of a compartment per leap from which every channel is drawn on its own
 struct IncStage { int n; int64_t e[VGX_INC_STAGE]; unsigned long long base; };
 
 static __device__ __forceinline__ void tau_incoming_global(const VgxTauArgs &a, int rep, int64_t entry) {
