@@ -78,3 +78,27 @@ def test_reference_example_script_runs(tmp_path):
     assert nwk.endswith(";") and nwk.count(",") == samples - 1          # a binary tree over all samples
     assert len((d / "sample_population.tsv").read_text().splitlines()) == 2 * samples - 1
     assert (d / "mutations.tsv").exists() and (d / "migrations.tsv").read_text().startswith("Node\tTime")
+
+
+def test_command_line_end_to_end(tmp_path, monkeypatch):
+    """`python -m vgsim_amd.cmd` with the reference's example settings files: simulate on the device, genealogy, all four
+    output files (VGsim_cmd.py:144-154)."""
+    import contextlib
+    import io
+    import os
+
+    import numpy as np
+
+    from vgsim_amd import cmd
+    d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cmd_example")
+    monkeypatch.chdir(tmp_path)
+    with contextlib.redirect_stdout(io.StringIO()) as out:
+        rc = cmd.main(["-it", "12000", "-seed", "17", "-rt", os.path.join(d, "example.rt"), "-pm", os.path.join(d, "example.pp"),
+                       os.path.join(d, "example.mg"), "-su", os.path.join(d, "example.su"), "-st", os.path.join(d, "example.st"),
+                       "-nwk", "run", "-tsv", "run_mut", "--writeMigrations", "run_mig", "--output_chain_events", "run_chain"])
+    assert rc == 0 and "Success number: 4" in out.getvalue()        # the same run as the cmd_example golden (seed 17)
+    for f in ("run_tree.nwk", "run_sample_population.tsv", "run_mig.tsv", "run_chain.npy"):
+        assert os.path.getsize(f) > 0, f
+    assert os.path.exists("run_mut.tsv")     # no mutation happens at the example's rates (3e-6 per site)
+    chain = np.load("run_chain.npy")
+    assert chain.shape == (6, 12000) and open("run_tree.nwk").read().endswith(";")
