@@ -1346,12 +1346,23 @@ extern "C" __global__ void __launch_bounds__(TB) vgx_tau_check_kernel(VgxTauArgs
         if (full) { int4 x = *(const int4 *)(a.dChk + off); d[0] = x.x; d[1] = x.y; d[2] = x.z; d[3] = x.w; }
         else for (int j = 0; j < 4; ++j) if (h0 + j < H) d[j] = a.dChk[off + j];
         if (d[0] | d[1] | d[2] | d[3]) {
-            for (int j = 0; j < 4; ++j)
-                if (d[j] != 0) {
-                    int64_t v = (int64_t)d[j] + (int64_t)a.I[off + j];
-                    bad = bad || v < 0 || v > p.sizes[pn];
-                    a.dChk[off + j] = 0;   // nobody reads it after this kernel: zero again for the next try
-                }
+            if (full) {   // one 16-byte load of the counts and one 16-byte clearing store for the four compartments
+                const int4 x = *(const int4 *)(a.I + off);
+                const int Iv[4] = {x.x, x.y, x.z, x.w};
+                for (int j = 0; j < 4; ++j)
+                    if (d[j] != 0) {
+                        int64_t v = (int64_t)d[j] + (int64_t)Iv[j];
+                        bad = bad || v < 0 || v > p.sizes[pn];
+                    }
+                *(int4 *)(a.dChk + off) = make_int4(0, 0, 0, 0);   // nobody reads it after this kernel: zero for the next try
+            } else {
+                for (int j = 0; j < 4; ++j)
+                    if (d[j] != 0) {
+                        int64_t v = (int64_t)d[j] + (int64_t)a.I[off + j];
+                        bad = bad || v < 0 || v > p.sizes[pn];
+                        a.dChk[off + j] = 0;
+                    }
+            }
         }
     }
     if (blockIdx.x == 0 && threadIdx.x < S) {
