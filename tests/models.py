@@ -253,6 +253,11 @@ for _name, (_sites, _P, _S, _seed, _nd, _nt) in {"tau_a": (0, 1, 1, 7, 2000, 200
     CASES[_name] = (_ctor(number_of_sites=_sites, populations_number=_P, number_of_susceptible_groups=_S, seed=_seed),
                     [(_tau_common(_P, _S), _direct(_nd)),
                      (_nothing, dict(iterations=_nt, sample_size=10 ** 12, method='tau'))])
+# direct -> tau -> direct on one object (capacity rules of events.pxi:52-68 across methods, stale rate caches after tau)
+CASES["tau_then_direct"] = (_ctor(number_of_sites=1, populations_number=2, number_of_susceptible_groups=2, seed=21),
+                            [(_tau_common(2, 2), _direct(1500)),
+                             (_nothing, dict(iterations=30, sample_size=10 ** 12, method='tau')),
+                             (_nothing, _direct(1500, sample_size=10 ** 9))])
 CASES["c3_s5_p16"] = (_ctor(number_of_sites=5, populations_number=16, number_of_susceptible_groups=1, seed=2021),
                       [(_c3_scaled, _direct(6000))])
 CASES["c3_s6_p8_spread"] = (_ctor(number_of_sites=6, populations_number=8, number_of_susceptible_groups=1, seed=2022),

@@ -250,3 +250,23 @@ def test_cross_compartment_list_grows_on_demand():
     assert (m.infectious >= 0).all()
     assert int(m.infectious.sum()) == before + m.bCounter - m.dCounter - m.sCounter
     assert int(m.susceptible.sum() + m.infectious.sum()) == int(m.sizes.sum())
+
+
+def test_direct_tau_direct_on_one_object():
+    """direct -> tau -> direct (case `tau_then_direct`, golden recorded from the reference): the first phase is bit-exact,
+    the log has the reference's length and capacity, and the bookkeeping stays consistent through the method changes."""
+    hip = helpers.run_case_hip("tau_then_direct").simulation
+    meta, z = helpers.load_golden("tau_then_direct")
+    chain = hip.events.as_array()
+    assert hip.events.ptr == meta["stats"]["ptr"] == 3030 and chain.shape[1] == meta["size"]
+    assert np.array_equal(chain[1:, :1500].astype(np.int64), z["ints"][:, :1500])
+    assert (chain[1, 1500:1530] == 6).all() and (chain[1, 1530:3030] != 6).all()      # 30 leaps, then single events again
+    assert np.all(np.diff(chain[0, :3030]) >= 0)
+    me = hip.multievents
+    by_type = np.bincount(me.types[:me.ptr], weights=me.num[:me.ptr], minlength=6)
+    single = np.bincount(chain[1, :3030].astype(int), minlength=7)
+    assert hip.bCounter == single[0] + by_type[0] and hip.dCounter == single[1] + by_type[1]
+    assert hip.sCounter == single[2] + by_type[2] and hip.mCounter == single[3] + by_type[3]
+    assert hip.iCounter == single[4] + by_type[4] and hip.migPlus == single[5] + by_type[5]
+    assert int(hip.susceptible.sum() + hip.infectious.sum()) == int(hip.sizes.sum())
+    assert np.array_equal(hip.totalInfectious, hip.infectious.sum(axis=1)) and hip.globalInfectious == hip.infectious.sum()
