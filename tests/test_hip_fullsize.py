@@ -89,3 +89,34 @@ def test_config3_spread_occupancy_exact_oracle_and_fast():
     assert np.array_equal(a[1:, :n], b[1:, :n])
     np.testing.assert_allclose(a[0, :n], b[0, :n], rtol=1e-9, atol=0.0)
     assert np.array_equal(fa.simulation.infectious, ex.simulation.infectious)
+
+
+def test_config4_tau_invariants_at_full_size():
+    """BASELINE config 4 at its full size (2^20 haplotypes x 256 populations, migration, dense occupancy): the reference
+    cannot construct this shape, so the check is on size-independent properties of three leaps — hosts conserved per
+    population, no negative compartment, totals equal to the compartments' sums, counters equal to the net change."""
+    import ctypes as C
+    from vgsim_amd import Simulator, _capi
+    with contextlib.redirect_stdout(io.StringIO()):
+        s = Simulator(number_of_sites=10, populations_number=256, seed=2020)
+    s.set_transmission_rate(2.5); s.set_recovery_rate(0.9); s.set_sampling_rate(0.1); s.set_mutation_rate(0.01)
+    s.set_total_migration_probability(0.01); s.set_population_size(10 ** 7)
+    m = s.simulation
+    m.infectious[:] = 3
+    m.susceptible[:, 0] -= 3 * m.hapNum
+    before_I = int(m.infectious.sum()) + 1       # + the index case the first call adds (pyx:435-448)
+    eng = _capi.HipEngine(m.sites, m.hapNum, m.popNum, m.susNum, n_replicates=1)
+    m.events.CreateEvents(3); m.events.ptr = 1; m.events.CreateEvents(3)
+    eng.set_params(m); eng.set_state(m); eng.set_seeds(np.array([2020], dtype=np.int64))
+    o = _capi.VgxRunOpts(); o.record_events = 0
+    eng._check(eng.lib.vgx_simulate_tau(eng.handle, 3, 10 ** 15, -1.0, 1, C.byref(o)))
+    eng.get_state(m, 0)
+    c = eng.counters(0)
+    eng.close()
+    assert c.loop_iterations == 3 and c.reserved[0] > 5 * 10 ** 6                      # millions of events per leap
+    assert c.reserved[0] == m.bCounter + m.dCounter + m.sCounter + m.mCounter + m.migPlus
+    assert m.infectious.min() >= 0 and m.susceptible.min() >= 0
+    assert np.array_equal(m.totalInfectious, m.infectious.sum(axis=1)) and m.globalInfectious == int(m.infectious.sum())
+    assert np.array_equal(m.susceptible.sum(axis=1) + m.infectious.sum(axis=1), m.sizes)     # per population: migrants infect in place
+    assert int(m.infectious.sum()) == before_I + m.bCounter + m.migPlus - m.dCounter - m.sCounter
+    assert m.currentTime > 0
