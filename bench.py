@@ -432,10 +432,13 @@ def main():
         traffic = pmc_traffic("headline", {"replicates_per_gpu": R, "events_per_replicate": N, "trajectory_points": a.traj_points})
         li = float(res.loop_iterations.sum()) / max(float(res.events.sum()), 1.0)
         line = {
-            "metric": "simulated events/sec (direct Gillespie)", "value": value, "unit": "events/s",
+            # BASELINE.json's metric string; `value` is its direct-Gillespie leg on config 3, the tau-leap leg (config 4) is the
+            # `tau_leap` object of the same line, the Cython-equivalent CPU path `cpu_baseline`
+            "metric": "simulated events/sec (direct + tau-leap) at 1/2/4/8 MI355X vs Cython CPU", "value": value, "unit": "events/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / max(a.steps, 1),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "BASELINE config 3: 65536 haplotypes (8 sites) x 64 populations x 1 susceptibility "
+            "config": {"value_leg": "direct Gillespie (BASELINE config 3); tau-leap (config 4) in tau_leap",
+                       "workload": "BASELINE config 3: 65536 haplotypes (8 sites) x 64 populations x 1 susceptibility "
                                    "group, direct Gillespie, bit-exact mode (PCG64 stream, reference summation order), "
                                    "index-case start, b=2.5 d=0.9 s=0.1 m=0.01/site, total migration 0.01, N=1e7",
                        "replicates_per_gpu": R, "events_per_replicate": N, "parallelism": "replicates x%d" % world,
