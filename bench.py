@@ -321,6 +321,82 @@ def tau_leg(device, steps=20, per_cell=3, seed=2020):
     return out
 
 
+class BenchLoop:
+    """The timed loop of one rank: `step(i)` runs one batch of replicates and hands that step's summary trajectories
+    to an asynchronous gather to rank 0 (it overlaps the next step's kernel), `drain()` waits for the last gather, `reduce(elapsed, events)` gives the whole job's MAX time and SUM of events.  The engine is
+    anything with `simulate(...)` / `gather_trajectories(...)` of `vgsim_amd.ensemble.Ensemble`: the world_size-2 gloo test
+    drives this same class with a stand-in engine on CPU tensors (tests/test_bench_ranks_gloo.py)."""
+
+    def __init__(self, ens, replicates, events, traj_points, world=1, rank=0, device="cuda", pops=POPS):
+        self.ens, self.R, self.N, self.T = ens, replicates, events, traj_points
+        self.world, self.rank, self.device, self.pops = world, rank, device, pops
+        self.gather_out = None      # [world, R, T, P, 2] on rank 0, allocated once
+        self.pending = None         # the gather of the previous step
+
+    def seeds(self, i):
+        """Distinct seeds per (step, rank, replicate): disjoint across ranks, independent of the GPU count."""
+        import numpy as np
+        return 2020 + (i * self.world + self.rank) * self.R + np.arange(self.R, dtype=np.int64)
+
+    def step(self, i):
+        res = self.ens.simulate(self.N, sample_size=10 ** 12, record_events=True, traj_points=self.T,
+                                traj_window=(0.0, 12.0), seeds=self.seeds(i))
+        if self.world > 1:
+            import torch
+            if self.pending is not None:
+                self.pending.wait()
+            if self.rank == 0 and self.gather_out is None:
+                self.gather_out = torch.empty((self.world, self.R, self.T, self.pops, 2), dtype=torch.float64, device=self.device)
+            self.pending = self.ens.gather_trajectories(dst=0, out=self.gather_out, async_op=True)
+        return res
+
+    def drain(self):
+        if self.pending is not None:
+            self.pending.wait()
+            self.pending = None
+
+    def reduce(self, elapsed, events):
+        """(max over ranks of the elapsed time, sum over ranks of the events)."""
+        if self.world == 1:
+            return float(elapsed), float(events)
+        import torch
+        import torch.distributed as dist
+        t = torch.tensor([elapsed], dtype=torch.float64, device=self.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        e = torch.tensor([float(events)], dtype=torch.float64, device=self.device)
+        dist.all_reduce(e, op=dist.ReduceOp.SUM)
+        return float(t.item()), float(e.item())
+
+    def per_rank(self, value):
+        """`value` of every rank, in rank order (the JSON line lists each rank's events)."""
+        if self.world == 1:
+            return [float(value)]
+        import torch
+        import torch.distributed as dist
+        mine = torch.tensor([float(value)], dtype=torch.float64, device=self.device)
+        out = [torch.zeros_like(mine) for _ in range(self.world)]
+        dist.all_gather(out, mine)
+        return [float(o.item()) for o in out]
+
+
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: start N fresh ranks (torch.distributed.run, one per GPU) as a CHILD
+    process and exit with its code.  Nothing in this parent has touched HIP or imported torch, and nothing is re-exec'ed."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % n, "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    rc = subprocess.call(cmd, env=env)
+    if rc != 0:
+        sys.stderr.write("bench.py: the %d-rank launch failed (exit code %d): %s\n" % (n, rc, " ".join(cmd)))
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -336,15 +412,27 @@ def main():
                                                "spread_occupancy_fast, config2, genealogy, single_trajectory, direct_config4_shape, tau_leap) and print its JSON")
     a = ap.parse_args()
 
+    # ---- ranks: one process per GPU.  Under a launcher (torch.distributed.run sets WORLD_SIZE) this process is one rank;
+    # without one, `--gpus N > 1` starts N fresh ranks as a child process BEFORE anything here imports torch or touches HIP.
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and a.gpus > 1:
+        sys.exit(launch_ranks(a.gpus, sys.argv[1:]))
+    world = int(env_world or "1")
+    if world != a.gpus:
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d; run `python bench.py --gpus %d` (it starts the ranks itself) or "
+                 "`python -m torch.distributed.run --nnodes=1 --nproc-per-node %d --master-addr 127.0.0.1 bench.py --gpus %d ...`"
+                 % (a.gpus, world, a.gpus, a.gpus, a.gpus))
+
     import numpy as np
     import torch
     import torch.distributed as dist
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the engine has no CPU fallback)")
+    if local >= torch.cuda.device_count():
+        raise SystemExit("bench.py: rank %d needs GPU %d but this node shows %d device(s)" % (rank, local, torch.cuda.device_count()))
     torch.cuda.set_device(local)
     if world > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
@@ -362,6 +450,7 @@ def main():
         return
     sim = make_simulator(2020)
     ens = Ensemble(sim, a.replicates, device=local)
+    loop = BenchLoop(ens, R, N, a.traj_points, world=world, rank=rank, device="cuda")
 
     def sync():
         torch.cuda.synchronize()
@@ -369,52 +458,22 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    gather_out = None      # [world, R, T, P, 2] on rank 0, allocated once
-    pending = [None]       # the gather of the previous step: overlaps this step's kernel (separate streams)
-
-    def step(i):
-        # distinct seeds per (step, rank, replicate): results do not depend on the GPU count
-        nonlocal gather_out
-        seeds = 2020 + (i * world + rank) * R + np.arange(R, dtype=np.int64)
-        res = ens.simulate(N, sample_size=10 ** 12, record_events=True, traj_points=a.traj_points,
-                           traj_window=(0.0, 12.0), seeds=seeds)
-        if world > 1:
-            if pending[0] is not None:
-                pending[0].wait()
-            if rank == 0 and gather_out is None:
-                gather_out = torch.empty((world, R, a.traj_points, POPS, 2), dtype=torch.float64, device="cuda")
-            pending[0] = ens.gather_trajectories(dst=0, out=gather_out, async_op=True)
-        return res
-
-    def drain():
-        if pending[0] is not None:
-            pending[0].wait()
-            pending[0] = None
-
     for i in range(a.warmup):
-        step(i)
-    drain()
+        loop.step(i)
+    loop.drain()
     sync()
     t0 = time.perf_counter()
     events = 0
     kernel_ms = 0.0
-    occ_entries = 0
     for i in range(a.steps):
-        res = step(a.warmup + i)
+        res = loop.step(a.warmup + i)
         events += res.total_events
         kernel_ms += res.kernel_ms
-    drain()
+    loop.drain()
     sync()
     elapsed = time.perf_counter() - t0
-
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        e = torch.tensor([float(events)], dtype=torch.float64, device="cuda")
-        dist.all_reduce(e, op=dist.ReduceOp.SUM)
-        elapsed, total_events = float(t.item()), float(e.item())
-    else:
-        total_events = float(events)
+    elapsed, total_events = loop.reduce(elapsed, events)
+    events_per_rank = loop.per_rank(events)
 
     if rank == 0:
         value = total_events / elapsed
@@ -441,7 +500,8 @@ def main():
                        "workload": "BASELINE config 3: 65536 haplotypes (8 sites) x 64 populations x 1 susceptibility "
                                    "group, direct Gillespie, bit-exact mode (PCG64 stream, reference summation order), "
                                    "index-case start, b=2.5 d=0.9 s=0.1 m=0.01/site, total migration 0.01, N=1e7",
-                       "replicates_per_gpu": R, "events_per_replicate": N, "parallelism": "replicates x%d" % world,
+                       "replicates_per_gpu": R, "events_per_replicate": N, "parallelism": "replicates x %d (one process per GPU, %d replicates each, no data-path collective)" % (world, R),
+                       "events_per_rank": events_per_rank,
                        "trajectory_points": a.traj_points, "loop_iterations_per_event": li},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
