@@ -65,8 +65,10 @@ def chain_of(model):
     return model.events.as_array()
 
 
-def check_against_golden(model, name, exact_time=True, rtol_time=1e-12):
-    """Compare a finished host model with the fixture recorded from the reference."""
+def check_against_golden(model, name, exact_time=True, rtol_time=1e-12, leftovers=True):
+    """Compare a finished host model with the fixture recorded from the reference.  ``leftovers``: the model's log still
+    holds, beyond ``events.ptr``, the rows of failed attempts exactly as the reference leaves them (true for the oracle,
+    which writes into the host arrays; the engine copies out rows below ``ptr`` only)."""
     meta, z = load_golden(name)
     st = meta["stats"]
     chain = chain_of(model)
@@ -86,8 +88,14 @@ def check_against_golden(model, name, exact_time=True, rtol_time=1e-12):
         head, tail = z["head"], z["tail"]
         assert np.array_equal(chain[1:, :256], head[1:]) and np.array_equal(chain[1:, ptr - tail.shape[1]:ptr], tail[1:])
         ref_t = None
+    if "sha256_ints" in meta:   # all five integer rows of the log, full length (rows 1-5 do not depend on the host's libm)
+        if leftovers or ptr == chain.shape[1]:
+            assert hashlib.sha256(np.ascontiguousarray(chain[1:]).tobytes()).hexdigest() == meta["sha256_ints"], "integer rows (sha256)"
     if exact_time:
-        assert hashlib.sha256(np.ascontiguousarray(chain).tobytes()).hexdigest() == meta["sha256_chain"]
+        if leftovers or ptr == chain.shape[1]:
+            assert hashlib.sha256(np.ascontiguousarray(chain).tobytes()).hexdigest() == meta["sha256_chain"]
+        if ref_t is not None:
+            assert np.array_equal(chain[0, :ptr], ref_t[:ptr]), "time row differs"
         assert model.currentTime == st["currentTime"]
     else:
         # documented tolerance for the float row when log() is not the fixture host's libm

@@ -36,7 +36,7 @@ def test_replicates_equal_single_runs(oracle_mod, name, n_events):
             one = Simulator(**dict(ctor, seed=int(seeds[r])))
         models.CASES[name][1][0][0](one)
         m = one.simulation
-        assert oracle_mod.run_direct(m, n_events, 10 ** 9, -1, 200, log_mode=oracle_mod.LOG_PORTABLE) == 0
+        assert oracle_mod.run_direct(m, n_events, 10 ** 9, -1, 200) == 0
         chain = ens.replicate_events(r)
         assert res.events[r] == m.events.ptr
         assert np.array_equal(chain, m.events.as_array()[:, :m.events.ptr]), "replicate %d" % r

@@ -1,83 +1,39 @@
-"""The reference's own example script (testing/example.py: parameters, direct phase, parameter changes, tau phase,
-genealogy, Newick / mutation / migration export) run unchanged except for its import line — `import vgsim_amd as VGsim`
-— on the GPU, in a scratch directory."""
+"""The workflow of the reference's example (testing/example.py) end to end on the GPU: the example model of
+``tests/models.py`` (``_example_1`` / ``_example_2`` restate its parameters), a direct phase up to an epidemic time,
+parameter changes, a tau-leaping call, the backward pass and the three exports.  Plus the command line."""
 import os
-import subprocess
-import sys
-import textwrap
 
 import pytest
 
+import helpers
+import models
+
 pytestmark = pytest.mark.gpu
 
-SCRIPT = textwrap.dedent("""
-    import sys
-    sys.path.insert(0, %r)
-    import vgsim_amd as VGsim
-    import os
-    import os.path
 
-    number_of_sites = 2
-    populations_number = 3
-    number_of_susceptible_groups = 3
-    simulator = VGsim.Simulator(number_of_sites, populations_number, number_of_susceptible_groups, seed=1234)
-    simulator.set_transmission_rate(0.25)
-    simulator.set_transmission_rate(0.5, haplotype="GG")
-    simulator.set_recovery_rate(0.099)
-    simulator.set_sampling_rate(0.001)
-    mutation_rate=0.00003
-    substitution_weights=[1,1,1,2]#ATCG
-    simulator.set_mutation_rate(mutation_rate)
-    simulator.set_mutation_probabilities(substitution_weights)
-    simulator.set_mutation_rate(3*mutation_rate, haplotype='G*', mutation=1)
-    simulator.set_susceptibility_type(1)
-    simulator.set_susceptibility_type(2, haplotype='G*')
-    simulator.set_susceptibility(0.1, susceptibility_type=1)
-    simulator.set_susceptibility(0.5, susceptibility_type=1, haplotype='G*')
-    simulator.set_susceptibility(0.0, susceptibility_type=2)
-    simulator.set_immunity_transition(1/90, source=1, target=0)
-    simulator.set_immunity_transition(1/180, source=2, target=0)
-    simulator.set_population_size(10000000, population=0)
-    simulator.set_population_size(5000000, population=1)
-    simulator.set_population_size(1000000, population=2)
-    simulator.set_migration_probability(10/365/2)
-    simulator.set_sampling_multiplier(3, population=1)
-    simulator.set_sampling_multiplier(0, population=2)
-    simulator.set_npi([0.1, 0.01, 0.002])
-    simulator.simulate(10000000, epidemic_time=110)
-    simulator.set_immunity_transition(0.05, source=0, target=1)
-    simulator.set_immunity_transition(0.05, source=0, target=2)
-    simulator.set_contact_density(0.7, population=0)
-    simulator.set_contact_density(0.7, population=1)
-    simulator.set_migration_probability(2/365/2, source=0, target=2)
-    simulator.set_migration_probability(2/365/2, source=1, target=2)
-    simulator.simulate(1000, epidemic_time=210, method='tau')
-    simulator.genealogy()
-    os.chdir('testing')
-    if os.path.exists('example_output') == False:
-        os.mkdir('example_output')
-    os.chdir('example_output')
-    simulator.export_newick()
-    simulator.export_mutations('mutations')
-    simulator.export_migrations('migrations')
-    print("EXAMPLE_DONE", simulator.simulation.sCounter, simulator.simulation.events.ptr)
-""")
-
-
-def test_reference_example_script_runs(tmp_path):
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    (tmp_path / "testing").mkdir()
-    script = tmp_path / "example.py"
-    script.write_text(SCRIPT % root)
-    p = subprocess.run([sys.executable, str(script)], cwd=str(tmp_path), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
-    out = p.stdout.decode()
-    assert p.returncode == 0 and "EXAMPLE_DONE" in out, out[-3000:]
-    samples = int(out.split("EXAMPLE_DONE")[1].split()[0])
-    d = tmp_path / "testing" / "example_output"
-    nwk = (d / "tree.nwk").read_text()
+def test_example_workflow_direct_tau_genealogy_exports(tmp_path, monkeypatch):
+    from vgsim_amd import Simulator
+    monkeypatch.chdir(tmp_path)
+    with helpers.quiet():
+        sim, phases = models.build(Simulator, "example")
+        setup, kw = phases[0]
+        setup(sim)
+        sim.simulate(**kw)                                   # direct, stops at epidemic time 110
+        m = sim.simulation
+        direct_events, direct_samples = m.events.ptr, m.sCounter
+        helpers.check_against_golden(m, "example", exact_time=helpers.libm_matches_fixture_host(), leftovers=False)
+        models._example_2(sim)                               # parameter changes between the calls
+        sim.simulate(1000, epidemic_time=210, method='tau')  # a no-op upstream too: sample_size defaults to 1000 < sCounter
+        sim.genealogy()
+        sim.export_newick()
+        sim.export_mutations('mutations')
+        sim.export_migrations('migrations')
+    assert (m.events.ptr, m.sCounter) == (direct_events, direct_samples)
+    samples = int(m.sCounter)
+    nwk = (tmp_path / "tree.nwk").read_text()
     assert nwk.endswith(";") and nwk.count(",") == samples - 1          # a binary tree over all samples
-    assert len((d / "sample_population.tsv").read_text().splitlines()) == 2 * samples - 1
-    assert (d / "mutations.tsv").exists() and (d / "migrations.tsv").read_text().startswith("Node\tTime")
+    assert len((tmp_path / "sample_population.tsv").read_text().splitlines()) == 2 * samples - 1
+    assert (tmp_path / "mutations.tsv").exists() and (tmp_path / "migrations.tsv").read_text().startswith("Node\tTime")
 
 
 def test_command_line_end_to_end(tmp_path, monkeypatch):

@@ -39,7 +39,7 @@ def _assert_tier_b(got, want, what):
 @pytest.mark.parametrize("name", DIRECT)
 def test_fast_integer_columns_match_oracle(oracle_mod, name):
     hip = helpers.run_case_hip(name, mode="fast").simulation
-    ref = helpers.run_case_oracle(oracle_mod, name, log_mode=oracle_mod.LOG_PORTABLE).simulation
+    ref = helpers.run_case_oracle(oracle_mod, name).simulation
     _assert_tier_b(hip, ref, name)
 
 

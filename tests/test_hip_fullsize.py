@@ -28,7 +28,7 @@ def test_config3_bit_exact_vs_sparse_oracle(oracle_mod, seed, mut, n):
     with helpers.quiet():
         hip.simulate(n, sample_size=10 ** 9)
     ref = c3(seed, mut).simulation
-    assert oracle_mod.run_direct(ref, n, 10 ** 9, -1, 200, sparse=True, log_mode=oracle_mod.LOG_PORTABLE) == 0
+    assert oracle_mod.run_direct(ref, n, 10 ** 9, -1, 200, sparse=True) == 0
     helpers.assert_models_equal(hip.simulation, ref, "config3 seed %d" % seed)
     assert (hip.simulation.infectious != 0).sum() > (50 if mut < 0.1 else 1000)   # the lists are really exercised
 
@@ -80,7 +80,7 @@ def test_config3_spread_occupancy_exact_oracle_and_fast():
     with helpers.quiet():
         ex.simulate(n, sample_size=10 ** 9)
     ref = spread(11).simulation
-    assert oracle_mod.run_direct(ref, n, 10 ** 9, -1, 200, sparse=True, log_mode=oracle_mod.LOG_PORTABLE) == 0
+    assert oracle_mod.run_direct(ref, n, 10 ** 9, -1, 200, sparse=True) == 0
     helpers.assert_models_equal(ex.simulation, ref, "config3 spread")
     fa = spread(11)
     with helpers.quiet():

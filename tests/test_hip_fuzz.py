@@ -60,7 +60,7 @@ def build(seed):
 
 
 def drive_oracle(oracle_mod, sim, n):
-    rc = oracle_mod.run_direct(sim.simulation, n, 10 ** 9, -1, 200, log_mode=oracle_mod.LOG_PORTABLE)
+    rc = oracle_mod.run_direct(sim.simulation, n, 10 ** 9, -1, 200)
     return rc
 
 

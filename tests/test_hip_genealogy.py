@@ -25,7 +25,7 @@ def _product(sim):
 @pytest.mark.parametrize("gseed", [None, 4711])
 def test_direct_pipeline_matches_oracle(oracle_mod, name, gseed):
     hip = helpers.run_case_hip(name)
-    ref = helpers.run_case_oracle(oracle_mod, name, log_mode=oracle_mod.LOG_PORTABLE)
+    ref = helpers.run_case_oracle(oracle_mod, name)
     if ref.simulation.sCounter < 2:
         pytest.skip("fewer than two samples")
     with helpers.quiet():

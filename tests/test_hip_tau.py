@@ -35,9 +35,9 @@ def run_tau_case(name, seed, engine, oracle=None):
                 ss = it if ss is None else ss
                 method = kw.pop("method", "direct")
                 if method == "direct":
-                    assert oracle.run_direct(m, it, ss, -1, 200, log_mode=oracle.LOG_PORTABLE) == 0
+                    assert oracle.run_direct(m, it, ss, -1, 200) == 0
                 else:
-                    assert oracle.run_tau(m, it, ss, -1, 200, log_mode=oracle.LOG_PORTABLE) == 0
+                    assert oracle.run_tau(m, it, ss, -1, 200) == 0
     return sim.simulation
 
 
@@ -208,8 +208,8 @@ def test_tiled_drift_leap_length_matches_oracle(oracle_mod, sites, weights, asym
                 s.simulate(3000)
                 s.simulate(2, sample_size=10 ** 9, method="tau")
             else:
-                assert oracle_mod.run_direct(m, 3000, 3000, -1, 200, log_mode=oracle_mod.LOG_PORTABLE) == 0
-                assert oracle_mod.run_tau(m, 2, 10 ** 9, -1, 200, log_mode=oracle_mod.LOG_PORTABLE) == 0
+                assert oracle_mod.run_direct(m, 3000, 3000, -1, 200) == 0
+                assert oracle_mod.run_tau(m, 2, 10 ** 9, -1, 200) == 0
         return m
     hip, ref = run("hip"), run("oracle")
     assert np.array_equal(hip.events.as_array()[:, :3000], ref.events.as_array()[:, :3000])

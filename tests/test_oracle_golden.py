@@ -39,3 +39,28 @@ def test_portable_log_time_tolerance(oracle_mod, name):
     """With the portable log (the device's), integer rows stay exact and times stay within 1e-12."""
     sim = helpers.run_case_oracle(oracle_mod, name, log_mode=1)
     helpers.check_against_golden(sim.simulation, name, exact_time=False, rtol_time=1e-12)
+
+
+REF_TESTING = "/root/reference/testing"
+
+
+@pytest.mark.parametrize("k", range(1, 10))
+def test_upstream_reference_blobs_if_present(oracle_mod, k):
+    """The reference's OWN goldens ``testing/reference_{1..9}.npy`` (``check_simulator.py:6-32`` compares all six rows
+    with ``!=``) are missing from the checkout (``.MISSING_LARGE_BLOBS``).  They are the only witnesses of the seed ->
+    uniform-stream mapping of the absent third-party ``mc_lib.rndm.RndmWrapper``; wherever they are available this test
+    pins the oracle's restatement of it.  Skipped while they are absent: parity stays "unpinned at the
+    RNG wrapper" (DESIGN.md §2)."""
+    import os
+    path = os.path.join(REF_TESTING, "reference_%d.npy" % k)
+    if not os.path.exists(path) or os.path.getsize(path) < 1000:
+        pytest.skip("upstream golden %s is not in this checkout" % path)
+    want = np.load(path)
+    sim = helpers.run_case_oracle(oracle_mod, "g%d" % k)
+    got = sim.simulation.events.as_array()
+    assert got.shape == want.shape
+    assert np.array_equal(got[1:], want[1:]), "integer rows differ from the upstream golden"
+    if helpers.libm_matches_fixture_host():
+        assert np.array_equal(got[0], want[0]), "time row differs from the upstream golden"
+    else:
+        np.testing.assert_allclose(got[0], want[0], rtol=1e-12, atol=0)

@@ -15,9 +15,15 @@ import sys
 
 import numpy as np
 
+from ._params import ParameterTable, need_count, need_number
 from ._report import Reporting
 
 BIRTH, DEATH, SAMPLING, MUTATION, SUSCCHANGE, MIGRATION, MULTITYPE = range(7)  # events.pxi:2-8
+
+_RED_WARNING = '\033[41m{}\033[0m'.format('WARNING!')
+_SIZE_ADVICE = ("is more than 10% different from the population size. The migration probabilities might be unrealistically high.",
+                "We recommend to check your model with print_populations() method before proceding to simulation.",
+                "Check the documentation file:https://vg-sim.readthedocs.io/en/latest/Migration.html for more details.")
 
 
 class Events:
@@ -124,52 +130,40 @@ class Recombination:
         self.posRecombs.append(int(posRecomb))
 
 
-class BirthDeathModel(Reporting):
+class BirthDeathModel(ParameterTable, Reporting):
     COUNTERS = ("bCounter", "dCounter", "sCounter", "mCounter", "iCounter", "swapLockdown", "migPlus",
                 "migNonPlus")
 
     def __init__(self, number_of_sites, populations_number, number_of_susceptible_groups, seed,
                  sampling_probability, memory_optimization, genome_length, recombination_probability):
-        # validation order and messages: pyx:70-98
-        self.check_amount(seed, 'seed', zero=False)
+        # order of the checks and their messages: pyx:70-98
+        need_count(seed, 'seed', positive=False)
         self.user_seed = seed
         self.first_simulation = False
-        if sampling_probability != True and sampling_probability != False:  # noqa: E712 (reference semantics)
-            raise ValueError('Incorrect value of sampling probability. Value of sampling probability should be True or False.')
+        for flag, what in ((sampling_probability, 'sampling probability'), (memory_optimization, 'memory optimization')):
+            if flag not in (True, False):
+                raise ValueError('Incorrect value of %s. Value of %s should be True or False.' % (what, what))
         self._sampling_probability = sampling_probability
-        if memory_optimization != True and memory_optimization != False:  # noqa: E712
-            raise ValueError('Incorrect value of memory optimization. Value of memory optimization should be True or False.')
         self._memory_optimization = memory_optimization
-
-        self.check_amount(number_of_sites, 'number of sites', zero=False)
-        self.sites = number_of_sites
+        need_count(number_of_sites, 'number of sites', positive=False)
+        need_count(number_of_susceptible_groups, 'number of susceptible groups')
+        need_count(populations_number, 'populations number')
+        self.sites, self.susNum, self.popNum = number_of_sites, number_of_susceptible_groups, populations_number
         self.hapNum = int(4 ** self.sites)
-        self.check_amount(number_of_susceptible_groups, 'number of susceptible groups')
-        self.susNum = number_of_susceptible_groups
-        self.check_amount(populations_number, 'populations number')
-        self.popNum = populations_number
-
-        self.check_value(recombination_probability, 'recombination probability', edge=1)
+        need_number(recombination_probability, 'recombination probability', upper=1)
         self.recombination = recombination_probability
-        self.check_amount(genome_length, 'genome length')
+        need_count(genome_length, 'genome length')
         self._genome_length = genome_length
-        self.sitesPosition = np.zeros(self.sites, dtype=np.int64)
         if self.sites > self._genome_length:
-            raise ValueError('Incorrect value of number of sites or genome length. Genome length should be more or equal number of sites.')
+            raise ValueError('Incorrect value of number of sites or genome length. Genome length should be more or equal '
+                             'number of sites.')
+        self.sitesPosition = np.zeros(self.sites, dtype=np.int64)
         if self.sites > 1:
-            for s in range(self.sites):
-                self.sitesPosition[s] = int(s * self._genome_length / (self.sites - 1))
-
-        if self._memory_optimization:
-            if self.sites > 2:
-                self.maxHapNum = int(4 ** (self.sites - 2))
-                self.addMemoryNum = int(4 ** (self.sites - 2))
-            else:
-                self.maxHapNum = 4
-                self.addMemoryNum = 4
-        else:
-            self.maxHapNum = self.hapNum
-            self.addMemoryNum = 0
+            self._spread_sites()
+        # haplotype table of memory_optimization (pyx:105-125): starts at 4^(sites-2) slots (at least 4) and grows by as many
+        block = int(4 ** max(self.sites - 2, 1)) if self._memory_optimization else 0
+        self.maxHapNum = block if self._memory_optimization else self.hapNum
+        self.addMemoryNum = block
 
         for c in self.COUNTERS:
             setattr(self, c, 0)
@@ -234,427 +228,6 @@ class BirthDeathModel(Reporting):
         self._rng_position = None   # (attempt, uniforms drawn) of the last direct simulate call's random stream
         self._rng_raw = None        # raw generator state after the last genealogy pass
 
-    # ------------------------------------------------------------------ haplotype patterns (pyx:1187-1267)
-    def calculate_indexes(self, indexes_list, edge):
-        if isinstance(indexes_list, list):
-            indexes = set()
-            for i in indexes_list:
-                indexes.update(self.calculate_index(i, edge))
-        else:
-            indexes = set(self.calculate_index(indexes_list, edge))
-        return indexes
-
-    def calculate_index(self, index, edge):
-        if isinstance(index, str):
-            haplotypes = [index]
-            for s in range(self.sites):
-                for i in range(len(haplotypes)):
-                    old = haplotypes[i]
-                    if old[s] == "*":
-                        for letter in ('A', 'T', 'C', 'G'):
-                            haplotypes.append(old.replace("*", letter, 1))
-            haplotypes = [h for h in haplotypes if h.count("*") == 0]
-            return [self.calculate_haplotype_from_string(h) for h in haplotypes]
-        elif isinstance(index, int):
-            return [index]
-        else:
-            return range(edge)
-
-    def calculate_string_from_haplotype(self, hapNum):
-        letters = ["A", "T", "C", "G"]
-        string = ""
-        for _ in range(self.sites):
-            string = letters[hapNum % 4] + string
-            hapNum = hapNum // 4
-        return string
-
-    def calculate_haplotype_from_string(self, string):
-        string = string[::-1]
-        haplotype = 0
-        for s in range(self.sites):
-            haplotype += {"A": 0, "T": 1, "C": 2, "G": 3}.get(string[s], 0) * (4 ** s)
-        return haplotype
-
-    def calculate_allele(self, haplotype, site):
-        allele = 0
-        for _ in range(self.sites - site):
-            allele = haplotype % 4
-            haplotype = haplotype // 4
-        return allele
-
-    # ------------------------------------------------------------------ validation (pyx:1298-1377)
-    def check_amount(self, amount, smth, zero=True):
-        if isinstance(amount, int) == False:  # noqa: E712
-            raise TypeError('Incorrect type of ' + smth + '. Type should be int.')
-        elif amount <= 0 and zero:
-            raise ValueError('Incorrect value of ' + smth + '. Value should be more 0.')
-        elif amount < 0 and zero == False:  # noqa: E712
-            raise ValueError('Incorrect value of ' + smth + '. Value should be more or equal 0.')
-
-    def check_value(self, value, smth, edge=None, none=False):
-        if none:
-            if isinstance(value, (int, float)) == False and value is not None:  # noqa: E712
-                raise TypeError('Incorrect type of ' + smth + '. Type should be int or float or None.')
-        else:
-            if isinstance(value, (int, float)) == False:  # noqa: E712
-                raise TypeError('Incorrect type of ' + smth + '. Type should be int or float.')
-        if isinstance(value, (int, float)):
-            if edge is None:
-                if value < 0:
-                    raise ValueError('Incorrect value of ' + smth + '. Value should be more or equal 0.')
-            elif value < 0 or value > edge:
-                raise ValueError('Incorrect value of ' + smth + '. Value should be more or equal 0 and equal or less ' + str(edge) + '.')
-
-    def check_indexes(self, index, edge, smth, hap=False, none=True):
-        if isinstance(index, list):
-            for i in index:
-                self.check_index(i, edge, smth, hap=hap, none=none)
-        else:
-            self.check_index(index, edge, smth, hap=hap, none=none)
-
-    def check_index(self, index, edge, smth, hap=False, none=True):
-        if none == False and index is None:  # noqa: E712
-            raise TypeError('Incorrect type of ' + smth + '. Type should be int.')
-        elif isinstance(index, int):
-            if index < 0 or index >= edge:
-                raise IndexError('There are no such ' + smth + '!')
-        elif isinstance(index, str) and hap:
-            if sum(index.count(ch) for ch in "ATCG*") != self.sites:
-                raise ValueError('Incorrect haplotype. Haplotype should contain only \"A\", \"T\", \"C\", \"G\", \"*\" and length of haplotype should be equal number of mutations sites.')
-        elif index is not None:
-            if hap:
-                raise TypeError('Incorrect type of haplotype. Type should be int or str or None.')
-            else:
-                raise TypeError('Incorrect type of ' + smth + '. Type should be int or None.')
-
-    def check_list(self, data, smth, length):
-        if isinstance(data, list):
-            if len(data) != length:
-                raise ValueError('Incorrect length of ' + smth + '. Length should be equal ' + str(length) + '.')
-        else:
-            raise TypeError('Incorrect type of ' + smth + '. Type should be list.')
-
-    def check_amount_sus(self, amount, source_type, target_type, population):
-        if self.susceptible[population, source_type] - amount < 0:
-            raise ValueError('Number of susceptible minus amount should be more or equal 0.')
-        if self.susceptible[population, target_type] + amount > self.sizes[population]:
-            raise ValueError('Number of susceptible plus amount should be equal or less population size.')
-
-    def check_amount_inf(self, amount, source_type, target_haplotype, population):
-        if self.susceptible[population, source_type] - amount < 0:
-            raise ValueError('Number of susceptible minus amount should be more or equal 0.')
-        if self.infectious[population, target_haplotype] + amount > self.sizes[population]:
-            raise ValueError('Number of infectious plus amount should be equal or less population size.')
-
-    def check_mig_rate(self):
-        for pn1 in range(self.popNum):
-            summa = 0
-            self.migrationRates[pn1, pn1] = 1.0
-            for pn2 in range(self.popNum):
-                if pn1 != pn2:
-                    summa += self.migrationRates[pn1, pn2]
-                    self.migrationRates[pn1, pn1] -= self.migrationRates[pn1, pn2]
-            if summa > 1:
-                raise ValueError('Incorrect the sum of migration probabilities. The sum of migration probabilities from each population should be equal or less 1.')
-        for pn in range(self.popNum):
-            if self.migrationRates[pn, pn] <= 1e-15:
-                raise ValueError('Incorrect value of migration probability. Value of migration probability from source population to target population should be more 0.')
-
-    # ------------------------------------------------------------------ read-only properties (pyx:1269-1295)
-    @property
-    def seed(self):
-        return self.user_seed
-
-    @property
-    def sampling_probability(self):
-        return self._sampling_probability
-
-    @property
-    def memory_optimization(self):
-        return self._memory_optimization
-
-    @property
-    def number_of_sites(self):
-        return self.sites
-
-    @property
-    def haplotypes_number(self):
-        return self.hapNum
-
-    @property
-    def populations_number(self):
-        return self.popNum
-
-    @property
-    def number_of_susceptible_groups(self):
-        return self.susNum
-
-    # ------------------------------------------------------------------ setters (pyx:1380-1702)
-    @property
-    def initial_haplotype(self):
-        return self.maxHapNum
-
-    def set_initial_haplotype(self, amount):
-        if self._memory_optimization == False:  # noqa: E712
-            raise ValueError('Incorrect value of memory optimization. Value should be equal \'True\' for work this function.')
-        self.check_amount(amount, 'amount of initial haplotype')
-        self.maxHapNum = self.hapNum if amount >= self.hapNum else amount
-
-    @property
-    def step_haplotype(self):
-        return self.addMemoryNum
-
-    def set_step_haplotype(self, amount):
-        if self._memory_optimization == False:  # noqa: E712
-            raise ValueError('Incorrect value of memory optimization. Value should be equal \'True\' for work this function.')
-        self.check_amount(amount, 'amount of step haplotype')
-        self.addMemoryNum = amount
-
-    @property
-    def genome_length(self):
-        return self._genome_length
-
-    def set_genome_length(self, genome_length):
-        self.check_amount(genome_length, 'genome length')
-        if self.sites > genome_length:
-            raise ValueError('Incorrect value of number of sites or genome length. Genome length should be more or equal number of sites.')
-        self._genome_length = genome_length
-        for s in range(self.sites):
-            self.sitesPosition[s] = int(s * self._genome_length / (self.sites - 1))
-
-    @property
-    def coinfection_parameters(self):
-        return self.recombination
-
-    def set_coinfection_parameters(self, recombination):
-        self.check_value(recombination, 'recombination probability', edge=1)
-        self.recombination = recombination
-
-    @property
-    def transmission_rate(self):
-        return self.bRate
-
-    def set_transmission_rate(self, rate, haplotype):
-        self.check_value(rate, 'transmission rate')
-        self.check_indexes(haplotype, self.hapNum, 'haplotype', True)
-        for hn in self.calculate_indexes(haplotype, self.hapNum):
-            self.bRate[hn] = rate
-
-    @property
-    def recovery_rate(self):
-        return self.dRate
-
-    def set_recovery_rate(self, rate, haplotype):
-        self.check_value(rate, 'recovery rate')
-        self.check_indexes(haplotype, self.hapNum, 'haplotype', True)
-        for hn in self.calculate_indexes(haplotype, self.hapNum):
-            self.dRate[hn] = rate
-
-    @property
-    def sampling_rate(self):
-        return self.sRate
-
-    def set_sampling_rate(self, rate, haplotype):
-        self.check_indexes(haplotype, self.hapNum, 'haplotype', True)
-        haplotypes = self.calculate_indexes(haplotype, self.hapNum)
-        if self._sampling_probability == True:  # noqa: E712
-            self.check_value(rate, 'sampling probability', edge=1)
-            for hn in haplotypes:
-                deathRate = self.dRate[hn] + self.sRate[hn]
-                self.dRate[hn] = (1 - rate) * deathRate
-                self.sRate[hn] = rate * deathRate
-        elif self._sampling_probability == False:  # noqa: E712
-            self.check_value(rate, 'sampling rate')
-            for hn in haplotypes:
-                self.sRate[hn] = rate
-
-    @property
-    def mutation_rate(self):
-        return self.mRate
-
-    def set_mutation_rate(self, rate, haplotype, mutation):
-        self.check_value(rate, 'mutation rate')
-        self.check_indexes(haplotype, self.hapNum, 'haplotype', True)
-        self.check_indexes(mutation, self.sites, 'mutation site')
-        haplotypes = self.calculate_indexes(haplotype, self.hapNum)
-        sites = self.calculate_indexes(mutation, self.sites)
-        for hn in haplotypes:
-            for s in sites:
-                self.mRate[hn, s] = rate
-
-    @property
-    def mutation_probabilities(self):
-        return self.hapMutType
-
-    def set_mutation_probabilities(self, probabilities, haplotype, mutation):
-        self.check_list(probabilities, 'probabilities list', 4)
-        for i in range(4):
-            self.check_value(probabilities[i], 'mutation probabilities')
-        self.check_indexes(haplotype, self.hapNum, 'haplotype', True)
-        self.check_indexes(mutation, self.sites, 'mutation site')
-        haplotypes = self.calculate_indexes(haplotype, self.hapNum)
-        sites = self.calculate_indexes(mutation, self.sites)
-        for hn in haplotypes:
-            for s in sites:
-                probabilities_allele = list(probabilities)
-                del probabilities_allele[self.calculate_allele(hn, s)]
-                if sum(probabilities_allele) == 0:
-                    raise ValueError('Incorrect probabilities list. The sum of three elements without mutation allele should be more 0.')
-                self.hapMutType[hn, s, 0] = probabilities_allele[0]
-                self.hapMutType[hn, s, 1] = probabilities_allele[1]
-                self.hapMutType[hn, s, 2] = probabilities_allele[2]
-
-    @property
-    def mutation_position(self):
-        return self.sitesPosition
-
-    def set_mutation_position(self, mutation, position):
-        self.check_index(mutation, self.sites, 'number of site', none=False)
-        self.check_index(position, self._genome_length, 'mutation position', none=False)
-        for s in range(self.sites):
-            if self.sitesPosition[s] == position and s != mutation:
-                raise IndexError('Incorrect value of position. Two mutations can\'t have the same position.')
-        self.sitesPosition[mutation] = position
-
-    @property
-    def susceptibility_type(self):
-        return self.suscType
-
-    def set_susceptibility_type(self, susceptibility_type, haplotype):
-        if isinstance(susceptibility_type, int) == False:  # noqa: E712
-            raise TypeError('Incorrect type of susceptibility type. Type should be int.')
-        elif susceptibility_type < 0 or susceptibility_type >= self.susNum:
-            raise IndexError('There are no such susceptibility type!')
-        self.check_indexes(haplotype, self.hapNum, 'haplotype', True)
-        for hn in self.calculate_indexes(haplotype, self.hapNum):
-            self.suscType[hn] = susceptibility_type
-
-    def set_susceptibility(self, rate, haplotype, susceptibility_type):
-        self.check_value(rate, 'susceptibility rate')
-        self.check_indexes(haplotype, self.hapNum, 'haplotype', True)
-        self.check_indexes(susceptibility_type, self.susNum, 'susceptibility type')
-        haplotypes = self.calculate_indexes(haplotype, self.hapNum)
-        sus_types = self.calculate_indexes(susceptibility_type, self.susNum)
-        for hn in haplotypes:
-            for sn in sus_types:
-                self.susceptibility[hn, sn] = rate
-
-    @property
-    def immunity_transition(self):
-        return self.suscepTransition
-
-    def set_immunity_transition(self, rate, source, target):
-        self.check_value(rate, 'immunity transition rate')
-        self.check_indexes(source, self.susNum, 'susceptibility type')
-        self.check_indexes(target, self.susNum, 'susceptibility type')
-        for sn1 in self.calculate_indexes(source, self.susNum):
-            for sn2 in self.calculate_indexes(target, self.susNum):
-                if sn1 != sn2:
-                    self.suscepTransition[sn1, sn2] = rate
-
-    @property
-    def population_size(self):
-        return self.sizes
-
-    def set_population_size(self, amount, population):
-        if self.first_simulation == True:  # noqa: E712
-            raise ValueError('Changing population size is available only before first simulation!')
-        self.check_amount(amount, 'population size')
-        self.check_index(population, self.popNum, 'population')
-        for pn in self.calculate_index(population, self.popNum):
-            self.sizes[pn] = amount
-            self.susceptible[pn, 0] = amount
-            for sn in range(1, self.susNum):
-                self.susceptible[pn, sn] = 0
-
-    def set_susceptible(self, amount, source_type, target_type, population):
-        """Working version of pyx:1593-1608.  The reference's own method always raises TypeError
-        (it calls ``check_amount(amount)`` without the required argument, pyx:1596); this engine
-        supplies the argument, everything else is as written there."""
-        if self.first_simulation:
-            raise ValueError('This function is available only before first simulation!')
-        self.check_amount(amount, 'amount')
-        self.check_index(source_type, self.susNum, 'susceptibility type')
-        self.check_index(target_type, self.susNum, 'susceptibility type')
-        if source_type == target_type:
-            raise ValueError('Source and target susceptibility type shouldn\'t be equal!')
-        self.check_indexes(population, self.popNum, 'population')
-        for pn in self.calculate_indexes(population, self.popNum):
-            self.check_amount_sus(amount, source_type, target_type, pn)
-            self.susceptible[pn, source_type] -= amount
-            self.susceptible[pn, target_type] += amount
-
-    def set_infectious(self, amount, source_type, target_haplotype, population):
-        """Working version of pyx:1614-1627 (same upstream defect as ``set_susceptible``, pyx:1617)."""
-        if self.first_simulation:
-            raise ValueError('This function is available only before first simulation!')
-        self.check_amount(amount, 'amount')
-        self.check_index(source_type, self.susNum, 'susceptibility type')
-        self.check_index(target_haplotype, self.hapNum, 'haplotype')
-        self.check_indexes(population, self.popNum, 'population')
-        for pn in self.calculate_indexes(population, self.popNum):
-            self.check_amount_inf(amount, source_type, target_haplotype, pn)
-            self.susceptible[pn, source_type] -= amount
-            self.infectious[pn, target_haplotype] += amount
-
-    @property
-    def contact_density(self):
-        return self.contactDensity
-
-    def set_contact_density(self, value, population):
-        self.check_value(value, 'contact density')
-        self.check_indexes(population, self.popNum, 'population')
-        for pn in self.calculate_indexes(population, self.popNum):
-            self.contactDensity[pn] = value
-            self.contactDensityBeforeLockdown[pn] = value
-
-    @property
-    def npi(self):
-        return [self.contactDensityAfterLockdown, self.startLD, self.endLD]
-
-    def set_npi(self, parameters, population):
-        self.check_list(parameters, 'npi parameters', 3)
-        self.check_value(parameters[0], 'first npi parameter')
-        self.check_value(parameters[1], 'second npi parameter', edge=1)
-        self.check_value(parameters[2], 'third npi parameter', edge=1)
-        self.check_indexes(population, self.popNum, 'population')
-        for pn in self.calculate_indexes(population, self.popNum):
-            self.contactDensityAfterLockdown[pn] = parameters[0]
-            self.startLD[pn] = parameters[1]
-            self.endLD[pn] = parameters[2]
-
-    @property
-    def sampling_multiplier(self):
-        return self.samplingMultiplier
-
-    def set_sampling_multiplier(self, multiplier, population):
-        self.check_value(multiplier, 'sampling multiplier')
-        self.check_indexes(population, self.popNum, 'population')
-        for pn in self.calculate_indexes(population, self.popNum):
-            self.samplingMultiplier[pn] = multiplier
-
-    @property
-    def migration_probability(self):
-        return self.migrationRates
-
-    def set_migration_probability(self, probability, source, target):
-        self.check_value(probability, 'migration probability', edge=1)
-        self.check_indexes(source, self.popNum, 'population')
-        self.check_indexes(target, self.popNum, 'population')
-        for pn1 in self.calculate_indexes(source, self.popNum):
-            for pn2 in self.calculate_indexes(target, self.popNum):
-                if pn1 != pn2:
-                    self.migrationRates[pn1, pn2] = probability
-        self.check_mig_rate()
-
-    def set_total_migration_probability(self, total_probability):
-        self.check_value(total_probability, 'total migration probability', edge=1)
-        source_rate = 1.0 - total_probability
-        target_rate = total_probability / (self.popNum - 1)
-        self.migrationRates[:, :] = target_rate
-        np.fill_diagonal(self.migrationRates, source_rate)
-        self.check_mig_rate()
-
     # ------------------------------------------------------------------ hot-path entry points
     def _check_supported(self):
         if self.recombination != 0 and self.sites < 2:
@@ -703,36 +276,28 @@ class BirthDeathModel(Reporting):
             self.actualSizes[pn1] = a
 
     def CheckSizes(self):
-        """stdout contract of pyx:456-471."""
+        """stdout contract of pyx:456-471: the effective population sizes and a warning where one is off by 10 % or more."""
         self._compute_actual_sizes()
-        check = False
-        list_pop = []
-        print('Actual sizes: ', end='')
-        for pn in range(self.popNum):
-            print(self.actualSizes[pn], end=' ')
-            if abs(self.actualSizes[pn] / self.sizes[pn] - 1) >= 0.1:
-                check = True
-                list_pop.append(str(pn))
-        print()
-        if check:
-            print('\033[41m{}\033[0m'.format('WARNING!'), 'Actual population size in deme: ', end='')
-            print(", ".join(list_pop))
-            print("\tis more than 10% different from the population size. The migration probabilities might be unrealistically high.")
-            print("\tWe recommend to check your model with print_populations() method before proceding to simulation.")
-            print("\tCheck the documentation file:https://vg-sim.readthedocs.io/en/latest/Migration.html for more details.")
+        print('Actual sizes: ' + ''.join('%s ' % v for v in self.actualSizes.tolist()))
+        off = np.nonzero(np.abs(self.actualSizes / self.sizes - 1) >= 0.1)[0]
+        if len(off):
+            print(_RED_WARNING, 'Actual population size in deme: ' + ", ".join(str(pn) for pn in off))
+            for line in _SIZE_ADVICE:
+                print("\t" + line)
 
     def _print_termination(self, sample_size, time):
-        """pyx:420-429 / pyx:2337-2346."""
-        if self.totalRate == 0.0 or self.globalInfectious == 0:
-            print('Simulation finished because no infections individuals remain!')
-        if self.events.ptr >= self.events.size:
-            print("Achieved maximal number of iterations.")
-        if self.sCounter > sample_size and sample_size != -1:
-            print("Achieved sample size.")
-        if self.currentTime > time and time != -1:
-            print("Achieved internal time limit.")
+        """Why the loop stopped, in the wording and order of pyx:420-429 / pyx:2337-2346."""
+        reasons = (
+            (self.totalRate == 0.0 or self.globalInfectious == 0, 'Simulation finished because no infections individuals remain!'),
+            (self.events.ptr >= self.events.size, "Achieved maximal number of iterations."),
+            (sample_size != -1 and self.sCounter > sample_size, "Achieved sample size."),
+            (time != -1 and self.currentTime > time, "Achieved internal time limit."),
+        )
+        for happened, text in reasons:
+            if happened:
+                print(text)
         if self.sCounter <= 1:
-            print('\033[41m{}\033[0m'.format('WARNING!'), 'Simulated less 2 samples, so genealogy will not work!')
+            print(_RED_WARNING, 'Simulated less 2 samples, so genealogy will not work!')
 
     def _get_engine(self):
         if self._engine is None:
@@ -782,30 +347,28 @@ class BirthDeathModel(Reporting):
 
     # ------------------------------------------------------------------ reporting (pyx:2048-2068, 2284, 2607-2613, 1849-1851)
     def Stats(self, time_simulation):
-        print("Number of samples:", self.sCounter)
-        print("Total number of iterations:", self.events.ptr)
-        print('Success number:', self.good_attempt)
-        print("Epidemic time:", self.currentTime)
-        print('Simulation time:', time_simulation)
-        print('Number of infections:', self.bCounter)
-        print('Number of recoveries:', self.dCounter)
+        """The counter block ``Simulator.simulate`` prints after every call (pyx:2048-2068)."""
+        rows = [("Number of samples:", self.sCounter), ("Total number of iterations:", self.events.ptr),
+                ('Success number:', self.good_attempt), ("Epidemic time:", self.currentTime),
+                ('Simulation time:', time_simulation), ('Number of infections:', self.bCounter),
+                ('Number of recoveries:', self.dCounter)]
         if self.sites >= 1:
-            print('Number of mutations:', self.mCounter)
+            rows.append(('Number of mutations:', self.mCounter))
         if self.popNum >= 2:
-            print('Number of accepted migrations:', self.migPlus)
-            print('Number of rejected migrations:', self.migNonPlus)
+            rows += [('Number of accepted migrations:', self.migPlus), ('Number of rejected migrations:', self.migNonPlus)]
         if np.any(self.suscepTransition.sum(axis=1) != 0.0):
-            print('Number of immunity transitions:', self.iCounter)
-        print('----------------------------------')
+            rows.append(('Number of immunity transitions:', self.iCounter))
+        for label, value in rows:
+            print(label, value)
+        print('-' * 34)
 
     def get_proportion(self):
+        """Share of loop iterations spent on rejected migrations (pyx:2284-2285)."""
         return self.migNonPlus / (self.events.ptr - 1)
 
     def PrintCounters(self):
-        print("Birth counter(mutable): ", self.bCounter)
-        print("Death counter(mutable): ", self.dCounter)
-        print("Sampling counter(mutable): ", self.sCounter)
-        print("Mutation counter(mutable): ", self.mCounter)
+        for label, name in (("Birth", "bCounter"), ("Death", "dCounter"), ("Sampling", "sCounter"), ("Mutation", "mCounter")):
+            print(label + " counter(mutable): ", getattr(self, name))
         print("Immunity transition counter(mutable):", self.iCounter)
         print("Migration counter(mutable):", self.migPlus)
 
@@ -912,13 +475,9 @@ class BirthDeathModel(Reporting):
                             str(self.mig.newPop[i]) + "\n")
 
     def output_sample_data(self):  # pyx:1756-1763
-        time, pop, hap = [], [], []
-        for i in range(self.events.ptr):
-            if self.events.types[i] == SAMPLING:
-                time.append(self.events.times[i])
-                pop.append(self.events.populations[i])
-                hap.append(self.events.haplotypes[i])
-        return time, pop, hap
+        ev = self.events
+        rows = np.nonzero(ev.types[:ev.ptr] == SAMPLING)[0]
+        return list(ev.times[rows]), list(ev.populations[rows]), list(ev.haplotypes[rows])
 
     # ------------------------------------------------------------------ log replays (pyx:1967-2045)
     def _replay(self, step_num, delta_of, sample_of=None, start=0.0):

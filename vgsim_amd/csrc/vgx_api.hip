@@ -15,6 +15,7 @@
 #include <vector>
 #include "../../include/vgx.h"
 #include "vgx_dev.h"
+#include "vgx_rng.h"
 
 // launchers defined next to their kernels (vgx_direct.hip)
 extern "C" hipError_t vgxi_launch_direct(const VgxDirectArgs *a, size_t lds, hipStream_t stream);
@@ -72,7 +73,7 @@ struct vgx_engine {
     int64_t genome_length = 1000000, rec_cap = 0;
     DevBuf r_rec;
     DevBuf r_popD, r_popI, r_sus, r_immSrc, r_birthC, r_xC, r_effMig, r_nocc, r_lhap, r_lcls, r_lcnt, r_ltsum, r_lanews, r_sc, r_seeds,
-        r_evtime, r_evcols, r_locrec, r_loctime, r_traj, r_prof;
+        r_evrate, r_evcols, r_locrec, r_loctime, r_lociter, r_farate, r_fakey, r_traj, r_prof;
     // tau-leaping (dense compartments)
     DevBuf t_I, t_S, t_dChk, t_dApp, t_dSi, t_dTot, t_totInf, t_gI, t_cd, t_lock, t_F, t_eff, t_Aeff, t_Gout, t_dS,
         t_taubits, t_tau, t_time, t_flags, t_counters, t_cnttry, t_mev, t_mevn, t_mevbase, t_locn, t_mutcum, t_migcdf, t_migIn, t_mutHi, t_colT, t_colTW, t_inc, t_incn, t_sieve, t_sieveskip, t_big, t_bign, t_res;
@@ -94,6 +95,18 @@ struct vgx_engine {
     VgxDevParams dp{};
     VgxDevRep dr{};
     int64_t cap = 0, evcap = 0, ev_base = 0, ev_ptr0 = 0, traj_points = 0;
+    // host clock of the last direct call (host_clock below)
+    int64_t loc_cap = 1, fa_cap = 0;
+    bool call_recorded = false, call_has_tlimit = false;
+    double call_tlimit = 0.0;
+    std::vector<double> call_t0;          // [R] currentTime at the start of the call
+    struct HostClock {
+        int64_t rep = -1, e0 = 0;         // replicate; first event index of the reconstructed range
+        bool exact = false;               // false: no rate log (record_events = 0), device clock reported
+        std::vector<double> times;        // [ev_ptr - e0] event times
+        double final_time = 0.0;          // currentTime after the call
+        std::vector<double> loc_times;    // lockdown records
+    } hc;
     bool last_used_lanes = false;
     int64_t last_ev_size = 0;
     std::vector<VgxRepScalars> sc_host;
@@ -552,8 +565,6 @@ static int init_device_state(vgx_engine *e, int64_t traj_points) {
     const int64_t capT = cap / 64 + 1;
     rc |= ensure(e, e->r_ltsum, (size_t)(R * P * capT) * 8);
     rc |= ensure(e, e->r_sc, (size_t)R * sizeof(VgxRepScalars));
-    rc |= ensure(e, e->r_locrec, (size_t)(R * VGX_LOC_CAP * 2) * 4);
-    rc |= ensure(e, e->r_loctime, (size_t)(R * VGX_LOC_CAP) * 8);
     rc |= ensure(e, e->r_prof, (size_t)(R * VGX_PROF_SLOTS) * 8);
     if (rc) return rc;
     HIPCHECK(e, hipMemsetAsync(e->r_effMig.p, 0, (size_t)(R * P * P) * 8, e->stream));
@@ -604,7 +615,6 @@ static int init_device_state(vgx_engine *e, int64_t traj_points) {
     d.i_cls = (const int32_t *)e->i_cls.p; d.i_cnt = (const int64_t *)e->i_cnt.p; d.i_cap = i_cap;
     d.i_sus = (const int64_t *)e->i_sus.p;
     d.sc = (VgxRepScalars *)e->r_sc.p; d.seeds = (const int64_t *)e->r_seeds.p;
-    d.loc_rec = (int32_t *)e->r_locrec.p; d.loc_time = (double *)e->r_loctime.p;
     d.prof = (unsigned long long *)e->r_prof.p;
     HIPCHECK(e, hipMemsetAsync(e->r_prof.p, 0, (size_t)(R * VGX_PROF_SLOTS) * 8, e->stream));
 
@@ -645,6 +655,7 @@ static int direct_core(vgx_engine *e, int64_t iterations, int64_t sample_size, f
                                         " bytes of LDS per wavefront (limit 163840): too many populations x rate classes");
 
     HostState &h = e->hs;
+    const bool fresh_state = !e->dev_state_valid;
     if (!e->dev_state_valid) {
         prepare_first(e);
         int rc = init_device_state(e, o.traj_points);
@@ -658,9 +669,21 @@ static int direct_core(vgx_engine *e, int64_t iterations, int64_t sample_size, f
     e->ev_base = may_restart ? 0 : ev_ptr0;
     e->ev_ptr0 = ev_ptr0;
     int64_t evcap = o.record_events ? std::max<int64_t>(ev_size - e->ev_base, 1) : 1;
+    // lockdown log: a population can switch on only if its threshold lies below its size, off only if it is on
+    bool ld_possible = false;
+    for (int64_t pn = 0; pn < P; pn++)
+        if (e->h_startLD[(size_t)pn] * (double)e->sizes[(size_t)pn] < (double)e->sizes[(size_t)pn] || h.lockdownON[(size_t)pn] != 0)
+            ld_possible = true;
+    e->loc_cap = ld_possible ? VGX_LOC_CAP : 1;
+    e->fa_cap = (ld_possible && may_restart && o.record_events) ? VGX_FA_CAP : 0;
     int rc = 0;
-    rc |= ensure(e, e->r_evtime, (size_t)(R * evcap) * 8);
-    rc |= ensure(e, e->r_evcols, (size_t)(R * evcap * 5) * 4);
+    rc |= ensure(e, e->r_locrec, (size_t)(R * e->loc_cap * 2) * 4);
+    rc |= ensure(e, e->r_loctime, (size_t)(R * e->loc_cap) * 8);
+    rc |= ensure(e, e->r_lociter, (size_t)(R * e->loc_cap) * 8);
+    rc |= ensure(e, e->r_farate, (size_t)(R * e->fa_cap) * 8);
+    rc |= ensure(e, e->r_fakey, (size_t)(R * e->fa_cap) * 8);
+    rc |= ensure(e, e->r_evrate, (size_t)(R * evcap) * 8);
+    rc |= ensure(e, e->r_evcols, (size_t)(R * evcap * VGX_EV_COLS) * 4);
     if (o.traj_points > 0) rc |= ensure(e, e->r_traj, (size_t)(R * o.traj_points * P * 2) * 8);
     if (rc) return rc;
     e->evcap = evcap;
@@ -670,8 +693,20 @@ static int direct_core(vgx_engine *e, int64_t iterations, int64_t sample_size, f
     VgxDirectArgs a{};
     a.p = e->dp;
     a.r = e->dr;
-    a.r.ev_time = (double *)e->r_evtime.p;
+    a.r.ev_rate = (double *)e->r_evrate.p;
     a.r.ev_cols = (int32_t *)e->r_evcols.p;
+    a.r.loc_rec = (int32_t *)e->r_locrec.p; a.r.loc_time = (double *)e->r_loctime.p; a.r.loc_iter = (int64_t *)e->r_lociter.p;
+    a.r.loc_cap = e->loc_cap;
+    a.r.fa_rate = (double *)e->r_farate.p; a.r.fa_key = (int64_t *)e->r_fakey.p; a.r.fa_cap = e->fa_cap;
+    // the host clock starts where the caller's state stands (one value for all replicates after vgx_set_state; the
+    // replicates' own device clocks when a call continues without a new state)
+    e->call_t0.assign((size_t)R, h.currentTime);
+    if (!fresh_state && e->sc_host_valid && e->sc_host.size() == (size_t)R)
+        for (int64_t r = 0; r < R; r++) e->call_t0[(size_t)r] = e->sc_host[(size_t)r].currentTime;
+    e->call_recorded = o.record_events != 0;
+    e->call_has_tlimit = !(time == -1.0f);
+    e->call_tlimit = (double)time;
+    e->hc.rep = -1;
     a.r.evcap = evcap;
     a.r.ev_base = e->ev_base;
     a.r.traj = o.traj_points > 0 ? (double *)e->r_traj.p : nullptr;
@@ -815,7 +850,7 @@ extern "C" int vgx_simulate_tau(vgx_engine *e, int64_t iterations, int64_t sampl
         h.totalRate = prep.totalRate;
         h.totalMigrationRate = prep.totalMig;
         rates_nonzero = prep.totalRate + prep.totalMig != 0.0;
-        int64_t n = std::min<int64_t>(prep.loc_n, VGX_LOC_CAP);
+        int64_t n = std::min<int64_t>(prep.loc_n, e->loc_cap);
         std::vector<int32_t> rec((size_t)n * 2);
         std::vector<double> tt((size_t)n);
         if (n > 0) {
@@ -1194,6 +1229,129 @@ extern "C" int vgx_simulate_tau(vgx_engine *e, int64_t iterations, int64_t sampl
     return VGX_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// The host clock.  The reference advances currentTime with the C library's log() (SampleTime, pyx:476-478:
+// currentTime += -log(u) / (totalRate + totalMigrationRate)), which is neither correctly rounded nor the same on every
+// CPU; the device cannot reproduce it, and time never feeds back into the dynamics.  So the kernels log, per recorded
+// event, the denominator of its time step and the index of its loop iteration, and the times are accumulated HERE, with
+// this host's libm, from the same PCG64 stream (uniform 2j of the attempt's stream is iteration j's time draw,
+// pyx:477,488): event times, the final currentTime and the lockdown timestamps come out as the reference computes them,
+// bit for bit on a host whose libm matches.  Rejected migrations (pyx:691-692) leave the state and therefore the
+// denominator unchanged, so every iteration between two records uses the later record's denominator.
+struct ClockRun {      // accumulates one attempt's clock
+    VgxPcg64 g;
+    int64_t iter = 0;
+    double t = 0.0;
+    void open(int64_t seed, int64_t attempt, double t0) { vgx_pcg64_seed(g, (uint64_t)seed, (uint32_t)attempt); iter = 0; t = t0; }
+    void advance(int64_t to_iter, double rate) {
+        while (iter < to_iter) {
+            double u = vgx_pcg64_double(g);
+            (void)vgx_pcg64_next(g);                 // the event's own uniform (pyx:488)
+            t += -std::log(u) / rate;
+            iter++;
+        }
+    }
+};
+
+static int host_clock(vgx_engine *e, int64_t rep) {
+    vgx_engine::HostClock &hc = e->hc;
+    if (hc.rep == rep) return VGX_OK;
+    const VgxRepScalars &s = e->sc_host[(size_t)rep];
+    hc.rep = -1;
+    hc.times.clear();
+    hc.loc_times.clear();
+    const bool rewound = s.restarts > 0;
+    hc.e0 = rewound ? 0 : e->ev_ptr0;
+    const int64_t n = std::max<int64_t>(s.ev_ptr - hc.e0, 0);
+    const int64_t nloc = std::min<int64_t>(s.loc_n, e->loc_cap);
+    std::vector<double> loc_dev((size_t)nloc);
+    std::vector<int64_t> loc_key((size_t)nloc);
+    if (nloc > 0) {
+        HIPCHECK(e, hipMemcpy(loc_dev.data(), (double *)e->r_loctime.p + rep * e->loc_cap, (size_t)nloc * 8, hipMemcpyDeviceToHost));
+        HIPCHECK(e, hipMemcpy(loc_key.data(), (int64_t *)e->r_lociter.p + rep * e->loc_cap, (size_t)nloc * 8, hipMemcpyDeviceToHost));
+    }
+    hc.loc_times = loc_dev;
+    hc.final_time = s.currentTime;
+    hc.exact = e->call_recorded;
+    if (!e->call_recorded) {       // no rate log: the device clock (vgx_log) is all there is
+        hc.rep = rep;
+        return VGX_OK;
+    }
+    const double t_call = e->call_t0[(size_t)rep];
+    const int64_t seed = e->seeds[(size_t)rep];
+    const int64_t IT = ((int64_t)1 << 40) - 1;
+    // lockdown records written outside the event loop (PrepareParameters / Restart): the attempt's start time
+    for (int64_t i = 0; i < nloc; i++)
+        if ((loc_key[(size_t)i] & IT) == 0) hc.loc_times[(size_t)i] = (loc_key[(size_t)i] >> 40) == 0 ? t_call : 0.0;
+    // failed attempts that switched a lockdown inside their loop: their own (rate, iteration) pairs
+    const int64_t nfa = std::min<int64_t>(s.fa_n, e->fa_cap);
+    if (nfa > 0) {
+        std::vector<double> fr((size_t)nfa);
+        std::vector<int64_t> fk((size_t)nfa);
+        HIPCHECK(e, hipMemcpy(fr.data(), (double *)e->r_farate.p + rep * e->fa_cap, (size_t)nfa * 8, hipMemcpyDeviceToHost));
+        HIPCHECK(e, hipMemcpy(fk.data(), (int64_t *)e->r_fakey.p + rep * e->fa_cap, (size_t)nfa * 8, hipMemcpyDeviceToHost));
+        int64_t k = 0;
+        while (k < nfa) {
+            const int64_t att = fk[(size_t)k] >> 40;
+            ClockRun c;
+            c.open(seed, att, att == 0 ? t_call : 0.0);
+            for (; k < nfa && (fk[(size_t)k] >> 40) == att; k++) {
+                c.advance(fk[(size_t)k] & IT, fr[(size_t)k]);
+                for (int64_t i = 0; i < nloc; i++)
+                    if (loc_key[(size_t)i] == fk[(size_t)k]) hc.loc_times[(size_t)i] = c.t;
+            }
+        }
+    }
+    // the attempt whose events are in the log
+    if (s.last_attempt < 0) {                 // no attempt drew a number
+        hc.final_time = t_call;
+    } else if (s.restarts > s.last_attempt) { // the last attempt failed too: Restart left currentTime = 0 (pyx:717)
+        hc.final_time = 0.0;
+    } else {
+        const int64_t slot0 = hc.e0 - e->ev_base;
+        if (slot0 < 0 || slot0 + n > e->evcap) return fail(e, VGX_ERR_ARG, "host_clock: event range outside the device log");
+        std::vector<double> rate((size_t)n);
+        std::vector<int32_t> cols((size_t)n * VGX_EV_COLS);
+        if (n > 0) {
+            HIPCHECK(e, hipMemcpy(rate.data(), (double *)e->r_evrate.p + rep * e->evcap + slot0, (size_t)n * 8, hipMemcpyDeviceToHost));
+            HIPCHECK(e, hipMemcpy(cols.data(), (int32_t *)e->r_evcols.p + (rep * e->evcap + slot0) * VGX_EV_COLS,
+                                  (size_t)n * VGX_EV_COLS * 4, hipMemcpyDeviceToHost));
+        }
+        ClockRun c;
+        c.open(seed, s.last_attempt, rewound ? 0.0 : t_call);
+        hc.times.resize((size_t)n);
+        int64_t li = 0;
+        while (li < nloc && ((loc_key[(size_t)li] >> 40) != s.last_attempt || (loc_key[(size_t)li] & IT) == 0)) li++;
+        bool limit_ok = true;
+        int64_t it = 0;
+        for (int64_t k = 0; k < n; k++) {
+            // iteration index: 32 bits logged, strictly increasing
+            const uint32_t lo = (uint32_t)cols[(size_t)(k * VGX_EV_COLS + 5)];
+            it += (int64_t)(uint32_t)(lo - (uint32_t)it);
+            if (e->call_has_tlimit && it > c.iter + 1) {   // loop condition of the iterations without a record (pyx:407)
+                ClockRun probe = c;
+                probe.advance(it - 1, rate[(size_t)k]);
+                if (!(probe.t < e->call_tlimit)) limit_ok = false;
+            }
+            c.advance(it, rate[(size_t)k]);
+            hc.times[(size_t)k] = c.t;
+            if (e->call_has_tlimit && k + 1 < n && !(c.t < e->call_tlimit)) limit_ok = false;
+            while (li < nloc && (loc_key[(size_t)li] >> 40) == s.last_attempt && (loc_key[(size_t)li] & IT) == it) {
+                hc.loc_times[(size_t)li] = c.t;
+                li++;
+            }
+        }
+        c.advance(s.last_attempt_loops, s.totalRate + s.totalMig);   // trailing iterations without a record
+        hc.final_time = c.t;
+        // the kernel took its `currentTime < time` decisions (pyx:407) on the device clock: both clocks must agree on them
+        if (e->call_has_tlimit && (!limit_ok || ((s.currentTime < e->call_tlimit) != (hc.final_time < e->call_tlimit))))
+            return fail(e, VGX_ERR_LOOP_GUARD, "host_clock: the time-limit stop differs between the device clock and the host "
+                                               "libm clock (an event time within rounding of the limit)");
+    }
+    hc.rep = rep;
+    return VGX_OK;
+}
+
 extern "C" int vgx_get_counters(vgx_engine *e, int64_t replicate, vgx_counters *out) {
     if (!e || !out || replicate < 0 || replicate >= e->R) return VGX_ERR_ARG;
     if (!e->sc_host_valid) return fail(e, VGX_ERR_ARG, "vgx_get_counters: no simulate call yet");
@@ -1249,13 +1407,22 @@ extern "C" int vgx_get_events(vgx_engine *e, int64_t replicate, int64_t first, i
     }
     int64_t slot0 = first - e->ev_base;
     if (slot0 < 0 || slot0 + count > e->evcap) return fail(e, VGX_ERR_ARG, "vgx_get_events: range outside the device log of the last call");
-    std::vector<int32_t> cols((size_t)count * 5);
-    HIPCHECK(e, hipMemcpy(cols.data(), (int32_t *)e->r_evcols.p + (replicate * e->evcap + slot0) * 5, (size_t)count * 20, hipMemcpyDeviceToHost));
-    if (times) HIPCHECK(e, hipMemcpy(times, (double *)e->r_evtime.p + replicate * e->evcap + slot0, (size_t)count * 8, hipMemcpyDeviceToHost));
+    if (!e->call_recorded) return fail(e, VGX_ERR_ARG, "vgx_get_events: the last call did not record events");
+    std::vector<int32_t> cols((size_t)count * VGX_EV_COLS);
+    HIPCHECK(e, hipMemcpy(cols.data(), (int32_t *)e->r_evcols.p + (replicate * e->evcap + slot0) * VGX_EV_COLS,
+                          (size_t)count * VGX_EV_COLS * 4, hipMemcpyDeviceToHost));
+    if (times) {   // accumulated on the host with libm, as the reference does (host_clock)
+        int rc = host_clock(e, replicate);
+        if (rc) return rc;
+        const int64_t i0 = first - e->hc.e0;
+        if (i0 < 0 || i0 + count > (int64_t)e->hc.times.size())
+            return fail(e, VGX_ERR_ARG, "vgx_get_events: times exist for the events of the last call only");
+        memcpy(times, e->hc.times.data() + i0, (size_t)count * 8);
+    }
     int64_t *dst[5] = {types, haplotypes, populations, newHaplotypes, newPopulations};
     for (int c = 0; c < 5; c++)
         if (dst[c])
-            for (int64_t i = 0; i < count; i++) dst[c][i] = cols[(size_t)(i * 5 + c)];
+            for (int64_t i = 0; i < count; i++) dst[c][i] = cols[(size_t)(i * VGX_EV_COLS + c)];
     return VGX_OK;
 }
 
@@ -1274,14 +1441,15 @@ extern "C" int vgx_get_lockdowns(vgx_engine *e, int64_t replicate, int64_t cap, 
         }
         return VGX_OK;
     }
-    int64_t cnt = std::min<int64_t>(e->sc_host[(size_t)replicate].loc_n, VGX_LOC_CAP);
+    int64_t cnt = std::min<int64_t>(e->sc_host[(size_t)replicate].loc_n, e->loc_cap);
     *n = cnt;
     cnt = std::min(cnt, cap);
     if (cnt <= 0) return VGX_OK;
     std::vector<int32_t> rec((size_t)cnt * 2);
-    std::vector<double> tt((size_t)cnt);
-    HIPCHECK(e, hipMemcpy(rec.data(), (int32_t *)e->r_locrec.p + replicate * VGX_LOC_CAP * 2, (size_t)cnt * 8, hipMemcpyDeviceToHost));
-    HIPCHECK(e, hipMemcpy(tt.data(), (double *)e->r_loctime.p + replicate * VGX_LOC_CAP, (size_t)cnt * 8, hipMemcpyDeviceToHost));
+    HIPCHECK(e, hipMemcpy(rec.data(), (int32_t *)e->r_locrec.p + replicate * e->loc_cap * 2, (size_t)cnt * 8, hipMemcpyDeviceToHost));
+    int rch = host_clock(e, replicate);
+    if (rch) return rch;
+    const std::vector<double> &tt = e->hc.loc_times;
     for (int64_t i = 0; i < cnt; i++) {
         if (states) states[i] = rec[(size_t)(i * 2)];
         if (populations) populations[i] = rec[(size_t)(i * 2 + 1)];
@@ -1412,7 +1580,11 @@ extern "C" int vgx_get_state(vgx_engine *e, int64_t replicate, vgx_state *out) {
     out->bCounter = s.bCounter; out->dCounter = s.dCounter; out->sCounter = s.sCounter; out->mCounter = s.mCounter;
     out->iCounter = s.iCounter; out->swapLockdown = s.swapLockdown; out->migPlus = s.migPlus;
     out->migNonPlus = s.migNonPlus; out->good_attempt = s.good_attempt;
-    out->currentTime = s.currentTime; out->totalRate = s.totalRate; out->totalMigrationRate = s.totalMig;
+    {
+        int rch = host_clock(e, replicate);
+        if (rch) return rch;
+    }
+    out->currentTime = e->hc.final_time; out->totalRate = s.totalRate; out->totalMigrationRate = s.totalMig;
     out->tau_l = s.tau_l;
     out->ev_ptr = s.ev_ptr; out->ev_size = e->last_ev_size;
     return VGX_OK;

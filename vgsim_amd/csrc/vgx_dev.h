@@ -18,6 +18,8 @@
 #define VGX_LOC_CAP 4096       // lockdown switches recorded per replicate and call
 #define VGX_INC_SHARDS 4096     // shards of the tau kernels' cross-compartment event list
 #define VGX_SIEVE_K 16          // halvings the tau sieve looks ahead
+#define VGX_EV_COLS 6           // int32 columns of a device log record
+#define VGX_FA_CAP 2048         // (rate, iteration) pairs kept per replicate for failed attempts that switched a lockdown
 #define VGX_PROF_SLOTS 16       // in-kernel phase stamps of the diagnostic (-DVGX_PROFILE) build
 
 // fields of the per-replicate f64 population block
@@ -65,6 +67,7 @@ struct VgxRepScalars {
     int64_t last_attempt;        // index of the last attempt that drew random numbers (-1: none)
     int64_t last_attempt_loops;  // loop iterations of that attempt (2 uniforms each)
     int64_t rec_n;               // recombination records written so far (kept across Restarts like upstream's `rec`)
+    int64_t fa_n;                // (rate, iteration) pairs of failed attempts kept for the host clock (may exceed fa_cap)
 };
 
 struct VgxDevRep {
@@ -91,14 +94,25 @@ struct VgxDevRep {
     const int64_t *i_sus;    // [P][S]
     VgxRepScalars *sc;       // [R]
     const int64_t *seeds;    // [R]
-    // event log
-    double *ev_time;         // [R][evcap]
-    int32_t *ev_cols;        // [R][evcap][5]  type, haplotype, population, newHaplotype, newPopulation
+    // event log.  Event TIMES are not logged: the reference accumulates them with the host's libm (pyx:476-478), so the
+    // kernel logs what the host needs to do the same bit for bit (vgx_api.hip: host_clock) — the denominator
+    // totalRate + totalMigrationRate of the event's time step and the index of its loop iteration (rejected migrations
+    // consume an iteration, two uniforms and a time step without a record, pyx:691-692).
+    double *ev_rate;         // [R][evcap]
+    int32_t *ev_cols;        // [R][evcap][VGX_EV_COLS]  type, haplotype, population, newHaplotype, newPopulation,
+                             //                          loop iteration of the attempt (1-based, low 32 bits)
     int64_t evcap;
     int64_t ev_base;         // absolute index of log slot 0
     // lockdown log
-    int32_t *loc_rec;        // [R][VGX_LOC_CAP][2]  state, population
-    double *loc_time;        // [R][VGX_LOC_CAP]
+    int32_t *loc_rec;        // [R][loc_cap][2]  state, population
+    double *loc_time;        // [R][loc_cap]     device clock (used only where the host clock cannot be rebuilt)
+    int64_t *loc_iter;       // [R][loc_cap]     (attempt << 40) | loop iteration of the attempt (0: before its first one)
+    int64_t loc_cap;
+    // failed attempts (<= 100 events, pyx:414) that switched a lockdown: their (rate, iteration) pairs, so that the
+    // lockdown records they leave behind (Restart does not clear `loc`, pyx:714-738) get the host clock too
+    double *fa_rate;         // [R][fa_cap]
+    int64_t *fa_key;         // [R][fa_cap]      (attempt << 40) | loop iteration
+    int64_t fa_cap;
     // trajectories
     double *traj;            // [R][T][P][2] or null
     int64_t traj_points;

@@ -126,10 +126,14 @@ struct Ctx {
     int64_t cap;
     int64_t *ltsum;    // per 64-entry tile of each list: sum of its counts
     int64_t capT;
-    double *ev_time;
+    double *ev_rate;
     int32_t *ev_cols;
     int32_t *loc_rec;
     double *loc_time;
+    int64_t *loc_iter;
+    int64_t loc_cap;
+    double den;        // totalRate + totalMigrationRate of the current iteration's time step (pyx:477)
+    int64_t iter_key;  // (attempt << 40) | loop iteration of the attempt (0 outside the event loop)
     double *traj;
     int64_t traj_points, traj_next;
     double traj_t0, traj_dt;
@@ -794,11 +798,12 @@ static __device__ __forceinline__ void add_event(Ctx &c, const EvRec &e) {  // e
         int64_t slot = c.ev_ptr - c.ev_base;
         if (slot >= 0 && slot < c.evcap) {
             int lane = c.lane;
-            if (lane < 5) {
-                int v = lane == 0 ? e.type : lane == 1 ? e.hap : lane == 2 ? e.pop : lane == 3 ? e.nh : e.np;
-                c.ev_cols[slot * 5 + lane] = v;
-            } else if (lane == 5) {
-                c.ev_time[slot] = c.currentTime;
+            if (lane < VGX_EV_COLS) {
+                int v = lane == 0 ? e.type : lane == 1 ? e.hap : lane == 2 ? e.pop : lane == 3 ? e.nh : lane == 4 ? e.np
+                                                                                                             : (int)(uint32_t)c.iter_key;
+                c.ev_cols[slot * VGX_EV_COLS + lane] = v;
+            } else if (lane == VGX_EV_COLS) {
+                c.ev_rate[slot] = c.den;
             }
         } else {
             c.error = ERR_CAPACITY;
@@ -824,13 +829,14 @@ static __device__ __forceinline__ bool check_lockdowns(Ctx &c, int lo, int hi) {
                 if (c.lane == 0) {
                     c.cd[pi] = pass == 0 ? p.cdAfter[pi] : p.cdBefore[pi];
                     c.lockON[pi] = pass == 0 ? 1 : 0;
-                    if (c.loc_n < VGX_LOC_CAP) {
+                    if (c.loc_n < c.loc_cap) {
                         c.loc_rec[c.loc_n * 2 + 0] = pass == 0 ? 1 : 0;
                         c.loc_rec[c.loc_n * 2 + 1] = pi;
                         c.loc_time[c.loc_n] = c.currentTime;
+                        c.loc_iter[c.loc_n] = c.iter_key;
                     }
                 }
-                if (c.loc_n >= VGX_LOC_CAP) c.error = ERR_CAPACITY;
+                if (c.loc_n >= c.loc_cap) c.error = ERR_CAPACITY;
                 BUMP(CNT_SWAP);
                 c.loc_n += 1;
                 any = true;
@@ -1154,10 +1160,13 @@ static __device__ __forceinline__ void direct_body(const VgxDirectArgs &a) {
     c.capT = r.capT;
     c.ltsum = r.ltsum + (int64_t)rep * P * r.capT;
     c.evcap = r.evcap; c.ev_base = r.ev_base;
-    c.ev_time = r.ev_time + (int64_t)rep * r.evcap;
-    c.ev_cols = r.ev_cols + (int64_t)rep * r.evcap * 5;
-    c.loc_rec = r.loc_rec + (int64_t)rep * VGX_LOC_CAP * 2;
-    c.loc_time = r.loc_time + (int64_t)rep * VGX_LOC_CAP;
+    c.ev_rate = r.ev_rate + (int64_t)rep * r.evcap;
+    c.ev_cols = r.ev_cols + (int64_t)rep * r.evcap * VGX_EV_COLS;
+    c.loc_cap = r.loc_cap;
+    c.loc_rec = r.loc_rec + (int64_t)rep * r.loc_cap * 2;
+    c.loc_time = r.loc_time + (int64_t)rep * r.loc_cap;
+    c.loc_iter = r.loc_iter + (int64_t)rep * r.loc_cap;
+    c.den = 0.0; c.iter_key = 0;
     c.traj_points = r.traj_points; c.traj_t0 = r.traj_t0; c.traj_dt = r.traj_dt;
     c.traj = r.traj ? r.traj + (int64_t)rep * r.traj_points * P * 2 : nullptr;
     c.record_events = a.record_events;
@@ -1191,6 +1200,7 @@ static __device__ __forceinline__ void direct_body(const VgxDirectArgs &a) {
     int64_t loops = 0, restarts = 0, good_attempt = sc->good_attempt;
     int64_t last_att = -1, last_att_loops = 0;
     int64_t att = 0;
+    int64_t att_ev0 = sc->ev_ptr, att_loc0 = 0, fa_n = 0;   // first log index / lockdown record of the current attempt
     RngBatch g;
     rng_init_lane(g, lane);
     g.sh = g.sl = g.ih = g.il = 0;
@@ -1223,6 +1233,7 @@ static __device__ __forceinline__ void direct_body(const VgxDirectArgs &a) {
 
         if (rebuild) {
             lk_lo = 0; lk_hi = P;
+            c.iter_key = att << 40;   // CheckLockdown of PrepareParameters / Restart: before the attempt's first iteration
         } else {
             if (!attempt_open) {
                 if (att >= a.attempts) { finished = true; continue; }
@@ -1241,7 +1252,9 @@ static __device__ __forceinline__ void direct_body(const VgxDirectArgs &a) {
                 if (g.pos == 32) rng_refill(g, lane);
                 double nlog = bcast(g.val, 2 * g.pos), u2 = bcast(g.val, 2 * g.pos + 1);
                 g.pos += 1;
-                double t_new = c.currentTime + (nlog / (c.totalRate + c.totalMig));  // SampleTime pyx:476-478
+                c.den = c.totalRate + c.totalMig;
+                c.iter_key = (att << 40) | last_att_loops;
+                double t_new = c.currentTime + (nlog / c.den);  // SampleTime pyx:476-478
                 if (c.traj) traj_emit(c, t_new, false);
                 c.currentTime = t_new;
                 PROF(1);
@@ -1279,7 +1292,22 @@ static __device__ __forceinline__ void direct_body(const VgxDirectArgs &a) {
         // end of an attempt (pyx:414-418)
         attempt_open = false;
         if (c.ev_ptr <= 100 && a.iterations > 100) {
+            // the lockdown records of this failed attempt stay in the log (pyx:714-738): keep what the host clock needs
+            if (c.loc_n > att_loc0 && c.record_events && r.fa_cap > 0) {
+                const int64_t n = c.ev_ptr - att_ev0;
+                for (int64_t k = lane; k < n; k += LANES) {
+                    const int64_t slot = att_ev0 + k - c.ev_base;
+                    if (fa_n + k < r.fa_cap && slot >= 0 && slot < c.evcap) {
+                        r.fa_rate[(int64_t)rep * r.fa_cap + fa_n + k] = c.ev_rate[slot];
+                        r.fa_key[(int64_t)rep * r.fa_cap + fa_n + k] = (att << 40) | (int64_t)(uint32_t)c.ev_cols[slot * VGX_EV_COLS + 5];
+                    }
+                }
+                fa_n += n;
+                WSYNC();
+            }
             restart_state(c, r);
+            att_ev0 = 0;
+            att_loc0 = c.loc_n;
             restarts += 1;
             att += 1;
             rebuild = true;  // CheckLockdown for all + UpdateAllRates, also after the last attempt
@@ -1321,6 +1349,7 @@ static __device__ __forceinline__ void direct_body(const VgxDirectArgs &a) {
         sc->ev_ptr = c.ev_ptr; sc->loop_iterations = loops; sc->restarts = restarts;
         sc->loc_n = c.loc_n; sc->error = c.error; sc->traj_next = c.traj_next;
         sc->last_attempt = last_att; sc->last_attempt_loops = last_att_loops;
+        sc->fa_n = fa_n;
     }
 }
 

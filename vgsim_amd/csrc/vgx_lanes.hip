@@ -36,8 +36,9 @@ struct Lane {
     int64_t cB, cD, cS, cM, cI, cSwap, cMigP, cMigN;
     int error;
     // logs
-    double *ev_time; int32_t *ev_cols; int64_t evcap, ev_base; int record_events;
-    int32_t *loc_rec; double *loc_time;
+    double *ev_rate; int32_t *ev_cols; int64_t evcap, ev_base; int record_events;
+    int32_t *loc_rec; double *loc_time; int64_t *loc_iter; int64_t loc_cap;
+    double den; int64_t iter_key;   // this iteration's totalRate + totalMigrationRate; (attempt << 40) | loop iteration
     int64_t *rec; int64_t rec_cap, rec_n;
     double *traj; int64_t traj_points, traj_next; double traj_t0, traj_dt;
 };
@@ -52,9 +53,9 @@ __device__ __forceinline__ void add_event(Lane &L, int type, int hap, int pop, i
     if (L.record_events) {
         int64_t slot = L.ev_ptr - L.ev_base;
         if (slot >= 0 && slot < L.evcap) {
-            int32_t *c = L.ev_cols + slot * 5;
-            c[0] = type; c[1] = hap; c[2] = pop; c[3] = nh; c[4] = np;
-            L.ev_time[slot] = L.currentTime;
+            int32_t *c = L.ev_cols + slot * VGX_EV_COLS;
+            c[0] = type; c[1] = hap; c[2] = pop; c[3] = nh; c[4] = np; c[5] = (int32_t)(uint32_t)L.iter_key;
+            L.ev_rate[slot] = L.den;
         } else {
             L.error = ERR_CAPACITY;
         }
@@ -381,10 +382,11 @@ __device__ bool check_lockdowns(Lane &L, int lo, int hi) {
             if (!flip) continue;
             AT(L.cd, pi) = pass == 0 ? p.cdAfter[pi] : p.cdBefore[pi];
             AT(L.lock, pi) = pass == 0 ? 1 : 0;
-            if (L.loc_n < VGX_LOC_CAP) {
+            if (L.loc_n < L.loc_cap) {
                 L.loc_rec[L.loc_n * 2 + 0] = pass == 0 ? 1 : 0;
                 L.loc_rec[L.loc_n * 2 + 1] = pi;
                 L.loc_time[L.loc_n] = L.currentTime;
+                L.loc_iter[L.loc_n] = L.iter_key;
             } else {
                 L.error = ERR_CAPACITY;
             }
@@ -442,10 +444,13 @@ static __device__ __forceinline__ void lanes_body(const VgxDirectArgs &a, Lane &
     L.cSwap = sc->swapLockdown; L.cMigP = sc->migPlus; L.cMigN = sc->migNonPlus;
     L.ev_ptr = sc->ev_ptr; L.loc_n = 0; L.error = 0;
     L.evcap = r.evcap; L.ev_base = r.ev_base; L.record_events = a.record_events;
-    L.ev_time = r.ev_time + rep * r.evcap;
-    L.ev_cols = r.ev_cols + rep * r.evcap * 5;
-    L.loc_rec = r.loc_rec + rep * VGX_LOC_CAP * 2;
-    L.loc_time = r.loc_time + rep * VGX_LOC_CAP;
+    L.ev_rate = r.ev_rate + rep * r.evcap;
+    L.ev_cols = r.ev_cols + rep * r.evcap * VGX_EV_COLS;
+    L.loc_cap = r.loc_cap;
+    L.loc_rec = r.loc_rec + rep * r.loc_cap * 2;
+    L.loc_time = r.loc_time + rep * r.loc_cap;
+    L.loc_iter = r.loc_iter + rep * r.loc_cap;
+    L.den = 0.0; L.iter_key = 0;
     L.rec = (RECOMB && r.rec) ? r.rec + rep * r.rec_cap * 5 : nullptr; L.rec_cap = r.rec_cap; L.rec_n = 0;
     L.traj_points = r.traj_points; L.traj_t0 = r.traj_t0; L.traj_dt = r.traj_dt; L.traj_next = 0;
     L.traj = r.traj ? r.traj + rep * r.traj_points * P * 2 : nullptr;
@@ -454,6 +459,7 @@ static __device__ __forceinline__ void lanes_body(const VgxDirectArgs &a, Lane &
     const bool has_tlimit = !(a.time == -1.0f);
     const int64_t seed = r.seeds[rep];
     int64_t loops = 0, restarts = 0, good_attempt = sc->good_attempt, last_att = -1, last_att_loops = 0;
+    int64_t att_ev0 = sc->ev_ptr, att_loc0 = 0, fa_n = 0;   // first log index / lockdown record of the current attempt
 
     // PrepareParameters tail (pyx:449-451): CheckLockdown for every population, UpdateAllRates
     check_lockdowns(L, 0, P);
@@ -469,7 +475,9 @@ static __device__ __forceinline__ void lanes_body(const VgxDirectArgs &a, Lane &
                 loops += 1;
                 last_att_loops += 1;
                 double u1 = vgx_pcg64_double(g);
-                double t_new = L.currentTime + (-vgx_log(u1) / (L.totalRate + L.totalMig));   // SampleTime pyx:476-478
+                L.den = L.totalRate + L.totalMig;
+                L.iter_key = (att << 40) | last_att_loops;
+                double t_new = L.currentTime + (-vgx_log(u1) / L.den);   // SampleTime pyx:476-478
                 if (L.traj) traj_emit(L, t_new, false);
                 L.currentTime = t_new;
                 double u2 = vgx_pcg64_double(g);
@@ -482,7 +490,21 @@ static __device__ __forceinline__ void lanes_body(const VgxDirectArgs &a, Lane &
         }
         if (L.error) break;
         if (L.ev_ptr <= 100 && a.iterations > 100) {
-            // Restart (pyx:714-738); swapLockdown survives
+            // Restart (pyx:714-738); swapLockdown survives.  Lockdown records of the failed attempt stay in the log: keep
+            // the (rate, iteration) pairs the host clock needs for them
+            if (L.loc_n > att_loc0 && L.record_events && r.fa_cap > 0) {
+                const int64_t n = L.ev_ptr - att_ev0;
+                for (int64_t k = 0; k < n; ++k) {
+                    const int64_t slot = att_ev0 + k - L.ev_base;
+                    if (fa_n + k < r.fa_cap && slot >= 0 && slot < L.evcap) {
+                        r.fa_rate[rep * r.fa_cap + fa_n + k] = L.ev_rate[slot];
+                        r.fa_key[rep * r.fa_cap + fa_n + k] = (att << 40) | (int64_t)(uint32_t)L.ev_cols[slot * VGX_EV_COLS + 5];
+                    }
+                }
+                fa_n += n;
+            }
+            att_ev0 = 0;
+            L.iter_key = (att + 1) << 40;   // the CheckLockdown below belongs to the next attempt, before its first iteration
             L.ev_ptr = 0;
             L.cB = L.cD = L.cS = L.cM = L.cI = 0; L.cMigP = L.cMigN = 0;
             L.currentTime = 0.0;
@@ -502,6 +524,7 @@ static __device__ __forceinline__ void lanes_body(const VgxDirectArgs &a, Lane &
                 L.gI += ti;
             }
             restarts += 1;
+            att_loc0 = L.loc_n;
             check_lockdowns(L, 0, P);
             update_all_rates(L);
         } else {
@@ -552,6 +575,7 @@ static __device__ __forceinline__ void lanes_body(const VgxDirectArgs &a, Lane &
     sc->loc_n = L.loc_n; sc->error = L.error; sc->traj_next = L.traj_next;
     sc->last_attempt = last_att; sc->last_attempt_loops = last_att_loops;
     sc->rec_n = L.rec_n;
+    sc->fa_n = fa_n;
 }
 
 // state in HBM, interleaved across all replicates
