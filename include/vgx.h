@@ -87,7 +87,9 @@ typedef struct vgx_run_opts {
                                 factored BirthRate, tree scans; same random stream and event semantics, identical
                                 integer columns on the same seed).  Ignored by vgx_simulate_tau. */
     int64_t kernel;          /* direct path: 0 = automatic, 1 = one replicate per wavefront (vgx_direct.hip), 2 = one replicate
-                                per lane (vgx_lanes.hip; small models: popNum <= 16, popNum*hapNum <= 1024, susNum <= 8, EXACT) */
+                                per lane (vgx_lanes.hip; small models: popNum <= 16, popNum*hapNum <= 1024, susNum <= 8, EXACT),
+                                3 = four replicates per wavefront, one per 16-lane row (vgx_quad.hip; EXACT, popNum <= 64, one
+                                susceptibility group, one rate class, no possible lockdown switch) */
     int64_t reserved[2];     /* [0] tau path: 1 = run every try of the halving loop (pyx:2316-2321) instead of starting at the
                                 first try that is not certain to be rejected (same accepted steps either way) */
 } vgx_run_opts;

@@ -308,13 +308,13 @@ class BirthDeathModel(ParameterTable, Reporting):
     def SimulatePopulation(self, iterations, sample_size, time, attempts, mode='exact', kernel='auto'):
         """pyx:396-429: direct Gillespie on the GPU.  ``mode``: 'exact' = the reference's floating-point summation
         order (bit-exact log); 'fast' = order-free sums (same random stream and event semantics; include/vgx.h
-        vgx_run_opts.mode).  ``kernel``: 'auto', 'wave' (one replicate per wavefront) or 'lane' (one replicate per
-        lane, small models; vgx_run_opts.kernel)."""
+        vgx_run_opts.mode).  ``kernel``: 'auto', 'wave' (one replicate per wavefront), 'quad' (four per wavefront, one per
+        16-lane row; one rate class) or 'lane' (one replicate per lane, small models; vgx_run_opts.kernel)."""
         self._check_supported()
         if mode not in ('exact', 'fast'):
             raise ValueError("mode must be 'exact' or 'fast'")
-        if kernel not in ('auto', 'wave', 'lane'):
-            raise ValueError("kernel must be 'auto', 'wave' or 'lane'")
+        if kernel not in ('auto', 'wave', 'lane', 'quad'):
+            raise ValueError("kernel must be 'auto', 'wave', 'lane' or 'quad'")
         self.events.CreateEvents(iterations)
         self.CheckSizes()
         time = float(np.float32(time))  # `float time` in the reference signature
@@ -324,7 +324,7 @@ class BirthDeathModel(ParameterTable, Reporting):
             opts = _capi.VgxRunOpts()
             opts.record_events = 1
             opts.mode = 1 if mode == 'fast' else 0
-            opts.kernel = {'auto': 0, 'wave': 1, 'lane': 2}[kernel]
+            opts.kernel = {'auto': 0, 'wave': 1, 'lane': 2, 'quad': 3}[kernel]
         eng = self._get_engine()
         eng.simulate_direct(self, iterations, sample_size, time, attempts, opts)
         c = eng.last_counters

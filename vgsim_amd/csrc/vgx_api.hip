@@ -22,6 +22,8 @@ extern "C" hipError_t vgxi_launch_direct(const VgxDirectArgs *a, size_t lds, hip
 extern "C" int vgxi_tau_inc_shards(int64_t H, int64_t P);
 extern "C" hipError_t vgxi_tau_sieve(const VgxTauArgs *a, hipStream_t s);
 extern "C" hipError_t vgxi_launch_lanes(const VgxDirectArgs *a, const VgxLaneWs *w, hipStream_t stream);
+extern "C" hipError_t vgxi_launch_quad(const VgxDirectArgs *a, const double *cd, double *effMig, double *maxEBM, int32_t *has_mig,
+                                       hipStream_t stream);
 extern "C" size_t vgxi_direct_lds_bytes(int P, int S, int C, int CB);
 extern "C" hipError_t vgxi_launch_init_reps(const VgxDevRep *r, int P, int S, int64_t R, const int32_t *s_nocc,
                                             const int32_t *s_hap, const int32_t *s_cls, const int64_t *s_cnt,
@@ -73,7 +75,7 @@ struct vgx_engine {
     int64_t genome_length = 1000000, rec_cap = 0;
     DevBuf r_rec;
     DevBuf r_popD, r_popI, r_sus, r_immSrc, r_birthC, r_xC, r_effMig, r_nocc, r_lhap, r_lcls, r_lcnt, r_ltsum, r_lanews, r_sc, r_seeds,
-        r_evrate, r_evcols, r_locrec, r_loctime, r_lociter, r_farate, r_fakey, r_traj, r_prof;
+        r_evrate, r_evcols, r_locrec, r_loctime, r_lociter, r_farate, r_fakey, r_traj, r_prof, r_qeff, r_qmebm, r_qflag;
     // tau-leaping (dense compartments)
     DevBuf t_I, t_S, t_dChk, t_dApp, t_dSi, t_dTot, t_totInf, t_gI, t_cd, t_lock, t_F, t_eff, t_Aeff, t_Gout, t_dS,
         t_taubits, t_tau, t_time, t_flags, t_counters, t_cnttry, t_mev, t_mevn, t_mevbase, t_locn, t_mutcum, t_migcdf, t_migIn, t_mutHi, t_colT, t_colTW, t_inc, t_incn, t_sieve, t_sieveskip, t_big, t_bign, t_res;
@@ -107,7 +109,7 @@ struct vgx_engine {
         double final_time = 0.0;          // currentTime after the call
         std::vector<double> loc_times;    // lockdown records
     } hc;
-    bool last_used_lanes = false;
+    bool last_used_lanes = false, last_used_quad = false;
     int64_t last_ev_size = 0;
     std::vector<VgxRepScalars> sc_host;
     bool sc_host_valid = false;
@@ -738,6 +740,16 @@ static int direct_core(vgx_engine *e, int64_t iterations, int64_t sample_size, f
     // measured (tools/probe_lanes.py): the lane kernel only wins for minimal models in very large ensembles (config 2 at
     // 262 144 replicates: 2.4e9 vs 7.0e8 events/s); its state lives in HBM/L2, so every other shape is latency-bound
     const bool use_lanes = recomb || o.kernel == 2 || (o.kernel == 0 && lane_ok && P * H * S <= 4 && R >= 65536);
+    // Four replicates per wavefront, one per 16-lane DPP row (vgx_quad.hip): one rate class, one susceptibility group,
+    // at most 64 populations, no population that can switch its lockdown state, exact mode.
+    bool quad_ok = o.mode == 0 && !recomb && P <= 64 && S == 1 && e->C == 1 && e->CB == 1 && !ld_possible &&
+                   e->suscepCumul[0] == 0.0;
+    for (int64_t pn = 0; pn < P && quad_ok; pn++)
+        if (h.totalSusceptible[(size_t)pn] != h.susceptible[(size_t)pn]) quad_ok = false;
+    if (o.kernel == 3 && !quad_ok)
+        return fail(e, VGX_ERR_ARG, "vgx_simulate_direct: the four-replicates-per-wavefront kernel needs exact mode, popNum <= 64, "
+                                    "one susceptibility group, one rate class and no possible lockdown switch");
+    const bool use_quad = o.kernel == 3 || (o.kernel == 0 && quad_ok && !use_lanes && R >= 4);
     VgxLaneWs ws{};
     a.r.rec = nullptr; a.r.rec_cap = 0;
     e->rec_cap = 0;
@@ -762,9 +774,19 @@ static int direct_core(vgx_engine *e, int64_t iterations, int64_t sample_size, f
         ws.popR = wd; wd += P * R; ws.migR = wd; wd += P * R; ws.maxEBM = wd; wd += P * R; ws.effMig = wd; wd += P * P * R;
     }
     e->last_used_lanes = use_lanes;
+    e->last_used_quad = use_quad;
+    if (use_quad) {
+        int rcq = 0;
+        rcq |= ensure(e, e->r_qeff, (size_t)(P * P) * 8);
+        rcq |= ensure(e, e->r_qmebm, (size_t)P * 8);
+        rcq |= ensure(e, e->r_qflag, 8);
+        if (rcq) return rcq;
+    }
 
     HIPCHECK(e, hipEventRecord(e->ev0, e->stream));
     if (use_lanes) HIPCHECK(e, vgxi_launch_lanes(&a, &ws, e->stream));
+    else if (use_quad) HIPCHECK(e, vgxi_launch_quad(&a, (const double *)e->s_cd.p, (double *)e->r_qeff.p, (double *)e->r_qmebm.p,
+                                                    (int32_t *)e->r_qflag.p, e->stream));
     else HIPCHECK(e, vgxi_launch_direct(&a, lds, e->stream));
     HIPCHECK(e, hipEventRecord(e->ev1, e->stream));
     HIPCHECK(e, hipStreamSynchronize(e->stream));
@@ -779,11 +801,14 @@ static int direct_core(vgx_engine *e, int64_t iterations, int64_t sample_size, f
     for (int64_t r = 0; r < R; r++) {
         int64_t er = e->sc_host[(size_t)r].error;
         if (er) {
+            const int64_t where = er >> 8;   // the quad kernel tags the site of a zero-weight alert (diagnostics)
+            er &= 255;
             const char *what = er == VGX_ERR_ZERO_WEIGHT ? "zero weight sampled (fastChoose alert)"
                                : er == VGX_ERR_CAPACITY  ? "capacity exceeded (occupancy list / event or lockdown log)"
                                : er == VGX_ERR_LOOP_GUARD ? "loop guard tripped"
                                                           : "kernel error";
-            return fail(e, (int)er, std::string("vgx_simulate_direct: replicate ") + std::to_string(r) + ": " + what);
+            return fail(e, (int)er, std::string("vgx_simulate_direct: replicate ") + std::to_string(r) + ": " + what +
+                                        (where ? " [site " + std::to_string(where) + "]" : std::string()));
         }
     }
     return VGX_OK;

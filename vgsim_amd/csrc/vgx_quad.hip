@@ -1,0 +1,940 @@
+// vgx_quad.hip — persistent direct-Gillespie kernel, FOUR replicates per wavefront (one per 16-lane DPP row).
+//
+// Same path as vgx_direct.hip (SimulatePopulation pyx:396-429 and everything it calls: SampleTime pyx:476,
+// GenerateEvent pyx:483, UpdateRates pyx:516, Birth pyx:568, Death/Sampling pyx:616/630, Mutation pyx:640,
+// GenerateMigration pyx:672, Restart pyx:714, fastChoose / fastChoose_skip fast_choose.pxi:18/36, Events.AddEvent
+// events.pxi:37), same HBM layout (vgx_dev.h), same bit-exact contract: every sum the reference forms left to right is
+// formed left to right, no contraction.
+//
+// Why four per wave.  A sequential f64 sum costs one dependent v_fmac_f64 per term whatever the number of active lanes;
+// the DPP source `row_newbcast:k` broadcasts inside a ROW of 16 lanes, so one such instruction can advance four
+// independent chains, one per row.  vgx_direct.hip spends a full 64-lane issue on one useful addition (its replicate's
+// chain) and, at the natural occupancy of a few haplotypes per population, keeps 3 of 4 rows idle in every list
+// operation.  Here each row owns a replicate: lane (row, l) holds populations l, l+16, l+32, l+48 of its replicate and
+// list entry 16c + l of the list chunk c being processed, every chain instruction serves four replicates, and everything
+// that is per-replicate "scalar" state is a row-uniform VGPR value.  Control flow is wave-uniform; rows that take
+// different branches (birth / death / mutation / migration, finished replicates) are predicated.
+//
+// Scope (the host chooses this kernel only then, vgx_api.hip): popNum <= 64, one susceptibility group, one rate class
+// (every haplotype has the same bRate / dRate / sRate / susceptibility / total mutation rate), no population can switch
+// its lockdown state, no recombination, exact mode — BASELINE configs 2 and 3.  With one susceptibility group
+// immunePopRate is +0.0 (suscepTransition is a 1x1 zero) and popRate = infectPopRate + 0.0 = infectPopRate exactly;
+// without lockdown switches contactDensity, effectiveMigration and maxEffectiveBirthMigration are functions of the
+// parameters only and come from vgx_quad_prep_kernel, shared by all replicates.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "vgx_dev.h"
+#include "vgx_rng.h"
+#include "vgx_wave.h"
+
+namespace {
+
+enum { Q_ERR_ZERO_WEIGHT = 3, Q_ERR_CAPACITY = 4, Q_ERR_LOOP_GUARD = 5 };
+enum { QEV_BIRTH = 0, QEV_DEATH, QEV_SAMPLING, QEV_MUTATION, QEV_SUSCCHANGE, QEV_MIGRATION };
+enum { ST_REBUILD = 0, ST_RUN = 1, ST_DONE = 2 };
+
+// ---- LDS layout (bytes), one wavefront per workgroup ---------------------------------------------------------
+// model constants [64] f64: cd, as, smul (= sRate * samplingMultiplier), maxEBM                      2048
+// random numbers  [4][64] f64: per row 32 x (-log u1, u2)                                            2048
+// per replicate   infect[64], cum[64], birthC[64] f64; totS[64], totI[64] i64; nocc[64] i32          4 x 2816
+#define Q_CONST_BYTES 2048
+#define Q_RNG_BYTES 2048
+#define Q_REP_BYTES 2816
+#define Q_LDS_BYTES (Q_CONST_BYTES + Q_RNG_BYTES + 4 * Q_REP_BYTES)
+
+// ---- row primitives --------------------------------------------------------------------------------------------
+// value of lane (row, j) for a row-uniform j in 0..15 (LDS crossbar, no memory)
+static __device__ __forceinline__ int rowget_i32(int v, int j) {
+    return __builtin_amdgcn_ds_bpermute((int)(((threadIdx.x & 48u) | (unsigned)j) << 2), v);
+}
+static __device__ __forceinline__ double rowget_f64(double v, int j) {
+    int lo = rowget_i32(__double2loint(v), j), hi = rowget_i32(__double2hiint(v), j);
+    return __hiloint2double(hi, lo);
+}
+static __device__ __forceinline__ int64_t rowget_i64(int64_t v, int j) {
+    int lo = rowget_i32((int)(uint32_t)v, j), hi = rowget_i32((int)(uint32_t)((uint64_t)v >> 32), j);
+    return (int64_t)(((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo);
+}
+// minimum over the 16 lanes of each row (row rotations: every lane ends with its row's minimum)
+#define QDPP_ROR(v, n) __builtin_amdgcn_update_dpp(0, (v), 0x120 + (n), 0xf, 0xf, false)
+static __device__ __forceinline__ int row_min(int v) {
+    v = min(v, QDPP_ROR(v, 8));
+    v = min(v, QDPP_ROR(v, 4));
+    v = min(v, QDPP_ROR(v, 2));
+    v = min(v, QDPP_ROR(v, 1));
+    return v;
+}
+static __device__ __forceinline__ int row_max(int v) { return -row_min(-v); }
+// inclusive integer prefix inside each row (lanes without a source receive 0)
+static __device__ __forceinline__ int64_t row_iscan(int64_t v) {
+    VGX_SCAN_STEPS(VGX_I64_STEP)
+    return v;
+}
+// maximum over the four rows of a row-uniform value (wave-uniform result)
+static __device__ __forceinline__ int rows_max(int v) {
+    int a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16);
+    int c = __builtin_amdgcn_readlane(v, 32), d = __builtin_amdgcn_readlane(v, 48);
+    return max(max(a, b), max(c, d));
+}
+
+// acc + v[0] + ... + v[15] of each row, in lane order: 16 dependent v_fmac_f64 (acc = fma(v[k], 1.0, acc) rounds like
+// acc + v[k]), every one of them serving the four rows.  acc row-uniform in and out; all 64 lanes active.
+#define QFM(K) "v_fmac_f64_dpp %0, %1, %2 row_newbcast:" #K " row_mask:0xf bank_mask:0xf\n\t"
+static __device__ __forceinline__ double row_sum16(double v, double acc) {
+    const double one = 1.0;
+    asm volatile("s_nop 1\n\t" QFM(0) QFM(1) QFM(2) QFM(3) QFM(4) QFM(5) QFM(6) QFM(7) QFM(8) QFM(9) QFM(10) QFM(11) QFM(12)
+                     QFM(13) QFM(14) QFM(15)
+                 : "+v"(acc)
+                 : "v"(v), "v"(one));
+    return acc;
+}
+// lane l of each row gets carry + v[0] + ... + v[l] (the serial prefix): the same chain with EXEC narrowed to the lanes
+// l >= k of every row before step k (5 wait states between an EXEC write and a DPP instruction).
+#define QFX(K, M) "s_mov_b32 exec_lo, " #M "\n\ts_mov_b32 exec_hi, " #M "\n\ts_nop 4\n\t" QFM(K)
+static __device__ __forceinline__ double row_scan16(double v, double carry) {
+    const double one = 1.0;
+    double acc = carry;
+    asm volatile("s_nop 1\n\t" QFM(0) QFX(1, 0xfffefffe) QFX(2, 0xfffcfffc) QFX(3, 0xfff8fff8) QFX(4, 0xfff0fff0)
+                     QFX(5, 0xffe0ffe0) QFX(6, 0xffc0ffc0) QFX(7, 0xff80ff80) QFX(8, 0xff00ff00) QFX(9, 0xfe00fe00)
+                         QFX(10, 0xfc00fc00) QFX(11, 0xf800f800) QFX(12, 0xf000f000) QFX(13, 0xe000e000)
+                             QFX(14, 0xc000c000) QFX(15, 0x80008000) "s_mov_b64 exec, -1\n\t"
+                 : "+v"(acc)
+                 : "v"(v), "v"(one));
+    return acc;
+}
+// value of lane 15 of each row in all its lanes (the chunk total after row_scan16)
+static __device__ __forceinline__ double row_last(double v) {
+    int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x15F, 0xf, 0xf, false);   // row_newbcast:15
+    int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x15F, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
+struct QArgs {          // what the prep kernel leaves for all replicates
+    const double *effMig;   // [P][P]
+    const double *maxEBM;   // [P]
+    const int32_t *has_mig; // [1]
+};
+
+}  // namespace
+
+// effectiveMigration, maxEffectiveBirthMigration (pyx:327-338) from the parameters and the (constant) contact densities:
+// lane <-> target population, serial over sources and the inner sum, the reference's operation order.
+extern "C" __global__ void __launch_bounds__(64) vgx_quad_prep_kernel(VgxDevParams p, const double *cd, double *effMig,
+                                                                     double *maxEBM, int32_t *has_mig) {
+    const int P = p.P, pn2 = threadIdx.x;
+    double mx = 0.0;
+    if (pn2 < P) {
+        const double *m2 = p.mig + (int64_t)pn2 * P;
+        for (int pn1 = 0; pn1 < P; ++pn1) {
+            if (pn1 == pn2) continue;
+            const double *m1 = p.mig + (int64_t)pn1 * P;
+            double e = 0.0;
+            for (int pn3 = 0; pn3 < P; ++pn3) e += m1[pn3] * m2[pn3] * cd[pn3] / p.actualSizes[pn3];
+            effMig[(int64_t)pn1 * P + pn2] = e;
+            if (e > mx) mx = e;
+        }
+        maxEBM[pn2] = mx * p.maxEffectiveBirth;
+    }
+    unsigned long long any = __ballot(pn2 < P && mx * p.maxEffectiveBirth != 0.0);
+    if (threadIdx.x == 0) *has_mig = any != 0ull ? 1 : 0;
+}
+
+extern "C" __global__ void __launch_bounds__(64) vgx_quad_kernel(VgxDirectArgs a, QArgs qa) {
+    const int lane = threadIdx.x, row = lane >> 4, rl = lane & 15;
+    const VgxDevParams &p = a.p;
+    const VgxDevRep &r = a.r;
+    const int P = p.P, sites = p.sites, H = p.H;
+    const int64_t R = a.n_replicates;
+    const int64_t rep_raw = (int64_t)blockIdx.x * 4 + row;
+    const bool live = rep_raw < R;
+    const int64_t rep = live ? rep_raw : R - 1;   // idle rows shadow the last replicate read-only
+    const int nslot = (P + 15) >> 4;              // register slots of the population arrays in use
+    const bool has_mig = qa.has_mig[0] != 0;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double *k_cd = (double *)smem, *k_as = k_cd + 64, *k_smul = k_as + 64, *k_mebm = k_smul + 64;
+    double *rbuf = (double *)(smem + Q_CONST_BYTES) + row * 64;
+    unsigned char *blk = smem + Q_CONST_BYTES + Q_RNG_BYTES + row * Q_REP_BYTES;
+    double *s_inf = (double *)blk, *s_cum = s_inf + 64, *s_bc = s_cum + 64;
+    int64_t *s_ts = (int64_t *)(s_bc + 64), *s_ti = s_ts + 64;
+    int32_t *s_nocc = (int32_t *)(s_ti + 64);
+
+    // the single rate class
+    const double c_b = p.cb_b[0], c_sig = p.cb_sigma[0], c_d = p.c_d[0], c_s = p.c_s[0], c_tm = p.c_tm[0];
+
+    // ---- load state ----
+    double *gD = r.popD + rep * PD_COUNT * P;
+    int64_t *gI64 = r.popI + rep * PI_COUNT * P;
+    int32_t *gN = r.nocc + rep * P;
+    {
+        const int pn = lane;
+        k_cd[pn] = pn < P ? gD[PD_CD * P + pn] : 0.0;   // identical in every replicate (no lockdown switches)
+        k_as[pn] = pn < P ? p.actualSizes[pn] : 1.0;
+        k_smul[pn] = pn < P ? c_s * p.sampMult[pn] : 0.0;
+        k_mebm[pn] = pn < P ? qa.maxEBM[pn] : 0.0;
+    }
+    for (int s = 0; s < 4; ++s) {
+        const int pn = s * 16 + rl;
+        const bool ok = pn < P;
+        s_inf[pn] = 0.0; s_cum[pn] = 0.0; s_bc[pn] = 0.0;
+        s_ts[pn] = ok ? gI64[PI_TOTSUS * P + pn] : 0;
+        s_ti[pn] = ok ? gI64[PI_TOTINF * P + pn] : 0;
+        s_nocc[pn] = ok ? gN[pn] : 0;
+    }
+    WSYNC();
+
+    const int64_t cap = r.cap, capT = r.capT;
+    int32_t *lhap = r.lhap + rep * P * cap;
+    int32_t *lcls = r.lcls + rep * P * cap;
+    int64_t *lcnt = r.lcnt + rep * P * cap;
+    int64_t *ltsum = r.ltsum + rep * P * capT;
+    double *ev_rate = r.ev_rate + rep * r.evcap;
+    int32_t *ev_cols = r.ev_cols + rep * r.evcap * VGX_EV_COLS;
+    double *traj = r.traj ? r.traj + rep * r.traj_points * P * 2 : nullptr;
+    VgxRepScalars *sc = r.sc + rep;
+
+    double t_now = sc->currentTime, totalRate = 0.0, totalMig = 0.0;
+    int64_t gI = sc->globalInfectious, ev_ptr = sc->ev_ptr;
+    int64_t cB = sc->bCounter, cD = sc->dCounter, cS = sc->sCounter, cM = sc->mCounter, cMigP = sc->migPlus, cMigN = sc->migNonPlus;
+    int64_t loops = 0, att_loops = 0, att = 0, restarts = 0, good_attempt = sc->good_attempt, last_att = -1, traj_next = 0;
+    int st = live ? ST_REBUILD : ST_DONE, err = 0;
+    bool open = false;
+    const int64_t seed = r.seeds[rep];
+    const double tlimit = (double)a.time;
+    const bool has_tl = !(a.time == -1.0f);
+
+    // random stream of the row: 64 outputs per refill by lane-parallel jump-ahead (vgx_direct.hip rng_refill)
+    uint64_t jAh, jAl, jGh, jGl;
+    {
+        const uint64_t MH = 0x2360ED051FC65DA4ull, ML = 0x4385DF649FCCF645ull;
+        uint64_t Ah = MH, Al = ML, Gh = 0, Gl = 1;
+        for (int j = 1; j < 64; ++j) {
+            uint64_t nh, nl, gh, gl;
+            vgx_mul128(Ah, Al, MH, ML, nh, nl);
+            vgx_mul128(Gh, Gl, MH, ML, gh, gl);
+            vgx_add128(gh, gl, 0, 1);
+            if (j <= lane) { Ah = nh; Al = nl; Gh = gh; Gl = gl; }
+        }
+        jAh = Ah; jAl = Al; jGh = Gh; jGl = Gl;
+    }
+    uint64_t g_sh = 0, g_sl = 0, g_ih = 0, g_il = 0;   // row-uniform: stream position, increment
+    int pos = 32;                                      // iterations consumed from the row's batch (32 = empty)
+
+    while (true) {
+        const bool run = st != ST_DONE;
+        if (!__ballot(run)) break;
+        const bool rebuild = st == ST_REBUILD;
+
+        // ================= front: open the attempt, loop condition (pyx:402-407) =================
+        bool end_attempt = false, ev = false;
+        if (st == ST_RUN) {
+            if (!open) {
+                if (att >= a.attempts) {
+                    st = ST_DONE;
+                } else {
+                    VgxPcg64 sd;
+                    vgx_pcg64_seed(sd, (uint64_t)seed, (uint32_t)att);
+                    g_sh = sd.sh; g_sl = sd.sl; g_ih = sd.ih; g_il = sd.il;
+                    pos = 32;
+                    open = true;
+                    last_att = att; att_loops = 0;
+                    if (!(totalRate + totalMig != 0.0 && gI != 0)) end_attempt = true;   // pyx:404
+                }
+            }
+            if (st == ST_RUN && !end_attempt &&
+                !(ev_ptr < a.ev_size && (a.sample_size == -1 || cS <= a.sample_size) && (!has_tl || t_now < tlimit)))
+                end_attempt = true;
+            if (st == ST_RUN && !end_attempt) {
+                if (loops >= a.max_loop) { err = Q_ERR_LOOP_GUARD; st = ST_DONE; }
+                else ev = true;
+            }
+        }
+
+        // update request of this pass: populations [u_lo, u_hi) of the row (rebuild: all; event: the one it touched)
+        int u_lo = 0, u_hi = rebuild ? P : 0;
+        // deferred list operations (mutation: +1 on the new haplotype, -1 on the old; death of the last carrier: -1;
+        // accepted migration: +1 in the target population)
+        int op_n = 0, op_pi = 0, op_h0 = 0, op_h1 = 0;
+        int op_d0 = 0;
+        int e_type = -1, e_hap = 0, e_pop = 0, e_nh = 0, e_np = 0;
+        double den = 0.0;
+
+        if (__ballot(ev)) {
+            // ---- random numbers: refill the batch of every row that ran dry ----
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int need = __builtin_amdgcn_readlane((int)(ev && pos == 32), rr * 16);
+                if (need) {
+                    const uint64_t sh = (uint64_t)bcast_i64((int64_t)g_sh, rr * 16), sl = (uint64_t)bcast_i64((int64_t)g_sl, rr * 16);
+                    const uint64_t ih = (uint64_t)bcast_i64((int64_t)g_ih, rr * 16), il = (uint64_t)bcast_i64((int64_t)g_il, rr * 16);
+                    uint64_t h, l, ch, cl;
+                    vgx_mul128(jAh, jAl, sh, sl, h, l);
+                    vgx_mul128(jGh, jGl, ih, il, ch, cl);
+                    vgx_add128(h, l, ch, cl);
+                    const double u = vgx_pcg64_output_double(h, l);
+                    ((double *)(smem + Q_CONST_BYTES))[rr * 64 + lane] = (lane & 1) ? u : -vgx_log(u);
+                    const uint64_t nh = (uint64_t)bcast_i64((int64_t)h, 63), nl = (uint64_t)bcast_i64((int64_t)l, 63);
+                    if (row == rr) { g_sh = nh; g_sl = nl; pos = 0; }
+                }
+            }
+            WSYNC();
+            const int pp = min(pos, 31);
+            const double nlog = rbuf[2 * pp], u2 = rbuf[2 * pp + 1];
+            if (ev) { pos += 1; loops += 1; att_loops += 1; }
+            den = totalRate + totalMig;
+            const double t_new = t_now + (nlog / den);   // SampleTime pyx:476-478
+            // summary trajectories: the state before the event for every grid point the step passes
+            if (traj) {
+                while (true) {
+                    const double tg = r.traj_t0 + (double)traj_next * r.traj_dt;
+                    const bool emit = ev && live && traj_next < r.traj_points && tg < t_new;
+                    if (!__ballot(emit)) break;
+                    if (emit) {
+                        double *o = traj + traj_next * (int64_t)P * 2;
+                        for (int s = 0; s < nslot; ++s) {
+                            const int pn = s * 16 + rl;
+                            if (pn < P) { o[pn * 2 + 0] = (double)s_ti[pn]; o[pn * 2 + 1] = (double)s_ts[pn]; }
+                        }
+                        traj_next += 1;
+                    }
+                }
+            }
+            if (ev) t_now = t_new;
+
+            // ================= GenerateEvent (pyx:483-512) =================
+            double rn = u2;
+            const double choose0 = rn * den;               // kept for the migration branch (pyx:490 / pyx:512)
+            double choose = choose0;
+            const bool evn = ev && (totalRate > choose);   // an event inside a population
+            const bool evm = ev && !evn;                   // a migration attempt
+
+            // ---- population by fastChoose over popRate = infectPopRate (cached serial prefix sums, fc:18-31) ----
+            int pi = 0;
+            {
+                rn = choose / totalRate;
+                const double rr_ = totalRate * rn;
+                int cand = 64;
+                for (int s = 0; s < nslot; ++s) {
+                    const int pn = s * 16 + rl;
+                    if (pn < P && !(s_cum[pn] < rr_)) cand = min(cand, pn);
+                }
+                cand = row_min(cand);
+                pi = cand < 64 ? cand : P - 1;       // clamp at n-1 (fc:26)
+                const double total = s_cum[pi], wi = s_inf[pi];
+                if (evn && wi == 0.0) err = Q_ERR_ZERO_WEIGHT + 256 * 1;
+                rn = (rr_ - (total - wi)) / wi;
+                choose = rn * wi;                    // pyx:493: rn * popRate[pi]
+            }
+            // immunePopRate[pi] = +0.0 is never > choose: the infect branch (pyx:499-500)
+            const double infect_pi = s_inf[pi];
+            rn = (choose - 0.0) / infect_pi;
+            const double bC = s_bc[pi];
+            const double smul = k_smul[pi];
+            const double tE = ((bC + c_d) + smul) + c_tm;          // tEventHapPopRate (pyx:522-526)
+            const int n_sel = evn ? s_nocc[pi] : 0;
+            const int32_t *lh = lhap + (int64_t)pi * cap;
+            int64_t *ln = lcnt + (int64_t)pi * cap;
+            int64_t *lt = ltsum + (int64_t)pi * capT;
+
+            // ---- haplotype by fastChoose over hapPopRate[pi] = tE * infectious in haplotype order ----
+            const double r2 = infect_pi * rn;
+            int k_hit = -1;          // list index of the chosen entry
+            double pre_hit = 0.0, w_hit = 0.0;
+            int hap_hit = 0;
+            int64_t cnt_hit = 0;
+            const int maxn = rows_max(n_sel);
+            if (maxn <= 16) {
+                const bool in = rl < n_sel;
+                const int64_t cn = in ? ln[rl] : 0;
+                const int hp = in ? lh[rl] : 0;
+                const double w = in ? tE * (double)cn : 0.0;
+                const double pre = row_scan16(w, 0.0);
+                const int q = row_min(in && !(pre < r2) ? rl : 16);
+                const int qq = q < 16 ? q : max(n_sel - 1, 0);
+                pre_hit = rowget_f64(pre, qq); w_hit = rowget_f64(w, qq);
+                hap_hit = rowget_i32(hp, qq); cnt_hit = rowget_i64(cn, qq);
+                if (q < 16) k_hit = q;
+                else if (evn) {
+                    // nothing reached r: the dense loop runs on to index H-1 (fc:26), a valid pick only if that haplotype
+                    // is occupied, otherwise the reference reports a zero weight
+                    if (n_sel > 0 && hap_hit == H - 1) k_hit = n_sel - 1; else err = Q_ERR_ZERO_WEIGHT + 256 * 2;
+                }
+            } else {
+                // long lists: the running sum advances one chunk of 16 entries per step; the chunk in which it first
+                // reaches r is then scanned lane by lane — same additions, same order.  Loads run QD chunks ahead.
+                enum { QD = 8 };
+                int64_t buf[QD];
+                double carry = 0.0, carry_hit = 0.0;
+                int c_hit = -1;
+#pragma unroll
+                for (int d = 0; d < QD; ++d) { const int k = d * 16 + rl; buf[d] = k < n_sel ? ln[k] : 0; }
+                for (int cb = 0; cb * 16 < maxn; cb += QD) {
+#pragma unroll
+                    for (int d = 0; d < QD; ++d) {
+                        const int c = cb + d;
+                        const int64_t cn = buf[d];
+                        const int kn = (c + QD) * 16 + rl;
+                        buf[d] = (kn < n_sel && c_hit < 0) ? ln[kn] : 0;
+                        const double w = (c * 16 + rl < n_sel) ? tE * (double)cn : 0.0;
+                        const double acc = row_sum16(w, carry);
+                        if (c_hit < 0 && c * 16 < n_sel && !(acc < r2)) { c_hit = c; carry_hit = carry; }
+                        carry = acc;
+                    }
+                    if (!__ballot(n_sel > (cb + QD) * 16 && c_hit < 0)) break;
+                }
+                // refine inside the hit chunk (rows without a hit look at their last chunk for the H-1 rule)
+                const int cc = c_hit >= 0 ? c_hit : max((n_sel - 1) >> 4, 0);
+                const int k = cc * 16 + rl;
+                const bool in = k < n_sel;
+                const int64_t cn = in ? ln[k] : 0;
+                const int hp = in ? lh[k] : 0;
+                const double w = in ? tE * (double)cn : 0.0;
+                const double pre = row_scan16(w, carry_hit);
+                const int q = row_min(c_hit >= 0 && in && !(pre < r2) ? rl : 16);
+                const int qq = q < 16 ? q : max(n_sel - 1 - cc * 16, 0);
+                pre_hit = q < 16 ? rowget_f64(pre, qq) : carry;   // no hit: the total of the whole list
+                w_hit = rowget_f64(w, qq);
+                hap_hit = rowget_i32(hp, qq); cnt_hit = rowget_i64(cn, qq);
+                if (q < 16) k_hit = cc * 16 + q;
+                else if (evn) {
+                    if (n_sel > 0 && hap_hit == H - 1) k_hit = n_sel - 1; else err = Q_ERR_ZERO_WEIGHT + 256 * 3;
+                }
+            }
+            const bool evn_ok = evn && err == 0;
+            if (evn && w_hit == 0.0 && err == 0) err = Q_ERR_ZERO_WEIGHT + 256 * 4;
+            rn = (r2 - (pre_hit - w_hit)) / w_hit;
+
+            // ---- event class by fastChoose over (birth, death, sampling, mutation) rates (pyx:503-511) ----
+            int ei = 0;
+            {
+                const double r3 = tE * rn;
+                double total = bC, wi = bC;
+                if (total < r3) { ei = 1; total += c_d; wi = c_d; }
+                if (ei == 1 && total < r3) { ei = 2; total += smul; wi = smul; }
+                if (ei == 2 && total < r3) { ei = 3; total += c_tm; wi = c_tm; }
+                if (evn_ok && wi == 0.0) err = Q_ERR_ZERO_WEIGHT + 256 * 5;
+                rn = (r3 - (total - wi)) / wi;
+            }
+            const bool go = evn && err == 0;
+            const int64_t ts_pi = s_ts[pi], ti_pi = s_ti[pi];
+            const bool isB = go && ei == 0, isD = go && (ei == 1 || ei == 2), isM = go && ei == 3;
+            if (isB) {
+                // ---- Birth (pyx:568-605; one susceptibility group: si = 0, its weight susceptHapPopRate = S * sigma) ----
+                if ((double)ts_pi * c_sig == 0.0) err = Q_ERR_ZERO_WEIGHT + 256 * 6;
+                if (rl == 0) { s_ts[pi] = ts_pi - 1; s_ti[pi] = ti_pi + 1; }
+                gI += 1; cB += 1;
+                if (live && rl == 0) { ln[k_hit] = cnt_hit + 1; if (n_sel > 64) lt[k_hit >> 6] += 1; }
+                e_type = QEV_BIRTH; e_hap = hap_hit; e_pop = pi; e_nh = 0; e_np = H;
+                u_lo = pi; u_hi = pi + 1;
+            }
+            if (isD) {
+                // ---- Death / Sampling (pyx:616-635): recovery into group suscType = 0 ----
+                if (rl == 0) { s_ts[pi] = ts_pi + 1; s_ti[pi] = ti_pi - 1; }
+                gI -= 1;
+                if (ei == 2) { cS += 1; e_type = QEV_SAMPLING; } else { cD += 1; e_type = QEV_DEATH; }
+                if (cnt_hit == 1) { op_n = 1; op_pi = pi; op_h0 = hap_hit; op_d0 = -1; }
+                else if (live && rl == 0) { ln[k_hit] = cnt_hit - 1; if (n_sel > 64) lt[k_hit >> 6] -= 1; }
+                e_hap = hap_hit; e_pop = pi; e_nh = 0; e_np = 0;
+                u_lo = pi; u_hi = pi + 1;
+            }
+            if (__ballot(isM)) {
+                // ---- Mutation (pyx:640-667): site by mRate[h, :], derived state by hapMutType[h, site, :] ----
+                const double *mr = p.mRate + (int64_t)hap_hit * sites;
+                int mi = 0;
+                {
+                    const double rq = c_tm * rn;
+                    double total = isM ? mr[0] : 1.0, wi = total;
+                    for (int i = 1; i < sites; ++i) {
+                        if (isM && mi == i - 1 && total < rq) { mi = i; wi = mr[i]; total += wi; }
+                    }
+                    if (isM && wi == 0.0) err = Q_ERR_ZERO_WEIGHT + 256 * 7;
+                    rn = (rq - (total - wi)) / wi;
+                }
+                const double *hm = p.hapMutType + ((int64_t)hap_hit * sites + mi) * 3;
+                int DS = 0;
+                if (isM) {
+                    const double h0 = hm[0], h1 = hm[1], h2 = hm[2];
+                    const double rq = ((h0 + h1) + h2) * rn;
+                    double total = h0, wi = h0;
+                    if (total < rq) { DS = 1; total += h1; wi = h1; }
+                    if (DS == 1 && total < rq) { DS = 2; total += h2; wi = h2; }
+                    if (wi == 0.0) err = Q_ERR_ZERO_WEIGHT + 256 * 8;
+                }
+                if (isM && err == 0) {
+                    const int digit4 = 1 << (2 * (sites - mi - 1));     // Mutate (pyx:2420-2427)
+                    const int AS = (hap_hit / digit4) % 4;
+                    if (DS >= AS) DS += 1;
+                    const int nhi = hap_hit + (DS - AS) * digit4;
+                    op_n = 2; op_pi = pi; op_h0 = nhi; op_d0 = +1; op_h1 = hap_hit;
+                    cM += 1;
+                    e_type = QEV_MUTATION; e_hap = hap_hit; e_pop = pi; e_nh = nhi; e_np = 0;
+                    u_lo = pi; u_hi = pi + 1;
+                }
+            }
+            if (__ballot(evm)) {
+                // ================= GenerateMigration (pyx:672-694) =================
+                double rm = (choose0 - totalRate) / totalMig;
+                // target population by fastChoose over migPopRate: serial prefix sums of the same terms as totalMigrationRate
+                int tpi = 0;
+                {
+                    const double rr_ = totalMig * rm;
+                    double carry = 0.0, tot_hit = 0.0, w_h = 0.0;
+                    int cand = 64;
+                    for (int s = 0; s < nslot; ++s) {
+                        const int pn = s * 16 + rl;
+                        const double w = pn < P ? k_mebm[pn] * (double)s_ts[pn] * (double)(gI - s_ti[pn]) : 0.0;
+                        const double pre = row_scan16(w, carry);
+                        const int q = row_min(cand == 64 && pn < P && !(pre < rr_) ? rl : 16);
+                        if (cand == 64 && q < 16) { cand = s * 16 + q; tot_hit = rowget_f64(pre, q); w_h = rowget_f64(w, q); }
+                        else if (s == nslot - 1 && cand == 64) {        // clamp at P-1
+                            const int ql = (P - 1) & 15;
+                            tot_hit = rowget_f64(pre, ql); w_h = rowget_f64(w, ql);
+                        }
+                        carry = row_last(pre);
+                    }
+                    tpi = cand < 64 ? cand : P - 1;
+                    if (evm && w_h == 0.0) err = Q_ERR_ZERO_WEIGHT + 256 * 9;
+                    rm = (rr_ - (tot_hit - w_h)) / w_h;
+                }
+                // source population: fastChoose_skip(totalInfectious, globalInfectious - totalInfectious[tpi], rn, skip = tpi)
+                int spi = -1;
+                {
+                    const double rr_ = (double)(gI - s_ti[tpi]) * rm;
+                    const int start = tpi == 0 ? 1 : 0;
+                    int64_t carry = 0, total = 0;
+                    for (int s = 0; s < nslot; ++s) {
+                        const int pn = s * 16 + rl;
+                        const bool in = pn < P && pn != tpi && pn >= start;
+                        const int64_t w = in ? s_ti[pn] : 0;
+                        const int64_t pre = row_iscan(w) + carry;
+                        const int q = row_min(spi < 0 && in && !((double)pre < rr_) ? rl : 16);
+                        if (spi < 0 && q < 16) { spi = s * 16 + q; total = rowget_i64(pre, q); }
+                        carry = rowget_i64(pre, 15);
+                    }
+                    if (spi < 0) { spi = P - 1; total = carry; }   // clamp at n-1 (may equal skip only then)
+                    const int64_t wi = s_ti[spi];
+                    if (evm && wi == 0) err = Q_ERR_ZERO_WEIGHT + 256 * 10;
+                    rm = (rr_ - (double)(total - wi)) / (double)wi;
+                }
+                // haplotype by fastChoose(infectious[spi], totalInfectious[spi], rn): int64 weights over the occupancy list
+                // (integer prefix sums are order-free: tile sums pick the 64-entry tile, then its four chunks)
+                int hi = 0;
+                {
+                    const int n = evm ? s_nocc[spi] : 0;
+                    const int32_t *lh2 = lhap + (int64_t)spi * cap;
+                    const int64_t *ln2 = lcnt + (int64_t)spi * cap;
+                    const int64_t *lt2 = ltsum + (int64_t)spi * capT;
+                    const double rr_ = (double)s_ti[spi] * rm;
+                    int64_t before = 0;
+                    int base = 0;
+                    bool none = false;
+                    const int maxn2 = rows_max(n);
+                    if (maxn2 > 64) {
+                        const int nt = n > 64 ? (n + 63) >> 6 : 0;     // tile sums exist only for lists longer than a tile
+                        const int maxt = rows_max(nt);
+                        int jt = -1;
+                        int64_t carry = 0;
+                        for (int tb = 0; tb < maxt; tb += 16) {
+                            const int j = tb + rl;
+                            const int64_t w = j < nt ? lt2[j] : 0;
+                            const int64_t pre = row_iscan(w) + carry;
+                            const int q = row_min(jt < 0 && j < nt && !((double)pre < rr_) ? rl : 16);
+                            if (jt < 0 && q < 16) { jt = tb + q; before = rowget_i64(pre, q) - rowget_i64(w, q); }
+                            carry = rowget_i64(pre, 15);
+                        }
+                        if (nt > 0) { if (jt < 0) { none = true; before = carry; } else base = jt * 64; }
+                    }
+                    int kq = -1;
+                    int64_t total = before, wi = 0;
+                    {
+                        int64_t carry = before;
+                        for (int c4 = 0; c4 < 4; ++c4) {
+                            const int k = base + c4 * 16 + rl;
+                            const bool in = !none && k < n;
+                            const int64_t w = in ? ln2[k] : 0;
+                            const int64_t pre = row_iscan(w) + carry;
+                            const int q = row_min(kq < 0 && in && !((double)pre < rr_) ? rl : 16);
+                            if (kq < 0 && q < 16) { kq = k - rl + q; total = rowget_i64(pre, q); wi = rowget_i64(w, q); }
+                            carry = rowget_i64(pre, 15);
+                            if (!__ballot(evm && kq < 0 && !none && base + (c4 + 1) * 16 < n)) break;
+                        }
+                        if (kq < 0) total = carry;
+                    }
+                    if (evm && kq < 0) {
+                        if (n > 0 && lh2[n - 1] == H - 1) { kq = n - 1; wi = ln2[n - 1]; }
+                        else {
+                            err = Q_ERR_ZERO_WEIGHT + 256 * 11;
+                            if (rl == 0 && r.prof) {
+                                unsigned long long *d = r.prof + rep * VGX_PROF_SLOTS;
+                                d[0] = n; d[1] = spi; d[2] = tpi; d[3] = s_ti[spi]; d[4] = __double_as_longlong(rr_); d[5] = __double_as_longlong(rm);
+                                d[6] = total; d[7] = before; d[8] = maxn2; d[9] = gI; d[10] = s_ti[tpi]; d[11] = n > 0 ? ln2[0] : -1;
+                                d[12] = ev_ptr; d[13] = loops; d[14] = __double_as_longlong(totalMig); d[15] = __double_as_longlong(choose);
+                            }
+                            kq = 0; wi = 1;
+                        }
+                    }
+                    if (kq < 0) { kq = 0; wi = 1; }
+                    rm = (rr_ - (double)(total - wi)) / (double)wi;
+                    hi = (evm && n > 0) ? lh2[kq] : 0;
+                }
+                // susceptibility group of the target (one group): fastChoose(susceptible[tpi, :], totalSusceptible[tpi], rn)
+                {
+                    const int64_t wi = s_ts[tpi];
+                    const double rr_ = (double)wi * rm;
+                    if (evm && wi == 0 && err == 0) err = Q_ERR_ZERO_WEIGHT + 256 * 12;
+                    rm = (rr_ - (double)(wi - wi)) / (double)wi;
+                }
+                const bool mgo = evm && err == 0;
+                if (mgo) {
+                    const double p_accept = qa.effMig[(int64_t)spi * P + tpi] * p.bRate[hi] * p.susc[hi] / k_mebm[tpi];
+                    if (rm < p_accept) {
+                        if (rl == 0) { s_ts[tpi] -= 1; s_ti[tpi] += 1; }     // NewInfections (pyx:246-251)
+                        gI += 1; cMigP += 1;
+                        op_n = 1; op_pi = tpi; op_h0 = hi; op_d0 = +1;
+                        e_type = QEV_MIGRATION; e_hap = hi; e_pop = spi; e_nh = 0; e_np = tpi;
+                        u_lo = tpi; u_hi = tpi + 1;
+                    } else {
+                        cMigN += 1;
+                    }
+                }
+            }
+            WSYNC();
+        }
+
+        // ================= deferred list operations: infectious[op_pi, hap] += delta, list kept ordered =================
+        if (err != 0) op_n = 0;
+        for (int oi = 0; oi < 2; ++oi) {
+            const bool act = live && oi < op_n;
+            if (!__ballot(act)) break;
+            const int hap = oi == 0 ? op_h0 : op_h1;
+            const int delta = oi == 0 ? op_d0 : -1;
+            const int n = act ? s_nocc[op_pi] : 0;
+            int32_t *lh = lhap + (int64_t)op_pi * cap;
+            int32_t *lc = lcls + (int64_t)op_pi * cap;
+            int64_t *ln = lcnt + (int64_t)op_pi * cap;
+            int64_t *lt = ltsum + (int64_t)op_pi * capT;
+            // ---- lower bound: first index whose haplotype is >= hap ----
+            int posn = 0;
+            bool found = false;
+            int64_t cur = 0;
+            {
+                int lo = 0;             // first entry of the 16^k-aligned window known to contain the bound
+                const int maxn = rows_max(n);
+                // 16-ary descent over the sorted list: strides 16^5 ... 16, 1
+                for (int stride = 1 << 20; stride >= 1; stride >>= 4) {
+                    if (stride >= 16 && maxn <= stride) continue;
+                    const int k = lo + rl * stride;
+                    const int h = (act && k < n) ? lh[k] : 0x7fffffff;
+                    // probes are sorted: the first lane with h > hap = the number of probes <= hap; the bound lies at or
+                    // after the last of those and before the next probe
+                    const int nle = row_min(h <= hap ? 16 : rl);
+                    if (stride == 1) {
+                        const int q = row_min(h >= hap ? rl : 16);
+                        posn = lo + q;
+                        if (posn > n) posn = n;
+                        const int hq = rowget_i32(h, min(q, 15));
+                        found = q < 16 && hq == hap;
+                    } else {
+                        lo = lo + (nle > 0 ? (nle - 1) * stride : 0);
+                    }
+                }
+                if (act && found) cur = ln[posn];
+            }
+            const bool bump = act && found && cur + delta != 0;       // count changes in place
+            const bool rem = act && found && cur + delta == 0;        // the entry disappears
+            const bool ins = act && !found;                           // a new entry (delta = +1)
+            if (ins && n >= cap) { err = Q_ERR_CAPACITY; }
+            const bool ins_ok = ins && err == 0;
+            if (bump && rl == 0) { ln[posn] = cur + delta; if (n > 64) lt[posn >> 6] += delta; }
+            // ---- tile sums of lists longer than one tile (vgx_direct.hip list_insert_at / list_remove_at) ----
+            if (__ballot((ins_ok || rem) && n > 64)) {
+                const bool tt = (ins_ok || rem) && n > 64;
+                const int jp = posn >> 6, jl = ins_ok ? (n >> 6) : ((n - 1) >> 6);
+                const int maxj = rows_max(tt ? jl + 1 : 0);
+                for (int tb = 0; tb < maxj; tb += 16) {
+                    const int j = tb + rl;
+                    if (tt && j >= jp && j <= jl) {
+                        int64_t in_, out_;
+                        if (ins_ok) {
+                            in_ = j == jp ? (int64_t)delta : ln[(int64_t)j * 64 - 1];
+                            const int kout = j * 64 + 63;
+                            out_ = kout < n ? ln[kout] : 0;
+                        } else {
+                            out_ = j == jp ? ln[posn] : ln[(int64_t)j * 64];
+                            const int kin = j * 64 + 64;
+                            in_ = kin < n ? ln[kin] : 0;
+                        }
+                        lt[j] += in_ - out_;
+                    }
+                }
+                WSYNC();
+            }
+            // ---- shift: insertion moves [posn, n) one slot up (highest block first), removal (posn, n) one slot down ----
+            if (__ballot(ins_ok)) {
+                enum { SU = 4 };
+                int hi_ = ins_ok ? n : 0;
+                const int lo_ = ins_ok ? posn : 0;
+                while (__ballot(hi_ > lo_)) {
+                    const int blo = max(lo_, hi_ - SU * 16);
+                    int h[SU];
+                    int64_t ct[SU];
+#pragma unroll
+                    for (int u = 0; u < SU; ++u) {
+                        const int k = blo + u * 16 + rl;
+                        h[u] = 0; ct[u] = 0;
+                        if (k < hi_) { h[u] = lh[k]; ct[u] = ln[k]; }
+                    }
+                    WSYNC();
+#pragma unroll
+                    for (int u = 0; u < SU; ++u) {
+                        const int k = blo + u * 16 + rl;
+                        if (k < hi_) { lh[k + 1] = h[u]; lc[k + 1] = 0; ln[k + 1] = ct[u]; }
+                    }
+                    WSYNC();
+                    hi_ = blo;
+                }
+                if (ins_ok && rl == 0) { lh[posn] = hap; lc[posn] = 0; ln[posn] = delta; s_nocc[op_pi] = n + 1; }
+                WSYNC();
+                if (ins_ok && n == 64) {   // the list outgrows one tile: start its tile sums
+                    int64_t s0 = 0;
+                    for (int c4 = 0; c4 < 4; ++c4) s0 += rowget_i64(row_iscan(ln[c4 * 16 + rl]), 15);
+                    if (rl == 0) { lt[0] = s0; lt[1] = ln[64]; }
+                }
+                WSYNC();
+            }
+            if (__ballot(rem)) {
+                enum { SU = 4 };
+                int lo_ = rem ? posn + 1 : 0;
+                const int hi_ = rem ? n : 0;
+                while (__ballot(lo_ < hi_)) {
+                    int h[SU];
+                    int64_t ct[SU];
+#pragma unroll
+                    for (int u = 0; u < SU; ++u) {
+                        const int k = lo_ + u * 16 + rl;
+                        h[u] = 0; ct[u] = 0;
+                        if (k < hi_) { h[u] = lh[k]; ct[u] = ln[k]; }
+                    }
+                    WSYNC();
+#pragma unroll
+                    for (int u = 0; u < SU; ++u) {
+                        const int k = lo_ + u * 16 + rl;
+                        if (k < hi_) { lh[k - 1] = h[u]; ln[k - 1] = ct[u]; }
+                    }
+                    WSYNC();
+                    lo_ += SU * 16;
+                }
+                if (rem && rl == 0) s_nocc[op_pi] = n - 1;
+                WSYNC();
+            }
+        }
+
+        // ================= Events.AddEvent (events.pxi:37-44) =================
+        if (err == 0 && e_type >= 0) {
+            if (a.record_events) {
+                const int64_t slot = ev_ptr - r.ev_base;
+                if (slot >= 0 && slot < r.evcap) {
+                    if (live) {
+                        const int64_t key = (att << 40) | att_loops;
+                        if (rl < VGX_EV_COLS) {
+                            const int v = rl == 0 ? e_type : rl == 1 ? e_hap : rl == 2 ? e_pop : rl == 3 ? e_nh : rl == 4 ? e_np
+                                                                                                          : (int)(uint32_t)key;
+                            ev_cols[slot * VGX_EV_COLS + rl] = v;
+                        } else if (rl == VGX_EV_COLS) {
+                            ev_rate[slot] = den;
+                        }
+                    }
+                } else {
+                    err = Q_ERR_CAPACITY;
+                }
+            }
+            ev_ptr += 1;
+        }
+
+        // ================= UpdateRates for [u_lo, u_hi) (pyx:516-546) / UpdateAllRates (pyx:279-351) =================
+        if (err != 0) u_hi = u_lo;
+        const int maxu = rows_max(u_hi - u_lo);
+        if (maxu > 0) {
+            for (int us = 0; us < maxu; ++us) {
+                const int pn0 = u_lo + us;
+                const bool act = pn0 < u_hi;
+                const int pi = act ? pn0 : 0;
+                // BirthRate of the class (pyx:382-392): ps += ((x*m)*m*cd)/as over the source populations, in order
+                const double x = (double)s_ts[pi] * c_sig;
+                const double *mrow = p.mig + (int64_t)pi * P;
+                double ps = 0.0;
+                for (int s = 0; s < nslot; ++s) {
+                    const int pn = s * 16 + rl;
+                    double tv = 0.0;
+                    if (pn < P) { const double m = mrow[pn]; tv = x * m * m * k_cd[pn] / k_as[pn]; }
+                    ps = row_sum16(tv, ps);
+                }
+                const double bC = c_b * ps;
+                const double tE = ((bC + c_d) + k_smul[pi]) + c_tm;
+                // infectPopRate[pi]: tE * infectious over the occupied haplotypes, in haplotype order (pyx:519-528)
+                const int n = act ? s_nocc[pi] : 0;
+                const int64_t *ln = lcnt + (int64_t)pi * cap;
+                const int maxn = rows_max(n);
+                double acc = 0.0;
+                if (maxn <= 16) {
+                    const double w = rl < n ? tE * (double)ln[rl] : 0.0;
+                    acc = row_sum16(w, 0.0);
+                } else {
+                    enum { QD = 8 };
+                    int64_t buf[QD];
+#pragma unroll
+                    for (int d = 0; d < QD; ++d) { const int k = d * 16 + rl; buf[d] = k < n ? ln[k] : 0; }
+                    for (int cb = 0; cb * 16 < maxn; cb += QD) {
+#pragma unroll
+                        for (int d = 0; d < QD; ++d) {
+                            const int c = cb + d;
+                            const int64_t cn = buf[d];
+                            const int kn = (c + QD) * 16 + rl;
+                            buf[d] = kn < n ? ln[kn] : 0;
+                            const double w = (c * 16 + rl < n) ? tE * (double)cn : 0.0;
+                            acc = row_sum16(w, acc);
+                        }
+                    }
+                }
+                if (act && rl == 0) { s_bc[pi] = bC; s_inf[pi] = acc; }
+                WSYNC();
+            }
+            // totalRate and the serial prefix sums of popRate (pyx:537-539)
+            {
+                double carry = 0.0;
+                for (int s = 0; s < nslot; ++s) {
+                    const int pn = s * 16 + rl;
+                    const double w = pn < P ? s_inf[pn] : 0.0;
+                    const double pre = row_scan16(w, carry);
+                    if (pn < P && u_hi > u_lo) s_cum[pn] = pre;
+                    carry = row_last(pre);
+                }
+                WSYNC();
+                if (u_hi > u_lo) totalRate = s_cum[P - 1];
+            }
+            // totalMigrationRate = sum of maxEffectiveBirthMigration * totalSusceptible * (globalInfectious - totalInfectious)
+            if (has_mig) {
+                double acc = 0.0;
+                for (int s = 0; s < nslot; ++s) {
+                    const int pn = s * 16 + rl;
+                    const double w = pn < P ? k_mebm[pn] * (double)s_ts[pn] * (double)(gI - s_ti[pn]) : 0.0;
+                    acc = row_sum16(w, acc);
+                }
+                if (u_hi > u_lo) totalMig = acc;
+            }
+        }
+
+        // ================= after the pass =================
+        if (rebuild && st == ST_REBUILD) st = err ? ST_DONE : ST_RUN;
+        if (err != 0) st = ST_DONE;
+        if (ev && st == ST_RUN && (totalRate == 0.0 || gI == 0)) end_attempt = true;   // pyx:410-411
+        if (st == ST_RUN && end_attempt) {
+            // end of an attempt (pyx:414-418)
+            open = false;
+            if (ev_ptr <= 100 && a.iterations > 100) {
+                // Restart (pyx:714-738): compartments back to the initial snapshot, then UpdateAllRates
+                ev_ptr = 0; cB = cD = cS = cM = cMigP = cMigN = 0;
+                t_now = 0.0; traj_next = 0;
+                restarts += 1; att += 1;
+                st = ST_REBUILD;
+            } else {
+                good_attempt = att + 1;
+                st = ST_DONE;
+            }
+        }
+        if (__ballot(st == ST_REBUILD && restarts > 0 && !rebuild)) {
+            const bool rs = st == ST_REBUILD && restarts > 0 && !rebuild && live;
+            int64_t g = 0;
+            for (int pn = 0; pn < P; ++pn) {
+                const int n = r.i_nocc[pn];
+                const int n_old = rs ? s_nocc[pn] : 0;
+                int64_t ti = 0;
+                for (int base = 0; base < n; base += 64) {
+                    int64_t tsum = 0;
+                    for (int c4 = 0; c4 < 4; ++c4) {
+                        const int k = base + c4 * 16 + rl;
+                        int64_t ct = 0;
+                        if (k < n) {
+                            ct = r.i_cnt[(int64_t)pn * r.i_cap + k];
+                            if (rs) {
+                                lhap[(int64_t)pn * cap + k] = r.i_hap[(int64_t)pn * r.i_cap + k];
+                                lcls[(int64_t)pn * cap + k] = r.i_cls[(int64_t)pn * r.i_cap + k];
+                                lcnt[(int64_t)pn * cap + k] = ct;
+                            }
+                        }
+                        tsum += rowget_i64(row_iscan(ct), 15);
+                    }
+                    if (rs && rl == 0) ltsum[(int64_t)pn * capT + base / 64] = tsum;
+                    ti += tsum;
+                }
+                if (rs)
+                    for (int j = (n + 63) / 64 + rl; j <= n_old / 64 && j < capT; j += 16) ltsum[(int64_t)pn * capT + j] = 0;
+                if (rs && rl == 0) { s_nocc[pn] = n; s_ts[pn] = r.i_sus[pn]; s_ti[pn] = ti; }
+                g += ti;
+            }
+            if (rs) gI = g;
+            WSYNC();
+        }
+    }
+
+    // trailing grid points of the trajectories: the final state
+    if (traj) {
+        while (true) {
+            const bool emit = live && traj_next < r.traj_points;
+            if (!__ballot(emit)) break;
+            if (emit) {
+                double *o = traj + traj_next * (int64_t)P * 2;
+                for (int s = 0; s < nslot; ++s) {
+                    const int pn = s * 16 + rl;
+                    if (pn < P) { o[pn * 2 + 0] = (double)s_ti[pn]; o[pn * 2 + 1] = (double)s_ts[pn]; }
+                }
+                traj_next += 1;
+            }
+        }
+    }
+
+    // ---- state back to HBM ----
+    WSYNC();
+    if (live) {
+        for (int s = 0; s < nslot; ++s) {
+            const int pn = s * 16 + rl;
+            if (pn < P) {
+                gD[PD_POPRATE * P + pn] = s_inf[pn];
+                gD[PD_INFECT * P + pn] = s_inf[pn];
+                gD[PD_IMMUNE * P + pn] = 0.0;
+                gD[PD_MIG * P + pn] = k_mebm[pn] * (double)s_ts[pn] * (double)(gI - s_ti[pn]);
+                gD[PD_MAXEBM * P + pn] = k_mebm[pn];
+                gI64[PI_TOTSUS * P + pn] = s_ts[pn];
+                gI64[PI_TOTINF * P + pn] = s_ti[pn];
+                gN[pn] = s_nocc[pn];
+                r.sus[rep * P + pn] = s_ts[pn];
+                r.immSrc[rep * P + pn] = 0.0;
+            }
+        }
+        if (rl == 0) {
+            sc->currentTime = t_now; sc->totalRate = totalRate; sc->totalMig = totalMig;
+            sc->globalInfectious = gI;
+            sc->bCounter = cB; sc->dCounter = cD; sc->sCounter = cS; sc->mCounter = cM;
+            sc->migPlus = cMigP; sc->migNonPlus = cMigN;
+            sc->good_attempt = good_attempt;
+            sc->ev_ptr = ev_ptr; sc->loop_iterations = loops; sc->restarts = restarts;
+            sc->loc_n = 0; sc->error = err; sc->traj_next = traj_next;
+            sc->last_attempt = last_att; sc->last_attempt_loops = att_loops;
+            sc->fa_n = 0;
+        }
+    }
+}
+
+// ---- host-side launchers ----
+extern "C" __attribute__((visibility("hidden"))) hipError_t vgxi_launch_quad(const VgxDirectArgs *a, const double *cd,
+                                                                            double *effMig, double *maxEBM, int32_t *has_mig,
+                                                                            hipStream_t stream) {
+    hipLaunchKernelGGL(vgx_quad_prep_kernel, dim3(1), dim3(64), 0, stream, a->p, cd, effMig, maxEBM, has_mig);
+    hipError_t err = hipGetLastError();
+    if (err != hipSuccess) return err;
+    QArgs qa;
+    qa.effMig = effMig; qa.maxEBM = maxEBM; qa.has_mig = has_mig;
+    const unsigned grid = (unsigned)((a->n_replicates + 3) / 4);
+    hipLaunchKernelGGL(vgx_quad_kernel, dim3(grid), dim3(64), Q_LDS_BYTES, stream, *a, qa);
+    return hipGetLastError();
+}

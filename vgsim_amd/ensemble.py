@@ -75,7 +75,7 @@ class Ensemble:
         o.traj_points = int(traj_points)
         o.traj_t0, o.traj_t1 = float(traj_window[0]), float(traj_window[1])
         o.mode = 1 if mode == 'fast' else 0
-        o.kernel = {'auto': 0, 'wave': 1, 'lane': 2}[kernel]
+        o.kernel = {'auto': 0, 'wave': 1, 'lane': 2, 'quad': 3}[kernel]
         rc = eng.lib.vgx_simulate_direct(eng.handle, int(iterations), int(sample_size), float(np.float32(epidemic_time)),
                                          int(attempts), C.byref(o))
         eng._check(rc)
