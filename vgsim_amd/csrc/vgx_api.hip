@@ -749,7 +749,9 @@ static int direct_core(vgx_engine *e, int64_t iterations, int64_t sample_size, f
     if (o.kernel == 3 && !quad_ok)
         return fail(e, VGX_ERR_ARG, "vgx_simulate_direct: the four-replicates-per-wavefront kernel needs exact mode, popNum <= 64, "
                                     "one susceptibility group, one rate class and no possible lockdown switch");
-    const bool use_quad = o.kernel == 3 || (o.kernel == 0 && quad_ok && !use_lanes && R >= 4);
+    // measured (tools/probe_quad.py): a lone wavefront runs one replicate faster than four (1.4e5 vs 1.1e5 events/s per
+    // replicate at config 3), so the row kernel pays from about one wavefront per SIMD upwards
+    const bool use_quad = o.kernel == 3 || (o.kernel == 0 && quad_ok && !use_lanes && R >= 2048);
     VgxLaneWs ws{};
     a.r.rec = nullptr; a.r.rec_cap = 0;
     e->rec_cap = 0;

@@ -27,6 +27,23 @@
 #include "vgx_rng.h"
 #include "vgx_wave.h"
 
+#ifndef VGX_QUAD_WAVES
+#define VGX_QUAD_WAVES 2     // waves per SIMD the register allocation aims at (measured: 3 spills into the hot loop and is slower)
+#endif
+
+// In-kernel stamps (diagnostic build only, -DVGX_PROFILE): shader cycles per phase of the loop, summed per wavefront
+// into the debug buffer r.prof of its first replicate.  No stamp executes in the product build.
+#ifdef VGX_PROFILE
+#define QPROF(i)                                                        \
+    do {                                                                \
+        unsigned long long prof_t1 = __builtin_readcyclecounter();      \
+        prof_acc[i] += prof_t1 - prof_t0;                               \
+        prof_t0 = prof_t1;                                              \
+    } while (0)
+#else
+#define QPROF(i)
+#endif
+
 namespace {
 
 enum { Q_ERR_ZERO_WEIGHT = 3, Q_ERR_CAPACITY = 4, Q_ERR_LOOP_GUARD = 5 };
@@ -35,12 +52,15 @@ enum { ST_REBUILD = 0, ST_RUN = 1, ST_DONE = 2 };
 
 // ---- LDS layout (bytes), one wavefront per workgroup ---------------------------------------------------------
 // model constants [64] f64: cd, as, smul (= sRate * samplingMultiplier), maxEBM                      2048
-// random numbers  [4][64] f64: per row 32 x (-log u1, u2)                                            2048
-// per replicate   infect[64], cum[64], birthC[64] f64; totS[64], totI[64] i64; nocc[64] i32          4 x 2816
+// PCG64 jump-ahead [16][4] u64: a^(l+1), 1 + a + ... + a^l (high, low words) for l = 0..15            512
+// per replicate   infect[64], birthC[64] f64; totS[64], totI[64] i64; nocc[64] i32; cc[4] f64 (serial prefix sum of
+//                 popRate at the end of each 16-population slot); counters[8] i64 (births, deaths, mutations,
+//                 accepted / rejected migrations)                                                     4 x 2400
 #define Q_CONST_BYTES 2048
-#define Q_RNG_BYTES 2048
-#define Q_REP_BYTES 2816
+#define Q_RNG_BYTES 512
+#define Q_REP_BYTES 2400
 #define Q_LDS_BYTES (Q_CONST_BYTES + Q_RNG_BYTES + 4 * Q_REP_BYTES)
+enum { QC_B = 0, QC_D, QC_M, QC_MIGP, QC_MIGN };
 
 // ---- row primitives --------------------------------------------------------------------------------------------
 // value of lane (row, j) for a row-uniform j in 0..15 (LDS crossbar, no memory)
@@ -88,25 +108,21 @@ static __device__ __forceinline__ double row_sum16(double v, double acc) {
                  : "v"(v), "v"(one));
     return acc;
 }
-// lane l of each row gets carry + v[0] + ... + v[l] (the serial prefix): the same chain with EXEC narrowed to the lanes
-// l >= k of every row before step k (5 wait states between an EXEC write and a DPP instruction).
-#define QFX(K, M) "s_mov_b32 exec_lo, " #M "\n\ts_mov_b32 exec_hi, " #M "\n\ts_nop 4\n\t" QFM(K)
-static __device__ __forceinline__ double row_scan16(double v, double carry) {
+// lane l of each row gets carry + v[0] + ... + v[l] (the serial prefix): the same chain, each lane keeping the running
+// sum of its own step (the selects are off the chain's critical path); `total` receives carry + v[0] + ... + v[15].
+#define QSTEP(K)                                                                                        \
+    asm volatile(QFM(K) : "+v"(acc) : "v"(v), "v"(one));                                                 \
+    res = rl_ == K ? acc : res;
+static __device__ __forceinline__ double row_scan16(double v, double carry, double &total) {
     const double one = 1.0;
-    double acc = carry;
-    asm volatile("s_nop 1\n\t" QFM(0) QFX(1, 0xfffefffe) QFX(2, 0xfffcfffc) QFX(3, 0xfff8fff8) QFX(4, 0xfff0fff0)
-                     QFX(5, 0xffe0ffe0) QFX(6, 0xffc0ffc0) QFX(7, 0xff80ff80) QFX(8, 0xff00ff00) QFX(9, 0xfe00fe00)
-                         QFX(10, 0xfc00fc00) QFX(11, 0xf800f800) QFX(12, 0xf000f000) QFX(13, 0xe000e000)
-                             QFX(14, 0xc000c000) QFX(15, 0x80008000) "s_mov_b64 exec, -1\n\t"
-                 : "+v"(acc)
-                 : "v"(v), "v"(one));
-    return acc;
-}
-// value of lane 15 of each row in all its lanes (the chunk total after row_scan16)
-static __device__ __forceinline__ double row_last(double v) {
-    int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x15F, 0xf, 0xf, false);   // row_newbcast:15
-    int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x15F, 0xf, 0xf, false);
-    return __hiloint2double(hi, lo);
+    const int rl_ = threadIdx.x & 15;
+    double acc = carry, res = carry;
+    asm volatile("s_nop 1\n\t" QFM(0) : "+v"(acc) : "v"(v), "v"(one));
+    res = rl_ == 0 ? acc : res;
+    QSTEP(1) QSTEP(2) QSTEP(3) QSTEP(4) QSTEP(5) QSTEP(6) QSTEP(7) QSTEP(8) QSTEP(9) QSTEP(10) QSTEP(11) QSTEP(12)
+    QSTEP(13) QSTEP(14) QSTEP(15)
+    total = acc;
+    return res;
 }
 
 struct QArgs {          // what the prep kernel leaves for all replicates
@@ -139,7 +155,7 @@ extern "C" __global__ void __launch_bounds__(64) vgx_quad_prep_kernel(VgxDevPara
     if (threadIdx.x == 0) *has_mig = any != 0ull ? 1 : 0;
 }
 
-extern "C" __global__ void __launch_bounds__(64) vgx_quad_kernel(VgxDirectArgs a, QArgs qa) {
+extern "C" __global__ void __launch_bounds__(64, VGX_QUAD_WAVES) vgx_quad_kernel(VgxDirectArgs a, QArgs qa) {
     const int lane = threadIdx.x, row = lane >> 4, rl = lane & 15;
     const VgxDevParams &p = a.p;
     const VgxDevRep &r = a.r;
@@ -153,11 +169,14 @@ extern "C" __global__ void __launch_bounds__(64) vgx_quad_kernel(VgxDirectArgs a
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double *k_cd = (double *)smem, *k_as = k_cd + 64, *k_smul = k_as + 64, *k_mebm = k_smul + 64;
-    double *rbuf = (double *)(smem + Q_CONST_BYTES) + row * 64;
+    uint64_t *k_jump = (uint64_t *)(smem + Q_CONST_BYTES) + rl * 4;
     unsigned char *blk = smem + Q_CONST_BYTES + Q_RNG_BYTES + row * Q_REP_BYTES;
-    double *s_inf = (double *)blk, *s_cum = s_inf + 64, *s_bc = s_cum + 64;
+    double *s_inf = (double *)blk, *s_bc = s_inf + 64;
     int64_t *s_ts = (int64_t *)(s_bc + 64), *s_ti = s_ts + 64;
     int32_t *s_nocc = (int32_t *)(s_ti + 64);
+    double *s_cc = (double *)(s_nocc + 64);
+    int64_t *s_cnt = (int64_t *)(s_cc + 4);
+#define QBUMP(i) do { if (rl == 0) s_cnt[i] += 1; } while (0)
 
     // the single rate class
     const double c_b = p.cb_b[0], c_sig = p.cb_sigma[0], c_d = p.c_d[0], c_s = p.c_s[0], c_tm = p.c_tm[0];
@@ -176,7 +195,8 @@ extern "C" __global__ void __launch_bounds__(64) vgx_quad_kernel(VgxDirectArgs a
     for (int s = 0; s < 4; ++s) {
         const int pn = s * 16 + rl;
         const bool ok = pn < P;
-        s_inf[pn] = 0.0; s_cum[pn] = 0.0; s_bc[pn] = 0.0;
+        s_inf[pn] = 0.0; s_bc[pn] = 0.0;
+        if (rl < 4) s_cc[rl] = 0.0;
         s_ts[pn] = ok ? gI64[PI_TOTSUS * P + pn] : 0;
         s_ti[pn] = ok ? gI64[PI_TOTINF * P + pn] : 0;
         s_nocc[pn] = ok ? gN[pn] : 0;
@@ -195,7 +215,11 @@ extern "C" __global__ void __launch_bounds__(64) vgx_quad_kernel(VgxDirectArgs a
 
     double t_now = sc->currentTime, totalRate = 0.0, totalMig = 0.0;
     int64_t gI = sc->globalInfectious, ev_ptr = sc->ev_ptr;
-    int64_t cB = sc->bCounter, cD = sc->dCounter, cS = sc->sCounter, cM = sc->mCounter, cMigP = sc->migPlus, cMigN = sc->migNonPlus;
+    int64_t cS = sc->sCounter;
+    if (rl == 0) {
+        s_cnt[QC_B] = sc->bCounter; s_cnt[QC_D] = sc->dCounter; s_cnt[QC_M] = sc->mCounter;
+        s_cnt[QC_MIGP] = sc->migPlus; s_cnt[QC_MIGN] = sc->migNonPlus;
+    }
     int64_t loops = 0, att_loops = 0, att = 0, restarts = 0, good_attempt = sc->good_attempt, last_att = -1, traj_next = 0;
     int st = live ? ST_REBUILD : ST_DONE, err = 0;
     bool open = false;
@@ -203,24 +227,34 @@ extern "C" __global__ void __launch_bounds__(64) vgx_quad_kernel(VgxDirectArgs a
     const double tlimit = (double)a.time;
     const bool has_tl = !(a.time == -1.0f);
 
-    // random stream of the row: 64 outputs per refill by lane-parallel jump-ahead (vgx_direct.hip rng_refill)
-    uint64_t jAh, jAl, jGh, jGl;
-    {
+    // random stream of the row: 16 outputs (8 loop iterations) per refill, lane l of the row jumping l+1 steps ahead
+    // (state * a^(l+1) + inc * (1 + a + ... + a^l), exact 128-bit arithmetic): the uniforms are the reference's, in order.
+    // Even lanes hold -log(u) for SampleTime (pyx:477), odd lanes the uniform of GenerateEvent (pyx:488).
+    if (row == 0) {
         const uint64_t MH = 0x2360ED051FC65DA4ull, ML = 0x4385DF649FCCF645ull;
         uint64_t Ah = MH, Al = ML, Gh = 0, Gl = 1;
-        for (int j = 1; j < 64; ++j) {
+        for (int j = 1; j < 16; ++j) {
             uint64_t nh, nl, gh, gl;
             vgx_mul128(Ah, Al, MH, ML, nh, nl);
             vgx_mul128(Gh, Gl, MH, ML, gh, gl);
             vgx_add128(gh, gl, 0, 1);
-            if (j <= lane) { Ah = nh; Al = nl; Gh = gh; Gl = gl; }
+            if (j <= rl) { Ah = nh; Al = nl; Gh = gh; Gl = gl; }
         }
-        jAh = Ah; jAl = Al; jGh = Gh; jGl = Gl;
+        k_jump[0] = Ah; k_jump[1] = Al; k_jump[2] = Gh; k_jump[3] = Gl;
     }
+    WSYNC();
     uint64_t g_sh = 0, g_sl = 0, g_ih = 0, g_il = 0;   // row-uniform: stream position, increment
-    int pos = 32;                                      // iterations consumed from the row's batch (32 = empty)
+    double g_val = 0.0;                                // this lane's output of the current batch
+    int pos = 8;                                       // iterations consumed from the row's batch (8 = empty)
+    // a list of up to 64 entries read for the haplotype choice stays in registers for the rate refresh
+    int64_t ch_cn[4] = {0, 0, 0, 0};
 
+#ifdef VGX_PROFILE
+    unsigned long long prof_acc[VGX_PROF_SLOTS], prof_t0 = __builtin_readcyclecounter();
+    for (int i = 0; i < VGX_PROF_SLOTS; ++i) prof_acc[i] = 0;
+#endif
     while (true) {
+        QPROF(0);
         const bool run = st != ST_DONE;
         if (!__ballot(run)) break;
         const bool rebuild = st == ST_REBUILD;
@@ -235,7 +269,7 @@ extern "C" __global__ void __launch_bounds__(64) vgx_quad_kernel(VgxDirectArgs a
                     VgxPcg64 sd;
                     vgx_pcg64_seed(sd, (uint64_t)seed, (uint32_t)att);
                     g_sh = sd.sh; g_sl = sd.sl; g_ih = sd.ih; g_il = sd.il;
-                    pos = 32;
+                    pos = 8;
                     open = true;
                     last_att = att; att_loops = 0;
                     if (!(totalRate + totalMig != 0.0 && gI != 0)) end_attempt = true;   // pyx:404
@@ -258,29 +292,28 @@ extern "C" __global__ void __launch_bounds__(64) vgx_quad_kernel(VgxDirectArgs a
         int op_d0 = 0;
         int e_type = -1, e_hap = 0, e_pop = 0, e_nh = 0, e_np = 0;
         double den = 0.0;
+        int ch_pi = -1;           // population whose list (<= 64 entries) ch_cn holds, as it stands after the event; -1: none
+        double m_pre[4] = {0.0, 0.0, 0.0, 0.0};   // migrationRates[pm_pi, :] of the event's population, loaded with its list
+        int pm_pi = -1;
 
+        QPROF(1);
         if (__ballot(ev)) {
             // ---- random numbers: refill the batch of every row that ran dry ----
-#pragma unroll
-            for (int rr = 0; rr < 4; ++rr) {
-                const int need = __builtin_amdgcn_readlane((int)(ev && pos == 32), rr * 16);
-                if (need) {
-                    const uint64_t sh = (uint64_t)bcast_i64((int64_t)g_sh, rr * 16), sl = (uint64_t)bcast_i64((int64_t)g_sl, rr * 16);
-                    const uint64_t ih = (uint64_t)bcast_i64((int64_t)g_ih, rr * 16), il = (uint64_t)bcast_i64((int64_t)g_il, rr * 16);
-                    uint64_t h, l, ch, cl;
-                    vgx_mul128(jAh, jAl, sh, sl, h, l);
-                    vgx_mul128(jGh, jGl, ih, il, ch, cl);
-                    vgx_add128(h, l, ch, cl);
-                    const double u = vgx_pcg64_output_double(h, l);
-                    ((double *)(smem + Q_CONST_BYTES))[rr * 64 + lane] = (lane & 1) ? u : -vgx_log(u);
-                    const uint64_t nh = (uint64_t)bcast_i64((int64_t)h, 63), nl = (uint64_t)bcast_i64((int64_t)l, 63);
-                    if (row == rr) { g_sh = nh; g_sl = nl; pos = 0; }
-                }
+            if (__ballot(ev && pos == 8)) {
+                const bool fill = ev && pos == 8;
+                uint64_t h, l, ch, cl;
+                vgx_mul128(k_jump[0], k_jump[1], g_sh, g_sl, h, l);
+                vgx_mul128(k_jump[2], k_jump[3], g_ih, g_il, ch, cl);
+                vgx_add128(h, l, ch, cl);
+                const double u = vgx_pcg64_output_double(h, l);
+                const double v = (rl & 1) ? u : -vgx_log(u);
+                const uint64_t nh = (uint64_t)rowget_i64((int64_t)h, 15), nl = (uint64_t)rowget_i64((int64_t)l, 15);
+                if (fill) { g_val = v; g_sh = nh; g_sl = nl; pos = 0; }
             }
-            WSYNC();
-            const int pp = min(pos, 31);
-            const double nlog = rbuf[2 * pp], u2 = rbuf[2 * pp + 1];
+            const int pp = min(pos, 7);
+            const double nlog = rowget_f64(g_val, 2 * pp), u2 = rowget_f64(g_val, 2 * pp + 1);
             if (ev) { pos += 1; loops += 1; att_loops += 1; }
+            QPROF(2);
             den = totalRate + totalMig;
             const double t_new = t_now + (nlog / den);   // SampleTime pyx:476-478
             // summary trajectories: the state before the event for every grid point the step passes
@@ -301,6 +334,7 @@ extern "C" __global__ void __launch_bounds__(64) vgx_quad_kernel(VgxDirectArgs a
             }
             if (ev) t_now = t_new;
 
+            QPROF(3);
             // ================= GenerateEvent (pyx:483-512) =================
             double rn = u2;
             const double choose0 = rn * den;               // kept for the migration branch (pyx:490 / pyx:512)
@@ -308,19 +342,24 @@ extern "C" __global__ void __launch_bounds__(64) vgx_quad_kernel(VgxDirectArgs a
             const bool evn = ev && (totalRate > choose);   // an event inside a population
             const bool evm = ev && !evn;                   // a migration attempt
 
-            // ---- population by fastChoose over popRate = infectPopRate (cached serial prefix sums, fc:18-31) ----
+            // ---- population by fastChoose over popRate = infectPopRate (fc:18-31).  The serial prefix sums at the end of
+            // every 16-population slot are cached (they are partial sums of the totalRate loop, pyx:537-539): the first slot
+            // whose end reaches r holds the pick, and the prefix sums inside it are formed again — same additions, same order.
             int pi = 0;
             {
                 rn = choose / totalRate;
                 const double rr_ = totalRate * rn;
-                int cand = 64;
-                for (int s = 0; s < nslot; ++s) {
-                    const int pn = s * 16 + rl;
-                    if (pn < P && !(s_cum[pn] < rr_)) cand = min(cand, pn);
-                }
-                cand = row_min(cand);
-                pi = cand < 64 ? cand : P - 1;       // clamp at n-1 (fc:26)
-                const double total = s_cum[pi], wi = s_inf[pi];
+                const double c0 = s_cc[0], c1 = s_cc[1], c2 = s_cc[2], c3 = s_cc[3];   // slots beyond P repeat the total
+                const int slot = !(c0 < rr_) ? 0 : !(c1 < rr_) ? 1 : !(c2 < rr_) ? 2 : 3;
+                const bool any = !(c3 < rr_);
+                const double cin = slot == 0 ? 0.0 : slot == 1 ? c0 : slot == 2 ? c1 : c2;
+                const double w = s_inf[slot * 16 + rl];
+                double tot_;
+                const double pre = row_scan16(w, cin, tot_);
+                const int q = row_min(any && slot * 16 + rl < P && !(pre < rr_) ? rl : 16);
+                double total, wi;
+                if (q < 16) { pi = slot * 16 + q; total = rowget_f64(pre, q); wi = rowget_f64(w, q); }
+                else { pi = P - 1; total = c3; wi = s_inf[P - 1]; }       // clamp at n-1 (fc:26)
                 if (evn && wi == 0.0) err = Q_ERR_ZERO_WEIGHT + 256 * 1;
                 rn = (rr_ - (total - wi)) / wi;
                 choose = rn * wi;                    // pyx:493: rn * popRate[pi]
@@ -335,7 +374,15 @@ extern "C" __global__ void __launch_bounds__(64) vgx_quad_kernel(VgxDirectArgs a
             const int32_t *lh = lhap + (int64_t)pi * cap;
             int64_t *ln = lcnt + (int64_t)pi * cap;
             int64_t *lt = ltsum + (int64_t)pi * capT;
+            {   // row pi of the migration matrix for the BirthRate refresh: in flight together with the list
+                const double *mrow = p.mig + (int64_t)pi * P;
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+                    if (s < nslot) m_pre[s] = mrow[min(s * 16 + rl, P - 1)];
+                pm_pi = evn ? pi : -1;
+            }
 
+            QPROF(4);
             // ---- haplotype by fastChoose over hapPopRate[pi] = tE * infectious in haplotype order ----
             const double r2 = infect_pi * rn;
             int k_hit = -1;          // list index of the chosen entry
@@ -343,21 +390,58 @@ extern "C" __global__ void __launch_bounds__(64) vgx_quad_kernel(VgxDirectArgs a
             int hap_hit = 0;
             int64_t cnt_hit = 0;
             const int maxn = rows_max(n_sel);
-            if (maxn <= 16) {
-                const bool in = rl < n_sel;
-                const int64_t cn = in ? ln[rl] : 0;
-                const int hp = in ? lh[rl] : 0;
-                const double w = in ? tE * (double)cn : 0.0;
-                const double pre = row_scan16(w, 0.0);
-                const int q = row_min(in && !(pre < r2) ? rl : 16);
-                const int qq = q < 16 ? q : max(n_sel - 1, 0);
-                pre_hit = rowget_f64(pre, qq); w_hit = rowget_f64(w, qq);
+            if (maxn <= 64) {
+                // the lists fit four register chunks: all loads in flight together (unconditional, on clamped indices)
+                const int nch = (maxn + 15) >> 4;
+                const int last = max(n_sel - 1, 0);
+                int64_t cn4[4];
+                int hp4[4];
+                double w4[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    cn4[c] = 0; hp4[c] = 0; w4[c] = 0.0;
+                    if (c < nch) {
+                        const int k = c * 16 + rl;
+                        cn4[c] = ln[min(k, last)];
+                        hp4[c] = lh[min(k, last)];
+                        w4[c] = k < n_sel ? tE * (double)cn4[c] : 0.0;
+                    }
+                }
+                // running sum chunk by chunk; the chunk in which it first reaches r is then scanned lane by lane
+                double carry = 0.0, carry_hit = 0.0;
+                int c_hit = nch == 1 ? 0 : -1;
+                if (nch > 1) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        if (c < nch) {
+                            const double acc = row_sum16(w4[c], carry);
+                            if (c_hit < 0 && c * 16 < n_sel && !(acc < r2)) { c_hit = c; carry_hit = carry; }
+                            carry = acc;
+                        }
+                    }
+                }
+                const int cc = c_hit >= 0 ? c_hit : (last >> 4);    // rows without a hit: their last chunk (H-1 rule)
+                const double w = cc == 0 ? w4[0] : cc == 1 ? w4[1] : cc == 2 ? w4[2] : w4[3];
+                const int64_t cn = cc == 0 ? cn4[0] : cc == 1 ? cn4[1] : cc == 2 ? cn4[2] : cn4[3];
+                const int hp = cc == 0 ? hp4[0] : cc == 1 ? hp4[1] : cc == 2 ? hp4[2] : hp4[3];
+                double tot_;
+                const double pre = row_scan16(w, c_hit >= 0 ? carry_hit : 0.0, tot_);
+                if (nch == 1) carry = tot_;
+                const int q = row_min(c_hit >= 0 && cc * 16 + rl < n_sel && !(pre < r2) ? rl : 16);
+                const int qq = q < 16 ? q : (last & 15);
+                pre_hit = q < 16 ? rowget_f64(pre, qq) : carry;      // no hit: the total of the whole list
+                w_hit = rowget_f64(w, qq);
                 hap_hit = rowget_i32(hp, qq); cnt_hit = rowget_i64(cn, qq);
-                if (q < 16) k_hit = q;
+                if (q < 16) k_hit = cc * 16 + q;
                 else if (evn) {
                     // nothing reached r: the dense loop runs on to index H-1 (fc:26), a valid pick only if that haplotype
                     // is occupied, otherwise the reference reports a zero weight
                     if (n_sel > 0 && hap_hit == H - 1) k_hit = n_sel - 1; else err = Q_ERR_ZERO_WEIGHT + 256 * 2;
+                }
+                if (evn) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) ch_cn[c] = cn4[c];
+                    ch_pi = pi;
                 }
             } else {
                 // long lists: the running sum advances one chunk of 16 entries per step; the chunk in which it first
@@ -366,15 +450,17 @@ extern "C" __global__ void __launch_bounds__(64) vgx_quad_kernel(VgxDirectArgs a
                 int64_t buf[QD];
                 double carry = 0.0, carry_hit = 0.0;
                 int c_hit = -1;
+                // (loads are unconditional on a clamped index, so that QD of them stay in flight; entries beyond the list or
+                // after the hit re-read entry 0 and are masked at their use)
 #pragma unroll
-                for (int d = 0; d < QD; ++d) { const int k = d * 16 + rl; buf[d] = k < n_sel ? ln[k] : 0; }
+                for (int d = 0; d < QD; ++d) { const int k = d * 16 + rl; buf[d] = ln[k < n_sel ? k : 0]; }
                 for (int cb = 0; cb * 16 < maxn; cb += QD) {
 #pragma unroll
                     for (int d = 0; d < QD; ++d) {
                         const int c = cb + d;
                         const int64_t cn = buf[d];
                         const int kn = (c + QD) * 16 + rl;
-                        buf[d] = (kn < n_sel && c_hit < 0) ? ln[kn] : 0;
+                        buf[d] = ln[(kn < n_sel && c_hit < 0) ? kn : 0];
                         const double w = (c * 16 + rl < n_sel) ? tE * (double)cn : 0.0;
                         const double acc = row_sum16(w, carry);
                         if (c_hit < 0 && c * 16 < n_sel && !(acc < r2)) { c_hit = c; carry_hit = carry; }
@@ -386,10 +472,11 @@ extern "C" __global__ void __launch_bounds__(64) vgx_quad_kernel(VgxDirectArgs a
                 const int cc = c_hit >= 0 ? c_hit : max((n_sel - 1) >> 4, 0);
                 const int k = cc * 16 + rl;
                 const bool in = k < n_sel;
-                const int64_t cn = in ? ln[k] : 0;
-                const int hp = in ? lh[k] : 0;
+                const int64_t cn = ln[in ? k : 0];
+                const int hp = lh[in ? k : 0];
                 const double w = in ? tE * (double)cn : 0.0;
-                const double pre = row_scan16(w, carry_hit);
+                double tot_;
+                const double pre = row_scan16(w, carry_hit, tot_);
                 const int q = row_min(c_hit >= 0 && in && !(pre < r2) ? rl : 16);
                 const int qq = q < 16 ? q : max(n_sel - 1 - cc * 16, 0);
                 pre_hit = q < 16 ? rowget_f64(pre, qq) : carry;   // no hit: the total of the whole list
@@ -404,6 +491,7 @@ extern "C" __global__ void __launch_bounds__(64) vgx_quad_kernel(VgxDirectArgs a
             if (evn && w_hit == 0.0 && err == 0) err = Q_ERR_ZERO_WEIGHT + 256 * 4;
             rn = (r2 - (pre_hit - w_hit)) / w_hit;
 
+            QPROF(5);
             // ---- event class by fastChoose over (birth, death, sampling, mutation) rates (pyx:503-511) ----
             int ei = 0;
             {
@@ -422,8 +510,11 @@ extern "C" __global__ void __launch_bounds__(64) vgx_quad_kernel(VgxDirectArgs a
                 // ---- Birth (pyx:568-605; one susceptibility group: si = 0, its weight susceptHapPopRate = S * sigma) ----
                 if ((double)ts_pi * c_sig == 0.0) err = Q_ERR_ZERO_WEIGHT + 256 * 6;
                 if (rl == 0) { s_ts[pi] = ts_pi - 1; s_ti[pi] = ti_pi + 1; }
-                gI += 1; cB += 1;
+                gI += 1; QBUMP(QC_B);
                 if (live && rl == 0) { ln[k_hit] = cnt_hit + 1; if (n_sel > 64) lt[k_hit >> 6] += 1; }
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    if (c == (k_hit >> 4) && rl == (k_hit & 15)) ch_cn[c] += 1;
                 e_type = QEV_BIRTH; e_hap = hap_hit; e_pop = pi; e_nh = 0; e_np = H;
                 u_lo = pi; u_hi = pi + 1;
             }
@@ -431,12 +522,18 @@ extern "C" __global__ void __launch_bounds__(64) vgx_quad_kernel(VgxDirectArgs a
                 // ---- Death / Sampling (pyx:616-635): recovery into group suscType = 0 ----
                 if (rl == 0) { s_ts[pi] = ts_pi + 1; s_ti[pi] = ti_pi - 1; }
                 gI -= 1;
-                if (ei == 2) { cS += 1; e_type = QEV_SAMPLING; } else { cD += 1; e_type = QEV_DEATH; }
-                if (cnt_hit == 1) { op_n = 1; op_pi = pi; op_h0 = hap_hit; op_d0 = -1; }
-                else if (live && rl == 0) { ln[k_hit] = cnt_hit - 1; if (n_sel > 64) lt[k_hit >> 6] -= 1; }
+                if (ei == 2) { cS += 1; e_type = QEV_SAMPLING; } else { QBUMP(QC_D); e_type = QEV_DEATH; }
+                if (cnt_hit == 1) { op_n = 1; op_pi = pi; op_h0 = hap_hit; op_d0 = -1; ch_pi = -1; }
+                else {
+                    if (live && rl == 0) { ln[k_hit] = cnt_hit - 1; if (n_sel > 64) lt[k_hit >> 6] -= 1; }
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        if (c == (k_hit >> 4) && rl == (k_hit & 15)) ch_cn[c] -= 1;
+                }
                 e_hap = hap_hit; e_pop = pi; e_nh = 0; e_np = 0;
                 u_lo = pi; u_hi = pi + 1;
             }
+            QPROF(6);
             if (__ballot(isM)) {
                 // ---- Mutation (pyx:640-667): site by mRate[h, :], derived state by hapMutType[h, site, :] ----
                 const double *mr = p.mRate + (int64_t)hap_hit * sites;
@@ -465,12 +562,13 @@ extern "C" __global__ void __launch_bounds__(64) vgx_quad_kernel(VgxDirectArgs a
                     const int AS = (hap_hit / digit4) % 4;
                     if (DS >= AS) DS += 1;
                     const int nhi = hap_hit + (DS - AS) * digit4;
-                    op_n = 2; op_pi = pi; op_h0 = nhi; op_d0 = +1; op_h1 = hap_hit;
-                    cM += 1;
+                    op_n = 2; op_pi = pi; op_h0 = nhi; op_d0 = +1; op_h1 = hap_hit; ch_pi = -1;
+                    QBUMP(QC_M);
                     e_type = QEV_MUTATION; e_hap = hap_hit; e_pop = pi; e_nh = nhi; e_np = 0;
                     u_lo = pi; u_hi = pi + 1;
                 }
             }
+            QPROF(7);
             if (__ballot(evm)) {
                 // ================= GenerateMigration (pyx:672-694) =================
                 double rm = (choose0 - totalRate) / totalMig;
@@ -483,14 +581,15 @@ extern "C" __global__ void __launch_bounds__(64) vgx_quad_kernel(VgxDirectArgs a
                     for (int s = 0; s < nslot; ++s) {
                         const int pn = s * 16 + rl;
                         const double w = pn < P ? k_mebm[pn] * (double)s_ts[pn] * (double)(gI - s_ti[pn]) : 0.0;
-                        const double pre = row_scan16(w, carry);
+                        double tot_;
+                        const double pre = row_scan16(w, carry, tot_);
                         const int q = row_min(cand == 64 && pn < P && !(pre < rr_) ? rl : 16);
                         if (cand == 64 && q < 16) { cand = s * 16 + q; tot_hit = rowget_f64(pre, q); w_h = rowget_f64(w, q); }
                         else if (s == nslot - 1 && cand == 64) {        // clamp at P-1
                             const int ql = (P - 1) & 15;
                             tot_hit = rowget_f64(pre, ql); w_h = rowget_f64(w, ql);
                         }
-                        carry = row_last(pre);
+                        carry = tot_;
                     }
                     tpi = cand < 64 ? cand : P - 1;
                     if (evm && w_h == 0.0) err = Q_ERR_ZERO_WEIGHT + 256 * 9;
@@ -589,18 +688,19 @@ extern "C" __global__ void __launch_bounds__(64) vgx_quad_kernel(VgxDirectArgs a
                     const double p_accept = qa.effMig[(int64_t)spi * P + tpi] * p.bRate[hi] * p.susc[hi] / k_mebm[tpi];
                     if (rm < p_accept) {
                         if (rl == 0) { s_ts[tpi] -= 1; s_ti[tpi] += 1; }     // NewInfections (pyx:246-251)
-                        gI += 1; cMigP += 1;
-                        op_n = 1; op_pi = tpi; op_h0 = hi; op_d0 = +1;
+                        gI += 1; QBUMP(QC_MIGP);
+                        op_n = 1; op_pi = tpi; op_h0 = hi; op_d0 = +1; ch_pi = -1;
                         e_type = QEV_MIGRATION; e_hap = hi; e_pop = spi; e_nh = 0; e_np = tpi;
                         u_lo = tpi; u_hi = tpi + 1;
                     } else {
-                        cMigN += 1;
+                        QBUMP(QC_MIGN);
                     }
                 }
             }
             WSYNC();
         }
 
+        QPROF(8);
         // ================= deferred list operations: infectious[op_pi, hap] += delta, list kept ordered =================
         if (err != 0) op_n = 0;
         for (int oi = 0; oi < 2; ++oi) {
@@ -729,6 +829,7 @@ extern "C" __global__ void __launch_bounds__(64) vgx_quad_kernel(VgxDirectArgs a
             }
         }
 
+        QPROF(9);
         // ================= Events.AddEvent (events.pxi:37-44) =================
         if (err == 0 && e_type >= 0) {
             if (a.record_events) {
@@ -751,6 +852,7 @@ extern "C" __global__ void __launch_bounds__(64) vgx_quad_kernel(VgxDirectArgs a
             ev_ptr += 1;
         }
 
+        QPROF(10);
         // ================= UpdateRates for [u_lo, u_hi) (pyx:516-546) / UpdateAllRates (pyx:279-351) =================
         if (err != 0) u_hi = u_lo;
         const int maxu = rows_max(u_hi - u_lo);
@@ -762,35 +864,56 @@ extern "C" __global__ void __launch_bounds__(64) vgx_quad_kernel(VgxDirectArgs a
                 // BirthRate of the class (pyx:382-392): ps += ((x*m)*m*cd)/as over the source populations, in order
                 const double x = (double)s_ts[pi] * c_sig;
                 const double *mrow = p.mig + (int64_t)pi * P;
-                double ps = 0.0;
-                for (int s = 0; s < nslot; ++s) {
-                    const int pn = s * 16 + rl;
-                    double tv = 0.0;
-                    if (pn < P) { const double m = mrow[pn]; tv = x * m * m * k_cd[pn] / k_as[pn]; }
-                    ps = row_sum16(tv, ps);
+                const bool mhave = act && pi == pm_pi;
+                double tv4[4], ps = 0.0;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    tv4[s] = 0.0;
+                    if (s < nslot) {
+                        const int pn = s * 16 + rl;
+                        const double m = mhave ? m_pre[s] : mrow[min(pn, P - 1)];
+                        tv4[s] = x * m * m * k_cd[pn] / k_as[pn];        // lanes beyond P: cd = +0.0, as = 1.0
+                        if (pn >= P) tv4[s] = 0.0;
+                    }
                 }
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+                    if (s < nslot) ps = row_sum16(tv4[s], ps);
                 const double bC = c_b * ps;
                 const double tE = ((bC + c_d) + k_smul[pi]) + c_tm;
+                QPROF(11);
                 // infectPopRate[pi]: tE * infectious over the occupied haplotypes, in haplotype order (pyx:519-528)
                 const int n = act ? s_nocc[pi] : 0;
                 const int64_t *ln = lcnt + (int64_t)pi * cap;
                 const int maxn = rows_max(n);
                 double acc = 0.0;
-                if (maxn <= 16) {
-                    const double w = rl < n ? tE * (double)ln[rl] : 0.0;
-                    acc = row_sum16(w, 0.0);
+                if (maxn <= 64) {
+                    const int nch = (maxn + 15) >> 4;
+                    const bool chave = act && pi == ch_pi;     // the list read for the haplotype choice, event applied
+                    int64_t cn4[4];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) cn4[c] = ch_cn[c];
+                    if (__ballot(act && !chave)) {             // some row refreshes a population it did not just read
+                        const int last = max(n - 1, 0);
+#pragma unroll
+                        for (int c = 0; c < 4; ++c)
+                            if (c < nch) { const int64_t cl = ln[min(c * 16 + rl, last)]; if (!chave) cn4[c] = cl; }
+                    }
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        if (c < nch) acc = row_sum16(c * 16 + rl < n ? tE * (double)cn4[c] : 0.0, acc);
                 } else {
                     enum { QD = 8 };
                     int64_t buf[QD];
 #pragma unroll
-                    for (int d = 0; d < QD; ++d) { const int k = d * 16 + rl; buf[d] = k < n ? ln[k] : 0; }
+                    for (int d = 0; d < QD; ++d) { const int k = d * 16 + rl; buf[d] = ln[k < n ? k : 0]; }
                     for (int cb = 0; cb * 16 < maxn; cb += QD) {
 #pragma unroll
                         for (int d = 0; d < QD; ++d) {
                             const int c = cb + d;
                             const int64_t cn = buf[d];
                             const int kn = (c + QD) * 16 + rl;
-                            buf[d] = kn < n ? ln[kn] : 0;
+                            buf[d] = ln[kn < n ? kn : 0];
                             const double w = (c * 16 + rl < n) ? tE * (double)cn : 0.0;
                             acc = row_sum16(w, acc);
                         }
@@ -798,32 +921,45 @@ extern "C" __global__ void __launch_bounds__(64) vgx_quad_kernel(VgxDirectArgs a
                 }
                 if (act && rl == 0) { s_bc[pi] = bC; s_inf[pi] = acc; }
                 WSYNC();
+                QPROF(12);
             }
             // totalRate and the serial prefix sums of popRate (pyx:537-539)
             {
-                double carry = 0.0;
-                for (int s = 0; s < nslot; ++s) {
-                    const int pn = s * 16 + rl;
-                    const double w = pn < P ? s_inf[pn] : 0.0;
-                    const double pre = row_scan16(w, carry);
-                    if (pn < P && u_hi > u_lo) s_cum[pn] = pre;
-                    carry = row_last(pre);
+                double w4[4], carry = 0.0, cend[4];
+#pragma unroll
+                for (int s = 0; s < 4; ++s) w4[s] = s_inf[s * 16 + rl];      // lanes beyond P hold +0.0
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    if (s < nslot) carry = row_sum16(w4[s], carry);
+                    cend[s] = carry;
+                }
+                if (u_hi > u_lo) {
+                    if (rl < 4) s_cc[rl] = rl == 0 ? cend[0] : rl == 1 ? cend[1] : rl == 2 ? cend[2] : cend[3];
+                    totalRate = carry;       // = the prefix sum at P-1: the lanes beyond P add +0.0
                 }
                 WSYNC();
-                if (u_hi > u_lo) totalRate = s_cum[P - 1];
             }
+            QPROF(13);
             // totalMigrationRate = sum of maxEffectiveBirthMigration * totalSusceptible * (globalInfectious - totalInfectious)
             if (has_mig) {
-                double acc = 0.0;
-                for (int s = 0; s < nslot; ++s) {
-                    const int pn = s * 16 + rl;
-                    const double w = pn < P ? k_mebm[pn] * (double)s_ts[pn] * (double)(gI - s_ti[pn]) : 0.0;
-                    acc = row_sum16(w, acc);
+                double w4[4], acc = 0.0;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    w4[s] = 0.0;
+                    if (s < nslot) {
+                        const int pn = s * 16 + rl;     // lanes beyond P: maxEBM = +0.0, counts 0
+                        w4[s] = k_mebm[pn] * (double)s_ts[pn] * (double)(gI - s_ti[pn]);
+                        if (pn >= P) w4[s] = 0.0;
+                    }
                 }
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+                    if (s < nslot) acc = row_sum16(w4[s], acc);
                 if (u_hi > u_lo) totalMig = acc;
             }
         }
 
+        QPROF(14);
         // ================= after the pass =================
         if (rebuild && st == ST_REBUILD) st = err ? ST_DONE : ST_RUN;
         if (err != 0) st = ST_DONE;
@@ -833,7 +969,8 @@ extern "C" __global__ void __launch_bounds__(64) vgx_quad_kernel(VgxDirectArgs a
             open = false;
             if (ev_ptr <= 100 && a.iterations > 100) {
                 // Restart (pyx:714-738): compartments back to the initial snapshot, then UpdateAllRates
-                ev_ptr = 0; cB = cD = cS = cM = cMigP = cMigN = 0;
+                ev_ptr = 0; cS = 0;
+                if (rl < 8) s_cnt[rl] = 0;
                 t_now = 0.0; traj_next = 0;
                 restarts += 1; att += 1;
                 st = ST_REBUILD;
@@ -893,6 +1030,10 @@ extern "C" __global__ void __launch_bounds__(64) vgx_quad_kernel(VgxDirectArgs a
         }
     }
 
+#ifdef VGX_PROFILE
+    if (lane == 0 && r.prof)
+        for (int i = 0; i < VGX_PROF_SLOTS; ++i) r.prof[rep * VGX_PROF_SLOTS + i] = prof_acc[i];
+#endif
     // ---- state back to HBM ----
     WSYNC();
     if (live) {
@@ -914,8 +1055,8 @@ extern "C" __global__ void __launch_bounds__(64) vgx_quad_kernel(VgxDirectArgs a
         if (rl == 0) {
             sc->currentTime = t_now; sc->totalRate = totalRate; sc->totalMig = totalMig;
             sc->globalInfectious = gI;
-            sc->bCounter = cB; sc->dCounter = cD; sc->sCounter = cS; sc->mCounter = cM;
-            sc->migPlus = cMigP; sc->migNonPlus = cMigN;
+            sc->bCounter = s_cnt[QC_B]; sc->dCounter = s_cnt[QC_D]; sc->sCounter = cS; sc->mCounter = s_cnt[QC_M];
+            sc->migPlus = s_cnt[QC_MIGP]; sc->migNonPlus = s_cnt[QC_MIGN];
             sc->good_attempt = good_attempt;
             sc->ev_ptr = ev_ptr; sc->loop_iterations = loops; sc->restarts = restarts;
             sc->loc_n = 0; sc->error = err; sc->traj_next = traj_next;
