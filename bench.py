@@ -159,9 +159,11 @@ def spread_leg(device, mode="exact", replicates=1024, events=20000, occupied=409
         # per event: the refreshed population's whole list (pyx:519-528), on average half of the selected population's
         # list (fast_choose.pxi:22-25), the popRate and migPopRate totals (pyx:537-546)
         steps = 1.5 * nocc + 2.0 * POPS
+        rows = 4 if replicates >= 2048 else 1     # vgx_quad.hip: every chain instruction serves four replicates
         out["chain_bound"] = {"bound": "dependent f64 additions in the reference's order (one v_fmac_f64 per term)",
-                              "steps_per_event": steps, "achieved": ev * steps / (ms * 1e-3), "peak": CHAIN_STEPS_PER_S,
-                              "unit": "chain steps/s", "frac": ev * steps / (ms * 1e-3) / CHAIN_STEPS_PER_S}
+                              "steps_per_event": steps, "achieved": ev * steps / (ms * 1e-3), "peak": CHAIN_STEPS_PER_S * rows,
+                              "unit": "chain steps/s", "frac": ev * steps / (ms * 1e-3) / (CHAIN_STEPS_PER_S * rows),
+                              "chains_per_instruction": rows}
     ens.close()
     return out
 
@@ -230,7 +232,9 @@ def single_leg(device):
 
 
 def fast_leg(device, replicates, events, traj_points):
-    """The headline workload (natural occupancy) in FAST mode, device time of one launch after a warm-up."""
+    """The headline workload (natural occupancy) in FAST mode (one replicate per wavefront), device time of one launch after
+    a warm-up."""
+    replicates, events = min(replicates, 4096), events * max(replicates // 4096, 1)
     import numpy as np
     from vgsim_amd.ensemble import Ensemble
     ens = Ensemble(make_simulator(2020), replicates, device=device)
@@ -402,8 +406,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--replicates", type=int, default=4096, help="replicates per GPU and step")
-    ap.add_argument("--events", type=int, default=100000, help="recorded events per replicate and step")
+    ap.add_argument("--replicates", type=int, default=16384, help="replicates per GPU and step (four per wavefront)")
+    ap.add_argument("--events", type=int, default=25000, help="recorded events per replicate and step")
     ap.add_argument("--traj-points", type=int, default=1001)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-tau", action="store_true", help="skip the tau-leap (config 4) leg")
@@ -441,7 +445,7 @@ def main():
     R, N = a.replicates, a.events
     H = 4 ** SITES
     extra_legs = (("fast_mode", lambda d: fast_leg(d, R, N, a.traj_points)),
-                  ("spread_occupancy", lambda d: spread_leg(d, "exact", replicates=4096, events=5000)),
+                  ("spread_occupancy", lambda d: spread_leg(d, "exact", replicates=8192, events=2500)),
                   ("spread_occupancy_fast", lambda d: spread_leg(d, "fast", replicates=4096)),
                   ("config2", c2_leg), ("genealogy", genealogy_leg), ("single_trajectory", single_leg),
                   ("direct_config4_shape", c4_direct_leg), ("tau_leap", tau_leg))
@@ -478,12 +482,12 @@ def main():
     if rank == 0:
         value = total_events / elapsed
         # ---- roofline of the dominant kernel (vgx_direct_kernel), this rank ----
-        # Algorithmic bytes per recorded event of THIS engine's layout (DESIGN.md §5): the chosen population's
+        # Algorithmic bytes per recorded event of THIS engine's layout (DESIGN.md §4.1): the chosen population's
         # occupancy-list stream (16 B/entry, read once and kept in registers), the migration row (8P), the
-        # event record (28 B) and the count write-back (8 B).  Mean list length measured from final state.
+        # event record (32 B) and the count write-back (8 B).  Mean list length measured from final state.
         st = ens.replicate_state(0)
         nocc_mean = float((st.infectious != 0).sum(axis=1).mean())
-        bytes_per_event = 16.0 * max(nocc_mean, 1.0) + 8.0 * POPS + 28.0 + 8.0
+        bytes_per_event = 16.0 * max(nocc_mean, 1.0) + 8.0 * POPS + 32.0 + 8.0
         ev_per_launch = events / max(a.steps, 1)
         launch_s = (kernel_ms / max(a.steps, 1)) * 1e-3
         achieved = ev_per_launch * bytes_per_event / launch_s / 1e9
@@ -505,7 +509,8 @@ def main():
                        "trajectory_points": a.traj_points, "loop_iterations_per_event": li},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "vgx_direct_kernel_p64s1c1", "kernel_ms_per_launch": kernel_ms / max(a.steps, 1),
+                         "kernel": "vgx_quad_kernel" if R >= 2048 else "vgx_direct_kernel_p64s1c1",
+                         "kernel_ms_per_launch": kernel_ms / max(a.steps, 1),
                          "bytes_per_event": bytes_per_event, "mean_occupancy_list_len": nocc_mean,
                          "note": "persistent sequential event loop: latency/issue-bound, not bandwidth-bound; the "
                                  "reference's dense layout would need %.3g B/event = %.3g GB/s at this event rate"
@@ -518,8 +523,9 @@ def main():
         for r in range(nrep):
             got += ens.replicate_events(r).shape[1]
         t_d = time.perf_counter() - t_d
-        line["event_log"] = {"device_bytes_per_event": 28, "d2h_sample_replicates": nrep, "d2h_events": got,
-                             "d2h_s": t_d, "note": "copy-out widens to the reference's (6,N) float64 layout on the host"}
+        line["event_log"] = {"device_bytes_per_event": 32, "d2h_sample_replicates": nrep, "d2h_events": got,
+                             "d2h_s": t_d, "note": "copy-out widens to the reference's (6,N) float64 layout on the host and rebuilds "
+                                                    "the event times with the host libm (PCG64 stream + logged rate denominators)"}
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
     ens.close()
