@@ -203,6 +203,13 @@ int64_t vgx_device_bytes(const vgx_engine *e);
  * call for one replicate (phase list: tools/profile_phases.py); all zeros in the product build. */
 int vgx_get_profile(vgx_engine *e, int64_t replicate, int64_t *out16);
 
+/* ---- test hooks: the samplers of the tau-leap kernels on their own -------------------------------- */
+/* Philox4x32-10 (Salmon et al. 2011) for one (counter, key): the host build of the same function, or the device's. */
+int vgx_test_philox(int on_device, const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
+/* n independent draws of the device's Poisson(lam) sampler (what replaces numpy's random_poisson, pyx:2531-2532:
+ * inversion below a mean of 10, PTRS from 10 on), draw i from the Philox stream of compartment i under `seed`. */
+int vgx_test_poisson(double lam, int64_t n, uint64_t seed, int64_t *out);
+
 #ifdef __cplusplus
 }
 #endif

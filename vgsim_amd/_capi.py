@@ -90,6 +90,8 @@ SIGNATURES = {
     "vgx_get_profile": (C.c_int, [_H, C.c_int64, _I]),
     "vgx_get_genealogy": (C.c_int, [C.POINTER(VgxGenealogyIO), C.c_char_p, C.c_int64]),
     "vgx_rng_position": (None, [C.c_int64, C.c_int64, C.c_int64, C.POINTER(C.c_uint64 * 4)]),
+    "vgx_test_philox": (C.c_int, [C.c_int, C.POINTER(C.c_uint32 * 4), C.POINTER(C.c_uint32 * 2), C.POINTER(C.c_uint32 * 4)]),
+    "vgx_test_poisson": (C.c_int, [C.c_double, C.c_int64, C.c_uint64, _I]),
 }
 
 _lib = None

@@ -23,6 +23,7 @@
 // distributionally (tests/test_hip_tau.py), as BASELINE.json asks.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "../../include/vgx.h"
 #include "vgx_dev.h"
 #include "vgx_rng.h"
 
@@ -1582,3 +1583,38 @@ TAU_LAUNCH(tau_check, CELL_GRID, dim3(TB))
 TAU_LAUNCH(tau_decide, dim3((unsigned)a->R), dim3(64))
 TAU_LAUNCH(tau_commit, CELL_GRID, dim3(TB))
 TAU_LAUNCH(tau_finish, dim3((unsigned)a->R), dim3(64))
+
+// ---- test hooks (include/vgx.h): the device samplers on their own ----------------------------------------------
+// Philox4x32-10 for one (counter, key) on the device, and n independent draws of the Poisson sampler the step kernels
+// use (inversion below a mean of 10, PTRS from 10 on), draw i from the stream of compartment i.
+extern "C" __global__ void vgx_test_philox_kernel(const uint32_t *ctr, const uint32_t *key, uint32_t *out) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) vgx_philox4x32(ctr, key, out);
+}
+extern "C" __global__ void __launch_bounds__(TB) vgx_test_poisson_kernel(double lam, int64_t n, uint64_t seed, int64_t *out) {
+    const int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x;
+    if (i >= n) return;
+    TauRng g;
+    g.init(seed, 0u, (uint64_t)i, 0u, 0u);
+    out[i] = tau_poisson(g, lam);
+}
+extern "C" int vgx_test_philox(int on_device, const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+    if (!ctr || !key || !out) return VGX_ERR_ARG;
+    if (!on_device) { vgx_philox4x32(ctr, key, out); return VGX_OK; }
+    uint32_t *d = nullptr;
+    if (hipMalloc(&d, 10 * sizeof(uint32_t)) != hipSuccess) return VGX_ERR_HIP;
+    hipError_t e1 = hipMemcpy(d, ctr, 16, hipMemcpyHostToDevice), e2 = hipMemcpy(d + 4, key, 8, hipMemcpyHostToDevice);
+    hipLaunchKernelGGL(vgx_test_philox_kernel, dim3(1), dim3(64), 0, 0, d, d + 4, d + 6);
+    hipError_t e3 = hipMemcpy(out, d + 6, 16, hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    return (e1 == hipSuccess && e2 == hipSuccess && e3 == hipSuccess) ? VGX_OK : VGX_ERR_HIP;
+}
+extern "C" int vgx_test_poisson(double lam, int64_t n, uint64_t seed, int64_t *out) {
+    if (!out || n < 0) return VGX_ERR_ARG;
+    if (n == 0) return VGX_OK;
+    int64_t *d = nullptr;
+    if (hipMalloc(&d, (size_t)n * 8) != hipSuccess) return VGX_ERR_HIP;
+    hipLaunchKernelGGL(vgx_test_poisson_kernel, dim3((unsigned)((n + TB - 1) / TB)), dim3(TB), 0, 0, lam, n, seed, d);
+    hipError_t e = hipMemcpy(out, d, (size_t)n * 8, hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    return e == hipSuccess ? VGX_OK : VGX_ERR_HIP;
+}
