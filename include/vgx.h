@@ -203,6 +203,33 @@ int64_t vgx_device_bytes(const vgx_engine *e);
  * call for one replicate (phase list: tools/profile_phases.py); all zeros in the product build. */
 int vgx_get_profile(vgx_engine *e, int64_t replicate, int64_t *out16);
 
+/* ---- the dense propensity row pass (K3) ------------------------------------------------------- */
+/* For callers that hold the reference's dense per-population arrays: the infect branch of UpdateRates (pyx:518-528:
+ * BirthRate, tEventHapPopRate, hapPopRate, infectPopRate) followed by fastChoose over hapPopRate (fast_choose.pxi:18-31)
+ * for `rows` independent (replicate, population) rows at once.  FAST-mode arithmetic: BirthRate factored
+ * through rowContact = sum_pn m[pi,pn]^2 * cd[pn] / actualSizes[pn], tree-order sums.  All pointers are host arrays. */
+typedef struct vgx_rowscan {
+    int64_t rows, H, S;
+    const int64_t *infectious;       /* [rows][H]      infectious[pi, :]                                   in  */
+    const double *eventRates123;     /* [rows][H][3]   eventHapPopRate[pi, :, 1:4] (pyx:311-314)          in  */
+    const int64_t *numToHap;         /* [H]            pyx:105-125 (identity without memory_optimization)  in  */
+    const double *bRate;             /* [H]                                                                in  */
+    const double *susceptibility;    /* [H][S]                                                             in  */
+    const double *rowSusceptible;    /* [rows][S]      susceptible[pi, :] as doubles                       in  */
+    const double *rowContact;        /* [rows]                                                             in  */
+    const double *u;                 /* [rows]         the random number of fastChoose                     in  */
+    double *birthRate, *tEvent, *hapPopRate;   /* [rows][H]  eventHapPopRate[pi,:,0], tEventHapPopRate, hapPopRate  out */
+    double *susceptHapPopRate;       /* [rows][H][S]                                                       out */
+    double *rowTotal;                /* [rows]         infectPopRate[pi]                                   out */
+    int64_t *chosen;                 /* [rows]         index returned by fastChoose                        out */
+    double *rnOut;                   /* [rows]         rescaled random number (fc:31)                      out */
+} vgx_rowscan;
+int vgx_propensity_scan(const vgx_rowscan *io);
+/* Measurement: `rows` copies of the caller's first row resident in HBM, `repeats` timed passes after a warm-up; average
+ * device time (HIP events) of the row update and of the choice; the first row's outputs are returned. */
+int vgx_propensity_scan_bench(const vgx_rowscan *first_row, int64_t rows, int repeats, double *ms_update, double *ms_choose);
+const char *vgx_propensity_scan_error(void);
+
 /* ---- test hooks: the samplers of the tau-leap kernels on their own -------------------------------- */
 /* Philox4x32-10 (Salmon et al. 2011) for one (counter, key): the host build of the same function, or the device's. */
 int vgx_test_philox(int on_device, const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);

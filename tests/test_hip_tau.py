@@ -340,3 +340,40 @@ def test_direct_tau_direct_on_one_object():
     assert hip.iCounter == single[4] + by_type[4] and hip.migPlus == single[5] + by_type[5]
     assert int(hip.susceptible.sum() + hip.infectious.sum()) == int(hip.sizes.sum())
     assert np.array_equal(hip.totalInfectious, hip.infectious.sum(axis=1)) and hip.globalInfectious == hip.infectious.sum()
+
+
+def test_tau_restart_rechecks_lockdowns_and_keeps_the_log():
+    """Tau as the first call on a model whose attempts die out (<= 100 steps, iterations > 100 -> Restart, pyx:2331): the
+    lockdown records of failed attempts stay, Restart re-checks every population at time 0, swapLockdown survives.  The
+    draws differ from the oracle's (other streams), so structural facts are checked on the device result: counters equal
+    the log, hosts are conserved."""
+    from vgsim_amd import Simulator
+    with helpers.quiet():
+        s = Simulator(number_of_sites=1, populations_number=2, number_of_susceptible_groups=1, seed=3)
+        s.set_transmission_rate(1.3); s.set_recovery_rate(1.0); s.set_sampling_rate(0.05)
+        s.set_population_size(400); s.set_migration_probability(0.05)
+        s.set_npi([0.2, 0.01, 0.002])
+        s.simulate(400, sample_size=10 ** 9, method='tau', attempts=30)
+    m = s.simulation
+    assert m.swapLockdown == len(m.loc.times)                  # every switch ever made is in the log, Restarts included
+    assert all(t >= 0.0 for t in m.loc.times)
+    hosts = m.susceptible.sum() + m.infectious.sum()
+    assert hosts == int(m.sizes.sum()) and (m.infectious >= 0).all()
+    assert m.multievents.ptr == 0 or (m.multievents.num[:m.multievents.ptr] > 0).all()
+
+
+def test_tau_without_multievent_rows():
+    """``record_multievents=False``: same trajectory (the rows are bookkeeping only), MULTITYPE records with empty ranges."""
+    a = run_tau_case("tau_b", 7, "hip")
+    from vgsim_amd import Simulator
+    ctor, phases = models.CASES["tau_b"]
+    with helpers.quiet():
+        sim = Simulator(**dict(ctor, seed=7))
+        phases[0][0](sim)
+        sim.simulate(**phases[0][1])
+        sim.simulate(record_multievents=False, **phases[1][1])
+    b = sim.simulation
+    assert np.array_equal(a.infectious, b.infectious) and a.bCounter == b.bCounter and a.currentTime == b.currentTime
+    assert np.array_equal(a.events.times[:a.events.ptr], b.events.times[:b.events.ptr])
+    nd = phases[0][1]["iterations"]
+    assert b.multievents.ptr == 0 and (b.events.haplotypes[nd:b.events.ptr] == 0).all()

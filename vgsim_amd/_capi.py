@@ -63,6 +63,13 @@ class VgxGenealogyIO(C.Structure):
                 ("mig_time", _F), ("nodes_used", C.c_int64)]
 
 
+class VgxRowScan(C.Structure):
+    _fields_ = [("rows", C.c_int64), ("H", C.c_int64), ("S", C.c_int64), ("infectious", _I), ("eventRates123", _F),
+                ("numToHap", _I), ("bRate", _F), ("susceptibility", _F), ("rowSusceptible", _F), ("rowContact", _F), ("u", _F),
+                ("birthRate", _F), ("tEvent", _F), ("hapPopRate", _F), ("susceptHapPopRate", _F), ("rowTotal", _F),
+                ("chosen", _I), ("rnOut", _F)]
+
+
 # every entry point include/vgx.h declares: (restype, argtypes)
 _H = C.c_void_p
 SIGNATURES = {
@@ -90,6 +97,9 @@ SIGNATURES = {
     "vgx_get_profile": (C.c_int, [_H, C.c_int64, _I]),
     "vgx_get_genealogy": (C.c_int, [C.POINTER(VgxGenealogyIO), C.c_char_p, C.c_int64]),
     "vgx_rng_position": (None, [C.c_int64, C.c_int64, C.c_int64, C.POINTER(C.c_uint64 * 4)]),
+    "vgx_propensity_scan": (C.c_int, [C.POINTER(VgxRowScan)]),
+    "vgx_propensity_scan_bench": (C.c_int, [C.POINTER(VgxRowScan), C.c_int64, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "vgx_propensity_scan_error": (C.c_char_p, []),
     "vgx_test_philox": (C.c_int, [C.c_int, C.POINTER(C.c_uint32 * 4), C.POINTER(C.c_uint32 * 2), C.POINTER(C.c_uint32 * 4)]),
     "vgx_test_poisson": (C.c_int, [C.c_double, C.c_int64, C.c_uint64, _I]),
 }
@@ -163,10 +173,12 @@ class HipEngine:
     # ---------------------------------------------------------------- hand-over
     def set_params(self, m):
         p = VgxParams()
-        for name, _ in VgxParams._fields_:
-            a = getattr(m, name)
-            setattr(p, name, _p(np.ascontiguousarray(a)))
-        self._keep = [getattr(m, n) for n, _ in VgxParams._fields_]
+        conv = []   # the arrays the pointers refer to (contiguous, of the declared dtype): alive until the call returns
+        for name, ctype in VgxParams._fields_:
+            a = np.ascontiguousarray(getattr(m, name), dtype=np.int64 if ctype is _I else np.float64)
+            conv.append(a)
+            setattr(p, name, _p(a))
+        self._keep = conv
         self._check(self.lib.vgx_set_params(self.handle, C.byref(p)))
         pos = np.ascontiguousarray(getattr(m, "sitesPosition", np.zeros(0)), dtype=np.int64)
         self._check(self.lib.vgx_set_recombination(self.handle, float(getattr(m, "recombination", 0.0)),
@@ -287,6 +299,9 @@ class HipEngine:
         m.events.ptr = c.ev_ptr
         if tau:
             rows = self.multievents(replicate)
+            if len(rows["times"]) == 0:    # nothing recorded (record_multievents=False or no event drawn): empty row ranges
+                m.events.haplotypes[first:c.ev_ptr] = 0
+                m.events.populations[first:c.ev_ptr] = 0
             rows = canonical_multievents(rows, m.events.haplotypes[first:c.ev_ptr], m.events.populations[first:c.ev_ptr],
                                          m.sites, m.susNum)
             if c.restarts > 0:  # Restart rewinds multievents.ptr too (pyx:716)
@@ -427,4 +442,38 @@ def get_genealogy(m, seed=None, rng_position=None, rng_raw=None):
             out[k] = out[k][:io.mig_n]
     out["nodes_used"] = int(io.nodes_used)
     out["rng_raw"] = tuple(int(io.rng_state[i]) for i in range(4)) + (int(io.rng_has_uint32), int(io.rng_uinteger))
+    return out
+
+
+def propensity_scan(infectious, rates123, numToHap, bRate, susceptibility, rowSusceptible, rowContact, u, bench_rows=0, repeats=3):
+    """The dense propensity row pass (``vgx_propensity_scan``, K3): returns a dict of the output arrays.  With ``bench_rows``
+    the first row is replicated that many times in HBM and timed (``ms_update``, ``ms_choose`` in the result)."""
+    lib = load_library()
+    inf = np.ascontiguousarray(infectious, dtype=np.int64)
+    rows, H = inf.shape
+    S = int(np.asarray(susceptibility).reshape(H, -1).shape[1])
+    n = bench_rows if bench_rows else rows
+
+    def fit(a, shape):   # bench mode: per-row inputs are repeated for the synthetic rows
+        a = np.ascontiguousarray(a, dtype=np.float64).reshape((rows,) + shape)
+        return np.ascontiguousarray(np.resize(a, (n,) + shape)) if bench_rows else a
+    keep = dict(infectious=inf, eventRates123=np.ascontiguousarray(rates123, dtype=np.float64).reshape(rows, H, 3),
+                numToHap=np.ascontiguousarray(numToHap, dtype=np.int64), bRate=np.ascontiguousarray(bRate, dtype=np.float64),
+                susceptibility=np.ascontiguousarray(susceptibility, dtype=np.float64).reshape(H, S),
+                rowSusceptible=fit(rowSusceptible, (S,)), rowContact=fit(rowContact, ()), u=fit(u, ()))
+    ro = 1 if bench_rows else rows
+    out = dict(birthRate=np.zeros((ro, H)), tEvent=np.zeros((ro, H)), hapPopRate=np.zeros((ro, H)),
+               susceptHapPopRate=np.zeros((ro, H, S)), rowTotal=np.zeros(ro), chosen=np.zeros(ro, dtype=np.int64), rnOut=np.zeros(ro))
+    io = VgxRowScan()
+    io.rows, io.H, io.S = rows, H, S
+    for k, v in list(keep.items()) + list(out.items()):
+        setattr(io, k, _p(v))
+    if bench_rows:
+        a, b = C.c_double(0), C.c_double(0)
+        rc = lib.vgx_propensity_scan_bench(C.byref(io), int(bench_rows), int(repeats), C.byref(a), C.byref(b))
+        out["ms_update"], out["ms_choose"] = a.value, b.value
+    else:
+        rc = lib.vgx_propensity_scan(C.byref(io))
+    if rc != VGX_OK:
+        raise VgxError(rc, lib.vgx_propensity_scan_error().decode())
     return out

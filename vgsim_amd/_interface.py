@@ -122,7 +122,7 @@ class Simulator(PlotMixin):
 
     # the drop-in boundary (if:799-829)
     def simulate(self, iterations=1000, sample_size=None, epidemic_time=-1, method='direct', attempts=200, mode='exact',
-                 kernel='auto'):
+                 kernel='auto', record_multievents=True):
         if sample_size is None:
             sample_size = iterations
         if epidemic_time is None:
@@ -132,7 +132,8 @@ class Simulator(PlotMixin):
             self.simulation.SimulatePopulation(iterations, sample_size, epidemic_time, attempts, mode=mode, kernel=kernel)
             self.simulation.Stats(time.time() - start_time)
         elif method == 'tau':
-            self.simulation.SimulatePopulation_tau(iterations, sample_size, epidemic_time, attempts)
+            self.simulation.SimulatePopulation_tau(iterations, sample_size, epidemic_time, attempts,
+                                                   record_multievents=record_multievents)
             self.simulation.Stats(time.time() - start_time)
         else:
             print("Unknown method. Choose between 'direct' and 'tau'.")

@@ -333,14 +333,21 @@ class BirthDeathModel(ParameterTable, Reporting):
         self._refresh_haplotype_table()
         self._print_termination(sample_size, time)
 
-    def SimulatePopulation_tau(self, iterations, sample_size, time, attempts):
-        """pyx:2293-2346: Poisson tau-leaping on the GPU."""
+    def SimulatePopulation_tau(self, iterations, sample_size, time, attempts, record_multievents=True):
+        """pyx:2293-2346: Poisson tau-leaping on the GPU.  ``record_multievents=False`` keeps the MULTITYPE records (step
+        times) but not the per-channel rows a later ``genealogy()`` would walk: for long dense runs whose rows would not
+        fit (the reference allocates iterations x propNum rows up front, pyx:2305)."""
         self._check_supported()
         self.events.CreateEvents(iterations)   # via PrepareParameters (pyx:2298 -> pyx:434)
         self.events.CreateEvents(iterations)   # pyx:2306
         self.CheckSizes()
         time = float(np.float32(time))
-        self._get_engine().simulate_tau(self, iterations, sample_size, time, attempts)
+        opts = None
+        if not record_multievents:
+            from . import _capi
+            opts = _capi.VgxRunOpts()
+            opts.record_events = 0
+        self._get_engine().simulate_tau(self, iterations, sample_size, time, attempts, opts)
         self._rng_position, self._rng_raw = None, None
         self._refresh_haplotype_table()
         self._print_termination(sample_size, time)

@@ -65,6 +65,7 @@ struct vgx_engine {
     std::vector<int32_t> cls;
     std::vector<int64_t> sizes, seeds;
     std::vector<double> suscepCumul, mig, actualSizes;
+    std::vector<char> h_class_pos;       // [C] the class has a positive recovery, sampling, mutation or transmission rate
     HostState hs;
     // device
     std::vector<DevBuf *> all;
@@ -280,6 +281,9 @@ extern "C" int vgx_set_params(vgx_engine *e, const vgx_params *p) {
     }
     e->C = (int)c_d.size();
     e->CB = (int)cb_b.size();
+    e->h_class_pos.assign(c_d.size(), 0);
+    for (size_t c = 0; c < c_d.size(); c++)
+        e->h_class_pos[c] = (c_d[c] > 0.0 || c_s[c] > 0.0 || c_tm[c] > 0.0 || cb_b[(size_t)c_bidx[c]] > 0.0) ? 1 : 0;
 
     // ---- parameter-only parts of UpdateAllRates, in the reference's order ----
     e->suscepCumul.assign((size_t)S, 0.0);
@@ -919,9 +923,28 @@ extern "C" int vgx_simulate_tau(vgx_engine *e, int64_t iterations, int64_t sampl
         if (e->sizes[(size_t)pn] >= ((int64_t)1 << 31)) return fail(e, VGX_ERR_ARG, "vgx_simulate_tau: population sizes must be below 2^31");
     if (e->C > 256 && (e->CB > 16 || S > 64)) return fail(e, VGX_ERR_CLASSES, "vgx_simulate_tau: more than 16 transmission classes together with more than 256 rate classes is not supported");
     const bool start_ok = rates_nonzero && h.globalInfectious != 0;
+    // the same guard for the state a Restart restores: does an infected host of the initial state have any event rate?
+    bool rates_nonzero_initial = false;
+    for (int64_t pn = 0; pn < P && !rates_nonzero_initial; pn++) {
+        for (int64_t hn = 0; hn < H && !rates_nonzero_initial; hn++) {
+            if (h.initial_infectious[(size_t)(pn * H + hn)] == 0) continue;
+            // any positive recovery / sampling / mutation / transmission rate of the haplotype's class makes tEventHapPopRate,
+            // hence totalRate, non-zero (transmission additionally needs a susceptible host; a model without the other
+            // three rates and without susceptibles has nothing left to simulate either way)
+            if (e->h_class_pos[(size_t)e->cls[(size_t)hn]]) rates_nonzero_initial = true;
+        }
+        for (int64_t sn = 0; sn < S; sn++)
+            if (e->suscepCumul[(size_t)sn] * (double)h.initial_susceptible[(size_t)(pn * S + sn)] != 0.0) rates_nonzero_initial = true;
+    }
 
     // ---- device arrays ----
-    const int64_t mev_cap = o.record_events ? std::max<int64_t>(1, std::min<int64_t>((int64_t)1 << 24, iterations * 8192)) : 0;
+    // multievent rows (num > 0 only): at most a few per occupied compartment and step; sized from the start state with
+    // room for the epidemic to grow, within 2^27 rows (6 GiB) per replicate; a run that still outgrows it fails loudly
+    const int64_t rows_per_step = 16 * occupied + 4 * P * S * S + 4096;
+    const int64_t mev_cap = o.record_events
+        ? std::max<int64_t>(1, std::min<int64_t>(((int64_t)1 << 27) / std::max<int64_t>(R, 1),
+                                                 std::max<int64_t>((int64_t)1 << 22, std::min<int64_t>(iterations, 1 << 20) * rows_per_step)))
+        : 0;
     const size_t nF = 10;  // int32 flag arrays
     const int64_t Ppad = (P + 31) / 32 * 32;
     rc = 0;
@@ -1068,7 +1091,7 @@ extern "C" int vgx_simulate_tau(vgx_engine *e, int64_t iterations, int64_t sampl
     std::vector<std::vector<int64_t>> cnt0((size_t)R, base_cnt);  // counters before this call / after a restart
     std::vector<int64_t> cnt((size_t)R * 8, 0);
     std::vector<int32_t> running((size_t)R, 0), finished((size_t)R, 0), step_h((size_t)R, 0), att32((size_t)R, 0), acc_h, err_h;
-    std::vector<int64_t> restarts((size_t)R, 0), steps_done((size_t)R, 0);
+    std::vector<int64_t> restarts((size_t)R, 0), steps_done((size_t)R, 0), swaps_kept((size_t)R, 0);
     e->tau_log.assign((size_t)R, {});
     e->tau_ev_ptr0.assign((size_t)R, ev_ptr_start);
     std::vector<unsigned long long> mevn((size_t)R, 0);
@@ -1096,11 +1119,58 @@ extern "C" int vgx_simulate_tau(vgx_engine *e, int64_t iterations, int64_t sampl
                 restarts[(size_t)r] += 1;
                 rc = upload_state(r, h.initial_infectious, h.initial_susceptible);
                 if (rc) return rc;
+                {   // the lockdown records of the failed attempt stay (Restart does not clear `loc`); then CheckLockdown for
+                    // every population on the restored totals at time 0 (pyx:736-737), whose switches change the contact
+                    // densities the next attempt starts with
+                    unsigned long long ln_r = 0;
+                    HIPCHECK(e, hipMemcpy(&ln_r, a.loc_n + r, 8, hipMemcpyDeviceToHost));
+                    const int64_t nrec = std::min<int64_t>((int64_t)ln_r, VGX_LOC_CAP);
+                    if (nrec > 0) {
+                        std::vector<int32_t> rec((size_t)nrec * 2);
+                        std::vector<double> tt((size_t)nrec);
+                        HIPCHECK(e, hipMemcpy(rec.data(), (int32_t *)e->r_locrec.p + r * VGX_LOC_CAP * 2, (size_t)nrec * 8, hipMemcpyDeviceToHost));
+                        HIPCHECK(e, hipMemcpy(tt.data(), (double *)e->r_loctime.p + r * VGX_LOC_CAP, (size_t)nrec * 8, hipMemcpyDeviceToHost));
+                        for (int64_t i = 0; i < nrec; i++) {
+                            e->tau_loc_state[(size_t)r].push_back(rec[(size_t)(i * 2)]);
+                            e->tau_loc_pop[(size_t)r].push_back(rec[(size_t)(i * 2 + 1)]);
+                            e->tau_loc_time[(size_t)r].push_back(tt[(size_t)i]);
+                        }
+                        HIPCHECK(e, hipMemset(a.loc_n + r, 0, 8));
+                    }
+                    std::vector<double> cd_r((size_t)P);
+                    std::vector<int32_t> lk_r((size_t)P);
+                    HIPCHECK(e, hipMemcpy(cd_r.data(), (double *)e->t_cd.p + r * P, (size_t)P * 8, hipMemcpyDeviceToHost));
+                    HIPCHECK(e, hipMemcpy(lk_r.data(), (int32_t *)e->t_lock.p + r * P, (size_t)P * 4, hipMemcpyDeviceToHost));
+                    int64_t flips = 0;
+                    for (int64_t pn = 0; pn < P; pn++) {
+                        int64_t ti = 0;
+                        for (int64_t hn = 0; hn < H; hn++) ti += h.initial_infectious[(size_t)(pn * H + hn)];
+                        for (int pass = 0; pass < 2; pass++) {
+                            const double sz = (double)e->sizes[(size_t)pn];
+                            const bool flip = pass == 0 ? ((double)ti > e->h_startLD[(size_t)pn] * sz && lk_r[(size_t)pn] == 0)
+                                                        : ((double)ti < e->h_endLD[(size_t)pn] * sz && lk_r[(size_t)pn] == 1);
+                            if (!flip) continue;
+                            cd_r[(size_t)pn] = pass == 0 ? e->h_cdAfter[(size_t)pn] : e->h_cdBefore[(size_t)pn];
+                            lk_r[(size_t)pn] = pass == 0 ? 1 : 0;
+                            e->tau_loc_state[(size_t)r].push_back(pass == 0 ? 1 : 0);
+                            e->tau_loc_pop[(size_t)r].push_back(pn);
+                            e->tau_loc_time[(size_t)r].push_back(0.0);
+                            flips += 1;
+                        }
+                    }
+                    if (flips > 0) {
+                        HIPCHECK(e, hipMemcpy((double *)e->t_cd.p + r * P, cd_r.data(), (size_t)P * 8, hipMemcpyHostToDevice));
+                        HIPCHECK(e, hipMemcpy((int32_t *)e->t_lock.p + r * P, lk_r.data(), (size_t)P * 4, hipMemcpyHostToDevice));
+                        const int32_t one = 1;
+                        HIPCHECK(e, hipMemcpy(a.eff_dirty + r, &one, 4, hipMemcpyHostToDevice));
+                    }
+                    swaps_kept[(size_t)r] += cnt[(size_t)r * 8 + 6] + flips;   // swapLockdown survives a Restart
+                }
                 HIPCHECK(e, hipMemset((int64_t *)e->t_counters.p + r * 8, 0, 64));
                 HIPCHECK(e, hipMemset((unsigned long long *)e->t_mevn.p + r, 0, 8));
                 HIPCHECK(e, hipMemset((unsigned long long *)e->t_mevbase.p + r, 0, 8));
                 for (int i = 0; i < 8; i++) cnt[(size_t)r * 8 + i] = 0;
-                cnt0[(size_t)r] = {0, 0, 0, 0, 0, 0, base_cnt[6], 0};
+                cnt0[(size_t)r] = {0, 0, 0, 0, 0, 0, base_cnt[6] + swaps_kept[(size_t)r], 0};
                 tnow[(size_t)r] = 0.0;
                 ev_ptr[(size_t)r] = 0;
                 e->tau_ev_ptr0[(size_t)r] = 0;
@@ -1110,7 +1180,7 @@ extern "C" int vgx_simulate_tau(vgx_engine *e, int64_t iterations, int64_t sampl
                 gI[(size_t)r] = g0;
                 att[(size_t)r] += 1;
                 if (att[(size_t)r] < attempts) {
-                    running[(size_t)r] = (g0 != 0) ? 1 : 0;
+                    running[(size_t)r] = (g0 != 0 && rates_nonzero_initial) ? 1 : 0;   // pyx:2311 on the restored state
                     fresh[(size_t)r] = 1;
                     if (running[(size_t)r]) any = true;
                     else r -= 1;  // re-evaluate: the attempt ends at once
@@ -1193,6 +1263,7 @@ extern "C" int vgx_simulate_tau(vgx_engine *e, int64_t iterations, int64_t sampl
         for (int64_t r = 0; r < R; r++) {
             if (!running[(size_t)r]) continue;
             if (err_h[(size_t)r] == VGX_ERR_CAPACITY) return fail(e, VGX_ERR_CAPACITY, "vgx_simulate_tau: replicate " + std::to_string(r) + ": list of cross-compartment events full");
+            if (err_h[(size_t)r] == 7) return fail(e, VGX_ERR_CAPACITY, "vgx_simulate_tau: replicate " + std::to_string(r) + ": lockdown log full (" + std::to_string(VGX_LOC_CAP) + " switches per call)");
             if (err_h[(size_t)r]) return fail(e, VGX_ERR_LOOP_GUARD, "vgx_simulate_tau: replicate " + std::to_string(r) + ": tau underflow in the halving loop");
             if (mev_cap > 0 && (int64_t)mevn[(size_t)r] > mev_cap)
                 return fail(e, VGX_ERR_CAPACITY, "vgx_simulate_tau: multievent buffer full (pass record_events=0 for large runs)");
@@ -1493,7 +1564,7 @@ extern "C" int vgx_get_multievents(vgx_engine *e, int64_t replicate, int64_t cap
     if (!e->last_was_tau) return VGX_OK;
     HIPCHECK(e, hipSetDevice(e->device));
     const auto &lg = e->tau_log[(size_t)replicate];
-    int64_t rows = lg.empty() ? 0 : lg.back().m1;
+    int64_t rows = (lg.empty() || e->tau_mev_cap <= 0) ? 0 : lg.back().m1;   // no rows when the call did not record them
     *n = rows;
     rows = std::min(rows, cap);
     if (rows <= 0) return VGX_OK;

@@ -1481,6 +1481,8 @@ extern "C" __global__ void __launch_bounds__(64) vgx_tau_finish_kernel(VgxTauArg
                         a.loc_rec[((int64_t)rep * VGX_LOC_CAP + slot) * 2 + 0] = pass == 0 ? 1 : 0;
                         a.loc_rec[((int64_t)rep * VGX_LOC_CAP + slot) * 2 + 1] = pn;
                         a.loc_time[(int64_t)rep * VGX_LOC_CAP + slot] = a.time_now[rep] + a.tau[rep];
+                    } else {
+                        a.error[rep] = 7;   // lockdown log full: the call fails like the direct path's (no silent truncation)
                     }
                     atomicAdd((unsigned long long *)&a.counters[(int64_t)rep * 8 + 6], 1ull);  // swapLockdown
                     a.eff_dirty[rep] = 1;
