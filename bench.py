@@ -231,6 +231,44 @@ def single_leg(device):
     return out
 
 
+def rowscan_leg(device, rows=4096):
+    """K3: the dense propensity row pass of the reference's layout (UpdateRates infect branch + fastChoose over hapPopRate,
+    pyx:518-528, fast_choose.pxi:18-31) streamed for `rows` (replicate, population) rows of config 3 (H = 65 536, S = 1)
+    resident in HBM.  Algorithmic bytes per row visit: SURVEY.md 8(d)'s H*(84+16S) + 16P + 48."""
+    import numpy as np
+    from vgsim_amd import _capi
+    H, S = 4 ** SITES, SUS
+    rng = np.random.default_rng(3)
+    inf = (rng.integers(1, 4, size=(1, H)) * (rng.random((1, H)) < 0.0625)).astype(np.int64)     # 4096 occupied haplotypes
+    r123 = np.broadcast_to(np.array([0.9, 0.1, 0.08]), (1, H, 3)).copy()
+    out = _capi.propensity_scan(inf, r123, np.arange(H), np.full(H, 2.5), np.ones((H, S)), np.full((1, S), 1e7 - 8000.0),
+                                np.array([9.9e-8]), rng.random(rows), bench_rows=rows, repeats=5)
+    survey_row = H * (84 + 16 * S) + 16 * POPS + 48
+    ms = out["ms_update"] + out["ms_choose"]
+    # what has to stream from HBM per row visit: the row's own arrays (infectious 8, eventHapPopRate[1:4] 24 read; the four rate
+    # arrays 24 + 8S written; on average half of hapPopRate read again by the choice).  The per-haplotype parameter arrays of
+    # SURVEY's count (numToHap, bRate, susceptibility: 16 + 8S B/hn) are shared by all rows and stay in L2 / Infinity Cache.
+    per_row = H * (8 + 24 + 24 + 8 * S) + 4 * H
+    exact = {"row_arrays_read": H * 32, "row_arrays_written": H * (24 + 8 * S), "choice_mean": 4 * H,
+             "shared_parameter_arrays_cached": H * (16 + 8 * S)}
+    traffic = None
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "pmc_rowscan.json")))
+        if d["config"] == {"rows": rows, "H": H, "S": S}:
+            traffic = d["hbm_bytes_per_pass"]
+    except Exception:
+        pass
+    return {"workload": "K3 dense propensity row pass: %d rows x %d haplotypes x %d group(s), row update + fastChoose" % (rows, H, S),
+            "rows_per_s": rows / (ms * 1e-3), "unit": "row visits/s (device time)", "ms_update": out["ms_update"], "ms_choose": out["ms_choose"],
+            "roofline": {"bound": "hbm", "achieved": rows * per_row / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": rows * per_row / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "vgx_rowscan_update_kernel + vgx_rowscan_choose_kernel",
+                         "bytes_per_row_visit": per_row, "bytes_by_array": exact,
+                         "survey_formula": {"bytes_per_row_visit": survey_row, "GBs": rows * survey_row / (ms * 1e-3) / 1e9,
+                                            "note": "SURVEY.md 8(d) counts the shared parameter arrays per row visit; they are "
+                                                    "cache-resident here, so this figure can exceed the HBM peak"}}}
+
+
 def fast_leg(device, replicates, events, traj_points):
     """The headline workload (natural occupancy) in FAST mode (one replicate per wavefront), device time of one launch after
     a warm-up."""
@@ -413,7 +451,7 @@ def main():
     ap.add_argument("--no-tau", action="store_true", help="skip the tau-leap (config 4) leg")
     ap.add_argument("--no-extra", action="store_true", help="skip the FAST-mode, spread-occupancy and config-2 legs")
     ap.add_argument("--only", default="", help="development/profiling: run only this extra leg (fast_mode, spread_occupancy, "
-                                               "spread_occupancy_fast, config2, genealogy, single_trajectory, direct_config4_shape, tau_leap) and print its JSON")
+                                               "spread_occupancy_fast, config2, genealogy, single_trajectory, direct_config4_shape, propensity_scan, tau_leap) and print its JSON")
     a = ap.parse_args()
 
     # ---- ranks: one process per GPU.  Under a launcher (torch.distributed.run sets WORLD_SIZE) this process is one rank;
@@ -448,7 +486,7 @@ def main():
                   ("spread_occupancy", lambda d: spread_leg(d, "exact", replicates=8192, events=2500)),
                   ("spread_occupancy_fast", lambda d: spread_leg(d, "fast", replicates=4096)),
                   ("config2", c2_leg), ("genealogy", genealogy_leg), ("single_trajectory", single_leg),
-                  ("direct_config4_shape", c4_direct_leg), ("tau_leap", tau_leg))
+                  ("direct_config4_shape", c4_direct_leg), ("propensity_scan", rowscan_leg), ("tau_leap", tau_leg))
     if a.only:
         print(json.dumps({a.only: dict(extra_legs)[a.only](local)}), flush=True)
         return
@@ -555,7 +593,7 @@ def main():
         if tau is not None:
             line["tau_leap"] = tau
         if world == 1 and not a.no_extra:
-            for name, fn in extra_legs[:7]:
+            for name, fn in extra_legs[:-1]:
                 try:
                     line[name] = fn(local)
                 except Exception as ex:

@@ -454,9 +454,9 @@ def propensity_scan(infectious, rates123, numToHap, bRate, susceptibility, rowSu
     S = int(np.asarray(susceptibility).reshape(H, -1).shape[1])
     n = bench_rows if bench_rows else rows
 
-    def fit(a, shape):   # bench mode: per-row inputs are repeated for the synthetic rows
-        a = np.ascontiguousarray(a, dtype=np.float64).reshape((rows,) + shape)
-        return np.ascontiguousarray(np.resize(a, (n,) + shape)) if bench_rows else a
+    def fit(a, shape):   # bench mode: per-row inputs are given per synthetic row, or repeated
+        a = np.ascontiguousarray(a, dtype=np.float64).reshape((-1,) + shape)
+        return np.ascontiguousarray(np.resize(a, (n,) + shape)) if len(a) != n else a
     keep = dict(infectious=inf, eventRates123=np.ascontiguousarray(rates123, dtype=np.float64).reshape(rows, H, 3),
                 numToHap=np.ascontiguousarray(numToHap, dtype=np.int64), bRate=np.ascontiguousarray(bRate, dtype=np.float64),
                 susceptibility=np.ascontiguousarray(susceptibility, dtype=np.float64).reshape(H, S),
