@@ -567,7 +567,7 @@ static int init_device_state(vgx_engine *e, int64_t traj_points) {
     rc |= ensure(e, e->r_nocc, (size_t)(R * P) * 4);
     rc |= ensure(e, e->r_lhap, (size_t)(R * P * cap) * 4);
     rc |= ensure(e, e->r_lcls, (size_t)(R * P * cap) * 4);
-    rc |= ensure(e, e->r_lcnt, (size_t)(R * P * cap) * 8);
+    rc |= ensure(e, e->r_lcnt, (size_t)(R * P * cap + 64) * 8);   // + one tile: vgx_quad.hip reads whole 64-entry tiles
     const int64_t capT = cap / 64 + 1;
     rc |= ensure(e, e->r_ltsum, (size_t)(R * P * capT) * 8);
     rc |= ensure(e, e->r_sc, (size_t)R * sizeof(VgxRepScalars));

@@ -125,6 +125,133 @@ static __device__ __forceinline__ double row_scan16(double v, double carry, doub
     return res;
 }
 
+// Long lists are streamed in TILES of 64 entries: lane l of the row holds entries 4l .. 4l+3 (32 contiguous bytes per lane,
+// 512 per row and load instruction group).  List order = (k = 0..15: lane k's four entries), so the chain takes the four
+// registers in turn for every broadcast lane.
+#define QFM4(K) "v_fmac_f64_dpp %0, %1, %5 row_newbcast:" #K " row_mask:0xf bank_mask:0xf\n\t" \
+                "v_fmac_f64_dpp %0, %2, %5 row_newbcast:" #K " row_mask:0xf bank_mask:0xf\n\t" \
+                "v_fmac_f64_dpp %0, %3, %5 row_newbcast:" #K " row_mask:0xf bank_mask:0xf\n\t" \
+                "v_fmac_f64_dpp %0, %4, %5 row_newbcast:" #K " row_mask:0xf bank_mask:0xf\n\t"
+static __device__ __forceinline__ double row_sum64(double w0, double w1, double w2, double w3, double acc) {
+    const double one = 1.0;
+    asm volatile("s_nop 1\n\t" QFM4(0) QFM4(1) QFM4(2) QFM4(3) QFM4(4) QFM4(5) QFM4(6) QFM4(7) QFM4(8) QFM4(9) QFM4(10) QFM4(11)
+                     QFM4(12) QFM4(13) QFM4(14) QFM4(15)
+                 : "+v"(acc)
+                 : "v"(w0), "v"(w1), "v"(w2), "v"(w3), "v"(one));
+    return acc;
+}
+// the serial prefix of every entry of a tile: p[j] of lane l = carry + (all entries before 4l + j) + its own
+#define QSTEP4(K)                                                                                                  \
+    asm volatile(QFM(K) : "+v"(acc) : "v"(w0), "v"(one)); p0 = rl_ == K ? acc : p0;                                 \
+    asm volatile(QFM(K) : "+v"(acc) : "v"(w1), "v"(one)); p1 = rl_ == K ? acc : p1;                                 \
+    asm volatile(QFM(K) : "+v"(acc) : "v"(w2), "v"(one)); p2 = rl_ == K ? acc : p2;                                 \
+    asm volatile(QFM(K) : "+v"(acc) : "v"(w3), "v"(one)); p3 = rl_ == K ? acc : p3;
+static __device__ __forceinline__ void row_scan64(double w0, double w1, double w2, double w3, double carry, double &p0, double &p1,
+                                                  double &p2, double &p3) {
+    const double one = 1.0;
+    const int rl_ = threadIdx.x & 15;
+    double acc = carry;
+    p0 = p1 = p2 = p3 = carry;
+    asm volatile("s_nop 1" ::: );
+    QSTEP4(0) QSTEP4(1) QSTEP4(2) QSTEP4(3) QSTEP4(4) QSTEP4(5) QSTEP4(6) QSTEP4(7) QSTEP4(8) QSTEP4(9) QSTEP4(10) QSTEP4(11)
+    QSTEP4(12) QSTEP4(13) QSTEP4(14) QSTEP4(15)
+}
+struct QTile { int64_t c0, c1, c2, c3; };
+static __device__ __forceinline__ QTile tile_load(const int64_t *ln, int t, int rl) {   // entries 64t + 4rl .. + 3
+    const longlong2 a = *(const longlong2 *)(ln + (int64_t)t * 64 + 4 * rl), b = *(const longlong2 *)(ln + (int64_t)t * 64 + 4 * rl + 2);
+    QTile q;
+    q.c0 = a.x; q.c1 = a.y; q.c2 = b.x; q.c3 = b.y;
+    return q;
+}
+
+struct QSel { int k_hit, hap_hit, err; double pre_hit, w_hit; int64_t cnt_hit; };
+// The haplotype choice over lists longer than 64 entries (inlined: an out-of-line call measured slower in both regimes).
+// Called with all lanes active.
+static __device__ __forceinline__ void q_long_select(const int64_t *ln, const int32_t *lh, int n_sel, int maxn, double tE,
+                                                               double r2, bool evn, int H, QSel &o) {
+    const int rl = threadIdx.x & 15;
+    o.k_hit = -1; o.err = 0;
+    // long lists: the running sum advances one tile of 64 entries per step; the tile in which it first reaches r is
+    // then scanned entry by entry — same additions, same order.  Loads run QT tiles ahead (unconditional: a row
+    // that is through, or has its hit, re-reads its tile 0; every list is followed by 64 entries of padding).
+    enum { QT = 3 };
+    QTile buf[QT];
+    double carry = 0.0, carry_hit = 0.0;
+    int t_hit = -1;
+    const int nt = (n_sel + 63) >> 6, maxt = (maxn + 63) >> 6;
+#pragma unroll
+    for (int d = 0; d < QT; ++d) buf[d] = tile_load(ln, d < nt ? d : 0, rl);
+    for (int tb = 0; tb < maxt; tb += QT) {
+#pragma unroll
+        for (int d = 0; d < QT; ++d) {
+            const int t = tb + d;
+            const QTile c = buf[d];
+            buf[d] = tile_load(ln, (t + QT < nt && t_hit < 0) ? t + QT : 0, rl);
+            const int e0 = t * 64 + 4 * rl;
+            const double w0 = e0 + 0 < n_sel ? tE * (double)c.c0 : 0.0, w1 = e0 + 1 < n_sel ? tE * (double)c.c1 : 0.0;
+            const double w2 = e0 + 2 < n_sel ? tE * (double)c.c2 : 0.0, w3 = e0 + 3 < n_sel ? tE * (double)c.c3 : 0.0;
+            const double acc = row_sum64(w0, w1, w2, w3, carry);
+            if (t_hit < 0 && t < nt && !(acc < r2)) { t_hit = t; carry_hit = carry; }
+            carry = acc;
+        }
+        if (!__ballot(nt > tb + QT && t_hit < 0)) break;
+    }
+    // refine inside the hit tile (rows without a hit look at their last tile for the H-1 rule)
+    const int tt = t_hit >= 0 ? t_hit : max((n_sel - 1) >> 6, 0);
+    const QTile c = tile_load(ln, tt, rl);
+    const int e0 = tt * 64 + 4 * rl;
+    const double w0 = e0 + 0 < n_sel ? tE * (double)c.c0 : 0.0, w1 = e0 + 1 < n_sel ? tE * (double)c.c1 : 0.0;
+    const double w2 = e0 + 2 < n_sel ? tE * (double)c.c2 : 0.0, w3 = e0 + 3 < n_sel ? tE * (double)c.c3 : 0.0;
+    double p0, p1, p2, p3;
+    row_scan64(w0, w1, w2, w3, t_hit >= 0 ? carry_hit : 0.0, p0, p1, p2, p3);
+    int mine = 64;
+    if (t_hit >= 0) {
+        if (e0 + 3 < n_sel && !(p3 < r2)) mine = 4 * rl + 3;
+        if (e0 + 2 < n_sel && !(p2 < r2)) mine = 4 * rl + 2;
+        if (e0 + 1 < n_sel && !(p1 < r2)) mine = 4 * rl + 1;
+        if (e0 + 0 < n_sel && !(p0 < r2)) mine = 4 * rl + 0;
+    }
+    const int q = row_min(mine);
+    const int qe = q < 64 ? q : ((n_sel - 1) & 63);      // entry inside the tile: the hit, or the list's last
+    const int ql = qe >> 2, qj = qe & 3;
+    const double psel = qj == 0 ? p0 : qj == 1 ? p1 : qj == 2 ? p2 : p3;
+    const double wsel = qj == 0 ? w0 : qj == 1 ? w1 : qj == 2 ? w2 : w3;
+    const int64_t csel = qj == 0 ? c.c0 : qj == 1 ? c.c1 : qj == 2 ? c.c2 : c.c3;
+    o.pre_hit = q < 64 ? rowget_f64(psel, ql) : carry;     // no hit: the total of the whole list
+    o.w_hit = rowget_f64(wsel, ql);
+    o.cnt_hit = rowget_i64(csel, ql);
+    o.hap_hit = lh[min(tt * 64 + qe, max(n_sel - 1, 0))];
+    if (q < 64) o.k_hit = tt * 64 + q;
+    else if (evn) {
+        if (n_sel > 0 && o.hap_hit == H - 1) o.k_hit = n_sel - 1; else o.err = Q_ERR_ZERO_WEIGHT + 256 * 3;
+    }
+            
+}
+
+// infectPopRate over a list longer than 64 entries (pyx:519-528)
+static __device__ __forceinline__ double q_long_sum(const int64_t *ln, int n, int maxn, double tE) {
+    const int rl = threadIdx.x & 15;
+    double acc = 0.0;
+    enum { QT = 3 };
+    QTile buf[QT];
+    const int nt = (n + 63) >> 6, maxt = (maxn + 63) >> 6;
+#pragma unroll
+    for (int d = 0; d < QT; ++d) buf[d] = tile_load(ln, d < nt ? d : 0, rl);
+    for (int tb = 0; tb < maxt; tb += QT) {
+#pragma unroll
+        for (int d = 0; d < QT; ++d) {
+            const int t = tb + d;
+            const QTile c = buf[d];
+            buf[d] = tile_load(ln, t + QT < nt ? t + QT : 0, rl);
+            const int e0 = t * 64 + 4 * rl;
+            const double w0 = e0 + 0 < n ? tE * (double)c.c0 : 0.0, w1 = e0 + 1 < n ? tE * (double)c.c1 : 0.0;
+            const double w2 = e0 + 2 < n ? tE * (double)c.c2 : 0.0, w3 = e0 + 3 < n ? tE * (double)c.c3 : 0.0;
+            acc = row_sum64(w0, w1, w2, w3, acc);
+        }
+    }
+    return acc;
+}
+
 struct QArgs {          // what the prep kernel leaves for all replicates
     const double *effMig;   // [P][P]
     const double *maxEBM;   // [P]
@@ -176,30 +303,31 @@ extern "C" __global__ void __launch_bounds__(64, VGX_QUAD_WAVES) vgx_quad_kernel
     int32_t *s_nocc = (int32_t *)(s_ti + 64);
     double *s_cc = (double *)(s_nocc + 64);
     int64_t *s_cnt = (int64_t *)(s_cc + 4);
+    uint64_t *s_inc = (uint64_t *)(s_cnt + 6);         // counters use 5 of their 8 slots; the last two hold the PCG64 increment
 #define QBUMP(i) do { if (rl == 0) s_cnt[i] += 1; } while (0)
 
     // the single rate class
     const double c_b = p.cb_b[0], c_sig = p.cb_sigma[0], c_d = p.c_d[0], c_s = p.c_s[0], c_tm = p.c_tm[0];
 
     // ---- load state ----
-    double *gD = r.popD + rep * PD_COUNT * P;
-    int64_t *gI64 = r.popI + rep * PI_COUNT * P;
-    int32_t *gN = r.nocc + rep * P;
     {
+        const double *gD = r.popD + rep * PD_COUNT * P;
+        const int64_t *gI64 = r.popI + rep * PI_COUNT * P;
+        const int32_t *gN = r.nocc + rep * P;
         const int pn = lane;
         k_cd[pn] = pn < P ? gD[PD_CD * P + pn] : 0.0;   // identical in every replicate (no lockdown switches)
         k_as[pn] = pn < P ? p.actualSizes[pn] : 1.0;
         k_smul[pn] = pn < P ? c_s * p.sampMult[pn] : 0.0;
         k_mebm[pn] = pn < P ? qa.maxEBM[pn] : 0.0;
-    }
-    for (int s = 0; s < 4; ++s) {
-        const int pn = s * 16 + rl;
-        const bool ok = pn < P;
-        s_inf[pn] = 0.0; s_bc[pn] = 0.0;
-        if (rl < 4) s_cc[rl] = 0.0;
-        s_ts[pn] = ok ? gI64[PI_TOTSUS * P + pn] : 0;
-        s_ti[pn] = ok ? gI64[PI_TOTINF * P + pn] : 0;
-        s_nocc[pn] = ok ? gN[pn] : 0;
+        for (int s = 0; s < 4; ++s) {
+            const int pq = s * 16 + rl;
+            const bool ok = pq < P;
+            s_inf[pq] = 0.0; s_bc[pq] = 0.0;
+            if (rl < 4) s_cc[rl] = 0.0;
+            s_ts[pq] = ok ? gI64[PI_TOTSUS * P + pq] : 0;
+            s_ti[pq] = ok ? gI64[PI_TOTINF * P + pq] : 0;
+            s_nocc[pq] = ok ? gN[pq] : 0;
+        }
     }
     WSYNC();
 
@@ -208,10 +336,8 @@ extern "C" __global__ void __launch_bounds__(64, VGX_QUAD_WAVES) vgx_quad_kernel
     int32_t *lcls = r.lcls + rep * P * cap;
     int64_t *lcnt = r.lcnt + rep * P * cap;
     int64_t *ltsum = r.ltsum + rep * P * capT;
-    double *ev_rate = r.ev_rate + rep * r.evcap;
-    int32_t *ev_cols = r.ev_cols + rep * r.evcap * VGX_EV_COLS;
-    double *traj = r.traj ? r.traj + rep * r.traj_points * P * 2 : nullptr;
-    VgxRepScalars *sc = r.sc + rep;
+    const bool has_traj = r.traj != nullptr;
+    const VgxRepScalars *sc = r.sc + rep;
 
     double t_now = sc->currentTime, totalRate = 0.0, totalMig = 0.0;
     int64_t gI = sc->globalInfectious, ev_ptr = sc->ev_ptr;
@@ -220,10 +346,10 @@ extern "C" __global__ void __launch_bounds__(64, VGX_QUAD_WAVES) vgx_quad_kernel
         s_cnt[QC_B] = sc->bCounter; s_cnt[QC_D] = sc->dCounter; s_cnt[QC_M] = sc->mCounter;
         s_cnt[QC_MIGP] = sc->migPlus; s_cnt[QC_MIGN] = sc->migNonPlus;
     }
-    int64_t loops = 0, att_loops = 0, att = 0, restarts = 0, good_attempt = sc->good_attempt, last_att = -1, traj_next = 0;
+    int64_t loops = 0, att_loops = 0, good_attempt = sc->good_attempt;
+    int att = 0, restarts = 0, last_att = -1, traj_next = 0;       // attempts and grid points are far below 2^31
     int st = live ? ST_REBUILD : ST_DONE, err = 0;
     bool open = false;
-    const int64_t seed = r.seeds[rep];
     const double tlimit = (double)a.time;
     const bool has_tl = !(a.time == -1.0f);
 
@@ -243,7 +369,7 @@ extern "C" __global__ void __launch_bounds__(64, VGX_QUAD_WAVES) vgx_quad_kernel
         k_jump[0] = Ah; k_jump[1] = Al; k_jump[2] = Gh; k_jump[3] = Gl;
     }
     WSYNC();
-    uint64_t g_sh = 0, g_sl = 0, g_ih = 0, g_il = 0;   // row-uniform: stream position, increment
+    uint64_t g_sh = 0, g_sl = 0;                       // row-uniform: stream position (the increment lives in LDS)
     double g_val = 0.0;                                // this lane's output of the current batch
     int pos = 8;                                       // iterations consumed from the row's batch (8 = empty)
     // a list of up to 64 entries read for the haplotype choice stays in registers for the rate refresh
@@ -267,8 +393,9 @@ extern "C" __global__ void __launch_bounds__(64, VGX_QUAD_WAVES) vgx_quad_kernel
                     st = ST_DONE;
                 } else {
                     VgxPcg64 sd;
-                    vgx_pcg64_seed(sd, (uint64_t)seed, (uint32_t)att);
-                    g_sh = sd.sh; g_sl = sd.sl; g_ih = sd.ih; g_il = sd.il;
+                    vgx_pcg64_seed(sd, (uint64_t)r.seeds[rep], (uint32_t)att);
+                    g_sh = sd.sh; g_sl = sd.sl;
+                    if (rl == 0) { s_inc[0] = sd.ih; s_inc[1] = sd.il; }     // the stream's increment: read back at every refill
                     pos = 8;
                     open = true;
                     last_att = att; att_loops = 0;
@@ -303,7 +430,7 @@ extern "C" __global__ void __launch_bounds__(64, VGX_QUAD_WAVES) vgx_quad_kernel
                 const bool fill = ev && pos == 8;
                 uint64_t h, l, ch, cl;
                 vgx_mul128(k_jump[0], k_jump[1], g_sh, g_sl, h, l);
-                vgx_mul128(k_jump[2], k_jump[3], g_ih, g_il, ch, cl);
+                vgx_mul128(k_jump[2], k_jump[3], s_inc[0], s_inc[1], ch, cl);
                 vgx_add128(h, l, ch, cl);
                 const double u = vgx_pcg64_output_double(h, l);
                 const double v = (rl & 1) ? u : -vgx_log(u);
@@ -317,13 +444,13 @@ extern "C" __global__ void __launch_bounds__(64, VGX_QUAD_WAVES) vgx_quad_kernel
             den = totalRate + totalMig;
             const double t_new = t_now + (nlog / den);   // SampleTime pyx:476-478
             // summary trajectories: the state before the event for every grid point the step passes
-            if (traj) {
+            if (has_traj) {
                 while (true) {
                     const double tg = r.traj_t0 + (double)traj_next * r.traj_dt;
                     const bool emit = ev && live && traj_next < r.traj_points && tg < t_new;
                     if (!__ballot(emit)) break;
                     if (emit) {
-                        double *o = traj + traj_next * (int64_t)P * 2;
+                        double *o = r.traj + (rep * r.traj_points + traj_next) * (int64_t)P * 2;
                         for (int s = 0; s < nslot; ++s) {
                             const int pn = s * 16 + rl;
                             if (pn < P) { o[pn * 2 + 0] = (double)s_ti[pn]; o[pn * 2 + 1] = (double)s_ts[pn]; }
@@ -444,48 +571,10 @@ extern "C" __global__ void __launch_bounds__(64, VGX_QUAD_WAVES) vgx_quad_kernel
                     ch_pi = pi;
                 }
             } else {
-                // long lists: the running sum advances one chunk of 16 entries per step; the chunk in which it first
-                // reaches r is then scanned lane by lane — same additions, same order.  Loads run QD chunks ahead.
-                enum { QD = 8 };
-                int64_t buf[QD];
-                double carry = 0.0, carry_hit = 0.0;
-                int c_hit = -1;
-                // (loads are unconditional on a clamped index, so that QD of them stay in flight; entries beyond the list or
-                // after the hit re-read entry 0 and are masked at their use)
-#pragma unroll
-                for (int d = 0; d < QD; ++d) { const int k = d * 16 + rl; buf[d] = ln[k < n_sel ? k : 0]; }
-                for (int cb = 0; cb * 16 < maxn; cb += QD) {
-#pragma unroll
-                    for (int d = 0; d < QD; ++d) {
-                        const int c = cb + d;
-                        const int64_t cn = buf[d];
-                        const int kn = (c + QD) * 16 + rl;
-                        buf[d] = ln[(kn < n_sel && c_hit < 0) ? kn : 0];
-                        const double w = (c * 16 + rl < n_sel) ? tE * (double)cn : 0.0;
-                        const double acc = row_sum16(w, carry);
-                        if (c_hit < 0 && c * 16 < n_sel && !(acc < r2)) { c_hit = c; carry_hit = carry; }
-                        carry = acc;
-                    }
-                    if (!__ballot(n_sel > (cb + QD) * 16 && c_hit < 0)) break;
-                }
-                // refine inside the hit chunk (rows without a hit look at their last chunk for the H-1 rule)
-                const int cc = c_hit >= 0 ? c_hit : max((n_sel - 1) >> 4, 0);
-                const int k = cc * 16 + rl;
-                const bool in = k < n_sel;
-                const int64_t cn = ln[in ? k : 0];
-                const int hp = lh[in ? k : 0];
-                const double w = in ? tE * (double)cn : 0.0;
-                double tot_;
-                const double pre = row_scan16(w, carry_hit, tot_);
-                const int q = row_min(c_hit >= 0 && in && !(pre < r2) ? rl : 16);
-                const int qq = q < 16 ? q : max(n_sel - 1 - cc * 16, 0);
-                pre_hit = q < 16 ? rowget_f64(pre, qq) : carry;   // no hit: the total of the whole list
-                w_hit = rowget_f64(w, qq);
-                hap_hit = rowget_i32(hp, qq); cnt_hit = rowget_i64(cn, qq);
-                if (q < 16) k_hit = cc * 16 + q;
-                else if (evn) {
-                    if (n_sel > 0 && hap_hit == H - 1) k_hit = n_sel - 1; else err = Q_ERR_ZERO_WEIGHT + 256 * 3;
-                }
+                QSel sel;
+                q_long_select(ln, lh, n_sel, maxn, tE, r2, evn, H, sel);
+                k_hit = sel.k_hit; pre_hit = sel.pre_hit; w_hit = sel.w_hit; hap_hit = sel.hap_hit; cnt_hit = sel.cnt_hit;
+                if (sel.err) err = sel.err;
             }
             const bool evn_ok = evn && err == 0;
             if (evn && w_hit == 0.0 && err == 0) err = Q_ERR_ZERO_WEIGHT + 256 * 4;
@@ -836,13 +925,12 @@ extern "C" __global__ void __launch_bounds__(64, VGX_QUAD_WAVES) vgx_quad_kernel
                 const int64_t slot = ev_ptr - r.ev_base;
                 if (slot >= 0 && slot < r.evcap) {
                     if (live) {
-                        const int64_t key = (att << 40) | att_loops;
                         if (rl < VGX_EV_COLS) {
                             const int v = rl == 0 ? e_type : rl == 1 ? e_hap : rl == 2 ? e_pop : rl == 3 ? e_nh : rl == 4 ? e_np
-                                                                                                          : (int)(uint32_t)key;
-                            ev_cols[slot * VGX_EV_COLS + rl] = v;
+                                                                                                          : (int)(uint32_t)att_loops;
+                            r.ev_cols[(rep * r.evcap + slot) * VGX_EV_COLS + rl] = v;
                         } else if (rl == VGX_EV_COLS) {
-                            ev_rate[slot] = den;
+                            r.ev_rate[rep * r.evcap + slot] = den;
                         }
                     }
                 } else {
@@ -903,21 +991,7 @@ extern "C" __global__ void __launch_bounds__(64, VGX_QUAD_WAVES) vgx_quad_kernel
                     for (int c = 0; c < 4; ++c)
                         if (c < nch) acc = row_sum16(c * 16 + rl < n ? tE * (double)cn4[c] : 0.0, acc);
                 } else {
-                    enum { QD = 8 };
-                    int64_t buf[QD];
-#pragma unroll
-                    for (int d = 0; d < QD; ++d) { const int k = d * 16 + rl; buf[d] = ln[k < n ? k : 0]; }
-                    for (int cb = 0; cb * 16 < maxn; cb += QD) {
-#pragma unroll
-                        for (int d = 0; d < QD; ++d) {
-                            const int c = cb + d;
-                            const int64_t cn = buf[d];
-                            const int kn = (c + QD) * 16 + rl;
-                            buf[d] = ln[kn < n ? kn : 0];
-                            const double w = (c * 16 + rl < n) ? tE * (double)cn : 0.0;
-                            acc = row_sum16(w, acc);
-                        }
-                    }
+                    acc = q_long_sum(ln, n, maxn, tE);
                 }
                 if (act && rl == 0) { s_bc[pi] = bC; s_inf[pi] = acc; }
                 WSYNC();
@@ -970,12 +1044,12 @@ extern "C" __global__ void __launch_bounds__(64, VGX_QUAD_WAVES) vgx_quad_kernel
             if (ev_ptr <= 100 && a.iterations > 100) {
                 // Restart (pyx:714-738): compartments back to the initial snapshot, then UpdateAllRates
                 ev_ptr = 0; cS = 0;
-                if (rl < 8) s_cnt[rl] = 0;
+                if (rl < 6) s_cnt[rl] = 0;
                 t_now = 0.0; traj_next = 0;
                 restarts += 1; att += 1;
                 st = ST_REBUILD;
             } else {
-                good_attempt = att + 1;
+                good_attempt = (int64_t)att + 1;
                 st = ST_DONE;
             }
         }
@@ -1015,12 +1089,12 @@ extern "C" __global__ void __launch_bounds__(64, VGX_QUAD_WAVES) vgx_quad_kernel
     }
 
     // trailing grid points of the trajectories: the final state
-    if (traj) {
+    if (has_traj) {
         while (true) {
             const bool emit = live && traj_next < r.traj_points;
             if (!__ballot(emit)) break;
             if (emit) {
-                double *o = traj + traj_next * (int64_t)P * 2;
+                double *o = r.traj + (rep * r.traj_points + traj_next) * (int64_t)P * 2;
                 for (int s = 0; s < nslot; ++s) {
                     const int pn = s * 16 + rl;
                     if (pn < P) { o[pn * 2 + 0] = (double)s_ti[pn]; o[pn * 2 + 1] = (double)s_ts[pn]; }
@@ -1037,6 +1111,10 @@ extern "C" __global__ void __launch_bounds__(64, VGX_QUAD_WAVES) vgx_quad_kernel
     // ---- state back to HBM ----
     WSYNC();
     if (live) {
+        double *gD = r.popD + rep * PD_COUNT * P;
+        int64_t *gI64 = r.popI + rep * PI_COUNT * P;
+        int32_t *gN = r.nocc + rep * P;
+        VgxRepScalars *sc = r.sc + rep;
         for (int s = 0; s < nslot; ++s) {
             const int pn = s * 16 + rl;
             if (pn < P) {
