@@ -91,7 +91,9 @@ typedef struct vgx_run_opts {
                                 3 = four replicates per wavefront, one per 16-lane row (vgx_quad.hip; EXACT, popNum <= 64, one
                                 susceptibility group, one rate class, no possible lockdown switch) */
     int64_t reserved[2];     /* [0] tau path: 1 = run every try of the halving loop (pyx:2316-2321) instead of starting at the
-                                first try that is not certain to be rejected (same accepted steps either way) */
+                                first try that is not certain to be rejected (same accepted steps either way);
+                                [1] tau path: 1 = run the bounds check (pyx:2522-2528) as one dense pass over all compartments
+                                after every try instead of the fused own-delta / arrival tests (same decisions either way) */
 } vgx_run_opts;
 
 /* Per-replicate results of the last simulate call. */

@@ -32,7 +32,7 @@ extern "C" hipError_t vgxi_launch_init_reps(const VgxDevRep *r, int P, int S, in
 
 #define TAU_DECL(name) extern "C" hipError_t vgxi_##name(const VgxTauArgs *a, hipStream_t s);
 TAU_DECL(tau_eff) TAU_DECL(tau_scatter) TAU_DECL(tau_prep) TAU_DECL(tau_drift) TAU_DECL(tau_choose) TAU_DECL(tau_draw) TAU_DECL(tau_suscep_draw)
-TAU_DECL(tau_check) TAU_DECL(tau_decide) TAU_DECL(tau_commit) TAU_DECL(tau_finish) TAU_DECL(tau_draw_big)
+TAU_DECL(tau_check) TAU_DECL(tau_decide) TAU_DECL(tau_commit) TAU_DECL(tau_finish) TAU_DECL(tau_draw_big) TAU_DECL(tau_suspect)
 
 static std::string g_create_error;
 
@@ -79,7 +79,7 @@ struct vgx_engine {
         r_evrate, r_evcols, r_locrec, r_loctime, r_lociter, r_farate, r_fakey, r_traj, r_prof, r_qeff, r_qmebm, r_qflag;
     // tau-leaping (dense compartments)
     DevBuf t_I, t_S, t_dChk, t_dApp, t_dSi, t_dTot, t_totInf, t_gI, t_cd, t_lock, t_F, t_eff, t_Aeff, t_Gout, t_dS,
-        t_taubits, t_tau, t_time, t_flags, t_counters, t_cnttry, t_mev, t_mevn, t_mevbase, t_locn, t_mutcum, t_migcdf, t_migIn, t_mutHi, t_colT, t_colTW, t_inc, t_incn, t_sieve, t_sieveskip, t_big, t_bign, t_res;
+        t_taubits, t_tau, t_time, t_flags, t_counters, t_cnttry, t_mev, t_mevn, t_mevbase, t_locn, t_mutcum, t_migcdf, t_migIn, t_mutHi, t_colT, t_colTW, t_inc, t_incn, t_sieve, t_sieveskip, t_big, t_bign, t_res, t_susp, t_suspn;
     std::vector<int64_t> tau_sieve_skipped;   // [R] tries left out by the sieve in the last tau call
     bool last_was_tau = false;
     int64_t tau_mev_cap = 0;
@@ -974,6 +974,9 @@ extern "C" int vgx_simulate_tau(vgx_engine *e, int64_t iterations, int64_t sampl
     rc |= ensure(e, e->t_big, (size_t)(R * big_cap) * 8);
     rc |= ensure(e, e->t_bign, (size_t)R * 8);
     rc |= ensure(e, e->t_res, (size_t)R * 16 * 8);
+    const int64_t suspect_cap = std::min<int64_t>(P * H, (int64_t)1 << 16);
+    rc |= ensure(e, e->t_susp, (size_t)(R * suspect_cap) * 8);
+    rc |= ensure(e, e->t_suspn, (size_t)R * 8);
     rc |= ensure(e, e->t_sieve, (size_t)R * VGX_SIEVE_K * 8);
     rc |= ensure(e, e->t_sieveskip, (size_t)R * 8);
     rc |= ensure(e, e->t_cnttry, (size_t)R * 8 * 8);
@@ -999,12 +1002,13 @@ extern "C" int vgx_simulate_tau(vgx_engine *e, int64_t iterations, int64_t sampl
     rc |= upload(e, e->r_seeds, e->seeds.data(), e->seeds.size());
     if (rc) return VGX_ERR_HIP;
     HIPCHECK(e, hipMemset(e->t_incn.p, 0, (size_t)R * VGX_INC_SHARDS * 8));
-    HIPCHECK(e, hipMemset(e->t_dChk.p, 0, (size_t)(R * P * H) * 4));   // the step kernels keep both delta arrays zero between tries
+    HIPCHECK(e, hipMemset(e->t_dChk.p, 0, (size_t)(R * P * H) * 4));   // (every try overwrites both delta arrays completely)
     HIPCHECK(e, hipMemset(e->t_dApp.p, 0, (size_t)(R * P * H) * 4));
     HIPCHECK(e, hipMemset(e->t_dSi.p, 0, (size_t)(R * P * S) * 8));
     HIPCHECK(e, hipMemset(e->t_dTot.p, 0, (size_t)(R * P) * 8));
     HIPCHECK(e, hipMemset(e->t_counters.p, 0, (size_t)R * 64));
     HIPCHECK(e, hipMemset(e->t_bign.p, 0, (size_t)R * 8));
+    HIPCHECK(e, hipMemset(e->t_suspn.p, 0, (size_t)R * 8));
     HIPCHECK(e, hipMemset(e->t_sieve.p, 0, (size_t)R * VGX_SIEVE_K * 8));
     HIPCHECK(e, hipMemset(e->t_sieveskip.p, 0, (size_t)R * 8));
     HIPCHECK(e, hipMemset(e->t_cnttry.p, 0, (size_t)R * 64));
@@ -1076,6 +1080,8 @@ extern "C" int vgx_simulate_tau(vgx_engine *e, int64_t iterations, int64_t sampl
     a.counters = (int64_t *)e->t_counters.p; a.cnt_try = (int64_t *)e->t_cnttry.p;
     a.big = (int64_t *)e->t_big.p; a.big_cap = big_cap; a.big_n = (unsigned long long *)e->t_bign.p;
     a.res = (int64_t *)e->t_res.p;
+    a.suspect = (int64_t *)e->t_susp.p; a.suspect_cap = suspect_cap; a.suspect_n = (unsigned long long *)e->t_suspn.p;
+    a.dense_check = o.reserved[1] == 1 ? 1 : 0;   // validation: the bounds check as one dense pass over all compartments
     a.sieve = (double *)e->t_sieve.p; a.sieve_skipped = (int64_t *)e->t_sieveskip.p;
     // vgx_run_opts.reserved[0] = 1: run every try of the halving loop; with few compartments no try is ever a certain rejection
     a.sieve_on = (o.reserved[0] == 1 || P * H < 32768) ? 0 : 1;
@@ -1097,6 +1103,7 @@ extern "C" int vgx_simulate_tau(vgx_engine *e, int64_t iterations, int64_t sampl
     std::vector<unsigned long long> mevn((size_t)R, 0);
     for (int64_t r = 0; r < R; r++) running[(size_t)r] = (attempts > 0 && start_ok) ? 1 : 0;
     std::vector<int32_t> fresh((size_t)R, 1);  // attempt just opened: the pyx:2311 guard applies
+    std::vector<unsigned long long> susp_h;
     float ms_total = 0.f;
     int64_t launches = 0;
     std::vector<int32_t> dev_active, dev_step, dev_att;   // what the device holds (empty: nothing uploaded yet)
@@ -1213,7 +1220,18 @@ extern "C" int vgx_simulate_tau(vgx_engine *e, int64_t iterations, int64_t sampl
             HIPCHECK(e, vgxi_tau_draw_big(&a, e->stream));
             HIPCHECK(e, vgxi_tau_suscep_draw(&a, e->stream));
             HIPCHECK(e, vgxi_tau_scatter(&a, e->stream));
-            HIPCHECK(e, vgxi_tau_check(&a, e->stream));
+            HIPCHECK(e, vgxi_tau_suspect(&a, e->stream));
+            if (a.dense_check) HIPCHECK(e, vgxi_tau_check(&a, e->stream));
+            else if (suspect_cap < P * H) {
+                // more compartments below zero on their own than the list holds (never at tries the sieve lets through; tiny
+                // models list every compartment): the dense pass decides
+                susp_h.resize((size_t)R);
+                HIPCHECK(e, hipMemcpyAsync(susp_h.data(), a.suspect_n, (size_t)R * 8, hipMemcpyDeviceToHost, e->stream));
+                HIPCHECK(e, hipStreamSynchronize(e->stream));
+                bool over = false;
+                for (int64_t r = 0; r < R; r++) over = over || (int64_t)susp_h[(size_t)r] > suspect_cap;
+                if (over) { HIPCHECK(e, vgxi_tau_check(&a, e->stream)); launches += 1; }
+            }
             HIPCHECK(e, vgxi_tau_decide(&a, e->stream));
             HIPCHECK(e, vgxi_tau_commit(&a, e->stream));
             launches += 7;

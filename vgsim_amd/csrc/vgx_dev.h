@@ -213,4 +213,10 @@ struct VgxTauArgs {
     double *sieve;       // [R][VGX_SIEVE_K]
     int64_t *sieve_skipped;  // [R] tries skipped so far in this call
     int32_t sieve_on;
+    // compartments whose own events alone would take them below zero in the current try (they may be rescued by incoming
+    // mutants): re-examined after the scatter kernel (vgx_tau_suspect_kernel).  Overflow falls back to the dense check pass.
+    int64_t *suspect;        // [R][suspect_cap] pn * H + hn
+    int64_t suspect_cap;
+    unsigned long long *suspect_n;   // [R]
+    int32_t dense_check;     // 1: run vgx_tau_check_kernel over all compartments after every try (validation / fallback)
 };

@@ -813,6 +813,17 @@ static __device__ __forceinline__ void tau_incoming_flush(const VgxTauArgs &a, I
     __syncthreads();
 }
 
+// Bounds check of GenerateEvents_tau (pyx:2522-2528) for a compartment's OWN deltas, v = infectious + delta as booked by the
+// reference's check.  Incoming mutants only add to it afterwards, so v > sizes is final (the try is rejected); v < 0 may still
+// be rescued: the compartment is listed and looked at again once the scatter kernel has added the arrivals.
+static __device__ __forceinline__ void tau_own_check(const VgxTauArgs &a, int rep, int pn, int hn, int64_t v) {
+    if (v > a.p.sizes[pn]) a.ok[rep] = 0;
+    else if (v < 0) {
+        const unsigned long long slot = atomicAdd(&a.suspect_n[rep], 1ull);
+        if ((int64_t)slot < a.suspect_cap) a.suspect[(int64_t)rep * a.suspect_cap + (int64_t)slot] = (int64_t)pn * a.p.H + hn;
+    }
+}
+
 // Per-block tables of the draw kernel (a block works on ONE population): class parameters, this population's
 // transmission / migration weights per birth class and the bisection tables, staged in LDS when they fit
 // (else the pointers refer to the global arrays).
@@ -1093,10 +1104,12 @@ extern "C" __global__ void __launch_bounds__(TB) vgx_tau_draw_kernel(VgxTauArgs 
                              (uint32_t)((uint64_t)a.seeds[rep] >> 32) ^ 0x85EBCA6Bu};
     const int groups = ((H + 255) / 256) * 64;   // 4 haplotypes per thread, 256 per wavefront chunk
     const uint32_t ctr_step = (uint32_t)a.step[rep], ctr_retry = ((uint32_t)a.retry[rep] << 20) | 0xFFFFFu;   // loop invariants
-    // Phase A (every tile): the quick test; the few compartments that may draw events are queued in LDS.  Phase B (when
-    // the queue holds a few wavefronts' worth, and at the end): the queue is worked off with all lanes busy and the queued
-    // compartments' deltas are stored.  Both delta arrays are all zero on entry: the check kernel clears the entries of
-    // dChk it finds set, the commit kernel those of dApp, so a try costs no 8-bytes-per-compartment zero fill.
+    // Phase A (every tile): the quick test; the few compartments that may draw events are queued in LDS, every other
+    // compartment gets its zero deltas stored (coalesced 16-byte stores).  Phase B (when the queue holds a few wavefronts'
+    // worth, and at the end): the queue is worked off with all lanes busy and the queued compartments' deltas are stored.
+    // So every try OVERWRITES both delta arrays completely: nothing has to be cleared after a rejected try, the bounds check
+    // needs no pass of its own (own deltas are tested here, incoming ones by the scatter kernel, pyx:2522-2528) and the
+    // commit pass runs for the accepted try only.
     enum { QCAP = 8 * TB, QGO = QCAP - 4 * TB };
     __shared__ int q_n, q_h[QCAP], q_w[QCAP];
     __shared__ IncStage stage;
@@ -1134,13 +1147,24 @@ extern "C" __global__ void __launch_bounds__(TB) vgx_tau_draw_kernel(VgxTauArgs 
                 for (int j = 0; j < 4; ++j)
                     if (h0 + j < H) Iv[j] = Irow[h0 + j];
             }
+            int queued = 0;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 if (h0 + j < H && tau_cell_count(a, T, rep, pn, h0 + j, tau, w[j], (int64_t)Iv[j])) {
                     int slot = atomicAdd(&q_n, 1);
                     q_h[slot] = h0 + j;
                     q_w[slot] = (int)w[j];
+                    queued |= 1 << j;
                 }
+            }
+            // zero deltas of the compartments that draw nothing here (large ones are overwritten by vgx_tau_draw_big_kernel,
+            // queued ones by phase B): together with phase B every entry of both arrays is written in every try
+            if (full && queued == 0) {
+                *(int4 *)(dCrow + h0) = make_int4(0, 0, 0, 0);
+                *(int4 *)(dArow + h0) = make_int4(0, 0, 0, 0);
+            } else {
+                for (int j = 0; j < 4; ++j)
+                    if (h0 + j < H && !((queued >> j) & 1)) { dCrow[h0 + j] = 0; dArow[h0 + j] = 0; }
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // LDS only: queue length visible to everyone
@@ -1151,9 +1175,11 @@ extern "C" __global__ void __launch_bounds__(TB) vgx_tau_draw_kernel(VgxTauArgs 
             for (int k = threadIdx.x; k < nq; k += TB) {
                 const int h = q_h[k];
                 int64_t oc, oa;
-                tau_cell_events(a, T, rep, pn, h, tau, (int64_t)Irow[h], (uint32_t)q_w[k], oc, oa, cnt, &stage, sS, &sTot);
-                if (oc != 0) dCrow[h] = (int32_t)oc;
-                if (oa != 0) dArow[h] = (int32_t)oa;
+                const int64_t Ih = (int64_t)Irow[h];
+                tau_cell_events(a, T, rep, pn, h, tau, Ih, (uint32_t)q_w[k], oc, oa, cnt, &stage, sS, &sTot);
+                dCrow[h] = (int32_t)oc;
+                dArow[h] = (int32_t)oa;
+                tau_own_check(a, rep, pn, h, Ih + oc);
             }
             __syncthreads();
             if (threadIdx.x == 0) q_n = 0;
@@ -1271,8 +1297,9 @@ extern "C" __global__ void __launch_bounds__(TB) vgx_tau_draw_big_kernel(VgxTauA
         if (lane == 0) {
             const int64_t own = v[0] - v[1] - v[2] - v[3];
             const int64_t off = (int64_t)rep * P * H + cell;
-            if (own + v[4] != 0) a.dChk[off] = (int32_t)(own + v[4]);   // pyx:2473: migrants are booked on their source here
-            if (own != 0) a.dApp[off] = (int32_t)own;
+            a.dChk[off] = (int32_t)(own + v[4]);   // pyx:2473: migrants are booked on their source here
+            a.dApp[off] = (int32_t)own;
+            tau_own_check(a, rep, pn, hn, (int64_t)a.I[off] + own + v[4]);
             unsigned long long *ct = (unsigned long long *)&a.cnt_try[(int64_t)rep * 8];
             if (v[0]) atomicAdd(&ct[0], (unsigned long long)v[0]);
             if (v[1]) atomicAdd(&ct[1], (unsigned long long)v[1]);
@@ -1328,11 +1355,40 @@ extern "C" __global__ void __launch_bounds__(64) vgx_tau_scatter_kernel(VgxTauAr
         int64_t cell = e & (((int64_t)1 << VGX_INC_CELL_BITS) - 1);
         int k = (int)((e >> VGX_INC_CELL_BITS) & VGX_INC_MAXMULT);
         atomicAdd(&a.dApp[(int64_t)rep * PH + cell], k);
-        if (!(e >> 62)) atomicAdd(&a.dChk[(int64_t)rep * PH + cell], k);
+        if (!(e >> 62)) {
+            // upper bound of the check (pyx:2522-2528): arrivals only increase the compartment's delta, so whoever adds
+            // last sees the final value (the compartment's own delta was stored by the draw kernels before this one)
+            const int old = atomicAdd(&a.dChk[(int64_t)rep * PH + cell], k);
+            if ((int64_t)a.I[(int64_t)rep * PH + cell] + (int64_t)old + (int64_t)k > a.p.sizes[cell / a.p.H]) a.ok[rep] = 0;
+        }
     }
 }
 
-// Bounds check of GenerateEvents_tau (pyx:2522-2528).  grid = (ceil(H/TB), P, R).
+// The listed compartments after the arrivals (vgx_tau_scatter_kernel): still below zero -> the try is rejected.  Also the
+// susceptible compartments' bounds.  grid = (32, R).
+extern "C" __global__ void __launch_bounds__(TB) vgx_tau_suspect_kernel(VgxTauArgs a) {
+    const int rep = blockIdx.y;
+    if (!a.active[rep] || a.accepted[rep]) return;
+    const VgxDevParams &p = a.p;
+    const int P = p.P, S = p.S;
+    const int64_t PH = (int64_t)P * p.H;
+    unsigned long long n = a.suspect_n[rep];
+    bool bad = false;
+    if ((int64_t)n > a.suspect_cap) n = (unsigned long long)a.suspect_cap;   // overflow: the host runs the dense check instead
+    for (unsigned long long i = (unsigned long long)blockIdx.x * TB + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * TB) {
+        const int64_t cell = a.suspect[(int64_t)rep * a.suspect_cap + (int64_t)i];
+        if ((int64_t)a.I[(int64_t)rep * PH + cell] + (int64_t)a.dChk[(int64_t)rep * PH + cell] < 0) bad = true;
+    }
+    if (blockIdx.x == 0)
+        for (int i = threadIdx.x; i < P * S; i += TB) {
+            const int64_t v = a.dSi[(int64_t)rep * P * S + i] + a.S[(int64_t)rep * P * S + i];
+            if (v < 0 || v > p.sizes[i / S]) bad = true;
+        }
+    if (__any(bad) && (threadIdx.x & 63) == 0) a.ok[rep] = 0;
+}
+
+// Bounds check of GenerateEvents_tau (pyx:2522-2528) as one dense pass over all compartments: the fallback when the list of
+// vgx_tau_suspect_kernel overflowed, and the validation mode (vgx_run_opts.reserved[1] = 1).  grid = (ceil(H/TB), P, R).
 extern "C" __global__ void __launch_bounds__(TB) vgx_tau_check_kernel(VgxTauArgs a) {
     const int rep = blockIdx.z, pn = blockIdx.y;
     if (!a.active[rep] || a.accepted[rep]) return;
@@ -1355,13 +1411,11 @@ extern "C" __global__ void __launch_bounds__(TB) vgx_tau_check_kernel(VgxTauArgs
                         int64_t v = (int64_t)d[j] + (int64_t)Iv[j];
                         bad = bad || v < 0 || v > p.sizes[pn];
                     }
-                *(int4 *)(a.dChk + off) = make_int4(0, 0, 0, 0);   // nobody reads it after this kernel: zero for the next try
             } else {
                 for (int j = 0; j < 4; ++j)
                     if (d[j] != 0) {
                         int64_t v = (int64_t)d[j] + (int64_t)a.I[off + j];
                         bad = bad || v < 0 || v > p.sizes[pn];
-                        a.dChk[off + j] = 0;
                     }
             }
         }
@@ -1383,7 +1437,7 @@ extern "C" __global__ void __launch_bounds__(64) vgx_tau_decide_kernel(VgxTauArg
     __syncthreads();
     if (live) {  // the cross-compartment list of this draw has been applied by vgx_tau_scatter_kernel
         for (int i = threadIdx.x; i < a.inc_shards; i += 64) a.inc_n[(int64_t)rep * VGX_INC_SHARDS + i] = 0;
-        if (threadIdx.x == 0) a.big_n[rep] = 0;
+        if (threadIdx.x == 0) { a.big_n[rep] = 0; a.suspect_n[rep] = 0; }
     }
     if (threadIdx.x != 0) return;
     a.deciding[rep] = 0;
@@ -1424,21 +1478,18 @@ extern "C" __global__ void __launch_bounds__(TB) vgx_tau_commit_kernel(VgxTauArg
     const int P = a.p.P, S = a.p.S, H = a.p.H;
     const bool acc = a.accepted[rep] && !a.error[rep];
     const int h0 = (blockIdx.x * TB + threadIdx.x) * 4;   // four compartments per thread
-    if (h0 < H) {   // rejected tries too: their entries of dApp are cleared
+    if (h0 < H && acc) {   // the accepted try only: a rejected one leaves nothing behind (the next try overwrites the deltas)
         const int64_t off = (int64_t)rep * P * H + (int64_t)pn * H + h0;
         if (h0 + 3 < H && (H & 3) == 0) {
-            int4 x = *(const int4 *)(a.dApp + off);
+            const int4 x = *(const int4 *)(a.dApp + off);
             if (x.x | x.y | x.z | x.w) {
-                if (acc) {
-                    int4 v = *(const int4 *)(a.I + off);
-                    v.x += x.x; v.y += x.y; v.z += x.z; v.w += x.w;
-                    *(int4 *)(a.I + off) = v;
-                }
-                *(int4 *)(a.dApp + off) = make_int4(0, 0, 0, 0);
+                int4 v = *(const int4 *)(a.I + off);
+                v.x += x.x; v.y += x.y; v.z += x.z; v.w += x.w;
+                *(int4 *)(a.I + off) = v;
             }
         } else {
             for (int j = 0; j < 4; ++j)
-                if (h0 + j < H) { int32_t dA = a.dApp[off + j]; if (dA != 0) { if (acc) a.I[off + j] += dA; a.dApp[off + j] = 0; } }
+                if (h0 + j < H) { const int32_t dA = a.dApp[off + j]; if (dA != 0) a.I[off + j] += dA; }
         }
     }
     if (blockIdx.x == 0 && threadIdx.x < S) {
@@ -1582,6 +1633,7 @@ extern "C" __attribute__((visibility("hidden"))) int vgxi_tau_inc_shards(int64_t
     return sh;
 }
 TAU_LAUNCH(tau_check, CELL_GRID, dim3(TB))
+TAU_LAUNCH(tau_suspect, dim3(32, (unsigned)a->R), dim3(TB))
 TAU_LAUNCH(tau_decide, dim3((unsigned)a->R), dim3(64))
 TAU_LAUNCH(tau_commit, CELL_GRID, dim3(TB))
 TAU_LAUNCH(tau_finish, dim3((unsigned)a->R), dim3(64))
