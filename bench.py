@@ -444,8 +444,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--replicates", type=int, default=32768, help="replicates per GPU and step (four per wavefront)")
-    ap.add_argument("--events", type=int, default=12500, help="recorded events per replicate and step")
+    ap.add_argument("--replicates", type=int, default=16384, help="replicates per GPU and step (four per wavefront)")
+    ap.add_argument("--events", type=int, default=100000, help="recorded events per replicate and step")
     ap.add_argument("--traj-points", type=int, default=1001)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-tau", action="store_true", help="skip the tau-leap (config 4) leg")

@@ -1,0 +1,16 @@
+import sys, os
+sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.getcwd())
+import numpy as np
+import bench
+from vgsim_amd.ensemble import Ensemble
+for kernel, R, N in (("quad", 16384, 100000), ("quad", 32768, 50000), ("wave", 4096, 100000)):
+    ens = Ensemble(bench.make_simulator(2020), R)
+    res = None
+    for it in range(2):
+        res = ens.simulate(N, sample_size=10 ** 12, record_events=True, traj_points=1001, traj_window=(0.0, 12.0),
+                           seeds=2020 + it * R + np.arange(R, dtype=np.int64), kernel=kernel)
+    st = ens.replicate_state(0)
+    print("%s R=%d N=%d  %.3e ev/s  %.1f ms  nocc %.1f  bytes %.1f GB" % (kernel, R, N, res.total_events / (res.kernel_ms * 1e-3), res.kernel_ms,
+          float((st.infectious != 0).sum(axis=1).mean()), ens.engine.device_bytes / 1e9), flush=True)
+    ens.close()

@@ -138,6 +138,35 @@ class Simulator(PlotMixin):
         else:
             print("Unknown method. Choose between 'direct' and 'tau'.")
 
+    def ensemble(self, n_replicates, seeds=None, device=0):
+        """Many independent seeded trajectories of THIS model on one GPU (``vgsim_amd.ensemble.Ensemble``): what the engine
+        is built for.  One ``simulate()`` call on a small model is a single sequential event loop and runs at the speed of
+        one wavefront (about 1e5 events/s, slower than the reference's CPU loop); replicates run concurrently, four per
+        wavefront, at up to 1e9 events/s in aggregate.  Every replicate starts from this simulator's current state and
+        parameters and is bit for bit the trajectory a ``Simulator`` with its seed would produce::
+
+            ens = simulator.ensemble(4096)                        # seeds seed, seed+1, ...
+            res = ens.simulate(100000, record_events=True)        # direct Gillespie for every replicate
+            chain = ens.replicate_events(17)                      # (6, n) chain of one replicate, as export_chain_events
+            state = ens.replicate_state(17)                       # compartments, counters, epidemic time
+        """
+        from .ensemble import Ensemble
+        return Ensemble(self, n_replicates, seeds=seeds, device=device)
+
+    def simulate_ensemble(self, n_replicates, iterations=1000, sample_size=None, epidemic_time=-1, method='direct', attempts=200,
+                          seeds=None, **kw):
+        """``simulate`` for ``n_replicates`` seeded copies of this model in one launch; returns ``(ensemble, result)``
+        (``result.events`` = events.ptr of every replicate; chains and states through the ensemble's ``replicate_*``)."""
+        ens = self.ensemble(n_replicates, seeds=seeds)
+        if method == 'direct':
+            res = ens.simulate(iterations, sample_size=sample_size, epidemic_time=epidemic_time, attempts=attempts,
+                               record_events=kw.pop('record_events', True), **kw)
+        elif method == 'tau':
+            res = ens.simulate_tau(iterations, sample_size=sample_size, epidemic_time=epidemic_time, attempts=attempts, **kw)
+        else:
+            raise ValueError("Unknown method. Choose between 'direct' and 'tau'.")
+        return ens, res
+
     def genealogy(self, seed=None):
         start_time = time.time()
         self.simulation.GetGenealogy(seed)
