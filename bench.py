@@ -147,8 +147,8 @@ def spread_leg(device, mode="exact", replicates=1024, events=20000, occupied=409
     # exact, one rate class: counts (8 B/entry) of the whole list for the rate refresh + of the entries up to the hit
     # (half the list on average) for the selection; fast: tile sums + one tile
     bpe = (12.0 * nocc if mode == "exact" else 8.0 * (nocc / 64.0) + 16.0 * 64) + 8.0 * POPS + 28.0 + 8.0
-    traffic = pmc_traffic("spread_occupancy", {"replicates_per_gpu": replicates, "events_per_replicate": events,
-                                                "occupied": occupied, "mode": mode})
+    traffic = pmc_traffic("spread_occupancy" if mode == "exact" else "spread_occupancy_fast",
+                          {"replicates_per_gpu": replicates, "events_per_replicate": events, "occupied": occupied, "mode": mode})
     out = {"workload": "BASELINE config 3, spread occupancy: %d occupied haplotypes per population at start "
                        "(mean %.0f at the end), %d replicates x %d events, %s mode" % (occupied, nocc, replicates, events, mode),
            "value": ev / (ms * 1e-3), "unit": "events/s (device time)", "kernel_ms_per_launch": ms,
