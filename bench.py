@@ -338,7 +338,9 @@ def tau_leg(device, steps=20, per_cell=3, seed=2020):
     m.events.CreateEvents(steps)
     eng.set_params(m); eng.set_state(m); eng.set_seeds(np.array([seed], dtype=np.int64))
     o = _capi.VgxRunOpts(); o.record_events = 0
+    t_wall = time.perf_counter()
     eng._check(eng.lib.vgx_simulate_tau(eng.handle, steps, 10 ** 15, -1.0, 1, C.byref(o)))
+    t_wall = time.perf_counter() - t_wall       # the whole C-ABI call: preparation, every step's launches and synchronisations
     c = eng.counters(0)
     ms = eng.last_kernel_ms
     n = max(int(c.loop_iterations), 1)
@@ -351,14 +353,17 @@ def tau_leg(device, steps=20, per_cell=3, seed=2020):
     except Exception:
         pass
     out = {"workload": "BASELINE config 4: 1048576 haplotypes (10 sites) x 256 populations, total migration 0.01, "
-                       "dense occupancy (%d infected per compartment), Poisson tau-leaping" % per_cell,
+                       "dense occupancy (%d infected per compartment: a uniform fill written into the model's arrays, not the "
+                       "mutation warm-up of SURVEY.md 8(d)), Poisson tau-leaping" % per_cell,
            "steps": n, "ms_per_step": ms / n, "events_drawn": int(c.reserved[0]),
            "value": c.reserved[0] / (ms * 1e-3), "unit": "events/s (device time)",
+           "wall": {"ms_per_step": 1e3 * t_wall / n, "value": c.reserved[0] / t_wall, "unit": "events/s (wall time of the "
+                    "vgx_simulate_tau call incl. its host-side preparation of the 2^28-compartment state)"},
            "roofline": {"bound": "hbm", "achieved": fused / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": fused / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
-                        "note": "all step kernels together (prep, migin, drift, sieve, draw x tries, check, commit); "
-                                "algorithmic bytes = 16*P*H per step (read+write infectious once, one try); traffic = "
-                                "PMC bytes per step (about four tries of the reference's halving loop per step)"}}
+                        "note": "all step kernels together (prep, colsum, drift, sieve, {draw, scatter, suspect, decide} x tries, "
+                                "commit of the accepted try); algorithmic bytes = 16*P*H per step (read+write infectious once, "
+                                "one try); traffic = PMC bytes per step (about four tries of the reference's halving loop per step)"}}
     eng.close()
     return out
 
