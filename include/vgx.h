@@ -92,8 +92,10 @@ typedef struct vgx_run_opts {
                                 susceptibility group, one rate class, no possible lockdown switch) */
     int64_t reserved[2];     /* [0] tau path: 1 = run every try of the halving loop (pyx:2316-2321) instead of starting at the
                                 first try that is not certain to be rejected (same accepted steps either way);
-                                [1] tau path: 1 = run the bounds check (pyx:2522-2528) as one dense pass over all compartments
-                                after every try instead of the fused own-delta / arrival tests (same decisions either way) */
+                                [1] tau path, how a try's deltas are kept and checked (same draws and decisions in every mode):
+                                0 = sparse (default): a list of moves, own deltas checked where they are drawn, no dense arrays;
+                                2 = dense delta arrays written by every try, the fused own-delta / arrival tests;
+                                1 = dense arrays and the bounds check (pyx:2522-2528) as one pass over all compartments */
 } vgx_run_opts;
 
 /* Per-replicate results of the last simulate call. */

@@ -256,23 +256,37 @@ def test_halving_sieve_leaves_the_accepted_steps_untouched():
         assert getattr(a, k) == getattr(b, k), k
 
 
-@pytest.mark.parametrize("case", ["sparse_large", "tiny_full"])
-def test_fused_bounds_check_equals_the_dense_pass(case):
-    """The bounds check of GenerateEvents_tau (pyx:2522-2528) is fused into the draw and scatter kernels (own deltas tested
-    where they are drawn, arrivals where they are added, locally negative compartments re-examined from a list); with
-    ``vgx_run_opts.reserved[1] = 1`` the engine runs it as one dense pass over all compartments instead.  Same decisions,
-    hence bit for bit the same accepted steps — on a large sparse state (thousands of rejected tries' worth of failing
-    compartments) and on a tiny population that sits at its upper bound (arrivals push compartments over ``sizes``)."""
+@pytest.mark.parametrize("case", ["sparse_large", "tiny_full", "large_compartments", "one_mutant_rescues"])
+def test_sparse_try_equals_the_dense_passes(case):
+    """A try of the halving loop keeps its deltas as a list of moves and checks the bounds of GenerateEvents_tau
+    (pyx:2522-2528) where the deltas are drawn (own deltas at once, compartments found below zero against the mutants of
+    their neighbours, the upper bound per population).  ``vgx_run_opts.reserved[1] = 2`` writes both dense delta arrays in
+    every try with the checks fused into the draw and scatter kernels, ``= 1`` additionally runs the check as one dense pass
+    over all compartments.  Same draws, same decisions, hence bit for bit the same accepted steps in all three — on a large
+    sparse state (thousands of rejected tries' worth of failing compartments), on a tiny population that sits at its upper
+    bound (arrivals push compartments over ``sizes``: the sparse mode hands those tries to the dense one), with compartments
+    that draw every channel on its own (vgx_tau_draw_big_kernel), and with a mutation rate so high that compartments below
+    zero on their own are regularly rescued by arriving mutants."""
     import ctypes as C
     from vgsim_amd import Simulator, _capi
 
-    def run(dense):
+    def run(mode):
         with helpers.quiet():
             if case == "sparse_large":
                 s = Simulator(number_of_sites=9, populations_number=16, seed=31)
                 s.set_transmission_rate(2.5); s.set_recovery_rate(0.9); s.set_sampling_rate(0.1); s.set_mutation_rate(0.05)
                 s.set_total_migration_probability(0.01); s.set_population_size(10 ** 8)
                 fill, steps = 2, 10
+            elif case == "large_compartments":
+                s = Simulator(number_of_sites=3, populations_number=4, seed=9)
+                s.set_transmission_rate(3.0); s.set_recovery_rate(1.0); s.set_sampling_rate(0.2); s.set_mutation_rate(0.02)
+                s.set_total_migration_probability(0.05); s.set_population_size(10 ** 7)
+                fill, steps = 20000, 30
+            elif case == "one_mutant_rescues":
+                s = Simulator(number_of_sites=5, populations_number=4, seed=13)
+                s.set_transmission_rate(0.5); s.set_recovery_rate(1.5); s.set_sampling_rate(0.5); s.set_mutation_rate(1.5)
+                s.set_total_migration_probability(0.02); s.set_population_size(10 ** 6)
+                fill, steps = 1, 40
             else:
                 s = Simulator(number_of_sites=2, populations_number=3, seed=5)
                 s.set_transmission_rate(6.0); s.set_recovery_rate(0.2); s.set_sampling_rate(0.05); s.set_mutation_rate(0.8)
@@ -294,21 +308,23 @@ def test_fused_bounds_check_equals_the_dense_pass(case):
         eng.set_params(m); eng.set_state(m); eng.set_seeds(np.array([77], dtype=np.int64))
         o = _capi.VgxRunOpts(); o.record_events = 0
         o.reserved[0] = 1                      # every try of the halving loop: many rejected ones
-        o.reserved[1] = 1 if dense else 0
+        o.reserved[1] = mode
         eng._check(eng.lib.vgx_simulate_tau(eng.handle, steps, 10 ** 15, -1.0, 1, C.byref(o)))
         eng.get_state(m, 0)
         c = eng.counters(0)
         out = (m, int(c.reserved[0]), int(c.ev_ptr))
         eng.close()
         return out
-    a, drawn_a, ptr_a = run(True)
-    b, drawn_b, ptr_b = run(False)
-    assert ptr_a == ptr_b and drawn_a == drawn_b > 0
-    assert a.currentTime == b.currentTime > 0
-    assert np.array_equal(a.infectious, b.infectious) and np.array_equal(a.susceptible, b.susceptible)
+    a, drawn_a, ptr_a = run(1)
     assert (a.infectious >= 0).all() and (a.infectious.sum(axis=1) + a.susceptible.sum(axis=1) == a.sizes).all()
-    for k in a.COUNTERS:
-        assert getattr(a, k) == getattr(b, k), k
+    assert not np.array_equal(a.infectious, a.initial_infectious)
+    for mode in (0, 2):
+        b, drawn_b, ptr_b = run(mode)
+        assert ptr_a == ptr_b and drawn_a == drawn_b > 0, mode
+        assert a.currentTime == b.currentTime > 0, mode
+        assert np.array_equal(a.infectious, b.infectious) and np.array_equal(a.susceptible, b.susceptible), mode
+        for k in a.COUNTERS:
+            assert getattr(a, k) == getattr(b, k), (mode, k)
 
 
 @pytest.mark.parametrize("sites,weights,asym", [(7, None, False), (8, [1.0, 2.0, 0.5, 1.5], False), (9, None, False), (10, None, False),

@@ -20,6 +20,8 @@
 // launchers defined next to their kernels (vgx_direct.hip)
 extern "C" hipError_t vgxi_launch_direct(const VgxDirectArgs *a, size_t lds, hipStream_t stream);
 extern "C" int vgxi_tau_inc_shards(int64_t H, int64_t P);
+extern "C" int64_t vgxi_tau_queue_shards(int64_t H, int64_t P);
+extern "C" int64_t vgxi_tau_queue_shard_max(int64_t H);
 extern "C" hipError_t vgxi_tau_sieve(const VgxTauArgs *a, hipStream_t s);
 extern "C" hipError_t vgxi_launch_lanes(const VgxDirectArgs *a, const VgxLaneWs *w, hipStream_t stream);
 extern "C" hipError_t vgxi_launch_quad(const VgxDirectArgs *a, const double *cd, double *effMig, double *maxEBM, int32_t *has_mig,
@@ -32,7 +34,7 @@ extern "C" hipError_t vgxi_launch_init_reps(const VgxDevRep *r, int P, int S, in
 
 #define TAU_DECL(name) extern "C" hipError_t vgxi_##name(const VgxTauArgs *a, hipStream_t s);
 TAU_DECL(tau_eff) TAU_DECL(tau_scatter) TAU_DECL(tau_prep) TAU_DECL(tau_drift) TAU_DECL(tau_choose) TAU_DECL(tau_draw) TAU_DECL(tau_suscep_draw)
-TAU_DECL(tau_check) TAU_DECL(tau_decide) TAU_DECL(tau_commit) TAU_DECL(tau_finish) TAU_DECL(tau_draw_big) TAU_DECL(tau_suspect)
+TAU_DECL(tau_arrivals) TAU_DECL(tau_verdict) TAU_DECL(tau_apply) TAU_DECL(tau_check) TAU_DECL(tau_decide) TAU_DECL(tau_commit) TAU_DECL(tau_finish) TAU_DECL(tau_draw_big) TAU_DECL(tau_suspect)
 
 static std::string g_create_error;
 
@@ -79,7 +81,7 @@ struct vgx_engine {
         r_evrate, r_evcols, r_locrec, r_loctime, r_lociter, r_farate, r_fakey, r_traj, r_prof, r_qeff, r_qmebm, r_qflag;
     // tau-leaping (dense compartments)
     DevBuf t_I, t_S, t_dChk, t_dApp, t_dSi, t_dTot, t_totInf, t_gI, t_cd, t_lock, t_F, t_eff, t_Aeff, t_Gout, t_dS,
-        t_taubits, t_tau, t_time, t_flags, t_counters, t_cnttry, t_mev, t_mevn, t_mevbase, t_locn, t_mutcum, t_migcdf, t_migIn, t_mutHi, t_colT, t_colTW, t_inc, t_incn, t_sieve, t_sieveskip, t_big, t_bign, t_res, t_susp, t_suspn;
+        t_taubits, t_tau, t_time, t_flags, t_counters, t_cnttry, t_mev, t_mevn, t_mevbase, t_locn, t_mutcum, t_migcdf, t_migIn, t_mutHi, t_colT, t_colTW, t_inc, t_incn, t_sieve, t_sieveskip, t_big, t_bign, t_res, t_susp, t_suspn, t_stkey, t_stval, t_dChkTot, t_q, t_qn;
     std::vector<int64_t> tau_sieve_skipped;   // [R] tries left out by the sieve in the last tau call
     bool last_was_tau = false;
     int64_t tau_mev_cap = 0;
@@ -952,8 +954,23 @@ extern "C" int vgx_simulate_tau(vgx_engine *e, int64_t iterations, int64_t sampl
     rc |= ensure(e, e->r_loctime, (size_t)(R * VGX_LOC_CAP) * 8);
     rc |= ensure(e, e->t_I, (size_t)(R * P * H) * 4);
     rc |= ensure(e, e->t_S, (size_t)(R * P * S) * 8);
-    rc |= ensure(e, e->t_dChk, (size_t)(R * P * H) * 4);
-    rc |= ensure(e, e->t_dApp, (size_t)(R * P * H) * 4);
+    // mode of the tries: sparse (no dense delta arrays; the default), or dense with the fused checks (reserved[1] = 2), or
+    // dense with the bounds check as a pass of its own (reserved[1] = 1); the dense arrays are allocated when first needed
+    const bool sparse_default = !(o.reserved[1] == 1 || o.reserved[1] == 2);
+    bool dense_ready = false;
+    auto ensure_dense = [&]() -> int {
+        if (dense_ready) return 0;
+        int r2 = ensure(e, e->t_dChk, (size_t)(R * P * H) * 4) | ensure(e, e->t_dApp, (size_t)(R * P * H) * 4);
+        dense_ready = r2 == 0;
+        return r2;
+    };
+    if (!sparse_default) rc |= ensure_dense();
+    rc |= ensure(e, e->t_dChkTot, (size_t)(R * P) * 8);
+    // queue of the compartments that may draw events in a try: an eighth of the compartments to begin with, grown on demand
+    const int64_t q_shards = vgxi_tau_queue_shards(H, P), q_shard_max = vgxi_tau_queue_shard_max(H);
+    int64_t q_scap = std::min<int64_t>(q_shard_max, std::max<int64_t>(256, q_shard_max / 8));
+    rc |= ensure(e, e->t_q, (size_t)(R * q_shards * q_scap) * 8);
+    rc |= ensure(e, e->t_qn, (size_t)(R * q_shards) * 8);
     rc |= ensure(e, e->t_dSi, (size_t)(R * P * S) * 8);
     rc |= ensure(e, e->t_dTot, (size_t)(R * P) * 8);
     rc |= ensure(e, e->t_totInf, (size_t)(R * P) * 8);
@@ -970,12 +987,16 @@ extern "C" int vgx_simulate_tau(vgx_engine *e, int64_t iterations, int64_t sampl
     rc |= ensure(e, e->t_time, (size_t)R * 8);
     rc |= ensure(e, e->t_flags, (size_t)R * nF * 4);
     rc |= ensure(e, e->t_counters, (size_t)R * 8 * 8);
-    const int64_t big_cap = std::min<int64_t>(P * H, (int64_t)1 << 20);
+    int64_t big_cap = std::min<int64_t>(P * H, (int64_t)1 << 20);   // grown on demand
     rc |= ensure(e, e->t_big, (size_t)(R * big_cap) * 8);
     rc |= ensure(e, e->t_bign, (size_t)R * 8);
     rc |= ensure(e, e->t_res, (size_t)R * 16 * 8);
-    const int64_t suspect_cap = std::min<int64_t>(P * H, (int64_t)1 << 16);
-    rc |= ensure(e, e->t_susp, (size_t)(R * suspect_cap) * 8);
+    const int64_t suspect_cap = std::min<int64_t>(P * H, (int64_t)1 << 18);
+    rc |= ensure(e, e->t_susp, (size_t)(R * suspect_cap * 2) * 8);
+    int64_t st_size = 64;
+    while (st_size < 2 * suspect_cap) st_size *= 2;
+    rc |= ensure(e, e->t_stkey, (size_t)(R * st_size) * 8);
+    rc |= ensure(e, e->t_stval, (size_t)(R * st_size) * 8);
     rc |= ensure(e, e->t_suspn, (size_t)R * 8);
     rc |= ensure(e, e->t_sieve, (size_t)R * VGX_SIEVE_K * 8);
     rc |= ensure(e, e->t_sieveskip, (size_t)R * 8);
@@ -1002,8 +1023,9 @@ extern "C" int vgx_simulate_tau(vgx_engine *e, int64_t iterations, int64_t sampl
     rc |= upload(e, e->r_seeds, e->seeds.data(), e->seeds.size());
     if (rc) return VGX_ERR_HIP;
     HIPCHECK(e, hipMemset(e->t_incn.p, 0, (size_t)R * VGX_INC_SHARDS * 8));
-    HIPCHECK(e, hipMemset(e->t_dChk.p, 0, (size_t)(R * P * H) * 4));   // (every try overwrites both delta arrays completely)
-    HIPCHECK(e, hipMemset(e->t_dApp.p, 0, (size_t)(R * P * H) * 4));
+    HIPCHECK(e, hipMemset(e->t_stkey.p, 0, (size_t)(R * st_size) * 8));   // try counter 0: every slot reads as empty
+    HIPCHECK(e, hipMemset(e->t_dChkTot.p, 0, (size_t)(R * P) * 8));
+    HIPCHECK(e, hipMemset(e->t_qn.p, 0, (size_t)(R * q_shards) * 8));
     HIPCHECK(e, hipMemset(e->t_dSi.p, 0, (size_t)(R * P * S) * 8));
     HIPCHECK(e, hipMemset(e->t_dTot.p, 0, (size_t)(R * P) * 8));
     HIPCHECK(e, hipMemset(e->t_counters.p, 0, (size_t)R * 64));
@@ -1082,6 +1104,11 @@ extern "C" int vgx_simulate_tau(vgx_engine *e, int64_t iterations, int64_t sampl
     a.res = (int64_t *)e->t_res.p;
     a.suspect = (int64_t *)e->t_susp.p; a.suspect_cap = suspect_cap; a.suspect_n = (unsigned long long *)e->t_suspn.p;
     a.dense_check = o.reserved[1] == 1 ? 1 : 0;   // validation: the bounds check as one dense pass over all compartments
+    a.sparse = sparse_default ? 1 : 0;
+    a.gen = 0;
+    a.st_key = (unsigned long long *)e->t_stkey.p; a.st_val = (long long *)e->t_stval.p; a.st_size = st_size;
+    a.dChkTot = (int64_t *)e->t_dChkTot.p;
+    a.q = (int64_t *)e->t_q.p; a.q_cap = q_shards * q_scap; a.q_shards = q_shards; a.q_n = (unsigned long long *)e->t_qn.p;
     a.sieve = (double *)e->t_sieve.p; a.sieve_skipped = (int64_t *)e->t_sieveskip.p;
     // vgx_run_opts.reserved[0] = 1: run every try of the halving loop; with few compartments no try is ever a certain rejection
     a.sieve_on = (o.reserved[0] == 1 || P * H < 32768) ? 0 : 1;
@@ -1215,26 +1242,45 @@ extern "C" int vgx_simulate_tau(vgx_engine *e, int64_t iterations, int64_t sampl
         HIPCHECK(e, vgxi_tau_choose(&a, e->stream));
         launches += 4;
         if (a.sieve_on) { HIPCHECK(e, vgxi_tau_sieve(&a, e->stream)); launches += 2; }
+        bool dense_once = false;   // the last try asked for dense delta arrays
         for (int tries = 0;; tries++) {
+            a.sparse = (sparse_default && !dense_once) ? 1 : 0;
+            if (!a.sparse && !dense_ready) {
+                int rcd = ensure_dense();
+                if (rcd) return rcd;
+                a.dChk = (int32_t *)e->t_dChk.p; a.dApp = (int32_t *)e->t_dApp.p;
+            }
+            dense_once = false;
+            if (++a.gen >= (1u << 25)) {   // the table's try counter wraps: start over with an empty table
+                HIPCHECK(e, hipMemsetAsync(e->t_stkey.p, 0, (size_t)(R * st_size) * 8, e->stream));
+                a.gen = 1;
+            }
             HIPCHECK(e, vgxi_tau_draw(&a, e->stream));
             HIPCHECK(e, vgxi_tau_draw_big(&a, e->stream));
             HIPCHECK(e, vgxi_tau_suscep_draw(&a, e->stream));
-            HIPCHECK(e, vgxi_tau_scatter(&a, e->stream));
-            HIPCHECK(e, vgxi_tau_suspect(&a, e->stream));
-            if (a.dense_check) HIPCHECK(e, vgxi_tau_check(&a, e->stream));
-            else if (suspect_cap < P * H) {
-                // more compartments below zero on their own than the list holds (never at tries the sieve lets through; tiny
-                // models list every compartment): the dense pass decides
-                susp_h.resize((size_t)R);
-                HIPCHECK(e, hipMemcpyAsync(susp_h.data(), a.suspect_n, (size_t)R * 8, hipMemcpyDeviceToHost, e->stream));
-                HIPCHECK(e, hipStreamSynchronize(e->stream));
-                bool over = false;
-                for (int64_t r = 0; r < R; r++) over = over || (int64_t)susp_h[(size_t)r] > suspect_cap;
-                if (over) { HIPCHECK(e, vgxi_tau_check(&a, e->stream)); launches += 1; }
+            if (a.sparse) {
+                HIPCHECK(e, vgxi_tau_arrivals(&a, e->stream));
+                HIPCHECK(e, vgxi_tau_verdict(&a, e->stream));
+                HIPCHECK(e, vgxi_tau_decide(&a, e->stream));
+                HIPCHECK(e, vgxi_tau_apply(&a, e->stream));
+            } else {
+                HIPCHECK(e, vgxi_tau_scatter(&a, e->stream));
+                HIPCHECK(e, vgxi_tau_suspect(&a, e->stream));
+                if (a.dense_check) HIPCHECK(e, vgxi_tau_check(&a, e->stream));
+                else if (suspect_cap < P * H) {
+                    // more compartments below zero on their own than the list holds (never at tries the sieve lets through; tiny
+                    // models list every compartment): the dense pass decides
+                    susp_h.resize((size_t)R);
+                    HIPCHECK(e, hipMemcpyAsync(susp_h.data(), a.suspect_n, (size_t)R * 8, hipMemcpyDeviceToHost, e->stream));
+                    HIPCHECK(e, hipStreamSynchronize(e->stream));
+                    bool over = false;
+                    for (int64_t r = 0; r < R; r++) over = over || (int64_t)susp_h[(size_t)r] > suspect_cap;
+                    if (over) { HIPCHECK(e, vgxi_tau_check(&a, e->stream)); launches += 1; }
+                }
+                HIPCHECK(e, vgxi_tau_decide(&a, e->stream));
+                HIPCHECK(e, vgxi_tau_commit(&a, e->stream));
             }
-            HIPCHECK(e, vgxi_tau_decide(&a, e->stream));
-            HIPCHECK(e, vgxi_tau_commit(&a, e->stream));
-            launches += 7;
+            launches += 8;
             HIPCHECK(e, hipStreamSynchronize(e->stream));
             acc_h.resize((size_t)R * 2);   // accepted[R], grow[R]
             HIPCHECK(e, hipMemcpy(acc_h.data(), a.accepted, (size_t)R * 8, hipMemcpyDeviceToHost));
@@ -1242,9 +1288,12 @@ extern "C" int vgx_simulate_tau(vgx_engine *e, int64_t iterations, int64_t sampl
             for (int64_t r = 0; r < R; r++)
                 if (running[(size_t)r] && !acc_h[(size_t)r]) all = false;
             if (all) break;
-            // a try that overflowed the list of individuals entering other compartments was discarded by the decide
-            // kernel without touching tau or the try index: double the list (it is empty now) and run the same try again
-            if (std::any_of(acc_h.begin() + R, acc_h.end(), [](int32_t g) { return g != 0; })) {
+            // a try that lost data (a full list) or that the sparse check could not decide was discarded by the decide kernel
+            // without touching tau or the try index: enlarge the list (it is empty now) / switch to the dense delta arrays
+            // and run the same try again
+            int again = 0;
+            for (int64_t r = 0; r < R; r++) again |= acc_h[(size_t)(R + r)];
+            if (again & 1) {
                 if (inc_cap > ((int64_t)1 << 33) / std::max<int64_t>(R, 1))
                     return fail(e, VGX_ERR_CAPACITY, "vgx_simulate_tau: more than 2^33 individuals change compartment in one leap");
                 inc_cap *= 2;
@@ -1252,8 +1301,25 @@ extern "C" int vgx_simulate_tau(vgx_engine *e, int64_t iterations, int64_t sampl
                 if (rcg) return rcg;
                 a.inc = (int64_t *)e->t_inc.p;
                 a.inc_cap = inc_cap;
-                HIPCHECK(e, hipMemset(a.grow, 0, (size_t)R * 4));
             }
+            if (again & 4) {
+                if (big_cap >= P * H) return fail(e, VGX_ERR_CAPACITY, "vgx_simulate_tau: list of large compartments full");
+                big_cap = std::min<int64_t>(P * H, big_cap * 2);
+                int rcg = ensure(e, e->t_big, (size_t)(R * big_cap) * 8);
+                if (rcg) return rcg;
+                a.big = (int64_t *)e->t_big.p;
+                a.big_cap = big_cap;
+            }
+            if (again & 8) {
+                if (q_scap >= q_shard_max) return fail(e, VGX_ERR_CAPACITY, "vgx_simulate_tau: queue of drawing compartments full");
+                q_scap = std::min<int64_t>(q_shard_max, q_scap * 2);
+                int rcg = ensure(e, e->t_q, (size_t)(R * q_shards * q_scap) * 8);
+                if (rcg) return rcg;
+                a.q = (int64_t *)e->t_q.p;
+                a.q_cap = q_shards * q_scap;
+            }
+            if (again & 2) dense_once = true;
+            if (again) HIPCHECK(e, hipMemset(a.grow, 0, (size_t)R * 4));
             if (tries > 300) return fail(e, VGX_ERR_LOOP_GUARD, "vgx_simulate_tau: tau halving did not converge");
         }
         HIPCHECK(e, vgxi_tau_finish(&a, e->stream));

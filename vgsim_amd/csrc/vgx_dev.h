@@ -152,7 +152,8 @@ struct VgxTauArgs {
     int64_t *S;          // [R][P][S] susceptible
     int32_t *dChk;       // [R][P][H] infectious deltas as the reference's bounds check books them (pyx:2473)
     int32_t *dApp;       // [R][P][H] infectious deltas as UpdateCompartmentCounts_tau applies them (pyx:2548)
-    int64_t *inc;        // [R][inc_cap] individuals entering another compartment: cell index | (applied-only << 62)
+    int64_t *inc;        // [R][inc_cap] list of individual moves: compartment | magnitude << 38 | sign << 61 | applied-only << 62
+                         // (mutants and migrants entering a compartment; in sparse mode also every compartment's own net change)
     int64_t inc_cap;
     int32_t inc_shards;  // shards in use: a power of two <= VGX_INC_SHARDS matched to the draw kernel's grid; inc_cap / inc_shards entries each
     unsigned long long *inc_n;  // [R][VGX_INC_SHARDS]
@@ -215,8 +216,26 @@ struct VgxTauArgs {
     int32_t sieve_on;
     // compartments whose own events alone would take them below zero in the current try (they may be rescued by incoming
     // mutants): re-examined after the scatter kernel (vgx_tau_suspect_kernel).  Overflow falls back to the dense check pass.
-    int64_t *suspect;        // [R][suspect_cap] pn * H + hn
+    int64_t *suspect;        // [R][suspect_cap][2] pn * H + hn, infectious + own delta (as the check books it)
     int64_t suspect_cap;
     unsigned long long *suspect_n;   // [R]
     int32_t dense_check;     // 1: run vgx_tau_check_kernel over all compartments after every try (validation / fallback)
+    // sparse mode (the default): a try writes no dense delta arrays.  Own net changes go to the list `inc`, the bounds check
+    // of a compartment's own change is made where it is drawn, compartments found below zero are entered in a small hash
+    // table (key = compartment | gen << 38: entries of earlier tries are stale, nothing is ever cleared) in which
+    // vgx_tau_arrivals_kernel adds the mutants that arrive there, and the upper bound is checked per population
+    // (sum of a population's compartments <= size implies it for each of them; if the sum test fails the try is run again
+    // in dense mode, `grow` = 2).  dense mode (sparse = 0): both delta arrays are written completely by every try.
+    int32_t sparse;
+    // queue of the compartments that may draw events in the current try (vgx_tau_scan_kernel -> vgx_tau_events_kernel):
+    // haplotype | bucket << 32, sharded by (population, block of the scan kernel)
+    int64_t *q;                      // [R][q_cap]
+    int64_t q_cap;                   // a multiple of q_shards
+    int64_t q_shards;
+    unsigned long long *q_n;         // [R][q_shards]
+    uint32_t gen;                    // try counter of this call, 1 .. 2^25 - 1
+    unsigned long long *st_key;      // [R][st_size]
+    long long *st_val;               // [R][st_size] infectious + own delta + arrivals
+    int64_t st_size;                 // power of two >= 2 * suspect_cap
+    int64_t *dChkTot;                // [R][P] sum over the population's compartments of the deltas as the check books them
 };

@@ -26,6 +26,7 @@
 #include "../../include/vgx.h"
 #include "vgx_dev.h"
 #include "vgx_rng.h"
+#include "vgx_wave.h"
 
 // The tau path is validated distributionally (different random streams anyway), so FMA contraction is allowed
 // here, unlike in the bit-exact direct kernel (the library is built with -ffp-contract=off).
@@ -764,63 +765,113 @@ static __device__ __forceinline__ void tau_row(const VgxTauArgs &a, int rep, int
     }
 }
 
-// One individual entering compartment `cell` from another compartment (a mutant: booked in both delta arrays; a
-// migrant: applied only, pyx:2473 vs pyx:2548).  Appended to the replicate's list; vgx_tau_scatter_kernel adds them
-// after the draw kernel, when every compartment has stored its own deltas.
-// The list is sharded by thread block (VGX_INC_SHARDS counters) so that appends do not serialise on one address.
-#define VGX_INC_STAGE 512   // entries staged in LDS per thread block before one reservation in the global list
+// ---- the list of individual moves of a try ---------------------------------------------------------------------------------
+// entry = compartment (bits 0-37) | magnitude (bits 38-60) | sign (bit 61) | applied-only (bit 62)
+//   a mutant entering a compartment:  +k, booked in both sets of deltas (pyx:2473 and pyx:2548)
+//   a migrant entering a compartment: +k, applied only (pyx:2548; the reference's check books it on its SOURCE, pyx:2473)
+//   sparse mode only, a compartment's own net change: signed, applied only (its check is made where it is drawn)
+// The list is sharded by thread block (VGX_INC_SHARDS counters) so that appends do not serialise on one address; a
+// wavefront stages its entries in LDS and reserves room for them with one atomic.
 #define VGX_TAU_BIG 64.0    // expected events of a compartment per leap from which every channel is drawn on its own
-struct IncStage { int n; int64_t e[VGX_INC_STAGE]; unsigned long long base; };
+#define VGX_INC_CELL_BITS 38
+#define VGX_INC_MAXMULT ((int64_t)((1 << 23) - 1))
+#define VGX_INC_NEG ((int64_t)1 << 61)
+#define VGX_INC_APPLIED ((int64_t)1 << 62)
+static __device__ __forceinline__ int64_t tau_entry_cell(int64_t e) { return e & (((int64_t)1 << VGX_INC_CELL_BITS) - 1); }
+static __device__ __forceinline__ int tau_entry_delta(int64_t e) {
+    const int k = (int)((e >> VGX_INC_CELL_BITS) & VGX_INC_MAXMULT);
+    return (e & VGX_INC_NEG) ? -k : k;
+}
+#define VGX_WSTAGE 192      // entries a wavefront stages before one reservation in the global list
+struct WaveStage { int n; int pad; int64_t e[VGX_WSTAGE]; };
 
-static __device__ __forceinline__ void tau_incoming_global(const VgxTauArgs &a, int rep, int64_t entry) {
+static __device__ __forceinline__ void tau_list_global(const VgxTauArgs &a, int rep, int64_t entry) {
     const int shard = (int)((blockIdx.x + gridDim.x * blockIdx.y) & (a.inc_shards - 1));
     const int64_t scap = a.inc_cap / a.inc_shards;
     unsigned long long slot = atomicAdd(&a.inc_n[(int64_t)rep * VGX_INC_SHARDS + shard], 1ull);
-    if ((int64_t)slot < scap) a.inc[(int64_t)rep * a.inc_cap + (int64_t)shard * scap + (int64_t)slot] = entry;
+    if ((int64_t)slot < scap) a.inc[(int64_t)rep * a.inc_cap + (int64_t)shard * scap + (int64_t)slot] = entry;   // a full shard is detected later
 }
-// Appends go to the block's LDS stage (an LDS atomic instead of a returning global atomic per mutant / migrant in the
-// divergent part of the kernel); tau_incoming_flush moves the stage to the global list with one reservation.
-// List entry: compartment (bits 0-37), multiplicity (bits 38-61), applied-only flag (bit 62).
-#define VGX_INC_CELL_BITS 38
-#define VGX_INC_MAXMULT ((int64_t)((1 << 24) - 1))
-static __device__ __forceinline__ void tau_incoming(const VgxTauArgs &a, IncStage *st, int rep, int64_t cell, bool applied_only,
-                                                    int64_t count = 1) {
-    while (count > 0) {
-        const int64_t k = count < VGX_INC_MAXMULT ? count : VGX_INC_MAXMULT;
-        const int64_t entry = cell | (k << VGX_INC_CELL_BITS) | (applied_only ? ((int64_t)1 << 62) : 0);
-        int slot = atomicAdd(&st->n, 1);
-        if (slot < VGX_INC_STAGE) st->e[slot] = entry;
-        else tau_incoming_global(a, rep, entry);
-        count -= k;
+// st == nullptr: straight to the global list
+static __device__ __forceinline__ void tau_list_add(const VgxTauArgs &a, WaveStage *st, int rep, int64_t cell, int64_t delta, bool applied_only) {
+    const int64_t flags = (delta < 0 ? VGX_INC_NEG : 0) | (applied_only ? VGX_INC_APPLIED : 0);
+    int64_t left = delta < 0 ? -delta : delta;
+    while (left > 0) {
+        const int64_t k = left < VGX_INC_MAXMULT ? left : VGX_INC_MAXMULT;
+        const int64_t entry = cell | (k << VGX_INC_CELL_BITS) | flags;
+        int slot = st ? atomicAdd(&st->n, 1) : VGX_WSTAGE;
+        if (slot < VGX_WSTAGE) st->e[slot] = entry;
+        else tau_list_global(a, rep, entry);
+        left -= k;
     }
 }
-// block-uniform call
-static __device__ __forceinline__ void tau_incoming_flush(const VgxTauArgs &a, IncStage *st, int rep) {
-    __syncthreads();
-    const int n = st->n < VGX_INC_STAGE ? st->n : VGX_INC_STAGE;
+// wave-uniform call: moves the wavefront's stage to the global list
+static __device__ __forceinline__ void tau_stage_flush(const VgxTauArgs &a, WaveStage *st, int rep) {
+    WSYNC();
+    int n = st->n;
+    n = __builtin_amdgcn_readfirstlane(n < VGX_WSTAGE ? n : VGX_WSTAGE);
     if (n > 0) {
+        const int lane = threadIdx.x & 63;
         const int shard = (int)((blockIdx.x + gridDim.x * blockIdx.y) & (a.inc_shards - 1));
         const int64_t scap = a.inc_cap / a.inc_shards;
-        if (threadIdx.x == 0) st->base = atomicAdd(&a.inc_n[(int64_t)rep * VGX_INC_SHARDS + shard], (unsigned long long)n);
-        __syncthreads();
-        const unsigned long long base = st->base;
+        unsigned long long base = 0;
+        if (lane == 0) base = atomicAdd(&a.inc_n[(int64_t)rep * VGX_INC_SHARDS + shard], (unsigned long long)n);
+        base = (unsigned long long)bcast_i64((int64_t)base, 0);
         int64_t *dst = a.inc + (int64_t)rep * a.inc_cap + (int64_t)shard * scap;
-        for (int i = threadIdx.x; i < n; i += blockDim.x)
-            if ((int64_t)(base + i) < scap) dst[base + i] = st->e[i];   // a full shard is detected by the scatter kernel
+        for (int i = lane; i < n; i += 64)
+            if ((int64_t)(base + i) < scap) dst[base + i] = st->e[i];
+        WSYNC();
     }
-    __syncthreads();
-    if (threadIdx.x == 0) st->n = 0;
-    __syncthreads();
+    if ((threadIdx.x & 63) == 0) st->n = 0;
+    WSYNC();
+}
+
+// ---- compartments found below zero on their own ------------------------------------------------------------------------
+// Hash table of the sparse mode (open addressing, linear probing).  A key carries the try counter `gen` of the call in its
+// upper bits: entries of earlier tries read as empty, nothing is ever cleared.
+static __device__ __forceinline__ uint32_t tau_hash(int64_t cell) {
+    return (uint32_t)(((uint64_t)cell * 0x9E3779B97F4A7C15ull) >> 32);
+}
+static __device__ void tau_st_insert(const VgxTauArgs &a, int rep, int64_t cell, int64_t v) {
+    unsigned long long *keys = a.st_key + (int64_t)rep * a.st_size;
+    const unsigned long long mine = (unsigned long long)cell | ((unsigned long long)a.gen << VGX_INC_CELL_BITS);
+    const uint32_t mask = (uint32_t)(a.st_size - 1);
+    uint32_t slot = tau_hash(cell) & mask;
+    for (int64_t probe = 0; probe < 2 * a.st_size; ++probe) {
+        const unsigned long long k = __atomic_load_n(&keys[slot], __ATOMIC_RELAXED);
+        if ((k >> VGX_INC_CELL_BITS) != (unsigned long long)a.gen) {   // empty or of an earlier try: claim it
+            if (atomicCAS(&keys[slot], k, mine) == k) { a.st_val[(int64_t)rep * a.st_size + slot] = v; return; }
+            continue;                                                   // somebody else was faster: look at the slot again
+        }
+        slot = (slot + 1) & mask;
+    }
+}
+// slot of `cell` in this try's table, or -1
+static __device__ __forceinline__ int64_t tau_st_find(const VgxTauArgs &a, int rep, int64_t cell) {
+    const unsigned long long *keys = a.st_key + (int64_t)rep * a.st_size;
+    const uint32_t mask = (uint32_t)(a.st_size - 1);
+    uint32_t slot = tau_hash(cell) & mask;
+    for (int64_t probe = 0; probe < a.st_size; ++probe) {
+        const unsigned long long k = keys[slot];
+        if ((k >> VGX_INC_CELL_BITS) != (unsigned long long)a.gen) return -1;
+        if ((int64_t)(k & (((unsigned long long)1 << VGX_INC_CELL_BITS) - 1)) == cell) return (int64_t)slot;
+        slot = (slot + 1) & mask;
+    }
+    return -1;
 }
 
 // Bounds check of GenerateEvents_tau (pyx:2522-2528) for a compartment's OWN deltas, v = infectious + delta as booked by the
 // reference's check.  Incoming mutants only add to it afterwards, so v > sizes is final (the try is rejected); v < 0 may still
-// be rescued: the compartment is listed and looked at again once the scatter kernel has added the arrivals.
+// be rescued: the compartment is listed and looked at again once the arrivals are known.
 static __device__ __forceinline__ void tau_own_check(const VgxTauArgs &a, int rep, int pn, int hn, int64_t v) {
     if (v > a.p.sizes[pn]) a.ok[rep] = 0;
     else if (v < 0) {
         const unsigned long long slot = atomicAdd(&a.suspect_n[rep], 1ull);
-        if ((int64_t)slot < a.suspect_cap) a.suspect[(int64_t)rep * a.suspect_cap + (int64_t)slot] = (int64_t)pn * a.p.H + hn;
+        if ((int64_t)slot < a.suspect_cap) {
+            const int64_t cell = (int64_t)pn * a.p.H + hn;
+            a.suspect[((int64_t)rep * a.suspect_cap + (int64_t)slot) * 2] = cell;
+            a.suspect[((int64_t)rep * a.suspect_cap + (int64_t)slot) * 2 + 1] = v;
+            if (a.sparse) tau_st_insert(a, rep, cell, v);
+        }
     }
 }
 
@@ -838,61 +889,54 @@ struct TauTab {
     const double *r1;                    // [C] total event rate per infected of the class in this population, or null
 };
 
+// ---- random numbers of a try -----------------------------------------------------------------------------------------
+// Every compartment owns a Philox stream keyed by (seed, attempt) with the counter (compartment, step, try).  Its FIRST
+// uniform is built in two parts: the top 8 bits (`bucket`) come from a Philox block shared by the 16 compartments a
+// lane of the draw kernel looks at (counter = (group, step, try | 0xFFFFF)), the remaining 52 bits from the compartment's
+// own stream and only when they are needed.  A compartment with a small mean draws no event whenever
+// (bucket + 1) / 256 <= 1 - lam <= exp(-lam), which the draw kernel tests in single precision with lam rounded up: one
+// Philox block and a handful of instructions for 16 compartments, and the law of the draw is exactly that of inversion
+// with a 60-bit uniform.
+// group of compartment hn of population pn: 1024 consecutive haplotypes form a wave tile, lane L of the wave looks at the
+// haplotypes tile*1024 + 256 k + 4 L + j (k, j = 0..3) and finds their buckets in byte j of word k.
+static __device__ __forceinline__ uint32_t tau_bucket(const VgxTauArgs &a, int rep, int pn, int hn) {
+    const int H = a.p.H;
+    const uint64_t tiles = (uint64_t)((H + 1023) >> 10);
+    const uint64_t gidx = ((uint64_t)pn * tiles + (uint64_t)(hn >> 10)) * 64u + (uint64_t)((hn & 255) >> 2);
+    const uint32_t key[2] = {(uint32_t)a.seeds[rep] ^ ((uint32_t)a.attempt[rep] * 0x9E3779B9u),
+                             (uint32_t)((uint64_t)a.seeds[rep] >> 32) ^ 0x85EBCA6Bu};
+    const uint32_t ctr[4] = {(uint32_t)gidx, (uint32_t)(gidx >> 32), (uint32_t)a.step[rep], ((uint32_t)a.retry[rep] << 20) | 0xFFFFFu};
+    uint32_t w[4];
+    vgx_philox4x32(ctr, key, w);
+    return (w[(hn >> 8) & 3] >> (8 * (hn & 3))) & 255u;
+}
+
 // GenerateEvents_tau for one compartment (pn, hn).  All channels out of a compartment are independent Poisson
 // variables, so their sum is Poisson with the summed rate and, given the sum, the channel of each event is
 // multinomial: ONE draw per compartment, then a split (same joint law as pyx:2464-2520, ~5x fewer draws).  The
 // split first only counts the frequent kinds (recovery, sampling, transmission) and the number of mutants and
 // migrants; their targets are then chosen by bisection in a second, short loop, so the rare, expensive branches
 // are not executed by the whole wavefront on every event.  Books
-//   dChk : the infectious deltas the reference's bounds check looks at (pyx:2473: a migrant is booked on its
-//          SOURCE compartment there),
-//   dApp : the infectious deltas UpdateCompartmentCounts_tau applies (pyx:2548: the migrant infects the
-//          TARGET population),
-//   the susceptible deltas (identical in both), the tentative counters and multievent rows.
+//   ownChk : the compartment's own infectious delta as the reference's bounds check sees it (pyx:2473: a migrant is booked
+//            on its SOURCE compartment there),
+//   ownApp : the own delta UpdateCompartmentCounts_tau applies (pyx:2548: the migrant infects the TARGET population),
+//   the susceptible deltas (identical in both), the tentative counters, multievent rows and the list of arrivals.
 // The compartment arrays themselves are not touched, so every thread sees the pre-step state.
-// Can compartment (pn, hn) draw any event in this step?  For most compartments the class's total rate and the shared
-// 32-bit word say no at once; the others are queued and tau_cell_events makes the draw (inversion with the same word
-// below a mean of 10, PTRS on the compartment's own stream from 10 on).
-static __device__ __forceinline__ int tau_cell_count(const VgxTauArgs &a, const TauTab &T, int rep, int pn, int hn, double tau,
-                                                     uint32_t first_word, int64_t Icell) {
-    const VgxDevParams &p = a.p;
-    if (Icell == 0) return 0;
-    const double Ih = (double)Icell;
-    const int c = (p.C == 1) ? 0 : p.cls[hn];
-    double rate;
-    if (T.r1) {
-        rate = T.r1[c];
-    } else {
-        const int cb = T.c_bidx[c];
-        rate = T.rmig[cb] + T.c_d[c] + T.c_s[c] * p.sampMult[pn] + (a.mut_uniform ? a.mut_total : T.c_tm[c]) + T.rtr[cb];
-    }
-    const double lam = rate * Ih * tau;
-    if (!(lam > 0.0)) return 0;
-    if (lam >= VGX_TAU_BIG) {   // many events: one wavefront draws its channels one by one (vgx_tau_draw_big_kernel)
-        const unsigned long long slot = atomicAdd(&a.big_n[rep], 1ull);
-        if ((int64_t)slot < a.big_cap) { a.big[(int64_t)rep * a.big_cap + (int64_t)slot] = (int64_t)pn * p.H + hn; return 0; }
-        return 1;               // list full: the compartment takes the event-by-event path below (slow, same law)
-    }
-    if (lam >= 10.0) return 1;
-    const double u = ((double)first_word + 0.5) * (1.0 / 4294967296.0);
-    return (u <= 1.0 - lam) ? 0 : 1;   // exp(-lam) >= 1 - lam: the inversion search of tau_cell_events would stop at 0
-}
-
-static __device__ __forceinline__ void tau_cell_events(const VgxTauArgs &a, const TauTab &T, int rep, int pn, int hn, double tau,
-                                                       int64_t Icell, uint32_t first_word, int64_t &ownChk, int64_t &ownApp, int64_t *cnt,
-                                                       IncStage *stage,
-                                                       unsigned long long *sS /* LDS [S]: this population's susceptible deltas */,
-                                                       unsigned long long *sTot /* LDS: delta of totalInfectious[pn] */) {
+// Returns 2 when the compartment expects VGX_TAU_BIG events or more (nothing drawn: vgx_tau_draw_big_kernel's case), else 0/1.
+// DRY = true: no bookkeeping at all; ownChk returns the number of mutants that go to haplotype `target` (the same random
+// numbers in the same order, so the count is the one the compartment's real draw produces).
+template <bool DRY>
+static __device__ __forceinline__ int tau_cell_events(const VgxTauArgs &a, const TauTab &T, int rep, int pn, int hn, double tau,
+                                                      int64_t Icell, uint32_t bucket, int64_t &ownChk, int64_t &ownApp, int64_t *cnt,
+                                                      WaveStage *stage, unsigned long long *sS /* LDS [S]: this population's susceptible deltas */,
+                                                      int target) {
     const VgxDevParams &p = a.p;
     const int P = p.P, S = p.S, H = p.H, sites = p.sites;
-    int64_t *dS = a.dSi + (int64_t)rep * P * S;
     ownChk = 0;
     ownApp = 0;
+    if (Icell <= 0) return 0;
     const double Ih = (double)Icell;
     const int c = (p.C == 1) ? 0 : p.cls[hn];
-    TauRng g;
-    g.init((uint64_t)a.seeds[rep], (uint32_t)a.attempt[rep], (uint64_t)pn * (uint64_t)H + (uint64_t)hn, (uint32_t)a.step[rep],
-           (uint32_t)a.retry[rep]);
     const int cb = T.c_bidx[c];
     const int st = T.c_stype[c];
     // ---- channel rates per unit time ----
@@ -902,23 +946,26 @@ static __device__ __forceinline__ void tau_cell_events(const VgxTauArgs &a, cons
     const double r_mut = (a.mut_uniform ? a.mut_total : T.c_tm[c]) * Ih;             // pyx:2400-2401 summed over (s, i)
     const double r_mig = T.rmig[cb] * Ih;                                            // pyx:2366-2367 summed over (tpn, sn)
     const double r_all = r_mig + r_rec + r_samp + r_mut + r_tr;
+    const double lam = r_all * tau;
+    if (!(lam > 0.0)) return 0;
+    if (lam >= VGX_TAU_BIG) return 2;
+    TauRng g;
+    g.init((uint64_t)a.seeds[rep], (uint32_t)a.attempt[rep], (uint64_t)pn * (uint64_t)H + (uint64_t)hn, (uint32_t)a.step[rep],
+           (uint32_t)a.retry[rep]);
     int64_t N;
-    {
-        const double lam = r_all * tau;
-        if (lam >= 10.0) {
-            N = tau_poisson(g, lam);
-        } else {   // inversion by sequential search with the shared word (same law as numpy's sampler below 10)
-            const double u = ((double)first_word + 0.5) * (1.0 / 4294967296.0);
-            double pk = exp(-lam), F = pk;
-            N = 0;
-            while (u > F && N < 200) {
-                N += 1;
-                pk *= lam / (double)N;
-                F += pk;
-            }
+    if (lam >= 10.0) {
+        N = tau_poisson(g, lam);
+    } else {   // inversion by sequential search (same law as numpy's sampler below 10)
+        const double u = ((double)bucket + g.uniform()) * (1.0 / 256.0);
+        double pk = exp(-lam), F = pk;
+        N = 0;
+        while (u > F && N < 200) {
+            N += 1;
+            pk *= lam / (double)N;
+            F += pk;
         }
-        if (N == 0) return;
     }
+    if (N == 0) return 0;
     int64_t rec = 0, samp = 0, births = 0, n_mut = 0, n_mig = 0;
     const double t1 = r_rec, t2 = t1 + r_samp, t3 = t2 + r_tr, t4 = t3 + r_mut;
     for (int64_t ev = 0; ev < N; ++ev) {
@@ -926,6 +973,7 @@ static __device__ __forceinline__ void tau_cell_events(const VgxTauArgs &a, cons
         if (u < t1) rec += 1;
         else if (u < t2) samp += 1;
         else if (u < t3 || (r_mut == 0.0 && r_mig == 0.0)) {
+            if (DRY) continue;
             // transmission to susceptibility group sn (pyx:2515-2520 / 2589-2593)
             double uu = (u - t2) / Ih, acc = 0.0;
             int sn_hit = -1;
@@ -943,7 +991,7 @@ static __device__ __forceinline__ void tau_cell_events(const VgxTauArgs &a, cons
         else n_mig += 1;
     }
     // ---- mutants (pyx:2506-2512 / 2579-2586): site and derived state ----
-    int64_t mut_done = 0;
+    int64_t mut_done = 0, to_target = 0;
     for (int64_t k = 0; k < n_mut; ++k) {
         int ss = -1, ii = 0;
         if (a.mut_uniform) {
@@ -976,11 +1024,14 @@ static __device__ __forceinline__ void tau_cell_events(const VgxTauArgs &a, cons
         if (ss < 0) continue;
         int nh = tau_mutate(sites, hn, ss, ii);
         mut_done += 1;
-        tau_incoming(a, stage, rep, (int64_t)pn * H + nh, false);
+        if (DRY) { if (nh == target) to_target += 1; continue; }
+        tau_list_add(a, stage, rep, (int64_t)pn * H + nh, 1, false);
         tau_row(a, rep, 1, 3, hn, pn, nh, 0);
     }
+    if (DRY) { ownChk = to_target; return 1; }
     // ---- migrants (pyx:2464-2474 / 2541-2550): target population and susceptibility group, by bisection in the
     // cumulative channel weights of this source population and birth class ----
+    int64_t *dS = a.dSi + (int64_t)rep * P * S;
     int64_t migrants = 0;
     for (int64_t k = 0; k < n_mig; ++k) {
         const double *cdf = T.cdf + (int64_t)cb * P * S;
@@ -995,7 +1046,7 @@ static __device__ __forceinline__ void tau_cell_events(const VgxTauArgs &a, cons
         int tp = lo / S, ts = lo % S;
         if (tp == pn || !(cdf[nch - 1] > 0.0)) continue;
         migrants += 1;
-        tau_incoming(a, stage, rep, (int64_t)tp * H + hn, true);
+        tau_list_add(a, stage, rep, (int64_t)tp * H + hn, 1, true);
         atomicAdd((unsigned long long *)&dS[tp * S + ts], (unsigned long long)(-1ll));
         atomicAdd((unsigned long long *)&a.dTot[(int64_t)rep * P + tp], 1ull);
         tau_row(a, rep, 1, 5, hn, pn, ts, tp);
@@ -1007,11 +1058,36 @@ static __device__ __forceinline__ void tau_cell_events(const VgxTauArgs &a, cons
     ownChk = own + migrants;
     ownApp = own;
     if (rec + samp != 0) { if (st < 4) cnt[8 + st] += rec + samp; else atomicAdd(&sS[st], (unsigned long long)(rec + samp)); }
-    int64_t dt = births - rec - samp;
-    cnt[6] += dt;   // delta of totalInfectious[pn], added to the block's total at the end
+    const int64_t dt = births - rec - samp;
+    cnt[6] += dt;             // delta of totalInfectious[pn], added to the block's total at the end
+    cnt[7] += dt + migrants;  // ... and the same sum as the check books it (mutants cancel inside the population)
+    return 1;
 }
 
-// LDS budget of the draw kernel's tables (doubles, then int32); 0 = tables stay in global memory
+// Mutants that arrive in compartment (pn, hn) in this try, computed from the draws of its single-site neighbours alone (their
+// streams depend on nothing but the compartment, the step and the try): decides at once whether a compartment found below
+// zero on its own is rescued (pyx:2522-2528 look at the sum).  -1: a neighbour is drawn channel by channel in
+// vgx_tau_draw_big_kernel and the answer has to wait for the list (never for the sparse epidemics this shortcut is for).
+static __device__ __forceinline__ int64_t tau_arrivals_dry(const VgxTauArgs &a, const TauTab &T, int rep, int pn, int hn, double tau, const int32_t *Irow) {
+    const int sites = a.p.sites;
+    int64_t cnt_unused[12];
+    int64_t total = 0;
+    for (int s = 0; s < sites; ++s) {
+        const int sh = 2 * (sites - s - 1);
+        for (int x = 1; x < 4; ++x) {
+            const int nb = hn ^ (x << sh);
+            const int64_t In = (int64_t)Irow[nb];
+            if (In <= 0) continue;
+            int64_t k = 0, dummy = 0;
+            const int r = tau_cell_events<true>(a, T, rep, pn, nb, tau, In, tau_bucket(a, rep, pn, nb), k, dummy, cnt_unused, nullptr, nullptr, hn);
+            if (r == 2) return -1;
+            total += k;
+        }
+    }
+    return total;
+}
+
+// LDS budget of the events kernel's tables (doubles, then int32); 0 = tables stay in global memory
 static __host__ __device__ inline size_t tau_tab_lds_bytes(int C, int CB, int S, int P, bool &cdf_in_lds) {
     cdf_in_lds = false;
     if (C > 256 || CB > 16) return 0;
@@ -1020,23 +1096,182 @@ static __host__ __device__ inline size_t tau_tab_lds_bytes(int C, int CB, int S,
     return dbl * 8 + 2 * (size_t)C * 4;
 }
 
-// grid = (ceil(H/TB), P, R); dSi/dTot are zero on entry
-extern "C" __global__ void __launch_bounds__(TB) vgx_tau_draw_kernel(VgxTauArgs a) {
+// A try is drawn by two kernels.  vgx_tau_scan_kernel streams over all compartments (light: many wavefronts per CU, HBM-bound)
+// and queues the few that may draw events; vgx_tau_events_kernel (heavy: the whole event logic, few wavefronts per CU) works
+// the queue off with all lanes busy.  The queue is sharded by (population, block of the scan kernel): block (bx, pn) of the
+// events kernel takes the entries block (bx, pn) of the scan kernel queued, so its tables are those of ONE population.
+#define VGX_QW 512          // entries a wavefront of the scan kernel stages in LDS: a quarter tile adds at most 256, they are moved out from 256 on
+#define EB 64               // threads per block of the events kernel
+static __host__ __device__ inline unsigned tau_draw_gx(int64_t H) {   // blocks of the scan kernel per (population, replicate)
+    const unsigned tiles = (unsigned)((H + 1023) >> 10);              // wave tiles of 1024 haplotypes
+    const unsigned blocks = (tiles + (TB / 64) - 1) / (TB / 64);
+    return blocks < VGX_DRAW_GX ? blocks : VGX_DRAW_GX;
+}
+// most compartments one block of the scan kernel looks at (= the most entries its shard of the queue can get)
+static __host__ __device__ inline int64_t tau_queue_shard_max(int64_t H) {
+    const int64_t tiles = (H + 1023) >> 10, waves = (int64_t)tau_draw_gx(H) * (TB / 64);
+    return (tiles + waves - 1) / waves * (TB / 64) * 1024;
+}
+
+// grid = (tau_draw_gx(H), P, R)
+extern "C" __global__ void __launch_bounds__(TB) vgx_tau_scan_kernel(VgxTauArgs a) {
     const int rep = blockIdx.z, pn = blockIdx.y;
     if (!a.active[rep] || a.accepted[rep]) return;
     const VgxDevParams &p = a.p;
-    const int P = p.P, S = p.S, C = p.C, CB = p.CB;
+    const int P = p.P, S = p.S, C = p.C, CB = p.CB, H = p.H;
+    __shared__ float s_rt[256];
+    __shared__ double s_rtr[16], s_rmig[16];
+    __shared__ int64_t q[TB / 64][VGX_QW];
+    const double tau = a.tau[rep];
+    const double F = a.F[(int64_t)rep * P + pn];
+    const int64_t *Sus = a.S + (int64_t)rep * P * S + (int64_t)pn * S;
+    const bool tab = C <= 256 && CB <= 16;   // (CB <= 16 whenever C > 256: checked by the host)
+    for (int cb = threadIdx.x; cb < CB && cb < 16; cb += TB) {
+        double r = 0.0;
+        for (int sn = 0; sn < S; ++sn) r += p.cb_b[cb] * p.cb_sigma[cb * S + sn] * (double)Sus[sn] * F;
+        s_rtr[cb] = r;
+        s_rmig[cb] = a.has_mig ? a.Gout[((int64_t)rep * P + pn) * CB + cb] * p.cb_b[cb] * p.mig[(int64_t)pn * P + pn] : 0.0;
+    }
+    __syncthreads();
+    if (tab)
+        for (int i = threadIdx.x; i < C; i += TB) {   // the terms of r_all in tau_cell_events, per infected
+            const int cb = p.c_bidx[i];
+            const double r1 = s_rmig[cb] + p.c_d[i] + p.c_s[i] * p.sampMult[pn] + (a.mut_uniform ? a.mut_total : p.c_tm[i]) + s_rtr[cb];
+            // rounded up: covers the roundings of the single-precision test and the other summation order of r_all
+            s_rt[i] = (float)(r1 * tau * (1.0 + 1.0 / 1048576.0)) * (1.0f + 1.0f / 1048576.0f);
+        }
+    __syncthreads();
+    const int L = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int32_t *Irow = a.I + ((int64_t)rep * P + pn) * H;
+    int32_t *dCrow = a.dChk + ((int64_t)rep * P + pn) * H, *dArow = a.dApp + ((int64_t)rep * P + pn) * H;
+    const bool dense = !a.sparse;
+    const uint32_t key[2] = {(uint32_t)a.seeds[rep] ^ ((uint32_t)a.attempt[rep] * 0x9E3779B9u),
+                             (uint32_t)((uint64_t)a.seeds[rep] >> 32) ^ 0x85EBCA6Bu};
+    const uint32_t ctr_step = (uint32_t)a.step[rep], ctr_retry = ((uint32_t)a.retry[rep] << 20) | 0xFFFFFu;   // loop invariants
+    const int tiles = (H + 1023) >> 10;
+    const bool vec = (H & 3) == 0;   // rows are 16-byte aligned
+    const int64_t scap = a.q_cap / a.q_shards;
+    const int64_t shard = (int64_t)pn * gridDim.x + blockIdx.x;
+    unsigned long long *qn = a.q_n + (int64_t)rep * a.q_shards + shard;
+    int64_t *qdst = a.q + (int64_t)rep * a.q_cap + shard * scap;
+    int nq = 0;                      // wave-uniform: entries in this wavefront's stage
+    auto flush = [&]() {             // wave-uniform call
+        WSYNC();
+        unsigned long long base = 0;
+        if (L == 0) base = atomicAdd(qn, (unsigned long long)nq);
+        base = (unsigned long long)bcast_i64((int64_t)base, 0);
+        for (int i = L; i < nq; i += 64)
+            if ((int64_t)(base + i) < scap) qdst[base + i] = q[wave][i];   // a full shard is detected by the events kernel
+        WSYNC();
+        nq = 0;
+    };
+    // a lane looks at 16 compartments of a tile of 1024 (four 16-byte loads, each instruction of the wave covers one
+    // contiguous KiB) with the 16 bytes of one Philox block
+    const int wstride = gridDim.x * (TB / 64);
+    int4 nx[4];
+    auto load_tile = [&](int t, int4 *x) {
+        const int base = t << 10;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int h0 = base + 256 * k + 4 * L;
+            if (vec && h0 + 3 < H) x[k] = *(const int4 *)(Irow + h0);
+            else {
+                x[k] = make_int4(0, 0, 0, 0);
+                if (h0 < H) x[k].x = Irow[h0];
+                if (h0 + 1 < H) x[k].y = Irow[h0 + 1];
+                if (h0 + 2 < H) x[k].z = Irow[h0 + 2];
+                if (h0 + 3 < H) x[k].w = Irow[h0 + 3];
+            }
+        }
+    };
+    const int wt0 = blockIdx.x * (TB / 64) + wave;
+    if (wt0 < tiles) load_tile(wt0, nx);
+    for (int wt = wt0; wt < tiles; wt += wstride) {
+        const int4 x[4] = {nx[0], nx[1], nx[2], nx[3]};
+        if (wt + wstride < tiles) load_tile(wt + wstride, nx);   // the next tile's loads are in flight while this one is worked on
+        const uint64_t gidx = ((uint64_t)pn * (uint64_t)tiles + (uint64_t)wt) * 64u + (uint64_t)L;
+        const uint32_t ctr[4] = {(uint32_t)gidx, (uint32_t)(gidx >> 32), ctr_step, ctr_retry};
+        uint32_t w[4];
+        vgx_philox4x32(ctr, key, w);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int h0 = (wt << 10) + 256 * k + 4 * L;
+            const int Iv[4] = {x[k].x, x[k].y, x[k].z, x[k].w};
+            int cl[4] = {0, 0, 0, 0};
+            if (C != 1) {
+                if (vec && h0 + 3 < H) { const int4 cc = *(const int4 *)(p.cls + h0); cl[0] = cc.x; cl[1] = cc.y; cl[2] = cc.z; cl[3] = cc.w; }
+                else for (int j = 0; j < 4; ++j) if (h0 + j < H) cl[j] = p.cls[h0 + j];
+            }
+            int qm = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t b = (w[k] >> (8 * j)) & 255u;
+                bool qd;
+                if (tab) {
+                    const float thr = fmaf(-256.0f, s_rt[cl[j]] * (float)Iv[j], 255.999f);
+                    qd = Iv[j] > 0 && (float)(b + 1u) > thr;
+                } else {
+                    const int c = cl[j];
+                    const int cb = p.c_bidx[c];
+                    const double rate = s_rmig[cb] + p.c_d[c] + p.c_s[c] * p.sampMult[pn] + (a.mut_uniform ? a.mut_total : p.c_tm[c]) + s_rtr[cb];
+                    const double lam = rate * (double)Iv[j] * tau * (1.0 + 1e-9);
+                    qd = Iv[j] > 0 && (double)(b + 1u) > 256.0 - 256.0 * lam;
+                }
+                if (qd) qm |= 1 << j;
+            }
+            if (dense && h0 < H) {
+                // zero deltas of the compartments that draw nothing here (the queued ones are written by the events kernel, large
+                // ones by vgx_tau_draw_big_kernel): every entry of both arrays is written in every try
+                if (qm == 0 && vec && h0 + 3 < H) {
+                    *(int4 *)(dCrow + h0) = make_int4(0, 0, 0, 0);
+                    *(int4 *)(dArow + h0) = make_int4(0, 0, 0, 0);
+                } else {
+                    for (int j = 0; j < 4; ++j)
+                        if (h0 + j < H && !((qm >> j) & 1)) { dCrow[h0 + j] = 0; dArow[h0 + j] = 0; }
+                }
+            }
+            if (__any(qm != 0)) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const bool qd = (qm >> j) & 1;
+                    const unsigned long long m = __ballot(qd);
+                    if (qd) {
+                        const int slot = nq + __popcll(m & ((1ull << L) - 1ull));
+                        q[wave][slot] = (int64_t)(h0 + j) | ((int64_t)((w[k] >> (8 * j)) & 255u) << 32);
+                    }
+                    nq += __popcll(m);
+                }
+                if (nq >= VGX_QW - 256) flush();
+            }
+        }
+    }
+    if (nq > 0) flush();
+}
+
+// grid = (tau_draw_gx(H), P, R), one wavefront per block; dSi / dTot / dChkTot are zero on entry
+extern "C" __global__ void __launch_bounds__(EB) vgx_tau_events_kernel(VgxTauArgs a) {
+    const int rep = blockIdx.z, pn = blockIdx.y;
+    if (!a.active[rep] || a.accepted[rep]) return;
+    const VgxDevParams &p = a.p;
+    const int P = p.P, S = p.S, C = p.C, CB = p.CB, H = p.H;
+    const int64_t scap = a.q_cap / a.q_shards;
+    const int64_t shard = (int64_t)pn * gridDim.x + blockIdx.x;
+    unsigned long long *qn = a.q_n + (int64_t)rep * a.q_shards + shard;
+    int64_t n = (int64_t)*qn;
+    if (n == 0) return;
+    if (n > scap) {   // the shard overflowed: compartments were lost, the host enlarges the queue and the same try runs again
+        if (threadIdx.x == 0) { atomicOr(&a.grow[rep], 8); *qn = 0; }
+        return;
+    }
     extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
-    // per-block accumulation of everything that all compartments of a population add to (one global atomic per
-    // block instead of one per compartment: the susceptible deltas of a population are a single address)
-    __shared__ unsigned long long sc[8], sS[64], sTot;
+    __shared__ unsigned long long sS[64];
     __shared__ double g_rtr[16], g_rmig[16], g_wtr[16 * 64];   // fallback storage when the class tables stay global
-    if (threadIdx.x < 8) sc[threadIdx.x] = 0;
-    if (threadIdx.x < 64) sS[threadIdx.x] = 0;
-    if (threadIdx.x == 0) sTot = 0;
+    __shared__ WaveStage stage_s;
+    sS[threadIdx.x] = 0;
     bool cdfL;
     const bool useL = tau_tab_lds_bytes(C, CB, S, P, cdfL) != 0;
     TauTab T;
+    const double tau = a.tau[rep];
     const double F = a.F[(int64_t)rep * P + pn];
     const int64_t *Sus = a.S + (int64_t)rep * P * S + (int64_t)pn * S;
     const double *gcdf = a.migcdf + ((int64_t)rep * P + pn) * CB * (int64_t)P * S;
@@ -1053,22 +1288,22 @@ extern "C" __global__ void __launch_bounds__(TB) vgx_tau_draw_kernel(VgxTauArgs 
         double *l_cdf = d; if (cdfL) d += CB * P * S;
         int32_t *l_bidx = (int32_t *)d;
         int32_t *l_stype = l_bidx + C;
-        for (int i = threadIdx.x; i < C; i += TB) {
+        for (int i = threadIdx.x; i < C; i += EB) {
             l_cd[i] = p.c_d[i]; l_cs[i] = p.c_s[i]; l_ctm[i] = p.c_tm[i]; l_bidx[i] = p.c_bidx[i]; l_stype[i] = p.c_stype[i];
         }
-        for (int i = threadIdx.x; i < CB * S; i += TB) l_wtr[i] = p.cb_b[i / S] * p.cb_sigma[i] * (double)Sus[i % S] * F;
-        for (int i = threadIdx.x; i < 3 * p.sites && i < 48; i += TB) l_mut[i] = a.mutcum[i];
+        for (int i = threadIdx.x; i < CB * S; i += EB) l_wtr[i] = p.cb_b[i / S] * p.cb_sigma[i] * (double)Sus[i % S] * F;
+        for (int i = threadIdx.x; i < 3 * p.sites && i < 48; i += EB) l_mut[i] = a.mutcum[i];
         if (cdfL)
-            for (int i = threadIdx.x; i < CB * P * S; i += TB) l_cdf[i] = gcdf[i];
+            for (int i = threadIdx.x; i < CB * P * S; i += EB) l_cdf[i] = gcdf[i];
         __syncthreads();
-        for (int cb = threadIdx.x; cb < CB; cb += TB) {
+        for (int cb = threadIdx.x; cb < CB; cb += EB) {
             double r = 0.0;
             for (int sn = 0; sn < S; ++sn) r += l_wtr[cb * S + sn];
             l_rtr[cb] = r;
             l_rmig[cb] = a.has_mig ? a.Gout[((int64_t)rep * P + pn) * CB + cb] * p.cb_b[cb] * p.mig[(int64_t)pn * P + pn] : 0.0;
         }
         __syncthreads();
-        for (int i = threadIdx.x; i < C; i += TB) {   // same terms as r_all in tau_cell, per infected
+        for (int i = threadIdx.x; i < C; i += EB) {
             int cb = l_bidx[i];
             l_r1[i] = l_rmig[cb] + l_cd[i] + l_cs[i] * p.sampMult[pn] + (a.mut_uniform ? a.mut_total : l_ctm[i]) + l_rtr[cb];
         }
@@ -1077,9 +1312,9 @@ extern "C" __global__ void __launch_bounds__(TB) vgx_tau_draw_kernel(VgxTauArgs 
     } else {
         // many classes: parameters stay in global memory; the per-population weights of up to 16 birth classes
         // are still prepared once per block (more birth classes are rejected by the host)
-        for (int i = threadIdx.x; i < CB * S && i < 16 * 64; i += TB) g_wtr[i] = p.cb_b[i / S] * p.cb_sigma[i] * (double)Sus[i % S] * F;
+        for (int i = threadIdx.x; i < CB * S && i < 16 * 64; i += EB) g_wtr[i] = p.cb_b[i / S] * p.cb_sigma[i] * (double)Sus[i % S] * F;
         __syncthreads();
-        for (int cb = threadIdx.x; cb < CB && cb < 16; cb += TB) {
+        for (int cb = threadIdx.x; cb < CB && cb < 16; cb += EB) {
             double r = 0.0;
             for (int sn = 0; sn < S; ++sn) r += g_wtr[cb * S + sn];
             g_rtr[cb] = r;
@@ -1088,121 +1323,64 @@ extern "C" __global__ void __launch_bounds__(TB) vgx_tau_draw_kernel(VgxTauArgs 
         T.c_d = p.c_d; T.c_s = p.c_s; T.c_tm = p.c_tm; T.c_bidx = p.c_bidx; T.c_stype = p.c_stype;
         T.rtr = g_rtr; T.wtr = g_wtr; T.rmig = g_rmig; T.mutcum = a.mutcum; T.cdf = gcdf; T.r1 = nullptr;
     }
+    WaveStage *stage = &stage_s;
+    if (threadIdx.x == 0) stage->n = 0;
     __syncthreads();
-    // per-thread tallies: [0..5] event counters, [6] delta of totalInfectious[pn], [8..11] susceptible deltas of the first
-    // four groups (all compartments of a population add to the same few addresses: no atomics per event)
+    // per-thread tallies: [0..5] event counters, [6] delta of totalInfectious[pn], [7] the same as the check books it,
+    // [8..11] susceptible deltas of the first four groups (all compartments of a population add to the same few addresses:
+    // no atomics per event)
     int64_t cnt[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    const double tau = a.tau[rep];
-    // Phase A: a thread looks at four neighbouring haplotypes (32 B loads and stores); their first uniforms are the
-    // four words of ONE Philox block keyed like the compartment streams, counter (group index, step, retry | 0xFFFFF).
-    // The few compartments that drew events are queued in LDS.  Phase B: the queue is worked off with all lanes busy
-    // (one queued compartment per thread), instead of one divergent lane per wavefront.
-    const int H = p.H;
+    const int L = threadIdx.x;
     const int32_t *Irow = a.I + ((int64_t)rep * P + pn) * H;
     int32_t *dCrow = a.dChk + ((int64_t)rep * P + pn) * H, *dArow = a.dApp + ((int64_t)rep * P + pn) * H;
-    const uint32_t key[2] = {(uint32_t)a.seeds[rep] ^ ((uint32_t)a.attempt[rep] * 0x9E3779B9u),
-                             (uint32_t)((uint64_t)a.seeds[rep] >> 32) ^ 0x85EBCA6Bu};
-    const int groups = ((H + 255) / 256) * 64;   // 4 haplotypes per thread, 256 per wavefront chunk
-    const uint32_t ctr_step = (uint32_t)a.step[rep], ctr_retry = ((uint32_t)a.retry[rep] << 20) | 0xFFFFFu;   // loop invariants
-    // Phase A (every tile): the quick test; the few compartments that may draw events are queued in LDS, every other
-    // compartment gets its zero deltas stored (coalesced 16-byte stores).  Phase B (when the queue holds a few wavefronts'
-    // worth, and at the end): the queue is worked off with all lanes busy and the queued compartments' deltas are stored.
-    // So every try OVERWRITES both delta arrays completely: nothing has to be cleared after a rejected try, the bounds check
-    // needs no pass of its own (own deltas are tested here, incoming ones by the scatter kernel, pyx:2522-2528) and the
-    // commit pass runs for the accepted try only.
-    enum { QCAP = 8 * TB, QGO = QCAP - 4 * TB };
-    __shared__ int q_n, q_h[QCAP], q_w[QCAP];
-    __shared__ IncStage stage;
-    if (threadIdx.x == 0) { q_n = 0; stage.n = 0; }
-    __syncthreads();
-    const int L = threadIdx.x & 63;
-    const int wave_off = (int)(threadIdx.x & ~63u) * 4;
-    // the load of the next tile is issued before this tile is worked on
-    int4 nx = make_int4(0, 0, 0, 0);
-    {
-        const int chunk = blockIdx.x * TB * 4 + wave_off;
-        if (chunk + 256 <= H) nx = *(const int4 *)(Irow + chunk + 4 * L);
-    }
-    for (int q0 = blockIdx.x * TB; q0 < groups; q0 += gridDim.x * TB) {   // persistent over tiles: the table staging is amortised
-        const int q = q0 + threadIdx.x;
-        // a thread owns four consecutive haplotypes (16 bytes of counts): every load/store instruction of the wave covers
-        // one contiguous KiB
-        const int chunk = q0 * 4 + wave_off;
-        const int4 x = nx;
-        {
-            const int nchunk = (q0 + gridDim.x * TB) * 4 + wave_off;
-            if (nchunk + 256 <= H) nx = *(const int4 *)(Irow + nchunk + 4 * L);
-        }
-        if (chunk < H) {
-            const int h0 = chunk + 4 * L;
-            const bool full = chunk + 256 <= H;
-            const uint64_t gidx = (uint64_t)pn * (uint64_t)groups + (uint64_t)q;
-            const uint32_t ctr[4] = {(uint32_t)gidx, (uint32_t)(gidx >> 32), ctr_step, ctr_retry};
-            uint32_t w[4];
-            vgx_philox4x32(ctr, key, w);
-            int Iv[4] = {0, 0, 0, 0};
-            if (full) {
-                Iv[0] = x.x; Iv[1] = x.y; Iv[2] = x.z; Iv[3] = x.w;
-            } else {
-                for (int j = 0; j < 4; ++j)
-                    if (h0 + j < H) Iv[j] = Irow[h0 + j];
+    const bool dense = !a.sparse;
+    const int64_t *qsrc = a.q + (int64_t)rep * a.q_cap + shard * scap;
+    for (int64_t k0 = 0; k0 < n; k0 += EB) {
+        if (*(volatile int32_t *)&a.ok[rep] == 0) break;   // the try is already lost: nothing of it counts (vgx_tau_decide_kernel)
+        const int64_t k = k0 + L;
+        if (k < n) {
+            const int64_t qe = qsrc[k];
+            const int h = (int)(qe & 0xFFFFFFFFll);
+            const int64_t Ih = (int64_t)Irow[h];
+            int64_t oc = 0, oa = 0;
+            const int r = tau_cell_events<false>(a, T, rep, pn, h, tau, Ih, (uint32_t)(qe >> 32), oc, oa, cnt, stage, sS, -1);
+            if (r == 2) {   // many events: one wavefront draws its channels one by one (vgx_tau_draw_big_kernel)
+                const unsigned long long slot = atomicAdd(&a.big_n[rep], 1ull);
+                if ((int64_t)slot < a.big_cap) a.big[(int64_t)rep * a.big_cap + (int64_t)slot] = (int64_t)pn * H + h;
+                else atomicOr(&a.grow[rep], 4);   // list full: the host enlarges it and the same try runs again
             }
-            int queued = 0;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if (h0 + j < H && tau_cell_count(a, T, rep, pn, h0 + j, tau, w[j], (int64_t)Iv[j])) {
-                    int slot = atomicAdd(&q_n, 1);
-                    q_h[slot] = h0 + j;
-                    q_w[slot] = (int)w[j];
-                    queued |= 1 << j;
+            if (dense) { dCrow[h] = (int32_t)oc; dArow[h] = (int32_t)oa; }
+            else if (oa != 0) tau_list_add(a, stage, rep, (int64_t)pn * H + h, oa, true);
+            if (r == 1) {
+                const int64_t v = Ih + oc;
+                if (v < 0 && !dense) {
+                    // below zero on its own: do the mutants of its neighbours rescue it?  Known at once from their streams;
+                    // a definite failure ends the try for everybody (the other wavefronts stop before their next round)
+                    const int64_t arr = tau_arrivals_dry(a, T, rep, pn, h, tau, Irow);
+                    if (arr < 0) tau_own_check(a, rep, pn, h, v);
+                    else if (v + arr < 0) a.ok[rep] = 0;
+                } else {
+                    tau_own_check(a, rep, pn, h, v);
                 }
             }
-            // zero deltas of the compartments that draw nothing here (large ones are overwritten by vgx_tau_draw_big_kernel,
-            // queued ones by phase B): together with phase B every entry of both arrays is written in every try
-            if (full && queued == 0) {
-                *(int4 *)(dCrow + h0) = make_int4(0, 0, 0, 0);
-                *(int4 *)(dArow + h0) = make_int4(0, 0, 0, 0);
-            } else {
-                for (int j = 0; j < 4; ++j)
-                    if (h0 + j < H && !((queued >> j) & 1)) { dCrow[h0 + j] = 0; dArow[h0 + j] = 0; }
-            }
         }
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // LDS only: queue length visible to everyone
-        const int nq = q_n;
-        const bool last = q0 + (int)(gridDim.x * TB) >= groups;
-        if (nq >= QGO || (last && nq > 0)) {   // block-uniform
-            __syncthreads();
-            for (int k = threadIdx.x; k < nq; k += TB) {
-                const int h = q_h[k];
-                int64_t oc, oa;
-                const int64_t Ih = (int64_t)Irow[h];
-                tau_cell_events(a, T, rep, pn, h, tau, Ih, (uint32_t)q_w[k], oc, oa, cnt, &stage, sS, &sTot);
-                dCrow[h] = (int32_t)oc;
-                dArow[h] = (int32_t)oa;
-                tau_own_check(a, rep, pn, h, Ih + oc);
-            }
-            __syncthreads();
-            if (threadIdx.x == 0) q_n = 0;
-            tau_incoming_flush(a, &stage, rep);   // at most QCAP queued compartments per round; overflow goes straight to the list
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        tau_stage_flush(a, stage, rep);
     }
-    __syncthreads();
-    for (int i = 0; i < 12; ++i) {   // wave-level sums first, then one LDS atomic per wave and tally
-        if (i == 7) continue;
+    if (threadIdx.x == 0) *qn = 0;   // the shard is empty for the next try
+    unsigned long long *ct = (unsigned long long *)&a.cnt_try[(int64_t)rep * 8];
+    for (int i = 0; i < 12; ++i) {   // wave-level sums, then one global atomic per tally
         long long v = cnt[i];
         for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
-        if ((threadIdx.x & 63) == 0 && v != 0) {
-            if (i < 6) atomicAdd(&sc[i], (unsigned long long)v);
-            else if (i == 6) atomicAdd(&sTot, (unsigned long long)v);
+        if (threadIdx.x == 0 && v != 0) {
+            if (i < 6) atomicAdd(&ct[i], (unsigned long long)v);
+            else if (i == 6) atomicAdd((unsigned long long *)&a.dTot[(int64_t)rep * P + pn], (unsigned long long)v);
+            else if (i == 7) atomicAdd((unsigned long long *)&a.dChkTot[(int64_t)rep * P + pn], (unsigned long long)v);
             else atomicAdd(&sS[i - 8], (unsigned long long)v);
         }
     }
     __syncthreads();
-    if (threadIdx.x < 6 && sc[threadIdx.x]) atomicAdd((unsigned long long *)&a.cnt_try[(int64_t)rep * 8 + threadIdx.x], sc[threadIdx.x]);
     if (threadIdx.x < S && sS[threadIdx.x])
         atomicAdd((unsigned long long *)&a.dSi[((int64_t)rep * P + pn) * S + threadIdx.x], sS[threadIdx.x]);
-    if (threadIdx.x == 0 && sTot) atomicAdd((unsigned long long *)&a.dTot[(int64_t)rep * P + pn], sTot);
 }
 
 
@@ -1265,12 +1443,7 @@ extern "C" __global__ void __launch_bounds__(TB) vgx_tau_draw_big_kernel(VgxTauA
                 if (k) {
                     const int nh = tau_mutate(sites, hn, ss, ii);
                     mut_done += k;
-                    int64_t left = k;
-                    while (left > 0) {
-                        const int64_t kk = left < VGX_INC_MAXMULT ? left : VGX_INC_MAXMULT;
-                        tau_incoming_global(a, rep, ((int64_t)pn * H + nh) | (kk << VGX_INC_CELL_BITS));
-                        left -= kk;
-                    }
+                    tau_list_add(a, nullptr, rep, (int64_t)pn * H + nh, k, false);
                     tau_row(a, rep, k, 3, hn, pn, nh, 0);
                 }
             } else {                                                                         // pyx:2366-2367
@@ -1279,12 +1452,7 @@ extern "C" __global__ void __launch_bounds__(TB) vgx_tau_draw_big_kernel(VgxTauA
                 const int64_t k = (wj > 0.0 && tp != pn) ? tau_poisson(g, wj / cdf[P * S - 1] * r_mig * tau) : 0;
                 if (k) {
                     migrants += k;
-                    int64_t left = k;
-                    while (left > 0) {
-                        const int64_t kk = left < VGX_INC_MAXMULT ? left : VGX_INC_MAXMULT;
-                        tau_incoming_global(a, rep, ((int64_t)tp * H + hn) | (kk << VGX_INC_CELL_BITS) | ((int64_t)1 << 62));
-                        left -= kk;
-                    }
+                    tau_list_add(a, nullptr, rep, (int64_t)tp * H + hn, k, true);
                     atomicAdd((unsigned long long *)&dS[tp * S + ts], (unsigned long long)(-k));
                     atomicAdd((unsigned long long *)&a.dTot[(int64_t)rep * P + tp], (unsigned long long)k);
                     tau_row(a, rep, k, 5, hn, pn, ts, tp);
@@ -1297,9 +1465,14 @@ extern "C" __global__ void __launch_bounds__(TB) vgx_tau_draw_big_kernel(VgxTauA
         if (lane == 0) {
             const int64_t own = v[0] - v[1] - v[2] - v[3];
             const int64_t off = (int64_t)rep * P * H + cell;
-            a.dChk[off] = (int32_t)(own + v[4]);   // pyx:2473: migrants are booked on their source here
-            a.dApp[off] = (int32_t)own;
+            if (!a.sparse) {
+                a.dChk[off] = (int32_t)(own + v[4]);   // pyx:2473: migrants are booked on their source here
+                a.dApp[off] = (int32_t)own;
+            } else if (own != 0) {
+                tau_list_add(a, nullptr, rep, cell, own, true);
+            }
             tau_own_check(a, rep, pn, hn, (int64_t)a.I[off] + own + v[4]);
+            if (v[0] - v[1] - v[2] + v[4]) atomicAdd((unsigned long long *)&a.dChkTot[(int64_t)rep * P + pn], (unsigned long long)(v[0] - v[1] - v[2] + v[4]));
             unsigned long long *ct = (unsigned long long *)&a.cnt_try[(int64_t)rep * 8];
             if (v[0]) atomicAdd(&ct[0], (unsigned long long)v[0]);
             if (v[1]) atomicAdd(&ct[1], (unsigned long long)v[1]);
@@ -1346,16 +1519,16 @@ extern "C" __global__ void __launch_bounds__(64) vgx_tau_scatter_kernel(VgxTauAr
     const int64_t scap = a.inc_cap / a.inc_shards;
     unsigned long long n = a.inc_n[(int64_t)rep * VGX_INC_SHARDS + shard];
     if ((int64_t)n > scap) {  // shard overflow: the step cannot be validated
-        if (threadIdx.x == 0 && blockIdx.z == 0) a.error[rep] = 4;
+        if (threadIdx.x == 0 && blockIdx.z == 0) atomicOr(&a.grow[rep], 1);
         n = (unsigned long long)scap;
     }
     const int64_t *lst = a.inc + (int64_t)rep * a.inc_cap + (int64_t)shard * scap;
     for (unsigned long long i = (unsigned long long)blockIdx.z * 64 + threadIdx.x; i < n; i += (unsigned long long)gridDim.z * 64) {
         int64_t e = lst[i];
-        int64_t cell = e & (((int64_t)1 << VGX_INC_CELL_BITS) - 1);
-        int k = (int)((e >> VGX_INC_CELL_BITS) & VGX_INC_MAXMULT);
+        int64_t cell = tau_entry_cell(e);
+        int k = tau_entry_delta(e);
         atomicAdd(&a.dApp[(int64_t)rep * PH + cell], k);
-        if (!(e >> 62)) {
+        if (!(e & VGX_INC_APPLIED)) {
             // upper bound of the check (pyx:2522-2528): arrivals only increase the compartment's delta, so whoever adds
             // last sees the final value (the compartment's own delta was stored by the draw kernels before this one)
             const int old = atomicAdd(&a.dChk[(int64_t)rep * PH + cell], k);
@@ -1376,7 +1549,7 @@ extern "C" __global__ void __launch_bounds__(TB) vgx_tau_suspect_kernel(VgxTauAr
     bool bad = false;
     if ((int64_t)n > a.suspect_cap) n = (unsigned long long)a.suspect_cap;   // overflow: the host runs the dense check instead
     for (unsigned long long i = (unsigned long long)blockIdx.x * TB + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * TB) {
-        const int64_t cell = a.suspect[(int64_t)rep * a.suspect_cap + (int64_t)i];
+        const int64_t cell = a.suspect[((int64_t)rep * a.suspect_cap + (int64_t)i) * 2];
         if ((int64_t)a.I[(int64_t)rep * PH + cell] + (int64_t)a.dChk[(int64_t)rep * PH + cell] < 0) bad = true;
     }
     if (blockIdx.x == 0)
@@ -1385,6 +1558,92 @@ extern "C" __global__ void __launch_bounds__(TB) vgx_tau_suspect_kernel(VgxTauAr
             if (v < 0 || v > p.sizes[i / S]) bad = true;
         }
     if (__any(bad) && (threadIdx.x & 63) == 0) a.ok[rep] = 0;
+}
+
+// ---- sparse mode: the two kernels that stand in for vgx_tau_scatter_kernel / vgx_tau_suspect_kernel --------------------
+// Adds the mutants that arrive in a listed compartment (found below zero on its own) to its sum in the hash table.
+// grid = (inc_shards, R, VGX_INC_SHARDS / inc_shards) as for the scatter kernel.
+extern "C" __global__ void __launch_bounds__(64) vgx_tau_arrivals_kernel(VgxTauArgs a) {
+    const int rep = blockIdx.y, shard = blockIdx.x;
+    if (!a.active[rep] || a.accepted[rep]) return;
+    const int64_t scap = a.inc_cap / a.inc_shards;
+    unsigned long long n = a.inc_n[(int64_t)rep * VGX_INC_SHARDS + shard];
+    if ((int64_t)n > scap) {  // shard overflow: entries were lost, nothing of this try counts
+        if (threadIdx.x == 0 && blockIdx.z == 0) atomicOr(&a.grow[rep], 1);
+        n = (unsigned long long)scap;
+    }
+    if (a.suspect_n[rep] == 0) return;   // nobody to rescue
+    const int64_t *lst = a.inc + (int64_t)rep * a.inc_cap + (int64_t)shard * scap;
+    for (unsigned long long i = (unsigned long long)blockIdx.z * 64 + threadIdx.x; i < n; i += (unsigned long long)gridDim.z * 64) {
+        const int64_t e = lst[i];
+        if (e & VGX_INC_APPLIED) continue;   // migrants and own changes are not booked on the compartment by the check (pyx:2473)
+        const int64_t slot = tau_st_find(a, rep, tau_entry_cell(e));
+        if (slot >= 0) atomicAdd((unsigned long long *)&a.st_val[(int64_t)rep * a.st_size + slot], (unsigned long long)(long long)tau_entry_delta(e));
+    }
+}
+
+// The listed compartments with their arrivals: still below zero -> the try is rejected (pyx:2522-2528).  The susceptible
+// compartments' bounds.  The upper bound of the infectious compartments, per population: the compartments of a population
+// that passed the lower bound sum to totalInfectious + (sum of the deltas as the check books them); if that is within the
+// population size so is each of them.  Otherwise the same try is run again with dense delta arrays (grow bit 1 << 1).
+// grid = (32, R).
+extern "C" __global__ void __launch_bounds__(TB) vgx_tau_verdict_kernel(VgxTauArgs a) {
+    const int rep = blockIdx.y;
+    if (!a.active[rep] || a.accepted[rep]) return;
+    const VgxDevParams &p = a.p;
+    const int P = p.P, S = p.S;
+    unsigned long long n = a.suspect_n[rep];
+    bool bad = false, redo = false;
+    if ((int64_t)n > a.suspect_cap) { n = (unsigned long long)a.suspect_cap; redo = true; }   // more than the table holds
+    for (unsigned long long i = (unsigned long long)blockIdx.x * TB + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * TB) {
+        const int64_t cell = a.suspect[((int64_t)rep * a.suspect_cap + (int64_t)i) * 2];
+        const int64_t slot = tau_st_find(a, rep, cell);
+        if (slot < 0 || a.st_val[(int64_t)rep * a.st_size + slot] < 0) bad = true;
+    }
+    if (blockIdx.x == 0) {
+        for (int i = threadIdx.x; i < P * S; i += TB) {
+            const int64_t v = a.dSi[(int64_t)rep * P * S + i] + a.S[(int64_t)rep * P * S + i];
+            if (v < 0 || v > p.sizes[i / S]) bad = true;
+        }
+        for (int pn = threadIdx.x; pn < P; pn += TB)
+            if (a.totInf[(int64_t)rep * P + pn] + a.dChkTot[(int64_t)rep * P + pn] > p.sizes[pn]) redo = true;
+    }
+    if (__any(bad) && (threadIdx.x & 63) == 0) a.ok[rep] = 0;
+    if (__any(redo) && (threadIdx.x & 63) == 0) atomicOr(&a.grow[rep], 2);
+}
+
+// UpdateCompartmentCounts_tau of the sparse mode: the list of the accepted try is added to the compartments (one atomic per
+// entry; a rejected try leaves nothing behind), the small per-population accumulators are applied / cleared as in
+// vgx_tau_commit_kernel.  grid = (inc_shards, R, VGX_INC_SHARDS / inc_shards).
+extern "C" __global__ void __launch_bounds__(64) vgx_tau_apply_kernel(VgxTauArgs a) {
+    const int rep = blockIdx.y, shard = blockIdx.x;
+    if (!a.deciding[rep]) return;
+    const int P = a.p.P, S = a.p.S;
+    const bool acc = a.accepted[rep] && !a.error[rep];
+    if (acc) {
+        const int64_t PH = (int64_t)P * a.p.H;
+        const int64_t scap = a.inc_cap / a.inc_shards;
+        unsigned long long n = a.inc_n[(int64_t)rep * VGX_INC_SHARDS + shard];
+        if ((int64_t)n > scap) n = (unsigned long long)scap;   // (an overflowing try is never accepted)
+        const int64_t *lst = a.inc + (int64_t)rep * a.inc_cap + (int64_t)shard * scap;
+        for (unsigned long long i = (unsigned long long)blockIdx.z * 64 + threadIdx.x; i < n; i += (unsigned long long)gridDim.z * 64) {
+            const int64_t e = lst[i];
+            atomicAdd(&a.I[(int64_t)rep * PH + tau_entry_cell(e)], tau_entry_delta(e));
+        }
+    }
+    if (shard == 0 && blockIdx.z == 0) {
+        for (int i = threadIdx.x; i < P * S; i += 64) {
+            const int64_t off = (int64_t)rep * P * S + i;
+            if (acc) a.S[off] += a.dSi[off];
+            a.dSi[off] = 0;
+        }
+        for (int pn = threadIdx.x; pn < P; pn += 64) {
+            const int64_t off = (int64_t)rep * P + pn;
+            if (acc) a.totInf[off] += a.dTot[off];
+            a.dTot[off] = 0;
+            a.dChkTot[off] = 0;
+        }
+    }
 }
 
 // Bounds check of GenerateEvents_tau (pyx:2522-2528) as one dense pass over all compartments: the fallback when the list of
@@ -1431,30 +1690,36 @@ extern "C" __global__ void __launch_bounds__(TB) vgx_tau_check_kernel(VgxTauArgs
 
 // After the check of one retry: accept, or halve tau and discard the tentative tallies (pyx:2316-2321).
 // grid = R, block = 64.  `deciding` marks the replicates whose deltas the commit kernel must now handle.
+// grow[rep] on entry: what the kernels of the try found out (1 = list of moves, 4 = list of large compartments, 8 = queue of
+// drawing compartments overflowed: data were lost, nothing of the try counts; 2 = the sparse check cannot decide the upper
+// bound); on exit: what the host has to do before the SAME try runs again (tau and the try index stay, the streams are keyed
+// by the try index): 1 / 4 / 8 = enlarge that list, 2 = run it with dense delta arrays; 0 = the try was accepted or rejected.
 extern "C" __global__ void __launch_bounds__(64) vgx_tau_decide_kernel(VgxTauArgs a) {
     const int rep = blockIdx.x;
     const bool live = a.active[rep] && !a.accepted[rep];
+    const int g = live ? a.grow[rep] : 0;
+    const bool ok = live && a.ok[rep];
+    const int again = (g & 13) ? (g & 13) : (ok ? (g & 2) : 0);
+    const bool accept = live && ok && again == 0;
     __syncthreads();
-    if (live) {  // the cross-compartment list of this draw has been applied by vgx_tau_scatter_kernel
+    // the list of moves: applied already (dense mode: vgx_tau_scatter_kernel) or discarded; the sparse mode's accepted list
+    // is applied after this kernel (vgx_tau_apply_kernel) and emptied by vgx_tau_finish_kernel
+    if (live && (!accept || !a.sparse))
         for (int i = threadIdx.x; i < a.inc_shards; i += 64) a.inc_n[(int64_t)rep * VGX_INC_SHARDS + i] = 0;
-        if (threadIdx.x == 0) { a.big_n[rep] = 0; a.suspect_n[rep] = 0; }
-    }
     if (threadIdx.x != 0) return;
     a.deciding[rep] = 0;
     if (!live) return;
+    a.big_n[rep] = 0;
+    a.suspect_n[rep] = 0;
     a.deciding[rep] = 1;
-    if (a.error[rep] == 4) {
-        // the cross-compartment list overflowed (vgx_tau_scatter_kernel): nothing of this try counts.  It is discarded like a
-        // rejected one but tau and the try index stay, so that the same draws are made again once the host has enlarged
-        // the list (the streams are keyed by the try index).
-        a.error[rep] = 0;
-        a.grow[rep] = 1;
+    a.grow[rep] = again;
+    if (again) {   // discarded like a rejected try, but tau and the try index stay
         a.ok[rep] = 1;
         for (int i = 0; i < 6; ++i) a.cnt_try[(int64_t)rep * 8 + i] = 0;
         a.mev_n[rep] = a.mev_base[rep];
         return;
     }
-    if (a.ok[rep]) {
+    if (accept) {
         a.accepted[rep] = 1;
         for (int i = 0; i < 6; ++i) { a.counters[(int64_t)rep * 8 + i] += a.cnt_try[(int64_t)rep * 8 + i]; }
         int64_t drawn = 0;
@@ -1501,6 +1766,7 @@ extern "C" __global__ void __launch_bounds__(TB) vgx_tau_commit_kernel(VgxTauArg
         int64_t off = (int64_t)rep * P + pn;
         if (acc) a.totInf[off] += a.dTot[off];
         a.dTot[off] = 0;
+        a.dChkTot[off] = 0;
     }
 }
 
@@ -1542,6 +1808,7 @@ extern "C" __global__ void __launch_bounds__(64) vgx_tau_finish_kernel(VgxTauArg
         }
     }
     __syncthreads();   // the lockdown records above use time_now + tau
+    for (int i = lane; i < a.inc_shards; i += 64) a.inc_n[(int64_t)rep * VGX_INC_SHARDS + i] = 0;   // (sparse mode: applied by now)
     if (lane == 0) {
         a.gI[rep] = g;
         // one packed record per replicate for the host, and the bookkeeping it used to upload before every step
@@ -1606,13 +1873,15 @@ TAU_LAUNCH(tau_choose, dim3((unsigned)a->R), dim3(64))
 extern "C" __attribute__((visibility("hidden"))) hipError_t vgxi_tau_draw(const VgxTauArgs *a, hipStream_t s) {
     bool cdfL;
     size_t lds = tau_tab_lds_bytes(a->p.C, a->p.CB, a->p.S, a->p.P, cdfL);
-    hipError_t err = hipFuncSetAttribute((const void *)vgx_tau_draw_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds ? lds : 16));
+    hipError_t err = hipFuncSetAttribute((const void *)vgx_tau_events_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds ? lds : 16));
     if (err != hipSuccess) return err;
-    unsigned tiles = (unsigned)((a->p.H + TB - 1) / TB);
-    unsigned gx = (tiles + 3u) / 4u < VGX_DRAW_GX ? (tiles + 3u) / 4u : VGX_DRAW_GX;   // blocks per (population, replicate); each loops over its tiles of 4*TB haplotypes
-    hipLaunchKernelGGL(vgx_tau_draw_kernel, dim3(gx, (unsigned)a->p.P, (unsigned)a->R), dim3(TB), lds ? lds : 16, s, *a);
+    const dim3 grid(tau_draw_gx(a->p.H), (unsigned)a->p.P, (unsigned)a->R);
+    hipLaunchKernelGGL(vgx_tau_scan_kernel, grid, dim3(TB), 0, s, *a);
+    hipLaunchKernelGGL(vgx_tau_events_kernel, grid, dim3(EB), lds ? lds : 16, s, *a);
     return hipGetLastError();
 }
+extern "C" __attribute__((visibility("hidden"))) int64_t vgxi_tau_queue_shards(int64_t H, int64_t P) { return (int64_t)tau_draw_gx(H) * P; }
+extern "C" __attribute__((visibility("hidden"))) int64_t vgxi_tau_queue_shard_max(int64_t H) { return tau_queue_shard_max(H); }
 TAU_LAUNCH(tau_suscep_draw, SUS_GRID, dim3(TB))
 TAU_LAUNCH(tau_draw_big, dim3(VGX_BIG_BLOCKS, (unsigned)a->R), dim3(TB))
 extern "C" __attribute__((visibility("hidden"))) hipError_t vgxi_tau_sieve(const VgxTauArgs *a, hipStream_t s) {
@@ -1626,12 +1895,14 @@ TAU_LAUNCH(tau_scatter, dim3((unsigned)a->inc_shards, (unsigned)a->R, (unsigned)
 // Number of thread blocks per replicate of the draw kernel: the cross-compartment list gets one shard per block (a
 // power of two, at most VGX_INC_SHARDS), so that its whole capacity is usable whatever the grid size.
 extern "C" __attribute__((visibility("hidden"))) int vgxi_tau_inc_shards(int64_t H, int64_t P) {
-    unsigned tiles = (unsigned)((H + TB - 1) / TB);
-    int64_t blocks = (int64_t)((tiles + 3u) / 4u < VGX_DRAW_GX ? (tiles + 3u) / 4u : VGX_DRAW_GX) * P;
+    int64_t blocks = (int64_t)tau_draw_gx(H) * P;
     int sh = 1;
     while (sh * 2 <= blocks && sh * 2 <= VGX_INC_SHARDS) sh *= 2;
     return sh;
 }
+TAU_LAUNCH(tau_arrivals, dim3((unsigned)a->inc_shards, (unsigned)a->R, (unsigned)(VGX_INC_SHARDS / a->inc_shards)), dim3(64))
+TAU_LAUNCH(tau_verdict, dim3(32, (unsigned)a->R), dim3(TB))
+TAU_LAUNCH(tau_apply, dim3((unsigned)a->inc_shards, (unsigned)a->R, (unsigned)(VGX_INC_SHARDS / a->inc_shards)), dim3(64))
 TAU_LAUNCH(tau_check, CELL_GRID, dim3(TB))
 TAU_LAUNCH(tau_suspect, dim3(32, (unsigned)a->R), dim3(TB))
 TAU_LAUNCH(tau_decide, dim3((unsigned)a->R), dim3(64))
