@@ -81,7 +81,7 @@ struct vgx_engine {
         r_evrate, r_evcols, r_locrec, r_loctime, r_lociter, r_farate, r_fakey, r_traj, r_prof, r_qeff, r_qmebm, r_qflag;
     // tau-leaping (dense compartments)
     DevBuf t_I, t_S, t_dChk, t_dApp, t_dSi, t_dTot, t_totInf, t_gI, t_cd, t_lock, t_F, t_eff, t_Aeff, t_Gout, t_dS,
-        t_taubits, t_tau, t_time, t_flags, t_counters, t_cnttry, t_mev, t_mevn, t_mevbase, t_locn, t_mutcum, t_migcdf, t_migIn, t_mutHi, t_colT, t_colTW, t_inc, t_incn, t_sieve, t_sieveskip, t_big, t_bign, t_res, t_susp, t_suspn, t_stkey, t_stval, t_dChkTot, t_q, t_qn;
+        t_taubits, t_tau, t_time, t_flags, t_counters, t_cnttry, t_mev, t_mevn, t_mevbase, t_locn, t_mutcum, t_migcdf, t_migIn, t_mutHi, t_colT, t_colTW, t_inc, t_incn, t_sieve, t_sieveskip, t_big, t_bign, t_res, t_susp, t_suspn, t_stkey, t_stval, t_dChkTot, t_q, t_qn, t_hist;
     std::vector<int64_t> tau_sieve_skipped;   // [R] tries left out by the sieve in the last tau call
     bool last_was_tau = false;
     int64_t tau_mev_cap = 0;
@@ -1112,6 +1112,23 @@ extern "C" int vgx_simulate_tau(vgx_engine *e, int64_t iterations, int64_t sampl
     a.sieve = (double *)e->t_sieve.p; a.sieve_skipped = (int64_t *)e->t_sieveskip.p;
     // vgx_run_opts.reserved[0] = 1: run every try of the halving loop; with few compartments no try is ever a certain rejection
     a.sieve_on = (o.reserved[0] == 1 || P * H < 32768) ? 0 : 1;
+    {   // low sites (the last min(sites, 6)): equally likely derived states at each of them?  one common rate?
+        const int ns = (int)e->d.sites, low = ns < 6 ? ns : 6, nh = ns - low;
+        bool flat = a.mut_uniform && low >= 2 && ns <= 10 && e->t_mutHi.p != nullptr && e->C <= 256 && e->CB <= 16, same = true;
+        for (int s2 = nh; s2 < ns && flat; s2++) {
+            if (e->h_mutp[s2][0] != e->h_mutp[s2][1] || e->h_mutp[s2][1] != e->h_mutp[s2][2]) flat = false;
+            if (e->h_mutp[s2][0] != e->h_mutp[nh][0]) same = false;
+        }
+        a.mutlow_fast = flat ? 1 : 0;
+        a.mutlow_same = (flat && same) ? 1 : 0;
+        a.hist = nullptr;
+        if (flat && a.sieve_on && e->C <= 8) {   // (VGX_HIST_CMAX classes x 64 sizes per population)
+            int rch = ensure(e, e->t_hist, (size_t)(R * P * e->C * 64) * 4);
+            if (rch) return rch;
+            HIPCHECK(e, hipMemset(e->t_hist.p, 0, (size_t)(R * P * e->C * 64) * 4));
+            a.hist = (unsigned int *)e->t_hist.p;
+        }
+    }
     a.mev = (int64_t *)e->t_mev.p; a.mev_cap = mev_cap;
     e->tau_mev_cap = mev_cap;
     a.mev_n = (unsigned long long *)e->t_mevn.p; a.mev_base = (unsigned long long *)e->t_mevbase.p;

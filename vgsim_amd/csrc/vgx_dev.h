@@ -172,6 +172,9 @@ struct VgxTauArgs {
     double *mutHi;       // [R][P][H]  incoming mutation drift through the high sites (tiled drift, sites > 6), or null
     int32_t mutHi_int;   // all high sites share one rate and equally likely derived states: mutHi holds int32 neighbour sums
     double mutHi_rate;   // ... to be scaled by this rate
+    int32_t mutlow_fast; // uniform mutation model, at least two low sites, each with equally likely derived states: vgx_tau_drift_fast_kernel
+    int32_t mutlow_same; // ... and all low sites share one rate
+    unsigned int *hist;  // [R][P][C][64] compartments of size 1..64 per class (filled by the fast drift kernel for the sieve), or null
     // uniform migration (every off-diagonal migration probability equal to mig_b, hence every diagonal equal to mig_d):
     // effMig[t][s] = b^2 W + (d b - b^2)(w_t + w_s), w = cd / actualSizes, W = sum w, so the incoming migration pressure
     // needs only the two column sums below instead of the [P x P] x [P x H] product

@@ -616,6 +616,175 @@ extern "C" __global__ void __launch_bounds__(TB) vgx_tau_drift_tiled_kernel(VgxT
     if (threadIdx.x == 0) atomicMin(&a.tau_bits[rep], smin);
 }
 
+// Pass 2, fast form: every low site has equally likely derived states (the usual models), at least two low sites.  A thread
+// takes four consecutive compartments: their neighbours through the LAST site are the other three of the four, and through
+// any other low site three 16-byte groups of the tile (t0 ^ (x << sh) keeps the low two bits), so the eighteen neighbour
+// counts of a compartment cost sixteen 16-byte LDS reads per FOUR compartments and are added as integers (their sums stay
+// below the population size).  The kernel also fills the histogram of compartment sizes the sieve of the halving loop works
+// on (vgx_tau_sieve_hist_kernel), so that the sieve needs no pass over the compartments of its own.
+// grid = (ceil(H / tile), P, R).
+#define VGX_HIST_CMAX 8      // rate classes up to which the histogram is kept (else vgx_tau_sieve_kernel makes its own pass)
+#define VGX_HIST_X 64        // = VGX_SIEVE_XMAX: compartment sizes 1..64
+// C1: one rate class (its constants are wave-uniform), S1: one susceptibility group; the class tables are in LDS (C <= 256 and
+// at most 16 transmission classes: the launcher takes the general tiled kernel otherwise).
+template <bool C1, bool S1>
+__global__ void __launch_bounds__(TB) vgx_tau_drift_fast_kernel(VgxTauArgs a) {
+    const int rep = blockIdx.z, pn = blockIdx.y;
+    if (!a.active[rep]) return;
+    const VgxDevParams &p = a.p;
+    const int P = p.P, S = p.S, H = p.H, sites = p.sites, C = p.C, CB = p.CB;
+    const int lane = threadIdx.x & 63;
+    const int low = sites < VGX_DRIFT_LOW ? sites : VGX_DRIFT_LOW, nh = sites - low;
+    const int TS = 1 << (2 * low);   // tile size (16 .. 4096 haplotypes)
+    const int64_t rowoff = ((int64_t)rep * P + pn) * H;
+    const int32_t *I = a.I + rowoff;
+    const int64_t *Sus = a.S + (int64_t)rep * P * S + (int64_t)pn * S;
+    __shared__ __attribute__((aligned(16))) int32_t tile[4096];
+    __shared__ double sdS[64];
+    __shared__ unsigned long long smin;
+    __shared__ double l_cd[256], l_cs[256], l_ctm[256], l_base[16 * 64], l_rate[VGX_DRIFT_LOW];
+    __shared__ int32_t l_bidx[256], l_stype[256];
+    __shared__ unsigned int hist[VGX_HIST_CMAX * VGX_HIST_X * 2];   // C * 64 bins in HK copies (lanes spread over the copies)
+    const bool do_hist = a.hist != nullptr;
+    if (threadIdx.x < 64) sdS[threadIdx.x] = 0.0;
+    if (threadIdx.x == 0) smin = (unsigned long long)__double_as_longlong(1.0);
+    // copies of the histogram: 16 for one class ... 2 for eight (same-address LDS atomics of a wavefront serialise)
+    const int HK = C == 1 ? 16 : (C == 2 ? 8 : (C <= 4 ? 4 : 2));
+    if (do_hist)
+        for (int i = threadIdx.x; i < C * VGX_HIST_X * HK; i += TB) hist[i] = 0;
+    for (int i = threadIdx.x; i < C; i += TB) {
+        l_cd[i] = p.c_d[i]; l_cs[i] = p.c_s[i] * p.sampMult[pn]; l_ctm[i] = p.c_tm[i];
+        l_bidx[i] = p.c_bidx[i]; l_stype[i] = p.c_stype[i];
+    }
+    for (int i = threadIdx.x; i < CB * S; i += TB) l_base[i] = p.cb_b[i / S] * p.cb_sigma[i] * (double)Sus[i % S];
+    if (threadIdx.x < low) l_rate[threadIdx.x] = a.mutp[nh + threadIdx.x][0];   // low site i <-> two-bit group low - 1 - i
+    const int h0 = blockIdx.x * TS;
+    for (int i = threadIdx.x * 4; i < TS; i += TB * 4) *(int4 *)(tile + i) = *(const int4 *)(I + h0 + i);
+    __syncthreads();
+    const double F = a.F[(int64_t)rep * P + pn];
+    __shared__ double s_wu[16];
+    MigU mu = {0.0, 0.0, 0.0};
+    if (a.has_mig && a.mig_uniform) mu = tau_migu_setup(a, rep, pn, s_wu);
+    const double cd0 = l_cd[0], cs0 = l_cs[0], ctm0 = l_ctm[0], base0 = l_base[0];   // (C1: the class's constants)
+    const int cb0 = l_bidx[0], st0 = l_stype[0];
+    const bool one_rate = a.mutlow_same != 0;
+    const double rate0 = l_rate[0];
+    double cand_min = 1.0, ad_max = 0.0;
+    double redS[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int t0 = threadIdx.x * 4; t0 < TS; t0 += TB * 4) {
+        double mh[4] = {0.0, 0.0, 0.0, 0.0}, mg[4] = {0.0, 0.0, 0.0, 0.0};
+        if (nh > 0 && a.mutHi_int) {
+            const int4 v = *(const int4 *)((const int32_t *)a.mutHi + rowoff + h0 + t0);
+            mh[0] = a.mutHi_rate * (double)v.x; mh[1] = a.mutHi_rate * (double)v.y; mh[2] = a.mutHi_rate * (double)v.z; mh[3] = a.mutHi_rate * (double)v.w;
+        } else if (nh > 0) {
+            const double4 v = *(const double4 *)(a.mutHi + rowoff + h0 + t0); mh[0] = v.x; mh[1] = v.y; mh[2] = v.z; mh[3] = v.w;
+        }
+        const int4 own = *(const int4 *)(tile + t0);
+        const int Iv[4] = {own.x, own.y, own.z, own.w};
+        if (a.has_mig && a.mig_uniform) {   // the two column sums are shared by all populations: they stay in the caches
+            const double4 v = *(const double4 *)(a.colT + (int64_t)rep * H + h0 + t0);
+            const double4 u = *(const double4 *)(a.colTW + (int64_t)rep * H + h0 + t0);
+            mg[0] = tau_migu(mu, v.x, u.x, (double)Iv[0]); mg[1] = tau_migu(mu, v.y, u.y, (double)Iv[1]);
+            mg[2] = tau_migu(mu, v.z, u.z, (double)Iv[2]); mg[3] = tau_migu(mu, v.w, u.w, (double)Iv[3]);
+        } else if (a.has_mig) {
+            const double4 v = *(const double4 *)(a.migIn + rowoff + h0 + t0); mg[0] = v.x; mg[1] = v.y; mg[2] = v.z; mg[3] = v.w;
+        }
+        // incoming mutation through the low sites
+        const int s4 = own.x + own.y + own.z + own.w;
+        int nb[4] = {s4 - own.x, s4 - own.y, s4 - own.z, s4 - own.w};   // last site: the other three of the four
+        double mlow[4] = {0.0, 0.0, 0.0, 0.0};
+        if (!one_rate) {
+            const double r = l_rate[low - 1];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { mlow[j] = r * (double)nb[j]; nb[j] = 0; }
+        }
+        for (int g = 1; g < low; ++g) {
+            const int sh = 2 * g;
+            const int4 x1 = *(const int4 *)(tile + (t0 ^ (1 << sh))), x2 = *(const int4 *)(tile + (t0 ^ (2 << sh))), x3 = *(const int4 *)(tile + (t0 ^ (3 << sh)));
+            const int sx[4] = {x1.x + x2.x + x3.x, x1.y + x2.y + x3.y, x1.z + x2.z + x3.z, x1.w + x2.w + x3.w};
+            if (one_rate) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) nb[j] += sx[j];
+            } else {
+                const double r = l_rate[low - 1 - g];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) mlow[j] += r * (double)sx[j];
+            }
+        }
+        if (one_rate) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) mlow[j] = rate0 * (double)nb[j];
+        }
+        int cl[4] = {0, 0, 0, 0};
+        if (!C1) { const int4 cc = *(const int4 *)(p.cls + h0 + t0); cl[0] = cc.x; cl[1] = cc.y; cl[2] = cc.z; cl[3] = cc.w; }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = C1 ? 0 : cl[j];
+            const int cb = C1 ? cb0 : l_bidx[c];
+            const int st = C1 ? st0 : l_stype[c];
+            const int32_t Icell = Iv[j];
+            const double Ih = (double)Icell;
+            double drift = 0.0;
+            const double rec = (C1 ? cd0 : l_cd[c]) * Ih;
+            const double samp = (C1 ? cs0 : l_cs[c]) * Ih;
+            drift -= rec;
+            drift -= samp;
+            drift -= (C1 ? ctm0 : l_ctm[c]) * Ih;
+            drift += mlow[j];
+            drift += mh[j];   // ... and through the high sites (pass 1)
+            const double to_st = rec + samp;
+            if (S1) {
+                const double base = C1 ? base0 : l_base[cb];
+                const double v = base * Ih * F + base * mg[j];
+                drift += v;
+                redS[0] += to_st - v;   // susceptible drift of (pn, 0)
+            } else {
+                for (int sn = 0; sn < S; ++sn) {
+                    const double base = l_base[cb * S + sn];
+                    const double v = base * Ih * F + base * mg[j];
+                    drift += v;
+                    const double red = -v + (st == sn ? to_st : 0.0);   // susceptible drift of (pn, sn)
+                    if (sn < 4) redS[sn] += red;
+                    else if (red != 0.0) atomicAdd(&sdS[sn], red);
+                }
+            }
+            // pyx:2440-2444: candidate max(eps * X / 2, 1) / |drift| (epsilon * X in single precision).  For the compartments
+            // with up to 66 hosts the numerator is 1: the smallest candidate is 1 / (largest |drift|), one division per thread
+            // at the end instead of one per compartment (the quotient is monotone in |drift|, so it is the same number)
+            const double ad = fabs(drift);
+            if (ad >= 1e-8) {
+                const double v = (double)(0.03f * (float)Icell) / 2.0;
+                if (v > 1.0) {
+                    const double cand = v / ad;
+                    if (cand < cand_min) cand_min = cand;
+                } else if (ad > ad_max) ad_max = ad;
+            }
+            if (do_hist && Icell >= 1 && Icell <= VGX_HIST_X)
+                atomicAdd(&hist[(c * VGX_HIST_X + Icell - 1) * HK + (lane & (HK - 1))], 1u);
+        }
+    }
+    for (int sn = 0; sn < 4 && sn < S; ++sn) {
+        double red = redS[sn];
+        for (int o = 32; o > 0; o >>= 1) red += __shfl_down(red, o);
+        if (lane == 0 && red != 0.0) atomicAdd(&sdS[sn], red);
+    }
+    if (ad_max > 0.0 && 1.0 / ad_max < cand_min) cand_min = 1.0 / ad_max;
+    for (int o = 32; o > 0; o >>= 1) {
+        double other = __shfl_down(cand_min, o);
+        if (other < cand_min) cand_min = other;
+    }
+    if (lane == 0) atomic_min_pos_double(&smin, cand_min);
+    __syncthreads();
+    if (threadIdx.x < S && sdS[threadIdx.x] != 0.0) atomicAdd(&a.dS[((int64_t)rep * P + pn) * S + threadIdx.x], sdS[threadIdx.x]);
+    if (threadIdx.x == 0) atomicMin(&a.tau_bits[rep], smin);
+    if (do_hist)
+        for (int i = threadIdx.x; i < C * VGX_HIST_X; i += TB) {
+            unsigned int v = 0;
+            for (int k = 0; k < HK; ++k) v += hist[i * HK + k];
+            if (v) atomicAdd(&a.hist[((int64_t)rep * P + pn) * C * VGX_HIST_X + i], v);
+        }
+}
+
 // Susceptible compartments: immunity-transition drift (pyx:2374-2381), tau candidates (pyx:2445-2450),
 // final tau_l; clears the per-step accumulators.  grid = R, block = 64.
 extern "C" __global__ void __launch_bounds__(64) vgx_tau_choose_kernel(VgxTauArgs a) {
@@ -734,6 +903,55 @@ extern "C" __global__ void __launch_bounds__(TB) vgx_tau_sieve_kernel(VgxTauArgs
     }
     __syncthreads();
     if (threadIdx.x < VGX_SIEVE_K && s_E[threadIdx.x] > 0.0) atomicAdd(&a.sieve[(int64_t)rep * VGX_SIEVE_K + threadIdx.x], s_E[threadIdx.x] * 0.99);
+}
+
+// The same bound from the histogram of compartment sizes vgx_tau_drift_fast_kernel filled (the term of a compartment depends
+// on its size, class and population only): no pass over the compartments.  Double precision; the histogram is cleared for
+// the next step.  grid = (P, R), block = 64: lane <-> compartment size 1..64.
+extern "C" __global__ void __launch_bounds__(64) vgx_tau_sieve_hist_kernel(VgxTauArgs a) {
+    const int rep = blockIdx.y, pn = blockIdx.x;
+    if (!a.active[rep]) return;
+    const VgxDevParams &p = a.p;
+    const int P = p.P, S = p.S, C = p.C;
+    const double F = a.F[(int64_t)rep * P + pn];
+    const int64_t *Sus = a.S + (int64_t)rep * P * S + (int64_t)pn * S;
+    const double tau0 = a.tau[rep];
+    const int X = threadIdx.x + 1;
+    const double Xd = (double)X, n = Xd + 1.0;
+    double acc[VGX_SIEVE_K];
+#pragma unroll
+    for (int k = 0; k < VGX_SIEVE_K; ++k) acc[k] = 0.0;
+    for (int c = 0; c < C; ++c) {
+        unsigned int *hp = a.hist + ((int64_t)rep * P + pn) * C * VGX_HIST_X + c * VGX_HIST_X + threadIdx.x;
+        const unsigned int cnt = *hp;
+        *hp = 0;
+        if (cnt == 0) continue;
+        const int cb = p.c_bidx[c];
+        double rtr = 0.0;
+        for (int sn = 0; sn < S; ++sn) rtr += p.cb_b[cb] * p.cb_sigma[cb * S + sn] * (double)Sus[sn] * F;
+        const double rmig = a.has_mig ? a.Gout[((int64_t)rep * P + pn) * p.CB + cb] * p.cb_b[cb] * p.mig[(int64_t)pn * P + pn] : 0.0;
+        const double dec = p.c_d[c] + p.c_s[c] * p.sampMult[pn];
+        const double all = (rmig + dec + (a.mut_uniform ? a.mut_total : p.c_tm[c]) + rtr) * 1.000001;   // rounded up
+        const double mu0 = dec * Xd * tau0;
+        if (!(mu0 > 0.0)) continue;
+        const double m = fmax(0.0151 * Xd, 1.0);
+        double Ak = -m + n * log(mu0) - lgamma(n + 1.0);
+        const double B = all * Xd * tau0 + mu0;
+        const double nl2 = n * 0.6931471805599454;   // ln 2 rounded up
+        double sc = 1.0;
+#pragma unroll
+        for (int k = 0; k < VGX_SIEVE_K; ++k) {
+            acc[k] += (double)cnt * exp(Ak - B * sc);
+            Ak -= nl2;
+            sc *= 0.5;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < VGX_SIEVE_K; ++k) {
+        double v = acc[k];
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+        if (threadIdx.x == 0 && v > 0.0) atomicAdd(&a.sieve[(int64_t)rep * VGX_SIEVE_K + k], v * 0.99);
+    }
 }
 
 // Starts the halving loop of the step at the first try that is not certain to fail.  grid = R, one thread.
@@ -1863,7 +2081,15 @@ extern "C" __attribute__((visibility("hidden"))) hipError_t vgxi_tau_drift(const
             if (err != hipSuccess) return err;
             hipLaunchKernelGGL(vgx_tau_muthigh_kernel, dim3((unsigned)((1 << (2 * low)) / CH), (unsigned)a->p.P, (unsigned)a->R), dim3(TB), lds, s, *a);
         }
-        hipLaunchKernelGGL(vgx_tau_drift_tiled_kernel, dim3((unsigned)(a->p.H >> (2 * low)), (unsigned)a->p.P, (unsigned)a->R), dim3(TB), 0, s, *a);
+        if (a->mutlow_fast) {
+            const dim3 grid((unsigned)(a->p.H >> (2 * low)), (unsigned)a->p.P, (unsigned)a->R);
+            const bool c1 = a->p.C == 1, s1 = a->p.S == 1;
+            if (c1 && s1) hipLaunchKernelGGL((vgx_tau_drift_fast_kernel<true, true>), grid, dim3(TB), 0, s, *a);
+            else if (c1) hipLaunchKernelGGL((vgx_tau_drift_fast_kernel<true, false>), grid, dim3(TB), 0, s, *a);
+            else if (s1) hipLaunchKernelGGL((vgx_tau_drift_fast_kernel<false, true>), grid, dim3(TB), 0, s, *a);
+            else hipLaunchKernelGGL((vgx_tau_drift_fast_kernel<false, false>), grid, dim3(TB), 0, s, *a);
+        } else
+            hipLaunchKernelGGL(vgx_tau_drift_tiled_kernel, dim3((unsigned)(a->p.H >> (2 * low)), (unsigned)a->p.P, (unsigned)a->R), dim3(TB), 0, s, *a);
         return hipGetLastError();
     }
     hipLaunchKernelGGL(vgx_tau_drift_kernel, dim3(gx, (unsigned)a->p.P, (unsigned)a->R), dim3(TB), 0, s, *a);
@@ -1887,7 +2113,8 @@ TAU_LAUNCH(tau_draw_big, dim3(VGX_BIG_BLOCKS, (unsigned)a->R), dim3(TB))
 extern "C" __attribute__((visibility("hidden"))) hipError_t vgxi_tau_sieve(const VgxTauArgs *a, hipStream_t s) {
     unsigned tiles = (unsigned)((a->p.H + 4 * TB - 1) / (4 * TB));
     unsigned gx = tiles < 64u ? tiles : 64u;
-    hipLaunchKernelGGL(vgx_tau_sieve_kernel, dim3(gx, (unsigned)a->p.P, (unsigned)a->R), dim3(TB), 0, s, *a);
+    if (a->hist) hipLaunchKernelGGL(vgx_tau_sieve_hist_kernel, dim3((unsigned)a->p.P, (unsigned)a->R), dim3(64), 0, s, *a);
+    else hipLaunchKernelGGL(vgx_tau_sieve_kernel, dim3(gx, (unsigned)a->p.P, (unsigned)a->R), dim3(TB), 0, s, *a);
     hipLaunchKernelGGL(vgx_tau_sieve_pick_kernel, dim3((unsigned)a->R), dim3(64), 0, s, *a);
     return hipGetLastError();
 }
