@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <cmath>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 #include "../../include/vgx.h"
@@ -825,6 +826,22 @@ static int direct_core(vgx_engine *e, int64_t iterations, int64_t sample_size, f
 // ------------------------------------------------------------------------------------------------
 static bool sites_ok16(const vgx_engine *e) { return e->d.sites <= 16; }
 
+// Host-side loops over all compartments of a large state (2^28 at BASELINE config 4): f(first, last, part) on up to 16 threads
+// (n items of `weight` elementary operations each; small jobs stay on the calling thread)
+template <class F>
+static void for_parts(int64_t n, F f, int64_t weight = 1) {
+    unsigned nt = (unsigned)std::min<int64_t>(std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16u), std::max<int64_t>(n, 1));
+    if (n * weight < ((int64_t)1 << 22)) nt = 1;
+    if (nt == 1) { f((int64_t)0, n, 0u); return; }
+    std::vector<std::thread> th;
+    const int64_t step = (n + nt - 1) / nt;
+    for (unsigned t = 0; t < nt; t++) {
+        const int64_t b = std::min<int64_t>(n, (int64_t)t * step), en = std::min<int64_t>(n, b + step);
+        th.emplace_back([=]() { f(b, en, t); });
+    }
+    for (auto &x : th) x.join();
+}
+
 // SimulatePopulation_tau (pyx:2293-2346): the step loop runs on the host, the steps on the device.
 template <typename T>
 static int dl(vgx_engine *e, std::vector<T> &dst, const DevBuf &b, size_t n) {
@@ -862,7 +879,15 @@ extern "C" int vgx_simulate_tau(vgx_engine *e, int64_t iterations, int64_t sampl
     e->tau_loc_pop.assign((size_t)R, {});
     prepare_first(e);
     int64_t occupied = 0;
-    for (int64_t i = 0; i < P * H; i++) occupied += h.infectious[(size_t)i] != 0;
+    {
+        int64_t part[16] = {0};
+        for_parts(P * H, [&](int64_t b, int64_t en, unsigned t) {
+            int64_t n = 0;
+            for (int64_t i = b; i < en; i++) n += h.infectious[(size_t)i] != 0;
+            part[t] = n;
+        });
+        for (int t = 0; t < 16; t++) occupied += part[t];
+    }
     bool rates_nonzero = false;
     int rc = 0;
     if (occupied <= ((int64_t)1 << 18)) {
@@ -1043,12 +1068,15 @@ extern "C" int vgx_simulate_tau(vgx_engine *e, int64_t iterations, int64_t sampl
     auto upload_state = [&](int64_t r, const std::vector<int64_t> &inf, const std::vector<int64_t> &sus) -> int {
         std::vector<int64_t> tot((size_t)P, 0);
         std::vector<int32_t> inf32((size_t)(P * H));   // device layout: 4 bytes per compartment (sizes < 2^31, checked above)
-        for (int64_t pn = 0; pn < P; pn++)
-            for (int64_t hn = 0; hn < H; hn++) {
-                int64_t v = inf[(size_t)(pn * H + hn)];
-                tot[(size_t)pn] += v;
-                inf32[(size_t)(pn * H + hn)] = (int32_t)v;
+        for_parts(P, [&](int64_t p0, int64_t p1, unsigned) {   // whole populations per thread
+            for (int64_t pn = p0; pn < p1; pn++) {
+                int64_t t = 0;
+                const int64_t *src = &inf[(size_t)(pn * H)];
+                int32_t *dst = &inf32[(size_t)(pn * H)];
+                for (int64_t hn = 0; hn < H; hn++) { t += src[hn]; dst[hn] = (int32_t)src[hn]; }
+                tot[(size_t)pn] = t;
             }
+        }, H);
         HIPCHECK(e, hipMemcpy((int32_t *)e->t_I.p + r * P * H, inf32.data(), (size_t)(P * H) * 4, hipMemcpyHostToDevice));
         HIPCHECK(e, hipMemcpy((int64_t *)e->t_S.p + r * P * S, sus.data(), (size_t)(P * S) * 8, hipMemcpyHostToDevice));
         HIPCHECK(e, hipMemcpy((int64_t *)e->t_totInf.p + r * P, tot.data(), (size_t)P * 8, hipMemcpyHostToDevice));

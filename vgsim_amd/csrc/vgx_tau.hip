@@ -162,33 +162,45 @@ extern "C" __global__ void __launch_bounds__(TB) vgx_tau_eff_kernel(VgxTauArgs a
 // Aeff[tpn][spn] = effMig[tpn,spn] * m[spn,spn] (pyx:2366-2367), and the out-migration weight of a source
 // population per birth class Gout[spn][cb] = sum_{tpn != spn, sn} effMig[tpn,spn] S[tpn,sn] sigma_cb[sn].
 extern "C" __global__ void __launch_bounds__(TB) vgx_tau_prep_kernel(VgxTauArgs a) {
-    const int rep = blockIdx.x;
+    // grid = (P, R): one block per source population spn; the running sums over the P * S channels (target population,
+    // susceptibility group) are a blocked scan: every thread sums a run of consecutive channels, the runs' totals are
+    // scanned in LDS (fixed order: the result does not depend on the launch)
+    const int rep = blockIdx.y, spn = blockIdx.x;
     const VgxDevParams &p = a.p;
     const int P = p.P, S = p.S, CB = p.CB;
     if (!a.active[rep]) return;
-    double *eff = a.effMig + (int64_t)rep * P * P;
-    double *Gout = a.Gout + (int64_t)rep * P * CB;
+    const double *eff = a.effMig + (int64_t)rep * P * P;
     const int64_t *Sus = a.S + (int64_t)rep * P * S;
-    __syncthreads();
-    for (int idx = threadIdx.x; idx < P * CB; idx += TB) {
-        int spn = idx / CB, cb = idx % CB;
-        double g = 0.0;
-        if (a.has_mig)
-            for (int t = 0; t < P; ++t) {
-                if (t == spn) continue;
-                double e = eff[(int64_t)t * P + spn];
-                for (int sn = 0; sn < S; ++sn) g += e * (double)Sus[t * S + sn] * p.cb_sigma[cb * S + sn];
-            }
-        Gout[idx] = g;
+    __shared__ double part[TB];
+    const int n = P * S, per = (n + TB - 1) / TB;
+    const int i0 = min(n, (int)threadIdx.x * per), i1 = min(n, i0 + per);
+    for (int cb = 0; cb < CB; ++cb) {
         // cumulative weights over (tpn, sn) of the out-migration channels of (spn, cb): target lookup by bisection
         double *cdf = a.migcdf + (((int64_t)rep * P + spn) * CB + cb) * (int64_t)P * S;
-        double acc = 0.0;
-        for (int t = 0; t < P; ++t)
-            for (int sn = 0; sn < S; ++sn) {
-                if (t != spn && a.has_mig) acc += eff[(int64_t)t * P + spn] * (double)Sus[t * S + sn] * p.cb_sigma[cb * S + sn];
-                cdf[t * S + sn] = acc;
-            }
+        double loc = 0.0;
+        for (int i = i0; i < i1; ++i) {
+            const int t = i / S, sn = i - t * S;
+            if (t != spn && a.has_mig) loc += eff[(int64_t)t * P + spn] * (double)Sus[t * S + sn] * p.cb_sigma[cb * S + sn];
+        }
+        part[threadIdx.x] = loc;
+        __syncthreads();
+        for (int off = 1; off < TB; off <<= 1) {
+            const double v = (int)threadIdx.x >= off ? part[threadIdx.x - off] : 0.0;
+            __syncthreads();
+            part[threadIdx.x] += v;
+            __syncthreads();
+        }
+        double acc = threadIdx.x > 0 ? part[threadIdx.x - 1] : 0.0;
+        for (int i = i0; i < i1; ++i) {
+            const int t = i / S, sn = i - t * S;
+            if (t != spn && a.has_mig) acc += eff[(int64_t)t * P + spn] * (double)Sus[t * S + sn] * p.cb_sigma[cb * S + sn];
+            cdf[i] = acc;
+        }
+        // out-migration weight of the source population per birth class = the last running sum
+        if (threadIdx.x == TB - 1) a.Gout[((int64_t)rep * P + spn) * CB + cb] = part[TB - 1];
+        __syncthreads();
     }
+    if (spn != 0) return;
     if (threadIdx.x == 0) {
         a.tau_bits[rep] = (unsigned long long)__double_as_longlong(1.0);  // tau_l starts at 1.0 (pyx:2437)
         a.ok[rep] = 1;
@@ -1081,7 +1093,7 @@ static __device__ __forceinline__ int64_t tau_st_find(const VgxTauArgs &a, int r
 // reference's check.  Incoming mutants only add to it afterwards, so v > sizes is final (the try is rejected); v < 0 may still
 // be rescued: the compartment is listed and looked at again once the arrivals are known.
 static __device__ __forceinline__ void tau_own_check(const VgxTauArgs &a, int rep, int pn, int hn, int64_t v) {
-    if (v > a.p.sizes[pn]) a.ok[rep] = 0;
+    if (v > a.p.sizes[pn]) atomicAnd(&a.ok[rep], 0);
     else if (v < 0) {
         const unsigned long long slot = atomicAdd(&a.suspect_n[rep], 1ull);
         if ((int64_t)slot < a.suspect_cap) {
@@ -1282,29 +1294,6 @@ static __device__ __forceinline__ int tau_cell_events(const VgxTauArgs &a, const
     return 1;
 }
 
-// Mutants that arrive in compartment (pn, hn) in this try, computed from the draws of its single-site neighbours alone (their
-// streams depend on nothing but the compartment, the step and the try): decides at once whether a compartment found below
-// zero on its own is rescued (pyx:2522-2528 look at the sum).  -1: a neighbour is drawn channel by channel in
-// vgx_tau_draw_big_kernel and the answer has to wait for the list (never for the sparse epidemics this shortcut is for).
-static __device__ __forceinline__ int64_t tau_arrivals_dry(const VgxTauArgs &a, const TauTab &T, int rep, int pn, int hn, double tau, const int32_t *Irow) {
-    const int sites = a.p.sites;
-    int64_t cnt_unused[12];
-    int64_t total = 0;
-    for (int s = 0; s < sites; ++s) {
-        const int sh = 2 * (sites - s - 1);
-        for (int x = 1; x < 4; ++x) {
-            const int nb = hn ^ (x << sh);
-            const int64_t In = (int64_t)Irow[nb];
-            if (In <= 0) continue;
-            int64_t k = 0, dummy = 0;
-            const int r = tau_cell_events<true>(a, T, rep, pn, nb, tau, In, tau_bucket(a, rep, pn, nb), k, dummy, cnt_unused, nullptr, nullptr, hn);
-            if (r == 2) return -1;
-            total += k;
-        }
-    }
-    return total;
-}
-
 // LDS budget of the events kernel's tables (doubles, then int32); 0 = tables stay in global memory
 static __host__ __device__ inline size_t tau_tab_lds_bytes(int C, int CB, int S, int P, bool &cdf_in_lds) {
     cdf_in_lds = false;
@@ -1477,6 +1466,10 @@ extern "C" __global__ void __launch_bounds__(EB) vgx_tau_events_kernel(VgxTauArg
     unsigned long long *qn = a.q_n + (int64_t)rep * a.q_shards + shard;
     int64_t n = (int64_t)*qn;
     if (n == 0) return;
+    if (__hip_atomic_load(&a.ok[rep], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {   // the try is already lost (see below)
+        if (threadIdx.x == 0) *qn = 0;
+        return;
+    }
     if (n > scap) {   // the shard overflowed: compartments were lost, the host enlarges the queue and the same try runs again
         if (threadIdx.x == 0) { atomicOr(&a.grow[rep], 8); *qn = 0; }
         return;
@@ -1553,12 +1546,19 @@ extern "C" __global__ void __launch_bounds__(EB) vgx_tau_events_kernel(VgxTauArg
     int32_t *dCrow = a.dChk + ((int64_t)rep * P + pn) * H, *dArow = a.dApp + ((int64_t)rep * P + pn) * H;
     const bool dense = !a.sparse;
     const int64_t *qsrc = a.q + (int64_t)rep * a.q_cap + shard * scap;
+    // `ok` is read and cleared at device scope: the XCDs' L2 caches are not coherent with each other for plain accesses, a
+    // wavefront on another XCD would never see the flag.  The load is issued one round ahead of its use.
+    int okv = __hip_atomic_load(&a.ok[rep], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     for (int64_t k0 = 0; k0 < n; k0 += EB) {
-        if (*(volatile int32_t *)&a.ok[rep] == 0) break;   // the try is already lost: nothing of it counts (vgx_tau_decide_kernel)
+        if (okv == 0) break;   // the try is already lost: nothing of it counts (vgx_tau_decide_kernel)
+        okv = __hip_atomic_load(&a.ok[rep], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const int64_t k = k0 + L;
+        int h = 0;
+        int64_t v = 0;
+        bool below = false;   // below zero on its own (sparse mode): looked at by the whole wavefront, see below
         if (k < n) {
             const int64_t qe = qsrc[k];
-            const int h = (int)(qe & 0xFFFFFFFFll);
+            h = (int)(qe & 0xFFFFFFFFll);
             const int64_t Ih = (int64_t)Irow[h];
             int64_t oc = 0, oa = 0;
             const int r = tau_cell_events<false>(a, T, rep, pn, h, tau, Ih, (uint32_t)(qe >> 32), oc, oa, cnt, stage, sS, -1);
@@ -1570,16 +1570,37 @@ extern "C" __global__ void __launch_bounds__(EB) vgx_tau_events_kernel(VgxTauArg
             if (dense) { dCrow[h] = (int32_t)oc; dArow[h] = (int32_t)oa; }
             else if (oa != 0) tau_list_add(a, stage, rep, (int64_t)pn * H + h, oa, true);
             if (r == 1) {
-                const int64_t v = Ih + oc;
-                if (v < 0 && !dense) {
-                    // below zero on its own: do the mutants of its neighbours rescue it?  Known at once from their streams;
-                    // a definite failure ends the try for everybody (the other wavefronts stop before their next round)
-                    const int64_t arr = tau_arrivals_dry(a, T, rep, pn, h, tau, Irow);
-                    if (arr < 0) tau_own_check(a, rep, pn, h, v);
-                    else if (v + arr < 0) a.ok[rep] = 0;
-                } else {
-                    tau_own_check(a, rep, pn, h, v);
-                }
+                v = Ih + oc;
+                if (v < 0 && !dense) below = true;
+                else tau_own_check(a, rep, pn, h, v);
+            }
+        }
+        // A compartment below zero on its own: do the mutants of its neighbours rescue it (pyx:2522-2528 look at the sum)?  Their
+        // streams depend on nothing but the compartment, the step and the try, so the wavefront draws them here and now, one
+        // single-site neighbour per lane (no bookkeeping: tau_cell_events<true>), and a definite failure ends the try for
+        // everybody at once: the other wavefronts stop before their next round.  A neighbour that is drawn channel by channel
+        // (vgx_tau_draw_big_kernel) leaves the question to the list of arrivals (vgx_tau_arrivals_kernel).
+        unsigned long long todo = __ballot(below);
+        while (todo) {
+            const int src = __ffsll((long long)todo) - 1;
+            todo &= todo - 1;
+            const int hs = __builtin_amdgcn_readlane(h, src);
+            int64_t arr = 0;
+            bool open = false;
+            for (int i = L; i < 3 * p.sites; i += EB) {
+                const int nb = hs ^ ((i % 3 + 1) << (2 * (p.sites - i / 3 - 1)));
+                const int64_t In = (int64_t)Irow[nb];
+                if (In <= 0) continue;
+                int64_t kk = 0, dummy = 0;
+                if (tau_cell_events<true>(a, T, rep, pn, nb, tau, In, tau_bucket(a, rep, pn, nb), kk, dummy, cnt, nullptr, nullptr, hs) == 2) open = true;
+                arr += kk;
+            }
+            for (int o = 32; o > 0; o >>= 1) arr += __shfl_down(arr, o);
+            arr = bcast_i64(arr, 0);
+            open = __any(open);
+            if (L == src) {
+                if (open) tau_own_check(a, rep, pn, h, v);
+                else if (v + arr < 0) atomicAnd(&a.ok[rep], 0);
             }
         }
         tau_stage_flush(a, stage, rep);
@@ -2053,7 +2074,7 @@ extern "C" __global__ void __launch_bounds__(64) vgx_tau_finish_kernel(VgxTauArg
 #define CELL_GRID dim3((unsigned)((a->p.H + 4 * TB - 1) / (4 * TB)), (unsigned)a->p.P, (unsigned)a->R)   /* 4 compartments per thread */
 #define SUS_GRID dim3((unsigned)((a->p.P * a->p.S * a->p.S + TB - 1) / TB), (unsigned)a->R)
 TAU_LAUNCH(tau_eff, dim3((unsigned)a->p.P, (unsigned)a->R), dim3(TB))
-TAU_LAUNCH(tau_prep, dim3((unsigned)a->R), dim3(TB))
+TAU_LAUNCH(tau_prep, dim3((unsigned)a->p.P, (unsigned)a->R), dim3(TB))
 extern "C" __attribute__((visibility("hidden"))) hipError_t vgxi_tau_drift(const VgxTauArgs *a, hipStream_t s) {
     if (a->has_mig && a->mig_uniform) {
         hipLaunchKernelGGL(vgx_tau_colsum_kernel, dim3((unsigned)((a->p.H + 4 * TB - 1) / (4 * TB)), (unsigned)a->R), dim3(TB), 0, s, *a);
