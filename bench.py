@@ -144,9 +144,11 @@ def spread_leg(device, mode="exact", replicates=1024, events=20000, occupied=409
     nocc = float((st.infectious != 0).sum(axis=1).mean())
     ms = best.kernel_ms
     ev = best.total_events
-    # exact, one rate class: counts (8 B/entry) of the whole list for the rate refresh + of the entries up to the hit
-    # (half the list on average) for the selection; fast: tile sums + one tile
-    bpe = (12.0 * nocc if mode == "exact" else 8.0 * (nocc / 64.0) + 16.0 * 64) + 8.0 * POPS + 28.0 + 8.0
+    # exact, one rate class: the counts of the whole list for the rate refresh + of the entries up to the hit (half the
+    # list on average) for the selection, 4 B per entry in the four-replicates-per-wavefront kernel (it streams a 4-byte
+    # copy of the counts), 8 B in the wave kernel; fast: tile sums + one tile
+    cnt_bytes = 4.0 if replicates >= 2048 else 8.0
+    bpe = (1.5 * cnt_bytes * nocc if mode == "exact" else 8.0 * (nocc / 64.0) + 16.0 * 64) + 8.0 * POPS + 28.0 + 8.0
     traffic = pmc_traffic("spread_occupancy" if mode == "exact" else "spread_occupancy_fast",
                           {"replicates_per_gpu": replicates, "events_per_replicate": events, "occupied": occupied, "mode": mode})
     out = {"workload": "BASELINE config 3, spread occupancy: %d occupied haplotypes per population at start "

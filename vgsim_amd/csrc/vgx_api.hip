@@ -28,6 +28,7 @@ extern "C" hipError_t vgxi_launch_lanes(const VgxDirectArgs *a, const VgxLaneWs 
 extern "C" hipError_t vgxi_launch_quad(const VgxDirectArgs *a, const double *cd, double *effMig, double *maxEBM, int32_t *has_mig,
                                        hipStream_t stream);
 extern "C" size_t vgxi_direct_lds_bytes(int P, int S, int C, int CB);
+extern "C" hipError_t vgxi_launch_counts32(const int64_t *c64, int32_t *c32, int64_t n, hipStream_t stream);
 extern "C" hipError_t vgxi_launch_init_reps(const VgxDevRep *r, int P, int S, int64_t R, const int32_t *s_nocc,
                                             const int32_t *s_hap, const int32_t *s_cls, const int64_t *s_cnt,
                                             int64_t s_cap, const int64_t *s_sus, const double *s_cd,
@@ -63,6 +64,7 @@ struct vgx_engine {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::string err;
     bool have_params = false, have_state = false, dev_state_valid = false;
+    bool counts32_valid = false;   // r_lcnt32 mirrors r_lcnt (vgx_quad.hip keeps it; other kernels do not)
     int C = 0, CB = 0;
     // host copies of what the host needs again
     std::vector<int32_t> cls;
@@ -78,7 +80,7 @@ struct vgx_engine {
     double recombination = 0.0;          // pyx:93, 1422-1426
     int64_t genome_length = 1000000, rec_cap = 0;
     DevBuf r_rec;
-    DevBuf r_popD, r_popI, r_sus, r_immSrc, r_birthC, r_xC, r_effMig, r_nocc, r_lhap, r_lcls, r_lcnt, r_ltsum, r_lanews, r_sc, r_seeds,
+    DevBuf r_popD, r_popI, r_sus, r_immSrc, r_birthC, r_xC, r_effMig, r_nocc, r_lhap, r_lcls, r_lcnt, r_lcnt32, r_ltsum, r_lanews, r_sc, r_seeds,
         r_evrate, r_evcols, r_locrec, r_loctime, r_lociter, r_farate, r_fakey, r_traj, r_prof, r_qeff, r_qmebm, r_qflag;
     // tau-leaping (dense compartments)
     DevBuf t_I, t_S, t_dChk, t_dApp, t_dSi, t_dTot, t_totInf, t_gI, t_cd, t_lock, t_F, t_eff, t_Aeff, t_Gout, t_dS,
@@ -553,7 +555,7 @@ static int init_device_state(vgx_engine *e, int64_t traj_points) {
     size_t free_b = 0, total_b = 0;
     HIPCHECK(e, hipMemGetInfo(&free_b, &total_b));
     int64_t need = std::max<int64_t>(std::max(s_cap, i_cap), 1);
-    int64_t budget = (int64_t)((double)(free_b + e->r_lhap.bytes + e->r_lcls.bytes + e->r_lcnt.bytes) * 0.45 / (double)(R * P * 16));
+    int64_t budget = (int64_t)((double)(free_b + e->r_lhap.bytes + e->r_lcls.bytes + e->r_lcnt.bytes) * 0.45 / (double)(R * P * 20));
     int64_t cap = std::min<int64_t>(H, std::max<int64_t>(budget, 64));
     cap = std::max(cap, std::min<int64_t>(H, need + 64));
     if (cap < need) return fail(e, VGX_ERR_CAPACITY, "occupancy lists do not fit device memory");
@@ -571,6 +573,8 @@ static int init_device_state(vgx_engine *e, int64_t traj_points) {
     rc |= ensure(e, e->r_lhap, (size_t)(R * P * cap) * 4);
     rc |= ensure(e, e->r_lcls, (size_t)(R * P * cap) * 4);
     rc |= ensure(e, e->r_lcnt, (size_t)(R * P * cap + 64) * 8);   // + one tile: vgx_quad.hip reads whole 64-entry tiles
+    const bool want32 = P <= 64 && S == 1 && e->C == 1 && e->CB == 1;   // shapes the four-replicates-per-wavefront kernel takes
+    if (want32) rc |= ensure(e, e->r_lcnt32, (size_t)(R * P * cap + 64) * 4);
     const int64_t capT = cap / 64 + 1;
     rc |= ensure(e, e->r_ltsum, (size_t)(R * P * capT) * 8);
     rc |= ensure(e, e->r_sc, (size_t)R * sizeof(VgxRepScalars));
@@ -618,6 +622,7 @@ static int init_device_state(vgx_engine *e, int64_t traj_points) {
     d.immSrc = (double *)e->r_immSrc.p; d.birthC = (double *)e->r_birthC.p; d.xC = (double *)e->r_xC.p;
     d.effMig = (double *)e->r_effMig.p; d.nocc = (int32_t *)e->r_nocc.p; d.lhap = (int32_t *)e->r_lhap.p;
     d.lcls = (int32_t *)e->r_lcls.p; d.lcnt = (int64_t *)e->r_lcnt.p; d.cap = cap;
+    d.lcnt32 = want32 ? (int32_t *)e->r_lcnt32.p : nullptr;
     d.ltsum = (int64_t *)e->r_ltsum.p; d.capT = capT;
     HIPCHECK(e, hipMemsetAsync(e->r_ltsum.p, 0, (size_t)(R * P * capT) * 8, e->stream));
     d.i_nocc = (const int32_t *)e->i_nocc.p; d.i_hap = (const int32_t *)e->i_hap.p;
@@ -633,6 +638,7 @@ static int init_device_state(vgx_engine *e, int64_t traj_points) {
                                       (const int64_t *)e->s_tot.p, e->stream));
     HIPCHECK(e, hipStreamSynchronize(e->stream));  // host vectors above go out of scope
     e->dev_state_valid = true;
+    e->counts32_valid = want32;   // (vgx_init_reps_kernel fills both)
     (void)traj_points;
     return VGX_OK;
 }
@@ -750,7 +756,9 @@ static int direct_core(vgx_engine *e, int64_t iterations, int64_t sample_size, f
     // Four replicates per wavefront, one per 16-lane DPP row (vgx_quad.hip): one rate class, one susceptibility group,
     // at most 64 populations, no population that can switch its lockdown state, exact mode.
     bool quad_ok = o.mode == 0 && !recomb && P <= 64 && S == 1 && e->C == 1 && e->CB == 1 && !ld_possible &&
-                   e->suscepCumul[0] == 0.0;
+                   e->suscepCumul[0] == 0.0 && e->dr.lcnt32 != nullptr;
+    for (int64_t pn = 0; pn < P && quad_ok; pn++)
+        if (e->sizes[(size_t)pn] >= ((int64_t)1 << 31)) quad_ok = false;   // its streaming passes read 4-byte counts
     for (int64_t pn = 0; pn < P && quad_ok; pn++)
         if (h.totalSusceptible[(size_t)pn] != h.susceptible[(size_t)pn]) quad_ok = false;
     if (o.kernel == 3 && !quad_ok)
@@ -792,6 +800,9 @@ static int direct_core(vgx_engine *e, int64_t iterations, int64_t sample_size, f
         if (rcq) return rcq;
     }
 
+    // the 4-byte copy of the counts is kept by the four-replicates-per-wavefront kernel alone
+    if (use_quad && !e->counts32_valid) HIPCHECK(e, vgxi_launch_counts32(e->dr.lcnt, e->dr.lcnt32, R * P * e->cap, e->stream));
+    e->counts32_valid = use_quad;
     HIPCHECK(e, hipEventRecord(e->ev0, e->stream));
     if (use_lanes) HIPCHECK(e, vgxi_launch_lanes(&a, &ws, e->stream));
     else if (use_quad) HIPCHECK(e, vgxi_launch_quad(&a, (const double *)e->s_cd.p, (double *)e->r_qeff.p, (double *)e->r_qmebm.p,

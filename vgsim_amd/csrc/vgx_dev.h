@@ -82,6 +82,7 @@ struct VgxDevRep {
     int32_t *lhap;       // [R][P][cap]
     int32_t *lcls;       // [R][P][cap]
     int64_t *lcnt;       // [R][P][cap]
+    int32_t *lcnt32;     // [R][P][cap] the same counts in 4 bytes (population sizes < 2^31), kept by vgx_quad.hip for its streaming passes; or null
     int64_t cap;
     int64_t *ltsum;      // [R][P][capT] sum of the counts of every 64-entry tile of the list (0 beyond the list)
     int64_t capT;        // cap / 64 + 1

@@ -1374,6 +1374,7 @@ extern "C" __global__ void __launch_bounds__(LANES) vgx_init_reps_kernel(
         int n = s_nocc[pn];
         int32_t *lh = r.lhap + (rep * P + pn) * r.cap, *lc = r.lcls + (rep * P + pn) * r.cap;
         int64_t *ln = r.lcnt + (rep * P + pn) * r.cap;
+        int32_t *l3 = r.lcnt32 ? r.lcnt32 + (rep * P + pn) * r.cap : nullptr;
         int64_t *lt = r.ltsum + (rep * P + pn) * r.capT;   // zero-filled by the host beyond the list
         for (int base = 0; base < n; base += LANES) {
             int k = base + lane;
@@ -1383,6 +1384,7 @@ extern "C" __global__ void __launch_bounds__(LANES) vgx_init_reps_kernel(
                 lh[k] = s_hap[(int64_t)pn * s_cap + k];
                 lc[k] = s_cls[(int64_t)pn * s_cap + k];
                 ln[k] = ct;
+                if (l3) l3[k] = (int32_t)ct;
             }
             int64_t tsum = bcast_i64(iscan(ct, lane), LANES - 1);
             if (lane == 0) lt[base / LANES] = tsum;

@@ -156,25 +156,28 @@ static __device__ __forceinline__ void row_scan64(double w0, double w1, double w
     QSTEP4(0) QSTEP4(1) QSTEP4(2) QSTEP4(3) QSTEP4(4) QSTEP4(5) QSTEP4(6) QSTEP4(7) QSTEP4(8) QSTEP4(9) QSTEP4(10) QSTEP4(11)
     QSTEP4(12) QSTEP4(13) QSTEP4(14) QSTEP4(15)
 }
-struct QTile { int64_t c0, c1, c2, c3; };
-static __device__ __forceinline__ QTile tile_load(const int64_t *ln, int t, int rl) {   // entries 64t + 4rl .. + 3
-    const longlong2 a = *(const longlong2 *)(ln + (int64_t)t * 64 + 4 * rl), b = *(const longlong2 *)(ln + (int64_t)t * 64 + 4 * rl + 2);
+#ifndef VGX_QT
+#define VGX_QT 5      // tiles of 64 four-byte counts a row keeps in flight ahead of its summation chain
+#endif
+struct QTile { int c0, c1, c2, c3; };
+static __device__ __forceinline__ QTile tile_load(const int32_t *l3, int t, int rl) {   // entries 64t + 4rl .. + 3 of the 4-byte counts
+    const int4 a = *(const int4 *)(l3 + (int64_t)t * 64 + 4 * rl);
     QTile q;
-    q.c0 = a.x; q.c1 = a.y; q.c2 = b.x; q.c3 = b.y;
+    q.c0 = a.x; q.c1 = a.y; q.c2 = a.z; q.c3 = a.w;
     return q;
 }
 
 struct QSel { int k_hit, hap_hit, err; double pre_hit, w_hit; int64_t cnt_hit; };
 // The haplotype choice over lists longer than 64 entries (inlined: an out-of-line call measured slower in both regimes).
 // Called with all lanes active.
-static __device__ __forceinline__ void q_long_select(const int64_t *ln, const int32_t *lh, int n_sel, int maxn, double tE,
+static __device__ __forceinline__ void q_long_select(const int32_t *ln, const int32_t *lh, int n_sel, int maxn, double tE,
                                                                double r2, bool evn, int H, QSel &o) {
     const int rl = threadIdx.x & 15;
     o.k_hit = -1; o.err = 0;
     // long lists: the running sum advances one tile of 64 entries per step; the tile in which it first reaches r is
     // then scanned entry by entry — same additions, same order.  Loads run QT tiles ahead (unconditional: a row
     // that is through, or has its hit, re-reads its tile 0; every list is followed by 64 entries of padding).
-    enum { QT = 3 };
+    enum { QT = VGX_QT };
     QTile buf[QT];
     double carry = 0.0, carry_hit = 0.0;
     int t_hit = -1;
@@ -216,7 +219,7 @@ static __device__ __forceinline__ void q_long_select(const int64_t *ln, const in
     const int ql = qe >> 2, qj = qe & 3;
     const double psel = qj == 0 ? p0 : qj == 1 ? p1 : qj == 2 ? p2 : p3;
     const double wsel = qj == 0 ? w0 : qj == 1 ? w1 : qj == 2 ? w2 : w3;
-    const int64_t csel = qj == 0 ? c.c0 : qj == 1 ? c.c1 : qj == 2 ? c.c2 : c.c3;
+    const int64_t csel = (int64_t)(qj == 0 ? c.c0 : qj == 1 ? c.c1 : qj == 2 ? c.c2 : c.c3);
     o.pre_hit = q < 64 ? rowget_f64(psel, ql) : carry;     // no hit: the total of the whole list
     o.w_hit = rowget_f64(wsel, ql);
     o.cnt_hit = rowget_i64(csel, ql);
@@ -229,10 +232,10 @@ static __device__ __forceinline__ void q_long_select(const int64_t *ln, const in
 }
 
 // infectPopRate over a list longer than 64 entries (pyx:519-528)
-static __device__ __forceinline__ double q_long_sum(const int64_t *ln, int n, int maxn, double tE) {
+static __device__ __forceinline__ double q_long_sum(const int32_t *ln, int n, int maxn, double tE) {
     const int rl = threadIdx.x & 15;
     double acc = 0.0;
-    enum { QT = 3 };
+    enum { QT = VGX_QT };
     QTile buf[QT];
     const int nt = (n + 63) >> 6, maxt = (maxn + 63) >> 6;
 #pragma unroll
@@ -335,6 +338,7 @@ extern "C" __global__ void __launch_bounds__(64, VGX_QUAD_WAVES) vgx_quad_kernel
     int32_t *lhap = r.lhap + rep * P * cap;
     int32_t *lcls = r.lcls + rep * P * cap;
     int64_t *lcnt = r.lcnt + rep * P * cap;
+    int32_t *lcnt32 = r.lcnt32 + rep * P * cap;   // the same counts in 4 bytes: what the streaming passes over long lists read
     int64_t *ltsum = r.ltsum + rep * P * capT;
     const bool has_traj = r.traj != nullptr;
     const VgxRepScalars *sc = r.sc + rep;
@@ -500,6 +504,7 @@ extern "C" __global__ void __launch_bounds__(64, VGX_QUAD_WAVES) vgx_quad_kernel
             const int n_sel = evn ? s_nocc[pi] : 0;
             const int32_t *lh = lhap + (int64_t)pi * cap;
             int64_t *ln = lcnt + (int64_t)pi * cap;
+            int32_t *l3 = lcnt32 + (int64_t)pi * cap;
             int64_t *lt = ltsum + (int64_t)pi * capT;
             {   // row pi of the migration matrix for the BirthRate refresh: in flight together with the list
                 const double *mrow = p.mig + (int64_t)pi * P;
@@ -572,7 +577,7 @@ extern "C" __global__ void __launch_bounds__(64, VGX_QUAD_WAVES) vgx_quad_kernel
                 }
             } else {
                 QSel sel;
-                q_long_select(ln, lh, n_sel, maxn, tE, r2, evn, H, sel);
+                q_long_select(l3, lh, n_sel, maxn, tE, r2, evn, H, sel);
                 k_hit = sel.k_hit; pre_hit = sel.pre_hit; w_hit = sel.w_hit; hap_hit = sel.hap_hit; cnt_hit = sel.cnt_hit;
                 if (sel.err) err = sel.err;
             }
@@ -600,7 +605,7 @@ extern "C" __global__ void __launch_bounds__(64, VGX_QUAD_WAVES) vgx_quad_kernel
                 if ((double)ts_pi * c_sig == 0.0) err = Q_ERR_ZERO_WEIGHT + 256 * 6;
                 if (rl == 0) { s_ts[pi] = ts_pi - 1; s_ti[pi] = ti_pi + 1; }
                 gI += 1; QBUMP(QC_B);
-                if (live && rl == 0) { ln[k_hit] = cnt_hit + 1; if (n_sel > 64) lt[k_hit >> 6] += 1; }
+                if (live && rl == 0) { ln[k_hit] = cnt_hit + 1; l3[k_hit] = (int32_t)(cnt_hit + 1); if (n_sel > 64) lt[k_hit >> 6] += 1; }
 #pragma unroll
                 for (int c = 0; c < 4; ++c)
                     if (c == (k_hit >> 4) && rl == (k_hit & 15)) ch_cn[c] += 1;
@@ -614,7 +619,7 @@ extern "C" __global__ void __launch_bounds__(64, VGX_QUAD_WAVES) vgx_quad_kernel
                 if (ei == 2) { cS += 1; e_type = QEV_SAMPLING; } else { QBUMP(QC_D); e_type = QEV_DEATH; }
                 if (cnt_hit == 1) { op_n = 1; op_pi = pi; op_h0 = hap_hit; op_d0 = -1; ch_pi = -1; }
                 else {
-                    if (live && rl == 0) { ln[k_hit] = cnt_hit - 1; if (n_sel > 64) lt[k_hit >> 6] -= 1; }
+                    if (live && rl == 0) { ln[k_hit] = cnt_hit - 1; l3[k_hit] = (int32_t)(cnt_hit - 1); if (n_sel > 64) lt[k_hit >> 6] -= 1; }
 #pragma unroll
                     for (int c = 0; c < 4; ++c)
                         if (c == (k_hit >> 4) && rl == (k_hit & 15)) ch_cn[c] -= 1;
@@ -801,6 +806,7 @@ extern "C" __global__ void __launch_bounds__(64, VGX_QUAD_WAVES) vgx_quad_kernel
             int32_t *lh = lhap + (int64_t)op_pi * cap;
             int32_t *lc = lcls + (int64_t)op_pi * cap;
             int64_t *ln = lcnt + (int64_t)op_pi * cap;
+            int32_t *l3 = lcnt32 + (int64_t)op_pi * cap;
             int64_t *lt = ltsum + (int64_t)op_pi * capT;
             // ---- lower bound: first index whose haplotype is >= hap ----
             int posn = 0;
@@ -834,7 +840,7 @@ extern "C" __global__ void __launch_bounds__(64, VGX_QUAD_WAVES) vgx_quad_kernel
             const bool ins = act && !found;                           // a new entry (delta = +1)
             if (ins && n >= cap) { err = Q_ERR_CAPACITY; }
             const bool ins_ok = ins && err == 0;
-            if (bump && rl == 0) { ln[posn] = cur + delta; if (n > 64) lt[posn >> 6] += delta; }
+            if (bump && rl == 0) { ln[posn] = cur + delta; l3[posn] = (int32_t)(cur + delta); if (n > 64) lt[posn >> 6] += delta; }
             // ---- tile sums of lists longer than one tile (vgx_direct.hip list_insert_at / list_remove_at) ----
             if (__ballot((ins_ok || rem) && n > 64)) {
                 const bool tt = (ins_ok || rem) && n > 64;
@@ -877,12 +883,12 @@ extern "C" __global__ void __launch_bounds__(64, VGX_QUAD_WAVES) vgx_quad_kernel
 #pragma unroll
                     for (int u = 0; u < SU; ++u) {
                         const int k = blo + u * 16 + rl;
-                        if (k < hi_) { lh[k + 1] = h[u]; lc[k + 1] = 0; ln[k + 1] = ct[u]; }
+                        if (k < hi_) { lh[k + 1] = h[u]; lc[k + 1] = 0; ln[k + 1] = ct[u]; l3[k + 1] = (int32_t)ct[u]; }
                     }
                     WSYNC();
                     hi_ = blo;
                 }
-                if (ins_ok && rl == 0) { lh[posn] = hap; lc[posn] = 0; ln[posn] = delta; s_nocc[op_pi] = n + 1; }
+                if (ins_ok && rl == 0) { lh[posn] = hap; lc[posn] = 0; ln[posn] = delta; l3[posn] = delta; s_nocc[op_pi] = n + 1; }
                 WSYNC();
                 if (ins_ok && n == 64) {   // the list outgrows one tile: start its tile sums
                     int64_t s0 = 0;
@@ -908,7 +914,7 @@ extern "C" __global__ void __launch_bounds__(64, VGX_QUAD_WAVES) vgx_quad_kernel
 #pragma unroll
                     for (int u = 0; u < SU; ++u) {
                         const int k = lo_ + u * 16 + rl;
-                        if (k < hi_) { lh[k - 1] = h[u]; ln[k - 1] = ct[u]; }
+                        if (k < hi_) { lh[k - 1] = h[u]; ln[k - 1] = ct[u]; l3[k - 1] = (int32_t)ct[u]; }
                     }
                     WSYNC();
                     lo_ += SU * 16;
@@ -973,6 +979,7 @@ extern "C" __global__ void __launch_bounds__(64, VGX_QUAD_WAVES) vgx_quad_kernel
                 // infectPopRate[pi]: tE * infectious over the occupied haplotypes, in haplotype order (pyx:519-528)
                 const int n = act ? s_nocc[pi] : 0;
                 const int64_t *ln = lcnt + (int64_t)pi * cap;
+                const int32_t *l3 = lcnt32 + (int64_t)pi * cap;
                 const int maxn = rows_max(n);
                 double acc = 0.0;
                 if (maxn <= 64) {
@@ -991,7 +998,7 @@ extern "C" __global__ void __launch_bounds__(64, VGX_QUAD_WAVES) vgx_quad_kernel
                     for (int c = 0; c < 4; ++c)
                         if (c < nch) acc = row_sum16(c * 16 + rl < n ? tE * (double)cn4[c] : 0.0, acc);
                 } else {
-                    acc = q_long_sum(ln, n, maxn, tE);
+                    acc = q_long_sum(l3, n, maxn, tE);
                 }
                 if (act && rl == 0) { s_bc[pi] = bC; s_inf[pi] = acc; }
                 WSYNC();
@@ -1071,6 +1078,7 @@ extern "C" __global__ void __launch_bounds__(64, VGX_QUAD_WAVES) vgx_quad_kernel
                                 lhap[(int64_t)pn * cap + k] = r.i_hap[(int64_t)pn * r.i_cap + k];
                                 lcls[(int64_t)pn * cap + k] = r.i_cls[(int64_t)pn * r.i_cap + k];
                                 lcnt[(int64_t)pn * cap + k] = ct;
+                                lcnt32[(int64_t)pn * cap + k] = (int32_t)ct;
                             }
                         }
                         tsum += rowget_i64(row_iscan(ct), 15);
@@ -1142,6 +1150,15 @@ extern "C" __global__ void __launch_bounds__(64, VGX_QUAD_WAVES) vgx_quad_kernel
             sc->fa_n = 0;
         }
     }
+}
+
+// The 4-byte copy of the counts after another kernel changed the lists (the copy is kept by vgx_quad_kernel only).
+extern "C" __global__ void __launch_bounds__(256) vgx_quad_counts32_kernel(const int64_t *c64, int32_t *c32, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) c32[i] = (int32_t)c64[i];
+}
+extern "C" __attribute__((visibility("hidden"))) hipError_t vgxi_launch_counts32(const int64_t *c64, int32_t *c32, int64_t n, hipStream_t stream) {
+    hipLaunchKernelGGL(vgx_quad_counts32_kernel, dim3(4096), dim3(256), 0, stream, c64, c32, n);
+    return hipGetLastError();
 }
 
 // ---- host-side launchers ----
