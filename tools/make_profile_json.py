@@ -40,7 +40,7 @@ direct = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE, rou
 for leg, kernel, cmd, cfg in (
         ("headline", "vgx_quad_kernel", "python3 bench.py --no-cpu-baseline --no-tau --no-extra --steps 3 --warmup 1",
          {"replicates_per_gpu": 16384, "events_per_replicate": 100000, "trajectory_points": 1001}),
-        ("spread_occupancy", "vgx_quad_kernel", "python3 bench.py --only spread_occupancy",
+        ("spread_occupancy", "vgx_quad_long_kernel", "python3 bench.py --only spread_occupancy",
          {"replicates_per_gpu": 8192, "events_per_replicate": 2500, "occupied": 4096, "mode": "exact"}),
         ("spread_occupancy_fast", "vgx_direct_fast_kernel_p64s1", "python3 bench.py --only spread_occupancy_fast",
          {"replicates_per_gpu": 4096, "events_per_replicate": 20000, "occupied": 4096, "mode": "fast"})):

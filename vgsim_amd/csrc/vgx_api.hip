@@ -25,7 +25,7 @@ extern "C" int64_t vgxi_tau_queue_shards(int64_t H, int64_t P);
 extern "C" int64_t vgxi_tau_queue_shard_max(int64_t H);
 extern "C" hipError_t vgxi_tau_sieve(const VgxTauArgs *a, hipStream_t s);
 extern "C" hipError_t vgxi_launch_lanes(const VgxDirectArgs *a, const VgxLaneWs *w, hipStream_t stream);
-extern "C" hipError_t vgxi_launch_quad(const VgxDirectArgs *a, const double *cd, double *effMig, double *maxEBM, int32_t *has_mig,
+extern "C" hipError_t vgxi_launch_quad(const VgxDirectArgs *a, const double *cd, double *effMig, double *maxEBM, int32_t *has_mig, int long_lists,
                                        hipStream_t stream);
 extern "C" size_t vgxi_direct_lds_bytes(int P, int S, int C, int CB);
 extern "C" hipError_t vgxi_launch_counts32(const int64_t *c64, int32_t *c32, int64_t n, hipStream_t stream);
@@ -64,6 +64,7 @@ struct vgx_engine {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::string err;
     bool have_params = false, have_state = false, dev_state_valid = false;
+    int64_t start_max_nocc = 0;    // longest occupancy list of the state last uploaded
     bool counts32_valid = false;   // r_lcnt32 mirrors r_lcnt (vgx_quad.hip keeps it; other kernels do not)
     int C = 0, CB = 0;
     // host copies of what the host needs again
@@ -555,6 +556,7 @@ static int init_device_state(vgx_engine *e, int64_t traj_points) {
     size_t free_b = 0, total_b = 0;
     HIPCHECK(e, hipMemGetInfo(&free_b, &total_b));
     int64_t need = std::max<int64_t>(std::max(s_cap, i_cap), 1);
+    e->start_max_nocc = s_cap;
     int64_t budget = (int64_t)((double)(free_b + e->r_lhap.bytes + e->r_lcls.bytes + e->r_lcnt.bytes) * 0.45 / (double)(R * P * 20));
     int64_t cap = std::min<int64_t>(H, std::max<int64_t>(budget, 64));
     cap = std::max(cap, std::min<int64_t>(H, need + 64));
@@ -806,7 +808,7 @@ static int direct_core(vgx_engine *e, int64_t iterations, int64_t sample_size, f
     HIPCHECK(e, hipEventRecord(e->ev0, e->stream));
     if (use_lanes) HIPCHECK(e, vgxi_launch_lanes(&a, &ws, e->stream));
     else if (use_quad) HIPCHECK(e, vgxi_launch_quad(&a, (const double *)e->s_cd.p, (double *)e->r_qeff.p, (double *)e->r_qmebm.p,
-                                                    (int32_t *)e->r_qflag.p, e->stream));
+                                                    (int32_t *)e->r_qflag.p, e->start_max_nocc > 64 ? 1 : 0, e->stream));
     else HIPCHECK(e, vgxi_launch_direct(&a, lds, e->stream));
     HIPCHECK(e, hipEventRecord(e->ev1, e->stream));
     HIPCHECK(e, hipStreamSynchronize(e->stream));

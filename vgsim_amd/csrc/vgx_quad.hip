@@ -156,9 +156,9 @@ static __device__ __forceinline__ void row_scan64(double w0, double w1, double w
     QSTEP4(0) QSTEP4(1) QSTEP4(2) QSTEP4(3) QSTEP4(4) QSTEP4(5) QSTEP4(6) QSTEP4(7) QSTEP4(8) QSTEP4(9) QSTEP4(10) QSTEP4(11)
     QSTEP4(12) QSTEP4(13) QSTEP4(14) QSTEP4(15)
 }
-#ifndef VGX_QT
-#define VGX_QT 5      // tiles of 64 four-byte counts a row keeps in flight ahead of its summation chain
-#endif
+// QT = tiles of 64 four-byte counts a row keeps in flight ahead of its summation chain: 3 in vgx_quad_kernel, 5 in
+// vgx_quad_long_kernel (start states with lists longer than one tile).  Measured: the deeper look-ahead gains 4 % on long
+// lists and costs 5 % on short ones (registers of the whole kernel).
 struct QTile { int c0, c1, c2, c3; };
 static __device__ __forceinline__ QTile tile_load(const int32_t *l3, int t, int rl) {   // entries 64t + 4rl .. + 3 of the 4-byte counts
     const int4 a = *(const int4 *)(l3 + (int64_t)t * 64 + 4 * rl);
@@ -170,6 +170,7 @@ static __device__ __forceinline__ QTile tile_load(const int32_t *l3, int t, int 
 struct QSel { int k_hit, hap_hit, err; double pre_hit, w_hit; int64_t cnt_hit; };
 // The haplotype choice over lists longer than 64 entries (inlined: an out-of-line call measured slower in both regimes).
 // Called with all lanes active.
+template <int QT>
 static __device__ __forceinline__ void q_long_select(const int32_t *ln, const int32_t *lh, int n_sel, int maxn, double tE,
                                                                double r2, bool evn, int H, QSel &o) {
     const int rl = threadIdx.x & 15;
@@ -177,7 +178,6 @@ static __device__ __forceinline__ void q_long_select(const int32_t *ln, const in
     // long lists: the running sum advances one tile of 64 entries per step; the tile in which it first reaches r is
     // then scanned entry by entry — same additions, same order.  Loads run QT tiles ahead (unconditional: a row
     // that is through, or has its hit, re-reads its tile 0; every list is followed by 64 entries of padding).
-    enum { QT = VGX_QT };
     QTile buf[QT];
     double carry = 0.0, carry_hit = 0.0;
     int t_hit = -1;
@@ -232,10 +232,10 @@ static __device__ __forceinline__ void q_long_select(const int32_t *ln, const in
 }
 
 // infectPopRate over a list longer than 64 entries (pyx:519-528)
+template <int QT>
 static __device__ __forceinline__ double q_long_sum(const int32_t *ln, int n, int maxn, double tE) {
     const int rl = threadIdx.x & 15;
     double acc = 0.0;
-    enum { QT = VGX_QT };
     QTile buf[QT];
     const int nt = (n + 63) >> 6, maxt = (maxn + 63) >> 6;
 #pragma unroll
@@ -285,7 +285,8 @@ extern "C" __global__ void __launch_bounds__(64) vgx_quad_prep_kernel(VgxDevPara
     if (threadIdx.x == 0) *has_mig = any != 0ull ? 1 : 0;
 }
 
-extern "C" __global__ void __launch_bounds__(64, VGX_QUAD_WAVES) vgx_quad_kernel(VgxDirectArgs a, QArgs qa) {
+template <int QT>
+static __device__ __forceinline__ void quad_body(const VgxDirectArgs &a, const QArgs &qa) {
     const int lane = threadIdx.x, row = lane >> 4, rl = lane & 15;
     const VgxDevParams &p = a.p;
     const VgxDevRep &r = a.r;
@@ -577,7 +578,7 @@ extern "C" __global__ void __launch_bounds__(64, VGX_QUAD_WAVES) vgx_quad_kernel
                 }
             } else {
                 QSel sel;
-                q_long_select(l3, lh, n_sel, maxn, tE, r2, evn, H, sel);
+                q_long_select<QT>(l3, lh, n_sel, maxn, tE, r2, evn, H, sel);
                 k_hit = sel.k_hit; pre_hit = sel.pre_hit; w_hit = sel.w_hit; hap_hit = sel.hap_hit; cnt_hit = sel.cnt_hit;
                 if (sel.err) err = sel.err;
             }
@@ -998,7 +999,7 @@ extern "C" __global__ void __launch_bounds__(64, VGX_QUAD_WAVES) vgx_quad_kernel
                     for (int c = 0; c < 4; ++c)
                         if (c < nch) acc = row_sum16(c * 16 + rl < n ? tE * (double)cn4[c] : 0.0, acc);
                 } else {
-                    acc = q_long_sum(l3, n, maxn, tE);
+                    acc = q_long_sum<QT>(l3, n, maxn, tE);
                 }
                 if (act && rl == 0) { s_bc[pi] = bC; s_inf[pi] = acc; }
                 WSYNC();
@@ -1152,6 +1153,9 @@ extern "C" __global__ void __launch_bounds__(64, VGX_QUAD_WAVES) vgx_quad_kernel
     }
 }
 
+extern "C" __global__ void __launch_bounds__(64, VGX_QUAD_WAVES) vgx_quad_kernel(VgxDirectArgs a, QArgs qa) { quad_body<3>(a, qa); }
+extern "C" __global__ void __launch_bounds__(64, VGX_QUAD_WAVES) vgx_quad_long_kernel(VgxDirectArgs a, QArgs qa) { quad_body<5>(a, qa); }
+
 // The 4-byte copy of the counts after another kernel changed the lists (the copy is kept by vgx_quad_kernel only).
 extern "C" __global__ void __launch_bounds__(256) vgx_quad_counts32_kernel(const int64_t *c64, int32_t *c32, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) c32[i] = (int32_t)c64[i];
@@ -1164,13 +1168,14 @@ extern "C" __attribute__((visibility("hidden"))) hipError_t vgxi_launch_counts32
 // ---- host-side launchers ----
 extern "C" __attribute__((visibility("hidden"))) hipError_t vgxi_launch_quad(const VgxDirectArgs *a, const double *cd,
                                                                             double *effMig, double *maxEBM, int32_t *has_mig,
-                                                                            hipStream_t stream) {
+                                                                            int long_lists, hipStream_t stream) {
     hipLaunchKernelGGL(vgx_quad_prep_kernel, dim3(1), dim3(64), 0, stream, a->p, cd, effMig, maxEBM, has_mig);
     hipError_t err = hipGetLastError();
     if (err != hipSuccess) return err;
     QArgs qa;
     qa.effMig = effMig; qa.maxEBM = maxEBM; qa.has_mig = has_mig;
     const unsigned grid = (unsigned)((a->n_replicates + 3) / 4);
-    hipLaunchKernelGGL(vgx_quad_kernel, dim3(grid), dim3(64), Q_LDS_BYTES, stream, *a, qa);
+    if (long_lists) hipLaunchKernelGGL(vgx_quad_long_kernel, dim3(grid), dim3(64), Q_LDS_BYTES, stream, *a, qa);
+    else hipLaunchKernelGGL(vgx_quad_kernel, dim3(grid), dim3(64), Q_LDS_BYTES, stream, *a, qa);
     return hipGetLastError();
 }
