@@ -363,8 +363,8 @@ def tau_leg(device, steps=20, per_cell=3, seed=2020):
                     "vgx_simulate_tau call incl. its host-side preparation of the 2^28-compartment state)"},
            "roofline": {"bound": "hbm", "achieved": fused / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": fused / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
-                        "note": "all step kernels together (prep, colsum, drift, sieve, {draw, scatter, suspect, decide} x tries, "
-                                "commit of the accepted try); algorithmic bytes = 16*P*H per step (read+write infectious once, "
+                        "note": "all step kernels together (prep, colsum, two drift passes, sieve, {scan, events, arrivals, verdict, decide} x tries, "
+                                "apply of the accepted try's list of moves); algorithmic bytes = 16*P*H per step (read+write infectious once, "
                                 "one try); traffic = PMC bytes per step (about four tries of the reference's halving loop per step)"}}
     eng.close()
     return out
