@@ -256,7 +256,7 @@ def test_halving_sieve_leaves_the_accepted_steps_untouched():
         assert getattr(a, k) == getattr(b, k), k
 
 
-@pytest.mark.parametrize("case", ["sparse_large", "tiny_full", "large_compartments", "one_mutant_rescues"])
+@pytest.mark.parametrize("case", ["sparse_large", "tiny_full", "large_compartments", "one_mutant_rescues", "small_next_to_large"])
 def test_sparse_try_equals_the_dense_passes(case):
     """A try of the halving loop keeps its deltas as a list of moves and checks the bounds of GenerateEvents_tau
     (pyx:2522-2528) where the deltas are drawn (own deltas at once, compartments found below zero against the mutants of
@@ -265,8 +265,9 @@ def test_sparse_try_equals_the_dense_passes(case):
     over all compartments.  Same draws, same decisions, hence bit for bit the same accepted steps in all three — on a large
     sparse state (thousands of rejected tries' worth of failing compartments), on a tiny population that sits at its upper
     bound (arrivals push compartments over ``sizes``: the sparse mode hands those tries to the dense one), with compartments
-    that draw every channel on its own (vgx_tau_draw_big_kernel), and with a mutation rate so high that compartments below
-    zero on their own are regularly rescued by arriving mutants."""
+    that draw every channel on its own (vgx_tau_draw_big_kernel), with a mutation rate so high that compartments below
+    zero on their own are regularly rescued by arriving mutants, and with single hosts next to compartments of 20 000 (their
+    rescue depends on neighbours that are drawn channel by channel: the hash table of vgx_tau_arrivals_kernel decides)."""
     import ctypes as C
     from vgsim_amd import Simulator, _capi
 
@@ -282,6 +283,11 @@ def test_sparse_try_equals_the_dense_passes(case):
                 s.set_transmission_rate(3.0); s.set_recovery_rate(1.0); s.set_sampling_rate(0.2); s.set_mutation_rate(0.02)
                 s.set_total_migration_probability(0.05); s.set_population_size(10 ** 7)
                 fill, steps = 20000, 30
+            elif case == "small_next_to_large":
+                s = Simulator(number_of_sites=6, populations_number=3, seed=17)
+                s.set_transmission_rate(5.2); s.set_recovery_rate(4.5); s.set_sampling_rate(0.5); s.set_mutation_rate(0.002)
+                s.set_total_migration_probability(0.02); s.set_population_size(10 ** 9)
+                fill, steps = 20000, 12
             elif case == "one_mutant_rescues":
                 s = Simulator(number_of_sites=5, populations_number=4, seed=13)
                 s.set_transmission_rate(0.5); s.set_recovery_rate(1.5); s.set_sampling_rate(0.5); s.set_mutation_rate(1.5)
@@ -294,8 +300,10 @@ def test_sparse_try_equals_the_dense_passes(case):
                 fill, steps = 20, 40          # 16 haplotypes x 20 = 320 of 400 hosts infected: the upper bound bites
         m = s.simulation
         m.infectious[:] = fill
-        m.susceptible[:, 0] -= fill * m.hapNum
-        m.totalInfectious[:] = fill * m.hapNum
+        if case == "small_next_to_large":
+            m.infectious[:, 1::2] = 1          # every other haplotype: one host
+        m.susceptible[:, 0] -= m.infectious.sum(axis=1)
+        m.totalInfectious[:] = m.infectious.sum(axis=1)
         m.totalSusceptible[:] = m.susceptible.sum(axis=1)
         m.globalInfectious = int(m.totalInfectious.sum())
         m.first_simulation = True
