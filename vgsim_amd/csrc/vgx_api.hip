@@ -85,7 +85,7 @@ struct vgx_engine {
         r_evrate, r_evcols, r_locrec, r_loctime, r_lociter, r_farate, r_fakey, r_traj, r_prof, r_qeff, r_qmebm, r_qflag;
     // tau-leaping (dense compartments)
     DevBuf t_I, t_S, t_dChk, t_dApp, t_dSi, t_dTot, t_totInf, t_gI, t_cd, t_lock, t_F, t_eff, t_Aeff, t_Gout, t_dS,
-        t_taubits, t_tau, t_time, t_flags, t_counters, t_cnttry, t_mev, t_mevn, t_mevbase, t_locn, t_mutcum, t_migcdf, t_migIn, t_mutHi, t_colT, t_colTW, t_inc, t_incn, t_sieve, t_sieveskip, t_big, t_bign, t_res, t_susp, t_suspn, t_stkey, t_stval, t_dChkTot, t_q, t_qn, t_hist;
+        t_taubits, t_tau, t_time, t_flags, t_counters, t_cnttry, t_mev, t_mevn, t_mevbase, t_locn, t_mutcum, t_migcdf, t_migIn, t_mutHi, t_colT, t_colTW, t_inc, t_incn, t_sieve, t_sieveskip, t_big, t_bign, t_res, t_susp, t_suspn, t_stkey, t_stval, t_dChkTot, t_q, t_qn, t_hist, t_I8;
     std::vector<int64_t> tau_sieve_skipped;   // [R] tries left out by the sieve in the last tau call
     bool last_was_tau = false;
     int64_t tau_mev_cap = 0;
@@ -992,6 +992,7 @@ extern "C" int vgx_simulate_tau(vgx_engine *e, int64_t iterations, int64_t sampl
     rc |= ensure(e, e->r_loctime, (size_t)(R * VGX_LOC_CAP) * 8);
     rc |= ensure(e, e->t_I, (size_t)(R * P * H) * 4);
     rc |= ensure(e, e->t_S, (size_t)(R * P * S) * 8);
+    rc |= ensure(e, e->t_I8, (size_t)(R * P * H) + 64);
     // mode of the tries: sparse (no dense delta arrays; the default), or dense with the fused checks (reserved[1] = 2), or
     // dense with the bounds check as a pass of its own (reserved[1] = 1); the dense arrays are allocated when first needed
     const bool sparse_default = !(o.reserved[1] == 1 || o.reserved[1] == 2);
@@ -1105,7 +1106,7 @@ extern "C" int vgx_simulate_tau(vgx_engine *e, int64_t iterations, int64_t sampl
     VgxTauArgs a{};
     a.p = e->dp;
     a.R = R;
-    a.I = (int32_t *)e->t_I.p; a.S = (int64_t *)e->t_S.p; a.dChk = (int32_t *)e->t_dChk.p; a.dApp = (int32_t *)e->t_dApp.p;
+    a.I = (int32_t *)e->t_I.p; a.I8 = (uint8_t *)e->t_I8.p; a.S = (int64_t *)e->t_S.p; a.dChk = (int32_t *)e->t_dChk.p; a.dApp = (int32_t *)e->t_dApp.p;
     a.dSi = (int64_t *)e->t_dSi.p; a.dTot = (int64_t *)e->t_dTot.p; a.totInf = (int64_t *)e->t_totInf.p;
     a.gI = (int64_t *)e->t_gI.p; a.cd = (double *)e->t_cd.p; a.lockON = (int32_t *)e->t_lock.p; a.F = (double *)e->t_F.p;
     a.effMig = (double *)e->t_eff.p; a.Aeff = (double *)e->t_Aeff.p; a.Gout = (double *)e->t_Gout.p;

@@ -150,6 +150,7 @@ struct VgxTauArgs {
     VgxDevParams p;
     int64_t R;
     int32_t *I;          // [R][P][H] infectious (tau population sizes are < 2^31: 4 bytes per compartment)
+    uint8_t *I8;         // [R][P][H] min(infectious, 255): rewritten by every step's drift pass, streamed by the scan kernel of its tries
     int64_t *S;          // [R][P][S] susceptible
     int32_t *dChk;       // [R][P][H] infectious deltas as the reference's bounds check books them (pyx:2473)
     int32_t *dApp;       // [R][P][H] infectious deltas as UpdateCompartmentCounts_tau applies them (pyx:2548)

@@ -122,6 +122,11 @@ static __device__ __forceinline__ int tau_mutate(int sites, int hi, int s, int D
     return hi + (DS - AS) * digit4;
 }
 
+// the one-byte copy of four counts (255 = "255 or more": vgx_tau_scan_kernel then reads the count proper)
+static __device__ __forceinline__ uint32_t tau_pack8(int a, int b, int c, int d) {
+    return (uint32_t)min(a, 255) | ((uint32_t)min(b, 255) << 8) | ((uint32_t)min(c, 255) << 16) | ((uint32_t)min(d, 255) << 24);
+}
+
 static __device__ __forceinline__ void atomic_min_pos_double(unsigned long long *addr, double v) {
     // for non-negative doubles the bit patterns order like the values
     atomicMin(addr, (unsigned long long)__double_as_longlong(v));
@@ -366,6 +371,7 @@ extern "C" __global__ void __launch_bounds__(TB) vgx_tau_drift_kernel(VgxTauArgs
         const int cb = useL ? l_bidx[c] : p.c_bidx[c];
         const int st = useL ? l_stype[c] : p.c_stype[c];
         const int64_t Icell = live ? I[hh] : 0;
+        if (live) a.I8[(int64_t)rep * P * H + (int64_t)pn * H + hh] = (uint8_t)(Icell < 255 ? Icell : 255);
         const double Ih = (double)Icell;
         double drift = 0.0;
         // recovery and sampling (pyx:2386-2395), outgoing mutation (pyx:2398-2404: sum_i w_i / sum w == 1)
@@ -539,8 +545,13 @@ extern "C" __global__ void __launch_bounds__(TB) vgx_tau_drift_tiled_kernel(VgxT
     for (int i = threadIdx.x; i < 3 * sites && i < 48; i += TB) l_mutp[i] = a.mutp[i / 3][i % 3];
     const int h0 = blockIdx.x * TS;
     for (int i = threadIdx.x * 4; i < TS; i += TB * 4) {
-        if (TS >= 4) *(int4 *)(tile + i) = *(const int4 *)(I + h0 + i);
-        else for (int j = 0; j < TS; ++j) tile[j] = I[h0 + j];
+        if (TS >= 4) {
+            const int4 v = *(const int4 *)(I + h0 + i);
+            *(int4 *)(tile + i) = v;
+            *(uint32_t *)(a.I8 + rowoff + h0 + i) = tau_pack8(v.x, v.y, v.z, v.w);
+        } else {
+            for (int j = 0; j < TS; ++j) { tile[j] = I[h0 + j]; a.I8[rowoff + h0 + j] = (uint8_t)min(I[h0 + j], 255); }
+        }
     }
     __syncthreads();
     const double F = a.F[(int64_t)rep * P + pn];
@@ -671,7 +682,11 @@ __global__ void __launch_bounds__(TB) vgx_tau_drift_fast_kernel(VgxTauArgs a) {
     for (int i = threadIdx.x; i < CB * S; i += TB) l_base[i] = p.cb_b[i / S] * p.cb_sigma[i] * (double)Sus[i % S];
     if (threadIdx.x < low) l_rate[threadIdx.x] = a.mutp[nh + threadIdx.x][0];   // low site i <-> two-bit group low - 1 - i
     const int h0 = blockIdx.x * TS;
-    for (int i = threadIdx.x * 4; i < TS; i += TB * 4) *(int4 *)(tile + i) = *(const int4 *)(I + h0 + i);
+    for (int i = threadIdx.x * 4; i < TS; i += TB * 4) {
+        const int4 v = *(const int4 *)(I + h0 + i);
+        *(int4 *)(tile + i) = v;
+        *(uint32_t *)(a.I8 + rowoff + h0 + i) = tau_pack8(v.x, v.y, v.z, v.w);   // the one-byte copy vgx_tau_scan_kernel streams
+    }
     __syncthreads();
     const double F = a.F[(int64_t)rep * P + pn];
     __shared__ double s_wu[16];
@@ -1127,18 +1142,18 @@ struct TauTab {
 // (bucket + 1) / 256 <= 1 - lam <= exp(-lam), which the draw kernel tests in single precision with lam rounded up: one
 // Philox block and a handful of instructions for 16 compartments, and the law of the draw is exactly that of inversion
 // with a 60-bit uniform.
-// group of compartment hn of population pn: 1024 consecutive haplotypes form a wave tile, lane L of the wave looks at the
-// haplotypes tile*1024 + 256 k + 4 L + j (k, j = 0..3) and finds their buckets in byte j of word k.
+// group of compartment hn of population pn: 16 consecutive haplotypes (what a lane of the scan kernel looks at); the bucket
+// of haplotype 16 g + 4 k + j is byte j of word k of the group's block.
 static __device__ __forceinline__ uint32_t tau_bucket(const VgxTauArgs &a, int rep, int pn, int hn) {
     const int H = a.p.H;
-    const uint64_t tiles = (uint64_t)((H + 1023) >> 10);
-    const uint64_t gidx = ((uint64_t)pn * tiles + (uint64_t)(hn >> 10)) * 64u + (uint64_t)((hn & 255) >> 2);
+    const uint64_t groups = (uint64_t)((H + 15) >> 4);
+    const uint64_t gidx = (uint64_t)pn * groups + (uint64_t)(hn >> 4);
     const uint32_t key[2] = {(uint32_t)a.seeds[rep] ^ ((uint32_t)a.attempt[rep] * 0x9E3779B9u),
                              (uint32_t)((uint64_t)a.seeds[rep] >> 32) ^ 0x85EBCA6Bu};
     const uint32_t ctr[4] = {(uint32_t)gidx, (uint32_t)(gidx >> 32), (uint32_t)a.step[rep], ((uint32_t)a.retry[rep] << 20) | 0xFFFFFu};
     uint32_t w[4];
     vgx_philox4x32(ctr, key, w);
-    return (w[(hn >> 8) & 3] >> (8 * (hn & 3))) & 255u;
+    return (w[(hn >> 2) & 3] >> (8 * (hn & 3))) & 255u;
 }
 
 // GenerateEvents_tau for one compartment (pn, hn).  All channels out of a compartment are independent Poisson
@@ -1350,13 +1365,15 @@ extern "C" __global__ void __launch_bounds__(TB) vgx_tau_scan_kernel(VgxTauArgs 
     __syncthreads();
     const int L = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int32_t *Irow = a.I + ((int64_t)rep * P + pn) * H;
+    const uint8_t *I8row = a.I8 + ((int64_t)rep * P + pn) * H;   // min(count, 255), written by this step's drift pass
     int32_t *dCrow = a.dChk + ((int64_t)rep * P + pn) * H, *dArow = a.dApp + ((int64_t)rep * P + pn) * H;
     const bool dense = !a.sparse;
     const uint32_t key[2] = {(uint32_t)a.seeds[rep] ^ ((uint32_t)a.attempt[rep] * 0x9E3779B9u),
                              (uint32_t)((uint64_t)a.seeds[rep] >> 32) ^ 0x85EBCA6Bu};
     const uint32_t ctr_step = (uint32_t)a.step[rep], ctr_retry = ((uint32_t)a.retry[rep] << 20) | 0xFFFFFu;   // loop invariants
     const int tiles = (H + 1023) >> 10;
-    const bool vec = (H & 3) == 0;   // rows are 16-byte aligned
+    const uint64_t groups = (uint64_t)((H + 15) >> 4);
+    const bool vec = (H & 15) == 0;   // rows of the one-byte copy are 16-byte aligned
     const int64_t scap = a.q_cap / a.q_shards;
     const int64_t shard = (int64_t)pn * gridDim.x + blockIdx.x;
     unsigned long long *qn = a.q_n + (int64_t)rep * a.q_shards + shard;
@@ -1372,41 +1389,44 @@ extern "C" __global__ void __launch_bounds__(TB) vgx_tau_scan_kernel(VgxTauArgs 
         WSYNC();
         nq = 0;
     };
-    // a lane looks at 16 compartments of a tile of 1024 (four 16-byte loads, each instruction of the wave covers one
-    // contiguous KiB) with the 16 bytes of one Philox block
+    // A lane looks at 16 consecutive compartments of a wave tile of 1024: ONE 16-byte load of the one-byte copy of the counts
+    // (the instruction of the wave covers one contiguous KiB) and the 16 bytes of one Philox block.  Only a lane that meets a
+    // saturated byte (255 hosts or more) reads its counts proper.
     const int wstride = gridDim.x * (TB / 64);
-    int4 nx[4];
-    auto load_tile = [&](int t, int4 *x) {
-        const int base = t << 10;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int h0 = base + 256 * k + 4 * L;
-            if (vec && h0 + 3 < H) x[k] = *(const int4 *)(Irow + h0);
-            else {
-                x[k] = make_int4(0, 0, 0, 0);
-                if (h0 < H) x[k].x = Irow[h0];
-                if (h0 + 1 < H) x[k].y = Irow[h0 + 1];
-                if (h0 + 2 < H) x[k].z = Irow[h0 + 2];
-                if (h0 + 3 < H) x[k].w = Irow[h0 + 3];
-            }
-        }
+    auto load_tile = [&](int t) -> uint4 {
+        const int h0 = (t << 10) + 16 * L;
+        if (vec && h0 + 15 < H) return *(const uint4 *)(I8row + h0);
+        uint32_t x[4] = {0, 0, 0, 0};
+        for (int j = 0; j < 16; ++j)
+            if (h0 + j < H) x[j >> 2] |= (uint32_t)I8row[h0 + j] << (8 * (j & 3));
+        return make_uint4(x[0], x[1], x[2], x[3]);
     };
     const int wt0 = blockIdx.x * (TB / 64) + wave;
-    if (wt0 < tiles) load_tile(wt0, nx);
+    uint4 nx = make_uint4(0, 0, 0, 0);
+    if (wt0 < tiles) nx = load_tile(wt0);
     for (int wt = wt0; wt < tiles; wt += wstride) {
-        const int4 x[4] = {nx[0], nx[1], nx[2], nx[3]};
-        if (wt + wstride < tiles) load_tile(wt + wstride, nx);   // the next tile's loads are in flight while this one is worked on
-        const uint64_t gidx = ((uint64_t)pn * (uint64_t)tiles + (uint64_t)wt) * 64u + (uint64_t)L;
+        const uint4 cur = nx;
+        if (wt + wstride < tiles) nx = load_tile(wt + wstride);   // the next tile's load is in flight while this one is worked on
+        const int hl = (wt << 10) + 16 * L;                       // the lane's first haplotype
+        const uint64_t gidx = (uint64_t)pn * groups + (uint64_t)(hl >> 4);
         const uint32_t ctr[4] = {(uint32_t)gidx, (uint32_t)(gidx >> 32), ctr_step, ctr_retry};
         uint32_t w[4];
         vgx_philox4x32(ctr, key, w);
+        const uint32_t b8[4] = {cur.x, cur.y, cur.z, cur.w};
+        // a byte is 255 iff its low seven bits + 1 carry into its top bit and that bit is set
+        auto has255 = [](uint32_t x) { return (((x & 0x7F7F7F7Fu) + 0x01010101u) & x & 0x80808080u) != 0u; };
+        const bool sat = has255(cur.x) || has255(cur.y) || has255(cur.z) || has255(cur.w);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const int h0 = (wt << 10) + 256 * k + 4 * L;
-            const int Iv[4] = {x[k].x, x[k].y, x[k].z, x[k].w};
+            const int h0 = hl + 4 * k;
+            int Iv[4] = {(int)(b8[k] & 255u), (int)((b8[k] >> 8) & 255u), (int)((b8[k] >> 16) & 255u), (int)(b8[k] >> 24)};
+            if (sat) {   // some count of this lane does not fit a byte: the four counts proper
+                for (int j = 0; j < 4; ++j)
+                    if (Iv[j] == 255 && h0 + j < H) Iv[j] = Irow[h0 + j];
+            }
             int cl[4] = {0, 0, 0, 0};
             if (C != 1) {
-                if (vec && h0 + 3 < H) { const int4 cc = *(const int4 *)(p.cls + h0); cl[0] = cc.x; cl[1] = cc.y; cl[2] = cc.z; cl[3] = cc.w; }
+                if ((H & 3) == 0 && h0 + 3 < H) { const int4 cc = *(const int4 *)(p.cls + h0); cl[0] = cc.x; cl[1] = cc.y; cl[2] = cc.z; cl[3] = cc.w; }
                 else for (int j = 0; j < 4; ++j) if (h0 + j < H) cl[j] = p.cls[h0 + j];
             }
             int qm = 0;
@@ -1424,12 +1444,12 @@ extern "C" __global__ void __launch_bounds__(TB) vgx_tau_scan_kernel(VgxTauArgs 
                     const double lam = rate * (double)Iv[j] * tau * (1.0 + 1e-9);
                     qd = Iv[j] > 0 && (double)(b + 1u) > 256.0 - 256.0 * lam;
                 }
-                if (qd) qm |= 1 << j;
+                if (qd && h0 + j < H) qm |= 1 << j;
             }
             if (dense && h0 < H) {
                 // zero deltas of the compartments that draw nothing here (the queued ones are written by the events kernel, large
                 // ones by vgx_tau_draw_big_kernel): every entry of both arrays is written in every try
-                if (qm == 0 && vec && h0 + 3 < H) {
+                if (qm == 0 && (H & 3) == 0 && h0 + 3 < H) {
                     *(int4 *)(dCrow + h0) = make_int4(0, 0, 0, 0);
                     *(int4 *)(dArow + h0) = make_int4(0, 0, 0, 0);
                 } else {
@@ -1453,6 +1473,162 @@ extern "C" __global__ void __launch_bounds__(TB) vgx_tau_scan_kernel(VgxTauArgs 
         }
     }
     if (nq > 0) flush();
+}
+
+// The scan for the usual shapes: at most 16 rate classes (thresholds tabulated in LDS), haplotype count a multiple of 16.
+// C1 = one rate class, DENSE = the dense delta arrays are written (validation modes).  Same decisions as the general kernel:
+// a compartment of X < 255 hosts is queued iff bucket >= T[class][X], T = the smallest bucket the single-precision test of the
+// general kernel queues (X = 0: never); counts of 255 or more take that test itself on the count proper.  Queued compartments
+// are collected as one bit per compartment and written with one wave-wide prefix sum per half tile.
+#define VGX_QWF 768          // stage of a wavefront: a half tile adds at most 512 entries, moved out from 256 on
+template <bool C1, bool DENSE>
+__global__ void __launch_bounds__(TB) vgx_tau_scan_fast_kernel(VgxTauArgs a) {
+    const int rep = blockIdx.z, pn = blockIdx.y;
+    if (!a.active[rep] || a.accepted[rep]) return;
+    const VgxDevParams &p = a.p;
+    const int P = p.P, S = p.S, C = p.C, CB = p.CB, H = p.H;
+    __shared__ float s_rt[16];
+    __shared__ double s_rtr[16], s_rmig[16];
+    __shared__ uint16_t s_thr[C1 ? 256 : 16 * 256];
+    __shared__ int64_t q[TB / 64][VGX_QWF];
+    const double tau = a.tau[rep];
+    const double F = a.F[(int64_t)rep * P + pn];
+    const int64_t *Sus = a.S + (int64_t)rep * P * S + (int64_t)pn * S;
+    for (int cb = threadIdx.x; cb < CB && cb < 16; cb += TB) {
+        double r = 0.0;
+        for (int sn = 0; sn < S; ++sn) r += p.cb_b[cb] * p.cb_sigma[cb * S + sn] * (double)Sus[sn] * F;
+        s_rtr[cb] = r;
+        s_rmig[cb] = a.has_mig ? a.Gout[((int64_t)rep * P + pn) * CB + cb] * p.cb_b[cb] * p.mig[(int64_t)pn * P + pn] : 0.0;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < C; i += TB) {   // as in vgx_tau_scan_kernel
+        const int cb = p.c_bidx[i];
+        const double r1 = s_rmig[cb] + p.c_d[i] + p.c_s[i] * p.sampMult[pn] + (a.mut_uniform ? a.mut_total : p.c_tm[i]) + s_rtr[cb];
+        s_rt[i] = (float)(r1 * tau * (1.0 + 1.0 / 1048576.0)) * (1.0f + 1.0f / 1048576.0f);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < C * 256; i += TB) {
+        const int X = i & 255;
+        const float thr = fmaf(-256.0f, s_rt[i >> 8] * (float)X, 255.999f);
+        // queued iff (float)(bucket + 1) > thr  <=>  bucket >= floor(thr) (thr >= 0), always (thr < 0), never (X = 0)
+        s_thr[i] = X == 0 ? (uint16_t)256 : (uint16_t)(thr < 0.0f ? 0 : (int)floorf(thr));
+    }
+    __syncthreads();
+    const int L = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int32_t *Irow = a.I + ((int64_t)rep * P + pn) * H;
+    const uint8_t *I8row = a.I8 + ((int64_t)rep * P + pn) * H;
+    int32_t *dCrow = a.dChk + ((int64_t)rep * P + pn) * H, *dArow = a.dApp + ((int64_t)rep * P + pn) * H;
+    const uint32_t key[2] = {(uint32_t)a.seeds[rep] ^ ((uint32_t)a.attempt[rep] * 0x9E3779B9u),
+                             (uint32_t)((uint64_t)a.seeds[rep] >> 32) ^ 0x85EBCA6Bu};
+    const uint32_t ctr_step = (uint32_t)a.step[rep], ctr_retry = ((uint32_t)a.retry[rep] << 20) | 0xFFFFFu;
+    const int tiles = (H + 1023) >> 10;
+    const uint64_t groups = (uint64_t)(H >> 4);
+    const int64_t scap = a.q_cap / a.q_shards;
+    const int64_t shard = (int64_t)pn * gridDim.x + blockIdx.x;
+    unsigned long long *qn = a.q_n + (int64_t)rep * a.q_shards + shard;
+    int64_t *qdst = a.q + (int64_t)rep * a.q_cap + shard * scap;
+    int nq = 0;                      // wave-uniform: entries in this wavefront's stage
+    const int wstride = gridDim.x * (TB / 64);
+    const int wt0 = blockIdx.x * (TB / 64) + wave;
+    uint4 nx = make_uint4(0, 0, 0, 0);
+    if (wt0 < tiles && (wt0 << 10) + 16 * L < H) nx = *(const uint4 *)(I8row + (wt0 << 10) + 16 * L);
+    for (int wt = wt0; wt < tiles; wt += wstride) {
+        const uint4 cur = nx;
+        {
+            const int hn = ((wt + wstride) << 10) + 16 * L;
+            if (wt + wstride < tiles && hn < H) nx = *(const uint4 *)(I8row + hn);   // in flight while this tile is worked on
+        }
+        const int hl = (wt << 10) + 16 * L;                       // the lane's first haplotype (a lane beyond H sees zeros)
+        const uint64_t gidx = (uint64_t)pn * groups + (uint64_t)(hl >> 4);
+        const uint32_t ctr[4] = {(uint32_t)gidx, (uint32_t)(gidx >> 32), ctr_step, ctr_retry};
+        uint32_t w[4];
+        vgx_philox4x32(ctr, key, w);
+        const uint32_t b8[4] = {cur.x, cur.y, cur.z, cur.w};
+        auto has255 = [](uint32_t x) { return (((x & 0x7F7F7F7Fu) + 0x01010101u) & x & 0x80808080u) != 0u; };
+        const bool sat = has255(cur.x) || has255(cur.y) || has255(cur.z) || has255(cur.w);
+        uint32_t qbits = 0;          // bit 4k + j: compartment hl + 4k + j is queued
+        int4 clv[4];
+        if (!C1 && hl < H) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) clv[k] = *(const int4 *)(p.cls + hl + 4 * k);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int cl[4] = {C1 ? 0 : clv[k].x, C1 ? 0 : clv[k].y, C1 ? 0 : clv[k].z, C1 ? 0 : clv[k].w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t X = (b8[k] >> (8 * j)) & 255u, b = (w[k] >> (8 * j)) & 255u;
+                const uint32_t T = s_thr[(C1 ? 0 : (cl[j] << 8)) + X];
+                if (b >= T) qbits |= 1u << (4 * k + j);
+            }
+        }
+        if (sat && hl < H) {   // counts of 255 or more: the general kernel's test on the count proper
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                for (int j = 0; j < 4; ++j)
+                    if (((b8[k] >> (8 * j)) & 255u) == 255u) {
+                        const int c = C1 ? 0 : (j == 0 ? clv[k].x : j == 1 ? clv[k].y : j == 2 ? clv[k].z : clv[k].w);
+                        const float thr = fmaf(-256.0f, s_rt[c] * (float)Irow[hl + 4 * k + j], 255.999f);
+                        const uint32_t b = (w[k] >> (8 * j)) & 255u;
+                        if ((float)(b + 1u) > thr) qbits |= 1u << (4 * k + j); else qbits &= ~(1u << (4 * k + j));
+                    }
+        }
+        if (DENSE && hl < H) {
+            // zero deltas of the compartments that draw nothing here: every entry of both arrays is written in every try
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t qm = (qbits >> (4 * k)) & 15u;
+                if (qm == 0) {
+                    *(int4 *)(dCrow + hl + 4 * k) = make_int4(0, 0, 0, 0);
+                    *(int4 *)(dArow + hl + 4 * k) = make_int4(0, 0, 0, 0);
+                } else {
+                    for (int j = 0; j < 4; ++j)
+                        if (!((qm >> j) & 1u)) { dCrow[hl + 4 * k + j] = 0; dArow[hl + 4 * k + j] = 0; }
+                }
+            }
+        }
+        // the queued compartments of the tile, half a tile at a time: a wave-wide prefix sum of the lanes' counts, then
+        // every lane writes its own entries
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const uint32_t hb = (qbits >> (8 * half)) & 255u;
+            if (!__any(hb != 0)) continue;
+            const int cnt = __popc(hb);
+            int pre = cnt;   // inclusive prefix over the lanes
+            for (int o = 1; o < 64; o <<= 1) {
+                const int v = __shfl_up(pre, o);
+                if (L >= o) pre += v;
+            }
+            const int total = __builtin_amdgcn_readlane(pre, 63);
+            int slot = nq + pre - cnt;
+            uint32_t m = hb;
+            while (m) {
+                const int i = __ffs((int)m) - 1;
+                m &= m - 1;
+                const int cell = 8 * half + i;
+                q[wave][slot++] = (int64_t)(hl + cell) | ((int64_t)((w[cell >> 2] >> (8 * (cell & 3))) & 255u) << 32);
+            }
+            nq += total;
+            if (nq >= VGX_QWF - 512) {
+                WSYNC();
+                unsigned long long base = 0;
+                if (L == 0) base = atomicAdd(qn, (unsigned long long)nq);
+                base = (unsigned long long)bcast_i64((int64_t)base, 0);
+                for (int i = L; i < nq; i += 64)
+                    if ((int64_t)(base + i) < scap) qdst[base + i] = q[wave][i];   // a full shard is detected by the events kernel
+                WSYNC();
+                nq = 0;
+            }
+        }
+    }
+    if (nq > 0) {
+        WSYNC();
+        unsigned long long base = 0;
+        if (L == 0) base = atomicAdd(qn, (unsigned long long)nq);
+        base = (unsigned long long)bcast_i64((int64_t)base, 0);
+        for (int i = L; i < nq; i += 64)
+            if ((int64_t)(base + i) < scap) qdst[base + i] = q[wave][i];
+    }
 }
 
 // grid = (tau_draw_gx(H), P, R), one wavefront per block; dSi / dTot / dChkTot are zero on entry
@@ -1549,17 +1725,24 @@ extern "C" __global__ void __launch_bounds__(EB) vgx_tau_events_kernel(VgxTauArg
     // `ok` is read and cleared at device scope: the XCDs' L2 caches are not coherent with each other for plain accesses, a
     // wavefront on another XCD would never see the flag.  The load is issued one round ahead of its use.
     int okv = __hip_atomic_load(&a.ok[rep], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // the queue entry is loaded two rounds ahead of its use, the compartment's count (a dependent, scattered load) one round
+    int64_t qe_c = L < n ? qsrc[L] : 0, qe_n = L + EB < n ? qsrc[L + EB] : 0;
+    int32_t I_c = L < n ? Irow[(int)(qe_c & 0xFFFFFFFFll)] : 0;
     for (int64_t k0 = 0; k0 < n; k0 += EB) {
         if (okv == 0) break;   // the try is already lost: nothing of it counts (vgx_tau_decide_kernel)
         okv = __hip_atomic_load(&a.ok[rep], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const int64_t k = k0 + L;
+        const int64_t qe = qe_c;
+        const int32_t I_now = I_c;
+        qe_c = qe_n;
+        I_c = k + EB < n ? Irow[(int)(qe_c & 0xFFFFFFFFll)] : 0;
+        qe_n = k + 2 * EB < n ? qsrc[k + 2 * EB] : 0;
         int h = 0;
         int64_t v = 0;
         bool below = false;   // below zero on its own (sparse mode): looked at by the whole wavefront, see below
         if (k < n) {
-            const int64_t qe = qsrc[k];
             h = (int)(qe & 0xFFFFFFFFll);
-            const int64_t Ih = (int64_t)Irow[h];
+            const int64_t Ih = (int64_t)I_now;
             int64_t oc = 0, oa = 0;
             const int r = tau_cell_events<false>(a, T, rep, pn, h, tau, Ih, (uint32_t)(qe >> 32), oc, oa, cnt, stage, sS, -1);
             if (r == 2) {   // many events: one wavefront draws its channels one by one (vgx_tau_draw_big_kernel)
@@ -1603,8 +1786,12 @@ extern "C" __global__ void __launch_bounds__(EB) vgx_tau_events_kernel(VgxTauArg
                 else if (v + arr < 0) atomicAnd(&a.ok[rep], 0);
             }
         }
-        tau_stage_flush(a, stage, rep);
+        // the staged moves go out when the next round might not fit (a round adds at most one own change per lane plus its
+        // mutants and migrants; what does not fit goes to the list entry by entry)
+        WSYNC();
+        if (stage->n > VGX_WSTAGE - 96 || k0 + EB >= n) tau_stage_flush(a, stage, rep);
     }
+    tau_stage_flush(a, stage, rep);   // (a wavefront that left the loop early)
     if (threadIdx.x == 0) *qn = 0;   // the shard is empty for the next try
     unsigned long long *ct = (unsigned long long *)&a.cnt_try[(int64_t)rep * 8];
     for (int i = 0; i < 12; ++i) {   // wave-level sums, then one global atomic per tally
@@ -2123,7 +2310,15 @@ extern "C" __attribute__((visibility("hidden"))) hipError_t vgxi_tau_draw(const 
     hipError_t err = hipFuncSetAttribute((const void *)vgx_tau_events_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds ? lds : 16));
     if (err != hipSuccess) return err;
     const dim3 grid(tau_draw_gx(a->p.H), (unsigned)a->p.P, (unsigned)a->R);
-    hipLaunchKernelGGL(vgx_tau_scan_kernel, grid, dim3(TB), 0, s, *a);
+    if (a->p.C <= 16 && a->p.CB <= 16 && (a->p.H & 15) == 0) {   // the usual shapes: thresholds tabulated
+        const bool c1 = a->p.C == 1, dn = !a->sparse;
+        if (c1 && !dn) hipLaunchKernelGGL((vgx_tau_scan_fast_kernel<true, false>), grid, dim3(TB), 0, s, *a);
+        else if (c1) hipLaunchKernelGGL((vgx_tau_scan_fast_kernel<true, true>), grid, dim3(TB), 0, s, *a);
+        else if (!dn) hipLaunchKernelGGL((vgx_tau_scan_fast_kernel<false, false>), grid, dim3(TB), 0, s, *a);
+        else hipLaunchKernelGGL((vgx_tau_scan_fast_kernel<false, true>), grid, dim3(TB), 0, s, *a);
+    } else {
+        hipLaunchKernelGGL(vgx_tau_scan_kernel, grid, dim3(TB), 0, s, *a);
+    }
     hipLaunchKernelGGL(vgx_tau_events_kernel, grid, dim3(EB), lds ? lds : 16, s, *a);
     return hipGetLastError();
 }
