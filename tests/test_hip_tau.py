@@ -256,7 +256,7 @@ def test_halving_sieve_leaves_the_accepted_steps_untouched():
         assert getattr(a, k) == getattr(b, k), k
 
 
-@pytest.mark.parametrize("case", ["sparse_large", "tiny_full", "large_compartments", "one_mutant_rescues", "small_next_to_large"])
+@pytest.mark.parametrize("case", ["sparse_large", "tiny_full", "large_compartments", "one_mutant_rescues", "small_next_to_large", "classes_short_rows"])
 def test_sparse_try_equals_the_dense_passes(case):
     """A try of the halving loop keeps its deltas as a list of moves and checks the bounds of GenerateEvents_tau
     (pyx:2522-2528) where the deltas are drawn (own deltas at once, compartments found below zero against the mutants of
@@ -288,6 +288,15 @@ def test_sparse_try_equals_the_dense_passes(case):
                 s.set_transmission_rate(5.2); s.set_recovery_rate(4.5); s.set_sampling_rate(0.5); s.set_mutation_rate(0.002)
                 s.set_total_migration_probability(0.02); s.set_population_size(10 ** 9)
                 fill, steps = 20000, 12
+            elif case == "classes_short_rows":
+                # several rate classes, rows shorter than one wave tile of the scan kernel (lanes beyond the row), two groups
+                s = Simulator(number_of_sites=3, populations_number=5, number_of_susceptible_groups=2, seed=21)
+                s.set_transmission_rate(2.5); s.set_recovery_rate(0.8); s.set_sampling_rate(0.2); s.set_mutation_rate(0.2)
+                s.set_transmission_rate(4.0, haplotype=5); s.set_recovery_rate(0.3, haplotype=17); s.set_transmission_rate(1.0, haplotype=40)
+                s.set_susceptibility(0.4, susceptibility_type=1); s.set_immunity_transition(0.05, source=1, target=0)
+                s.set_susceptibility_type(1)
+                s.set_total_migration_probability(0.1); s.set_population_size(10 ** 5)
+                fill, steps = 30, 40
             elif case == "one_mutant_rescues":
                 s = Simulator(number_of_sites=5, populations_number=4, seed=13)
                 s.set_transmission_rate(0.5); s.set_recovery_rate(1.5); s.set_sampling_rate(0.5); s.set_mutation_rate(1.5)

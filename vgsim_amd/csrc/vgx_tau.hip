@@ -1547,7 +1547,7 @@ __global__ void __launch_bounds__(TB) vgx_tau_scan_fast_kernel(VgxTauArgs a) {
         auto has255 = [](uint32_t x) { return (((x & 0x7F7F7F7Fu) + 0x01010101u) & x & 0x80808080u) != 0u; };
         const bool sat = has255(cur.x) || has255(cur.y) || has255(cur.z) || has255(cur.w);
         uint32_t qbits = 0;          // bit 4k + j: compartment hl + 4k + j is queued
-        int4 clv[4];
+        int4 clv[4] = {make_int4(0, 0, 0, 0), make_int4(0, 0, 0, 0), make_int4(0, 0, 0, 0), make_int4(0, 0, 0, 0)};
         if (!C1 && hl < H) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) clv[k] = *(const int4 *)(p.cls + hl + 4 * k);
@@ -1562,6 +1562,7 @@ __global__ void __launch_bounds__(TB) vgx_tau_scan_fast_kernel(VgxTauArgs a) {
                 if (b >= T) qbits |= 1u << (4 * k + j);
             }
         }
+        if (hl >= H) qbits = 0;   // (a lane beyond the row: its counts read as zero, nothing is queued)
         if (sat && hl < H) {   // counts of 255 or more: the general kernel's test on the count proper
 #pragma unroll
             for (int k = 0; k < 4; ++k)
@@ -1727,7 +1728,7 @@ extern "C" __global__ void __launch_bounds__(EB) vgx_tau_events_kernel(VgxTauArg
     int okv = __hip_atomic_load(&a.ok[rep], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // the queue entry is loaded two rounds ahead of its use, the compartment's count (a dependent, scattered load) one round
     int64_t qe_c = L < n ? qsrc[L] : 0, qe_n = L + EB < n ? qsrc[L + EB] : 0;
-    int32_t I_c = L < n ? Irow[(int)(qe_c & 0xFFFFFFFFll)] : 0;
+    int32_t I_c = L < n ? Irow[min((int)(qe_c & 0x7FFFFFFFll), H - 1)] : 0;   // (indices clamped: a bad entry must not fault)
     for (int64_t k0 = 0; k0 < n; k0 += EB) {
         if (okv == 0) break;   // the try is already lost: nothing of it counts (vgx_tau_decide_kernel)
         okv = __hip_atomic_load(&a.ok[rep], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1735,13 +1736,13 @@ extern "C" __global__ void __launch_bounds__(EB) vgx_tau_events_kernel(VgxTauArg
         const int64_t qe = qe_c;
         const int32_t I_now = I_c;
         qe_c = qe_n;
-        I_c = k + EB < n ? Irow[(int)(qe_c & 0xFFFFFFFFll)] : 0;
+        I_c = k + EB < n ? Irow[min((int)(qe_c & 0x7FFFFFFFll), H - 1)] : 0;
         qe_n = k + 2 * EB < n ? qsrc[k + 2 * EB] : 0;
         int h = 0;
         int64_t v = 0;
         bool below = false;   // below zero on its own (sparse mode): looked at by the whole wavefront, see below
-        if (k < n) {
-            h = (int)(qe & 0xFFFFFFFFll);
+        if (k < n && (int)(qe & 0x7FFFFFFFll) < H) {
+            h = (int)(qe & 0x7FFFFFFFll);
             const int64_t Ih = (int64_t)I_now;
             int64_t oc = 0, oa = 0;
             const int r = tau_cell_events<false>(a, T, rep, pn, h, tau, Ih, (uint32_t)(qe >> 32), oc, oa, cnt, stage, sS, -1);
