@@ -23,6 +23,7 @@
 // distributionally (tests/test_hip_tau.py), as BASELINE.json asks.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <algorithm>
 #include "../../include/vgx.h"
 #include "vgx_dev.h"
 #include "vgx_rng.h"
@@ -681,12 +682,22 @@ __global__ void __launch_bounds__(TB) vgx_tau_drift_fast_kernel(VgxTauArgs a) {
     }
     for (int i = threadIdx.x; i < CB * S; i += TB) l_base[i] = p.cb_b[i / S] * p.cb_sigma[i] * (double)Sus[i % S];
     if (threadIdx.x < low) l_rate[threadIdx.x] = a.mutp[nh + threadIdx.x][0];   // low site i <-> two-bit group low - 1 - i
-    const int h0 = blockIdx.x * TS;
-    for (int i = threadIdx.x * 4; i < TS; i += TB * 4) {
-        const int4 v = *(const int4 *)(I + h0 + i);
-        *(int4 *)(tile + i) = v;
-        *(uint32_t *)(a.I8 + rowoff + h0 + i) = tau_pack8(v.x, v.y, v.z, v.w);   // the one-byte copy vgx_tau_scan_kernel streams
-    }
+    const int ntiles = H >> (2 * low);
+    // the per-compartment inputs from global memory (high-site neighbour sums, the two column sums of uniform migration) are
+    // loaded one iteration ahead — the first ones before the tile is in LDS: their latency was most of a block's life
+    struct DIn { int4 hi; double4 cT, cTW; };
+    auto load_in = [&](int h0, int t0) -> DIn {
+        DIn d;
+        d.hi = make_int4(0, 0, 0, 0); d.cT = make_double4(0.0, 0.0, 0.0, 0.0); d.cTW = d.cT;
+        if (t0 < TS) {
+            if (nh > 0 && a.mutHi_int) d.hi = *(const int4 *)((const int32_t *)a.mutHi + rowoff + h0 + t0);
+            if (a.has_mig && a.mig_uniform) {   // shared by all populations: they stay in the caches
+                d.cT = *(const double4 *)(a.colT + (int64_t)rep * H + h0 + t0);
+                d.cTW = *(const double4 *)(a.colTW + (int64_t)rep * H + h0 + t0);
+            }
+        }
+        return d;
+    };
     __syncthreads();
     const double F = a.F[(int64_t)rep * P + pn];
     __shared__ double s_wu[16];
@@ -698,19 +709,32 @@ __global__ void __launch_bounds__(TB) vgx_tau_drift_fast_kernel(VgxTauArgs a) {
     const double rate0 = l_rate[0];
     double cand_min = 1.0, ad_max = 0.0;
     double redS[4] = {0.0, 0.0, 0.0, 0.0};
+    // a block works on several tiles of its population one after the other: its tables, the migration constants and the
+    // final reductions are paid once (they were most of a one-tile block's life)
+    for (int tb = blockIdx.x; tb < ntiles; tb += gridDim.x) {
+    const int h0 = tb * TS;
+    DIn nxt = load_in(h0, threadIdx.x * 4);
+    __syncthreads();   // the previous tile has been read by everybody
+    for (int i = threadIdx.x * 4; i < TS; i += TB * 4) {
+        const int4 v = *(const int4 *)(I + h0 + i);
+        *(int4 *)(tile + i) = v;
+        *(uint32_t *)(a.I8 + rowoff + h0 + i) = tau_pack8(v.x, v.y, v.z, v.w);   // the one-byte copy vgx_tau_scan_kernel streams
+    }
+    __syncthreads();
     for (int t0 = threadIdx.x * 4; t0 < TS; t0 += TB * 4) {
+        const DIn in = nxt;
+        nxt = load_in(h0, t0 + TB * 4);
         double mh[4] = {0.0, 0.0, 0.0, 0.0}, mg[4] = {0.0, 0.0, 0.0, 0.0};
         if (nh > 0 && a.mutHi_int) {
-            const int4 v = *(const int4 *)((const int32_t *)a.mutHi + rowoff + h0 + t0);
+            const int4 v = in.hi;
             mh[0] = a.mutHi_rate * (double)v.x; mh[1] = a.mutHi_rate * (double)v.y; mh[2] = a.mutHi_rate * (double)v.z; mh[3] = a.mutHi_rate * (double)v.w;
         } else if (nh > 0) {
             const double4 v = *(const double4 *)(a.mutHi + rowoff + h0 + t0); mh[0] = v.x; mh[1] = v.y; mh[2] = v.z; mh[3] = v.w;
         }
         const int4 own = *(const int4 *)(tile + t0);
         const int Iv[4] = {own.x, own.y, own.z, own.w};
-        if (a.has_mig && a.mig_uniform) {   // the two column sums are shared by all populations: they stay in the caches
-            const double4 v = *(const double4 *)(a.colT + (int64_t)rep * H + h0 + t0);
-            const double4 u = *(const double4 *)(a.colTW + (int64_t)rep * H + h0 + t0);
+        if (a.has_mig && a.mig_uniform) {
+            const double4 v = in.cT, u = in.cTW;
             mg[0] = tau_migu(mu, v.x, u.x, (double)Iv[0]); mg[1] = tau_migu(mu, v.y, u.y, (double)Iv[1]);
             mg[2] = tau_migu(mu, v.z, u.z, (double)Iv[2]); mg[3] = tau_migu(mu, v.w, u.w, (double)Iv[3]);
         } else if (a.has_mig) {
@@ -779,23 +803,23 @@ __global__ void __launch_bounds__(TB) vgx_tau_drift_fast_kernel(VgxTauArgs a) {
             // with up to 66 hosts the numerator is 1: the smallest candidate is 1 / (largest |drift|), one division per thread
             // at the end instead of one per compartment (the quotient is monotone in |drift|, so it is the same number)
             const double ad = fabs(drift);
-            if (ad >= 1e-8) {
-                const double v = (double)(0.03f * (float)Icell) / 2.0;
-                if (v > 1.0) {
-                    const double cand = v / ad;
-                    if (cand < cand_min) cand_min = cand;
-                } else if (ad > ad_max) ad_max = ad;
+            const double v = (double)(0.03f * (float)Icell) / 2.0;
+            const bool large = v > 1.0;                       // more than 66 hosts: its own numerator (rare here)
+            ad_max = fmax(ad_max, large ? 0.0 : ad);          // (|drift| < 1e-8 is sorted out at the end)
+            if (__any(large && ad >= 1e-8)) {
+                if (large && ad >= 1e-8) cand_min = fmin(cand_min, v / ad);
             }
             if (do_hist && Icell >= 1 && Icell <= VGX_HIST_X)
                 atomicAdd(&hist[(c * VGX_HIST_X + Icell - 1) * HK + (lane & (HK - 1))], 1u);
         }
     }
+    }   // tiles
     for (int sn = 0; sn < 4 && sn < S; ++sn) {
         double red = redS[sn];
         for (int o = 32; o > 0; o >>= 1) red += __shfl_down(red, o);
         if (lane == 0 && red != 0.0) atomicAdd(&sdS[sn], red);
     }
-    if (ad_max > 0.0 && 1.0 / ad_max < cand_min) cand_min = 1.0 / ad_max;
+    if (ad_max >= 1e-8 && 1.0 / ad_max < cand_min) cand_min = 1.0 / ad_max;
     for (int o = 32; o > 0; o >>= 1) {
         double other = __shfl_down(cand_min, o);
         if (other < cand_min) cand_min = other;
@@ -2291,7 +2315,9 @@ extern "C" __attribute__((visibility("hidden"))) hipError_t vgxi_tau_drift(const
             hipLaunchKernelGGL(vgx_tau_muthigh_kernel, dim3((unsigned)((1 << (2 * low)) / CH), (unsigned)a->p.P, (unsigned)a->R), dim3(TB), lds, s, *a);
         }
         if (a->mutlow_fast) {
-            const dim3 grid((unsigned)(a->p.H >> (2 * low)), (unsigned)a->p.P, (unsigned)a->R);
+            // blocks per (population, replicate): enough blocks to fill the chip, the rest of the tiles in each block's loop
+            const int64_t ntiles = a->p.H >> (2 * low), want = std::max<int64_t>(1, 4096 / std::max<int64_t>(1, (int64_t)a->p.P * a->R));
+            const dim3 grid((unsigned)std::min<int64_t>(ntiles, want), (unsigned)a->p.P, (unsigned)a->R);
             const bool c1 = a->p.C == 1, s1 = a->p.S == 1;
             if (c1 && s1) hipLaunchKernelGGL((vgx_tau_drift_fast_kernel<true, true>), grid, dim3(TB), 0, s, *a);
             else if (c1) hipLaunchKernelGGL((vgx_tau_drift_fast_kernel<true, false>), grid, dim3(TB), 0, s, *a);
