@@ -1755,7 +1755,8 @@ extern "C" __global__ void __launch_bounds__(EB) vgx_tau_events_kernel(VgxTauArg
     int32_t I_c = L < n ? Irow[min((int)(qe_c & 0x7FFFFFFFll), H - 1)] : 0;   // (indices clamped: a bad entry must not fault)
     for (int64_t k0 = 0; k0 < n; k0 += EB) {
         if (okv == 0) break;   // the try is already lost: nothing of it counts (vgx_tau_decide_kernel)
-        okv = __hip_atomic_load(&a.ok[rep], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // (a device-scope load goes past the L2: a few microseconds, and every wait for memory waits for it too — every fourth round)
+        if (((k0 / EB) & 3) == 3) okv = __hip_atomic_load(&a.ok[rep], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const int64_t k = k0 + L;
         const int64_t qe = qe_c;
         const int32_t I_now = I_c;
