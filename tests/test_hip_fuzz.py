@@ -133,3 +133,33 @@ def test_random_model_tau_invariants(seed):
     if len(multi):   # contiguous, ordered row ranges
         lo, hi = ev.haplotypes[multi], ev.populations[multi]
         assert (hi >= lo).all() and (lo[1:] == hi[:-1]).all() and hi[-1] == mv.ptr
+
+
+@pytest.mark.parametrize("seed", list(range(int(__import__("os").environ.get("VGX_FUZZ_SEEDS", "40")))))
+def test_random_model_tau_modes_agree(seed):
+    """The three ways a try of the halving loop can keep and check its deltas (vgx_run_opts.reserved[1]: list of moves /
+    dense arrays with fused checks / dense arrays and a dense bounds check) make the same draws and the same decisions:
+    bit for bit the same state, counters and multievent rows on every random model (shapes with rows shorter than a wave
+    tile, several rate classes, several susceptibility groups, migration, lockdowns)."""
+    from vgsim_amd import _capi
+    out = []
+    for mode in (0, 2, 1):
+        sim, n = build(seed)
+        m = sim.simulation
+        with helpers.quiet():
+            sim.simulate(min(n, 600), sample_size=10 ** 9)
+            if m.globalInfectious == 0:
+                return
+            o = _capi.VgxRunOpts(); o.record_events = 1; o.reserved[1] = mode
+            m.events.CreateEvents(25); m.events.CreateEvents(25); m.CheckSizes()
+            m._get_engine().simulate_tau(m, 25, 10 ** 12, -1.0, 200, o)
+        mv = m.multievents
+        rows = np.stack([mv.num[:mv.ptr], mv.types[:mv.ptr], mv.haplotypes[:mv.ptr], mv.populations[:mv.ptr],
+                         mv.newHaplotypes[:mv.ptr], mv.newPopulations[:mv.ptr]])
+        # rows of one step are appended by concurrent wavefronts: compare them as a multiset per step
+        out.append((m.infectious.copy(), m.susceptible.copy(), m.currentTime, [int(getattr(m, k)) for k in m.COUNTERS],
+                    int(m.events.ptr), sorted(map(tuple, rows.T.tolist()))))
+    for other in out[1:]:
+        assert np.array_equal(out[0][0], other[0]) and np.array_equal(out[0][1], other[1])
+        assert out[0][2] == other[2] and out[0][3] == other[3] and out[0][4] == other[4]
+        assert out[0][5] == other[5]
