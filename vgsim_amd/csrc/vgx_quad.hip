@@ -1154,7 +1154,10 @@ static __device__ __forceinline__ void quad_body(const VgxDirectArgs &a, const Q
 }
 
 extern "C" __global__ void __launch_bounds__(64, VGX_QUAD_WAVES) vgx_quad_kernel(VgxDirectArgs a, QArgs qa) { quad_body<3>(a, qa); }
-extern "C" __global__ void __launch_bounds__(64, VGX_QUAD_WAVES) vgx_quad_long_kernel(VgxDirectArgs a, QArgs qa) { quad_body<5>(a, qa); }
+#ifndef VGX_QT_LONG
+#define VGX_QT_LONG 5
+#endif
+extern "C" __global__ void __launch_bounds__(64, VGX_QUAD_WAVES) vgx_quad_long_kernel(VgxDirectArgs a, QArgs qa) { quad_body<VGX_QT_LONG>(a, qa); }
 
 // The 4-byte copy of the counts after another kernel changed the lists (the copy is kept by vgx_quad_kernel only).
 extern "C" __global__ void __launch_bounds__(256) vgx_quad_counts32_kernel(const int64_t *c64, int32_t *c32, int64_t n) {
