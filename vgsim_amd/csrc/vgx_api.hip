@@ -981,10 +981,11 @@ extern "C" int vgx_simulate_tau(vgx_engine *e, int64_t iterations, int64_t sampl
     // multievent rows (num > 0 only): at most a few per occupied compartment and step; sized from the start state with
     // room for the epidemic to grow, within 2^27 rows (6 GiB) per replicate; a run that still outgrows it fails loudly
     const int64_t rows_per_step = 16 * occupied + 4 * P * S * S + 4096;
-    const int64_t mev_cap = o.record_events
-        ? std::max<int64_t>(1, std::min<int64_t>(((int64_t)1 << 27) / std::max<int64_t>(R, 1),
+    const int64_t mev_max = ((int64_t)1 << 28) / std::max<int64_t>(R, 1);   // 12 GiB of rows over all replicates
+    int64_t mev_cap = o.record_events
+        ? std::max<int64_t>(1, std::min<int64_t>(mev_max / 2,
                                                  std::max<int64_t>((int64_t)1 << 22, std::min<int64_t>(iterations, 1 << 20) * rows_per_step)))
-        : 0;
+        : 0;   // doubled on demand (a try whose rows do not fit is run again), up to mev_max
     const size_t nF = 10;  // int32 flag arrays
     const int64_t Ppad = (P + 31) / 32 * 32;
     rc = 0;
@@ -1377,6 +1378,29 @@ extern "C" int vgx_simulate_tau(vgx_engine *e, int64_t iterations, int64_t sampl
                 a.q = (int64_t *)e->t_q.p;
                 a.q_cap = q_shards * q_scap;
             }
+            if (again & 16) {   // multievent rows: a larger buffer, the rows of the accepted steps move over
+                if (mev_cap >= mev_max)
+                    return fail(e, VGX_ERR_CAPACITY, "vgx_simulate_tau: multievent buffer full (" + std::to_string(mev_cap) +
+                                                     " rows per replicate; pass record_events=0 for large runs)");
+                const int64_t new_cap = std::min<int64_t>(mev_max, mev_cap * 2);
+                DevBuf nb;
+                int rcg = ensure(e, nb, (size_t)(R * new_cap * 6) * 8);
+                if (rcg) return rcg;
+                std::vector<unsigned long long> base_h((size_t)R);
+                HIPCHECK(e, hipMemcpy(base_h.data(), a.mev_base, (size_t)R * 8, hipMemcpyDeviceToHost));
+                for (int64_t r = 0; r < R; r++)
+                    if (base_h[(size_t)r] > 0)
+                        HIPCHECK(e, hipMemcpy((int64_t *)nb.p + r * new_cap * 6, (int64_t *)e->t_mev.p + r * mev_cap * 6,
+                                              (size_t)std::min<int64_t>((int64_t)base_h[(size_t)r], mev_cap) * 48, hipMemcpyDeviceToDevice));
+                // the new buffer takes the old one's place in the engine's bookkeeping
+                HIPCHECK(e, hipFree(e->t_mev.p));
+                e->dev_bytes -= e->t_mev.bytes;
+                e->all.erase(std::remove(e->all.begin(), e->all.end(), &nb), e->all.end());
+                e->t_mev.p = nb.p; e->t_mev.bytes = nb.bytes;
+                mev_cap = new_cap;
+                a.mev = (int64_t *)e->t_mev.p; a.mev_cap = mev_cap;
+                e->tau_mev_cap = mev_cap;
+            }
             if (again & 2) dense_once = true;
             if (again) HIPCHECK(e, hipMemset(a.grow, 0, (size_t)R * 4));
             if (tries > 300) return fail(e, VGX_ERR_LOOP_GUARD, "vgx_simulate_tau: tau halving did not converge");
@@ -1409,7 +1433,9 @@ extern "C" int vgx_simulate_tau(vgx_engine *e, int64_t iterations, int64_t sampl
             if (err_h[(size_t)r] == 7) return fail(e, VGX_ERR_CAPACITY, "vgx_simulate_tau: replicate " + std::to_string(r) + ": lockdown log full (" + std::to_string(VGX_LOC_CAP) + " switches per call)");
             if (err_h[(size_t)r]) return fail(e, VGX_ERR_LOOP_GUARD, "vgx_simulate_tau: replicate " + std::to_string(r) + ": tau underflow in the halving loop");
             if (mev_cap > 0 && (int64_t)mevn[(size_t)r] > mev_cap)
-                return fail(e, VGX_ERR_CAPACITY, "vgx_simulate_tau: multievent buffer full (pass record_events=0 for large runs)");
+                return fail(e, VGX_ERR_CAPACITY, "vgx_simulate_tau: multievent buffer full (" + std::to_string(mevn[(size_t)r]) + " rows after " +
+                                                     std::to_string(steps_done[(size_t)r] + 1) + " steps, room for " + std::to_string(mev_cap) +
+                                                     "; pass record_events=0 for large runs)");
             tnow[(size_t)r] += tau_h[(size_t)r];                       // pyx:2322
             e->tau_log[(size_t)r].push_back({tnow[(size_t)r], (int64_t)mevb[(size_t)r], (int64_t)mevn[(size_t)r]});  // pyx:2325
             ev_ptr[(size_t)r] += 1;

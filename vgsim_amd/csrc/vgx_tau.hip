@@ -1236,6 +1236,7 @@ static __device__ __forceinline__ int tau_cell_events(const VgxTauArgs &a, const
     }
     if (N == 0) return 0;
     int64_t rec = 0, samp = 0, births = 0, n_mut = 0, n_mig = 0;
+    int bsn[4] = {0, 0, 0, 0};   // births per susceptibility group (first four): ONE multievent row per channel, as upstream's
     const double t1 = r_rec, t2 = t1 + r_samp, t3 = t2 + r_tr, t4 = t3 + r_mut;
     for (int64_t ev = 0; ev < N; ++ev) {
         double u = g.uniform() * r_all;
@@ -1254,8 +1255,8 @@ static __device__ __forceinline__ int tau_cell_events(const VgxTauArgs &a, const
             }
             if (sn_hit < 0) continue;
             births += 1;
-            if (sn_hit < 4) cnt[8 + sn_hit] -= 1; else atomicAdd(&sS[sn_hit], (unsigned long long)(-1ll));
-            tau_row(a, rep, 1, 0, hn, pn, sn_hit, 0);
+            if (sn_hit < 4) { cnt[8 + sn_hit] -= 1; bsn[sn_hit] += 1; }
+            else { atomicAdd(&sS[sn_hit], (unsigned long long)(-1ll)); tau_row(a, rep, 1, 0, hn, pn, sn_hit, 0); }
         } else if (u < t4 || r_mig == 0.0) n_mut += 1;
         else n_mig += 1;
     }
@@ -1321,6 +1322,8 @@ static __device__ __forceinline__ int tau_cell_events(const VgxTauArgs &a, const
         tau_row(a, rep, 1, 5, hn, pn, ts, tp);
     }
     cnt[0] += births; cnt[1] += rec; cnt[2] += samp; cnt[3] += mut_done; cnt[5] += migrants;
+    for (int sn = 0; sn < 4; ++sn)
+        if (bsn[sn]) tau_row(a, rep, bsn[sn], 0, hn, pn, sn, 0);
     if (rec) tau_row(a, rep, rec, 1, hn, pn, st, 0);
     if (samp) tau_row(a, rep, samp, 2, hn, pn, st, 0);
     const int64_t own = births - rec - samp - mut_done;
@@ -2145,13 +2148,15 @@ extern "C" __global__ void __launch_bounds__(TB) vgx_tau_check_kernel(VgxTauArgs
 // grow[rep] on entry: what the kernels of the try found out (1 = list of moves, 4 = list of large compartments, 8 = queue of
 // drawing compartments overflowed: data were lost, nothing of the try counts; 2 = the sparse check cannot decide the upper
 // bound); on exit: what the host has to do before the SAME try runs again (tau and the try index stay, the streams are keyed
-// by the try index): 1 / 4 / 8 = enlarge that list, 2 = run it with dense delta arrays; 0 = the try was accepted or rejected.
+// by the try index): 1 / 4 / 8 / 16 = enlarge that list (16: the multievent rows), 2 = run it with dense delta arrays; 0 = the
+// try was accepted or rejected.
 extern "C" __global__ void __launch_bounds__(64) vgx_tau_decide_kernel(VgxTauArgs a) {
     const int rep = blockIdx.x;
     const bool live = a.active[rep] && !a.accepted[rep];
-    const int g = live ? a.grow[rep] : 0;
+    int g = live ? a.grow[rep] : 0;
+    if (live && a.mev_cap > 0 && (int64_t)a.mev_n[rep] > a.mev_cap) g |= 16;   // rows were lost: the host enlarges the buffer
     const bool ok = live && a.ok[rep];
-    const int again = (g & 13) ? (g & 13) : (ok ? (g & 2) : 0);
+    const int again = (g & 29) ? (g & 29) : (ok ? (g & 2) : 0);
     const bool accept = live && ok && again == 0;
     __syncthreads();
     // the list of moves: applied already (dense mode: vgx_tau_scatter_kernel) or discarded; the sparse mode's accepted list
