@@ -1152,6 +1152,8 @@ extern "C" int vgx_simulate_tau(vgx_engine *e, int64_t iterations, int64_t sampl
     a.st_key = (unsigned long long *)e->t_stkey.p; a.st_val = (long long *)e->t_stval.p; a.st_size = st_size;
     a.dChkTot = (int64_t *)e->t_dChkTot.p;
     a.q = (int64_t *)e->t_q.p; a.q_cap = q_shards * q_scap; a.q_shards = q_shards; a.q_n = (unsigned long long *)e->t_qn.p;
+    // enough blocks of the events kernel to fill the chip whatever the number of shards (mid-size models have few)
+    a.ev_split = (int32_t)std::max<int64_t>(1, std::min<int64_t>(q_shard_max / 64, 4096 / std::max<int64_t>(1, q_shards * R)));
     a.sieve = (double *)e->t_sieve.p; a.sieve_skipped = (int64_t *)e->t_sieveskip.p;
     // vgx_run_opts.reserved[0] = 1: run every try of the halving loop; with few compartments no try is ever a certain rejection
     a.sieve_on = (o.reserved[0] == 1 || P * H < 32768) ? 0 : 1;

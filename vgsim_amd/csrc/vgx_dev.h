@@ -238,6 +238,7 @@ struct VgxTauArgs {
     int64_t q_cap;                   // a multiple of q_shards
     int64_t q_shards;
     unsigned long long *q_n;         // [R][q_shards]
+    int32_t ev_split;                // blocks of the events kernel per shard of the queue
     uint32_t gen;                    // try counter of this call, 1 .. 2^25 - 1
     unsigned long long *st_key;      // [R][st_size]
     long long *st_val;               // [R][st_size] infectious + own delta + arrivals

@@ -1659,23 +1659,22 @@ __global__ void __launch_bounds__(TB) vgx_tau_scan_fast_kernel(VgxTauArgs a) {
     }
 }
 
-// grid = (tau_draw_gx(H), P, R), one wavefront per block; dSi / dTot / dChkTot are zero on entry
+// grid = (tau_draw_gx(H) * ev_split, P, R), one wavefront per block: ev_split blocks share a shard of the queue and take its
+// rounds of 64 entries in turn (few shards with many entries each — mid-size models — still fill the chip); dSi / dTot /
+// dChkTot are zero on entry.  The shards' counters are cleared by vgx_tau_decide_kernel.
 extern "C" __global__ void __launch_bounds__(EB) vgx_tau_events_kernel(VgxTauArgs a) {
     const int rep = blockIdx.z, pn = blockIdx.y;
     if (!a.active[rep] || a.accepted[rep]) return;
     const VgxDevParams &p = a.p;
     const int P = p.P, S = p.S, C = p.C, CB = p.CB, H = p.H;
     const int64_t scap = a.q_cap / a.q_shards;
-    const int64_t shard = (int64_t)pn * gridDim.x + blockIdx.x;
-    unsigned long long *qn = a.q_n + (int64_t)rep * a.q_shards + shard;
-    int64_t n = (int64_t)*qn;
-    if (n == 0) return;
-    if (__hip_atomic_load(&a.ok[rep], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {   // the try is already lost (see below)
-        if (threadIdx.x == 0) *qn = 0;
-        return;
-    }
+    const int split = a.ev_split, sub = (int)(blockIdx.x % split);
+    const int64_t shard = (int64_t)pn * (gridDim.x / split) + blockIdx.x / split;
+    const int64_t n = (int64_t)a.q_n[(int64_t)rep * a.q_shards + shard];
+    if ((int64_t)sub * EB >= n) return;
+    if (__hip_atomic_load(&a.ok[rep], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return;   // the try is already lost (see below)
     if (n > scap) {   // the shard overflowed: compartments were lost, the host enlarges the queue and the same try runs again
-        if (threadIdx.x == 0) { atomicOr(&a.grow[rep], 8); *qn = 0; }
+        if (threadIdx.x == 0) atomicOr(&a.grow[rep], 8);
         return;
     }
     extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
@@ -1754,18 +1753,20 @@ extern "C" __global__ void __launch_bounds__(EB) vgx_tau_events_kernel(VgxTauArg
     // wavefront on another XCD would never see the flag.  The load is issued one round ahead of its use.
     int okv = __hip_atomic_load(&a.ok[rep], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // the queue entry is loaded two rounds ahead of its use, the compartment's count (a dependent, scattered load) one round
-    int64_t qe_c = L < n ? qsrc[L] : 0, qe_n = L + EB < n ? qsrc[L + EB] : 0;
-    int32_t I_c = L < n ? Irow[min((int)(qe_c & 0x7FFFFFFFll), H - 1)] : 0;   // (indices clamped: a bad entry must not fault)
-    for (int64_t k0 = 0; k0 < n; k0 += EB) {
+    const int64_t kstep = (int64_t)split * EB, kfirst = (int64_t)sub * EB;
+    int64_t qe_c = kfirst + L < n ? qsrc[kfirst + L] : 0, qe_n = kfirst + kstep + L < n ? qsrc[kfirst + kstep + L] : 0;
+    int32_t I_c = kfirst + L < n ? Irow[min((int)(qe_c & 0x7FFFFFFFll), H - 1)] : 0;   // (indices clamped: a bad entry must not fault)
+    int round = 0;
+    for (int64_t k0 = kfirst; k0 < n; k0 += kstep, ++round) {
         if (okv == 0) break;   // the try is already lost: nothing of it counts (vgx_tau_decide_kernel)
         // (a device-scope load goes past the L2: a few microseconds, and every wait for memory waits for it too — every fourth round)
-        if (((k0 / EB) & 3) == 3) okv = __hip_atomic_load(&a.ok[rep], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((round & 3) == 3) okv = __hip_atomic_load(&a.ok[rep], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const int64_t k = k0 + L;
         const int64_t qe = qe_c;
         const int32_t I_now = I_c;
         qe_c = qe_n;
-        I_c = k + EB < n ? Irow[min((int)(qe_c & 0x7FFFFFFFll), H - 1)] : 0;
-        qe_n = k + 2 * EB < n ? qsrc[k + 2 * EB] : 0;
+        I_c = k + kstep < n ? Irow[min((int)(qe_c & 0x7FFFFFFFll), H - 1)] : 0;
+        qe_n = k + 2 * kstep < n ? qsrc[k + 2 * kstep] : 0;
         int h = 0;
         int64_t v = 0;
         bool below = false;   // below zero on its own (sparse mode): looked at by the whole wavefront, see below
@@ -1818,10 +1819,9 @@ extern "C" __global__ void __launch_bounds__(EB) vgx_tau_events_kernel(VgxTauArg
         // the staged moves go out when the next round might not fit (a round adds at most one own change per lane plus its
         // mutants and migrants; what does not fit goes to the list entry by entry)
         WSYNC();
-        if (stage->n > VGX_WSTAGE - 96 || k0 + EB >= n) tau_stage_flush(a, stage, rep);
+        if (stage->n > VGX_WSTAGE - 96 || k0 + kstep >= n) tau_stage_flush(a, stage, rep);
     }
     tau_stage_flush(a, stage, rep);   // (a wavefront that left the loop early)
-    if (threadIdx.x == 0) *qn = 0;   // the shard is empty for the next try
     unsigned long long *ct = (unsigned long long *)&a.cnt_try[(int64_t)rep * 8];
     for (int i = 0; i < 12; ++i) {   // wave-level sums, then one global atomic per tally
         long long v = cnt[i];
@@ -1845,7 +1845,7 @@ extern "C" __global__ void __launch_bounds__(EB) vgx_tau_events_kernel(VgxTauArg
 // compartment with 10^5 hosts would do for tens of thousands of events on one lane (natural epidemics: most hosts carry a
 // few haplotypes); the joint law of the channel counts is the same (Poisson splitting).  A channel's stream is keyed by
 // (compartment, channel), so the result does not depend on the lane mapping.  grid = (VGX_BIG_BLOCKS, R), 4 waves a block.
-#define VGX_BIG_BLOCKS 256
+#define VGX_BIG_BLOCKS 2048   // (blocks without work leave at once)
 extern "C" __global__ void __launch_bounds__(TB) vgx_tau_draw_big_kernel(VgxTauArgs a) {
     const int rep = blockIdx.y;
     if (!a.active[rep] || a.accepted[rep]) return;
@@ -1856,6 +1856,7 @@ extern "C" __global__ void __launch_bounds__(TB) vgx_tau_draw_big_kernel(VgxTauA
     if ((int64_t)n > a.big_cap) n = (unsigned long long)a.big_cap;
     const double tau = a.tau[rep];
     int64_t *dS = a.dSi + (int64_t)rep * P * S;
+    long long tot[5] = {0, 0, 0, 0, 0};   // lane 0: this wavefront's tallies (one atomic each at the end, not one per compartment)
     for (unsigned long long e = (unsigned long long)blockIdx.x * (TB / 64) + (threadIdx.x >> 6); e < n; e += (unsigned long long)gridDim.x * (TB / 64)) {
         const int64_t cell = a.big[(int64_t)rep * a.big_cap + (int64_t)e];
         const int pn = (int)(cell / H), hn = (int)(cell - (int64_t)pn * H);
@@ -1928,15 +1929,16 @@ extern "C" __global__ void __launch_bounds__(TB) vgx_tau_draw_big_kernel(VgxTauA
             }
             tau_own_check(a, rep, pn, hn, (int64_t)a.I[off] + own + v[4]);
             if (v[0] - v[1] - v[2] + v[4]) atomicAdd((unsigned long long *)&a.dChkTot[(int64_t)rep * P + pn], (unsigned long long)(v[0] - v[1] - v[2] + v[4]));
-            unsigned long long *ct = (unsigned long long *)&a.cnt_try[(int64_t)rep * 8];
-            if (v[0]) atomicAdd(&ct[0], (unsigned long long)v[0]);
-            if (v[1]) atomicAdd(&ct[1], (unsigned long long)v[1]);
-            if (v[2]) atomicAdd(&ct[2], (unsigned long long)v[2]);
-            if (v[3]) atomicAdd(&ct[3], (unsigned long long)v[3]);
-            if (v[4]) atomicAdd(&ct[5], (unsigned long long)v[4]);
+            for (int i = 0; i < 5; ++i) tot[i] += v[i];
             if (v[1] + v[2]) atomicAdd((unsigned long long *)&dS[pn * S + st], (unsigned long long)(v[1] + v[2]));
             if (v[0] - v[1] - v[2]) atomicAdd((unsigned long long *)&a.dTot[(int64_t)rep * P + pn], (unsigned long long)(v[0] - v[1] - v[2]));
         }
+    }
+    if (lane == 0) {
+        unsigned long long *ct = (unsigned long long *)&a.cnt_try[(int64_t)rep * 8];
+        const int slot[5] = {0, 1, 2, 3, 5};
+        for (int i = 0; i < 5; ++i)
+            if (tot[i]) atomicAdd(&ct[slot[i]], (unsigned long long)tot[i]);
     }
 }
 
@@ -2163,6 +2165,8 @@ extern "C" __global__ void __launch_bounds__(64) vgx_tau_decide_kernel(VgxTauArg
     // is applied after this kernel (vgx_tau_apply_kernel) and emptied by vgx_tau_finish_kernel
     if (live && (!accept || !a.sparse))
         for (int i = threadIdx.x; i < a.inc_shards; i += 64) a.inc_n[(int64_t)rep * VGX_INC_SHARDS + i] = 0;
+    if (live)   // the queue of the try has been worked off
+        for (int64_t i = threadIdx.x; i < a.q_shards; i += 64) a.q_n[(int64_t)rep * a.q_shards + i] = 0;
     if (threadIdx.x != 0) return;
     a.deciding[rep] = 0;
     if (!live) return;
@@ -2343,6 +2347,7 @@ extern "C" __attribute__((visibility("hidden"))) hipError_t vgxi_tau_draw(const 
     hipError_t err = hipFuncSetAttribute((const void *)vgx_tau_events_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds ? lds : 16));
     if (err != hipSuccess) return err;
     const dim3 grid(tau_draw_gx(a->p.H), (unsigned)a->p.P, (unsigned)a->R);
+    const dim3 egrid(tau_draw_gx(a->p.H) * (unsigned)a->ev_split, (unsigned)a->p.P, (unsigned)a->R);
     if (a->p.C <= 16 && a->p.CB <= 16 && (a->p.H & 15) == 0) {   // the usual shapes: thresholds tabulated
         const bool c1 = a->p.C == 1, dn = !a->sparse;
         if (c1 && !dn) hipLaunchKernelGGL((vgx_tau_scan_fast_kernel<true, false>), grid, dim3(TB), 0, s, *a);
@@ -2352,7 +2357,7 @@ extern "C" __attribute__((visibility("hidden"))) hipError_t vgxi_tau_draw(const 
     } else {
         hipLaunchKernelGGL(vgx_tau_scan_kernel, grid, dim3(TB), 0, s, *a);
     }
-    hipLaunchKernelGGL(vgx_tau_events_kernel, grid, dim3(EB), lds ? lds : 16, s, *a);
+    hipLaunchKernelGGL(vgx_tau_events_kernel, egrid, dim3(EB), lds ? lds : 16, s, *a);
     return hipGetLastError();
 }
 extern "C" __attribute__((visibility("hidden"))) int64_t vgxi_tau_queue_shards(int64_t H, int64_t P) { return (int64_t)tau_draw_gx(H) * P; }
