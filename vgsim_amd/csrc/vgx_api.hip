@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <cmath>
 #include <string>
+#include <chrono>
 #include <thread>
 #include <unordered_map>
 #include <vector>
@@ -65,6 +66,8 @@ struct vgx_engine {
     std::string err;
     bool have_params = false, have_state = false, dev_state_valid = false;
     int64_t start_max_nocc = 0;    // longest occupancy list of the state last uploaded
+    void *pin[2] = {nullptr, nullptr};   // pinned staging buffers of large uploads (VGX_PIN_BYTES each), allocated on first use
+    hipEvent_t pin_ev[2] = {nullptr, nullptr};
     bool counts32_valid = false;   // r_lcnt32 mirrors r_lcnt (vgx_quad.hip keeps it; other kernels do not)
     int C = 0, CB = 0;
     // host copies of what the host needs again
@@ -139,6 +142,22 @@ static int fail(vgx_engine *e, int code, const std::string &msg) {
     return code;
 }
 
+// Host-side loops over all compartments of a large state (2^28 at BASELINE config 4): f(first, last, part) on up to 16 threads
+// (n items of `weight` elementary operations each; small jobs stay on the calling thread)
+template <class F>
+static void for_parts(int64_t n, F f, int64_t weight = 1) {
+    unsigned nt = (unsigned)std::min<int64_t>(std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16u), std::max<int64_t>(n, 1));
+    if (n * weight < ((int64_t)1 << 22)) nt = 1;
+    if (nt == 1) { f((int64_t)0, n, 0u); return; }
+    std::vector<std::thread> th;
+    const int64_t step = (n + nt - 1) / nt;
+    for (unsigned t = 0; t < nt; t++) {
+        const int64_t b = std::min<int64_t>(n, (int64_t)t * step), en = std::min<int64_t>(n, b + step);
+        th.emplace_back([=]() { f(b, en, t); });
+    }
+    for (auto &x : th) x.join();
+}
+
 static int ensure(vgx_engine *e, DevBuf &b, size_t bytes) {
     if (bytes == 0) bytes = 8;
     if (b.bytes >= bytes) return VGX_OK;
@@ -206,6 +225,10 @@ extern "C" void vgx_destroy(vgx_engine *e) {
     (void)hipStreamSynchronize(e->stream);
     for (DevBuf *b : e->all)
         if (b->p) (void)hipFree(b->p);
+    for (int i = 0; i < 2; i++) {
+        if (e->pin[i]) (void)hipHostFree(e->pin[i]);
+        if (e->pin_ev[i]) (void)hipEventDestroy(e->pin_ev[i]);
+    }
     if (e->ev0) (void)hipEventDestroy(e->ev0);
     if (e->ev1) (void)hipEventDestroy(e->ev1);
     if (e->stream) (void)hipStreamDestroy(e->stream);
@@ -525,20 +548,23 @@ static void prepare_first(vgx_engine *e) {
             }
         }
         h.globalInfectious = 0;
-        for (int64_t pn = 0; pn < P; pn++) {
-            h.totalSusceptible[(size_t)pn] = 0;
-            for (int64_t sn = 0; sn < S; sn++) {
-                h.initial_susceptible[(size_t)(pn * S + sn)] = h.susceptible[(size_t)(pn * S + sn)];
-                h.totalSusceptible[(size_t)pn] += h.susceptible[(size_t)(pn * S + sn)];
+        for_parts(P, [&](int64_t p0, int64_t p1, unsigned) {   // whole populations per thread
+            for (int64_t pn = p0; pn < p1; pn++) {
+                h.totalSusceptible[(size_t)pn] = 0;
+                for (int64_t sn = 0; sn < S; sn++) {
+                    h.initial_susceptible[(size_t)(pn * S + sn)] = h.susceptible[(size_t)(pn * S + sn)];
+                    h.totalSusceptible[(size_t)pn] += h.susceptible[(size_t)(pn * S + sn)];
+                }
+                int64_t t = 0;
+                for (int64_t hn = 0; hn < H; hn++) {
+                    const int64_t v = h.infectious[(size_t)(pn * H + hn)];
+                    h.initial_infectious[(size_t)(pn * H + hn)] = v;
+                    t += v;
+                }
+                h.totalInfectious[(size_t)pn] = t;
             }
-            h.totalInfectious[(size_t)pn] = 0;
-            for (int64_t hn = 0; hn < H; hn++) {
-                int64_t v = h.infectious[(size_t)(pn * H + hn)];
-                h.initial_infectious[(size_t)(pn * H + hn)] = v;
-                h.totalInfectious[(size_t)pn] += v;
-                h.globalInfectious += v;
-            }
-        }
+        }, H);
+        for (int64_t pn = 0; pn < P; pn++) h.globalInfectious += h.totalInfectious[(size_t)pn];
         h.first_simulation = 1;
     }
 }
@@ -837,23 +863,8 @@ static int direct_core(vgx_engine *e, int64_t iterations, int64_t sample_size, f
 }
 
 // ------------------------------------------------------------------------------------------------
+#define VGX_PIN_BYTES ((int64_t)64 << 20)
 static bool sites_ok16(const vgx_engine *e) { return e->d.sites <= 16; }
-
-// Host-side loops over all compartments of a large state (2^28 at BASELINE config 4): f(first, last, part) on up to 16 threads
-// (n items of `weight` elementary operations each; small jobs stay on the calling thread)
-template <class F>
-static void for_parts(int64_t n, F f, int64_t weight = 1) {
-    unsigned nt = (unsigned)std::min<int64_t>(std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16u), std::max<int64_t>(n, 1));
-    if (n * weight < ((int64_t)1 << 22)) nt = 1;
-    if (nt == 1) { f((int64_t)0, n, 0u); return; }
-    std::vector<std::thread> th;
-    const int64_t step = (n + nt - 1) / nt;
-    for (unsigned t = 0; t < nt; t++) {
-        const int64_t b = std::min<int64_t>(n, (int64_t)t * step), en = std::min<int64_t>(n, b + step);
-        th.emplace_back([=]() { f(b, en, t); });
-    }
-    for (auto &x : th) x.join();
-}
 
 // SimulatePopulation_tau (pyx:2293-2346): the step loop runs on the host, the steps on the device.
 template <typename T>
@@ -886,11 +897,21 @@ extern "C" int vgx_simulate_tau(vgx_engine *e, int64_t iterations, int64_t sampl
     // occupied states the direct kernel does that preparation exactly (run with zero attempts); for densely
     // occupied large states (its exact, lane-ordered row sums would take seconds) the lockdown switches and the
     // non-zero test are done on the host and totalRate is reported as NaN (the reference leaves a stale value).
+    // VGX_TIMING=1: host-side phases of the call on stderr (diagnostics)
+    const bool timing = getenv("VGX_TIMING") != nullptr;
+    auto t_last = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!timing) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "vgx_simulate_tau: %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+        t_last = now;
+    };
     e->dev_state_valid = false;
     e->tau_loc_time.assign((size_t)R, {});
     e->tau_loc_state.assign((size_t)R, {});
     e->tau_loc_pop.assign((size_t)R, {});
     prepare_first(e);
+    lap("first-call snapshot");
     int64_t occupied = 0;
     {
         int64_t part[16] = {0};
@@ -901,6 +922,7 @@ extern "C" int vgx_simulate_tau(vgx_engine *e, int64_t iterations, int64_t sampl
         });
         for (int t = 0; t < 16; t++) occupied += part[t];
     }
+    lap("count of occupied");
     bool rates_nonzero = false;
     int rc = 0;
     if (occupied <= ((int64_t)1 << 18)) {
@@ -977,6 +999,7 @@ extern "C" int vgx_simulate_tau(vgx_engine *e, int64_t iterations, int64_t sampl
             if (e->suscepCumul[(size_t)sn] * (double)h.initial_susceptible[(size_t)(pn * S + sn)] != 0.0) rates_nonzero_initial = true;
     }
 
+    lap("PrepareParameters");
     // ---- device arrays ----
     // multievent rows (num > 0 only): at most a few per occupied compartment and step; sized from the start state with
     // room for the epidemic to grow, within 2^27 rows (6 GiB) per replicate; a run that still outgrows it fails loudly
@@ -1062,6 +1085,7 @@ extern "C" int vgx_simulate_tau(vgx_engine *e, int64_t iterations, int64_t sampl
     }
     rc |= upload(e, e->r_seeds, e->seeds.data(), e->seeds.size());
     if (rc) return VGX_ERR_HIP;
+    lap("device allocations");
     HIPCHECK(e, hipMemset(e->t_incn.p, 0, (size_t)R * VGX_INC_SHARDS * 8));
     HIPCHECK(e, hipMemset(e->t_stkey.p, 0, (size_t)(R * st_size) * 8));   // try counter 0: every slot reads as empty
     HIPCHECK(e, hipMemset(e->t_dChkTot.p, 0, (size_t)(R * P) * 8));
@@ -1081,18 +1105,41 @@ extern "C" int vgx_simulate_tau(vgx_engine *e, int64_t iterations, int64_t sampl
     std::vector<int32_t> lock32((size_t)P);
     for (int64_t pn = 0; pn < P; pn++) lock32[(size_t)pn] = (int32_t)h.lockdownON[(size_t)pn];
     auto upload_state = [&](int64_t r, const std::vector<int64_t> &inf, const std::vector<int64_t> &sus) -> int {
+        // device layout: 4 bytes per compartment (sizes < 2^31, checked above).  Large states are converted chunk by chunk
+        // into two pinned staging buffers, the copy of one chunk overlapping the conversion of the next.
+        const int64_t n = P * H;
         std::vector<int64_t> tot((size_t)P, 0);
-        std::vector<int32_t> inf32((size_t)(P * H));   // device layout: 4 bytes per compartment (sizes < 2^31, checked above)
         for_parts(P, [&](int64_t p0, int64_t p1, unsigned) {   // whole populations per thread
             for (int64_t pn = p0; pn < p1; pn++) {
                 int64_t t = 0;
                 const int64_t *src = &inf[(size_t)(pn * H)];
-                int32_t *dst = &inf32[(size_t)(pn * H)];
-                for (int64_t hn = 0; hn < H; hn++) { t += src[hn]; dst[hn] = (int32_t)src[hn]; }
+                for (int64_t hn = 0; hn < H; hn++) t += src[hn];
                 tot[(size_t)pn] = t;
             }
         }, H);
-        HIPCHECK(e, hipMemcpy((int32_t *)e->t_I.p + r * P * H, inf32.data(), (size_t)(P * H) * 4, hipMemcpyHostToDevice));
+        int32_t *dst = (int32_t *)e->t_I.p + r * n;
+        const int64_t chunk = VGX_PIN_BYTES / 4;
+        if (n >= chunk) {
+            for (int i = 0; i < 2; i++) {
+                if (!e->pin[i]) HIPCHECK(e, hipHostMalloc(&e->pin[i], VGX_PIN_BYTES, hipHostMallocDefault));
+                if (!e->pin_ev[i]) HIPCHECK(e, hipEventCreateWithFlags(&e->pin_ev[i], hipEventDisableTiming));
+            }
+            int k = 0;
+            for (int64_t c0 = 0; c0 < n; c0 += chunk, k ^= 1) {
+                const int64_t len = std::min<int64_t>(chunk, n - c0);
+                if (c0 >= 2 * chunk) HIPCHECK(e, hipEventSynchronize(e->pin_ev[k]));   // the buffer's previous copy is through
+                int32_t *buf = (int32_t *)e->pin[k];
+                const int64_t *src = inf.data() + c0;
+                for_parts(len, [&](int64_t b, int64_t en, unsigned) { for (int64_t i = b; i < en; i++) buf[i] = (int32_t)src[i]; });
+                HIPCHECK(e, hipMemcpyAsync(dst + c0, buf, (size_t)len * 4, hipMemcpyHostToDevice, e->stream));
+                HIPCHECK(e, hipEventRecord(e->pin_ev[k], e->stream));
+            }
+            HIPCHECK(e, hipStreamSynchronize(e->stream));
+        } else {
+            std::vector<int32_t> inf32((size_t)n);
+            for (int64_t i = 0; i < n; i++) inf32[(size_t)i] = (int32_t)inf[(size_t)i];
+            HIPCHECK(e, hipMemcpy(dst, inf32.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+        }
         HIPCHECK(e, hipMemcpy((int64_t *)e->t_S.p + r * P * S, sus.data(), (size_t)(P * S) * 8, hipMemcpyHostToDevice));
         HIPCHECK(e, hipMemcpy((int64_t *)e->t_totInf.p + r * P, tot.data(), (size_t)P * 8, hipMemcpyHostToDevice));
         return VGX_OK;
@@ -1104,6 +1151,7 @@ extern "C" int vgx_simulate_tau(vgx_engine *e, int64_t iterations, int64_t sampl
         HIPCHECK(e, hipMemcpy((int32_t *)e->t_lock.p + r * P, lock32.data(), (size_t)P * 4, hipMemcpyHostToDevice));
     }
 
+    lap("memsets + state upload");
     VgxTauArgs a{};
     a.p = e->dp;
     a.R = R;
@@ -1449,6 +1497,7 @@ extern "C" int vgx_simulate_tau(vgx_engine *e, int64_t iterations, int64_t sampl
         }
     }
 
+    lap("step loop");
     // ---- results ----
     std::vector<unsigned long long> locn((size_t)R);
     HIPCHECK(e, hipMemcpy(locn.data(), a.loc_n, (size_t)R * 8, hipMemcpyDeviceToHost));
