@@ -10,6 +10,7 @@
 #include <string.h>
 #include <algorithm>
 #include <cmath>
+#include <memory>
 #include <string>
 #include <chrono>
 #include <thread>
@@ -1824,9 +1825,11 @@ extern "C" int vgx_get_state(vgx_engine *e, int64_t replicate, vgx_state *out) {
         HostState &h = e->hs;
         if (out->susceptible) HIPCHECK(e, hipMemcpy(out->susceptible, (int64_t *)e->t_S.p + replicate * P * S, (size_t)(P * S) * 8, hipMemcpyDeviceToHost));
         if (out->infectious) {
-            std::vector<int32_t> inf32((size_t)(P * H));
-            HIPCHECK(e, hipMemcpy(inf32.data(), (int32_t *)e->t_I.p + replicate * P * H, (size_t)(P * H) * 4, hipMemcpyDeviceToHost));
-            for (int64_t i = 0; i < P * H; i++) out->infectious[i] = inf32[(size_t)i];
+            std::unique_ptr<int32_t[]> inf32(new int32_t[(size_t)(P * H)]);   // (not zero-filled: it is overwritten at once)
+            HIPCHECK(e, hipMemcpy(inf32.get(), (int32_t *)e->t_I.p + replicate * P * H, (size_t)(P * H) * 4, hipMemcpyDeviceToHost));
+            int64_t *dst = out->infectious;
+            const int32_t *src = inf32.get();
+            for_parts(P * H, [&](int64_t b0, int64_t en, unsigned) { for (int64_t i = b0; i < en; i++) dst[i] = src[i]; });
         }
         if (out->initial_susceptible) memcpy(out->initial_susceptible, h.initial_susceptible.data(), (size_t)(P * S) * 8);
         if (out->initial_infectious) memcpy(out->initial_infectious, h.initial_infectious.data(), (size_t)(P * H) * 8);
