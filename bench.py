@@ -286,6 +286,13 @@ def fast_leg(device, replicates, events, traj_points):
     out = {"workload": "headline workload in FAST mode (order-free sums, same PCG64 stream)",
            "value": res.total_events / (res.kernel_ms * 1e-3), "unit": "events/s (device time)",
            "kernel_ms_per_launch": res.kernel_ms}
+    # the same with the counter-based random stream (vgx_run_opts.mode = 2: Philox4x32-10, every draw formed on its own)
+    for it in range(2):
+        res = ens.simulate(events, sample_size=10 ** 12, record_events=True, traj_points=traj_points,
+                           traj_window=(0.0, 12.0), seeds=2020 + it * replicates + np.arange(replicates, dtype=np.int64),
+                           mode="fast_philox")
+    out["philox_stream"] = {"value": res.total_events / (res.kernel_ms * 1e-3), "unit": "events/s (device time)",
+                            "kernel_ms_per_launch": res.kernel_ms}
     ens.close()
     return out
 

@@ -85,7 +85,10 @@ typedef struct vgx_run_opts {
     int64_t mode;            /* direct path: 0 = EXACT (the reference's floating-point summation order, bit-exact log);
                                 1 = FAST (order-free sums: class-aggregated infection rate, integer prefix search,
                                 factored BirthRate, tree scans; same random stream and event semantics, identical
-                                integer columns on the same seed).  Ignored by vgx_simulate_tau. */
+                                integer columns on the same seed); 2 = FAST with a counter-based random stream
+                                (Philox4x32-10 keyed by the seed, counter = (draw index, attempt): every draw can be formed
+                                on its own; other numbers than PCG64's, so another trajectory of the same law).  Ignored by
+                                vgx_simulate_tau. */
     int64_t kernel;          /* direct path: 0 = automatic, 1 = one replicate per wavefront (vgx_direct.hip), 2 = one replicate
                                 per lane (vgx_lanes.hip; small models: popNum <= 16, popNum*hapNum <= 1024, susNum <= 8, EXACT),
                                 3 = four replicates per wavefront, one per 16-lane row (vgx_quad.hip; EXACT, popNum <= 64, one

@@ -16,6 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB = os.environ.get("VGX_ORACLE_LIBRARY") or os.path.join(HERE, "libvgx_oracle.so")
 
 LOG_LIBM, LOG_PORTABLE = 0, 1
+RNG_PHILOX = 16   # flag for log_mode: the direct path draws from the engine's counter-based stream (vgx_oracle.h)
 
 _F = C.POINTER(C.c_double)
 _I = C.POINTER(C.c_int64)

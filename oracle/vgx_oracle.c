@@ -387,7 +387,30 @@ done:
 /* =====================================================================================
  * State helpers
  * ===================================================================================== */
-typedef struct { vgo_pcg64 g; } rng_t;
+typedef struct { vgo_pcg64 g; int philox; uint64_t seed, n; uint32_t att; } rng_t;
+
+/* Philox4x32-10 (Salmon et al. 2011) and the engine's counter-based stream on top of it (FAST mode 2 of libvgx: output n of
+ * (seed, attempt) = low / high 64 bits of the block with counter (n >> 1, attempt, 'VGXs') and the seed's halves as key).
+ * Test infrastructure only: the reference has no such stream. */
+static void philox4x32(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+    uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3], k0 = key[0], k1 = key[1];
+    for (int r = 0; r < 10; r++) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+static double rng_uniform(rng_t *r) {
+    if (!r->philox) return vgo_pcg64_double(&r->g);
+    uint64_t blk = r->n >> 1;
+    uint32_t ctr[4] = {(uint32_t)blk, (uint32_t)(blk >> 32), r->att, 0x56475873u}, key[2] = {(uint32_t)r->seed, (uint32_t)(r->seed >> 32)}, o[4];
+    philox4x32(ctr, key, o);
+    uint64_t v = (r->n & 1) ? (((uint64_t)o[3] << 32) | o[2]) : (((uint64_t)o[1] << 32) | o[0]);
+    r->n += 1;
+    return (double)(v >> 11) * (1.0 / 9007199254740992.0);
+}
 
 static inline void NewInfections(vgo_model *m, int64_t pi, int64_t si, int64_t hi, int64_t num) { /* pyx:246-251 */
     IDX2(m->susceptible, pi, si, S_) -= num;
@@ -719,7 +742,7 @@ static int64_t GenerateMigration(vgo_model *m) { /* pyx:672-694 */
 static int64_t GenerateEvent(vgo_model *m, rng_t *r) { /* pyx:483-512 */
     int64_t pi;
     double choose;
-    m->rn = vgo_pcg64_double(&r->g);
+    m->rn = rng_uniform(r);
     choose = m->rn * (m->totalRate + m->totalMigrationRate);
     if (m->totalRate > choose) {
         m->rn = choose / m->totalRate;
@@ -816,12 +839,13 @@ int vgo_simulate_direct(vgo_model *m, int64_t iterations, int64_t sample_size, f
     PrepareParameters(m);
     for (int64_t i = 0; i < attempts; i++) {
         vgo_pcg64_seed(&r.g, (uint64_t)m->user_seed, (uint32_t)i);
+        r.philox = (m->log_mode & VGO_RNG_PHILOX) ? 1 : 0; r.seed = (uint64_t)m->user_seed; r.att = (uint32_t)i; r.n = 0;
         if (m->totalRate + m->totalMigrationRate != 0.0 && m->globalInfectious != 0) {
             while (m->ev_ptr < m->ev_size && (sample_size == -1 || m->sCounter <= sample_size) &&
                    (time == -1 || m->currentTime < time)) {
                 /* SampleTime pyx:476-478 */
-                double u = vgo_pcg64_double(&r.g);
-                double lg = (m->log_mode == VGO_LOG_PORTABLE) ? vgo_portable_log(u) : log(u);
+                double u = rng_uniform(&r);
+                double lg = ((m->log_mode & 15) == VGO_LOG_PORTABLE) ? vgo_portable_log(u) : log(u);
                 double tau = -lg / (m->totalRate + m->totalMigrationRate);
                 m->currentTime += tau;
                 int64_t pi = GenerateEvent(m, &r);
@@ -1076,6 +1100,7 @@ static void UpdateCompartmentCounts_tau(vgo_model *m, tau_arrays *A) { /* pyx:25
 
 int vgo_simulate_tau(vgo_model *m, int64_t iterations, int64_t sample_size, float time, int64_t attempts) { /* pyx:2293-2346 */
     rng_t r;
+    r.philox = 0; r.seed = 0; r.n = 0; r.att = 0;   /* (tau draws from PCG64 through vgo_poisson) */
     tau_arrays A;
     int64_t sparse_saved = m->sparse;
     m->sparse = 0; /* tau walks every channel; the bitmap is not maintained here */

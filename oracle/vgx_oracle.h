@@ -36,7 +36,10 @@ enum { VGO_OK = 0, VGO_ERR_ZERO_WEIGHT = 1, VGO_ERR_LOCKDOWN_LOG_FULL = 2, VGO_E
        VGO_ERR_BAD_ARG = 4 };
 
 enum { VGO_LOG_LIBM = 0,     /* host libm log(): what the reference calls (pyx:477) */
-       VGO_LOG_PORTABLE = 1  /* self-contained fdlibm-style log, bit-identical to the device kernel's */ };
+       VGO_LOG_PORTABLE = 1, /* self-contained fdlibm-style log, bit-identical to the device kernel's */
+       /* flag in the same field (not a reference behaviour): the direct path draws its uniforms from the counter-based
+          Philox stream of the engine's FAST mode 2 (include/vgx.h) instead of PCG64, to check that mode draw for draw */
+       VGO_RNG_PHILOX = 16 };
 
 typedef struct vgo_model {
     /* ---- dimensions (pyx:84-90) ---- */

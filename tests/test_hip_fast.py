@@ -67,3 +67,38 @@ def test_fast_ensemble_matches_exact_ensemble():
     for a, b in zip(e[4], f[4]):
         assert np.array_equal(a, b)
     assert np.array_equal(e[5], f[5])
+
+
+# ---- FAST mode with the counter-based random stream (vgx_run_opts.mode = 2) -------------------------------------------
+# Other random numbers than the reference's, so the chain cannot equal a reference fixture; the checker is the oracle fed
+# with the same Philox stream (oracle.RNG_PHILOX: the two uniform draws of an iteration come from outputs 2 i and 2 i + 1
+# of the stream of (seed, attempt)).  Same tier as FAST: integer columns, counters and compartments identical, times 1e-9.
+@pytest.mark.parametrize("name", DIRECT)
+def test_fast_philox_matches_oracle_on_the_same_stream(oracle_mod, name):
+    hip = helpers.run_case_hip(name, mode="fast_philox").simulation
+    ref = helpers.run_case_oracle(oracle_mod, name, log_mode=oracle_mod.RNG_PHILOX).simulation
+    _assert_tier_b(hip, ref, name)
+
+
+def test_fast_philox_is_another_trajectory_of_the_same_model():
+    """Not the PCG64 chain, reproducible, and the stream's definition: the first uniform of an attempt is the low half of
+    the Philox block with counter (0, 0, attempt, 'VGXs') and the seed as key."""
+    import ctypes as C
+    from vgsim_amd import _capi
+    a = helpers.run_case_hip("g1", mode="fast_philox").simulation
+    b = helpers.run_case_hip("g1", mode="fast_philox").simulation
+    c = helpers.run_case_hip("g1", mode="fast").simulation
+    assert np.array_equal(helpers.chain_of(a), helpers.chain_of(b))
+    assert not np.array_equal(helpers.chain_of(a)[1:, :a.events.ptr], helpers.chain_of(c)[1:, :c.events.ptr])
+    lib = _capi.load_library()
+    # (the attempt that succeeded: earlier ones went extinct within 100 events and were restarted, pyx:414-418)
+    att_a, att_c = a.good_attempt - 1, c.good_attempt - 1
+    ctr, key, o = (C.c_uint32 * 4)(0, 0, att_a, 0x56475873), (C.c_uint32 * 2)(a.user_seed & 0xFFFFFFFF, a.user_seed >> 32), (C.c_uint32 * 4)()
+    assert lib.vgx_test_philox(0, C.byref(ctr), C.byref(key), C.byref(o)) == 0
+    u0 = float(((o[1] << 32) | o[0]) >> 11) / 2.0 ** 53
+    # the first event's time is -log(u0) / (totalRate + totalMigrationRate) with the start state's rates: the same
+    # denominator the PCG64 run divided by
+    seq = np.random.Generator(np.random.PCG64(np.random.SeedSequence(c.user_seed, spawn_key=(att_c,))))
+    u0_pcg = seq.random()
+    ta, tc = helpers.chain_of(a)[0, 0], helpers.chain_of(c)[0, 0]
+    assert ta / tc == pytest.approx(np.log(u0) / np.log(u0_pcg), rel=1e-9)

@@ -311,19 +311,19 @@ class BirthDeathModel(ParameterTable, Reporting):
         vgx_run_opts.mode).  ``kernel``: 'auto', 'wave' (one replicate per wavefront), 'quad' (four per wavefront, one per
         16-lane row; one rate class) or 'lane' (one replicate per lane, small models; vgx_run_opts.kernel)."""
         self._check_supported()
-        if mode not in ('exact', 'fast'):
-            raise ValueError("mode must be 'exact' or 'fast'")
+        if mode not in ('exact', 'fast', 'fast_philox'):
+            raise ValueError("mode must be 'exact', 'fast' or 'fast_philox'")
         if kernel not in ('auto', 'wave', 'lane', 'quad'):
             raise ValueError("kernel must be 'auto', 'wave', 'lane' or 'quad'")
         self.events.CreateEvents(iterations)
         self.CheckSizes()
         time = float(np.float32(time))  # `float time` in the reference signature
         opts = None
-        if mode == 'fast' or kernel != 'auto':
+        if mode != 'exact' or kernel != 'auto':
             from . import _capi
             opts = _capi.VgxRunOpts()
             opts.record_events = 1
-            opts.mode = 1 if mode == 'fast' else 0
+            opts.mode = {'exact': 0, 'fast': 1, 'fast_philox': 2}[mode]
             opts.kernel = {'auto': 0, 'wave': 1, 'lane': 2, 'quad': 3}[kernel]
         eng = self._get_engine()
         eng.simulate_direct(self, iterations, sample_size, time, attempts, opts)

@@ -66,6 +66,7 @@ struct vgx_engine {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::string err;
     bool have_params = false, have_state = false, dev_state_valid = false;
+    bool call_philox = false;      // the last direct call drew from the counter-based stream (the host clock must too)
     int64_t start_max_nocc = 0;    // longest occupancy list of the state last uploaded
     void *pin[2] = {nullptr, nullptr};   // pinned staging buffers of large uploads (VGX_PIN_BYTES each), allocated on first use
     hipEvent_t pin_ev[2] = {nullptr, nullptr};
@@ -692,7 +693,7 @@ static int direct_core(vgx_engine *e, int64_t iterations, int64_t sample_size, f
     o.record_events = 1;
     if (opts) o = *opts;
     if (o.max_loop_factor <= 0) o.max_loop_factor = 1024;
-    if (o.mode != 0 && o.mode != 1) return fail(e, VGX_ERR_ARG, "vgx_simulate_direct: mode must be 0 (exact) or 1 (fast)");
+    if (o.mode < 0 || o.mode > 2) return fail(e, VGX_ERR_ARG, "vgx_simulate_direct: mode must be 0 (exact), 1 (fast) or 2 (fast, Philox stream)");
     size_t lds = lds_bytes_for(e);
     if (lds > 160 * 1024)
         return fail(e, VGX_ERR_ARG, "vgx_simulate_direct: the population/class tables need " + std::to_string(lds) +
@@ -762,7 +763,9 @@ static int direct_core(vgx_engine *e, int64_t iterations, int64_t sample_size, f
     a.ev_size = ev_size;
     a.max_loop = o.max_loop_factor * std::max<int64_t>(iterations, 1) + (1 << 20);
     a.record_events = o.record_events ? 1 : 0;
-    a.fast = o.mode == 1 ? 1 : 0;
+    a.fast = o.mode >= 1 ? 1 : 0;
+    a.rng_philox = o.mode == 2 ? 1 : 0;
+    e->call_philox = o.mode == 2;
     a.lds_bytes = (int32_t)lds;
 
     // Kernel choice: small models run one replicate per LANE (vgx_lanes.hip: the reference's serial loops, dense state);
@@ -1559,13 +1562,25 @@ extern "C" int vgx_simulate_tau(vgx_engine *e, int64_t iterations, int64_t sampl
 // denominator unchanged, so every iteration between two records uses the later record's denominator.
 struct ClockRun {      // accumulates one attempt's clock
     VgxPcg64 g;
+    bool philox = false;   // the call drew from the counter-based stream: iteration i took outputs 2 i (time) and 2 i + 1 (event)
+    uint64_t seed_ = 0;
+    uint32_t att_ = 0;
     int64_t iter = 0;
     double t = 0.0;
-    void open(int64_t seed, int64_t attempt, double t0) { vgx_pcg64_seed(g, (uint64_t)seed, (uint32_t)attempt); iter = 0; t = t0; }
+    void open(int64_t seed, int64_t attempt, double t0) {
+        vgx_pcg64_seed(g, (uint64_t)seed, (uint32_t)attempt);
+        seed_ = (uint64_t)seed; att_ = (uint32_t)attempt;
+        iter = 0; t = t0;
+    }
     void advance(int64_t to_iter, double rate) {
         while (iter < to_iter) {
-            double u = vgx_pcg64_double(g);
-            (void)vgx_pcg64_next(g);                 // the event's own uniform (pyx:488)
+            double u;
+            if (philox) {
+                u = vgx_philox_stream_double(seed_, att_, 2 * (uint64_t)iter);
+            } else {
+                u = vgx_pcg64_double(g);
+                (void)vgx_pcg64_next(g);             // the event's own uniform (pyx:488)
+            }
             t += -std::log(u) / rate;
             iter++;
         }
@@ -1613,6 +1628,7 @@ static int host_clock(vgx_engine *e, int64_t rep) {
         while (k < nfa) {
             const int64_t att = fk[(size_t)k] >> 40;
             ClockRun c;
+            c.philox = e->call_philox;
             c.open(seed, att, att == 0 ? t_call : 0.0);
             for (; k < nfa && (fk[(size_t)k] >> 40) == att; k++) {
                 c.advance(fk[(size_t)k] & IT, fr[(size_t)k]);
@@ -1637,6 +1653,7 @@ static int host_clock(vgx_engine *e, int64_t rep) {
                                   (size_t)n * VGX_EV_COLS * 4, hipMemcpyDeviceToHost));
         }
         ClockRun c;
+        c.philox = e->call_philox;
         c.open(seed, s.last_attempt, rewound ? 0.0 : t_call);
         hc.times.resize((size_t)n);
         int64_t li = 0;

@@ -135,6 +135,7 @@ struct VgxDirectArgs {
     int32_t record_events;
     int32_t lds_bytes;
     int32_t fast;            // 0: reference summation order (bit-exact); 1: order-free sums (vgx_run_opts.mode)
+    int32_t rng_philox;      // FAST mode only: 1 = the counter-based Philox stream of vgx_rng.h instead of PCG64 (vgx_run_opts.mode = 2)
     int32_t pad_;
 };
 

@@ -67,6 +67,10 @@ struct RngBatch {
     uint64_t sh, sl, ih, il;   // stream position before the batch; increment
     double val;
     int pos;                   // iterations consumed from the current batch (32 = empty)
+    // counter-based variant (FAST mode, vgx_run_opts.mode = 2): outputs base .. base + 63 of vgx_philox_stream_*
+    int philox;
+    uint64_t seed, base;
+    uint32_t att;
 };
 static __device__ __forceinline__ void rng_init_lane(RngBatch &g, int lane) {
     const uint64_t MH = 0x2360ED051FC65DA4ull, ML = 0x4385DF649FCCF645ull;
@@ -86,8 +90,16 @@ static __device__ __forceinline__ void rng_seed(RngBatch &g, uint64_t seed, uint
     vgx_pcg64_seed(s, seed, attempt);
     g.sh = s.sh; g.sl = s.sl; g.ih = s.ih; g.il = s.il;
     g.pos = 32;
+    g.seed = seed; g.att = attempt; g.base = 0;
 }
 static __device__ __forceinline__ void rng_refill(RngBatch &g, int lane) {
+    if (g.philox) {   // every lane forms its own output of the counter-based stream
+        const double u = vgx_philox_stream_double(g.seed, g.att, g.base + (uint64_t)lane);
+        g.val = (lane & 1) ? u : -vgx_log(u);
+        g.base += LANES;
+        g.pos = 0;
+        return;
+    }
     uint64_t h, l, ch, cl;
     vgx_mul128(g.Ah, g.Al, g.sh, g.sl, h, l);
     vgx_mul128(g.Gh, g.Gl, g.ih, g.il, ch, cl);
@@ -1203,6 +1215,7 @@ static __device__ __forceinline__ void direct_body(const VgxDirectArgs &a) {
     int64_t att_ev0 = sc->ev_ptr, att_loc0 = 0, fa_n = 0;   // first log index / lockdown record of the current attempt
     RngBatch g;
     rng_init_lane(g, lane);
+    g.philox = a.rng_philox;
     g.sh = g.sl = g.ih = g.il = 0;
     g.val = 0.0;
 

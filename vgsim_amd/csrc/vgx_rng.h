@@ -136,6 +136,23 @@ VGX_HD void vgx_philox4x32(const uint32_t ctr[4], const uint32_t key[2], uint32_
     out[0] = c[0]; out[1] = c[1]; out[2] = c[2]; out[3] = c[3];
 }
 
+// ---- counter-based uniform stream (FAST mode with vgx_run_opts.mode = 2) ---------------------------
+// Output number n = 0, 1, ... of the stream of (seed, attempt): the low (n even) / high (n odd) 64 bits of Philox4x32-10
+// with counter (n >> 1 as two words, attempt, 'VGXs') and the seed's two halves as key; as a double like PCG64's outputs
+// (top 53 bits).  Any output can be formed independently of the others: a wavefront's lanes fill a batch without the
+// 128-bit jump-ahead arithmetic of the PCG64 stream, and the host clock regenerates single uniforms.
+VGX_HD uint64_t vgx_philox_stream_u64(uint64_t seed, uint32_t attempt, uint64_t n) {
+    const uint64_t blk = n >> 1;
+    const uint32_t ctr[4] = {(uint32_t)blk, (uint32_t)(blk >> 32), attempt, 0x56475873u};
+    const uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+    uint32_t o[4];
+    vgx_philox4x32(ctr, key, o);
+    return (n & 1) ? (((uint64_t)o[3] << 32) | o[2]) : (((uint64_t)o[1] << 32) | o[0]);
+}
+VGX_HD double vgx_philox_stream_double(uint64_t seed, uint32_t attempt, uint64_t n) {
+    return (double)(vgx_philox_stream_u64(seed, attempt, n) >> 11) * (1.0 / 9007199254740992.0);
+}
+
 // ---- portable natural logarithm ------------------------------------------------------------------
 // fdlibm e_log.c algorithm (argument reduction to [sqrt(2)/2, sqrt(2)], s = f/(2+f), degree-14 even
 // polynomial; < 1 ulp).  Only +,-,*,/ on binary64 and no contraction, so host and device agree bit for

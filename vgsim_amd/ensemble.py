@@ -50,8 +50,8 @@ class Ensemble:
         """Direct Gillespie for every replicate from the model's current state (``SimulatePopulation`` semantics
         per replicate, pyx:396-429).  ``mode``: 'exact' (reference summation order, bit-exact) or 'fast'
         (order-free sums).  Returns an :class:`EnsembleResult`."""
-        if mode not in ('exact', 'fast'):
-            raise ValueError("mode must be 'exact' or 'fast'")
+        if mode not in ('exact', 'fast', 'fast_philox'):
+            raise ValueError("mode must be 'exact', 'fast' or 'fast_philox'")
         m, eng = self.model, self.engine
         if seeds is not None:
             self.seeds = np.ascontiguousarray(seeds, dtype=np.int64)
@@ -74,7 +74,7 @@ class Ensemble:
         o.record_events = 1 if record_events else 0
         o.traj_points = int(traj_points)
         o.traj_t0, o.traj_t1 = float(traj_window[0]), float(traj_window[1])
-        o.mode = 1 if mode == 'fast' else 0
+        o.mode = {'exact': 0, 'fast': 1, 'fast_philox': 2}[mode]
         o.kernel = {'auto': 0, 'wave': 1, 'lane': 2, 'quad': 3}[kernel]
         rc = eng.lib.vgx_simulate_direct(eng.handle, int(iterations), int(sample_size), float(np.float32(epidemic_time)),
                                          int(attempts), C.byref(o))
