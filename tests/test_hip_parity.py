@@ -42,12 +42,23 @@ def test_lane_kernel_bit_exact_vs_oracle(oracle_mod, name):
     helpers.assert_models_equal(hip, ref, name)
 
 
-def test_recombination_is_refused_by_the_wave_kernel_and_fast_mode():
+@pytest.mark.parametrize("name", models.RECOMBINATION_CASES)
+def test_recombination_on_the_wave_kernel_bit_exact_vs_oracle(oracle_mod, name):
+    """Recombinant births (pyx:575-596) on the occupancy-list kernel (what large haplotype spaces use): the second parent is
+    chosen over the list in haplotype order with the reference's weights; log, records, counters and state equal the
+    oracle's, which is pinned on fixtures recorded from the reference."""
+    hip = helpers.run_case_hip(name, kernel="wave").simulation
+    ref = helpers.run_case_oracle(oracle_mod, name).simulation
+    helpers.assert_models_equal(hip, ref, name)
+    assert len(hip.rec.his) > 0
+
+
+def test_recombination_is_refused_in_fast_mode():
     from vgsim_amd._capi import VgxError
     with helpers.quiet():
         sim, phases = models.build(__import__("vgsim_amd").Simulator, "recomb_a")
         phases[0][0](sim)
-    for kw in (dict(kernel="wave"), dict(mode="fast")):
+    for kw in (dict(mode="fast"), dict(mode="fast_philox")):
         with pytest.raises(VgxError), helpers.quiet():
             sim.simulate(100, **kw)
     assert len(helpers.run_case_hip("recomb_a").simulation.rec.his) > 1000

@@ -453,7 +453,7 @@ extern "C" int vgx_get_recombinations(vgx_engine *e, int64_t replicate, int64_t 
     if (!e || !n || replicate < 0 || replicate >= e->R) return VGX_ERR_ARG;
     if (!e->sc_host_valid) return fail(e, VGX_ERR_ARG, "vgx_get_recombinations: no simulate call yet");
     *n = 0;
-    if (e->last_was_tau || !e->last_used_lanes || e->rec_cap == 0) return VGX_OK;
+    if (e->last_was_tau || e->rec_cap == 0) return VGX_OK;   // (rec_cap is set by calls with recombination only)
     HIPCHECK(e, hipSetDevice(e->device));
     int64_t cnt = std::min<int64_t>(e->sc_host[(size_t)replicate].rec_n, e->rec_cap);
     *n = cnt;
@@ -771,20 +771,19 @@ static int direct_core(vgx_engine *e, int64_t iterations, int64_t sample_size, f
     // Kernel choice: small models run one replicate per LANE (vgx_lanes.hip: the reference's serial loops, dense state);
     // everything else one replicate per wavefront.  opts.kernel: 0 = automatic, 1 = wavefront, 2 = lane.
     const int64_t H = e->d.hapNum, S = e->d.susNum;
-    // Recombination (pyx:575-596) is implemented by the lane kernel only: serial, dense state, any shape whose dense
-    // arrays fit (upstream's recombinants carry a single site, so the option has no large-haplotype-space use).
+    // Recombination (pyx:575-596), exact mode only: the lane kernel (serial, dense state) while the dense arrays fit, the
+    // wavefront kernel (occupancy lists) beyond that and whenever it is asked for.
     const bool recomb = e->recombination != 0.0;
     const bool lane_ok = o.mode == 0 && (recomb ? P * H * std::max<int64_t>(S, 1) <= (1 << 24)
                                                 : (P * H <= 1024 && P <= 16 && S <= 8 && H <= e->cap));
-    if (recomb && (o.kernel == 1 || !lane_ok))
-        return fail(e, VGX_ERR_ARG, "vgx_simulate_direct: recombination runs on the lane-per-replicate kernel in exact "
-                                    "mode (popNum * hapNum * susNum <= 2^24)");
+    if (recomb && o.mode != 0)
+        return fail(e, VGX_ERR_ARG, "vgx_simulate_direct: recombination runs in exact mode only");
     if (o.kernel == 2 && !lane_ok)
         return fail(e, VGX_ERR_ARG, "vgx_simulate_direct: the lane-per-replicate kernel needs exact mode, popNum <= 16, "
                                     "popNum * hapNum <= 1024 and susNum <= 8");
     // measured (tools/probe_lanes.py): the lane kernel only wins for minimal models in very large ensembles (config 2 at
     // 262 144 replicates: 2.4e9 vs 7.0e8 events/s); its state lives in HBM/L2, so every other shape is latency-bound
-    const bool use_lanes = recomb || o.kernel == 2 || (o.kernel == 0 && lane_ok && P * H * S <= 4 && R >= 65536);
+    const bool use_lanes = (recomb && lane_ok && o.kernel != 1) || o.kernel == 2 || (o.kernel == 0 && lane_ok && P * H * S <= 4 && R >= 65536);
     // Four replicates per wavefront, one per 16-lane DPP row (vgx_quad.hip): one rate class, one susceptibility group,
     // at most 64 populations, no population that can switch its lockdown state, exact mode.
     bool quad_ok = o.mode == 0 && !recomb && P <= 64 && S == 1 && e->C == 1 && e->CB == 1 && !ld_possible &&

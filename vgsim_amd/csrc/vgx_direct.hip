@@ -148,6 +148,8 @@ struct Ctx {
     int64_t iter_key;  // (attempt << 40) | loop iteration of the attempt (0 outside the event loop)
     double *traj;
     int64_t traj_points, traj_next;
+    int64_t *rec;          // forward record of recombinant births [rec_cap][5] (models.pxi:69-89), or null
+    int64_t rec_cap, rec_n;
     double traj_t0, traj_dt;
     int64_t evcap, ev_base;
     int record_events;
@@ -896,6 +898,48 @@ static __device__ __forceinline__ void traj_emit(Ctx &c, double t_new, bool fina
 
 // ------------------------------------------------------------------------------------------------
 // One GenerateEvent (pyx:483-512): selects and applies the event, fills the deferred work.
+// The second parent of a recombinant birth (pyx:575-585): fastChoose over eventHapPopRate[pi, h, 0] * (infectious[pi, h] minus
+// the first parent's host) in haplotype order, on the occupancy list (empty haplotypes add +0.0 and cannot be the first index
+// at which the running sum reaches r > 0).  Recombinant births are rare: plain chunks of 64 entries, exact mode only.
+// Returns the haplotype; c.rn is rescaled as fast_choose.pxi:30 does.
+static __device__ __forceinline__ int recomb_partner(Ctx &c, int pi, int hi) {
+    const int lane = c.lane, n = c.nocc[pi];
+    const int32_t *lh = LH(c, pi), *lc = LC(c, pi);
+    const int64_t *ln = LN(c, pi);
+    auto weight = [&](int k) -> double {
+        if (k >= n) return 0.0;
+        return c.birthC[pi * c.CB + c.c_bidx[lc[k]]] * (double)(ln[k] - (lh[k] == hi ? 1 : 0));
+    };
+    double hs = 0.0;
+    for (int base = 0; base < n; base += LANES) hs = seq_sum(weight(base + lane), min(LANES, n - base), hs);
+    const double r = hs * c.rn;
+    if (!(0.0 < r) && !(n > 0 && lh[0] == 0)) { c.error = ERR_ZERO_WEIGHT; return 0; }   // the dense loop stops at haplotype 0
+    double carry = 0.0;
+    for (int base = 0; base < n; base += LANES) {
+        const int nn = min(LANES, n - base);
+        const double w = weight(base + lane);
+        const double pre = seq_scan(w, nn, carry);
+        const unsigned long long hit = __ballot(lane < nn && !(pre < r));
+        if (hit) {
+            const int j = __ffsll((long long)hit) - 1;
+            const double total = bcast(pre, j), wi = bcast(w, j);
+            if (wi == 0.0) { c.error = ERR_ZERO_WEIGHT; return 0; }
+            c.rn = (r - (total - wi)) / wi;
+            return lh[base + j];
+        }
+        carry = bcast(pre, nn - 1);
+    }
+    // rounding left the total below r: the dense loop ends at haplotype H - 1 (fast_choose.pxi:26)
+    if (n > 0 && lh[n - 1] == c.H - 1) {
+        const double wi = c.birthC[pi * c.CB + c.c_bidx[lc[n - 1]]] * (double)(ln[n - 1] - (lh[n - 1] == hi ? 1 : 0));
+        if (wi == 0.0) { c.error = ERR_ZERO_WEIGHT; return 0; }
+        c.rn = (r - (carry - wi)) / wi;
+        return c.H - 1;
+    }
+    c.error = ERR_ZERO_WEIGHT;
+    return 0;
+}
+
 static __device__ __forceinline__ int generate_event(Ctx &c, double u, Tile &t, UpdReq &q, ListOp &op0, ListOp &op1,
                                                      int &n_ops, EvRec &ev) {
     const VgxDevParams &p = *c.p;
@@ -947,6 +991,33 @@ static __device__ __forceinline__ int generate_event(Ctx &c, double u, Tile &t, 
                 double ws = 0.0;
                 for (int sn = 0; sn < S; ++sn) ws += x[sn];
                 int si = choose_serial(c, [&](int i) { return x[i]; }, S, ws, c.rn);
+                if (p.recombination != 0.0 && c.rn < p.recombination && c.totalInf[pi] > 1) {
+                    // ---- recombinant birth (pyx:575-596): the new host carries nhi, the event names both parents ----
+                    c.rn = c.rn / p.recombination;
+                    const int hi2 = recomb_partner(c, pi, hi);
+                    if (c.error) return pi;
+                    const int64_t posRecomb = (int64_t)((double)p.genome_length * c.rn);
+                    // pyx:586-591 as written: the recombinant carries only the last site of one parent
+                    int nhi = 0;
+                    if (c.sites > 0) nhi = (p.sitesPosition[c.sites - 1] < posRecomb ? hi : hi2) % 4;
+                    if (c.rec && lane == 0) {
+                        if (c.rec_n < c.rec_cap) {
+                            int64_t *o = c.rec + c.rec_n * 5;
+                            o[0] = c.ev_ptr; o[1] = hi; o[2] = hi2; o[3] = nhi; o[4] = posRecomb;
+                        }
+                    }
+                    if (c.rec && c.rec_n >= c.rec_cap) { c.error = ERR_CAPACITY; return pi; }
+                    c.rec_n += 1;
+                    counters_infect(c, pi, si);
+                    if (lane == 0) c.immSrc[pi * S + si] = c.cumul[si] * (double)c.sus[pi * S + si];
+                    WSYNC();
+                    t.valid = false;
+                    op0.pi = pi; op0.hap = nhi; op0.delta = +1; n_ops = 1;
+                    q.immune = true; q.migration = true;
+                    BUMP(CNT_B);
+                    ev.type = EV_BIRTH; ev.hap = hi; ev.pop = pi; ev.nh = si; ev.np = hi2;
+                    return pi;
+                }
                 counters_infect(c, pi, si);
                 if (t.valid) {
                     if (lane == k) { t.cnt += 1; LN(c, pi)[k] = t.cnt; }
@@ -1192,6 +1263,7 @@ static __device__ __forceinline__ void direct_body(const VgxDirectArgs &a) {
     }
     c.ev_ptr = sc->ev_ptr; c.ev_size = a.ev_size; c.loc_n = 0; c.error = 0;
     c.traj_next = 0;
+    c.rec = r.rec ? r.rec + rep * r.rec_cap * 5 : nullptr; c.rec_cap = r.rec_cap; c.rec_n = 0;
     c.has_mig = true;
     c.mig_cum_ok = false;
     WSYNC();
@@ -1363,6 +1435,7 @@ static __device__ __forceinline__ void direct_body(const VgxDirectArgs &a) {
         sc->loc_n = c.loc_n; sc->error = c.error; sc->traj_next = c.traj_next;
         sc->last_attempt = last_att; sc->last_attempt_loops = last_att_loops;
         sc->fa_n = fa_n;
+        sc->rec_n = c.rec_n;
     }
 }
 
