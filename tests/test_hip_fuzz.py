@@ -163,3 +163,27 @@ def test_random_model_tau_modes_agree(seed):
         assert np.array_equal(out[0][0], other[0]) and np.array_equal(out[0][1], other[1])
         assert out[0][2] == other[2] and out[0][3] == other[3] and out[0][4] == other[4]
         assert out[0][5] == other[5]
+
+
+@pytest.mark.parametrize("seed", list(range(int(__import__("os").environ.get("VGX_FUZZ_SEEDS", "40")))))
+def test_random_model_recombination_kernels_agree(oracle_mod, seed):
+    """Recombinant births (pyx:575-596) on the random models with two sites or more: the occupancy-list kernel and the
+    dense lane kernel give the oracle's log, records and state bit for bit."""
+    sim0, n = build(seed)
+    if sim0.simulation.sites < 2:
+        return
+    rng = np.random.default_rng(1000 + seed)
+    prob = float(rng.uniform(0.05, 0.6))
+    out = []
+    for kernel in ("wave", "lane", None):
+        sim, n = build(seed)
+        m = sim.simulation
+        m.recombination = prob
+        with helpers.quiet():
+            if kernel is None:
+                oracle_mod.run_direct(m, min(n, 1500), 10 ** 9, -1, 200)
+            else:
+                sim.simulate(min(n, 1500), sample_size=10 ** 9, kernel=kernel)
+        out.append(m)
+    helpers.assert_models_equal(out[0], out[2], "fuzz %d recombination, wave kernel" % seed)
+    helpers.assert_models_equal(out[1], out[2], "fuzz %d recombination, lane kernel" % seed)
