@@ -1147,15 +1147,21 @@ static __device__ __forceinline__ void tau_own_check(const VgxTauArgs &a, int re
 // Per-block tables of the draw kernel (a block works on ONE population): class parameters, this population's
 // transmission / migration weights per birth class and the bisection tables, staged in LDS when they fit
 // (else the pointers refer to the global arrays).
-struct TauTab {
-    const double *c_d, *c_s, *c_tm;      // [C]
-    const int32_t *c_bidx, *c_stype;     // [C]
-    const double *rtr;                   // [CB]   transmission rate per infected of the class: sum_sn wtr
-    const double *wtr;                   // [CB][S] b * sigma[sn] * S[pn][sn] * F[pn]
-    const double *rmig;                  // [CB]   out-migration rate per infected: Gout * b * m[pn][pn]
-    const double *mutcum;                // [3*sites] running sums of the uniform mutation model
-    const double *cdf;                   // [CB][P*S] running sums of the out-migration channel weights of pn
-    const double *r1;                    // [C] total event rate per infected of the class in this population, or null
+// TABS says where they are: 0 = global memory (generic pointers), 1 = LDS except the migration table, 2 = all in LDS.  The LDS
+// forms carry address-space-3 pointers: a generic pointer that may be LDS or global compiles to FLAT loads, and every flat
+// load waits for ALL outstanding memory operations of the wavefront (the loads issued ahead, the atomics of the round).
+#define VGX_AS3 __attribute__((address_space(3)))
+template <int TABS> struct TauTabSel { typedef const double *DP; typedef const int32_t *IP; typedef const double *CP; };
+template <> struct TauTabSel<1> { typedef const VGX_AS3 double *DP; typedef const VGX_AS3 int32_t *IP; typedef const double *CP; };
+template <> struct TauTabSel<2> { typedef const VGX_AS3 double *DP; typedef const VGX_AS3 int32_t *IP; typedef const VGX_AS3 double *CP; };
+template <int TABS> struct TauTabT {
+    typename TauTabSel<TABS>::DP c_d, c_s, c_tm;      // [C]
+    typename TauTabSel<TABS>::IP c_bidx, c_stype;     // [C]
+    typename TauTabSel<TABS>::DP rtr;                 // [CB]   transmission rate per infected of the class: sum_sn wtr
+    typename TauTabSel<TABS>::DP wtr;                 // [CB][S] b * sigma[sn] * S[pn][sn] * F[pn]
+    typename TauTabSel<TABS>::DP rmig;                // [CB]   out-migration rate per infected: Gout * b * m[pn][pn]
+    typename TauTabSel<TABS>::DP mutcum;              // [3*sites] running sums of the uniform mutation model
+    typename TauTabSel<TABS>::CP cdf;                 // [CB][P*S] running sums of the out-migration channel weights of pn
 };
 
 // ---- random numbers of a try -----------------------------------------------------------------------------------------
@@ -1168,13 +1174,22 @@ struct TauTab {
 // with a 60-bit uniform.
 // group of compartment hn of population pn: 16 consecutive haplotypes (what a lane of the scan kernel looks at); the bucket
 // of haplotype 16 g + 4 k + j is byte j of word k of the group's block.
-static __device__ __forceinline__ uint32_t tau_bucket(const VgxTauArgs &a, int rep, int pn, int hn) {
+// What a block of the events kernel reads from global memory about its (replicate, population) ONCE: inside the round loop the
+// compiler cannot keep such values in registers across the loop's stores and atomics, and every reload is a dependent scalar
+// load (pointer from the kernel arguments, then the value).
+struct TauEnv { uint64_t seed; uint32_t att, step, retry; double sampMult; };
+static __device__ __forceinline__ TauEnv tau_env(const VgxTauArgs &a, int rep, int pn) {
+    TauEnv e;
+    e.seed = (uint64_t)a.seeds[rep]; e.att = (uint32_t)a.attempt[rep]; e.step = (uint32_t)a.step[rep]; e.retry = (uint32_t)a.retry[rep];
+    e.sampMult = a.p.sampMult[pn];
+    return e;
+}
+static __device__ __forceinline__ uint32_t tau_bucket(const VgxTauArgs &a, const TauEnv &E, int pn, int hn) {
     const int H = a.p.H;
     const uint64_t groups = (uint64_t)((H + 15) >> 4);
     const uint64_t gidx = (uint64_t)pn * groups + (uint64_t)(hn >> 4);
-    const uint32_t key[2] = {(uint32_t)a.seeds[rep] ^ ((uint32_t)a.attempt[rep] * 0x9E3779B9u),
-                             (uint32_t)((uint64_t)a.seeds[rep] >> 32) ^ 0x85EBCA6Bu};
-    const uint32_t ctr[4] = {(uint32_t)gidx, (uint32_t)(gidx >> 32), (uint32_t)a.step[rep], ((uint32_t)a.retry[rep] << 20) | 0xFFFFFu};
+    const uint32_t key[2] = {(uint32_t)E.seed ^ (E.att * 0x9E3779B9u), (uint32_t)(E.seed >> 32) ^ 0x85EBCA6Bu};
+    const uint32_t ctr[4] = {(uint32_t)gidx, (uint32_t)(gidx >> 32), E.step, (E.retry << 20) | 0xFFFFFu};
     uint32_t w[4];
     vgx_philox4x32(ctr, key, w);
     return (w[(hn >> 2) & 3] >> (8 * (hn & 3))) & 255u;
@@ -1194,8 +1209,8 @@ static __device__ __forceinline__ uint32_t tau_bucket(const VgxTauArgs &a, int r
 // Returns 2 when the compartment expects VGX_TAU_BIG events or more (nothing drawn: vgx_tau_draw_big_kernel's case), else 0/1.
 // DRY = true: no bookkeeping at all; ownChk returns the number of mutants that go to haplotype `target` (the same random
 // numbers in the same order, so the count is the one the compartment's real draw produces).
-template <bool DRY>
-static __device__ __forceinline__ int tau_cell_events(const VgxTauArgs &a, const TauTab &T, int rep, int pn, int hn, double tau,
+template <bool DRY, int TABS>
+static __device__ __forceinline__ int tau_cell_events(const VgxTauArgs &a, const TauTabT<TABS> &T, const TauEnv &E, int rep, int pn, int hn, double tau,
                                                       int64_t Icell, uint32_t bucket, int64_t &ownChk, int64_t &ownApp, int64_t *cnt,
                                                       WaveStage *stage, unsigned long long *sS /* LDS [S]: this population's susceptible deltas */,
                                                       int target) {
@@ -1210,7 +1225,7 @@ static __device__ __forceinline__ int tau_cell_events(const VgxTauArgs &a, const
     const int st = T.c_stype[c];
     // ---- channel rates per unit time ----
     const double r_rec = T.c_d[c] * Ih;                                              // pyx:2386
-    const double r_samp = T.c_s[c] * Ih * p.sampMult[pn];                            // pyx:2392
+    const double r_samp = T.c_s[c] * Ih * E.sampMult;                                // pyx:2392
     const double r_tr = T.rtr[cb] * Ih;                                              // pyx:2412-2414 summed over sn
     const double r_mut = (a.mut_uniform ? a.mut_total : T.c_tm[c]) * Ih;             // pyx:2400-2401 summed over (s, i)
     const double r_mig = T.rmig[cb] * Ih;                                            // pyx:2366-2367 summed over (tpn, sn)
@@ -1219,8 +1234,7 @@ static __device__ __forceinline__ int tau_cell_events(const VgxTauArgs &a, const
     if (!(lam > 0.0)) return 0;
     if (lam >= VGX_TAU_BIG) return 2;
     TauRng g;
-    g.init((uint64_t)a.seeds[rep], (uint32_t)a.attempt[rep], (uint64_t)pn * (uint64_t)H + (uint64_t)hn, (uint32_t)a.step[rep],
-           (uint32_t)a.retry[rep]);
+    g.init(E.seed, E.att, (uint64_t)pn * (uint64_t)H + (uint64_t)hn, E.step, E.retry);
     int64_t N;
     if (lam >= 10.0) {
         N = tau_poisson(g, lam);
@@ -1304,7 +1318,7 @@ static __device__ __forceinline__ int tau_cell_events(const VgxTauArgs &a, const
     int64_t *dS = a.dSi + (int64_t)rep * P * S;
     int64_t migrants = 0;
     for (int64_t k = 0; k < n_mig; ++k) {
-        const double *cdf = T.cdf + (int64_t)cb * P * S;
+        const typename TauTabSel<TABS>::CP cdf = T.cdf + (int64_t)cb * P * S;
         const int nch = P * S;
         double uu = g.uniform() * cdf[nch - 1];
         int lo = 0, hi = nch - 1;
@@ -1662,7 +1676,8 @@ __global__ void __launch_bounds__(TB) vgx_tau_scan_fast_kernel(VgxTauArgs a) {
 // grid = (tau_draw_gx(H) * ev_split, P, R), one wavefront per block: ev_split blocks share a shard of the queue and take its
 // rounds of 64 entries in turn (few shards with many entries each — mid-size models — still fill the chip); dSi / dTot /
 // dChkTot are zero on entry.  The shards' counters are cleared by vgx_tau_decide_kernel.
-extern "C" __global__ void __launch_bounds__(EB) vgx_tau_events_kernel(VgxTauArgs a) {
+template <int TABS>
+__global__ void __launch_bounds__(EB) vgx_tau_events_kernel(VgxTauArgs a) {
     const int rep = blockIdx.z, pn = blockIdx.y;
     if (!a.active[rep] || a.accepted[rep]) return;
     const VgxDevParams &p = a.p;
@@ -1682,26 +1697,25 @@ extern "C" __global__ void __launch_bounds__(EB) vgx_tau_events_kernel(VgxTauArg
     __shared__ double g_rtr[16], g_rmig[16], g_wtr[16 * 64];   // fallback storage when the class tables stay global
     __shared__ WaveStage stage_s;
     sS[threadIdx.x] = 0;
-    bool cdfL;
-    const bool useL = tau_tab_lds_bytes(C, CB, S, P, cdfL) != 0;
-    TauTab T;
+    const bool cdfL = TABS == 2;   // (the launcher picks the instantiation from tau_tab_lds_bytes)
+    TauTabT<TABS> T;
     const double tau = a.tau[rep];
     const double F = a.F[(int64_t)rep * P + pn];
     const int64_t *Sus = a.S + (int64_t)rep * P * S + (int64_t)pn * S;
     const double *gcdf = a.migcdf + ((int64_t)rep * P + pn) * CB * (int64_t)P * S;
-    if (useL) {
-        double *d = (double *)dsm;
-        double *l_cd = d; d += C;
-        double *l_cs = d; d += C;
-        double *l_ctm = d; d += C;
-        double *l_rtr = d; d += CB;
-        double *l_rmig = d; d += CB;
-        double *l_wtr = d; d += CB * S;
-        double *l_mut = d; d += 48;
-        double *l_r1 = d; d += C;
-        double *l_cdf = d; if (cdfL) d += CB * P * S;
-        int32_t *l_bidx = (int32_t *)d;
-        int32_t *l_stype = l_bidx + C;
+    if constexpr (TABS != 0) {
+        VGX_AS3 double *d = (VGX_AS3 double *)dsm;
+        VGX_AS3 double *l_cd = d; d += C;
+        VGX_AS3 double *l_cs = d; d += C;
+        VGX_AS3 double *l_ctm = d; d += C;
+        VGX_AS3 double *l_rtr = d; d += CB;
+        VGX_AS3 double *l_rmig = d; d += CB;
+        VGX_AS3 double *l_wtr = d; d += CB * S;
+        VGX_AS3 double *l_mut = d; d += 48;
+        VGX_AS3 double *l_r1 = d; d += C;
+        VGX_AS3 double *l_cdf = d; if (cdfL) d += CB * P * S;
+        VGX_AS3 int32_t *l_bidx = (VGX_AS3 int32_t *)d;
+        VGX_AS3 int32_t *l_stype = l_bidx + C;
         for (int i = threadIdx.x; i < C; i += EB) {
             l_cd[i] = p.c_d[i]; l_cs[i] = p.c_s[i]; l_ctm[i] = p.c_tm[i]; l_bidx[i] = p.c_bidx[i]; l_stype[i] = p.c_stype[i];
         }
@@ -1717,12 +1731,10 @@ extern "C" __global__ void __launch_bounds__(EB) vgx_tau_events_kernel(VgxTauArg
             l_rmig[cb] = a.has_mig ? a.Gout[((int64_t)rep * P + pn) * CB + cb] * p.cb_b[cb] * p.mig[(int64_t)pn * P + pn] : 0.0;
         }
         __syncthreads();
-        for (int i = threadIdx.x; i < C; i += EB) {
-            int cb = l_bidx[i];
-            l_r1[i] = l_rmig[cb] + l_cd[i] + l_cs[i] * p.sampMult[pn] + (a.mut_uniform ? a.mut_total : l_ctm[i]) + l_rtr[cb];
-        }
+        (void)l_r1;
         T.c_d = l_cd; T.c_s = l_cs; T.c_tm = l_ctm; T.c_bidx = l_bidx; T.c_stype = l_stype;
-        T.rtr = l_rtr; T.wtr = l_wtr; T.rmig = l_rmig; T.mutcum = l_mut; T.cdf = cdfL ? l_cdf : gcdf; T.r1 = l_r1;
+        T.rtr = l_rtr; T.wtr = l_wtr; T.rmig = l_rmig; T.mutcum = l_mut;
+        if constexpr (TABS == 2) T.cdf = l_cdf; else T.cdf = gcdf;
     } else {
         // many classes: parameters stay in global memory; the per-population weights of up to 16 birth classes
         // are still prepared once per block (more birth classes are rejected by the host)
@@ -1735,7 +1747,7 @@ extern "C" __global__ void __launch_bounds__(EB) vgx_tau_events_kernel(VgxTauArg
             g_rmig[cb] = a.has_mig ? a.Gout[((int64_t)rep * P + pn) * CB + cb] * p.cb_b[cb] * p.mig[(int64_t)pn * P + pn] : 0.0;
         }
         T.c_d = p.c_d; T.c_s = p.c_s; T.c_tm = p.c_tm; T.c_bidx = p.c_bidx; T.c_stype = p.c_stype;
-        T.rtr = g_rtr; T.wtr = g_wtr; T.rmig = g_rmig; T.mutcum = a.mutcum; T.cdf = gcdf; T.r1 = nullptr;
+        T.rtr = g_rtr; T.wtr = g_wtr; T.rmig = g_rmig; T.mutcum = a.mutcum; T.cdf = gcdf;
     }
     WaveStage *stage = &stage_s;
     if (threadIdx.x == 0) stage->n = 0;
@@ -1749,6 +1761,7 @@ extern "C" __global__ void __launch_bounds__(EB) vgx_tau_events_kernel(VgxTauArg
     int32_t *dCrow = a.dChk + ((int64_t)rep * P + pn) * H, *dArow = a.dApp + ((int64_t)rep * P + pn) * H;
     const bool dense = !a.sparse;
     const int64_t *qsrc = a.q + (int64_t)rep * a.q_cap + shard * scap;
+    const TauEnv E = tau_env(a, rep, pn);
     // `ok` is read and cleared at device scope: the XCDs' L2 caches are not coherent with each other for plain accesses, a
     // wavefront on another XCD would never see the flag.  The load is issued one round ahead of its use.
     int okv = __hip_atomic_load(&a.ok[rep], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1774,7 +1787,7 @@ extern "C" __global__ void __launch_bounds__(EB) vgx_tau_events_kernel(VgxTauArg
             h = (int)(qe & 0x7FFFFFFFll);
             const int64_t Ih = (int64_t)I_now;
             int64_t oc = 0, oa = 0;
-            const int r = tau_cell_events<false>(a, T, rep, pn, h, tau, Ih, (uint32_t)(qe >> 32), oc, oa, cnt, stage, sS, -1);
+            const int r = tau_cell_events<false, TABS>(a, T, E, rep, pn, h, tau, Ih, (uint32_t)(qe >> 32), oc, oa, cnt, stage, sS, -1);
             if (r == 2) {   // many events: one wavefront draws its channels one by one (vgx_tau_draw_big_kernel)
                 const unsigned long long slot = atomicAdd(&a.big_n[rep], 1ull);
                 if ((int64_t)slot < a.big_cap) a.big[(int64_t)rep * a.big_cap + (int64_t)slot] = (int64_t)pn * H + h;
@@ -1805,7 +1818,7 @@ extern "C" __global__ void __launch_bounds__(EB) vgx_tau_events_kernel(VgxTauArg
                 const int64_t In = (int64_t)Irow[nb];
                 if (In <= 0) continue;
                 int64_t kk = 0, dummy = 0;
-                if (tau_cell_events<true>(a, T, rep, pn, nb, tau, In, tau_bucket(a, rep, pn, nb), kk, dummy, cnt, nullptr, nullptr, hs) == 2) open = true;
+                if (tau_cell_events<true, TABS>(a, T, E, rep, pn, nb, tau, In, tau_bucket(a, E, pn, nb), kk, dummy, cnt, nullptr, nullptr, hs) == 2) open = true;
                 arr += kk;
             }
             for (int o = 32; o > 0; o >>= 1) arr += __shfl_down(arr, o);
@@ -1818,7 +1831,8 @@ extern "C" __global__ void __launch_bounds__(EB) vgx_tau_events_kernel(VgxTauArg
         }
         // the staged moves go out when the next round might not fit (a round adds at most one own change per lane plus its
         // mutants and migrants; what does not fit goes to the list entry by entry)
-        WSYNC();
+        // (LDS only: a full fence would also wait for the loads issued ahead and for this round's global atomics)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (stage->n > VGX_WSTAGE - 96 || k0 + kstep >= n) tau_stage_flush(a, stage, rep);
     }
     tau_stage_flush(a, stage, rep);   // (a wavefront that left the loop early)
@@ -2344,7 +2358,9 @@ TAU_LAUNCH(tau_choose, dim3((unsigned)a->R), dim3(64))
 extern "C" __attribute__((visibility("hidden"))) hipError_t vgxi_tau_draw(const VgxTauArgs *a, hipStream_t s) {
     bool cdfL;
     size_t lds = tau_tab_lds_bytes(a->p.C, a->p.CB, a->p.S, a->p.P, cdfL);
-    hipError_t err = hipFuncSetAttribute((const void *)vgx_tau_events_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds ? lds : 16));
+    const int tabs = lds == 0 ? 0 : (cdfL ? 2 : 1);
+    const void *evk = tabs == 2 ? (const void *)vgx_tau_events_kernel<2> : tabs == 1 ? (const void *)vgx_tau_events_kernel<1> : (const void *)vgx_tau_events_kernel<0>;
+    hipError_t err = hipFuncSetAttribute(evk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds ? lds : 16));
     if (err != hipSuccess) return err;
     const dim3 grid(tau_draw_gx(a->p.H), (unsigned)a->p.P, (unsigned)a->R);
     const dim3 egrid(tau_draw_gx(a->p.H) * (unsigned)a->ev_split, (unsigned)a->p.P, (unsigned)a->R);
@@ -2357,7 +2373,9 @@ extern "C" __attribute__((visibility("hidden"))) hipError_t vgxi_tau_draw(const 
     } else {
         hipLaunchKernelGGL(vgx_tau_scan_kernel, grid, dim3(TB), 0, s, *a);
     }
-    hipLaunchKernelGGL(vgx_tau_events_kernel, egrid, dim3(EB), lds ? lds : 16, s, *a);
+    if (tabs == 2) hipLaunchKernelGGL(vgx_tau_events_kernel<2>, egrid, dim3(EB), lds, s, *a);
+    else if (tabs == 1) hipLaunchKernelGGL(vgx_tau_events_kernel<1>, egrid, dim3(EB), lds, s, *a);
+    else hipLaunchKernelGGL(vgx_tau_events_kernel<0>, egrid, dim3(EB), 16, s, *a);
     return hipGetLastError();
 }
 extern "C" __attribute__((visibility("hidden"))) int64_t vgxi_tau_queue_shards(int64_t H, int64_t P) { return (int64_t)tau_draw_gx(H) * P; }
