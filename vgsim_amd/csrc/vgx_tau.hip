@@ -1365,6 +1365,9 @@ static __host__ __device__ inline size_t tau_tab_lds_bytes(int C, int CB, int S,
 // events kernel takes the entries block (bx, pn) of the scan kernel queued, so its tables are those of ONE population.
 #define VGX_QW 512          // entries a wavefront of the scan kernel stages in LDS: a quarter tile adds at most 256, they are moved out from 256 on
 #define EB 64               // threads per block of the events kernel
+#ifndef VGX_EV_WAVES
+#define VGX_EV_WAVES 2      // wavefronts per SIMD the events kernel's register allocation aims at
+#endif
 static __host__ __device__ inline unsigned tau_draw_gx(int64_t H) {   // blocks of the scan kernel per (population, replicate)
     const unsigned tiles = (unsigned)((H + 1023) >> 10);              // wave tiles of 1024 haplotypes
     const unsigned blocks = (tiles + (TB / 64) - 1) / (TB / 64);
@@ -1677,7 +1680,7 @@ __global__ void __launch_bounds__(TB) vgx_tau_scan_fast_kernel(VgxTauArgs a) {
 // rounds of 64 entries in turn (few shards with many entries each — mid-size models — still fill the chip); dSi / dTot /
 // dChkTot are zero on entry.  The shards' counters are cleared by vgx_tau_decide_kernel.
 template <int TABS>
-__global__ void __launch_bounds__(EB) vgx_tau_events_kernel(VgxTauArgs a) {
+__global__ void __launch_bounds__(EB, VGX_EV_WAVES) vgx_tau_events_kernel(VgxTauArgs a) {
     const int rep = blockIdx.z, pn = blockIdx.y;
     if (!a.active[rep] || a.accepted[rep]) return;
     const VgxDevParams &p = a.p;
