@@ -61,3 +61,32 @@ def test_portable_log_within_one_ulp(oracle_mod):
             assert a == 0.0
     assert worst <= 1.0, worst
     assert L.vgo_portable_log(0.0) == -math.inf
+
+
+def test_oracle_counter_based_stream_matches_the_library_definition(oracle_mod):
+    """The oracle's optional Philox stream (oracle.RNG_PHILOX: the checker of the engine's FAST mode 2) is the stream
+    include/vgx.h defines: output 0 of (seed, attempt) = low 64 bits of Philox4x32-10 with counter (0, 0, attempt, 'VGXs')
+    and the seed as key (libvgx's host Philox, itself pinned on Random123 vectors in test_samplers.py).  The first event's
+    time is -log(u0) / (totalRate + totalMigrationRate) with the start state's rates, the same denominator in both runs."""
+    import helpers
+    import models
+    from vgsim_amd import Simulator, _capi
+
+    def first_event(log_mode):
+        with helpers.quiet():
+            sim, phases = models.build(Simulator, "g1")
+            phases[0][0](sim)
+        m = sim.simulation
+        assert oracle_mod.run_direct(m, 2000, 10 ** 9, -1, 200, log_mode=log_mode) == 0
+        return m
+
+    a, b = first_event(oracle_mod.RNG_PHILOX), first_event(0)
+    lib = _capi.load_library()
+    ctr = (C.c_uint32 * 4)(0, 0, a.good_attempt - 1, 0x56475873)
+    key = (C.c_uint32 * 2)(a.user_seed & 0xFFFFFFFF, a.user_seed >> 32)
+    o = (C.c_uint32 * 4)()
+    assert lib.vgx_test_philox(0, C.byref(ctr), C.byref(key), C.byref(o)) == 0
+    u0 = float(((o[1] << 32) | o[0]) >> 11) / 2.0 ** 53
+    u0_pcg = np.random.Generator(np.random.PCG64(np.random.SeedSequence(b.user_seed, spawn_key=(b.good_attempt - 1,)))).random()
+    assert a.events.times[0] / b.events.times[0] == pytest.approx(math.log(u0) / math.log(u0_pcg), rel=1e-12)
+    assert not np.array_equal(a.events.types[:a.events.ptr], b.events.types[:b.events.ptr])
