@@ -278,10 +278,12 @@ class VgoGenealogy(C.Structure):
                 ("mig_time", _F), ("nodes_used", C.c_int64)]
 
 
-def run_genealogy(model, seed=None):
+def run_genealogy(model, seed=None, multievents=None):
     """The oracle's GetGenealogy (pyx:743-1000) on a host model whose forward phases were run by this oracle.
     ``seed=None`` continues the simulation's random stream (pyx:766-767).  Walks ``model.infectious`` back in place like
-    the reference; returns a dict with tree, tree_pop, times, mut_* and mig_* arrays."""
+    the reference; returns a dict with tree, tree_pop, times, mut_* and mig_* arrays.  ``multievents``: the rows to walk for
+    MULTITYPE events when the chain was not produced by this oracle (an object with the arrays num, times, types,
+    haplotypes, populations, newHaplotypes, newPopulations and ``ptr``: the model's own log)."""
     st = get_state(model)
     ev = model.events
     g = VgoGenealogy()
@@ -290,7 +292,15 @@ def run_genealogy(model, seed=None):
     g.ev_populations, g.ev_newHaplotypes, g.ev_newPopulations = _ptr(ev.populations), _ptr(ev.newHaplotypes), _ptr(ev.newPopulations)
     n_mut = int((ev.types[:ev.ptr] == 3).sum())
     n_mig = int((ev.types[:ev.ptr] == 5).sum())
-    if st.mev is not None:
+    if multievents is not None:
+        keep = {k: np.ascontiguousarray(getattr(multievents, k)[:multievents.ptr], dtype=(np.float64 if k == "times" else np.int64))
+                for k in ("num", "times", "types", "haplotypes", "populations", "newHaplotypes", "newPopulations")}
+        g.mev_num, g.mev_times, g.mev_types = _ptr(keep["num"]), _ptr(keep["times"]), _ptr(keep["types"])
+        g.mev_haplotypes, g.mev_populations = _ptr(keep["haplotypes"]), _ptr(keep["populations"])
+        g.mev_newHaplotypes, g.mev_newPopulations = _ptr(keep["newHaplotypes"]), _ptr(keep["newPopulations"])
+        n_mut += int(keep["num"][keep["types"] == 3].sum())
+        n_mig += int(keep["num"][keep["types"] == 5].sum())
+    elif st.mev is not None:
         mv = st.mev
         g.mev_num, g.mev_times, g.mev_types = _ptr(mv["num"]), _ptr(mv["times"]), _ptr(mv["types"])
         g.mev_haplotypes, g.mev_populations = _ptr(mv["haplotypes"]), _ptr(mv["populations"])

@@ -2,7 +2,8 @@
 host code, against the CPU oracle running the same two stages.  Direct chains are bit-identical to the oracle's
 (portable log), so trees, node times, mutation and migration records must be identical too — including
 ``genealogy(None)``, which continues the simulation's random stream from the position the kernel reports
-(last attempt, loop iterations).  Tau chains (Philox on the device) are checked for structure and reproducibility."""
+(last attempt, loop iterations).  Tau chains (Philox on the device: other chains than the oracle's own) are walked back by
+both passes and the trees compared, plus structure and reproducibility."""
 import numpy as np
 import pytest
 
@@ -47,6 +48,24 @@ def _tree_is_valid(m):
     child = np.nonzero(tree >= 0)[0]
     assert (times[tree[child]] <= times[child]).all()          # a parent is older than its children
     assert np.bincount(tree[child], minlength=len(tree)).max() == 2 and (np.bincount(tree[child]) != 1).all()
+
+
+@pytest.mark.parametrize("name", ["tau_b", "tau_c", "tau_d"])
+def test_tau_pipeline_tree_equals_the_oracles_backward_pass(oracle_mod, name):
+    """A tau chain produced on the device (events + multievent rows brought into the reference's order and granularity by
+    the host layer) walked back by libvgx's host pass and, on a second identical run, by the oracle's backward pass
+    (pinned on trees recorded from the reference): the same tree, node times, mutation and migration records."""
+    hip = helpers.run_case_hip(name)
+    if hip.simulation.sCounter < 2:
+        pytest.skip("fewer than two samples")
+    with helpers.quiet():
+        hip.genealogy(99)
+    twin = helpers.run_case_hip(name)
+    want = oracle_mod.run_genealogy(twin.simulation, 99, multievents=twin.simulation.multievents)
+    assert want["rc"] == 0
+    got = _product(hip)
+    for k in got:
+        assert np.array_equal(got[k], want[k]), "%s %s" % (name, k)
 
 
 @pytest.mark.parametrize("name", ["tau_b", "tau_c"])
