@@ -3,6 +3,7 @@ need ~6 ms per event there, so the check uses (a) the oracle's occupied-only mod
 proves bit-identical to the dense reference order, on one replicate, and (b) size-independent invariants on a
 whole ensemble: host conservation per population, counters vs compartments, event-type bookkeeping."""
 import contextlib
+import hashlib
 import io
 
 import numpy as np
@@ -94,7 +95,8 @@ def test_config3_spread_occupancy_exact_oracle_and_fast():
 def test_config4_tau_invariants_at_full_size():
     """BASELINE config 4 at its full size (2^20 haplotypes x 256 populations, migration, dense occupancy): the reference
     cannot construct this shape, so the check is on size-independent properties of three leaps — hosts conserved per
-    population, no negative compartment, totals equal to the compartments' sums, counters equal to the net change."""
+    population, no negative compartment, totals equal to the compartments' sums, counters equal to the net change — and on the
+    two ways a try keeps its deltas (list of moves / dense arrays) giving the same 2^28 compartments bit for bit."""
     import ctypes as C
     from vgsim_amd import Simulator, _capi
     with contextlib.redirect_stdout(io.StringIO()):
@@ -113,6 +115,28 @@ def test_config4_tau_invariants_at_full_size():
     eng.get_state(m, 0)
     c = eng.counters(0)
     eng.close()
+    # ... and the same three leaps with the dense delta arrays and the fused per-compartment tests (reserved[1] = 2): the same
+    # draws and decisions, so the 2^28 compartments, the counters and the clock must come out bit for bit the same
+    keep = (hashlib.sha256(m.infectious.tobytes()).hexdigest(), m.susceptible.copy(), m.currentTime, int(c.reserved[0]),
+            [int(getattr(m, k)) for k in m.COUNTERS])
+    with contextlib.redirect_stdout(io.StringIO()):
+        s2 = Simulator(number_of_sites=10, populations_number=256, seed=2020)
+    s2.set_transmission_rate(2.5); s2.set_recovery_rate(0.9); s2.set_sampling_rate(0.1); s2.set_mutation_rate(0.01)
+    s2.set_total_migration_probability(0.01); s2.set_population_size(10 ** 7)
+    m2 = s2.simulation
+    m2.infectious[:] = 3
+    m2.susceptible[:, 0] -= 3 * m2.hapNum
+    eng2 = _capi.HipEngine(m2.sites, m2.hapNum, m2.popNum, m2.susNum, n_replicates=1)
+    m2.events.CreateEvents(3); m2.events.ptr = 1; m2.events.CreateEvents(3)
+    eng2.set_params(m2); eng2.set_state(m2); eng2.set_seeds(np.array([2020], dtype=np.int64))
+    o2 = _capi.VgxRunOpts(); o2.record_events = 0; o2.reserved[1] = 2
+    eng2._check(eng2.lib.vgx_simulate_tau(eng2.handle, 3, 10 ** 15, -1.0, 1, C.byref(o2)))
+    eng2.get_state(m2, 0)
+    c2 = eng2.counters(0)
+    eng2.close()
+    assert keep == (hashlib.sha256(m2.infectious.tobytes()).hexdigest(), keep[1], m2.currentTime, int(c2.reserved[0]),
+                    [int(getattr(m2, k)) for k in m2.COUNTERS]) and np.array_equal(keep[1], m2.susceptible)
+    del m2, s2
     assert c.loop_iterations == 3 and c.reserved[0] > 5 * 10 ** 6                      # millions of events per leap
     assert c.reserved[0] == m.bCounter + m.dCounter + m.sCounter + m.mCounter + m.migPlus
     assert m.infectious.min() >= 0 and m.susceptible.min() >= 0
