@@ -156,9 +156,12 @@ static __device__ __forceinline__ void row_scan64(double w0, double w1, double w
     QSTEP4(0) QSTEP4(1) QSTEP4(2) QSTEP4(3) QSTEP4(4) QSTEP4(5) QSTEP4(6) QSTEP4(7) QSTEP4(8) QSTEP4(9) QSTEP4(10) QSTEP4(11)
     QSTEP4(12) QSTEP4(13) QSTEP4(14) QSTEP4(15)
 }
-// QT = tiles of 64 four-byte counts a row keeps in flight ahead of its summation chain: 3 in vgx_quad_kernel, 5 in
-// vgx_quad_long_kernel (start states with lists longer than one tile).  Measured: the deeper look-ahead gains 4 % on long
-// lists and costs 5 % on short ones (registers of the whole kernel).
+// QT = tiles of 64 four-byte counts a row keeps in flight ahead of its summation chain: 1 in vgx_quad_kernel, 5 in
+// vgx_quad_long_kernel (start states with lists longer than one tile).  The event loop is sensitive to its CODE SIZE (46 to
+// 51 KB of instructions against a 64 KB instruction cache shared by two CUs): every tile of look-ahead unrolls two more
+// 64-step chains, and on short lists — where that code never runs — one tile less is worth 3-4 % of throughput; the branch
+// hints on the slow paths (mutation, migration, list insertions / removals, restart, the other form of the list passes) move
+// their code behind the loop for another 3 %.
 struct QTile { int c0, c1, c2, c3; };
 static __device__ __forceinline__ QTile tile_load(const int32_t *l3, int t, int rl) {   // entries 64t + 4rl .. + 3 of the 4-byte counts
     const int4 a = *(const int4 *)(l3 + (int64_t)t * 64 + 4 * rl);
@@ -523,7 +526,7 @@ static __device__ __forceinline__ void quad_body(const VgxDirectArgs &a, const Q
             int hap_hit = 0;
             int64_t cnt_hit = 0;
             const int maxn = rows_max(n_sel);
-            if (maxn <= 64) {
+            if (__builtin_expect(maxn <= 64, QT < 4)) {
                 // the lists fit four register chunks: all loads in flight together (unconditional, on clamped indices)
                 const int nch = (maxn + 15) >> 4;
                 const int last = max(n_sel - 1, 0);
@@ -629,7 +632,7 @@ static __device__ __forceinline__ void quad_body(const VgxDirectArgs &a, const Q
                 u_lo = pi; u_hi = pi + 1;
             }
             QPROF(6);
-            if (__ballot(isM)) {
+            if (__builtin_expect(__ballot(isM) != 0, 0)) {   // slow paths: a few per cent of the iterations
                 // ---- Mutation (pyx:640-667): site by mRate[h, :], derived state by hapMutType[h, site, :] ----
                 const double *mr = p.mRate + (int64_t)hap_hit * sites;
                 int mi = 0;
@@ -664,7 +667,7 @@ static __device__ __forceinline__ void quad_body(const VgxDirectArgs &a, const Q
                 }
             }
             QPROF(7);
-            if (__ballot(evm)) {
+            if (__builtin_expect(__ballot(evm) != 0, 0)) {
                 // ================= GenerateMigration (pyx:672-694) =================
                 double rm = (choose0 - totalRate) / totalMig;
                 // target population by fastChoose over migPopRate: serial prefix sums of the same terms as totalMigrationRate
@@ -723,7 +726,7 @@ static __device__ __forceinline__ void quad_body(const VgxDirectArgs &a, const Q
                     int base = 0;
                     bool none = false;
                     const int maxn2 = rows_max(n);
-                    if (maxn2 > 64) {
+                    if (__builtin_expect(maxn2 > 64, QT >= 4)) {
                         const int nt = n > 64 ? (n + 63) >> 6 : 0;     // tile sums exist only for lists longer than a tile
                         const int maxt = rows_max(nt);
                         int jt = -1;
@@ -843,7 +846,7 @@ static __device__ __forceinline__ void quad_body(const VgxDirectArgs &a, const Q
             const bool ins_ok = ins && err == 0;
             if (bump && rl == 0) { ln[posn] = cur + delta; l3[posn] = (int32_t)(cur + delta); if (n > 64) lt[posn >> 6] += delta; }
             // ---- tile sums of lists longer than one tile (vgx_direct.hip list_insert_at / list_remove_at) ----
-            if (__ballot((ins_ok || rem) && n > 64)) {
+            if (__builtin_expect(__ballot((ins_ok || rem) && n > 64) != 0, 0)) {
                 const bool tt = (ins_ok || rem) && n > 64;
                 const int jp = posn >> 6, jl = ins_ok ? (n >> 6) : ((n - 1) >> 6);
                 const int maxj = rows_max(tt ? jl + 1 : 0);
@@ -866,7 +869,7 @@ static __device__ __forceinline__ void quad_body(const VgxDirectArgs &a, const Q
                 WSYNC();
             }
             // ---- shift: insertion moves [posn, n) one slot up (highest block first), removal (posn, n) one slot down ----
-            if (__ballot(ins_ok)) {
+            if (__builtin_expect(__ballot(ins_ok) != 0, 0)) {
                 enum { SU = 4 };
                 int hi_ = ins_ok ? n : 0;
                 const int lo_ = ins_ok ? posn : 0;
@@ -898,7 +901,7 @@ static __device__ __forceinline__ void quad_body(const VgxDirectArgs &a, const Q
                 }
                 WSYNC();
             }
-            if (__ballot(rem)) {
+            if (__builtin_expect(__ballot(rem) != 0, 0)) {
                 enum { SU = 4 };
                 int lo_ = rem ? posn + 1 : 0;
                 const int hi_ = rem ? n : 0;
@@ -983,7 +986,7 @@ static __device__ __forceinline__ void quad_body(const VgxDirectArgs &a, const Q
                 const int32_t *l3 = lcnt32 + (int64_t)pi * cap;
                 const int maxn = rows_max(n);
                 double acc = 0.0;
-                if (maxn <= 64) {
+                if (__builtin_expect(maxn <= 64, QT < 4)) {
                     const int nch = (maxn + 15) >> 4;
                     const bool chave = act && pi == ch_pi;     // the list read for the haplotype choice, event applied
                     int64_t cn4[4];
@@ -1061,7 +1064,7 @@ static __device__ __forceinline__ void quad_body(const VgxDirectArgs &a, const Q
                 st = ST_DONE;
             }
         }
-        if (__ballot(st == ST_REBUILD && restarts > 0 && !rebuild)) {
+        if (__builtin_expect(__ballot(st == ST_REBUILD && restarts > 0 && !rebuild) != 0, 0)) {
             const bool rs = st == ST_REBUILD && restarts > 0 && !rebuild && live;
             int64_t g = 0;
             for (int pn = 0; pn < P; ++pn) {
@@ -1153,7 +1156,10 @@ static __device__ __forceinline__ void quad_body(const VgxDirectArgs &a, const Q
     }
 }
 
-extern "C" __global__ void __launch_bounds__(64, VGX_QUAD_WAVES) vgx_quad_kernel(VgxDirectArgs a, QArgs qa) { quad_body<3>(a, qa); }
+#ifndef VGX_QT_SHORT
+#define VGX_QT_SHORT 1   // measured at the headline workload: 3 -> 7.9e8, 2 -> 8.2e8, 1 -> 8.6e8 events/s (8.8e8 with the branch hints)
+#endif
+extern "C" __global__ void __launch_bounds__(64, VGX_QUAD_WAVES) vgx_quad_kernel(VgxDirectArgs a, QArgs qa) { quad_body<VGX_QT_SHORT>(a, qa); }
 #ifndef VGX_QT_LONG
 #define VGX_QT_LONG 5
 #endif
