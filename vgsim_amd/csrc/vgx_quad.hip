@@ -434,7 +434,7 @@ static __device__ __forceinline__ void quad_body(const VgxDirectArgs &a, const Q
         QPROF(1);
         if (__ballot(ev)) {
             // ---- random numbers: refill the batch of every row that ran dry ----
-            if (__ballot(ev && pos == 8)) {
+            if (__builtin_expect(__ballot(ev && pos == 8) != 0, 0)) {   // (every eighth iteration while the rows stay in step)
                 const bool fill = ev && pos == 8;
                 uint64_t h, l, ch, cl;
                 vgx_mul128(k_jump[0], k_jump[1], g_sh, g_sl, h, l);
@@ -456,7 +456,7 @@ static __device__ __forceinline__ void quad_body(const VgxDirectArgs &a, const Q
                 while (true) {
                     const double tg = r.traj_t0 + (double)traj_next * r.traj_dt;
                     const bool emit = ev && live && traj_next < r.traj_points && tg < t_new;
-                    if (!__ballot(emit)) break;
+                    if (__builtin_expect(!__ballot(emit), 1)) break;
                     if (emit) {
                         double *o = r.traj + (rep * r.traj_points + traj_next) * (int64_t)P * 2;
                         for (int s = 0; s < nslot; ++s) {
