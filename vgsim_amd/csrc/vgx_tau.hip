@@ -1791,7 +1791,7 @@ __global__ void __launch_bounds__(EB, VGX_EV_WAVES) vgx_tau_events_kernel(VgxTau
             const int64_t Ih = (int64_t)I_now;
             int64_t oc = 0, oa = 0;
             const int r = tau_cell_events<false, TABS>(a, T, E, rep, pn, h, tau, Ih, (uint32_t)(qe >> 32), oc, oa, cnt, stage, sS, -1);
-            if (r == 2) {   // many events: one wavefront draws its channels one by one (vgx_tau_draw_big_kernel)
+            if (__builtin_expect(r == 2, 0)) {   // many events: one wavefront draws its channels one by one (vgx_tau_draw_big_kernel)
                 const unsigned long long slot = atomicAdd(&a.big_n[rep], 1ull);
                 if ((int64_t)slot < a.big_cap) a.big[(int64_t)rep * a.big_cap + (int64_t)slot] = (int64_t)pn * H + h;
                 else atomicOr(&a.grow[rep], 4);   // list full: the host enlarges it and the same try runs again
@@ -1810,7 +1810,7 @@ __global__ void __launch_bounds__(EB, VGX_EV_WAVES) vgx_tau_events_kernel(VgxTau
         // everybody at once: the other wavefronts stop before their next round.  A neighbour that is drawn channel by channel
         // (vgx_tau_draw_big_kernel) leaves the question to the list of arrivals (vgx_tau_arrivals_kernel).
         unsigned long long todo = __ballot(below);
-        while (todo) {
+        while (__builtin_expect(todo != 0, 0)) {   // (rare: keeps this code out of the round loop's way in the instruction cache)
             const int src = __ffsll((long long)todo) - 1;
             todo &= todo - 1;
             const int hs = __builtin_amdgcn_readlane(h, src);
