@@ -991,7 +991,7 @@ static __device__ __forceinline__ int generate_event(Ctx &c, double u, Tile &t, 
                 double ws = 0.0;
                 for (int sn = 0; sn < S; ++sn) ws += x[sn];
                 int si = choose_serial(c, [&](int i) { return x[i]; }, S, ws, c.rn);
-                if (p.recombination != 0.0 && c.rn < p.recombination && c.totalInf[pi] > 1) {
+                if (__builtin_expect(p.recombination != 0.0 && c.rn < p.recombination && c.totalInf[pi] > 1, 0)) {
                     // ---- recombinant birth (pyx:575-596): the new host carries nhi, the event names both parents ----
                     c.rn = c.rn / p.recombination;
                     const int hi2 = recomb_partner(c, pi, hi);
