@@ -25,6 +25,7 @@ extern "C" hipError_t vgxi_launch_direct(const VgxDirectArgs *a, size_t lds, hip
 extern "C" int vgxi_tau_inc_shards(int64_t H, int64_t P);
 extern "C" int64_t vgxi_tau_queue_shards(int64_t H, int64_t P);
 extern "C" int64_t vgxi_tau_queue_shard_max(int64_t H);
+extern "C" int vgxi_tau_drift_blocks(const VgxTauArgs *a);
 extern "C" hipError_t vgxi_tau_sieve(const VgxTauArgs *a, hipStream_t s);
 extern "C" hipError_t vgxi_launch_lanes(const VgxDirectArgs *a, const VgxLaneWs *w, hipStream_t stream);
 extern "C" hipError_t vgxi_launch_quad(const VgxDirectArgs *a, const double *cd, double *effMig, double *maxEBM, int32_t *has_mig, int long_lists,
@@ -90,7 +91,7 @@ struct vgx_engine {
         r_evrate, r_evcols, r_locrec, r_loctime, r_lociter, r_farate, r_fakey, r_traj, r_prof, r_qeff, r_qmebm, r_qflag;
     // tau-leaping (dense compartments)
     DevBuf t_I, t_S, t_dChk, t_dApp, t_dSi, t_dTot, t_totInf, t_gI, t_cd, t_lock, t_F, t_eff, t_Aeff, t_Gout, t_dS,
-        t_taubits, t_tau, t_time, t_flags, t_counters, t_cnttry, t_mev, t_mevn, t_mevbase, t_locn, t_mutcum, t_migcdf, t_migIn, t_mutHi, t_colT, t_colTW, t_inc, t_incn, t_sieve, t_sieveskip, t_big, t_bign, t_res, t_susp, t_suspn, t_stkey, t_stval, t_dChkTot, t_q, t_qn, t_hist, t_I8;
+        t_taubits, t_tau, t_time, t_flags, t_counters, t_cnttry, t_mev, t_mevn, t_mevbase, t_locn, t_mutcum, t_migcdf, t_migIn, t_mutHi, t_colT, t_colTW, t_inc, t_incn, t_sieve, t_sieveskip, t_big, t_bign, t_res, t_susp, t_suspn, t_stkey, t_stval, t_dChkTot, t_q, t_qn, t_hist, t_I8, t_dSpart;
     std::vector<int64_t> tau_sieve_skipped;   // [R] tries left out by the sieve in the last tau call
     bool last_was_tau = false;
     int64_t tau_mev_cap = 0;
@@ -1224,6 +1225,12 @@ extern "C" int vgx_simulate_tau(vgx_engine *e, int64_t iterations, int64_t sampl
             HIPCHECK(e, hipMemset(e->t_hist.p, 0, (size_t)(R * P * e->C * 64) * 4));
             a.hist = (unsigned int *)e->t_hist.p;
         }
+    }
+    {   // the drift kernel's blocks write their parts of the susceptible drift into their own slots
+        a.ds_nb = vgxi_tau_drift_blocks(&a);
+        int rcd = ensure(e, e->t_dSpart, (size_t)(R * P * a.ds_nb * S) * 8);
+        if (rcd) return rcd;
+        a.dS_part = (double *)e->t_dSpart.p;
     }
     a.mev = (int64_t *)e->t_mev.p; a.mev_cap = mev_cap;
     e->tau_mev_cap = mev_cap;

@@ -187,6 +187,8 @@ struct VgxTauArgs {
     double *colTW;       // [R][H] sum_spn w[spn] I[spn][h]
     double *Gout;        // [R][P][CB] out-migration weight of a source population per birth class
     double *dS;          // [R][P][S]  drift of the susceptible compartments
+    double *dS_part;     // [R][P][ds_nb][S] the drift kernel's blocks' parts of it (summed in block order: reproducible)
+    int32_t ds_nb;       // blocks of the drift kernel per (population, replicate)
     unsigned long long *tau_bits;  // [R] running minimum of the tau candidates (bit pattern)
     double *tau;         // [R]
     double *time_now;    // [R]

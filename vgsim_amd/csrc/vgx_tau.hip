@@ -341,13 +341,13 @@ extern "C" __global__ void __launch_bounds__(TB) vgx_tau_drift_kernel(VgxTauArgs
     const int lane = threadIdx.x & 63;
     const int32_t *I = a.I + (int64_t)rep * P * H + (int64_t)pn * H;
     const int64_t *Sus = a.S + (int64_t)rep * P * S + (int64_t)pn * S;
-    __shared__ double sdS[64];      // S <= 64 susceptibility groups
+    __shared__ double sdS[TB / 64][64];   // S <= 64 susceptibility groups; one row per wavefront (fixed summation order: no atomics)
     __shared__ unsigned long long smin;
     // class tables and this population's per-class factors in LDS when they are small (else global)
     __shared__ double l_cd[256], l_cs[256], l_ctm[256], l_base[16 * 64], l_mutp[48];
     __shared__ int32_t l_bidx[256], l_stype[256], l_site_flat[16];
     const bool useL = C <= 256 && CB <= 16;
-    if (threadIdx.x < 64) sdS[threadIdx.x] = 0.0;
+    sdS[threadIdx.x >> 6][threadIdx.x & 63] = 0.0;
     if (threadIdx.x == 0) smin = (unsigned long long)__double_as_longlong(1.0);
     if (useL) {
         for (int i = threadIdx.x; i < C; i += TB) {
@@ -422,7 +422,7 @@ extern "C" __global__ void __launch_bounds__(TB) vgx_tau_drift_kernel(VgxTauArgs
             drift += v;
             double red = -v + (st == sn ? to_st : 0.0);   // susceptible drift of (pn, sn)
             for (int o = 32; o > 0; o >>= 1) red += __shfl_down(red, o);
-            if (lane == 0 && red != 0.0) atomicAdd(&sdS[sn], red);
+            if (lane == 0) sdS[threadIdx.x >> 6][sn] += red;
         }
         if (live && fabs(drift) >= 1e-8) {  // pyx:2440-2444, epsilon*X in single precision
             float eps = 0.03f;
@@ -437,7 +437,13 @@ extern "C" __global__ void __launch_bounds__(TB) vgx_tau_drift_kernel(VgxTauArgs
     }
     if (lane == 0) atomic_min_pos_double(&smin, cand_min);
     __syncthreads();
-    if (threadIdx.x < S && sdS[threadIdx.x] != 0.0) atomicAdd(&a.dS[((int64_t)rep * P + pn) * S + threadIdx.x], sdS[threadIdx.x]);
+    // the block's part of the susceptible drift: its own slot, summed over the blocks in a fixed order by the choose kernel
+    // (floating-point atomics would make tau, hence the whole run, depend on the order in which blocks finish)
+    if (threadIdx.x < S) {
+        double v = 0.0;
+        for (int w = 0; w < TB / 64; ++w) v += sdS[w][threadIdx.x];
+        a.dS_part[(((int64_t)rep * P + pn) * a.ds_nb + blockIdx.x) * S + threadIdx.x] = v;
+    }
     if (threadIdx.x == 0) atomicMin(&a.tau_bits[rep], smin);
 }
 
@@ -529,12 +535,12 @@ extern "C" __global__ void __launch_bounds__(TB) vgx_tau_drift_tiled_kernel(VgxT
     const int32_t *I = a.I + rowoff;
     const int64_t *Sus = a.S + (int64_t)rep * P * S + (int64_t)pn * S;
     __shared__ int32_t tile[4096];
-    __shared__ double sdS[64];
+    __shared__ double sdS[TB / 64][64];
     __shared__ unsigned long long smin;
     __shared__ double l_cd[256], l_cs[256], l_ctm[256], l_base[16 * 64], l_mutp[48];
     __shared__ int32_t l_bidx[256], l_stype[256];
     const bool useL = C <= 256 && CB <= 16;
-    if (threadIdx.x < 64) sdS[threadIdx.x] = 0.0;
+    sdS[threadIdx.x >> 6][threadIdx.x & 63] = 0.0;
     if (threadIdx.x == 0) smin = (unsigned long long)__double_as_longlong(1.0);
     if (useL) {
         for (int i = threadIdx.x; i < C; i += TB) {
@@ -615,7 +621,8 @@ extern "C" __global__ void __launch_bounds__(TB) vgx_tau_drift_tiled_kernel(VgxT
                 drift += v;
                 const double red = -v + (st == sn ? to_st : 0.0);   // susceptible drift of (pn, sn)
                 if (sn < 4) redS[sn] += red;
-                else if (red != 0.0) atomicAdd(&sdS[sn], red);
+                else if (red != 0.0) atomicAdd(&sdS[0][sn], red);   // (beyond four groups: an LDS atomic per compartment; the order of
+                                                                     //  these few additions is not fixed)
             }
             if (fabs(drift) >= 1e-8) {  // pyx:2440-2444, epsilon*X in single precision
                 float eps = 0.03f;
@@ -628,7 +635,7 @@ extern "C" __global__ void __launch_bounds__(TB) vgx_tau_drift_tiled_kernel(VgxT
     for (int sn = 0; sn < 4 && sn < S; ++sn) {
         double red = redS[sn];
         for (int o = 32; o > 0; o >>= 1) red += __shfl_down(red, o);
-        if (lane == 0 && red != 0.0) atomicAdd(&sdS[sn], red);
+        if (lane == 0) sdS[threadIdx.x >> 6][sn] += red;
     }
     for (int o = 32; o > 0; o >>= 1) {
         double other = __shfl_down(cand_min, o);
@@ -636,7 +643,13 @@ extern "C" __global__ void __launch_bounds__(TB) vgx_tau_drift_tiled_kernel(VgxT
     }
     if (lane == 0) atomic_min_pos_double(&smin, cand_min);
     __syncthreads();
-    if (threadIdx.x < S && sdS[threadIdx.x] != 0.0) atomicAdd(&a.dS[((int64_t)rep * P + pn) * S + threadIdx.x], sdS[threadIdx.x]);
+    // the block's part of the susceptible drift: its own slot, summed over the blocks in a fixed order by the choose kernel
+    // (floating-point atomics would make tau, hence the whole run, depend on the order in which blocks finish)
+    if (threadIdx.x < S) {
+        double v = 0.0;
+        for (int w = 0; w < TB / 64; ++w) v += sdS[w][threadIdx.x];
+        a.dS_part[(((int64_t)rep * P + pn) * a.ds_nb + blockIdx.x) * S + threadIdx.x] = v;
+    }
     if (threadIdx.x == 0) atomicMin(&a.tau_bits[rep], smin);
 }
 
@@ -664,13 +677,13 @@ __global__ void __launch_bounds__(TB) vgx_tau_drift_fast_kernel(VgxTauArgs a) {
     const int32_t *I = a.I + rowoff;
     const int64_t *Sus = a.S + (int64_t)rep * P * S + (int64_t)pn * S;
     __shared__ __attribute__((aligned(16))) int32_t tile[4096];
-    __shared__ double sdS[64];
+    __shared__ double sdS[TB / 64][64];
     __shared__ unsigned long long smin;
     __shared__ double l_cd[256], l_cs[256], l_ctm[256], l_base[16 * 64], l_rate[VGX_DRIFT_LOW];
     __shared__ int32_t l_bidx[256], l_stype[256];
     __shared__ unsigned int hist[VGX_HIST_CMAX * VGX_HIST_X * 2];   // C * 64 bins in HK copies (lanes spread over the copies)
     const bool do_hist = a.hist != nullptr;
-    if (threadIdx.x < 64) sdS[threadIdx.x] = 0.0;
+    sdS[threadIdx.x >> 6][threadIdx.x & 63] = 0.0;
     if (threadIdx.x == 0) smin = (unsigned long long)__double_as_longlong(1.0);
     // copies of the histogram: 16 for one class ... 2 for eight (same-address LDS atomics of a wavefront serialise)
     const int HK = C == 1 ? 16 : (C == 2 ? 8 : (C <= 4 ? 4 : 2));
@@ -796,7 +809,7 @@ __global__ void __launch_bounds__(TB) vgx_tau_drift_fast_kernel(VgxTauArgs a) {
                     drift += v;
                     const double red = -v + (st == sn ? to_st : 0.0);   // susceptible drift of (pn, sn)
                     if (sn < 4) redS[sn] += red;
-                    else if (red != 0.0) atomicAdd(&sdS[sn], red);
+                    else if (red != 0.0) atomicAdd(&sdS[0][sn], red);
                 }
             }
             // pyx:2440-2444: candidate max(eps * X / 2, 1) / |drift| (epsilon * X in single precision).  For the compartments
@@ -817,7 +830,7 @@ __global__ void __launch_bounds__(TB) vgx_tau_drift_fast_kernel(VgxTauArgs a) {
     for (int sn = 0; sn < 4 && sn < S; ++sn) {
         double red = redS[sn];
         for (int o = 32; o > 0; o >>= 1) red += __shfl_down(red, o);
-        if (lane == 0 && red != 0.0) atomicAdd(&sdS[sn], red);
+        if (lane == 0) sdS[threadIdx.x >> 6][sn] += red;
     }
     if (ad_max >= 1e-8 && 1.0 / ad_max < cand_min) cand_min = 1.0 / ad_max;
     for (int o = 32; o > 0; o >>= 1) {
@@ -826,7 +839,13 @@ __global__ void __launch_bounds__(TB) vgx_tau_drift_fast_kernel(VgxTauArgs a) {
     }
     if (lane == 0) atomic_min_pos_double(&smin, cand_min);
     __syncthreads();
-    if (threadIdx.x < S && sdS[threadIdx.x] != 0.0) atomicAdd(&a.dS[((int64_t)rep * P + pn) * S + threadIdx.x], sdS[threadIdx.x]);
+    // the block's part of the susceptible drift: its own slot, summed over the blocks in a fixed order by the choose kernel
+    // (floating-point atomics would make tau, hence the whole run, depend on the order in which blocks finish)
+    if (threadIdx.x < S) {
+        double v = 0.0;
+        for (int w = 0; w < TB / 64; ++w) v += sdS[w][threadIdx.x];
+        a.dS_part[(((int64_t)rep * P + pn) * a.ds_nb + blockIdx.x) * S + threadIdx.x] = v;
+    }
     if (threadIdx.x == 0) atomicMin(&a.tau_bits[rep], smin);
     if (do_hist)
         for (int i = threadIdx.x; i < C * VGX_HIST_X; i += TB) {
@@ -844,11 +863,11 @@ extern "C" __global__ void __launch_bounds__(64) vgx_tau_choose_kernel(VgxTauArg
     const VgxDevParams &p = a.p;
     const int P = p.P, S = p.S;
     const int64_t *Sus = a.S + (int64_t)rep * P * S;
-    double *dS = a.dS + (int64_t)rep * P * S;
     double best = 1.0;
     for (int idx = threadIdx.x; idx < P * S; idx += 64) {
         int pn = idx / S, sn = idx % S;
-        double d = dS[idx];
+        double d = 0.0;   // the blocks' parts in block order
+        for (int b = 0; b < a.ds_nb; ++b) d += a.dS_part[(((int64_t)rep * P + pn) * a.ds_nb + b) * S + sn];
         for (int o = 0; o < S; ++o) {
             if (o == sn) continue;
             d += p.suscepTransition[o * S + sn] * (double)Sus[pn * S + o];
@@ -2314,6 +2333,17 @@ extern "C" __global__ void __launch_bounds__(64) vgx_tau_finish_kernel(VgxTauArg
 #define SUS_GRID dim3((unsigned)((a->p.P * a->p.S * a->p.S + TB - 1) / TB), (unsigned)a->R)
 TAU_LAUNCH(tau_eff, dim3((unsigned)a->p.P, (unsigned)a->R), dim3(TB))
 TAU_LAUNCH(tau_prep, dim3((unsigned)a->p.P, (unsigned)a->R), dim3(TB))
+// blocks per (population, replicate) of the drift kernel vgxi_tau_drift launches last (= slots of VgxTauArgs.dS_part in use)
+extern "C" __attribute__((visibility("hidden"))) int vgxi_tau_drift_blocks(const VgxTauArgs *a) {
+    if (tau_drift_tiled_ok(a->p.sites, a->mut_uniform) && a->mutHi) {
+        const int sites = a->p.sites, low = sites < VGX_DRIFT_LOW ? sites : VGX_DRIFT_LOW;
+        const int64_t ntiles = a->p.H >> (2 * low);
+        if (a->mutlow_fast) return (int)std::min<int64_t>(ntiles, std::max<int64_t>(1, 4096 / std::max<int64_t>(1, (int64_t)a->p.P * a->R)));
+        return (int)ntiles;
+    }
+    const unsigned tiles = (unsigned)((a->p.H + TB - 1) / TB);
+    return (int)(tiles < 32u ? tiles : 32u);
+}
 extern "C" __attribute__((visibility("hidden"))) hipError_t vgxi_tau_drift(const VgxTauArgs *a, hipStream_t s) {
     if (a->has_mig && a->mig_uniform) {
         hipLaunchKernelGGL(vgx_tau_colsum_kernel, dim3((unsigned)((a->p.H + 4 * TB - 1) / (4 * TB)), (unsigned)a->R), dim3(TB), 0, s, *a);
@@ -2343,8 +2373,7 @@ extern "C" __attribute__((visibility("hidden"))) hipError_t vgxi_tau_drift(const
         }
         if (a->mutlow_fast) {
             // blocks per (population, replicate): enough blocks to fill the chip, the rest of the tiles in each block's loop
-            const int64_t ntiles = a->p.H >> (2 * low), want = std::max<int64_t>(1, 4096 / std::max<int64_t>(1, (int64_t)a->p.P * a->R));
-            const dim3 grid((unsigned)std::min<int64_t>(ntiles, want), (unsigned)a->p.P, (unsigned)a->R);
+            const dim3 grid((unsigned)vgxi_tau_drift_blocks(a), (unsigned)a->p.P, (unsigned)a->R);
             const bool c1 = a->p.C == 1, s1 = a->p.S == 1;
             if (c1 && s1) hipLaunchKernelGGL((vgx_tau_drift_fast_kernel<true, true>), grid, dim3(TB), 0, s, *a);
             else if (c1) hipLaunchKernelGGL((vgx_tau_drift_fast_kernel<true, false>), grid, dim3(TB), 0, s, *a);
