@@ -402,8 +402,9 @@ class BenchLoop:
             if self.pending is not None:
                 self.pending.wait()
             if self.rank == 0 and self.gather_out is None:
-                self.gather_out = torch.empty((self.world, self.R, self.T, self.pops, 2), dtype=torch.float64, device=self.device)
-            self.pending = self.ens.gather_trajectories(dst=0, out=self.gather_out, async_op=True)
+                self.gather_out = torch.empty((self.world, self.R, self.T, self.pops, 2), dtype=torch.int32, device=self.device)
+            # compartment totals are whole numbers below the population size (1e7): 32-bit on the wire, half the bytes per link
+            self.pending = self.ens.gather_trajectories(dst=0, out=self.gather_out, async_op=True, wire_dtype=torch.int32)
         return res
 
     def drain(self):
@@ -582,6 +583,9 @@ def main():
             line["cpu_baseline"] = cpu_baseline()
     ens.close()
     ens = None
+    loop.gather_out = None      # rank 0's [world, R, T, P, 2] result: release it before the other legs allocate
+    loop = None
+    torch.cuda.empty_cache()
     # tau-leaping leg (BASELINE config 4): one independent replicate per GPU (replicas only, no collective on the path)
     tau = None
     if not a.no_tau:

@@ -31,11 +31,12 @@ WORKER = textwrap.dedent("""
     R, T, P, N = 3, 5, 2, 40
 
     def block(seeds):            # what this rank's engine "simulated": a function of its seeds only
-        return seeds[:, None, None, None].astype(np.float64) + np.arange(T * P * 2, dtype=np.float64).reshape(1, T, P, 2) / 100.0
+        return seeds[:, None, None, None].astype(np.float64) + np.arange(T * P * 2, dtype=np.float64).reshape(1, T, P, 2) * 100000.0
 
     class StubEnsemble(Ensemble):     # engine stand-in: everything above the C ABI is the product's code
         def __init__(self):
             self.R, self.traj_shape, self.calls = R, (R, T, P, 2), []
+            self.model = type("Model", (), {"sizes": np.array([10 ** 7, 10 ** 7])})   # the 32-bit wire format asks for the sizes
         def simulate(self, iterations, sample_size=None, record_events=False, traj_points=0, traj_window=(0.0, 1.0), seeds=None, **kw):
             assert iterations == N and traj_points == T and len(seeds) == R
             self.calls.append(np.asarray(seeds).copy())
@@ -56,6 +57,7 @@ WORKER = textwrap.dedent("""
     if rank == 0:
         want = np.stack([block(2020 + (2 * world + k) * R + np.arange(R)) for k in range(world)])
         assert loop.gather_out.shape == (world, R, T, P, 2)
+        assert loop.gather_out.dtype == torch.int32     # whole numbers below the population size: 32 bits on the wire
         assert np.array_equal(loop.gather_out.numpy(), want), "gathered trajectories of the last step"
     else:
         assert loop.gather_out is None

@@ -56,6 +56,18 @@ WORKER = textwrap.dedent("""
     if rank == 0:
         assert np.array_equal(res[0].numpy(), np.arange(R * T * P * 2, dtype=np.float64).reshape(R, T, P, 2) + 14.0)
         print("ASYNC_OK")
+    # 32-bit wire format: same numbers, int32 result; refused when a population could overflow it
+    ens.model = type("Model", (), {"sizes": np.array([10 ** 7, 10 ** 7])})
+    got32 = ens.gather_trajectories(dst=0, wire_dtype=torch.int32)
+    if rank == 0:
+        assert got32.dtype == torch.int32 and np.array_equal(got32.numpy(), res.numpy())
+        print("WIRE32_OK")
+    ens.model = type("Model", (), {"sizes": np.array([10 ** 7, 2 ** 31])})
+    try:
+        ens.gather_trajectories(dst=0, wire_dtype=torch.int32)
+        raise SystemExit("int32 wire format accepted a population of 2^31 hosts")
+    except ValueError:
+        pass
     # seed partition used by bench.py: disjoint and independent of the world size
     step, seeds = 0, 2020 + (0 * world + rank) * R + np.arange(R)
     allseeds = [torch.zeros(R, dtype=torch.int64) for _ in range(world)]
@@ -76,4 +88,4 @@ def test_gather_world_size_2(tmp_path):
         procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     outs = [p.communicate(timeout=240)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
-    assert "GATHER_OK" in outs[0] and "ASYNC_OK" in outs[0]
+    assert "GATHER_OK" in outs[0] and "ASYNC_OK" in outs[0] and "WIRE32_OK" in outs[0]

@@ -173,24 +173,36 @@ class Ensemble:
         eng._check(eng.lib.vgx_get_trajectories(eng.handle, C.c_void_p(out.data_ptr()), 1 if out.is_cuda else 0))
         return out
 
-    def gather_trajectories(self, dst=0, out=None, async_op=False):
+    def gather_trajectories(self, dst=0, out=None, async_op=False, wire_dtype=None):
         """One collective for the whole ensemble: every rank's ``[R, T, P, 2]`` block to rank ``dst``
         (``torch.distributed.gather``; backend nccl = RCCL over xGMI, gloo on CPU).  Returns the stacked
         ``[world, R, T, P, 2]`` tensor on ``dst`` and None elsewhere; ``out`` may be a preallocated result tensor on
         ``dst``.  With ``async_op=True`` the trajectories are first copied out of the engine (so the next ``simulate``
         may overwrite them) and a :class:`PendingGather` is returned: the transfer overlaps the next step and
-        ``.wait()`` gives the result."""
+        ``.wait()`` gives the result.  ``wire_dtype=torch.int32`` sends the compartment totals as 32-bit integers (they are
+        whole numbers; refused unless every population size is below 2^31): half the bytes on every xGMI link and in the
+        result on ``dst``, which then has that dtype."""
         import torch
         import torch.distributed as dist
+
+        def narrow(t):
+            if wire_dtype is None or wire_dtype == torch.float64:
+                return t
+            if wire_dtype != torch.int32:
+                raise ValueError("wire_dtype must be None, torch.float64 or torch.int32")
+            if int(np.max(self.model.sizes)) >= 2 ** 31:
+                raise ValueError("wire_dtype=int32 needs population sizes below 2^31")
+            return t.to(torch.int32)
+
         if not (dist.is_available() and dist.is_initialized()):
-            res = torch.from_numpy(self.trajectories())[None]
+            res = narrow(torch.from_numpy(self.trajectories()))[None]
             return PendingGather(None, res, None) if async_op else res
         backend = dist.get_backend()
         if backend == "nccl":
             dev = torch.device("cuda", torch.cuda.current_device())
-            mine = self.trajectories(torch.empty(self.traj_shape, dtype=torch.float64, device=dev))
+            mine = narrow(self.trajectories(torch.empty(self.traj_shape, dtype=torch.float64, device=dev)))
         else:
-            mine = torch.from_numpy(self.trajectories())
+            mine = narrow(torch.from_numpy(self.trajectories()))
         world, rank = dist.get_world_size(), dist.get_rank()
         if rank == dst:   # gather straight into the rows of the result: no second copy of [world, R, T, P, 2]
             if out is None:
