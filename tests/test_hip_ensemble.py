@@ -112,6 +112,9 @@ def test_rccl_gather_single_rank(tmp_path):
         torch.cuda.synchronize()
         assert res is out and np.array_equal(res[0].cpu().numpy(), want)      # the first call's trajectories
         assert not np.array_equal(ens.trajectories(), want)
+        want2 = ens.trajectories()
+        got32 = ens.gather_trajectories(dst=0, wire_dtype=torch.int32)      # the wire format bench.py uses
+        assert got32.is_cuda and got32.dtype == torch.int32 and np.array_equal(got32[0].cpu().numpy(), want2)
         dist.destroy_process_group()
         print("RCCL_OK")
     """) % (root, root))
