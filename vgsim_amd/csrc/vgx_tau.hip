@@ -1232,14 +1232,16 @@ template <bool DRY, int TABS>
 static __device__ __forceinline__ int tau_cell_events(const VgxTauArgs &a, const TauTabT<TABS> &T, const TauEnv &E, int rep, int pn, int hn, double tau,
                                                       int64_t Icell, uint32_t bucket, int64_t &ownChk, int64_t &ownApp, int64_t *cnt,
                                                       WaveStage *stage, unsigned long long *sS /* LDS [S]: this population's susceptible deltas */,
-                                                      int target) {
+                                                      int target, int cls = -1 /* the compartment's rate class if the caller has it */,
+                                                      long long *prof = nullptr /* diagnostic build: [0] last stamp, [1..5] phases */) {
+#define CEPROF(i) do { if (prof) { const long long t_ = clock64(); prof[i] += t_ - prof[0]; prof[0] = t_; } } while (0)
     const VgxDevParams &p = a.p;
     const int P = p.P, S = p.S, H = p.H, sites = p.sites;
     ownChk = 0;
     ownApp = 0;
     if (Icell <= 0) return 0;
     const double Ih = (double)Icell;
-    const int c = (p.C == 1) ? 0 : p.cls[hn];
+    const int c = cls >= 0 ? cls : ((p.C == 1) ? 0 : p.cls[hn]);
     const int cb = T.c_bidx[c];
     const int st = T.c_stype[c];
     // ---- channel rates per unit time ----
@@ -1267,6 +1269,7 @@ static __device__ __forceinline__ int tau_cell_events(const VgxTauArgs &a, const
             F += pk;
         }
     }
+    CEPROF(1);
     if (N == 0) return 0;
     int64_t rec = 0, samp = 0, births = 0, n_mut = 0, n_mig = 0;
     int bsn[4] = {0, 0, 0, 0};   // births per susceptibility group (first four): ONE multievent row per channel, as upstream's
@@ -1293,6 +1296,7 @@ static __device__ __forceinline__ int tau_cell_events(const VgxTauArgs &a, const
         } else if (u < t4 || r_mig == 0.0) n_mut += 1;
         else n_mig += 1;
     }
+    CEPROF(2);
     // ---- mutants (pyx:2506-2512 / 2579-2586): site and derived state ----
     int64_t mut_done = 0, to_target = 0;
     for (int64_t k = 0; k < n_mut; ++k) {
@@ -1332,6 +1336,7 @@ static __device__ __forceinline__ int tau_cell_events(const VgxTauArgs &a, const
         tau_row(a, rep, 1, 3, hn, pn, nh, 0);
     }
     if (DRY) { ownChk = to_target; return 1; }
+    CEPROF(3);
     // ---- migrants (pyx:2464-2474 / 2541-2550): target population and susceptibility group, by bisection in the
     // cumulative channel weights of this source population and birth class ----
     int64_t *dS = a.dSi + (int64_t)rep * P * S;
@@ -1354,6 +1359,7 @@ static __device__ __forceinline__ int tau_cell_events(const VgxTauArgs &a, const
         atomicAdd((unsigned long long *)&a.dTot[(int64_t)rep * P + tp], 1ull);
         tau_row(a, rep, 1, 5, hn, pn, ts, tp);
     }
+    CEPROF(4);
     cnt[0] += births; cnt[1] += rec; cnt[2] += samp; cnt[3] += mut_done; cnt[5] += migrants;
     for (int sn = 0; sn < 4; ++sn)
         if (bsn[sn]) tau_row(a, rep, bsn[sn], 0, hn, pn, sn, 0);
@@ -1366,7 +1372,9 @@ static __device__ __forceinline__ int tau_cell_events(const VgxTauArgs &a, const
     const int64_t dt = births - rec - samp;
     cnt[6] += dt;             // delta of totalInfectious[pn], added to the block's total at the end
     cnt[7] += dt + migrants;  // ... and the same sum as the check books it (mutants cancel inside the population)
+    CEPROF(5);
     return 1;
+#undef CEPROF
 }
 
 // LDS budget of the events kernel's tables (doubles, then int32); 0 = tables stay in global memory
@@ -1386,6 +1394,12 @@ static __host__ __device__ inline size_t tau_tab_lds_bytes(int C, int CB, int S,
 #define EB 64               // threads per block of the events kernel
 #ifndef VGX_EV_WAVES
 #define VGX_EV_WAVES 2      // wavefronts per SIMD the events kernel's register allocation aims at
+#endif
+#ifndef VGX_EV_CHUNK
+#define VGX_EV_CHUNK 8      // rounds whose queue entries and counts a wavefront of the events kernel loads in one go
+#endif
+#ifndef VGX_EV_BLOCKS
+#define VGX_EV_BLOCKS 2048  // wavefronts of the events kernel per launch: what the chip holds at VGX_EV_WAVES per SIMD
 #endif
 static __host__ __device__ inline unsigned tau_draw_gx(int64_t H) {   // blocks of the scan kernel per (population, replicate)
     const unsigned tiles = (unsigned)((H + 1023) >> 10);              // wave tiles of 1024 haplotypes
@@ -1695,29 +1709,58 @@ __global__ void __launch_bounds__(TB) vgx_tau_scan_fast_kernel(VgxTauArgs a) {
     }
 }
 
-// grid = (tau_draw_gx(H) * ev_split, P, R), one wavefront per block: ev_split blocks share a shard of the queue and take its
-// rounds of 64 entries in turn (few shards with many entries each — mid-size models — still fill the chip); dSi / dTot /
-// dChkTot are zero on entry.  The shards' counters are cleared by vgx_tau_decide_kernel.
+// In-kernel stamps of the events kernel (diagnostic build only, -DVGX_PROFILE; tools/profile_tau_events.py): shader cycles per
+// phase summed over all wavefronts.  [0] prologue, [1] wait for the round's count, [2] draws + bookkeeping, [3] rescue tests,
+// [4] staged list -> global, [5] epilogue, [7..11] inside tau_cell_events (lane 0's stamps: rates + count, split, mutants,
+// migrants, tallies), [12] rounds, [13] wavefronts.
+#ifdef VGX_PROFILE
+__device__ unsigned long long vgx_tau_ev_prof[16];
+extern "C" int vgx_tau_get_profile(unsigned long long *out, int clear) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(vgx_tau_ev_prof), sizeof(unsigned long long) * 16) != hipSuccess) return 1;
+    if (clear) {
+        unsigned long long z[16] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(vgx_tau_ev_prof), z, sizeof z) != hipSuccess) return 1;
+    }
+    return 0;
+}
+#define EVPROF(i) do { const long long t_ = clock64(); pacc[i] += t_ - pt; pt = t_; } while (0)
+#else
+#define EVPROF(i)
+#endif
+// grid = (tau_events_gx * ev_split, P, R), one wavefront per block: ev_split blocks share a shard of the queue and take its
+// rounds of 64 entries in turn (few shards with many entries each — mid-size models — still fill the chip), and a block works
+// through several shards of its population one after the other when there are more shards than the chip holds wavefronts;
+// dSi / dTot / dChkTot are zero on entry.  The shards' counters are cleared by vgx_tau_decide_kernel.
 template <int TABS>
 __global__ void __launch_bounds__(EB, VGX_EV_WAVES) vgx_tau_events_kernel(VgxTauArgs a) {
     const int rep = blockIdx.z, pn = blockIdx.y;
     if (!a.active[rep] || a.accepted[rep]) return;
+#ifdef VGX_PROFILE
+    long long pacc[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, prounds = 0;
+    long long &pt = pacc[6];   // (tau_cell_events stamps through the same array: [6] = last stamp, [7..11] its phases)
+    pt = clock64();
+#endif
     const VgxDevParams &p = a.p;
     const int P = p.P, S = p.S, C = p.C, CB = p.CB, H = p.H;
     const int64_t scap = a.q_cap / a.q_shards;
     const int split = a.ev_split, sub = (int)(blockIdx.x % split);
-    const int64_t shard = (int64_t)pn * (gridDim.x / split) + blockIdx.x / split;
-    const int64_t n = (int64_t)a.q_n[(int64_t)rep * a.q_shards + shard];
-    if ((int64_t)sub * EB >= n) return;
-    if (__hip_atomic_load(&a.ok[rep], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return;   // the try is already lost (see below)
-    if (n > scap) {   // the shard overflowed: compartments were lost, the host enlarges the queue and the same try runs again
-        if (threadIdx.x == 0) atomicOr(&a.grow[rep], 8);
-        return;
+    // the block's shards of its population's part of the queue: sb0, sb0 + sbstep, ... (its tables, the state of the try and
+    // the final sums are set up / added once per block: with one shard per block they were a quarter of a wavefront's life)
+    const int shards_pop = (int)(a.q_shards / P), sb0 = (int)(blockIdx.x / split), sbstep = (int)(gridDim.x / split);
+    const unsigned long long *qn_pop = a.q_n + (int64_t)rep * a.q_shards + (int64_t)pn * shards_pop;
+    {
+        bool any = false;
+        for (int sb = sb0; sb < shards_pop; sb += sbstep) any = any || (int64_t)sub * EB < (int64_t)qn_pop[sb];
+        if (!any) return;
     }
+    if (__hip_atomic_load(&a.ok[rep], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return;   // the try is already lost (see below)
     extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
     __shared__ unsigned long long sS[64];
     __shared__ double g_rtr[16], g_rmig[16], g_wtr[16 * 64];   // fallback storage when the class tables stay global
     __shared__ WaveStage stage_s;
+    __shared__ int64_t s_q[VGX_EV_CHUNK * EB];   // queue entries and counts of the rounds of a chunk, one column per lane
+    __shared__ int32_t s_I[VGX_EV_CHUNK * EB], s_c[VGX_EV_CHUNK * EB];   // (s_c: rate classes, when there are several)
+    const bool many_cls = C != 1;
     sS[threadIdx.x] = 0;
     const bool cdfL = TABS == 2;   // (the launcher picks the instantiation from tau_tab_lds_bytes)
     TauTabT<TABS> T;
@@ -1782,26 +1825,64 @@ __global__ void __launch_bounds__(EB, VGX_EV_WAVES) vgx_tau_events_kernel(VgxTau
     const int32_t *Irow = a.I + ((int64_t)rep * P + pn) * H;
     int32_t *dCrow = a.dChk + ((int64_t)rep * P + pn) * H, *dArow = a.dApp + ((int64_t)rep * P + pn) * H;
     const bool dense = !a.sparse;
-    const int64_t *qsrc = a.q + (int64_t)rep * a.q_cap + shard * scap;
     const TauEnv E = tau_env(a, rep, pn);
     // `ok` is read and cleared at device scope: the XCDs' L2 caches are not coherent with each other for plain accesses, a
     // wavefront on another XCD would never see the flag.  The load is issued one round ahead of its use.
     int okv = __hip_atomic_load(&a.ok[rep], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    // the queue entry is loaded two rounds ahead of its use, the compartment's count (a dependent, scattered load) one round
     const int64_t kstep = (int64_t)split * EB, kfirst = (int64_t)sub * EB;
-    int64_t qe_c = kfirst + L < n ? qsrc[kfirst + L] : 0, qe_n = kfirst + kstep + L < n ? qsrc[kfirst + kstep + L] : 0;
-    int32_t I_c = kfirst + L < n ? Irow[min((int)(qe_c & 0x7FFFFFFFll), H - 1)] : 0;   // (indices clamped: a bad entry must not fault)
     int round = 0;
-    for (int64_t k0 = kfirst; k0 < n; k0 += kstep, ++round) {
-        if (okv == 0) break;   // the try is already lost: nothing of it counts (vgx_tau_decide_kernel)
-        // (a device-scope load goes past the L2: a few microseconds, and every wait for memory waits for it too — every fourth round)
-        if ((round & 3) == 3) okv = __hip_atomic_load(&a.ok[rep], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    EVPROF(0);
+    for (int sb = sb0; sb < shards_pop && okv != 0; sb += sbstep) {
+    const int64_t n = (int64_t)qn_pop[sb];
+    if (kfirst >= n) continue;
+    if (n > scap) {   // the shard overflowed: compartments were lost, the host enlarges the queue and the same try runs again
+        if (threadIdx.x == 0) atomicOr(&a.grow[rep], 8);
+        continue;
+    }
+    const int64_t *qsrc = a.q + (int64_t)rep * a.q_cap + ((int64_t)pn * shards_pop + sb) * scap;
+    for (int64_t kc = kfirst; kc < n && okv != 0; kc += (int64_t)VGX_EV_CHUNK * kstep) {
+    {   // The queue entries of the next VGX_EV_CHUNK rounds and, from them, the compartments' counts (dependent, scattered): two
+        // bursts of unconditional loads (indices clamped), parked in the wavefront's LDS stage.  One load per round issued
+        // "ahead" does not work here: vmcnt counts loads and stores together and the round's body has stores and atomics, so
+        // the compiler has to wait for everything (vmcnt(0)) at each use — every round paid a full trip to HBM.
+        // `ok` rides along (a device-scope load goes past the L2: a few microseconds): a lost try is noticed within a chunk.
+        okv = __hip_atomic_load(&a.ok[rep], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int64_t qv[VGX_EV_CHUNK];
+        int32_t Iv[VGX_EV_CHUNK], Cv[VGX_EV_CHUNK];
+#pragma unroll
+        for (int j = 0; j < VGX_EV_CHUNK; ++j) {
+            const int64_t kk = kc + (int64_t)j * kstep + L;
+            qv[j] = qsrc[kk < n ? kk : n - 1];
+        }
+#ifdef VGX_PROFILE
+        { int t_; asm volatile("v_mov_b32 %0, %1" : "=v"(t_) : "v"((int)qv[VGX_EV_CHUNK - 1])); asm volatile("" :: "v"(t_)); }
+        { const long long t_ = clock64(); pacc[12] += t_ - pt; pt = t_; }
+#endif
+#pragma unroll
+        for (int j = 0; j < VGX_EV_CHUNK; ++j) {
+            const int hh = min((int)(qv[j] & 0x7FFFFFFFll), H - 1);   // (a bad entry must not fault)
+            Iv[j] = Irow[hh];
+            Cv[j] = many_cls ? p.cls[hh] : 0;
+        }
+#pragma unroll
+        for (int j = 0; j < VGX_EV_CHUNK; ++j) {
+            s_q[j * EB + L] = qv[j]; s_I[j * EB + L] = Iv[j];
+            if (many_cls) s_c[j * EB + L] = Cv[j];
+        }
+    }
+#ifdef VGX_PROFILE
+    EVPROF(1);
+#endif
+    for (int j = 0; j < VGX_EV_CHUNK; ++j, ++round) {
+        const int64_t k0 = kc + (int64_t)j * kstep;
+        if (k0 >= n || okv == 0) break;   // (okv == 0: the try is already lost, nothing of it counts: vgx_tau_decide_kernel)
         const int64_t k = k0 + L;
-        const int64_t qe = qe_c;
-        const int32_t I_now = I_c;
-        qe_c = qe_n;
-        I_c = k + kstep < n ? Irow[min((int)(qe_c & 0x7FFFFFFFll), H - 1)] : 0;
-        qe_n = k + 2 * kstep < n ? qsrc[k + 2 * kstep] : 0;
+        const int64_t qe = s_q[j * EB + L];
+        const int32_t I_now = s_I[j * EB + L];
+        const int cls_now = many_cls ? s_c[j * EB + L] : 0;
+#ifdef VGX_PROFILE
+        prounds += 1;
+#endif
         int h = 0;
         int64_t v = 0;
         bool below = false;   // below zero on its own (sparse mode): looked at by the whole wavefront, see below
@@ -1809,7 +1890,11 @@ __global__ void __launch_bounds__(EB, VGX_EV_WAVES) vgx_tau_events_kernel(VgxTau
             h = (int)(qe & 0x7FFFFFFFll);
             const int64_t Ih = (int64_t)I_now;
             int64_t oc = 0, oa = 0;
-            const int r = tau_cell_events<false, TABS>(a, T, E, rep, pn, h, tau, Ih, (uint32_t)(qe >> 32), oc, oa, cnt, stage, sS, -1);
+#ifdef VGX_PROFILE
+            const int r = tau_cell_events<false, TABS>(a, T, E, rep, pn, h, tau, Ih, (uint32_t)(qe >> 32), oc, oa, cnt, stage, sS, -1, cls_now, pacc + 6);
+#else
+            const int r = tau_cell_events<false, TABS>(a, T, E, rep, pn, h, tau, Ih, (uint32_t)(qe >> 32), oc, oa, cnt, stage, sS, -1, cls_now);
+#endif
             if (__builtin_expect(r == 2, 0)) {   // many events: one wavefront draws its channels one by one (vgx_tau_draw_big_kernel)
                 const unsigned long long slot = atomicAdd(&a.big_n[rep], 1ull);
                 if ((int64_t)slot < a.big_cap) a.big[(int64_t)rep * a.big_cap + (int64_t)slot] = (int64_t)pn * H + h;
@@ -1829,6 +1914,7 @@ __global__ void __launch_bounds__(EB, VGX_EV_WAVES) vgx_tau_events_kernel(VgxTau
         // everybody at once: the other wavefronts stop before their next round.  A neighbour that is drawn channel by channel
         // (vgx_tau_draw_big_kernel) leaves the question to the list of arrivals (vgx_tau_arrivals_kernel).
         unsigned long long todo = __ballot(below);
+        EVPROF(2);
         while (__builtin_expect(todo != 0, 0)) {   // (rare: keeps this code out of the round loop's way in the instruction cache)
             const int src = __ffsll((long long)todo) - 1;
             todo &= todo - 1;
@@ -1855,9 +1941,13 @@ __global__ void __launch_bounds__(EB, VGX_EV_WAVES) vgx_tau_events_kernel(VgxTau
         // mutants and migrants; what does not fit goes to the list entry by entry)
         // (LDS only: a full fence would also wait for the loads issued ahead and for this round's global atomics)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (stage->n > VGX_WSTAGE - 96 || k0 + kstep >= n) tau_stage_flush(a, stage, rep);
-    }
-    tau_stage_flush(a, stage, rep);   // (a wavefront that left the loop early)
+        EVPROF(3);
+        if (stage->n > VGX_WSTAGE - 96) tau_stage_flush(a, stage, rep);
+        EVPROF(4);
+    }   // rounds
+    }   // chunks
+    }   // shards
+    tau_stage_flush(a, stage, rep);   // what is left
     unsigned long long *ct = (unsigned long long *)&a.cnt_try[(int64_t)rep * 8];
     for (int i = 0; i < 12; ++i) {   // wave-level sums, then one global atomic per tally
         long long v = cnt[i];
@@ -1872,6 +1962,16 @@ __global__ void __launch_bounds__(EB, VGX_EV_WAVES) vgx_tau_events_kernel(VgxTau
     __syncthreads();
     if (threadIdx.x < S && sS[threadIdx.x])
         atomicAdd((unsigned long long *)&a.dSi[((int64_t)rep * P + pn) * S + threadIdx.x], sS[threadIdx.x]);
+#ifdef VGX_PROFILE
+    EVPROF(5);
+    if (threadIdx.x == 0) {
+        for (int i = 0; i < 6; ++i) atomicAdd(&vgx_tau_ev_prof[i], (unsigned long long)pacc[i]);
+        for (int i = 7; i < 12; ++i) atomicAdd(&vgx_tau_ev_prof[i], (unsigned long long)pacc[i]);
+        atomicAdd(&vgx_tau_ev_prof[14], (unsigned long long)pacc[12]);   // first burst (queue entries + ok) of "wait for the count"
+        atomicAdd(&vgx_tau_ev_prof[12], (unsigned long long)prounds);
+        atomicAdd(&vgx_tau_ev_prof[13], 1ull);
+    }
+#endif
 }
 
 
@@ -2395,7 +2495,10 @@ extern "C" __attribute__((visibility("hidden"))) hipError_t vgxi_tau_draw(const 
     hipError_t err = hipFuncSetAttribute(evk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds ? lds : 16));
     if (err != hipSuccess) return err;
     const dim3 grid(tau_draw_gx(a->p.H), (unsigned)a->p.P, (unsigned)a->R);
-    const dim3 egrid(tau_draw_gx(a->p.H) * (unsigned)a->ev_split, (unsigned)a->p.P, (unsigned)a->R);
+    // blocks of the events kernel per (population, replicate): about VGX_EV_BLOCKS in all, each taking its share of the shards
+    unsigned egx = (unsigned)((VGX_EV_BLOCKS + (int64_t)a->p.P * a->R * a->ev_split - 1) / ((int64_t)a->p.P * a->R * a->ev_split));
+    egx = egx < 1u ? 1u : (egx > tau_draw_gx(a->p.H) ? tau_draw_gx(a->p.H) : egx);
+    const dim3 egrid(egx * (unsigned)a->ev_split, (unsigned)a->p.P, (unsigned)a->R);
     if (a->p.C <= 16 && a->p.CB <= 16 && (a->p.H & 15) == 0) {   // the usual shapes: thresholds tabulated
         const bool c1 = a->p.C == 1, dn = !a->sparse;
         if (c1 && !dn) hipLaunchKernelGGL((vgx_tau_scan_fast_kernel<true, false>), grid, dim3(TB), 0, s, *a);
