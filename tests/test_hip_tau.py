@@ -256,7 +256,8 @@ def test_halving_sieve_leaves_the_accepted_steps_untouched():
         assert getattr(a, k) == getattr(b, k), k
 
 
-@pytest.mark.parametrize("case", ["sparse_large", "tiny_full", "large_compartments", "one_mutant_rescues", "small_next_to_large", "classes_short_rows"])
+@pytest.mark.parametrize("case", ["sparse_large", "tiny_full", "large_compartments", "one_mutant_rescues", "small_next_to_large", "classes_short_rows",
+                                  "queue_grows"])
 def test_sparse_try_equals_the_dense_passes(case):
     """A try of the halving loop keeps its deltas as a list of moves and checks the bounds of GenerateEvents_tau
     (pyx:2522-2528) where the deltas are drawn (own deltas at once, compartments found below zero against the mutants of
@@ -297,6 +298,13 @@ def test_sparse_try_equals_the_dense_passes(case):
                 s.set_susceptibility_type(1)
                 s.set_total_migration_probability(0.1); s.set_population_size(10 ** 5)
                 fill, steps = 30, 40
+            elif case == "queue_grows":
+                # 4096 haplotypes with 50 hosts each: most compartments draw events in every try, far more than a shard of the
+                # queue holds at first (an eighth of its compartments): the try is run again with a larger queue
+                s = Simulator(number_of_sites=6, populations_number=2, seed=23)
+                s.set_transmission_rate(2.5); s.set_recovery_rate(0.9); s.set_sampling_rate(0.1); s.set_mutation_rate(0.03)
+                s.set_total_migration_probability(0.02); s.set_population_size(10 ** 7)
+                fill, steps = 50, 12
             elif case == "one_mutant_rescues":
                 s = Simulator(number_of_sites=5, populations_number=4, seed=13)
                 s.set_transmission_rate(0.5); s.set_recovery_rate(1.5); s.set_sampling_rate(0.5); s.set_mutation_rate(1.5)
