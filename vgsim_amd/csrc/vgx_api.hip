@@ -1216,6 +1216,9 @@ extern "C" int vgx_simulate_tau(vgx_engine *e, int64_t iterations, int64_t sampl
             if (e->h_mutp[s2][0] != e->h_mutp[s2][1] || e->h_mutp[s2][1] != e->h_mutp[s2][2]) flat = false;
             if (e->h_mutp[s2][0] != e->h_mutp[nh][0]) same = false;
         }
+        // the fast drift kernel's inner loop loads its inputs unconditionally an iteration ahead: high-site sums as integers,
+        // migration (if any) through the two column sums; the other forms take the general tiled kernel
+        flat = flat && (nh == 0 || a.mutHi_int) && (!a.has_mig || a.mig_uniform);
         a.mutlow_fast = flat ? 1 : 0;
         a.mutlow_same = (flat && same) ? 1 : 0;
         a.hist = nullptr;

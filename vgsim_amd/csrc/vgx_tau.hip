@@ -698,17 +698,21 @@ __global__ void __launch_bounds__(TB) vgx_tau_drift_fast_kernel(VgxTauArgs a) {
     const int ntiles = H >> (2 * low);
     // the per-compartment inputs from global memory (high-site neighbour sums, the two column sums of uniform migration) are
     // loaded one iteration ahead — the first ones before the tile is in LDS: their latency was most of a block's life
+    // (The loads are UNCONDITIONAL — an input that is not used reads the counts instead, an index past the tile its last group
+    // — and the tile phase below ends with an explicit wait: vmcnt counts loads and stores together, so with a store possibly
+    // pending, or with loads that only some paths issue, the compiler can only wait for everything (vmcnt(0)) where the
+    // inputs are used, which would wait for the loads just issued for the NEXT iteration as well.)
     struct DIn { int4 hi; double4 cT, cTW; };
+    const bool use_hi = nh > 0 && a.mutHi_int, use_col = a.has_mig && a.mig_uniform;
+    const int32_t *hiP = use_hi ? (const int32_t *)a.mutHi + rowoff : I;
+    const double *cTP = use_col ? a.colT + (int64_t)rep * H : (const double *)I, *cTWP = use_col ? a.colTW + (int64_t)rep * H : (const double *)I;
     auto load_in = [&](int h0, int t0) -> DIn {
         DIn d;
-        d.hi = make_int4(0, 0, 0, 0); d.cT = make_double4(0.0, 0.0, 0.0, 0.0); d.cTW = d.cT;
-        if (t0 < TS) {
-            if (nh > 0 && a.mutHi_int) d.hi = *(const int4 *)((const int32_t *)a.mutHi + rowoff + h0 + t0);
-            if (a.has_mig && a.mig_uniform) {   // shared by all populations: they stay in the caches
-                d.cT = *(const double4 *)(a.colT + (int64_t)rep * H + h0 + t0);
-                d.cTW = *(const double4 *)(a.colTW + (int64_t)rep * H + h0 + t0);
-            }
-        }
+        const int tc = t0 < TS ? t0 : TS - 4;
+        d.hi = *(const int4 *)(hiP + h0 + tc);
+        const int64_t ci = use_col ? (int64_t)h0 + tc : 0;   // shared by all populations: they stay in the caches
+        d.cT = *(const double4 *)(cTP + ci);
+        d.cTW = *(const double4 *)(cTWP + ci);
         return d;
     };
     __syncthreads();
@@ -728,31 +732,39 @@ __global__ void __launch_bounds__(TB) vgx_tau_drift_fast_kernel(VgxTauArgs a) {
     const int h0 = tb * TS;
     DIn nxt = load_in(h0, threadIdx.x * 4);
     __syncthreads();   // the previous tile has been read by everybody
-    for (int i = threadIdx.x * 4; i < TS; i += TB * 4) {
-        const int4 v = *(const int4 *)(I + h0 + i);
-        *(int4 *)(tile + i) = v;
-        *(uint32_t *)(a.I8 + rowoff + h0 + i) = tau_pack8(v.x, v.y, v.z, v.w);   // the one-byte copy vgx_tau_scan_kernel streams
+    {   // the tile (at most 4096 = 4 * 4 * TB counts): all of a thread's loads in flight at once
+        int4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = (threadIdx.x + u * TB) * 4;
+            v[u] = *(const int4 *)(I + h0 + (i < TS ? i : 0));
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = (threadIdx.x + u * TB) * 4;
+            if (i < TS) {
+                *(int4 *)(tile + i) = v[u];
+                *(uint32_t *)(a.I8 + rowoff + h0 + i) = tau_pack8(v[u].x, v[u].y, v[u].z, v[u].w);   // the one-byte copy vgx_tau_scan_kernel streams
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): no store pending in the loop below (see load_in)
     }
     __syncthreads();
     for (int t0 = threadIdx.x * 4; t0 < TS; t0 += TB * 4) {
         const DIn in = nxt;
         nxt = load_in(h0, t0 + TB * 4);
         double mh[4] = {0.0, 0.0, 0.0, 0.0}, mg[4] = {0.0, 0.0, 0.0, 0.0};
-        if (nh > 0 && a.mutHi_int) {
+        if (use_hi) {   // (nh > 0 without integer sums: the launcher takes the general tiled kernel)
             const int4 v = in.hi;
             mh[0] = a.mutHi_rate * (double)v.x; mh[1] = a.mutHi_rate * (double)v.y; mh[2] = a.mutHi_rate * (double)v.z; mh[3] = a.mutHi_rate * (double)v.w;
-        } else if (nh > 0) {
-            const double4 v = *(const double4 *)(a.mutHi + rowoff + h0 + t0); mh[0] = v.x; mh[1] = v.y; mh[2] = v.z; mh[3] = v.w;
         }
         const int4 own = *(const int4 *)(tile + t0);
         const int Iv[4] = {own.x, own.y, own.z, own.w};
-        if (a.has_mig && a.mig_uniform) {
+        if (use_col) {
             const double4 v = in.cT, u = in.cTW;
             mg[0] = tau_migu(mu, v.x, u.x, (double)Iv[0]); mg[1] = tau_migu(mu, v.y, u.y, (double)Iv[1]);
             mg[2] = tau_migu(mu, v.z, u.z, (double)Iv[2]); mg[3] = tau_migu(mu, v.w, u.w, (double)Iv[3]);
-        } else if (a.has_mig) {
-            const double4 v = *(const double4 *)(a.migIn + rowoff + h0 + t0); mg[0] = v.x; mg[1] = v.y; mg[2] = v.z; mg[3] = v.w;
-        }
+        }   // (migration that is not uniform: the general tiled kernel)
         // incoming mutation through the low sites
         const int s4 = own.x + own.y + own.z + own.w;
         int nb[4] = {s4 - own.x, s4 - own.y, s4 - own.z, s4 - own.w};   // last site: the other three of the four
