@@ -1772,7 +1772,7 @@ __global__ void __launch_bounds__(EB, VGX_EV_WAVES) vgx_tau_events_kernel(VgxTau
     if (__hip_atomic_load(&a.ok[rep], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return;   // the try is already lost (see below)
     extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
     __shared__ unsigned long long sS[64];
-    __shared__ double g_rtr[16], g_rmig[16], g_wtr[16 * 64];   // fallback storage when the class tables stay global
+    __shared__ double g_rtr[16], g_rmig[16], g_wtr[TABS == 0 ? 16 * 64 : 1];   // fallback storage when the class tables stay global
     __shared__ WaveStage stage_s;
     __shared__ int64_t s_q[VGX_EV_CHUNK * EB];   // queue entries and counts of the rounds of a chunk, one column per lane
     __shared__ int32_t s_I[VGX_EV_CHUNK * EB], s_c[VGX_EV_CHUNK * EB];   // (s_c: rate classes, when there are several)
