@@ -380,6 +380,44 @@ ORACLE_ONLY_CASES = {
                          [(_lockdown_restart, _direct(3000, sample_size=10 ** 9, attempts=50))]),
 }
 
+def _tau_many_classes(s):   # 300 haplotypes with a recovery rate of their own: more than 256 rate classes
+    s.set_transmission_rate(2.5)
+    s.set_recovery_rate(0.9)
+    s.set_sampling_rate(0.1)
+    s.set_mutation_rate(0.08)
+    for hn in range(300):
+        s.set_recovery_rate(0.5 + 0.002 * hn, haplotype=hn)
+    s.set_migration_probability(0.01)
+
+
+def _tau_wide_table(s):     # 16 transmission classes x 130 populations x 2 susceptibility groups: 4160 out-migration channels
+    s.set_transmission_rate(2.0)
+    s.set_recovery_rate(0.9)
+    s.set_sampling_rate(0.1)
+    s.set_mutation_rate(0.08)
+    for hn in range(15):
+        s.set_transmission_rate(2.1 + 0.1 * hn, haplotype=hn)
+    s.set_susceptibility_type(1)
+    s.set_susceptibility(0.5, susceptibility_type=1)
+    s.set_immunity_transition(0.02, source=1, target=0)
+    s.set_population_size(100000)
+    s.set_total_migration_probability(0.05)
+
+
+# tau cases of the device engine's less common table layouts (class tables in global memory / the migration table bisected in
+# global memory): the oracle is the checker, distributionally (tests/test_hip_tau.py)
+TAU_ORACLE_ONLY_CASES = {
+    "tau_many_classes": (_ctor(number_of_sites=5, populations_number=3, number_of_susceptible_groups=1, seed=41),
+                         [(_tau_many_classes, _direct(4000)), (_nothing, dict(iterations=120, sample_size=10 ** 12, method='tau'))]),
+    "tau_wide_table": (_ctor(number_of_sites=3, populations_number=130, number_of_susceptible_groups=2, seed=43),
+                       [(_tau_wide_table, _direct(4000)), (_nothing, dict(iterations=80, sample_size=10 ** 12, method='tau'))]),
+}
+
+
+def tau_case(name):
+    return CASES[name] if name in CASES else TAU_ORACLE_ONLY_CASES[name]
+
+
 # cases whose full (6,N) chain is committed; the others commit head/tail columns + sha256 + counters
 FULL_CHAIN_LIMIT = 20000
 

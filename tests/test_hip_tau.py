@@ -22,7 +22,7 @@ N_SEEDS = 24
 
 def run_tau_case(name, seed, engine, oracle=None):
     from vgsim_amd import Simulator
-    ctor, phases = models.CASES[name]
+    ctor, phases = models.tau_case(name)
     ctor = dict(ctor, seed=seed)
     with helpers.quiet():
         sim = Simulator(**ctor)
@@ -44,9 +44,9 @@ def run_tau_case(name, seed, engine, oracle=None):
     return sim.simulation
 
 
-@pytest.mark.parametrize("name", ["tau_a", "tau_b", "tau_c"])
+@pytest.mark.parametrize("name", ["tau_a", "tau_b", "tau_c", "tau_many_classes", "tau_wide_table"])
 def test_first_leap_length_matches_oracle(oracle_mod, name):
-    ctor, phases = models.CASES[name]
+    ctor, phases = models.tau_case(name)
     hip = run_tau_case(name, ctor["seed"], "hip")
     ref = run_tau_case(name, ctor["seed"], "oracle", oracle_mod)
     nd = phases[0][1]["iterations"]
@@ -57,9 +57,9 @@ def test_first_leap_length_matches_oracle(oracle_mod, name):
     assert dt_hip == pytest.approx(dt_ref, rel=1e-9)
 
 
-@pytest.mark.parametrize("name", ["tau_a", "tau_b", "tau_c", "tau_d"])
+@pytest.mark.parametrize("name", ["tau_a", "tau_b", "tau_c", "tau_d", "tau_many_classes", "tau_wide_table"])
 def test_tau_moments_match_oracle(oracle_mod, name):
-    ctor, _ = models.CASES[name]
+    ctor, _ = models.tau_case(name)
     keys = ("bCounter", "dCounter", "sCounter", "mCounter", "migPlus", "currentTime")
     diffs = {k: [] for k in keys + ("infected",)}
     means = {k: [] for k in keys + ("infected",)}
@@ -257,7 +257,7 @@ def test_halving_sieve_leaves_the_accepted_steps_untouched():
 
 
 @pytest.mark.parametrize("case", ["sparse_large", "tiny_full", "large_compartments", "one_mutant_rescues", "small_next_to_large", "classes_short_rows",
-                                  "queue_grows"])
+                                  "queue_grows", "many_classes", "wide_migration_table"])
 def test_sparse_try_equals_the_dense_passes(case):
     """A try of the halving loop keeps its deltas as a list of moves and checks the bounds of GenerateEvents_tau
     (pyx:2522-2528) where the deltas are drawn (own deltas at once, compartments found below zero against the mutants of
@@ -305,6 +305,26 @@ def test_sparse_try_equals_the_dense_passes(case):
                 s.set_transmission_rate(2.5); s.set_recovery_rate(0.9); s.set_sampling_rate(0.1); s.set_mutation_rate(0.03)
                 s.set_total_migration_probability(0.02); s.set_population_size(10 ** 7)
                 fill, steps = 50, 12
+            elif case == "many_classes":
+                # 300 haplotypes with a recovery rate of their own: more than 256 rate classes, the class tables of the events
+                # kernel stay in global memory and the scan / drift kernels take their general forms
+                s = Simulator(number_of_sites=5, populations_number=3, seed=29)
+                s.set_transmission_rate(2.5); s.set_recovery_rate(0.9); s.set_sampling_rate(0.1); s.set_mutation_rate(0.05)
+                for hn in range(300):
+                    s.set_recovery_rate(0.5 + 0.002 * hn, haplotype=hn)
+                s.set_total_migration_probability(0.02); s.set_population_size(10 ** 6)
+                fill, steps = 3, 25
+            elif case == "wide_migration_table":
+                # 16 transmission classes x 130 populations x 2 susceptibility groups: the out-migration table of a population
+                # (4160 running sums) does not fit the events kernel's LDS budget and is bisected in global memory
+                s = Simulator(number_of_sites=3, populations_number=130, number_of_susceptible_groups=2, seed=37)
+                s.set_transmission_rate(2.0); s.set_recovery_rate(0.9); s.set_sampling_rate(0.1); s.set_mutation_rate(0.05)
+                for hn in range(15):
+                    s.set_transmission_rate(2.1 + 0.1 * hn, haplotype=hn)
+                s.set_susceptibility(0.5, susceptibility_type=1); s.set_immunity_transition(0.02, source=1, target=0)
+                s.set_susceptibility_type(1)
+                s.set_total_migration_probability(0.05); s.set_population_size(10 ** 5)
+                fill, steps = 4, 25
             elif case == "one_mutant_rescues":
                 s = Simulator(number_of_sites=5, populations_number=4, seed=13)
                 s.set_transmission_rate(0.5); s.set_recovery_rate(1.5); s.set_sampling_rate(0.5); s.set_mutation_rate(1.5)
