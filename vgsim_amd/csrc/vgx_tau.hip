@@ -1730,6 +1730,10 @@ __global__ void __launch_bounds__(TB) vgx_tau_scan_fast_kernel(VgxTauArgs a) {
 // [4] staged list -> global, [5] epilogue, [7..11] inside tau_cell_events (lane 0's stamps: rates + count, split, mutants,
 // migrants, tallies), [12] rounds, [13] wavefronts.
 #ifdef VGX_PROFILE
+__device__ unsigned long long vgx_tau_big_prof[8];   // vgx_tau_draw_big_kernel: setup loads, means, draws, books, sums + leader, flush, end, iterations
+extern "C" int vgx_tau_get_big_profile(unsigned long long *out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(vgx_tau_big_prof), sizeof(unsigned long long) * 8) != hipSuccess;
+}
 __device__ unsigned long long vgx_tau_ev_prof[16];
 extern "C" int vgx_tau_get_profile(unsigned long long *out, int clear) {
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(vgx_tau_ev_prof), sizeof(unsigned long long) * 16) != hipSuccess) return 1;
@@ -1902,6 +1906,7 @@ __global__ void __launch_bounds__(EB, VGX_EV_WAVES) vgx_tau_events_kernel(VgxTau
         int h = 0;
         int64_t v = 0;
         bool below = false;   // below zero on its own (sparse mode): looked at by the whole wavefront, see below
+        bool isbig = false;
         if (k < n && (int)(qe & 0x7FFFFFFFll) < H) {
             h = (int)(qe & 0x7FFFFFFFll);
             const int64_t Ih = (int64_t)I_now;
@@ -1911,11 +1916,7 @@ __global__ void __launch_bounds__(EB, VGX_EV_WAVES) vgx_tau_events_kernel(VgxTau
 #else
             const int r = tau_cell_events<false, TABS>(a, T, E, rep, pn, h, tau, Ih, (uint32_t)(qe >> 32), oc, oa, cnt, stage, sS, -1, cls_now);
 #endif
-            if (__builtin_expect(r == 2, 0)) {   // many events: one wavefront draws its channels one by one (vgx_tau_draw_big_kernel)
-                const unsigned long long slot = atomicAdd(&a.big_n[rep], 1ull);
-                if ((int64_t)slot < a.big_cap) a.big[(int64_t)rep * a.big_cap + (int64_t)slot] = (int64_t)pn * H + h;
-                else atomicOr(&a.grow[rep], 4);   // list full: the host enlarges it and the same try runs again
-            }
+            isbig = r == 2;   // many events: a group of lanes draws its channels one by one (vgx_tau_draw_big_kernel)
             if (dense) { dCrow[h] = (int32_t)oc; dArow[h] = (int32_t)oa; }
             else if (oa != 0) tau_list_add(a, stage, rep, (int64_t)pn * H + h, oa, true);
             if (r == 1) {
@@ -1929,6 +1930,20 @@ __global__ void __launch_bounds__(EB, VGX_EV_WAVES) vgx_tau_events_kernel(VgxTau
         // single-site neighbour per lane (no bookkeeping: tau_cell_events<true>), and a definite failure ends the try for
         // everybody at once: the other wavefronts stop before their next round.  A neighbour that is drawn channel by channel
         // (vgx_tau_draw_big_kernel) leaves the question to the list of arrivals (vgx_tau_arrivals_kernel).
+        // the compartments for vgx_tau_draw_big_kernel: ONE reservation per wavefront in their list (an atomic per compartment
+        // on the one counter is worked off one after the other by the memory side: in a large epidemic on a small model, where
+        // every compartment is of this kind, that was the whole kernel)
+        const unsigned long long bigm = __ballot(isbig);
+        if (__builtin_expect(bigm != 0, 0)) {
+            unsigned long long base = 0;
+            if (L == __ffsll((long long)bigm) - 1) base = atomicAdd(&a.big_n[rep], (unsigned long long)__popcll(bigm));
+            base = (unsigned long long)bcast_i64((int64_t)base, __ffsll((long long)bigm) - 1);
+            if (isbig) {
+                const unsigned long long slot = base + (unsigned long long)__popcll(bigm & ((1ull << L) - 1ull));
+                if ((int64_t)slot < a.big_cap) a.big[(int64_t)rep * a.big_cap + (int64_t)slot] = (int64_t)pn * H + h;
+                else atomicOr(&a.grow[rep], 4);   // list full: the host enlarges it and the same try runs again
+            }
+        }
         unsigned long long todo = __ballot(below);
         EVPROF(2);
         while (__builtin_expect(todo != 0, 0)) {   // (rare: keeps this code out of the round loop's way in the instruction cache)
@@ -1997,7 +2012,12 @@ __global__ void __launch_bounds__(EB, VGX_EV_WAVES) vgx_tau_events_kernel(VgxTau
 // compartment with 10^5 hosts would do for tens of thousands of events on one lane (natural epidemics: most hosts carry a
 // few haplotypes); the joint law of the channel counts is the same (Poisson splitting).  A channel's stream is keyed by
 // (compartment, channel), so the result does not depend on the lane mapping.  grid = (VGX_BIG_BLOCKS, R), 4 waves a block.
-#define VGX_BIG_BLOCKS 2048   // (blocks without work leave at once)
+#define VGX_BIG_BLOCKS 512    // four wavefronts each: what the chip holds at two wavefronts per SIMD (blocks without work leave at once)
+#define VGX_BIG_LT 2048       // block-local sums kept in LDS: P * (S + 2) + 5 entries (else straight to global memory)
+// A compartment is worked on by a GROUP of 16, 32 or 64 lanes (the smallest that holds its channels, or 64): with few channels
+// — small models, where such compartments are the whole epidemic — a wavefront draws four or two compartments at a time.  The
+// lanes first work out their channel's mean, then ALL draw through one call of the sampler (five inlined copies, one per kind
+// of channel, ran one after the other), then book the result.
 extern "C" __global__ void __launch_bounds__(TB) vgx_tau_draw_big_kernel(VgxTauArgs a) {
     const int rep = blockIdx.y;
     if (!a.active[rep] || a.accepted[rep]) return;
@@ -2006,11 +2026,51 @@ extern "C" __global__ void __launch_bounds__(TB) vgx_tau_draw_big_kernel(VgxTauA
     const int lane = threadIdx.x & 63;
     unsigned long long n = a.big_n[rep];
     if ((int64_t)n > a.big_cap) n = (unsigned long long)a.big_cap;
+    if (n == 0) return;
+#ifdef VGX_PROFILE
+    long long bp[8] = {0, 0, 0, 0, 0, 0, 0, 0}, bt = clock64();
+#define BPROF(i) do { const long long t_ = clock64(); bp[i] += t_ - bt; bt = t_; } while (0)
+#else
+#define BPROF(i)
+#endif
     const double tau = a.tau[rep];
+    const uint64_t seed = (uint64_t)a.seeds[rep];
+    const uint32_t att = (uint32_t)a.attempt[rep], step = (uint32_t)a.step[rep], retry = (uint32_t)a.retry[rep];
     int64_t *dS = a.dSi + (int64_t)rep * P * S;
-    long long tot[5] = {0, 0, 0, 0, 0};   // lane 0: this wavefront's tallies (one atomic each at the end, not one per compartment)
-    for (unsigned long long e = (unsigned long long)blockIdx.x * (TB / 64) + (threadIdx.x >> 6); e < n; e += (unsigned long long)gridDim.x * (TB / 64)) {
-        const int64_t cell = a.big[(int64_t)rep * a.big_cap + (int64_t)e];
+    const int n_mut = 3 * sites, nchan_max = 2 + S + n_mut + (a.has_mig ? P * S : 0);
+    const int G = nchan_max <= 16 ? 16 : (nchan_max <= 32 ? 32 : 64), per_wave = 64 / G, gl = lane & (G - 1);
+    long long tot[5] = {0, 0, 0, 0, 0};   // group leaders: their tallies (one atomic each at the end, not one per compartment)
+    // the moves are staged per wavefront (one reservation in the global list per ~128 entries instead of one per entry: every
+    // channel of a large compartment has events, and all wavefronts of a small model append to the same few shards)
+    // Sums per population (susceptible deltas, the two infectious totals) and the counters are collected per BLOCK in LDS and
+    // added to global memory once at the end: every compartment of a population adds to the same few addresses, and atomics
+    // on one address are worked off one after the other by the memory side — with eight populations that was half the kernel.
+    __shared__ unsigned long long lt[VGX_BIG_LT];
+    const int lt_n = P * (S + 2) + 5;
+    const bool use_lt = lt_n <= VGX_BIG_LT;
+    if (use_lt) {
+        for (int i = threadIdx.x; i < lt_n; i += TB) lt[i] = 0;
+        __syncthreads();
+    }
+    unsigned long long *ct = (unsigned long long *)&a.cnt_try[(int64_t)rep * 8];
+    auto add_dS = [&](int idx, long long v) {
+        if (use_lt) atomicAdd(&lt[idx], (unsigned long long)v); else atomicAdd((unsigned long long *)&dS[idx], (unsigned long long)v);
+    };
+    auto add_tot = [&](int pn_, long long v) {
+        if (use_lt) atomicAdd(&lt[P * S + pn_], (unsigned long long)v); else atomicAdd((unsigned long long *)&a.dTot[(int64_t)rep * P + pn_], (unsigned long long)v);
+    };
+    auto add_chk = [&](int pn_, long long v) {
+        if (use_lt) atomicAdd(&lt[P * S + P + pn_], (unsigned long long)v); else atomicAdd((unsigned long long *)&a.dChkTot[(int64_t)rep * P + pn_], (unsigned long long)v);
+    };
+    __shared__ WaveStage stages[TB / 64];
+    WaveStage *stage = &stages[threadIdx.x >> 6];
+    if (lane == 0) stage->n = 0;
+    WSYNC();
+    const unsigned long long wave = (unsigned long long)blockIdx.x * (TB / 64) + (threadIdx.x >> 6), nwaves = (unsigned long long)gridDim.x * (TB / 64);
+    for (unsigned long long e0 = wave * per_wave; e0 < n; e0 += nwaves * per_wave) {
+        const unsigned long long e = e0 + (unsigned long long)(lane / G);
+        const bool have = e < n;
+        const int64_t cell = have ? a.big[(int64_t)rep * a.big_cap + (int64_t)e] : 0;
         const int pn = (int)(cell / H), hn = (int)(cell - (int64_t)pn * H);
         const double Ih = (double)a.I[(int64_t)rep * P * H + cell];
         const int c = (p.C == 1) ? 0 : p.cls[hn];
@@ -2019,27 +2079,21 @@ extern "C" __global__ void __launch_bounds__(TB) vgx_tau_draw_big_kernel(VgxTauA
         const int64_t *Sus = a.S + (int64_t)rep * P * S + (int64_t)pn * S;
         const double *cdf = a.migcdf + (((int64_t)rep * P + pn) * CB + cb) * (int64_t)P * S;
         const double r_mig = a.has_mig ? a.Gout[((int64_t)rep * P + pn) * CB + cb] * p.cb_b[cb] * p.mig[(int64_t)pn * P + pn] * Ih : 0.0;
-        const int n_mut = 3 * sites, n_mig = (r_mig > 0.0) ? P * S : 0, nchan = 2 + S + n_mut + n_mig;
+        const int n_mig = (r_mig > 0.0) ? P * S : 0, nchan = have ? 2 + S + n_mut + n_mig : 0;
         int64_t births = 0, rec = 0, samp = 0, mut_done = 0, migrants = 0;
-        for (int ch = lane; ch < nchan; ch += 64) {
-            TauRng g;
-            g.init((uint64_t)a.seeds[rep], (uint32_t)a.attempt[rep], (uint64_t)cell | ((uint64_t)(ch + 1) << 40), (uint32_t)a.step[rep],
-                   (uint32_t)a.retry[rep]);
-            if (ch == 0) {
-                rec = tau_poisson(g, p.c_d[c] * Ih * tau);                                   // pyx:2386
-                if (rec) tau_row(a, rep, rec, 1, hn, pn, st, 0);
-            } else if (ch == 1) {
-                samp = tau_poisson(g, p.c_s[c] * Ih * p.sampMult[pn] * tau);                 // pyx:2392
-                if (samp) tau_row(a, rep, samp, 2, hn, pn, st, 0);
-            } else if (ch < 2 + S) {                                                         // pyx:2412-2414
+#ifdef VGX_PROFILE
+        { int t_; asm volatile("v_mov_b32 %0, %1" : "=v"(t_) : "v"((int)(r_mig != 0.0) + cb + st + (int)F)); asm volatile("" :: "v"(t_)); }
+#endif
+        BPROF(0);
+        for (int ch = gl; ch < nchan; ch += G) {
+            // the channel's mean number of events in this leap ...
+            double lam;
+            if (ch == 0) lam = p.c_d[c] * Ih * tau;                                          // recovery, pyx:2386
+            else if (ch == 1) lam = p.c_s[c] * Ih * p.sampMult[pn] * tau;                    // sampling, pyx:2392
+            else if (ch < 2 + S) {                                                           // transmission to group sn, pyx:2412-2414
                 const int sn = ch - 2;
-                const int64_t k = tau_poisson(g, p.cb_b[cb] * p.cb_sigma[cb * S + sn] * (double)Sus[sn] * F * Ih * tau);
-                if (k) {
-                    births += k;
-                    atomicAdd((unsigned long long *)&dS[pn * S + sn], (unsigned long long)(-k));
-                    tau_row(a, rep, k, 0, hn, pn, sn, 0);
-                }
-            } else if (ch < 2 + S + n_mut) {                                                 // pyx:2400-2401
+                lam = p.cb_b[cb] * p.cb_sigma[cb * S + sn] * (double)Sus[sn] * F * Ih * tau;
+            } else if (ch < 2 + S + n_mut) {                                                 // mutation, pyx:2400-2401
                 const int m = ch - 2 - S, ss = m / 3, ii = m % 3;
                 double rate;
                 if (a.mut_uniform) rate = a.mutp[ss][ii];
@@ -2047,50 +2101,93 @@ extern "C" __global__ void __launch_bounds__(TB) vgx_tau_draw_big_kernel(VgxTauA
                     const double *hm = p.hapMutType + ((int64_t)hn * sites + ss) * 3;
                     rate = p.mRate[(int64_t)hn * sites + ss] * hm[ii] / (hm[0] + hm[1] + hm[2]);
                 }
-                const int64_t k = tau_poisson(g, rate * Ih * tau);
-                if (k) {
-                    const int nh = tau_mutate(sites, hn, ss, ii);
-                    mut_done += k;
-                    tau_list_add(a, nullptr, rep, (int64_t)pn * H + nh, k, false);
-                    tau_row(a, rep, k, 3, hn, pn, nh, 0);
-                }
-            } else {                                                                         // pyx:2366-2367
-                const int j = ch - 2 - S - n_mut, tp = j / S, ts = j % S;
+                lam = rate * Ih * tau;
+            } else {                                                                         // migration, pyx:2366-2367
+                const int j = ch - 2 - S - n_mut, tp = j / S;
                 const double wj = cdf[j] - (j > 0 ? cdf[j - 1] : 0.0);
-                const int64_t k = (wj > 0.0 && tp != pn) ? tau_poisson(g, wj / cdf[P * S - 1] * r_mig * tau) : 0;
-                if (k) {
-                    migrants += k;
-                    tau_list_add(a, nullptr, rep, (int64_t)tp * H + hn, k, true);
-                    atomicAdd((unsigned long long *)&dS[tp * S + ts], (unsigned long long)(-k));
-                    atomicAdd((unsigned long long *)&a.dTot[(int64_t)rep * P + tp], (unsigned long long)k);
-                    tau_row(a, rep, k, 5, hn, pn, ts, tp);
-                }
+                lam = (wj > 0.0 && tp != pn) ? wj / cdf[P * S - 1] * r_mig * tau : 0.0;
+            }
+#ifdef VGX_PROFILE
+            { int t_; asm volatile("v_mov_b32 %0, %1" : "=v"(t_) : "v"((int)lam)); asm volatile("" :: "v"(t_)); }
+#endif
+            BPROF(1);
+            // ... its draw (a mean of zero draws nothing and uses no random number) ...
+            TauRng g;
+            g.init(seed, att, (uint64_t)cell | ((uint64_t)(ch + 1) << 40), step, retry);
+            const int64_t k = tau_poisson(g, lam);
+            BPROF(2);
+            if (k == 0) continue;
+            // ... and its books
+            if (ch == 0) { rec = k; tau_row(a, rep, k, 1, hn, pn, st, 0); }
+            else if (ch == 1) { samp = k; tau_row(a, rep, k, 2, hn, pn, st, 0); }
+            else if (ch < 2 + S) {
+                const int sn = ch - 2;
+                births += k;
+                add_dS(pn * S + sn, -k);
+                tau_row(a, rep, k, 0, hn, pn, sn, 0);
+            } else if (ch < 2 + S + n_mut) {
+                const int m = ch - 2 - S;
+                const int nh = tau_mutate(sites, hn, m / 3, m % 3);
+                mut_done += k;
+                tau_list_add(a, stage, rep, (int64_t)pn * H + nh, k, false);
+                tau_row(a, rep, k, 3, hn, pn, nh, 0);
+            } else {
+                const int j = ch - 2 - S - n_mut, tp = j / S, ts = j % S;
+                migrants += k;
+                tau_list_add(a, stage, rep, (int64_t)tp * H + hn, k, true);
+                add_dS(tp * S + ts, -k);
+                add_tot(tp, k);
+                tau_row(a, rep, k, 5, hn, pn, ts, tp);
             }
         }
+        BPROF(3);
         long long v[5] = {births, rec, samp, mut_done, migrants};
         for (int i = 0; i < 5; ++i)
-            for (int o = 32; o > 0; o >>= 1) v[i] += __shfl_down(v[i], o);
-        if (lane == 0) {
+            for (int o = G >> 1; o > 0; o >>= 1) v[i] += __shfl_down(v[i], o, G);
+        if (gl == 0 && have) {
             const int64_t own = v[0] - v[1] - v[2] - v[3];
             const int64_t off = (int64_t)rep * P * H + cell;
             if (!a.sparse) {
                 a.dChk[off] = (int32_t)(own + v[4]);   // pyx:2473: migrants are booked on their source here
                 a.dApp[off] = (int32_t)own;
             } else if (own != 0) {
-                tau_list_add(a, nullptr, rep, cell, own, true);
+                tau_list_add(a, stage, rep, cell, own, true);
             }
             tau_own_check(a, rep, pn, hn, (int64_t)a.I[off] + own + v[4]);
-            if (v[0] - v[1] - v[2] + v[4]) atomicAdd((unsigned long long *)&a.dChkTot[(int64_t)rep * P + pn], (unsigned long long)(v[0] - v[1] - v[2] + v[4]));
+            if (v[0] - v[1] - v[2] + v[4]) add_chk(pn, v[0] - v[1] - v[2] + v[4]);
             for (int i = 0; i < 5; ++i) tot[i] += v[i];
-            if (v[1] + v[2]) atomicAdd((unsigned long long *)&dS[pn * S + st], (unsigned long long)(v[1] + v[2]));
-            if (v[0] - v[1] - v[2]) atomicAdd((unsigned long long *)&a.dTot[(int64_t)rep * P + pn], (unsigned long long)(v[0] - v[1] - v[2]));
+            if (v[1] + v[2]) add_dS(pn * S + st, v[1] + v[2]);
+            if (v[0] - v[1] - v[2]) add_tot(pn, v[0] - v[1] - v[2]);
         }
+        WSYNC();
+        BPROF(4);
+        if (stage->n > VGX_WSTAGE - 96) tau_stage_flush(a, stage, rep);   // (what does not fit goes to the list entry by entry)
+        BPROF(5);
+#ifdef VGX_PROFILE
+        bp[7] += 1;
+#endif
     }
-    if (lane == 0) {
-        unsigned long long *ct = (unsigned long long *)&a.cnt_try[(int64_t)rep * 8];
-        const int slot[5] = {0, 1, 2, 3, 5};
+    tau_stage_flush(a, stage, rep);
+#ifdef VGX_PROFILE
+    BPROF(6);
+    if (lane == 0) for (int i = 0; i < 8; ++i) atomicAdd(&vgx_tau_big_prof[i], (unsigned long long)bp[i]);
+#endif
+#undef BPROF
+    const int slot[5] = {0, 1, 2, 3, 5};
+    if (gl == 0) {
         for (int i = 0; i < 5; ++i)
-            if (tot[i]) atomicAdd(&ct[slot[i]], (unsigned long long)tot[i]);
+            if (tot[i]) { if (use_lt) atomicAdd(&lt[P * (S + 2) + i], (unsigned long long)tot[i]); else atomicAdd(&ct[slot[i]], (unsigned long long)tot[i]); }
+    }
+    if (use_lt) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < lt_n; i += TB) {
+            const unsigned long long v = lt[i];
+            if (v == 0) continue;
+            if (i < P * S) atomicAdd((unsigned long long *)&dS[i], v);
+            else if (i < P * S + P) atomicAdd((unsigned long long *)&a.dTot[(int64_t)rep * P + (i - P * S)], v);
+            else if (i < P * S + 2 * P) atomicAdd((unsigned long long *)&a.dChkTot[(int64_t)rep * P + (i - P * S - P)], v);
+            else atomicAdd(&ct[slot[i - P * (S + 2)]], v);
+        }
     }
 }
 
