@@ -23,3 +23,13 @@ if os.environ.get("VGX_LIBRARY"):   # diagnostic build: phases of vgx_tau_draw_b
     v = list(out); tot = float(sum(v[:7]))
     for nme, x in zip(["setup loads", "channel means", "draws", "books", "sums + leader", "flush", "end"], v[:7]):
         print("  %-14s %5.1f %%  %8.0f cycles per iteration" % (nme, 100 * x / tot, x / max(v[7], 1)))
+    out = (C.c_ulonglong * 16)()
+    C.CDLL(_capi.LIB_PATH).vgx_tau_get_profile(out, 0)
+    v = [float(x) for x in out]
+    names = ["prologue", "bursts (second half)", "after the draws", "rescue tests", "staged list -> global", "epilogue", None,
+             "  rates + number of events", "  split", "  mutants", "  migrants", "  tallies", None, None, "bursts (first half)"]
+    tot = sum(v[:6]) + sum(v[7:12]) + v[14]
+    print("events kernel: %d wavefronts, %.1f rounds each, %.0f cycles each" % (v[13], v[12] / max(v[13], 1), tot / max(v[13], 1)))
+    for nme, x in zip(names, v[:15]):
+        if nme:
+            print("  %-28s %5.1f %%  %8.0f cycles per wavefront" % (nme, 100 * x / tot, x / max(v[13], 1)))
