@@ -185,6 +185,9 @@ static __device__ __forceinline__ void q_long_select(const int32_t *ln, const in
     double carry = 0.0, carry_hit = 0.0;
     int t_hit = -1;
     const int nt = (n_sel + 63) >> 6, maxt = (maxn + 63) >> 6;
+    // tiles that lie inside the list of EVERY row that has one: no bounds to look at (a row without a list adds zeros)
+    const int full = -rows_max(n_sel > 0 ? -n_sel : -0x7fffffff) >> 6;
+    const double tEz = n_sel > 0 ? tE : 0.0;
 #pragma unroll
     for (int d = 0; d < QT; ++d) buf[d] = tile_load(ln, d < nt ? d : 0, rl);
     for (int tb = 0; tb < maxt; tb += QT) {
@@ -193,9 +196,14 @@ static __device__ __forceinline__ void q_long_select(const int32_t *ln, const in
             const int t = tb + d;
             const QTile c = buf[d];
             buf[d] = tile_load(ln, (t + QT < nt && t_hit < 0) ? t + QT : 0, rl);
-            const int e0 = t * 64 + 4 * rl;
-            const double w0 = e0 + 0 < n_sel ? tE * (double)c.c0 : 0.0, w1 = e0 + 1 < n_sel ? tE * (double)c.c1 : 0.0;
-            const double w2 = e0 + 2 < n_sel ? tE * (double)c.c2 : 0.0, w3 = e0 + 3 < n_sel ? tE * (double)c.c3 : 0.0;
+            double w0, w1, w2, w3;
+            if (QT >= 4 && t < full) {   // (the short-list instantiation keeps its code small: see VGX_QT_SHORT)
+                w0 = tEz * (double)c.c0; w1 = tEz * (double)c.c1; w2 = tEz * (double)c.c2; w3 = tEz * (double)c.c3;
+            } else {
+                const int e0 = t * 64 + 4 * rl;
+                w0 = e0 + 0 < n_sel ? tE * (double)c.c0 : 0.0; w1 = e0 + 1 < n_sel ? tE * (double)c.c1 : 0.0;
+                w2 = e0 + 2 < n_sel ? tE * (double)c.c2 : 0.0; w3 = e0 + 3 < n_sel ? tE * (double)c.c3 : 0.0;
+            }
             const double acc = row_sum64(w0, w1, w2, w3, carry);
             if (t_hit < 0 && t < nt && !(acc < r2)) { t_hit = t; carry_hit = carry; }
             carry = acc;
@@ -241,6 +249,9 @@ static __device__ __forceinline__ double q_long_sum(const int32_t *ln, int n, in
     double acc = 0.0;
     QTile buf[QT];
     const int nt = (n + 63) >> 6, maxt = (maxn + 63) >> 6;
+    // tiles that lie inside the list of EVERY row that has one: no bounds to look at (a row without a list adds zeros)
+    const int full = -rows_max(n > 0 ? -n : -0x7fffffff) >> 6;
+    const double tEz = n > 0 ? tE : 0.0;
 #pragma unroll
     for (int d = 0; d < QT; ++d) buf[d] = tile_load(ln, d < nt ? d : 0, rl);
     for (int tb = 0; tb < maxt; tb += QT) {
@@ -249,9 +260,14 @@ static __device__ __forceinline__ double q_long_sum(const int32_t *ln, int n, in
             const int t = tb + d;
             const QTile c = buf[d];
             buf[d] = tile_load(ln, t + QT < nt ? t + QT : 0, rl);
-            const int e0 = t * 64 + 4 * rl;
-            const double w0 = e0 + 0 < n ? tE * (double)c.c0 : 0.0, w1 = e0 + 1 < n ? tE * (double)c.c1 : 0.0;
-            const double w2 = e0 + 2 < n ? tE * (double)c.c2 : 0.0, w3 = e0 + 3 < n ? tE * (double)c.c3 : 0.0;
+            double w0, w1, w2, w3;
+            if (QT >= 4 && t < full) {   // (the short-list instantiation keeps its code small: see VGX_QT_SHORT)
+                w0 = tEz * (double)c.c0; w1 = tEz * (double)c.c1; w2 = tEz * (double)c.c2; w3 = tEz * (double)c.c3;
+            } else {
+                const int e0 = t * 64 + 4 * rl;
+                w0 = e0 + 0 < n ? tE * (double)c.c0 : 0.0; w1 = e0 + 1 < n ? tE * (double)c.c1 : 0.0;
+                w2 = e0 + 2 < n ? tE * (double)c.c2 : 0.0; w3 = e0 + 3 < n ? tE * (double)c.c3 : 0.0;
+            }
             acc = row_sum64(w0, w1, w2, w3, acc);
         }
     }
