@@ -1204,6 +1204,11 @@ extern "C" int vgx_simulate_tau(vgx_engine *e, int64_t iterations, int64_t sampl
     a.st_key = (unsigned long long *)e->t_stkey.p; a.st_val = (long long *)e->t_stval.p; a.st_size = st_size;
     a.dChkTot = (int64_t *)e->t_dChkTot.p;
     a.q = (int64_t *)e->t_q.p; a.q_cap = q_shards * q_scap; a.q_shards = q_shards; a.q_n = (unsigned long long *)e->t_qn.p;
+    // A compartment's events are drawn by ONE lane of the events kernel (a draw of their number, then one by one) up to this
+    // mean, by a group of lanes of vgx_tau_draw_big_kernel (one Poisson draw per channel) from it on.  The lane's way is far
+    // cheaper per compartment but its time grows with the mean, and the slowest lane holds its wavefront: with few
+    // compartments (nothing else to overlap with) the switch comes earlier.  Same joint law either way.
+    a.big_lam = P * H * R <= ((int64_t)1 << 18) ? VGX_TAU_BIG_SMALL : VGX_TAU_BIG;
     // enough blocks of the events kernel to fill the chip whatever the number of shards (mid-size models have few)
     a.ev_split = (int32_t)std::max<int64_t>(1, std::min<int64_t>(q_shard_max / 64, 4096 / std::max<int64_t>(1, q_shards * R)));
     a.sieve = (double *)e->t_sieve.p; a.sieve_skipped = (int64_t *)e->t_sieveskip.p;

@@ -20,6 +20,8 @@
 #define VGX_SIEVE_K 16          // halvings the tau sieve looks ahead
 #define VGX_EV_COLS 6           // int32 columns of a device log record
 #define VGX_FA_CAP 2048         // (rate, iteration) pairs kept per replicate for failed attempts that switched a lockdown
+#define VGX_TAU_BIG 64.0         // tau: expected events of a compartment per leap from which every channel is drawn on its own
+#define VGX_TAU_BIG_SMALL 16.0   // ... on models with few compartments (the wavefront's slowest lane sets the step time there)
 #define VGX_PROF_SLOTS 16       // in-kernel phase stamps of the diagnostic (-DVGX_PROFILE) build
 
 // fields of the per-replicate f64 population block
@@ -242,6 +244,7 @@ struct VgxTauArgs {
     int64_t q_shards;
     unsigned long long *q_n;         // [R][q_shards]
     int32_t ev_split;                // blocks of the events kernel per shard of the queue
+    double big_lam;                  // expected events of a compartment per leap from which its channels are drawn one by one
     uint32_t gen;                    // try counter of this call, 1 .. 2^25 - 1
     unsigned long long *st_key;      // [R][st_size]
     long long *st_val;               // [R][st_size] infectious + own delta + arrivals

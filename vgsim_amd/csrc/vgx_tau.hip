@@ -1072,7 +1072,6 @@ static __device__ __forceinline__ void tau_row(const VgxTauArgs &a, int rep, int
 //   sparse mode only, a compartment's own net change: signed, applied only (its check is made where it is drawn)
 // The list is sharded by thread block (VGX_INC_SHARDS counters) so that appends do not serialise on one address; a
 // wavefront stages its entries in LDS and reserves room for them with one atomic.
-#define VGX_TAU_BIG 64.0    // expected events of a compartment per leap from which every channel is drawn on its own
 #define VGX_INC_CELL_BITS 38
 #define VGX_INC_MAXMULT ((int64_t)((1 << 23) - 1))
 #define VGX_INC_NEG ((int64_t)1 << 61)
@@ -1237,7 +1236,7 @@ static __device__ __forceinline__ uint32_t tau_bucket(const VgxTauArgs &a, const
 //   ownApp : the own delta UpdateCompartmentCounts_tau applies (pyx:2548: the migrant infects the TARGET population),
 //   the susceptible deltas (identical in both), the tentative counters, multievent rows and the list of arrivals.
 // The compartment arrays themselves are not touched, so every thread sees the pre-step state.
-// Returns 2 when the compartment expects VGX_TAU_BIG events or more (nothing drawn: vgx_tau_draw_big_kernel's case), else 0/1.
+// Returns 2 when the compartment expects a.big_lam (VGX_TAU_BIG / VGX_TAU_BIG_SMALL) events or more (nothing drawn: vgx_tau_draw_big_kernel's case), else 0/1.
 // DRY = true: no bookkeeping at all; ownChk returns the number of mutants that go to haplotype `target` (the same random
 // numbers in the same order, so the count is the one the compartment's real draw produces).
 template <bool DRY, int TABS>
@@ -1265,7 +1264,7 @@ static __device__ __forceinline__ int tau_cell_events(const VgxTauArgs &a, const
     const double r_all = r_mig + r_rec + r_samp + r_mut + r_tr;
     const double lam = r_all * tau;
     if (!(lam > 0.0)) return 0;
-    if (lam >= VGX_TAU_BIG) return 2;
+    if (lam >= a.big_lam) return 2;
     TauRng g;
     g.init(E.seed, E.att, (uint64_t)pn * (uint64_t)H + (uint64_t)hn, E.step, E.retry);
     int64_t N;
@@ -2006,7 +2005,7 @@ __global__ void __launch_bounds__(EB, VGX_EV_WAVES) vgx_tau_events_kernel(VgxTau
 }
 
 
-// Compartments that expect many events in this leap (>= VGX_TAU_BIG; the draw kernel's quick test lists them): every channel
+// Compartments that expect many events in this leap (>= a.big_lam; the events kernel lists them): every channel
 // gets its own Poisson draw, as in the reference (pyx:2464-2520), with the channels of one compartment spread over the
 // lanes of a wavefront.  The single draw + split of tau_cell_events walks through the events one by one, which a
 // compartment with 10^5 hosts would do for tens of thousands of events on one lane (natural epidemics: most hosts carry a
