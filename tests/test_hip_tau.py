@@ -57,8 +57,13 @@ def test_first_leap_length_matches_oracle(oracle_mod, name):
     assert dt_hip == pytest.approx(dt_ref, rel=1e-9)
 
 
-@pytest.mark.parametrize("name", ["tau_a", "tau_b", "tau_c", "tau_d", "tau_many_classes", "tau_wide_table"])
-def test_tau_moments_match_oracle(oracle_mod, name):
+@pytest.mark.parametrize("name", ["tau_a", "tau_b", "tau_c", "tau_d", "tau_many_classes", "tau_wide_table", "tau_d:large", "tau_c:large"])
+def test_tau_moments_match_oracle(oracle_mod, name, monkeypatch):
+    # ":large": the draw thresholds of large models (a compartment's events drawn kind by kind between means of 16 and 64,
+    # channel by channel only from 64 on) on these small ones
+    if name.endswith(":large"):
+        name = name[:-6]
+        monkeypatch.setenv("VGX_TAU_LARGE_MODEL_THRESHOLDS", "1")
     ctor, _ = models.tau_case(name)
     keys = ("bCounter", "dCounter", "sCounter", "mCounter", "migPlus", "currentTime")
     diffs = {k: [] for k in keys + ("infected",)}
@@ -91,8 +96,8 @@ def test_tau_moments_match_oracle(oracle_mod, name):
 N_ENSEMBLE = 512
 
 
-@pytest.mark.parametrize("name", ["tau_a", "tau_b", "tau_c", "tau_d"])
-def test_tau_distribution_matches_oracle_many_seeds(oracle_mod, name):
+@pytest.mark.parametrize("name", ["tau_a", "tau_b", "tau_c", "tau_d", "tau_c:large", "tau_d:large"])
+def test_tau_distribution_matches_oracle_many_seeds(oracle_mod, name, monkeypatch):
     """One common start state (the case's direct warm-up, bit-exact on both engines), then N_ENSEMBLE tau runs that differ
     by their seed only: the device's in one ensemble launch, the oracle's one after the other.  Two independent samples
     of the same law: for every scalar quantity q, with n = N_ENSEMBLE per sample and s the pooled standard deviation,
@@ -100,6 +105,9 @@ def test_tau_distribution_matches_oracle_many_seeds(oracle_mod, name):
       |var_1 - var_2|           <= 4.5 * sqrt((m4_1 - s1^4)/n + (m4_2 - s2^4)/n)    + floor
       |quartile_1 - quartile_2| <= 4.5 * sqrt(2) * 1.36 * s / sqrt(n)               + 1     (integers: one count)
     (1.36 s / sqrt(n) = the standard error of a quartile of a near-normal sample); floor = 0.5 events, 1e-9 time units."""
+    if name.endswith(":large"):   # the draw thresholds of large models (see test_tau_moments_match_oracle)
+        name = name[:-6]
+        monkeypatch.setenv("VGX_TAU_LARGE_MODEL_THRESHOLDS", "1")
     from vgsim_amd import Simulator
     from vgsim_amd.ensemble import Ensemble
     ctor, phases = models.CASES[name]

@@ -1209,6 +1209,10 @@ extern "C" int vgx_simulate_tau(vgx_engine *e, int64_t iterations, int64_t sampl
     // cheaper per compartment but its time grows with the mean, and the slowest lane holds its wavefront: with few
     // compartments (nothing else to overlap with) the switch comes earlier.  Same joint law either way.
     a.big_lam = P * H * R <= ((int64_t)1 << 18) ? VGX_TAU_BIG_SMALL : VGX_TAU_BIG;
+    {   // tests: the thresholds of large models on a small one (so that its draws go through the one-draw-per-kind form)
+        const char *th = getenv("VGX_TAU_LARGE_MODEL_THRESHOLDS");
+        if (th && th[0] == '1') a.big_lam = VGX_TAU_BIG;
+    }
     // enough blocks of the events kernel to fill the chip whatever the number of shards (mid-size models have few)
     a.ev_split = (int32_t)std::max<int64_t>(1, std::min<int64_t>(q_shard_max / 64, 4096 / std::max<int64_t>(1, q_shards * R)));
     a.sieve = (double *)e->t_sieve.p; a.sieve_skipped = (int64_t *)e->t_sieveskip.p;

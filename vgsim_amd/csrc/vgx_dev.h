@@ -22,6 +22,7 @@
 #define VGX_FA_CAP 2048         // (rate, iteration) pairs kept per replicate for failed attempts that switched a lockdown
 #define VGX_TAU_BIG 64.0         // tau: expected events of a compartment per leap from which every channel is drawn on its own
 #define VGX_TAU_BIG_SMALL 16.0   // ... on models with few compartments (the wavefront's slowest lane sets the step time there)
+#define VGX_TAU_KINDS 16.0       // ... and from which a lane draws one Poisson number per KIND of event instead of walking through the events
 #define VGX_PROF_SLOTS 16       // in-kernel phase stamps of the diagnostic (-DVGX_PROFILE) build
 
 // fields of the per-replicate f64 population block

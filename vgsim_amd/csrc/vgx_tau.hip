@@ -1268,8 +1268,29 @@ static __device__ __forceinline__ int tau_cell_events(const VgxTauArgs &a, const
     TauRng g;
     g.init(E.seed, E.att, (uint64_t)pn * (uint64_t)H + (uint64_t)hn, E.step, E.retry);
     int64_t N;
-    if (lam >= 10.0) {
-        N = tau_poisson(g, lam);
+    int64_t rec = 0, samp = 0, births = 0, n_mut = 0, n_mig = 0;
+    int bsn[4] = {0, 0, 0, 0};   // births per susceptibility group (first four): ONE multievent row per channel, as upstream's
+    const bool by_kind = lam >= VGX_TAU_KINDS;
+    if (by_kind) {
+        // A mean of several events: one Poisson draw per KIND of event (recoveries, samples, mutants, migrants, births per
+        // susceptibility group) instead of the total and a walk through the events one by one (half a Philox block each, and
+        // the lane with the most events holds its wavefront): Poisson splitting, the same joint law.  (Below a mean of 1 the
+        // scan kernel's bucket test relies on the FIRST uniform deciding "no event": that form stays for small means.)
+        N = 0;
+        for (int kd = 0; kd < 4 + S; ++kd) {
+            double lk;
+            if (kd == 0) lk = r_rec; else if (kd == 1) lk = r_samp; else if (kd == 2) lk = r_mut; else if (kd == 3) lk = r_mig;
+            else lk = T.wtr[cb * S + (kd - 4)] * Ih;
+            const int64_t x = tau_poisson(g, lk * tau);
+            N += x;
+            if (kd == 0) rec = x; else if (kd == 1) samp = x; else if (kd == 2) n_mut = x; else if (kd == 3) n_mig = x;
+            else if (x != 0 && !DRY) {   // transmission to susceptibility group sn (pyx:2515-2520 / 2589-2593)
+                const int sn = kd - 4;
+                births += x;
+                if (sn < 4) { cnt[8 + sn] -= x; bsn[sn] += (int)x; }
+                else { atomicAdd(&sS[sn], (unsigned long long)(-x)); tau_row(a, rep, x, 0, hn, pn, sn, 0); }
+            }
+        }
     } else {   // inversion by sequential search (same law as numpy's sampler below 10)
         const double u = ((double)bucket + g.uniform()) * (1.0 / 256.0);
         double pk = exp(-lam), F = pk;
@@ -1282,10 +1303,8 @@ static __device__ __forceinline__ int tau_cell_events(const VgxTauArgs &a, const
     }
     CEPROF(1);
     if (N == 0) return 0;
-    int64_t rec = 0, samp = 0, births = 0, n_mut = 0, n_mig = 0;
-    int bsn[4] = {0, 0, 0, 0};   // births per susceptibility group (first four): ONE multievent row per channel, as upstream's
     const double t1 = r_rec, t2 = t1 + r_samp, t3 = t2 + r_tr, t4 = t3 + r_mut;
-    for (int64_t ev = 0; ev < N; ++ev) {
+    for (int64_t ev = 0; ev < (by_kind ? 0 : N); ++ev) {
         double u = g.uniform() * r_all;
         if (u < t1) rec += 1;
         else if (u < t2) samp += 1;
