@@ -38,7 +38,7 @@ extern "C" hipError_t vgxi_launch_init_reps(const VgxDevRep *r, int P, int S, in
                                             const int64_t *s_tot, hipStream_t stream);
 
 #define TAU_DECL(name) extern "C" hipError_t vgxi_##name(const VgxTauArgs *a, hipStream_t s);
-TAU_DECL(tau_eff) TAU_DECL(tau_scatter) TAU_DECL(tau_prep) TAU_DECL(tau_drift) TAU_DECL(tau_choose) TAU_DECL(tau_draw) TAU_DECL(tau_suscep_draw)
+TAU_DECL(tau_eff) TAU_DECL(tau_scatter) TAU_DECL(tau_prep) TAU_DECL(tau_drift) TAU_DECL(tau_choose) TAU_DECL(tau_draw)
 TAU_DECL(tau_arrivals) TAU_DECL(tau_verdict) TAU_DECL(tau_apply) TAU_DECL(tau_check) TAU_DECL(tau_decide) TAU_DECL(tau_commit) TAU_DECL(tau_finish) TAU_DECL(tau_draw_big) TAU_DECL(tau_suspect)
 
 static std::string g_create_error;
@@ -1388,8 +1388,7 @@ extern "C" int vgx_simulate_tau(vgx_engine *e, int64_t iterations, int64_t sampl
                 a.gen = 1;
             }
             HIPCHECK(e, vgxi_tau_draw(&a, e->stream));
-            HIPCHECK(e, vgxi_tau_draw_big(&a, e->stream));
-            HIPCHECK(e, vgxi_tau_suscep_draw(&a, e->stream));
+            HIPCHECK(e, vgxi_tau_draw_big(&a, e->stream));   // (+ the immunity transitions: extra blocks of the same launch)
             if (a.sparse) {
                 HIPCHECK(e, vgxi_tau_arrivals(&a, e->stream));
                 HIPCHECK(e, vgxi_tau_verdict(&a, e->stream));

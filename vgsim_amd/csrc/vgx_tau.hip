@@ -2030,6 +2030,28 @@ __global__ void __launch_bounds__(EB, VGX_EV_WAVES) vgx_tau_events_kernel(VgxTau
 // compartment with 10^5 hosts would do for tens of thousands of events on one lane (natural epidemics: most hosts carry a
 // few haplotypes); the joint law of the channel counts is the same (Poisson splitting).  A channel's stream is keyed by
 // (compartment, channel), so the result does not depend on the lane mapping.  grid = (VGX_BIG_BLOCKS, R), 4 waves a block.
+// Immunity transitions (pyx:2479-2487 / 2554-2562): P*S*S slots per replicate, one thread each: the blocks of
+// vgx_tau_draw_big_kernel beyond VGX_BIG_BLOCKS (a launch of its own was 3 % of a small model's step).
+static __device__ __forceinline__ void tau_suscep_draw(const VgxTauArgs &a, int rep, int idx) {
+    const VgxDevParams &p = a.p;
+    const int P = p.P, S = p.S;
+    if (idx >= P * S * S) return;
+    int pn = idx / (S * S), rest = idx % (S * S), ssn = rest / S, tsn = rest % S;
+    if (ssn == tsn) return;
+    const int64_t *Sus = a.S + (int64_t)rep * P * S;
+    int64_t *dS = a.dSi + (int64_t)rep * P * S;
+    double lam = p.suscepTransition[ssn * S + tsn] * (double)Sus[pn * S + ssn] * a.tau[rep];
+    if (!(lam > 0.0)) return;
+    TauRng g;
+    g.init((uint64_t)a.seeds[rep], (uint32_t)a.attempt[rep], ((uint64_t)1 << 62) + (uint64_t)idx, (uint32_t)a.step[rep], (uint32_t)a.retry[rep]);
+    int64_t k = tau_poisson(g, lam);
+    if (k == 0) return;
+    atomicAdd((unsigned long long *)&dS[pn * S + tsn], (unsigned long long)k);
+    atomicAdd((unsigned long long *)&dS[pn * S + ssn], (unsigned long long)(-k));
+    atomicAdd((unsigned long long *)&a.cnt_try[(int64_t)rep * 8 + 4], (unsigned long long)k);
+    tau_row(a, rep, k, 4, ssn, pn, tsn, 0);
+}
+
 #define VGX_BIG_BLOCKS 512    // four wavefronts each: what the chip holds at two wavefronts per SIMD (blocks without work leave at once)
 #define VGX_BIG_LT 2048       // block-local sums kept in LDS: P * (S + 2) + 5 entries (else straight to global memory)
 // A compartment is worked on by a GROUP of 16, 32 or 64 lanes (the smallest that holds its channels, or 64): with few channels
@@ -2039,6 +2061,10 @@ __global__ void __launch_bounds__(EB, VGX_EV_WAVES) vgx_tau_events_kernel(VgxTau
 extern "C" __global__ void __launch_bounds__(TB) vgx_tau_draw_big_kernel(VgxTauArgs a) {
     const int rep = blockIdx.y;
     if (!a.active[rep] || a.accepted[rep]) return;
+    if (blockIdx.x >= VGX_BIG_BLOCKS) {   // the susceptible compartments' immunity transitions
+        tau_suscep_draw(a, rep, (int)(blockIdx.x - VGX_BIG_BLOCKS) * TB + (int)threadIdx.x);
+        return;
+    }
     const VgxDevParams &p = a.p;
     const int P = p.P, S = p.S, H = p.H, sites = p.sites, CB = p.CB;
     const int lane = threadIdx.x & 63;
@@ -2084,7 +2110,7 @@ extern "C" __global__ void __launch_bounds__(TB) vgx_tau_draw_big_kernel(VgxTauA
     WaveStage *stage = &stages[threadIdx.x >> 6];
     if (lane == 0) stage->n = 0;
     WSYNC();
-    const unsigned long long wave = (unsigned long long)blockIdx.x * (TB / 64) + (threadIdx.x >> 6), nwaves = (unsigned long long)gridDim.x * (TB / 64);
+    const unsigned long long wave = (unsigned long long)blockIdx.x * (TB / 64) + (threadIdx.x >> 6), nwaves = (unsigned long long)VGX_BIG_BLOCKS * (TB / 64);   // (the blocks beyond are the immunity transitions')
     for (unsigned long long e0 = wave * per_wave; e0 < n; e0 += nwaves * per_wave) {
         const unsigned long long e = e0 + (unsigned long long)(lane / G);
         const bool have = e < n;
@@ -2207,30 +2233,6 @@ extern "C" __global__ void __launch_bounds__(TB) vgx_tau_draw_big_kernel(VgxTauA
             else atomicAdd(&ct[slot[i - P * (S + 2)]], v);
         }
     }
-}
-
-// Immunity transitions (pyx:2479-2487 / 2554-2562): P*S*S slots per replicate, one thread each.
-extern "C" __global__ void __launch_bounds__(TB) vgx_tau_suscep_draw_kernel(VgxTauArgs a) {
-    const int rep = blockIdx.y;
-    if (!a.active[rep] || a.accepted[rep]) return;
-    const VgxDevParams &p = a.p;
-    const int P = p.P, S = p.S;
-    const int idx = blockIdx.x * TB + threadIdx.x;
-    if (idx >= P * S * S) return;
-    int pn = idx / (S * S), rest = idx % (S * S), ssn = rest / S, tsn = rest % S;
-    if (ssn == tsn) return;
-    const int64_t *Sus = a.S + (int64_t)rep * P * S;
-    int64_t *dS = a.dSi + (int64_t)rep * P * S;
-    double lam = p.suscepTransition[ssn * S + tsn] * (double)Sus[pn * S + ssn] * a.tau[rep];
-    if (!(lam > 0.0)) return;
-    TauRng g;
-    g.init((uint64_t)a.seeds[rep], (uint32_t)a.attempt[rep], ((uint64_t)1 << 62) + (uint64_t)idx, (uint32_t)a.step[rep], (uint32_t)a.retry[rep]);
-    int64_t k = tau_poisson(g, lam);
-    if (k == 0) return;
-    atomicAdd((unsigned long long *)&dS[pn * S + tsn], (unsigned long long)k);
-    atomicAdd((unsigned long long *)&dS[pn * S + ssn], (unsigned long long)(-k));
-    atomicAdd((unsigned long long *)&a.cnt_try[(int64_t)rep * 8 + 4], (unsigned long long)k);
-    tau_row(a, rep, k, 4, ssn, pn, tsn, 0);
 }
 
 // Adds the appended incoming individuals to the delta arrays.  grid = (inc_shards, R, VGX_INC_SHARDS / inc_shards):
@@ -2561,7 +2563,6 @@ extern "C" __global__ void __launch_bounds__(64) vgx_tau_finish_kernel(VgxTauArg
         return hipGetLastError();                                                                \
     }
 #define CELL_GRID dim3((unsigned)((a->p.H + 4 * TB - 1) / (4 * TB)), (unsigned)a->p.P, (unsigned)a->R)   /* 4 compartments per thread */
-#define SUS_GRID dim3((unsigned)((a->p.P * a->p.S * a->p.S + TB - 1) / TB), (unsigned)a->R)
 TAU_LAUNCH(tau_eff, dim3((unsigned)a->p.P, (unsigned)a->R), dim3(TB))
 TAU_LAUNCH(tau_prep, dim3((unsigned)a->p.P, (unsigned)a->R), dim3(TB))
 // blocks per (population, replicate) of the drift kernel vgxi_tau_drift launches last (= slots of VgxTauArgs.dS_part in use)
@@ -2646,8 +2647,7 @@ extern "C" __attribute__((visibility("hidden"))) hipError_t vgxi_tau_draw(const 
 }
 extern "C" __attribute__((visibility("hidden"))) int64_t vgxi_tau_queue_shards(int64_t H, int64_t P) { return (int64_t)tau_draw_gx(H) * P; }
 extern "C" __attribute__((visibility("hidden"))) int64_t vgxi_tau_queue_shard_max(int64_t H) { return tau_queue_shard_max(H); }
-TAU_LAUNCH(tau_suscep_draw, SUS_GRID, dim3(TB))
-TAU_LAUNCH(tau_draw_big, dim3(VGX_BIG_BLOCKS, (unsigned)a->R), dim3(TB))
+TAU_LAUNCH(tau_draw_big, dim3(VGX_BIG_BLOCKS + (unsigned)((a->p.P * a->p.S * a->p.S + TB - 1) / TB), (unsigned)a->R), dim3(TB))
 extern "C" __attribute__((visibility("hidden"))) hipError_t vgxi_tau_sieve(const VgxTauArgs *a, hipStream_t s) {
     unsigned tiles = (unsigned)((a->p.H + 4 * TB - 1) / (4 * TB));
     unsigned gx = tiles < 64u ? tiles : 64u;
