@@ -2008,7 +2008,8 @@ __global__ void __launch_bounds__(EB, VGX_EV_WAVES) vgx_tau_events_kernel(VgxTau
             else atomicAdd(&sS[i - 8], (unsigned long long)v);
         }
     }
-    __syncthreads();
+    WSYNC();   // (one wavefront per block: no barrier instruction, and above all no wait for the global atomics just issued —
+               //  all blocks add to the same few addresses, their acknowledgements were a fifth of a wavefront's life)
     if (threadIdx.x < S && sS[threadIdx.x])
         atomicAdd((unsigned long long *)&a.dSi[((int64_t)rep * P + pn) * S + threadIdx.x], sS[threadIdx.x]);
 #ifdef VGX_PROFILE
