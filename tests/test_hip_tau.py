@@ -163,11 +163,16 @@ def test_tau_distribution_matches_oracle_many_seeds(oracle_mod, name, monkeypatc
             assert abs(qa - qb) <= tolq, "%s: %d %% quantiles %.6g vs %.6g (tolerance %.3g)" % (what, int(100 * q), qa, qb, tolq)
 
 
-def test_multievent_rows_account_for_counters():
+@pytest.mark.parametrize("case", ["tau_b", "tau_c:large", "tau_d:large"])
+def test_multievent_rows_account_for_counters(case, monkeypatch):
     """Sparse multievent log: rows with num > 0 only; their sums reproduce the counter increments and every
-    MULTITYPE record points at its own [start, end) row range."""
-    ctor, phases = models.CASES["tau_b"]
-    hip = run_tau_case("tau_b", ctor["seed"], "hip")
+    MULTITYPE record points at its own [start, end) row range (":large": with the draw thresholds of large models, i.e.
+    through the one-draw-per-kind form and the channel-by-channel kernel from a mean of 64 on)."""
+    if case.endswith(":large"):
+        case = case[:-6]
+        monkeypatch.setenv("VGX_TAU_LARGE_MODEL_THRESHOLDS", "1")
+    ctor, phases = models.CASES[case]
+    hip = run_tau_case(case, ctor["seed"], "hip")
     nd = phases[0][1]["iterations"]
     me = hip.multievents
     assert me.ptr > 0 and (me.num[:me.ptr] > 0).all()
