@@ -192,6 +192,97 @@ def c4_direct_leg(device, replicates=1024, events=20000):
     return out
 
 
+# ---- the reference's only published benchmark for this path: data/Table 3 ----------------------------------
+# seconds for 10^8 direct-Gillespie iterations, ONE trajectory, hardware not stated (data/Table 3/table.txt:9-17)
+TABLE3_PUBLISHED_S = {(0.001, 2): 28.7, (0.001, 5): 30.0, (0.001, 10): 31.9, (0.001, 20): 35.1, (0.001, 50): 47.2, (0.001, 100): 69.3,
+                      (0.1, 2): 30.3, (0.1, 5): 31.9, (0.1, 10): 33.8, (0.1, 20): 37.0, (0.1, 50): 50.3, (0.1, 100): 73.0}
+
+
+def make_table3(K, M, seed=2023):
+    """The model of data/Table 3/Table 3.py:5-22 through the current public setters (the script's `set_lockdown` and
+    `set_migration_probability(total_probability=)` are today's `set_npi` and `set_total_migration_probability`):
+    16 haplotypes (2 sites), 3 susceptibility groups, K demes of 2e9/K hosts, four rate classes, NPI on every deme."""
+    from vgsim_amd import Simulator
+    with contextlib.redirect_stdout(io.StringIO()):
+        s = Simulator(number_of_sites=2, populations_number=K, number_of_susceptible_groups=3, seed=seed)
+    s.set_transmission_rate(2.5)
+    s.set_transmission_rate(4.0, haplotype='GG')
+    s.set_recovery_rate(0.9)
+    s.set_sampling_rate(0.1)
+    s.set_total_migration_probability(M)
+    s.set_population_size(int(2 * 10 ** 9 / K))
+    s.set_susceptibility(1.0, susceptibility_type=0)
+    s.set_susceptibility(0.0, susceptibility_type=1)
+    s.set_susceptibility(0.5, susceptibility_type=1, haplotype='C*')
+    s.set_susceptibility(1.0, susceptibility_type=1, haplotype='G*')
+    s.set_susceptibility(0.0, susceptibility_type=2)
+    s.set_susceptibility_type(1)
+    s.set_susceptibility_type(2, haplotype='C*')
+    s.set_susceptibility_type(2, haplotype='G*')
+    s.set_immunity_transition(0.01, target=0)
+    s.set_npi([0.1, 0.02, 0.01])
+    return s
+
+
+def table3_cpu(K, M, iterations=3000000):
+    """The oracle (op-for-op port of the reference's algorithm) on the Table-3 model, one host core: events/s."""
+    from oracle import oracle
+    oracle.build()
+    m = make_table3(K, M).simulation
+    t0 = time.time()
+    oracle.run_direct(m, iterations, 10 ** 12, -1, 200)
+    t1 = time.time()
+    return {"value": m.events.ptr / max(t1 - t0, 1e-9), "unit": "events/s", "cores": 1, "kind": "port",
+            "events": int(m.events.ptr), "s_per_1e8_iterations": 1e8 * (t1 - t0) / max(m.events.ptr + m.migNonPlus, 1)}
+
+
+def table3_leg(device, cpu=True, replicates=16384, events=50000, single_events=300000):
+    """data/Table 3 (the reference's published timing): K in {2, 10, 100} demes x cumulative migration M in
+    {0.001, 0.1}.  Per cell: ONE trajectory (the published quantity: seconds per 10^8 iterations, device time of the
+    persistent kernel), an ensemble of `replicates` seeded trajectories (aggregate events/s, bit-exact mode), and the oracle on
+    one host core."""
+    import numpy as np
+    from vgsim_amd.ensemble import Ensemble
+    out = {"workload": "data/Table 3/Table 3.py:5-22: sites=2 (16 haplotypes), 3 susceptibility groups, K demes of 2e9/K hosts, "
+                       "b=2.5 (GG: 4.0), d=0.9, s=0.1, 4 rate classes, immunity loss 0.01, NPI [0.1, 0.02, 0.01] on every deme, "
+                       "seed 2023; exact mode",
+           "published": "data/Table 3/table.txt:9-17: seconds per 1e8 iterations of one trajectory, hardware not stated",
+           "cells": {}}
+    for M in (0.001, 0.1):
+        for K in (2, 10, 100):
+            cell = {"published_s_per_1e8": TABLE3_PUBLISHED_S[(M, K)], "published_events_per_s": 1e8 / TABLE3_PUBLISHED_S[(M, K)]}
+            sim = make_table3(K, M)
+            ens = Ensemble(sim, 1, device=device)
+            res = None
+            for it in range(2):
+                res = ens.simulate(single_events, sample_size=10 ** 12, record_events=True, seeds=np.array([2023 + it], dtype=np.int64))
+            it1 = float(res.loop_iterations.sum())
+            cell["single_trajectory"] = {"events_per_s": res.total_events / (res.kernel_ms * 1e-3),
+                                         "iterations_per_s": it1 / (res.kernel_ms * 1e-3),
+                                         "s_per_1e8_iterations": 1e8 * res.kernel_ms * 1e-3 / max(it1, 1.0),
+                                         "vs_baseline": (it1 / (res.kernel_ms * 1e-3)) / (1e8 / TABLE3_PUBLISHED_S[(M, K)])}
+            ens.close()
+            R = replicates if K <= 16 else max(replicates // 4, 1024)
+            ens = Ensemble(sim, R, device=device)
+            for it in range(2):
+                res = ens.simulate(events, sample_size=10 ** 12, record_events=True,
+                                   seeds=2023 + it * R + np.arange(R, dtype=np.int64))
+            its = float(res.loop_iterations.sum())
+            cell["ensemble"] = {"replicates": R, "events_per_replicate": events, "events_per_s": res.total_events / (res.kernel_ms * 1e-3),
+                                "iterations_per_s": its / (res.kernel_ms * 1e-3), "kernel_ms_per_launch": res.kernel_ms,
+                                "rejected_migration_share": 1.0 - res.total_events / max(its, 1.0),
+                                "vs_baseline": (its / (res.kernel_ms * 1e-3)) / (1e8 / TABLE3_PUBLISHED_S[(M, K)])}
+            ens.close()
+            if cpu:
+                cell["cpu_baseline"] = table3_cpu(K, M)
+            out["cells"]["K=%d,M=%g" % (K, M)] = cell
+    k10 = out["cells"]["K=10,M=0.001"]
+    out["value"] = k10["ensemble"]["events_per_s"]
+    out["unit"] = "events/s (device time, K=10 M=0.001 ensemble)"
+    out["vs_baseline"] = k10["ensemble"]["vs_baseline"]
+    return out
+
+
 # Sequential f64 additions in the reference's order run as a chain of dependent v_fmac_f64 (DPP) steps, one term per
 # step; measured issue rate of that chain: 1.9 ns per step and SIMD at >= 4 waves/SIMD (profiles/r01_microbench_chain.txt),
 # 1024 SIMDs.  This is the bound of the exact mode on long occupancy lists (DESIGN.md 4.1), reported beside the HBM one.
@@ -466,7 +557,7 @@ def main():
     ap.add_argument("--no-tau", action="store_true", help="skip the tau-leap (config 4) leg")
     ap.add_argument("--no-extra", action="store_true", help="skip the FAST-mode, spread-occupancy and config-2 legs")
     ap.add_argument("--only", default="", help="development/profiling: run only this extra leg (fast_mode, spread_occupancy, "
-                                               "spread_occupancy_fast, config2, genealogy, single_trajectory, direct_config4_shape, propensity_scan, tau_leap) and print its JSON")
+                                               "spread_occupancy_fast, config2, genealogy, single_trajectory, direct_config4_shape, table3, propensity_scan, tau_leap) and print its JSON")
     a = ap.parse_args()
 
     # ---- ranks: one process per GPU.  Under a launcher (torch.distributed.run sets WORLD_SIZE) this process is one rank;
@@ -501,7 +592,8 @@ def main():
                   ("spread_occupancy", lambda d: spread_leg(d, "exact", replicates=8192, events=2500)),
                   ("spread_occupancy_fast", lambda d: spread_leg(d, "fast", replicates=4096)),
                   ("config2", c2_leg), ("genealogy", genealogy_leg), ("single_trajectory", single_leg),
-                  ("direct_config4_shape", c4_direct_leg), ("propensity_scan", rowscan_leg), ("tau_leap", tau_leg))
+                  ("direct_config4_shape", c4_direct_leg), ("table3", lambda d: table3_leg(d, cpu=not a.no_cpu_baseline)),
+                  ("propensity_scan", rowscan_leg), ("tau_leap", tau_leg))
     if a.only:
         print(json.dumps({a.only: dict(extra_legs)[a.only](local)}), flush=True)
         return
