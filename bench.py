@@ -530,14 +530,10 @@ class BenchLoop:
 def launch_ranks(n, argv):
     """`python bench.py --gpus N` without a launcher: start N fresh ranks (torch.distributed.run, one per GPU) as a CHILD
     process and exit with its code.  Nothing in this parent has touched HIP or imported torch, and nothing is re-exec'ed."""
-    import socket
     import subprocess
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % n, "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    # --standalone: the launcher picks a free rendezvous port itself (no bind-then-close race with other jobs on the node)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+           "--nproc-per-node=%d" % n, os.path.abspath(__file__)] + list(argv)
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     rc = subprocess.call(cmd, env=env)
     if rc != 0:

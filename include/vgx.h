@@ -91,8 +91,10 @@ typedef struct vgx_run_opts {
                                 vgx_simulate_tau. */
     int64_t kernel;          /* direct path: 0 = automatic, 1 = one replicate per wavefront (vgx_direct.hip), 2 = one replicate
                                 per lane (vgx_lanes.hip; small models: popNum <= 16, popNum*hapNum <= 1024, susNum <= 8, EXACT),
-                                3 = four replicates per wavefront, one per 16-lane row (vgx_quad.hip; EXACT, popNum <= 64, one
-                                susceptibility group, one rate class, no possible lockdown switch) */
+                                3 = four replicates per wavefront, one per 16-lane row (EXACT, no recombination): vgx_quad.hip
+                                for popNum <= 64, one susceptibility group, one rate class and no possible lockdown switch,
+                                else the general form vgx_quadg.hip (popNum <= 128, susNum <= 8, <= 64 rate classes, <= 16
+                                transmission/susceptibility classes); 4 = the general form even where 3 would take the other */
     int64_t reserved[2];     /* [0] tau path: 1 = run every try of the halving loop (pyx:2316-2321) instead of starting at the
                                 first try that is not certain to be rejected (same accepted steps either way);
                                 [1] tau path, how a try's deltas are kept and checked (same draws and decisions in every mode):
@@ -167,6 +169,13 @@ int vgx_get_multievents(vgx_engine *e, int64_t replicate, int64_t cap, int64_t *
 /* Summary trajectories of the last call: out[replicate][point][population][0=infectious,1=susceptible], f64.
  * `out` is a host pointer, or a device pointer when out_is_device != 0 (e.g. a torch tensor for an RCCL gather). */
 int vgx_get_trajectories(vgx_engine *e, double *out, int out_is_device);
+/* The same trajectories as 32-bit integers written to a DEVICE buffer of the same shape (compartment totals are whole numbers;
+ * refused when a population size is 2^31 or more): the wire format of the ensemble gather, formed without an f64 copy. */
+int vgx_get_trajectories_int(vgx_engine *e, int32_t *out_device);
+/* Direct calls with a time limit take their `currentTime < time` stop decisions (pyx:407) on the device clock; event times are
+ * rebuilt on the host with libm.  Number of replicates (fetched so far) for which the two clocks disagreed on one such
+ * decision (an event time within rounding of the limit): the run reported is then the device clock's. */
+int64_t vgx_clock_mismatches(const vgx_engine *e);
 
 /* ---- backward pass ------------------------------------------------------------------------- */
 /* Replaces BirthDeathModel.GetGenealogy(seed) (pyx:743-1000) with its recorders Mutations / Migrations

@@ -28,10 +28,11 @@ def test_quad_kernel_vs_reference_goldens(name):
 
 
 def test_quad_refuses_models_outside_its_scope():
+    """Models the one-class form does not take go to the general form (vgx_quadg.hip, tests/test_hip_quadg.py); recombination
+    is outside both."""
     from vgsim_amd._capi import VgxError
-    for name in ("g2_short", "g7_short", "g3_short"):    # two rate classes / a lockdown threshold / two susceptibility groups
-        with pytest.raises(VgxError), helpers.quiet():
-            helpers.run_case_hip(name, kernel="quad")
+    with pytest.raises(VgxError), helpers.quiet():
+        helpers.run_case_hip("recomb_pos", kernel="quad")
 
 
 def _single(oracle_mod, name, seed, n_events, mut=None):

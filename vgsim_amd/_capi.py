@@ -91,6 +91,8 @@ SIGNATURES = {
     "vgx_get_lockdowns": (C.c_int, [_H, C.c_int64, C.c_int64, _I, _I, _F, _I]),
     "vgx_get_multievents": (C.c_int, [_H, C.c_int64, C.c_int64, _I, _F, _I, _I, _I, _I, _I, _I]),
     "vgx_get_trajectories": (C.c_int, [_H, C.c_void_p, C.c_int]),
+    "vgx_get_trajectories_int": (C.c_int, [_H, C.c_void_p]),
+    "vgx_clock_mismatches": (C.c_int64, [_H]),
     "vgx_last_kernel_ms": (C.c_double, [_H]),
     "vgx_last_kernel_launches": (C.c_int64, [_H]),
     "vgx_device_bytes": (C.c_int64, [_H]),

@@ -302,30 +302,23 @@ class Reporting:
                         row("", a[i, j])
                     print()
             print()
+        # scalar dump of pyx:2071-2094 (labels are the reference's output text); None = blank line, r[...] = recomputed cache
         print("Parameters")
-        print('first_simulation(mutable): ', self.first_simulation)
-        print("sampling_probability(const): ", self.sampling_probability)
-        print("memory_optimization(const): ", self.memory_optimization)
-        print()
-        print("sites(const): ", self.sites)
-        print("hapNum(const): ", self.hapNum)
-        print("currentHapNum(mutable): ", self.currentHapNum)
-        print("maxHapNum(mutable): ", self.maxHapNum)
-        print("popNum(const): ", self.popNum)
-        print("susNum(const): ", self.susNum)
-        print("bCounter(mutable): ", self.bCounter)
-        print("dCounter(mutable): ", self.dCounter)
-        print("sCounter(mutable): ", self.sCounter)
-        print("mCounter(mutable): ", self.mCounter)
-        print("iCounter(mutable):", self.iCounter)
-        print("swapLockdown(mutable): ", self.swapLockdown)
-        print("migPlus(mutable): ", self.migPlus)
-        print("migNonPlus(mutable): ", self.migNonPlus)
-        print("globalInfectious(mutable): ", self.globalInfectious)
-        print()
-        print("currentTime(mutable): ", self.currentTime)
-        print("totalRate(mutable): ", r["totalRate"])
-        print("totalMigrationTate(mutable): ", r["totalMigrationRate"])
+        scalars = (("first_simulation", "mutable", ": "), ("sampling_probability", "const", ": "),
+                   ("memory_optimization", "const", ": "), None, ("sites", "const", ": "), ("hapNum", "const", ": "),
+                   ("currentHapNum", "mutable", ": "), ("maxHapNum", "mutable", ": "), ("popNum", "const", ": "),
+                   ("susNum", "const", ": "), ("bCounter", "mutable", ": "), ("dCounter", "mutable", ": "),
+                   ("sCounter", "mutable", ": "), ("mCounter", "mutable", ": "), ("iCounter", "mutable", ":"),
+                   ("swapLockdown", "mutable", ": "), ("migPlus", "mutable", ": "), ("migNonPlus", "mutable", ": "),
+                   ("globalInfectious", "mutable", ": "), None, ("currentTime", "mutable", ": "))
+        for item in scalars:
+            if item is None:
+                print()
+            else:
+                name, kind, sep = item
+                print("%s(%s)%s" % (name, kind, sep), getattr(self, name))
+        for label, key in (("totalRate", "totalRate"), ("totalMigrationTate", "totalMigrationRate")):   # (upstream's spelling)
+            print("%s(mutable): " % label, r[key])
         print()
         row("suscType(const): ", self.suscType)
         print()

@@ -18,6 +18,7 @@
 #include <vector>
 #include "../../include/vgx.h"
 #include "vgx_dev.h"
+#include "vgx_quadg.h"
 #include "vgx_rng.h"
 
 // launchers defined next to their kernels (vgx_direct.hip)
@@ -31,6 +32,8 @@ extern "C" hipError_t vgxi_launch_lanes(const VgxDirectArgs *a, const VgxLaneWs 
 extern "C" hipError_t vgxi_launch_quad(const VgxDirectArgs *a, const double *cd, double *effMig, double *maxEBM, int32_t *has_mig, int long_lists,
                                        hipStream_t stream);
 extern "C" size_t vgxi_direct_lds_bytes(int P, int S, int C, int CB);
+extern "C" hipError_t vgxi_launch_quad_prep(const VgxDevParams *p, const double *cd, double *effMig, double *maxEBM, int32_t *has_mig, hipStream_t stream);
+extern "C" hipError_t vgxi_launch_quadg(const VgxDirectArgs *a, const VgxQuadgArgs *qa, hipStream_t stream);
 extern "C" hipError_t vgxi_launch_counts32(const int64_t *c64, int32_t *c32, int64_t n, hipStream_t stream);
 extern "C" hipError_t vgxi_launch_init_reps(const VgxDevRep *r, int P, int S, int64_t R, const int32_t *s_nocc,
                                             const int32_t *s_hap, const int32_t *s_cls, const int64_t *s_cnt,
@@ -121,8 +124,14 @@ struct vgx_engine {
         std::vector<double> times;        // [ev_ptr - e0] event times
         double final_time = 0.0;          // currentTime after the call
         std::vector<double> loc_times;    // lockdown records
+        bool limit_mismatch = false;      // device and host clock disagreed on a time-limit stop (see host_clock)
     } hc;
-    bool last_used_lanes = false, last_used_quad = false;
+    int64_t clock_mismatches = 0;
+    bool last_used_lanes = false, last_used_quad = false, last_used_quadg = false;
+    // BirthRate program of the general row kernel (vgx_quadg.h)
+    std::vector<int32_t> h_seg_par, h_seg_sn, h_cb_seg;
+    std::vector<double> h_seg_sig;
+    DevBuf q_segpar, q_segsn, q_segsig, q_cbseg, r_cold;
     int64_t last_ev_size = 0;
     std::vector<VgxRepScalars> sc_host;
     bool sc_host_valid = false;
@@ -313,6 +322,32 @@ extern "C" int vgx_set_params(vgx_engine *e, const vgx_params *p) {
     }
     e->C = (int)c_d.size();
     e->CB = (int)cb_b.size();
+    {   // BirthRate (pyx:382-392) per birth class as a program of chain segments: the groups with a non-zero susceptibility in
+        // order, common prefixes (group, susceptibility) of different classes shared (vgx_quadg.hip)
+        e->h_seg_par.clear(); e->h_seg_sn.clear(); e->h_seg_sig.clear();
+        e->h_cb_seg.assign(cb_b.size(), -1);
+        std::unordered_map<std::string, int> segmap;
+        for (size_t cb = 0; cb < cb_b.size(); cb++) {
+            int cur = -1;
+            for (int64_t sn = 0; sn < S; sn++) {
+                const double sg = cb_sig[cb * (size_t)S + (size_t)sn];
+                if (sg == 0.0) continue;
+                std::string k((const char *)&cur, sizeof(cur));
+                k.append((const char *)&sn, sizeof(sn));
+                k.append((const char *)&sg, sizeof(sg));
+                auto it = segmap.find(k);
+                if (it == segmap.end()) {
+                    const int id = (int)e->h_seg_par.size();
+                    segmap.emplace(k, id);
+                    e->h_seg_par.push_back(cur); e->h_seg_sn.push_back((int32_t)sn); e->h_seg_sig.push_back(sg);
+                    cur = id;
+                } else {
+                    cur = it->second;
+                }
+            }
+            e->h_cb_seg[cb] = cur;
+        }
+    }
     e->h_class_pos.assign(c_d.size(), 0);
     for (size_t c = 0; c < c_d.size(); c++)
         e->h_class_pos[c] = (c_d[c] > 0.0 || c_s[c] > 0.0 || c_tm[c] > 0.0 || cb_b[(size_t)c_bidx[c]] > 0.0) ? 1 : 0;
@@ -384,6 +419,15 @@ extern "C" int vgx_set_params(vgx_engine *e, const vgx_params *p) {
     rc |= upload(e, e->p_cstype, c_stype.data(), c_stype.size());
     rc |= upload(e, e->p_cbb, cb_b.data(), cb_b.size());
     rc |= upload(e, e->p_cbsig, cb_sig.data(), cb_sig.size());
+    {
+        static const int32_t zero_i = 0;
+        static const double zero_d = 0.0;
+        const size_t ns = e->h_seg_par.size();
+        rc |= upload(e, e->q_segpar, ns ? e->h_seg_par.data() : &zero_i, ns ? ns : 1);
+        rc |= upload(e, e->q_segsn, ns ? e->h_seg_sn.data() : &zero_i, ns ? ns : 1);
+        rc |= upload(e, e->q_segsig, ns ? e->h_seg_sig.data() : &zero_d, ns ? ns : 1);
+        rc |= upload(e, e->q_cbseg, e->h_cb_seg.data(), e->h_cb_seg.size());
+    }
     rc |= upload(e, e->p_sizes, p->sizes, (size_t)P);
     rc |= upload(e, e->p_cdBefore, p->contactDensityBeforeLockdown, (size_t)P);
     rc |= upload(e, e->p_cdAfter, p->contactDensityAfterLockdown, (size_t)P);
@@ -586,9 +630,16 @@ static int init_device_state(vgx_engine *e, int64_t traj_points) {
     HIPCHECK(e, hipMemGetInfo(&free_b, &total_b));
     int64_t need = std::max<int64_t>(std::max(s_cap, i_cap), 1);
     e->start_max_nocc = s_cap;
-    int64_t budget = (int64_t)((double)(free_b + e->r_lhap.bytes + e->r_lcls.bytes + e->r_lcnt.bytes) * 0.45 / (double)(R * P * 20));
+    // capacity per list: what fits 45 % of the free memory (buffers of an earlier state count as free: they are reused), at most
+    // 32 GiB for all lists together (an ensemble of 16 384 x 64 lists still gets 1600 entries each; the rest of the memory
+    // belongs to the event logs and trajectories), never below the start state's longest list + one tile.  Rounded down to a
+    // multiple of 64 entries: the row kernels read whole 64-entry tiles with 16-byte loads.
+    const double reusable = (double)(e->r_lhap.bytes + e->r_lcls.bytes + e->r_lcnt.bytes + e->r_lcnt32.bytes);
+    const double list_bytes = std::min(((double)free_b + reusable) * 0.45, 32.0 * 1073741824.0);
+    int64_t budget = (int64_t)(list_bytes / (double)(R * P * 24));
     int64_t cap = std::min<int64_t>(H, std::max<int64_t>(budget, 64));
     cap = std::max(cap, std::min<int64_t>(H, need + 64));
+    if (cap < H) cap = std::max<int64_t>((cap / 64) * 64, ((need + 63) / 64) * 64);
     if (cap < need) return fail(e, VGX_ERR_CAPACITY, "occupancy lists do not fit device memory");
     e->cap = cap;
 
@@ -793,12 +844,21 @@ static int direct_core(vgx_engine *e, int64_t iterations, int64_t sample_size, f
         if (e->sizes[(size_t)pn] >= ((int64_t)1 << 31)) quad_ok = false;   // its streaming passes read 4-byte counts
     for (int64_t pn = 0; pn < P && quad_ok; pn++)
         if (h.totalSusceptible[(size_t)pn] != h.susceptible[(size_t)pn]) quad_ok = false;
-    if (o.kernel == 3 && !quad_ok)
-        return fail(e, VGX_ERR_ARG, "vgx_simulate_direct: the four-replicates-per-wavefront kernel needs exact mode, popNum <= 64, "
-                                    "one susceptibility group, one rate class and no possible lockdown switch");
+    // The general form of that kernel (vgx_quadg.hip): several susceptibility groups and rate classes, lockdown switches,
+    // up to 128 populations.
+    const int64_t qg_W = 3 * S + e->CB;
+    const bool quadg_ok = o.mode == 0 && !recomb && P <= VGX_QG_MAX_P && S <= VGX_QG_MAX_S && e->C <= VGX_QG_MAX_C &&
+                          e->CB <= VGX_QG_MAX_CB && qg_W <= VGX_QG_MAX_W && (int64_t)e->h_seg_par.size() <= VGX_QG_MAX_SEG;
+    if (o.kernel == 3 && !quad_ok && !quadg_ok)
+        return fail(e, VGX_ERR_ARG, "vgx_simulate_direct: the four-replicates-per-wavefront kernels need exact mode, no recombination, "
+                                    "popNum <= 128, susNum <= 8, at most 64 rate classes and 16 transmission/susceptibility classes");
+    if (o.kernel == 4 && !quadg_ok)
+        return fail(e, VGX_ERR_ARG, "vgx_simulate_direct: the general four-replicates-per-wavefront kernel needs exact mode, no "
+                                    "recombination, popNum <= 128, susNum <= 8, at most 64 rate classes and 16 transmission/susceptibility classes");
     // measured (tools/probe_quad.py): a lone wavefront runs one replicate faster than four (1.4e5 vs 1.1e5 events/s per
-    // replicate at config 3), so the row kernel pays from about one wavefront per SIMD upwards
-    const bool use_quad = o.kernel == 3 || (o.kernel == 0 && quad_ok && !use_lanes && R >= 2048);
+    // replicate at config 3), so the row kernels pay from about one wavefront per SIMD upwards
+    const bool use_quad = (o.kernel == 3 && quad_ok) || (o.kernel == 0 && quad_ok && !use_lanes && R >= 2048);
+    const bool use_quadg = !use_quad && (o.kernel == 4 || (o.kernel == 3 && quadg_ok) || (o.kernel == 0 && quadg_ok && !use_lanes && R >= 2048));
     VgxLaneWs ws{};
     a.r.rec = nullptr; a.r.rec_cap = 0;
     e->rec_cap = 0;
@@ -824,12 +884,25 @@ static int direct_core(vgx_engine *e, int64_t iterations, int64_t sample_size, f
     }
     e->last_used_lanes = use_lanes;
     e->last_used_quad = use_quad;
-    if (use_quad) {
+    e->last_used_quadg = use_quadg;
+    VgxQuadgArgs qga{};
+    if (use_quadg) {
+        int rcq = ensure(e, e->r_cold, (size_t)(R * P * qg_W) * 8);
+        if (rcq) return rcq;
+        qga.effMig0 = (const double *)e->r_qeff.p; qga.mebm0 = (const double *)e->r_qmebm.p; qga.has_mig0 = (const int32_t *)e->r_qflag.p;
+        qga.cd0 = (const double *)e->s_cd.p;
+        qga.seg_par = (const int32_t *)e->q_segpar.p; qga.seg_sn = (const int32_t *)e->q_segsn.p;
+        qga.seg_sig = (const double *)e->q_segsig.p; qga.cb_seg = (const int32_t *)e->q_cbseg.p;
+        qga.nseg = (int32_t)e->h_seg_par.size(); qga.W = (int32_t)qg_W;
+        qga.cold = (int64_t *)e->r_cold.p;
+    }
+    if (use_quad || use_quadg) {
         int rcq = 0;
         rcq |= ensure(e, e->r_qeff, (size_t)(P * P) * 8);
         rcq |= ensure(e, e->r_qmebm, (size_t)P * 8);
         rcq |= ensure(e, e->r_qflag, 8);
         if (rcq) return rcq;
+        if (use_quadg) { qga.effMig0 = (const double *)e->r_qeff.p; qga.mebm0 = (const double *)e->r_qmebm.p; qga.has_mig0 = (const int32_t *)e->r_qflag.p; }
     }
 
     // the 4-byte copy of the counts is kept by the four-replicates-per-wavefront kernel alone
@@ -839,6 +912,11 @@ static int direct_core(vgx_engine *e, int64_t iterations, int64_t sample_size, f
     if (use_lanes) HIPCHECK(e, vgxi_launch_lanes(&a, &ws, e->stream));
     else if (use_quad) HIPCHECK(e, vgxi_launch_quad(&a, (const double *)e->s_cd.p, (double *)e->r_qeff.p, (double *)e->r_qmebm.p,
                                                     (int32_t *)e->r_qflag.p, e->start_max_nocc > 64 ? 1 : 0, e->stream));
+    else if (use_quadg) {
+        HIPCHECK(e, vgxi_launch_quad_prep(&a.p, (const double *)e->s_cd.p, (double *)e->r_qeff.p, (double *)e->r_qmebm.p,
+                                          (int32_t *)e->r_qflag.p, e->stream));
+        HIPCHECK(e, vgxi_launch_quadg(&a, &qga, e->stream));
+    }
     else HIPCHECK(e, vgxi_launch_direct(&a, lds, e->stream));
     HIPCHECK(e, hipEventRecord(e->ev1, e->stream));
     HIPCHECK(e, hipStreamSynchronize(e->stream));
@@ -1611,6 +1689,7 @@ static int host_clock(vgx_engine *e, int64_t rep) {
     hc.rep = -1;
     hc.times.clear();
     hc.loc_times.clear();
+    hc.limit_mismatch = false;
     const bool rewound = s.restarts > 0;
     hc.e0 = rewound ? 0 : e->ev_ptr0;
     const int64_t n = std::max<int64_t>(s.ev_ptr - hc.e0, 0);
@@ -1696,10 +1775,14 @@ static int host_clock(vgx_engine *e, int64_t rep) {
         }
         c.advance(s.last_attempt_loops, s.totalRate + s.totalMig);   // trailing iterations without a record
         hc.final_time = c.t;
-        // the kernel took its `currentTime < time` decisions (pyx:407) on the device clock: both clocks must agree on them
-        if (e->call_has_tlimit && (!limit_ok || ((s.currentTime < e->call_tlimit) != (hc.final_time < e->call_tlimit))))
-            return fail(e, VGX_ERR_LOOP_GUARD, "host_clock: the time-limit stop differs between the device clock and the host "
-                                               "libm clock (an event time within rounding of the limit)");
+        // The kernel took its `currentTime < time` decisions (pyx:407) on the device clock (vgx_log, < 1 ulp from the host's
+        // log).  If an event time lands within rounding of the limit the two clocks can disagree on one stop decision; the
+        // run is then the device clock's run (a getter must not fail after the work is done): times stay the host clock's,
+        // the mismatch is kept for vgx_clock_mismatches().
+        if (e->call_has_tlimit && (!limit_ok || ((s.currentTime < e->call_tlimit) != (hc.final_time < e->call_tlimit)))) {
+            hc.limit_mismatch = true;
+            e->clock_mismatches += 1;
+        }
     }
     hc.rep = rep;
     return VGX_OK;
@@ -1849,6 +1932,20 @@ extern "C" int vgx_get_trajectories(vgx_engine *e, double *out, int out_is_devic
     HIPCHECK(e, hipMemcpy(out, e->r_traj.p, bytes, out_is_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost));
     return VGX_OK;
 }
+
+extern "C" hipError_t vgxi_launch_traj_i32(const double *src, int32_t *dst, int64_t n, hipStream_t stream);
+extern "C" int vgx_get_trajectories_int(vgx_engine *e, int32_t *out_device) {
+    if (!e || !out_device) return VGX_ERR_ARG;
+    if (e->traj_points <= 0) return fail(e, VGX_ERR_ARG, "vgx_get_trajectories_int: the last call recorded none");
+    for (int64_t pn = 0; pn < e->d.popNum; pn++)
+        if (e->sizes[(size_t)pn] >= ((int64_t)1 << 31)) return fail(e, VGX_ERR_ARG, "vgx_get_trajectories_int: population sizes of 2^31 or more");
+    HIPCHECK(e, hipSetDevice(e->device));
+    HIPCHECK(e, vgxi_launch_traj_i32((const double *)e->r_traj.p, out_device, e->R * e->traj_points * e->d.popNum * 2, e->stream));
+    HIPCHECK(e, hipStreamSynchronize(e->stream));
+    return VGX_OK;
+}
+
+extern "C" int64_t vgx_clock_mismatches(const vgx_engine *e) { return e ? e->clock_mismatches : 0; }
 
 extern "C" int vgx_get_state(vgx_engine *e, int64_t replicate, vgx_state *out) {
     if (!e || !out || replicate < 0 || replicate >= e->R) return VGX_ERR_ARG;

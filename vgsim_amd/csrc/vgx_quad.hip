@@ -224,22 +224,31 @@ struct QArgs {          // what the prep kernel leaves for all replicates
 // lane <-> target population, serial over sources and the inner sum, the reference's operation order.
 extern "C" __global__ void __launch_bounds__(64) vgx_quad_prep_kernel(VgxDevParams p, const double *cd, double *effMig,
                                                                      double *maxEBM, int32_t *has_mig) {
-    const int P = p.P, pn2 = threadIdx.x;
-    double mx = 0.0;
-    if (pn2 < P) {
-        const double *m2 = p.mig + (int64_t)pn2 * P;
-        for (int pn1 = 0; pn1 < P; ++pn1) {
-            if (pn1 == pn2) continue;
-            const double *m1 = p.mig + (int64_t)pn1 * P;
-            double e = 0.0;
-            for (int pn3 = 0; pn3 < P; ++pn3) e += m1[pn3] * m2[pn3] * cd[pn3] / p.actualSizes[pn3];
-            effMig[(int64_t)pn1 * P + pn2] = e;
-            if (e > mx) mx = e;
+    const int P = p.P;
+    bool anyf = false;
+    for (int base = 0; base < P; base += 64) {
+        const int pn2 = base + (int)threadIdx.x;
+        double mx = 0.0;
+        if (pn2 < P) {
+            const double *m2 = p.mig + (int64_t)pn2 * P;
+            for (int pn1 = 0; pn1 < P; ++pn1) {
+                if (pn1 == pn2) continue;
+                const double *m1 = p.mig + (int64_t)pn1 * P;
+                double e = 0.0;
+                for (int pn3 = 0; pn3 < P; ++pn3) e += m1[pn3] * m2[pn3] * cd[pn3] / p.actualSizes[pn3];
+                effMig[(int64_t)pn1 * P + pn2] = e;
+                if (e > mx) mx = e;
+            }
+            maxEBM[pn2] = mx * p.maxEffectiveBirth;
         }
-        maxEBM[pn2] = mx * p.maxEffectiveBirth;
+        anyf = anyf || (__ballot(pn2 < P && mx * p.maxEffectiveBirth != 0.0) != 0ull);
     }
-    unsigned long long any = __ballot(pn2 < P && mx * p.maxEffectiveBirth != 0.0);
-    if (threadIdx.x == 0) *has_mig = any != 0ull ? 1 : 0;
+    if (threadIdx.x == 0) *has_mig = anyf ? 1 : 0;
+}
+extern "C" __attribute__((visibility("hidden"))) hipError_t vgxi_launch_quad_prep(const VgxDevParams *p, const double *cd, double *effMig,
+                                                                                 double *maxEBM, int32_t *has_mig, hipStream_t stream) {
+    hipLaunchKernelGGL(vgx_quad_prep_kernel, dim3(1), dim3(64), 0, stream, *p, cd, effMig, maxEBM, has_mig);
+    return hipGetLastError();
 }
 
 template <int QT>
@@ -1125,6 +1134,15 @@ extern "C" __global__ void __launch_bounds__(256) vgx_quad_counts32_kernel(const
 }
 extern "C" __attribute__((visibility("hidden"))) hipError_t vgxi_launch_counts32(const int64_t *c64, int32_t *c32, int64_t n, hipStream_t stream) {
     hipLaunchKernelGGL(vgx_quad_counts32_kernel, dim3(4096), dim3(256), 0, stream, c64, c32, n);
+    return hipGetLastError();
+}
+
+// Summary trajectories as 32-bit integers for the wire (compartment totals are whole numbers below 2^31).
+extern "C" __global__ void __launch_bounds__(256) vgx_traj_i32_kernel(const double *src, int32_t *dst, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) dst[i] = (int32_t)src[i];
+}
+extern "C" __attribute__((visibility("hidden"))) hipError_t vgxi_launch_traj_i32(const double *src, int32_t *dst, int64_t n, hipStream_t stream) {
+    hipLaunchKernelGGL(vgx_traj_i32_kernel, dim3(8192), dim3(256), 0, stream, src, dst, n);
     return hipGetLastError();
 }
 

@@ -75,7 +75,7 @@ class Ensemble:
         o.traj_points = int(traj_points)
         o.traj_t0, o.traj_t1 = float(traj_window[0]), float(traj_window[1])
         o.mode = {'exact': 0, 'fast': 1, 'fast_philox': 2}[mode]
-        o.kernel = {'auto': 0, 'wave': 1, 'lane': 2, 'quad': 3}[kernel]
+        o.kernel = {'auto': 0, 'wave': 1, 'lane': 2, 'quad': 3, 'quadg': 4}[kernel]
         rc = eng.lib.vgx_simulate_direct(eng.handle, int(iterations), int(sample_size), float(np.float32(epidemic_time)),
                                          int(attempts), C.byref(o))
         eng._check(rc)
@@ -200,7 +200,13 @@ class Ensemble:
         backend = dist.get_backend()
         if backend == "nccl":
             dev = torch.device("cuda", torch.cuda.current_device())
-            mine = narrow(self.trajectories(torch.empty(self.traj_shape, dtype=torch.float64, device=dev)))
+            if wire_dtype == torch.int32:      # narrowed on the device straight from the engine's buffer: no f64 copy
+                narrow(torch.empty(0))         # (the checks)
+                mine = torch.empty(self.traj_shape, dtype=torch.int32, device=dev)
+                eng = self.engine
+                eng._check(eng.lib.vgx_get_trajectories_int(eng.handle, C.c_void_p(mine.data_ptr())))
+            else:
+                mine = narrow(self.trajectories(torch.empty(self.traj_shape, dtype=torch.float64, device=dev)))
         else:
             mine = narrow(torch.from_numpy(self.trajectories()))
         world, rank = dist.get_world_size(), dist.get_rank()
@@ -208,6 +214,7 @@ class Ensemble:
             if out is None:
                 out = torch.empty((world,) + tuple(mine.shape), dtype=mine.dtype, device=mine.device)
             assert tuple(out.shape) == (world,) + tuple(mine.shape) and out.is_contiguous()
+            assert out.dtype == mine.dtype and out.device == mine.device, "`out` must have the wire dtype and live where the collective runs"
             work = dist.gather(mine, list(out.unbind(0)), dst=dst, async_op=async_op)
         else:
             out = None
