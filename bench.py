@@ -40,6 +40,17 @@ def pmc_traffic(leg, config):
     return None
 
 
+def libm_probe_match():
+    """Whether this host's log() reproduces the 4096 (u, log u) pairs recorded on the fixture host (tests/golden/libm_probe.json):
+    where it does, the engine's event TIMES are bit-identical to the reference goldens (the integer rows are everywhere)."""
+    import math
+    try:
+        probe = json.load(open(os.path.join(ROOT, "tests", "golden", "libm_probe.json")))
+        return all(math.log(float.fromhex(u)) == float.fromhex(v) for u, v in probe)
+    except Exception:
+        return None
+
+
 def make_simulator(seed):
     from vgsim_amd import Simulator
     with contextlib.redirect_stdout(io.StringIO()):
@@ -236,7 +247,7 @@ def table3_cpu(K, M, iterations=3000000):
             "events": int(m.events.ptr), "s_per_1e8_iterations": 1e8 * (t1 - t0) / max(m.events.ptr + m.migNonPlus, 1)}
 
 
-def table3_leg(device, cpu=True, replicates=16384, events=50000, single_events=300000):
+def table3_leg(device, cpu=True, replicates=16384, events=50000, single_events=300000, cells=None):
     """data/Table 3 (the reference's published timing): K in {2, 10, 100} demes x cumulative migration M in
     {0.001, 0.1}.  Per cell: ONE trajectory (the published quantity: seconds per 10^8 iterations, device time of the
     persistent kernel), an ensemble of `replicates` seeded trajectories (aggregate events/s, bit-exact mode), and the oracle on
@@ -250,6 +261,8 @@ def table3_leg(device, cpu=True, replicates=16384, events=50000, single_events=3
            "cells": {}}
     for M in (0.001, 0.1):
         for K in (2, 10, 100):
+            if cells is not None and (K, M) not in cells:
+                continue
             cell = {"published_s_per_1e8": TABLE3_PUBLISHED_S[(M, K)], "published_events_per_s": 1e8 / TABLE3_PUBLISHED_S[(M, K)]}
             sim = make_table3(K, M)
             ens = Ensemble(sim, 1, device=device)
@@ -276,7 +289,9 @@ def table3_leg(device, cpu=True, replicates=16384, events=50000, single_events=3
             if cpu:
                 cell["cpu_baseline"] = table3_cpu(K, M)
             out["cells"]["K=%d,M=%g" % (K, M)] = cell
-    k10 = out["cells"]["K=10,M=0.001"]
+    k10 = out["cells"].get("K=10,M=0.001")
+    if k10 is None:
+        return out
     out["value"] = k10["ensemble"]["events_per_s"]
     out["unit"] = "events/s (device time, K=10 M=0.001 ensemble)"
     out["vs_baseline"] = k10["ensemble"]["vs_baseline"]
@@ -468,6 +483,48 @@ def tau_leg(device, steps=20, per_cell=3, seed=2020):
     return out
 
 
+def config5_leg(device, world=1, rank=0, events=100000, traj_points=1001):
+    """BASELINE config 5 as written: 256 independent seeded replicates of config 3 (seeds 2020..2275) sharded over the GPUs of the
+    node (256 / world per GPU; all 256 on the one GPU at N = 1), one RCCL gather of the f64 epidemic trajectories
+    [replicates, 1001, 64, 2] to rank 0 (32.8 MB per GPU at 8 GPUs).  Runs on every rank."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from vgsim_amd.ensemble import Ensemble
+    R = max(256 // world, 1)
+    ens = Ensemble(make_simulator(2020), R, device=device)
+    seeds = 2020 + rank * R + np.arange(R, dtype=np.int64)
+    res = None
+    for it in range(2):      # the first launch is the warm-up
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        res = ens.simulate(events, sample_size=10 ** 12, record_events=True, traj_points=traj_points, traj_window=(0.0, 12.0), seeds=seeds)
+        t_sim = time.perf_counter() - t0
+        t1 = time.perf_counter()
+        out = ens.gather_trajectories(dst=0)
+        torch.cuda.synchronize()
+        t_gather = time.perf_counter() - t1
+    ev = float(res.total_events)
+    tot, tmax = ev, t_sim + t_gather
+    if world > 1:
+        v = torch.tensor([ev], dtype=torch.float64, device="cuda")
+        dist.all_reduce(v, op=dist.ReduceOp.SUM)
+        m = torch.tensor([t_sim + t_gather, t_gather], dtype=torch.float64, device="cuda")
+        dist.all_reduce(m, op=dist.ReduceOp.MAX)
+        tot, tmax, t_gather = float(v.item()), float(m[0].item()), float(m[1].item())
+    shape = list(out.shape) if out is not None else None
+    o = {"workload": "BASELINE config 5: 256 seeded replicates of config 3 (seeds 2020..2275), %d per GPU on %d GPU(s), %d events each, "
+                     "f64 trajectories [%d, %d, %d, 2] gathered to rank 0" % (R, world, events, R, traj_points, POPS),
+         "value": tot / tmax, "unit": "events/s (wall: simulate + gather, max over ranks)", "replicates_per_gpu": R,
+         "kernel_ms_per_launch": res.kernel_ms, "simulate_s": t_sim, "gather_ms": 1e3 * t_gather,
+         "gather_bytes_per_gpu": R * traj_points * POPS * 2 * 8, "gathered_shape_on_rank0": shape,
+         "collective": "torch.distributed.gather (RCCL)" if world > 1 else "none (one rank)"}
+    ens.close()
+    return o
+
+
 class BenchLoop:
     """The timed loop of one rank: `step(i)` runs one batch of replicates and hands that step's summary trajectories
     to an asynchronous gather to rank 0 (it overlaps the next step's kernel), `drain()` waits for the last gather, `reduce(elapsed, events)` gives the whole job's MAX time and SUM of events.  The engine is
@@ -554,7 +611,9 @@ def main():
     ap.add_argument("--no-extra", action="store_true", help="skip the FAST-mode, spread-occupancy and config-2 legs")
     ap.add_argument("--only", default="", help="development/profiling: run only this extra leg (fast_mode, spread_occupancy, "
                                                "spread_occupancy_fast, config2, genealogy, single_trajectory, direct_config4_shape, table3, propensity_scan, tau_leap) and print its JSON")
+    ap.add_argument("--table3-cells", default="", help="profiling: restrict the table3 leg to these cells, e.g. 10:0.001,100:0.1")
     a = ap.parse_args()
+    cells3 = {(int(c.split(":")[0]), float(c.split(":")[1])) for c in a.table3_cells.split(",") if c} or None
 
     # ---- ranks: one process per GPU.  Under a launcher (torch.distributed.run sets WORLD_SIZE) this process is one rank;
     # without one, `--gpus N > 1` starts N fresh ranks as a child process BEFORE anything here imports torch or touches HIP.
@@ -588,7 +647,7 @@ def main():
                   ("spread_occupancy", lambda d: spread_leg(d, "exact", replicates=8192, events=2500)),
                   ("spread_occupancy_fast", lambda d: spread_leg(d, "fast", replicates=4096)),
                   ("config2", c2_leg), ("genealogy", genealogy_leg), ("single_trajectory", single_leg),
-                  ("direct_config4_shape", c4_direct_leg), ("table3", lambda d: table3_leg(d, cpu=not a.no_cpu_baseline)),
+                  ("direct_config4_shape", c4_direct_leg), ("table3", lambda d: table3_leg(d, cpu=not a.no_cpu_baseline, cells=cells3)),
                   ("propensity_scan", rowscan_leg), ("tau_leap", tau_leg))
     if a.only:
         print(json.dumps({a.only: dict(extra_legs)[a.only](local)}), flush=True)
@@ -641,6 +700,7 @@ def main():
             "metric": "simulated events/sec (direct + tau-leap) at 1/2/4/8 MI355X vs Cython CPU", "value": value, "unit": "events/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / max(a.steps, 1),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "libm_probe_match": libm_probe_match(),
             "config": {"value_leg": "direct Gillespie (BASELINE config 3); tau-leap (config 4) in tau_leap",
                        "workload": "BASELINE config 3: 65536 haplotypes (8 sites) x 64 populations x 1 susceptibility "
                                    "group, direct Gillespie, bit-exact mode (PCG64 stream, reference summation order), "
@@ -695,7 +755,17 @@ def main():
                 tau["value"] = tot[1].item() / max(mx[2].item() * 1e-3, 1e-12)   # all ranks' events / slowest rank's device time
                 tau["unit"] = "events/s (device time, %d replicas)" % world
                 tau.pop("roofline", None)
+    c5 = None
+    if not a.no_extra:
+        try:
+            c5 = config5_leg(local, world=world, rank=rank)
+        except Exception as ex:
+            c5 = {"error": repr(ex)}
+            if world > 1:
+                raise      # a rank that leaves a collective alone would hang the others: fail the run visibly
     if rank == 0:
+        if c5 is not None:
+            line["config5"] = c5
         if tau is not None:
             line["tau_leap"] = tau
         if world == 1 and not a.no_extra:

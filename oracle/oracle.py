@@ -53,6 +53,8 @@ _FIELDS = [
     ("recombination", C.c_double), ("genome_length", C.c_int64), ("sitesPosition", _I),
     ("rec_cap", C.c_int64), ("rec_n", C.c_int64), ("rec_idevents", _I), ("rec_his", _I), ("rec_hi2s", _I),
     ("rec_nhis", _I), ("rec_posRecombs", _I),
+    ("memory_optimization", C.c_int64), ("currentHapNum", C.c_int64), ("maxHapNum", C.c_int64), ("addMemoryNum", C.c_int64),
+    ("hapToNum", _I), ("numToHap", _I),
 ]
 
 
@@ -222,6 +224,49 @@ def run_direct(model, iterations, sample_size, time, attempts, sparse=False, log
     m = _struct(model, st, sparse, log_mode)
     rc = lib().vgo_simulate_direct(C.byref(m), iterations, sample_size, float(time), attempts)
     _absorb(model, st, m)
+    return rc
+
+
+class MemoptTable:
+    """State of the reference's haplotype table (pyx:105-125) beside a host model, for ``run_direct_memopt``."""
+
+    def __init__(self, model):
+        H, P = model.hapNum, model.popNum
+        block = int(4 ** max(model.sites - 2, 1))            # pyx:105-111: 4^(sites-2), at least 4
+        self.currentHapNum, self.maxHapNum, self.addMemoryNum = 0, block, block
+        self.hapToNum = np.zeros(H, dtype=np.int64)
+        self.numToHap = np.zeros(max(H, block) + 1, dtype=np.int64)
+        self.infectious = np.zeros((P, H), dtype=np.int64)   # counts by PROGRAM NUMBER (upstream's layout), hapNum columns
+        self.initial_infectious = np.zeros((P, H), dtype=np.int64)
+
+    def infectious_by_haplotype(self, model):
+        out = np.zeros((model.popNum, model.hapNum), dtype=np.int64)
+        n = self.currentHapNum
+        out[:, self.numToHap[:n]] = self.infectious[:, :n]
+        return out
+
+
+def run_direct_memopt(model, iterations, sample_size, time, attempts, log_mode=LOG_LIBM):
+    """The oracle's SimulatePopulation with ``memory_optimization=True`` (AddMemory pyx:264-274, AddHaplotype pyx:355-377, the
+    lookup of Mutation pyx:651-660 restated op for op; see vgx_oracle.h for the one difference: bounds are honoured).  The
+    counts live in the reference's program-number layout in ``model._memopt`` (a :class:`MemoptTable`); the host model's own
+    ``infectious`` (indexed by haplotype in this repository) is refreshed from it after the call.  Returns the error code."""
+    st = get_state(model)
+    tb = getattr(model, "_memopt", None)
+    if tb is None:
+        tb = model._memopt = MemoptTable(model)
+        if model.hapNum < 4 or model.infectious.any():
+            raise ValueError("run_direct_memopt: needs at least one site and a model that has not been infected yet")
+    model.events.CreateEvents(iterations)
+    m = _struct(model, st, False, log_mode)
+    m.infectious, m.initial_infectious = _ptr(tb.infectious), _ptr(tb.initial_infectious)
+    m.memory_optimization = 1
+    m.currentHapNum, m.maxHapNum, m.addMemoryNum = tb.currentHapNum, tb.maxHapNum, tb.addMemoryNum
+    m.hapToNum, m.numToHap = _ptr(tb.hapToNum), _ptr(tb.numToHap)
+    rc = lib().vgo_simulate_direct(C.byref(m), iterations, sample_size, float(time), attempts)
+    tb.currentHapNum, tb.maxHapNum, tb.addMemoryNum = m.currentHapNum, m.maxHapNum, m.addMemoryNum
+    _absorb(model, st, m)
+    model.infectious[:] = tb.infectious_by_haplotype(model)
     return rc
 
 

@@ -412,6 +412,13 @@ static double rng_uniform(rng_t *r) {
     return (double)(v >> 11) * (1.0 / 9007199254740992.0);
 }
 
+/* memory_optimization (pyx:105-125): program numbers vs haplotypes.  NH = numToHap[hn], HN = hapToNum[h], CUR = the number of
+ * program numbers in use (currentHapNum), ROWN = the length of a row indexed by program number as fastChoose sees it. */
+#define NH(hn) (m->memory_optimization ? m->numToHap[(hn)] : (int64_t)(hn))
+#define HN(h) (m->memory_optimization ? m->hapToNum[(h)] : (int64_t)(h))
+#define CUR (m->memory_optimization ? m->currentHapNum : H_)
+#define ROWN (m->memory_optimization ? m->maxHapNum : H_)
+
 static inline void NewInfections(vgo_model *m, int64_t pi, int64_t si, int64_t hi, int64_t num) { /* pyx:246-251 */
     IDX2(m->susceptible, pi, si, S_) -= num;
     m->totalSusceptible[pi] -= num;
@@ -447,13 +454,13 @@ static inline void AddEvent(vgo_model *m, double t, int64_t type, int64_t hap, i
 static inline double BirthRate(vgo_model *m, int64_t pi, int64_t hi) { /* pyx:382-392 */
     double ps = 0.0;
     for (int64_t sn = 0; sn < S_; sn++) {
-        double x = (double)IDX2(m->susceptible, pi, sn, S_) * IDX2(m->susceptibility, hi, sn, S_);
+        double x = (double)IDX2(m->susceptible, pi, sn, S_) * IDX2(m->susceptibility, NH(hi), sn, S_);
         IDX3(m->susceptHapPopRate, pi, hi, sn, H_, S_) = x;
         for (int64_t pn = 0; pn < P_; pn++)
             ps += x * IDX2(m->migrationRates, pi, pn, P_) * IDX2(m->migrationRates, pi, pn, P_) *
                   m->contactDensity[pn] / m->actualSizes[pn];
     }
-    return m->bRate[hi] * ps;
+    return m->bRate[NH(hi)] * ps;
 }
 
 void vgo_update_all_rates(vgo_model *m) { /* pyx:279-351 */
@@ -476,9 +483,9 @@ void vgo_update_all_rates(vgo_model *m) { /* pyx:279-351 */
     m->totalRate = 0.0;
     for (int64_t pn = 0; pn < P_; pn++) { m->infectPopRate[pn] = 0; m->immunePopRate[pn] = 0; m->popRate[pn] = 0.; }
     for (int64_t pn = 0; pn < P_; pn++) {
-        for (int64_t hn = 0; hn < H_; hn++) {
+        for (int64_t hn = 0; hn < CUR; hn++) {
             m->tmRate[hn] = 0;
-            for (int64_t s = 0; s < SITES_; s++) m->tmRate[hn] += IDX2(m->mRate, hn, s, SITES_);
+            for (int64_t s = 0; s < SITES_; s++) m->tmRate[hn] += IDX2(m->mRate, NH(hn), s, SITES_);
             if (m->sparse && IDX2(m->infectious, pn, hn, H_) == 0) {
                 /* dead state for an unoccupied haplotype, except the static rates and a zero hapPopRate */
                 IDX3(m->eventHapPopRate, pn, hn, 1, H_, 4) = m->dRate[hn];
@@ -488,8 +495,8 @@ void vgo_update_all_rates(vgo_model *m) { /* pyx:279-351 */
                 continue;
             }
             IDX3(m->eventHapPopRate, pn, hn, 0, H_, 4) = BirthRate(m, pn, hn);
-            IDX3(m->eventHapPopRate, pn, hn, 1, H_, 4) = m->dRate[hn];
-            IDX3(m->eventHapPopRate, pn, hn, 2, H_, 4) = m->sRate[hn] * m->samplingMultiplier[pn];
+            IDX3(m->eventHapPopRate, pn, hn, 1, H_, 4) = m->dRate[NH(hn)];
+            IDX3(m->eventHapPopRate, pn, hn, 2, H_, 4) = m->sRate[NH(hn)] * m->samplingMultiplier[pn];
             IDX3(m->eventHapPopRate, pn, hn, 3, H_, 4) = m->tmRate[hn];
             IDX2(m->tEventHapPopRate, pn, hn, H_) = 0;
             for (int i = 0; i < 4; i++) IDX2(m->tEventHapPopRate, pn, hn, H_) += IDX3(m->eventHapPopRate, pn, hn, i, H_, 4);
@@ -517,10 +524,10 @@ void vgo_update_all_rates(vgo_model *m) { /* pyx:279-351 */
         }
     }
     double maxEffectiveBirth = 0.0;
-    for (int64_t hn = 0; hn < H_; hn++)
+    for (int64_t hn = 0; hn < CUR; hn++)
         for (int64_t sn = 0; sn < S_; sn++)
-            if (m->bRate[hn] * IDX2(m->susceptibility, hn, sn, S_) > maxEffectiveBirth)
-                maxEffectiveBirth = m->bRate[hn] * IDX2(m->susceptibility, hn, sn, S_);
+            if (m->bRate[NH(hn)] * IDX2(m->susceptibility, NH(hn), sn, S_) > maxEffectiveBirth)
+                maxEffectiveBirth = m->bRate[NH(hn)] * IDX2(m->susceptibility, NH(hn), sn, S_);
 
     m->totalMigrationRate = 0.0;
     for (int64_t pn = 0; pn < P_; pn++) {
@@ -536,7 +543,7 @@ static void UpdateRates(vgo_model *m, int64_t pi, int infect, int immune, int mi
     if (infect) {
         m->infectPopRate[pi] = 0.0;
         int64_t hn = m->sparse ? occ_next(m, pi, 0) : 0;
-        while (hn < H_) {
+        while (hn < CUR) {
             double tmp;
             IDX3(m->eventHapPopRate, pi, hn, 0, H_, 4) = BirthRate(m, pi, hn);
             tmp = (IDX3(m->eventHapPopRate, pi, hn, 0, H_, 4) + IDX3(m->eventHapPopRate, pi, hn, 1, H_, 4) +
@@ -662,10 +669,10 @@ static void Birth(vgo_model *m, int64_t pi, int64_t hi) { /* pyx:568-605 */
         }
         m->rec_n += 1;
         NewInfections(m, pi, si, nhi, 1);
-        AddEvent(m, m->currentTime, VGO_BIRTH, hi, pi, si, hi2);
+        AddEvent(m, m->currentTime, VGO_BIRTH, NH(hi), pi, si, NH(hi2));
     } else {
         NewInfections(m, pi, si, hi, 1);
-        AddEvent(m, m->currentTime, VGO_BIRTH, hi, pi, si, H_);
+        AddEvent(m, m->currentTime, VGO_BIRTH, NH(hi), pi, si, H_);
     }
     IDX2(m->immuneSourcePopRate, pi, si, S_) = m->suscepCumulTransition[si] * (double)IDX2(m->susceptible, pi, si, S_);
     UpdateRates(m, pi, 1, 1, 1);
@@ -673,24 +680,56 @@ static void Birth(vgo_model *m, int64_t pi, int64_t hi) { /* pyx:568-605 */
 }
 
 static void Death(vgo_model *m, int64_t pi, int64_t hi, int add_event) { /* pyx:616-626 */
-    int64_t st = m->suscType[hi];
+    int64_t st = m->suscType[NH(hi)];
     NewRecoveries(m, pi, st, hi, 1);
     IDX2(m->immuneSourcePopRate, pi, st, S_) = (double)IDX2(m->susceptible, pi, st, S_) * m->suscepCumulTransition[st];
     UpdateRates(m, pi, 1, 1, 1);
     if (add_event) {
         m->dCounter += 1;
-        AddEvent(m, m->currentTime, VGO_DEATH, hi, pi, st, 0);
+        AddEvent(m, m->currentTime, VGO_DEATH, NH(hi), pi, st, 0);
     }
 }
 
 static void Sampling(vgo_model *m, int64_t pi, int64_t hi) { /* pyx:630-635 */
     Death(m, pi, hi, 0);
     m->sCounter += 1;
-    AddEvent(m, m->currentTime, VGO_SAMPLING, hi, pi, m->suscType[hi], 0);
+    AddEvent(m, m->currentTime, VGO_SAMPLING, NH(hi), pi, m->suscType[NH(hi)], 0);
+}
+
+/* pyx:264-274.  Upstream grows every array indexed by program number by addMemoryNum columns; here those arrays have hapNum
+ * columns from the start, so only the bookkeeping remains. */
+static void AddMemory(vgo_model *m) {
+    if (m->addMemoryNum + m->maxHapNum > H_) m->addMemoryNum = H_ - m->maxHapNum;
+    m->maxHapNum += m->addMemoryNum;
+}
+
+/* pyx:355-377: insert haplotype nhi into the sorted table, moving the later program numbers up by one — in the table and in
+ * the counts of population pi ONLY (as written upstream: the other populations' counts keep their old program numbers). */
+static void AddHaplotype(vgo_model *m, int64_t nhi, int64_t pi) {
+    int check = 0;
+    int64_t mem_h = 0, mem_inf = 0;
+    if (m->currentHapNum == m->maxHapNum && m->maxHapNum < H_) AddMemory(m);
+    for (int64_t i = 1; i < m->currentHapNum + 1; i++) {
+        if (check) {
+            m->hapToNum[mem_h] += 1;
+            int64_t t = IDX2(m->infectious, pi, i, H_); IDX2(m->infectious, pi, i, H_) = mem_inf; mem_inf = t;
+            t = m->numToHap[i]; m->numToHap[i] = mem_h; mem_h = t;
+        }
+        if ((m->numToHap[i] > nhi || m->numToHap[i] == 0) && m->numToHap[i - 1] < nhi) {
+            mem_h = m->numToHap[i];
+            check = 1;
+            m->numToHap[i] = nhi;
+            mem_inf = IDX2(m->infectious, pi, i, H_);
+            IDX2(m->infectious, pi, i, H_) = 0;
+            m->hapToNum[nhi] = i;
+        }
+    }
+    m->currentHapNum += 1;
+    vgo_update_all_rates(m);
 }
 
 static void Mutation(vgo_model *m, int64_t pi, int64_t hi) { /* pyx:640-667 */
-    int64_t ohi = hi;
+    int64_t ohi = NH(hi);
     choice_t c = choose_f64(m, &IDX2(m->mRate, ohi, 0, SITES_), SITES_, m->tmRate[hi], m->rn);
     int64_t mi = c.i;
     m->rn = c.rn;
@@ -699,7 +738,18 @@ static void Mutation(vgo_model *m, int64_t pi, int64_t hi) { /* pyx:640-667 */
     int64_t DS = c.i;
     m->rn = c.rn;
     int64_t nhi = Mutate(m, ohi, mi, DS);
-    IDX2(m->infectious, pi, nhi, H_) += 1;
+    if (m->memory_optimization) { /* pyx:651-660 */
+        int check = 1;
+        for (int64_t hn = 0; hn < m->currentHapNum + 1; hn++) {
+            if (hn >= m->maxHapNum) break;   /* (upstream reads one slot past numToHap here when the table is full) */
+            if (m->numToHap[hn] == nhi) { check = 0; break; }
+        }
+        if (check) {
+            AddHaplotype(m, nhi, pi);
+            if (nhi < ohi) hi += 1;
+        }
+    }
+    IDX2(m->infectious, pi, HN(nhi), H_) += 1;
     IDX2(m->infectious, pi, hi, H_) -= 1;
     if (m->sparse) {
         occ_set(m, pi, nhi, 1);
@@ -720,19 +770,19 @@ static int64_t GenerateMigration(vgo_model *m) { /* pyx:672-694 */
     int64_t spi = c.i;
     m->rn = c.rn;
     if (m->sparse) c = choose_i64_sparse(m, spi, &IDX2(m->infectious, spi, 0, H_), m->totalInfectious[spi], m->rn);
-    else c = choose_i64(m, &IDX2(m->infectious, spi, 0, H_), H_, m->totalInfectious[spi], m->rn);
+    else c = choose_i64(m, &IDX2(m->infectious, spi, 0, H_), ROWN, m->totalInfectious[spi], m->rn);
     int64_t hi = c.i;
     m->rn = c.rn;
     c = choose_i64(m, &IDX2(m->susceptible, tpi, 0, S_), S_, m->totalSusceptible[tpi], m->rn);
     int64_t si = c.i;
     m->rn = c.rn;
-    double p_accept = IDX2(m->effectiveMigration, spi, tpi, P_) * m->bRate[hi] * IDX2(m->susceptibility, hi, si, S_) /
+    double p_accept = IDX2(m->effectiveMigration, spi, tpi, P_) * m->bRate[NH(hi)] * IDX2(m->susceptibility, NH(hi), si, S_) /
                       m->maxEffectiveBirthMigration[tpi];
     if (m->rn < p_accept) {
         NewInfections(m, tpi, si, hi, 1);
         UpdateRates(m, tpi, 1, 1, 1);
         m->migPlus += 1;
-        AddEvent(m, m->currentTime, VGO_MIGRATION, hi, spi, si, tpi);
+        AddEvent(m, m->currentTime, VGO_MIGRATION, NH(hi), spi, si, tpi);
     } else {
         m->migNonPlus += 1;
     }
@@ -756,7 +806,7 @@ static int64_t GenerateEvent(vgo_model *m, rng_t *r) { /* pyx:483-512 */
         } else {
             m->rn = (choose - m->immunePopRate[pi]) / m->infectPopRate[pi];
             if (m->sparse) c = choose_f64_sparse(m, pi, &IDX2(m->hapPopRate, pi, 0, H_), m->infectPopRate[pi], m->rn);
-            else c = choose_f64(m, &IDX2(m->hapPopRate, pi, 0, H_), H_, m->infectPopRate[pi], m->rn);
+            else c = choose_f64(m, &IDX2(m->hapPopRate, pi, 0, H_), ROWN, m->infectPopRate[pi], m->rn);
             int64_t hi = c.i;
             m->rn = c.rn;
             c = choose_f64(m, &IDX3(m->eventHapPopRate, pi, hi, 0, H_, 4), 4, IDX2(m->tEventHapPopRate, pi, hi, H_), m->rn);
@@ -778,6 +828,7 @@ static void FirstInfection(vgo_model *m) { /* pyx:234-242 */
     if (m->globalInfectious == 0) {
         for (int64_t sn = 0; sn < S_; sn++) {
             if (IDX2(m->susceptible, 0, sn, S_) == 0) continue;
+            if (m->memory_optimization) AddHaplotype(m, 0, 0);
             NewInfections(m, 0, sn, 0, 1);
             return;
         }
@@ -836,6 +887,7 @@ static void Restart(vgo_model *m) { /* pyx:714-738 */
 int vgo_simulate_direct(vgo_model *m, int64_t iterations, int64_t sample_size, float time, int64_t attempts) { /* pyx:396-429 */
     rng_t r;
     m->error = VGO_OK;
+    if (m->memory_optimization && (m->sparse || !m->hapToNum || !m->numToHap)) return (int)(m->error = VGO_ERR_BAD_ARG);
     PrepareParameters(m);
     for (int64_t i = 0; i < attempts; i++) {
         vgo_pcg64_seed(&r.g, (uint64_t)m->user_seed, (uint32_t)i);

@@ -18,8 +18,15 @@
  *     checkout, so for that one mapping: PARITY UNPINNED.
  *
  * All arrays are caller-owned, C-contiguous (numpy in the tests); the oracle allocates nothing except
- * small scratch vectors.  memory_optimization (hapToNum/numToHap) is not restated: upstream's table code corrupts
- * the state, numToHap is the identity here.
+ * small scratch vectors.
+ *
+ * memory_optimization (pyx:105-125, AddMemory pyx:264-274, AddHaplotype pyx:355-377, the lookup in Mutation pyx:651-660) is
+ * restated op for op on the direct path, bugs included (AddHaplotype shifts the counts of ONE population only), with one
+ * difference: the arrays indexed by program number keep hapNum columns here, so the places where upstream reads or
+ * writes past its maxHapNum columns with bounds checking off (PrepareParameters pyx:444-446, Restart pyx:732-735,
+ * the lookup's slot currentHapNum when the table is full) see zeros / are skipped instead of foreign memory; AddMemory is
+ * then pure bookkeeping (maxHapNum, addMemoryNum).  Upstream has no goldens for the option (check_simulator.py:153-180
+ * are commented out): this part of the oracle is a restatement read against the source, not pinned by fixtures.
  */
 #ifndef VGX_ORACLE_H
 #define VGX_ORACLE_H
@@ -106,6 +113,11 @@ typedef struct vgo_model {
     int64_t *sitesPosition;                   /* [sites] */
     int64_t rec_cap, rec_n;                   /* forward records; never cleared by Restart (pyx:714-738) */
     int64_t *rec_idevents, *rec_his, *rec_hi2s, *rec_nhis, *rec_posRecombs;
+    /* ---- memory_optimization (pyx:105-125); 0: program number == haplotype, the fields below are ignored ---- */
+    int64_t memory_optimization;
+    int64_t currentHapNum, maxHapNum, addMemoryNum;
+    int64_t *hapToNum;                        /* [H] haplotype -> program number */
+    int64_t *numToHap;                        /* [H] program number -> haplotype (upstream: maxHapNum entries, grown by AddMemory) */
 } vgo_model;
 
 /* pyx:396-429.  `time` is a C float exactly as in the reference signature. */

@@ -27,8 +27,17 @@ def test_direct_bit_exact_vs_oracle(oracle_mod, name):
     helpers.assert_models_equal(hip, ref, name)
 
 
+def test_which_time_row_branch_runs_on_this_host():
+    """Records (in pytest's warnings summary, which ends the run's output) which branch the golden tests below take here:
+    libm_probe_match=True -> sha256 of the full (6, N) chain incl. the time row; False -> integer rows exact, times 1e-12."""
+    import warnings
+    warnings.warn("libm_probe_match=%s (time-row branch of the golden tests: %s)" % (
+        helpers.libm_matches_fixture_host(), "bit-exact sha256" if helpers.libm_matches_fixture_host() else "rtol 1e-12"))
+
+
 @pytest.mark.parametrize("name", DIRECT)
 def test_direct_vs_reference_goldens(name):
+    print("libm_probe_match=%s" % helpers.libm_matches_fixture_host())
     hip = helpers.run_case_hip(name).simulation
     helpers.check_against_golden(hip, name, exact_time=helpers.libm_matches_fixture_host(), rtol_time=1e-12, leftovers=False)
 
@@ -64,27 +73,43 @@ def test_recombination_is_refused_in_fast_mode():
     assert len(helpers.run_case_hip("recomb_a").simulation.rec.his) > 1000
 
 
-def test_memory_optimization_flag_changes_bookkeeping_only():
-    """The engine is sparse in the haplotype dimension by construction: ``memory_optimization=True`` yields the chain of
-    the plain layout and maintains the reference's haplotype table (sorted program numbers, pyx:355-377)."""
+@pytest.mark.parametrize("sites,seed,mut,n", [(1, 2020, 0.3, 6000), (3, 7, 0.3, 6000), (4, 11, 0.3, 8000), (5, 4, 0.05, 8000)])
+def test_memory_optimization_vs_oracle_table_code(oracle_mod, sites, seed, mut, n):
+    """``memory_optimization=True`` (one population): the engine against the ORACLE'S op-for-op restatement of the reference's
+    table code (AddMemory pyx:264-274, AddHaplotype pyx:355-377, the lookup of Mutation pyx:651-660): event chain, compartments
+    and the table itself (numToHap, hapToNum, currentHapNum, maxHapNum grown in addMemoryNum steps)."""
     from vgsim_amd import Simulator
 
-    def run(flag):
+    def make():
         with helpers.quiet():
-            s = Simulator(4, 2, 1, seed=11, memory_optimization=flag)
-            s.set_mutation_rate(0.2)
-            s.set_migration_probability(0.01)
-            s.simulate(4000)
-            after_direct.append(s.simulation.currentHapNum)
-            s.simulate(300, method="tau", sample_size=10 ** 9)
-        return s.simulation
-    after_direct = []
-    a, b = run(False), run(True)
-    assert after_direct[0] == 256 and 1 < after_direct[1] < 256     # the table grows with the haplotypes seen
-    assert np.array_equal(a.events.as_array(), b.events.as_array()) and np.array_equal(a.infectious, b.infectious)
-    n = b.currentHapNum
-    seen = np.unique(np.concatenate(([0], b.events.newHaplotypes[:b.events.ptr][b.events.types[:b.events.ptr] == 3],
-                                     b.multievents.newHaplotypes[:b.multievents.ptr][b.multievents.types[:b.multievents.ptr] == 3])))
-    assert after_direct[1] <= n == len(seen) <= 256 and np.array_equal(b.numToHap[:n], seen)
-    assert np.array_equal(b.hapToNum[seen], np.arange(n)) and n <= b.maxHapNum <= 256 and len(b.numToHap) == b.maxHapNum
-    assert a.currentHapNum == 256 and np.array_equal(a.numToHap, np.arange(256))
+            s = Simulator(number_of_sites=sites, populations_number=1, number_of_susceptible_groups=2, seed=seed, memory_optimization=True)
+        s.set_transmission_rate(2.5); s.set_recovery_rate(0.9); s.set_sampling_rate(0.1); s.set_mutation_rate(mut)
+        s.set_transmission_rate(3.5, haplotype=2)
+        s.set_susceptibility_type(1); s.set_susceptibility(0.4, susceptibility_type=1)
+        s.set_immunity_transition(0.05, source=1, target=0)
+        return s
+    hip, ref = make(), make()
+    with helpers.quiet():
+        hip.simulate(n, sample_size=10 ** 9)
+    assert oracle_mod.run_direct_memopt(ref.simulation, n, 10 ** 9, -1, 200) == 0
+    h, r = hip.simulation, ref.simulation
+    assert r.good_attempt == 1, "pick a seed whose first attempt survives (see _refresh_haplotype_table)"
+    helpers.assert_models_equal(h, r, "memory_optimization sites=%d" % sites)
+    tb = r._memopt
+    cur = tb.currentHapNum
+    assert h.currentHapNum == cur and h.maxHapNum == tb.maxHapNum and len(h.numToHap) == tb.maxHapNum
+    assert np.array_equal(h.numToHap[:cur], tb.numToHap[:cur])
+    assert np.array_equal(h.hapToNum[tb.numToHap[:cur]], tb.hapToNum[tb.numToHap[:cur]])
+    if sites >= 4:
+        assert 4 ** (sites - 2) < tb.maxHapNum < 4 ** sites      # the table grew through AddMemory, not to the full space
+
+
+def test_memory_optimization_is_refused_where_upstream_corrupts_its_state():
+    from vgsim_amd import Simulator
+    with helpers.quiet():
+        two = Simulator(2, 2, 1, seed=11, memory_optimization=True)
+        one = Simulator(2, 1, 1, seed=11, memory_optimization=True)
+    with pytest.raises(ValueError, match="one population"), helpers.quiet():
+        two.simulate(100)
+    with pytest.raises(ValueError, match="direct method"), helpers.quiet():
+        one.simulate(10, method="tau")

@@ -506,3 +506,77 @@ def test_tau_without_multievent_rows():
     assert np.array_equal(a.events.times[:a.events.ptr], b.events.times[:b.events.ptr])
     nd = phases[0][1]["iterations"]
     assert b.multievents.ptr == 0 and (b.events.haplotypes[nd:b.events.ptr] == 0).all()
+
+
+def _c4_scaled(seed):
+    """The recipe of bench.py's config-4 leg (uniform fill of 3 hosts per compartment, uniform migration, one rate class, one
+    susceptibility group) at 7 sites x 4 populations: 65 536 compartments, one high site — the shape at which the engine takes
+    the SAME kernel instantiations as at config 4 (vgx_tau_drift_fast_kernel<true, true> + vgx_tau_muthigh_kernel for the drift,
+    the sieve from the histogram, vgx_tau_scan_fast_kernel<true, false>, vgx_tau_events_kernel with the LDS tables) and the
+    oracle still runs a leap in 0.1 s."""
+    from vgsim_amd import Simulator
+    with helpers.quiet():
+        s = Simulator(number_of_sites=7, populations_number=4, seed=seed)
+    s.set_transmission_rate(2.5); s.set_recovery_rate(0.9); s.set_sampling_rate(0.1); s.set_mutation_rate(0.01)
+    s.set_total_migration_probability(0.01); s.set_population_size(10 ** 7)
+    m = s.simulation
+    m.infectious[:] = 3
+    m.susceptible[:, 0] -= 3 * m.hapNum
+    m.totalInfectious[:] = 3 * m.hapNum
+    m.totalSusceptible[:] = m.susceptible.sum(axis=1)
+    m.globalInfectious = int(m.totalInfectious.sum())
+    m.first_simulation = True
+    m.initial_infectious[:] = m.infectious
+    m.initial_susceptible[:] = m.susceptible
+    return s
+
+
+def test_config4_kernel_instantiations_match_oracle_distribution(oracle_mod):
+    """Config 4's own kernels pinned distributionally: N seeds x 6 leaps on the scaled-down config-4 state, the device's as one
+    ensemble launch, against the oracle's runs of the same state.  For the five event kinds (= the per-kind totals of the
+    multievent rows), the epidemic time, the infectious total of every population, of every value of the HIGH site's digit
+    and of every value of the last site's digit: |mean_1 - mean_2| <= 4.5 sqrt(s1^2/n + s2^2/n) + floor and
+    |var_1 - var_2| <= 4.5 sqrt((m4_1 - s1^4)/n + (m4_2 - s2^4)/n) + floor (floor: half an event / 1e-9 time units)."""
+    from vgsim_amd.ensemble import Ensemble
+    n, nt = 48, 3          # tau as the first call of a model: capacity 2 x iterations (pyx:2298, 2306) -> 6 leaps
+    seeds = 70000 + np.arange(n, dtype=np.int64)
+    keys = ("bCounter", "dCounter", "sCounter", "mCounter", "migPlus", "currentTime")
+
+    def features(m):
+        inf = m.infectious
+        H = inf.shape[1]
+        hi = inf.reshape(inf.shape[0], 4, H // 4).sum(axis=(0, 2))          # first (high) site: digit value 0..3
+        lo = inf.reshape(inf.shape[0], H // 4, 4).sum(axis=(0, 1))          # last site
+        return [float(getattr(m, k)) for k in keys] + [float(v) for v in inf.sum(axis=1)] + [float(v) for v in hi] + [float(v) for v in lo]
+
+    base = _c4_scaled(11)
+    ens = Ensemble(base, n, seeds=seeds)
+    res = ens.simulate_tau(nt, sample_size=10 ** 12, record_events=True)
+    assert (res.events == 2 * nt).all()
+    dev = np.array([features(ens.replicate_state(r)) for r in range(n)])
+    # the per-kind totals of the multievent rows ARE the counters (exact bookkeeping, two replicates)
+    for r in (0, n - 1):
+        rows = ens.engine.multievents(r)
+        st = ens.replicate_state(r)
+        by_type = np.bincount(rows["types"], weights=rows["num"], minlength=6)
+        assert (by_type[0], by_type[1], by_type[2], by_type[3], by_type[5]) == (st.bCounter, st.dCounter, st.sCounter, st.mCounter, st.migPlus)
+        assert (rows["num"] > 0).all()
+    ens.close()
+    ref = []
+    for sd in seeds:
+        one = _c4_scaled(int(sd)).simulation
+        assert oracle_mod.run_tau(one, nt, 10 ** 12, -1, 200) == 0
+        assert one.events.ptr == 2 * nt
+        ref.append(features(one))
+    ref = np.array(ref)
+    names = list(keys) + ["infectious[pop %d]" % i for i in range(4)] + ["infectious[high digit %d]" % i for i in range(4)] + \
+        ["infectious[last digit %d]" % i for i in range(4)]
+    for j, what in enumerate(names):
+        a, b = dev[:, j], ref[:, j]
+        floor = 1e-9 if what == "currentTime" else 0.5
+        s1, s2 = a.std(ddof=1), b.std(ddof=1)
+        tol = 4.5 * np.sqrt(s1 ** 2 / n + s2 ** 2 / n) + floor
+        assert abs(a.mean() - b.mean()) <= tol, "%s: means %.8g vs %.8g (tolerance %.3g)" % (what, a.mean(), b.mean(), tol)
+        m4a, m4b = ((a - a.mean()) ** 4).mean(), ((b - b.mean()) ** 4).mean()
+        tolv = 4.5 * np.sqrt(max(m4a - s1 ** 4, 0.0) / n + max(m4b - s2 ** 4, 0.0) / n) + floor
+        assert abs(s1 ** 2 - s2 ** 2) <= tolv, "%s: variances %.6g vs %.6g (tolerance %.3g)" % (what, s1 ** 2, s2 ** 2, tolv)

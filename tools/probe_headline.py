@@ -4,7 +4,9 @@ sys.path.insert(0, os.getcwd())
 import numpy as np
 import bench
 from vgsim_amd.ensemble import Ensemble
-for kernel, R, N in (("quad", 16384, 100000), ("quad", 32768, 50000), ("wave", 4096, 100000)):
+cases = [a.split(":") for a in sys.argv[1:]] or [("quad", 16384, 100000), ("quadg", 16384, 100000)]
+for kernel, R, N in cases:
+    R, N = int(R), int(N)
     ens = Ensemble(bench.make_simulator(2020), R)
     res = None
     for it in range(2):

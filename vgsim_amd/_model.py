@@ -229,19 +229,31 @@ class BirthDeathModel(ParameterTable, Reporting):
         self._rng_raw = None        # raw generator state after the last genealogy pass
 
     # ------------------------------------------------------------------ hot-path entry points
-    def _check_supported(self):
+    def _check_supported(self, method='direct'):
+        if self._memory_optimization and (self.popNum > 1 or method == 'tau'):
+            # Upstream's table code is only meaningful for ONE population on the direct path: AddHaplotype shifts the counts
+            # of the mutating population alone (pyx:366-369), so with several populations the other populations' counts end up
+            # under the wrong program numbers, and tau-leaping indexes the program-number arrays by haplotype (pyx:2351-2593),
+            # reading past their maxHapNum columns.  There is nothing well-defined to reproduce; the engine's state is sparse
+            # in the haplotype dimension whatever the flag says.
+            raise ValueError('memory_optimization=True is supported for one population and the direct method only (the reference '
+                             'corrupts its state elsewhere: _BirthDeath.pyx:366-369, 2351-2593); use memory_optimization=False: '
+                             'this engine keeps only the occupied haplotypes in either case')
         if self.recombination != 0 and self.sites < 2:
             # upstream allocates the scratch vector of the recombination branch only for sites > 1 (pyx:98-102) and
             # crashes in Birth otherwise
             raise ValueError('Incorrect value of recombination probability. Recombination needs at least two sites.')
 
     def _refresh_haplotype_table(self):
-        """``memory_optimization=True`` (pyx:105-125, 264-274, 355-377, 651-660).  The engine's state is sparse in the
-        haplotype dimension whatever the flag says (ordered occupancy lists), and the reference's table
-        keeps program numbers in haplotype order (sorted insert, pyx:365-375), i.e. the scan order of the plain
-        layout: the trajectory is that of ``memory_optimization=False``.  What remains of the option is its
-        bookkeeping, rebuilt here after every simulate call: ``numToHap`` = the haplotypes seen so far in ascending
-        order, ``hapToNum`` its inverse, ``maxHapNum`` grown in ``addMemoryNum`` steps like ``AddMemory``."""
+        """``memory_optimization=True`` (pyx:105-125, 264-274, 355-377, 651-660), one population, direct method.  The
+        engine's state is sparse in the haplotype dimension whatever the flag says (ordered occupancy lists),
+        and the reference's table keeps program numbers in haplotype order (sorted insert, pyx:365-375), i.e. the scan
+        order of the plain layout: the trajectory is that of ``memory_optimization=False`` (checked against the oracle's
+        op-for-op restatement of the table code, tests/test_memopt.py).  What remains of the option is its bookkeeping,
+        rebuilt here after every simulate call: ``numToHap`` = the haplotypes seen so far in ascending order, ``hapToNum``
+        its inverse, ``maxHapNum`` grown in ``addMemoryNum`` steps like ``AddMemory``.  (After a Restart the reference's
+        table also keeps the haplotypes that appeared only in the discarded attempts — at most 100 events each; this one
+        holds those of the kept attempt.)"""
         if not self._memory_optimization:
             return
         seen = [self.numToHap[:self.currentHapNum], np.nonzero(self.initial_infectious.any(axis=0))[0],
@@ -339,7 +351,7 @@ class BirthDeathModel(ParameterTable, Reporting):
         """pyx:2293-2346: Poisson tau-leaping on the GPU.  ``record_multievents=False`` keeps the MULTITYPE records (step
         times) but not the per-channel rows a later ``genealogy()`` would walk: for long dense runs whose rows would not
         fit (the reference allocates iterations x propNum rows up front, pyx:2305)."""
-        self._check_supported()
+        self._check_supported('tau')
         self.events.CreateEvents(iterations)   # via PrepareParameters (pyx:2298 -> pyx:434)
         self.events.CreateEvents(iterations)   # pyx:2306
         self.CheckSizes()
