@@ -650,7 +650,9 @@ def main():
                   ("direct_config4_shape", c4_direct_leg), ("table3", lambda d: table3_leg(d, cpu=not a.no_cpu_baseline, cells=cells3)),
                   ("propensity_scan", rowscan_leg), ("tau_leap", tau_leg))
     if a.only:
-        print(json.dumps({a.only: dict(extra_legs)[a.only](local)}), flush=True)
+        legs = dict(extra_legs)
+        legs["config5"] = lambda d: config5_leg(d, world=world, rank=rank)
+        print(json.dumps({a.only: legs[a.only](local)}), flush=True)
         return
     sim = make_simulator(2020)
     ens = Ensemble(sim, a.replicates, device=local)

@@ -42,7 +42,7 @@ extern "C" hipError_t vgxi_launch_init_reps(const VgxDevRep *r, int P, int S, in
 
 #define TAU_DECL(name) extern "C" hipError_t vgxi_##name(const VgxTauArgs *a, hipStream_t s);
 TAU_DECL(tau_eff) TAU_DECL(tau_scatter) TAU_DECL(tau_prep) TAU_DECL(tau_drift) TAU_DECL(tau_choose) TAU_DECL(tau_draw)
-TAU_DECL(tau_arrivals) TAU_DECL(tau_verdict) TAU_DECL(tau_apply) TAU_DECL(tau_check) TAU_DECL(tau_decide) TAU_DECL(tau_commit) TAU_DECL(tau_finish) TAU_DECL(tau_draw_big) TAU_DECL(tau_suspect)
+TAU_DECL(tau_conv8) TAU_DECL(tau_sync8) TAU_DECL(tau_arrivals) TAU_DECL(tau_verdict) TAU_DECL(tau_apply) TAU_DECL(tau_check) TAU_DECL(tau_decide) TAU_DECL(tau_commit) TAU_DECL(tau_finish) TAU_DECL(tau_draw_big) TAU_DECL(tau_suspect)
 
 static std::string g_create_error;
 
@@ -94,7 +94,7 @@ struct vgx_engine {
         r_evrate, r_evcols, r_locrec, r_loctime, r_lociter, r_farate, r_fakey, r_traj, r_prof, r_qeff, r_qmebm, r_qflag;
     // tau-leaping (dense compartments)
     DevBuf t_I, t_S, t_dChk, t_dApp, t_dSi, t_dTot, t_totInf, t_gI, t_cd, t_lock, t_F, t_eff, t_Aeff, t_Gout, t_dS,
-        t_taubits, t_tau, t_time, t_flags, t_counters, t_cnttry, t_mev, t_mevn, t_mevbase, t_locn, t_mutcum, t_migcdf, t_migIn, t_mutHi, t_colT, t_colTW, t_inc, t_incn, t_sieve, t_sieveskip, t_big, t_bign, t_res, t_susp, t_suspn, t_stkey, t_stval, t_dChkTot, t_q, t_qn, t_hist, t_I8, t_dSpart;
+        t_taubits, t_tau, t_time, t_flags, t_counters, t_cnttry, t_mev, t_mevn, t_mevbase, t_locn, t_mutcum, t_migcdf, t_migIn, t_mutHi, t_colT, t_colTW, t_inc, t_incn, t_sieve, t_sieveskip, t_big, t_bign, t_res, t_susp, t_suspn, t_stkey, t_stval, t_dChkTot, t_q, t_qn, t_hist, t_I8, t_dSpart, t_sat8;
     std::vector<int64_t> tau_sieve_skipped;   // [R] tries left out by the sieve in the last tau call
     bool last_was_tau = false;
     int64_t tau_mev_cap = 0;
@@ -1308,6 +1308,16 @@ extern "C" int vgx_simulate_tau(vgx_engine *e, int64_t iterations, int64_t sampl
         flat = flat && (nh == 0 || a.mutHi_int) && (!a.has_mig || a.mig_uniform);
         a.mutlow_fast = flat ? 1 : 0;
         a.mutlow_same = (flat && same) ? 1 : 0;
+        // the drift pass on the one-byte counts (vgx_tau_drift8_kernel): the fast form's models from seven sites on with one
+        // rate class and one rate for the low sites (VGX_TAU_NO_BYTE_DRIFT=1: the two-pass form, for comparisons)
+        const char *nb8 = getenv("VGX_TAU_NO_BYTE_DRIFT");
+        a.use8 = (flat && same && nh >= 1 && e->C == 1 && S <= 64 && !(nb8 && nb8[0] == '1')) ? 1 : 0;
+        a.nt8 = ns > 8 ? 1 << (2 * (ns - 8)) : 1;
+        {
+            int rc8 = ensure(e, e->t_sat8, (size_t)(R * P * a.nt8) + 64);
+            if (rc8) return rc8;
+            a.sat8 = (uint8_t *)e->t_sat8.p;
+        }
         a.hist = nullptr;
         if (flat && a.sieve_on && e->C <= 8) {   // (VGX_HIST_CMAX classes x 64 sizes per population)
             int rch = ensure(e, e->t_hist, (size_t)(R * P * e->C * 64) * 4);
@@ -1348,6 +1358,7 @@ extern "C" int vgx_simulate_tau(vgx_engine *e, int64_t iterations, int64_t sampl
     const bool has_tl = !(time == -1.0f);
     auto sC_of = [&](int64_t r) { return cnt0[(size_t)r][2] + cnt[(size_t)r * 8 + 2]; };
     int64_t guard = 0;
+    bool i8_dirty = true;    // I8 does not mirror I (start of the call, after a Restart's upload, after a dense try)
     while (true) {
         // loop condition (pyx:2312) / end of attempt (pyx:2331-2335)
         bool any = false;
@@ -1363,6 +1374,7 @@ extern "C" int vgx_simulate_tau(vgx_engine *e, int64_t iterations, int64_t sampl
                 restarts[(size_t)r] += 1;
                 rc = upload_state(r, h.initial_infectious, h.initial_susceptible);
                 if (rc) return rc;
+                i8_dirty = true;
                 {   // the lockdown records of the failed attempt stay (Restart does not clear `loc`); then CheckLockdown for
                     // every population on the restored totals at time 0 (pyx:736-737), whose switches change the contact
                     // densities the next attempt starts with
@@ -1446,6 +1458,12 @@ extern "C" int vgx_simulate_tau(vgx_engine *e, int64_t iterations, int64_t sampl
         if (att32 != dev_att) { HIPCHECK(e, hipMemcpy(a.attempt, att32.data(), (size_t)R * 4, hipMemcpyHostToDevice)); dev_att = att32; }
         if (tnow != dev_time) { HIPCHECK(e, hipMemcpy(a.time_now, tnow.data(), (size_t)R * 8, hipMemcpyHostToDevice)); dev_time = tnow; }
         HIPCHECK(e, hipEventRecord(e->ev0, e->stream));
+        if (a.use8 && i8_dirty) {     // the one-byte counts after an upload / a dense try: one pass over the 4-byte counts
+            HIPCHECK(e, hipMemsetAsync(a.sat8, 0, (size_t)(R * P * a.nt8), e->stream));
+            HIPCHECK(e, vgxi_tau_conv8(&a, e->stream));
+            i8_dirty = false;
+            launches += 1;
+        }
         HIPCHECK(e, vgxi_tau_eff(&a, e->stream));
         HIPCHECK(e, vgxi_tau_prep(&a, e->stream));
         HIPCHECK(e, vgxi_tau_drift(&a, e->stream));
@@ -1472,7 +1490,9 @@ extern "C" int vgx_simulate_tau(vgx_engine *e, int64_t iterations, int64_t sampl
                 HIPCHECK(e, vgxi_tau_verdict(&a, e->stream));
                 HIPCHECK(e, vgxi_tau_decide(&a, e->stream));
                 HIPCHECK(e, vgxi_tau_apply(&a, e->stream));
+                if (a.use8) { HIPCHECK(e, vgxi_tau_sync8(&a, e->stream)); launches += 1; }
             } else {
+                i8_dirty = true;     // (the dense commit pass changes the counts without the one-byte copy)
                 HIPCHECK(e, vgxi_tau_scatter(&a, e->stream));
                 HIPCHECK(e, vgxi_tau_suspect(&a, e->stream));
                 if (a.dense_check) HIPCHECK(e, vgxi_tau_check(&a, e->stream));

@@ -867,6 +867,250 @@ __global__ void __launch_bounds__(TB) vgx_tau_drift_fast_kernel(VgxTauArgs a) {
         }
 }
 
+// ---- the drift pass on the ONE-BYTE counts (config 4's shape: 7 to 10 sites, one rate class, the uniform mutation model with
+// equally likely derived states, one rate for the low and one for the high sites, no or uniform migration) -------------------
+// The two-pass form above reads the 4-byte counts three times per step (column sums, high-site pass, low-site pass) and moves the
+// high-site neighbour sums through memory: 5.9 GB per step at config 4 before a single event is drawn.  Here I8 = min(count, 255)
+// is kept in step with the counts (vgx_tau_sync8_kernel after the accepted try's list has been applied; vgx_tau_conv8_kernel
+// after an upload) and the drift pass READS it: a block stages a tile of 4^8 haplotypes = 64 KB of bytes in LDS — the neighbours
+// through the last eight sites are inside it — and fetches the neighbours through the first one or two sites (three or six
+// other tiles of the same population row) from global memory, where the block-to-XCD mapping keeps them in the L2 of the XCD
+// the row's tiles run on.  No intermediate array, one read of 1 byte per compartment.  Neighbour counts are summed as integers
+// in 16-bit lanes (two compartments per register), separately for the low six and the high sites, and enter the drift with the
+// arithmetic of vgx_tau_drift_fast_kernel: tau has the same bits as with the two-pass form.  A byte of 255 stands for "255 or
+// more": tiles that may hold one are flagged (sat8), their blocks test every byte they add, and a wavefront that meets one
+// forms its compartments' sums again from the 4-byte counts.
+#define VGX_D8_LOW 8
+#define D8_TB 512       // two blocks per CU (2 x 77 KB of LDS, 16 wavefronts)
+static __device__ __forceinline__ uint32_t d8_even(uint32_t x) { return __builtin_amdgcn_perm(0u, x, 0x0C020C00u); }   // bytes 0, 2 -> 16-bit lanes
+static __device__ __forceinline__ uint32_t d8_odd(uint32_t x) { return __builtin_amdgcn_perm(0u, x, 0x0C030C01u); }    // bytes 1, 3
+static __device__ __forceinline__ uint32_t d8_sat(uint32_t x) { return ((x & 0x7F7F7F7Fu) + 0x01010101u) & x & 0x80808080u; }   // some byte == 255
+
+// I8 = min(I, 255) and the saturation flags of the tiles, for the whole state.  grid = (ceil(H / (4 TB)), P, R); sat8 zeroed before.
+extern "C" __global__ void __launch_bounds__(TB) vgx_tau_conv8_kernel(VgxTauArgs a) {
+    const int rep = blockIdx.z, pn = blockIdx.y;
+    const int P = a.p.P, H = a.p.H;
+    const int h0 = (blockIdx.x * TB + threadIdx.x) * 4;
+    if (h0 >= H) return;
+    const int64_t off = ((int64_t)rep * P + pn) * H + h0;
+    const int4 v = *(const int4 *)(a.I + off);
+    *(uint32_t *)(a.I8 + off) = tau_pack8(v.x, v.y, v.z, v.w);
+    if (v.x >= 255 || v.y >= 255 || v.z >= 255 || v.w >= 255) a.sat8[((int64_t)rep * P + pn) * a.nt8 + (h0 >> (2 * VGX_D8_LOW))] = 1;
+}
+
+// Column sums over the populations from the one-byte counts (a saturated byte: the 4-byte counts).  grid = (ceil(H / (4 TB)), R).
+extern "C" __global__ void __launch_bounds__(TB) vgx_tau_colsum8_kernel(VgxTauArgs a) {
+    const int rep = blockIdx.y;
+    if (!a.active[rep]) return;
+    const VgxDevParams &p = a.p;
+    const int P = p.P, H = p.H;
+    __shared__ double s_w[VGX_MIGU_PMAX];
+    for (int q = threadIdx.x; q < P; q += TB) s_w[q] = a.cd[(int64_t)rep * P + q] / p.actualSizes[q];
+    __syncthreads();
+    const int h0 = (blockIdx.x * TB + threadIdx.x) * 4;
+    if (h0 >= H) return;
+    const uint8_t *I8 = a.I8 + (int64_t)rep * P * H;
+    const int32_t *I = a.I + (int64_t)rep * P * H;
+    long long t[4] = {0, 0, 0, 0};
+    double tw[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int q0 = 0; q0 < P; q0 += 8) {      // eight rows' loads in flight together
+        uint32_t xs[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) xs[u] = *(const uint32_t *)(I8 + (int64_t)min(q0 + u, P - 1) * H + h0);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int q = q0 + u;
+            if (q >= P) break;
+            int x[4] = {(int)(xs[u] & 255u), (int)((xs[u] >> 8) & 255u), (int)((xs[u] >> 16) & 255u), (int)(xs[u] >> 24)};
+            if (d8_sat(xs[u])) { const int4 v = *(const int4 *)(I + (int64_t)q * H + h0); x[0] = v.x; x[1] = v.y; x[2] = v.z; x[3] = v.w; }
+            const double w = s_w[q];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { t[j] += x[j]; tw[j] += w * (double)x[j]; }
+        }
+    }
+    for (int j = 0; j < 4; ++j) { a.colT[(int64_t)rep * H + h0 + j] = (double)t[j]; a.colTW[(int64_t)rep * H + h0 + j] = tw[j]; }
+}
+
+// grid = (8 * ceil(P / 8) * nt8, R): flattened (population, tile) with the tiles of one population on one XCD (workgroups go to
+// the XCDs round-robin in the order of their flattened index); dynamic LDS = 4^min(sites, 8) bytes.
+template <bool S1>
+__global__ void __launch_bounds__(D8_TB) vgx_tau_drift8_kernel(VgxTauArgs a) {
+    const VgxDevParams &p = a.p;
+    const int P = p.P, S = p.S, H = p.H, sites = p.sites;
+    const int nt = a.nt8;
+    const unsigned f = blockIdx.x;
+    const int xcd = (int)(f & 7u);
+    const unsigned sq = f >> 3;
+    const int tl = (int)(sq % (unsigned)nt), pn = (int)(sq / (unsigned)nt) * 8 + xcd, rep = blockIdx.y;
+    if (pn >= P || !a.active[rep]) return;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int low = sites < VGX_D8_LOW ? sites : VGX_D8_LOW, ntop = sites - low;     // sites inside the tile / above it
+    const int TSd = 1 << (2 * low - 2);                                              // dwords of a tile
+    const int64_t rowoff = ((int64_t)rep * P + pn) * H;
+    const uint32_t *row32 = (const uint32_t *)(a.I8 + rowoff);
+    const int32_t *Irow = a.I + rowoff;
+    const int64_t *Sus = a.S + (int64_t)rep * P * S + (int64_t)pn * S;
+    extern __shared__ __attribute__((aligned(16))) unsigned char d8sm[];
+    uint32_t *tile32 = (uint32_t *)d8sm;
+    __shared__ double sdS[D8_TB / 64][64];
+    __shared__ unsigned long long smin;
+    __shared__ double l_base[64];
+    __shared__ unsigned int hist[VGX_HIST_X * 16];
+    __shared__ double s_wu[16];
+    __shared__ int s_careful;
+    const bool do_hist = a.hist != nullptr;
+    sdS[wv][lane] = 0.0;
+    if (threadIdx.x == 0) {
+        smin = (unsigned long long)__double_as_longlong(1.0);
+        int c = a.sat8[((int64_t)rep * P + pn) * nt + tl];
+        for (int g = 0; g < ntop; ++g)
+            for (int x = 1; x < 4; ++x) c |= a.sat8[((int64_t)rep * P + pn) * nt + (tl ^ (x << (2 * g)))];
+        s_careful = c;
+    }
+    if (do_hist)
+        for (int i = threadIdx.x; i < VGX_HIST_X * 16; i += D8_TB) hist[i] = 0;
+    for (int i = threadIdx.x; i < S; i += D8_TB) l_base[i] = p.cb_b[0] * p.cb_sigma[i] * (double)Sus[i];
+    // the tile: all of a thread's loads in flight at once
+    {
+        const uint32_t *src = row32 + (int64_t)tl * TSd;
+        for (int i = threadIdx.x * 4; i < TSd; i += D8_TB * 4) *(uint4 *)(tile32 + i) = *(const uint4 *)(src + i);
+    }
+    __syncthreads();
+    const bool careful = s_careful != 0;
+    const double F = a.F[(int64_t)rep * P + pn];
+    const bool use_col = a.has_mig && a.mig_uniform;
+    MigU mu = {0.0, 0.0, 0.0};
+    if (use_col) mu = tau_migu_setup(a, rep, pn, s_wu);
+    const double cd0 = p.c_d[0], cs0 = p.c_s[0] * p.sampMult[pn], ctm0 = p.c_tm[0], base0 = l_base[0];
+    const int st0 = p.c_stype[0];
+    // sites of the tile: digit g of the cell index, g = 0 .. low-1 (g = 0: the four bytes of a dword); the LOW six sites of the
+    // model (VGX_DRIFT_LOW: the rate a.mutp[nh + .]) are digits 0..5, the high ones digits 6.. and the tiles above
+    const int nh6 = sites - VGX_DRIFT_LOW;
+    const double rate_lo = a.mutp[nh6][0], rate_hi = a.mutHi_rate;
+    const double *cTP = a.colT + (int64_t)rep * H, *cTWP = a.colTW + (int64_t)rep * H;
+    double cand_min = 1.0, ad_max = 0.0;
+    double redS[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int q = threadIdx.x; q < TSd; q += D8_TB) {
+        const int h = (tl << (2 * low)) + 4 * q;          // first of the thread's four haplotypes
+        const uint32_t own = tile32[q];
+        uint32_t loE = 0, loO = 0, hiE = 0, hiO = 0, bad = careful ? d8_sat(own) : 0u;
+        // halo: the neighbours through the sites above the tile (other tiles of the row), issued first
+        uint32_t hv[6];
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int x = 1; x < 4; ++x) {
+                const int k = g * 3 + x - 1;
+                hv[k] = 0;
+                if (g < ntop) hv[k] = row32[(int64_t)(tl ^ (x << (2 * g))) * TSd + q];
+            }
+        double4 cT = {0.0, 0.0, 0.0, 0.0}, cTW = {0.0, 0.0, 0.0, 0.0};
+        if (use_col) { cT = *(const double4 *)(cTP + h); cTW = *(const double4 *)(cTWP + h); }
+        // inside the tile: digit g >= 1 of the cell index = two-bit group g - 1 of the dword index
+#pragma unroll
+        for (int g = 1; g < VGX_D8_LOW; ++g) {
+            if (g < low) {
+                const int sh = 2 * g - 2;
+                const uint32_t x1 = tile32[q ^ (1 << sh)], x2 = tile32[q ^ (2 << sh)], x3 = tile32[q ^ (3 << sh)];
+                if (careful) bad |= d8_sat(x1) | d8_sat(x2) | d8_sat(x3);
+                if (g < VGX_DRIFT_LOW) { loE += d8_even(x1) + d8_even(x2) + d8_even(x3); loO += d8_odd(x1) + d8_odd(x2) + d8_odd(x3); }
+                else { hiE += d8_even(x1) + d8_even(x2) + d8_even(x3); hiO += d8_odd(x1) + d8_odd(x2) + d8_odd(x3); }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            if (k < 3 * ntop) {
+                if (careful) bad |= d8_sat(hv[k]);
+                hiE += d8_even(hv[k]); hiO += d8_odd(hv[k]);
+            }
+        }
+        int Iv[4] = {(int)(own & 255u), (int)((own >> 8) & 255u), (int)((own >> 16) & 255u), (int)(own >> 24)};
+        const int s4 = Iv[0] + Iv[1] + Iv[2] + Iv[3];
+        int nlo[4] = {(int)(loE & 0xFFFFu) + s4 - Iv[0], (int)(loO & 0xFFFFu) + s4 - Iv[1], (int)(loE >> 16) + s4 - Iv[2], (int)(loO >> 16) + s4 - Iv[3]};
+        int nhi[4] = {(int)(hiE & 0xFFFFu), (int)(hiO & 0xFFFFu), (int)(hiE >> 16), (int)(hiO >> 16)};
+        if (sites <= VGX_DRIFT_LOW) { /* (not reached: the launcher takes this kernel from seven sites on) */ }
+        if (careful && __any(bad != 0u)) {
+            if (bad != 0u) {      // a count of 255 or more among the bytes added: the sums again from the 4-byte counts
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int hh = h + j;
+                    Iv[j] = Irow[hh];
+                    int sl = 0, shh = 0;
+                    for (int g = 0; g < sites; ++g) {
+                        const int v3 = Irow[hh ^ (1 << (2 * g))] + Irow[hh ^ (2 << (2 * g))] + Irow[hh ^ (3 << (2 * g))];
+                        if (g < VGX_DRIFT_LOW) sl += v3; else shh += v3;
+                    }
+                    nlo[j] = sl; nhi[j] = shh;
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int32_t Icell = Iv[j];
+            const double Ih = (double)Icell;
+            const double mlow = rate_lo * (double)nlo[j];
+            const double mh = rate_hi * (double)nhi[j];
+            double mg = 0.0;
+            if (use_col) mg = tau_migu(mu, j == 0 ? cT.x : j == 1 ? cT.y : j == 2 ? cT.z : cT.w, j == 0 ? cTW.x : j == 1 ? cTW.y : j == 2 ? cTW.z : cTW.w, Ih);
+            double drift = 0.0;
+            const double rec = cd0 * Ih;
+            const double samp = cs0 * Ih;
+            drift -= rec;
+            drift -= samp;
+            drift -= ctm0 * Ih;
+            drift += mlow;
+            drift += mh;
+            const double to_st = rec + samp;
+            if (S1) {
+                const double v = base0 * Ih * F + base0 * mg;
+                drift += v;
+                redS[0] += to_st - v;
+            } else {
+                for (int sn = 0; sn < S; ++sn) {
+                    const double base = l_base[sn];
+                    const double v = base * Ih * F + base * mg;
+                    drift += v;
+                    const double red = -v + (st0 == sn ? to_st : 0.0);
+                    if (sn < 4) redS[sn] += red;
+                    else if (red != 0.0) atomicAdd(&sdS[0][sn], red);
+                }
+            }
+            const double ad = fabs(drift);
+            const double v = (double)(0.03f * (float)Icell) / 2.0;      // pyx:2440-2444 (see vgx_tau_drift_fast_kernel)
+            const bool large = v > 1.0;
+            ad_max = fmax(ad_max, large ? 0.0 : ad);
+            if (__any(large && ad >= 1e-8)) {
+                if (large && ad >= 1e-8) cand_min = fmin(cand_min, v / ad);
+            }
+            if (do_hist && Icell >= 1 && Icell <= VGX_HIST_X) atomicAdd(&hist[(Icell - 1) * 16 + (lane & 15)], 1u);
+        }
+    }
+    for (int sn = 0; sn < 4 && sn < S; ++sn) {
+        double red = redS[sn];
+        for (int o = 32; o > 0; o >>= 1) red += __shfl_down(red, o);
+        if (lane == 0) sdS[wv][sn] += red;
+    }
+    if (ad_max >= 1e-8 && 1.0 / ad_max < cand_min) cand_min = 1.0 / ad_max;
+    for (int o = 32; o > 0; o >>= 1) {
+        double other = __shfl_down(cand_min, o);
+        if (other < cand_min) cand_min = other;
+    }
+    if (lane == 0) atomic_min_pos_double(&smin, cand_min);
+    __syncthreads();
+    if (threadIdx.x < S) {
+        double v = 0.0;
+        for (int w = 0; w < D8_TB / 64; ++w) v += sdS[w][threadIdx.x];
+        a.dS_part[(((int64_t)rep * P + pn) * a.ds_nb + tl) * S + threadIdx.x] = v;
+    }
+    if (threadIdx.x == 0) atomicMin(&a.tau_bits[rep], smin);
+    if (do_hist)
+        for (int i = threadIdx.x; i < VGX_HIST_X; i += D8_TB) {
+            unsigned int v = 0;
+            for (int k = 0; k < 16; ++k) v += hist[i * 16 + k];
+            if (v) atomicAdd(&a.hist[((int64_t)rep * P + pn) * VGX_HIST_X + i], v);
+        }
+}
+
 // Susceptible compartments: immunity-transition drift (pyx:2374-2381), tau candidates (pyx:2445-2450),
 // final tau_l; clears the per-step accumulators.  grid = R, block = 64.
 extern "C" __global__ void __launch_bounds__(64) vgx_tau_choose_kernel(VgxTauArgs a) {
@@ -2373,6 +2617,25 @@ extern "C" __global__ void __launch_bounds__(64) vgx_tau_apply_kernel(VgxTauArgs
     }
 }
 
+// After vgx_tau_apply_kernel: the one-byte copy of every compartment the accepted try's list touched (same grid as the apply kernel;
+// a compartment listed twice is written twice with the same, final, value).
+extern "C" __global__ void __launch_bounds__(64) vgx_tau_sync8_kernel(VgxTauArgs a) {
+    const int rep = blockIdx.y, shard = blockIdx.x;
+    if (!a.deciding[rep] || !(a.accepted[rep] && !a.error[rep])) return;
+    const int P = a.p.P, H = a.p.H;
+    const int64_t PH = (int64_t)P * H;
+    const int64_t scap = a.inc_cap / a.inc_shards;
+    unsigned long long n = a.inc_n[(int64_t)rep * VGX_INC_SHARDS + shard];
+    if ((int64_t)n > scap) n = (unsigned long long)scap;
+    const int64_t *lst = a.inc + (int64_t)rep * a.inc_cap + (int64_t)shard * scap;
+    for (unsigned long long i = (unsigned long long)blockIdx.z * 64 + threadIdx.x; i < n; i += (unsigned long long)gridDim.z * 64) {
+        const int64_t cell = tau_entry_cell(lst[i]);
+        const int32_t v = __hip_atomic_load(&a.I[(int64_t)rep * PH + cell], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        a.I8[(int64_t)rep * PH + cell] = (uint8_t)(v < 255 ? v : 255);
+        if (v >= 255) a.sat8[((int64_t)rep * P + cell / H) * a.nt8 + ((cell % H) >> (2 * VGX_D8_LOW))] = 1;
+    }
+}
+
 // Bounds check of GenerateEvents_tau (pyx:2522-2528) as one dense pass over all compartments: the fallback when the list of
 // vgx_tau_suspect_kernel overflowed, and the validation mode (vgx_run_opts.reserved[1] = 1).  grid = (ceil(H/TB), P, R).
 extern "C" __global__ void __launch_bounds__(TB) vgx_tau_check_kernel(VgxTauArgs a) {
@@ -2568,6 +2831,7 @@ TAU_LAUNCH(tau_eff, dim3((unsigned)a->p.P, (unsigned)a->R), dim3(TB))
 TAU_LAUNCH(tau_prep, dim3((unsigned)a->p.P, (unsigned)a->R), dim3(TB))
 // blocks per (population, replicate) of the drift kernel vgxi_tau_drift launches last (= slots of VgxTauArgs.dS_part in use)
 extern "C" __attribute__((visibility("hidden"))) int vgxi_tau_drift_blocks(const VgxTauArgs *a) {
+    if (a->use8) return a->nt8;
     if (tau_drift_tiled_ok(a->p.sites, a->mut_uniform) && a->mutHi) {
         const int sites = a->p.sites, low = sites < VGX_DRIFT_LOW ? sites : VGX_DRIFT_LOW;
         const int64_t ntiles = a->p.H >> (2 * low);
@@ -2577,7 +2841,28 @@ extern "C" __attribute__((visibility("hidden"))) int vgxi_tau_drift_blocks(const
     const unsigned tiles = (unsigned)((a->p.H + TB - 1) / TB);
     return (int)(tiles < 32u ? tiles : 32u);
 }
+extern "C" __attribute__((visibility("hidden"))) hipError_t vgxi_tau_conv8(const VgxTauArgs *a, hipStream_t s) {
+    hipLaunchKernelGGL(vgx_tau_conv8_kernel, dim3((unsigned)((a->p.H + 4 * TB - 1) / (4 * TB)), (unsigned)a->p.P, (unsigned)a->R), dim3(TB), 0, s, *a);
+    return hipGetLastError();
+}
+TAU_LAUNCH(tau_sync8, dim3((unsigned)a->inc_shards, (unsigned)a->R, (unsigned)(VGX_INC_SHARDS / a->inc_shards)), dim3(64))
 extern "C" __attribute__((visibility("hidden"))) hipError_t vgxi_tau_drift(const VgxTauArgs *a, hipStream_t s) {
+    if (a->use8) {
+        if (a->has_mig) {     // (uniform: the condition of use8)
+            hipLaunchKernelGGL(vgx_tau_colsum8_kernel, dim3((unsigned)((a->p.H + 4 * TB - 1) / (4 * TB)), (unsigned)a->R), dim3(TB), 0, s, *a);
+            hipError_t err = hipGetLastError();
+            if (err != hipSuccess) return err;
+        }
+        const int low = a->p.sites < VGX_D8_LOW ? a->p.sites : VGX_D8_LOW;
+        const size_t lds = (size_t)1 << (2 * low);
+        const void *k = a->p.S == 1 ? (const void *)vgx_tau_drift8_kernel<true> : (const void *)vgx_tau_drift8_kernel<false>;
+        hipError_t err = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (err != hipSuccess) return err;
+        const dim3 grid((unsigned)(8 * ((a->p.P + 7) / 8) * a->nt8), (unsigned)a->R);
+        if (a->p.S == 1) hipLaunchKernelGGL(vgx_tau_drift8_kernel<true>, grid, dim3(D8_TB), lds, s, *a);
+        else hipLaunchKernelGGL(vgx_tau_drift8_kernel<false>, grid, dim3(D8_TB), lds, s, *a);
+        return hipGetLastError();
+    }
     if (a->has_mig && a->mig_uniform) {
         hipLaunchKernelGGL(vgx_tau_colsum_kernel, dim3((unsigned)((a->p.H + 4 * TB - 1) / (4 * TB)), (unsigned)a->R), dim3(TB), 0, s, *a);
         hipError_t err = hipGetLastError();
