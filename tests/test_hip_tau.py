@@ -621,10 +621,9 @@ def _fill_saturated(rng, shape):      # mostly small counts, a few hundred compa
 def test_byte_drift_pass_equals_the_two_pass_form(monkeypatch, sites, P, S, fill, migration):
     """vgx_tau_drift8_kernel (one read of the one-byte counts, neighbour sums inside a 4^8 tile and from the row's other tiles)
     against the two-pass form it replaces (VGX_TAU_NO_BYTE_DRIFT=1: column sums, high-site pass, low-site pass on the 4-byte
-    counts).  Every compartment's drift is formed with the same arithmetic, so the infectious compartments' tau candidates have
-    the same bits; the susceptible compartments' drift is a sum over the blocks' parts, whose partition differs between the two
-    forms: the leap lengths agree to 1e-12 (bit for bit when an infectious compartment sets tau), and — a last-bit difference of
-    tau moves no Poisson draw — the accepted steps, events and states are identical.  Also where bytes are saturated (counts of
+    counts).  The byte form collects the terms of a compartment's drift (fused multiply-adds) and sums the susceptible
+    compartments' drift over another partition of the compartments: the leap lengths agree to 1e-12, and — a last-bit difference
+    of tau moves no Poisson draw — the accepted steps, events and states are identical.  Also where bytes are saturated (counts of
     255 and more: flagged tiles, sums formed again from the 4-byte counts), with the one-byte copy kept in step by the apply pass
     over several leaps."""
     def run(two_pass):
@@ -639,8 +638,6 @@ def test_byte_drift_pass_equals_the_two_pass_form(monkeypatch, sites, P, S, fill
     a, b = run(False), run(True)
     assert a.events.ptr == b.events.ptr == 6
     np.testing.assert_allclose(a.events.times[:6], b.events.times[:6], rtol=1e-12, atol=0)
-    if S == 1 and fill is _fill_small:
-        assert np.array_equal(a.events.times[:6], b.events.times[:6])     # (an infectious compartment sets tau here)
     assert np.array_equal(a.infectious, b.infectious) and np.array_equal(a.susceptible, b.susceptible)
     for k in a.COUNTERS:
         assert getattr(a, k) == getattr(b, k), k

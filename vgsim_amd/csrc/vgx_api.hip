@@ -94,7 +94,7 @@ struct vgx_engine {
         r_evrate, r_evcols, r_locrec, r_loctime, r_lociter, r_farate, r_fakey, r_traj, r_prof, r_qeff, r_qmebm, r_qflag;
     // tau-leaping (dense compartments)
     DevBuf t_I, t_S, t_dChk, t_dApp, t_dSi, t_dTot, t_totInf, t_gI, t_cd, t_lock, t_F, t_eff, t_Aeff, t_Gout, t_dS,
-        t_taubits, t_tau, t_time, t_flags, t_counters, t_cnttry, t_mev, t_mevn, t_mevbase, t_locn, t_mutcum, t_migcdf, t_migIn, t_mutHi, t_colT, t_colTW, t_inc, t_incn, t_sieve, t_sieveskip, t_big, t_bign, t_res, t_susp, t_suspn, t_stkey, t_stval, t_dChkTot, t_q, t_qn, t_hist, t_I8, t_dSpart, t_sat8;
+        t_taubits, t_tau, t_time, t_flags, t_counters, t_cnttry, t_mev, t_mevn, t_mevbase, t_locn, t_mutcum, t_migcdf, t_migIn, t_mutHi, t_colT, t_colTW, t_inc, t_incn, t_sieve, t_sieveskip, t_big, t_bign, t_res, t_susp, t_suspn, t_stkey, t_stval, t_dChkTot, t_q, t_qn, t_hist, t_I8, t_dSpart, t_tmax8;
     std::vector<int64_t> tau_sieve_skipped;   // [R] tries left out by the sieve in the last tau call
     bool last_was_tau = false;
     int64_t tau_mev_cap = 0;
@@ -1314,9 +1314,9 @@ extern "C" int vgx_simulate_tau(vgx_engine *e, int64_t iterations, int64_t sampl
         a.use8 = (flat && same && nh >= 1 && e->C == 1 && S <= 64 && !(nb8 && nb8[0] == '1')) ? 1 : 0;
         a.nt8 = ns > 8 ? 1 << (2 * (ns - 8)) : 1;
         {
-            int rc8 = ensure(e, e->t_sat8, (size_t)(R * P * a.nt8) + 64);
+            int rc8 = ensure(e, e->t_tmax8, (size_t)(R * P * a.nt8) * 4 + 64);
             if (rc8) return rc8;
-            a.sat8 = (uint8_t *)e->t_sat8.p;
+            a.tmax8 = (unsigned int *)e->t_tmax8.p;
         }
         a.hist = nullptr;
         if (flat && a.sieve_on && e->C <= 8) {   // (VGX_HIST_CMAX classes x 64 sizes per population)
@@ -1459,7 +1459,7 @@ extern "C" int vgx_simulate_tau(vgx_engine *e, int64_t iterations, int64_t sampl
         if (tnow != dev_time) { HIPCHECK(e, hipMemcpy(a.time_now, tnow.data(), (size_t)R * 8, hipMemcpyHostToDevice)); dev_time = tnow; }
         HIPCHECK(e, hipEventRecord(e->ev0, e->stream));
         if (a.use8 && i8_dirty) {     // the one-byte counts after an upload / a dense try: one pass over the 4-byte counts
-            HIPCHECK(e, hipMemsetAsync(a.sat8, 0, (size_t)(R * P * a.nt8), e->stream));
+            HIPCHECK(e, hipMemsetAsync(a.tmax8, 0, (size_t)(R * P * a.nt8) * 4, e->stream));
             HIPCHECK(e, vgxi_tau_conv8(&a, e->stream));
             i8_dirty = false;
             launches += 1;

@@ -156,7 +156,7 @@ struct VgxTauArgs {
     int32_t *I;          // [R][P][H] infectious (tau population sizes are < 2^31: 4 bytes per compartment)
     uint8_t *I8;         // [R][P][H] min(infectious, 255): streamed by the scan kernel of a step's tries.  Rewritten by every step's
                          // drift pass, or (use8) kept in step with I by vgx_tau_sync8_kernel / vgx_tau_conv8_kernel and READ by the drift pass
-    uint8_t *sat8;       // [R][P][nt8] a tile of 4^8 haplotypes (the whole row up to 8 sites) may hold a count >= 255 (use8)
+    unsigned int *tmax8; // [R][P][nt8] upper bound of the bytes of a tile of 4^8 haplotypes (the whole row up to 8 sites) (use8)
     int32_t nt8;         // tiles of 4^8 haplotypes per population row: 1, 4 or 16
     int32_t use8;        // the drift pass is vgx_tau_colsum8_kernel + vgx_tau_drift8_kernel on the one-byte counts
     int64_t *S;          // [R][P][S] susceptible

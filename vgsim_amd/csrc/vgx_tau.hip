@@ -877,25 +877,33 @@ __global__ void __launch_bounds__(TB) vgx_tau_drift_fast_kernel(VgxTauArgs a) {
 // other tiles of the same population row) from global memory, where the block-to-XCD mapping keeps them in the L2 of the XCD
 // the row's tiles run on.  No intermediate array, one read of 1 byte per compartment.  Neighbour counts are summed as integers
 // in 16-bit lanes (two compartments per register), separately for the low six and the high sites, and enter the drift with the
-// arithmetic of vgx_tau_drift_fast_kernel: tau has the same bits as with the two-pass form.  A byte of 255 stands for "255 or
-// more": tiles that may hold one are flagged (sat8), their blocks test every byte they add, and a wavefront that meets one
-// forms its compartments' sums again from the 4-byte counts.
+// terms of vgx_tau_drift_fast_kernel collected (tau agrees with the two-pass form's to rounding).  A byte of 255 stands for
+// "255 or more": every tile's largest byte is kept (tmax8: an upper bound between two conversions); blocks whose tiles may hold
+// a 255 test every byte they add, and a wavefront that meets one forms its compartments' sums again from the 4-byte counts.
 #define VGX_D8_LOW 8
 #define D8_TB 512       // two blocks per CU (2 x 77 KB of LDS, 16 wavefronts)
 static __device__ __forceinline__ uint32_t d8_even(uint32_t x) { return __builtin_amdgcn_perm(0u, x, 0x0C020C00u); }   // bytes 0, 2 -> 16-bit lanes
 static __device__ __forceinline__ uint32_t d8_odd(uint32_t x) { return __builtin_amdgcn_perm(0u, x, 0x0C030C01u); }    // bytes 1, 3
 static __device__ __forceinline__ uint32_t d8_sat(uint32_t x) { return ((x & 0x7F7F7F7Fu) + 0x01010101u) & x & 0x80808080u; }   // some byte == 255
 
-// I8 = min(I, 255) and the saturation flags of the tiles, for the whole state.  grid = (ceil(H / (4 TB)), P, R); sat8 zeroed before.
+// I8 = min(I, 255) and the largest byte of every tile, for the whole state.  grid = (ceil(H / (4 TB)), P, R); tmax8 zeroed before.
 extern "C" __global__ void __launch_bounds__(TB) vgx_tau_conv8_kernel(VgxTauArgs a) {
     const int rep = blockIdx.z, pn = blockIdx.y;
     const int P = a.p.P, H = a.p.H;
-    const int h0 = (blockIdx.x * TB + threadIdx.x) * 4;
-    if (h0 >= H) return;
+    const int h0 = (blockIdx.x * TB + threadIdx.x) * 4;      // (H is a multiple of 4 TB from five sites on; this pass: seven and more)
     const int64_t off = ((int64_t)rep * P + pn) * H + h0;
     const int4 v = *(const int4 *)(a.I + off);
     *(uint32_t *)(a.I8 + off) = tau_pack8(v.x, v.y, v.z, v.w);
-    if (v.x >= 255 || v.y >= 255 || v.z >= 255 || v.w >= 255) a.sat8[((int64_t)rep * P + pn) * a.nt8 + (h0 >> (2 * VGX_D8_LOW))] = 1;
+    // the largest byte of the block's 4 TB compartments (they lie inside one tile): one atomic per block
+    __shared__ unsigned int s_m[TB / 64];
+    unsigned int m = (unsigned int)min(max(max(v.x, v.y), max(v.z, v.w)), 255);
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned int)__shfl_down((int)m, o));
+    if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < TB / 64; ++w) m = max(m, s_m[w]);
+        atomicMax(a.tmax8 + ((int64_t)rep * P + pn) * a.nt8 + (h0 >> (2 * VGX_D8_LOW)), m);
+    }
 }
 
 // Column sums over the populations from the one-byte counts (a saturated byte: the 4-byte counts).  grid = (ceil(H / (4 TB)), R).
@@ -933,8 +941,109 @@ extern "C" __global__ void __launch_bounds__(TB) vgx_tau_colsum8_kernel(VgxTauAr
 
 // grid = (8 * ceil(P / 8) * nt8, R): flattened (population, tile) with the tiles of one population on one XCD (workgroups go to
 // the XCDs round-robin in the order of their flattened index); dynamic LDS = 4^min(sites, 8) bytes.
-template <bool S1>
-__global__ void __launch_bounds__(D8_TB) vgx_tau_drift8_kernel(VgxTauArgs a) {
+// The drift of a compartment is linear in its own count Ih, its neighbour counts and the column sums of uniform migration:
+//   drift = kI Ih + rate_lo nlo + rate_hi nhi + B (c1 T + c2 TW),   B = sum_sn b sigma_sn S_sn,
+//   kI = B F - (d + s + m) - B (c1 + c2 wt)
+// (the terms of vgx_tau_drift_fast_kernel collected; fused multiply-adds), and the susceptible compartments' drift is a function
+// of the block's sums of Ih and of c1 T + c2 TW, formed once per thread.  MODE: 0 = no count above 66 in the tile and the tiles it
+// reads, so none of its compartments has its own numerator in ChooseTau either (the three neighbours through a site are added as
+// packed bytes before they are widened; up to 85 would do for that), 1 = no count of 255 or more,
+// 2 = every byte is tested for 255 and a wavefront that meets one forms its sums again from the 4-byte counts.
+struct D8Ctx {
+    const uint32_t *tile32, *row32;
+    const int32_t *Irow;
+    const double *cTP, *cTWP;
+    int tl, low, ntop, TSd, sites;
+    bool use_col, do_hist, one_rate;
+    double kI, rate_lo, rate_hi, Bsum, c1, c2;
+    unsigned int *hist;
+};
+template <int MODE>
+static __device__ __forceinline__ void d8_cells(const D8Ctx &c, int lane, double &cand_min, double &ad_max, long long &sumI, double &sumMg) {
+    for (int q = threadIdx.x; q < c.TSd; q += D8_TB) {
+        const int h = (c.tl << (2 * c.low)) + 4 * q;          // first of the thread's four haplotypes
+        const uint32_t own = c.tile32[q];
+        uint32_t loE = 0, loO = 0, hiE = 0, hiO = 0, bad = MODE == 2 ? d8_sat(own) : 0u;
+        uint32_t hv[6];     // the neighbours through the sites above the tile (other tiles of the row), issued first
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int x = 1; x < 4; ++x) {
+                const int k = g * 3 + x - 1;
+                hv[k] = 0;
+                if (g < c.ntop) hv[k] = c.row32[(int64_t)(c.tl ^ (x << (2 * g))) * c.TSd + q];
+            }
+        double4 cT = {0.0, 0.0, 0.0, 0.0}, cTW = {0.0, 0.0, 0.0, 0.0};
+        if (c.use_col) { cT = *(const double4 *)(c.cTP + h); cTW = *(const double4 *)(c.cTWP + h); }
+        // inside the tile: digit g >= 1 of the cell index = two-bit group g - 1 of the dword index
+#pragma unroll
+        for (int g = 1; g < VGX_D8_LOW; ++g) {
+            if (g < c.low) {
+                const int sh = 2 * g - 2;
+                const uint32_t x1 = c.tile32[q ^ (1 << sh)], x2 = c.tile32[q ^ (2 << sh)], x3 = c.tile32[q ^ (3 << sh)];
+                if (MODE == 2) bad |= d8_sat(x1) | d8_sat(x2) | d8_sat(x3);
+                uint32_t e, o;
+                if (MODE == 0) { const uint32_t t = x1 + x2 + x3; e = d8_even(t); o = d8_odd(t); }
+                else { e = d8_even(x1) + d8_even(x2) + d8_even(x3); o = d8_odd(x1) + d8_odd(x2) + d8_odd(x3); }
+                if (g < VGX_DRIFT_LOW) { loE += e; loO += o; } else { hiE += e; hiO += o; }
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            if (g < c.ntop) {
+                const uint32_t x1 = hv[g * 3], x2 = hv[g * 3 + 1], x3 = hv[g * 3 + 2];
+                if (MODE == 2) bad |= d8_sat(x1) | d8_sat(x2) | d8_sat(x3);
+                if (MODE == 0) { const uint32_t t = x1 + x2 + x3; hiE += d8_even(t); hiO += d8_odd(t); }
+                else { hiE += d8_even(x1) + d8_even(x2) + d8_even(x3); hiO += d8_odd(x1) + d8_odd(x2) + d8_odd(x3); }
+            }
+        }
+        int Iv[4] = {(int)(own & 255u), (int)((own >> 8) & 255u), (int)((own >> 16) & 255u), (int)(own >> 24)};
+        const int s4 = Iv[0] + Iv[1] + Iv[2] + Iv[3];
+        int nlo[4] = {(int)(loE & 0xFFFFu) + s4 - Iv[0], (int)(loO & 0xFFFFu) + s4 - Iv[1], (int)(loE >> 16) + s4 - Iv[2], (int)(loO >> 16) + s4 - Iv[3]};
+        int nhi[4] = {(int)(hiE & 0xFFFFu), (int)(hiO & 0xFFFFu), (int)(hiE >> 16), (int)(hiO >> 16)};
+        if (MODE == 2 && __any(bad != 0u)) {
+            if (bad != 0u) {      // a count of 255 or more among the bytes added: the sums again from the 4-byte counts
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int hh = h + j;
+                    Iv[j] = c.Irow[hh];
+                    int sl = 0, shh = 0;
+                    for (int g = 0; g < c.sites; ++g) {
+                        const int v3 = c.Irow[hh ^ (1 << (2 * g))] + c.Irow[hh ^ (2 << (2 * g))] + c.Irow[hh ^ (3 << (2 * g))];
+                        if (g < VGX_DRIFT_LOW) sl += v3; else shh += v3;
+                    }
+                    nlo[j] = sl; nhi[j] = shh;
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int32_t Icell = Iv[j];
+            const double Ih = (double)Icell;
+            double drift = c.kI * Ih;
+            if (c.one_rate) drift = __builtin_fma(c.rate_lo, (double)(nlo[j] + nhi[j]), drift);
+            else drift = __builtin_fma(c.rate_hi, (double)nhi[j], __builtin_fma(c.rate_lo, (double)nlo[j], drift));
+            if (c.use_col) {
+                const double T = j == 0 ? cT.x : j == 1 ? cT.y : j == 2 ? cT.z : cT.w, TW = j == 0 ? cTW.x : j == 1 ? cTW.y : j == 2 ? cTW.z : cTW.w;
+                const double mgT = __builtin_fma(c.c2, TW, c.c1 * T);
+                drift = __builtin_fma(c.Bsum, mgT, drift);
+                sumMg += mgT;
+            }
+            sumI += Icell;
+            // pyx:2440-2444: candidate max(eps * X / 2, 1) / |drift| with eps * X in single precision; the numerator is 1 up to 66
+            // hosts ((double)(0.03f * (float)X) / 2 > 1 from X = 67 on), and the smallest of those candidates is 1 / (largest |drift|)
+            const double ad = fabs(drift);
+            const bool large = Icell > 66;
+            ad_max = fmax(ad_max, large ? 0.0 : ad);          // (|drift| < 1e-8 is sorted out at the end)
+            if (MODE != 0 && __any(large && ad >= 1e-8)) {
+                if (large && ad >= 1e-8) cand_min = fmin(cand_min, ((double)(0.03f * (float)Icell) / 2.0) / ad);
+            }
+            if (c.do_hist && Icell >= 1 && Icell <= VGX_HIST_X) atomicAdd(&c.hist[(Icell - 1) * 16 + (lane & 15)], 1u);
+        }
+    }
+}
+
+extern "C" __global__ void __launch_bounds__(D8_TB) vgx_tau_drift8_kernel(VgxTauArgs a) {
     const VgxDevParams &p = a.p;
     const int P = p.P, S = p.S, H = p.H, sites = p.sites;
     const int nt = a.nt8;
@@ -948,24 +1057,23 @@ __global__ void __launch_bounds__(D8_TB) vgx_tau_drift8_kernel(VgxTauArgs a) {
     const int TSd = 1 << (2 * low - 2);                                              // dwords of a tile
     const int64_t rowoff = ((int64_t)rep * P + pn) * H;
     const uint32_t *row32 = (const uint32_t *)(a.I8 + rowoff);
-    const int32_t *Irow = a.I + rowoff;
     const int64_t *Sus = a.S + (int64_t)rep * P * S + (int64_t)pn * S;
     extern __shared__ __attribute__((aligned(16))) unsigned char d8sm[];
     uint32_t *tile32 = (uint32_t *)d8sm;
-    __shared__ double sdS[D8_TB / 64][64];
+    __shared__ double s_sum[D8_TB / 64][2];
     __shared__ unsigned long long smin;
     __shared__ double l_base[64];
     __shared__ unsigned int hist[VGX_HIST_X * 16];
     __shared__ double s_wu[16];
-    __shared__ int s_careful;
+    __shared__ unsigned int s_mx;
     const bool do_hist = a.hist != nullptr;
-    sdS[wv][lane] = 0.0;
     if (threadIdx.x == 0) {
         smin = (unsigned long long)__double_as_longlong(1.0);
-        int c = a.sat8[((int64_t)rep * P + pn) * nt + tl];
+        const unsigned int *tm = a.tmax8 + ((int64_t)rep * P + pn) * nt;
+        unsigned int c = tm[tl];
         for (int g = 0; g < ntop; ++g)
-            for (int x = 1; x < 4; ++x) c |= a.sat8[((int64_t)rep * P + pn) * nt + (tl ^ (x << (2 * g)))];
-        s_careful = c;
+            for (int x = 1; x < 4; ++x) c = max(c, tm[tl ^ (x << (2 * g))]);
+        s_mx = c;
     }
     if (do_hist)
         for (int i = threadIdx.x; i < VGX_HIST_X * 16; i += D8_TB) hist[i] = 0;
@@ -976,119 +1084,38 @@ __global__ void __launch_bounds__(D8_TB) vgx_tau_drift8_kernel(VgxTauArgs a) {
         for (int i = threadIdx.x * 4; i < TSd; i += D8_TB * 4) *(uint4 *)(tile32 + i) = *(const uint4 *)(src + i);
     }
     __syncthreads();
-    const bool careful = s_careful != 0;
+    const unsigned int mx = s_mx;
     const double F = a.F[(int64_t)rep * P + pn];
     const bool use_col = a.has_mig && a.mig_uniform;
     MigU mu = {0.0, 0.0, 0.0};
     if (use_col) mu = tau_migu_setup(a, rep, pn, s_wu);
-    const double cd0 = p.c_d[0], cs0 = p.c_s[0] * p.sampMult[pn], ctm0 = p.c_tm[0], base0 = l_base[0];
+    double Bsum = 0.0;
+    for (int sn = 0; sn < S; ++sn) Bsum += l_base[sn];
+    const double cd0 = p.c_d[0], cs0 = p.c_s[0] * p.sampMult[pn], ctm0 = p.c_tm[0];
     const int st0 = p.c_stype[0];
-    // sites of the tile: digit g of the cell index, g = 0 .. low-1 (g = 0: the four bytes of a dword); the LOW six sites of the
-    // model (VGX_DRIFT_LOW: the rate a.mutp[nh + .]) are digits 0..5, the high ones digits 6.. and the tiles above
-    const int nh6 = sites - VGX_DRIFT_LOW;
-    const double rate_lo = a.mutp[nh6][0], rate_hi = a.mutHi_rate;
-    const double *cTP = a.colT + (int64_t)rep * H, *cTWP = a.colTW + (int64_t)rep * H;
-    double cand_min = 1.0, ad_max = 0.0;
-    double redS[4] = {0.0, 0.0, 0.0, 0.0};
-    for (int q = threadIdx.x; q < TSd; q += D8_TB) {
-        const int h = (tl << (2 * low)) + 4 * q;          // first of the thread's four haplotypes
-        const uint32_t own = tile32[q];
-        uint32_t loE = 0, loO = 0, hiE = 0, hiO = 0, bad = careful ? d8_sat(own) : 0u;
-        // halo: the neighbours through the sites above the tile (other tiles of the row), issued first
-        uint32_t hv[6];
-#pragma unroll
-        for (int g = 0; g < 2; ++g)
-#pragma unroll
-            for (int x = 1; x < 4; ++x) {
-                const int k = g * 3 + x - 1;
-                hv[k] = 0;
-                if (g < ntop) hv[k] = row32[(int64_t)(tl ^ (x << (2 * g))) * TSd + q];
-            }
-        double4 cT = {0.0, 0.0, 0.0, 0.0}, cTW = {0.0, 0.0, 0.0, 0.0};
-        if (use_col) { cT = *(const double4 *)(cTP + h); cTW = *(const double4 *)(cTWP + h); }
-        // inside the tile: digit g >= 1 of the cell index = two-bit group g - 1 of the dword index
-#pragma unroll
-        for (int g = 1; g < VGX_D8_LOW; ++g) {
-            if (g < low) {
-                const int sh = 2 * g - 2;
-                const uint32_t x1 = tile32[q ^ (1 << sh)], x2 = tile32[q ^ (2 << sh)], x3 = tile32[q ^ (3 << sh)];
-                if (careful) bad |= d8_sat(x1) | d8_sat(x2) | d8_sat(x3);
-                if (g < VGX_DRIFT_LOW) { loE += d8_even(x1) + d8_even(x2) + d8_even(x3); loO += d8_odd(x1) + d8_odd(x2) + d8_odd(x3); }
-                else { hiE += d8_even(x1) + d8_even(x2) + d8_even(x3); hiO += d8_odd(x1) + d8_odd(x2) + d8_odd(x3); }
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < 6; ++k) {
-            if (k < 3 * ntop) {
-                if (careful) bad |= d8_sat(hv[k]);
-                hiE += d8_even(hv[k]); hiO += d8_odd(hv[k]);
-            }
-        }
-        int Iv[4] = {(int)(own & 255u), (int)((own >> 8) & 255u), (int)((own >> 16) & 255u), (int)(own >> 24)};
-        const int s4 = Iv[0] + Iv[1] + Iv[2] + Iv[3];
-        int nlo[4] = {(int)(loE & 0xFFFFu) + s4 - Iv[0], (int)(loO & 0xFFFFu) + s4 - Iv[1], (int)(loE >> 16) + s4 - Iv[2], (int)(loO >> 16) + s4 - Iv[3]};
-        int nhi[4] = {(int)(hiE & 0xFFFFu), (int)(hiO & 0xFFFFu), (int)(hiE >> 16), (int)(hiO >> 16)};
-        if (sites <= VGX_DRIFT_LOW) { /* (not reached: the launcher takes this kernel from seven sites on) */ }
-        if (careful && __any(bad != 0u)) {
-            if (bad != 0u) {      // a count of 255 or more among the bytes added: the sums again from the 4-byte counts
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int hh = h + j;
-                    Iv[j] = Irow[hh];
-                    int sl = 0, shh = 0;
-                    for (int g = 0; g < sites; ++g) {
-                        const int v3 = Irow[hh ^ (1 << (2 * g))] + Irow[hh ^ (2 << (2 * g))] + Irow[hh ^ (3 << (2 * g))];
-                        if (g < VGX_DRIFT_LOW) sl += v3; else shh += v3;
-                    }
-                    nlo[j] = sl; nhi[j] = shh;
-                }
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int32_t Icell = Iv[j];
-            const double Ih = (double)Icell;
-            const double mlow = rate_lo * (double)nlo[j];
-            const double mh = rate_hi * (double)nhi[j];
-            double mg = 0.0;
-            if (use_col) mg = tau_migu(mu, j == 0 ? cT.x : j == 1 ? cT.y : j == 2 ? cT.z : cT.w, j == 0 ? cTW.x : j == 1 ? cTW.y : j == 2 ? cTW.z : cTW.w, Ih);
-            double drift = 0.0;
-            const double rec = cd0 * Ih;
-            const double samp = cs0 * Ih;
-            drift -= rec;
-            drift -= samp;
-            drift -= ctm0 * Ih;
-            drift += mlow;
-            drift += mh;
-            const double to_st = rec + samp;
-            if (S1) {
-                const double v = base0 * Ih * F + base0 * mg;
-                drift += v;
-                redS[0] += to_st - v;
-            } else {
-                for (int sn = 0; sn < S; ++sn) {
-                    const double base = l_base[sn];
-                    const double v = base * Ih * F + base * mg;
-                    drift += v;
-                    const double red = -v + (st0 == sn ? to_st : 0.0);
-                    if (sn < 4) redS[sn] += red;
-                    else if (red != 0.0) atomicAdd(&sdS[0][sn], red);
-                }
-            }
-            const double ad = fabs(drift);
-            const double v = (double)(0.03f * (float)Icell) / 2.0;      // pyx:2440-2444 (see vgx_tau_drift_fast_kernel)
-            const bool large = v > 1.0;
-            ad_max = fmax(ad_max, large ? 0.0 : ad);
-            if (__any(large && ad >= 1e-8)) {
-                if (large && ad >= 1e-8) cand_min = fmin(cand_min, v / ad);
-            }
-            if (do_hist && Icell >= 1 && Icell <= VGX_HIST_X) atomicAdd(&hist[(Icell - 1) * 16 + (lane & 15)], 1u);
-        }
-    }
-    for (int sn = 0; sn < 4 && sn < S; ++sn) {
-        double red = redS[sn];
-        for (int o = 32; o > 0; o >>= 1) red += __shfl_down(red, o);
-        if (lane == 0) sdS[wv][sn] += red;
+    D8Ctx c;
+    c.tile32 = tile32; c.row32 = row32; c.Irow = a.I + rowoff;
+    c.cTP = a.colT + (int64_t)rep * H; c.cTWP = a.colTW + (int64_t)rep * H;
+    c.tl = tl; c.low = low; c.ntop = ntop; c.TSd = TSd; c.sites = sites;
+    c.use_col = use_col; c.do_hist = do_hist;
+    // the LOW six sites of the model (VGX_DRIFT_LOW: the rate a.mutp[nh + .]) are digits 0..5 of the cell index, the high ones
+    // digits 6.. and the tiles above
+    c.rate_lo = a.mutp[sites - VGX_DRIFT_LOW][0]; c.rate_hi = a.mutHi_rate;
+    c.one_rate = c.rate_lo == c.rate_hi;
+    c.Bsum = Bsum; c.c1 = mu.c1; c.c2 = mu.c2;
+    const double kmig = mu.c1 + mu.c2 * mu.wt;         // mg = (c1 T + c2 TW) - kmig Ih
+    c.kI = Bsum * F - (cd0 + cs0 + ctm0) - Bsum * kmig;
+    c.hist = hist;
+    double cand_min = 1.0, ad_max = 0.0, sumMg = 0.0;
+    long long sumI = 0;
+    if (mx <= 66u) d8_cells<0>(c, lane, cand_min, ad_max, sumI, sumMg);
+    else if (mx < 255u) d8_cells<1>(c, lane, cand_min, ad_max, sumI, sumMg);
+    else d8_cells<2>(c, lane, cand_min, ad_max, sumI, sumMg);
+    // the block's sums of Ih and of c1 T + c2 TW (wavefronts in a fixed order: reproducible), from which the susceptible drift
+    {
+        double vI = (double)sumI, vM = sumMg;
+        for (int o = 32; o > 0; o >>= 1) { vI += __shfl_down(vI, o); vM += __shfl_down(vM, o); }
+        if (lane == 0) { s_sum[wv][0] = vI; s_sum[wv][1] = vM; }
     }
     if (ad_max >= 1e-8 && 1.0 / ad_max < cand_min) cand_min = 1.0 / ad_max;
     for (int o = 32; o > 0; o >>= 1) {
@@ -1098,9 +1125,15 @@ __global__ void __launch_bounds__(D8_TB) vgx_tau_drift8_kernel(VgxTauArgs a) {
     if (lane == 0) atomic_min_pos_double(&smin, cand_min);
     __syncthreads();
     if (threadIdx.x < S) {
-        double v = 0.0;
-        for (int w = 0; w < D8_TB / 64; ++w) v += sdS[w][threadIdx.x];
-        a.dS_part[(((int64_t)rep * P + pn) * a.ds_nb + tl) * S + threadIdx.x] = v;
+        // susceptible drift of (pn, sn) from this block's compartments: -base_sn (F Ih + mg) summed, plus the recoveries and
+        // samplings into the class's group (pyx:2384-2394)
+        double tI = 0.0, tM = 0.0;
+        for (int w = 0; w < D8_TB / 64; ++w) { tI += s_sum[w][0]; tM += s_sum[w][1]; }
+        const int sn = threadIdx.x;
+        const double mgsum = tM - kmig * tI;
+        double v = -l_base[sn] * (F * tI + mgsum);
+        if (sn == st0) v += (cd0 + cs0) * tI;
+        a.dS_part[(((int64_t)rep * P + pn) * a.ds_nb + tl) * S + sn] = v;
     }
     if (threadIdx.x == 0) atomicMin(&a.tau_bits[rep], smin);
     if (do_hist)
@@ -1209,8 +1242,8 @@ extern "C" __global__ void __launch_bounds__(TB) vgx_tau_sieve_kernel(VgxTauArgs
             const float mu0 = s_dec[c] * Xf * tau0;
             if (!(mu0 > 0.f)) continue;
             const float m = fmaxf(0.0151f * Xf, 1.0f);
-            const float A = -m + n * (__logf(mu0) - 1e-6f) - s_lf[X + 1];
-            const float B = (s_all[c] * Xf * tau0 + mu0);
+            const float A = n * (__logf(mu0) - 1e-6f) - s_lf[X + 1];
+            const float B = (s_all[c] * Xf * tau0 + mu0) + m;      // (the arrivals' bound |drift| tau <= m halves with tau like the rest)
             const float nl2 = n * 0.69314724f;   // ln 2 rounded up
             float sc = 1.0f, Ak = A;
 #pragma unroll
@@ -1261,8 +1294,8 @@ extern "C" __global__ void __launch_bounds__(64) vgx_tau_sieve_hist_kernel(VgxTa
         const double mu0 = dec * Xd * tau0;
         if (!(mu0 > 0.0)) continue;
         const double m = fmax(0.0151 * Xd, 1.0);
-        double Ak = -m + n * log(mu0) - lgamma(n + 1.0);
-        const double B = all * Xd * tau0 + mu0;
+        double Ak = n * log(mu0) - lgamma(n + 1.0);
+        const double B = all * Xd * tau0 + mu0 + m;     // (the arrivals' bound |drift| tau <= m halves with tau like the rest)
         const double nl2 = n * 0.6931471805599454;   // ln 2 rounded up
         double sc = 1.0;
 #pragma unroll
@@ -2632,7 +2665,9 @@ extern "C" __global__ void __launch_bounds__(64) vgx_tau_sync8_kernel(VgxTauArgs
         const int64_t cell = tau_entry_cell(lst[i]);
         const int32_t v = __hip_atomic_load(&a.I[(int64_t)rep * PH + cell], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         a.I8[(int64_t)rep * PH + cell] = (uint8_t)(v < 255 ? v : 255);
-        if (v >= 255) a.sat8[((int64_t)rep * P + cell / H) * a.nt8 + ((cell % H) >> (2 * VGX_D8_LOW))] = 1;
+        unsigned int *tm = a.tmax8 + ((int64_t)rep * P + cell / H) * a.nt8 + ((cell % H) >> (2 * VGX_D8_LOW));
+        const unsigned int b = (unsigned int)(v < 255 ? v : 255);
+        if (b > *tm) atomicMax(tm, b);     // (never lowered between two conversions: an upper bound is all the drift pass needs)
     }
 }
 
@@ -2855,12 +2890,10 @@ extern "C" __attribute__((visibility("hidden"))) hipError_t vgxi_tau_drift(const
         }
         const int low = a->p.sites < VGX_D8_LOW ? a->p.sites : VGX_D8_LOW;
         const size_t lds = (size_t)1 << (2 * low);
-        const void *k = a->p.S == 1 ? (const void *)vgx_tau_drift8_kernel<true> : (const void *)vgx_tau_drift8_kernel<false>;
-        hipError_t err = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t err = hipFuncSetAttribute((const void *)vgx_tau_drift8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (err != hipSuccess) return err;
         const dim3 grid((unsigned)(8 * ((a->p.P + 7) / 8) * a->nt8), (unsigned)a->R);
-        if (a->p.S == 1) hipLaunchKernelGGL(vgx_tau_drift8_kernel<true>, grid, dim3(D8_TB), lds, s, *a);
-        else hipLaunchKernelGGL(vgx_tau_drift8_kernel<false>, grid, dim3(D8_TB), lds, s, *a);
+        hipLaunchKernelGGL(vgx_tau_drift8_kernel, grid, dim3(D8_TB), lds, s, *a);
         return hipGetLastError();
     }
     if (a->has_mig && a->mig_uniform) {
