@@ -279,13 +279,20 @@ extern "C" __global__ void __launch_bounds__(MIGIN_TB) vgx_tau_migin_kernel(cons
 // with the two column sums T = sum_s I[s][h], TW = sum_s w[s] I[s][h]: O(P H) work and no [P][H] f64 array, instead of
 // the [P x P] x [P x H] product of vgx_tau_migin_kernel.
 #define VGX_MIGU_PMAX 1024
-struct MigU { double c1, c2, wt; };
+struct MigU { double c1, c2, wt; bool weq; };   // weq: one common weight cd / actualSizes for all populations
 // block-uniform (all threads of the block call it); s_part: 16 doubles of shared scratch; ends with a barrier
 static __device__ __forceinline__ MigU tau_migu_setup(const VgxTauArgs &a, int rep, int pn, double *s_part) {
     const VgxDevParams &p = a.p;
     const int P = p.P;
     double part = 0.0;
-    for (int q = threadIdx.x; q < P; q += blockDim.x) part += a.cd[(int64_t)rep * P + q] / p.actualSizes[q];
+    const double w0 = a.cd[(int64_t)rep * P] / p.actualSizes[0];
+    int ne = 0;
+    for (int q = threadIdx.x; q < P; q += blockDim.x) {
+        const double w = a.cd[(int64_t)rep * P + q] / p.actualSizes[q];
+        part += w;
+        ne |= w != w0;
+    }
+    ne = __syncthreads_or(ne);
     for (int o = 32; o > 0; o >>= 1) part += __shfl_down(part, o);
     if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = part;
     __syncthreads();
@@ -296,6 +303,7 @@ static __device__ __forceinline__ MigU tau_migu_setup(const VgxTauArgs &a, int r
     u.wt = a.cd[(int64_t)rep * P + pn] / p.actualSizes[pn];
     u.c1 = d * (b * b * W + g * u.wt);
     u.c2 = d * g;
+    u.weq = ne == 0;
     __syncthreads();
     return u;
 }
@@ -362,7 +370,7 @@ extern "C" __global__ void __launch_bounds__(TB) vgx_tau_drift_kernel(VgxTauArgs
     __syncthreads();
     const double F = a.F[(int64_t)rep * P + pn];
     __shared__ double s_wu[16];
-    MigU mu = {0.0, 0.0, 0.0};
+    MigU mu = {0.0, 0.0, 0.0, true};
     if (a.has_mig && a.mig_uniform) mu = tau_migu_setup(a, rep, pn, s_wu);
     double cand_min = 1.0;
     for (int hn = blockIdx.x * TB + threadIdx.x; hn - (int)threadIdx.x < H; hn += gridDim.x * TB) {
@@ -563,7 +571,7 @@ extern "C" __global__ void __launch_bounds__(TB) vgx_tau_drift_tiled_kernel(VgxT
     __syncthreads();
     const double F = a.F[(int64_t)rep * P + pn];
     __shared__ double s_wu[16];
-    MigU mu = {0.0, 0.0, 0.0};
+    MigU mu = {0.0, 0.0, 0.0, true};
     if (a.has_mig && a.mig_uniform) mu = tau_migu_setup(a, rep, pn, s_wu);
     double cand_min = 1.0;
     // a thread takes four consecutive compartments at a time (32-byte loads of the two f64 inputs); its contributions to
@@ -718,7 +726,7 @@ __global__ void __launch_bounds__(TB) vgx_tau_drift_fast_kernel(VgxTauArgs a) {
     __syncthreads();
     const double F = a.F[(int64_t)rep * P + pn];
     __shared__ double s_wu[16];
-    MigU mu = {0.0, 0.0, 0.0};
+    MigU mu = {0.0, 0.0, 0.0, true};
     if (a.has_mig && a.mig_uniform) mu = tau_migu_setup(a, rep, pn, s_wu);
     const double cd0 = l_cd[0], cs0 = l_cs[0], ctm0 = l_ctm[0], base0 = l_base[0];   // (C1: the class's constants)
     const int cb0 = l_bidx[0], st0 = l_stype[0];
@@ -881,7 +889,7 @@ __global__ void __launch_bounds__(TB) vgx_tau_drift_fast_kernel(VgxTauArgs a) {
 // "255 or more": every tile's largest byte is kept (tmax8: an upper bound between two conversions); blocks whose tiles may hold
 // a 255 test every byte they add, and a wavefront that meets one forms its compartments' sums again from the 4-byte counts.
 #define VGX_D8_LOW 8
-#define D8_TB 512       // two blocks per CU (2 x 77 KB of LDS, 16 wavefronts)
+#define D8_TB 512       // two blocks per CU (2 x 77 KB of LDS, 16 wavefronts); one block of 1024 threads: 1.8 instead of 2.4 GB fetched per launch, but 0.64 instead of 0.50 ms (a block's load phase is not covered by another block's compute phase)
 static __device__ __forceinline__ uint32_t d8_even(uint32_t x) { return __builtin_amdgcn_perm(0u, x, 0x0C020C00u); }   // bytes 0, 2 -> 16-bit lanes
 static __device__ __forceinline__ uint32_t d8_odd(uint32_t x) { return __builtin_amdgcn_perm(0u, x, 0x0C030C01u); }    // bytes 1, 3
 static __device__ __forceinline__ uint32_t d8_sat(uint32_t x) { return ((x & 0x7F7F7F7Fu) + 0x01010101u) & x & 0x80808080u; }   // some byte == 255
@@ -913,8 +921,14 @@ extern "C" __global__ void __launch_bounds__(TB) vgx_tau_colsum8_kernel(VgxTauAr
     const VgxDevParams &p = a.p;
     const int P = p.P, H = p.H;
     __shared__ double s_w[VGX_MIGU_PMAX];
+    __shared__ int s_neq;
+    if (threadIdx.x == 0) s_neq = 0;
     for (int q = threadIdx.x; q < P; q += TB) s_w[q] = a.cd[(int64_t)rep * P + q] / p.actualSizes[q];
     __syncthreads();
+    for (int q = threadIdx.x; q < P; q += TB)
+        if (s_w[q] != s_w[0]) s_neq = 1;
+    __syncthreads();
+    const bool weq = s_neq == 0;      // one common weight w: TW = w T, formed by the drift pass (no second array to stream)
     const int h0 = (blockIdx.x * TB + threadIdx.x) * 4;
     if (h0 >= H) return;
     const uint8_t *I8 = a.I8 + (int64_t)rep * P * H;
@@ -936,7 +950,9 @@ extern "C" __global__ void __launch_bounds__(TB) vgx_tau_colsum8_kernel(VgxTauAr
             for (int j = 0; j < 4; ++j) { t[j] += x[j]; tw[j] += w * (double)x[j]; }
         }
     }
-    for (int j = 0; j < 4; ++j) { a.colT[(int64_t)rep * H + h0 + j] = (double)t[j]; a.colTW[(int64_t)rep * H + h0 + j] = tw[j]; }
+    for (int j = 0; j < 4; ++j) a.colT[(int64_t)rep * H + h0 + j] = (double)t[j];
+    if (!weq)
+        for (int j = 0; j < 4; ++j) a.colTW[(int64_t)rep * H + h0 + j] = tw[j];
 }
 
 // grid = (8 * ceil(P / 8) * nt8, R): flattened (population, tile) with the tiles of one population on one XCD (workgroups go to
@@ -954,7 +970,7 @@ struct D8Ctx {
     const int32_t *Irow;
     const double *cTP, *cTWP;
     int tl, low, ntop, TSd, sites;
-    bool use_col, do_hist, one_rate;
+    bool use_col, use_tw, do_hist, one_rate;
     double kI, rate_lo, rate_hi, Bsum, c1, c2;
     unsigned int *hist;
 };
@@ -974,7 +990,8 @@ static __device__ __forceinline__ void d8_cells(const D8Ctx &c, int lane, double
                 if (g < c.ntop) hv[k] = c.row32[(int64_t)(c.tl ^ (x << (2 * g))) * c.TSd + q];
             }
         double4 cT = {0.0, 0.0, 0.0, 0.0}, cTW = {0.0, 0.0, 0.0, 0.0};
-        if (c.use_col) { cT = *(const double4 *)(c.cTP + h); cTW = *(const double4 *)(c.cTWP + h); }
+        if (c.use_col) cT = *(const double4 *)(c.cTP + h);
+        if (c.use_tw) cTW = *(const double4 *)(c.cTWP + h);
         // inside the tile: digit g >= 1 of the cell index = two-bit group g - 1 of the dword index
 #pragma unroll
         for (int g = 1; g < VGX_D8_LOW; ++g) {
@@ -1025,7 +1042,7 @@ static __device__ __forceinline__ void d8_cells(const D8Ctx &c, int lane, double
             else drift = __builtin_fma(c.rate_hi, (double)nhi[j], __builtin_fma(c.rate_lo, (double)nlo[j], drift));
             if (c.use_col) {
                 const double T = j == 0 ? cT.x : j == 1 ? cT.y : j == 2 ? cT.z : cT.w, TW = j == 0 ? cTW.x : j == 1 ? cTW.y : j == 2 ? cTW.z : cTW.w;
-                const double mgT = __builtin_fma(c.c2, TW, c.c1 * T);
+                const double mgT = c.use_tw ? __builtin_fma(c.c2, TW, c.c1 * T) : c.c1 * T;     // (one common weight: c1 holds c1 + c2 w)
                 drift = __builtin_fma(c.Bsum, mgT, drift);
                 sumMg += mgT;
             }
@@ -1087,7 +1104,7 @@ extern "C" __global__ void __launch_bounds__(D8_TB) vgx_tau_drift8_kernel(VgxTau
     const unsigned int mx = s_mx;
     const double F = a.F[(int64_t)rep * P + pn];
     const bool use_col = a.has_mig && a.mig_uniform;
-    MigU mu = {0.0, 0.0, 0.0};
+    MigU mu = {0.0, 0.0, 0.0, true};
     if (use_col) mu = tau_migu_setup(a, rep, pn, s_wu);
     double Bsum = 0.0;
     for (int sn = 0; sn < S; ++sn) Bsum += l_base[sn];
@@ -1098,11 +1115,13 @@ extern "C" __global__ void __launch_bounds__(D8_TB) vgx_tau_drift8_kernel(VgxTau
     c.cTP = a.colT + (int64_t)rep * H; c.cTWP = a.colTW + (int64_t)rep * H;
     c.tl = tl; c.low = low; c.ntop = ntop; c.TSd = TSd; c.sites = sites;
     c.use_col = use_col; c.do_hist = do_hist;
+    // one common weight w = cd / actualSizes for all populations (the usual case): TW = w T, no second array
+    c.use_tw = use_col && !mu.weq;
     // the LOW six sites of the model (VGX_DRIFT_LOW: the rate a.mutp[nh + .]) are digits 0..5 of the cell index, the high ones
     // digits 6.. and the tiles above
     c.rate_lo = a.mutp[sites - VGX_DRIFT_LOW][0]; c.rate_hi = a.mutHi_rate;
     c.one_rate = c.rate_lo == c.rate_hi;
-    c.Bsum = Bsum; c.c1 = mu.c1; c.c2 = mu.c2;
+    c.Bsum = Bsum; c.c1 = c.use_tw ? mu.c1 : mu.c1 + mu.c2 * mu.wt; c.c2 = mu.c2;
     const double kmig = mu.c1 + mu.c2 * mu.wt;         // mg = (c1 T + c2 TW) - kmig Ih
     c.kI = Bsum * F - (cd0 + cs0 + ctm0) - Bsum * kmig;
     c.hist = hist;
