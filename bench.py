@@ -540,6 +540,37 @@ def config5_leg(device, world=1, rank=0, events=100000, traj_points=1001):
     return o
 
 
+def tau_small_leg(device):
+    """Tau-leaping on SMALL models (the regime users run for large epidemics with few haplotypes): the on-device step loop of
+    vgx_taus.hip — one workgroup per replicate, no host round trip per step.  Steps per second of one trajectory, and of an ensemble."""
+    import numpy as np
+    from vgsim_amd import Simulator
+    from vgsim_amd.ensemble import Ensemble
+    out = {"workload": "tau-leaping, small models after a 2000-event direct warm-up: b=2.5 d=0.9 s=0.1 m=0.05/site, total migration 0.002; "
+                       "1000 steps per replicate, device time"}
+    for name, sites, pops, size, reps in (("16x3", 2, 3, 10 ** 6, 2048), ("256x5", 4, 5, 10 ** 6, 512)):
+        with contextlib.redirect_stdout(io.StringIO()):
+            s = Simulator(number_of_sites=sites, populations_number=pops, seed=7)
+        s.set_transmission_rate(2.5); s.set_recovery_rate(0.9); s.set_sampling_rate(0.1); s.set_mutation_rate(0.05)
+        s.set_total_migration_probability(0.002); s.set_population_size(size)
+        with contextlib.redirect_stdout(io.StringIO()):
+            s.simulate(2000, sample_size=10 ** 12)
+        cell = {}
+        for key, R in (("single", 1), ("ensemble", reps)):
+            ens = Ensemble(s, R, device=device)
+            res = None
+            for it in range(2):
+                # (a replicate can run into upstream's own dead end — a compartment left below zero because the bounds check books
+                # migrants on their source, pyx:2473 — which this engine reports as an error after 200 halvings; DESIGN.md 4.3)
+                res = ens.simulate_tau(1000, sample_size=10 ** 15, seeds=7 + it * R + np.arange(R, dtype=np.int64))
+            steps = float(res.loop_iterations.sum())
+            cell[key] = {"replicates": R, "steps_per_s": steps / (res.kernel_ms * 1e-3), "events_per_s": float(res.events_drawn.sum()) / (res.kernel_ms * 1e-3),
+                         "kernel_ms": res.kernel_ms}
+            ens.close()
+        out[name] = cell
+    return out
+
+
 class BenchLoop:
     """The timed loop of one rank: `step(i)` runs one batch of replicates and hands that step's summary trajectories
     to an asynchronous gather to rank 0 (it overlaps the next step's kernel), `drain()` waits for the last gather, `reduce(elapsed, events)` gives the whole job's MAX time and SUM of events.  The engine is
@@ -625,7 +656,7 @@ def main():
     ap.add_argument("--no-tau", action="store_true", help="skip the tau-leap (config 4) leg")
     ap.add_argument("--no-extra", action="store_true", help="skip the FAST-mode, spread-occupancy and config-2 legs")
     ap.add_argument("--only", default="", help="development/profiling: run only this extra leg (fast_mode, spread_occupancy, "
-                                               "spread_occupancy_fast, config2, genealogy, single_trajectory, direct_config4_shape, table3, propensity_scan, tau_leap) and print its JSON")
+                                               "spread_occupancy_fast, config2, genealogy, single_trajectory, direct_config4_shape, table3, tau_small, config5, propensity_scan, tau_leap) and print its JSON")
     ap.add_argument("--table3-cells", default="", help="profiling: restrict the table3 leg to these cells, e.g. 10:0.001,100:0.1")
     a = ap.parse_args()
     cells3 = {(int(c.split(":")[0]), float(c.split(":")[1])) for c in a.table3_cells.split(",") if c} or None
@@ -663,7 +694,7 @@ def main():
                   ("spread_occupancy_fast", lambda d: spread_leg(d, "fast", replicates=4096)),
                   ("config2", c2_leg), ("genealogy", genealogy_leg), ("single_trajectory", single_leg),
                   ("direct_config4_shape", c4_direct_leg), ("table3", lambda d: table3_leg(d, cpu=not a.no_cpu_baseline, cells=cells3)),
-                  ("propensity_scan", rowscan_leg), ("tau_leap", tau_leg))
+                  ("tau_small", tau_small_leg), ("propensity_scan", rowscan_leg), ("tau_leap", tau_leg))
     if a.only:
         legs = dict(extra_legs)
         legs["config5"] = lambda d: config5_leg(d, world=world, rank=rank)

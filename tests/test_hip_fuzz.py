@@ -136,12 +136,13 @@ def test_random_model_tau_invariants(seed):
 
 
 @pytest.mark.parametrize("seed", list(range(int(__import__("os").environ.get("VGX_FUZZ_SEEDS", "40")))))
-def test_random_model_tau_modes_agree(seed):
-    """The three ways a try of the halving loop can keep and check its deltas (vgx_run_opts.reserved[1]: list of moves /
+def test_random_model_tau_modes_agree(seed, monkeypatch):
+    """(Step kernels of vgx_tau.hip, forced for these small models: VGX_TAU_STEP_KERNELS=1.)  The three ways a try of the halving loop can keep and check its deltas (vgx_run_opts.reserved[1]: list of moves /
     dense arrays with fused checks / dense arrays and a dense bounds check) make the same draws and the same decisions:
     bit for bit the same state, counters and multievent rows on every random model (shapes with rows shorter than a wave
     tile, several rate classes, several susceptibility groups, migration, lockdowns)."""
     from vgsim_amd import _capi
+    monkeypatch.setenv("VGX_TAU_STEP_KERNELS", "1")
     out = []
     for mode in (0, 2, 1):
         sim, n = build(seed)

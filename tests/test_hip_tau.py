@@ -54,13 +54,22 @@ def test_first_leap_length_matches_oracle(oracle_mod, name):
     assert hip.events.types[nd] == 6 and ref.events.types[nd] == 6
     dt_hip = hip.events.times[nd] - hip.events.times[nd - 1]
     dt_ref = ref.events.times[nd] - ref.events.times[nd - 1]
-    assert dt_hip == pytest.approx(dt_ref, rel=1e-9)
+    # the accepted leap is the chosen tau after however many halvings each side's own random draws needed (pyx:2316-2321):
+    # equal up to a power of two
+    k = np.log2(dt_ref / dt_hip)
+    assert abs(k - round(k)) < 1e-8 and abs(round(k)) <= 12, (dt_hip, dt_ref)
+    assert dt_hip * 2.0 ** round(k) == pytest.approx(dt_ref, rel=1e-9)
 
 
-@pytest.mark.parametrize("name", ["tau_a", "tau_b", "tau_c", "tau_d", "tau_many_classes", "tau_wide_table", "tau_d:large", "tau_c:large"])
+@pytest.mark.parametrize("name", ["tau_a", "tau_b", "tau_c", "tau_d", "tau_many_classes", "tau_wide_table", "tau_d:large", "tau_c:large",
+                                  "tau_b:steps", "tau_many_classes:steps"])
 def test_tau_moments_match_oracle(oracle_mod, name, monkeypatch):
-    # ":large": the draw thresholds of large models (a compartment's events drawn kind by kind between means of 16 and 64,
-    # channel by channel only from 64 on) on these small ones
+    # Small models run the on-device step loop (vgx_taus.hip).  ":steps": the step kernels of vgx_tau.hip on the same models
+    # (VGX_TAU_STEP_KERNELS=1); ":large": those kernels with the draw thresholds of large models (a compartment's events drawn
+    # kind by kind between means of 16 and 64, channel by channel only from 64 on)
+    if name.endswith(":steps"):
+        name = name[:-6]
+        monkeypatch.setenv("VGX_TAU_STEP_KERNELS", "1")
     if name.endswith(":large"):
         name = name[:-6]
         monkeypatch.setenv("VGX_TAU_LARGE_MODEL_THRESHOLDS", "1")
@@ -96,7 +105,7 @@ def test_tau_moments_match_oracle(oracle_mod, name, monkeypatch):
 N_ENSEMBLE = 512
 
 
-@pytest.mark.parametrize("name", ["tau_a", "tau_b", "tau_c", "tau_d", "tau_c:large", "tau_d:large"])
+@pytest.mark.parametrize("name", ["tau_a", "tau_b", "tau_c", "tau_d", "tau_c:large", "tau_d:large", "tau_b:steps", "tau_c:steps"])
 def test_tau_distribution_matches_oracle_many_seeds(oracle_mod, name, monkeypatch):
     """One common start state (the case's direct warm-up, bit-exact on both engines), then N_ENSEMBLE tau runs that differ
     by their seed only: the device's in one ensemble launch, the oracle's one after the other.  Two independent samples
@@ -105,7 +114,10 @@ def test_tau_distribution_matches_oracle_many_seeds(oracle_mod, name, monkeypatc
       |var_1 - var_2|           <= 4.5 * sqrt((m4_1 - s1^4)/n + (m4_2 - s2^4)/n)    + floor
       |quartile_1 - quartile_2| <= 4.5 * sqrt(2) * 1.36 * s / sqrt(n)               + 1     (integers: one count)
     (1.36 s / sqrt(n) = the standard error of a quartile of a near-normal sample); floor = 0.5 events, 1e-9 time units."""
-    if name.endswith(":large"):   # the draw thresholds of large models (see test_tau_moments_match_oracle)
+    if name.endswith(":steps"):   # the step kernels on the small models (see test_tau_moments_match_oracle)
+        name = name[:-6]
+        monkeypatch.setenv("VGX_TAU_STEP_KERNELS", "1")
+    if name.endswith(":large"):   # ... with the draw thresholds of large models
         name = name[:-6]
         monkeypatch.setenv("VGX_TAU_LARGE_MODEL_THRESHOLDS", "1")
     from vgsim_amd import Simulator
@@ -163,11 +175,14 @@ def test_tau_distribution_matches_oracle_many_seeds(oracle_mod, name, monkeypatc
             assert abs(qa - qb) <= tolq, "%s: %d %% quantiles %.6g vs %.6g (tolerance %.3g)" % (what, int(100 * q), qa, qb, tolq)
 
 
-@pytest.mark.parametrize("case", ["tau_b", "tau_c:large", "tau_d:large"])
+@pytest.mark.parametrize("case", ["tau_b", "tau_c", "tau_b:steps", "tau_c:large", "tau_d:large"])
 def test_multievent_rows_account_for_counters(case, monkeypatch):
     """Sparse multievent log: rows with num > 0 only; their sums reproduce the counter increments and every
     MULTITYPE record points at its own [start, end) row range (":large": with the draw thresholds of large models, i.e.
     through the one-draw-per-kind form and the channel-by-channel kernel from a mean of 64 on)."""
+    if case.endswith(":steps"):
+        case = case[:-6]
+        monkeypatch.setenv("VGX_TAU_STEP_KERNELS", "1")
     if case.endswith(":large"):
         case = case[:-6]
         monkeypatch.setenv("VGX_TAU_LARGE_MODEL_THRESHOLDS", "1")
@@ -271,8 +286,9 @@ def test_halving_sieve_leaves_the_accepted_steps_untouched():
 
 @pytest.mark.parametrize("case", ["sparse_large", "tiny_full", "large_compartments", "one_mutant_rescues", "small_next_to_large", "classes_short_rows",
                                   "queue_grows", "many_classes", "wide_migration_table"])
-def test_sparse_try_equals_the_dense_passes(case):
-    """A try of the halving loop keeps its deltas as a list of moves and checks the bounds of GenerateEvents_tau
+def test_sparse_try_equals_the_dense_passes(case, monkeypatch):
+    """(Step kernels of vgx_tau.hip, forced here also for the small shapes that the on-device step loop would take.)
+    A try of the halving loop keeps its deltas as a list of moves and checks the bounds of GenerateEvents_tau
     (pyx:2522-2528) where the deltas are drawn (own deltas at once, compartments found below zero against the mutants of
     their neighbours, the upper bound per population).  ``vgx_run_opts.reserved[1] = 2`` writes both dense delta arrays in
     every try with the checks fused into the draw and scatter kernels, ``= 1`` additionally runs the check as one dense pass
@@ -284,6 +300,7 @@ def test_sparse_try_equals_the_dense_passes(case):
     rescue depends on neighbours that are drawn channel by channel: the hash table of vgx_tau_arrivals_kernel decides)."""
     import ctypes as C
     from vgsim_amd import Simulator, _capi
+    monkeypatch.setenv("VGX_TAU_STEP_KERNELS", "1")
 
     def run(mode):
         with helpers.quiet():

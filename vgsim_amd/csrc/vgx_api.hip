@@ -19,6 +19,7 @@
 #include "../../include/vgx.h"
 #include "vgx_dev.h"
 #include "vgx_quadg.h"
+#include "vgx_taus.h"
 #include "vgx_rng.h"
 
 // launchers defined next to their kernels (vgx_direct.hip)
@@ -33,6 +34,7 @@ extern "C" hipError_t vgxi_launch_quad(const VgxDirectArgs *a, const double *cd,
                                        hipStream_t stream);
 extern "C" size_t vgxi_direct_lds_bytes(int P, int S, int C, int CB);
 extern "C" hipError_t vgxi_launch_quad_prep(const VgxDevParams *p, const double *cd, double *effMig, double *maxEBM, int32_t *has_mig, hipStream_t stream);
+extern "C" hipError_t vgxi_launch_taus(const VgxTausArgs *a, hipStream_t s);
 extern "C" hipError_t vgxi_launch_quadg(const VgxDirectArgs *a, const VgxQuadgArgs *qa, hipStream_t stream);
 extern "C" hipError_t vgxi_launch_counts32(const int64_t *c64, int32_t *c32, int64_t n, hipStream_t stream);
 extern "C" hipError_t vgxi_launch_init_reps(const VgxDevRep *r, int P, int S, int64_t R, const int32_t *s_nocc,
@@ -94,7 +96,7 @@ struct vgx_engine {
         r_evrate, r_evcols, r_locrec, r_loctime, r_lociter, r_farate, r_fakey, r_traj, r_prof, r_qeff, r_qmebm, r_qflag;
     // tau-leaping (dense compartments)
     DevBuf t_I, t_S, t_dChk, t_dApp, t_dSi, t_dTot, t_totInf, t_gI, t_cd, t_lock, t_F, t_eff, t_Aeff, t_Gout, t_dS,
-        t_taubits, t_tau, t_time, t_flags, t_counters, t_cnttry, t_mev, t_mevn, t_mevbase, t_locn, t_mutcum, t_migcdf, t_migIn, t_mutHi, t_colT, t_colTW, t_inc, t_incn, t_sieve, t_sieveskip, t_big, t_bign, t_res, t_susp, t_suspn, t_stkey, t_stval, t_dChkTot, t_q, t_qn, t_hist, t_I8, t_dSpart, t_tmax8;
+        t_taubits, t_tau, t_time, t_flags, t_counters, t_cnttry, t_mev, t_mevn, t_mevbase, t_locn, t_mutcum, t_migcdf, t_migIn, t_mutHi, t_colT, t_colTW, t_inc, t_incn, t_sieve, t_sieveskip, t_big, t_bign, t_res, t_susp, t_suspn, t_stkey, t_stval, t_dChkTot, t_q, t_qn, t_hist, t_I8, t_dSpart, t_tmax8, t_iI, t_iS, t_slog, t_sres;
     std::vector<int64_t> tau_sieve_skipped;   // [R] tries left out by the sieve in the last tau call
     bool last_was_tau = false;
     int64_t tau_mev_cap = 0;
@@ -1359,6 +1361,92 @@ extern "C" int vgx_simulate_tau(vgx_engine *e, int64_t iterations, int64_t sampl
     auto sC_of = [&](int64_t r) { return cnt0[(size_t)r][2] + cnt[(size_t)r * 8 + 2]; };
     int64_t guard = 0;
     bool i8_dirty = true;    // I8 does not mirror I (start of the call, after a Restart's upload, after a dense try)
+    // Small models: the whole step loop on the device, one workgroup per replicate (vgx_taus.hip).  VGX_TAU_STEP_KERNELS=1 and the
+    // test switches of the step kernels (dense validation modes, the large-model draw thresholds) keep the step kernels.
+    const int64_t slog_cap = std::max<int64_t>(ev_size - ((ev_ptr_start <= 100 && iterations > 100) ? 0 : ev_ptr_start), 1);
+    // One workgroup (one CU) runs a replicate's whole loop: that wins where a step is launch-bound (few channels) or where there are
+    // replicates to fill the chip with; one replicate of a mid-size model (tens of thousands of channels, every draw a PTRS
+    // sample) is faster spread over the chip by the step kernels (256 haplotypes x 5 populations, 3e6 infected: 8.5e3 against
+    // 2.0e3 steps/s).
+    const int64_t n_channels = P * H * (2 + 3 * e->d.sites + S + (P - 1) * S) + P * S * S;
+    bool use_small = P * H <= VGX_TAUS_MAX_CELLS && P <= VGX_TAUS_MAX_P && S <= VGX_TAUS_MAX_S && e->d.sites <= 15 && sparse_default &&
+                     e->C <= VGX_TAUS_MAX_C && e->CB <= VGX_TAUS_MAX_CB && (n_channels <= 4096 || R >= 32) &&
+                     vgx_taus_lds_bytes(P, H, S, e->C, e->CB) <= 150 * 1024 && (double)R * (double)slog_cap * 24.0 <= 8e9;
+    {
+        const char *fs = getenv("VGX_TAU_STEP_KERNELS"), *th = getenv("VGX_TAU_LARGE_MODEL_THRESHOLDS");
+        if ((fs && fs[0] == '1') || (th && th[0] == '1')) use_small = false;
+        if (fs && fs[0] == '0' && P * H <= VGX_TAUS_MAX_CELLS && P <= VGX_TAUS_MAX_P && S <= VGX_TAUS_MAX_S && e->d.sites <= 15 && sparse_default &&
+            e->C <= VGX_TAUS_MAX_C && e->CB <= VGX_TAUS_MAX_CB && vgx_taus_lds_bytes(P, H, S, e->C, e->CB) <= 150 * 1024)
+            use_small = true;      // (VGX_TAU_STEP_KERNELS=0: the on-device loop wherever it can run, for tests and comparisons)
+    }
+    if (use_small) {
+        std::vector<int32_t> i32((size_t)(P * H));
+        for (int64_t i = 0; i < P * H; i++) i32[(size_t)i] = (int32_t)h.initial_infectious[(size_t)i];
+        rc = upload(e, e->t_iI, i32.data(), i32.size());
+        rc |= upload(e, e->t_iS, h.initial_susceptible.data(), h.initial_susceptible.size());
+        rc |= ensure(e, e->t_slog, (size_t)(R * slog_cap * 3) * 8);
+        rc |= ensure(e, e->t_sres, (size_t)(R * 24) * 8);
+        if (rc) return rc;
+        VgxTausArgs ta{};
+        ta.p = e->dp; ta.R = R;
+        ta.I = a.I; ta.S = a.S; ta.totInf = a.totInf; ta.cd = a.cd; ta.lock = a.lockON;
+        ta.i_I = (const int32_t *)e->t_iI.p; ta.i_S = (const int64_t *)e->t_iS.p;
+        ta.seeds = a.seeds;
+        ta.iterations = iterations; ta.sample_size = sample_size; ta.attempts = attempts; ta.time = time;
+        ta.start_ok = start_ok ? 1 : 0; ta.rates_nonzero_initial = rates_nonzero_initial ? 1 : 0;
+        ta.ev_ptr0 = ev_ptr_start; ta.ev_size = ev_size;
+        ta.t0 = h.currentTime; ta.gI0 = h.globalInfectious; ta.good0 = h.good_attempt;
+        for (int i = 0; i < 8; i++) ta.base_cnt[i] = base_cnt[(size_t)i];
+        ta.mut_uniform = a.mut_uniform;
+        memcpy(ta.mutp, a.mutp, sizeof(ta.mutp));
+        ta.mev = a.mev; ta.mev_cap = mev_cap;
+        ta.slog = (int64_t *)e->t_slog.p; ta.slog_cap = slog_cap;
+        ta.loc_rec = a.loc_rec; ta.loc_time = a.loc_time; ta.loc_n = a.loc_n;
+        ta.res = (int64_t *)e->t_sres.p;
+        HIPCHECK(e, hipEventRecord(e->ev0, e->stream));
+        HIPCHECK(e, vgxi_launch_taus(&ta, e->stream));
+        HIPCHECK(e, hipEventRecord(e->ev1, e->stream));
+        HIPCHECK(e, hipStreamSynchronize(e->stream));
+        HIPCHECK(e, hipEventElapsedTime(&ms_total, e->ev0, e->ev1));
+        launches = 1;
+        std::vector<int64_t> res((size_t)R * 24);
+        HIPCHECK(e, hipMemcpy(res.data(), e->t_sres.p, res.size() * 8, hipMemcpyDeviceToHost));
+        tau_h.assign((size_t)R, 0.0);
+        std::vector<int64_t> sl;
+        for (int64_t r = 0; r < R; r++) {
+            const int64_t *o2 = &res[(size_t)r * 24];
+            const int64_t er = o2[TS_ERROR];
+            if (er == VGX_ERR_CAPACITY)
+                return fail(e, VGX_ERR_CAPACITY, "vgx_simulate_tau: replicate " + std::to_string(r) + ": multievent buffer full (" + std::to_string(mev_cap) +
+                                                     " rows per replicate; pass record_events=0 for large runs)");
+            if (er == 7) return fail(e, VGX_ERR_CAPACITY, "vgx_simulate_tau: replicate " + std::to_string(r) + ": lockdown log full (" + std::to_string(VGX_LOC_CAP) + " switches per call)");
+            if (er) {
+                double tl_, tn_;
+                memcpy(&tl_, &o2[TS_TAU], 8); memcpy(&tn_, &o2[TS_TIME], 8);
+                return fail(e, VGX_ERR_LOOP_GUARD, "vgx_simulate_tau: replicate " + std::to_string(r) + (er == 6 ? ": step loop guard" : ": tau underflow in the halving loop") +
+                                                       " (step " + std::to_string(o2[TS_STEPS]) + ", tries " + std::to_string(o2[TS_TRIES]) + ", tau " + std::to_string(tl_) +
+                                                       ", time " + std::to_string(tn_) + ", infected " + std::to_string(o2[TS_GI]) + ")");
+            }
+            memcpy(&tau_h[(size_t)r], &o2[TS_TAU], 8);
+            if (o2[TS_STEPS] == 0 && o2[TS_RESTARTS] == 0) tau_h[(size_t)r] = h.tau_l;
+            if (timing && r == 0) fprintf(stderr, "vgx_simulate_tau: on-device loop: %lld steps, %lld tries, %.3f ms\n", (long long)o2[TS_STEPS], (long long)o2[TS_TRIES], (double)ms_total);
+            gI[(size_t)r] = o2[TS_GI];
+            for (int i = 0; i < 8; i++) { cnt[(size_t)r * 8 + i] = o2[TS_CNT0 + i]; cnt0[(size_t)r][(size_t)i] = 0; }
+            ev_ptr[(size_t)r] = o2[TS_EVPTR]; att[(size_t)r] = o2[TS_ATT]; good[(size_t)r] = o2[TS_GOOD];
+            restarts[(size_t)r] = o2[TS_RESTARTS]; steps_done[(size_t)r] = o2[TS_STEPS];
+            mevn[(size_t)r] = (unsigned long long)o2[TS_MEVROWS];
+            memcpy(&tnow[(size_t)r], &o2[TS_TIME], 8);
+            e->tau_ev_ptr0[(size_t)r] = o2[TS_EVPTR0];
+            const int64_t n = o2[TS_EVPTR] - o2[TS_EVPTR0];
+            sl.resize((size_t)std::max<int64_t>(n, 0) * 3);
+            if (n > 0) HIPCHECK(e, hipMemcpy(sl.data(), (int64_t *)e->t_slog.p + r * slog_cap * 3, (size_t)n * 24, hipMemcpyDeviceToHost));
+            for (int64_t k = 0; k < n; k++) {
+                double t;
+                memcpy(&t, &sl[(size_t)k * 3], 8);
+                e->tau_log[(size_t)r].push_back({t, sl[(size_t)k * 3 + 1], sl[(size_t)k * 3 + 2]});
+            }
+        }
+    } else
     while (true) {
         // loop condition (pyx:2312) / end of attempt (pyx:2331-2335)
         bool any = false;
