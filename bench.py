@@ -378,20 +378,24 @@ def rowscan_leg(device, rows=4096):
 
 
 def fast_leg(device, replicates, events, traj_points):
-    """The headline workload (natural occupancy) in FAST mode (one replicate per wavefront), device time of one launch after
-    a warm-up."""
-    replicates, events = min(replicates, 4096), events * max(replicates // 4096, 1)
+    """The headline workload (natural occupancy) in FAST mode: the row-per-replicate kernel vgx_quadf.hip (four replicates per
+    wavefront, three wavefronts per SIMD: 24 576 replicates are two full rounds of the chip), device time of one launch after a
+    warm-up; the counter-based stream (mode 2) stays on the one-replicate-per-wavefront kernel."""
     import numpy as np
     from vgsim_amd.ensemble import Ensemble
+    replicates = 24576 if replicates >= 16384 else replicates
     ens = Ensemble(make_simulator(2020), replicates, device=device)
     res = None
     for it in range(2):
         res = ens.simulate(events, sample_size=10 ** 12, record_events=True, traj_points=traj_points,
                            traj_window=(0.0, 12.0), seeds=2020 + it * replicates + np.arange(replicates, dtype=np.int64),
                            mode="fast")
-    out = {"workload": "headline workload in FAST mode (order-free sums, same PCG64 stream)",
+    out = {"workload": "headline workload in FAST mode (order-free sums, same PCG64 stream), %d replicates x %d events" % (replicates, events),
            "value": res.total_events / (res.kernel_ms * 1e-3), "unit": "events/s (device time)",
-           "kernel_ms_per_launch": res.kernel_ms}
+           "kernel": "vgx_quadf_kernel" if replicates >= 2048 else "vgx_direct_fast_kernel_p64s1", "kernel_ms_per_launch": res.kernel_ms}
+    ens.close()
+    replicates, events = 4096, events
+    ens = Ensemble(make_simulator(2020), replicates, device=device)
     # the same with the counter-based random stream (vgx_run_opts.mode = 2: Philox4x32-10, every draw formed on its own)
     for it in range(2):
         res = ens.simulate(events, sample_size=10 ** 12, record_events=True, traj_points=traj_points,
@@ -691,7 +695,7 @@ def main():
     H = 4 ** SITES
     extra_legs = (("fast_mode", lambda d: fast_leg(d, R, N, a.traj_points)),
                   ("spread_occupancy", lambda d: spread_leg(d, "exact", replicates=8192, events=2500)),
-                  ("spread_occupancy_fast", lambda d: spread_leg(d, "fast", replicates=4096)),
+                  ("spread_occupancy_fast", lambda d: spread_leg(d, "fast", replicates=12288, events=2500)),
                   ("config2", c2_leg), ("genealogy", genealogy_leg), ("single_trajectory", single_leg),
                   ("direct_config4_shape", c4_direct_leg), ("table3", lambda d: table3_leg(d, cpu=not a.no_cpu_baseline, cells=cells3)),
                   ("tau_small", tau_small_leg), ("propensity_scan", rowscan_leg), ("tau_leap", tau_leg))

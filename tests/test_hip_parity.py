@@ -27,6 +27,15 @@ def test_direct_bit_exact_vs_oracle(oracle_mod, name):
     helpers.assert_models_equal(hip, ref, name)
 
 
+@pytest.mark.parametrize("name", DIRECT + list(models.ORACLE_ONLY_CASES))
+def test_wave_kernel_bit_exact_vs_oracle(oracle_mod, name):
+    """The one-replicate-per-wavefront kernel (vgx_direct.hip) forced for every case: the automatic choice hands single runs of
+    small general models to the row kernel (vgx_quadg.hip) since round 3."""
+    hip = helpers.run_case_hip(name, kernel="wave").simulation
+    ref = helpers.run_case_oracle(oracle_mod, name).simulation
+    helpers.assert_models_equal(hip, ref, name)
+
+
 def test_which_time_row_branch_runs_on_this_host():
     """Records (in pytest's warnings summary, which ends the run's output) which branch the golden tests below take here:
     libm_probe_match=True -> sha256 of the full (6, N) chain incl. the time row; False -> integer rows exact, times 1e-12."""

@@ -1,0 +1,73 @@
+"""FAST mode on the row-per-replicate layout (vgx_quadf.hip: four replicates per wavefront, order-free sums — infection rate of a
+population = tEvent x totalInfectious, haplotype by integer prefix search, factored BirthRate, tree prefix sums over the
+populations) against the oracle on the same PCG64 stream: integer columns of the log, counters and compartments identical,
+times within 1e-9 (the tolerance of FAST mode, tests/test_hip_fast.py), on every case the one-class row kernel takes, on
+ensembles whose rows diverge, and on BASELINE config 3 in both occupancy regimes."""
+import numpy as np
+import pytest
+
+import helpers
+import models
+from test_hip_fast import _assert_tier_b, RTOL_TIME
+from test_hip_quad import QUAD_OK, _c3
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name", QUAD_OK)
+def test_fast_row_kernel_integer_columns_match_oracle(oracle_mod, name):
+    hip = helpers.run_case_hip(name, mode="fast", kernel="quad").simulation
+    ref = helpers.run_case_oracle(oracle_mod, name).simulation
+    _assert_tier_b(hip, ref, name)
+
+
+def test_fast_row_kernel_refuses_general_models():
+    from vgsim_amd._capi import VgxError
+    with pytest.raises(VgxError), helpers.quiet():
+        helpers.run_case_hip("g9_short", mode="fast", kernel="quad")
+
+
+@pytest.mark.parametrize("name,n_events,mut", [("c3_s5_p16", 3000, None), ("g6_short", 4000, None), ("c3_s5_p16", 2500, 0.5), ("extinct_restart", 1000, None)])
+def test_fast_row_kernel_replicates_equal_single_oracle_runs(oracle_mod, name, n_events, mut):
+    from vgsim_amd import Simulator
+    from vgsim_amd.ensemble import Ensemble
+    R = 11
+    ctor, phases = models.CASES[name]
+    with helpers.quiet():
+        sim = Simulator(**ctor)
+    phases[0][0](sim)
+    if mut is not None:
+        sim.set_mutation_rate(mut)
+    seeds = np.array([3, 4, 5, 6, 7, 2021, 2022, 99, 100000, 12345678901, 1], dtype=np.int64)
+    ens = Ensemble(sim, R, seeds=seeds)
+    res = ens.simulate(n_events, sample_size=10 ** 9, record_events=True, kernel="quad", mode="fast")
+    for r in range(R):
+        with helpers.quiet():
+            one = Simulator(**dict(ctor, seed=int(seeds[r])))
+        phases[0][0](one)
+        if mut is not None:
+            one.set_mutation_rate(mut)
+        m = one.simulation
+        assert oracle_mod.run_direct(m, n_events, 10 ** 9, -1, 200) == 0
+        assert res.events[r] == m.events.ptr, "replicate %d" % r
+        chain = ens.replicate_events(r)
+        want = m.events.as_array()[:, :m.events.ptr]
+        assert np.array_equal(chain[1:], want[1:]), "replicate %d: %s" % (r, helpers.describe_first_diff(chain[1:], want[1:], m.events.ptr))
+        np.testing.assert_allclose(chain[0], want[0], rtol=RTOL_TIME, atol=0.0)
+        st = ens.replicate_state(r)
+        assert np.array_equal(st.infectious, m.infectious) and np.array_equal(st.susceptible, m.susceptible)
+        assert st.good_attempt == m.good_attempt
+        for k in st.COUNTERS:
+            assert getattr(st, k) == getattr(m, k), k
+    ens.close()
+
+
+@pytest.mark.parametrize("seed,mut,n", [(2020, 0.01, 40000), (2021, 0.4, 12000)])
+def test_fast_row_kernel_config3_vs_sparse_oracle(oracle_mod, seed, mut, n):
+    """Config 3 at full size: natural occupancy and a high mutation rate (lists of hundreds of entries: tile sums)."""
+    hip = _c3(seed, mut)
+    with helpers.quiet():
+        hip.simulate(n, sample_size=10 ** 9, kernel="quad", mode="fast")
+    ref = _c3(seed, mut).simulation
+    assert oracle_mod.run_direct(ref, n, 10 ** 9, -1, 200, sparse=True) == 0
+    _assert_tier_b(hip.simulation, ref, "config3 seed %d" % seed)

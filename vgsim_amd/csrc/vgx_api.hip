@@ -34,6 +34,7 @@ extern "C" hipError_t vgxi_launch_quad(const VgxDirectArgs *a, const double *cd,
                                        hipStream_t stream);
 extern "C" size_t vgxi_direct_lds_bytes(int P, int S, int C, int CB);
 extern "C" hipError_t vgxi_launch_quad_prep(const VgxDevParams *p, const double *cd, double *effMig, double *maxEBM, int32_t *has_mig, hipStream_t stream);
+extern "C" hipError_t vgxi_launch_quadf(const VgxDirectArgs *a, const double *cd, double *effMig, double *maxEBM, int32_t *has_mig, hipStream_t stream);
 extern "C" hipError_t vgxi_launch_taus(const VgxTausArgs *a, hipStream_t s);
 extern "C" hipError_t vgxi_launch_quadg(const VgxDirectArgs *a, const VgxQuadgArgs *qa, hipStream_t stream);
 extern "C" hipError_t vgxi_launch_counts32(const int64_t *c64, int32_t *c32, int64_t n, hipStream_t stream);
@@ -654,7 +655,7 @@ static int init_device_state(vgx_engine *e, int64_t traj_points) {
     rc |= ensure(e, e->r_xC, (size_t)(R * P * e->CB * S) * 8);
     rc |= ensure(e, e->r_effMig, (size_t)(R * P * P) * 8);
     rc |= ensure(e, e->r_nocc, (size_t)(R * P) * 4);
-    rc |= ensure(e, e->r_lhap, (size_t)(R * P * cap) * 4);
+    rc |= ensure(e, e->r_lhap, (size_t)(R * P * cap + 64) * 4);
     rc |= ensure(e, e->r_lcls, (size_t)(R * P * cap) * 4);
     rc |= ensure(e, e->r_lcnt, (size_t)(R * P * cap + 64) * 8);   // + one tile: vgx_quad.hip reads whole 64-entry tiles
     const bool want32 = P <= 64 && S == 1 && e->C == 1 && e->CB == 1;   // shapes the four-replicates-per-wavefront kernel takes
@@ -840,18 +841,21 @@ static int direct_core(vgx_engine *e, int64_t iterations, int64_t sample_size, f
     const bool use_lanes = (recomb && lane_ok && o.kernel != 1) || o.kernel == 2 || (o.kernel == 0 && lane_ok && P * H * S <= 4 && R >= 65536);
     // Four replicates per wavefront, one per 16-lane DPP row (vgx_quad.hip): one rate class, one susceptibility group,
     // at most 64 populations, no population that can switch its lockdown state, exact mode.
-    bool quad_ok = o.mode == 0 && !recomb && P <= 64 && S == 1 && e->C == 1 && e->CB == 1 && !ld_possible &&
-                   e->suscepCumul[0] == 0.0 && e->dr.lcnt32 != nullptr;
-    for (int64_t pn = 0; pn < P && quad_ok; pn++)
-        if (e->sizes[(size_t)pn] >= ((int64_t)1 << 31)) quad_ok = false;   // its streaming passes read 4-byte counts
-    for (int64_t pn = 0; pn < P && quad_ok; pn++)
-        if (h.totalSusceptible[(size_t)pn] != h.susceptible[(size_t)pn]) quad_ok = false;
+    bool quad_shape = !recomb && P <= 64 && S == 1 && e->C == 1 && e->CB == 1 && !ld_possible &&
+                      e->suscepCumul[0] == 0.0 && e->dr.lcnt32 != nullptr;
+    for (int64_t pn = 0; pn < P && quad_shape; pn++)
+        if (e->sizes[(size_t)pn] >= ((int64_t)1 << 31)) quad_shape = false;   // its streaming passes read 4-byte counts
+    for (int64_t pn = 0; pn < P && quad_shape; pn++)
+        if (h.totalSusceptible[(size_t)pn] != h.susceptible[(size_t)pn]) quad_shape = false;
+    const bool quad_ok = o.mode == 0 && quad_shape;
+    // FAST mode (order-free sums, PCG64 stream) on the same layout and scope: vgx_quadf.hip
+    const bool quadf_ok = o.mode == 1 && quad_shape;
     // The general form of that kernel (vgx_quadg.hip): several susceptibility groups and rate classes, lockdown switches,
     // up to 128 populations.
     const int64_t qg_W = 3 * S + e->CB;
     const bool quadg_ok = o.mode == 0 && !recomb && P <= VGX_QG_MAX_P && S <= VGX_QG_MAX_S && e->C <= VGX_QG_MAX_C &&
                           e->CB <= VGX_QG_MAX_CB && qg_W <= VGX_QG_MAX_W && (int64_t)e->h_seg_par.size() <= VGX_QG_MAX_SEG;
-    if (o.kernel == 3 && !quad_ok && !quadg_ok)
+    if (o.kernel == 3 && !quad_ok && !quadg_ok && !quadf_ok)
         return fail(e, VGX_ERR_ARG, "vgx_simulate_direct: the four-replicates-per-wavefront kernels need exact mode, no recombination, "
                                     "popNum <= 128, susNum <= 8, at most 64 rate classes and 16 transmission/susceptibility classes");
     if (o.kernel == 4 && !quadg_ok)
@@ -860,7 +864,12 @@ static int direct_core(vgx_engine *e, int64_t iterations, int64_t sample_size, f
     // measured (tools/probe_quad.py): a lone wavefront runs one replicate faster than four (1.4e5 vs 1.1e5 events/s per
     // replicate at config 3), so the row kernels pay from about one wavefront per SIMD upwards
     const bool use_quad = (o.kernel == 3 && quad_ok) || (o.kernel == 0 && quad_ok && !use_lanes && R >= 2048);
-    const bool use_quadg = !use_quad && (o.kernel == 4 || (o.kernel == 3 && quadg_ok) || (o.kernel == 0 && quadg_ok && !use_lanes && R >= 2048));
+    const bool use_quadf = (o.kernel == 3 && quadf_ok) || (o.kernel == 0 && quadf_ok && R >= 2048);
+    // The general form also for FEW replicates of models with up to 16 populations (one register slot): a wavefront running alone
+    // does a Table-3 trajectory at 1.7e5 events/s there against 1.0e5 on the one-replicate-per-wavefront kernel
+    // (tools/probe_single.py; at 64 populations the wave kernel leads, 1.25e5 against 0.94e5).
+    const bool use_quadg = !use_quad && (o.kernel == 4 || (o.kernel == 3 && quadg_ok) ||
+                                         (o.kernel == 0 && quadg_ok && !use_lanes && (R >= 2048 || (P <= 16 && (S > 1 || e->C > 1 || ld_possible)))));
     VgxLaneWs ws{};
     a.r.rec = nullptr; a.r.rec_cap = 0;
     e->rec_cap = 0;
@@ -898,7 +907,7 @@ static int direct_core(vgx_engine *e, int64_t iterations, int64_t sample_size, f
         qga.nseg = (int32_t)e->h_seg_par.size(); qga.W = (int32_t)qg_W;
         qga.cold = (int64_t *)e->r_cold.p;
     }
-    if (use_quad || use_quadg) {
+    if (use_quad || use_quadg || use_quadf) {
         int rcq = 0;
         rcq |= ensure(e, e->r_qeff, (size_t)(P * P) * 8);
         rcq |= ensure(e, e->r_qmebm, (size_t)P * 8);
@@ -908,12 +917,14 @@ static int direct_core(vgx_engine *e, int64_t iterations, int64_t sample_size, f
     }
 
     // the 4-byte copy of the counts is kept by the four-replicates-per-wavefront kernel alone
-    if (use_quad && !e->counts32_valid) HIPCHECK(e, vgxi_launch_counts32(e->dr.lcnt, e->dr.lcnt32, R * P * e->cap, e->stream));
-    e->counts32_valid = use_quad;
+    if ((use_quad || use_quadf) && !e->counts32_valid) HIPCHECK(e, vgxi_launch_counts32(e->dr.lcnt, e->dr.lcnt32, R * P * e->cap, e->stream));
+    e->counts32_valid = use_quad || use_quadf;
     HIPCHECK(e, hipEventRecord(e->ev0, e->stream));
     if (use_lanes) HIPCHECK(e, vgxi_launch_lanes(&a, &ws, e->stream));
     else if (use_quad) HIPCHECK(e, vgxi_launch_quad(&a, (const double *)e->s_cd.p, (double *)e->r_qeff.p, (double *)e->r_qmebm.p,
                                                     (int32_t *)e->r_qflag.p, e->start_max_nocc > 64 ? 1 : 0, e->stream));
+    else if (use_quadf) HIPCHECK(e, vgxi_launch_quadf(&a, (const double *)e->s_cd.p, (double *)e->r_qeff.p, (double *)e->r_qmebm.p,
+                                                      (int32_t *)e->r_qflag.p, e->stream));
     else if (use_quadg) {
         HIPCHECK(e, vgxi_launch_quad_prep(&a.p, (const double *)e->s_cd.p, (double *)e->r_qeff.p, (double *)e->r_qmebm.p,
                                           (int32_t *)e->r_qflag.p, e->stream));
