@@ -157,7 +157,7 @@ def spread_leg(device, mode="exact", replicates=1024, events=20000, occupied=409
     ev = best.total_events
     # exact, one rate class: the counts of the whole list for the rate refresh + of the entries up to the hit (half the
     # list on average) for the selection, 4 B per entry in the four-replicates-per-wavefront kernel (it streams a 4-byte
-    # copy of the counts), 8 B in the wave kernel; fast: tile sums + one tile
+    # copy of the counts), 8 B in the wave kernel; fast: tile sums + one tile (4-byte counts and haplotypes)
     cnt_bytes = 4.0 if replicates >= 2048 else 8.0
     bpe = (1.5 * cnt_bytes * nocc if mode == "exact" else 8.0 * (nocc / 64.0) + 16.0 * 64) + 8.0 * POPS + 28.0 + 8.0
     traffic = pmc_traffic("spread_occupancy" if mode == "exact" else "spread_occupancy_fast",
@@ -695,7 +695,7 @@ def main():
     H = 4 ** SITES
     extra_legs = (("fast_mode", lambda d: fast_leg(d, R, N, a.traj_points)),
                   ("spread_occupancy", lambda d: spread_leg(d, "exact", replicates=8192, events=2500)),
-                  ("spread_occupancy_fast", lambda d: spread_leg(d, "fast", replicates=12288, events=2500)),
+                  ("spread_occupancy_fast", lambda d: spread_leg(d, "fast", replicates=12288, events=10000)),
                   ("config2", c2_leg), ("genealogy", genealogy_leg), ("single_trajectory", single_leg),
                   ("direct_config4_shape", c4_direct_leg), ("table3", lambda d: table3_leg(d, cpu=not a.no_cpu_baseline, cells=cells3)),
                   ("tau_small", tau_small_leg), ("propensity_scan", rowscan_leg), ("tau_leap", tau_leg))

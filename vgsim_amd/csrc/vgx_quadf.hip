@@ -16,7 +16,16 @@
 #include "vgx_wave.h"
 #include "vgx_rowprim.h"
 
+#ifdef VGX_PROFILE
+#define QPROF(i)                                                        \
+    do {                                                                \
+        unsigned long long prof_t1 = __builtin_readcyclecounter();      \
+        prof_acc[i] += prof_t1 - prof_t0;                               \
+        prof_t0 = prof_t1;                                              \
+    } while (0)
+#else
 #define QPROF(i)
+#endif
 
 namespace {
 
@@ -48,7 +57,8 @@ static __device__ __forceinline__ double row_prev_f64(double v) {
     return __hiloint2double(hi, lo);
 }
 
-struct QCount { int k, hap; int64_t total, wi; bool none; };
+struct __attribute__((packed, aligned(4))) QV4 { int x, y, z, w; };   // four list entries at any 4-byte boundary
+struct QCount { int k, hap; int64_t total, wi, tsum; bool none, tk; };   // tk: tsum = the sum of the hit's tile
 // inclusive int32 prefix inside each row
 static __device__ __forceinline__ int row_iscan32(int v) {
     v += VGX_DPP_SHR(v, 1); v += VGX_DPP_SHR(v, 2); v += VGX_DPP_SHR(v, 4); v += VGX_DPP_SHR(v, 8);
@@ -62,9 +72,9 @@ static __device__ __forceinline__ int row_iscan32(int v) {
 static __device__ __forceinline__ QCount q_count_select(const int32_t *lh2, const int32_t *l32, const int64_t *lt2, int n, double rr_, bool on) {
     const int rl = threadIdx.x & 15;
     QCount o;
-    int64_t before = 0;
+    int64_t before = 0, tsum = 0;
     int base = 0;
-    bool none = false;
+    bool none = false, tk = false;
     const int maxn2 = rows_max(n);
     if (__builtin_expect(maxn2 > 64, 0)) {
         const int nt = n > 64 ? (n + 63) >> 6 : 0;     // tile sums exist only for lists longer than a tile
@@ -91,6 +101,7 @@ static __device__ __forceinline__ QCount q_count_select(const int32_t *lh2, cons
                 const int k = q & 3;
                 const int64_t pk = ex + (k == 0 ? q0 : k == 1 ? q1 : k == 2 ? q2 : q3), wk = k == 0 ? w[0] : k == 1 ? w[1] : k == 2 ? w[2] : w[3];
                 before = rowget_i64(pk - wk, q >> 2);
+                tsum = rowget_i64(wk, q >> 2); tk = true;
             }
             carry += rowget_i64(incl, 15);
             if (!__ballot(on && jt < 0 && tb + 64 < nt)) break;
@@ -98,8 +109,8 @@ static __device__ __forceinline__ QCount q_count_select(const int32_t *lh2, cons
         if (nt > 0) { if (jt < 0) { none = true; before = carry; } else base = jt * 64; }
     }
     // the tile at `base` (every list is followed by one tile of padding; a row without a choice reads its tile 0)
-    const int4 c = *(const int4 *)(l32 + base + 4 * rl);
-    const int4 hh = *(const int4 *)(lh2 + base + 4 * rl);
+    const QV4 c = *(const QV4 *)(l32 + base + 4 * rl);
+    const QV4 hh = *(const QV4 *)(lh2 + base + 4 * rl);
     const int e0 = base + 4 * rl;
     const int c0 = (!none && e0 + 0 < n) ? c.x : 0, c1 = (!none && e0 + 1 < n) ? c.y : 0, c2 = (!none && e0 + 2 < n) ? c.z : 0, c3 = (!none && e0 + 3 < n) ? c.w : 0;
     const int q0 = c0, q1 = q0 + c1, q2 = q1 + c2, q3 = q2 + c3;
@@ -119,8 +130,49 @@ static __device__ __forceinline__ QCount q_count_select(const int32_t *lh2, cons
     } else {
         o.k = -1; o.total = before + rowget_i32(incl, 15); o.wi = 0; o.hap = 0;
     }
-    o.none = none;
+    o.none = none; o.tsum = tsum; o.tk = tk;
     return o;
+}
+
+// A row squeezes the zero-count entries out of its list (in place, tile by tile) and rewrites the tile sums; returns the new length.
+// Rows with on = false pass through (all rows of the wavefront must call).
+static __device__ __forceinline__ int q_compact_list(int32_t *lh, int32_t *l3, int64_t *lt, int n, bool on) {
+    const int rl = threadIdx.x & 15;
+    const int maxn = rows_max(on ? n : 0);
+    int out = 0;
+    for (int tb = 0; tb < maxn; tb += 64) {
+        const bool in = on && tb < n;
+        QV4 hv = {0, 0, 0, 0}, cv = {0, 0, 0, 0};
+        if (in) { hv = *(const QV4 *)(lh + tb + 4 * rl); cv = *(const QV4 *)(l3 + tb + 4 * rl); }
+        const int e0 = tb + 4 * rl;
+        const bool k0 = in && e0 + 0 < n && cv.x != 0, k1 = in && e0 + 1 < n && cv.y != 0, k2 = in && e0 + 2 < n && cv.z != 0,
+                   k3 = in && e0 + 3 < n && cv.w != 0;
+        const int cnt = (int)k0 + (int)k1 + (int)k2 + (int)k3;
+        const int incl = row_iscan32(cnt);
+        WSYNC();
+        int pos = out + incl - cnt;
+        if (k0) { lh[pos] = hv.x; l3[pos] = cv.x; pos += 1; }
+        if (k1) { lh[pos] = hv.y; l3[pos] = cv.y; pos += 1; }
+        if (k2) { lh[pos] = hv.z; l3[pos] = cv.z; pos += 1; }
+        if (k3) { lh[pos] = hv.w; l3[pos] = cv.w; pos += 1; }
+        out += rowget_i32(incl, 15);
+        WSYNC();
+    }
+    const int nn = on ? out : 0;
+    const int maxn2 = rows_max(nn);
+    if (maxn2 > 64) {
+        for (int tb = 0; tb < maxn2; tb += 64) {
+            const bool in = on && nn > 64 && tb < nn;
+            QV4 cv = {0, 0, 0, 0};
+            if (in) cv = *(const QV4 *)(l3 + tb + 4 * rl);
+            const int e0 = tb + 4 * rl;
+            const int sm = (e0 + 0 < nn ? cv.x : 0) + (e0 + 1 < nn ? cv.y : 0) + (e0 + 2 < nn ? cv.z : 0) + (e0 + 3 < nn ? cv.w : 0);
+            const int tot = rowget_i32(row_iscan32(sm), 15);
+            if (in && rl == 0) lt[tb >> 6] = tot;
+        }
+        WSYNC();
+    }
+    return nn;
 }
 
 }  // namespace
@@ -222,9 +274,14 @@ static __device__ __forceinline__ void quadf_body(const VgxDirectArgs &a, const 
     // prefix sums of popRate over the populations 4 rl .. 4 rl + 3 of this lane (tree order), refreshed by every update
     double pre0 = 0.0, pre1 = 0.0, pre2 = 0.0, pre3 = 0.0;
 
+#ifdef VGX_PROFILE
+    unsigned long long prof_acc[VGX_PROF_SLOTS], prof_t0 = __builtin_readcyclecounter();
+    for (int i = 0; i < VGX_PROF_SLOTS; ++i) prof_acc[i] = 0;
+#endif
     while (true) {
         const bool run = st != ST_DONE;
         if (!__ballot(run)) break;
+        QPROF(0);
         const bool rebuild = st == ST_REBUILD;
 
         // ================= front: open the attempt, loop condition (pyx:402-407) =================
@@ -254,8 +311,7 @@ static __device__ __forceinline__ void quadf_body(const VgxDirectArgs &a, const 
         }
 
         int u_lo = 0, u_hi = rebuild ? P : 0;
-        int op_n = 0, op_pi = 0, op_h0 = 0, op_h1 = 0;
-        int op_d0 = 0;
+        int op_n = 0, op_pi = 0, op_h0 = 0;      // a deferred infectious[op_pi, op_h0] += 1 (mutation target, migrant)
         int e_type = -1, e_hap = 0, e_pop = 0, e_nh = 0, e_np = 0;
         double den = 0.0;
 
@@ -327,20 +383,23 @@ static __device__ __forceinline__ void quadf_body(const VgxDirectArgs &a, const 
             const double smul = k_smul[pi];
             const double tE = ((bC + c_d) + smul) + c_tm;
             const int n_sel = evn ? s_nocc[pi] : 0;
-            int64_t *ln = lcnt + (int64_t)pi * cap;
             int32_t *l3 = lcnt32 + (int64_t)pi * cap;
             int64_t *lt = ltsum + (int64_t)pi * capT;
 
             // ---- haplotype: one rate class, so hapPopRate is proportional to the counts: integer prefix search ----
             const int64_t ti_sel = s_ti[pi];
             const double r2 = (double)ti_sel * rn;
+            QPROF(3);
             const QCount hs = q_count_select(lhap + (int64_t)pi * cap, l3, lt, n_sel, r2, evn);
+            QPROF(4);
             int k_hit = hs.k, hap_hit = hs.hap;
             int64_t cnt_hit = hs.wi, tot_hit = hs.total;
+            const int64_t ts_hit = hs.tsum;
+            bool tk_hit = hs.tk;
             if (evn && err == 0 && k_hit < 0) {
                 // nothing reached r: the dense loop runs on to index H-1 (fc:26), a valid pick only if that haplotype is occupied
                 const int32_t *lh = lhap + (int64_t)pi * cap;
-                if (n_sel > 0 && lh[n_sel - 1] == H - 1) { k_hit = n_sel - 1; cnt_hit = ln[n_sel - 1]; hap_hit = H - 1; }
+                if (n_sel > 0 && lh[n_sel - 1] == H - 1 && l3[n_sel - 1] != 0) { k_hit = n_sel - 1; cnt_hit = l3[n_sel - 1]; hap_hit = H - 1; tk_hit = false; }
                 else err = Q_ERR_ZERO_WEIGHT + 256 * 2;
             }
             if (k_hit < 0) { k_hit = 0; cnt_hit = 1; }
@@ -365,7 +424,7 @@ static __device__ __forceinline__ void quadf_body(const VgxDirectArgs &a, const 
                 if ((double)ts_pi * c_sig == 0.0) err = Q_ERR_ZERO_WEIGHT + 256 * 6;
                 if (rl == 0) { s_ts[pi] = ts_pi - 1; s_ti[pi] = ti_pi + 1; }
                 gI += 1; QBUMP(QC_B);
-                if (live && rl == 0) { ln[k_hit] = cnt_hit + 1; l3[k_hit] = (int32_t)(cnt_hit + 1); if (n_sel > 64) lt[k_hit >> 6] += 1; }
+                if (live && rl == 0) { l3[k_hit] = (int32_t)(cnt_hit + 1); if (n_sel > 64) lt[k_hit >> 6] = (tk_hit ? ts_hit : lt[k_hit >> 6]) + 1; }
                 e_type = QEV_BIRTH; e_hap = hap_hit; e_pop = pi; e_nh = 0; e_np = H;
                 u_lo = pi; u_hi = pi + 1;
             }
@@ -373,11 +432,12 @@ static __device__ __forceinline__ void quadf_body(const VgxDirectArgs &a, const 
                 if (rl == 0) { s_ts[pi] = ts_pi + 1; s_ti[pi] = ti_pi - 1; }
                 gI -= 1;
                 if (ei == 2) { cS += 1; e_type = QEV_SAMPLING; } else { QBUMP(QC_D); e_type = QEV_DEATH; }
-                if (cnt_hit == 1) { op_n = 1; op_pi = pi; op_h0 = hap_hit; op_d0 = -1; }
-                else if (live && rl == 0) { ln[k_hit] = cnt_hit - 1; l3[k_hit] = (int32_t)(cnt_hit - 1); if (n_sel > 64) lt[k_hit >> 6] -= 1; }
+                if (live && rl == 0)   // (a count of 0 stays in the list, see the list operations below)
+                    { l3[k_hit] = (int32_t)(cnt_hit - 1); if (n_sel > 64) lt[k_hit >> 6] = (tk_hit ? ts_hit : lt[k_hit >> 6]) - 1; }
                 e_hap = hap_hit; e_pop = pi; e_nh = 0; e_np = 0;
                 u_lo = pi; u_hi = pi + 1;
             }
+            QPROF(5);
             if (__builtin_expect(__ballot(isM) != 0, 0)) {   // slow paths: a few per cent of the iterations
                 // ---- Mutation (pyx:640-667): site by mRate[h, :], derived state by hapMutType[h, site, :] ----
                 const double *mr = p.mRate + (int64_t)hap_hit * sites;
@@ -406,7 +466,8 @@ static __device__ __forceinline__ void quadf_body(const VgxDirectArgs &a, const 
                     const int AS = (hap_hit / digit4) % 4;
                     if (DS >= AS) DS += 1;
                     const int nhi = hap_hit + (DS - AS) * digit4;
-                    op_n = 2; op_pi = pi; op_h0 = nhi; op_d0 = +1; op_h1 = hap_hit;
+                    if (live && rl == 0) { l3[k_hit] = (int32_t)(cnt_hit - 1); if (n_sel > 64) lt[k_hit >> 6] = (tk_hit ? ts_hit : lt[k_hit >> 6]) - 1; }
+                    op_n = 1; op_pi = pi; op_h0 = nhi;
                     QBUMP(QC_M);
                     e_type = QEV_MUTATION; e_hap = hap_hit; e_pop = pi; e_nh = nhi; e_np = 0;
                     u_lo = pi; u_hi = pi + 1;
@@ -472,13 +533,13 @@ static __device__ __forceinline__ void quadf_body(const VgxDirectArgs &a, const 
                 {
                     const int n = (evm && err == 0) ? s_nocc[spi] : 0;
                     const int32_t *lh2 = lhap + (int64_t)spi * cap;
-                    const int64_t *ln2 = lcnt + (int64_t)spi * cap;
+                    const int32_t *ln2 = lcnt32 + (int64_t)spi * cap;
                     const double rr_ = (double)s_ti[spi] * rm;
                     const QCount ms = q_count_select(lh2, lcnt32 + (int64_t)spi * cap, ltsum + (int64_t)spi * capT, n, rr_, evm);
                     int kq = ms.k;
                     int64_t total = ms.total, wi = ms.wi;
                     if (evm && err == 0 && kq < 0) {
-                        if (n > 0 && lh2[n - 1] == H - 1) { kq = n - 1; wi = ln2[n - 1]; }
+                        if (n > 0 && lh2[n - 1] == H - 1 && ln2[n - 1] != 0) { kq = n - 1; wi = ln2[n - 1]; }
                         else { err = Q_ERR_ZERO_WEIGHT + 256 * 11; kq = 0; wi = 1; }
                     }
                     if (kq < 0) { kq = 0; wi = 1; }
@@ -498,7 +559,7 @@ static __device__ __forceinline__ void quadf_body(const VgxDirectArgs &a, const 
                     if (rm < p_accept) {
                         if (rl == 0) { s_ts[tpi] -= 1; s_ti[tpi] += 1; }     // NewInfections (pyx:246-251)
                         gI += 1; QBUMP(QC_MIGP);
-                        op_n = 1; op_pi = tpi; op_h0 = hi; op_d0 = +1;
+                        op_n = 1; op_pi = tpi; op_h0 = hi;
                         e_type = QEV_MIGRATION; e_hap = hi; e_pop = spi; e_nh = 0; e_np = tpi;
                         u_lo = tpi; u_hi = tpi + 1;
                     } else {
@@ -506,138 +567,132 @@ static __device__ __forceinline__ void quadf_body(const VgxDirectArgs &a, const 
                     }
                 }
             }
+            QPROF(6);
             WSYNC();
+            QPROF(7);
         }
 
         // ================= deferred list operations: infectious[op_pi, hap] += delta, list kept ordered =================
         if (err != 0) op_n = 0;
-        for (int oi = 0; oi < 2; ++oi) {
-            const bool act = live && oi < op_n;
-            if (!__ballot(act)) break;
-            const int hap = oi == 0 ? op_h0 : op_h1;
-            const int delta = oi == 0 ? op_d0 : -1;
-            const int n = act ? s_nocc[op_pi] : 0;
+        if (__builtin_expect(__ballot(live && op_n > 0) != 0, 0)) {
+            const bool act = live && op_n > 0;
+            const int hap = op_h0;
+            const int delta = 1;
+            int n = act ? s_nocc[op_pi] : 0;
             int32_t *lh = lhap + (int64_t)op_pi * cap;
             int32_t *lc = lcls + (int64_t)op_pi * cap;
-            int64_t *ln = lcnt + (int64_t)op_pi * cap;
             int32_t *l3 = lcnt32 + (int64_t)op_pi * cap;
             int64_t *lt = ltsum + (int64_t)op_pi * capT;
+            if (__builtin_expect(__ballot(act && n >= cap && cap < H) != 0, 0)) {   // a full list: squeeze its zero-count entries out first
+                const bool cm = act && n >= cap && cap < H;
+                const int n2 = q_compact_list(lh, l3, lt, n, cm);
+                if (cm) { n = n2; if (rl == 0) s_nocc[op_pi] = n2; }
+                WSYNC();
+            }
             // ---- lower bound: first index whose haplotype is >= hap ----
             int posn = 0;
             bool found = false;
             int64_t cur = 0;
             {
-                int lo = 0;             // first entry of the 16^k-aligned window known to contain the bound
-                const int maxn = rows_max(n);
-                // 16-ary descent over the sorted list: strides 16^5 ... 16, 1
-                for (int stride = 1 << 20; stride >= 1; stride >>= 4) {
-                    if (stride >= 16 && maxn <= stride) continue;
-                    const int k = lo + rl * stride;
-                    const int h = (act && k < n) ? lh[k] : 0x7fffffff;
-                    // probes are sorted: the first lane with h > hap = the number of probes <= hap; the bound lies at or
-                    // after the last of those and before the next probe
-                    const int nle = row_min(h <= hap ? 16 : rl);
-                    if (stride == 1) {
-                        const int q = row_min(h >= hap ? rl : 16);
-                        posn = lo + q;
-                        if (posn > n) posn = n;
-                        const int hq = rowget_i32(h, min(q, 15));
-                        found = q < 16 && hq == hap;
-                    } else {
-                        lo = lo + (nle > 0 ? (nle - 1) * stride : 0);
+                {
+                    const bool sr = act;
+                    const int ns = sr ? n : 0;
+                    const int maxn = rows_max(ns);
+                    int lo = 0;             // first entry of the 64^k-aligned window known to contain the bound
+                    // 64-ary descent over the sorted list (a lane probes four of the 64 sub-windows): strides 64^3, 64^2, 64
+                    for (int stride = 1 << 18; stride >= 64; stride >>= 6) {
+                        if (maxn <= stride) continue;
+                        int c = 0;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const int64_t k = lo + (int64_t)(4 * rl + j) * stride;
+                            const int h = k < ns ? lh[k] : 0x7fffffff;
+                            c += h <= hap ? 1 : 0;
+                        }
+                        // probes are sorted: the bound lies at or after the last probe <= hap and before the next probe
+                        const int nle = rowget_i32(row_iscan32(c), 15);
+                        lo += nle > 0 ? (nle - 1) * stride : 0;
+                    }
+                    // the tile at lo: four consecutive entries per lane, the counts with them
+                    const QV4 hv = *(const QV4 *)(lh + lo + 4 * rl);
+                    const QV4 cv = *(const QV4 *)(l3 + lo + 4 * rl);
+                    const int e0 = lo + 4 * rl;
+                    const int h0 = e0 + 0 < ns ? hv.x : 0x7fffffff, h1 = e0 + 1 < ns ? hv.y : 0x7fffffff;
+                    const int h2 = e0 + 2 < ns ? hv.z : 0x7fffffff, h3 = e0 + 3 < ns ? hv.w : 0x7fffffff;
+                    const int jl = h0 >= hap ? 0 : h1 >= hap ? 1 : h2 >= hap ? 2 : h3 >= hap ? 3 : 4;
+                    const int q = row_min(jl < 4 ? 4 * rl + jl : 64);
+                    const int qq = min(q, 63), j = qq & 3;
+                    const int hq = rowget_i32(j == 0 ? h0 : j == 1 ? h1 : j == 2 ? h2 : h3, qq >> 2);
+                    const int cq = rowget_i32(j == 0 ? cv.x : j == 1 ? cv.y : j == 2 ? cv.z : cv.w, qq >> 2);
+                    if (sr) {
+                        posn = min(lo + q, n);
+                        found = q < 64 && hq == hap;
+                        cur = found ? cq : 0;
                     }
                 }
-                if (act && found) cur = ln[posn];
             }
-            const bool bump = act && found && cur + delta != 0;       // count changes in place
-            const bool rem = act && found && cur + delta == 0;        // the entry disappears
+            QPROF(8);
+            // A count that drops to 0 stays in the list as a zero-count entry (the selections skip it, a later insertion next to
+            // it takes its slot): nothing moves on removal.  The zero entries are squeezed out after the launch
+            // (vgx_lists_settle_kernel), or here when a list is about to overflow.
+            const bool bump = act && found;                           // count changes in place
             const bool ins = act && !found;                           // a new entry (delta = +1)
             if (ins && n >= cap) { err = Q_ERR_CAPACITY; }
             const bool ins_ok = ins && err == 0;
-            if (bump && rl == 0) { ln[posn] = cur + delta; l3[posn] = (int32_t)(cur + delta); if (n > 64) lt[posn >> 6] += delta; }
-            // ---- tile sums of lists longer than one tile (vgx_direct.hip list_insert_at / list_remove_at) ----
-            if (__builtin_expect(__ballot((ins_ok || rem) && n > 64) != 0, 0)) {
-                const bool tt = (ins_ok || rem) && n > 64;
-                const int jp = posn >> 6, jl = ins_ok ? (n >> 6) : ((n - 1) >> 6);
-                const int maxj = rows_max(tt ? jl + 1 : 0);
-                for (int tb = 0; tb < maxj; tb += 16) {
-                    const int j = tb + rl;
-                    if (tt && j >= jp && j <= jl) {
-                        int64_t in_, out_;
-                        if (ins_ok) {
-                            in_ = j == jp ? (int64_t)delta : ln[(int64_t)j * 64 - 1];
-                            const int kout = j * 64 + 63;
-                            out_ = kout < n ? ln[kout] : 0;
-                        } else {
-                            out_ = j == jp ? ln[posn] : ln[(int64_t)j * 64];
-                            const int kin = j * 64 + 64;
-                            in_ = kin < n ? ln[kin] : 0;
-                        }
-                        lt[j] += in_ - out_;
-                    }
-                }
-                WSYNC();
-            }
-            // ---- shift: insertion moves [posn, n) one slot up (highest block first), removal (posn, n) one slot down ----
+            if (bump && rl == 0) { l3[posn] = (int32_t)(cur + delta); if (n > 64) lt[posn >> 6] += delta; }
+            QPROF(9);
+            // ---- insertion: the entries from posn up to the next zero-count entry (or the end of the list) move one slot up, a
+            // tile (16 lanes x 4 entries) per step, the entry pushed out of a tile carried into the next ----
             if (__builtin_expect(__ballot(ins_ok) != 0, 0)) {
-                enum { SU = 4 };
-                int hi_ = ins_ok ? n : 0;
-                const int lo_ = ins_ok ? posn : 0;
-                while (__ballot(hi_ > lo_)) {
-                    const int blo = max(lo_, hi_ - SU * 16);
-                    int h[SU];
-                    int64_t ct[SU];
-#pragma unroll
-                    for (int u = 0; u < SU; ++u) {
-                        const int k = blo + u * 16 + rl;
-                        h[u] = 0; ct[u] = 0;
-                        if (k < hi_) { h[u] = lh[k]; ct[u] = ln[k]; }
+                int b = ins_ok ? posn : 0, nn = n, ch = hap, cc = delta;
+                bool going = ins_ok;
+                while (__ballot(going)) {
+                    const int tb = b & ~63;
+                    QV4 hv = {0, 0, 0, 0}, cv = {0, 0, 0, 0};
+                    int64_t tsum = 0;
+                    if (going) {
+                        hv = *(const QV4 *)(lh + tb + 4 * rl); cv = *(const QV4 *)(l3 + tb + 4 * rl);
+                        if (n > 64 && rl == 0) tsum = lt[tb >> 6];
                     }
-                    WSYNC();
-#pragma unroll
-                    for (int u = 0; u < SU; ++u) {
-                        const int k = blo + u * 16 + rl;
-                        if (k < hi_) { lh[k + 1] = h[u]; lc[k + 1] = 0; ln[k + 1] = ct[u]; l3[k + 1] = (int32_t)ct[u]; }
+                    const int i0 = 4 * rl;                       // index of the lane's first entry inside the tile
+                    const int bq = b - tb, lim = min(64, nn - tb);
+                    const int jl = (i0 + 0 >= bq && i0 + 0 < lim && cv.x == 0) ? 0 : (i0 + 1 >= bq && i0 + 1 < lim && cv.y == 0) ? 1
+                                 : (i0 + 2 >= bq && i0 + 2 < lim && cv.z == 0) ? 2 : (i0 + 3 >= bq && i0 + 3 < lim && cv.w == 0) ? 3 : 4;
+                    const int zq = row_min(going && jl < 4 ? i0 + jl : 64);
+                    const int endq = zq < 64 ? zq : lim;         // the slot that takes the last moved entry (64: the next tile's first)
+                    const int ph = VGX_DPP_SHR(hv.w, 1), pc = VGX_DPP_SHR(cv.w, 1);    // the entry below the lane's first
+                    const int h63 = rowget_i32(hv.w, 15), c63 = rowget_i32(cv.w, 15);
+                    QV4 nh = hv, nc = cv;
+                    if (i0 + 0 == bq) { nh.x = ch; nc.x = cc; } else if (i0 + 0 > bq && i0 + 0 <= endq) { nh.x = ph; nc.x = pc; }
+                    if (i0 + 1 == bq) { nh.y = ch; nc.y = cc; } else if (i0 + 1 > bq && i0 + 1 <= endq) { nh.y = hv.x; nc.y = cv.x; }
+                    if (i0 + 2 == bq) { nh.z = ch; nc.z = cc; } else if (i0 + 2 > bq && i0 + 2 <= endq) { nh.z = hv.y; nc.z = cv.y; }
+                    if (i0 + 3 == bq) { nh.w = ch; nc.w = cc; } else if (i0 + 3 > bq && i0 + 3 <= endq) { nh.w = hv.z; nc.w = cv.z; }
+                    if (going && i0 + 3 >= bq && i0 <= endq) {
+                        if (tb + i0 + 3 < cap) { *(QV4 *)(lh + tb + i0) = nh; *(QV4 *)(l3 + tb + i0) = nc; }
+                        else {      // (a list of fewer than four slots: the lane's entries beyond it belong to another list)
+                            if (i0 + 0 >= bq && i0 + 0 <= endq) { lh[tb + i0 + 0] = nh.x; l3[tb + i0 + 0] = nc.x; }
+                            if (i0 + 1 >= bq && i0 + 1 <= endq) { lh[tb + i0 + 1] = nh.y; l3[tb + i0 + 1] = nc.y; }
+                            if (i0 + 2 >= bq && i0 + 2 <= endq) { lh[tb + i0 + 2] = nh.z; l3[tb + i0 + 2] = nc.z; }
+                            if (i0 + 3 >= bq && i0 + 3 <= endq) { lh[tb + i0 + 3] = nh.w; l3[tb + i0 + 3] = nc.w; }
+                        }
                     }
-                    WSYNC();
-                    hi_ = blo;
+                    const bool cont = going && endq == 64;
+                    if (going && n > 64 && rl == 0) lt[tb >> 6] = tsum + cc - (cont ? c63 : 0);
+                    if (cont) { ch = h63; cc = c63; b = tb + 64; }
+                    else if (going) { if (zq >= 64) nn += 1; going = false; }
                 }
-                if (ins_ok && rl == 0) { lh[posn] = hap; lc[posn] = 0; ln[posn] = delta; l3[posn] = delta; s_nocc[op_pi] = n + 1; }
+                if (ins_ok && nn != n && rl == 0) { lc[n] = 0; s_nocc[op_pi] = nn; }
                 WSYNC();
-                if (ins_ok && n == 64) {   // the list outgrows one tile: start its tile sums
+                if (ins_ok && n == 64 && nn == 65) {   // the list outgrows one tile: start its tile sums
                     int64_t s0 = 0;
-                    for (int c4 = 0; c4 < 4; ++c4) s0 += rowget_i64(row_iscan(ln[c4 * 16 + rl]), 15);
-                    if (rl == 0) { lt[0] = s0; lt[1] = ln[64]; }
+                    for (int c4 = 0; c4 < 4; ++c4) s0 += rowget_i64(row_iscan((int64_t)l3[c4 * 16 + rl]), 15);
+                    if (rl == 0) { lt[0] = s0; lt[1] = l3[64]; }
                 }
-                WSYNC();
-            }
-            if (__builtin_expect(__ballot(rem) != 0, 0)) {
-                enum { SU = 4 };
-                int lo_ = rem ? posn + 1 : 0;
-                const int hi_ = rem ? n : 0;
-                while (__ballot(lo_ < hi_)) {
-                    int h[SU];
-                    int64_t ct[SU];
-#pragma unroll
-                    for (int u = 0; u < SU; ++u) {
-                        const int k = lo_ + u * 16 + rl;
-                        h[u] = 0; ct[u] = 0;
-                        if (k < hi_) { h[u] = lh[k]; ct[u] = ln[k]; }
-                    }
-                    WSYNC();
-#pragma unroll
-                    for (int u = 0; u < SU; ++u) {
-                        const int k = lo_ + u * 16 + rl;
-                        if (k < hi_) { lh[k - 1] = h[u]; ln[k - 1] = ct[u]; l3[k - 1] = (int32_t)ct[u]; }
-                    }
-                    WSYNC();
-                    lo_ += SU * 16;
-                }
-                if (rem && rl == 0) s_nocc[op_pi] = n - 1;
                 WSYNC();
             }
         }
 
+        QPROF(10);
         // ================= Events.AddEvent (events.pxi:37-44) =================
         if (err == 0 && e_type >= 0) {
             if (a.record_events) {
@@ -659,6 +714,7 @@ static __device__ __forceinline__ void quadf_body(const VgxDirectArgs &a, const 
             ev_ptr += 1;
         }
 
+        QPROF(11);
         // ================= UpdateRates for [u_lo, u_hi) (pyx:516-546) / UpdateAllRates (pyx:279-351), order-free =================
         if (err != 0) u_hi = u_lo;
         const int maxu = rows_max(u_hi - u_lo);
@@ -715,6 +771,7 @@ static __device__ __forceinline__ void quadf_body(const VgxDirectArgs &a, const 
                 st = ST_DONE;
             }
         }
+        QPROF(13);
         if (__builtin_expect(__ballot(st == ST_REBUILD && restarts > 0 && !rebuild) != 0, 0)) {
             const bool rs = st == ST_REBUILD && restarts > 0 && !rebuild && live;
             int64_t g = 0;
@@ -799,10 +856,29 @@ static __device__ __forceinline__ void quadf_body(const VgxDirectArgs &a, const 
             sc->loc_n = 0; sc->error = err; sc->traj_next = traj_next;
             sc->last_attempt = last_att; sc->last_attempt_loops = att_loops;
             sc->fa_n = 0;
+#ifdef VGX_PROFILE
+            for (int i = 0; i < VGX_PROF_SLOTS; ++i) r.prof[rep * VGX_PROF_SLOTS + i] = prof_acc[i];
+#endif
         }
     }
 }
 
+
+// After the event loop: zero-count entries leave the lists, the tile sums and the 8-byte counts (the loop keeps the 4-byte ones only)
+// are rewritten; one list per 16-lane row.
+extern "C" __global__ void __launch_bounds__(256) vgx_lists_settle_kernel(int32_t *lhap, int32_t *c32, int64_t *c64, int64_t *ltsum, int32_t *nocc,
+                                                                           int64_t lists, int64_t cap, int64_t capT) {
+    const int64_t li = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+    const int rl = threadIdx.x & 15;
+    const bool on = li < lists;
+    const int64_t l = on ? li : 0;
+    const int n = on ? nocc[l] : 0;
+    const int nn = q_compact_list(lhap + l * cap, c32 + l * cap, ltsum + l * capT, n, on);
+    if (on) {
+        for (int k = rl; k < nn; k += 16) c64[l * cap + k] = c32[l * cap + k];
+        if (rl == 0) nocc[l] = nn;
+    }
+}
 
 extern "C" __global__ void __launch_bounds__(64, 3) vgx_quadf_kernel(VgxDirectArgs a, QFArgs qa) { quadf_body(a, qa); }
 
@@ -816,5 +892,8 @@ extern "C" __attribute__((visibility("hidden"))) hipError_t vgxi_launch_quadf(co
     qa.effMig = effMig; qa.maxEBM = maxEBM; qa.has_mig = has_mig;
     const unsigned grid = (unsigned)((a->n_replicates + 3) / 4);
     hipLaunchKernelGGL(vgx_quadf_kernel, dim3(grid), dim3(64), Q_LDS_BYTES, stream, *a, qa);
+    const int64_t lists = (int64_t)a->n_replicates * a->p.P;
+    hipLaunchKernelGGL(vgx_lists_settle_kernel, dim3((unsigned)((lists + 15) / 16)), dim3(256), 0, stream, a->r.lhap, a->r.lcnt32, a->r.lcnt,
+                       a->r.ltsum, a->r.nocc, lists, (int64_t)a->r.cap, (int64_t)a->r.capT);
     return hipGetLastError();
 }
