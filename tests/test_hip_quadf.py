@@ -71,3 +71,41 @@ def test_fast_row_kernel_config3_vs_sparse_oracle(oracle_mod, seed, mut, n):
     ref = _c3(seed, mut).simulation
     assert oracle_mod.run_direct(ref, n, 10 ** 9, -1, 200, sparse=True) == 0
     _assert_tier_b(hip.simulation, ref, "config3 seed %d" % seed)
+
+
+def test_fast_row_kernel_spread_occupancy_zero_count_entries_and_continuation():
+    """Long occupancy lists with many counts of 1 (removals leave zero-count entries, insertions ripple to the next free slot
+    across tiles, the lists are settled after every launch): integer columns and the final compartments equal the exact row
+    kernel's over three launches, the middle one by the exact kernel on the lists the FAST launch left."""
+    from vgsim_amd.ensemble import Ensemble
+    sim = _c3(2020)
+    m = sim.simulation
+    rng = np.random.default_rng(5)
+    occ = [700, 3, 64, 65, 130, 17, 16, 1000] + [int(v) for v in rng.integers(1, 400, size=56)]
+    for pn in range(64):
+        haps = rng.choice(m.hapNum, size=occ[pn], replace=False)
+        if pn == 4:
+            haps[0] = m.hapNum - 1
+        m.infectious[pn, haps] = rng.integers(1, 3, size=occ[pn])
+        m.susceptible[pn, 0] -= int(m.infectious[pn].sum())
+    m.set_mutation_rate(0.2, None, None)
+    R = 7
+    seeds = 900 + np.arange(R, dtype=np.int64)
+    plan = [(3000, "fast"), (1500, "exact"), (3000, "fast")]
+    ens = Ensemble(sim, R, seeds=seeds)
+    got = []
+    for n_ev, mode in plan:
+        res = ens.simulate(n_ev, sample_size=10 ** 9, record_events=True, kernel="quad", mode=mode)
+        got.append((res.events.copy(), [ens.replicate_events(r) for r in range(R)], [ens.replicate_state(r) for r in range(R)]))
+    ens.close()
+    ens = Ensemble(sim, R, seeds=seeds)
+    for (n_ev, _), (events, chains, states) in zip(plan, got):
+        res = ens.simulate(n_ev, sample_size=10 ** 9, record_events=True, kernel="quad", mode="exact")
+        assert np.array_equal(res.events, events)
+        for r in range(R):
+            want = ens.replicate_events(r)
+            assert np.array_equal(chains[r][1:], want[1:]), "replicate %d: %s" % (r, helpers.describe_first_diff(chains[r][1:], want[1:], want.shape[1]))
+            np.testing.assert_allclose(chains[r][0], want[0], rtol=RTOL_TIME, atol=0.0)
+            sw = ens.replicate_state(r)
+            assert np.array_equal(states[r].infectious, sw.infectious) and np.array_equal(states[r].susceptible, sw.susceptible)
+    ens.close()

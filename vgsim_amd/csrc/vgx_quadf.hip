@@ -136,7 +136,7 @@ static __device__ __forceinline__ QCount q_count_select(const int32_t *lh2, cons
 
 // A row squeezes the zero-count entries out of its list (in place, tile by tile) and rewrites the tile sums; returns the new length.
 // Rows with on = false pass through (all rows of the wavefront must call).
-static __device__ __forceinline__ int q_compact_list(int32_t *lh, int32_t *l3, int64_t *lt, int n, bool on) {
+static __device__ __forceinline__ int q_compact_list(int32_t *lh, int32_t *l3, int64_t *lt, int n, bool on, int64_t *c64 = nullptr) {
     const int rl = threadIdx.x & 15;
     const int maxn = rows_max(on ? n : 0);
     int out = 0;
@@ -151,13 +151,14 @@ static __device__ __forceinline__ int q_compact_list(int32_t *lh, int32_t *l3, i
         const int incl = row_iscan32(cnt);
         WSYNC();
         int pos = out + incl - cnt;
-        if (k0) { lh[pos] = hv.x; l3[pos] = cv.x; pos += 1; }
-        if (k1) { lh[pos] = hv.y; l3[pos] = cv.y; pos += 1; }
-        if (k2) { lh[pos] = hv.z; l3[pos] = cv.z; pos += 1; }
-        if (k3) { lh[pos] = hv.w; l3[pos] = cv.w; pos += 1; }
-        out += rowget_i32(incl, 15);
-        WSYNC();
+        const bool moved = pos != tb + 4 * rl || cnt != 4;      // (an untouched chunk of four stays where it is)
+        if (k0) { if (moved) { lh[pos] = hv.x; l3[pos] = cv.x; } if (c64) c64[pos] = cv.x; pos += 1; }
+        if (k1) { if (moved) { lh[pos] = hv.y; l3[pos] = cv.y; } if (c64) c64[pos] = cv.y; pos += 1; }
+        if (k2) { if (moved) { lh[pos] = hv.z; l3[pos] = cv.z; } if (c64) c64[pos] = cv.z; pos += 1; }
+        if (k3) { if (moved) { lh[pos] = hv.w; l3[pos] = cv.w; } if (c64) c64[pos] = cv.w; pos += 1; }
+        out += rowget_i32(incl, 15);      // (the next tile's loads lie above everything stored here)
     }
+    WSYNC();
     const int nn = on ? out : 0;
     const int maxn2 = rows_max(nn);
     if (maxn2 > 64) {
@@ -869,15 +870,11 @@ static __device__ __forceinline__ void quadf_body(const VgxDirectArgs &a, const 
 extern "C" __global__ void __launch_bounds__(256) vgx_lists_settle_kernel(int32_t *lhap, int32_t *c32, int64_t *c64, int64_t *ltsum, int32_t *nocc,
                                                                            int64_t lists, int64_t cap, int64_t capT) {
     const int64_t li = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
-    const int rl = threadIdx.x & 15;
     const bool on = li < lists;
     const int64_t l = on ? li : 0;
     const int n = on ? nocc[l] : 0;
-    const int nn = q_compact_list(lhap + l * cap, c32 + l * cap, ltsum + l * capT, n, on);
-    if (on) {
-        for (int k = rl; k < nn; k += 16) c64[l * cap + k] = c32[l * cap + k];
-        if (rl == 0) nocc[l] = nn;
-    }
+    const int nn = q_compact_list(lhap + l * cap, c32 + l * cap, ltsum + l * capT, n, on, c64 + l * cap);
+    if (on && (threadIdx.x & 15) == 0) nocc[l] = nn;
 }
 
 extern "C" __global__ void __launch_bounds__(64, 3) vgx_quadf_kernel(VgxDirectArgs a, QFArgs qa) { quadf_body(a, qa); }
