@@ -1,10 +1,11 @@
-"""Turns gpurun_out/prof_r02/ (tools/collect_profiles.sh) into the committed artefacts under profiles/: kernel-stats CSVs,
-the raw PMC rows, and the JSON files bench.py reads for its `traffic` fields."""
+"""Turns gpurun_out/prof_r03/ (tools/collect_profiles.sh) into the committed artefacts under profiles/: kernel-stats CSVs,
+the raw PMC rows, the SQ summary, and the JSON files bench.py reads for its `traffic` fields."""
 import collections, csv, glob, json, os, shutil, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = os.path.join(ROOT, "gpurun_out", "prof_r02")
+TAG = "r03"
+SRC = os.path.join(ROOT, "gpurun_out", "prof_" + TAG)
 DST = os.path.join(ROOT, "profiles")
-TAG = "r02"
+LEGS = ("headline", "spread_occupancy", "spread_occupancy_fast", "tau_leap", "fast_mode", "table3", "tau_small")
 
 
 def one(pattern):
@@ -13,66 +14,120 @@ def one(pattern):
     return f[0]
 
 
-def pmc(leg, counter):
-    """counter KiB and dispatch count per kernel name"""
-    agg = collections.defaultdict(lambda: [0.0, 0])
+def pmc(leg, counter, big=False):
+    """counter KiB and dispatch count per kernel name; big=True: only the launches within a factor 2 of the kernel's largest
+    (a leg may also run the kernel on a single trajectory)"""
+    per = collections.defaultdict(lambda: collections.defaultdict(float))
     for r in csv.DictReader(open(one("%s_%s/*/*counter_collection.csv" % (leg, "fetch" if counter == "FETCH_SIZE" else "write")))):
         if r["Counter_Name"] == counter:
-            a = agg[r["Kernel_Name"]]
-            a[0] += float(r["Counter_Value"]); a[1] += 1
+            per[r["Kernel_Name"]][r["Dispatch_Id"]] += float(r["Counter_Value"])
+    agg = collections.defaultdict(lambda: [0.0, 0])
+    for k, d in per.items():
+        top = max(d.values())
+        vals = [v for v in d.values() if not big or v >= 0.5 * top]
+        agg[k] = [sum(vals), len(vals)]
     return agg
+
+
+def sq(leg):
+    """SQ counters per kernel, per launch (tools/sq_summary.py's reduction)"""
+    agg = collections.defaultdict(lambda: collections.defaultdict(float))
+    launches = collections.Counter()
+    seen = set()
+    for f in glob.glob(os.path.join(SRC, "%s_sq/*/*counter_collection.csv" % leg)):
+        for r in csv.DictReader(open(f)):
+            k = r["Kernel_Name"]
+            if "vgx_" not in k:
+                continue
+            agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
+            if (k, r["Dispatch_Id"]) not in seen:
+                seen.add((k, r["Dispatch_Id"])); launches[k] += 1
+    out = {}
+    for k, c in agg.items():
+        w = max(c.get("SQ_WAVES", 1.0), 1.0)
+        wc = c.get("SQ_WAVE_CYCLES", 0.0)
+        d = {"launches": launches[k], "waves_per_launch": c.get("SQ_WAVES", 0) / launches[k], "valu_per_wave": c.get("SQ_INSTS_VALU", 0) / w,
+             "salu_per_wave": c.get("SQ_INSTS_SALU", 0) / w, "lds_per_wave": c.get("SQ_INSTS_LDS", 0) / w}
+        if wc:
+            d.update({"wait_any_frac": c.get("SQ_WAIT_ANY", 0) / wc, "wait_inst_any_frac": c.get("SQ_WAIT_INST_ANY", 0) / wc,
+                      "active_inst_any_frac": c.get("SQ_ACTIVE_INST_ANY", 0) / wc,
+                      "wave_cycles_per_wave": 4.0 * wc / w})      # SQ_*_CYCLES count quad-cycles (MI355X_MICROARCH.md)
+        out[k] = d
+    return out
 
 
 CORR = ("gfx950: FETCH_SIZE counts 64 B per 128-B read request (MI355X_MICROARCH.md, HBM section) -> doubled; WRITE_SIZE taken as is; "
         "both in KiB; separate rocprofv3 --pmc passes with --kernel-trace only")
-for leg in ("headline", "spread_occupancy", "spread_occupancy_fast", "tau_leap"):
+have = [leg for leg in LEGS if glob.glob(os.path.join(SRC, "%s_stats/*/*kernel_stats.csv" % leg))]
+sq_all = {}
+for leg in have:
     shutil.copy(one("%s_stats/*/*kernel_stats.csv" % leg), os.path.join(DST, "%s_%s_kernel_stats.csv" % (TAG, leg)))
-    for c in ("fetch", "write"):
-        shutil.copy(one("%s_%s/*/*counter_collection.csv" % (leg, c)), os.path.join(DST, "%s_%s_pmc_%s.csv" % (TAG, leg, c.upper())))
-    # the JSON line each profiled run printed
+    for c in ("fetch", "write", "sq"):
+        f = glob.glob(os.path.join(SRC, "%s_%s/*/*counter_collection.csv" % (leg, c)))
+        if f:
+            shutil.copy(f[0], os.path.join(DST, "%s_%s_pmc_%s.csv" % (TAG, leg, c.upper())))
     log = open(os.path.join(SRC, "%s_stats.log" % leg)).read().splitlines()
     js = [ln for ln in log if ln.startswith("{")]
     if js:
         open(os.path.join(DST, "%s_%s_under_rocprof.json" % (TAG, leg)), "w").write(js[-1] + "\n")
+    s = sq(leg)
+    if s:
+        sq_all[leg] = s
+json.dump({"source": "rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU "
+                     "SQ_INSTS_SALU SQ_INSTS_LDS, one pass per bench leg (tools/collect_profiles.sh), round 3; raw rows in profiles/r03_*_pmc_SQ.csv",
+           "legs": sq_all}, open(os.path.join(DST, "%s_sq_counters.json" % TAG), "w"), indent=1)
 
-direct = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE, round 2; raw rows in profiles/r02_*_pmc_*.csv; round-1 values in git history",
+direct = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE, round 3; raw rows in profiles/r03_*_pmc_*.csv; earlier rounds' values in git history",
           "correction": CORR}
+HEAD = "python3 bench.py --no-cpu-baseline --no-tau --no-extra --steps 3 --warmup 1"
 for leg, kernel, cmd, cfg in (
-        ("headline", "vgx_quad_kernel", "python3 bench.py --no-cpu-baseline --no-tau --no-extra --steps 3 --warmup 1",
-         {"replicates_per_gpu": 16384, "events_per_replicate": 100000, "trajectory_points": 1001}),
+        ("headline", "vgx_quad_kernel", HEAD, {"replicates_per_gpu": 16384, "events_per_replicate": 100000, "trajectory_points": 1001}),
         ("spread_occupancy", "vgx_quad_long_kernel", "python3 bench.py --only spread_occupancy",
          {"replicates_per_gpu": 8192, "events_per_replicate": 2500, "occupied": 4096, "mode": "exact"}),
-        ("spread_occupancy_fast", "vgx_direct_fast_kernel_p64s1", "python3 bench.py --only spread_occupancy_fast",
-         {"replicates_per_gpu": 4096, "events_per_replicate": 20000, "occupied": 4096, "mode": "fast"})):
-    f, w = pmc(leg, "FETCH_SIZE")[kernel], pmc(leg, "WRITE_SIZE")[kernel]
-    assert f[1] == w[1] and f[1] > 0
+        ("spread_occupancy_fast", "vgx_quadf_kernel", "python3 bench.py --only spread_occupancy_fast",
+         {"replicates_per_gpu": 12288, "events_per_replicate": 10000, "occupied": 4096, "mode": "fast"}),
+        ("fast_mode", "vgx_quadf_kernel", "python3 bench.py --only fast_mode", {"replicates_per_gpu": 24576, "events_per_replicate": 100000, "mode": "fast"}),
+        ("table3", "vgx_quadg_kernel_p16", "python3 bench.py --only table3 --no-cpu-baseline --table3-cells 10:0.001",
+         {"replicates_per_gpu": 16384, "events_per_replicate": 50000, "K": 10, "M": 0.001})):
+    if leg not in have:
+        continue
+    fa, wa = pmc(leg, "FETCH_SIZE", True), pmc(leg, "WRITE_SIZE", True)
+    # the largest launches of the kernel (a leg may also run it on a small ensemble: fast_mode, table3)
+    f, w = fa[kernel], wa[kernel]
+    assert f[1] == w[1] and f[1] > 0, (leg, kernel, sorted(fa))
     direct[leg] = {"command": cmd, "config": cfg, "kernel": kernel, "launches": f[1], "FETCH_SIZE_KiB_per_launch": f[0] / f[1],
                    "WRITE_SIZE_KiB_per_launch": w[0] / w[1], "hbm_bytes_per_launch": (2.0 * f[0] / f[1] + w[0] / w[1]) * 1024}
 json.dump(direct, open(os.path.join(DST, "pmc_direct_c3.json"), "w"), indent=1)
 
-steps = 20
-fk, wk = pmc("tau_leap", "FETCH_SIZE"), pmc("tau_leap", "WRITE_SIZE")
-kern = {}
-tot = 0.0
-for k in sorted(set(fk) | set(wk)):
-    if "vgx_tau" not in k:   # (template instances are listed as "void vgx_tau_...<...>(VgxTauArgs)")
-        continue
-    rb, wb = 2.0 * fk[k][0] * 1024 / steps, wk[k][0] * 1024 / steps
-    kern[k] = {"launches": fk[k][1], "read_bytes_per_step": rb, "write_bytes_per_step": wb}
-    tot += rb + wb
-old = json.load(open(os.path.join(DST, "pmc_tau_c4.json")))
-hist = old.get("history", {})
-if isinstance(hist, dict):
-    hist = dict(hist)
+if "tau_leap" in have:
+    fk, wk = pmc("tau_leap", "FETCH_SIZE"), pmc("tau_leap", "WRITE_SIZE")
+    # steps actually run by the leg: every step launches the drift pass once
+    steps = max(v[1] for k, v in fk.items() if "drift8" in k)
+    kern = {}
+    tot = 0.0
+    for k in sorted(set(fk) | set(wk)):
+        if "vgx_tau" not in k:   # (template instances are listed as "void vgx_tau_...<...>(VgxTauArgs)")
+            continue
+        rb, wb = 2.0 * fk[k][0] * 1024 / steps, wk[k][0] * 1024 / steps
+        kern[k] = {"launches": fk[k][1], "read_bytes_per_step": rb, "write_bytes_per_step": wb}
+        tot += rb + wb
+    old = json.load(open(os.path.join(DST, "pmc_tau_c4.json")))
+    hist = dict(old.get("history", {}))
     prev = old.get("hbm_bytes_per_step")
     if prev and abs(prev - tot) > 1e6 and prev not in hist.values():
-        hist["before this collection (%s)" % TAG] = prev   # rename by hand to what that kernel set was
-json.dump({"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes, csv), command: python3 bench.py --only tau_leap "
-                     "(config 4, 20 steps), round 2; raw rows in profiles/r02_tau_leap_pmc_*.csv",
-           "correction": CORR, "config": {"steps": steps, "per_cell": 3}, "steps": steps, "kernels": kern,
-           "hbm_bytes_per_step": tot, "history": hist}, open(os.path.join(DST, "pmc_tau_c4.json"), "w"), indent=1)
-print("headline %.3g B/launch, spread %.3g, spread_fast %.3g, tau %.3g B/step" % (
-    direct["headline"]["hbm_bytes_per_launch"], direct["spread_occupancy"]["hbm_bytes_per_launch"],
-    direct["spread_occupancy_fast"]["hbm_bytes_per_launch"], tot))
-for k, v in sorted(kern.items(), key=lambda kv: -(kv[1]["read_bytes_per_step"] + kv[1]["write_bytes_per_step"]))[:8]:
-    print("  %-30s %6.2f GB/step" % (k, (v["read_bytes_per_step"] + v["write_bytes_per_step"]) / 1e9))
+        hist["round 2 (count passes on the 8-byte counts)"] = prev
+    json.dump({"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes, csv), command: python3 bench.py --only tau_leap "
+                         "(config 4: the timed 20 steps and the call of 200 steps), round 3; raw rows in profiles/r03_tau_leap_pmc_*.csv",
+               "correction": CORR, "config": {"steps": 20, "per_cell": 3}, "steps_profiled": steps,
+               "note": "per-step averages over every step the leg runs (its timed call of 20 steps and its call of 200 steps)", "kernels": kern,
+               "hbm_bytes_per_step": tot, "history": hist}, open(os.path.join(DST, "pmc_tau_c4.json"), "w"), indent=1)
+    print("tau %.3g B/step over %d steps" % (tot, steps))
+    for k, v in sorted(kern.items(), key=lambda kv: -(kv[1]["read_bytes_per_step"] + kv[1]["write_bytes_per_step"]))[:8]:
+        print("  %-60s %6.2f GB/step" % (k[:60], (v["read_bytes_per_step"] + v["write_bytes_per_step"]) / 1e9))
+for leg in direct:
+    if isinstance(direct[leg], dict):
+        print("%-24s %.3g B/launch" % (leg, direct[leg]["hbm_bytes_per_launch"]))
+for leg, s in sq_all.items():
+    for k, d in s.items():
+        if d["waves_per_launch"] > 256:
+            print("%-22s %-40s valu/wave %.3g active %.2f wait %.2f" % (leg, k[:40], d["valu_per_wave"], d.get("active_inst_any_frac", 0), d.get("wait_any_frac", 0)))
