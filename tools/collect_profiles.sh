@@ -6,7 +6,7 @@ cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/prof_r03
 mkdir -p $O
-run() { name=$1; shift; echo "== $name" ; "$@" > $O/$name.log 2>&1; echo "   rc=$?"; }
+run() { name=$1; shift; echo "== $name" ; "$@" > $O/$name.log 2>&1; echo "   rc=$?"; find $O/$name -name "*kernel_trace.csv" -delete 2>/dev/null; }   # (gpurun copies back at most 64 MiB)
 HEAD="--no-cpu-baseline --no-tau --no-extra --steps 3 --warmup 1"
 LEGS=${LEGS:-"spread_occupancy spread_occupancy_fast tau_leap fast_mode table3 tau_small"}
 if [ -z "${SKIP_HEAD:-}" ]; then
@@ -22,8 +22,10 @@ for leg in $LEGS; do
   EXTRA=""
   if [ "$leg" = table3 ]; then EXTRA="--no-cpu-baseline --table3-cells 10:0.001"; fi
   run ${leg}_stats rocprofv3 --kernel-trace --stats --output-format csv -d $O/${leg}_stats -- python3 bench.py --only $leg $EXTRA
+  if [ "$leg" = tau_small ]; then continue; fi      # (tens of thousands of launches: the stats pass only)
   run ${leg}_fetch rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/${leg}_fetch -- python3 bench.py --only $leg $EXTRA
   run ${leg}_write rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/${leg}_write -- python3 bench.py --only $leg $EXTRA
   run ${leg}_sq rocprofv3 --kernel-trace --pmc $SQ --output-format csv -d $O/${leg}_sq -- python3 bench.py --only $leg $EXTRA
 done
+du -sh $O
 echo done

@@ -135,44 +135,67 @@ static __device__ __forceinline__ QCount q_count_select(const int32_t *lh2, cons
 }
 
 // A row squeezes the zero-count entries out of its list (in place, tile by tile) and rewrites the tile sums; returns the new length.
-// Rows with on = false pass through (all rows of the wavefront must call).
+// Rows with on = false pass through (all rows of the wavefront must call).  UN tiles are loaded before any of them is stored (the
+// stores of a tile never reach beyond it, so the later tiles may already be in registers); c64: the 8-byte counts are written too.
+struct __attribute__((aligned(16))) QL2 { int64_t a, b; };
+template <int UN>
 static __device__ __forceinline__ int q_compact_list(int32_t *lh, int32_t *l3, int64_t *lt, int n, bool on, int64_t *c64 = nullptr) {
     const int rl = threadIdx.x & 15;
     const int maxn = rows_max(on ? n : 0);
     int out = 0;
-    for (int tb = 0; tb < maxn; tb += 64) {
-        const bool in = on && tb < n;
-        QV4 hv = {0, 0, 0, 0}, cv = {0, 0, 0, 0};
-        if (in) { hv = *(const QV4 *)(lh + tb + 4 * rl); cv = *(const QV4 *)(l3 + tb + 4 * rl); }
-        const int e0 = tb + 4 * rl;
-        const bool k0 = in && e0 + 0 < n && cv.x != 0, k1 = in && e0 + 1 < n && cv.y != 0, k2 = in && e0 + 2 < n && cv.z != 0,
-                   k3 = in && e0 + 3 < n && cv.w != 0;
-        const int cnt = (int)k0 + (int)k1 + (int)k2 + (int)k3;
-        const int incl = row_iscan32(cnt);
+    for (int tb0 = 0; tb0 < maxn; tb0 += 64 * UN) {
+        QV4 hv[UN], cv[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int tb = tb0 + 64 * u;
+            hv[u] = QV4{0, 0, 0, 0}; cv[u] = QV4{0, 0, 0, 0};
+            if (on && tb < n) { hv[u] = *(const QV4 *)(lh + tb + 4 * rl); cv[u] = *(const QV4 *)(l3 + tb + 4 * rl); }
+        }
         WSYNC();
-        int pos = out + incl - cnt;
-        const bool moved = pos != tb + 4 * rl || cnt != 4;      // (an untouched chunk of four stays where it is)
-        if (k0) { if (moved) { lh[pos] = hv.x; l3[pos] = cv.x; } if (c64) c64[pos] = cv.x; pos += 1; }
-        if (k1) { if (moved) { lh[pos] = hv.y; l3[pos] = cv.y; } if (c64) c64[pos] = cv.y; pos += 1; }
-        if (k2) { if (moved) { lh[pos] = hv.z; l3[pos] = cv.z; } if (c64) c64[pos] = cv.z; pos += 1; }
-        if (k3) { if (moved) { lh[pos] = hv.w; l3[pos] = cv.w; } if (c64) c64[pos] = cv.w; pos += 1; }
-        out += rowget_i32(incl, 15);      // (the next tile's loads lie above everything stored here)
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int tb = tb0 + 64 * u;
+            const bool in = on && tb < n;
+            const int e0 = tb + 4 * rl;
+            const bool k0 = in && e0 + 0 < n && cv[u].x != 0, k1 = in && e0 + 1 < n && cv[u].y != 0, k2 = in && e0 + 2 < n && cv[u].z != 0,
+                       k3 = in && e0 + 3 < n && cv[u].w != 0;
+            const int cnt = (int)k0 + (int)k1 + (int)k2 + (int)k3;
+            const int incl = row_iscan32(cnt);
+            int pos = out + incl - cnt;
+            if (cnt == 4 && pos == e0) {      // an untouched chunk of four stays where it is
+                if (c64) { *(QL2 *)(c64 + pos) = QL2{cv[u].x, cv[u].y}; *(QL2 *)(c64 + pos + 2) = QL2{cv[u].z, cv[u].w}; }
+            } else {
+                if (k0) { lh[pos] = hv[u].x; l3[pos] = cv[u].x; if (c64) c64[pos] = cv[u].x; pos += 1; }
+                if (k1) { lh[pos] = hv[u].y; l3[pos] = cv[u].y; if (c64) c64[pos] = cv[u].y; pos += 1; }
+                if (k2) { lh[pos] = hv[u].z; l3[pos] = cv[u].z; if (c64) c64[pos] = cv[u].z; pos += 1; }
+                if (k3) { lh[pos] = hv[u].w; l3[pos] = cv[u].w; if (c64) c64[pos] = cv[u].w; pos += 1; }
+            }
+            out += rowget_i32(incl, 15);
+        }
     }
     WSYNC();
     const int nn = on ? out : 0;
-    const int maxn2 = rows_max(nn);
-    if (maxn2 > 64) {
-        for (int tb = 0; tb < maxn2; tb += 64) {
-            const bool in = on && nn > 64 && tb < nn;
-            QV4 cv = {0, 0, 0, 0};
-            if (in) cv = *(const QV4 *)(l3 + tb + 4 * rl);
-            const int e0 = tb + 4 * rl;
-            const int sm = (e0 + 0 < nn ? cv.x : 0) + (e0 + 1 < nn ? cv.y : 0) + (e0 + 2 < nn ? cv.z : 0) + (e0 + 3 < nn ? cv.w : 0);
-            const int tot = rowget_i32(row_iscan32(sm), 15);
-            if (in && rl == 0) lt[tb >> 6] = tot;
+    // the tile sums (maintained by the event loop while nothing moves: rewritten only for lists that lost entries)
+    const bool redo = on && nn != n && nn > 64;
+    const int maxn2 = rows_max(redo ? nn : 0);
+    for (int tb0 = 0; tb0 < maxn2; tb0 += 64 * UN) {
+        QV4 cv[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int tb = tb0 + 64 * u;
+            cv[u] = QV4{0, 0, 0, 0};
+            if (redo && tb < nn) cv[u] = *(const QV4 *)(l3 + tb + 4 * rl);
         }
-        WSYNC();
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int tb = tb0 + 64 * u;
+            const int e0 = tb + 4 * rl;
+            const int sm = (e0 + 0 < nn ? cv[u].x : 0) + (e0 + 1 < nn ? cv[u].y : 0) + (e0 + 2 < nn ? cv[u].z : 0) + (e0 + 3 < nn ? cv[u].w : 0);
+            const int tot = rowget_i32(row_iscan32(sm), 15);
+            if (redo && tb < nn && rl == 0) lt[tb >> 6] = tot;
+        }
     }
+    WSYNC();
     return nn;
 }
 
@@ -586,7 +609,7 @@ static __device__ __forceinline__ void quadf_body(const VgxDirectArgs &a, const 
             int64_t *lt = ltsum + (int64_t)op_pi * capT;
             if (__builtin_expect(__ballot(act && n >= cap && cap < H) != 0, 0)) {   // a full list: squeeze its zero-count entries out first
                 const bool cm = act && n >= cap && cap < H;
-                const int n2 = q_compact_list(lh, l3, lt, n, cm);
+                const int n2 = q_compact_list<1>(lh, l3, lt, n, cm);
                 if (cm) { n = n2; if (rl == 0) s_nocc[op_pi] = n2; }
                 WSYNC();
             }
@@ -873,7 +896,7 @@ extern "C" __global__ void __launch_bounds__(256) vgx_lists_settle_kernel(int32_
     const bool on = li < lists;
     const int64_t l = on ? li : 0;
     const int n = on ? nocc[l] : 0;
-    const int nn = q_compact_list(lhap + l * cap, c32 + l * cap, ltsum + l * capT, n, on, c64 + l * cap);
+    const int nn = q_compact_list<4>(lhap + l * cap, c32 + l * cap, ltsum + l * capT, n, on, c64 + l * cap);
     if (on && (threadIdx.x & 15) == 0) nocc[l] = nn;
 }
 
