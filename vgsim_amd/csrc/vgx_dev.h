@@ -87,7 +87,8 @@ struct VgxDevRep {
     int64_t *lcnt;       // [R][P][cap]
     int32_t *lcnt32;     // [R][P][cap] the same counts in 4 bytes (population sizes < 2^31), kept by vgx_quad.hip for its streaming passes; or null
     int64_t cap;
-    int64_t *ltsum;      // [R][P][capT] sum of the counts of every 64-entry tile of the list (0 beyond the list)
+    int64_t *ltsum;      // [R][P][capT] sum of the counts of every 64-entry tile of the list (0 beyond the list); behind it, [R][P][capT] doubles:
+                         // exact row kernel, long lists: running sum of hapPopRate at the end of every tile as of the last refresh
     int64_t capT;        // cap / 64 + 1
     // initial state for Restart (pyx:714-738), one copy shared by the replicates
     const int32_t *i_nocc;   // [P]

@@ -113,7 +113,7 @@ struct QSel { int k_hit, hap_hit, err; double pre_hit, w_hit; int64_t cnt_hit; }
 // Called with all lanes active.
 template <int QT>
 static __device__ __forceinline__ void q_long_select(const int32_t *ln, const int32_t *lh, int n_sel, int maxn, double tE,
-                                                               double r2, bool evn, int H, QSel &o) {
+                                                               double r2, bool evn, int H, QSel &o, const double *ltp) {
     const int rl = threadIdx.x & 15;
     o.k_hit = -1; o.err = 0;
     // long lists: the running sum advances one tile of 64 entries per step; the tile in which it first reaches r is
@@ -126,6 +126,36 @@ static __device__ __forceinline__ void q_long_select(const int32_t *ln, const in
     // tiles that lie inside the list of EVERY row that has one: no bounds to look at (a row without a list adds zeros)
     const int full = -rows_max(n_sel > 0 ? -n_sel : -0x7fffffff) >> 6;
     const double tEz = n_sel > 0 ? tE : 0.0;
+    if (QT >= 4) {
+        // The tile by the running sums the last refresh of this population left at the end of every tile (q_long_sum: the same
+        // additions in the same order as the loop below would make, on the same counts and the same tE): lane l looks at tiles
+        // 4l .. 4l+3 of a group of 64.  Rows whose list fits one tile have nothing cached: their tile is scanned below.
+        const int ntc = nt > 1 ? nt : 0;
+        const int maxtc = rows_max(ntc);
+        const int lastc = max(ntc - 1, 0);
+        double gcarry = 0.0;          // the running sum at the end of the previous group
+        for (int tb = 0; tb < maxtc; tb += 64) {
+            const int j0 = tb + 4 * rl;
+            const double q0 = ltp[min(j0 + 0, lastc)], q1 = ltp[min(j0 + 1, lastc)], q2 = ltp[min(j0 + 2, lastc)], q3 = ltp[min(j0 + 3, lastc)];
+            const int kk = (j0 + 0 < ntc && !(q0 < r2)) ? 0 : (j0 + 1 < ntc && !(q1 < r2)) ? 1 : (j0 + 2 < ntc && !(q2 < r2)) ? 2
+                         : (j0 + 3 < ntc && !(q3 < r2)) ? 3 : 4;
+            const int q = row_min(t_hit < 0 && kk < 4 ? 4 * rl + kk : 64);
+            double pl = q3;            // the lane below's last tile
+            {
+                const int lo = VGX_DPP_SHR(__double2loint(q3), 1), hi = VGX_DPP_SHR(__double2hiint(q3), 1);
+                pl = rl == 0 ? gcarry : __hiloint2double(hi, lo);
+            }
+            if (t_hit < 0 && q < 64) {
+                const int k = q & 3;
+                t_hit = tb + q;
+                carry_hit = rowget_f64(k == 0 ? pl : k == 1 ? q0 : k == 2 ? q1 : q2, q >> 2);
+            }
+            gcarry = rowget_f64(q3, 15);
+            if (!__ballot(ntc > tb + 64 && t_hit < 0)) break;
+        }
+        if (ntc > 0) carry = ltp[lastc];                   // no hit: the total of the whole list
+        else if (n_sel > 0) { t_hit = 0; carry_hit = 0.0; }
+    } else {
 #pragma unroll
     for (int d = 0; d < QT; ++d) buf[d] = tile_load(ln, d < nt ? d : 0, rl);
     for (int tb = 0; tb < maxt; tb += QT) {
@@ -148,6 +178,7 @@ static __device__ __forceinline__ void q_long_select(const int32_t *ln, const in
         }
         if (!__ballot(nt > tb + QT && t_hit < 0)) break;
     }
+    }
     // refine inside the hit tile (rows without a hit look at their last tile for the H-1 rule)
     const int tt = t_hit >= 0 ? t_hit : max((n_sel - 1) >> 6, 0);
     const QTile c = tile_load(ln, tt, rl);
@@ -169,7 +200,8 @@ static __device__ __forceinline__ void q_long_select(const int32_t *ln, const in
     const double psel = qj == 0 ? p0 : qj == 1 ? p1 : qj == 2 ? p2 : p3;
     const double wsel = qj == 0 ? w0 : qj == 1 ? w1 : qj == 2 ? w2 : w3;
     const int64_t csel = (int64_t)(qj == 0 ? c.c0 : qj == 1 ? c.c1 : qj == 2 ? c.c2 : c.c3);
-    o.pre_hit = q < 64 ? rowget_f64(psel, ql) : carry;     // no hit: the total of the whole list
+    // no hit: the total of the whole list (a one-tile list of the cached form: the end of this scan)
+    o.pre_hit = q < 64 ? rowget_f64(psel, ql) : (QT >= 4 && nt <= 1) ? rowget_f64(p3, 15) : carry;
     o.w_hit = rowget_f64(wsel, ql);
     o.cnt_hit = rowget_i64(csel, ql);
     o.hap_hit = lh[min(tt * 64 + qe, max(n_sel - 1, 0))];
@@ -182,7 +214,7 @@ static __device__ __forceinline__ void q_long_select(const int32_t *ln, const in
 
 // infectPopRate over a list longer than 64 entries (pyx:519-528)
 template <int QT>
-static __device__ __forceinline__ double q_long_sum(const int32_t *ln, int n, int maxn, double tE) {
+static __device__ __forceinline__ double q_long_sum(const int32_t *ln, int n, int maxn, double tE, double *ltp) {
     const int rl = threadIdx.x & 15;
     double acc = 0.0;
     QTile buf[QT];
@@ -207,6 +239,7 @@ static __device__ __forceinline__ double q_long_sum(const int32_t *ln, int n, in
                 w2 = e0 + 2 < n ? tE * (double)c.c2 : 0.0; w3 = e0 + 3 < n ? tE * (double)c.c3 : 0.0;
             }
             acc = row_sum64(w0, w1, w2, w3, acc);
+            if (QT >= 4 && t < nt && rl == (t & 15)) ltp[t] = acc;      // for the next haplotype choice in this population (q_long_select)
         }
     }
     return acc;
@@ -544,7 +577,7 @@ static __device__ __forceinline__ void quad_body(const VgxDirectArgs &a, const Q
                 }
             } else {
                 QSel sel;
-                q_long_select<QT>(l3, lh, n_sel, maxn, tE, r2, evn, H, sel);
+                q_long_select<QT>(l3, lh, n_sel, maxn, tE, r2, evn, H, sel, (double *)(ltsum + (int64_t)pi * capT + R * P * capT))   /* the cached running sums lie behind the tile sums (vgx_dev.h) */;
                 k_hit = sel.k_hit; pre_hit = sel.pre_hit; w_hit = sel.w_hit; hap_hit = sel.hap_hit; cnt_hit = sel.cnt_hit;
                 if (sel.err) err = sel.err;
             }
@@ -965,7 +998,7 @@ static __device__ __forceinline__ void quad_body(const VgxDirectArgs &a, const Q
                     for (int c = 0; c < 4; ++c)
                         if (c < nch) acc = row_sum16(c * 16 + rl < n ? tE * (double)cn4[c] : 0.0, acc);
                 } else {
-                    acc = q_long_sum<QT>(l3, n, maxn, tE);
+                    acc = q_long_sum<QT>(l3, n, maxn, tE, (double *)(ltsum + (int64_t)pi * capT + R * P * capT))   /* the cached running sums lie behind the tile sums (vgx_dev.h) */;
                 }
                 if (act && rl == 0) { s_bc[pi] = bC; s_inf[pi] = acc; }
                 WSYNC();
@@ -1124,7 +1157,7 @@ static __device__ __forceinline__ void quad_body(const VgxDirectArgs &a, const Q
 #endif
 extern "C" __global__ void __launch_bounds__(64, VGX_QUAD_WAVES) vgx_quad_kernel(VgxDirectArgs a, QArgs qa) { quad_body<VGX_QT_SHORT>(a, qa); }
 #ifndef VGX_QT_LONG
-#define VGX_QT_LONG 5
+#define VGX_QT_LONG 7     // (254 VGPRs, no spill; 5: 1.31e8, 7: 1.33e8 events/s at 4096-entry lists)
 #endif
 extern "C" __global__ void __launch_bounds__(64, VGX_QUAD_WAVES) vgx_quad_long_kernel(VgxDirectArgs a, QArgs qa) { quad_body<VGX_QT_LONG>(a, qa); }
 
