@@ -109,3 +109,60 @@ def test_fast_row_kernel_spread_occupancy_zero_count_entries_and_continuation():
             sw = ens.replicate_state(r)
             assert np.array_equal(states[r].infectious, sw.infectious) and np.array_equal(states[r].susceptible, sw.susceptible)
     ens.close()
+
+
+def test_fast_row_kernel_one_haplotype_several_populations(oracle_mod):
+    """Lists of ONE slot (no sites) filled by migrants: insertions into lists shorter than a lane's four entries."""
+    from vgsim_amd import Simulator
+
+    def build(seed):
+        with helpers.quiet():
+            s = Simulator(number_of_sites=0, populations_number=3, number_of_susceptible_groups=1, seed=seed)
+        s.set_transmission_rate(3.0); s.set_recovery_rate(1.0); s.set_sampling_rate(0.2)
+        s.set_population_size(5000); s.set_total_migration_probability(0.2)
+        return s
+    for seed in (5, 6, 7):
+        hip = build(seed)
+        with helpers.quiet():
+            hip.simulate(6000, sample_size=10 ** 9, kernel="quad", mode="fast")
+        ref = build(seed).simulation
+        assert oracle_mod.run_direct(ref, 6000, 10 ** 9, -1, 200) == 0
+        _assert_tier_b(hip.simulation, ref, "one haplotype, seed %d" % seed)
+        assert ref.migPlus > 0
+
+
+def test_fast_row_kernel_squeezes_a_full_list(oracle_mod, monkeypatch):
+    """List capacity forced down to 192 entries (VGX_LIST_CAP): with a high mutation rate the lists fill up with zero-count
+    entries, the kernel squeezes them out in place when an insertion finds the list full, and the run equals the exact
+    kernel's with the default capacity."""
+    from vgsim_amd.ensemble import Ensemble
+
+    def run(mode, cap):
+        if cap:
+            monkeypatch.setenv("VGX_LIST_CAP", str(cap))
+        else:
+            monkeypatch.delenv("VGX_LIST_CAP", raising=False)
+        sim = _c3(2020)
+        m = sim.simulation
+        rng = np.random.default_rng(11)
+        for pn in range(64):
+            haps = rng.choice(m.hapNum, size=100, replace=False)
+            m.infectious[pn, haps] = 1
+            m.susceptible[pn, 0] -= 100
+        sim.set_transmission_rate(1.0)        # balanced: about a hundred occupied haplotypes per population throughout
+        m.set_mutation_rate(0.6, None, None)
+        R = 5
+        ens = Ensemble(sim, R, seeds=300 + np.arange(R, dtype=np.int64))
+        # 1250 events per population, two thirds of them mutations: every one leaves a zero-count entry, and an insertion behind the
+        # list's last zero-count entry appends, so the lists reach the 192 slots several times over
+        res = ens.simulate(80000, sample_size=10 ** 9, record_events=True, kernel="quad", mode=mode)
+        out = (res.events.copy(), [ens.replicate_events(r) for r in range(R)], [ens.replicate_state(r) for r in range(R)])
+        ens.close()
+        return out
+    ev_f, ch_f, st_f = run("fast", 192)
+    ev_e, ch_e, st_e = run("exact", 0)
+    assert np.array_equal(ev_f, ev_e)
+    for r in range(len(ch_f)):
+        assert np.array_equal(ch_f[r][1:], ch_e[r][1:]), "replicate %d" % r
+        assert np.array_equal(st_f[r].infectious, st_e[r].infectious)
+        assert (st_f[r].infectious != 0).sum(axis=1).max() <= 192

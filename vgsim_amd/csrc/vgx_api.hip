@@ -640,6 +640,10 @@ static int init_device_state(vgx_engine *e, int64_t traj_points) {
     const double reusable = (double)(e->r_lhap.bytes + e->r_lcls.bytes + e->r_lcnt.bytes + e->r_lcnt32.bytes);
     const double list_bytes = std::min(((double)free_b + reusable) * 0.45, 32.0 * 1073741824.0);
     int64_t budget = (int64_t)(list_bytes / (double)(R * P * 24));
+    if (const char *lc = getenv("VGX_LIST_CAP")) {     // diagnostics / tests: a small list capacity (the overflow paths of the kernels)
+        const long long v = atoll(lc);
+        if (v > 0) budget = std::min<int64_t>(budget, (int64_t)v);
+    }
     int64_t cap = std::min<int64_t>(H, std::max<int64_t>(budget, 64));
     cap = std::max(cap, std::min<int64_t>(H, need + 64));
     if (cap < H) cap = std::max<int64_t>((cap / 64) * 64, ((need + 63) / 64) * 64);
