@@ -43,6 +43,15 @@ def test_fast_integer_columns_match_oracle(oracle_mod, name):
     _assert_tier_b(hip, ref, name)
 
 
+@pytest.mark.parametrize("name", DIRECT)
+def test_fast_wave_kernel_integer_columns_match_oracle(oracle_mod, name):
+    """The one-replicate-per-wavefront kernel's FAST path forced for every case (the automatic choice gives the one-class cases to
+    the FAST row kernel, vgx_quadf.hip, at every ensemble size since round 3)."""
+    hip = helpers.run_case_hip(name, mode="fast", kernel="wave").simulation
+    ref = helpers.run_case_oracle(oracle_mod, name).simulation
+    _assert_tier_b(hip, ref, name)
+
+
 def test_fast_ensemble_matches_exact_ensemble():
     """Replicate ensembles: FAST and EXACT agree on every replicate's counters and final compartments."""
     from vgsim_amd import Simulator

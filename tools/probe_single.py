@@ -13,7 +13,7 @@ def c2():
     return s
 for name, mk in (("table3 K=2", lambda: bench.make_table3(2, 0.001)), ("table3 K=10", lambda: bench.make_table3(10, 0.001)),
                  ("config2", c2), ("config3", lambda: bench.make_simulator(2020))):
-    for kernel in ("wave", "quadg", "lane"):
+    for kernel in (sys.argv[1:] or ["wave", "quad", "quadg", "lane"]):
         for R in (1, 4):
             try:
                 ens = Ensemble(mk(), R)

@@ -865,10 +865,11 @@ static int direct_core(vgx_engine *e, int64_t iterations, int64_t sample_size, f
     if (o.kernel == 4 && !quadg_ok)
         return fail(e, VGX_ERR_ARG, "vgx_simulate_direct: the general four-replicates-per-wavefront kernel needs exact mode, no "
                                     "recombination, popNum <= 128, susNum <= 8, at most 64 rate classes and 16 transmission/susceptibility classes");
-    // measured (tools/probe_quad.py): a lone wavefront runs one replicate faster than four (1.4e5 vs 1.1e5 events/s per
-    // replicate at config 3), so the row kernels pay from about one wavefront per SIMD upwards
-    const bool use_quad = (o.kernel == 3 && quad_ok) || (o.kernel == 0 && quad_ok && !use_lanes && R >= 2048);
-    const bool use_quadf = (o.kernel == 3 && quadf_ok) || (o.kernel == 0 && quadf_ok && R >= 2048);
+    // measured (tools/probe_single.py, round 3): the row kernels lead at every ensemble size, a single trajectory included —
+    // config 2: 2.9e5 events/s against 2.0e5 on the one-replicate-per-wavefront kernel, config 3: 1.75e5 against 1.26e5; four
+    // replicates in one wavefront: 1.1e6 / 5.9e5 against 7.9e5 / 4.9e5 in four wavefronts
+    const bool use_quad = (o.kernel == 3 && quad_ok) || (o.kernel == 0 && quad_ok && !use_lanes);
+    const bool use_quadf = (o.kernel == 3 && quadf_ok) || (o.kernel == 0 && quadf_ok);
     // The general form also for FEW replicates of models with up to 16 populations (one register slot): a wavefront running alone
     // does a Table-3 trajectory at 1.7e5 events/s there against 1.0e5 on the one-replicate-per-wavefront kernel
     // (tools/probe_single.py; at 64 populations the wave kernel leads, 1.25e5 against 0.94e5).
