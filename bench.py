@@ -155,12 +155,10 @@ def spread_leg(device, mode="exact", replicates=1024, events=20000, occupied=409
     nocc = float((st.infectious != 0).sum(axis=1).mean())
     ms = best.kernel_ms
     ev = best.total_events
-    # exact, one rate class, four-replicates-per-wavefront kernel: the 4-byte counts of the whole list for the rate refresh, which
-    # leaves the running sum at the end of every tile (8 B per 64 entries written, read back by the next choice) + one tile of
-    # counts for the choice; the wave kernel (fewer than 2048 replicates) streams the 8-byte counts, half the list again for the
-    # choice.  fast: tile sums + one tile (4-byte counts and haplotypes)
-    row = replicates >= 2048
-    exact_bytes = 4.0 * nocc + 16.0 * (nocc / 64.0) + 4.0 * 64 if row else 1.5 * 8.0 * nocc
+    # exact, one rate class, long-list row kernel: the ONE-BYTE counts of the whole list for the rate refresh, which leaves the
+    # running sum at the end of every tile (8 B per 64 entries written, read back by the next choice) + one tile of 4-byte counts
+    # for the choice.  fast: tile sums + one tile (4-byte counts and haplotypes)
+    exact_bytes = 1.0 * nocc + 16.0 * (nocc / 64.0) + 4.0 * 64
     bpe = (exact_bytes if mode == "exact" else 8.0 * (nocc / 64.0) + 8.0 * 64) + 8.0 * POPS + 28.0 + 8.0
     traffic = pmc_traffic("spread_occupancy" if mode == "exact" else "spread_occupancy_fast",
                           {"replicates_per_gpu": replicates, "events_per_replicate": events, "occupied": occupied, "mode": mode})
@@ -173,9 +171,9 @@ def spread_leg(device, mode="exact", replicates=1024, events=20000, occupied=409
     if mode == "exact":
         # per event: the refreshed population's whole list (pyx:519-528), on average half of the selected population's
         # list (fast_choose.pxi:22-25), the popRate and migPopRate totals (pyx:537-546)
-        rows = 4 if replicates >= 2048 else 1     # vgx_quad.hip: every chain instruction serves four replicates
-        # row kernel: the choice starts at the tile the cached running sums point to (64 steps instead of half the list)
-        steps = (1.0 * nocc + 64.0 if rows == 4 else 1.5 * nocc) + 2.0 * POPS
+        rows = 4     # vgx_quad.hip: every chain instruction serves four replicates
+        # the choice starts at the tile the cached running sums point to (64 steps instead of half the list)
+        steps = 1.0 * nocc + 64.0 + 2.0 * POPS
         out["chain_bound"] = {"bound": "dependent f64 additions in the reference's order (one v_fmac_f64 per term)",
                               "steps_per_event": steps, "achieved": ev * steps / (ms * 1e-3), "peak": CHAIN_STEPS_PER_S * rows,
                               "unit": "chain steps/s", "frac": ev * steps / (ms * 1e-3) / (CHAIN_STEPS_PER_S * rows),
@@ -697,7 +695,7 @@ def main():
     R, N = a.replicates, a.events
     H = 4 ** SITES
     extra_legs = (("fast_mode", lambda d: fast_leg(d, R, N, a.traj_points)),
-                  ("spread_occupancy", lambda d: spread_leg(d, "exact", replicates=8192, events=2500)),
+                  ("spread_occupancy", lambda d: spread_leg(d, "exact", replicates=8192, events=10000)),
                   ("spread_occupancy_fast", lambda d: spread_leg(d, "fast", replicates=12288, events=10000)),
                   ("config2", c2_leg), ("genealogy", genealogy_leg), ("single_trajectory", single_leg),
                   ("direct_config4_shape", c4_direct_leg), ("table3", lambda d: table3_leg(d, cpu=not a.no_cpu_baseline, cells=cells3)),

@@ -6,6 +6,7 @@ import numpy as np
 import bench
 from vgsim_amd.ensemble import Ensemble
 R, N, lo, hi, occ = (int(x) for x in sys.argv[1:6])
+mode = sys.argv[6] if len(sys.argv) > 6 else "fast"     # "exact": the stamps of vgx_quad(_long)_kernel
 sim = bench.make_simulator(2020)
 m = sim.simulation
 if occ:
@@ -15,7 +16,7 @@ if occ:
         m.infectious[pn, haps] = rng.integers(lo, hi, size=occ)
         m.susceptible[pn, 0] -= int(m.infectious[pn].sum())
 ens = Ensemble(sim, R)
-res = ens.simulate(N, sample_size=10 ** 12, record_events=True, traj_points=0, mode="fast")
+res = ens.simulate(N, sample_size=10 ** 12, record_events=True, traj_points=0, mode=mode)
 tot = np.zeros(16)
 eng = ens.engine
 for rep in range(0, R, 4 * 37):
@@ -24,6 +25,9 @@ for rep in range(0, R, 4 * 37):
     tot += out
 names = ["loop top", "-", "front+rng+time", "pop select", "hap select", "class+apply", "mutation+migration", "sync", "lower bound", "tile sums",
          "shift", "add event", "-", "rates+tail", "-", "-"]
+if mode == "exact":
+    names = ["loop top", "front", "rng", "time+traj", "pop select", "hap select", "class+apply", "mutation", "migration", "list ops", "add event",
+             "birth rate", "row sum", "cum scan", "mig sum", "tail"]
 iters = res.loop_iterations[::4 * 37].sum()
 print("%.3e ev/s, %.1f ms; cycles per wave-iteration: %.0f" % (res.total_events / (res.kernel_ms * 1e-3), res.kernel_ms, tot.sum() / iters))
 for n, v in zip(names, tot):

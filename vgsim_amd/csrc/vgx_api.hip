@@ -663,7 +663,7 @@ static int init_device_state(vgx_engine *e, int64_t traj_points) {
     rc |= ensure(e, e->r_lcls, (size_t)(R * P * cap) * 4);
     rc |= ensure(e, e->r_lcnt, (size_t)(R * P * cap + 64) * 8);   // + one tile: vgx_quad.hip reads whole 64-entry tiles
     const bool want32 = P <= 64 && S == 1 && e->C == 1 && e->CB == 1;   // shapes the four-replicates-per-wavefront kernel takes
-    if (want32) rc |= ensure(e, e->r_lcnt32, (size_t)(R * P * cap + 64) * 4);
+    if (want32) rc |= ensure(e, e->r_lcnt32, (size_t)(R * P * cap + 64) * 4 + (size_t)(R * P * cap) + 128);   // + the one-byte copy of vgx_quad_long_kernel
     const int64_t capT = cap / 64 + 1;
     rc |= ensure(e, e->r_ltsum, (size_t)(R * P * capT) * 16 + 64);   // tile sums, then the exact row kernel's cached running sums
     rc |= ensure(e, e->r_sc, (size_t)R * sizeof(VgxRepScalars));

@@ -27,6 +27,7 @@
 #include "vgx_rng.h"
 #include "vgx_wave.h"
 #include "vgx_rowprim.h"
+#include "vgx_rowlist.h"
 
 #ifndef VGX_QUAD_WAVES
 #define VGX_QUAD_WAVES 2     // waves per SIMD the register allocation aims at (measured: 3 spills into the hot loop and is slower)
@@ -207,21 +208,56 @@ static __device__ __forceinline__ void q_long_select(const int32_t *ln, const in
     o.hap_hit = lh[min(tt * 64 + qe, max(n_sel - 1, 0))];
     if (q < 64) o.k_hit = tt * 64 + q;
     else if (evn) {
-        if (n_sel > 0 && o.hap_hit == H - 1) o.k_hit = n_sel - 1; else o.err = Q_ERR_ZERO_WEIGHT + 256 * 3;
+        if (n_sel > 0 && o.hap_hit == H - 1 && (QT < 4 || o.cnt_hit != 0)) o.k_hit = n_sel - 1; else o.err = Q_ERR_ZERO_WEIGHT + 256 * 3;
     }
             
 }
 
 // infectPopRate over a list longer than 64 entries (pyx:519-528)
+// The long-list instantiation (QT >= 4) streams a ONE-BYTE copy of the counts (l8: min(count, 255), kept next to the 4-byte
+// copy by every count update of that kernel): a tile of 64 entries is one 4-byte load per lane, QB8 tiles in flight.  A byte of
+// 255 stands for "255 or more": a row that meets one takes that tile's counts from the 4-byte copy.  The running sum at the end
+// of every tile is left in ltp for the next haplotype choice in this population (q_long_select).
+#define VGX_QB8 8
 template <int QT>
-static __device__ __forceinline__ double q_long_sum(const int32_t *ln, int n, int maxn, double tE, double *ltp) {
+static __device__ __forceinline__ double q_long_sum(const int32_t *ln, const uint8_t *l8, int n, int maxn, double tE, double *ltp) {
     const int rl = threadIdx.x & 15;
     double acc = 0.0;
-    QTile buf[QT];
     const int nt = (n + 63) >> 6, maxt = (maxn + 63) >> 6;
     // tiles that lie inside the list of EVERY row that has one: no bounds to look at (a row without a list adds zeros)
     const int full = -rows_max(n > 0 ? -n : -0x7fffffff) >> 6;
     const double tEz = n > 0 ? tE : 0.0;
+    if (QT >= 4) {
+        uint32_t buf8[VGX_QB8];
+#pragma unroll
+        for (int d = 0; d < VGX_QB8; ++d) buf8[d] = *(const uint32_t *)(l8 + (int64_t)(d < nt ? d : 0) * 64 + 4 * rl);
+        for (int tb = 0; tb < maxt; tb += VGX_QB8) {
+#pragma unroll
+            for (int d = 0; d < VGX_QB8; ++d) {
+                const int t = tb + d;
+                const uint32_t w = buf8[d];
+                buf8[d] = *(const uint32_t *)(l8 + (int64_t)(t + VGX_QB8 < nt ? t + VGX_QB8 : 0) * 64 + 4 * rl);
+                int c0 = (int)(w & 255u), c1 = (int)((w >> 8) & 255u), c2 = (int)((w >> 16) & 255u), c3 = (int)(w >> 24);
+                const bool sat = t < nt && ((((w & 0x7F7F7F7Fu) + 0x01010101u) & w & 0x80808080u) != 0u);      // some byte == 255
+                if (__builtin_expect(__ballot(sat) != 0, 0)) {
+                    const QTile q = tile_load(ln, t < nt ? t : 0, rl);
+                    if (row_max(sat ? 1 : 0)) { c0 = q.c0; c1 = q.c1; c2 = q.c2; c3 = q.c3; }
+                }
+                double w0, w1, w2, w3;
+                if (t < full) {
+                    w0 = tEz * (double)c0; w1 = tEz * (double)c1; w2 = tEz * (double)c2; w3 = tEz * (double)c3;
+                } else {
+                    const int e0 = t * 64 + 4 * rl;
+                    w0 = e0 + 0 < n ? tE * (double)c0 : 0.0; w1 = e0 + 1 < n ? tE * (double)c1 : 0.0;
+                    w2 = e0 + 2 < n ? tE * (double)c2 : 0.0; w3 = e0 + 3 < n ? tE * (double)c3 : 0.0;
+                }
+                acc = row_sum64(w0, w1, w2, w3, acc);
+                if (t < nt && rl == (t & 15)) ltp[t] = acc;
+            }
+        }
+        return acc;
+    }
+    QTile buf[QT];
 #pragma unroll
     for (int d = 0; d < QT; ++d) buf[d] = tile_load(ln, d < nt ? d : 0, rl);
     for (int tb = 0; tb < maxt; tb += QT) {
@@ -230,16 +266,10 @@ static __device__ __forceinline__ double q_long_sum(const int32_t *ln, int n, in
             const int t = tb + d;
             const QTile c = buf[d];
             buf[d] = tile_load(ln, t + QT < nt ? t + QT : 0, rl);
-            double w0, w1, w2, w3;
-            if (QT >= 4 && t < full) {   // (the short-list instantiation keeps its code small: see VGX_QT_SHORT)
-                w0 = tEz * (double)c.c0; w1 = tEz * (double)c.c1; w2 = tEz * (double)c.c2; w3 = tEz * (double)c.c3;
-            } else {
-                const int e0 = t * 64 + 4 * rl;
-                w0 = e0 + 0 < n ? tE * (double)c.c0 : 0.0; w1 = e0 + 1 < n ? tE * (double)c.c1 : 0.0;
-                w2 = e0 + 2 < n ? tE * (double)c.c2 : 0.0; w3 = e0 + 3 < n ? tE * (double)c.c3 : 0.0;
-            }
+            const int e0 = t * 64 + 4 * rl;
+            const double w0 = e0 + 0 < n ? tE * (double)c.c0 : 0.0, w1 = e0 + 1 < n ? tE * (double)c.c1 : 0.0;
+            const double w2 = e0 + 2 < n ? tE * (double)c.c2 : 0.0, w3 = e0 + 3 < n ? tE * (double)c.c3 : 0.0;
             acc = row_sum64(w0, w1, w2, w3, acc);
-            if (QT >= 4 && t < nt && rl == (t & 15)) ltp[t] = acc;      // for the next haplotype choice in this population (q_long_select)
         }
     }
     return acc;
@@ -339,6 +369,9 @@ static __device__ __forceinline__ void quad_body(const VgxDirectArgs &a, const Q
     int32_t *lcls = r.lcls + rep * P * cap;
     int64_t *lcnt = r.lcnt + rep * P * cap;
     int32_t *lcnt32 = r.lcnt32 + rep * P * cap;   // the same counts in 4 bytes: what the streaming passes over long lists read
+    // ... and in ONE byte (min(count, 255)) behind the 4-byte copies of all replicates: what the long-list kernel's rate refresh streams
+#define L8(pop) ((uint8_t *)(r.lcnt32 + R * P * cap) + (rep * P + (int64_t)(pop)) * cap)
+#define B8(v) ((uint8_t)((v) < 255 ? (v) : 255))
     int64_t *ltsum = r.ltsum + rep * P * capT;
     const bool has_traj = r.traj != nullptr;
     const VgxRepScalars *sc = r.sc + rep;
@@ -534,7 +567,7 @@ static __device__ __forceinline__ void quad_body(const VgxDirectArgs &a, const Q
                     cn4[c] = 0; hp4[c] = 0; w4[c] = 0.0;
                     if (c < nch) {
                         const int k = c * 16 + rl;
-                        cn4[c] = ln[min(k, last)];
+                        cn4[c] = QT >= 4 ? (int64_t)l3[min(k, last)] : ln[min(k, last)];    // (the long-list kernel keeps the 4-byte counts only)
                         hp4[c] = lh[min(k, last)];
                         w4[c] = k < n_sel ? tE * (double)cn4[c] : 0.0;
                     }
@@ -568,7 +601,7 @@ static __device__ __forceinline__ void quad_body(const VgxDirectArgs &a, const Q
                 else if (evn) {
                     // nothing reached r: the dense loop runs on to index H-1 (fc:26), a valid pick only if that haplotype
                     // is occupied, otherwise the reference reports a zero weight
-                    if (n_sel > 0 && hap_hit == H - 1) k_hit = n_sel - 1; else err = Q_ERR_ZERO_WEIGHT + 256 * 2;
+                    if (n_sel > 0 && hap_hit == H - 1 && (QT < 4 || cnt_hit != 0)) k_hit = n_sel - 1; else err = Q_ERR_ZERO_WEIGHT + 256 * 2;
                 }
                 if (evn) {
 #pragma unroll
@@ -605,7 +638,7 @@ static __device__ __forceinline__ void quad_body(const VgxDirectArgs &a, const Q
                 if ((double)ts_pi * c_sig == 0.0) err = Q_ERR_ZERO_WEIGHT + 256 * 6;
                 if (rl == 0) { s_ts[pi] = ts_pi - 1; s_ti[pi] = ti_pi + 1; }
                 gI += 1; QBUMP(QC_B);
-                if (live && rl == 0) { ln[k_hit] = cnt_hit + 1; l3[k_hit] = (int32_t)(cnt_hit + 1); if (n_sel > 64) lt[k_hit >> 6] += 1; }
+                if (live && rl == 0) { if (QT < 4) ln[k_hit] = cnt_hit + 1; l3[k_hit] = (int32_t)(cnt_hit + 1); if (QT >= 4) L8(pi)[k_hit] = B8(cnt_hit + 1); if (n_sel > 64) lt[k_hit >> 6] += 1; }
 #pragma unroll
                 for (int c = 0; c < 4; ++c)
                     if (c == (k_hit >> 4) && rl == (k_hit & 15)) ch_cn[c] += 1;
@@ -617,9 +650,10 @@ static __device__ __forceinline__ void quad_body(const VgxDirectArgs &a, const Q
                 if (rl == 0) { s_ts[pi] = ts_pi + 1; s_ti[pi] = ti_pi - 1; }
                 gI -= 1;
                 if (ei == 2) { cS += 1; e_type = QEV_SAMPLING; } else { QBUMP(QC_D); e_type = QEV_DEATH; }
-                if (cnt_hit == 1) { op_n = 1; op_pi = pi; op_h0 = hap_hit; op_d0 = -1; ch_pi = -1; }
+                // (the long-list kernel leaves a count of 0 in the list: vgx_rowlist.h)
+                if (QT < 4 && cnt_hit == 1) { op_n = 1; op_pi = pi; op_h0 = hap_hit; op_d0 = -1; ch_pi = -1; }
                 else {
-                    if (live && rl == 0) { ln[k_hit] = cnt_hit - 1; l3[k_hit] = (int32_t)(cnt_hit - 1); if (n_sel > 64) lt[k_hit >> 6] -= 1; }
+                    if (live && rl == 0) { if (QT < 4) ln[k_hit] = cnt_hit - 1; l3[k_hit] = (int32_t)(cnt_hit - 1); if (QT >= 4) L8(pi)[k_hit] = B8(cnt_hit - 1); if (n_sel > 64) lt[k_hit >> 6] -= 1; }
 #pragma unroll
                     for (int c = 0; c < 4; ++c)
                         if (c == (k_hit >> 4) && rl == (k_hit & 15)) ch_cn[c] -= 1;
@@ -656,7 +690,12 @@ static __device__ __forceinline__ void quad_body(const VgxDirectArgs &a, const Q
                     const int AS = (hap_hit / digit4) % 4;
                     if (DS >= AS) DS += 1;
                     const int nhi = hap_hit + (DS - AS) * digit4;
-                    op_n = 2; op_pi = pi; op_h0 = nhi; op_d0 = +1; op_h1 = hap_hit; ch_pi = -1;
+                    if (QT >= 4) {      // the source's count drops in place (0 stays in the list), the mutant is the one deferred insertion
+                        if (live && rl == 0) { l3[k_hit] = (int32_t)(cnt_hit - 1); L8(pi)[k_hit] = B8(cnt_hit - 1); if (n_sel > 64) lt[k_hit >> 6] -= 1; }
+                        op_n = 1; op_pi = pi; op_h0 = nhi; op_d0 = +1; ch_pi = -1;
+                    } else {
+                        op_n = 2; op_pi = pi; op_h0 = nhi; op_d0 = +1; op_h1 = hap_hit; ch_pi = -1;
+                    }
                     QBUMP(QC_M);
                     e_type = QEV_MUTATION; e_hap = hap_hit; e_pop = pi; e_nh = nhi; e_np = 0;
                     u_lo = pi; u_hi = pi + 1;
@@ -716,6 +755,8 @@ static __device__ __forceinline__ void quad_body(const VgxDirectArgs &a, const Q
                     const int n = evm ? s_nocc[spi] : 0;
                     const int32_t *lh2 = lhap + (int64_t)spi * cap;
                     const int64_t *ln2 = lcnt + (int64_t)spi * cap;
+                    const int32_t *l32 = lcnt32 + (int64_t)spi * cap;
+#define CN2(k) (QT >= 4 ? (int64_t)l32[k] : ln2[k])      /* (the long-list kernel keeps the 4-byte counts only) */
                     const int64_t *lt2 = ltsum + (int64_t)spi * capT;
                     const double rr_ = (double)s_ti[spi] * rm;
                     int64_t before = 0;
@@ -744,9 +785,9 @@ static __device__ __forceinline__ void quad_body(const VgxDirectArgs &a, const Q
                         for (int c4 = 0; c4 < 4; ++c4) {
                             const int k = base + c4 * 16 + rl;
                             const bool in = !none && k < n;
-                            const int64_t w = in ? ln2[k] : 0;
+                            const int64_t w = in ? CN2(k) : 0;
                             const int64_t pre = row_iscan(w) + carry;
-                            const int q = row_min(kq < 0 && in && !((double)pre < rr_) ? rl : 16);
+                            const int q = row_min(kq < 0 && in && (QT < 4 || w != 0) && !((double)pre < rr_) ? rl : 16);
                             if (kq < 0 && q < 16) { kq = k - rl + q; total = rowget_i64(pre, q); wi = rowget_i64(w, q); }
                             carry = rowget_i64(pre, 15);
                             if (!__ballot(evm && kq < 0 && !none && base + (c4 + 1) * 16 < n)) break;
@@ -754,13 +795,13 @@ static __device__ __forceinline__ void quad_body(const VgxDirectArgs &a, const Q
                         if (kq < 0) total = carry;
                     }
                     if (evm && kq < 0) {
-                        if (n > 0 && lh2[n - 1] == H - 1) { kq = n - 1; wi = ln2[n - 1]; }
+                        if (n > 0 && lh2[n - 1] == H - 1 && (QT < 4 || CN2(n - 1) != 0)) { kq = n - 1; wi = CN2(n - 1); }
                         else {
                             err = Q_ERR_ZERO_WEIGHT + 256 * 11;
                             if (rl == 0 && r.prof) {
                                 unsigned long long *d = r.prof + rep * VGX_PROF_SLOTS;
                                 d[0] = n; d[1] = spi; d[2] = tpi; d[3] = s_ti[spi]; d[4] = __double_as_longlong(rr_); d[5] = __double_as_longlong(rm);
-                                d[6] = total; d[7] = before; d[8] = maxn2; d[9] = gI; d[10] = s_ti[tpi]; d[11] = n > 0 ? ln2[0] : -1;
+                                d[6] = total; d[7] = before; d[8] = maxn2; d[9] = gI; d[10] = s_ti[tpi]; d[11] = n > 0 ? CN2(0) : -1;
                                 d[12] = ev_ptr; d[13] = loops; d[14] = __double_as_longlong(totalMig); d[15] = __double_as_longlong(choose);
                             }
                             kq = 0; wi = 1;
@@ -797,6 +838,18 @@ static __device__ __forceinline__ void quad_body(const VgxDirectArgs &a, const Q
         QPROF(8);
         // ================= deferred list operations: infectious[op_pi, hap] += delta, list kept ordered =================
         if (err != 0) op_n = 0;
+        if (QT >= 4) {      // the long-list kernel: lists with zero-count entries, one deferred insertion at most (vgx_rowlist.h)
+            if (__builtin_expect(__ballot(live && op_n > 0) != 0, 0)) {
+                const bool act = live && op_n > 0;
+                int n = act ? s_nocc[op_pi] : 0;
+                const int n_was = n;
+                const bool fits = q_list_add_one<true>(act, op_h0, lhap + (int64_t)op_pi * cap, lcls + (int64_t)op_pi * cap, lcnt32 + (int64_t)op_pi * cap,
+                                                       ltsum + (int64_t)op_pi * capT, L8(op_pi), n, (int)cap, H);
+                if (act && !fits) err = Q_ERR_CAPACITY;
+                if (act && n != n_was && rl == 0) s_nocc[op_pi] = n;
+                WSYNC();
+            }
+        } else
         for (int oi = 0; oi < 2; ++oi) {
             const bool act = live && oi < op_n;
             if (!__ballot(act)) break;
@@ -840,7 +893,7 @@ static __device__ __forceinline__ void quad_body(const VgxDirectArgs &a, const Q
             const bool ins = act && !found;                           // a new entry (delta = +1)
             if (ins && n >= cap) { err = Q_ERR_CAPACITY; }
             const bool ins_ok = ins && err == 0;
-            if (bump && rl == 0) { ln[posn] = cur + delta; l3[posn] = (int32_t)(cur + delta); if (n > 64) lt[posn >> 6] += delta; }
+            if (bump && rl == 0) { ln[posn] = cur + delta; l3[posn] = (int32_t)(cur + delta); if (QT >= 4) L8(op_pi)[posn] = B8(cur + delta); if (n > 64) lt[posn >> 6] += delta; }
             // ---- tile sums of lists longer than one tile (vgx_direct.hip list_insert_at / list_remove_at) ----
             if (__builtin_expect(__ballot((ins_ok || rem) && n > 64) != 0, 0)) {
                 const bool tt = (ins_ok || rem) && n > 64;
@@ -883,12 +936,12 @@ static __device__ __forceinline__ void quad_body(const VgxDirectArgs &a, const Q
 #pragma unroll
                     for (int u = 0; u < SU; ++u) {
                         const int k = blo + u * 16 + rl;
-                        if (k < hi_) { lh[k + 1] = h[u]; lc[k + 1] = 0; ln[k + 1] = ct[u]; l3[k + 1] = (int32_t)ct[u]; }
+                        if (k < hi_) { lh[k + 1] = h[u]; lc[k + 1] = 0; ln[k + 1] = ct[u]; l3[k + 1] = (int32_t)ct[u]; if (QT >= 4) L8(op_pi)[k + 1] = B8(ct[u]); }
                     }
                     WSYNC();
                     hi_ = blo;
                 }
-                if (ins_ok && rl == 0) { lh[posn] = hap; lc[posn] = 0; ln[posn] = delta; l3[posn] = delta; s_nocc[op_pi] = n + 1; }
+                if (ins_ok && rl == 0) { lh[posn] = hap; lc[posn] = 0; ln[posn] = delta; l3[posn] = delta; if (QT >= 4) L8(op_pi)[posn] = B8(delta); s_nocc[op_pi] = n + 1; }
                 WSYNC();
                 if (ins_ok && n == 64) {   // the list outgrows one tile: start its tile sums
                     int64_t s0 = 0;
@@ -914,7 +967,7 @@ static __device__ __forceinline__ void quad_body(const VgxDirectArgs &a, const Q
 #pragma unroll
                     for (int u = 0; u < SU; ++u) {
                         const int k = lo_ + u * 16 + rl;
-                        if (k < hi_) { lh[k - 1] = h[u]; ln[k - 1] = ct[u]; l3[k - 1] = (int32_t)ct[u]; }
+                        if (k < hi_) { lh[k - 1] = h[u]; ln[k - 1] = ct[u]; l3[k - 1] = (int32_t)ct[u]; if (QT >= 4) L8(op_pi)[k - 1] = B8(ct[u]); }
                     }
                     WSYNC();
                     lo_ += SU * 16;
@@ -992,13 +1045,13 @@ static __device__ __forceinline__ void quad_body(const VgxDirectArgs &a, const Q
                         const int last = max(n - 1, 0);
 #pragma unroll
                         for (int c = 0; c < 4; ++c)
-                            if (c < nch) { const int64_t cl = ln[min(c * 16 + rl, last)]; if (!chave) cn4[c] = cl; }
+                            if (c < nch) { const int64_t cl = QT >= 4 ? (int64_t)l3[min(c * 16 + rl, last)] : ln[min(c * 16 + rl, last)]; if (!chave) cn4[c] = cl; }
                     }
 #pragma unroll
                     for (int c = 0; c < 4; ++c)
                         if (c < nch) acc = row_sum16(c * 16 + rl < n ? tE * (double)cn4[c] : 0.0, acc);
                 } else {
-                    acc = q_long_sum<QT>(l3, n, maxn, tE, (double *)(ltsum + (int64_t)pi * capT + R * P * capT))   /* the cached running sums lie behind the tile sums (vgx_dev.h) */;
+                    acc = q_long_sum<QT>(l3, L8(pi), n, maxn, tE, (double *)(ltsum + (int64_t)pi * capT + R * P * capT));   // (the cached running sums lie behind the tile sums, vgx_dev.h)
                 }
                 if (act && rl == 0) { s_bc[pi] = bC; s_inf[pi] = acc; }
                 WSYNC();
@@ -1079,6 +1132,7 @@ static __device__ __forceinline__ void quad_body(const VgxDirectArgs &a, const Q
                                 lcls[(int64_t)pn * cap + k] = r.i_cls[(int64_t)pn * r.i_cap + k];
                                 lcnt[(int64_t)pn * cap + k] = ct;
                                 lcnt32[(int64_t)pn * cap + k] = (int32_t)ct;
+                                if (QT >= 4) L8(pn)[k] = B8(ct);
                             }
                         }
                         tsum += rowget_i64(row_iscan(ct), 15);
@@ -1170,6 +1224,15 @@ extern "C" __attribute__((visibility("hidden"))) hipError_t vgxi_launch_counts32
     return hipGetLastError();
 }
 
+// The one-byte copy behind the 4-byte one (vgx_quad_long_kernel streams it): before every launch of that kernel.
+extern "C" __global__ void __launch_bounds__(256) vgx_quad_counts8_kernel(const int32_t *c32, uint8_t *c8, int64_t n4) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const int4 v = *(const int4 *)(c32 + 4 * i);
+        *(uint32_t *)(c8 + 4 * i) = (uint32_t)min(max(v.x, 0), 255) | ((uint32_t)min(max(v.y, 0), 255) << 8) | ((uint32_t)min(max(v.z, 0), 255) << 16) |
+                                    ((uint32_t)min(max(v.w, 0), 255) << 24);
+    }
+}
+
 // Summary trajectories as 32-bit integers for the wire (compartment totals are whole numbers below 2^31).
 extern "C" __global__ void __launch_bounds__(256) vgx_traj_i32_kernel(const double *src, int32_t *dst, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) dst[i] = (int32_t)src[i];
@@ -1180,6 +1243,7 @@ extern "C" __attribute__((visibility("hidden"))) hipError_t vgxi_launch_traj_i32
 }
 
 // ---- host-side launchers ----
+extern "C" __attribute__((visibility("hidden"))) hipError_t vgxi_launch_lists_settle(const VgxDirectArgs *a, hipStream_t stream);
 extern "C" __attribute__((visibility("hidden"))) hipError_t vgxi_launch_quad(const VgxDirectArgs *a, const double *cd,
                                                                             double *effMig, double *maxEBM, int32_t *has_mig,
                                                                             int long_lists, hipStream_t stream) {
@@ -1189,7 +1253,14 @@ extern "C" __attribute__((visibility("hidden"))) hipError_t vgxi_launch_quad(con
     QArgs qa;
     qa.effMig = effMig; qa.maxEBM = maxEBM; qa.has_mig = has_mig;
     const unsigned grid = (unsigned)((a->n_replicates + 3) / 4);
-    if (long_lists) hipLaunchKernelGGL(vgx_quad_long_kernel, dim3(grid), dim3(64), Q_LDS_BYTES, stream, *a, qa);
+    if (long_lists) {
+        const int64_t n = (int64_t)a->n_replicates * a->p.P * a->r.cap;      // (list capacities are multiples of 4 from one site on)
+        hipLaunchKernelGGL(vgx_quad_counts8_kernel, dim3(4096), dim3(256), 0, stream, a->r.lcnt32, (uint8_t *)(a->r.lcnt32 + n), (n + 3) / 4);
+        hipLaunchKernelGGL(vgx_quad_long_kernel, dim3(grid), dim3(64), Q_LDS_BYTES, stream, *a, qa);
+        // its lists hold zero-count entries and 4-byte counts only: squeeze, tile sums, 8-byte counts (vgx_quadf.hip)
+        hipError_t e2 = vgxi_launch_lists_settle(a, stream);
+        if (e2 != hipSuccess) return e2;
+    }
     else hipLaunchKernelGGL(vgx_quad_kernel, dim3(grid), dim3(64), Q_LDS_BYTES, stream, *a, qa);
     return hipGetLastError();
 }
