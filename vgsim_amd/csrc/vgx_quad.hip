@@ -218,7 +218,7 @@ static __device__ __forceinline__ void q_long_select(const int32_t *ln, const in
 // copy by every count update of that kernel): a tile of 64 entries is one 4-byte load per lane, QB8 tiles in flight.  A byte of
 // 255 stands for "255 or more": a row that meets one takes that tile's counts from the 4-byte copy.  The running sum at the end
 // of every tile is left in ltp for the next haplotype choice in this population (q_long_select).
-#define VGX_QB8 8
+#define VGX_QB8 6      // (tiles in flight; 4: 1.88e8, 6: 2.00e8, 8: 1.92e8 events/s at 4096-entry lists: the unrolled chains are code)
 template <int QT>
 static __device__ __forceinline__ double q_long_sum(const int32_t *ln, const uint8_t *l8, int n, int maxn, double tE, double *ltp) {
     const int rl = threadIdx.x & 15;
