@@ -83,7 +83,7 @@ HEAD = "python3 bench.py --no-cpu-baseline --no-tau --no-extra --steps 3 --warmu
 for leg, kernel, cmd, cfg in (
         ("headline", "vgx_quad_kernel", HEAD, {"replicates_per_gpu": 16384, "events_per_replicate": 100000, "trajectory_points": 1001}),
         ("spread_occupancy", "vgx_quad_long_kernel", "python3 bench.py --only spread_occupancy",
-         {"replicates_per_gpu": 8192, "events_per_replicate": 2500, "occupied": 4096, "mode": "exact"}),
+         {"replicates_per_gpu": 8192, "events_per_replicate": 10000, "occupied": 4096, "mode": "exact"}),
         ("spread_occupancy_fast", "vgx_quadf_kernel", "python3 bench.py --only spread_occupancy_fast",
          {"replicates_per_gpu": 12288, "events_per_replicate": 10000, "occupied": 4096, "mode": "fast"}),
         ("fast_mode", "vgx_quadf_kernel", "python3 bench.py --only fast_mode", {"replicates_per_gpu": 24576, "events_per_replicate": 100000, "mode": "fast"}),

@@ -33,6 +33,7 @@ extern "C" hipError_t vgxi_launch_lanes(const VgxDirectArgs *a, const VgxLaneWs 
 extern "C" hipError_t vgxi_launch_quad(const VgxDirectArgs *a, const double *cd, double *effMig, double *maxEBM, int32_t *has_mig, int long_lists,
                                        hipStream_t stream);
 extern "C" size_t vgxi_direct_lds_bytes(int P, int S, int C, int CB);
+extern "C" hipError_t vgxi_launch_counts64(const int32_t *c32, int64_t *c64, int64_t n, hipStream_t stream);
 extern "C" hipError_t vgxi_launch_quad_prep(const VgxDevParams *p, const double *cd, double *effMig, double *maxEBM, int32_t *has_mig, hipStream_t stream);
 extern "C" hipError_t vgxi_launch_quadf(const VgxDirectArgs *a, const double *cd, double *effMig, double *maxEBM, int32_t *has_mig, hipStream_t stream);
 extern "C" hipError_t vgxi_launch_taus(const VgxTausArgs *a, hipStream_t s);
@@ -78,6 +79,7 @@ struct vgx_engine {
     void *pin[2] = {nullptr, nullptr};   // pinned staging buffers of large uploads (VGX_PIN_BYTES each), allocated on first use
     hipEvent_t pin_ev[2] = {nullptr, nullptr};
     bool counts32_valid = false;   // r_lcnt32 mirrors r_lcnt (vgx_quad.hip keeps it; other kernels do not)
+    bool counts64_valid = true;    // r_lcnt is current (vgx_quadf.hip and the long-list kernel of vgx_quad.hip keep the 4-byte counts only)
     int C = 0, CB = 0;
     // host copies of what the host needs again
     std::vector<int32_t> cls;
@@ -728,6 +730,7 @@ static int init_device_state(vgx_engine *e, int64_t traj_points) {
     HIPCHECK(e, hipStreamSynchronize(e->stream));  // host vectors above go out of scope
     e->dev_state_valid = true;
     e->counts32_valid = want32;   // (vgx_init_reps_kernel fills both)
+    e->counts64_valid = true;
     (void)traj_points;
     return VGX_OK;
 }
@@ -922,8 +925,15 @@ static int direct_core(vgx_engine *e, int64_t iterations, int64_t sample_size, f
     }
 
     // the 4-byte copy of the counts is kept by the four-replicates-per-wavefront kernel alone
+    // the row kernels with zero-count entries work on the 4-byte counts alone; everything else reads the 8-byte ones
+    const bool leaves32 = use_quadf || (use_quad && e->start_max_nocc > 64);
+    if (!e->counts64_valid && !(leaves32 && e->counts32_valid)) {
+        HIPCHECK(e, vgxi_launch_counts64(e->dr.lcnt32, e->dr.lcnt, R * P * e->cap, e->stream));
+        e->counts64_valid = true;
+    }
     if ((use_quad || use_quadf) && !e->counts32_valid) HIPCHECK(e, vgxi_launch_counts32(e->dr.lcnt, e->dr.lcnt32, R * P * e->cap, e->stream));
     e->counts32_valid = use_quad || use_quadf;
+    if (leaves32) e->counts64_valid = false;
     HIPCHECK(e, hipEventRecord(e->ev0, e->stream));
     if (use_lanes) HIPCHECK(e, vgxi_launch_lanes(&a, &ws, e->stream));
     else if (use_quad) HIPCHECK(e, vgxi_launch_quad(&a, (const double *)e->s_cd.p, (double *)e->r_qeff.p, (double *)e->r_qmebm.p,
@@ -2127,6 +2137,11 @@ extern "C" int vgx_get_state(vgx_engine *e, int64_t replicate, vgx_state *out) {
     if (out->susceptible)
         HIPCHECK(e, hipMemcpy(out->susceptible, (int64_t *)e->r_sus.p + replicate * P * S, (size_t)(P * S) * 8, hipMemcpyDeviceToHost));
     if (out->infectious) {
+        if (!e->counts64_valid) {
+            HIPCHECK(e, vgxi_launch_counts64(e->dr.lcnt32, e->dr.lcnt, e->R * P * cap, e->stream));
+            HIPCHECK(e, hipStreamSynchronize(e->stream));
+            e->counts64_valid = true;
+        }
         std::vector<int32_t> nocc((size_t)P);
         HIPCHECK(e, hipMemcpy(nocc.data(), (int32_t *)e->r_nocc.p + replicate * P, (size_t)P * 4, hipMemcpyDeviceToHost));
         memset(out->infectious, 0, (size_t)(P * H) * 8);

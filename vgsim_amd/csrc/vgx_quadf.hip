@@ -721,7 +721,7 @@ extern "C" __global__ void __launch_bounds__(256) vgx_lists_settle_kernel(int32_
     const bool on = li < lists;
     const int64_t l = on ? li : 0;
     const int n = on ? nocc[l] : 0;
-    const int nn = q_compact_list<4>(lhap + l * cap, c32 + l * cap, ltsum + l * capT, n, on, c64 + l * cap);
+    const int nn = q_compact_list<4>(lhap + l * cap, c32 + l * cap, ltsum + l * capT, n, on, c64 ? c64 + l * cap : nullptr);
     if (on && (threadIdx.x & 15) == 0) nocc[l] = nn;
 }
 
@@ -731,8 +731,17 @@ extern "C" __attribute__((visibility("hidden"))) hipError_t vgxi_launch_quad_pre
                                                                                  double *maxEBM, int32_t *has_mig, hipStream_t stream);
 extern "C" __attribute__((visibility("hidden"))) hipError_t vgxi_launch_lists_settle(const VgxDirectArgs *a, hipStream_t stream) {
     const int64_t lists = (int64_t)a->n_replicates * a->p.P;
-    hipLaunchKernelGGL(vgx_lists_settle_kernel, dim3((unsigned)((lists + 15) / 16)), dim3(256), 0, stream, a->r.lhap, a->r.lcnt32, a->r.lcnt,
+    // (the 8-byte counts are rewritten on demand: vgxi_launch_counts64, the engine's counts64_valid)
+    hipLaunchKernelGGL(vgx_lists_settle_kernel, dim3((unsigned)((lists + 15) / 16)), dim3(256), 0, stream, a->r.lhap, a->r.lcnt32, (int64_t *)nullptr,
                        a->r.ltsum, a->r.nocc, lists, (int64_t)a->r.cap, (int64_t)a->r.capT);
+    return hipGetLastError();
+}
+// The 8-byte counts from the 4-byte ones, for the kernels and the copy-out that read them.
+extern "C" __global__ void __launch_bounds__(256) vgx_counts64_kernel(const int32_t *c32, int64_t *c64, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) c64[i] = c32[i];
+}
+extern "C" __attribute__((visibility("hidden"))) hipError_t vgxi_launch_counts64(const int32_t *c32, int64_t *c64, int64_t n, hipStream_t stream) {
+    hipLaunchKernelGGL(vgx_counts64_kernel, dim3(8192), dim3(256), 0, stream, c32, c64, n);
     return hipGetLastError();
 }
 extern "C" __attribute__((visibility("hidden"))) hipError_t vgxi_launch_quadf(const VgxDirectArgs *a, const double *cd, double *effMig,
