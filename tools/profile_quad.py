@@ -17,5 +17,8 @@ names = ["loop top", "front", "rng", "time+traj", "pop select", "hap select", "c
          "birth rate", "row sum", "cum scan", "mig sum", "tail"]
 iters = res.loop_iterations[::4 * 37].sum()
 print("%.3e ev/s, %.1f ms; cycles per wave-iteration: %.0f" % (res.total_events / (res.kernel_ms * 1e-3), res.kernel_ms, tot.sum() / iters))
+long_iters = tot[15]          # slot 15 counts iterations, not cycles: the haplotype choice took the long-list form
+tot[15] = 0
 for n, v in zip(names, tot):
     print("%-12s %6.1f %%  %8.0f cycles/iteration" % (n, 100 * v / tot.sum(), v / iters))
+print("iterations whose haplotype choice streamed a list of more than 64 entries: %.3f %%" % (100.0 * long_iters / iters))

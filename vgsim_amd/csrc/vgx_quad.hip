@@ -60,7 +60,7 @@ enum { ST_REBUILD = 0, ST_RUN = 1, ST_DONE = 2 };
 //                 accepted / rejected migrations)                                                     4 x 2400
 #define Q_CONST_BYTES 2048
 #define Q_RNG_BYTES 512
-#define Q_REP_BYTES 2400
+#define Q_REP_BYTES 2656
 #define Q_LDS_BYTES (Q_CONST_BYTES + Q_RNG_BYTES + 4 * Q_REP_BYTES)
 enum { QC_B = 0, QC_D, QC_M, QC_MIGP, QC_MIGN };
 
@@ -183,6 +183,7 @@ static __device__ __forceinline__ void q_long_select(const int32_t *ln, const in
     // refine inside the hit tile (rows without a hit look at their last tile for the H-1 rule)
     const int tt = t_hit >= 0 ? t_hit : max((n_sel - 1) >> 6, 0);
     const QTile c = tile_load(ln, tt, rl);
+    const int4 hv = *(const int4 *)(lh + (int64_t)tt * 64 + 4 * rl);     // the haplotypes with the counts (every list is followed by a tile of padding)
     const int e0 = tt * 64 + 4 * rl;
     const double w0 = e0 + 0 < n_sel ? tE * (double)c.c0 : 0.0, w1 = e0 + 1 < n_sel ? tE * (double)c.c1 : 0.0;
     const double w2 = e0 + 2 < n_sel ? tE * (double)c.c2 : 0.0, w3 = e0 + 3 < n_sel ? tE * (double)c.c3 : 0.0;
@@ -205,7 +206,7 @@ static __device__ __forceinline__ void q_long_select(const int32_t *ln, const in
     o.pre_hit = q < 64 ? rowget_f64(psel, ql) : (QT >= 4 && nt <= 1) ? rowget_f64(p3, 15) : carry;
     o.w_hit = rowget_f64(wsel, ql);
     o.cnt_hit = rowget_i64(csel, ql);
-    o.hap_hit = lh[min(tt * 64 + qe, max(n_sel - 1, 0))];
+    o.hap_hit = rowget_i32(qj == 0 ? hv.x : qj == 1 ? hv.y : qj == 2 ? hv.z : hv.w, ql);
     if (q < 64) o.k_hit = tt * 64 + q;
     else if (evn) {
         if (n_sel > 0 && o.hap_hit == H - 1 && (QT < 4 || o.cnt_hit != 0)) o.k_hit = n_sel - 1; else o.err = Q_ERR_ZERO_WEIGHT + 256 * 3;
@@ -237,6 +238,7 @@ static __device__ __forceinline__ double q_long_sum(const int32_t *ln, const uin
                 const int t = tb + d;
                 const uint32_t w = buf8[d];
                 buf8[d] = *(const uint32_t *)(l8 + (int64_t)(t + VGX_QB8 < nt ? t + VGX_QB8 : 0) * 64 + 4 * rl);
+                if (t >= maxt) continue;       // (the group runs past the longest list of the four rows)
                 int c0 = (int)(w & 255u), c1 = (int)((w >> 8) & 255u), c2 = (int)((w >> 16) & 255u), c3 = (int)(w >> 24);
                 const bool sat = t < nt && ((((w & 0x7F7F7F7Fu) + 0x01010101u) & w & 0x80808080u) != 0u);      // some byte == 255
                 if (__builtin_expect(__ballot(sat) != 0, 0)) {
@@ -337,6 +339,7 @@ static __device__ __forceinline__ void quad_body(const VgxDirectArgs &a, const Q
     double *s_cc = (double *)(s_nocc + 64);
     int64_t *s_cnt = (int64_t *)(s_cc + 4);
     uint64_t *s_inc = (uint64_t *)(s_cnt + 6);         // counters use 5 of their 8 slots; the last two hold the PCG64 increment
+    int32_t *s_zero = (int32_t *)(s_inc + 2);           // long-list kernel: zero-count entries in every population's list (vgx_rowlist.h)
 #define QBUMP(i) do { if (rl == 0) s_cnt[i] += 1; } while (0)
 
     // the single rate class
@@ -360,6 +363,7 @@ static __device__ __forceinline__ void quad_body(const VgxDirectArgs &a, const Q
             s_ts[pq] = ok ? gI64[PI_TOTSUS * P + pq] : 0;
             s_ti[pq] = ok ? gI64[PI_TOTINF * P + pq] : 0;
             s_nocc[pq] = ok ? gN[pq] : 0;
+            s_zero[pq] = 0;                 // (the lists arrive settled)
         }
     }
     WSYNC();
@@ -609,6 +613,9 @@ static __device__ __forceinline__ void quad_body(const VgxDirectArgs &a, const Q
                     ch_pi = pi;
                 }
             } else {
+#ifdef VGX_PROFILE
+                prof_acc[15] += 1;       // (diagnostic build: iterations whose haplotype choice took the long-list form)
+#endif
                 QSel sel;
                 q_long_select<QT>(l3, lh, n_sel, maxn, tE, r2, evn, H, sel, (double *)(ltsum + (int64_t)pi * capT + R * P * capT))   /* the cached running sums lie behind the tile sums (vgx_dev.h) */;
                 k_hit = sel.k_hit; pre_hit = sel.pre_hit; w_hit = sel.w_hit; hap_hit = sel.hap_hit; cnt_hit = sel.cnt_hit;
@@ -654,6 +661,7 @@ static __device__ __forceinline__ void quad_body(const VgxDirectArgs &a, const Q
                 if (QT < 4 && cnt_hit == 1) { op_n = 1; op_pi = pi; op_h0 = hap_hit; op_d0 = -1; ch_pi = -1; }
                 else {
                     if (live && rl == 0) { if (QT < 4) ln[k_hit] = cnt_hit - 1; l3[k_hit] = (int32_t)(cnt_hit - 1); if (QT >= 4) L8(pi)[k_hit] = B8(cnt_hit - 1); if (n_sel > 64) lt[k_hit >> 6] -= 1; }
+                    if (QT >= 4 && cnt_hit == 1 && rl == 0) s_zero[pi] += 1;
 #pragma unroll
                     for (int c = 0; c < 4; ++c)
                         if (c == (k_hit >> 4) && rl == (k_hit & 15)) ch_cn[c] -= 1;
@@ -691,7 +699,7 @@ static __device__ __forceinline__ void quad_body(const VgxDirectArgs &a, const Q
                     if (DS >= AS) DS += 1;
                     const int nhi = hap_hit + (DS - AS) * digit4;
                     if (QT >= 4) {      // the source's count drops in place (0 stays in the list), the mutant is the one deferred insertion
-                        if (live && rl == 0) { l3[k_hit] = (int32_t)(cnt_hit - 1); L8(pi)[k_hit] = B8(cnt_hit - 1); if (n_sel > 64) lt[k_hit >> 6] -= 1; }
+                        if (live && rl == 0) { l3[k_hit] = (int32_t)(cnt_hit - 1); L8(pi)[k_hit] = B8(cnt_hit - 1); if (n_sel > 64) lt[k_hit >> 6] -= 1; if (cnt_hit == 1) s_zero[pi] += 1; }
                         op_n = 1; op_pi = pi; op_h0 = nhi; op_d0 = +1; ch_pi = -1;
                     } else {
                         op_n = 2; op_pi = pi; op_h0 = nhi; op_d0 = +1; op_h1 = hap_hit; ch_pi = -1;
@@ -843,11 +851,32 @@ static __device__ __forceinline__ void quad_body(const VgxDirectArgs &a, const Q
                 const bool act = live && op_n > 0;
                 int n = act ? s_nocc[op_pi] : 0;
                 const int n_was = n;
-                const bool fits = q_list_add_one<true>(act, op_h0, lhap + (int64_t)op_pi * cap, lcls + (int64_t)op_pi * cap, lcnt32 + (int64_t)op_pi * cap,
-                                                       ltsum + (int64_t)op_pi * capT, L8(op_pi), n, (int)cap, H);
-                if (act && !fits) err = Q_ERR_CAPACITY;
-                if (act && n != n_was && rl == 0) s_nocc[op_pi] = n;
                 WSYNC();
+                int zeros = act ? s_zero[op_pi] : 0;
+                const int z_was = zeros;
+                const bool fits = q_list_add_one<true>(act, op_h0, lhap + (int64_t)op_pi * cap, lcls + (int64_t)op_pi * cap, lcnt32 + (int64_t)op_pi * cap,
+                                                       ltsum + (int64_t)op_pi * capT, L8(op_pi), n, (int)cap, H, zeros);
+                if (act && !fits) err = Q_ERR_CAPACITY;
+                if (act && rl == 0) { if (n != n_was) s_nocc[op_pi] = n; if (zeros != z_was) s_zero[op_pi] = max(zeros, 0); }
+                WSYNC();
+            }
+            // a list whose zero-count entries pile up (every one is a step of the refresh chain) is squeezed before the refresh below
+            {
+                WSYNC();
+                const int zp = (live && err == 0 && u_hi == u_lo + 1) ? u_lo : -1;      // the population this event changed
+                const int nz = zp >= 0 ? s_zero[zp] : 0, nl = zp >= 0 ? s_nocc[zp] : 0;
+                const bool sq = zp >= 0 && nz > max(16, nl >> 3);
+                if (__builtin_expect(__ballot(sq) != 0, 0)) {
+                    const int zq = sq ? zp : 0;
+                    int32_t *l3z = lcnt32 + (int64_t)zq * cap;
+                    const int n2 = q_compact_list<1>(lhap + (int64_t)zq * cap, l3z, ltsum + (int64_t)zq * capT, nl, sq);
+                    uint8_t *l8z = L8(zq);
+                    const int m8 = rows_max(sq ? n2 : 0);
+                    for (int k = rl; k < m8; k += 16) if (sq && k < n2) l8z[k] = B8(l3z[k]);
+                    if (sq && rl == 0) { s_nocc[zq] = n2; s_zero[zq] = 0; }
+                    if (sq && ch_pi == zq) ch_pi = -1;
+                    WSYNC();
+                }
             }
         } else
         for (int oi = 0; oi < 2; ++oi) {
@@ -1142,7 +1171,7 @@ static __device__ __forceinline__ void quad_body(const VgxDirectArgs &a, const Q
                 }
                 if (rs)
                     for (int j = (n + 63) / 64 + rl; j <= n_old / 64 && j < capT; j += 16) ltsum[(int64_t)pn * capT + j] = 0;
-                if (rs && rl == 0) { s_nocc[pn] = n; s_ts[pn] = r.i_sus[pn]; s_ti[pn] = ti; }
+                if (rs && rl == 0) { s_nocc[pn] = n; s_zero[pn] = 0; s_ts[pn] = r.i_sus[pn]; s_ti[pn] = ti; }
                 g += ti;
             }
             if (rs) gI = g;

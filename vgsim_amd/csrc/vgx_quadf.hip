@@ -533,8 +533,9 @@ static __device__ __forceinline__ void quadf_body(const VgxDirectArgs &a, const 
             const int hap = op_h0;
             int n = act ? s_nocc[op_pi] : 0;
             const int n_was = n;
+            int zeros_unused = 0;
             const bool fits = q_list_add_one<false>(act, hap, lhap + (int64_t)op_pi * cap, lcls + (int64_t)op_pi * cap, lcnt32 + (int64_t)op_pi * cap,
-                                                    ltsum + (int64_t)op_pi * capT, nullptr, n, (int)cap, H);
+                                                    ltsum + (int64_t)op_pi * capT, nullptr, n, (int)cap, H, zeros_unused);
             if (act && !fits) err = Q_ERR_CAPACITY;
             if (act && n != n_was && rl == 0) s_nocc[op_pi] = n;
             WSYNC();

@@ -83,10 +83,11 @@ static __device__ __forceinline__ int q_compact_list(int32_t *lh, int32_t *l3, i
 // infectious[population of the lists given, hap] += 1 for the rows with `act` (a mutant or a migrant arrives).  lh / lc / l3 / lt:
 // the population's haplotypes, rate classes (all 0 in these kernels), 4-byte counts and tile sums; l8 (BYTE8): its one-byte counts
 // (min(count, 255)).  n: the list's length incl. zero-count entries, updated.  Returns false where the list is full (cap < H and no
-// zero-count entry left to squeeze out).
+// zero-count entry left to squeeze out).  zeros: the number of zero-count entries the caller believes the list holds (kept up to
+// date here: -1 when the arrival takes one, 0 after a squeeze).
 template <bool BYTE8>
 static __device__ __forceinline__ bool q_list_add_one(bool act, int hap, int32_t *lh, int32_t *lc, int32_t *l3, int64_t *lt, uint8_t *l8,
-                                                      int &n, int cap, int H) {
+                                                      int &n, int cap, int H, int &zeros) {
     const int rl = threadIdx.x & 15;
     const int delta = 1;
     bool ok = true;
@@ -97,7 +98,7 @@ static __device__ __forceinline__ bool q_list_add_one(bool act, int hap, int32_t
             const int m8 = rows_max(cm ? n2 : 0);
             for (int k = rl; k < m8; k += 16) if (cm && k < n2) l8[k] = (uint8_t)min(l3[k], 255);
         }
-        if (cm) n = n2;
+        if (cm) { n = n2; zeros = 0; }
         WSYNC();
     }
     // ---- lower bound: first index whose haplotype is >= hap ----
@@ -143,6 +144,7 @@ static __device__ __forceinline__ bool q_list_add_one(bool act, int hap, int32_t
     const bool ins = act && !found;                           // a new entry
     if (ins && n >= cap) ok = false;
     const bool ins_ok = ins && ok;
+    if (bump && cur == 0) zeros -= 1;
     if (bump && rl == 0) {
         l3[posn] = cur + delta;
         if (BYTE8) l8[posn] = (uint8_t)min(cur + delta, 255);
@@ -189,7 +191,7 @@ static __device__ __forceinline__ bool q_list_add_one(bool act, int hap, int32_t
             const bool cont = going && endq == 64;
             if (going && n > 64 && rl == 0) lt[tb >> 6] = tsum + cc - (cont ? c63 : 0);
             if (cont) { ch = h63; cc = c63; b = tb + 64; }
-            else if (going) { if (zq >= 64) nn += 1; going = false; }
+            else if (going) { if (zq >= 64) nn += 1; else zeros -= 1; going = false; }
         }
         if (ins_ok && nn != n && rl == 0) lc[n] = 0;
         WSYNC();
