@@ -79,21 +79,21 @@ static __device__ __forceinline__ double row_sum64(double w0, double w1, double 
                  : "v"(w0), "v"(w1), "v"(w2), "v"(w3), "v"(one));
     return acc;
 }
-// the serial prefix of every entry of a tile: p[j] of lane l = carry + (all entries before 4l + j) + its own
-#define QSTEP4(K)                                                                                                  \
-    asm volatile(QFM(K) : "+v"(acc) : "v"(w0), "v"(one)); p0 = rl_ == K ? acc : p0;                                 \
-    asm volatile(QFM(K) : "+v"(acc) : "v"(w1), "v"(one)); p1 = rl_ == K ? acc : p1;                                 \
-    asm volatile(QFM(K) : "+v"(acc) : "v"(w2), "v"(one)); p2 = rl_ == K ? acc : p2;                                 \
-    asm volatile(QFM(K) : "+v"(acc) : "v"(w3), "v"(one)); p3 = rl_ == K ? acc : p3;
+// the serial prefix of every entry of a tile: p[j] of lane l = carry + (all entries before 4l + j) + its own.  The chain is the one
+// of row_sum64; lane K keeps the running sum as it stands before its own four entries (one select per group of four steps) and
+// forms its four prefixes from it afterwards — the same additions on the same operands in the same order as the chain made.
+#define QCAP4(K)                                                                                                   \
+    st = rl_ == K ? acc : st;                                                                                      \
+    asm volatile(QFM4(K) : "+v"(acc) : "v"(w0), "v"(w1), "v"(w2), "v"(w3), "v"(one));
 static __device__ __forceinline__ void row_scan64(double w0, double w1, double w2, double w3, double carry, double &p0, double &p1,
                                                   double &p2, double &p3) {
     const double one = 1.0;
     const int rl_ = threadIdx.x & 15;
-    double acc = carry;
-    p0 = p1 = p2 = p3 = carry;
+    double acc = carry, st = carry;
     asm volatile("s_nop 1" ::: );
-    QSTEP4(0) QSTEP4(1) QSTEP4(2) QSTEP4(3) QSTEP4(4) QSTEP4(5) QSTEP4(6) QSTEP4(7) QSTEP4(8) QSTEP4(9) QSTEP4(10) QSTEP4(11)
-    QSTEP4(12) QSTEP4(13) QSTEP4(14) QSTEP4(15)
+    QCAP4(0) QCAP4(1) QCAP4(2) QCAP4(3) QCAP4(4) QCAP4(5) QCAP4(6) QCAP4(7) QCAP4(8) QCAP4(9) QCAP4(10) QCAP4(11)
+    QCAP4(12) QCAP4(13) QCAP4(14) QCAP4(15)
+    p0 = st + w0; p1 = p0 + w1; p2 = p1 + w2; p3 = p2 + w3;
 }
 // QT = tiles of 64 four-byte counts a row keeps in flight ahead of its summation chain: 1 in vgx_quad_kernel, 5 in
 // vgx_quad_long_kernel (start states with lists longer than one tile).  The event loop is sensitive to its CODE SIZE (46 to
