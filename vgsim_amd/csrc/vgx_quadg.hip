@@ -76,6 +76,15 @@ static __device__ __forceinline__ void quadg_body(const VgxDirectArgs &a, const 
     uint64_t *s_inc = (uint64_t *)(blk + L.s_inc);
     int32_t *s_nocc = (int32_t *)(blk + L.s_nocc), *s_lock = (int32_t *)(blk + L.s_lock);
 #define GBUMP(i) do { if (rl == 0) s_cnt[i] += 1; } while (0)
+    // In-kernel stamps (diagnostic build only, -DVGX_PROFILE): shader cycles per phase, summed per wavefront into r.prof of its first
+    // replicate (tools/profile_quadg.py).  Stamp k closes the phase that precedes it.
+#ifdef VGX_PROFILE
+    unsigned long long prof_acc[VGX_PROF_SLOTS], prof_t0 = __builtin_readcyclecounter();
+    for (int i = 0; i < VGX_PROF_SLOTS; ++i) prof_acc[i] = 0;
+#define GPROF(i) do { unsigned long long prof_t1 = __builtin_readcyclecounter(); prof_acc[i] += prof_t1 - prof_t0; prof_t0 = prof_t1; } while (0)
+#else
+#define GPROF(i)
+#endif
     // words of the staged cold record
 #define R_SUS(j) s_reci[(j)]
 #define R_IMS(j) s_recd[S + (j)]
@@ -208,6 +217,7 @@ static __device__ __forceinline__ void quadg_body(const VgxDirectArgs &a, const 
         const bool rebuild = st == GS_REBUILD;
         const bool full = rebuild || st == GS_FULL;
 
+        GPROF(0);
         // ================= front: open the attempt, loop condition (pyx:402-407) =================
         bool end_attempt = false, ev = false;
         if (st == GS_RUN) {
@@ -246,6 +256,7 @@ static __device__ __forceinline__ void quadg_body(const VgxDirectArgs &a, const 
         int ch_cl = 0, ch_pi = -1;
 
         if (__ballot(ev)) {
+            GPROF(1);
             // ---- random numbers ----
             if (__builtin_expect(__ballot(ev && pos == 8) != 0, 0)) {
                 const bool fill = ev && pos == 8;
@@ -280,6 +291,7 @@ static __device__ __forceinline__ void quadg_body(const VgxDirectArgs &a, const 
             }
             if (ev) t_now = t_new;
 
+            GPROF(2);
             // ================= GenerateEvent (pyx:483-512) =================
             double rn = u2;
             const double choose0 = rn * den;
@@ -316,6 +328,7 @@ static __device__ __forceinline__ void quadg_body(const VgxDirectArgs &a, const 
             const bool isI = evn && err == 0 && (imm_pi > choose);    // pyx:494: ImmunityTransition
             const bool isN = evn && err == 0 && !isI;                 // an event of an infectious host
 
+            GPROF(3);
             // ---- migration, first half (pyx:676-678): target and source population from the LDS arrays ----
             int tpi = 0, spi = 0;
             double rm = 0.0;
@@ -365,11 +378,13 @@ static __device__ __forceinline__ void quadg_body(const VgxDirectArgs &a, const 
                 }
             }
 
+            GPROF(4);
             // ---- the cold record of the population this iteration works on ----
             const int sp = evn ? pi : (evm ? tpi : 0);
             rec_load(sp, ev);
             lk_pop = ev ? sp : -1;
 
+            GPROF(5);
             // ---- ImmunityTransition (pyx:550-564) ----
             if (__builtin_expect(__ballot(isI) != 0, 0)) {
                 double ri = choose / imm_pi;
@@ -410,6 +425,7 @@ static __device__ __forceinline__ void quadg_body(const VgxDirectArgs &a, const 
                 WSYNC();
             }
 
+            GPROF(6);
             // ---- an infectious host's event: haplotype, then event class (pyx:496-511) ----
             if (__ballot(isN)) {
                 rn = (choose - imm_pi) / inf_pi;
@@ -490,6 +506,7 @@ static __device__ __forceinline__ void quadg_body(const VgxDirectArgs &a, const 
                 if (isN_ok && w_hit == 0.0) err = G_ERR_ZERO_WEIGHT + 256 * 4;
                 rn = (r2 - (pre_hit - w_hit)) / w_hit;
 
+                GPROF(7);
                 // ---- event class by fastChoose over (birth, death, sampling, mutation) rates (pyx:503-511) ----
                 const int cbh = k_bidx[cls_hit];
                 const double e0 = R_BC(cbh), e1 = k_d[cls_hit], e2 = k_s[cls_hit] * mult, e3 = k_tm[cls_hit];
@@ -595,6 +612,7 @@ static __device__ __forceinline__ void quadg_body(const VgxDirectArgs &a, const 
                 WSYNC();
             }
 
+            GPROF(8);
             // ---- migration, second half (pyx:679-692): haplotype of the source, group of the target, thinning ----
             if (__builtin_expect(__ballot(evm) != 0, 0)) {
                 int hi = 0;
@@ -679,6 +697,7 @@ static __device__ __forceinline__ void quadg_body(const VgxDirectArgs &a, const 
             WSYNC();
         }
 
+        GPROF(9);
         // ================= deferred list operations: infectious[op_pi, hap] += delta, list kept ordered =================
         if (err != 0) op_n = 0;
         for (int oi = 0; oi < 2; ++oi) {
@@ -805,6 +824,7 @@ static __device__ __forceinline__ void quadg_body(const VgxDirectArgs &a, const 
             }
         }
 
+        GPROF(10);
         // ================= Events.AddEvent (events.pxi:37-44) =================
         if (err == 0 && e_type >= 0) {
             if (a.record_events) {
@@ -826,6 +846,7 @@ static __device__ __forceinline__ void quadg_body(const VgxDirectArgs &a, const 
             ev_ptr += 1;
         }
 
+        GPROF(11);
         // ================= CheckLockdown for every population (PrepareParameters pyx:449-450, Restart pyx:736-737) =================
         // UpdateAllRates is a pure function of the state: one rebuild after the last switch leaves what the reference's call
         // after every switch leaves.
@@ -898,6 +919,7 @@ static __device__ __forceinline__ void quadg_body(const VgxDirectArgs &a, const 
             WSYNC();
         }
 
+        GPROF(12);
         // ================= UpdateRates(u_pop, ...) (pyx:516-546) / UpdateAllRates (pyx:279-351) =================
         if (err != 0) { u_pop = -1; }
         const bool want = err == 0 && (full || u_pop >= 0);
@@ -945,6 +967,7 @@ static __device__ __forceinline__ void quadg_body(const VgxDirectArgs &a, const 
                     R_BC(rl) = k_cbb[rl] * (sgi < 0 ? 0.0 : s_seg[sgi]);
                 }
                 WSYNC();
+                GPROF(13);
                 // ---- infectPopRate[pu]: tEvent * infectious over the occupied haplotypes, in haplotype order (pyx:519-528) ----
                 const int n = d_inf ? s_nocc[pu] : 0;
                 const int32_t *lc = lcls + (int64_t)pu * cap;
@@ -1025,6 +1048,7 @@ static __device__ __forceinline__ void quadg_body(const VgxDirectArgs &a, const 
             }
         }
 
+        GPROF(14);
         // ================= after the pass =================
         if (full && st != GS_DONE) st = err ? GS_DONE : GS_RUN;
         if (err != 0) st = GS_DONE;
@@ -1149,6 +1173,10 @@ static __device__ __forceinline__ void quadg_body(const VgxDirectArgs &a, const 
 
     // ---- state back to HBM ----
     WSYNC();
+#ifdef VGX_PROFILE
+    if (live && rl == 0 && r.prof)
+        for (int i = 0; i < VGX_PROF_SLOTS; ++i) r.prof[rep * VGX_PROF_SLOTS + i] = prof_acc[i];
+#endif
     if (live) {
         double *gD = r.popD + rep * PD_COUNT * P;
         int64_t *gI64 = r.popI + rep * PI_COUNT * P;
