@@ -288,7 +288,11 @@ extern "C" __global__ void __launch_bounds__(TT) vgx_taus_kernel(VgxTausArgs a) 
                     own_c = -1;
                     if (x0 != x1) { kind = 5; lam = p.suscepTransition[x0 * S + x1] * (double)Sv[pn * S + x0] * tau_l; }
                 } else if (w < nwork) {
-                    const int c = (int)(w / NCH), ch = (int)(w - (int64_t)c * NCH);
+                    // items in CHANNEL-major order, the kinds with the large rates first (recovery, sampling, transmissions, then the
+                    // mutations, then the migrations): the lanes of a wavefront draw from rates of one scale (one branch of the sampler),
+                    // and what spills over the TT threads into a second round are the cheapest draws
+                    const int chm = (int)(w / PH), c = (int)(w - (int64_t)chm * PH);
+                    const int ch = chm < 2 ? chm : chm < 2 + S ? 2 + 3 * sites + (chm - 2) : chm < 2 + S + 3 * sites ? 2 + (chm - 2 - S) : chm;
                     own_c = c;
                     const int Ic = I[c];
                     if (Ic != 0) {                 // (propensity 0: no draw, as random_poisson)
@@ -354,19 +358,11 @@ extern "C" __global__ void __launch_bounds__(TT) vgx_taus_kernel(VgxTausArgs a) 
                         row(k, TY_SUSCCHANGE, x0, pn, x1, 0);
                     }
                 }
-                // the compartments' own changes: segmented sums over the lanes of one compartment (they are contiguous), one pair of
-                // atomics per compartment and wavefront
-                {
-                    int vc = own_chk, va = own_app;
-                    for (int o = 1; o < 64; o <<= 1) {
-                        const int uc = __shfl_up(vc, o), ua = __shfl_up(va, o), cu = __shfl_up(own_c, o);
-                        if (lane >= o && cu == own_c) { vc += uc; va += ua; }
-                    }
-                    const int cn = __shfl_down(own_c, 1);
-                    if (own_c >= 0 && (lane == 63 || cn != own_c)) {
-                        if (vc) atomicAdd(&dChk[own_c], vc);
-                        if (va) atomicAdd(&dApp[own_c], va);
-                    }
+                // the compartments' own changes (neighbouring lanes hold different compartments: no two lanes of a wavefront meet on
+                // an address here unless the model has fewer compartments than a wavefront has lanes)
+                if (own_c >= 0) {
+                    if (own_chk) atomicAdd(&dChk[own_c], own_chk);
+                    if (own_app) atomicAdd(&dApp[own_c], own_app);
                 }
                 // the susceptible compartments: one sum per distinct compartment among the wavefront's lanes
                 {
