@@ -84,7 +84,8 @@ static __device__ int64_t tau_poisson(TauRng &g, double lam) {
         int64_t k = (int64_t)floor((2 * a / us + b) * U + lam + 0.43);
         if (us >= 0.07 && V <= vr) return k;
         if (k < 0 || (us < 0.013 && V > us)) continue;
-        if ((log(V) + log(invalpha) - log(a / (us * us) + b)) <= (-lam + k * loglam - tau_loggam((double)k + 1))) return k;
+        // (log V + log invalpha - log(a / us^2 + b) as one logarithm: the wavefront pays for every log some lane needs)
+        if (log(V * invalpha / (a / (us * us) + b)) <= (-lam + k * loglam - tau_loggam((double)k + 1))) return k;
     }
 }
 

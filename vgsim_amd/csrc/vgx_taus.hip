@@ -26,6 +26,23 @@
 #define TT VGX_TAUS_TB
 enum { TY_BIRTH = 0, TY_DEATH = 1, TY_SAMPLING = 2, TY_MUTATION = 3, TY_SUSCCHANGE = 4, TY_MIGRATION = 5 };
 
+// In-kernel stamps of the diagnostic build (-DVGX_PROFILE; tools/profile_taus.py): shader cycles per phase of the step loop, thread 0 of
+// replicate 0: [0] loop condition + contact densities, [1] drift + ChooseTau, [2] a try's zeroing, [3] draws, [4] bounds check,
+// [5] apply + totals + record, [6] steps, [7] tries; inside the draws (wavefront 0): [8] rates, [9] sampler, [10] bookkeeping of a round.
+#ifdef VGX_PROFILE
+__device__ unsigned long long vgx_taus_prof[12];
+extern "C" int vgx_taus_get_profile(unsigned long long *out, int clear) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(vgx_taus_prof), sizeof(unsigned long long) * 12) != hipSuccess) return 1;
+    if (clear) {
+        unsigned long long z[12] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(vgx_taus_prof), z, sizeof z) != hipSuccess) return 1;
+    }
+    return 0;
+}
+#define TSPROF(i) do { const long long t_ = clock64(); pacc[i] += t_ - pt; pt = t_; } while (0)
+#else
+#define TSPROF(i)
+#endif
 extern "C" __global__ void __launch_bounds__(TT) vgx_taus_kernel(VgxTausArgs a) {
     const VgxDevParams &p = a.p;
     const int rep = blockIdx.x;
@@ -68,7 +85,7 @@ extern "C" __global__ void __launch_bounds__(TT) vgx_taus_kernel(VgxTausArgs a) 
     for (int i = tid; i < CB * S; i += TT) l_sig[i] = p.cb_sigma[i];
     for (int i = tid; i < H; i += TT) l_cls[i] = p.cls[i];
     if (tid < 48) l_mutp[tid] = a.mutp[tid / 3][tid % 3];
-    if (tid == 0) { s_dirty = 1; s_flips = 0; s_fail = 0; }
+    if (tid == 0) { s_dirty = 1; s_flips = 0; s_fail = 0; s_tau = (unsigned long long)__double_as_longlong(1.0); }
     __syncthreads();
 
     // ---- call state (thread-uniform copies in every thread) ----
@@ -113,6 +130,9 @@ extern "C" __global__ void __launch_bounds__(TT) vgx_taus_kernel(VgxTausArgs a) 
         }
     };
 
+#ifdef VGX_PROFILE
+    long long pacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, pt = clock64();
+#endif
     while (!finished) {
         // ---- loop condition (pyx:2312) / end of an attempt (pyx:2331-2335) ----
         const bool go = running && ev_ptr < a.ev_size && (a.sample_size == -1 || cnt[2] < a.sample_size) &&
@@ -127,7 +147,7 @@ extern "C" __global__ void __launch_bounds__(TT) vgx_taus_kernel(VgxTausArgs a) 
                 __syncthreads();
                 for (int i = tid; i < PH; i += TT) I[i] = a.i_I[i];
                 for (int i = tid; i < P * S; i += TT) Sv[i] = a.i_S[i];
-                if (tid == 0) { s_flips = 0; s_fail = 0; }
+                if (tid == 0) { s_flips = 0; s_fail = 0; s_tau = (unsigned long long)__double_as_longlong(1.0); }
                 __syncthreads();
                 for (int pn = wv; pn < P; pn += NW) {
                     long long t = 0;
@@ -175,9 +195,8 @@ extern "C" __global__ void __launch_bounds__(TT) vgx_taus_kernel(VgxTausArgs a) 
             __syncthreads();
             if (tid == 0) s_dirty = 0;
         }
-        if (tid == 0) { s_tau = (unsigned long long)__double_as_longlong(1.0); }
-        __syncthreads();
 
+        TSPROF(0);
         // ---- Propensities + ChooseTau: net drift of every compartment, tau candidates ----
         double cand = 1.0;
         for (int pn = wv; pn < P; pn += NW) {
@@ -246,6 +265,7 @@ extern "C" __global__ void __launch_bounds__(TT) vgx_taus_kernel(VgxTausArgs a) 
         __syncthreads();
         tau_l = __longlong_as_double((long long)s_tau);
 
+        TSPROF(1);
         // ---- GenerateEvents_tau until a try passes the bounds check (pyx:2316-2321) ----
         uint32_t retry = 0;
         while (true) {
@@ -255,6 +275,7 @@ extern "C" __global__ void __launch_bounds__(TT) vgx_taus_kernel(VgxTausArgs a) 
             if (tid < 8) s_cnt[tid] = 0;
             if (tid == 0) { s_fail = 0; s_nrows = 0; }
             __syncthreads();
+            TSPROF(2);
             long long tl[6] = {0, 0, 0, 0, 0, 0};
             auto row = [&](long long num, int type, int hap, int pop, int nh, int np) {
                 if (a.mev_cap <= 0) return;
@@ -322,12 +343,14 @@ extern "C" __global__ void __launch_bounds__(TT) vgx_taus_kernel(VgxTausArgs a) 
                         }
                     }
                 }
+                TSPROF(8);
                 long long k = 0;
                 if (kind >= 0 && lam > 0.0) {
                     TauRng g;
                     g.init(seed, (uint32_t)att, (uint64_t)w, step, retry);
                     k = tau_poisson(g, lam);
                 }
+                TSPROF(9);
                 if (k) {
                     if (kind <= 1) {
                         if (kind == 0) tl[1] += k; else tl[2] += k;
@@ -378,6 +401,7 @@ extern "C" __global__ void __launch_bounds__(TT) vgx_taus_kernel(VgxTausArgs a) 
                         todo &= ~__ballot(mine);
                     }
                 }
+                TSPROF(10);
             }
             for (int i = 0; i < 6; ++i) {
                 long long v = tl[i];
@@ -385,6 +409,7 @@ extern "C" __global__ void __launch_bounds__(TT) vgx_taus_kernel(VgxTausArgs a) 
                 if (lane == 0 && v) atomicAdd((unsigned long long *)&s_cnt[i], (unsigned long long)v);
             }
             __syncthreads();
+            TSPROF(3);
             // bounds check (pyx:2522-2528)
             int bad = 0;
             for (int i = tid; i < PH; i += TT) {
@@ -398,6 +423,10 @@ extern "C" __global__ void __launch_bounds__(TT) vgx_taus_kernel(VgxTausArgs a) 
             if (bad) s_fail = 1;
             __syncthreads();
             tries_total += 1;
+            TSPROF(4);
+#ifdef VGX_PROFILE
+            pacc[7] += 1;
+#endif
             if (a.mev_cap > 0 && mev_base + (long long)s_nrows > a.mev_cap) { err = VGX_ERR_CAPACITY; break; }
             if (!s_fail) break;
             tau_l *= 0.5;
@@ -431,11 +460,15 @@ extern "C" __global__ void __launch_bounds__(TT) vgx_taus_kernel(VgxTausArgs a) 
         }
         mev_base += nrows;
         ev_ptr += 1; steps += 1; step += 1;
+        TSPROF(5);
+#ifdef VGX_PROFILE
+        pacc[6] += 1;
+#endif
         __syncthreads();
         long long g = 0;
         for (int pn = 0; pn < P; ++pn) g += tot[pn];
         gI = g;
-        if (tid == 0) s_flips = 0;
+        if (tid == 0) { s_flips = 0; s_tau = (unsigned long long)__double_as_longlong(1.0); }     // (s_tau: the next step's ChooseTau starts from 1)
         __syncthreads();
         if (gI != 0) {          // pyx:2326-2329: no lockdown check after extinction
             check_lockdowns(tnow);
@@ -445,6 +478,9 @@ extern "C" __global__ void __launch_bounds__(TT) vgx_taus_kernel(VgxTausArgs a) 
         }
     }
 
+#ifdef VGX_PROFILE
+    if (tid == 0 && rep == 0) for (int i = 0; i < 12; ++i) atomicAdd(&vgx_taus_prof[i], (unsigned long long)pacc[i]);
+#endif
     // ---- state and results back ----
     __syncthreads();
     for (int i = tid; i < PH; i += TT) gIr[i] = I[i];
