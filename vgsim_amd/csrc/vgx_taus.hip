@@ -262,6 +262,11 @@ extern "C" __global__ void __launch_bounds__(TT) vgx_taus_kernel(VgxTausArgs a) 
         }
         for (int o = 32; o > 0; o >>= 1) cand = fmin(cand, __shfl_down(cand, o));
         if (lane == 0) atomicMin(&s_tau, (unsigned long long)__double_as_longlong(cand));   // (positive doubles order like their bits)
+        // the deltas of the first try (nothing above reads them; the previous step is through with its counters)
+        for (int i = tid; i < PH; i += TT) { dChk[i] = 0; dApp[i] = 0; }
+        for (int i = tid; i < P * S; i += TT) dS[i] = 0;
+        if (tid < 8) s_cnt[tid] = 0;
+        if (tid == 0) { s_fail = 0; s_nrows = 0; }
         __syncthreads();
         tau_l = __longlong_as_double((long long)s_tau);
 
@@ -269,12 +274,14 @@ extern "C" __global__ void __launch_bounds__(TT) vgx_taus_kernel(VgxTausArgs a) 
         // ---- GenerateEvents_tau until a try passes the bounds check (pyx:2316-2321) ----
         uint32_t retry = 0;
         while (true) {
-            __syncthreads();
-            for (int i = tid; i < PH; i += TT) { dChk[i] = 0; dApp[i] = 0; }
-            for (int i = tid; i < P * S; i += TT) dS[i] = 0;
-            if (tid < 8) s_cnt[tid] = 0;
-            if (tid == 0) { s_fail = 0; s_nrows = 0; }
-            __syncthreads();
+            if (retry > 0) {     // (the first try's deltas were cleared before the barrier that closed ChooseTau)
+                __syncthreads();
+                for (int i = tid; i < PH; i += TT) { dChk[i] = 0; dApp[i] = 0; }
+                for (int i = tid; i < P * S; i += TT) dS[i] = 0;
+                if (tid < 8) s_cnt[tid] = 0;
+                if (tid == 0) { s_fail = 0; s_nrows = 0; }
+                __syncthreads();
+            }
             TSPROF(2);
             long long tl[6] = {0, 0, 0, 0, 0, 0};
             auto row = [&](long long num, int type, int hap, int pop, int nh, int np) {
