@@ -75,6 +75,15 @@ static __device__ __forceinline__ int q_compact_list(int32_t *lh, int32_t *l3, i
             if (redo && tb < nn && rl == 0) lt[tb >> 6] = tot;
         }
     }
+    // the tile sums behind the shortened list go back to 0 (vgx_dev.h: "0 beyond the list"; an insertion that opens a tile adds to them)
+    {
+        const int j0 = nn > 64 ? (nn + 63) >> 6 : 0, j1 = on ? n >> 6 : -1;
+        const int mj = rows_max(on && nn != n ? j1 + 1 : 0);
+        for (int jb = 0; jb < mj; jb += 16) {
+            const int j = jb + rl;
+            if (on && nn != n && j >= j0 && j <= j1) lt[j] = 0;
+        }
+    }
     WSYNC();
     return nn;
 }
