@@ -381,7 +381,7 @@ def rowscan_leg(device, rows=4096):
 def fast_leg(device, replicates, events, traj_points):
     """The headline workload (natural occupancy) in FAST mode: the row-per-replicate kernel vgx_quadf.hip (four replicates per
     wavefront, three wavefronts per SIMD: 24 576 replicates are two full rounds of the chip), device time of one launch after a
-    warm-up; the counter-based stream (mode 2) stays on the one-replicate-per-wavefront kernel."""
+    warm-up; then the same with the counter-based stream (mode 2: Philox4x32-10 per lane), on the same kernel since round 3."""
     import numpy as np
     from vgsim_amd.ensemble import Ensemble
     replicates = 24576 if replicates >= 16384 else replicates
@@ -393,17 +393,14 @@ def fast_leg(device, replicates, events, traj_points):
                            mode="fast")
     out = {"workload": "headline workload in FAST mode (order-free sums, same PCG64 stream), %d replicates x %d events" % (replicates, events),
            "value": res.total_events / (res.kernel_ms * 1e-3), "unit": "events/s (device time)",
-           "kernel": "vgx_quadf_kernel" if replicates >= 2048 else "vgx_direct_fast_kernel_p64s1", "kernel_ms_per_launch": res.kernel_ms}
-    ens.close()
-    replicates, events = 4096, events
-    ens = Ensemble(make_simulator(2020), replicates, device=device)
+           "kernel": "vgx_quadf_kernel", "kernel_ms_per_launch": res.kernel_ms}
     # the same with the counter-based random stream (vgx_run_opts.mode = 2: Philox4x32-10, every draw formed on its own)
     for it in range(2):
         res = ens.simulate(events, sample_size=10 ** 12, record_events=True, traj_points=traj_points,
                            traj_window=(0.0, 12.0), seeds=2020 + it * replicates + np.arange(replicates, dtype=np.int64),
                            mode="fast_philox")
-    out["philox_stream"] = {"value": res.total_events / (res.kernel_ms * 1e-3), "unit": "events/s (device time)",
-                            "kernel_ms_per_launch": res.kernel_ms}
+    out["philox_stream"] = {"value": res.total_events / (res.kernel_ms * 1e-3), "unit": "events/s (device time)", "kernel": "vgx_quadf_kernel",
+                            "replicates": replicates, "kernel_ms_per_launch": res.kernel_ms}
     ens.close()
     return out
 

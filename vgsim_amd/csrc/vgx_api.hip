@@ -856,7 +856,7 @@ static int direct_core(vgx_engine *e, int64_t iterations, int64_t sample_size, f
         if (h.totalSusceptible[(size_t)pn] != h.susceptible[(size_t)pn]) quad_shape = false;
     const bool quad_ok = o.mode == 0 && quad_shape;
     // FAST mode (order-free sums, PCG64 stream) on the same layout and scope: vgx_quadf.hip
-    const bool quadf_ok = o.mode == 1 && quad_shape;
+    const bool quadf_ok = (o.mode == 1 || o.mode == 2) && quad_shape;     // FAST, with the PCG64 or the counter-based stream
     // The general form of that kernel (vgx_quadg.hip): several susceptibility groups and rate classes, lockdown switches,
     // up to 128 populations.
     const int64_t qg_W = 3 * S + e->CB;

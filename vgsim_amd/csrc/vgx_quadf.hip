@@ -273,14 +273,22 @@ static __device__ __forceinline__ void quadf_body(const VgxDirectArgs &a, const 
             // ---- random numbers: refill the batch of every row that ran dry ----
             if (__builtin_expect(__ballot(ev && pos == 8) != 0, 0)) {   // (every eighth iteration while the rows stay in step)
                 const bool fill = ev && pos == 8;
-                uint64_t h, l, ch, cl;
-                vgx_mul128(k_jump[0], k_jump[1], g_sh, g_sl, h, l);
-                vgx_mul128(k_jump[2], k_jump[3], s_inc[0], s_inc[1], ch, cl);
-                vgx_add128(h, l, ch, cl);
-                const double u = vgx_pcg64_output_double(h, l);
-                const double v = (rl & 1) ? u : -vgx_log(u);
-                const uint64_t nh = (uint64_t)rowget_i64((int64_t)h, 15), nl = (uint64_t)rowget_i64((int64_t)l, 15);
-                if (fill) { g_val = v; g_sh = nh; g_sl = nl; pos = 0; }
+                if (a.rng_philox) {
+                    // the counter-based stream (vgx_run_opts.mode = 2): iteration i of the attempt takes outputs 2 i (time) and 2 i + 1
+                    // (event) of the stream of (seed, attempt); every lane forms its own output, no state is carried
+                    const double u = vgx_philox_stream_double((uint64_t)r.seeds[rep], (uint32_t)last_att, 2 * (uint64_t)att_loops + (uint64_t)rl);
+                    const double v = (rl & 1) ? u : -vgx_log(u);
+                    if (fill) { g_val = v; pos = 0; }
+                } else {
+                    uint64_t h, l, ch, cl;
+                    vgx_mul128(k_jump[0], k_jump[1], g_sh, g_sl, h, l);
+                    vgx_mul128(k_jump[2], k_jump[3], s_inc[0], s_inc[1], ch, cl);
+                    vgx_add128(h, l, ch, cl);
+                    const double u = vgx_pcg64_output_double(h, l);
+                    const double v = (rl & 1) ? u : -vgx_log(u);
+                    const uint64_t nh = (uint64_t)rowget_i64((int64_t)h, 15), nl = (uint64_t)rowget_i64((int64_t)l, 15);
+                    if (fill) { g_val = v; g_sh = nh; g_sl = nl; pos = 0; }
+                }
             }
             const int pp = min(pos, 7);
             const double nlog = rowget_f64(g_val, 2 * pp), u2 = rowget_f64(g_val, 2 * pp + 1);
