@@ -1,6 +1,6 @@
 // vgx_quadf.hip — FAST mode of the direct path on the row-per-replicate layout (four replicates per wavefront, one per 16-lane
-// DPP row): the same event semantics and the same PCG64 stream as vgx_quad.hip, ORDER-FREE sums (vgx_run_opts.mode = 1, SURVEY.md
-// §7.1).  With one rate class the infection rate of a population is tEvent x totalInfectious — no pass over the occupancy list —
+// DPP row): the same event semantics and the same PCG64 stream as vgx_quad.hip (vgx_run_opts.mode = 1; mode = 2: the counter-based
+// Philox stream), ORDER-FREE sums.  With one rate class the infection rate of a population is tEvent x totalInfectious — no pass over the occupancy list —
 // and the haplotype is chosen by an integer prefix search over the counts (fast_choose.pxi:18-31 on int64 weights, tile sums for
 // lists longer than a tile); BirthRate (pyx:382-392) is factored through sum_pn m^2 cd / as, a constant of the model where no
 // lockdown can switch; the prefix sums of popRate over the populations (what fastChoose accumulates, pyx:537-539) are formed
@@ -9,6 +9,7 @@
 // instructions.  Same scope as vgx_quad.hip (popNum <= 64, one susceptibility group, one rate class, no possible lockdown switch,
 // no recombination).  On the same seed the integer columns of the log, the counters and the compartments equal the exact
 // mode's (rates differ at the 1e-16 level), times agree within 1e-9: tests/test_hip_quadf.py.
+// The lists may hold zero-count entries while the kernel runs (vgx_rowlist.h); vgx_lists_settle_kernel squeezes them out afterwards.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "vgx_dev.h"
