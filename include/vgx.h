@@ -94,7 +94,10 @@ typedef struct vgx_run_opts {
                                 3 = four replicates per wavefront, one per 16-lane row (EXACT, no recombination): vgx_quad.hip
                                 for popNum <= 64, one susceptibility group, one rate class and no possible lockdown switch,
                                 else the general form vgx_quadg.hip (popNum <= 128, susNum <= 8, <= 64 rate classes, <= 16
-                                transmission/susceptibility classes); 4 = the general form even where 3 would take the other */
+                                transmission/susceptibility classes); 4 = the general form even where 3 would take the other;
+                                5 = one replicate per wavefront with the whole DENSE model in LDS and registers (vgx_solo.hip: the
+                                latency kernel of single trajectories; EXACT, no recombination, hapNum <= 64, popNum <= 128,
+                                susNum <= 16).  Automatic: 5 for fewer than 2048 replicates of a model it takes */
     int64_t reserved[2];     /* [0] tau path: 1 = run every try of the halving loop (pyx:2316-2321) instead of starting at the
                                 first try that is not certain to be rejected (same accepted steps either way);
                                 [1] tau path, how a try's deltas are kept and checked (same draws and decisions in every mode):
@@ -211,6 +214,8 @@ void vgx_rng_position(int64_t seed, int64_t attempt, int64_t draws, uint64_t out
 /* ---- measurement ---------------------------------------------------------------------------- */
 /* Device time of the last simulate call's kernels, from HIP events on the engine's stream (ms). */
 double vgx_last_kernel_ms(const vgx_engine *e);
+/* The kernel the last vgx_simulate_direct call ran on, as a value of vgx_run_opts.kernel (1 .. 5; 3 also for the FAST row kernel). */
+int vgx_last_direct_kernel(const vgx_engine *e);
 /* Number of kernel launches timed by the last simulate call. */
 int64_t vgx_last_kernel_launches(const vgx_engine *e);
 /* Bytes of device memory held by the engine. */
@@ -252,6 +257,10 @@ int vgx_test_philox(int on_device, const uint32_t ctr[4], const uint32_t key[2],
 /* n independent draws of the device's Poisson(lam) sampler (what replaces numpy's random_poisson, pyx:2531-2532:
  * inversion below a mean of 10, PTRS from 10 on), draw i from the Philox stream of compartment i under `seed`. */
 int vgx_test_poisson(double lam, int64_t n, uint64_t seed, int64_t *out);
+
+/* count quotients n[i] / b[i] formed on the device two ways: q_seq = through the correctly rounded reciprocal of b with two residual
+ * corrections (how the single-trajectory kernel divides BirthRate's terms by actualSizes, pyx:390), q_div = the division. */
+int vgx_test_div_by_const(const double *n, const double *b, int64_t count, double *q_seq, double *q_div);
 
 #ifdef __cplusplus
 }

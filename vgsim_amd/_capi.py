@@ -95,6 +95,7 @@ SIGNATURES = {
     "vgx_clock_mismatches": (C.c_int64, [_H]),
     "vgx_last_kernel_ms": (C.c_double, [_H]),
     "vgx_last_kernel_launches": (C.c_int64, [_H]),
+    "vgx_last_direct_kernel": (C.c_int, [_H]),
     "vgx_device_bytes": (C.c_int64, [_H]),
     "vgx_get_profile": (C.c_int, [_H, C.c_int64, _I]),
     "vgx_get_genealogy": (C.c_int, [C.POINTER(VgxGenealogyIO), C.c_char_p, C.c_int64]),
@@ -104,6 +105,7 @@ SIGNATURES = {
     "vgx_propensity_scan_error": (C.c_char_p, []),
     "vgx_test_philox": (C.c_int, [C.c_int, C.POINTER(C.c_uint32 * 4), C.POINTER(C.c_uint32 * 2), C.POINTER(C.c_uint32 * 4)]),
     "vgx_test_poisson": (C.c_int, [C.c_double, C.c_int64, C.c_uint64, _I]),
+    "vgx_test_div_by_const": (C.c_int, [_F, _F, C.c_int64, _F, _F]),
 }
 
 _lib = None
@@ -325,6 +327,11 @@ class HipEngine:
     @property
     def last_kernel_ms(self):
         return self.lib.vgx_last_kernel_ms(self.handle)
+
+    @property
+    def last_kernel(self):
+        """Name of the kernel the last direct call ran on (vgx_run_opts.kernel)."""
+        return {1: "wave", 2: "lane", 3: "quad", 4: "quadg", 5: "solo"}[self.lib.vgx_last_direct_kernel(self.handle)]
 
     @property
     def device_bytes(self):

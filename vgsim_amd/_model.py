@@ -327,8 +327,8 @@ class BirthDeathModel(ParameterTable, Reporting):
         self._check_supported()
         if mode not in ('exact', 'fast', 'fast_philox'):
             raise ValueError("mode must be 'exact', 'fast' or 'fast_philox'")
-        if kernel not in ('auto', 'wave', 'lane', 'quad', 'quadg'):
-            raise ValueError("kernel must be 'auto', 'wave', 'lane', 'quad' or 'quadg'")
+        if kernel not in ('auto', 'wave', 'lane', 'quad', 'quadg', 'solo'):
+            raise ValueError("kernel must be 'auto', 'wave', 'lane', 'quad', 'quadg' or 'solo'")
         self.events.CreateEvents(iterations)
         self.CheckSizes()
         time = float(np.float32(time))  # `float time` in the reference signature
@@ -338,7 +338,7 @@ class BirthDeathModel(ParameterTable, Reporting):
             opts = _capi.VgxRunOpts()
             opts.record_events = 1
             opts.mode = {'exact': 0, 'fast': 1, 'fast_philox': 2}[mode]
-            opts.kernel = {'auto': 0, 'wave': 1, 'lane': 2, 'quad': 3, 'quadg': 4}[kernel]
+            opts.kernel = {'auto': 0, 'wave': 1, 'lane': 2, 'quad': 3, 'quadg': 4, 'solo': 5}[kernel]
         eng = self._get_engine()
         eng.simulate_direct(self, iterations, sample_size, time, attempts, opts)
         c = eng.last_counters

@@ -20,6 +20,7 @@
 #include "vgx_dev.h"
 #include "vgx_quadg.h"
 #include "vgx_taus.h"
+#include "vgx_solo.h"
 #include "vgx_rng.h"
 
 // launchers defined next to their kernels (vgx_direct.hip)
@@ -38,6 +39,7 @@ extern "C" hipError_t vgxi_launch_quad_prep(const VgxDevParams *p, const double 
 extern "C" hipError_t vgxi_launch_quadf(const VgxDirectArgs *a, const double *cd, double *effMig, double *maxEBM, int32_t *has_mig, hipStream_t stream);
 extern "C" hipError_t vgxi_launch_taus(const VgxTausArgs *a, hipStream_t s);
 extern "C" hipError_t vgxi_launch_quadg(const VgxDirectArgs *a, const VgxQuadgArgs *qa, hipStream_t stream);
+extern "C" hipError_t vgxi_launch_solo(const VgxDirectArgs *a, const VgxSoloArgs *sa, int clock, hipStream_t stream);
 extern "C" hipError_t vgxi_launch_counts32(const int64_t *c64, int32_t *c32, int64_t n, hipStream_t stream);
 extern "C" hipError_t vgxi_launch_init_reps(const VgxDevRep *r, int P, int S, int64_t R, const int32_t *s_nocc,
                                             const int32_t *s_hap, const int32_t *s_cls, const int64_t *s_cnt,
@@ -132,11 +134,16 @@ struct vgx_engine {
         bool limit_mismatch = false;      // device and host clock disagreed on a time-limit stop (see host_clock)
     } hc;
     int64_t clock_mismatches = 0;
-    bool last_used_lanes = false, last_used_quad = false, last_used_quadg = false;
+    bool last_used_lanes = false, last_used_quad = false, last_used_quadg = false, last_used_quadf = false;
     // BirthRate program of the general row kernel (vgx_quadg.h)
     std::vector<int32_t> h_seg_par, h_seg_sn, h_cb_seg;
     std::vector<double> h_seg_sig;
     DevBuf q_segpar, q_segsn, q_segsig, q_cbseg, r_cold;
+    // BirthRate segments of the single-trajectory kernel (vgx_solo.h): distinct (group, non-zero susceptibility) pairs by group
+    std::vector<int32_t> h_so_sn;
+    std::vector<double> h_so_sig;
+    DevBuf so_sn, so_sig, so_rcp;
+    bool last_used_solo = false;
     int64_t last_ev_size = 0;
     std::vector<VgxRepScalars> sc_host;
     bool sc_host_valid = false;
@@ -255,6 +262,10 @@ extern "C" void vgx_destroy(vgx_engine *e) {
 extern "C" const char *vgx_last_error(const vgx_engine *e) { return e ? e->err.c_str() : g_create_error.c_str(); }
 extern "C" double vgx_last_kernel_ms(const vgx_engine *e) { return e ? (double)e->last_ms : 0.0; }
 extern "C" int64_t vgx_last_kernel_launches(const vgx_engine *e) { return e ? e->last_launches : 0; }
+extern "C" int vgx_last_direct_kernel(const vgx_engine *e) {
+    if (!e) return 0;
+    return e->last_used_solo ? 5 : e->last_used_quadg ? 4 : (e->last_used_quad || e->last_used_quadf) ? 3 : e->last_used_lanes ? 2 : 1;
+}
 extern "C" int64_t vgx_device_bytes(const vgx_engine *e) { return e ? (int64_t)e->dev_bytes : 0; }
 
 extern "C" int vgx_set_seeds(vgx_engine *e, const int64_t *seeds) {
@@ -353,6 +364,19 @@ extern "C" int vgx_set_params(vgx_engine *e, const vgx_params *p) {
             e->h_cb_seg[cb] = cur;
         }
     }
+    {   // segments of the single-trajectory kernel: for every group the distinct non-zero susceptibility values, in group order
+        e->h_so_sn.clear(); e->h_so_sig.clear();
+        for (int64_t sn = 0; sn < S; sn++) {
+            const size_t first = e->h_so_sn.size();
+            for (size_t cb = 0; cb < cb_b.size(); cb++) {
+                const double sg = cb_sig[cb * (size_t)S + (size_t)sn];
+                if (sg == 0.0) continue;
+                bool seen = false;
+                for (size_t k = first; k < e->h_so_sn.size() && !seen; k++) seen = memcmp(&e->h_so_sig[k], &sg, 8) == 0;
+                if (!seen) { e->h_so_sn.push_back((int32_t)sn); e->h_so_sig.push_back(sg); }
+            }
+        }
+    }
     e->h_class_pos.assign(c_d.size(), 0);
     for (size_t c = 0; c < c_d.size(); c++)
         e->h_class_pos[c] = (c_d[c] > 0.0 || c_s[c] > 0.0 || c_tm[c] > 0.0 || cb_b[(size_t)c_bidx[c]] > 0.0) ? 1 : 0;
@@ -432,6 +456,17 @@ extern "C" int vgx_set_params(vgx_engine *e, const vgx_params *p) {
         rc |= upload(e, e->q_segsn, ns ? e->h_seg_sn.data() : &zero_i, ns ? ns : 1);
         rc |= upload(e, e->q_segsig, ns ? e->h_seg_sig.data() : &zero_d, ns ? ns : 1);
         rc |= upload(e, e->q_cbseg, e->h_cb_seg.data(), e->h_cb_seg.size());
+    }
+    {
+        static const int32_t zero_i = 0;
+        static const double zero_d = 0.0;
+        const size_t ns = e->h_so_sn.size();
+        rc |= upload(e, e->so_sn, ns ? e->h_so_sn.data() : &zero_i, ns ? ns : 1);
+        rc |= upload(e, e->so_sig, ns ? e->h_so_sig.data() : &zero_d, ns ? ns : 1);
+        std::vector<double> rcp((size_t)P);
+        for (int64_t pn = 0; pn < P; pn++) rcp[(size_t)pn] = 1.0 / e->actualSizes[(size_t)pn];
+        rc |= upload(e, e->so_rcp, rcp.data(), rcp.size());
+        if (rc == 0 && hipStreamSynchronize(e->stream) != hipSuccess) rc = VGX_ERR_HIP;   // rcp goes out of scope
     }
     rc |= upload(e, e->p_sizes, p->sizes, (size_t)P);
     rc |= upload(e, e->p_cdBefore, p->contactDensityBeforeLockdown, (size_t)P);
@@ -840,6 +875,7 @@ static int direct_core(vgx_engine *e, int64_t iterations, int64_t sample_size, f
                                                 : (P * H <= 1024 && P <= 16 && S <= 8 && H <= e->cap));
     if (recomb && o.mode != 0)
         return fail(e, VGX_ERR_ARG, "vgx_simulate_direct: recombination runs in exact mode only");
+    if (o.kernel < 0 || o.kernel > 5) return fail(e, VGX_ERR_ARG, "vgx_simulate_direct: kernel must be 0..5");
     if (o.kernel == 2 && !lane_ok)
         return fail(e, VGX_ERR_ARG, "vgx_simulate_direct: the lane-per-replicate kernel needs exact mode, popNum <= 16, "
                                     "popNum * hapNum <= 1024 and susNum <= 8");
@@ -862,6 +898,19 @@ static int direct_core(vgx_engine *e, int64_t iterations, int64_t sample_size, f
     const int64_t qg_W = 3 * S + e->CB;
     const bool quadg_ok = o.mode == 0 && !recomb && P <= VGX_QG_MAX_P && S <= VGX_QG_MAX_S && e->C <= VGX_QG_MAX_C &&
                           e->CB <= VGX_QG_MAX_CB && qg_W <= VGX_QG_MAX_W && (int64_t)e->h_seg_par.size() <= VGX_QG_MAX_SEG;
+    // One trajectory (or a few) of a small model: the latency kernel (vgx_solo.hip), the whole model in LDS and registers.
+    VgxSoloArgs soa{};
+    bool solo_ok = o.mode == 0 && !recomb && H <= VGX_SOLO_MAX_H && P <= VGX_SOLO_MAX_P && S <= VGX_SOLO_MAX_S &&
+                   (int64_t)e->h_so_sn.size() <= VGX_SOLO_MAX_SEG && H <= e->cap;
+    for (int64_t pn = 0; pn < P && solo_ok; pn++)
+        if (e->sizes[(size_t)pn] >= ((int64_t)1 << 52)) solo_ok = false;   // counts are kept as doubles
+    if (solo_ok) {
+        soa.mig_in_lds = vgx_solo_layout((int)P, (int)H, (int)S, (int)e->d.sites, 1).total <= VGX_SOLO_MAX_LDS ? 1 : 0;
+        if (vgx_solo_layout((int)P, (int)H, (int)S, (int)e->d.sites, soa.mig_in_lds).total > VGX_SOLO_MAX_LDS) solo_ok = false;
+    }
+    if (o.kernel == 5 && !solo_ok)
+        return fail(e, VGX_ERR_ARG, "vgx_simulate_direct: the single-trajectory kernel needs exact mode, no recombination, hapNum <= 64, "
+                                    "popNum <= 128, susNum <= 16 and a model that fits 160 KB of LDS");
     if (o.kernel == 3 && !quad_ok && !quadg_ok && !quadf_ok)
         return fail(e, VGX_ERR_ARG, "vgx_simulate_direct: the four-replicates-per-wavefront kernels need exact mode, no recombination, "
                                     "popNum <= 128, susNum <= 8, at most 64 rate classes and 16 transmission/susceptibility classes");
@@ -871,12 +920,15 @@ static int direct_core(vgx_engine *e, int64_t iterations, int64_t sample_size, f
     // measured (tools/probe_single.py, round 3): the row kernels lead at every ensemble size, a single trajectory included —
     // config 2: 2.9e5 events/s against 2.0e5 on the one-replicate-per-wavefront kernel, config 3: 1.75e5 against 1.26e5; four
     // replicates in one wavefront: 1.1e6 / 5.9e5 against 7.9e5 / 4.9e5 in four wavefronts
-    const bool use_quad = (o.kernel == 3 && quad_ok) || (o.kernel == 0 && quad_ok && !use_lanes);
-    const bool use_quadf = (o.kernel == 3 && quadf_ok) || (o.kernel == 0 && quadf_ok);
+    // measured (bench legs table3 / single_trajectory, round 4): a lone wavefront of the latency kernel does a Table-3 trajectory
+    // several times faster than a row of the row kernels; those win back from a few thousand replicates on (four per wavefront)
+    const bool use_solo = o.kernel == 5 || (o.kernel == 0 && solo_ok && !use_lanes && R < 2048);
+    const bool use_quad = !use_solo && ((o.kernel == 3 && quad_ok) || (o.kernel == 0 && quad_ok && !use_lanes));
+    const bool use_quadf = !use_solo && ((o.kernel == 3 && quadf_ok) || (o.kernel == 0 && quadf_ok));
     // The general form also for FEW replicates of models with up to 16 populations (one register slot): a wavefront running alone
     // does a Table-3 trajectory at 1.7e5 events/s there against 1.0e5 on the one-replicate-per-wavefront kernel
     // (tools/probe_single.py; at 64 populations the wave kernel leads, 1.25e5 against 0.94e5).
-    const bool use_quadg = !use_quad && (o.kernel == 4 || (o.kernel == 3 && quadg_ok) ||
+    const bool use_quadg = !use_solo && !use_quad && (o.kernel == 4 || (o.kernel == 3 && quadg_ok) ||
                                          (o.kernel == 0 && quadg_ok && !use_lanes && (R >= 2048 || (P <= 16 && (S > 1 || e->C > 1 || ld_possible)))));
     VgxLaneWs ws{};
     a.r.rec = nullptr; a.r.rec_cap = 0;
@@ -904,6 +956,13 @@ static int direct_core(vgx_engine *e, int64_t iterations, int64_t sample_size, f
     e->last_used_lanes = use_lanes;
     e->last_used_quad = use_quad;
     e->last_used_quadg = use_quadg;
+    e->last_used_quadf = use_quadf;
+    e->last_used_solo = use_solo;
+    if (use_solo) {
+        soa.seg_sn = (const int32_t *)e->so_sn.p; soa.seg_sig = (const double *)e->so_sig.p; soa.nseg = (int32_t)e->h_so_sn.size();
+        soa.rcpAs = (const double *)e->so_rcp.p;
+        soa.exact_rcp_div = getenv("VGX_SOLO_PLAIN_DIV") ? 0 : 1;
+    }
     VgxQuadgArgs qga{};
     if (use_quadg) {
         int rcq = ensure(e, e->r_cold, (size_t)(R * P * qg_W) * 8);
@@ -935,7 +994,8 @@ static int direct_core(vgx_engine *e, int64_t iterations, int64_t sample_size, f
     e->counts32_valid = use_quad || use_quadf;
     if (leaves32) e->counts64_valid = false;
     HIPCHECK(e, hipEventRecord(e->ev0, e->stream));
-    if (use_lanes) HIPCHECK(e, vgxi_launch_lanes(&a, &ws, e->stream));
+    if (use_solo) HIPCHECK(e, vgxi_launch_solo(&a, &soa, (e->call_has_tlimit || o.traj_points > 0 || !o.record_events) ? 1 : 0, e->stream));
+    else if (use_lanes) HIPCHECK(e, vgxi_launch_lanes(&a, &ws, e->stream));
     else if (use_quad) HIPCHECK(e, vgxi_launch_quad(&a, (const double *)e->s_cd.p, (double *)e->r_qeff.p, (double *)e->r_qmebm.p,
                                                     (int32_t *)e->r_qflag.p, e->start_max_nocc > 64 ? 1 : 0, e->stream));
     else if (use_quadf) HIPCHECK(e, vgxi_launch_quadf(&a, (const double *)e->s_cd.p, (double *)e->r_qeff.p, (double *)e->r_qmebm.p,

@@ -1,0 +1,50 @@
+// vgx_solo.h — what the host (vgx_api.hip) and the latency kernel of small models (vgx_solo.hip) share: the kernel's extra
+// arguments, the limits of the shapes it takes and its LDS layout.
+#pragma once
+#include <stdint.h>
+
+#define VGX_SOLO_MAX_H 64      // haplotypes: one lane each
+#define VGX_SOLO_MAX_P 128     // populations: one lane each in up to two registers
+#define VGX_SOLO_MAX_S 16      // susceptibility groups: one lane each
+#define VGX_SOLO_MAX_SEG 32    // distinct (group, non-zero susceptibility) pairs: one bit of a lane's path word each
+#define VGX_SOLO_MAX_LDS (160 * 1024)
+
+struct VgxSoloArgs {
+    // BirthRate (pyx:382-392) as a list of SEGMENTS: segment s = the P terms ((S[pi, sn_s] * sig_s) * m * m * cd) / as of one
+    // susceptibility group sn_s at one non-zero susceptibility value sig_s, sorted by group.  A haplotype's sum runs over the
+    // segments whose value is its own (its "path"), in this order: the reference's (sn, pn) order with the zero terms left out.
+    const int32_t *seg_sn;     // [nseg]
+    const double *seg_sig;     // [nseg]
+    int32_t nseg;
+    const double *rcpAs;       // [P] 1 / actualSizes, correctly rounded (the host's IEEE division)
+    int32_t exact_rcp_div;     // 1: x / actualSizes through the reciprocal with two exact residual corrections (see vgx_solo.hip);
+                               // 0: the compiler's division (validation: VGX_SOLO_PLAIN_DIV=1)
+    int32_t mig_in_lds;        // migrationRates [P][P] fits the LDS budget
+};
+
+struct VgxSoloLayout {
+    int rowI, rowCum, rowHpr, rowBirth, rowTE;   // [P][H] f64: counts and rate caches of every population's row
+    int susS, susSt, susImm;                     // [P][S] f64: susceptible counts, their copy as of the row's last infect-update, immuneSourcePopRate
+    int sigma, trans, mrate, hmt;                // [H][S], [S][S], [H][sites], [H][sites][3] f64
+    int cd, as;                                  // [P] f64 (uniform reads of the rebuild)
+    int mig;                                     // [P][P] f64 or -1
+    int rng, stage;                              // 64 f64; 64 staged log records of 32 bytes
+    int total;
+};
+
+static inline __host__ __device__ VgxSoloLayout vgx_solo_layout(int P, int H, int S, int sites, int mig_in_lds) {
+    VgxSoloLayout L;
+    int o = 0;
+    L.rng = o; o += 64 * 8;
+    L.stage = o; o += 64 * 32;
+    L.rowI = o; o += 8 * P * H;   L.rowCum = o; o += 8 * P * H;   L.rowHpr = o; o += 8 * P * H;
+    L.rowBirth = o; o += 8 * P * H;   L.rowTE = o; o += 8 * P * H;
+    L.susS = o; o += 8 * P * S;   L.susSt = o; o += 8 * P * S;   L.susImm = o; o += 8 * P * S;
+    L.sigma = o; o += 8 * H * S;  L.trans = o; o += 8 * S * S;
+    L.mrate = o; o += 8 * H * (sites > 0 ? sites : 1);   L.hmt = o; o += 24 * H * (sites > 0 ? sites : 1);
+    L.cd = o; o += 8 * P;         L.as = o; o += 8 * P;
+    L.mig = -1;
+    if (mig_in_lds) { L.mig = o; o += 8 * P * P; }
+    L.total = (o + 15) & ~15;
+    return L;
+}
