@@ -258,9 +258,10 @@ int vgx_test_philox(int on_device, const uint32_t ctr[4], const uint32_t key[2],
  * inversion below a mean of 10, PTRS from 10 on), draw i from the Philox stream of compartment i under `seed`. */
 int vgx_test_poisson(double lam, int64_t n, uint64_t seed, int64_t *out);
 
-/* count quotients n[i] / b[i] formed on the device two ways: q_seq = through the correctly rounded reciprocal of b with two residual
- * corrections (how the single-trajectory kernel divides BirthRate's terms by actualSizes, pyx:390), q_div = the division. */
-int vgx_test_div_by_const(const double *n, const double *b, int64_t count, double *q_seq, double *q_div);
+/* count quotients n[i] / b[i] formed on the device three ways: q_seq = through the correctly rounded reciprocal of b with two residual
+ * corrections (how the single-trajectory kernel divides BirthRate's terms by actualSizes, pyx:390), q_lean = its division sequence
+ * without range scaling and special-case fix-up (fastChoose's rescalings, fast_choose.pxi:31), q_div = the division. */
+int vgx_test_div_by_const(const double *n, const double *b, int64_t count, double *q_seq, double *q_lean, double *q_div);
 
 #ifdef __cplusplus
 }

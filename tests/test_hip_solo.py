@@ -31,6 +31,15 @@ def test_solo_kernel_bit_exact_vs_oracle(oracle_mod, name):
     helpers.assert_models_equal(hip, ref, name)
 
 
+@pytest.mark.parametrize("name", [n for n in SOLO if not n.startswith("g") or n.endswith("_short")])
+def test_solo_general_layout_bit_exact_vs_oracle(oracle_mod, name, monkeypatch):
+    """The general BirthRate layout (one pass per segment) on models the compact layout would take."""
+    monkeypatch.setenv("VGX_SOLO_GENERAL", "1")
+    hip = helpers.run_case_hip(name, kernel="solo").simulation
+    ref = helpers.run_case_oracle(oracle_mod, name).simulation
+    helpers.assert_models_equal(hip, ref, name)
+
+
 @pytest.mark.parametrize("name", GOLDEN)
 def test_solo_kernel_matches_the_goldens(name):
     hip = helpers.run_case_hip(name, kernel="solo").simulation
@@ -153,8 +162,9 @@ def test_solo_without_event_log_and_with_trajectories(oracle_mod):
 
 
 def test_reciprocal_division_equals_the_division():
-    """x / actualSizes through the correctly rounded reciprocal and two residual corrections (vgx_solo.hip div_by_const) is
-    the IEEE quotient: random operands over the ranges BirthRate's terms take, plus adversarial significands."""
+    """x / actualSizes through the correctly rounded reciprocal and two residual corrections (vgx_solo.hip div_by_const), and the
+    division sequence without range scaling (fdiv), are the IEEE quotient: random operands over the ranges the kernel's operands
+    take, plus adversarial significands."""
     from vgsim_amd import _capi
     lib = _capi.load_library()
     rng = np.random.default_rng(12345)
@@ -164,11 +174,13 @@ def test_reciprocal_division_equals_the_division():
     den = np.concatenate([rng.random(n) * 10.0 ** rng.integers(0, 12, n) + 1e-3, rng.integers(1, 1 << 40, n).astype(np.float64),
                           np.ldexp(2.0 - rng.integers(1, 64, n) * 2.0 ** -52, rng.integers(-20, 40, n)), rng.random(16) + 0.5])
     num = np.ascontiguousarray(num); den = np.ascontiguousarray(den)
-    q1 = np.empty_like(num); q2 = np.empty_like(num)
+    q1 = np.empty_like(num); q2 = np.empty_like(num); q3 = np.empty_like(num)
     import ctypes as C
     F = C.POINTER(C.c_double)
-    rc = lib.vgx_test_div_by_const(num.ctypes.data_as(F), den.ctypes.data_as(F), len(num), q1.ctypes.data_as(F), q2.ctypes.data_as(F))
+    rc = lib.vgx_test_div_by_const(num.ctypes.data_as(F), den.ctypes.data_as(F), len(num), q1.ctypes.data_as(F), q3.ctypes.data_as(F),
+                                   q2.ctypes.data_as(F))
     assert rc == 0
     assert np.array_equal(q2, num / den)          # the device's division is the IEEE quotient
-    bad = np.nonzero(q1 != q2)[0]
-    assert len(bad) == 0, "first mismatch: %r / %r -> %r vs %r" % (num[bad[0]], den[bad[0]], q1[bad[0]], q2[bad[0]])
+    for name, q in (("reciprocal sequence", q1), ("lean division", q3)):
+        bad = np.nonzero(q != q2)[0]
+        assert len(bad) == 0, "%s, first mismatch: %r / %r -> %r vs %r" % (name, num[bad[0]], den[bad[0]], q[bad[0]], q2[bad[0]])

@@ -105,7 +105,7 @@ SIGNATURES = {
     "vgx_propensity_scan_error": (C.c_char_p, []),
     "vgx_test_philox": (C.c_int, [C.c_int, C.POINTER(C.c_uint32 * 4), C.POINTER(C.c_uint32 * 2), C.POINTER(C.c_uint32 * 4)]),
     "vgx_test_poisson": (C.c_int, [C.c_double, C.c_int64, C.c_uint64, _I]),
-    "vgx_test_div_by_const": (C.c_int, [_F, _F, C.c_int64, _F, _F]),
+    "vgx_test_div_by_const": (C.c_int, [_F, _F, C.c_int64, _F, _F, _F]),
 }
 
 _lib = None

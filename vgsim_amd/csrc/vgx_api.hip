@@ -140,9 +140,10 @@ struct vgx_engine {
     std::vector<double> h_seg_sig;
     DevBuf q_segpar, q_segsn, q_segsig, q_cbseg, r_cold;
     // BirthRate segments of the single-trajectory kernel (vgx_solo.h): distinct (group, non-zero susceptibility) pairs by group
-    std::vector<int32_t> h_so_sn;
-    std::vector<double> h_so_sig;
-    DevBuf so_sn, so_sig, so_rcp;
+    std::vector<int32_t> h_so_sn, h_so_hapcls, h_so_nnz, h_so_tsn;
+    std::vector<double> h_so_sig, h_so_tsig, h_so_clssig;
+    int h_so_ncls = 0, h_so_maxnnz = 0;
+    DevBuf so_sn, so_sig, so_rcp, so_hapcls, so_nnz, so_tsn, so_tsig, so_clssig;
     bool last_used_solo = false;
     int64_t last_ev_size = 0;
     std::vector<VgxRepScalars> sc_host;
@@ -377,6 +378,41 @@ extern "C" int vgx_set_params(vgx_engine *e, const vgx_params *p) {
             }
         }
     }
+    {   // susceptibility classes of the single-trajectory kernel's compact layout: haplotypes with identical susceptibility rows
+        std::unordered_map<std::string, int> cmap;
+        e->h_so_hapcls.assign((size_t)H, 0);
+        e->h_so_nnz.assign(VGX_SOLO_ROWS, 0);
+        e->h_so_tsn.assign(VGX_SOLO_ROWS * VGX_SOLO_MAX_S, 0);
+        e->h_so_tsig.assign(VGX_SOLO_ROWS * VGX_SOLO_MAX_S, 0.0);
+        e->h_so_clssig.assign(VGX_SOLO_ROWS * VGX_SOLO_MAX_S, 0.0);
+        e->h_so_ncls = 0; e->h_so_maxnnz = 0;
+        for (int64_t h = 0; h < H; h++) {
+            std::string k((const char *)&p->susceptibility[h * S], (size_t)S * 8);
+            auto it = cmap.find(k);
+            int c;
+            if (it == cmap.end()) {
+                c = (int)cmap.size();
+                cmap.emplace(k, c);
+                if (c < VGX_SOLO_ROWS && S <= VGX_SOLO_MAX_S) {
+                    int n = 0;
+                    for (int64_t sn = 0; sn < S; sn++) {
+                        const double sg = p->susceptibility[h * S + sn];
+                        e->h_so_clssig[(size_t)(c * VGX_SOLO_MAX_S + sn)] = sg;
+                        if (sg == 0.0) continue;
+                        e->h_so_tsn[(size_t)(c * VGX_SOLO_MAX_S + n)] = (int32_t)sn;
+                        e->h_so_tsig[(size_t)(c * VGX_SOLO_MAX_S + n)] = sg;
+                        n++;
+                    }
+                    e->h_so_nnz[(size_t)c] = n;
+                    e->h_so_maxnnz = std::max(e->h_so_maxnnz, n);
+                }
+            } else {
+                c = it->second;
+            }
+            e->h_so_hapcls[(size_t)h] = c;
+        }
+        e->h_so_ncls = (int)cmap.size();
+    }
     e->h_class_pos.assign(c_d.size(), 0);
     for (size_t c = 0; c < c_d.size(); c++)
         e->h_class_pos[c] = (c_d[c] > 0.0 || c_s[c] > 0.0 || c_tm[c] > 0.0 || cb_b[(size_t)c_bidx[c]] > 0.0) ? 1 : 0;
@@ -466,6 +502,11 @@ extern "C" int vgx_set_params(vgx_engine *e, const vgx_params *p) {
         std::vector<double> rcp((size_t)P);
         for (int64_t pn = 0; pn < P; pn++) rcp[(size_t)pn] = 1.0 / e->actualSizes[(size_t)pn];
         rc |= upload(e, e->so_rcp, rcp.data(), rcp.size());
+        rc |= upload(e, e->so_hapcls, e->h_so_hapcls.data(), e->h_so_hapcls.size());
+        rc |= upload(e, e->so_nnz, e->h_so_nnz.data(), e->h_so_nnz.size());
+        rc |= upload(e, e->so_tsn, e->h_so_tsn.data(), e->h_so_tsn.size());
+        rc |= upload(e, e->so_tsig, e->h_so_tsig.data(), e->h_so_tsig.size());
+        rc |= upload(e, e->so_clssig, e->h_so_clssig.data(), e->h_so_clssig.size());
         if (rc == 0 && hipStreamSynchronize(e->stream) != hipSuccess) rc = VGX_ERR_HIP;   // rcp goes out of scope
     }
     rc |= upload(e, e->p_sizes, p->sizes, (size_t)P);
@@ -962,6 +1003,13 @@ static int direct_core(vgx_engine *e, int64_t iterations, int64_t sample_size, f
         soa.seg_sn = (const int32_t *)e->so_sn.p; soa.seg_sig = (const double *)e->so_sig.p; soa.nseg = (int32_t)e->h_so_sn.size();
         soa.rcpAs = (const double *)e->so_rcp.p;
         soa.exact_rcp_div = getenv("VGX_SOLO_PLAIN_DIV") ? 0 : 1;
+        soa.hap_cls = (const int32_t *)e->so_hapcls.p; soa.cls_nnz = (const int32_t *)e->so_nnz.p; soa.cls_tsn = (const int32_t *)e->so_tsn.p;
+        soa.cls_tsig = (const double *)e->so_tsig.p; soa.cls_sigma = (const double *)e->so_clssig.p;
+        soa.n_cls = e->h_so_ncls;
+        soa.maxterms = (int32_t)(e->h_so_maxnnz * P);
+        soa.compact = 0;
+        if (e->h_so_ncls <= VGX_SOLO_ROWS && S <= VGX_SOLO_MAX_S && P <= 64 && soa.maxterms <= 32 && !getenv("VGX_SOLO_GENERAL"))
+            soa.compact = soa.maxterms <= 16 ? 1 : 2;
     }
     VgxQuadgArgs qga{};
     if (use_quadg) {

@@ -8,6 +8,8 @@
 #define VGX_SOLO_MAX_S 16      // susceptibility groups: one lane each
 #define VGX_SOLO_MAX_SEG 32    // distinct (group, non-zero susceptibility) pairs: one bit of a lane's path word each
 #define VGX_SOLO_MAX_LDS (160 * 1024)
+#define VGX_SOLO_COLD 16
+#define VGX_SOLO_ROWS 4        // 16-lane DPP rows of a wavefront
 
 struct VgxSoloArgs {
     // BirthRate (pyx:382-392) as a list of SEGMENTS: segment s = the P terms ((S[pi, sn_s] * sig_s) * m * m * cd) / as of one
@@ -17,6 +19,17 @@ struct VgxSoloArgs {
     const double *seg_sig;     // [nseg]
     int32_t nseg;
     const double *rcpAs;       // [P] 1 / actualSizes, correctly rounded (the host's IEEE division)
+    // Susceptibility CLASSES: haplotypes with bit-identical susceptibility rows.  With at most VGX_SOLO_ROWS classes every class gets
+    // a 16-lane DPP row: lane (c, j) holds term j of class c's BirthRate sum (its non-zero groups in order, P terms each) and group
+    // j's susceptibility of class c ("compact" layout, terms = max over the classes of (non-zero groups) * P <= 32).
+    const int32_t *hap_cls;    // [H] class of a haplotype
+    const int32_t *cls_nnz;    // [VGX_SOLO_ROWS] non-zero groups of a class
+    const int32_t *cls_tsn;    // [VGX_SOLO_ROWS][VGX_SOLO_MAX_S] their group numbers, in order
+    const double *cls_tsig;    // [VGX_SOLO_ROWS][VGX_SOLO_MAX_S] their susceptibilities
+    const double *cls_sigma;   // [VGX_SOLO_ROWS][VGX_SOLO_MAX_S] susceptibility of a class per group (zero padded)
+    int32_t n_cls;             // classes (<= VGX_SOLO_ROWS in the compact layout)
+    int32_t maxterms;          // max over the classes of (non-zero groups) * P
+    int32_t compact;           // 0: general layout; 1 / 2: compact layout with one / two registers of terms
     int32_t exact_rcp_div;     // 1: x / actualSizes through the reciprocal with two exact residual corrections (see vgx_solo.hip);
                                // 0: the compiler's division (validation: VGX_SOLO_PLAIN_DIV=1)
     int32_t mig_in_lds;        // migrationRates [P][P] fits the LDS budget
@@ -29,6 +42,9 @@ struct VgxSoloLayout {
     int cd, as;                                  // [P] f64 (uniform reads of the rebuild)
     int mig;                                     // [P][P] f64 or -1
     int rng, stage;                              // 64 f64; 64 staged log records of 32 bytes
+    int rngk, rngs;                              // PCG64 jump constants [64][4] u64; stream position and increment [4] u64
+    int cold;                                    // [VGX_SOLO_COLD] 8-byte slots: the call's bookkeeping that the event loop does not touch
+    int smult;                                   // [P] f64 samplingMultiplier
     int total;
 };
 
@@ -37,12 +53,15 @@ static inline __host__ __device__ VgxSoloLayout vgx_solo_layout(int P, int H, in
     int o = 0;
     L.rng = o; o += 64 * 8;
     L.stage = o; o += 64 * 32;
+    L.rngk = o; o += 64 * 32;
+    L.rngs = o; o += 32;
+    L.cold = o; o += 8 * VGX_SOLO_COLD;
     L.rowI = o; o += 8 * P * H;   L.rowCum = o; o += 8 * P * H;   L.rowHpr = o; o += 8 * P * H;
     L.rowBirth = o; o += 8 * P * H;   L.rowTE = o; o += 8 * P * H;
     L.susS = o; o += 8 * P * S;   L.susSt = o; o += 8 * P * S;   L.susImm = o; o += 8 * P * S;
     L.sigma = o; o += 8 * H * S;  L.trans = o; o += 8 * S * S;
     L.mrate = o; o += 8 * H * (sites > 0 ? sites : 1);   L.hmt = o; o += 24 * H * (sites > 0 ? sites : 1);
-    L.cd = o; o += 8 * P;         L.as = o; o += 8 * P;
+    L.cd = o; o += 8 * P;         L.as = o; o += 8 * P;         L.smult = o; o += 8 * P;
     L.mig = -1;
     if (mig_in_lds) { L.mig = o; o += 8 * P * P; }
     L.total = (o + 15) & ~15;

@@ -39,6 +39,24 @@
 #include "vgx_wave.h"
 #include "vgx_solo.h"
 
+// In-kernel stamps (diagnostic build only, -DVGX_PROFILE: tools/profile_solo.py): shader cycles per phase of the event loop, lane i of
+// a counter vector <-> phase i, written to the debug buffer r.prof at the end.  No stamp executes in the product build.
+#ifdef VGX_PROFILE
+#define PROF(i)                                                                   \
+    do {                                                                          \
+        const unsigned long long prof_t1 = __builtin_readcyclecounter();          \
+        prof_acc += (lane == (i)) ? prof_t1 - prof_t0 : 0ull;                      \
+        prof_t0 = prof_t1;                                                        \
+    } while (0)
+#else
+#define PROF(i)
+#endif
+#ifdef VGX_SOLO_MARKS
+#define MARK(name) asm volatile("; MARK " name)
+#else
+#define MARK(name)
+#endif
+
 namespace {
 
 enum { ERR_ZERO_WEIGHT = 3, ERR_CAPACITY = 4, ERR_LOOP_GUARD = 5 };
@@ -74,6 +92,27 @@ struct Masks { double m[16]; };   // m[k] = (lane & 15) >= k ? 1.0 : 0.0
                  : [v] "v"(v), [mu] "v"(mu), [n] "s"(nn)                                                                          \
                  : "scc")
 
+static __device__ __forceinline__ bool any_lane(bool c) { return __builtin_amdgcn_ballot_w64(c) != 0ull; }
+static __device__ __forceinline__ int uni_i32(int v) { return __builtin_amdgcn_readfirstlane(v); }
+static __device__ __forceinline__ int64_t uni_i64(int64_t v) {
+    int lo = __builtin_amdgcn_readfirstlane((int)(uint32_t)v), hi = __builtin_amdgcn_readfirstlane((int)(uint32_t)((uint64_t)v >> 32));
+    return (int64_t)(((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo);
+}
+static __device__ __forceinline__ double uni_f64(double v) {
+    int lo = __builtin_amdgcn_readfirstlane(__double2loint(v)), hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+
+// the same with exactly four steps and no way out: shapes of at most four terms (TINY instantiations) save the compare and the branch
+#define SOLO_SCAN4(RM)                                                                                                        \
+    asm volatile("s_nop 4\n\t" SOLO_FM(0, "m0", RM) SOLO_FM(1, "m1", RM) SOLO_FM(2, "m2", RM) SOLO_FM(3, "m3", RM)            \
+                 : [acc] "+v"(acc)                                                                                               \
+                 : [v] "v"(v), [m0] "v"(M.m[0]), [m1] "v"(M.m[1]), [m2] "v"(M.m[2]), [m3] "v"(M.m[3]))
+#define SOLO_SUM4(RM)                                                                                                         \
+    asm volatile("s_nop 4\n\t" SOLO_FM(0, "mu", RM) SOLO_FM(1, "mu", RM) SOLO_FM(2, "mu", RM) SOLO_FM(3, "mu", RM)            \
+                 : [acc] "+v"(acc)                                                                                               \
+                 : [v] "v"(v), [mu] "v"(mu))
+
 // the running sum of row r-1 (its lane 15) moves to the lanes of row r
 static __device__ __forceinline__ double row_carry(double acc, int which) {
     int lo = __double2loint(acc), hi = __double2hiint(acc);
@@ -86,10 +125,15 @@ static __device__ __forceinline__ double row_carry(double acc, int which) {
 // SCAN: lane l < n ends with carry + v[0] + ... + v[l] (the serial prefix); lanes >= n-1 of the last row that ran hold the total.
 // SUM: every lane of the last row that ran ends with carry + v[0] + ... + v[n-1].  One value per lane, lanes >= n hold +0.0,
 // carry wave-uniform, n wave-uniform (1..64), all lanes active.
-template <bool SCAN>
+template <bool SCAN, bool TINY = false>
 static __device__ __forceinline__ double flat_chain(double v, int n, double carry, const Masks &M) {
     double acc = carry;
     const double mu = 1.0;
+    if (TINY) {   // n <= 4
+        if (SCAN) SOLO_SCAN4("0x1"); else SOLO_SUM4("0x1");
+        return acc;
+    }
+    n = uni_i32(n);
     int nn = n;
     if (SCAN) SOLO_SCAN16("0x1"); else SOLO_SUM16("0x1");
     if (n > 16) {
@@ -109,9 +153,38 @@ static __device__ __forceinline__ double flat_chain(double v, int n, double carr
 
 // every lane: acc += mu * (v[lane 0 of its row] + ... in order ... + v[lane n-1 of its row]) term by term, mu = 1.0 or 0.0 per
 // lane; v must hold the same 16 values in every row (nn <= 16, entries beyond nn +0.0)
+template <bool TINY = false>
 static __device__ __forceinline__ double rows_chain(double acc, double v, double mu, int nn) {
+    if (TINY) { SOLO_SUM4("0xf"); return acc; }
+    nn = uni_i32(nn);
     SOLO_SUM16("0xf");
     return acc;
+}
+// every lane (row, l): v[lane 0 of its row] + ... + v[lane l of its row], the serial prefix inside each row (nn <= 16 terms, entries
+// beyond nn +0.0); lanes >= nn - 1 of a row end with the row's total
+template <bool TINY = false>
+static __device__ __forceinline__ double rows_scan(double v, int nn, const Masks &M) {
+    double acc = 0.0;
+    if (TINY) { SOLO_SCAN4("0xf"); return acc; }
+    nn = uni_i32(nn);
+    SOLO_SCAN16("0xf");
+    return acc;
+}
+
+// a / b without the range scaling and the special-case fix-up of the compiler's division sequence (v_div_scale / v_div_fmas /
+// v_div_fixup): the same reciprocal refinement and the same final correction step, so for operands whose quotient and intermediate
+// products stay clear of overflow and underflow — rates, host counts and numbers in [0, 1) here — it is the same correctly rounded
+// quotient (vgx_test_div_by_const compares it with the division on the device).  b = 0 gives NaN instead of +-inf: only lanes whose
+// result is never read divide by zero.
+static __device__ __forceinline__ double fdiv(double a, double b) {
+    double y = __builtin_amdgcn_rcp(b);
+    double e = __builtin_fma(-b, y, 1.0);
+    y = __builtin_fma(y, e, y);
+    e = __builtin_fma(-b, y, 1.0);
+    y = __builtin_fma(y, e, y);
+    const double q = a * y;
+    const double r = __builtin_fma(-b, q, a);
+    return __builtin_fma(r, y, q);
 }
 
 static __device__ __forceinline__ double bperm_f64(double v, int src_lane) {
@@ -134,16 +207,8 @@ static __device__ __forceinline__ double div_by_const(double n, double b, double
     return __builtin_fma(r, y, q);
 }
 
-static __device__ __forceinline__ bool any_lane(bool c) { return __builtin_amdgcn_ballot_w64(c) != 0ull; }
-static __device__ __forceinline__ int uni_i32(int v) { return __builtin_amdgcn_readfirstlane(v); }
-static __device__ __forceinline__ int64_t uni_i64(int64_t v) {
-    int lo = __builtin_amdgcn_readfirstlane((int)(uint32_t)v), hi = __builtin_amdgcn_readfirstlane((int)(uint32_t)((uint64_t)v >> 32));
-    return (int64_t)(((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo);
-}
-static __device__ __forceinline__ double uni_f64(double v) {
-    int lo = __builtin_amdgcn_readfirstlane(__double2loint(v)), hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
-    return __hiloint2double(hi, lo);
-}
+// lane `k` (a constant) of v takes the wave-uniform value val
+#define SOLO_WRITELANE(v, val, k) asm("v_writelane_b32 %0, %1, " #k : "+v"(v) : "s"(val))
 
 template <int NPR>
 static __device__ __forceinline__ double pop_get(const double (&v)[NPR], int pi) {
@@ -156,55 +221,92 @@ static __device__ __forceinline__ void pop_set(double (&v)[NPR], int pi, double 
     for (int r = 0; r < NPR; ++r) v[r] = (lane + 64 * r == pi) ? val : v[r];
 }
 
-template <int NPR, bool CLOCK>
+// slots of the cold block (LDS): bookkeeping of the call that the event loop itself never reads
+enum { C_EV_PTR = 0, C_LOOPS, C_ATT_LOOPS, C_LOC_N, C_TRAJ_NEXT, C_FA_N, C_ATT_EV0, C_ATT_LOC0, C_RESTARTS, C_ATT, C_GOOD, C_LAST_ATT };
+// lanes of the counter vector
+enum { CNT_MIGN = 6, CNT_SWAP = 7 };
+#define SOLO_BIG (1 << 30)
+
+// The kernel's arguments are read through the kernarg segment pointer (constant address space: scalar loads, wave-uniform values;
+// taking the address of a by-value kernel parameter would make a private copy whose loads count as divergent).  The cold paths see
+// that pointer as an opaque value, so that nothing they read from it is hoisted into the event loop and held in registers there.
+struct VgxSoloKArgs { VgxDirectArgs a; VgxSoloArgs sa; };
+typedef const VgxSoloKArgs __attribute__((address_space(4))) *SoloKA;
+static __device__ __forceinline__ SoloKA cold_args(SoloKA k) {
+    asm volatile("" : "+s"(k));
+    return k;
+}
+
+// NPR: registers of population lanes (1: popNum <= 64, 2: <= 128).  CLOCK: the device clock runs (SampleTime's logarithm).
+// RCPDIV: BirthRate's x / actualSizes through the reciprocal.  NT: 0 = general BirthRate (one pass per segment), 1 / 2 = compact layout
+// with that many registers of terms (popNum <= 64 only).  TINY: popNum, susNum and the compact layout's terms are all <= 4: the
+// chains over them are four steps without a way out.
+template <int NPR, bool CLOCK, bool RCPDIV, int NT, bool TINY>
 struct Solo {
-    // ---- shape, pointers ----
-    int P, H, S, sites, nseg, lane;
-    bool small;           // P <= 16 and H <= 16: the terms of BirthRate already sit in the row of the haplotype lanes
-    bool no_imm;          // every suscepCumulTransition is zero: immuneSourcePopRate stays +0.0
-    bool exact_rcp;
-    const VgxDevParams *p;
-    const VgxDevRep *r;
-    int64_t rep;
+    static constexpr int NTT = NT > 0 ? NT : 1;
+    // ---- shape (wave-uniform: every one of these went through v_readfirstlane, so the compiler keeps them scalar) ----
+    int P, H, S, sites, nseg, lane, l15;
+    int small;            // P <= 16 and H <= 16: the terms of BirthRate already sit in the row of the haplotype lanes (general layout)
+    int no_imm;           // every suscepCumulTransition is zero: immuneSourcePopRate stays +0.0
+    int maxterms;         // compact layout: terms of the longest class sum
     Masks M;
     // LDS
-    double *rowI, *rowCum, *rowHpr, *rowBirth, *rowTE, *susS, *susSt, *susImm, *ldSigma, *ldTrans, *ldMrate, *ldHmt, *ldCd, *ldAs, *ldMig, *ldRng;
+    double *rowI, *rowCum, *rowHpr, *rowBirth, *rowTE, *susS, *susSt, *susImm, *ldSigma, *ldTrans, *ldMrate, *ldHmt, *ldCd, *ldAs, *ldSmult, *ldMig, *ldRng;
     uint32_t *ldStage;
+    uint64_t *ldRngK, *ldRngS;
+    int64_t *ldCold;
     const double *gMig;   // migrationRates in global memory (when it does not fit LDS)
     double *gEff;         // effectiveMigration of this replicate [P][P]
     // ---- haplotype lanes ----
     double bh, dh, sh, tmh;      // bRate, dRate, sRate, sum of mRate of haplotype `lane`
     int stype;                   // suscType
-    uint32_t path;               // bit s: segment s is on this haplotype's path
+    uint32_t path;               // general layout, bit s: segment s is on this haplotype's path
+    int hapClsLane;              // compact layout: 16 * (susceptibility class of the haplotype) = first lane of its class's row
     // the current row (population `cur`)
     int cur;
     double I, cum, hpr, birth, tE, e1, e2, sm;
-    double mrow[NPR];            // migrationRates[cur][lane + 64 r]
-    // ---- susceptibility-group lanes of the current row ----
+    double mrow[NPR];            // general layout: migrationRates[cur][lane + 64 r]
+    // ---- susceptibility-group lanes of the current row: lane (row, s) <-> group s, the same values in all four rows ----
     double Ssus, Sst, imms, cumul_l;
-    // ---- segment lanes ----
+    double sigcs;                // compact layout: susceptibility of class `row` in group s
+    // ---- segment lanes (general layout) ----
     double Sseg, sgsig;
     int sgsn;
+    // ---- term lanes (compact layout): lane (c, j), register t <-> term 16 t + j of class c's BirthRate sum ----
+    double tlS[NTT], tlSig[NTT], tlM[NTT], tlCd[NTT], tlAs[NTT], tlRcp[NTT];   // susceptible count of the term's group, its susceptibility,
+                                                                            // migrationRates[cur][pn], contact density, actualSizes and 1 / it
+    int tlSn[NTT], tlPn[NTT];    // the term's group and population
     // ---- population lanes ----
-    double popRate[NPR], cumPop[NPR], infectP[NPR], immuneP[NPR], migR[NPR], maxEBM[NPR], totS[NPR], totI[NPR], cd[NPR], asz[NPR], rcp[NPR],
-        thrOn[NPR], thrOff[NPR], smult[NPR];
-    int lock[NPR];
+    double popRate[NPR], cumPop[NPR], infectP[NPR], immuneP[NPR], migR[NPR], maxEBM[NPR], totS[NPR], totI[NPR], cd[NPR], asz[NPR], rcp[NPR];
+    double thrCur[NPR], sgnLD[NPR];   // the threshold whose crossing switches the population's lockdown state; +1: switch on above it, -1: off below it
+    // ---- counters: lane t < 6 <-> events of type t, lane 6 rejected migrations, lane 7 lockdown switches ----
+    uint64_t cnt;
     // ---- wave-uniform ----
-    double totalRate, totalMig, Rtot, currentTime, gI, rn;
-    bool has_mig, ld_any;
-    int64_t cB, cD, cS, cM, cI, cSwap, cMigP, cMigN;
-    int64_t ev_ptr, loc_n;
-    int error;
-    // logs
-    int record_events;
-    int64_t evcap, ev_base;
-    double *ev_rate; int32_t *ev_cols;
-    int stage_n; int64_t stage_slot0;
-    int32_t *loc_rec; double *loc_time; int64_t *loc_iter; int64_t loc_cap;
-    double den; int64_t iter_key; int64_t att_loops;
-    double *traj; int64_t traj_points, traj_next; double traj_t0, traj_dt;
+    double totalRate, totalMig, Rtot, currentTime, gI;
+    int has_mig, ld_any;
+    unsigned long long zero_w;    // some fastChoose of this call stopped on a zero weight
+    int stage_n;
+    int pos;                      // iterations consumed from the current batch of 64 uniforms (32 = empty)
+    double u_pre, n_pre;          // the uniform of GenerateEvent / -log of the uniform of SampleTime for iteration `pos`, read ahead
+    double tlimit, next_tg;       // CLOCK: the call's time limit (+inf without one); the next trajectory grid time (+inf without trajectories)
+    int ev_left, loop_left, s_left, ev_left0, loop_left0;
+    uint32_t iter_base;           // low word of the attempt's loop-iteration count at the segment's start + loop_left0
+#ifdef VGX_PROFILE
+    unsigned long long prof_t0, prof_acc;
+#endif
 
     __device__ __forceinline__ double mig_at(int i) const { return ldMig ? ldMig[i] : gMig[i]; }
+    __device__ __forceinline__ int64_t cold_get(int i) const { return ldCold[i]; }
+    __device__ __forceinline__ void cold_set(int i, int64_t v) {
+        if (lane == 0) ldCold[i] = v;
+        WSYNC();
+    }
+    // the uniforms of iteration `pos` (of the batch in LDS) on their way into registers
+    __device__ __forceinline__ void prefetch_uniforms() {
+        const int q = min(pos, 31);
+        u_pre = ldRng[2 * q + 1];
+        if (CLOCK) n_pre = ldRng[2 * q];
+    }
 
     // ---- row cache -------------------------------------------------------------------------------------------------------
     __device__ __forceinline__ void row_store() {
@@ -226,62 +328,97 @@ struct Solo {
             I = rowI[o]; cum = rowCum[o]; hpr = rowHpr[o]; birth = rowBirth[o]; tE = rowTE[o];
         }
         Ssus = 0.0; Sst = 0.0; imms = 0.0;
-        if (lane < S) {
-            const int o = pi * S + lane;
+        if (l15 < S) {
+            const int o = pi * S + l15;
             Ssus = susS[o]; Sst = susSt[o]; imms = susImm[o];
         }
-        Sseg = (lane < nseg) ? susS[pi * S + sgsn] : 0.0;
+        if (NT > 0) {
 #pragma unroll
-        for (int q = 0; q < NPR; ++q) {
-            const int pn = lane + 64 * q;
-            mrow[q] = pn < P ? mig_at(pi * P + pn) : 0.0;
+            for (int t = 0; t < NTT; ++t) {
+                tlS[t] = susS[pi * S + tlSn[t]];
+                tlM[t] = mig_at(pi * P + tlPn[t]);
+            }
+        } else {
+            Sseg = (lane < nseg) ? susS[pi * S + sgsn] : 0.0;
+#pragma unroll
+            for (int q = 0; q < NPR; ++q) {
+                const int pn = lane + 64 * q;
+                mrow[q] = pn < P ? mig_at(pi * P + pn) : 0.0;
+            }
         }
-        sm = sh * pop_get<NPR>(smult, pi);
+        sm = sh * ldSmult[pi];
         e1 = birth + dh;
         e2 = e1 + sm;
-        cur = pi;
+        cur = uni_i32(pi);
     }
     __device__ __forceinline__ void row_switch(int pi) {
         if (pi == cur) return;
         row_store();
         row_load(pi);
     }
+    // the current row's susceptible group `sidx` changes by -d (NewInfections +1 / NewRecoveries -1, pyx:246-260)
+    __device__ __forceinline__ void sus_add(int sidx, double d) {
+        Ssus -= (l15 == sidx ? d : 0.0);
+        if (NT > 0) {
+#pragma unroll
+            for (int t = 0; t < NTT; ++t) tlS[t] -= (tlSn[t] == sidx ? d : 0.0);
+        } else {
+            Sseg -= (lane < nseg && sgsn == sidx ? d : 0.0);
+        }
+    }
 
     // ---- UpdateRates, infect branch, for the current row (pyx:518-528 with BirthRate pyx:382-392); returns infectPopRate ----
     __device__ __forceinline__ double refresh_row() {
         Sst = Ssus;                                 // BirthRate stores susceptHapPopRate = S * sigma (pyx:385-386)
-        const double xseg = Sseg * sgsig;           // segment lanes
-        double ps = 0.0;
-        for (int s = 0; s < nseg; ++s) {
-            const double xs = bcast(xseg, s);
-            const double mu = (double)((path >> s) & 1u);
-            double T[NPR];
+        double ps;
+        if (NT > 0) {
+            // compact layout: every term of every class at once, one class per row; a row's chain is the class's sum in the
+            // reference's (sn, pn) order with the zero-susceptibility terms left out (+0.0 upstream)
+            double acc = 0.0;
 #pragma unroll
-            for (int q = 0; q < NPR; ++q) {
-                const double t = xs * mrow[q] * mrow[q] * cd[q];
-                T[q] = exact_rcp ? div_by_const(t, asz[q], rcp[q]) : t / asz[q];
+            for (int t = 0; t < NTT; ++t) {
+                const double tt = tlS[t] * tlSig[t] * tlM[t] * tlM[t] * tlCd[t];
+                const double T = RCPDIV ? div_by_const(tt, tlAs[t], tlRcp[t]) : tt / tlAs[t];
+                acc = t == 0 ? rows_chain<TINY>(acc, T, 1.0, min(16, maxterms)) : rows_chain<false>(acc, T, 1.0, maxterms - 16);
             }
-            if (small) {
-                ps = rows_chain(ps, T[0], mu, P);
-            } else {
-                for (int b = 0; b < P; b += 16) {
-                    const double src = bperm_f64(b < 64 ? T[0] : T[NPR - 1], (b & 63) + (lane & 15));
-                    ps = rows_chain(ps, src, mu, min(16, P - b));
+            ps = bperm_f64(acc, hapClsLane);
+        } else {
+            const double xseg = Sseg * sgsig;       // segment lanes
+            ps = 0.0;
+            for (int s = 0; s < nseg; ++s) {
+                const double xs = bcast(xseg, s);
+                const double mu = (double)((path >> s) & 1u);
+                double T[NPR];
+#pragma unroll
+                for (int q = 0; q < NPR; ++q) {
+                    const double t = xs * mrow[q] * mrow[q] * cd[q];
+                    T[q] = RCPDIV ? div_by_const(t, asz[q], rcp[q]) : t / asz[q];
+                }
+                if (small) {
+                    ps = rows_chain<false>(ps, T[0], mu, P);
+                } else {
+                    for (int b = 0; b < P; b += 16) {
+                        const double src = bperm_f64(b < 64 ? T[0] : T[NPR - 1], (b & 63) + l15);
+                        ps = rows_chain<false>(ps, src, mu, min(16, P - b));
+                    }
                 }
             }
         }
+        PROF(8);
+        MARK("birthrate_done");
         birth = bh * ps;
         e1 = birth + dh;
         e2 = e1 + sm;
         tE = e2 + tmh;                              // ((r0 + r1) + r2) + r3, pyx:522-525
         hpr = tE * I;
         cum = flat_chain<true>(hpr, H, 0.0, M);
+        MARK("row_scanned");
         return bcast(cum, H - 1);
     }
 
     // popRate[pi] changed: its serial prefix sums and totalRate (pyx:536-539)
     __device__ __forceinline__ void rescan_pop() {
-        cumPop[0] = flat_chain<true>(popRate[0], min(P, 64), 0.0, M);
+        cumPop[0] = flat_chain<true, TINY>(popRate[0], min(P, 64), 0.0, M);
         if (NPR > 1) {
             const double c = bcast(cumPop[0], 63);
             cumPop[NPR - 1] = flat_chain<true>(popRate[NPR - 1], P - 64, c, M);
@@ -295,7 +432,7 @@ struct Solo {
         if (!has_mig) { totalMig = 0.0; return; }
 #pragma unroll
         for (int q = 0; q < NPR; ++q) migR[q] = maxEBM[q] * totS[q] * (gI - totI[q]);
-        double acc = flat_chain<false>(migR[0], min(P, 64), 0.0, M);
+        double acc = flat_chain<false, TINY>(migR[0], min(P, 64), 0.0, M);
         if (NPR > 1) {
             const double c = bcast(acc, 63);
             acc = flat_chain<false>(migR[NPR - 1], P - 64, c, M);
@@ -306,22 +443,16 @@ struct Solo {
     }
     __device__ __forceinline__ double immune_sum() {   // immunePopRate[pi] = 0 + immuneSourcePopRate[pi, 0] + ... (pyx:530-533)
         if (no_imm) return 0.0;
-        const double acc = flat_chain<false>(imms, S, 0.0, M);
+        const double acc = flat_chain<false, TINY>(imms, S, 0.0, M);
         return bcast(acc, S - 1);
-    }
-    // UpdateRates(pi, infect, immune, migration) for pi == cur; inP / imP: the population's current infect / immune rate where
-    // the branch that would refresh it is off
-    __device__ __forceinline__ void update(int pi, bool infect, bool immune, bool migration, double inP, double imP) {
-        if (infect) { inP = refresh_row(); pop_set<NPR>(infectP, pi, inP, lane); }
-        if (immune) { imP = immune_sum(); pop_set<NPR>(immuneP, pi, imP, lane); }
-        pop_set<NPR>(popRate, pi, inP + imP, lane);
-        rescan_pop();
-        if (migration) remig();
-        Rtot = totalRate + totalMig;
     }
 
     // ---- UpdateAllRates (pyx:279-351); the parameter-only parts come from the host (vgx_api.hip) ----
-    __device__ void rebuild_all() {
+    __device__ __forceinline__ void rebuild_all(SoloKA ka) {
+        if (NT > 0) {
+#pragma unroll
+            for (int t = 0; t < NTT; ++t) tlCd[t] = ldCd[tlPn[t]];
+        }
         for (int pn = 0; pn < P; ++pn) {
             row_switch(pn);
             imms = cumul_l * Ssus;                          // pyx:319-321
@@ -359,12 +490,13 @@ struct Solo {
             }
         }
         bool any = false;
+        const double meb = cold_args(ka)->a.p.maxEffectiveBirth;
 #pragma unroll
         for (int q = 0; q < NPR; ++q) {
-            maxEBM[q] = mx[q] * p->maxEffectiveBirth;
+            maxEBM[q] = mx[q] * meb;
             any = any || maxEBM[q] > 0.0;
         }
-        has_mig = any_lane(any);
+        has_mig = any_lane(any) ? 1 : 0;
 #pragma unroll
         for (int q = 0; q < NPR; ++q) migR[q] = 0.0;
         remig();
@@ -372,81 +504,72 @@ struct Solo {
         WSYNC();
     }
 
-    // ---- event log ---------------------------------------------------------------------------------------------------------
-    __device__ __forceinline__ void stage_flush() {
+    // ---- event log: records are staged in LDS (32 bytes each) and written out 64 at a time ----
+    __device__ __forceinline__ void stage_flush(SoloKA ka_, int64_t rep) {
         if (stage_n > 0) {
+            const auto *a = &cold_args(ka_)->a;
             WSYNC();
-            if (lane < stage_n) {
+            // slot of the first staged record: events.ptr now, minus the staged ones, relative to the log's base
+            const int64_t ev_now = cold_get(C_EV_PTR) + (int64_t)(ev_left0 - ev_left);
+            const int64_t slot0 = ev_now - stage_n - a->r.ev_base;
+            if (slot0 < 0 || slot0 + stage_n > a->r.evcap) {
+                zero_w |= 2ull << 32;   // (reported as a capacity error)
+            } else if (lane < stage_n) {
                 const uint32_t *s = ldStage + lane * 8;
-                const int64_t slot = stage_slot0 + lane;
-                int32_t *c = ev_cols + slot * VGX_EV_COLS;
+                const int64_t slot = slot0 + lane;
+                int32_t *c = a->r.ev_cols + (rep * a->r.evcap + slot) * VGX_EV_COLS;
                 c[0] = (int32_t)s[0]; c[1] = (int32_t)s[1]; c[2] = (int32_t)s[2]; c[3] = (int32_t)s[3]; c[4] = (int32_t)s[4]; c[5] = (int32_t)s[5];
-                ev_rate[slot] = __hiloint2double((int)s[7], (int)s[6]);
+                a->r.ev_rate[rep * a->r.evcap + slot] = __hiloint2double((int)s[7], (int)s[6]);
             }
             WSYNC();
         }
         stage_n = 0;
     }
-    __device__ __forceinline__ void add_event(int type, int hap, int pop, int nh, int np) {   // events.pxi:37-44
-        if (record_events) {
-            const int64_t slot = ev_ptr - ev_base;
-            if (slot >= 0 && slot < evcap) {
-                if (stage_n == 0) stage_slot0 = slot;
-                int v = type;
-                v = lane == 1 ? hap : v;
-                v = lane == 2 ? pop : v;
-                v = lane == 3 ? nh : v;
-                v = lane == 4 ? np : v;
-                v = lane == 5 ? (int)(uint32_t)att_loops : v;
-                v = lane == 6 ? __double2loint(den) : v;
-                v = lane == 7 ? __double2hiint(den) : v;
-                if (lane < 8) ldStage[stage_n * 8 + lane] = (uint32_t)v;
-                stage_n += 1;
-                if (stage_n == 64) stage_flush();
-            } else {
-                error = ERR_CAPACITY;
-            }
-        }
-        ev_ptr += 1;
-    }
 
     // ---- CheckLockdown (pyx:698-710) for populations [lo, hi): applies and logs the switches; returns whether any happened ----
-    __device__ bool check_lockdowns(int lo, int hi) {
+    __device__ __forceinline__ bool check_lockdowns(SoloKA ka_, int64_t rep, int lo, int hi) {
+        const auto *a = &cold_args(ka_)->a;
+        const auto &p = a->p;
+        const auto &r = a->r;
         bool any = false;
+        int64_t loc_n = cold_get(C_LOC_N);
+        const int64_t iter_key = (cold_get(C_ATT) << 40) | (cold_get(C_ATT_LOOPS) + (int64_t)(loop_left0 - loop_left));
         for (int pi = lo; pi < hi; ++pi)
             for (int pass = 0; pass < 2; ++pass) {
-                const double ti = pop_get<NPR>(totI, pi);
-                const int lk = NPR == 1 ? __builtin_amdgcn_readlane(lock[0], pi)
-                                        : (pi < 64 ? __builtin_amdgcn_readlane(lock[0], pi) : __builtin_amdgcn_readlane(lock[NPR - 1], pi - 64));
-                const bool flip = pass == 0 ? (ti > pop_get<NPR>(thrOn, pi) && lk == 0) : (ti < pop_get<NPR>(thrOff, pi) && lk == 1);
+                const double ti = pop_get<NPR>(totI, pi), sg = pop_get<NPR>(sgnLD, pi);
+                const double sz = (double)p.sizes[pi];
+                const bool flip = pass == 0 ? (ti > p.startLD[pi] * sz && sg > 0.0) : (ti < p.endLD[pi] * sz && sg < 0.0);
                 if (!any_lane(flip)) continue;
-                const double ncd = pass == 0 ? p->cdAfter[pi] : p->cdBefore[pi];
+                const double ncd = pass == 0 ? p.cdAfter[pi] : p.cdBefore[pi];
                 pop_set<NPR>(cd, pi, ncd, lane);
-#pragma unroll
-                for (int q = 0; q < NPR; ++q) lock[q] = (lane + 64 * q == pi) ? (pass == 0 ? 1 : 0) : lock[q];
+                pop_set<NPR>(sgnLD, pi, pass == 0 ? -1.0 : 1.0, lane);
+                pop_set<NPR>(thrCur, pi, pass == 0 ? p.endLD[pi] * sz : p.startLD[pi] * sz, lane);
                 if (lane == 0) {
                     ldCd[pi] = ncd;
-                    if (loc_n < loc_cap) {
-                        loc_rec[loc_n * 2 + 0] = pass == 0 ? 1 : 0;
-                        loc_rec[loc_n * 2 + 1] = pi;
-                        loc_time[loc_n] = currentTime;
-                        loc_iter[loc_n] = iter_key;
+                    if (loc_n < r.loc_cap) {
+                        r.loc_rec[(rep * r.loc_cap + loc_n) * 2 + 0] = pass == 0 ? 1 : 0;
+                        r.loc_rec[(rep * r.loc_cap + loc_n) * 2 + 1] = pi;
+                        r.loc_time[rep * r.loc_cap + loc_n] = currentTime;
+                        r.loc_iter[rep * r.loc_cap + loc_n] = iter_key;
                     }
                 }
-                if (loc_n >= loc_cap) error = ERR_CAPACITY;
-                cSwap += 1;
+                if (loc_n >= r.loc_cap) zero_w |= 2ull << 32;
+                cnt += (lane == CNT_SWAP) ? 1u : 0u;
                 loc_n += 1;
                 any = true;
             }
-        if (any) WSYNC();
+        if (any) cold_set(C_LOC_N, loc_n);
         return any;
     }
 
-    __device__ void traj_emit(double t_new, bool final_fill) {
-        while (traj_next < traj_points) {
-            const double tg = traj_t0 + (double)traj_next * traj_dt;
+    __device__ __forceinline__ void traj_emit(SoloKA ka_, int64_t rep, double t_new, bool final_fill) {
+        const auto &r = cold_args(ka_)->a.r;
+        int64_t traj_next = cold_get(C_TRAJ_NEXT);
+        const int64_t n0 = traj_next;
+        while (traj_next < r.traj_points) {
+            const double tg = r.traj_t0 + (double)traj_next * r.traj_dt;
             if (!final_fill && !(tg < t_new)) break;
-            double *o = traj + traj_next * (int64_t)P * 2;
+            double *o = r.traj + (rep * r.traj_points + traj_next) * (int64_t)P * 2;
 #pragma unroll
             for (int q = 0; q < NPR; ++q) {
                 const int pn = lane + 64 * q;
@@ -454,39 +577,190 @@ struct Solo {
             }
             traj_next += 1;
         }
+        if (traj_next != n0) cold_set(C_TRAJ_NEXT, traj_next);
     }
 
     // first lane of `hit` or the clamp at n - 1 (fast_choose.pxi:26)
     static __device__ __forceinline__ int first_or_last(unsigned long long hit, int n) {
-        return hit ? (int)__builtin_ctzll(hit) : n - 1;
+        return uni_i32(hit ? (int)__builtin_ctzll(hit) : n - 1);   // (readfirstlane: the index is wave-uniform, and the compiler should know)
+    }
+    // a fastChoose that stops on a zero weight makes the reference exit (fast_choose.pxi:5-13); here the call ends with an error
+    // after the event (indices stay valid, so the rest of the event runs on harmlessly)
+    __device__ __forceinline__ void zero_weight(bool c) { zero_w |= __builtin_amdgcn_ballot_w64(c); }
+
+    // fastChoose(popRate, totalRate, rn) on the cached serial prefix sums (fast_choose.pxi:18-31): r2 = totalRate * rn
+    __device__ __forceinline__ int choose_pop(double r2) {
+        unsigned long long hit = __builtin_amdgcn_ballot_w64(lane < P && !(cumPop[0] < r2));
+        if (NPR == 1) return first_or_last(hit, P);
+        int pi;
+        if (hit) pi = (int)__builtin_ctzll(hit);
+        else {
+            hit = __builtin_amdgcn_ballot_w64(lane + 64 < P && !(cumPop[NPR - 1] < r2));
+            pi = hit ? 64 + (int)__builtin_ctzll(hit) : P - 1;
+        }
+        return uni_i32(pi);
+    }
+    // Birth's fastChoose(susceptHapPopRate[pi, hi, :], their sum, rn7) (pyx:569-572): the group that loses a host
+    __device__ __forceinline__ int choose_group(int hi, double rn7) {
+        if (NT > 0) {
+            // compact layout: lane (c, s) holds class c's susceptHapPopRate for group s; hi's class decides which row is read
+            const double x = Sst * sigcs;
+            const int c16 = uni_i32(__builtin_amdgcn_readlane(hapClsLane, hi));
+            int sidx = 0;
+            if (S > 1) {
+                const double cx = rows_scan<TINY>(x, S, M);
+                const double r8 = bcast(cx, c16 + S - 1) * rn7;
+                const unsigned long long hit = (__builtin_amdgcn_ballot_w64(l15 < S && !(cx < r8)) >> c16) & 0xffffull;
+                sidx = first_or_last(hit, S);
+            }
+            zero_w |= (__builtin_amdgcn_ballot_w64(x == 0.0) >> (c16 + sidx)) & 1ull;
+            return sidx;
+        }
+        const double x = lane < S ? Sst * ldSigma[hi * S + lane] : 0.0;   // susceptHapPopRate[pi, hi, :]
+        int sidx = 0;
+        if (S > 1) {
+            const double cx = flat_chain<true>(x, S, 0.0, M);
+            const double r8 = bcast(cx, S - 1) * rn7;
+            sidx = first_or_last(__builtin_amdgcn_ballot_w64(lane < S && !(cx < r8)), S);
+        }
+        zero_weight(lane == sidx && x == 0.0);
+        return sidx;
     }
 
-    // ---- GenerateEvent (pyx:483-512); returns the population whose lockdown state has to be checked ----
-    __device__ __forceinline__ int generate_event(double u) {
-        double choose = u * Rtot;
-        if (any_lane(totalRate > choose)) {
-            rn = choose / totalRate;
-            // fastChoose(popRate, totalRate, rn), fast_choose.pxi:18-31, on the cached serial prefix sums
-            const double r2 = totalRate * rn;
-            int pi;
-            {
-                unsigned long long hit = __builtin_amdgcn_ballot_w64(lane < P && !(cumPop[0] < r2));
-                if (NPR == 1) {
-                    pi = first_or_last(hit, P);
-                } else {
-                    if (hit) pi = (int)__builtin_ctzll(hit);
-                    else {
-                        hit = __builtin_amdgcn_ballot_w64(lane + 64 < P && !(cumPop[NPR - 1] < r2));
-                        pi = hit ? 64 + (int)__builtin_ctzll(hit) : P - 1;
-                    }
-                }
+    // ---- AddEvent (events.pxi:37-44) into the LDS stage + the counters; type < 0: a rejected migration (counter only) ----
+    __device__ __forceinline__ void log_event(int type, int hap, int pop, int nh, int np, double den) {
+        const int ctr = type >= 0 ? type : CNT_MIGN;
+        cnt += (lane == ctr) ? 1u : 0u;
+        if (type >= 0) {
+            int v = __double2hiint(den);                                  // lane 7 (and the unused lanes)
+            const int it = uni_i32((int)(iter_base - (uint32_t)loop_left));
+            type = uni_i32(type); hap = uni_i32(hap); pop = uni_i32(pop); nh = uni_i32(nh); np = uni_i32(np);
+            SOLO_WRITELANE(v, type, 0); SOLO_WRITELANE(v, hap, 1); SOLO_WRITELANE(v, pop, 2); SOLO_WRITELANE(v, nh, 3);
+            SOLO_WRITELANE(v, np, 4); SOLO_WRITELANE(v, it, 5);
+            v = lane == 6 ? __double2loint(den) : v;
+            if (lane < 8) ldStage[stage_n * 8 + lane] = (uint32_t)v;   // (staged also without an event log: never flushed then)
+            stage_n += 1;
+            ev_left -= 1;
+            if (type == EV_SAMPLING) s_left -= 1;
+        }
+    }
+
+    // ---- the event loop proper: iterations whose event is a Birth, Death or Sampling (pyx:568-635) run here back to back as one
+    // straight path; it returns when something else has to happen — why, and for FAST_SLOW the uniform of GenerateEvent (nothing of
+    // the iteration is consumed yet: the general form below repeats its choice), for FAST_POST the event's population ----
+    enum { FAST_END = 0, FAST_REFILL, FAST_SLOW, FAST_POST };
+    __device__ __forceinline__ int fast_loop(double &u_slow, int &pi_post) {
+        for (;;) {
+            PROF(14);
+            MARK("loop_top");
+            if (min(min(ev_left, loop_left), s_left) <= 0) return FAST_END;
+            if (CLOCK && !any_lane(currentTime < tlimit)) return FAST_END;
+            if (pos == 32) return FAST_REFILL;
+            const double u = u_pre;
+            double t_new = 0.0;
+            if (CLOCK) {
+                t_new = currentTime + (n_pre / Rtot);                      // SampleTime pyx:476-478
+                if (any_lane(next_tg < t_new)) { u_slow = u; return FAST_SLOW; }
             }
+            PROF(0);
+            MARK("event_begin");
+            // GenerateEvent (pyx:483-512)
+            double choose = u * Rtot;
+            if (!any_lane(totalRate > choose)) { u_slow = u; return FAST_SLOW; }
+            double rn = fdiv(choose, totalRate);
+            const int pi = choose_pop(totalRate * rn);
+            PROF(2);
             const double W = pop_get<NPR>(popRate, pi), Cm = pop_get<NPR>(cumPop, pi);
             const double IM = pop_get<NPR>(immuneP, pi), IN = pop_get<NPR>(infectP, pi);
-            if (any_lane(W == 0.0)) { error = ERR_ZERO_WEIGHT; return pi; }
+            zero_weight(W == 0.0);
+            rn = fdiv(totalRate * rn - (Cm - W), W);
+            choose = rn * W;
+            if (any_lane(IM > choose)) { u_slow = u; return FAST_SLOW; }
+            PROF(3);
+            row_switch(pi);
+            PROF(4);
+            rn = fdiv(choose - IM, IN);
+            const double r4 = IN * rn;                                     // fastChoose(hapPopRate[pi], infectPopRate[pi], rn)
+            const int hi = first_or_last(__builtin_amdgcn_ballot_w64(lane < H && !(cum < r4)), H);
+            const double rn5 = fdiv(r4 - (cum - hpr), hpr);                // every candidate lane forms its own rescaled number
+            const double r6 = tE * rn5;                                    // fastChoose(eventHapPopRate[pi, hi, 0..3], tEventHapPopRate[pi, hi], rn)
+            const int eil = (birth < r6 ? 1 : 0) + (e1 < r6 ? 1 : 0) + (e2 < r6 ? 1 : 0);
+            const int ei = __builtin_amdgcn_readlane(eil, hi);
+            if (ei == 3) { u_slow = u; return FAST_SLOW; }
+            PROF(5);
+            // ---- the iteration is this path's: Birth (pyx:568-605, no recombination) / Death / Sampling (pyx:616-635) ----
+            loop_left -= 1;
+            pos += 1;
+            prefetch_uniforms();
+            if (CLOCK) currentTime = t_new;
+            zero_weight(lane == hi && hpr == 0.0);
+            int sidx;
+            if (ei == 0) {
+                zero_weight(lane == hi && birth == 0.0);
+                sidx = choose_group(hi, S > 1 ? bcast(fdiv(r6, birth), hi) : 0.0);   // (r - (e0 - e0)) / e0
+            } else {
+                sidx = uni_i32(__builtin_amdgcn_readlane(stype, hi));
+            }
+            // NewInfections / NewRecoveries (pyx:246-260)
+            const double sgn = ei == 0 ? 1.0 : -1.0;
+            sus_add(sidx, sgn);
+            I += (lane == hi ? sgn : 0.0);
+#pragma unroll
+            for (int q = 0; q < NPR; ++q) {
+                const double d1 = (lane + 64 * q == pi) ? sgn : 0.0;
+                totS[q] -= d1; totI[q] += d1;
+            }
+            gI += sgn;
+            imms = l15 == sidx ? cumul_l * Ssus : imms;
+            PROF(6);
+            // UpdateRates(pi, True, True, True), pyx:516-546
+            const double inP = refresh_row();
+            PROF(9);
+            const double imP = immune_sum();
+            PROF(10);
+            pop_set<NPR>(infectP, pi, inP, lane);
+            pop_set<NPR>(immuneP, pi, imP, lane);
+            pop_set<NPR>(popRate, pi, inP + imP, lane);
+            rescan_pop();
+            PROF(11);
+            remig();
+            PROF(12);
+            const double den = Rtot;
+            Rtot = totalRate + totalMig;
+            log_event(ei, hi, pi, sidx, ei == 0 ? H : 0, den);
+            PROF(13);
+            // what ends the run of fast iterations: a full stage, a zero weight, extinction (pyx:410-411), a lockdown threshold crossed (pyx:412)
+            bool post = stage_n == 64 || zero_w != 0ull || any_lane(totalRate == 0.0) || any_lane(gI == 0.0);
+            if (ld_any) {
+                bool cross = false;
+#pragma unroll
+                for (int q = 0; q < NPR; ++q) cross = cross || (lane + 64 * q == pi && (totI[q] - thrCur[q]) * sgnLD[q] > 0.0);
+                post = post || any_lane(cross);
+            }
+            if (post) { pi_post = pi; return FAST_POST; }
+        }
+    }
+
+    // ---- one iteration of the event loop after SampleTime in its general form: GenerateEvent (pyx:483-512) with UpdateRates and
+    // AddEvent; returns the population whose lockdown state has to be checked ----
+    __device__ __forceinline__ int event(double u) {
+        // what the event leaves for the common tail
+        int u_pi;                      // population whose rates change
+        bool f_infect, f_immune, f_mig;
+        double inP = 0.0, imP = 0.0;   // its infect / immune rate where the tail does not refresh them
+        int ev_type, ev_hap, ev_pop, ev_nh, ev_np;
+        double choose = u * Rtot;
+        if (any_lane(totalRate > choose)) {
+            double rn = choose / totalRate;
+            const double r2 = totalRate * rn;
+            const int pi = choose_pop(r2);
+            const double W = pop_get<NPR>(popRate, pi), Cm = pop_get<NPR>(cumPop, pi);
+            const double IM = pop_get<NPR>(immuneP, pi), IN = pop_get<NPR>(infectP, pi);
+            zero_weight(W == 0.0);
             rn = (r2 - (Cm - W)) / W;
             choose = rn * W;
             row_switch(pi);
+            u_pi = pi; ev_pop = pi;
             if (any_lane(IM > choose)) {
                 // ---- ImmunityTransition (pyx:550-564) ----
                 rn = choose / IM;
@@ -496,7 +770,7 @@ struct Solo {
                     const double r = IM * rn;
                     ssi = first_or_last(__builtin_amdgcn_ballot_w64(lane < S && !(ci < r)), S);
                     const double w = bcast(imms, ssi), tot = bcast(ci, ssi);
-                    if (any_lane(w == 0.0)) { error = ERR_ZERO_WEIGHT; return pi; }
+                    zero_weight(w == 0.0);
                     rn = (r - (tot - w)) / w;
                 }
                 {
@@ -504,75 +778,52 @@ struct Solo {
                     const double ct = flat_chain<true>(tr, S, 0.0, M);
                     const double r = bcast(cumul_l, ssi) * rn;
                     tsi = first_or_last(__builtin_amdgcn_ballot_w64(lane < S && !(ct < r)), S);
-                    const double w = bcast(tr, tsi), tot = bcast(ct, tsi);
-                    if (any_lane(w == 0.0)) { error = ERR_ZERO_WEIGHT; return pi; }
-                    rn = (r - (tot - w)) / w;
+                    zero_weight(lane == tsi && tr == 0.0);
                 }
-                Ssus += (lane == tsi ? 1.0 : 0.0) - (lane == ssi ? 1.0 : 0.0);
-                Sseg += (lane < nseg && sgsn == tsi ? 1.0 : 0.0) - (lane < nseg && sgsn == ssi ? 1.0 : 0.0);
-                imms = (lane == ssi || lane == tsi) ? Ssus * cumul_l : imms;
-                update(pi, false, true, false, IN, 0.0);
-                cI += 1;
-                add_event(EV_SUSCCHANGE, ssi, pi, tsi, 0);
+                sus_add(ssi, 1.0);
+                sus_add(tsi, -1.0);
+                imms = (l15 == ssi || l15 == tsi) ? Ssus * cumul_l : imms;
+                f_infect = false; f_immune = true; f_mig = false; inP = IN;
+                ev_type = EV_SUSCCHANGE; ev_hap = ssi; ev_nh = tsi; ev_np = 0;
             } else {
                 rn = (choose - IM) / IN;
                 // fastChoose(hapPopRate[pi], infectPopRate[pi], rn) on the row's cached prefix sums
                 const double r4 = IN * rn;
                 const int hi = first_or_last(__builtin_amdgcn_ballot_w64(lane < H && !(cum < r4)), H);
-                if (any_lane(lane == hi && hpr == 0.0)) { error = ERR_ZERO_WEIGHT; return pi; }
+                zero_weight(lane == hi && hpr == 0.0);
                 const double rn5 = (r4 - (cum - hpr)) / hpr;           // every candidate lane forms its own rescaled number
                 // fastChoose(eventHapPopRate[pi, hi, 0..3], tEventHapPopRate[pi, hi], rn): the running totals are e0, e1, e2
                 const double r6 = tE * rn5;
                 const int eil = (birth < r6 ? 1 : 0) + (e1 < r6 ? 1 : 0) + (e2 < r6 ? 1 : 0);
                 const int ei = __builtin_amdgcn_readlane(eil, hi);
-                if (ei == 0) {
-                    // ---- Birth (pyx:568-605), no recombination ----
-                    if (any_lane(lane == hi && birth == 0.0)) { error = ERR_ZERO_WEIGHT; return pi; }
-                    int si = 0;
-                    {
-                        const double x = lane < S ? Sst * ldSigma[hi * S + lane] : 0.0;   // susceptHapPopRate[pi, hi, :]
-                        if (S > 1) {
-                            const double rn7 = bcast(r6 / birth, hi);                    // (r - (e0 - e0)) / e0
-                            const double cx = flat_chain<true>(x, S, 0.0, M);
-                            const double r8 = bcast(cx, S - 1) * rn7;
-                            si = first_or_last(__builtin_amdgcn_ballot_w64(lane < S && !(cx < r8)), S);
-                        }
-                        if (any_lane(lane == si && x == 0.0)) { error = ERR_ZERO_WEIGHT; return pi; }
+                ev_hap = hi;
+                if (ei < 3) {
+                    // ---- Birth (pyx:568-605, no recombination) / Death / Sampling (pyx:616-635) ----
+                    int sidx;
+                    if (ei == 0) {
+                        zero_weight(lane == hi && birth == 0.0);
+                        sidx = choose_group(hi, S > 1 ? bcast(r6 / birth, hi) : 0.0);   // (r - (e0 - e0)) / e0
+                    } else {
+                        sidx = __builtin_amdgcn_readlane(stype, hi);
                     }
-                    // NewInfections(pi, si, hi, 1), pyx:246-251
-                    Ssus -= (lane == si ? 1.0 : 0.0);
-                    Sseg -= (lane < nseg && sgsn == si ? 1.0 : 0.0);
-                    I += (lane == hi ? 1.0 : 0.0);
+                    sidx = uni_i32(sidx);
+                    // NewInfections / NewRecoveries (pyx:246-260)
+                    const double sgn = ei == 0 ? 1.0 : -1.0;
+                    sus_add(sidx, sgn);
+                    I += (lane == hi ? sgn : 0.0);
 #pragma unroll
                     for (int q = 0; q < NPR; ++q) {
-                        const double d1 = (lane + 64 * q == pi) ? 1.0 : 0.0;
+                        const double d1 = (lane + 64 * q == pi) ? sgn : 0.0;
                         totS[q] -= d1; totI[q] += d1;
                     }
-                    gI += 1.0;
-                    add_event(EV_BIRTH, hi, pi, si, H);
-                    imms = lane == si ? cumul_l * Ssus : imms;
-                    update(pi, true, true, true, 0.0, 0.0);
-                    cB += 1;
-                } else if (ei == 1 || ei == 2) {
-                    // ---- Death / Sampling (pyx:616-635) ----
-                    const int st = __builtin_amdgcn_readlane(stype, hi);
-                    Ssus += (lane == st ? 1.0 : 0.0);
-                    Sseg += (lane < nseg && sgsn == st ? 1.0 : 0.0);
-                    I -= (lane == hi ? 1.0 : 0.0);
-#pragma unroll
-                    for (int q = 0; q < NPR; ++q) {
-                        const double d1 = (lane + 64 * q == pi) ? 1.0 : 0.0;
-                        totS[q] += d1; totI[q] -= d1;
-                    }
-                    gI -= 1.0;
-                    imms = lane == st ? Ssus * cumul_l : imms;
-                    update(pi, true, true, true, 0.0, 0.0);
-                    if (ei == 1) { cD += 1; add_event(EV_DEATH, hi, pi, st, 0); }
-                    else { cS += 1; add_event(EV_SAMPLING, hi, pi, st, 0); }
+                    gI += sgn;
+                    imms = l15 == sidx ? cumul_l * Ssus : imms;
+                    f_infect = true; f_immune = true; f_mig = true;
+                    ev_type = ei; ev_nh = sidx; ev_np = ei == 0 ? H : 0;
                 } else {
                     // ---- Mutation (pyx:640-667) ----
                     const double tEh = bcast(tE, hi), tmv = bcast(tmh, hi), r6h = bcast(r6, hi);
-                    if (any_lane(tmv == 0.0)) { error = ERR_ZERO_WEIGHT; return pi; }
+                    zero_weight(tmv == 0.0);
                     rn = (r6h - (tEh - tmv)) / tmv;
                     int mi, DS;
                     {   // fastChoose(mRate[hi, :], tmRate[hi], rn)
@@ -582,9 +833,9 @@ struct Solo {
                         double total = w[0];
                         while (any_lane(total < r) && i < sites - 1) { i += 1; total += w[i]; }
                         const double wi = w[i];
-                        if (any_lane(wi == 0.0)) { error = ERR_ZERO_WEIGHT; return pi; }
+                        zero_weight(wi == 0.0);
                         rn = (r - (total - wi)) / wi;
-                        mi = i;
+                        mi = uni_i32(i);
                     }
                     {   // fastChoose(hapMutType[hi, mi, :], their sum, rn)
                         const double *w = ldHmt + (hi * sites + mi) * 3;
@@ -592,162 +843,179 @@ struct Solo {
                         int i = 0;
                         double total = w[0];
                         while (any_lane(total < r) && i < 2) { i += 1; total += w[i]; }
-                        const double wi = w[i];
-                        if (any_lane(wi == 0.0)) { error = ERR_ZERO_WEIGHT; return pi; }
-                        rn = (r - (total - wi)) / wi;
-                        DS = i;
+                        zero_weight(w[i] == 0.0);
+                        DS = uni_i32(i);
                     }
                     const int digit4 = 1 << (2 * (sites - mi - 1));      // Mutate, pyx:2420-2427
                     const int AS = (hi / digit4) % 4;
                     if (DS >= AS) DS += 1;
                     const int nhi = hi + (DS - AS) * digit4;
                     I += (lane == nhi ? 1.0 : 0.0) - (lane == hi ? 1.0 : 0.0);
-                    update(pi, true, false, false, 0.0, IM);
-                    cM += 1;
-                    add_event(EV_MUTATION, hi, pi, nhi, 0);
+                    f_infect = true; f_immune = false; f_mig = false; imP = IM;
+                    ev_type = EV_MUTATION; ev_nh = nhi; ev_np = 0;
                 }
             }
-            return pi;
-        }
-        // ---- GenerateMigration (pyx:672-694) ----
-        rn = (choose - totalRate) / totalMig;
-        int tpi;
-        {   // fastChoose(migPopRate, totalMigrationRate, rn)
-            double cm[NPR];
-            cm[0] = flat_chain<true>(migR[0], min(P, 64), 0.0, M);
-            if (NPR > 1) cm[NPR - 1] = flat_chain<true>(migR[NPR - 1], P - 64, bcast(cm[0], 63), M);
-            const double r = totalMig * rn;
-            unsigned long long hit = __builtin_amdgcn_ballot_w64(lane < P && !(cm[0] < r));
-            if (NPR == 1) tpi = first_or_last(hit, P);
-            else if (hit) tpi = (int)__builtin_ctzll(hit);
-            else { hit = __builtin_amdgcn_ballot_w64(lane + 64 < P && !(cm[NPR - 1] < r)); tpi = hit ? 64 + (int)__builtin_ctzll(hit) : P - 1; }
-            const double w = pop_get<NPR>(migR, tpi), tot = pop_get<NPR>(cm, tpi);
-            if (any_lane(w == 0.0)) { error = ERR_ZERO_WEIGHT; return tpi; }
-            rn = (r - (tot - w)) / w;
-        }
-        int spi;
-        {   // fastChoose_skip(totalInfectious, globalInfectious - totalInfectious[tpi], rn, tpi), fast_choose.pxi:36-52 (integer
-            // weights: whole numbers below 2^53 add exactly in any order)
-            double wv[NPR], cs[NPR];
-#pragma unroll
-            for (int q = 0; q < NPR; ++q) wv[q] = (lane + 64 * q == tpi || lane + 64 * q >= P) ? 0.0 : totI[q];
-            cs[0] = flat_chain<true>(wv[0], min(P, 64), 0.0, M);
-            if (NPR > 1) cs[NPR - 1] = flat_chain<true>(wv[NPR - 1], P - 64, bcast(cs[0], 63), M);
-            const double r = (gI - pop_get<NPR>(totI, tpi)) * rn;
-            unsigned long long hit = __builtin_amdgcn_ballot_w64(lane < P && lane != tpi && !(cs[0] < r));
-            if (hit) spi = (int)__builtin_ctzll(hit);
-            else if (NPR == 1) spi = P - 1;
-            else { hit = __builtin_amdgcn_ballot_w64(lane + 64 < P && lane + 64 != tpi && !(cs[NPR - 1] < r)); spi = hit ? 64 + (int)__builtin_ctzll(hit) : P - 1; }
-            const double w = pop_get<NPR>(totI, spi), tot = pop_get<NPR>(cs, spi);
-            if (any_lane(w == 0.0)) { error = ERR_ZERO_WEIGHT; return tpi; }
-            // running total at the stop: every weight up to spi except the skipped one (also at a clamp on the skipped index, where
-            // upstream's total does not hold the weight it then subtracts)
-            rn = (r - (tot - w)) / w;
-        }
-        int hi;
-        double b_hi;
-        {   // fastChoose(infectious[spi], totalInfectious[spi], rn)
-            row_switch(spi);
-            const double ci = flat_chain<true>(I, H, 0.0, M);
-            const double r = pop_get<NPR>(totI, spi) * rn;
-            hi = first_or_last(__builtin_amdgcn_ballot_w64(lane < H && !(ci < r)), H);
-            const double w = bcast(I, hi), tot = bcast(ci, hi);
-            if (any_lane(w == 0.0)) { error = ERR_ZERO_WEIGHT; return tpi; }
-            rn = (r - (tot - w)) / w;
-            b_hi = bcast(bh, hi);
-        }
-        int si;
-        {   // fastChoose(susceptible[tpi], totalSusceptible[tpi], rn)
-            row_switch(tpi);
-            const double cs = flat_chain<true>(Ssus, S, 0.0, M);
-            const double r = pop_get<NPR>(totS, tpi) * rn;
-            si = first_or_last(__builtin_amdgcn_ballot_w64(lane < S && !(cs < r)), S);
-            const double w = bcast(Ssus, si), tot = bcast(cs, si);
-            if (any_lane(w == 0.0)) { error = ERR_ZERO_WEIGHT; return tpi; }
-            rn = (r - (tot - w)) / w;
-        }
-        const double p_accept = gEff[spi * P + tpi] * b_hi * ldSigma[hi * S + si] / pop_get<NPR>(maxEBM, tpi);
-        if (any_lane(rn < p_accept)) {
-            Ssus -= (lane == si ? 1.0 : 0.0);
-            Sseg -= (lane < nseg && sgsn == si ? 1.0 : 0.0);
-            I += (lane == hi ? 1.0 : 0.0);
-#pragma unroll
-            for (int q = 0; q < NPR; ++q) {
-                const double d1 = (lane + 64 * q == tpi) ? 1.0 : 0.0;
-                totS[q] -= d1; totI[q] += d1;
-            }
-            gI += 1.0;
-            update(tpi, true, true, true, 0.0, 0.0);
-            cMigP += 1;
-            add_event(EV_MIGRATION, hi, spi, si, tpi);
         } else {
-            cMigN += 1;
+            // ---- GenerateMigration (pyx:672-694) ----
+            double rn = (choose - totalRate) / totalMig;
+            int tpi;
+            {   // fastChoose(migPopRate, totalMigrationRate, rn)
+                double cm[NPR];
+                cm[0] = flat_chain<true>(migR[0], min(P, 64), 0.0, M);
+                if (NPR > 1) cm[NPR - 1] = flat_chain<true>(migR[NPR - 1], P - 64, bcast(cm[0], 63), M);
+                const double r = totalMig * rn;
+                unsigned long long hit = __builtin_amdgcn_ballot_w64(lane < P && !(cm[0] < r));
+                if (NPR == 1) tpi = first_or_last(hit, P);
+                else if (hit) tpi = (int)__builtin_ctzll(hit);
+                else { hit = __builtin_amdgcn_ballot_w64(lane + 64 < P && !(cm[NPR - 1] < r)); tpi = hit ? 64 + (int)__builtin_ctzll(hit) : P - 1; }
+                tpi = uni_i32(tpi);
+                const double w = pop_get<NPR>(migR, tpi), tot = pop_get<NPR>(cm, tpi);
+                zero_weight(w == 0.0);
+                rn = (r - (tot - w)) / w;
+            }
+            int spi;
+            {   // fastChoose_skip(totalInfectious, globalInfectious - totalInfectious[tpi], rn, tpi), fast_choose.pxi:36-52 (integer
+                // weights: whole numbers below 2^53 add exactly in any order)
+                double wv[NPR], cs[NPR];
+#pragma unroll
+                for (int q = 0; q < NPR; ++q) wv[q] = (lane + 64 * q == tpi || lane + 64 * q >= P) ? 0.0 : totI[q];
+                cs[0] = flat_chain<true>(wv[0], min(P, 64), 0.0, M);
+                if (NPR > 1) cs[NPR - 1] = flat_chain<true>(wv[NPR - 1], P - 64, bcast(cs[0], 63), M);
+                const double r = (gI - pop_get<NPR>(totI, tpi)) * rn;
+                unsigned long long hit = __builtin_amdgcn_ballot_w64(lane < P && lane != tpi && !(cs[0] < r));
+                if (hit) spi = (int)__builtin_ctzll(hit);
+                else if (NPR == 1) spi = P - 1;
+                else { hit = __builtin_amdgcn_ballot_w64(lane + 64 < P && lane + 64 != tpi && !(cs[NPR - 1] < r)); spi = hit ? 64 + (int)__builtin_ctzll(hit) : P - 1; }
+                spi = uni_i32(spi);
+                const double w = pop_get<NPR>(totI, spi), tot = pop_get<NPR>(cs, spi);
+                zero_weight(w == 0.0);
+                // running total at the stop: every weight up to spi except the skipped one (also at a clamp on the skipped index, where
+                // upstream's total does not hold the weight it then subtracts)
+                rn = (r - (tot - w)) / w;
+            }
+            int hi;
+            double b_hi;
+            {   // fastChoose(infectious[spi], totalInfectious[spi], rn)
+                row_switch(spi);
+                const double ci = flat_chain<true>(I, H, 0.0, M);
+                const double r = pop_get<NPR>(totI, spi) * rn;
+                hi = first_or_last(__builtin_amdgcn_ballot_w64(lane < H && !(ci < r)), H);
+                const double w = bcast(I, hi), tot = bcast(ci, hi);
+                zero_weight(w == 0.0);
+                rn = (r - (tot - w)) / w;
+                b_hi = bcast(bh, hi);
+            }
+            int si;
+            {   // fastChoose(susceptible[tpi], totalSusceptible[tpi], rn)
+                row_switch(tpi);
+                const double cs = flat_chain<true>(Ssus, S, 0.0, M);
+                const double r = pop_get<NPR>(totS, tpi) * rn;
+                si = first_or_last(__builtin_amdgcn_ballot_w64(lane < S && !(cs < r)), S);
+                const double w = bcast(Ssus, si), tot = bcast(cs, si);
+                zero_weight(w == 0.0);
+                rn = (r - (tot - w)) / w;
+            }
+            const double p_accept = gEff[spi * P + tpi] * b_hi * ldSigma[hi * S + si] / pop_get<NPR>(maxEBM, tpi);
+            u_pi = tpi;
+            ev_type = -1; ev_hap = hi; ev_pop = spi; ev_nh = si; ev_np = tpi;
+            f_infect = false; f_immune = false; f_mig = false;
+            if (any_lane(rn < p_accept)) {
+                sus_add(si, 1.0);
+                I += (lane == hi ? 1.0 : 0.0);
+#pragma unroll
+                for (int q = 0; q < NPR; ++q) {
+                    const double d1 = (lane + 64 * q == tpi) ? 1.0 : 0.0;
+                    totS[q] -= d1; totI[q] += d1;
+                }
+                gI += 1.0;
+                f_infect = true; f_immune = true; f_mig = true;
+                ev_type = EV_MIGRATION;
+            }
         }
-        return tpi;
+        // ---- UpdateRates(u_pi, f_infect, f_immune, f_mig) (pyx:516-546): u_pi is the current row ----
+        if (f_infect) { inP = refresh_row(); pop_set<NPR>(infectP, u_pi, inP, lane); }
+        if (f_immune) { imP = immune_sum(); pop_set<NPR>(immuneP, u_pi, imP, lane); }
+        if (f_infect || f_immune) {
+            pop_set<NPR>(popRate, u_pi, inP + imP, lane);
+            rescan_pop();
+        }
+        if (f_mig) remig();
+        // ---- AddEvent (events.pxi:37-44) and the counters ----
+        const double den = Rtot;       // the denominator of this iteration's time step
+        Rtot = totalRate + totalMig;
+        log_event(ev_type, ev_hap, ev_pop, ev_nh, ev_np, den);
+        return u_pi;
     }
 };
 
-struct SoloRng {
-    uint64_t Ah, Al, Gh, Gl;   // per lane: a^(lane+1), sum_{j<=lane} a^j
-    uint64_t sh, sl, ih, il;   // stream position before the batch; increment
-    int pos;                   // iterations consumed from the current batch (32 = empty)
-};
-static __device__ void solo_rng_init(SoloRng &g, int lane) {
-    const uint64_t MH = 0x2360ED051FC65DA4ull, ML = 0x4385DF649FCCF645ull;
-    uint64_t Ah = MH, Al = ML, Gh = 0, Gl = 1;
-    for (int j = 1; j < 64; ++j) {
-        uint64_t nh, nl, gh, gl;
-        vgx_mul128(Ah, Al, MH, ML, nh, nl);
-        vgx_mul128(Gh, Gl, MH, ML, gh, gl);
-        vgx_add128(gh, gl, 0, 1);
-        if (j <= lane) { Ah = nh; Al = nl; Gh = gh; Gl = gl; }
-    }
-    g.Ah = Ah; g.Al = Al; g.Gh = Gh; g.Gl = Gl;
-    g.pos = 32;
-}
-
-template <int NPR, bool CLOCK>
-static __device__ __forceinline__ void solo_body(const VgxDirectArgs &a, const VgxSoloArgs &sa) {
+template <int NPR, bool CLOCK, bool RCPDIV, int NT, bool TINY>
+static __device__ __forceinline__ void solo_body() {
+    const SoloKA ka = (SoloKA)__builtin_amdgcn_kernarg_segment_ptr();
+    const auto &a = ka->a;
+    const auto &sa = ka->sa;
     const int64_t rep = blockIdx.x;
     if (rep >= a.n_replicates) return;
     const int lane = threadIdx.x;
-    const VgxDevParams &p = a.p;
-    const VgxDevRep &r = a.r;
-    const int P = p.P, H = p.H, S = p.S, sites = p.sites;
+    const auto &p = a.p;
+    const auto &r = a.r;
+    const int P = uni_i32(p.P), H = uni_i32(p.H), S = uni_i32(p.S), sites = uni_i32(p.sites);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const VgxSoloLayout L = vgx_solo_layout(P, H, S, sites, sa.mig_in_lds);
 
-    Solo<NPR, CLOCK> c;
-    c.P = P; c.H = H; c.S = S; c.sites = sites; c.nseg = sa.nseg; c.lane = lane;
-    c.small = P <= 16 && H <= 16;
-    c.exact_rcp = sa.exact_rcp_div != 0;
-    c.p = &a.p; c.r = &a.r; c.rep = rep;
+    Solo<NPR, CLOCK, RCPDIV, NT, TINY> c;
+    constexpr int NTT = NT > 0 ? NT : 1;
+    c.P = P; c.H = H; c.S = S; c.sites = sites; c.nseg = uni_i32(sa.nseg); c.lane = lane; c.l15 = lane & 15;
+    c.small = uni_i32((P <= 16 && H <= 16) ? 1 : 0);
+    c.maxterms = uni_i32(sa.maxterms);
 #pragma unroll
     for (int k = 0; k < 16; ++k) c.M.m[k] = (lane & 15) >= k ? 1.0 : 0.0;
     c.ldRng = (double *)(smem + L.rng); c.ldStage = (uint32_t *)(smem + L.stage);
+    c.ldRngK = (uint64_t *)(smem + L.rngk); c.ldRngS = (uint64_t *)(smem + L.rngs); c.ldCold = (int64_t *)(smem + L.cold);
     c.rowI = (double *)(smem + L.rowI); c.rowCum = (double *)(smem + L.rowCum); c.rowHpr = (double *)(smem + L.rowHpr);
     c.rowBirth = (double *)(smem + L.rowBirth); c.rowTE = (double *)(smem + L.rowTE);
     c.susS = (double *)(smem + L.susS); c.susSt = (double *)(smem + L.susSt); c.susImm = (double *)(smem + L.susImm);
     c.ldSigma = (double *)(smem + L.sigma); c.ldTrans = (double *)(smem + L.trans);
     c.ldMrate = (double *)(smem + L.mrate); c.ldHmt = (double *)(smem + L.hmt);
-    c.ldCd = (double *)(smem + L.cd); c.ldAs = (double *)(smem + L.as);
+    c.ldCd = (double *)(smem + L.cd); c.ldAs = (double *)(smem + L.as); c.ldSmult = (double *)(smem + L.smult);
     c.ldMig = L.mig >= 0 ? (double *)(smem + L.mig) : nullptr;
     c.gMig = p.mig;
     c.gEff = r.effMig + rep * P * P;
 
     // ---- parameters ----
-    c.bh = 0.0; c.dh = 0.0; c.sh = 0.0; c.tmh = 0.0; c.stype = 0; c.path = 0u;
+    c.bh = 0.0; c.dh = 0.0; c.sh = 0.0; c.tmh = 0.0; c.stype = 0; c.path = 0u; c.hapClsLane = 0;
     if (lane < H) {
         const int cl = p.cls[lane];
         c.bh = p.bRate[lane]; c.dh = p.c_d[cl]; c.sh = p.c_s[cl]; c.tmh = p.c_tm[cl];
         c.stype = (int)p.suscType[lane];
-        for (int s = 0; s < sa.nseg; ++s)
-            if (p.susc[lane * S + sa.seg_sn[s]] == sa.seg_sig[s]) c.path |= 1u << s;
+        if (NT > 0) {
+            c.hapClsLane = 16 * sa.hap_cls[lane];
+        } else {
+            for (int s = 0; s < sa.nseg; ++s)
+                if (p.susc[lane * S + sa.seg_sn[s]] == sa.seg_sig[s]) c.path |= 1u << s;
+        }
     }
     c.sgsn = 0; c.sgsig = 0.0;
-    if (lane < sa.nseg) { c.sgsn = sa.seg_sn[lane]; c.sgsig = sa.seg_sig[lane]; }
-    c.cumul_l = lane < S ? p.suscepCumul[lane] : 0.0;
-    c.no_imm = !any_lane(c.cumul_l != 0.0);
+    if (NT == 0 && lane < sa.nseg) { c.sgsn = sa.seg_sn[lane]; c.sgsig = sa.seg_sig[lane]; }
+    c.cumul_l = c.l15 < S ? p.suscepCumul[c.l15] : 0.0;
+    c.no_imm = any_lane(c.cumul_l != 0.0) ? 0 : 1;
+    c.sigcs = 0.0;
+#pragma unroll
+    for (int t = 0; t < NTT; ++t) { c.tlS[t] = 0.0; c.tlSig[t] = 0.0; c.tlM[t] = 0.0; c.tlCd[t] = 0.0; c.tlAs[t] = 1.0; c.tlRcp[t] = 1.0; c.tlSn[t] = 0; c.tlPn[t] = 0; }
+    if (NT > 0) {
+        const int cl = lane >> 4;                               // the class of this lane's row
+        if (cl < sa.n_cls && c.l15 < S) c.sigcs = sa.cls_sigma[cl * VGX_SOLO_MAX_S + c.l15];
+#pragma unroll
+        for (int t = 0; t < NTT; ++t) {
+            const int k = 16 * t + c.l15, o = k / P, pn = k - o * P;
+            if (cl < sa.n_cls && o < sa.cls_nnz[cl]) {
+                c.tlSn[t] = sa.cls_tsn[cl * VGX_SOLO_MAX_S + o];
+                c.tlSig[t] = sa.cls_tsig[cl * VGX_SOLO_MAX_S + o];
+                c.tlPn[t] = pn;
+                c.tlAs[t] = p.actualSizes[pn];
+                c.tlRcp[t] = sa.rcpAs[pn];
+            }
+        }
+    }
     for (int i = lane; i < H * S; i += 64) c.ldSigma[i] = p.susc[i];
     for (int i = lane; i < S * S; i += 64) c.ldTrans[i] = p.suscepTransition[i];
     for (int i = lane; i < H * sites; i += 64) c.ldMrate[i] = p.mRate[i];
@@ -780,127 +1048,195 @@ static __device__ __forceinline__ void solo_body(const VgxDirectArgs &a, const V
         c.cd[q] = in ? gD[PD_CD * P + pn] : 0.0;
         c.asz[q] = in ? p.actualSizes[pn] : 1.0;
         c.rcp[q] = in ? sa.rcpAs[pn] : 1.0;
-        c.smult[q] = in ? p.sampMult[pn] : 0.0;
         c.totS[q] = in ? (double)gI[PI_TOTSUS * P + pn] : 0.0;
         c.totI[q] = in ? (double)gI[PI_TOTINF * P + pn] : 0.0;
-        c.lock[q] = in ? (int)gI[PI_LOCK * P + pn] : 0;
+        const bool on = in && gI[PI_LOCK * P + pn] != 0;
         const double sz = in ? (double)p.sizes[pn] : 0.0;
-        c.thrOn[q] = in ? p.startLD[pn] * sz : 0.0;
-        c.thrOff[q] = in ? p.endLD[pn] * sz : 0.0;
+        const double thrOn = in ? p.startLD[pn] * sz : 0.0, thrOff = in ? p.endLD[pn] * sz : 0.0;
+        c.sgnLD[q] = on ? -1.0 : 1.0;
+        c.thrCur[q] = on ? thrOff : thrOn;
         // a population can switch on only if its threshold lies below its size, off only if it is on
-        ldp = ldp || (in && (c.thrOn[q] < sz || c.lock[q] != 0));
-        if (in) { c.ldCd[pn] = c.cd[q]; c.ldAs[pn] = c.asz[q]; }
+        ldp = ldp || (in && (thrOn < sz || on));
+        if (in) { c.ldCd[pn] = c.cd[q]; c.ldAs[pn] = c.asz[q]; c.ldSmult[pn] = p.sampMult[pn]; }
     }
-    c.ld_any = any_lane(ldp);
-    WSYNC();
+    c.ld_any = any_lane(ldp) ? 1 : 0;
 
     VgxRepScalars *sc = r.sc + rep;
-    c.currentTime = sc->currentTime; c.totalRate = 0.0; c.totalMig = 0.0; c.Rtot = 0.0; c.rn = 0.0;
+    c.currentTime = sc->currentTime; c.totalRate = 0.0; c.totalMig = 0.0; c.Rtot = 0.0;
     c.gI = (double)uni_i64(sc->globalInfectious);
-    c.cB = uni_i64(sc->bCounter); c.cD = uni_i64(sc->dCounter); c.cS = uni_i64(sc->sCounter); c.cM = uni_i64(sc->mCounter);
-    c.cI = uni_i64(sc->iCounter); c.cSwap = uni_i64(sc->swapLockdown); c.cMigP = uni_i64(sc->migPlus); c.cMigN = uni_i64(sc->migNonPlus);
-    c.ev_ptr = uni_i64(sc->ev_ptr); c.loc_n = 0; c.error = 0;
-    c.record_events = a.record_events;
-    c.evcap = r.evcap; c.ev_base = r.ev_base;
-    c.ev_rate = r.ev_rate + rep * r.evcap;
-    c.ev_cols = r.ev_cols + rep * r.evcap * VGX_EV_COLS;
-    c.stage_n = 0; c.stage_slot0 = 0;
-    c.loc_cap = r.loc_cap;
-    c.loc_rec = r.loc_rec + rep * r.loc_cap * 2;
-    c.loc_time = r.loc_time + rep * r.loc_cap;
-    c.loc_iter = r.loc_iter + rep * r.loc_cap;
-    c.den = 0.0; c.iter_key = 0; c.att_loops = 0;
-    c.traj_points = r.traj_points; c.traj_t0 = r.traj_t0; c.traj_dt = r.traj_dt; c.traj_next = 0;
-    c.traj = r.traj ? r.traj + rep * r.traj_points * P * 2 : nullptr;
+    {
+        const int64_t v = lane == 0 ? sc->bCounter : lane == 1 ? sc->dCounter : lane == 2 ? sc->sCounter : lane == 3 ? sc->mCounter
+                        : lane == 4 ? sc->iCounter : lane == 5 ? sc->migPlus : lane == 6 ? sc->migNonPlus : lane == 7 ? sc->swapLockdown : 0;
+        c.cnt = (uint64_t)v;
+    }
+    c.zero_w = 0ull;
+#ifdef VGX_PROFILE
+    c.prof_acc = 0ull; c.prof_t0 = __builtin_readcyclecounter();
+#endif
+    c.stage_n = 0;
+    c.pos = 32; c.u_pre = 0.0; c.n_pre = 0.0;
+    c.ev_left = 0; c.loop_left = 0; c.s_left = 0; c.ev_left0 = 0; c.loop_left0 = 0; c.iter_base = 0u;
     c.cur = -1;
-    c.has_mig = true;
+    c.has_mig = 1;
     c.I = 0.0; c.cum = 0.0; c.hpr = 0.0; c.birth = 0.0; c.tE = 0.0; c.e1 = 0.0; c.e2 = 0.0; c.sm = 0.0;
     c.Ssus = 0.0; c.Sst = 0.0; c.imms = 0.0; c.Sseg = 0.0;
 #pragma unroll
     for (int q = 0; q < NPR; ++q) c.mrow[q] = 0.0;
+    if (lane == 0) {
+        c.ldCold[C_EV_PTR] = sc->ev_ptr; c.ldCold[C_LOOPS] = 0; c.ldCold[C_ATT_LOOPS] = 0; c.ldCold[C_LOC_N] = 0; c.ldCold[C_TRAJ_NEXT] = 0;
+        c.ldCold[C_FA_N] = 0; c.ldCold[C_ATT_EV0] = sc->ev_ptr; c.ldCold[C_ATT_LOC0] = 0; c.ldCold[C_RESTARTS] = 0; c.ldCold[C_ATT] = 0;
+        c.ldCold[C_GOOD] = sc->good_attempt; c.ldCold[C_LAST_ATT] = -1;
+    }
+    {   // PCG64 jump constants of this lane: a^(lane+1), sum_{j<=lane} a^j
+        const uint64_t MH = 0x2360ED051FC65DA4ull, ML = 0x4385DF649FCCF645ull;
+        uint64_t Ah = MH, Al = ML, Gh = 0, Gl = 1;
+        for (int j = 1; j < 64; ++j) {
+            uint64_t nh, nl, gh, gl;
+            vgx_mul128(Ah, Al, MH, ML, nh, nl);
+            vgx_mul128(Gh, Gl, MH, ML, gh, gl);
+            vgx_add128(gh, gl, 0, 1);
+            if (j <= lane) { Ah = nh; Al = nl; Gh = gh; Gl = gl; }
+        }
+        c.ldRngK[lane * 4 + 0] = Ah; c.ldRngK[lane * 4 + 1] = Al; c.ldRngK[lane * 4 + 2] = Gh; c.ldRngK[lane * 4 + 3] = Gl;
+    }
+    WSYNC();
 
-    const double tlimit = (double)a.time;
     const bool has_tlimit = !(a.time == -1.0f);
-    const int64_t seed = r.seeds[rep];
-    int64_t loops = 0, restarts = 0, good_attempt = sc->good_attempt, last_att = -1;
-    int64_t att_ev0 = c.ev_ptr, att_loc0 = 0, fa_n = 0;   // first log index / lockdown record of the current attempt
-    SoloRng g;
-    solo_rng_init(g, lane);
-    g.sh = g.sl = g.ih = g.il = 0;
+    const double tlimit = has_tlimit ? (double)a.time : __builtin_inf();
+    c.tlimit = tlimit;
+    c.next_tg = (CLOCK && r.traj != nullptr && r.traj_points > 0) ? r.traj_t0 : __builtin_inf();
+    const bool has_traj = r.traj != nullptr;
+    const int record_events = a.record_events;
+    int error = 0;
 
     // PrepareParameters tail (pyx:449-451): CheckLockdown for every population, UpdateAllRates
-    c.iter_key = 0;
-    if (c.ld_any) c.check_lockdowns(0, P);
-    c.rebuild_all();
+    if (c.ld_any) c.check_lockdowns(ka, rep, 0, P);
+    c.rebuild_all(ka);
 
-    for (int64_t att = 0; att < a.attempts && !c.error; ++att) {   // pyx:399-418
+    for (int64_t att = 0; att < a.attempts && !error; ++att) {   // pyx:399-418
         {
             VgxPcg64 s;
-            vgx_pcg64_seed(s, (uint64_t)seed, (uint32_t)att);
-            g.sh = s.sh; g.sl = s.sl; g.ih = s.ih; g.il = s.il;
-            g.pos = 32;
+            vgx_pcg64_seed(s, (uint64_t)r.seeds[rep], (uint32_t)att);
+            if (lane == 0) {
+                c.ldRngS[0] = s.sh; c.ldRngS[1] = s.sl; c.ldRngS[2] = s.ih; c.ldRngS[3] = s.il;
+                c.ldCold[C_ATT] = att; c.ldCold[C_LAST_ATT] = att; c.ldCold[C_ATT_LOOPS] = 0;
+            }
+            WSYNC();
         }
-        last_att = att; c.att_loops = 0;
+        c.pos = 32;
         if (any_lane(c.Rtot != 0.0) && any_lane(c.gI != 0.0)) {
-            while (c.ev_ptr < a.ev_size && (a.sample_size == -1 || c.cS <= a.sample_size) && (!has_tlimit || any_lane(c.currentTime < tlimit))) {
-                if (loops >= a.max_loop) { c.error = ERR_LOOP_GUARD; break; }
-                loops += 1;
-                c.att_loops += 1;
-                if (g.pos == 32) {
-                    // 64 PCG64 outputs: lane k jumps the stream k + 1 steps ahead (exact 128-bit arithmetic); even outputs are the
-                    // uniforms of SampleTime (pyx:477), odd ones those of GenerateEvent (pyx:488)
-                    uint64_t h, l, ch, cl;
-                    vgx_mul128(g.Ah, g.Al, g.sh, g.sl, h, l);
-                    vgx_mul128(g.Gh, g.Gl, g.ih, g.il, ch, cl);
-                    vgx_add128(h, l, ch, cl);
-                    const double u = vgx_pcg64_output_double(h, l);
-                    WSYNC();
-                    c.ldRng[lane] = (CLOCK && !(lane & 1)) ? -vgx_log(u) : u;
-                    g.sh = (uint64_t)bcast_i64((int64_t)h, 63);
-                    g.sl = (uint64_t)bcast_i64((int64_t)l, 63);
-                    g.pos = 0;
-                    WSYNC();
+            bool done = false;
+            while (!done) {
+                // ---- a segment of the event loop: at most 2^30 iterations on 32-bit countdowns ----
+                int64_t ev_ptr = c.cold_get(C_EV_PTR), loops = c.cold_get(C_LOOPS), att_loops = c.cold_get(C_ATT_LOOPS);
+                {
+                    const int64_t cS = (int64_t)bcast_i64((int64_t)c.cnt, EV_SAMPLING);
+                    const bool go = ev_ptr < a.ev_size && (a.sample_size == -1 || cS <= a.sample_size) && (!has_tlimit || any_lane(c.currentTime < tlimit));
+                    if (!go) break;
+                    if (loops >= a.max_loop) { error = ERR_LOOP_GUARD; break; }
+                    c.ev_left0 = (int)min((int64_t)SOLO_BIG, a.ev_size - ev_ptr);
+                    c.loop_left0 = (int)min((int64_t)SOLO_BIG, a.max_loop - loops);
+                    c.s_left = a.sample_size == -1 ? SOLO_BIG : (int)min((int64_t)SOLO_BIG, a.sample_size - cS + 1);
+                    c.ev_left = c.ev_left0; c.loop_left = c.loop_left0;
+                    c.iter_base = (uint32_t)att_loops + (uint32_t)c.loop_left0;
                 }
-                const double u2 = c.ldRng[2 * g.pos + 1];
-                c.den = c.Rtot;
-                c.iter_key = (att << 40) | c.att_loops;
-                if (CLOCK) {
-                    const double nlog = c.ldRng[2 * g.pos];
-                    const double t_new = c.currentTime + (nlog / c.den);   // SampleTime pyx:476-478
-                    if (c.traj) c.traj_emit(t_new, false);
-                    c.currentTime = t_new;
+                for (;;) {
+                    double u_slow = 0.0;
+                    int pi = 0;
+                    const int why = c.fast_loop(u_slow, pi);
+                    if (why == c.FAST_END) break;
+                    if (why == c.FAST_REFILL) {
+                        // 64 PCG64 outputs: lane k jumps the stream k + 1 steps ahead (exact 128-bit arithmetic); even outputs are the
+                        // uniforms of SampleTime (pyx:477), odd ones those of GenerateEvent (pyx:488)
+                        WSYNC();
+                        const uint64_t Ah = c.ldRngK[lane * 4 + 0], Al = c.ldRngK[lane * 4 + 1], Gh = c.ldRngK[lane * 4 + 2], Gl = c.ldRngK[lane * 4 + 3];
+                        const uint64_t sh = c.ldRngS[0], sl = c.ldRngS[1], ih = c.ldRngS[2], il = c.ldRngS[3];
+                        uint64_t h, l, ch, cl;
+                        vgx_mul128(Ah, Al, sh, sl, h, l);
+                        vgx_mul128(Gh, Gl, ih, il, ch, cl);
+                        vgx_add128(h, l, ch, cl);
+                        const double u = vgx_pcg64_output_double(h, l);
+                        WSYNC();
+                        c.ldRng[lane] = (CLOCK && !(lane & 1)) ? -vgx_log(u) : u;
+                        if (lane == 63) { c.ldRngS[0] = h; c.ldRngS[1] = l; }
+                        c.pos = 0;
+                        WSYNC();
+                        c.prefetch_uniforms();
+                        continue;
+                    }
+                    if (why == c.FAST_SLOW) {
+                        // any other event (or a trajectory grid point first): the general form of one iteration
+                        c.loop_left -= 1;
+                        if (CLOCK) {
+                            const double t_new = c.currentTime + (c.n_pre / c.Rtot);   // SampleTime pyx:476-478
+                            if (has_traj) {
+                                c.traj_emit(ka, rep, t_new, false);
+                                const int64_t tn = c.cold_get(C_TRAJ_NEXT);
+                                c.next_tg = tn < r.traj_points ? r.traj_t0 + (double)tn * r.traj_dt : __builtin_inf();
+                            }
+                            c.currentTime = t_new;
+                        }
+                        c.pos = uni_i32(c.pos + 1);
+                        c.prefetch_uniforms();
+                        pi = c.event(u_slow);
+                        MARK("event_end");
+                    }
+                    // after an iteration: a full stage, a zero weight, extinction (pyx:410-411), CheckLockdown (pyx:412)
+                    if (c.stage_n == 64) {
+                        if (record_events) c.stage_flush(ka, rep);
+                        c.stage_n = 0;
+                    }
+                    if (c.zero_w) { done = true; break; }
+                    if (any_lane(c.totalRate == 0.0) || any_lane(c.gI == 0.0)) { done = true; break; }
+                    if (c.ld_any) {
+                        bool cross = false;
+#pragma unroll
+                        for (int q = 0; q < NPR; ++q) cross = cross || (lane + 64 * q == pi && (c.totI[q] - c.thrCur[q]) * c.sgnLD[q] > 0.0);
+                        if (any_lane(cross)) {
+                            if (c.check_lockdowns(ka, rep, pi, pi + 1)) c.rebuild_all(ka);
+                            if (c.zero_w) { done = true; break; }
+                        }
+                    }
                 }
-                g.pos += 1;
-                const int pi = c.generate_event(u2);
-                if (c.error) break;
-                if (any_lane(c.totalRate == 0.0) || any_lane(c.gI == 0.0)) break;   // pyx:410-411
-                if (c.ld_any && c.check_lockdowns(pi, pi + 1)) c.rebuild_all();    // pyx:412
-                if (c.error) break;
+                // ---- end of the segment: the 64-bit bookkeeping ----
+                if (record_events) c.stage_flush(ka, rep);
+                c.stage_n = 0;
+                if (lane == 0) {
+                    c.ldCold[C_EV_PTR] = ev_ptr + (c.ev_left0 - c.ev_left);
+                    c.ldCold[C_LOOPS] = loops + (c.loop_left0 - c.loop_left);
+                    c.ldCold[C_ATT_LOOPS] = att_loops + (c.loop_left0 - c.loop_left);
+                }
+                c.ev_left0 = 0; c.ev_left = 0; c.loop_left0 = 0; c.loop_left = 0;
+                WSYNC();
             }
         }
-        if (c.error) break;
-        c.stage_flush();
-        if (c.ev_ptr <= 100 && a.iterations > 100) {
+        if (c.zero_w) { error = (c.zero_w >> 32) == 2ull ? ERR_CAPACITY : ERR_ZERO_WEIGHT; }
+        if (error) break;
+        const int64_t ev_ptr = c.cold_get(C_EV_PTR);
+        if (ev_ptr <= 100 && a.iterations > 100) {
             // Restart (pyx:714-738); swapLockdown survives.  Lockdown records of the failed attempt stay in the log: keep the
             // (rate, iteration) pairs the host clock needs for them
-            if (c.loc_n > att_loc0 && c.record_events && r.fa_cap > 0) {
-                const int64_t n = c.ev_ptr - att_ev0;
+            const int64_t loc_n = c.cold_get(C_LOC_N), att_loc0 = c.cold_get(C_ATT_LOC0), att_ev0 = c.cold_get(C_ATT_EV0);
+            int64_t fa_n = c.cold_get(C_FA_N);
+            if (loc_n > att_loc0 && a.record_events && r.fa_cap > 0) {
+                const int64_t n = ev_ptr - att_ev0;
                 for (int64_t k = lane; k < n; k += 64) {
-                    const int64_t slot = att_ev0 + k - c.ev_base;
-                    if (fa_n + k < r.fa_cap && slot >= 0 && slot < c.evcap) {
-                        r.fa_rate[rep * r.fa_cap + fa_n + k] = c.ev_rate[slot];
-                        r.fa_key[rep * r.fa_cap + fa_n + k] = (att << 40) | (int64_t)(uint32_t)c.ev_cols[slot * VGX_EV_COLS + 5];
+                    const int64_t slot = att_ev0 + k - r.ev_base;
+                    if (fa_n + k < r.fa_cap && slot >= 0 && slot < r.evcap) {
+                        r.fa_rate[rep * r.fa_cap + fa_n + k] = r.ev_rate[rep * r.evcap + slot];
+                        r.fa_key[rep * r.fa_cap + fa_n + k] = (att << 40) | (int64_t)(uint32_t)r.ev_cols[(rep * r.evcap + slot) * VGX_EV_COLS + 5];
                     }
                 }
                 fa_n += n;
-                WSYNC();
             }
-            att_ev0 = 0;
-            c.iter_key = (att + 1) << 40;   // the CheckLockdown below belongs to the next attempt, before its first iteration
-            c.ev_ptr = 0;
-            c.cB = c.cD = c.cS = c.cM = c.cI = 0; c.cMigP = c.cMigN = 0;
+            if (lane == 0) {
+                c.ldCold[C_FA_N] = fa_n; c.ldCold[C_ATT_EV0] = 0; c.ldCold[C_EV_PTR] = 0; c.ldCold[C_TRAJ_NEXT] = 0;
+                c.ldCold[C_ATT_LOC0] = loc_n; c.ldCold[C_RESTARTS] = c.ldCold[C_RESTARTS] + 1;
+                c.ldCold[C_ATT] = att + 1; c.ldCold[C_ATT_LOOPS] = 0;   // the CheckLockdown below belongs to the next attempt, before its first iteration
+            }
+            c.cnt = lane == CNT_SWAP ? c.cnt : 0ull;
             c.currentTime = 0.0;
-            c.traj_next = 0;
+            c.next_tg = (CLOCK && has_traj && r.traj_points > 0) ? r.traj_t0 : __builtin_inf();
             // compartments back to the initial snapshot
             c.cur = -1;
             WSYNC();
@@ -926,17 +1262,15 @@ static __device__ __forceinline__ void solo_body(const VgxDirectArgs &a, const V
             }
             c.gI = g_all;
             WSYNC();
-            restarts += 1;
-            att_loc0 = c.loc_n;
-            if (c.ld_any) c.check_lockdowns(0, P);
-            c.rebuild_all();
+            if (c.ld_any) c.check_lockdowns(ka, rep, 0, P);
+            c.rebuild_all(ka);
         } else {
-            good_attempt = att + 1;
+            if (lane == 0) c.ldCold[C_GOOD] = att + 1;
+            WSYNC();
             break;
         }
     }
-    c.stage_flush();
-    if (c.traj) c.traj_emit(0.0, true);
+    if (has_traj) c.traj_emit(ka, rep, 0.0, true);
 
     // ---- end state back in the layout of the other direct kernels ----
     c.row_store();
@@ -947,7 +1281,7 @@ static __device__ __forceinline__ void solo_body(const VgxDirectArgs &a, const V
         const unsigned long long nz = __builtin_amdgcn_ballot_w64(v != 0.0);
         const int n = __builtin_popcountll(nz);
         const int pos = __builtin_popcountll(nz & ((1ull << lane) - 1ull));
-        if (n > r.cap) c.error = ERR_CAPACITY;
+        if (n > r.cap) error = ERR_CAPACITY;
         if (v != 0.0 && pos < r.cap) { lh[pos] = lane; lc[pos] = p.cls[lane]; ln[pos] = (int64_t)v; }
         for (int j = lane; j < r.capT; j += 64) lt[j] = j == 0 ? (int64_t)pop_get<NPR>(c.totI, pn) : 0;
         if (lane == 0) gN[pn] = n < r.cap ? n : (int)r.cap;
@@ -964,70 +1298,97 @@ static __device__ __forceinline__ void solo_body(const VgxDirectArgs &a, const V
             gD[PD_CD * P + pn] = c.cd[q];
             gI[PI_TOTSUS * P + pn] = (int64_t)c.totS[q];
             gI[PI_TOTINF * P + pn] = (int64_t)c.totI[q];
-            gI[PI_LOCK * P + pn] = c.lock[q];
+            gI[PI_LOCK * P + pn] = c.sgnLD[q] < 0.0 ? 1 : 0;
         }
     }
     for (int i = lane; i < P * S; i += 64) {
         r.sus[rep * P * S + i] = (int64_t)c.susS[i];
         r.immSrc[rep * P * S + i] = c.susImm[i];
     }
-    if (lane == 0) {
-        sc->currentTime = c.currentTime; sc->totalRate = c.totalRate; sc->totalMig = c.totalMig;
-        sc->globalInfectious = (int64_t)c.gI;
-        sc->bCounter = c.cB; sc->dCounter = c.cD; sc->sCounter = c.cS; sc->mCounter = c.cM; sc->iCounter = c.cI;
-        sc->swapLockdown = c.cSwap; sc->migPlus = c.cMigP; sc->migNonPlus = c.cMigN;
-        sc->good_attempt = good_attempt;
-        sc->ev_ptr = c.ev_ptr; sc->loop_iterations = loops; sc->restarts = restarts;
-        sc->loc_n = c.loc_n; sc->error = c.error; sc->traj_next = c.traj_next;
-        sc->last_attempt = last_att; sc->last_attempt_loops = c.att_loops;
-        sc->rec_n = 0;
-        sc->fa_n = fa_n;
+#ifdef VGX_PROFILE
+    if (lane < VGX_PROF_SLOTS && r.prof) r.prof[rep * VGX_PROF_SLOTS + lane] = c.prof_acc;
+#endif
+    {
+        const int64_t cB = bcast_i64((int64_t)c.cnt, 0), cD = bcast_i64((int64_t)c.cnt, 1), cS = bcast_i64((int64_t)c.cnt, 2), cM = bcast_i64((int64_t)c.cnt, 3);
+        const int64_t cI = bcast_i64((int64_t)c.cnt, 4), cMigP = bcast_i64((int64_t)c.cnt, 5), cMigN = bcast_i64((int64_t)c.cnt, 6), cSwap = bcast_i64((int64_t)c.cnt, 7);
+        if (lane == 0) {
+            sc->currentTime = c.currentTime; sc->totalRate = c.totalRate; sc->totalMig = c.totalMig;
+            sc->globalInfectious = (int64_t)c.gI;
+            sc->bCounter = cB; sc->dCounter = cD; sc->sCounter = cS; sc->mCounter = cM; sc->iCounter = cI;
+            sc->swapLockdown = cSwap; sc->migPlus = cMigP; sc->migNonPlus = cMigN;
+            sc->good_attempt = c.ldCold[C_GOOD];
+            sc->ev_ptr = c.ldCold[C_EV_PTR]; sc->loop_iterations = c.ldCold[C_LOOPS]; sc->restarts = c.ldCold[C_RESTARTS];
+            sc->loc_n = c.ldCold[C_LOC_N]; sc->error = error; sc->traj_next = c.ldCold[C_TRAJ_NEXT];
+            sc->last_attempt = c.ldCold[C_LAST_ATT]; sc->last_attempt_loops = c.ldCold[C_ATT_LOOPS];
+            sc->rec_n = 0;
+            sc->fa_n = c.ldCold[C_FA_N];
+        }
     }
 }
 
 }  // namespace
 
-extern "C" __global__ void __launch_bounds__(64) vgx_solo_kernel_p64(VgxDirectArgs a, VgxSoloArgs sa) { solo_body<1, false>(a, sa); }
-extern "C" __global__ void __launch_bounds__(64) vgx_solo_kernel_p64_clock(VgxDirectArgs a, VgxSoloArgs sa) { solo_body<1, true>(a, sa); }
-extern "C" __global__ void __launch_bounds__(64) vgx_solo_kernel_p128(VgxDirectArgs a, VgxSoloArgs sa) { solo_body<2, false>(a, sa); }
-extern "C" __global__ void __launch_bounds__(64) vgx_solo_kernel_p128_clock(VgxDirectArgs a, VgxSoloArgs sa) { solo_body<2, true>(a, sa); }
+// kernel <-> (population registers, device clock, reciprocal division, compact layout's term registers, tiny shape)
+#define SOLO_KERNEL(name, NPR, CLOCK, RCPDIV, NT, TINY) \
+    extern "C" __global__ void __launch_bounds__(64) name(VgxSoloKArgs) { solo_body<NPR, CLOCK, RCPDIV, NT, TINY>(); }
+SOLO_KERNEL(vgx_solo_kernel_tiny, 1, false, true, 1, true)
+SOLO_KERNEL(vgx_solo_kernel_c1, 1, false, true, 1, false)
+SOLO_KERNEL(vgx_solo_kernel_c2, 1, false, true, 2, false)
+SOLO_KERNEL(vgx_solo_kernel_p64, 1, false, true, 0, false)
+SOLO_KERNEL(vgx_solo_kernel_p128, 2, false, true, 0, false)
+SOLO_KERNEL(vgx_solo_kernel_c1_clock, 1, true, true, 1, false)
+SOLO_KERNEL(vgx_solo_kernel_p64_clock, 1, true, true, 0, false)
+SOLO_KERNEL(vgx_solo_kernel_p128_clock, 2, true, true, 0, false)
+// validation: x / actualSizes as the compiler's division instead of the reciprocal sequence (VGX_SOLO_PLAIN_DIV=1; calls with an event log
+// and no time limit only)
+SOLO_KERNEL(vgx_solo_kernel_tiny_plaindiv, 1, false, false, 1, true)
+SOLO_KERNEL(vgx_solo_kernel_c2_plaindiv, 1, false, false, 2, false)
+SOLO_KERNEL(vgx_solo_kernel_p64_plaindiv, 1, false, false, 0, false)
+SOLO_KERNEL(vgx_solo_kernel_p128_plaindiv, 2, false, false, 0, false)
 
 extern "C" __attribute__((visibility("hidden"))) hipError_t vgxi_launch_solo(const VgxDirectArgs *a, const VgxSoloArgs *sa, int clock,
                                                                             hipStream_t stream) {
     const VgxSoloLayout L = vgx_solo_layout(a->p.P, a->p.H, a->p.S, a->p.sites, sa->mig_in_lds);
-    void (*k)(VgxDirectArgs, VgxSoloArgs) =
-        a->p.P <= 64 ? (clock ? vgx_solo_kernel_p64_clock : vgx_solo_kernel_p64) : (clock ? vgx_solo_kernel_p128_clock : vgx_solo_kernel_p128);
+    const bool tiny = sa->compact == 1 && a->p.P <= 4 && a->p.S <= 4 && sa->maxterms <= 4;
+    void (*k)(VgxSoloKArgs);
+    if (a->p.P > 64) k = clock ? vgx_solo_kernel_p128_clock : sa->exact_rcp_div ? vgx_solo_kernel_p128 : vgx_solo_kernel_p128_plaindiv;
+    else if (clock) k = sa->compact == 1 ? vgx_solo_kernel_c1_clock : vgx_solo_kernel_p64_clock;
+    else if (!sa->exact_rcp_div) k = tiny ? vgx_solo_kernel_tiny_plaindiv : sa->compact == 2 ? vgx_solo_kernel_c2_plaindiv : vgx_solo_kernel_p64_plaindiv;
+    else k = tiny ? vgx_solo_kernel_tiny : sa->compact == 1 ? vgx_solo_kernel_c1 : sa->compact == 2 ? vgx_solo_kernel_c2 : vgx_solo_kernel_p64;
     hipError_t err = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, L.total);
     if (err != hipSuccess) return err;
-    hipLaunchKernelGGL(k, dim3((unsigned)a->n_replicates), dim3(64), (size_t)L.total, stream, *a, *sa);
+    VgxSoloKArgs ka;
+    ka.a = *a; ka.sa = *sa;
+    hipLaunchKernelGGL(k, dim3((unsigned)a->n_replicates), dim3(64), (size_t)L.total, stream, ka);
     return hipGetLastError();
 }
 
-// ---- test hook: the reciprocal division of BirthRate's terms against the division, on the device ----
-extern "C" __global__ void vgx_solo_divtest_kernel(const double *n, const double *b, double *q_seq, double *q_div, int64_t count) {
+// ---- test hook: the two division forms of this file against the division, on the device ----
+extern "C" __global__ void vgx_solo_divtest_kernel(const double *n, const double *b, double *q_seq, double *q_lean, double *q_div, int64_t count) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
     const double y = 1.0 / b[i];
     q_seq[i] = div_by_const(n[i], b[i], y);
+    q_lean[i] = fdiv(n[i], b[i]);
     q_div[i] = n[i] / b[i];
 }
-extern "C" __attribute__((visibility("hidden"))) hipError_t vgxi_launch_solo_divtest(const double *n, const double *b, double *q_seq, double *q_div,
-                                                                                    int64_t count, hipStream_t stream) {
-    hipLaunchKernelGGL(vgx_solo_divtest_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, stream, n, b, q_seq, q_div, count);
-    return hipGetLastError();
-}
-extern "C" int vgx_test_div_by_const(const double *n, const double *b, int64_t count, double *q_seq, double *q_div) {
-    if (!n || !b || !q_seq || !q_div || count < 0) return 1;
+extern "C" int vgx_test_div_by_const(const double *n, const double *b, int64_t count, double *q_seq, double *q_lean, double *q_div) {
+    if (!n || !b || !q_seq || !q_lean || !q_div || count < 0) return 1;
     double *d = nullptr;
-    if (hipMalloc((void **)&d, (size_t)(count > 0 ? count : 1) * 32) != hipSuccess) return 2;
+    const size_t c = (size_t)(count > 0 ? count : 1);
+    if (hipMalloc((void **)&d, c * 40) != hipSuccess) return 2;
     int rc = 0;
     if (hipMemcpy(d, n, (size_t)count * 8, hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemcpy(d + count, b, (size_t)count * 8, hipMemcpyHostToDevice) != hipSuccess ||
-        vgxi_launch_solo_divtest(d, d + count, d + 2 * count, d + 3 * count, count, nullptr) != hipSuccess ||
-        hipDeviceSynchronize() != hipSuccess ||
-        hipMemcpy(q_seq, d + 2 * count, (size_t)count * 8, hipMemcpyDeviceToHost) != hipSuccess ||
-        hipMemcpy(q_div, d + 3 * count, (size_t)count * 8, hipMemcpyDeviceToHost) != hipSuccess)
+        hipMemcpy(d + c, b, (size_t)count * 8, hipMemcpyHostToDevice) != hipSuccess)
         rc = 2;
+    if (!rc) {
+        hipLaunchKernelGGL(vgx_solo_divtest_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, nullptr, d, d + c, d + 2 * c, d + 3 * c, d + 4 * c, count);
+        if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess ||
+            hipMemcpy(q_seq, d + 2 * c, (size_t)count * 8, hipMemcpyDeviceToHost) != hipSuccess ||
+            hipMemcpy(q_lean, d + 3 * c, (size_t)count * 8, hipMemcpyDeviceToHost) != hipSuccess ||
+            hipMemcpy(q_div, d + 4 * c, (size_t)count * 8, hipMemcpyDeviceToHost) != hipSuccess)
+            rc = 2;
+    }
     (void)hipFree(d);
     return rc;
 }
