@@ -125,8 +125,9 @@ static __device__ __forceinline__ double row_carry(double acc, int which) {
 // SCAN: lane l < n ends with carry + v[0] + ... + v[l] (the serial prefix); lanes >= n-1 of the last row that ran hold the total.
 // SUM: every lane of the last row that ran ends with carry + v[0] + ... + v[n-1].  One value per lane, lanes >= n hold +0.0,
 // carry wave-uniform, n wave-uniform (1..64), all lanes active.
-template <bool SCAN, bool TINY = false>
+template <bool SCAN, bool TINY = false, bool UNIT = false>
 static __device__ __forceinline__ double flat_chain(double v, int n, double carry, const Masks &M) {
+    if (UNIT) return carry + v;   // one term (lane 0 holds it; the other lanes' sums are never read)
     double acc = carry;
     const double mu = 1.0;
     if (TINY) {   // n <= 4
@@ -153,8 +154,9 @@ static __device__ __forceinline__ double flat_chain(double v, int n, double carr
 
 // every lane: acc += mu * (v[lane 0 of its row] + ... in order ... + v[lane n-1 of its row]) term by term, mu = 1.0 or 0.0 per
 // lane; v must hold the same 16 values in every row (nn <= 16, entries beyond nn +0.0)
-template <bool TINY = false>
+template <bool TINY = false, bool UNIT = false>
 static __device__ __forceinline__ double rows_chain(double acc, double v, double mu, int nn) {
+    if (UNIT) return acc + v;     // one term per row, in the row's lane 0 (the lanes that read the sum: one haplotype, lane 0)
     if (TINY) { SOLO_SUM4("0xf"); return acc; }
     nn = uni_i32(nn);
     SOLO_SUM16("0xf");
@@ -176,16 +178,20 @@ static __device__ __forceinline__ double rows_scan(double v, int nn, const Masks
 // products stay clear of overflow and underflow — rates, host counts and numbers in [0, 1) here — it is the same correctly rounded
 // quotient (vgx_test_div_by_const compares it with the division on the device).  b = 0 gives NaN instead of +-inf: only lanes whose
 // result is never read divide by zero.
-static __device__ __forceinline__ double fdiv(double a, double b) {
+// (in two halves: the refined reciprocal of a divisor can be formed as soon as the divisor exists, the quotient when the dividend does)
+static __device__ __forceinline__ double refined_rcp(double b) {
     double y = __builtin_amdgcn_rcp(b);
     double e = __builtin_fma(-b, y, 1.0);
     y = __builtin_fma(y, e, y);
     e = __builtin_fma(-b, y, 1.0);
-    y = __builtin_fma(y, e, y);
+    return __builtin_fma(y, e, y);
+}
+static __device__ __forceinline__ double fdiv_y(double a, double b, double y) {
     const double q = a * y;
     const double r = __builtin_fma(-b, q, a);
     return __builtin_fma(r, y, q);
 }
+static __device__ __forceinline__ double fdiv(double a, double b) { return fdiv_y(a, b, refined_rcp(b)); }
 
 static __device__ __forceinline__ double bperm_f64(double v, int src_lane) {
     int lo = __builtin_amdgcn_ds_bpermute(src_lane << 2, __double2loint(v));
@@ -237,11 +243,13 @@ static __device__ __forceinline__ SoloKA cold_args(SoloKA k) {
     return k;
 }
 
+// UNIT: one haplotype, one population, one susceptibility group (BASELINE config 2; upstream's default model): every chain is one addition,
+// every fastChoose over them stops at index 0.
 // NPR: registers of population lanes (1: popNum <= 64, 2: <= 128).  CLOCK: the device clock runs (SampleTime's logarithm).
 // RCPDIV: BirthRate's x / actualSizes through the reciprocal.  NT: 0 = general BirthRate (one pass per segment), 1 / 2 = compact layout
 // with that many registers of terms (popNum <= 64 only).  TINY: popNum, susNum and the compact layout's terms are all <= 4: the
 // chains over them are four steps without a way out.
-template <int NPR, bool CLOCK, bool RCPDIV, int NT, bool TINY>
+template <int NPR, bool CLOCK, bool RCPDIV, int NT, bool TINY, bool UNIT>
 struct Solo {
     static constexpr int NTT = NT > 0 ? NT : 1;
     // ---- shape (wave-uniform: every one of these went through v_readfirstlane, so the compiler keeps them scalar) ----
@@ -249,6 +257,8 @@ struct Solo {
     int small;            // P <= 16 and H <= 16: the terms of BirthRate already sit in the row of the haplotype lanes (general layout)
     int no_imm;           // every suscepCumulTransition is zero: immuneSourcePopRate stays +0.0
     int maxterms;         // compact layout: terms of the longest class sum
+    int mig_lds;          // migrationRates lies in LDS
+    int one_cls;          // compact layout with ONE susceptibility class: all four rows hold its terms (no cross-row read of the sum)
     Masks M;
     // LDS
     double *rowI, *rowCum, *rowHpr, *rowBirth, *rowTE, *susS, *susSt, *susImm, *ldSigma, *ldTrans, *ldMrate, *ldHmt, *ldCd, *ldAs, *ldSmult, *ldMig, *ldRng;
@@ -295,7 +305,10 @@ struct Solo {
     unsigned long long prof_t0, prof_acc;
 #endif
 
-    __device__ __forceinline__ double mig_at(int i) const { return ldMig ? ldMig[i] : gMig[i]; }
+    __device__ __forceinline__ double mig_at(int i) const {   // (a branch, not a select of pointers: that would be a flat access)
+        if (mig_lds) return ldMig[i];
+        return gMig[i];
+    }
     __device__ __forceinline__ int64_t cold_get(int i) const { return ldCold[i]; }
     __device__ __forceinline__ void cold_set(int i, int64_t v) {
         if (lane == 0) ldCold[i] = v;
@@ -367,8 +380,11 @@ struct Solo {
         }
     }
 
-    // ---- UpdateRates, infect branch, for the current row (pyx:518-528 with BirthRate pyx:382-392); returns infectPopRate ----
-    __device__ __forceinline__ double refresh_row() {
+    // ---- UpdateRates, infect branch, for the current row (pyx:518-528) in two halves: BirthRate's sum (pyx:382-392) of every
+    // haplotype lane, then the rates, hapPopRate and its prefix sums; returns infectPopRate.  (Two halves so that the event loop can
+    // put work that does not depend on the sum between them: the compact layout reads it across rows, an LDS round trip.) ----
+    __device__ __forceinline__ double refresh_row() { return refresh_rates(birth_sums()); }
+    __device__ __forceinline__ double birth_sums() {
         Sst = Ssus;                                 // BirthRate stores susceptHapPopRate = S * sigma (pyx:385-386)
         double ps;
         if (NT > 0) {
@@ -379,9 +395,9 @@ struct Solo {
             for (int t = 0; t < NTT; ++t) {
                 const double tt = tlS[t] * tlSig[t] * tlM[t] * tlM[t] * tlCd[t];
                 const double T = RCPDIV ? div_by_const(tt, tlAs[t], tlRcp[t]) : tt / tlAs[t];
-                acc = t == 0 ? rows_chain<TINY>(acc, T, 1.0, min(16, maxterms)) : rows_chain<false>(acc, T, 1.0, maxterms - 16);
+                acc = t == 0 ? rows_chain<TINY, UNIT>(acc, T, 1.0, min(16, maxterms)) : rows_chain<false>(acc, T, 1.0, maxterms - 16);
             }
-            ps = bperm_f64(acc, hapClsLane);
+            ps = one_cls ? acc : bperm_f64(acc, hapClsLane);
         } else {
             const double xseg = Sseg * sgsig;       // segment lanes
             ps = 0.0;
@@ -404,6 +420,9 @@ struct Solo {
                 }
             }
         }
+        return ps;
+    }
+    __device__ __forceinline__ double refresh_rates(double ps) {
         PROF(8);
         MARK("birthrate_done");
         birth = bh * ps;
@@ -411,14 +430,14 @@ struct Solo {
         e2 = e1 + sm;
         tE = e2 + tmh;                              // ((r0 + r1) + r2) + r3, pyx:522-525
         hpr = tE * I;
-        cum = flat_chain<true>(hpr, H, 0.0, M);
+        cum = flat_chain<true, false, UNIT>(hpr, H, 0.0, M);
         MARK("row_scanned");
         return bcast(cum, H - 1);
     }
 
     // popRate[pi] changed: its serial prefix sums and totalRate (pyx:536-539)
     __device__ __forceinline__ void rescan_pop() {
-        cumPop[0] = flat_chain<true, TINY>(popRate[0], min(P, 64), 0.0, M);
+        cumPop[0] = flat_chain<true, TINY, UNIT>(popRate[0], min(P, 64), 0.0, M);
         if (NPR > 1) {
             const double c = bcast(cumPop[0], 63);
             cumPop[NPR - 1] = flat_chain<true>(popRate[NPR - 1], P - 64, c, M);
@@ -432,7 +451,7 @@ struct Solo {
         if (!has_mig) { totalMig = 0.0; return; }
 #pragma unroll
         for (int q = 0; q < NPR; ++q) migR[q] = maxEBM[q] * totS[q] * (gI - totI[q]);
-        double acc = flat_chain<false, TINY>(migR[0], min(P, 64), 0.0, M);
+        double acc = flat_chain<false, TINY, UNIT>(migR[0], min(P, 64), 0.0, M);
         if (NPR > 1) {
             const double c = bcast(acc, 63);
             acc = flat_chain<false>(migR[NPR - 1], P - 64, c, M);
@@ -443,7 +462,7 @@ struct Solo {
     }
     __device__ __forceinline__ double immune_sum() {   // immunePopRate[pi] = 0 + immuneSourcePopRate[pi, 0] + ... (pyx:530-533)
         if (no_imm) return 0.0;
-        const double acc = flat_chain<false, TINY>(imms, S, 0.0, M);
+        const double acc = flat_chain<false, TINY, UNIT>(imms, S, 0.0, M);
         return bcast(acc, S - 1);
     }
 
@@ -590,6 +609,7 @@ struct Solo {
 
     // fastChoose(popRate, totalRate, rn) on the cached serial prefix sums (fast_choose.pxi:18-31): r2 = totalRate * rn
     __device__ __forceinline__ int choose_pop(double r2) {
+        if (UNIT) return 0;
         unsigned long long hit = __builtin_amdgcn_ballot_w64(lane < P && !(cumPop[0] < r2));
         if (NPR == 1) return first_or_last(hit, P);
         int pi;
@@ -605,7 +625,7 @@ struct Solo {
         if (NT > 0) {
             // compact layout: lane (c, s) holds class c's susceptHapPopRate for group s; hi's class decides which row is read
             const double x = Sst * sigcs;
-            const int c16 = uni_i32(__builtin_amdgcn_readlane(hapClsLane, hi));
+            const int c16 = one_cls ? 0 : uni_i32(__builtin_amdgcn_readlane(hapClsLane, hi));
             int sidx = 0;
             if (S > 1) {
                 const double cx = rows_scan<TINY>(x, S, M);
@@ -628,10 +648,11 @@ struct Solo {
     }
 
     // ---- AddEvent (events.pxi:37-44) into the LDS stage + the counters; type < 0: a rejected migration (counter only) ----
+    template <bool KNOWN = false>   // KNOWN: type >= 0
     __device__ __forceinline__ void log_event(int type, int hap, int pop, int nh, int np, double den) {
-        const int ctr = type >= 0 ? type : CNT_MIGN;
+        const int ctr = (KNOWN || type >= 0) ? type : CNT_MIGN;
         cnt += (lane == ctr) ? 1u : 0u;
-        if (type >= 0) {
+        if (KNOWN || type >= 0) {
             int v = __double2hiint(den);                                  // lane 7 (and the unused lanes)
             const int it = uni_i32((int)(iter_base - (uint32_t)loop_left));
             type = uni_i32(type); hap = uni_i32(hap); pop = uni_i32(pop); nh = uni_i32(nh); np = uni_i32(np);
@@ -641,7 +662,7 @@ struct Solo {
             if (lane < 8) ldStage[stage_n * 8 + lane] = (uint32_t)v;   // (staged also without an event log: never flushed then)
             stage_n += 1;
             ev_left -= 1;
-            if (type == EV_SAMPLING) s_left -= 1;
+            s_left -= (type == EV_SAMPLING) ? 1 : 0;
         }
     }
 
@@ -681,7 +702,7 @@ struct Solo {
             PROF(4);
             rn = fdiv(choose - IM, IN);
             const double r4 = IN * rn;                                     // fastChoose(hapPopRate[pi], infectPopRate[pi], rn)
-            const int hi = first_or_last(__builtin_amdgcn_ballot_w64(lane < H && !(cum < r4)), H);
+            const int hi = UNIT ? 0 : first_or_last(__builtin_amdgcn_ballot_w64(lane < H && !(cum < r4)), H);
             const double rn5 = fdiv(r4 - (cum - hpr), hpr);                // every candidate lane forms its own rescaled number
             const double r6 = tE * rn5;                                    // fastChoose(eventHapPopRate[pi, hi, 0..3], tEventHapPopRate[pi, hi], rn)
             const int eil = (birth < r6 ? 1 : 0) + (e1 < r6 ? 1 : 0) + (e2 < r6 ? 1 : 0);
@@ -714,29 +735,29 @@ struct Solo {
             imms = l15 == sidx ? cumul_l * Ssus : imms;
             PROF(6);
             // UpdateRates(pi, True, True, True), pyx:516-546
-            const double inP = refresh_row();
-            PROF(9);
+            const double ps = birth_sums();
             const double imP = immune_sum();
             PROF(10);
+            remig();
+            PROF(12);
+            const double inP = refresh_rates(ps);
+            PROF(9);
             pop_set<NPR>(infectP, pi, inP, lane);
             pop_set<NPR>(immuneP, pi, imP, lane);
             pop_set<NPR>(popRate, pi, inP + imP, lane);
             rescan_pop();
             PROF(11);
-            remig();
-            PROF(12);
             const double den = Rtot;
             Rtot = totalRate + totalMig;
-            log_event(ei, hi, pi, sidx, ei == 0 ? H : 0, den);
+            log_event<true>(ei, hi, pi, sidx, ei == 0 ? H : 0, den);
             PROF(13);
-            // what ends the run of fast iterations: a full stage, a zero weight, extinction (pyx:410-411), a lockdown threshold crossed (pyx:412)
-            bool post = stage_n == 64 || zero_w != 0ull || any_lane(totalRate == 0.0) || any_lane(gI == 0.0);
-            if (ld_any) {
-                bool cross = false;
+            // what ends the run of fast iterations: a full stage, a zero weight, extinction (pyx:410-411), a lockdown threshold crossed
+            // (pyx:412; never true where no lockdown can switch: the threshold then lies at or above the population's size) — one test,
+            // no short circuits
+            bool stop = (totalRate == 0.0) | (gI == 0.0);
 #pragma unroll
-                for (int q = 0; q < NPR; ++q) cross = cross || (lane + 64 * q == pi && (totI[q] - thrCur[q]) * sgnLD[q] > 0.0);
-                post = post || any_lane(cross);
-            }
+            for (int q = 0; q < NPR; ++q) stop = stop | ((lane + 64 * q == pi) & ((totI[q] - thrCur[q]) * sgnLD[q] > 0.0));
+            const unsigned long long post = __builtin_amdgcn_ballot_w64(stop) | zero_w | (unsigned long long)(stage_n >> 6);
             if (post) { pi_post = pi; return FAST_POST; }
         }
     }
@@ -948,7 +969,7 @@ struct Solo {
     }
 };
 
-template <int NPR, bool CLOCK, bool RCPDIV, int NT, bool TINY>
+template <int NPR, bool CLOCK, bool RCPDIV, int NT, bool TINY, bool UNIT>
 static __device__ __forceinline__ void solo_body() {
     const SoloKA ka = (SoloKA)__builtin_amdgcn_kernarg_segment_ptr();
     const auto &a = ka->a;
@@ -962,11 +983,12 @@ static __device__ __forceinline__ void solo_body() {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const VgxSoloLayout L = vgx_solo_layout(P, H, S, sites, sa.mig_in_lds);
 
-    Solo<NPR, CLOCK, RCPDIV, NT, TINY> c;
+    Solo<NPR, CLOCK, RCPDIV, NT, TINY, UNIT> c;
     constexpr int NTT = NT > 0 ? NT : 1;
     c.P = P; c.H = H; c.S = S; c.sites = sites; c.nseg = uni_i32(sa.nseg); c.lane = lane; c.l15 = lane & 15;
     c.small = uni_i32((P <= 16 && H <= 16) ? 1 : 0);
     c.maxterms = uni_i32(sa.maxterms);
+    c.one_cls = uni_i32((NT > 0 && sa.n_cls == 1) ? 1 : 0);
 #pragma unroll
     for (int k = 0; k < 16; ++k) c.M.m[k] = (lane & 15) >= k ? 1.0 : 0.0;
     c.ldRng = (double *)(smem + L.rng); c.ldStage = (uint32_t *)(smem + L.stage);
@@ -977,7 +999,8 @@ static __device__ __forceinline__ void solo_body() {
     c.ldSigma = (double *)(smem + L.sigma); c.ldTrans = (double *)(smem + L.trans);
     c.ldMrate = (double *)(smem + L.mrate); c.ldHmt = (double *)(smem + L.hmt);
     c.ldCd = (double *)(smem + L.cd); c.ldAs = (double *)(smem + L.as); c.ldSmult = (double *)(smem + L.smult);
-    c.ldMig = L.mig >= 0 ? (double *)(smem + L.mig) : nullptr;
+    c.ldMig = (double *)(smem + (L.mig >= 0 ? L.mig : 0));
+    c.mig_lds = uni_i32(L.mig >= 0 ? 1 : 0);
     c.gMig = p.mig;
     c.gEff = r.effMig + rep * P * P;
 
@@ -1002,7 +1025,7 @@ static __device__ __forceinline__ void solo_body() {
 #pragma unroll
     for (int t = 0; t < NTT; ++t) { c.tlS[t] = 0.0; c.tlSig[t] = 0.0; c.tlM[t] = 0.0; c.tlCd[t] = 0.0; c.tlAs[t] = 1.0; c.tlRcp[t] = 1.0; c.tlSn[t] = 0; c.tlPn[t] = 0; }
     if (NT > 0) {
-        const int cl = lane >> 4;                               // the class of this lane's row
+        const int cl = c.one_cls ? 0 : lane >> 4;               // the class of this lane's row
         if (cl < sa.n_cls && c.l15 < S) c.sigcs = sa.cls_sigma[cl * VGX_SOLO_MAX_S + c.l15];
 #pragma unroll
         for (int t = 0; t < NTT; ++t) {
@@ -1020,7 +1043,7 @@ static __device__ __forceinline__ void solo_body() {
     for (int i = lane; i < S * S; i += 64) c.ldTrans[i] = p.suscepTransition[i];
     for (int i = lane; i < H * sites; i += 64) c.ldMrate[i] = p.mRate[i];
     for (int i = lane; i < H * sites * 3; i += 64) c.ldHmt[i] = p.hapMutType[i];
-    if (c.ldMig)
+    if (c.mig_lds)
         for (int i = lane; i < P * P; i += 64) c.ldMig[i] = p.mig[i];
 
     // ---- start state from the layout of the other direct kernels (vgx_dev.h) ----
@@ -1329,22 +1352,23 @@ static __device__ __forceinline__ void solo_body() {
 }  // namespace
 
 // kernel <-> (population registers, device clock, reciprocal division, compact layout's term registers, tiny shape)
-#define SOLO_KERNEL(name, NPR, CLOCK, RCPDIV, NT, TINY) \
-    extern "C" __global__ void __launch_bounds__(64) name(VgxSoloKArgs) { solo_body<NPR, CLOCK, RCPDIV, NT, TINY>(); }
-SOLO_KERNEL(vgx_solo_kernel_tiny, 1, false, true, 1, true)
-SOLO_KERNEL(vgx_solo_kernel_c1, 1, false, true, 1, false)
-SOLO_KERNEL(vgx_solo_kernel_c2, 1, false, true, 2, false)
-SOLO_KERNEL(vgx_solo_kernel_p64, 1, false, true, 0, false)
-SOLO_KERNEL(vgx_solo_kernel_p128, 2, false, true, 0, false)
-SOLO_KERNEL(vgx_solo_kernel_c1_clock, 1, true, true, 1, false)
-SOLO_KERNEL(vgx_solo_kernel_p64_clock, 1, true, true, 0, false)
-SOLO_KERNEL(vgx_solo_kernel_p128_clock, 2, true, true, 0, false)
+#define SOLO_KERNEL(name, NPR, CLOCK, RCPDIV, NT, TINY, UNIT) \
+    extern "C" __global__ void __launch_bounds__(64) name(VgxSoloKArgs) { solo_body<NPR, CLOCK, RCPDIV, NT, TINY, UNIT>(); }
+SOLO_KERNEL(vgx_solo_kernel_unit, 1, false, true, 1, true, true)
+SOLO_KERNEL(vgx_solo_kernel_tiny, 1, false, true, 1, true, false)
+SOLO_KERNEL(vgx_solo_kernel_c1, 1, false, true, 1, false, false)
+SOLO_KERNEL(vgx_solo_kernel_c2, 1, false, true, 2, false, false)
+SOLO_KERNEL(vgx_solo_kernel_p64, 1, false, true, 0, false, false)
+SOLO_KERNEL(vgx_solo_kernel_p128, 2, false, true, 0, false, false)
+SOLO_KERNEL(vgx_solo_kernel_c1_clock, 1, true, true, 1, false, false)
+SOLO_KERNEL(vgx_solo_kernel_p64_clock, 1, true, true, 0, false, false)
+SOLO_KERNEL(vgx_solo_kernel_p128_clock, 2, true, true, 0, false, false)
 // validation: x / actualSizes as the compiler's division instead of the reciprocal sequence (VGX_SOLO_PLAIN_DIV=1; calls with an event log
 // and no time limit only)
-SOLO_KERNEL(vgx_solo_kernel_tiny_plaindiv, 1, false, false, 1, true)
-SOLO_KERNEL(vgx_solo_kernel_c2_plaindiv, 1, false, false, 2, false)
-SOLO_KERNEL(vgx_solo_kernel_p64_plaindiv, 1, false, false, 0, false)
-SOLO_KERNEL(vgx_solo_kernel_p128_plaindiv, 2, false, false, 0, false)
+SOLO_KERNEL(vgx_solo_kernel_tiny_plaindiv, 1, false, false, 1, true, false)
+SOLO_KERNEL(vgx_solo_kernel_c2_plaindiv, 1, false, false, 2, false, false)
+SOLO_KERNEL(vgx_solo_kernel_p64_plaindiv, 1, false, false, 0, false, false)
+SOLO_KERNEL(vgx_solo_kernel_p128_plaindiv, 2, false, false, 0, false, false)
 
 extern "C" __attribute__((visibility("hidden"))) hipError_t vgxi_launch_solo(const VgxDirectArgs *a, const VgxSoloArgs *sa, int clock,
                                                                             hipStream_t stream) {
@@ -1354,6 +1378,7 @@ extern "C" __attribute__((visibility("hidden"))) hipError_t vgxi_launch_solo(con
     if (a->p.P > 64) k = clock ? vgx_solo_kernel_p128_clock : sa->exact_rcp_div ? vgx_solo_kernel_p128 : vgx_solo_kernel_p128_plaindiv;
     else if (clock) k = sa->compact == 1 ? vgx_solo_kernel_c1_clock : vgx_solo_kernel_p64_clock;
     else if (!sa->exact_rcp_div) k = tiny ? vgx_solo_kernel_tiny_plaindiv : sa->compact == 2 ? vgx_solo_kernel_c2_plaindiv : vgx_solo_kernel_p64_plaindiv;
+    else if (tiny && a->p.P == 1 && a->p.H == 1 && a->p.S == 1 && sa->maxterms <= 1 && !getenv("VGX_SOLO_NO_UNIT")) k = vgx_solo_kernel_unit;
     else k = tiny ? vgx_solo_kernel_tiny : sa->compact == 1 ? vgx_solo_kernel_c1 : sa->compact == 2 ? vgx_solo_kernel_c2 : vgx_solo_kernel_p64;
     hipError_t err = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, L.total);
     if (err != hipSuccess) return err;
