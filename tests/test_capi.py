@@ -67,3 +67,32 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp", "Makefile")):
                 text = open(os.path.join(dirpath, f)).read()
                 assert not pat.search(text), (dirpath, f)
+
+
+def test_isa_hazard_scan_finds_a_dpp_read_right_after_its_write():
+    """tools/isa_hazard_scan.py (run by build() on the shipped code objects) on synthetic listings: a VALU write of a DPP source one
+    wait state before the read is reported, through a branch edge too; with the s_nop the chains carry it is clean."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("isa_hazard_scan", os.path.join(os.path.dirname(__file__), "..", "tools", "isa_hazard_scan.py"))
+    hz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(hz)
+    def listing(lines):
+        out = ["0000000000001000 <k>:"]
+        for n, l in enumerate(lines):
+            out.append("\t%s // %012X: 00000000" % (l, 0x1000 + 4 * n))
+        return "\n".join(out)
+    dpp = "v_fmac_f64_dpp v[6:7], v[10:11], v[2:3] row_newbcast:0 row_mask:0xf bank_mask:0xf"
+    bad = hz.parse(listing(["v_accvgpr_read_b32 v10, a3", dpp]))
+    assert hz.scan(bad["k"])[1], "write right before the DPP read"
+    bad = hz.parse(listing(["v_mov_b32_e32 v11, v4", "s_nop 0", dpp]))
+    assert hz.scan(bad["k"])[1], "one wait state is not enough"
+    ok = hz.parse(listing(["v_mov_b32_e32 v11, v4", "s_nop 1", dpp, dpp]))
+    assert hz.scan(ok["k"]) == (2, [])
+    ok = hz.parse(listing(["v_mov_b32_e32 v12, v4", dpp]))
+    assert hz.scan(ok["k"]) == (1, [])
+    # through a branch: the writer sits right before a branch to the DPP instruction (branch = 1 wait state)
+    edge = hz.parse(listing(["v_mov_b32_e32 v10, v4", "s_branch 2", "s_nop 1", "s_nop 1", dpp]))
+    assert hz.scan(edge["k"])[1]
+    ex = hz.parse(listing(["v_cmpx_lt_f64_e32 vcc, v[0:1], v[2:3]", "s_nop 2", dpp]))
+    assert hz.scan(ex["k"])[1], "EXEC written by a VALU instruction within five wait states"

@@ -123,3 +123,47 @@ def test_rccl_gather_single_rank(tmp_path):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     p = subprocess.run([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
     assert p.returncode == 0 and b"RCCL_OK" in p.stdout, p.stdout.decode()[-3000:]
+
+
+@pytest.mark.parametrize("kernel", ["auto", "wave", "quadg"])
+def test_continued_calls_keep_the_host_clock(oracle_mod, kernel):
+    """Time-sliced runs through the C ABI: a second vgx_simulate_direct on the device-resident state (no vgx_set_state in between)
+    continues every replicate where IT stopped — its own events.ptr, and its own clock: the event times of the second slice are the
+    reference's libm sums continued from the first slice's last event, bit for bit what the oracle gives when one model runs both
+    slices (the host clock of the first slice is rebuilt before its logs are overwritten; vgx_api.hip direct_core)."""
+    import ctypes as C
+    from vgsim_amd import Simulator, _capi
+    ctor, phases = models.CASES["g5_short"]
+    seeds = np.array([5, 6, 2020], dtype=np.int64)
+    R, cap, t1, t2 = len(seeds), 30000, 2.5, 5.0
+    with helpers.quiet():
+        sim = Simulator(**ctor)
+    phases[0][0](sim)
+    m = sim.simulation
+    eng = _capi.HipEngine(m.sites, m.hapNum, m.popNum, m.susNum, n_replicates=R)
+    m.events.CreateEvents(cap)
+    eng.set_params(m); eng.set_state(m); eng.set_seeds(seeds)
+    o = _capi.VgxRunOpts(); o.record_events = 1
+    o.kernel = {"auto": 0, "wave": 1, "quadg": 4}[kernel]
+    eng._check(eng.lib.vgx_simulate_direct(eng.handle, cap, 10 ** 9, t1, 200, C.byref(o)))
+    first_ptr = [eng.counters(r).ev_ptr for r in range(R)]
+    eng._check(eng.lib.vgx_simulate_direct(eng.handle, cap, 10 ** 9, t2, 200, C.byref(o)))
+    for r in range(R):
+        with helpers.quiet():
+            one = Simulator(**dict(ctor, seed=int(seeds[r])))
+        phases[0][0](one)
+        om = one.simulation
+        assert oracle_mod.run_direct(om, cap, 10 ** 9, t1, 200) == 0
+        p1 = om.events.ptr
+        assert oracle_mod.run_direct(om, cap, 10 ** 9, t2, 200) == 0
+        c = eng.counters(r)
+        assert first_ptr[r] == p1 and c.ev_first_new == p1 and c.ev_ptr == om.events.ptr, (r, first_ptr[r], p1, c.ev_ptr, om.events.ptr)
+        n = c.ev_ptr - p1
+        assert n > 100
+        times = np.zeros(n); cols = [np.zeros(n, dtype=np.int64) for _ in range(5)]
+        eng._check(eng.lib.vgx_get_events(eng.handle, r, p1, n, _capi._p(times), *[_capi._p(x) for x in cols]))
+        ref = om.events.as_array()[:, p1:om.events.ptr]
+        assert np.array_equal(times, ref[0]), "replicate %d: times of the second slice" % r
+        for k in range(5):
+            assert np.array_equal(cols[k], ref[k + 1].astype(np.int64))
+    eng.close()

@@ -113,12 +113,30 @@ def test_memory_optimization_vs_oracle_table_code(oracle_mod, sites, seed, mut, 
         assert 4 ** (sites - 2) < tb.maxHapNum < 4 ** sites      # the table grew through AddMemory, not to the full space
 
 
-def test_memory_optimization_is_refused_where_upstream_corrupts_its_state():
+def test_memory_optimization_where_upstream_corrupts_its_state(monkeypatch):
+    """Several populations / tau with memory_optimization=True: the reference accepts the call (and corrupts its state); here it runs
+    as the plain layout's trajectory with a warning, single runs and ensembles alike; VGX_STRICT_MEMOPT=1 refuses instead."""
     from vgsim_amd import Simulator
+    from vgsim_amd.ensemble import Ensemble
     with helpers.quiet():
         two = Simulator(2, 2, 1, seed=11, memory_optimization=True)
+        plain = Simulator(2, 2, 1, seed=11)
         one = Simulator(2, 1, 1, seed=11, memory_optimization=True)
+    for s in (two, plain):
+        s.set_mutation_rate(0.3); s.set_migration_probability(0.05)
+    with pytest.warns(RuntimeWarning, match="memory_optimization"), helpers.quiet():
+        two.simulate(3000)
+    with helpers.quiet():
+        plain.simulate(3000)
+    assert np.array_equal(two.simulation.events.as_array(), plain.simulation.events.as_array())
+    assert np.array_equal(two.simulation.infectious, plain.simulation.infectious)
+    seen = np.nonzero(two.simulation.infectious.any(axis=0))[0]
+    tb = two.simulation
+    assert set(seen) <= set(tb.numToHap[:tb.currentHapNum])            # the table's bookkeeping covers what is there
+    with pytest.warns(RuntimeWarning, match="memory_optimization"), helpers.quiet():
+        one.simulate(10, method="tau")
+    with pytest.warns(RuntimeWarning, match="memory_optimization"), helpers.quiet():
+        Ensemble(two, 2).close()
+    monkeypatch.setenv("VGX_STRICT_MEMOPT", "1")
     with pytest.raises(ValueError, match="one population"), helpers.quiet():
         two.simulate(100)
-    with pytest.raises(ValueError, match="direct method"), helpers.quiet():
-        one.simulate(10, method="tau")

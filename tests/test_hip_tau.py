@@ -659,3 +659,38 @@ def test_byte_drift_pass_equals_the_two_pass_form(monkeypatch, sites, P, S, fill
     for k in a.COUNTERS:
         assert getattr(a, k) == getattr(b, k), k
     assert a.bCounter > 0
+
+
+@pytest.mark.parametrize("sites,P,S", [(8, 3, 2), (2, 3, 1)])
+def test_staged_start_state_gives_the_same_run(sites, P, S):
+    """vgx_stage_tau (snapshot, conversion and upload of the start state ahead of the call: the bench's hand-over) against
+    vgx_simulate_tau doing that work itself: same steps, same state, also for a second call after a new vgx_set_state."""
+    import ctypes as C
+    from vgsim_amd import _capi
+
+    def run(stage):
+        s = _filled(sites, P, S, 300 + sites, _fill_small, True)
+        m = s.simulation
+        eng = _capi.HipEngine(m.sites, m.hapNum, m.popNum, m.susNum, n_replicates=2)
+        out = []
+        for call in range(2):
+            m.events.CreateEvents(4); m.events.CreateEvents(4)
+            eng.set_params(m); eng.set_state(m); eng.set_seeds(np.array([11, 12], dtype=np.int64))
+            if stage:
+                eng.stage_tau()
+            o = _capi.VgxRunOpts(); o.record_events = 0
+            eng._check(eng.lib.vgx_simulate_tau(eng.handle, 4, 10 ** 15, -1.0, 1, C.byref(o)))
+            for r in range(2):
+                c = eng.counters(r)
+                out.append((c.ev_ptr, c.loop_iterations, c.reserved[0]))
+            eng.get_state(m, 1)            # continue the second call from replicate 1's end state
+            out.append((m.infectious.copy(), m.susceptible.copy(), m.currentTime))
+        eng.close()
+        return out
+    a, b = run(False), run(True)
+    for x, y in zip(a, b):
+        if isinstance(x[0], np.ndarray):
+            assert np.array_equal(x[0], y[0]) and np.array_equal(x[1], y[1]) and x[2] == y[2]
+        else:
+            assert x == y
+    assert a[0][1] >= 4 and a[0][2] > 0

@@ -83,6 +83,7 @@ SIGNATURES = {
     "vgx_set_state": (C.c_int, [_H, C.POINTER(VgxState)]),
     "vgx_get_state": (C.c_int, [_H, C.c_int64, C.POINTER(VgxState)]),
     "vgx_set_seeds": (C.c_int, [_H, _I]),
+    "vgx_stage_tau": (C.c_int, [_H]),
     "vgx_simulate_direct": (C.c_int, [_H, C.c_int64, C.c_int64, C.c_float, C.c_int64, C.POINTER(VgxRunOpts)]),
     "vgx_simulate_tau": (C.c_int, [_H, C.c_int64, C.c_int64, C.c_float, C.c_int64, C.POINTER(VgxRunOpts)]),
     "vgx_get_counters": (C.c_int, [_H, C.c_int64, C.POINTER(VgxCounters)]),
@@ -222,6 +223,11 @@ class HipEngine:
         for c in m.COUNTERS + ("good_attempt",):
             setattr(m, c, getattr(s, c))
         m.currentTime, m.totalRate, m.totalMigrationRate, m.tau_l = s.currentTime, s.totalRate, s.totalMigrationRate, s.tau_l
+
+    def stage_tau(self):
+        """Put the state of the last ``set_state`` on the device in the tau kernels' layout now (``vgx_stage_tau``): the next
+        ``vgx_simulate_tau`` then starts from resident inputs."""
+        self._check(self.lib.vgx_stage_tau(self.handle))
 
     def set_seeds(self, seeds):
         a = np.ascontiguousarray(np.asarray(seeds, dtype=np.int64))

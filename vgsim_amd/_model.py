@@ -13,6 +13,9 @@ without ``libvgx.so`` and a GPU the simulate calls raise.
 """
 import sys
 
+import os
+import warnings
+
 import numpy as np
 
 from ._params import ParameterTable, need_count, need_number
@@ -235,10 +238,15 @@ class BirthDeathModel(ParameterTable, Reporting):
             # of the mutating population alone (pyx:366-369), so with several populations the other populations' counts end up
             # under the wrong program numbers, and tau-leaping indexes the program-number arrays by haplotype (pyx:2351-2593),
             # reading past their maxHapNum columns.  There is nothing well-defined to reproduce; the engine's state is sparse
-            # in the haplotype dimension whatever the flag says.
-            raise ValueError('memory_optimization=True is supported for one population and the direct method only (the reference '
-                             'corrupts its state elsewhere: _BirthDeath.pyx:366-369, 2351-2593); use memory_optimization=False: '
-                             'this engine keeps only the occupied haplotypes in either case')
+            # in the haplotype dimension whatever the flag says, so the run is the plain layout's trajectory with the table kept
+            # as bookkeeping (``_refresh_haplotype_table``).  The reference accepts the call, so this one does too — with a
+            # warning; VGX_STRICT_MEMOPT=1 turns it into the refusal.
+            msg = ('memory_optimization=True with several populations or method="tau": the reference corrupts its state there '
+                   '(_BirthDeath.pyx:366-369, 2351-2593); this engine keeps only the occupied haplotypes in either case and runs the '
+                   'trajectory of memory_optimization=False, with the haplotype table kept as bookkeeping')
+            if os.environ.get('VGX_STRICT_MEMOPT'):
+                raise ValueError('memory_optimization=True is supported for one population and the direct method only. ' + msg)
+            warnings.warn(msg, RuntimeWarning, stacklevel=3)
         if self.recombination != 0 and self.sites < 2:
             # upstream allocates the scratch vector of the recombination branch only for sites > 1 (pyx:98-102) and
             # crashes in Birth otherwise

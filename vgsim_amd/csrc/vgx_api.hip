@@ -104,6 +104,9 @@ struct vgx_engine {
         t_taubits, t_tau, t_time, t_flags, t_counters, t_cnttry, t_mev, t_mevn, t_mevbase, t_locn, t_mutcum, t_migcdf, t_migIn, t_mutHi, t_colT, t_colTW, t_inc, t_incn, t_sieve, t_sieveskip, t_big, t_bign, t_res, t_susp, t_suspn, t_stkey, t_stval, t_dChkTot, t_q, t_qn, t_hist, t_I8, t_dSpart, t_tmax8, t_iI, t_iS, t_slog, t_sres;
     std::vector<int64_t> tau_sieve_skipped;   // [R] tries left out by the sieve in the last tau call
     bool last_was_tau = false;
+    bool tau_staged = false;              // vgx_stage_tau put the current start state on the device in the tau kernels' layout
+    int64_t tau_occupied = 0;             // ... and counted its occupied compartments
+    bool direct_logs_valid = false;   // the rate / iteration logs of the last direct call are on the device (host_clock can run)
     int64_t tau_mev_cap = 0;
     struct TauStep { double time; int64_t m0, m1; };
     std::vector<std::vector<TauStep>> tau_log;      // [R] MULTITYPE records of the last tau call
@@ -120,6 +123,8 @@ struct vgx_engine {
     VgxDevParams dp{};
     VgxDevRep dr{};
     int64_t cap = 0, evcap = 0, ev_base = 0, ev_ptr0 = 0, traj_points = 0;
+    std::vector<int64_t> call_ev0;        // [R] events.ptr of every replicate at the start of the last call (they differ once replicates of a
+                                          // continued ensemble stopped at different places)
     // host clock of the last direct call (host_clock below)
     int64_t loc_cap = 1, fa_cap = 0;
     bool call_recorded = false, call_has_tlimit = false;
@@ -548,6 +553,7 @@ extern "C" int vgx_set_params(vgx_engine *e, const vgx_params *p) {
     d.recombination = e->recombination; d.genome_length = e->genome_length;
     d.sitesPosition = (const int64_t *)e->p_sitesPos.p;
     e->have_params = true;
+    e->tau_staged = false;
     e->dev_state_valid = false;  // class ids in the occupancy lists refer to the old parameter rows
     return VGX_OK;
 }
@@ -622,6 +628,7 @@ extern "C" int vgx_set_state(vgx_engine *e, const vgx_state *s) {
     h.ev_ptr = s->ev_ptr; h.ev_size = s->ev_size;
     e->have_state = true;
     e->dev_state_valid = false;
+    e->tau_staged = false;
     return VGX_OK;
 }
 
@@ -813,6 +820,7 @@ static int init_device_state(vgx_engine *e, int64_t traj_points) {
 
 static int direct_core(vgx_engine *e, int64_t iterations, int64_t sample_size, float time, int64_t attempts,
                        const vgx_run_opts *opts);
+static int host_clock(vgx_engine *e, int64_t rep);
 
 extern "C" int vgx_simulate_direct(vgx_engine *e, int64_t iterations, int64_t sample_size, float time,
                                    int64_t attempts, const vgx_run_opts *opts) {
@@ -844,12 +852,37 @@ static int direct_core(vgx_engine *e, int64_t iterations, int64_t sample_size, f
         int rc = init_device_state(e, o.traj_points);
         if (rc) return rc;
     }
+    std::vector<double> cont_t0((size_t)R, h.currentTime);
+    {
+        std::vector<double> &t0 = cont_t0;
+        if (!fresh_state && e->sc_host_valid && e->sc_host.size() == (size_t)R) {
+            // A call that continues the device-resident state of the previous one: its clock starts where the HOST clock of the
+            // previous call ended (the reference's own libm sums), rebuilt now from that call's logs while they still exist —
+            // for up to 5e7 loop iterations over all replicates (about half a second of host time); beyond that, and after calls
+            // without an event log, from the device clock (vgx_log: < 1 ulp per step from the host's).
+            int64_t work = 0;
+            for (int64_t r = 0; r < R; r++) work += e->sc_host[(size_t)r].loop_iterations;
+            const bool rebuild = e->direct_logs_valid && work <= 50000000;
+            const int64_t mism = e->clock_mismatches;
+            for (int64_t r = 0; r < R; r++) {
+                t0[(size_t)r] = e->sc_host[(size_t)r].currentTime;
+                if (rebuild && host_clock(e, r) == VGX_OK && e->hc.exact) t0[(size_t)r] = e->hc.final_time;
+            }
+            e->clock_mismatches = mism;   // (counted when a caller fetches the replicate)
+            e->hc.rep = -1;
+        }
+    }
     // events.ptr / events.size as maintained by the caller's Events.CreateEvents (events.pxi:52-68)
     const int64_t ev_ptr0 = h.ev_ptr, ev_size = h.ev_size;
     if (ev_size < ev_ptr0) return fail(e, VGX_ERR_ARG, "vgx_simulate_direct: ev_size < ev_ptr");
+    // every replicate's own events.ptr (one value after vgx_set_state; where each one stopped when the call continues)
+    e->call_ev0.assign((size_t)R, ev_ptr0);
+    if (!fresh_state && e->sc_host_valid && e->sc_host.size() == (size_t)R)
+        for (int64_t r = 0; r < R; r++) e->call_ev0[(size_t)r] = e->sc_host[(size_t)r].ev_ptr;
+    const int64_t ev_min = *std::min_element(e->call_ev0.begin(), e->call_ev0.end());
     // a Restart (pyx:414-415) rewinds the log to 0, so the device log must then cover [0, ev_size)
-    const bool may_restart = ev_ptr0 <= 100 && iterations > 100;
-    e->ev_base = may_restart ? 0 : ev_ptr0;
+    const bool may_restart = ev_min <= 100 && iterations > 100;
+    e->ev_base = may_restart ? 0 : ev_min;
     e->ev_ptr0 = ev_ptr0;
     int64_t evcap = o.record_events ? std::max<int64_t>(ev_size - e->ev_base, 1) : 1;
     // lockdown log: a population can switch on only if its threshold lies below its size, off only if it is on
@@ -883,9 +916,7 @@ static int direct_core(vgx_engine *e, int64_t iterations, int64_t sample_size, f
     a.r.fa_rate = (double *)e->r_farate.p; a.r.fa_key = (int64_t *)e->r_fakey.p; a.r.fa_cap = e->fa_cap;
     // the host clock starts where the caller's state stands (one value for all replicates after vgx_set_state; the
     // replicates' own device clocks when a call continues without a new state)
-    e->call_t0.assign((size_t)R, h.currentTime);
-    if (!fresh_state && e->sc_host_valid && e->sc_host.size() == (size_t)R)
-        for (int64_t r = 0; r < R; r++) e->call_t0[(size_t)r] = e->sc_host[(size_t)r].currentTime;
+    e->call_t0 = cont_t0;
     e->call_recorded = o.record_events != 0;
     e->call_has_tlimit = !(time == -1.0f);
     e->call_tlimit = (double)time;
@@ -1062,6 +1093,7 @@ static int direct_core(vgx_engine *e, int64_t iterations, int64_t sample_size, f
     e->sc_host.resize((size_t)R);
     HIPCHECK(e, hipMemcpy(e->sc_host.data(), e->r_sc.p, (size_t)R * sizeof(VgxRepScalars), hipMemcpyDeviceToHost));
     e->sc_host_valid = true;
+    e->direct_logs_valid = e->call_recorded;
     // the caller's next simulate continues from where replicate 0 stopped unless it sets a new state
     h.ev_ptr = e->sc_host[0].ev_ptr;
     for (int64_t r = 0; r < R; r++) {
@@ -1097,6 +1129,87 @@ static int ul(vgx_engine *e, const DevBuf &b, const std::vector<T> &src) {
     return VGX_OK;
 }
 
+// One replicate's compartments into the tau kernels' layout: 4 bytes per compartment (population sizes < 2^31, checked by the
+// callers), susceptible counts and population totals.  Large states are converted chunk by chunk into two pinned staging buffers,
+// the copy of one chunk overlapping the conversion of the next.
+static int tau_upload_state(vgx_engine *e, int64_t r, const std::vector<int64_t> &inf, const std::vector<int64_t> &sus) {
+    const int64_t H = e->d.hapNum, P = e->d.popNum, S = e->d.susNum;
+    const int64_t n = P * H;
+    std::vector<int64_t> tot((size_t)P, 0);
+    for_parts(P, [&](int64_t p0, int64_t p1, unsigned) {   // whole populations per thread
+        for (int64_t pn = p0; pn < p1; pn++) {
+            int64_t t = 0;
+            const int64_t *src = &inf[(size_t)(pn * H)];
+            for (int64_t hn = 0; hn < H; hn++) t += src[hn];
+            tot[(size_t)pn] = t;
+        }
+    }, H);
+    int32_t *dst = (int32_t *)e->t_I.p + r * n;
+    const int64_t chunk = VGX_PIN_BYTES / 4;
+    if (n >= chunk) {
+        for (int i = 0; i < 2; i++) {
+            if (!e->pin[i]) HIPCHECK(e, hipHostMalloc(&e->pin[i], VGX_PIN_BYTES, hipHostMallocDefault));
+            if (!e->pin_ev[i]) HIPCHECK(e, hipEventCreateWithFlags(&e->pin_ev[i], hipEventDisableTiming));
+        }
+        int k = 0;
+        for (int64_t c0 = 0; c0 < n; c0 += chunk, k ^= 1) {
+            const int64_t len = std::min<int64_t>(chunk, n - c0);
+            if (c0 >= 2 * chunk) HIPCHECK(e, hipEventSynchronize(e->pin_ev[k]));   // the buffer's previous copy is through
+            int32_t *buf = (int32_t *)e->pin[k];
+            const int64_t *src = inf.data() + c0;
+            for_parts(len, [&](int64_t b, int64_t en, unsigned) { for (int64_t i = b; i < en; i++) buf[i] = (int32_t)src[i]; });
+            HIPCHECK(e, hipMemcpyAsync(dst + c0, buf, (size_t)len * 4, hipMemcpyHostToDevice, e->stream));
+            HIPCHECK(e, hipEventRecord(e->pin_ev[k], e->stream));
+        }
+        HIPCHECK(e, hipStreamSynchronize(e->stream));
+    } else {
+        std::vector<int32_t> inf32((size_t)n);
+        for (int64_t i = 0; i < n; i++) inf32[(size_t)i] = (int32_t)inf[(size_t)i];
+        HIPCHECK(e, hipMemcpy(dst, inf32.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+    }
+    HIPCHECK(e, hipMemcpy((int64_t *)e->t_S.p + r * P * S, sus.data(), (size_t)(P * S) * 8, hipMemcpyHostToDevice));
+    HIPCHECK(e, hipMemcpy((int64_t *)e->t_totInf.p + r * P, tot.data(), (size_t)P * 8, hipMemcpyHostToDevice));
+    return VGX_OK;
+}
+
+static int64_t count_occupied(const vgx_engine *e) {
+    const HostState &h = e->hs;
+    int64_t part[16] = {0}, occupied = 0;
+    for_parts(e->d.popNum * e->d.hapNum, [&](int64_t b, int64_t en, unsigned t) {
+        int64_t n = 0;
+        for (int64_t i = b; i < en; i++) n += h.infectious[(size_t)i] != 0;
+        part[t] = n;
+    });
+    for (int t = 0; t < 16; t++) occupied += part[t];
+    return occupied;
+}
+
+// Puts the state handed over by vgx_set_state on the device in the tau kernels' layout ahead of vgx_simulate_tau (which does it itself
+// otherwise): the first-call snapshot of PrepareParameters (pyx:435-448), the count of occupied compartments, conversion and upload of
+// the P x H counts of every replicate.  At BASELINE config 4 that is 2^28 compartments: about 0.1 s of host work and PCIe transfer
+// that a caller who times the simulate call may want outside it.  Valid until the next vgx_set_state / vgx_set_params / simulate call.
+extern "C" int vgx_stage_tau(vgx_engine *e) {
+    if (!e) return VGX_ERR_ARG;
+    if (!e->have_params || !e->have_state) return fail(e, VGX_ERR_ARG, "vgx_stage_tau: set params and state first");
+    HIPCHECK(e, hipSetDevice(e->device));
+    const int64_t H = e->d.hapNum, P = e->d.popNum, S = e->d.susNum, R = e->R;
+    for (int64_t pn = 0; pn < P; pn++)
+        if (e->sizes[(size_t)pn] >= ((int64_t)1 << 31)) return fail(e, VGX_ERR_ARG, "vgx_stage_tau: population sizes must be below 2^31");
+    prepare_first(e);
+    e->tau_occupied = count_occupied(e);
+    int rc = 0;
+    rc |= ensure(e, e->t_I, (size_t)(R * P * H) * 4);
+    rc |= ensure(e, e->t_S, (size_t)(R * P * S) * 8);
+    rc |= ensure(e, e->t_totInf, (size_t)(R * P) * 8);
+    if (rc) return rc;
+    for (int64_t r = 0; r < R; r++) {
+        rc = tau_upload_state(e, r, e->hs.infectious, e->hs.susceptible);
+        if (rc) return rc;
+    }
+    e->tau_staged = true;
+    return VGX_OK;
+}
+
 extern "C" int vgx_simulate_tau(vgx_engine *e, int64_t iterations, int64_t sample_size, float time, int64_t attempts,
                                 const vgx_run_opts *opts) {
     if (!e) return VGX_ERR_ARG;
@@ -1128,18 +1241,11 @@ extern "C" int vgx_simulate_tau(vgx_engine *e, int64_t iterations, int64_t sampl
     e->tau_loc_time.assign((size_t)R, {});
     e->tau_loc_state.assign((size_t)R, {});
     e->tau_loc_pop.assign((size_t)R, {});
-    prepare_first(e);
+    const bool staged = e->tau_staged;     // vgx_stage_tau already did the snapshot, the count and the upload of this start state
+    e->tau_staged = false;                 // (the device copy stops being the start state as soon as a step is applied)
+    if (!staged) prepare_first(e);
     lap("first-call snapshot");
-    int64_t occupied = 0;
-    {
-        int64_t part[16] = {0};
-        for_parts(P * H, [&](int64_t b, int64_t en, unsigned t) {
-            int64_t n = 0;
-            for (int64_t i = b; i < en; i++) n += h.infectious[(size_t)i] != 0;
-            part[t] = n;
-        });
-        for (int t = 0; t < 16; t++) occupied += part[t];
-    }
+    const int64_t occupied = staged ? e->tau_occupied : count_occupied(e);
     lap("count of occupied");
     bool rates_nonzero = false;
     int rc = 0;
@@ -1322,49 +1428,11 @@ extern "C" int vgx_simulate_tau(vgx_engine *e, int64_t iterations, int64_t sampl
     HIPCHECK(e, hipMemset(e->t_flags.p, 0, (size_t)R * nF * 4));
     std::vector<int32_t> lock32((size_t)P);
     for (int64_t pn = 0; pn < P; pn++) lock32[(size_t)pn] = (int32_t)h.lockdownON[(size_t)pn];
-    auto upload_state = [&](int64_t r, const std::vector<int64_t> &inf, const std::vector<int64_t> &sus) -> int {
-        // device layout: 4 bytes per compartment (sizes < 2^31, checked above).  Large states are converted chunk by chunk
-        // into two pinned staging buffers, the copy of one chunk overlapping the conversion of the next.
-        const int64_t n = P * H;
-        std::vector<int64_t> tot((size_t)P, 0);
-        for_parts(P, [&](int64_t p0, int64_t p1, unsigned) {   // whole populations per thread
-            for (int64_t pn = p0; pn < p1; pn++) {
-                int64_t t = 0;
-                const int64_t *src = &inf[(size_t)(pn * H)];
-                for (int64_t hn = 0; hn < H; hn++) t += src[hn];
-                tot[(size_t)pn] = t;
-            }
-        }, H);
-        int32_t *dst = (int32_t *)e->t_I.p + r * n;
-        const int64_t chunk = VGX_PIN_BYTES / 4;
-        if (n >= chunk) {
-            for (int i = 0; i < 2; i++) {
-                if (!e->pin[i]) HIPCHECK(e, hipHostMalloc(&e->pin[i], VGX_PIN_BYTES, hipHostMallocDefault));
-                if (!e->pin_ev[i]) HIPCHECK(e, hipEventCreateWithFlags(&e->pin_ev[i], hipEventDisableTiming));
-            }
-            int k = 0;
-            for (int64_t c0 = 0; c0 < n; c0 += chunk, k ^= 1) {
-                const int64_t len = std::min<int64_t>(chunk, n - c0);
-                if (c0 >= 2 * chunk) HIPCHECK(e, hipEventSynchronize(e->pin_ev[k]));   // the buffer's previous copy is through
-                int32_t *buf = (int32_t *)e->pin[k];
-                const int64_t *src = inf.data() + c0;
-                for_parts(len, [&](int64_t b, int64_t en, unsigned) { for (int64_t i = b; i < en; i++) buf[i] = (int32_t)src[i]; });
-                HIPCHECK(e, hipMemcpyAsync(dst + c0, buf, (size_t)len * 4, hipMemcpyHostToDevice, e->stream));
-                HIPCHECK(e, hipEventRecord(e->pin_ev[k], e->stream));
-            }
-            HIPCHECK(e, hipStreamSynchronize(e->stream));
-        } else {
-            std::vector<int32_t> inf32((size_t)n);
-            for (int64_t i = 0; i < n; i++) inf32[(size_t)i] = (int32_t)inf[(size_t)i];
-            HIPCHECK(e, hipMemcpy(dst, inf32.data(), (size_t)n * 4, hipMemcpyHostToDevice));
-        }
-        HIPCHECK(e, hipMemcpy((int64_t *)e->t_S.p + r * P * S, sus.data(), (size_t)(P * S) * 8, hipMemcpyHostToDevice));
-        HIPCHECK(e, hipMemcpy((int64_t *)e->t_totInf.p + r * P, tot.data(), (size_t)P * 8, hipMemcpyHostToDevice));
-        return VGX_OK;
-    };
     for (int64_t r = 0; r < R; r++) {
-        rc = upload_state(r, h.infectious, h.susceptible);
-        if (rc) return rc;
+        if (!staged) {
+            rc = tau_upload_state(e, r, h.infectious, h.susceptible);
+            if (rc) return rc;
+        }
         HIPCHECK(e, hipMemcpy((double *)e->t_cd.p + r * P, h.contactDensity.data(), (size_t)P * 8, hipMemcpyHostToDevice));
         HIPCHECK(e, hipMemcpy((int32_t *)e->t_lock.p + r * P, lock32.data(), (size_t)P * 4, hipMemcpyHostToDevice));
     }
@@ -1594,7 +1662,7 @@ extern "C" int vgx_simulate_tau(vgx_engine *e, int64_t iterations, int64_t sampl
             running[(size_t)r] = 0;
             if (ev_ptr[(size_t)r] <= 100 && iterations > 100) {  // Restart (pyx:714-738)
                 restarts[(size_t)r] += 1;
-                rc = upload_state(r, h.initial_infectious, h.initial_susceptible);
+                rc = tau_upload_state(e, r, h.initial_infectious, h.initial_susceptible);
                 if (rc) return rc;
                 i8_dirty = true;
                 {   // the lockdown records of the failed attempt stay (Restart does not clear `loc`); then CheckLockdown for
@@ -1879,6 +1947,7 @@ extern "C" int vgx_simulate_tau(vgx_engine *e, int64_t iterations, int64_t sampl
     HIPCHECK(e, hipMemcpy(e->tau_sieve_skipped.data(), a.sieve_skipped, (size_t)R * 8, hipMemcpyDeviceToHost));
     e->sc_host = e->tau_sc;
     e->sc_host_valid = true;
+    e->direct_logs_valid = false;
     e->last_was_tau = true;
     e->last_ms = ms_total;
     e->last_launches = launches;
@@ -1933,7 +2002,7 @@ static int host_clock(vgx_engine *e, int64_t rep) {
     hc.loc_times.clear();
     hc.limit_mismatch = false;
     const bool rewound = s.restarts > 0;
-    hc.e0 = rewound ? 0 : e->ev_ptr0;
+    hc.e0 = rewound ? 0 : ((size_t)rep < e->call_ev0.size() ? e->call_ev0[(size_t)rep] : e->ev_ptr0);
     const int64_t n = std::max<int64_t>(s.ev_ptr - hc.e0, 0);
     const int64_t nloc = std::min<int64_t>(s.loc_n, e->loc_cap);
     std::vector<double> loc_dev((size_t)nloc);
@@ -2036,7 +2105,7 @@ extern "C" int vgx_get_counters(vgx_engine *e, int64_t replicate, vgx_counters *
     const VgxRepScalars &s = e->sc_host[(size_t)replicate];
     memset(out, 0, sizeof(*out));
     out->ev_ptr = s.ev_ptr;
-    out->ev_first_new = s.restarts > 0 ? 0 : e->ev_ptr0;
+    out->ev_first_new = s.restarts > 0 ? 0 : ((!e->last_was_tau && (size_t)replicate < e->call_ev0.size()) ? e->call_ev0[(size_t)replicate] : e->ev_ptr0);
     if (e->last_was_tau) out->reserved[0] = s.traj_next;  // tau: events drawn (sum of channel multiplicities)
     if (e->last_was_tau && (size_t)replicate < e->tau_sieve_skipped.size()) out->reserved[3] = e->tau_sieve_skipped[(size_t)replicate];
     out->loop_iterations = s.loop_iterations;

@@ -65,14 +65,16 @@ enum { EV_BIRTH = 0, EV_DEATH, EV_SAMPLING, EV_MUTATION, EV_SUSCCHANGE, EV_MIGRA
 struct Masks { double m[16]; };   // m[k] = (lane & 15) >= k ? 1.0 : 0.0
 
 // ---- chains ---------------------------------------------------------------------------------------------------------------
-// One asm statement per row of 16 steps (safe by construction: the leading s_nop 4 covers both hazards the compiler cannot see
-// into an asm statement for — a DPP read of a VGPR written by the previous VALU instruction needs 2 wait states, a DPP
-// instruction after a write of EXEC needs 5 — and nothing can be scheduled between the steps); steps run in groups of four, a
-// row of n <= 4 / 8 / 12 terms leaves early (entries beyond n MUST hold +0.0: they are added when n is not a multiple of four).
+// One asm statement per row of 16 steps, safe by construction: the leading s_nop 1 gives the two wait states a DPP read of a VGPR
+// needs after a VALU write of it (the compiler's hazard recogniser cannot see into an asm statement, and whatever it schedules
+// right before one — a spill reload, a phi copy — may write the chain's source), and nothing can be scheduled between the steps.
+// (The other DPP hazard, five wait states after a VALU write of EXEC, needs a v_cmpx, which hipcc does not emit for gfx9 targets;
+// tools/isa_hazard_scan.py checks both on the shipped code objects at every build.)  Steps run in groups of four, a row of
+// n <= 4 / 8 / 12 terms leaves early (entries beyond n MUST hold +0.0: they are added when n is not a multiple of four).
 #define SOLO_FM(K, MUL, RM) "v_fmac_f64_dpp %[acc], %[v], %[" MUL "] row_newbcast:" #K " row_mask:" RM " bank_mask:0xf\n\t"
 #define SOLO_EXIT(N) "s_cmp_le_i32 %[n], " #N "\n\ts_cbranch_scc1 .Lsolo_done%=\n\t"
 #define SOLO_SCAN16(RM)                                                                                                        \
-    asm volatile("s_nop 4\n\t" SOLO_FM(0, "m0", RM) SOLO_FM(1, "m1", RM) SOLO_FM(2, "m2", RM) SOLO_FM(3, "m3", RM) SOLO_EXIT(4)  \
+    asm volatile("s_nop 1\n\t" SOLO_FM(0, "m0", RM) SOLO_FM(1, "m1", RM) SOLO_FM(2, "m2", RM) SOLO_FM(3, "m3", RM) SOLO_EXIT(4)  \
                  SOLO_FM(4, "m4", RM) SOLO_FM(5, "m5", RM) SOLO_FM(6, "m6", RM) SOLO_FM(7, "m7", RM) SOLO_EXIT(8)                 \
                  SOLO_FM(8, "m8", RM) SOLO_FM(9, "m9", RM) SOLO_FM(10, "m10", RM) SOLO_FM(11, "m11", RM) SOLO_EXIT(12)            \
                  SOLO_FM(12, "m12", RM) SOLO_FM(13, "m13", RM) SOLO_FM(14, "m14", RM) SOLO_FM(15, "m15", RM)                      \
@@ -83,7 +85,7 @@ struct Masks { double m[16]; };   // m[k] = (lane & 15) >= k ? 1.0 : 0.0
                    [m11] "v"(M.m[11]), [m12] "v"(M.m[12]), [m13] "v"(M.m[13]), [m14] "v"(M.m[14]), [m15] "v"(M.m[15]), [n] "s"(nn) \
                  : "scc")
 #define SOLO_SUM16(RM)                                                                                                         \
-    asm volatile("s_nop 4\n\t" SOLO_FM(0, "mu", RM) SOLO_FM(1, "mu", RM) SOLO_FM(2, "mu", RM) SOLO_FM(3, "mu", RM) SOLO_EXIT(4)  \
+    asm volatile("s_nop 1\n\t" SOLO_FM(0, "mu", RM) SOLO_FM(1, "mu", RM) SOLO_FM(2, "mu", RM) SOLO_FM(3, "mu", RM) SOLO_EXIT(4)  \
                  SOLO_FM(4, "mu", RM) SOLO_FM(5, "mu", RM) SOLO_FM(6, "mu", RM) SOLO_FM(7, "mu", RM) SOLO_EXIT(8)                 \
                  SOLO_FM(8, "mu", RM) SOLO_FM(9, "mu", RM) SOLO_FM(10, "mu", RM) SOLO_FM(11, "mu", RM) SOLO_EXIT(12)              \
                  SOLO_FM(12, "mu", RM) SOLO_FM(13, "mu", RM) SOLO_FM(14, "mu", RM) SOLO_FM(15, "mu", RM)                          \
@@ -105,11 +107,11 @@ static __device__ __forceinline__ double uni_f64(double v) {
 
 // the same with exactly four steps and no way out: shapes of at most four terms (TINY instantiations) save the compare and the branch
 #define SOLO_SCAN4(RM)                                                                                                        \
-    asm volatile("s_nop 4\n\t" SOLO_FM(0, "m0", RM) SOLO_FM(1, "m1", RM) SOLO_FM(2, "m2", RM) SOLO_FM(3, "m3", RM)            \
+    asm volatile("s_nop 1\n\t" SOLO_FM(0, "m0", RM) SOLO_FM(1, "m1", RM) SOLO_FM(2, "m2", RM) SOLO_FM(3, "m3", RM)            \
                  : [acc] "+v"(acc)                                                                                               \
                  : [v] "v"(v), [m0] "v"(M.m[0]), [m1] "v"(M.m[1]), [m2] "v"(M.m[2]), [m3] "v"(M.m[3]))
 #define SOLO_SUM4(RM)                                                                                                         \
-    asm volatile("s_nop 4\n\t" SOLO_FM(0, "mu", RM) SOLO_FM(1, "mu", RM) SOLO_FM(2, "mu", RM) SOLO_FM(3, "mu", RM)            \
+    asm volatile("s_nop 1\n\t" SOLO_FM(0, "mu", RM) SOLO_FM(1, "mu", RM) SOLO_FM(2, "mu", RM) SOLO_FM(3, "mu", RM)            \
                  : [acc] "+v"(acc)                                                                                               \
                  : [v] "v"(v), [mu] "v"(mu))
 
