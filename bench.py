@@ -384,6 +384,7 @@ def fast_leg(device, replicates, events, traj_points):
     warm-up; then the same with the counter-based stream (mode 2: Philox4x32-10 per lane), on the same kernel since round 3."""
     import numpy as np
     from vgsim_amd.ensemble import Ensemble
+    requested = replicates
     replicates = 24576 if replicates >= 16384 else replicates
     ens = Ensemble(make_simulator(2020), replicates, device=device)
     res = None
@@ -393,7 +394,8 @@ def fast_leg(device, replicates, events, traj_points):
                            mode="fast")
     out = {"workload": "headline workload in FAST mode (order-free sums, same PCG64 stream), %d replicates x %d events" % (replicates, events),
            "value": res.total_events / (res.kernel_ms * 1e-3), "unit": "events/s (device time)",
-           "kernel": "vgx_quadf_kernel", "kernel_ms_per_launch": res.kernel_ms}
+           "kernel": "vgx_quadf_kernel", "kernel_ms_per_launch": res.kernel_ms,
+           "replicates": replicates, "requested_replicates": requested}
     # the same with the counter-based random stream (vgx_run_opts.mode = 2: Philox4x32-10, every draw formed on its own)
     for it in range(2):
         res = ens.simulate(events, sample_size=10 ** 12, record_events=True, traj_points=traj_points,
@@ -564,8 +566,19 @@ def config5_leg(device, world=1, rank=0, events=100000, traj_points=1001):
         if world > 1:
             dist.barrier()
         t0 = time.perf_counter()
-        res = ens.simulate(events, sample_size=10 ** 12, record_events=True, traj_points=traj_points, traj_window=(0.0, 12.0), seeds=seeds)
+        err = None
+        try:
+            res = ens.simulate(events, sample_size=10 ** 12, record_events=True, traj_points=traj_points, traj_window=(0.0, 12.0), seeds=seeds)
+        except Exception as ex:   # every rank must learn of it BEFORE the gather: a rank alone in a collective hangs the others
+            err = ex
         t_sim = time.perf_counter() - t0
+        if world > 1:
+            okv = torch.tensor([0.0 if err is not None else 1.0], dtype=torch.float64, device="cuda")
+            dist.all_reduce(okv, op=dist.ReduceOp.MIN)
+            if okv.item() < 1.0:
+                raise RuntimeError("config5: a rank failed in simulate (%r on this rank)" % (err,))
+        elif err is not None:
+            raise err
         t1 = time.perf_counter()
         out = ens.gather_trajectories(dst=0)
         torch.cuda.synchronize()
@@ -688,6 +701,24 @@ class BenchLoop:
         return [float(o.item()) for o in out]
 
 
+def memory_plan(R, N, T, world, rank, free_bytes, total_bytes):
+    """Device memory the headline leg of this rank needs (bytes, by item) — printed on stderr, and the run refused before anything is
+    allocated when it cannot fit: occupancy lists (capped at 32 GiB, vgx_api.hip init_device_state), the event log resident in HBM
+    (32 B per event), the f64 summary trajectories, their int32 wire copy and, on rank 0, the gathered result of all ranks."""
+    P = POPS
+    plan = {"occupancy_lists": min(32 * 2 ** 30, int(0.45 * free_bytes)), "event_log": R * N * 32, "trajectories_f64": R * T * P * 2 * 8,
+            "wire_int32": (R * T * P * 2 * 4) if world > 1 else 0, "gathered_on_rank0": (world * R * T * P * 2 * 4) if (world > 1 and rank == 0) else 0,
+            "population_blocks_and_scalars": R * (P * 9 * 8 + P * P * 8 + 512)}
+    need = sum(plan.values())
+    sys.stderr.write("bench.py rank %d/%d memory plan: %s = %.1f GB of %.1f GB free (%.1f GB device)\n" % (
+        rank, world, ", ".join("%s %.1f GB" % (k, v / 1e9) for k, v in plan.items() if v), need / 1e9, free_bytes / 1e9, total_bytes / 1e9))
+    if need > 0.92 * free_bytes:
+        raise SystemExit("bench.py: rank %d needs %.1f GB of device memory for %d replicates x %d events (%s) but %.1f GB are free: "
+                         "lower --replicates / --events / --traj-points" % (rank, need / 1e9, R, N, ", ".join(
+                             "%s %.1f GB" % (k, v / 1e9) for k, v in plan.items() if v), free_bytes / 1e9))
+    return plan
+
+
 def launch_ranks(n, argv):
     """`python bench.py --gpus N` without a launcher: start N fresh ranks (torch.distributed.run, one per GPU) as a CHILD
     process and exit with its code.  Nothing in this parent has touched HIP or imported torch, and nothing is re-exec'ed."""
@@ -747,6 +778,9 @@ def main():
     from vgsim_amd.ensemble import Ensemble
     R, N = a.replicates, a.events
     H = 4 ** SITES
+    if not a.only:
+        free_b, total_b = torch.cuda.mem_get_info(local)
+        memory_plan(R, N, a.traj_points, world, rank, free_b, total_b)
     extra_legs = (("fast_mode", lambda d: fast_leg(d, R, N, a.traj_points)),
                   ("spread_occupancy", lambda d: spread_leg(d, "exact", replicates=8192, events=10000)),
                   ("spread_occupancy_fast", lambda d: spread_leg(d, "fast", replicates=12288, events=10000)),
@@ -792,9 +826,24 @@ def main():
         # Algorithmic bytes per recorded event of THIS engine's layout: the chosen population's
         # occupancy-list stream (16 B/entry, read once and kept in registers), the migration row (8P), the
         # event record (32 B) and the count write-back (8 B).  Mean list length measured from final state.
-        st = ens.replicate_state(0)
-        nocc_mean = float((st.infectious != 0).sum(axis=1).mean())
-        bytes_per_event = 16.0 * max(nocc_mean, 1.0) + 8.0 * POPS + 32.0 + 8.0
+        # The list an event works on is the list of ITS population, and events fall where the infected are: the index-case
+        # population holds most of them AND the longest list (the mean over the populations understates the bytes an event
+        # touches several-fold).  Event-weighted list length from the final states of a sample of replicates: population p gets
+        # weight totalInfectious[p] (the share of the infection-driven events it draws).
+        nocc_mean, nocc_w, wsum = 0.0, 0.0, 0.0
+        sample = list(range(0, R, max(R // 16, 1)))[:16]
+        for r in sample:
+            st = ens.replicate_state(r)
+            occ = (st.infectious != 0).sum(axis=1).astype(float)
+            w = st.infectious.sum(axis=1).astype(float)
+            nocc_mean += occ.mean() / len(sample)
+            nocc_w += float((occ * w).sum())
+            wsum += float(w.sum())
+        nocc_w = nocc_w / max(wsum, 1.0)
+        # short-list form of the row kernel: 16 B per entry (haplotype, class, count) of the event's list read once; lists beyond a
+        # tile stream the 4-byte counts (refresh: the whole list; choice: on average half of it) + haplotypes of the hit tile
+        list_bytes = 16.0 * nocc_w if nocc_w <= 64 else 6.0 * nocc_w + 4.0 * 64
+        bytes_per_event = max(list_bytes, 16.0) + 8.0 * POPS + 32.0 + 8.0
         ev_per_launch = events / max(a.steps, 1)
         launch_s = (kernel_ms / max(a.steps, 1)) * 1e-3
         achieved = ev_per_launch * bytes_per_event / launch_s / 1e9
@@ -820,9 +869,19 @@ def main():
                          "kernel": "vgx_quad_kernel" if R >= 2048 else "vgx_direct_kernel_p64s1c1",
                          "kernel_ms_per_launch": kernel_ms / max(a.steps, 1),
                          "bytes_per_event": bytes_per_event, "mean_occupancy_list_len": nocc_mean,
-                         "note": "persistent sequential event loop: latency/issue-bound, not bandwidth-bound; the "
-                                 "reference's dense layout would need %.3g B/event = %.3g GB/s at this event rate"
+                         "event_weighted_list_len": nocc_w,
+                         "note": "persistent sequential event loop: latency/issue-bound, not bandwidth-bound (chain_bound below); "
+                                 "bytes_per_event from the EVENT-WEIGHTED list length (final states of 16 replicates, population weight "
+                                 "= its infected hosts); the reference's dense layout would need %.3g B/event = %.3g GB/s at this event rate"
                                  % (dense_bytes, ev_per_launch * dense_bytes / launch_s / 1e9)},
+            # the binding resource: dependent f64 additions in the reference's order.  Per event: the refresh of the event's list
+            # (pyx:519-528), on average half of it for the choice (fast_choose.pxi:22-25), the popRate and migPopRate totals
+            # (pyx:537-546); one v_fmac_f64 (DPP) per term, each instruction serving the four replicates of a wavefront
+            "chain_bound": {"bound": "dependent f64 additions in the reference's order (one v_fmac_f64 per term)",
+                            "steps_per_event": 1.5 * nocc_w + 2.0 * POPS,
+                            "achieved": ev_per_launch * (1.5 * nocc_w + 2.0 * POPS) / launch_s, "peak": CHAIN_STEPS_PER_S * 4,
+                            "unit": "chain steps/s", "frac": ev_per_launch * (1.5 * nocc_w + 2.0 * POPS) / launch_s / (CHAIN_STEPS_PER_S * 4),
+                            "chains_per_instruction": 4},
         }
         # event log: resident in HBM per replicate (28 B/event); D2H through vgx_get_events on a sample
         t_d = time.perf_counter()
@@ -881,6 +940,32 @@ def main():
                     line[name] = fn(local)
                 except Exception as ex:
                     line[name] = {"error": repr(ex)}
+        # the numbers of the other legs once more, short, as the LAST object of the line (a reader that keeps only the tail of a long
+        # line still gets them)
+        def pick(d, *path):
+            for k in path:
+                if not isinstance(d, dict) or k not in d:
+                    return None
+                d = d[k]
+            return d
+        line["summary"] = {
+            "headline_events_per_s": line["value"], "headline_roofline_frac": pick(line, "roofline", "frac"),
+            "headline_chain_frac": pick(line, "chain_bound", "frac"),
+            "tau_leap_ms_per_step": pick(line, "tau_leap", "ms_per_step"), "tau_leap_events_per_s": pick(line, "tau_leap", "value"),
+            "tau_leap_roofline_frac": pick(line, "tau_leap", "roofline", "frac"), "tau_leap_wall_ms_per_step": pick(line, "tau_leap", "wall", "ms_per_step"),
+            "tau_cpu_ns_per_channel_step": pick(line, "tau_leap", "cpu_baseline", "4096x8", "ns_per_channel_step"),
+            "config5_events_per_s": pick(line, "config5", "value"), "fast_mode_events_per_s": pick(line, "fast_mode", "value"),
+            "single_trajectory_config2": pick(line, "single_trajectory", "config2"),
+            "single_trajectory_config3": pick(line, "single_trajectory", "config3"),
+            "table3_K2_single_events_per_s": pick(line, "table3", "cells", "K=2,M=0.001", "single_trajectory", "events_per_s"),
+            "table3_K2_single_vs_published": pick(line, "table3", "cells", "K=2,M=0.001", "single_trajectory", "vs_baseline"),
+            "table3_K2_ensemble_events_per_s": pick(line, "table3", "cells", "K=2,M=0.001", "ensemble", "events_per_s"),
+            "table3_K10_ensemble_events_per_s": pick(line, "table3", "cells", "K=10,M=0.001", "ensemble", "events_per_s"),
+            "table3_K100_ensemble_events_per_s": pick(line, "table3", "cells", "K=100,M=0.001", "ensemble", "events_per_s"),
+            "spread_occupancy_events_per_s": pick(line, "spread_occupancy", "value"),
+            "propensity_scan_roofline_frac": pick(line, "propensity_scan", "roofline", "frac"),
+            "cpu_baseline_events_per_s": pick(line, "cpu_baseline", "value"),
+        }
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

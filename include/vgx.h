@@ -13,6 +13,16 @@
  * One engine = one model shape and `n_replicates` independent trajectories of it (replicate = one
  * seeded run; the classic API uses 1).  Engines are independent; calls on one engine must not overlap.
  * Every function returns VGX_OK (0) or an error code; vgx_last_error() gives the message.
+ *
+ * Environment switches read by the library (diagnostics and tests; none is needed in production):
+ *   VGX_LIST_CAP=n                 caps the capacity of every occupancy list at n entries (exercises the kernels' overflow paths)
+ *   VGX_TIMING=1                   vgx_simulate_tau prints its host-side phases on stderr
+ *   VGX_SOLO_PLAIN_DIV=1           single-trajectory kernel: x / actualSizes by the compiler's division instead of the reciprocal sequence
+ *   VGX_SOLO_GENERAL=1             ... its general BirthRate layout where the compact one would be taken
+ *   VGX_SOLO_NO_UNIT=1             ... no one-haplotype / one-population instantiation
+ *   VGX_TAU_STEP_KERNELS=1 / 0     tau: always / never the step kernels (default: the on-device step loop for small models)
+ *   VGX_TAU_NO_BYTE_DRIFT=1        tau: the two-pass drift instead of the pass on the one-byte counts
+ *   VGX_TAU_LARGE_MODEL_THRESHOLDS=1  tau: the draw thresholds of large models on a small one
  */
 #ifndef VGX_H
 #define VGX_H

@@ -44,8 +44,15 @@ def run_tau_case(name, seed, engine, oracle=None):
     return sim.simulation
 
 
+@pytest.mark.parametrize("step_kernels", [True, False])
 @pytest.mark.parametrize("name", ["tau_a", "tau_b", "tau_c", "tau_many_classes", "tau_wide_table"])
-def test_first_leap_length_matches_oracle(oracle_mod, name):
+def test_first_leap_length_matches_oracle(oracle_mod, name, step_kernels, monkeypatch):
+    """ChooseTau (pyx:2432-2450) after a bit-exact direct warm-up: the first leap's length against the oracle's.  On the step kernels
+    (VGX_TAU_STEP_KERNELS=1) the first try of these cases is accepted on both sides: the leap IS the chosen tau, compared to 1e-9.
+    The on-device loop of small models (vgx_taus.hip) draws from other streams and may halve where the oracle does not (pyx:2316-2321):
+    there the leap equals the oracle's up to a few halvings — a power of two, 2^k with |k| <= 3."""
+    if step_kernels:
+        monkeypatch.setenv("VGX_TAU_STEP_KERNELS", "1")
     ctor, phases = models.tau_case(name)
     hip = run_tau_case(name, ctor["seed"], "hip")
     ref = run_tau_case(name, ctor["seed"], "oracle", oracle_mod)
@@ -54,10 +61,11 @@ def test_first_leap_length_matches_oracle(oracle_mod, name):
     assert hip.events.types[nd] == 6 and ref.events.types[nd] == 6
     dt_hip = hip.events.times[nd] - hip.events.times[nd - 1]
     dt_ref = ref.events.times[nd] - ref.events.times[nd - 1]
-    # the accepted leap is the chosen tau after however many halvings each side's own random draws needed (pyx:2316-2321):
-    # equal up to a power of two
+    if step_kernels:
+        assert dt_hip == pytest.approx(dt_ref, rel=1e-9)
+        return
     k = np.log2(dt_ref / dt_hip)
-    assert abs(k - round(k)) < 1e-8 and abs(round(k)) <= 12, (dt_hip, dt_ref)
+    assert abs(k - round(k)) < 1e-8 and abs(round(k)) <= 3, (dt_hip, dt_ref)
     assert dt_hip * 2.0 ** round(k) == pytest.approx(dt_ref, rel=1e-9)
 
 

@@ -957,7 +957,8 @@ static int direct_core(vgx_engine *e, int64_t iterations, int64_t sample_size, f
     // Four replicates per wavefront, one per 16-lane DPP row (vgx_quad.hip): one rate class, one susceptibility group,
     // at most 64 populations, no population that can switch its lockdown state, exact mode.
     bool quad_shape = !recomb && P <= 64 && S == 1 && e->C == 1 && e->CB == 1 && !ld_possible &&
-                      e->suscepCumul[0] == 0.0 && e->dr.lcnt32 != nullptr;
+                      e->suscepCumul[0] == 0.0 && e->dr.lcnt32 != nullptr &&
+                      e->cap <= ((int64_t)1 << 24);   // (the 64-ary lower bound of vgx_rowlist.h descends from stride 64^3: lists of up to 2^24 entries)
     for (int64_t pn = 0; pn < P && quad_shape; pn++)
         if (e->sizes[(size_t)pn] >= ((int64_t)1 << 31)) quad_shape = false;   // its streaming passes read 4-byte counts
     for (int64_t pn = 0; pn < P && quad_shape; pn++)
@@ -994,7 +995,15 @@ static int direct_core(vgx_engine *e, int64_t iterations, int64_t sample_size, f
     // replicates in one wavefront: 1.1e6 / 5.9e5 against 7.9e5 / 4.9e5 in four wavefronts
     // measured (bench legs table3 / single_trajectory, round 4): a lone wavefront of the latency kernel does a Table-3 trajectory
     // several times faster than a row of the row kernels; those win back from a few thousand replicates on (four per wavefront)
-    const bool use_solo = o.kernel == 5 || (o.kernel == 0 && solo_ok && !use_lanes && R < 2048);
+    // ... except general models (what the general row kernel would take) in the compact layout with a small LDS footprint: there two
+    // wavefronts per SIMD of this kernel beat it too (tools/probe_solo_ens.py, 16 384 replicates of the Table-3 model: K = 2 1.68e9
+    // against 1.09e9 events/s, K = 10 1.37e9 against 1.09e9; K = 100, general layout, 150 KB of LDS: 4.7e7 against 3.6e8)
+    bool solo_many = false;
+    if (solo_ok && !quad_ok) {
+        const bool compact = e->h_so_ncls <= VGX_SOLO_ROWS && S <= VGX_SOLO_MAX_S && P <= 64 && (int64_t)e->h_so_maxnnz * P <= 32;
+        solo_many = compact && vgx_solo_layout((int)P, (int)H, (int)S, (int)e->d.sites, soa.mig_in_lds).total <= 20 * 1024;
+    }
+    const bool use_solo = o.kernel == 5 || (o.kernel == 0 && solo_ok && !use_lanes && (R < 2048 || solo_many));
     const bool use_quad = !use_solo && ((o.kernel == 3 && quad_ok) || (o.kernel == 0 && quad_ok && !use_lanes));
     const bool use_quadf = !use_solo && ((o.kernel == 3 && quadf_ok) || (o.kernel == 0 && quadf_ok));
     // The general form also for FEW replicates of models with up to 16 populations (one register slot): a wavefront running alone
@@ -1069,9 +1078,12 @@ static int direct_core(vgx_engine *e, int64_t iterations, int64_t sample_size, f
         HIPCHECK(e, vgxi_launch_counts64(e->dr.lcnt32, e->dr.lcnt, R * P * e->cap, e->stream));
         e->counts64_valid = true;
     }
-    if ((use_quad || use_quadf) && !e->counts32_valid) HIPCHECK(e, vgxi_launch_counts32(e->dr.lcnt, e->dr.lcnt32, R * P * e->cap, e->stream));
-    e->counts32_valid = use_quad || use_quadf;
-    if (leaves32) e->counts64_valid = false;
+    if ((use_quad || use_quadf) && !e->counts32_valid) {
+        HIPCHECK(e, vgxi_launch_counts32(e->dr.lcnt, e->dr.lcnt32, R * P * e->cap, e->stream));
+        e->counts32_valid = true;
+    }
+    // (which copy of the counts the kernel leaves current is recorded once it has been enqueued: a failure before that leaves the flags
+    // describing what is on the device; whatever a failed launch may have touched is rebuilt from the host state, below)
     HIPCHECK(e, hipEventRecord(e->ev0, e->stream));
     if (use_solo) HIPCHECK(e, vgxi_launch_solo(&a, &soa, (e->call_has_tlimit || o.traj_points > 0 || !o.record_events) ? 1 : 0, e->stream));
     else if (use_lanes) HIPCHECK(e, vgxi_launch_lanes(&a, &ws, e->stream));
@@ -1085,8 +1097,13 @@ static int direct_core(vgx_engine *e, int64_t iterations, int64_t sample_size, f
         HIPCHECK(e, vgxi_launch_quadg(&a, &qga, e->stream));
     }
     else HIPCHECK(e, vgxi_launch_direct(&a, lds, e->stream));
+    e->counts32_valid = use_quad || use_quadf;
+    if (leaves32) e->counts64_valid = false;
     HIPCHECK(e, hipEventRecord(e->ev1, e->stream));
-    HIPCHECK(e, hipStreamSynchronize(e->stream));
+    if (hipStreamSynchronize(e->stream) != hipSuccess) {
+        e->dev_state_valid = false;     // a kernel that did not finish leaves no state to continue from
+        return fail(e, VGX_ERR_HIP, std::string("vgx_simulate_direct: kernel failed: ") + hipGetErrorString(hipGetLastError()));
+    }
     HIPCHECK(e, hipEventElapsedTime(&e->last_ms, e->ev0, e->ev1));
     e->last_launches = 1;
 

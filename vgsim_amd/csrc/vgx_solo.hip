@@ -1354,8 +1354,14 @@ static __device__ __forceinline__ void solo_body() {
 }  // namespace
 
 // kernel <-> (population registers, device clock, reciprocal division, compact layout's term registers, tiny shape)
+#ifndef VGX_SOLO_WAVES
+#define VGX_SOLO_WAVES 2     // wavefronts per SIMD the register allocation aims at.  Measured (tools/probe_solo_ens.py, Table-3 model, 16 384
+                             // replicates): 2 costs a lone wavefront nothing (the compact kernels need 243-256 registers anyway) and lets
+                             // ensembles of the 10-deme model run two wavefronts per SIMD (8.1e8 -> 1.37e9 events/s); 3 and 4 spill 100-300
+                             // registers into the event loop and lose (K = 2: 1.68e9 / 1.31e9 / 1.06e9 at 2 / 3 / 4)
+#endif
 #define SOLO_KERNEL(name, NPR, CLOCK, RCPDIV, NT, TINY, UNIT) \
-    extern "C" __global__ void __launch_bounds__(64) name(VgxSoloKArgs) { solo_body<NPR, CLOCK, RCPDIV, NT, TINY, UNIT>(); }
+    extern "C" __global__ void __launch_bounds__(64, VGX_SOLO_WAVES) name(VgxSoloKArgs) { solo_body<NPR, CLOCK, RCPDIV, NT, TINY, UNIT>(); }
 SOLO_KERNEL(vgx_solo_kernel_unit, 1, false, true, 1, true, true)
 SOLO_KERNEL(vgx_solo_kernel_tiny, 1, false, true, 1, true, false)
 SOLO_KERNEL(vgx_solo_kernel_c1, 1, false, true, 1, false, false)
