@@ -15,7 +15,6 @@ pytestmark = pytest.mark.gpu
 def _takes(name):
     ctor, phases = models.CASES[name] if name in models.CASES else models.ORACLE_ONLY_CASES[name]
     return (ctor.get("number_of_sites", 0) <= 3 and ctor.get("populations_number", 1) <= 128
-            and name not in models.RECOMBINATION_CASES
             and all(kw.get("method", "direct") == "direct" for _, kw in phases))
 
 
@@ -55,8 +54,19 @@ def test_larger_shapes_are_refused():
     from vgsim_amd._capi import VgxError
     with pytest.raises(VgxError), helpers.quiet():
         helpers.run_case_hip("stress_h256", kernel="solo")      # 256 haplotypes
-    with pytest.raises(VgxError), helpers.quiet():
-        helpers.run_case_hip("recomb_a", kernel="solo")
+
+
+@pytest.mark.parametrize("name", models.RECOMBINATION_CASES)
+def test_recombinant_births_on_the_solo_kernel(oracle_mod, name):
+    """The recombination branch of Birth (pyx:575-596) on the single-trajectory kernel — what a Simulator with a
+    recombination probability now runs on: second parent, breakpoint, records (kept across Restarts like upstream's), log and state
+    equal the oracle's, which is pinned on fixtures recorded from the reference; also against those fixtures directly."""
+    hip = helpers.run_case_hip(name).simulation
+    assert hip._engine.last_kernel == "solo"
+    ref = helpers.run_case_oracle(oracle_mod, name).simulation
+    helpers.assert_models_equal(hip, ref, name)
+    assert len(hip.rec.his) > 0
+    helpers.check_against_golden(hip, name, exact_time=helpers.libm_matches_fixture_host(), rtol_time=1e-12, leftovers=False)
 
 
 def _single(oracle_mod, name, seed, n_events):

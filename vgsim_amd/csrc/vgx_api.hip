@@ -951,9 +951,23 @@ static int direct_core(vgx_engine *e, int64_t iterations, int64_t sample_size, f
     if (o.kernel == 2 && !lane_ok)
         return fail(e, VGX_ERR_ARG, "vgx_simulate_direct: the lane-per-replicate kernel needs exact mode, popNum <= 16, "
                                     "popNum * hapNum <= 1024 and susNum <= 8");
+    // One trajectory (or a few) of a small model: the latency kernel (vgx_solo.hip), the whole model in LDS and registers.
+    VgxSoloArgs soa{};
+    bool solo_ok = o.mode == 0 && H <= VGX_SOLO_MAX_H && P <= VGX_SOLO_MAX_P && S <= VGX_SOLO_MAX_S &&
+                   (int64_t)e->h_so_sn.size() <= VGX_SOLO_MAX_SEG && H <= e->cap;
+    for (int64_t pn = 0; pn < P && solo_ok; pn++)
+        if (e->sizes[(size_t)pn] >= ((int64_t)1 << 52)) solo_ok = false;   // counts are kept as doubles
+    if (solo_ok) {
+        soa.mig_in_lds = vgx_solo_layout((int)P, (int)H, (int)S, (int)e->d.sites, 1).total <= VGX_SOLO_MAX_LDS ? 1 : 0;
+        if (vgx_solo_layout((int)P, (int)H, (int)S, (int)e->d.sites, soa.mig_in_lds).total > VGX_SOLO_MAX_LDS) solo_ok = false;
+    }
+    if (o.kernel == 5 && !solo_ok)
+        return fail(e, VGX_ERR_ARG, "vgx_simulate_direct: the single-trajectory kernel needs exact mode, hapNum <= 64, "
+                                    "popNum <= 128, susNum <= 16 and a model that fits 160 KB of LDS");
     // measured (tools/probe_lanes.py): the lane kernel only wins for minimal models in very large ensembles (config 2 at
     // 262 144 replicates: 2.4e9 vs 7.0e8 events/s); its state lives in HBM/L2, so every other shape is latency-bound
-    const bool use_lanes = (recomb && lane_ok && o.kernel != 1) || o.kernel == 2 || (o.kernel == 0 && lane_ok && P * H * S <= 4 && R >= 65536);
+    // (recombination: the single-trajectory kernel where it takes the model, else the lane kernel, else the wavefront kernel)
+    const bool use_lanes = (recomb && lane_ok && o.kernel != 1 && o.kernel != 5 && !(o.kernel == 0 && solo_ok && R < 2048)) || o.kernel == 2 || (o.kernel == 0 && lane_ok && P * H * S <= 4 && R >= 65536);
     // Four replicates per wavefront, one per 16-lane DPP row (vgx_quad.hip): one rate class, one susceptibility group,
     // at most 64 populations, no population that can switch its lockdown state, exact mode.
     bool quad_shape = !recomb && P <= 64 && S == 1 && e->C == 1 && e->CB == 1 && !ld_possible &&
@@ -971,19 +985,6 @@ static int direct_core(vgx_engine *e, int64_t iterations, int64_t sample_size, f
     const int64_t qg_W = 3 * S + e->CB;
     const bool quadg_ok = o.mode == 0 && !recomb && P <= VGX_QG_MAX_P && S <= VGX_QG_MAX_S && e->C <= VGX_QG_MAX_C &&
                           e->CB <= VGX_QG_MAX_CB && qg_W <= VGX_QG_MAX_W && (int64_t)e->h_seg_par.size() <= VGX_QG_MAX_SEG;
-    // One trajectory (or a few) of a small model: the latency kernel (vgx_solo.hip), the whole model in LDS and registers.
-    VgxSoloArgs soa{};
-    bool solo_ok = o.mode == 0 && !recomb && H <= VGX_SOLO_MAX_H && P <= VGX_SOLO_MAX_P && S <= VGX_SOLO_MAX_S &&
-                   (int64_t)e->h_so_sn.size() <= VGX_SOLO_MAX_SEG && H <= e->cap;
-    for (int64_t pn = 0; pn < P && solo_ok; pn++)
-        if (e->sizes[(size_t)pn] >= ((int64_t)1 << 52)) solo_ok = false;   // counts are kept as doubles
-    if (solo_ok) {
-        soa.mig_in_lds = vgx_solo_layout((int)P, (int)H, (int)S, (int)e->d.sites, 1).total <= VGX_SOLO_MAX_LDS ? 1 : 0;
-        if (vgx_solo_layout((int)P, (int)H, (int)S, (int)e->d.sites, soa.mig_in_lds).total > VGX_SOLO_MAX_LDS) solo_ok = false;
-    }
-    if (o.kernel == 5 && !solo_ok)
-        return fail(e, VGX_ERR_ARG, "vgx_simulate_direct: the single-trajectory kernel needs exact mode, no recombination, hapNum <= 64, "
-                                    "popNum <= 128, susNum <= 16 and a model that fits 160 KB of LDS");
     if (o.kernel == 3 && !quad_ok && !quadg_ok && !quadf_ok)
         return fail(e, VGX_ERR_ARG, "vgx_simulate_direct: the four-replicates-per-wavefront kernels need exact mode, no recombination, "
                                     "popNum <= 128, susNum <= 8, at most 64 rate classes and 16 transmission/susceptibility classes");

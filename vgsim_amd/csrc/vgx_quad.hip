@@ -60,7 +60,7 @@ enum { ST_REBUILD = 0, ST_RUN = 1, ST_DONE = 2 };
 //                 accepted / rejected migrations)                                                     4 x 2400
 #define Q_CONST_BYTES 2048
 #define Q_RNG_BYTES 512
-#define Q_REP_BYTES 2656
+#define Q_REP_BYTES 2912     // ... + the stage of eight event records (256 bytes)
 #define Q_LDS_BYTES (Q_CONST_BYTES + Q_RNG_BYTES + 4 * Q_REP_BYTES)
 enum { QC_B = 0, QC_D, QC_M, QC_MIGP, QC_MIGN };
 
@@ -340,6 +340,26 @@ static __device__ __forceinline__ void quad_body(const VgxDirectArgs &a, const Q
     int64_t *s_cnt = (int64_t *)(s_cc + 4);
     uint64_t *s_inc = (uint64_t *)(s_cnt + 6);         // counters use 5 of their 8 slots; the last two hold the PCG64 increment
     int32_t *s_zero = (int32_t *)(s_inc + 2);           // long-list kernel: zero-count entries in every population's list (vgx_rowlist.h)
+    // Event records are staged here, eight per replicate, and written out together: 192 contiguous bytes of columns + 64 of rates
+    // instead of eight lone 24 + 8 byte stores per stream (16 384 streams: every lone store cost a 64-byte memory transaction).
+    // Dwords 0..47: the six columns of records 0..7; dwords 48..63: their rates.
+    uint32_t *s_stage = (uint32_t *)(s_zero + 64);
+    int stage_n = 0;                // records staged (row-uniform)
+    int64_t stage_slot0 = 0;        // log slot of the first of them
+    auto stage_flush = [&](bool f) {   // rows with f: their staged records go to the log
+        WSYNC();
+        if (f && live) {
+            const int n6 = stage_n * 6;
+            int32_t *c = r.ev_cols + (rep * r.evcap + stage_slot0) * VGX_EV_COLS;
+            uint32_t *q = (uint32_t *)(r.ev_rate + rep * r.evcap + stage_slot0);
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+                if (rl + 16 * j < n6) c[rl + 16 * j] = (int32_t)s_stage[rl + 16 * j];
+            if (rl < 2 * stage_n) q[rl] = s_stage[48 + rl];
+        }
+        if (f) stage_n = 0;
+        WSYNC();
+    };
 #define QBUMP(i) do { if (rl == 0) s_cnt[i] += 1; } while (0)
 
     // the single rate class
@@ -1012,21 +1032,20 @@ static __device__ __forceinline__ void quad_body(const VgxDirectArgs &a, const Q
             if (a.record_events) {
                 const int64_t slot = ev_ptr - r.ev_base;
                 if (slot >= 0 && slot < r.evcap) {
-                    if (live) {
-                        if (rl < VGX_EV_COLS) {
-                            const int v = rl == 0 ? e_type : rl == 1 ? e_hap : rl == 2 ? e_pop : rl == 3 ? e_nh : rl == 4 ? e_np
-                                                                                                          : (int)(uint32_t)att_loops;
-                            r.ev_cols[(rep * r.evcap + slot) * VGX_EV_COLS + rl] = v;
-                        } else if (rl == VGX_EV_COLS) {
-                            r.ev_rate[rep * r.evcap + slot] = den;
-                        }
+                    if (stage_n == 0) stage_slot0 = slot;
+                    if (rl < 8) {
+                        const int v = rl == 0 ? e_type : rl == 1 ? e_hap : rl == 2 ? e_pop : rl == 3 ? e_nh : rl == 4 ? e_np
+                                      : rl == 5 ? (int)(uint32_t)att_loops : rl == 6 ? __double2loint(den) : __double2hiint(den);
+                        s_stage[rl < 6 ? stage_n * 6 + rl : 48 + 2 * stage_n + (rl - 6)] = (uint32_t)v;
                     }
+                    stage_n += 1;
                 } else {
                     err = Q_ERR_CAPACITY;
                 }
             }
             ev_ptr += 1;
         }
+        if (__builtin_expect(__ballot(stage_n == 8) != 0, 0)) stage_flush(stage_n == 8);
 
         QPROF(10);
         // ================= UpdateRates for [u_lo, u_hi) (pyx:516-546) / UpdateAllRates (pyx:279-351) =================
@@ -1133,6 +1152,7 @@ static __device__ __forceinline__ void quad_body(const VgxDirectArgs &a, const Q
             if (ev_ptr <= 100 && a.iterations > 100) {
                 // Restart (pyx:714-738): compartments back to the initial snapshot, then UpdateAllRates
                 ev_ptr = 0; cS = 0;
+                stage_n = 0;                      // (the failed attempt's records are dropped with its log)
                 if (rl < 6) s_cnt[rl] = 0;
                 t_now = 0.0; traj_next = 0;
                 restarts += 1; att += 1;
@@ -1200,6 +1220,7 @@ static __device__ __forceinline__ void quad_body(const VgxDirectArgs &a, const Q
         for (int i = 0; i < VGX_PROF_SLOTS; ++i) r.prof[rep * VGX_PROF_SLOTS + i] = prof_acc[i];
 #endif
     // ---- state back to HBM ----
+    stage_flush(stage_n > 0);
     WSYNC();
     if (live) {
         double *gD = r.popD + rep * PD_COUNT * P;

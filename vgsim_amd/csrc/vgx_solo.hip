@@ -230,7 +230,7 @@ static __device__ __forceinline__ void pop_set(double (&v)[NPR], int pi, double 
 }
 
 // slots of the cold block (LDS): bookkeeping of the call that the event loop itself never reads
-enum { C_EV_PTR = 0, C_LOOPS, C_ATT_LOOPS, C_LOC_N, C_TRAJ_NEXT, C_FA_N, C_ATT_EV0, C_ATT_LOC0, C_RESTARTS, C_ATT, C_GOOD, C_LAST_ATT };
+enum { C_EV_PTR = 0, C_LOOPS, C_ATT_LOOPS, C_LOC_N, C_TRAJ_NEXT, C_FA_N, C_ATT_EV0, C_ATT_LOC0, C_RESTARTS, C_ATT, C_GOOD, C_LAST_ATT, C_REC_N };
 // lanes of the counter vector
 enum { CNT_MIGN = 6, CNT_SWAP = 7 };
 #define SOLO_BIG (1 << 30)
@@ -259,6 +259,7 @@ struct Solo {
     int small;            // P <= 16 and H <= 16: the terms of BirthRate already sit in the row of the haplotype lanes (general layout)
     int no_imm;           // every suscepCumulTransition is zero: immuneSourcePopRate stays +0.0
     int maxterms;         // compact layout: terms of the longest class sum
+    int recomb;           // recombination_probability > 0: births go through the general form (the recombination branch of Birth, pyx:575-596)
     int mig_lds;          // migrationRates lies in LDS
     int one_cls;          // compact layout with ONE susceptibility class: all four rows hold its terms (no cross-row read of the sum)
     Masks M;
@@ -623,7 +624,8 @@ struct Solo {
         return uni_i32(pi);
     }
     // Birth's fastChoose(susceptHapPopRate[pi, hi, :], their sum, rn7) (pyx:569-572): the group that loses a host
-    __device__ __forceinline__ int choose_group(int hi, double rn7) {
+    // (rn_out: the random number rescaled once more, fast_choose.pxi:31 — read by the recombination branch only)
+    __device__ __forceinline__ int choose_group(int hi, double rn7, double *rn_out = nullptr) {
         if (NT > 0) {
             // compact layout: lane (c, s) holds class c's susceptHapPopRate for group s; hi's class decides which row is read
             const double x = Sst * sigcs;
@@ -636,6 +638,11 @@ struct Solo {
                 sidx = first_or_last(hit, S);
             }
             zero_w |= (__builtin_amdgcn_ballot_w64(x == 0.0) >> (c16 + sidx)) & 1ull;
+            if (rn_out) {
+                const double w = bcast(x, c16 + sidx), tot = S > 1 ? bcast(rows_scan<TINY>(x, S, M), c16 + sidx) : w;
+                const double r8 = (S > 1 ? bcast(rows_scan<TINY>(x, S, M), c16 + S - 1) : w) * rn7;
+                *rn_out = (r8 - (tot - w)) / w;
+            }
             return sidx;
         }
         const double x = lane < S ? Sst * ldSigma[hi * S + lane] : 0.0;   // susceptHapPopRate[pi, hi, :]
@@ -646,6 +653,11 @@ struct Solo {
             sidx = first_or_last(__builtin_amdgcn_ballot_w64(lane < S && !(cx < r8)), S);
         }
         zero_weight(lane == sidx && x == 0.0);
+        if (rn_out) {
+            const double cx = flat_chain<true>(x, S, 0.0, M);
+            const double w = bcast(x, sidx), tot = bcast(cx, sidx);
+            *rn_out = (bcast(cx, S - 1) * rn7 - (tot - w)) / w;
+        }
         return sidx;
     }
 
@@ -709,7 +721,7 @@ struct Solo {
             const double r6 = tE * rn5;                                    // fastChoose(eventHapPopRate[pi, hi, 0..3], tEventHapPopRate[pi, hi], rn)
             const int eil = (birth < r6 ? 1 : 0) + (e1 < r6 ? 1 : 0) + (e2 < r6 ? 1 : 0);
             const int ei = __builtin_amdgcn_readlane(eil, hi);
-            if (ei == 3) { u_slow = u; return FAST_SLOW; }
+            if (ei == 3 || (ei == 0 && recomb)) { u_slow = u; return FAST_SLOW; }
             PROF(5);
             // ---- the iteration is this path's: Birth (pyx:568-605, no recombination) / Death / Sampling (pyx:616-635) ----
             loop_left -= 1;
@@ -823,9 +835,48 @@ struct Solo {
                 if (ei < 3) {
                     // ---- Birth (pyx:568-605, no recombination) / Death / Sampling (pyx:616-635) ----
                     int sidx;
+                    int hnew = hi;                 // the haplotype whose count changes
+                    ev_np = ei == 0 ? H : 0;
                     if (ei == 0) {
                         zero_weight(lane == hi && birth == 0.0);
-                        sidx = choose_group(hi, S > 1 ? bcast(r6 / birth, hi) : 0.0);   // (r - (e0 - e0)) / e0
+                        if (!recomb) {
+                            sidx = choose_group(hi, S > 1 ? bcast(r6 / birth, hi) : 0.0);   // (r - (e0 - e0)) / e0
+                        } else {
+                            double rnr;
+                            sidx = choose_group(hi, bcast(r6 / birth, hi), &rnr);
+                            const auto &p = cold_args((SoloKA)__builtin_amdgcn_kernarg_segment_ptr())->a.p;
+                            if (any_lane(rnr < p.recombination) && any_lane(pop_get<NPR>(totI, pi) > 1.0)) {
+                                // ---- recombinant birth (pyx:575-596): the second parent by fastChoose over
+                                // birthInf[hn] = eventHapPopRate[pi, hn, 0] * infectious[pi, hn] with one host of hi set aside ----
+                                rnr = rnr / p.recombination;
+                                const double w = birth * (I - (lane == hi ? 1.0 : 0.0));
+                                const double cw = flat_chain<true>(w, H, 0.0, M);
+                                const double r = bcast(cw, H - 1) * rnr;
+                                const int hi2 = first_or_last(__builtin_amdgcn_ballot_w64(lane < H && !(cw < r)), H);
+                                const double w2 = bcast(w, hi2), tot2 = bcast(cw, hi2);
+                                zero_weight(w2 == 0.0);
+                                rnr = (r - (tot2 - w2)) / w2;
+                                const int64_t posRecomb = (int64_t)((double)p.genome_length * uni_f64(rnr));
+                                // pyx:586-591 as written: `4**k * floor(h / 4**k) % 4` is 0 for every site but the last, where it is
+                                // h % 4 — the recombinant carries only the last site of one parent
+                                hnew = sites > 0 ? ((p.sitesPosition[sites - 1] < posRecomb ? hi : hi2) % 4) : 0;
+                                hnew = uni_i32(hnew);
+                                const auto &rr = cold_args((SoloKA)__builtin_amdgcn_kernarg_segment_ptr())->a.r;
+                                const int64_t rec_n = cold_get(C_REC_N), rep = blockIdx.x;
+                                if (rr.rec) {
+                                    if (rec_n < rr.rec_cap) {
+                                        if (lane == 0) {
+                                            int64_t *o = rr.rec + (rep * rr.rec_cap + rec_n) * 5;
+                                            o[0] = cold_get(C_EV_PTR) + (int64_t)(ev_left0 - ev_left); o[1] = hi; o[2] = hi2; o[3] = hnew; o[4] = posRecomb;
+                                        }
+                                    } else {
+                                        zero_w |= 2ull << 32;
+                                    }
+                                }
+                                cold_set(C_REC_N, rec_n + 1);
+                                ev_np = hi2;
+                            }
+                        }
                     } else {
                         sidx = __builtin_amdgcn_readlane(stype, hi);
                     }
@@ -833,7 +884,7 @@ struct Solo {
                     // NewInfections / NewRecoveries (pyx:246-260)
                     const double sgn = ei == 0 ? 1.0 : -1.0;
                     sus_add(sidx, sgn);
-                    I += (lane == hi ? sgn : 0.0);
+                    I += (lane == hnew ? sgn : 0.0);
 #pragma unroll
                     for (int q = 0; q < NPR; ++q) {
                         const double d1 = (lane + 64 * q == pi) ? sgn : 0.0;
@@ -842,7 +893,7 @@ struct Solo {
                     gI += sgn;
                     imms = l15 == sidx ? cumul_l * Ssus : imms;
                     f_infect = true; f_immune = true; f_mig = true;
-                    ev_type = ei; ev_nh = sidx; ev_np = ei == 0 ? H : 0;
+                    ev_type = ei; ev_nh = sidx;
                 } else {
                     // ---- Mutation (pyx:640-667) ----
                     const double tEh = bcast(tE, hi), tmv = bcast(tmh, hi), r6h = bcast(r6, hi);
@@ -991,6 +1042,7 @@ static __device__ __forceinline__ void solo_body() {
     c.small = uni_i32((P <= 16 && H <= 16) ? 1 : 0);
     c.maxterms = uni_i32(sa.maxterms);
     c.one_cls = uni_i32((NT > 0 && sa.n_cls == 1) ? 1 : 0);
+    c.recomb = uni_i32(p.recombination != 0.0 ? 1 : 0);
 #pragma unroll
     for (int k = 0; k < 16; ++k) c.M.m[k] = (lane & 15) >= k ? 1.0 : 0.0;
     c.ldRng = (double *)(smem + L.rng); c.ldStage = (uint32_t *)(smem + L.stage);
@@ -1110,7 +1162,7 @@ static __device__ __forceinline__ void solo_body() {
     if (lane == 0) {
         c.ldCold[C_EV_PTR] = sc->ev_ptr; c.ldCold[C_LOOPS] = 0; c.ldCold[C_ATT_LOOPS] = 0; c.ldCold[C_LOC_N] = 0; c.ldCold[C_TRAJ_NEXT] = 0;
         c.ldCold[C_FA_N] = 0; c.ldCold[C_ATT_EV0] = sc->ev_ptr; c.ldCold[C_ATT_LOC0] = 0; c.ldCold[C_RESTARTS] = 0; c.ldCold[C_ATT] = 0;
-        c.ldCold[C_GOOD] = sc->good_attempt; c.ldCold[C_LAST_ATT] = -1;
+        c.ldCold[C_GOOD] = sc->good_attempt; c.ldCold[C_LAST_ATT] = -1; c.ldCold[C_REC_N] = 0;
     }
     {   // PCG64 jump constants of this lane: a^(lane+1), sum_{j<=lane} a^j
         const uint64_t MH = 0x2360ED051FC65DA4ull, ML = 0x4385DF649FCCF645ull;
@@ -1345,7 +1397,7 @@ static __device__ __forceinline__ void solo_body() {
             sc->ev_ptr = c.ldCold[C_EV_PTR]; sc->loop_iterations = c.ldCold[C_LOOPS]; sc->restarts = c.ldCold[C_RESTARTS];
             sc->loc_n = c.ldCold[C_LOC_N]; sc->error = error; sc->traj_next = c.ldCold[C_TRAJ_NEXT];
             sc->last_attempt = c.ldCold[C_LAST_ATT]; sc->last_attempt_loops = c.ldCold[C_ATT_LOOPS];
-            sc->rec_n = 0;
+            sc->rec_n = c.ldCold[C_REC_N];   // (like upstream's `rec`, records of failed attempts stay: Restart does not clear them)
             sc->fa_n = c.ldCold[C_FA_N];
         }
     }
