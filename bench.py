@@ -182,6 +182,48 @@ def spread_leg(device, mode="exact", replicates=1024, events=20000, occupied=409
     return out
 
 
+def make_general_c3(seed=2020):
+    """BASELINE config 3's shape as a GENERAL model (what testing/getting_reference.py:14-19 does at scale): two susceptibility groups
+    (recovered hosts are half as susceptible and lose their immunity at rate 0.02), one fitter haplotype (transmission 3.0 instead of
+    2.5: a second rate class), an NPI on every deme (contact density 0.5 above 1 % infected, off below 0.2 %)."""
+    from vgsim_amd import Simulator
+    with contextlib.redirect_stdout(io.StringIO()):
+        s = Simulator(number_of_sites=SITES, populations_number=POPS, number_of_susceptible_groups=2, seed=seed)
+    s.set_transmission_rate(2.5)
+    s.set_transmission_rate(3.0, haplotype=5)
+    s.set_recovery_rate(0.9); s.set_sampling_rate(0.1); s.set_mutation_rate(0.01)
+    s.set_susceptibility_type(1)
+    s.set_susceptibility(0.5, susceptibility_type=1)
+    s.set_immunity_transition(0.02, source=1, target=0)
+    s.set_total_migration_probability(0.01)
+    s.set_population_size(10 ** 7)
+    s.set_npi([0.5, 0.01, 0.002])
+    return s
+
+
+def general_c3_leg(device, replicates=16384, events=50000):
+    """config3_general: the headline shape with several susceptibility groups, rate classes and NPIs — the general row kernel
+    (vgx_quadg.hip) on lists of config-3 length; exact mode, index-case start (natural occupancy)."""
+    import numpy as np
+    from vgsim_amd.ensemble import Ensemble
+    ens = Ensemble(make_general_c3(), replicates, device=device)
+    res = None
+    for it in range(2):
+        res = ens.simulate(events, sample_size=10 ** 12, record_events=True,
+                           seeds=2020 + it * replicates + np.arange(replicates, dtype=np.int64))
+    st = ens.replicate_state(0)
+    occ = (st.infectious != 0).sum(axis=1).astype(float)
+    w = st.infectious.sum(axis=1).astype(float)
+    out = {"workload": "BASELINE config 3's shape as a general model: 65536 haplotypes x 64 populations x 2 susceptibility groups, one fitter "
+                       "haplotype (2 rate classes), immunity loss 0.02, NPI [0.5, 0.01, 0.002] on every deme; %d replicates x %d events, exact mode, "
+                       "index-case start" % (replicates, events),
+           "value": res.total_events / (res.kernel_ms * 1e-3), "unit": "events/s (device time)", "kernel": ens.engine.last_kernel,
+           "kernel_ms_per_launch": res.kernel_ms, "event_weighted_list_len": float((occ * w).sum() / max(w.sum(), 1.0)),
+           "mean_occupancy_list_len": float(occ.mean()), "immunity_transitions_share": None}
+    ens.close()
+    return out
+
+
 def c4_direct_leg(device, replicates=1024, events=20000):
     """Direct Gillespie at BASELINE config 4's shape (2^20 haplotypes x 256 populations, migration), index-case start: the
     general instantiation of the wave kernel (populations in tiles of 64, 37 KB of LDS tables per wavefront)."""
@@ -471,7 +513,53 @@ def tau_cpu_dense(sites, P, per_cell=3, seconds_target=4.0):
     return out
 
 
-def tau_leg(device, steps=20, per_cell=3, seed=2020, cpu=True):
+def tau_warm_start(device, warm_steps=6000, timed_steps=100, seed=2020):
+    """config 4 started the way SURVEY.md 8(d) prescribes instead of by a uniform fill: one index case, a high-mutation warm-up
+    (mutation rate 0.4 per site, tau-leaping, until on average >= 4096 haplotypes per population are occupied), mutation rate back
+    to 0.01, then the timed steps.  Natural occupancy: well under 1 % of the 2^28 compartments hold anyone, and the step kernels
+    still stream the dense arrays."""
+    import ctypes as C
+    import numpy as np
+    from vgsim_amd import Simulator, _capi
+    with contextlib.redirect_stdout(io.StringIO()):
+        s = Simulator(number_of_sites=10, populations_number=256, seed=seed)
+    s.set_transmission_rate(2.5); s.set_recovery_rate(0.9); s.set_sampling_rate(0.1); s.set_mutation_rate(0.4)
+    s.set_total_migration_probability(0.01); s.set_population_size(10 ** 7)
+    m = s.simulation
+    t0 = time.perf_counter()
+    done = 0
+    while done < warm_steps:
+        n = min(3000, warm_steps - done)
+        with contextlib.redirect_stdout(io.StringIO()):
+            s.simulate(n, sample_size=10 ** 15, method="tau", record_multievents=False)
+        done += n
+    warm_s = time.perf_counter() - t0
+    occupied = int((m.infectious != 0).sum())
+    s.set_mutation_rate(0.01)
+    eng = _capi.HipEngine(m.sites, m.hapNum, m.popNum, m.susNum, n_replicates=1, device=device)
+    m.events.CreateEvents(timed_steps)
+    eng.set_params(m); eng.set_state(m); eng.set_seeds(np.array([seed], dtype=np.int64)); eng.stage_tau()
+    o = _capi.VgxRunOpts(); o.record_events = 0
+    t_wall = time.perf_counter()
+    eng._check(eng.lib.vgx_simulate_tau(eng.handle, timed_steps, 10 ** 15, -1.0, 1, C.byref(o)))
+    t_wall = time.perf_counter() - t_wall
+    c = eng.counters(0)
+    n = max(int(c.loop_iterations), 1)
+    ms = eng.last_kernel_ms
+    out = {"start": "SURVEY.md 8(d): index case, %d tau steps at mutation rate 0.4 per site (%.1f s of wall time through the Simulator API), then "
+                    "mutation rate 0.01" % (warm_steps, warm_s),
+           "epidemic_time_at_start": float(m.currentTime), "infected_at_start": int(m.globalInfectious), "occupied_compartments": occupied,
+           "occupied_haplotypes_per_population": occupied / float(m.popNum), "occupied_share": occupied / float(m.infectious.size),
+           "steps": n, "ms_per_step": ms / n, "wall_ms_per_step": 1e3 * t_wall / n, "events_drawn": int(c.reserved[0]),
+           "value": c.reserved[0] / (ms * 1e-3), "unit": "events/s (device time)",
+           "roofline_frac": 16.0 * m.popNum * m.hapNum * n / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+           "note": "the step kernels stream the dense [P][H] arrays whatever the occupancy: per step as many bytes as the uniform fill, for 1/400 "
+                   "of its events (DESIGN.md 9: occupancy lists for tau)"}
+    eng.close()
+    return out
+
+
+def tau_leg(device, steps=20, per_cell=3, seed=2020, cpu=True, warm=True):
     """Tau-leaping on BASELINE config 4 (2^20 haplotypes x 256 populations, migration), dense ("spread")
     occupancy written straight into the model's arrays; the reference cannot even construct this shape
     (SURVEY.md §0.8).  Reports events drawn per second of device time and the step's HBM roofline against the
@@ -546,6 +634,11 @@ def tau_leg(device, steps=20, per_cell=3, seed=2020, cpu=True):
                                 "bytes = 16*P*H per step (read+write infectious once, one try); traffic = PMC bytes per step (about three "
                                 "tries of the reference's halving loop per step)"}}
     eng.close()
+    if warm:
+        try:
+            out["warmup_start"] = tau_warm_start(device, seed=seed)
+        except Exception as ex:
+            out["warmup_start"] = {"error": repr(ex)}
     return out
 
 
@@ -745,7 +838,7 @@ def main():
     ap.add_argument("--no-tau", action="store_true", help="skip the tau-leap (config 4) leg")
     ap.add_argument("--no-extra", action="store_true", help="skip the FAST-mode, spread-occupancy and config-2 legs")
     ap.add_argument("--only", default="", help="development/profiling: run only this extra leg (fast_mode, spread_occupancy, "
-                                               "spread_occupancy_fast, config2, genealogy, single_trajectory, direct_config4_shape, table3, tau_small, config5, propensity_scan, tau_leap) and print its JSON")
+                                               "spread_occupancy_fast, config2, genealogy, single_trajectory, direct_config4_shape, config3_general, table3, tau_small, config5, propensity_scan, tau_leap) and print its JSON")
     ap.add_argument("--table3-cells", default="", help="profiling: restrict the table3 leg to these cells, e.g. 10:0.001,100:0.1")
     a = ap.parse_args()
     cells3 = {(int(c.split(":")[0]), float(c.split(":")[1])) for c in a.table3_cells.split(",") if c} or None
@@ -785,7 +878,7 @@ def main():
                   ("spread_occupancy", lambda d: spread_leg(d, "exact", replicates=8192, events=10000)),
                   ("spread_occupancy_fast", lambda d: spread_leg(d, "fast", replicates=12288, events=10000)),
                   ("config2", c2_leg), ("genealogy", genealogy_leg), ("single_trajectory", single_leg),
-                  ("direct_config4_shape", c4_direct_leg), ("table3", lambda d: table3_leg(d, cpu=not a.no_cpu_baseline, cells=cells3)),
+                  ("direct_config4_shape", c4_direct_leg), ("config3_general", general_c3_leg), ("table3", lambda d: table3_leg(d, cpu=not a.no_cpu_baseline, cells=cells3)),
                   ("tau_small", lambda d: tau_small_leg(d, cpu=not a.no_cpu_baseline)), ("propensity_scan", rowscan_leg),
                   ("tau_leap", lambda d: tau_leg(d, cpu=not a.no_cpu_baseline)))
     if a.only:
@@ -904,7 +997,7 @@ def main():
     tau = None
     if not a.no_tau:
         try:
-            tau = tau_leg(local, seed=2020 + rank, cpu=(rank == 0 and world == 1 and not a.no_cpu_baseline))
+            tau = tau_leg(local, seed=2020 + rank, cpu=(rank == 0 and world == 1 and not a.no_cpu_baseline), warm=(world == 1))
         except Exception as ex:  # never lose the headline line
             tau = {"error": repr(ex)}
         if world > 1:
@@ -954,6 +1047,7 @@ def main():
             "tau_leap_ms_per_step": pick(line, "tau_leap", "ms_per_step"), "tau_leap_events_per_s": pick(line, "tau_leap", "value"),
             "tau_leap_roofline_frac": pick(line, "tau_leap", "roofline", "frac"), "tau_leap_wall_ms_per_step": pick(line, "tau_leap", "wall", "ms_per_step"),
             "tau_cpu_ns_per_channel_step": pick(line, "tau_leap", "cpu_baseline", "4096x8", "ns_per_channel_step"),
+            "tau_warmup_start_ms_per_step": pick(line, "tau_leap", "warmup_start", "ms_per_step"),
             "config5_events_per_s": pick(line, "config5", "value"), "fast_mode_events_per_s": pick(line, "fast_mode", "value"),
             "single_trajectory_config2": pick(line, "single_trajectory", "config2"),
             "single_trajectory_config3": pick(line, "single_trajectory", "config3"),
@@ -963,6 +1057,7 @@ def main():
             "table3_K10_ensemble_events_per_s": pick(line, "table3", "cells", "K=10,M=0.001", "ensemble", "events_per_s"),
             "table3_K100_ensemble_events_per_s": pick(line, "table3", "cells", "K=100,M=0.001", "ensemble", "events_per_s"),
             "spread_occupancy_events_per_s": pick(line, "spread_occupancy", "value"),
+            "config3_general_events_per_s": pick(line, "config3_general", "value"),
             "propensity_scan_roofline_frac": pick(line, "propensity_scan", "roofline", "frac"),
             "cpu_baseline_events_per_s": pick(line, "cpu_baseline", "value"),
         }
