@@ -218,6 +218,7 @@ struct VgxTauArgs {
     double *migcdf;          // [R][P][CB][P*S] running sums of the out-migration channel weights
     int64_t *counters;   // [R][8]: births, recoveries, samples, mutations, immunity, migrations, lockdown switches, events drawn
     int64_t *cnt_try;    // [R][8] tallies of the retry being validated
+    unsigned long long *cnt_pop;   // [R][P][8] the events kernel's share of them per population, folded into cnt_try by vgx_tau_decide_kernel
     int64_t *mev;        // [R][mev_cap][6]  num, type, hap, pop, newHap, newPop (rows with num > 0 only)
     int64_t mev_cap;
     unsigned long long *mev_n;     // [R]

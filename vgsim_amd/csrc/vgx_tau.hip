@@ -1644,6 +1644,9 @@ static __host__ __device__ inline size_t tau_tab_lds_bytes(int C, int CB, int S,
 #ifndef VGX_EV_CHUNK
 #define VGX_EV_CHUNK 8      // rounds whose queue entries and counts a wavefront of the events kernel loads in one go
 #endif
+#ifndef VGX_EV_SHORT_CHUNKS
+#define VGX_EV_SHORT_CHUNKS 1   // the first chunks of a wavefront of the events kernel are 1, 1, 2, 4 rounds long (a rejected try is noticed early)
+#endif
 #ifndef VGX_EV_BLOCKS
 #define VGX_EV_BLOCKS 2048  // wavefronts of the events kernel per launch: what the chip holds at VGX_EV_WAVES per SIMD
 #endif
@@ -2082,27 +2085,51 @@ __global__ void __launch_bounds__(EB, VGX_EV_WAVES) vgx_tau_events_kernel(VgxTau
     const int64_t kstep = (int64_t)split * EB, kfirst = (int64_t)sub * EB;
     int round = 0;
     EVPROF(0);
-    for (int sb = sb0; sb < shards_pop && okv != 0; sb += sbstep) {
-    const int64_t n = (int64_t)qn_pop[sb];
-    if (kfirst >= n) continue;
-    if (n > scap) {   // the shard overflowed: compartments were lost, the host enlarges the queue and the same try runs again
-        if (threadIdx.x == 0) atomicOr(&a.grow[rep], 8);
-        continue;
-    }
-    const int64_t *qsrc = a.q + (int64_t)rep * a.q_cap + ((int64_t)pn * shards_pop + sb) * scap;
-    for (int64_t kc = kfirst; kc < n && okv != 0; kc += (int64_t)VGX_EV_CHUNK * kstep) {
-    {   // The queue entries of the next VGX_EV_CHUNK rounds and, from them, the compartments' counts (dependent, scattered): two
+    // The rounds are staged in chunks (below); the first chunks are short (1, 1, 2, 4 rounds, then VGX_EV_CHUNK): a try that is
+    // going to be rejected usually meets its first failing compartment within the first rounds of SOME wavefront, and the others
+    // notice at their next chunk boundary — with full chunks from the start a rejected try cost 0.2 ms of this kernel, two
+    // thirds of an accepted one.
+    int sb = sb0 - sbstep;
+    int64_t n = 0, kc = 0;
+    const int64_t *qsrc = nullptr;
+    bool shard_open = false;
+    int chunk_no = 0;
+    for (;;) {
+    int nr = 0;                     // rounds staged in s_q / s_I / s_c
+    if (okv == 0) break;
+    {
+        if (!shard_open || kc >= n) {   // the next shard of the block with entries for it
+            shard_open = false;
+            for (sb += sbstep; sb < shards_pop; sb += sbstep) {
+                n = (int64_t)qn_pop[sb];
+                if (kfirst >= n) continue;
+                if (n > scap) {   // the shard overflowed: compartments were lost, the host enlarges the queue and the same try runs again
+                    if (threadIdx.x == 0) atomicOr(&a.grow[rep], 8);
+                    continue;
+                }
+                shard_open = true;
+                break;
+            }
+            if (!shard_open) break;
+            qsrc = a.q + (int64_t)rep * a.q_cap + ((int64_t)pn * shards_pop + sb) * scap;
+            kc = kfirst;
+        }
+        // The queue entries of the next VGX_EV_CHUNK rounds and, from them, the compartments' counts (dependent, scattered): two
         // bursts of unconditional loads (indices clamped), parked in the wavefront's LDS stage.  One load per round issued
         // "ahead" does not work here: vmcnt counts loads and stores together and the round's body has stores and atomics, so
         // the compiler has to wait for everything (vmcnt(0)) at each use — every round paid a full trip to HBM.
         // `ok` rides along (a device-scope load goes past the L2: a few microseconds): a lost try is noticed within a chunk.
         okv = __hip_atomic_load(&a.ok[rep], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int want = VGX_EV_SHORT_CHUNKS ? (chunk_no < 2 ? 1 : chunk_no == 2 ? 2 : chunk_no == 3 ? 4 : VGX_EV_CHUNK) : VGX_EV_CHUNK;
+        chunk_no += 1;
         int64_t qv[VGX_EV_CHUNK];
         int32_t Iv[VGX_EV_CHUNK], Cv[VGX_EV_CHUNK];
 #pragma unroll
         for (int j = 0; j < VGX_EV_CHUNK; ++j) {
             const int64_t kk = kc + (int64_t)j * kstep + L;
-            qv[j] = qsrc[kk < n ? kk : n - 1];
+            qv[j] = -1;
+            if (j < want) qv[j] = qsrc[kk < n ? kk : n - 1];
+            if (kk >= n) qv[j] = -1;   // (nothing there)
         }
 #ifdef VGX_PROFILE
         { int t_; asm volatile("v_mov_b32 %0, %1" : "=v"(t_) : "v"((int)qv[VGX_EV_CHUNK - 1])); asm volatile("" :: "v"(t_)); }
@@ -2111,22 +2138,26 @@ __global__ void __launch_bounds__(EB, VGX_EV_WAVES) vgx_tau_events_kernel(VgxTau
 #pragma unroll
         for (int j = 0; j < VGX_EV_CHUNK; ++j) {
             const int hh = min((int)(qv[j] & 0x7FFFFFFFll), H - 1);   // (a bad entry must not fault)
-            Iv[j] = Irow[hh];
-            Cv[j] = many_cls ? p.cls[hh] : 0;
+            Iv[j] = 0; Cv[j] = 0;
+            if (j < want) {
+                Iv[j] = Irow[hh];
+                Cv[j] = many_cls ? p.cls[hh] : 0;
+            }
         }
 #pragma unroll
         for (int j = 0; j < VGX_EV_CHUNK; ++j) {
             s_q[j * EB + L] = qv[j]; s_I[j * EB + L] = Iv[j];
             if (many_cls) s_c[j * EB + L] = Cv[j];
         }
+        const int64_t left = (n - kc + kstep - 1) / kstep;     // rounds of this shard from kc on
+        nr = left < want ? (int)left : want;
+        kc += (int64_t)nr * kstep;
     }
 #ifdef VGX_PROFILE
     EVPROF(1);
 #endif
-    for (int j = 0; j < VGX_EV_CHUNK; ++j, ++round) {
-        const int64_t k0 = kc + (int64_t)j * kstep;
-        if (k0 >= n || okv == 0) break;   // (okv == 0: the try is already lost, nothing of it counts: vgx_tau_decide_kernel)
-        const int64_t k = k0 + L;
+    for (int j = 0; j < nr; ++j, ++round) {
+        if (okv == 0) break;   // (the try is already lost, nothing of it counts: vgx_tau_decide_kernel)
         const int64_t qe = s_q[j * EB + L];
         const int32_t I_now = s_I[j * EB + L];
         const int cls_now = many_cls ? s_c[j * EB + L] : 0;
@@ -2137,7 +2168,7 @@ __global__ void __launch_bounds__(EB, VGX_EV_WAVES) vgx_tau_events_kernel(VgxTau
         int64_t v = 0;
         bool below = false;   // below zero on its own (sparse mode): looked at by the whole wavefront, see below
         bool isbig = false;
-        if (k < n && (int)(qe & 0x7FFFFFFFll) < H) {
+        if (qe >= 0 && (int)(qe & 0x7FFFFFFFll) < H) {
             h = (int)(qe & 0x7FFFFFFFll);
             const int64_t Ih = (int64_t)I_now;
             int64_t oc = 0, oa = 0;
@@ -2207,9 +2238,13 @@ __global__ void __launch_bounds__(EB, VGX_EV_WAVES) vgx_tau_events_kernel(VgxTau
         EVPROF(4);
     }   // rounds
     }   // chunks
-    }   // shards
+    // a lost try: nothing of it counts (vgx_tau_decide_kernel discards the tallies, the list and the deltas), so a wavefront that
+    // leaves early adds nothing — its atomics on the few shared addresses would be worked off one after the other
+    if (okv == 0) return;
     tau_stage_flush(a, stage, rep);   // what is left
-    unsigned long long *ct = (unsigned long long *)&a.cnt_try[(int64_t)rep * 8];
+    // the event counters go to the population's own slots (vgx_tau_decide_kernel folds them): all wavefronts of a launch adding to
+    // the same six addresses were worked off one after the other by the memory side, a quarter of an accepted try's kernel time
+    unsigned long long *ct = a.cnt_pop + ((int64_t)rep * P + pn) * 8;
     for (int i = 0; i < 12; ++i) {   // wave-level sums, then one global atomic per tally
         long long v = cnt[i];
         for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
@@ -2663,6 +2698,19 @@ extern "C" __global__ void __launch_bounds__(64) vgx_tau_decide_kernel(VgxTauArg
     const bool ok = live && a.ok[rep];
     const int again = (g & 29) ? (g & 29) : (ok ? (g & 2) : 0);
     const bool accept = live && ok && again == 0;
+    if (live) {   // the events kernel's tallies, kept per population (vgx_tau_events_kernel's epilogue)
+        const int P = a.p.P;
+        unsigned long long part[6] = {0, 0, 0, 0, 0, 0};
+        for (int pn = threadIdx.x; pn < P; pn += 64) {
+            unsigned long long *cp = a.cnt_pop + ((int64_t)rep * P + pn) * 8;
+            for (int i = 0; i < 6; ++i) { part[i] += cp[i]; cp[i] = 0; }
+        }
+        for (int i = 0; i < 6; ++i) {
+            long long v = (long long)part[i];
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+            if (threadIdx.x == 0) a.cnt_try[(int64_t)rep * 8 + i] += v;
+        }
+    }
     __syncthreads();
     // the list of moves: applied already (dense mode: vgx_tau_scatter_kernel) or discarded; the sparse mode's accepted list
     // is applied after this kernel (vgx_tau_apply_kernel) and emptied by vgx_tau_finish_kernel
