@@ -836,6 +836,7 @@ def main():
     ap.add_argument("--traj-points", type=int, default=1001)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-tau", action="store_true", help="skip the tau-leap (config 4) leg")
+    ap.add_argument("--no-tau-warmup-start", action="store_true", help="profiling: leave out tau_leap.warmup_start (6000 tau steps of warm-up: a quarter of a million launches in a trace)")
     ap.add_argument("--no-extra", action="store_true", help="skip the FAST-mode, spread-occupancy and config-2 legs")
     ap.add_argument("--only", default="", help="development/profiling: run only this extra leg (fast_mode, spread_occupancy, "
                                                "spread_occupancy_fast, config2, genealogy, single_trajectory, direct_config4_shape, config3_general, table3, tau_small, config5, propensity_scan, tau_leap) and print its JSON")
@@ -880,7 +881,7 @@ def main():
                   ("config2", c2_leg), ("genealogy", genealogy_leg), ("single_trajectory", single_leg),
                   ("direct_config4_shape", c4_direct_leg), ("config3_general", general_c3_leg), ("table3", lambda d: table3_leg(d, cpu=not a.no_cpu_baseline, cells=cells3)),
                   ("tau_small", lambda d: tau_small_leg(d, cpu=not a.no_cpu_baseline)), ("propensity_scan", rowscan_leg),
-                  ("tau_leap", lambda d: tau_leg(d, cpu=not a.no_cpu_baseline)))
+                  ("tau_leap", lambda d: tau_leg(d, cpu=not a.no_cpu_baseline, warm=not a.no_tau_warmup_start)))
     if a.only:
         legs = dict(extra_legs)
         legs["config5"] = lambda d: config5_leg(d, world=world, rank=rank)
@@ -997,7 +998,7 @@ def main():
     tau = None
     if not a.no_tau:
         try:
-            tau = tau_leg(local, seed=2020 + rank, cpu=(rank == 0 and world == 1 and not a.no_cpu_baseline), warm=(world == 1))
+            tau = tau_leg(local, seed=2020 + rank, cpu=(rank == 0 and world == 1 and not a.no_cpu_baseline), warm=(world == 1 and not a.no_tau_warmup_start))
         except Exception as ex:  # never lose the headline line
             tau = {"error": repr(ex)}
         if world > 1:

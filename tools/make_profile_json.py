@@ -1,11 +1,12 @@
-"""Turns gpurun_out/prof_r03/ (tools/collect_profiles.sh) into the committed artefacts under profiles/: kernel-stats CSVs,
+"""Turns gpurun_out/prof_<TAG>/ (tools/collect_profiles.sh; TAG from the environment, default r04) into the committed artefacts under profiles/: kernel-stats CSVs,
 the raw PMC rows, the SQ summary, and the JSON files bench.py reads for its `traffic` fields."""
 import collections, csv, glob, json, os, shutil, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-TAG = "r03"
+TAG = os.environ.get("TAG", "r04")
 SRC = os.path.join(ROOT, "gpurun_out", "prof_" + TAG)
 DST = os.path.join(ROOT, "profiles")
-LEGS = ("headline", "spread_occupancy", "spread_occupancy_fast", "tau_leap", "fast_mode", "table3", "tau_small")
+LEGS = ("headline", "spread_occupancy", "spread_occupancy_fast", "tau_leap", "fast_mode", "table3", "tau_small", "single_trajectory",
+        "config3_general", "propensity_scan")
 
 
 def one(pattern):
@@ -74,11 +75,17 @@ for leg in have:
     if s:
         sq_all[leg] = s
 json.dump({"source": "rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU "
-                     "SQ_INSTS_SALU SQ_INSTS_LDS, one pass per bench leg (tools/collect_profiles.sh), round 3; raw rows in profiles/r03_*_pmc_SQ.csv",
+                     "SQ_INSTS_SALU SQ_INSTS_LDS, one pass per bench leg (tools/collect_profiles.sh), %s; raw rows in profiles/%s_*_pmc_SQ.csv" % (TAG, TAG),
            "legs": sq_all}, open(os.path.join(DST, "%s_sq_counters.json" % TAG), "w"), indent=1)
 
-direct = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE, round 3; raw rows in profiles/r03_*_pmc_*.csv; earlier rounds' values in git history",
-          "correction": CORR}
+# legs not collected again this round keep their entry (their kernels did not change)
+try:
+    direct = json.load(open(os.path.join(DST, "pmc_direct_c3.json")))
+except Exception:
+    direct = {}
+direct["source"] = ("rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE; raw rows in profiles/<round>_*_pmc_*.csv (each leg's entry names its round); "
+                    "earlier rounds' values in git history")
+direct["correction"] = CORR
 HEAD = "python3 bench.py --no-cpu-baseline --no-tau --no-extra --steps 3 --warmup 1"
 for leg, kernel, cmd, cfg in (
         ("headline", "vgx_quad_kernel", HEAD, {"replicates_per_gpu": 16384, "events_per_replicate": 100000, "trajectory_points": 1001}),
@@ -87,7 +94,8 @@ for leg, kernel, cmd, cfg in (
         ("spread_occupancy_fast", "vgx_quadf_kernel", "python3 bench.py --only spread_occupancy_fast",
          {"replicates_per_gpu": 12288, "events_per_replicate": 10000, "occupied": 4096, "mode": "fast"}),
         ("fast_mode", "vgx_quadf_kernel", "python3 bench.py --only fast_mode", {"replicates_per_gpu": 24576, "events_per_replicate": 100000, "mode": "fast"}),
-        ("table3", "vgx_quadg_kernel_p16", "python3 bench.py --only table3 --no-cpu-baseline --table3-cells 10:0.001",
+        ("config3_general", "vgx_quadg_kernel_p64", "python3 bench.py --only config3_general", {"replicates_per_gpu": 16384, "events_per_replicate": 50000}),
+        ("table3", "vgx_solo_kernel_c2" if TAG >= "r04" else "vgx_quadg_kernel_p16", "python3 bench.py --only table3 --no-cpu-baseline --table3-cells 2:0.001,10:0.001",
          {"replicates_per_gpu": 16384, "events_per_replicate": 50000, "K": 10, "M": 0.001})):
     if leg not in have:
         continue
@@ -95,7 +103,7 @@ for leg, kernel, cmd, cfg in (
     # the largest launches of the kernel (a leg may also run it on a small ensemble: fast_mode, table3)
     f, w = fa[kernel], wa[kernel]
     assert f[1] == w[1] and f[1] > 0, (leg, kernel, sorted(fa))
-    direct[leg] = {"command": cmd, "config": cfg, "kernel": kernel, "launches": f[1], "FETCH_SIZE_KiB_per_launch": f[0] / f[1],
+    direct[leg] = {"round": TAG, "command": cmd, "config": cfg, "kernel": kernel, "launches": f[1], "FETCH_SIZE_KiB_per_launch": f[0] / f[1],
                    "WRITE_SIZE_KiB_per_launch": w[0] / w[1], "hbm_bytes_per_launch": (2.0 * f[0] / f[1] + w[0] / w[1]) * 1024}
 json.dump(direct, open(os.path.join(DST, "pmc_direct_c3.json"), "w"), indent=1)
 
@@ -115,15 +123,27 @@ if "tau_leap" in have:
     hist = dict(old.get("history", {}))
     prev = old.get("hbm_bytes_per_step")
     if prev and abs(prev - tot) > 1e6 and prev not in hist.values():
-        hist["round 2 (count passes on the 8-byte counts)"] = prev
+        hist["before %s" % TAG] = prev
     json.dump({"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes, csv), command: python3 bench.py --only tau_leap "
-                         "(config 4: the timed 20 steps and the call of 200 steps), round 3; raw rows in profiles/r03_tau_leap_pmc_*.csv",
+                         "(config 4: the timed 20 steps and the call of 200 steps), %s; raw rows in profiles/%s_tau_leap_pmc_*.csv" % (TAG, TAG),
                "correction": CORR, "config": {"steps": 20, "per_cell": 3}, "steps_profiled": steps,
                "note": "per-step averages over every step the leg runs (its timed call of 20 steps and its call of 200 steps)", "kernels": kern,
                "hbm_bytes_per_step": tot, "history": hist}, open(os.path.join(DST, "pmc_tau_c4.json"), "w"), indent=1)
     print("tau %.3g B/step over %d steps" % (tot, steps))
     for k, v in sorted(kern.items(), key=lambda kv: -(kv[1]["read_bytes_per_step"] + kv[1]["write_bytes_per_step"]))[:8]:
         print("  %-60s %6.2f GB/step" % (k[:60], (v["read_bytes_per_step"] + v["write_bytes_per_step"]) / 1e9))
+if "propensity_scan" in have:
+    fk, wk = pmc("propensity_scan", "FETCH_SIZE"), pmc("propensity_scan", "WRITE_SIZE")
+    ks = [k for k in fk if "vgx_rowscan" in k]
+    passes = max(fk[k][1] for k in ks)
+    old = json.load(open(os.path.join(DST, "pmc_rowscan.json")))
+    fb = sum(2.0 * fk[k][0] * 1024 for k in ks) / passes
+    wb = sum(wk[k][0] * 1024 for k in ks) / passes
+    old.update({"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE (and, separately, WRITE_SIZE) --output-format csv -- python3 bench.py --only propensity_scan, %s; "
+                          "sums over vgx_rowscan_update_kernel + vgx_rowscan_choose_kernel, %d passes each; FETCH_SIZE doubled (gfx950 correction)" % (TAG, passes),
+                "fetch_bytes_per_pass": fb, "write_bytes_per_pass": wb, "hbm_bytes_per_pass": fb + wb})
+    json.dump(old, open(os.path.join(DST, "pmc_rowscan.json"), "w"), indent=1)
+    print("rowscan %.4g B/pass (algorithmic %.4g)" % (fb + wb, old.get("algorithmic_bytes_per_pass", 0)))
 for leg in direct:
     if isinstance(direct[leg], dict):
         print("%-24s %.3g B/launch" % (leg, direct[leg]["hbm_bytes_per_launch"]))

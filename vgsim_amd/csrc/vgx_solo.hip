@@ -23,7 +23,7 @@
 //     residual corrections (div_by_const below: the result IS the correctly rounded quotient);
 //   * fastChoose's rescaled random number (fast_choose.pxi:31) is formed by every candidate lane at once and read from the
 //     chosen one; the rescaling after the last choice of an event is skipped where nothing reads it (Death, Sampling, and Birth
-//     without recombination);
+//     when the model has no recombination);
 //   * uniforms: 64 PCG64 outputs per refill by lane-parallel jump-ahead into LDS, two per iteration as upstream (pyx:477, 488);
 //     the logarithm of SampleTime only in calls that need the device clock (a time limit, trajectories, or no event log: event
 //     times are rebuilt on the host with libm from the logged rates, vgx_api.hip host_clock);
@@ -31,7 +31,8 @@
 // Everything else (Restart, lockdown switches with UpdateAllRates, migration with its rejection step, mutations, immunity
 // transitions, trajectories, the logs the host clock needs) follows vgx_direct.hip / vgx_lanes.hip; start and end state are exchanged
 // in their layout (occupancy lists, population blocks), so the host side and the other kernels see no difference.
-// Exact mode, no recombination.  One wavefront per replicate: small ensembles run as independent wavefronts.
+// Exact mode.  Recombinant births (pyx:575-596) take the general path of event().  One wavefront per replicate: ensembles run as
+// independent wavefronts.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "vgx_dev.h"
