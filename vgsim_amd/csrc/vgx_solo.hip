@@ -234,7 +234,10 @@ static __device__ __forceinline__ void pop_set(double (&v)[NPR], int pi, double 
 enum { C_EV_PTR = 0, C_LOOPS, C_ATT_LOOPS, C_LOC_N, C_TRAJ_NEXT, C_FA_N, C_ATT_EV0, C_ATT_LOC0, C_RESTARTS, C_ATT, C_GOOD, C_LAST_ATT, C_REC_N };
 // lanes of the counter vector
 enum { CNT_MIGN = 6, CNT_SWAP = 7 };
-#define SOLO_BIG (1 << 30)
+#ifndef VGX_SOLO_SEG
+#define VGX_SOLO_SEG (1 << 30)   // iterations per segment of the event loop (a test build shortens it: the segment ends are then exercised)
+#endif
+#define SOLO_BIG VGX_SOLO_SEG
 
 // The kernel's arguments are read through the kernarg segment pointer (constant address space: scalar loads, wave-uniform values;
 // taking the address of a by-value kernel parameter would make a private copy whose loads count as divergent).  The cold paths see
