@@ -669,6 +669,29 @@ def test_byte_drift_pass_equals_the_two_pass_form(monkeypatch, sites, P, S, fill
     assert a.bCounter > 0
 
 
+@pytest.mark.parametrize("sites,P,S,fill", [(8, 3, 2, _fill_saturated), (9, 3, 1, _fill_small), (7, 4, 1, _fill_small), (10, 2, 1, _fill_small)])
+def test_front_pass_only_ends_lost_tries_early(monkeypatch, sites, P, S, fill):
+    """The front pass of a try (vgx_tau_front_kernel + vgx_tau_events_kernel<., true>: the compartments that can fall below zero on
+    their own, drawn first and without bookkeeping) may only end a try early that the try proper would have rejected: eight leaps
+    with it and without it (VGX_TAU_NO_FRONT=1) are the same leaps — same number of tries (the sieve's and the loop's), same times,
+    same events, same state."""
+    def run(off):
+        if off:
+            monkeypatch.setenv("VGX_TAU_NO_FRONT", "1")
+        else:
+            monkeypatch.delenv("VGX_TAU_NO_FRONT", raising=False)
+        s = _filled(sites, P, S, 700 + sites, fill, True)
+        with helpers.quiet():
+            s.simulate(8, sample_size=10 ** 12, method="tau", record_multievents=False)
+        return s.simulation
+    a, b = run(False), run(True)
+    assert a.events.ptr == b.events.ptr == 16
+    assert np.array_equal(a.events.times[:16], b.events.times[:16])
+    assert np.array_equal(a.infectious, b.infectious) and np.array_equal(a.susceptible, b.susceptible)
+    for k in a.COUNTERS:
+        assert getattr(a, k) == getattr(b, k), k
+
+
 @pytest.mark.parametrize("sites,P,S", [(8, 3, 2), (2, 3, 1)])
 def test_staged_start_state_gives_the_same_run(sites, P, S):
     """vgx_stage_tau (snapshot, conversion and upload of the start state ahead of the call: the bench's hand-over) against

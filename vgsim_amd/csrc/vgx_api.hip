@@ -101,7 +101,7 @@ struct vgx_engine {
         r_evrate, r_evcols, r_locrec, r_loctime, r_lociter, r_farate, r_fakey, r_traj, r_prof, r_qeff, r_qmebm, r_qflag;
     // tau-leaping (dense compartments)
     DevBuf t_I, t_S, t_dChk, t_dApp, t_dSi, t_dTot, t_totInf, t_gI, t_cd, t_lock, t_F, t_eff, t_Aeff, t_Gout, t_dS,
-        t_taubits, t_tau, t_time, t_flags, t_counters, t_cnttry, t_cntpop, t_mev, t_mevn, t_mevbase, t_locn, t_mutcum, t_migcdf, t_migIn, t_mutHi, t_colT, t_colTW, t_inc, t_incn, t_sieve, t_sieveskip, t_big, t_bign, t_res, t_susp, t_suspn, t_stkey, t_stval, t_dChkTot, t_q, t_qn, t_hist, t_I8, t_dSpart, t_tmax8, t_iI, t_iS, t_slog, t_sres;
+        t_taubits, t_tau, t_time, t_flags, t_counters, t_cnttry, t_cntpop, t_front, t_frontn, t_mev, t_mevn, t_mevbase, t_locn, t_mutcum, t_migcdf, t_migIn, t_mutHi, t_colT, t_colTW, t_inc, t_incn, t_sieve, t_sieveskip, t_big, t_bign, t_res, t_susp, t_suspn, t_stkey, t_stval, t_dChkTot, t_q, t_qn, t_hist, t_I8, t_dSpart, t_tmax8, t_iI, t_iS, t_slog, t_sres;
     std::vector<int64_t> tau_sieve_skipped;   // [R] tries left out by the sieve in the last tau call
     bool last_was_tau = false;
     bool tau_staged = false;              // vgx_stage_tau put the current start state on the device in the tau kernels' layout
@@ -1497,6 +1497,16 @@ extern "C" int vgx_simulate_tau(vgx_engine *e, int64_t iterations, int64_t sampl
     a.colT = (double *)e->t_colT.p; a.colTW = (double *)e->t_colTW.p;
     a.inc = (int64_t *)e->t_inc.p; a.inc_cap = inc_cap; a.inc_shards = vgxi_tau_inc_shards(H, P); a.inc_n = (unsigned long long *)e->t_incn.p;
     a.counters = (int64_t *)e->t_counters.p; a.cnt_try = (int64_t *)e->t_cnttry.p; a.cnt_pop = (unsigned long long *)e->t_cntpop.p;
+    {   // the front pass of a try (vgx_tau_front_kernel): one rate class, the tabulated scan's shapes, sparse mode
+        const char *nf = getenv("VGX_TAU_NO_FRONT");
+        a.front_cap = 512;
+        a.front_on = (sparse_default && e->C == 1 && e->CB <= 16 && (H & 15) == 0 && !(nf && nf[0] == '1')) ? 1 : 0;
+        int rcf = ensure(e, e->t_front, (size_t)(R * P) * (size_t)a.front_cap * 8);
+        if (!rcf) rcf = ensure(e, e->t_frontn, (size_t)(R * P) * 4 + 64);
+        if (rcf) return rcf;
+        HIPCHECK(e, hipMemset(e->t_frontn.p, 0, (size_t)(R * P) * 4));
+        a.front = (int64_t *)e->t_front.p; a.front_n = (unsigned int *)e->t_frontn.p;
+    }
     a.big = (int64_t *)e->t_big.p; a.big_cap = big_cap; a.big_n = (unsigned long long *)e->t_bign.p;
     a.res = (int64_t *)e->t_res.p;
     a.suspect = (int64_t *)e->t_susp.p; a.suspect_cap = suspect_cap; a.suspect_n = (unsigned long long *)e->t_suspn.p;

@@ -218,6 +218,9 @@ struct VgxTauArgs {
     double *migcdf;          // [R][P][CB][P*S] running sums of the out-migration channel weights
     int64_t *counters;   // [R][8]: births, recoveries, samples, mutations, immunity, migrations, lockdown switches, events drawn
     int64_t *cnt_try;    // [R][8] tallies of the retry being validated
+    int64_t *front;      // [R][P][front_cap] the front pass's lists: compartments that can fall below zero on their own in this try (vgx_tau_front_kernel)
+    unsigned int *front_n;   // [R][P] their counts (may exceed front_cap: the rest is found by the try proper); cleared by vgx_tau_decide_kernel
+    int32_t front_cap, front_on;
     unsigned long long *cnt_pop;   // [R][P][8] the events kernel's share of them per population, folded into cnt_try by vgx_tau_decide_kernel
     int64_t *mev;        // [R][mev_cap][6]  num, type, hap, pop, newHap, newPop (rows with num > 0 only)
     int64_t mev_cap;

@@ -1449,15 +1449,18 @@ static __device__ __forceinline__ uint32_t tau_bucket(const VgxTauArgs &a, const
 //   the susceptible deltas (identical in both), the tentative counters, multievent rows and the list of arrivals.
 // The compartment arrays themselves are not touched, so every thread sees the pre-step state.
 // Returns 2 when the compartment expects a.big_lam (VGX_TAU_BIG / VGX_TAU_BIG_SMALL) events or more (nothing drawn: vgx_tau_draw_big_kernel's case), else 0/1.
-// DRY = true: no bookkeeping at all; ownChk returns the number of mutants that go to haplotype `target` (the same random
+// MODE 1 (DRY): no bookkeeping at all; ownChk returns the number of mutants that go to haplotype `target` (the same random
 // numbers in the same order, so the count is the one the compartment's real draw produces).
-template <bool DRY, int TABS>
+// MODE 2 (CHECK): no bookkeeping either, but ownChk / ownApp are the real draw's (births, migrants and mutants are counted, their
+// targets drawn and dropped): what the front pass of a try needs to know whether the compartment falls below zero on its own.
+template <int MODE, int TABS>
 static __device__ __forceinline__ int tau_cell_events(const VgxTauArgs &a, const TauTabT<TABS> &T, const TauEnv &E, int rep, int pn, int hn, double tau,
                                                       int64_t Icell, uint32_t bucket, int64_t &ownChk, int64_t &ownApp, int64_t *cnt,
                                                       WaveStage *stage, unsigned long long *sS /* LDS [S]: this population's susceptible deltas */,
                                                       int target, int cls = -1 /* the compartment's rate class if the caller has it */,
                                                       long long *prof = nullptr /* diagnostic build: [0] last stamp, [1..5] phases */) {
 #define CEPROF(i) do { if (prof) { const long long t_ = clock64(); prof[i] += t_ - prof[0]; prof[0] = t_; } } while (0)
+    constexpr bool DRY = MODE == 1, CHECK = MODE == 2;
     const VgxDevParams &p = a.p;
     const int P = p.P, S = p.S, H = p.H, sites = p.sites;
     ownChk = 0;
@@ -1499,6 +1502,7 @@ static __device__ __forceinline__ int tau_cell_events(const VgxTauArgs &a, const
             else if (x != 0 && !DRY) {   // transmission to susceptibility group sn (pyx:2515-2520 / 2589-2593)
                 const int sn = kd - 4;
                 births += x;
+                if (CHECK) continue;
                 if (sn < 4) { cnt[8 + sn] -= x; bsn[sn] += (int)x; }
                 else { atomicAdd(&sS[sn], (unsigned long long)(-x)); tau_row(a, rep, x, 0, hn, pn, sn, 0); }
             }
@@ -1537,6 +1541,7 @@ static __device__ __forceinline__ int tau_cell_events(const VgxTauArgs &a, const
             }
             if (sn_hit < 0) continue;
             births += 1;
+            if (CHECK) continue;
             if (sn_hit < 4) { cnt[8 + sn_hit] -= 1; bsn[sn_hit] += 1; }
             else { atomicAdd(&sS[sn_hit], (unsigned long long)(-1ll)); tau_row(a, rep, 1, 0, hn, pn, sn_hit, 0); }
         } else if (u < t4 || r_mig == 0.0) n_mut += 1;
@@ -1578,6 +1583,7 @@ static __device__ __forceinline__ int tau_cell_events(const VgxTauArgs &a, const
         int nh = tau_mutate(sites, hn, ss, ii);
         mut_done += 1;
         if (DRY) { if (nh == target) to_target += 1; continue; }
+        if (CHECK) continue;
         tau_list_add(a, stage, rep, (int64_t)pn * H + nh, 1, false);
         tau_row(a, rep, 1, 3, hn, pn, nh, 0);
     }
@@ -1600,12 +1606,18 @@ static __device__ __forceinline__ int tau_cell_events(const VgxTauArgs &a, const
         int tp = lo / S, ts = lo % S;
         if (tp == pn || !(cdf[nch - 1] > 0.0)) continue;
         migrants += 1;
+        if (CHECK) continue;
         tau_list_add(a, stage, rep, (int64_t)tp * H + hn, 1, true);
         atomicAdd((unsigned long long *)&dS[tp * S + ts], (unsigned long long)(-1ll));
         atomicAdd((unsigned long long *)&a.dTot[(int64_t)rep * P + tp], 1ull);
         tau_row(a, rep, 1, 5, hn, pn, ts, tp);
     }
     CEPROF(4);
+    if (CHECK) {
+        ownChk = births - rec - samp - mut_done + migrants;
+        ownApp = births - rec - samp - mut_done;
+        return 1;
+    }
     cnt[0] += births; cnt[1] += rec; cnt[2] += samp; cnt[3] += mut_done; cnt[5] += migrants;
     for (int sn = 0; sn < 4; ++sn)
         if (bsn[sn]) tau_row(a, rep, bsn[sn], 0, hn, pn, sn, 0);
@@ -1811,6 +1823,7 @@ template <bool C1, bool DENSE>
 __global__ void __launch_bounds__(TB) vgx_tau_scan_fast_kernel(VgxTauArgs a) {
     const int rep = blockIdx.z, pn = blockIdx.y;
     if (!a.active[rep] || a.accepted[rep]) return;
+    if (a.front_on && a.ok[rep] == 0) return;   // the front pass found a failure: the try is lost, nothing of it is needed
     const VgxDevParams &p = a.p;
     const int P = p.P, S = p.S, C = p.C, CB = p.CB, H = p.H;
     __shared__ float s_rt[16];
@@ -1958,6 +1971,120 @@ __global__ void __launch_bounds__(TB) vgx_tau_scan_fast_kernel(VgxTauArgs a) {
     }
 }
 
+// ---- the front pass of a try: the likely failures first -------------------------------------------------------------------
+// A try of the halving loop is rejected as soon as ONE compartment falls below zero on its own and no mutant arrives to rescue it
+// (pyx:2522-2528), and most tries are rejected (three of four at config 4).  A compartment of X hosts can fall below zero only with
+// N >= X + 1 events, i.e. with its first uniform u in the far upper tail: 1 - u < P(N >= X + 1) <= lam^(X+1) / (X+1)!.  The top
+// eight bits of u are the bucket byte of the group's Philox block (see above), so this kernel — the scan's Philox block per 16
+// compartments and nothing else for the 15 of 16 lanes that see no bucket of 255 — finds every compartment that CAN fail that way
+// (lam rounded up, the bound evaluated in single precision with slack: a superset), a few dozen to a few thousand per try, and
+// lists them per population.  vgx_tau_events_kernel<TABS, true> then draws exactly those compartments with the code of the try
+// proper (no bookkeeping) and clears `ok` on a definite failure; the scan and the events kernel of a try whose `ok` is already
+// clear return at once.  What the front pass does not see (a failure with a smaller bucket: large means; compartments drawn kind by
+// kind or channel by channel; the upper bounds) the try finds as before: the pass only ever ends a try early that would have been
+// rejected anyway, results are bit for bit those without it (VGX_TAU_NO_FRONT=1).  grid = (tau_draw_gx(H), P, R); one rate class.
+extern "C" __global__ void __launch_bounds__(TB) vgx_tau_front_kernel(VgxTauArgs a) {
+    const int rep = blockIdx.z, pn = blockIdx.y;
+    if (!a.active[rep] || a.accepted[rep]) return;
+    const VgxDevParams &p = a.p;
+    const int P = p.P, S = p.S, H = p.H;
+    float rt;
+    {   // as in vgx_tau_scan_fast_kernel: the terms of r_all per infected, times tau, rounded up
+        double rtr = 0.0;
+        const double F = a.F[(int64_t)rep * P + pn];
+        const int64_t *Sus = a.S + (int64_t)rep * P * S + (int64_t)pn * S;
+        const int cb = p.c_bidx[0];
+        for (int sn = 0; sn < S; ++sn) rtr += p.cb_b[cb] * p.cb_sigma[cb * S + sn] * (double)Sus[sn] * F;
+        const double rmig = a.has_mig ? a.Gout[((int64_t)rep * P + pn) * p.CB + cb] * p.cb_b[cb] * p.mig[(int64_t)pn * P + pn] : 0.0;
+        const double r1 = rmig + p.c_d[0] + p.c_s[0] * p.sampMult[pn] + (a.mut_uniform ? a.mut_total : p.c_tm[0]) + rtr;
+        rt = (float)(r1 * a.tau[rep] * (1.0 + 1.0 / 1048576.0)) * (1.0f + 1.0f / 1048576.0f);
+    }
+    const int L = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int32_t *Irow = a.I + ((int64_t)rep * P + pn) * H;
+    const uint8_t *I8row = a.I8 + ((int64_t)rep * P + pn) * H;
+    const uint64_t seed = (uint64_t)a.seeds[rep];
+    const uint32_t att = (uint32_t)a.attempt[rep], step = (uint32_t)a.step[rep], retry = (uint32_t)a.retry[rep];
+    const uint32_t key[2] = {(uint32_t)seed ^ (att * 0x9E3779B9u), (uint32_t)(seed >> 32) ^ 0x85EBCA6Bu};
+    const uint32_t ctr_retry = (retry << 20) | 0xFFFFFu;
+    const int tiles = (H + 1023) >> 10;
+    const uint64_t groups = (uint64_t)(H >> 4);
+    unsigned int *fn = a.front_n + (int64_t)rep * P + pn;
+    int64_t *fdst = a.front + ((int64_t)rep * P + pn) * a.front_cap;
+    const int wstride = gridDim.x * (TB / 64);
+    // The compartments with bucket 255 (one in 256) are collected per wavefront in LDS and looked at 64 at a time, one per lane: the
+    // second Philox block and the bound are then paid by full wavefronts, not by the one lane in sixteen that holds such a bucket.
+    __shared__ float s_lf[257];                     // log(n!)
+    __shared__ int32_t s_c[TB / 64][64 + 1024];     // (a tile adds at most 1024)
+    for (int i = threadIdx.x; i < 257; i += TB) s_lf[i] = lgammaf((float)i + 1.0f);
+    __syncthreads();
+    int nq = 0;                                     // wave-uniform
+    auto look = [&](int base, int cnt) {            // `cnt` (<= 64) collected compartments from `base` on, one per lane
+        if (L < cnt) {
+            const int hn = s_c[wave][base + L];
+            int64_t X = I8row[hn];
+            if (X == 255) X = Irow[hn];
+            if (X > 0) {
+                const float lam = rt * (float)X, n = (float)X + 1.0f;
+                bool cand = true;
+                if (lam < 8.0f && X < 256) {   // (beyond: drawn kind by kind or close to it, always listed)
+                    TauRng g;
+                    g.init(seed, att, (uint64_t)pn * (uint64_t)H + (uint64_t)hn, step, retry);
+                    const double u52 = g.uniform();
+                    const float lhs = __logf((float)(1.0 - u52)) - 5.5451775f;          // log(1 - u), rounded down (log 256 = 5.545177444)
+                    const float rhs = n * __logf(lam) - s_lf[(int)X + 1] + 0.01f * n + 0.05f;   // log(lam^n / n!) with slack
+                    // (1 - u within rounding of 0: the inversion's running sum reaches 1.0 in double precision before the exact one would)
+                    cand = lhs <= rhs || (1.0 - u52) < 1e-11;
+                }
+                if (cand) {
+                    const unsigned int slot = atomicAdd(fn, 1u);
+                    if ((int)slot < a.front_cap) fdst[slot] = (int64_t)hn | ((int64_t)255 << 32);
+                }
+            }
+        }
+    };
+    for (int wt = blockIdx.x * (TB / 64) + wave; wt < tiles; wt += wstride) {
+        const int hl = (wt << 10) + 16 * L;
+        uint32_t z[4] = {0, 0, 0, 0};               // bit 8 j + 7 of z[k]: the bucket of compartment hl + 4 k + j is 255
+        if (hl < H) {
+            const uint64_t gidx = (uint64_t)pn * groups + (uint64_t)(hl >> 4);
+            const uint32_t ctr[4] = {(uint32_t)gidx, (uint32_t)(gidx >> 32), step, ctr_retry};
+            uint32_t w[4];
+            vgx_philox4x32(ctr, key, w);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t y = ~w[k];           // a zero byte of y <-> a byte 255 of w (exact per byte)
+                z[k] = ~(((y & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | y | 0x7F7F7F7Fu);
+            }
+        }
+        const int cnt = __popc(z[0]) + __popc(z[1]) + __popc(z[2]) + __popc(z[3]);
+        if (!__any(cnt != 0)) continue;
+        int pre = cnt;                              // inclusive prefix over the lanes
+        for (int o = 1; o < 64; o <<= 1) {
+            const int v = __shfl_up(pre, o);
+            if (L >= o) pre += v;
+        }
+        const int total = __builtin_amdgcn_readlane(pre, 63);
+        int slot = nq + pre - cnt;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            uint32_t m = z[k];
+            while (m) {
+                const int bit = __ffs((int)m) - 1;
+                m &= m - 1;
+                s_c[wave][slot++] = hl + 4 * k + (bit >> 3);
+            }
+        }
+        nq += total;
+        WSYNC();
+        while (nq >= 64) {   // (the last 64 of the stage: nothing has to move)
+            look(nq - 64, 64);
+            nq -= 64;
+        }
+        WSYNC();
+    }
+    if (nq > 0) look(0, nq);
+}
+
 // In-kernel stamps of the events kernel (diagnostic build only, -DVGX_PROFILE; tools/profile_tau_events.py): shader cycles per
 // phase summed over all wavefronts.  [0] prologue, [1] wait for the round's count, [2] draws + bookkeeping, [3] rescue tests,
 // [4] staged list -> global, [5] epilogue, [7..11] inside tau_cell_events (lane 0's stamps: rates + count, split, mutants,
@@ -1984,7 +2111,9 @@ extern "C" int vgx_tau_get_profile(unsigned long long *out, int clear) {
 // rounds of 64 entries in turn (few shards with many entries each — mid-size models — still fill the chip), and a block works
 // through several shards of its population one after the other when there are more shards than the chip holds wavefronts;
 // dSi / dTot / dChkTot are zero on entry.  The shards' counters are cleared by vgx_tau_decide_kernel.
-template <int TABS>
+// FRONT = true: the front pass of a try (see vgx_tau_front_kernel): the same code on the population's short list of likely
+// failures, no bookkeeping (tau_cell_events MODE 2); all it may do is clear `ok`.  grid = (1, P, R).
+template <int TABS, bool FRONT = false>
 __global__ void __launch_bounds__(EB, VGX_EV_WAVES) vgx_tau_events_kernel(VgxTauArgs a) {
     const int rep = blockIdx.z, pn = blockIdx.y;
     if (!a.active[rep] || a.accepted[rep]) return;
@@ -1995,13 +2124,16 @@ __global__ void __launch_bounds__(EB, VGX_EV_WAVES) vgx_tau_events_kernel(VgxTau
 #endif
     const VgxDevParams &p = a.p;
     const int P = p.P, S = p.S, C = p.C, CB = p.CB, H = p.H;
-    const int64_t scap = a.q_cap / a.q_shards;
-    const int split = a.ev_split, sub = (int)(blockIdx.x % split);
+    const int64_t scap = FRONT ? (int64_t)a.front_cap : a.q_cap / a.q_shards;
+    const int split = FRONT ? 1 : a.ev_split, sub = FRONT ? 0 : (int)(blockIdx.x % split);
     // the block's shards of its population's part of the queue: sb0, sb0 + sbstep, ... (its tables, the state of the try and
     // the final sums are set up / added once per block: with one shard per block they were a quarter of a wavefront's life)
-    const int shards_pop = (int)(a.q_shards / P), sb0 = (int)(blockIdx.x / split), sbstep = (int)(gridDim.x / split);
+    const int shards_pop = FRONT ? 1 : (int)(a.q_shards / P), sb0 = FRONT ? 0 : (int)(blockIdx.x / split), sbstep = FRONT ? 1 : (int)(gridDim.x / split);
     const unsigned long long *qn_pop = a.q_n + (int64_t)rep * a.q_shards + (int64_t)pn * shards_pop;
-    {
+    const int64_t front_n = FRONT ? min((int64_t)a.front_n[(int64_t)rep * P + pn], scap) : 0;   // (what did not fit is drawn with the rest)
+    if (FRONT) {
+        if (front_n == 0 || blockIdx.x != 0) return;
+    } else {
         bool any = false;
         for (int sb = sb0; sb < shards_pop; sb += sbstep) any = any || (int64_t)sub * EB < (int64_t)qn_pop[sb];
         if (!any) return;
@@ -2101,7 +2233,7 @@ __global__ void __launch_bounds__(EB, VGX_EV_WAVES) vgx_tau_events_kernel(VgxTau
         if (!shard_open || kc >= n) {   // the next shard of the block with entries for it
             shard_open = false;
             for (sb += sbstep; sb < shards_pop; sb += sbstep) {
-                n = (int64_t)qn_pop[sb];
+                n = FRONT ? front_n : (int64_t)qn_pop[sb];
                 if (kfirst >= n) continue;
                 if (n > scap) {   // the shard overflowed: compartments were lost, the host enlarges the queue and the same try runs again
                     if (threadIdx.x == 0) atomicOr(&a.grow[rep], 8);
@@ -2111,7 +2243,7 @@ __global__ void __launch_bounds__(EB, VGX_EV_WAVES) vgx_tau_events_kernel(VgxTau
                 break;
             }
             if (!shard_open) break;
-            qsrc = a.q + (int64_t)rep * a.q_cap + ((int64_t)pn * shards_pop + sb) * scap;
+            qsrc = FRONT ? a.front + ((int64_t)rep * P + pn) * scap : a.q + (int64_t)rep * a.q_cap + ((int64_t)pn * shards_pop + sb) * scap;
             kc = kfirst;
         }
         // The queue entries of the next VGX_EV_CHUNK rounds and, from them, the compartments' counts (dependent, scattered): two
@@ -2173,10 +2305,13 @@ __global__ void __launch_bounds__(EB, VGX_EV_WAVES) vgx_tau_events_kernel(VgxTau
             const int64_t Ih = (int64_t)I_now;
             int64_t oc = 0, oa = 0;
 #ifdef VGX_PROFILE
-            const int r = tau_cell_events<false, TABS>(a, T, E, rep, pn, h, tau, Ih, (uint32_t)(qe >> 32), oc, oa, cnt, stage, sS, -1, cls_now, pacc + 6);
+            const int r = tau_cell_events<FRONT ? 2 : 0, TABS>(a, T, E, rep, pn, h, tau, Ih, (uint32_t)(qe >> 32) & 255u, oc, oa, cnt, stage, sS, -1, cls_now, pacc + 6);
 #else
-            const int r = tau_cell_events<false, TABS>(a, T, E, rep, pn, h, tau, Ih, (uint32_t)(qe >> 32), oc, oa, cnt, stage, sS, -1, cls_now);
+            const int r = tau_cell_events<FRONT ? 2 : 0, TABS>(a, T, E, rep, pn, h, tau, Ih, (uint32_t)(qe >> 32) & 255u, oc, oa, cnt, stage, sS, -1, cls_now);
 #endif
+            if (FRONT) {
+                if (r == 1) { v = Ih + oc; below = v < 0; }
+            } else {
             isbig = r == 2;   // many events: a group of lanes draws its channels one by one (vgx_tau_draw_big_kernel)
             if (dense) { dCrow[h] = (int32_t)oc; dArow[h] = (int32_t)oa; }
             else if (oa != 0) tau_list_add(a, stage, rep, (int64_t)pn * H + h, oa, true);
@@ -2184,6 +2319,7 @@ __global__ void __launch_bounds__(EB, VGX_EV_WAVES) vgx_tau_events_kernel(VgxTau
                 v = Ih + oc;
                 if (v < 0 && !dense) below = true;
                 else tau_own_check(a, rep, pn, h, v);
+            }
             }
         }
         // A compartment below zero on its own: do the mutants of its neighbours rescue it (pyx:2522-2528 look at the sum)?  Their
@@ -2218,14 +2354,14 @@ __global__ void __launch_bounds__(EB, VGX_EV_WAVES) vgx_tau_events_kernel(VgxTau
                 const int64_t In = (int64_t)Irow[nb];
                 if (In <= 0) continue;
                 int64_t kk = 0, dummy = 0;
-                if (tau_cell_events<true, TABS>(a, T, E, rep, pn, nb, tau, In, tau_bucket(a, E, pn, nb), kk, dummy, cnt, nullptr, nullptr, hs) == 2) open = true;
+                if (tau_cell_events<1, TABS>(a, T, E, rep, pn, nb, tau, In, tau_bucket(a, E, pn, nb), kk, dummy, cnt, nullptr, nullptr, hs) == 2) open = true;
                 arr += kk;
             }
             for (int o = 32; o > 0; o >>= 1) arr += __shfl_down(arr, o);
             arr = bcast_i64(arr, 0);
             open = __any(open);
             if (L == src) {
-                if (open) tau_own_check(a, rep, pn, h, v);
+                if (open) { if (!FRONT) tau_own_check(a, rep, pn, h, v); }   // (front pass: left to the try proper)
                 else if (v + arr < 0) atomicAnd(&a.ok[rep], 0);
             }
         }
@@ -2240,7 +2376,7 @@ __global__ void __launch_bounds__(EB, VGX_EV_WAVES) vgx_tau_events_kernel(VgxTau
     }   // chunks
     // a lost try: nothing of it counts (vgx_tau_decide_kernel discards the tallies, the list and the deltas), so a wavefront that
     // leaves early adds nothing — its atomics on the few shared addresses would be worked off one after the other
-    if (okv == 0) return;
+    if (okv == 0 || FRONT) return;
     tau_stage_flush(a, stage, rep);   // what is left
     // the event counters go to the population's own slots (vgx_tau_decide_kernel folds them): all wavefronts of a launch adding to
     // the same six addresses were worked off one after the other by the memory side, a quarter of an accepted try's kernel time
@@ -2716,8 +2852,11 @@ extern "C" __global__ void __launch_bounds__(64) vgx_tau_decide_kernel(VgxTauArg
     // is applied after this kernel (vgx_tau_apply_kernel) and emptied by vgx_tau_finish_kernel
     if (live && (!accept || !a.sparse))
         for (int i = threadIdx.x; i < a.inc_shards; i += 64) a.inc_n[(int64_t)rep * VGX_INC_SHARDS + i] = 0;
-    if (live)   // the queue of the try has been worked off
+    if (live) {  // the queue of the try has been worked off
         for (int64_t i = threadIdx.x; i < a.q_shards; i += 64) a.q_n[(int64_t)rep * a.q_shards + i] = 0;
+        if (a.front_on)
+            for (int i = threadIdx.x; i < a.p.P; i += 64) a.front_n[(int64_t)rep * a.p.P + i] = 0;
+    }
     if (threadIdx.x != 0) return;
     a.deciding[rep] = 0;
     if (!live) return;
@@ -2928,11 +3067,23 @@ extern "C" __attribute__((visibility("hidden"))) hipError_t vgxi_tau_draw(const 
     const void *evk = tabs == 2 ? (const void *)vgx_tau_events_kernel<2> : tabs == 1 ? (const void *)vgx_tau_events_kernel<1> : (const void *)vgx_tau_events_kernel<0>;
     hipError_t err = hipFuncSetAttribute(evk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds ? lds : 16));
     if (err != hipSuccess) return err;
+    if (a->front_on) {
+        const void *fk = tabs == 2 ? (const void *)vgx_tau_events_kernel<2, true> : tabs == 1 ? (const void *)vgx_tau_events_kernel<1, true> : (const void *)vgx_tau_events_kernel<0, true>;
+        err = hipFuncSetAttribute(fk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds ? lds : 16));
+        if (err != hipSuccess) return err;
+    }
     const dim3 grid(tau_draw_gx(a->p.H), (unsigned)a->p.P, (unsigned)a->R);
     // blocks of the events kernel per (population, replicate): about VGX_EV_BLOCKS in all, each taking its share of the shards
     unsigned egx = (unsigned)((VGX_EV_BLOCKS + (int64_t)a->p.P * a->R * a->ev_split - 1) / ((int64_t)a->p.P * a->R * a->ev_split));
     egx = egx < 1u ? 1u : (egx > tau_draw_gx(a->p.H) ? tau_draw_gx(a->p.H) : egx);
     const dim3 egrid(egx * (unsigned)a->ev_split, (unsigned)a->p.P, (unsigned)a->R);
+    if (a->front_on && a->sparse) {   // the likely failures first (vgx_tau_front_kernel)
+        const dim3 fgrid(1, (unsigned)a->p.P, (unsigned)a->R);
+        hipLaunchKernelGGL(vgx_tau_front_kernel, grid, dim3(TB), 0, s, *a);
+        if (tabs == 2) hipLaunchKernelGGL((vgx_tau_events_kernel<2, true>), fgrid, dim3(EB), lds, s, *a);
+        else if (tabs == 1) hipLaunchKernelGGL((vgx_tau_events_kernel<1, true>), fgrid, dim3(EB), lds, s, *a);
+        else hipLaunchKernelGGL((vgx_tau_events_kernel<0, true>), fgrid, dim3(EB), 16, s, *a);
+    }
     if (a->p.C <= 16 && a->p.CB <= 16 && (a->p.H & 15) == 0) {   // the usual shapes: thresholds tabulated
         const bool c1 = a->p.C == 1, dn = !a->sparse;
         if (c1 && !dn) hipLaunchKernelGGL((vgx_tau_scan_fast_kernel<true, false>), grid, dim3(TB), 0, s, *a);
