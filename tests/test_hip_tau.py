@@ -607,8 +607,9 @@ def test_config4_kernel_instantiations_match_oracle_distribution(oracle_mod):
         assert abs(s1 ** 2 - s2 ** 2) <= tolv, "%s: variances %.6g vs %.6g (tolerance %.3g)" % (what, s1 ** 2, s2 ** 2, tolv)
 
 
-def _filled(sites, P, S, seed, fill, migration=True):
-    """A model whose compartments are written straight into the arrays (``fill(rng, shape) -> counts``)."""
+def _filled(sites, P, S, seed, fill, migration=True, classes=1):
+    """A model whose compartments are written straight into the arrays (``fill(rng, shape) -> counts``); classes = 3: two
+    haplotypes with rates of their own (three rate classes)."""
     from vgsim_amd import Simulator
     with helpers.quiet():
         s = Simulator(number_of_sites=sites, populations_number=P, number_of_susceptible_groups=S, seed=seed)
@@ -617,6 +618,8 @@ def _filled(sites, P, S, seed, fill, migration=True):
         s.set_total_migration_probability(0.01)
     if S > 1:
         s.set_susceptibility_type(1); s.set_susceptibility(0.3, susceptibility_type=1); s.set_immunity_transition(0.02, source=1, target=0)
+    if classes == 3:
+        s.set_transmission_rate(3.1, haplotype=5); s.set_recovery_rate(0.5, haplotype=9)
     s.set_population_size(10 ** 8)
     m = s.simulation
     m.infectious[:] = fill(np.random.default_rng(seed), m.infectious.shape)
@@ -669,8 +672,9 @@ def test_byte_drift_pass_equals_the_two_pass_form(monkeypatch, sites, P, S, fill
     assert a.bCounter > 0
 
 
-@pytest.mark.parametrize("sites,P,S,fill", [(8, 3, 2, _fill_saturated), (9, 3, 1, _fill_small), (7, 4, 1, _fill_small), (10, 2, 1, _fill_small)])
-def test_front_pass_only_ends_lost_tries_early(monkeypatch, sites, P, S, fill):
+@pytest.mark.parametrize("sites,P,S,fill,classes", [(8, 3, 2, _fill_saturated, 1), (9, 3, 1, _fill_small, 1), (7, 4, 1, _fill_small, 1), (10, 2, 1, _fill_small, 1),
+                                                    (7, 4, 2, _fill_small, 3), (8, 2, 1, _fill_saturated, 3)])
+def test_front_pass_only_ends_lost_tries_early(monkeypatch, sites, P, S, fill, classes):
     """The front pass of a try (vgx_tau_front_kernel + vgx_tau_events_kernel<., true>: the compartments that can fall below zero on
     their own, drawn first and without bookkeeping) may only end a try early that the try proper would have rejected: eight leaps
     with it and without it (VGX_TAU_NO_FRONT=1) are the same leaps — same number of tries (the sieve's and the loop's), same times,
@@ -680,7 +684,7 @@ def test_front_pass_only_ends_lost_tries_early(monkeypatch, sites, P, S, fill):
             monkeypatch.setenv("VGX_TAU_NO_FRONT", "1")
         else:
             monkeypatch.delenv("VGX_TAU_NO_FRONT", raising=False)
-        s = _filled(sites, P, S, 700 + sites, fill, True)
+        s = _filled(sites, P, S, 700 + sites, fill, True, classes=classes)
         with helpers.quiet():
             s.simulate(8, sample_size=10 ** 12, method="tau", record_multievents=False)
         return s.simulation

@@ -1497,10 +1497,10 @@ extern "C" int vgx_simulate_tau(vgx_engine *e, int64_t iterations, int64_t sampl
     a.colT = (double *)e->t_colT.p; a.colTW = (double *)e->t_colTW.p;
     a.inc = (int64_t *)e->t_inc.p; a.inc_cap = inc_cap; a.inc_shards = vgxi_tau_inc_shards(H, P); a.inc_n = (unsigned long long *)e->t_incn.p;
     a.counters = (int64_t *)e->t_counters.p; a.cnt_try = (int64_t *)e->t_cnttry.p; a.cnt_pop = (unsigned long long *)e->t_cntpop.p;
-    {   // the front pass of a try (vgx_tau_front_kernel): one rate class, the tabulated scan's shapes, sparse mode
+    {   // the front pass of a try (vgx_tau_front_kernel): the tabulated scan's shapes, sparse mode
         const char *nf = getenv("VGX_TAU_NO_FRONT");
         a.front_cap = 512;
-        a.front_on = (sparse_default && e->C == 1 && e->CB <= 16 && (H & 15) == 0 && !(nf && nf[0] == '1')) ? 1 : 0;
+        a.front_on = (sparse_default && e->C <= 16 && e->CB <= 16 && (H & 15) == 0 && !(nf && nf[0] == '1')) ? 1 : 0;
         int rcf = ensure(e, e->t_front, (size_t)(R * P) * (size_t)a.front_cap * 8);
         if (!rcf) rcf = ensure(e, e->t_frontn, (size_t)(R * P) * 4 + 64);
         if (rcf) return rcf;

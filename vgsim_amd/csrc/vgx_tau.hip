@@ -1982,22 +1982,32 @@ __global__ void __launch_bounds__(TB) vgx_tau_scan_fast_kernel(VgxTauArgs a) {
 // proper (no bookkeeping) and clears `ok` on a definite failure; the scan and the events kernel of a try whose `ok` is already
 // clear return at once.  What the front pass does not see (a failure with a smaller bucket: large means; compartments drawn kind by
 // kind or channel by channel; the upper bounds) the try finds as before: the pass only ever ends a try early that would have been
-// rejected anyway, results are bit for bit those without it (VGX_TAU_NO_FRONT=1).  grid = (tau_draw_gx(H), P, R); one rate class.
+// rejected anyway, results are bit for bit those without it (VGX_TAU_NO_FRONT=1).  grid = (tau_draw_gx(H), P, R); the tabulated scan's shapes
+// (at most 16 rate classes).
 extern "C" __global__ void __launch_bounds__(TB) vgx_tau_front_kernel(VgxTauArgs a) {
     const int rep = blockIdx.z, pn = blockIdx.y;
     if (!a.active[rep] || a.accepted[rep]) return;
     const VgxDevParams &p = a.p;
     const int P = p.P, S = p.S, H = p.H;
-    float rt;
-    {   // as in vgx_tau_scan_fast_kernel: the terms of r_all per infected, times tau, rounded up
-        double rtr = 0.0;
+    const int C = p.C, CB = p.CB;
+    __shared__ float s_rt[16];
+    __shared__ double s_rtr[16], s_rmig[16];
+    {   // as in vgx_tau_scan_fast_kernel: the terms of r_all per infected and class, times tau, rounded up
         const double F = a.F[(int64_t)rep * P + pn];
         const int64_t *Sus = a.S + (int64_t)rep * P * S + (int64_t)pn * S;
-        const int cb = p.c_bidx[0];
-        for (int sn = 0; sn < S; ++sn) rtr += p.cb_b[cb] * p.cb_sigma[cb * S + sn] * (double)Sus[sn] * F;
-        const double rmig = a.has_mig ? a.Gout[((int64_t)rep * P + pn) * p.CB + cb] * p.cb_b[cb] * p.mig[(int64_t)pn * P + pn] : 0.0;
-        const double r1 = rmig + p.c_d[0] + p.c_s[0] * p.sampMult[pn] + (a.mut_uniform ? a.mut_total : p.c_tm[0]) + rtr;
-        rt = (float)(r1 * a.tau[rep] * (1.0 + 1.0 / 1048576.0)) * (1.0f + 1.0f / 1048576.0f);
+        for (int cb = threadIdx.x; cb < CB && cb < 16; cb += TB) {
+            double r = 0.0;
+            for (int sn = 0; sn < S; ++sn) r += p.cb_b[cb] * p.cb_sigma[cb * S + sn] * (double)Sus[sn] * F;
+            s_rtr[cb] = r;
+            s_rmig[cb] = a.has_mig ? a.Gout[((int64_t)rep * P + pn) * CB + cb] * p.cb_b[cb] * p.mig[(int64_t)pn * P + pn] : 0.0;
+        }
+        __syncthreads();
+        const double tau = a.tau[rep];
+        for (int i = threadIdx.x; i < C && i < 16; i += TB) {
+            const int cb = p.c_bidx[i];
+            const double r1 = s_rmig[cb] + p.c_d[i] + p.c_s[i] * p.sampMult[pn] + (a.mut_uniform ? a.mut_total : p.c_tm[i]) + s_rtr[cb];
+            s_rt[i] = (float)(r1 * tau * (1.0 + 1.0 / 1048576.0)) * (1.0f + 1.0f / 1048576.0f);
+        }
     }
     const int L = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int32_t *Irow = a.I + ((int64_t)rep * P + pn) * H;
@@ -2024,7 +2034,7 @@ extern "C" __global__ void __launch_bounds__(TB) vgx_tau_front_kernel(VgxTauArgs
             int64_t X = I8row[hn];
             if (X == 255) X = Irow[hn];
             if (X > 0) {
-                const float lam = rt * (float)X, n = (float)X + 1.0f;
+                const float lam = s_rt[C == 1 ? 0 : p.cls[hn]] * (float)X, n = (float)X + 1.0f;
                 bool cand = true;
                 if (lam < 8.0f && X < 256) {   // (beyond: drawn kind by kind or close to it, always listed)
                     TauRng g;
