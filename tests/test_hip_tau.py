@@ -696,6 +696,47 @@ def test_front_pass_only_ends_lost_tries_early(monkeypatch, sites, P, S, fill, c
         assert getattr(a, k) == getattr(b, k), k
 
 
+def _fill_sparse(rng, shape):          # 1 % of the compartments occupied: mostly a few hosts, some hundreds, a few far beyond a byte
+    a = np.zeros(shape, dtype=np.int64)
+    n = a.size // 100
+    idx = rng.choice(a.size, size=n, replace=False)
+    a.reshape(-1)[idx] = rng.choice([1, 1, 2, 3, 5, 40, 254, 255, 300, 5000], size=n)
+    return a
+
+
+def _fill_one_region(rng, shape):      # sparse overall, but 8192 occupied compartments in ONE region of the lists (capacity 1024)
+    a = np.zeros(shape, dtype=np.int64)
+    h = np.arange(65536)
+    a[0, h[(h % 2048) < 256]] = rng.integers(1, 6, size=8192)
+    a[1, rng.choice(shape[1], size=500, replace=False)] = 3
+    return a
+
+
+@pytest.mark.parametrize("sites,P,S,fill", [(8, 3, 2, _fill_sparse), (9, 2, 1, _fill_sparse), (10, 2, 1, _fill_sparse), (7, 4, 1, _fill_sparse),
+                                             (9, 2, 1, _fill_one_region)])
+def test_tries_over_the_lists_of_occupied_compartments(monkeypatch, sites, P, S, fill):
+    """Sparse states: the drift pass lists the occupied compartments and a try's scan and front pass go over the lists
+    (vgx_tau_listscan_kernel) instead of streaming all P x H compartments.  Same buckets, same thresholds: eight leaps with the lists
+    and without them (VGX_TAU_NO_OCCLIST=1) are the same leaps.  `_fill_one_region` puts 8192 occupied compartments into one region of the lists
+    (capacity 1024): that region is swept compartment by compartment, and the run is still the same."""
+    def run(off):
+        if off:
+            monkeypatch.setenv("VGX_TAU_NO_OCCLIST", "1")
+        else:
+            monkeypatch.delenv("VGX_TAU_NO_OCCLIST", raising=False)
+        s = _filled(sites, P, S, 900 + sites, fill, True)
+        with helpers.quiet():
+            s.simulate(8, sample_size=10 ** 12, method="tau", record_multievents=False)
+        return s.simulation
+    a, b = run(False), run(True)
+    assert a.events.ptr == b.events.ptr == 16
+    assert np.array_equal(a.events.times[:16], b.events.times[:16])
+    assert np.array_equal(a.infectious, b.infectious) and np.array_equal(a.susceptible, b.susceptible)
+    for k in a.COUNTERS:
+        assert getattr(a, k) == getattr(b, k), k
+    assert a.bCounter > 0
+
+
 @pytest.mark.parametrize("sites,P,S", [(8, 3, 2), (2, 3, 1)])
 def test_staged_start_state_gives_the_same_run(sites, P, S):
     """vgx_stage_tau (snapshot, conversion and upload of the start state ahead of the call: the bench's hand-over) against

@@ -4,7 +4,7 @@ cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/prof_tau/trace
 rm -rf $O; mkdir -p $O
-rocprofv3 --kernel-trace --output-format csv -d $O -- python3 tools/probe_tau_wall.py 20 > $O.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $O -- python3 ${PROBE:-tools/probe_tau_wall.py 20} > $O.log 2>&1
 f=$(find $O -name "*kernel_trace.csv" | head -1)
 python3 - "$f" <<'PY'
 import csv, sys
@@ -17,16 +17,17 @@ for r in rows:
     dur = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
     gap = 0.0 if t_prev is None else (int(r["Start_Timestamp"]) - t_prev) / 1e3
     t_prev = int(r["End_Timestamp"])
-    k = "S" if "scan_fast" in n else "E" if "events_kernel" in n else short.get(n)
+    k = "L" if "listscan" in n else "S" if "scan_fast" in n else "E" if "events_kernel" in n else "f" if "front_kernel" in n else short.get(n)
     if k is None:
         k = "."
     out.append((k, dur, gap, n))
 # the last call's steps only
 idx = [i for i, o in enumerate(out) if o[0] == "F"]
-start = idx[-21] + 1 if len(idx) > 21 else 0
+NLAST = int(__import__("os").environ.get("NLAST", "20"))
+start = idx[-NLAST - 1] + 1 if len(idx) > NLAST else 0
 line = []
 for k, dur, gap, n in out[start:]:
-    if k in "SEAYD":
+    if k in "SEAYDfL":
         line.append("%s%.0f" % (k, dur))
     if k == "F":
         print(" ".join(line)); line = []

@@ -101,7 +101,7 @@ struct vgx_engine {
         r_evrate, r_evcols, r_locrec, r_loctime, r_lociter, r_farate, r_fakey, r_traj, r_prof, r_qeff, r_qmebm, r_qflag;
     // tau-leaping (dense compartments)
     DevBuf t_I, t_S, t_dChk, t_dApp, t_dSi, t_dTot, t_totInf, t_gI, t_cd, t_lock, t_F, t_eff, t_Aeff, t_Gout, t_dS,
-        t_taubits, t_tau, t_time, t_flags, t_counters, t_cnttry, t_cntpop, t_front, t_frontn, t_mev, t_mevn, t_mevbase, t_locn, t_mutcum, t_migcdf, t_migIn, t_mutHi, t_colT, t_colTW, t_inc, t_incn, t_sieve, t_sieveskip, t_big, t_bign, t_res, t_susp, t_suspn, t_stkey, t_stval, t_dChkTot, t_q, t_qn, t_hist, t_I8, t_dSpart, t_tmax8, t_iI, t_iS, t_slog, t_sres;
+        t_taubits, t_tau, t_time, t_flags, t_counters, t_cnttry, t_cntpop, t_front, t_frontn, t_occ, t_occn, t_occpop, t_mev, t_mevn, t_mevbase, t_locn, t_mutcum, t_migcdf, t_migIn, t_mutHi, t_colT, t_colTW, t_inc, t_incn, t_sieve, t_sieveskip, t_big, t_bign, t_res, t_susp, t_suspn, t_stkey, t_stval, t_dChkTot, t_q, t_qn, t_hist, t_I8, t_dSpart, t_tmax8, t_iI, t_iS, t_slog, t_sres;
     std::vector<int64_t> tau_sieve_skipped;   // [R] tries left out by the sieve in the last tau call
     bool last_was_tau = false;
     bool tau_staged = false;              // vgx_stage_tau put the current start state on the device in the tau kernels' layout
@@ -1552,6 +1552,15 @@ extern "C" int vgx_simulate_tau(vgx_engine *e, int64_t iterations, int64_t sampl
             if (rc8) return rc8;
             a.tmax8 = (unsigned int *)e->t_tmax8.p;
         }
+        if (a.use8) {   // lists of the occupied compartments for sparse states (vgx_tau_listscan_kernel), filled by the drift pass
+            a.occ_nreg = a.nt8 * VGX_D8_WAVES;
+            int rco = ensure(e, e->t_occ, (size_t)(R * P) * (size_t)a.occ_nreg * VGX_OCC_CAP * 4);
+            if (!rco) rco = ensure(e, e->t_occn, (size_t)(R * P) * (size_t)a.occ_nreg * 4 + 64);
+            if (!rco) rco = ensure(e, e->t_occpop, (size_t)(R * P) * 8 + 64);
+            if (rco) return rco;
+            HIPCHECK(e, hipMemset(e->t_occpop.p, 0, (size_t)(R * P) * 8));
+            a.occ = (int32_t *)e->t_occ.p; a.occ_n = (unsigned int *)e->t_occn.p; a.occ_pop = (unsigned long long *)e->t_occpop.p;
+        }
         a.hist = nullptr;
         if (flat && a.sieve_on && e->C <= 8) {   // (VGX_HIST_CMAX classes x 64 sizes per population)
             int rch = ensure(e, e->t_hist, (size_t)(R * P * e->C * 64) * 4);
@@ -1592,6 +1601,13 @@ extern "C" int vgx_simulate_tau(vgx_engine *e, int64_t iterations, int64_t sampl
     const bool has_tl = !(time == -1.0f);
     auto sC_of = [&](int64_t r) { return cnt0[(size_t)r][2] + cnt[(size_t)r * 8 + 2]; };
     int64_t guard = 0;
+    // occupied-compartment lists (sparse states): possible with the byte drift pass and the front pass; the estimate is the count of the
+    // uploaded state, then what the drift pass of the last step counted (the largest replicate)
+    const char *nol = getenv("VGX_TAU_NO_OCCLIST");
+    const bool occ_lists_ok = a.use8 && a.front_on && a.occ != nullptr && !(nol && nol[0] == '1');
+    const bool occ_lists_banned = false;
+    int64_t occ_est = occupied;
+    int64_t tries_total = 0, tries_lists = 0;
     bool i8_dirty = true;    // I8 does not mirror I (start of the call, after a Restart's upload, after a dense try)
     // Small models: the whole step loop on the device, one workgroup per replicate (vgx_taus.hip).  VGX_TAU_STEP_KERNELS=1 and the
     // test switches of the step kernels (dense validation modes, the large-model draw thresholds) keep the step kernels.
@@ -1695,6 +1711,7 @@ extern "C" int vgx_simulate_tau(vgx_engine *e, int64_t iterations, int64_t sampl
                 rc = tau_upload_state(e, r, h.initial_infectious, h.initial_susceptible);
                 if (rc) return rc;
                 i8_dirty = true;
+                occ_est = occupied;   // (the start state again)
                 {   // the lockdown records of the failed attempt stay (Restart does not clear `loc`); then CheckLockdown for
                     // every population on the restored totals at time 0 (pyx:736-737), whose switches change the contact
                     // densities the next attempt starts with
@@ -1784,6 +1801,9 @@ extern "C" int vgx_simulate_tau(vgx_engine *e, int64_t iterations, int64_t sampl
             i8_dirty = false;
             launches += 1;
         }
+        // a sparse state (at most 1/32 of the compartments occupied when the last step began): the drift pass lists the occupied
+        // compartments and the tries' scan and front pass go over the lists
+        a.build_occ = a.use_list = (occ_lists_ok && !occ_lists_banned && occ_est >= 0 && occ_est * 32 <= P * H) ? 1 : 0;
         HIPCHECK(e, vgxi_tau_eff(&a, e->stream));
         HIPCHECK(e, vgxi_tau_prep(&a, e->stream));
         HIPCHECK(e, vgxi_tau_drift(&a, e->stream));
@@ -1803,6 +1823,8 @@ extern "C" int vgx_simulate_tau(vgx_engine *e, int64_t iterations, int64_t sampl
                 HIPCHECK(e, hipMemsetAsync(e->t_stkey.p, 0, (size_t)(R * st_size) * 8, e->stream));
                 a.gen = 1;
             }
+            tries_total += 1;
+            if (a.use_list && a.front_on && a.sparse) tries_lists += 1;
             HIPCHECK(e, vgxi_tau_draw(&a, e->stream));
             HIPCHECK(e, vgxi_tau_draw_big(&a, e->stream));   // (+ the immunity transitions: extra blocks of the same launch)
             if (a.sparse) {
@@ -1904,6 +1926,7 @@ extern "C" int vgx_simulate_tau(vgx_engine *e, int64_t iterations, int64_t sampl
         tau_h.resize((size_t)R);
         err_h.resize((size_t)R);
         std::vector<int64_t> gI_d((size_t)R), res_h((size_t)R * 16);
+        int64_t occ_step = -1;
         std::vector<unsigned long long> mevb((size_t)R);
         HIPCHECK(e, hipMemcpy(res_h.data(), a.res, (size_t)R * 16 * 8, hipMemcpyDeviceToHost));   // packed by the finish kernel
         for (int64_t r = 0; r < R; r++) {
@@ -1915,7 +1938,9 @@ extern "C" int vgx_simulate_tau(vgx_engine *e, int64_t iterations, int64_t sampl
             mevb[(size_t)r] = (unsigned long long)o[10];
             mevn[(size_t)r] = (unsigned long long)o[11];
             err_h[(size_t)r] = (int32_t)o[12];
+            if (o[13] >= 0) occ_step = std::max<int64_t>(occ_step, o[13]);
         }
+        if (occ_step >= 0) occ_est = occ_step;
         for (int64_t r = 0; r < R; r++) {
             if (!running[(size_t)r]) continue;
             if (err_h[(size_t)r] == VGX_ERR_CAPACITY) return fail(e, VGX_ERR_CAPACITY, "vgx_simulate_tau: replicate " + std::to_string(r) + ": list of cross-compartment events full");
@@ -1937,6 +1962,8 @@ extern "C" int vgx_simulate_tau(vgx_engine *e, int64_t iterations, int64_t sampl
     }
 
     lap("step loop");
+    if (timing) fprintf(stderr, "vgx_simulate_tau: %lld tries, %lld of them over the lists of occupied compartments%s\n", (long long)tries_total,
+                        (long long)tries_lists, "");
     // ---- results ----
     std::vector<unsigned long long> locn((size_t)R);
     HIPCHECK(e, hipMemcpy(locn.data(), a.loc_n, (size_t)R * 8, hipMemcpyDeviceToHost));

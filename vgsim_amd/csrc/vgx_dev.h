@@ -22,6 +22,8 @@
 #define VGX_FA_CAP 2048         // (rate, iteration) pairs kept per replicate for failed attempts that switched a lockdown
 #define VGX_TAU_BIG 64.0         // tau: expected events of a compartment per leap from which every channel is drawn on its own
 #define VGX_TAU_BIG_SMALL 16.0   // ... on models with few compartments (the wavefront's slowest lane sets the step time there)
+#define VGX_D8_WAVES 8           // wavefronts of a block of vgx_tau_drift8_kernel (= regions of the occupied-compartment lists per tile)
+#define VGX_OCC_CAP 1024         // entries of a region of the occupied-compartment lists (a region covers 8192 compartments from eight sites on)
 #define VGX_TAU_KINDS 16.0       // ... and from which a lane draws one Poisson number per KIND of event instead of walking through the events
 #define VGX_PROF_SLOTS 16       // in-kernel phase stamps of the diagnostic (-DVGX_PROFILE) build
 
@@ -218,6 +220,12 @@ struct VgxTauArgs {
     double *migcdf;          // [R][P][CB][P*S] running sums of the out-migration channel weights
     int64_t *counters;   // [R][8]: births, recoveries, samples, mutations, immunity, migrations, lockdown switches, events drawn
     int64_t *cnt_try;    // [R][8] tallies of the retry being validated
+    // Occupied compartments (sparse states; vgx_tau_drift8_kernel lists them while it streams the bytes, vgx_tau_listscan_kernel draws a
+    // try's buckets for them instead of streaming all P x H compartments).  One region per (population, tile of the drift pass, wavefront).
+    int32_t *occ;            // [R][P][occ_nreg][VGX_OCC_CAP] haplotype numbers
+    unsigned int *occ_n;     // [R][P][occ_nreg] occupied compartments per region (beyond VGX_OCC_CAP the list is incomplete: the region is swept)
+    unsigned long long *occ_pop;   // [R][P] occupied compartments of the population as the drift pass saw them (summed and cleared by the finish kernel)
+    int32_t occ_nreg, build_occ, use_list, occ_pad;
     int64_t *front;      // [R][P][front_cap] the front pass's lists: compartments that can fall below zero on their own in this try (vgx_tau_front_kernel)
     unsigned int *front_n;   // [R][P] their counts (may exceed front_cap: the rest is found by the try proper); cleared by vgx_tau_decide_kernel
     int32_t front_cap, front_on;

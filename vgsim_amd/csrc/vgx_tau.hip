@@ -806,6 +806,7 @@ __global__ void __launch_bounds__(TB) vgx_tau_drift_fast_kernel(VgxTauArgs a) {
 // a 255 test every byte they add, and a wavefront that meets one forms its compartments' sums again from the 4-byte counts.
 #define VGX_D8_LOW 8
 #define D8_TB 512       // two blocks per CU (2 x 77 KB of LDS, 16 wavefronts); one block of 1024 threads: 1.8 instead of 2.4 GB fetched per launch, but 0.64 instead of 0.50 ms (a block's load phase is not covered by another block's compute phase)
+static_assert(D8_TB / 64 == VGX_D8_WAVES, "regions of the occupied-compartment lists");
 static __device__ __forceinline__ uint32_t d8_even(uint32_t x) { return __builtin_amdgcn_perm(0u, x, 0x0C020C00u); }   // bytes 0, 2 -> 16-bit lanes
 static __device__ __forceinline__ uint32_t d8_odd(uint32_t x) { return __builtin_amdgcn_perm(0u, x, 0x0C030C01u); }    // bytes 1, 3
 static __device__ __forceinline__ uint32_t d8_sat(uint32_t x) { return ((x & 0x7F7F7F7Fu) + 0x01010101u) & x & 0x80808080u; }   // some byte == 255
@@ -889,12 +890,31 @@ struct D8Ctx {
     bool use_col, use_tw, do_hist, one_rate;
     double kI, rate_lo, rate_hi, Bsum, c1, c2;
     unsigned int *hist;
+    int32_t *occ_dst;      // this wavefront's region of the occupied-compartment lists, or null
 };
 template <int MODE>
-static __device__ __forceinline__ void d8_cells(const D8Ctx &c, int lane, double &cand_min, double &ad_max, long long &sumI, double &sumMg) {
+static __device__ __forceinline__ void d8_cells(const D8Ctx &c, int lane, double &cand_min, double &ad_max, long long &sumI, double &sumMg,
+                                                int &occ_cnt) {
     for (int q = threadIdx.x; q < c.TSd; q += D8_TB) {
         const int h = (c.tl << (2 * c.low)) + 4 * q;          // first of the thread's four haplotypes
         const uint32_t own = c.tile32[q];
+        if (c.occ_dst) {       // (wave-uniform) the occupied compartments among the wavefront's 256: listed, region by region
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool nz = ((own >> (8 * j)) & 255u) != 0u;
+                const unsigned long long m = __ballot(nz);
+                if (m == 0ull) continue;
+                if (nz) {
+                    const int pos = occ_cnt + (int)__popcll(m & ((1ull << lane) - 1ull));
+                    if (pos < VGX_OCC_CAP) c.occ_dst[pos] = h + j;
+                }
+                occ_cnt += (int)__popcll(m);
+            }
+        } else {               // only counted (what decides whether the next step builds the lists)
+            const uint32_t y = own;
+            const uint32_t zf = ~(((y & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | y | 0x7F7F7F7Fu);   // bit 8 j + 7: byte j is zero
+            occ_cnt += 4 - __popc(zf);
+        }
         uint32_t loE = 0, loO = 0, hiE = 0, hiO = 0, bad = MODE == 2 ? d8_sat(own) : 0u;
         uint32_t hv[6];     // the neighbours through the sites above the tile (other tiles of the row), issued first
 #pragma unroll
@@ -1043,9 +1063,18 @@ extern "C" __global__ void __launch_bounds__(D8_TB) vgx_tau_drift8_kernel(VgxTau
     c.hist = hist;
     double cand_min = 1.0, ad_max = 0.0, sumMg = 0.0;
     long long sumI = 0;
-    if (mx <= 66u) d8_cells<0>(c, lane, cand_min, ad_max, sumI, sumMg);
-    else if (mx < 255u) d8_cells<1>(c, lane, cand_min, ad_max, sumI, sumMg);
-    else d8_cells<2>(c, lane, cand_min, ad_max, sumI, sumMg);
+    int occ_cnt = 0;       // listing: wave-uniform, entries of this wavefront's region; counting: the lane's occupied compartments
+    const int64_t region = ((int64_t)rep * P + pn) * a.occ_nreg + (int64_t)tl * (D8_TB / 64) + wv;
+    c.occ_dst = a.build_occ ? a.occ + region * VGX_OCC_CAP : nullptr;
+    if (mx <= 66u) d8_cells<0>(c, lane, cand_min, ad_max, sumI, sumMg, occ_cnt);
+    else if (mx < 255u) d8_cells<1>(c, lane, cand_min, ad_max, sumI, sumMg, occ_cnt);
+    else d8_cells<2>(c, lane, cand_min, ad_max, sumI, sumMg, occ_cnt);
+    {
+        int tot = occ_cnt;
+        if (a.build_occ) { if (lane == 0) a.occ_n[region] = (unsigned int)occ_cnt; }
+        else for (int o = 32; o > 0; o >>= 1) tot += __shfl_down(tot, o);
+        if (lane == 0 && tot != 0) atomicAdd(&a.occ_pop[(int64_t)rep * P + pn], (unsigned long long)tot);
+    }
     // the block's sums of Ih and of c1 T + c2 TW (wavefronts in a fixed order: reproducible), from which the susceptible drift
     {
         double vI = (double)sumI, vM = sumMg;
@@ -2095,6 +2124,146 @@ extern "C" __global__ void __launch_bounds__(TB) vgx_tau_front_kernel(VgxTauArgs
     if (nq > 0) look(0, nq);
 }
 
+// ---- sparse states: the scan and the front pass of a try over the LIST of occupied compartments ------------------------------------
+// At natural occupancy (an epidemic grown from an index case: 0.65 % of config 4's compartments hold a host after SURVEY 8(d)'s
+// warm-up) the two passes above draw a Philox block for every group of 16 compartments to find out that almost all of them are empty.
+// vgx_tau_drift8_kernel, which streams every byte once per step anyway, lists the occupied compartments (one region per population,
+// tile and wavefront: no atomics), and this kernel makes the same decisions for the listed compartments only: the compartment's
+// bucket (byte hn & 15 of its group's block — the block of vgx_tau_scan_fast_kernel), queued iff bucket >= T[class][X] (the same
+// table), and for a bucket of 255 the front pass's bound (vgx_tau_front_kernel).  Same queue entries, same front lists, another
+// order.  A region with more occupied compartments than its list holds (VGX_OCC_CAP of 8192: the neighbourhood of a large lineage)
+// is swept compartment by compartment instead.
+// grid = (tau_draw_gx(H), P, R); the blocks' shards of the queue as in the scan.
+extern "C" __global__ void __launch_bounds__(TB) vgx_tau_listscan_kernel(VgxTauArgs a) {
+    const int rep = blockIdx.z, pn = blockIdx.y;
+    if (!a.active[rep] || a.accepted[rep]) return;
+    const VgxDevParams &p = a.p;
+    const int P = p.P, S = p.S, C = p.C, CB = p.CB, H = p.H;
+    __shared__ float s_rt[16], s_lf[257];
+    __shared__ double s_rtr[16], s_rmig[16];
+    __shared__ uint16_t s_thr[16 * 256];
+    __shared__ int64_t q[TB / 64][256];
+    {
+        const double tau = a.tau[rep];
+        const double F = a.F[(int64_t)rep * P + pn];
+        const int64_t *Sus = a.S + (int64_t)rep * P * S + (int64_t)pn * S;
+        for (int cb = threadIdx.x; cb < CB && cb < 16; cb += TB) {
+            double r = 0.0;
+            for (int sn = 0; sn < S; ++sn) r += p.cb_b[cb] * p.cb_sigma[cb * S + sn] * (double)Sus[sn] * F;
+            s_rtr[cb] = r;
+            s_rmig[cb] = a.has_mig ? a.Gout[((int64_t)rep * P + pn) * CB + cb] * p.cb_b[cb] * p.mig[(int64_t)pn * P + pn] : 0.0;
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < C && i < 16; i += TB) {   // as in vgx_tau_scan_fast_kernel
+            const int cb = p.c_bidx[i];
+            const double r1 = s_rmig[cb] + p.c_d[i] + p.c_s[i] * p.sampMult[pn] + (a.mut_uniform ? a.mut_total : p.c_tm[i]) + s_rtr[cb];
+            s_rt[i] = (float)(r1 * tau * (1.0 + 1.0 / 1048576.0)) * (1.0f + 1.0f / 1048576.0f);
+        }
+        for (int i = threadIdx.x; i < 257; i += TB) s_lf[i] = lgammaf((float)i + 1.0f);
+        __syncthreads();
+        for (int i = threadIdx.x; i < C * 256 && i < 16 * 256; i += TB) {
+            const int X = i & 255;
+            const float thr = fmaf(-256.0f, s_rt[i >> 8] * (float)X, 255.999f);
+            s_thr[i] = X == 0 ? (uint16_t)256 : (uint16_t)(thr < 0.0f ? 0 : (int)floorf(thr));
+        }
+        __syncthreads();
+    }
+    const int L = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int32_t *Irow = a.I + ((int64_t)rep * P + pn) * H;
+    const uint8_t *I8row = a.I8 + ((int64_t)rep * P + pn) * H;
+    const uint64_t seed = (uint64_t)a.seeds[rep];
+    const uint32_t att = (uint32_t)a.attempt[rep], step = (uint32_t)a.step[rep], retry = (uint32_t)a.retry[rep];
+    const uint32_t key[2] = {(uint32_t)seed ^ (att * 0x9E3779B9u), (uint32_t)(seed >> 32) ^ 0x85EBCA6Bu};
+    const uint32_t ctr_retry = (retry << 20) | 0xFFFFFu;
+    const uint64_t groups = (uint64_t)(H >> 4);
+    const int64_t scap = a.q_cap / a.q_shards;
+    const int64_t shard = (int64_t)pn * gridDim.x + blockIdx.x;
+    unsigned long long *qn = a.q_n + (int64_t)rep * a.q_shards + shard;
+    int64_t *qdst = a.q + (int64_t)rep * a.q_cap + shard * scap;
+    unsigned int *fn = a.front_n + (int64_t)rep * P + pn;
+    int64_t *fdst = a.front + ((int64_t)rep * P + pn) * a.front_cap;
+    int nq = 0;                      // wave-uniform: entries in this wavefront's stage
+    auto flush = [&]() {
+        WSYNC();
+        unsigned long long base = 0;
+        if (L == 0) base = atomicAdd(qn, (unsigned long long)nq);
+        base = (unsigned long long)bcast_i64((int64_t)base, 0);
+        for (int i = L; i < nq; i += 64)
+            if ((int64_t)(base + i) < scap) qdst[base + i] = q[wave][i];   // a full shard is detected by the events kernel
+        WSYNC();
+        nq = 0;
+    };
+    // one compartment per lane: queued iff its bucket reaches the threshold of its count; a bucket of 255 also takes the front pass's test
+    auto cell = [&](bool valid, int hn, int64_t X, uint32_t b) {
+        const int cl = (C == 1 || !valid) ? 0 : p.cls[hn];
+        bool queued = false;
+        if (valid && X > 0) {
+            if (X < 255) queued = b >= (uint32_t)s_thr[(cl << 8) + (int)X];
+            else {               // 255 or more: the general kernel's test on the count proper
+                X = Irow[hn];
+                queued = (float)(b + 1u) > fmaf(-256.0f, s_rt[cl] * (float)X, 255.999f);
+            }
+        }
+        if (queued && b == 255u) {      // the front pass's bound (vgx_tau_front_kernel)
+            const float lam = s_rt[cl] * (float)X, nn = (float)X + 1.0f;
+            bool cand = true;
+            if (lam < 8.0f && X < 256) {
+                TauRng g;
+                g.init(seed, att, (uint64_t)pn * (uint64_t)H + (uint64_t)hn, step, retry);
+                const double u52 = g.uniform();
+                const float lhs = __logf((float)(1.0 - u52)) - 5.5451775f;
+                const float rhs = nn * __logf(lam) - s_lf[(int)X + 1] + 0.01f * nn + 0.05f;
+                cand = lhs <= rhs || (1.0 - u52) < 1e-11;
+            }
+            if (cand) {
+                const unsigned int slot = atomicAdd(fn, 1u);
+                if ((int)slot < a.front_cap) fdst[slot] = (int64_t)hn | ((int64_t)255 << 32);
+            }
+        }
+        const unsigned long long m = __ballot(queued);
+        if (m != 0ull) {
+            if (queued) q[wave][nq + (int)__popcll(m & ((1ull << L) - 1ull))] = (int64_t)hn | ((int64_t)b << 32);
+            nq += (int)__popcll(m);
+            if (nq > 256 - 64) flush();
+        }
+    };
+    const int low = p.sites < VGX_D8_LOW ? p.sites : VGX_D8_LOW, TSd = 1 << (2 * low - 2);   // the drift pass's tile: its dwords
+    const int nwaves = gridDim.x * (TB / 64);
+    for (int reg = blockIdx.x * (TB / 64) + wave; reg < a.occ_nreg; reg += nwaves) {
+        const int64_t region = ((int64_t)rep * P + pn) * a.occ_nreg + reg;
+        const int n = (int)a.occ_n[region];
+        if (n > VGX_OCC_CAP) {
+            // a densely occupied region (the neighbourhood of a large lineage): its list is incomplete, so its compartments are
+            // swept — the cells the drift pass's wavefront `reg % 8` of tile `reg / 8` looked at, four per lane and turn
+            const int tl = reg / VGX_D8_WAVES, wv = reg % VGX_D8_WAVES;
+            for (int qd = wv * 64 + L; qd < TSd; qd += D8_TB) {
+                const int h0 = (tl << (2 * low)) + 4 * qd;
+                const uint32_t own = *(const uint32_t *)(I8row + h0);
+                const uint64_t gidx = (uint64_t)pn * groups + (uint64_t)(h0 >> 4);
+                const uint32_t ctr[4] = {(uint32_t)gidx, (uint32_t)(gidx >> 32), step, ctr_retry};
+                uint32_t w[4];
+                vgx_philox4x32(ctr, key, w);
+                const uint32_t word = w[(h0 >> 2) & 3];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) cell(true, h0 + j, (int64_t)((own >> (8 * j)) & 255u), (word >> (8 * j)) & 255u);
+            }
+            continue;
+        }
+        const int32_t *src = a.occ + region * VGX_OCC_CAP;
+        for (int i0 = 0; i0 < n; i0 += 64) {
+            const bool valid = i0 + L < n;
+            const int hn = valid ? src[i0 + L] : 0;
+            const int64_t X = valid ? (int64_t)I8row[hn] : 0;
+            const uint64_t gidx = (uint64_t)pn * groups + (uint64_t)(hn >> 4);
+            const uint32_t ctr[4] = {(uint32_t)gidx, (uint32_t)(gidx >> 32), step, ctr_retry};
+            uint32_t w[4];
+            vgx_philox4x32(ctr, key, w);
+            cell(valid, hn, X, (w[(hn >> 2) & 3] >> (8 * (hn & 3))) & 255u);
+        }
+    }
+    if (nq > 0) flush();
+}
+
 // In-kernel stamps of the events kernel (diagnostic build only, -DVGX_PROFILE; tools/profile_tau_events.py): shader cycles per
 // phase summed over all wavefronts.  [0] prologue, [1] wait for the round's count, [2] draws + bookkeeping, [3] rescue tests,
 // [4] staged list -> global, [5] epilogue, [7..11] inside tau_cell_events (lane 0's stamps: rates + count, split, mutants,
@@ -2970,6 +3139,11 @@ extern "C" __global__ void __launch_bounds__(64) vgx_tau_finish_kernel(VgxTauArg
     }
     __syncthreads();   // the lockdown records above use time_now + tau
     for (int i = lane; i < a.inc_shards; i += 64) a.inc_n[(int64_t)rep * VGX_INC_SHARDS + i] = 0;   // (sparse mode: applied by now)
+    long long occ_sum = 0;
+    if (a.occ_pop) {
+        for (int pn = lane; pn < P; pn += 64) { occ_sum += (long long)a.occ_pop[(int64_t)rep * P + pn]; a.occ_pop[(int64_t)rep * P + pn] = 0; }
+        for (int o = 32; o > 0; o >>= 1) occ_sum += __shfl_down(occ_sum, o);
+    }
     if (lane == 0) {
         a.gI[rep] = g;
         // one packed record per replicate for the host, and the bookkeeping it used to upload before every step
@@ -2980,6 +3154,7 @@ extern "C" __global__ void __launch_bounds__(64) vgx_tau_finish_kernel(VgxTauArg
         o[10] = (int64_t)a.mev_base[rep];        // multievent rows of this step: [o[10], o[11])
         o[11] = (int64_t)a.mev_n[rep];
         o[12] = a.error[rep];
+        o[13] = (a.occ_pop && a.use8) ? occ_sum : -1;   // occupied compartments at the start of this step (drift pass on the bytes), else -1
         a.mev_base[rep] = a.mev_n[rep];          // rows of the accepted step stay (pyx:2325)
         a.time_now[rep] += a.tau[rep];           // pyx:2322
         a.step[rep] += 1;
@@ -3087,14 +3262,23 @@ extern "C" __attribute__((visibility("hidden"))) hipError_t vgxi_tau_draw(const 
     unsigned egx = (unsigned)((VGX_EV_BLOCKS + (int64_t)a->p.P * a->R * a->ev_split - 1) / ((int64_t)a->p.P * a->R * a->ev_split));
     egx = egx < 1u ? 1u : (egx > tau_draw_gx(a->p.H) ? tau_draw_gx(a->p.H) : egx);
     const dim3 egrid(egx * (unsigned)a->ev_split, (unsigned)a->p.P, (unsigned)a->R);
-    if (a->front_on && a->sparse) {   // the likely failures first (vgx_tau_front_kernel)
+    const bool lists = a->use_list && a->front_on && a->sparse;
+    if (lists) {   // a sparse state: scan and front pass over the occupied compartments only
+        const dim3 fgrid(1, (unsigned)a->p.P, (unsigned)a->R);
+        hipLaunchKernelGGL(vgx_tau_listscan_kernel, grid, dim3(TB), 0, s, *a);
+        if (tabs == 2) hipLaunchKernelGGL((vgx_tau_events_kernel<2, true>), fgrid, dim3(EB), lds, s, *a);
+        else if (tabs == 1) hipLaunchKernelGGL((vgx_tau_events_kernel<1, true>), fgrid, dim3(EB), lds, s, *a);
+        else hipLaunchKernelGGL((vgx_tau_events_kernel<0, true>), fgrid, dim3(EB), 16, s, *a);
+    } else if (a->front_on && a->sparse) {   // the likely failures first (vgx_tau_front_kernel)
         const dim3 fgrid(1, (unsigned)a->p.P, (unsigned)a->R);
         hipLaunchKernelGGL(vgx_tau_front_kernel, grid, dim3(TB), 0, s, *a);
         if (tabs == 2) hipLaunchKernelGGL((vgx_tau_events_kernel<2, true>), fgrid, dim3(EB), lds, s, *a);
         else if (tabs == 1) hipLaunchKernelGGL((vgx_tau_events_kernel<1, true>), fgrid, dim3(EB), lds, s, *a);
         else hipLaunchKernelGGL((vgx_tau_events_kernel<0, true>), fgrid, dim3(EB), 16, s, *a);
     }
-    if (a->p.C <= 16 && a->p.CB <= 16 && (a->p.H & 15) == 0) {   // the usual shapes: thresholds tabulated
+    if (lists) {
+        // (the queue is there already)
+    } else if (a->p.C <= 16 && a->p.CB <= 16 && (a->p.H & 15) == 0) {   // the usual shapes: thresholds tabulated
         const bool c1 = a->p.C == 1, dn = !a->sparse;
         if (c1 && !dn) hipLaunchKernelGGL((vgx_tau_scan_fast_kernel<true, false>), grid, dim3(TB), 0, s, *a);
         else if (c1) hipLaunchKernelGGL((vgx_tau_scan_fast_kernel<true, true>), grid, dim3(TB), 0, s, *a);
