@@ -79,6 +79,8 @@ struct vgx_engine {
     bool call_philox = false;      // the last direct call drew from the counter-based stream (the host clock must too)
     int64_t start_max_nocc = 0;    // longest occupancy list of the state last uploaded
     void *pin[2] = {nullptr, nullptr};   // pinned staging buffers of large uploads (VGX_PIN_BYTES each), allocated on first use
+    void *pin_tau = nullptr;              // pinned mirror of what the tau step loop reads after every try and step (flags, the finish kernel's record)
+    size_t pin_tau_bytes = 0;
     hipEvent_t pin_ev[2] = {nullptr, nullptr};
     bool counts32_valid = false;   // r_lcnt32 mirrors r_lcnt (vgx_quad.hip keeps it; other kernels do not)
     bool counts64_valid = true;    // r_lcnt is current (vgx_quadf.hip and the long-list kernel of vgx_quad.hip keep the 4-byte counts only)
@@ -259,6 +261,7 @@ extern "C" void vgx_destroy(vgx_engine *e) {
         if (e->pin[i]) (void)hipHostFree(e->pin[i]);
         if (e->pin_ev[i]) (void)hipEventDestroy(e->pin_ev[i]);
     }
+    if (e->pin_tau) (void)hipHostFree(e->pin_tau);
     if (e->ev0) (void)hipEventDestroy(e->ev0);
     if (e->ev1) (void)hipEventDestroy(e->ev1);
     if (e->stream) (void)hipStreamDestroy(e->stream);
@@ -1469,6 +1472,23 @@ extern "C" int vgx_simulate_tau(vgx_engine *e, int64_t iterations, int64_t sampl
     a.time_now = (double *)e->t_time.p;
     int32_t *fl = (int32_t *)e->t_flags.p;
     a.active = fl; a.ok = fl + R; a.accepted = fl + 2 * R; a.grow = fl + 3 * R; a.retry = fl + 4 * R;   // accepted, grow: one copy per try
+    {   // the host's pinned mirror of accepted / grow (written by the decide kernel) and of the finish kernel's record: read after a
+        // stream synchronisation, no copy in between
+        const size_t need = (size_t)R * 2 * 4 + 64 + (size_t)R * 16 * 8;
+        if (e->pin_tau_bytes < need) {
+            if (e->pin_tau) (void)hipHostFree(e->pin_tau);
+            e->pin_tau = nullptr; e->pin_tau_bytes = 0;
+            HIPCHECK(e, hipHostMalloc(&e->pin_tau, need, hipHostMallocDefault));
+            e->pin_tau_bytes = need;
+        }
+        memset(e->pin_tau, 0, need);
+        void *dp = nullptr;
+        HIPCHECK(e, hipHostGetDevicePointer(&dp, e->pin_tau, 0));
+        a.host_flags = (int32_t *)dp;
+        a.host_res = (int64_t *)((char *)dp + (((size_t)R * 2 * 4 + 63) & ~(size_t)63));
+    }
+    const int32_t *pin_flags = (const int32_t *)e->pin_tau;
+    const int64_t *pin_res = (const int64_t *)((const char *)e->pin_tau + (((size_t)R * 2 * 4 + 63) & ~(size_t)63));
     a.step = fl + 5 * R; a.error = fl + 6 * R; a.attempt = fl + 7 * R; a.eff_dirty = fl + 8 * R; a.deciding = fl + 9 * R;
     a.Ppad = (int32_t)Ppad;
     {
@@ -1853,8 +1873,7 @@ extern "C" int vgx_simulate_tau(vgx_engine *e, int64_t iterations, int64_t sampl
             }
             launches += 8;
             HIPCHECK(e, hipStreamSynchronize(e->stream));
-            acc_h.resize((size_t)R * 2);   // accepted[R], grow[R]
-            HIPCHECK(e, hipMemcpy(acc_h.data(), a.accepted, (size_t)R * 8, hipMemcpyDeviceToHost));
+            acc_h.assign(pin_flags, pin_flags + (size_t)R * 2);   // accepted[R], grow[R]: the decide kernel's copy in pinned host memory
             bool all = true;
             for (int64_t r = 0; r < R; r++)
                 if (running[(size_t)r] && !acc_h[(size_t)r]) all = false;
@@ -1928,7 +1947,7 @@ extern "C" int vgx_simulate_tau(vgx_engine *e, int64_t iterations, int64_t sampl
         std::vector<int64_t> gI_d((size_t)R), res_h((size_t)R * 16);
         int64_t occ_step = -1;
         std::vector<unsigned long long> mevb((size_t)R);
-        HIPCHECK(e, hipMemcpy(res_h.data(), a.res, (size_t)R * 16 * 8, hipMemcpyDeviceToHost));   // packed by the finish kernel
+        memcpy(res_h.data(), pin_res, (size_t)R * 16 * 8);   // packed by the finish kernel, its copy in pinned host memory
         for (int64_t r = 0; r < R; r++) {
             if (!running[(size_t)r]) continue;
             const int64_t *o = &res_h[(size_t)r * 16];

@@ -209,6 +209,8 @@ struct VgxTauArgs {
     unsigned long long *big_n;  // [R]
     int64_t *res;        // [R][16] what the host reads after a step, packed by vgx_tau_finish_kernel: tau (bits),
                          // globalInfectious, counters[8], multievent row range of the step, error
+    int32_t *host_flags; // [2 R] accepted, grow as the decide kernel left them, in pinned HOST memory (or null)
+    int64_t *host_res;   // [R][16] the finish kernel's record per replicate, in pinned host memory (or null)
     int32_t *grow;       // [R] the try overflowed the cross-compartment list: the host enlarges it and the SAME try runs again
     int32_t *attempt;    // [R]
     const int64_t *seeds;  // [R]

@@ -3037,6 +3037,11 @@ extern "C" __global__ void __launch_bounds__(64) vgx_tau_decide_kernel(VgxTauArg
             for (int i = threadIdx.x; i < a.p.P; i += 64) a.front_n[(int64_t)rep * a.p.P + i] = 0;
     }
     if (threadIdx.x != 0) return;
+    // what the host looks at after every try, written to its (pinned) memory as well: no copy to wait for
+    struct Mirror {
+        const VgxTauArgs &a; int rep;
+        __device__ ~Mirror() { if (a.host_flags) { a.host_flags[rep] = a.accepted[rep]; a.host_flags[a.R + rep] = a.grow[rep]; } }
+    } mirror{a, rep};
     a.deciding[rep] = 0;
     if (!live) return;
     a.big_n[rep] = 0;
@@ -3155,6 +3160,8 @@ extern "C" __global__ void __launch_bounds__(64) vgx_tau_finish_kernel(VgxTauArg
         o[11] = (int64_t)a.mev_n[rep];
         o[12] = a.error[rep];
         o[13] = (a.occ_pop && a.use8) ? occ_sum : -1;   // occupied compartments at the start of this step (drift pass on the bytes), else -1
+        if (a.host_res)
+            for (int i = 0; i < 14; ++i) a.host_res[(int64_t)rep * 16 + i] = o[i];   // the host's (pinned) copy
         a.mev_base[rep] = a.mev_n[rep];          // rows of the accepted step stay (pyx:2325)
         a.time_now[rep] += a.tau[rep];           // pyx:2322
         a.step[rep] += 1;
