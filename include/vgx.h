@@ -22,6 +22,8 @@
  *   VGX_SOLO_NO_UNIT=1             ... no one-haplotype / one-population instantiation
  *   VGX_TAU_STEP_KERNELS=1 / 0     tau: always / never the step kernels (default: the on-device step loop for small models)
  *   VGX_TAU_NO_BYTE_DRIFT=1        tau: the two-pass drift instead of the pass on the one-byte counts
+ *   VGX_TAU_NO_FRONT=1             tau: no front pass of a try (the compartments that can fall below zero on their own drawn first)
+ *   VGX_TAU_NO_OCCLIST=1           tau: a try's scan and front pass always stream all compartments (no lists of the occupied ones)
  *   VGX_TAU_LARGE_MODEL_THRESHOLDS=1  tau: the draw thresholds of large models on a small one
  */
 #ifndef VGX_H
