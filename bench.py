@@ -553,8 +553,8 @@ def tau_warm_start(device, warm_steps=6000, timed_steps=100, seed=2020):
            "steps": n, "ms_per_step": ms / n, "wall_ms_per_step": 1e3 * t_wall / n, "events_drawn": int(c.reserved[0]),
            "value": c.reserved[0] / (ms * 1e-3), "unit": "events/s (device time)",
            "roofline_frac": 16.0 * m.popNum * m.hapNum * n / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-           "note": "the step kernels stream the dense [P][H] arrays whatever the occupancy: per step as many bytes as the uniform fill, for 1/400 "
-                   "of its events (DESIGN.md 9: occupancy lists for tau)"}
+           "note": "the drift pass and the column sums stream the dense [P][H] byte arrays whatever the occupancy; a try's scan and front pass "
+                   "run over the lists of occupied compartments the drift pass writes (DESIGN.md 4.3d); 1/400 of the uniform fill's events"}
     eng.close()
     return out
 
