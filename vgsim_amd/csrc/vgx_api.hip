@@ -1474,7 +1474,7 @@ extern "C" int vgx_simulate_tau(vgx_engine *e, int64_t iterations, int64_t sampl
     a.active = fl; a.ok = fl + R; a.accepted = fl + 2 * R; a.grow = fl + 3 * R; a.retry = fl + 4 * R;   // accepted, grow: one copy per try
     {   // the host's pinned mirror of accepted / grow (written by the decide kernel) and of the finish kernel's record: read after a
         // stream synchronisation, no copy in between
-        const size_t need = (size_t)R * 2 * 4 + 64 + (size_t)R * 16 * 8;
+        const size_t need = (size_t)R * 3 * 4 + 64 + (size_t)R * 16 * 8;
         if (e->pin_tau_bytes < need) {
             if (e->pin_tau) (void)hipHostFree(e->pin_tau);
             e->pin_tau = nullptr; e->pin_tau_bytes = 0;
@@ -1485,10 +1485,10 @@ extern "C" int vgx_simulate_tau(vgx_engine *e, int64_t iterations, int64_t sampl
         void *dp = nullptr;
         HIPCHECK(e, hipHostGetDevicePointer(&dp, e->pin_tau, 0));
         a.host_flags = (int32_t *)dp;
-        a.host_res = (int64_t *)((char *)dp + (((size_t)R * 2 * 4 + 63) & ~(size_t)63));
+        a.host_res = (int64_t *)((char *)dp + (((size_t)R * 3 * 4 + 63) & ~(size_t)63));
     }
     const int32_t *pin_flags = (const int32_t *)e->pin_tau;
-    const int64_t *pin_res = (const int64_t *)((const char *)e->pin_tau + (((size_t)R * 2 * 4 + 63) & ~(size_t)63));
+    const int64_t *pin_res = (const int64_t *)((const char *)e->pin_tau + (((size_t)R * 3 * 4 + 63) & ~(size_t)63));
     a.step = fl + 5 * R; a.error = fl + 6 * R; a.attempt = fl + 7 * R; a.eff_dirty = fl + 8 * R; a.deciding = fl + 9 * R;
     a.Ppad = (int32_t)Ppad;
     {
@@ -1628,6 +1628,9 @@ extern "C" int vgx_simulate_tau(vgx_engine *e, int64_t iterations, int64_t sampl
     const bool occ_lists_banned = false;
     int64_t occ_est = occupied;
     int64_t tries_total = 0, tries_lists = 0;
+    const char *nfo = getenv("VGX_TAU_NO_FRONT_ALONE");
+    const bool front_split = R == 1 && a.front_on && !(nfo && nfo[0] == '1');   // (several replicates: their tries end at different places)
+    bool front_done = false;
     bool i8_dirty = true;    // I8 does not mirror I (start of the call, after a Restart's upload, after a dense try)
     // Small models: the whole step loop on the device, one workgroup per replicate (vgx_taus.hip).  VGX_TAU_STEP_KERNELS=1 and the
     // test switches of the step kernels (dense validation modes, the large-model draw thresholds) keep the step kernels.
@@ -1843,8 +1846,28 @@ extern "C" int vgx_simulate_tau(vgx_engine *e, int64_t iterations, int64_t sampl
                 HIPCHECK(e, hipMemsetAsync(e->t_stkey.p, 0, (size_t)(R * st_size) * 8, e->stream));
                 a.gen = 1;
             }
-            tries_total += 1;
-            if (a.use_list && a.front_on && a.sparse) tries_lists += 1;
+            if (front_split && a.sparse && !front_done) {
+                // One replicate: the front pass of the try first, alone (most tries end there: three kernels and the host's turn instead
+                // of ten); if it finds nothing the try proper follows (phase 2), with the queue the list pass has already built.
+                a.phase = 1;
+                tries_total += 1;
+                if (a.use_list) tries_lists += 1;
+                HIPCHECK(e, vgxi_tau_draw(&a, e->stream));
+                HIPCHECK(e, vgxi_tau_decide(&a, e->stream));
+                launches += 3;
+                HIPCHECK(e, hipStreamSynchronize(e->stream));
+                a.phase = 0;
+                if (pin_flags[2 * R] == 1) { front_done = true; continue; }     // nothing found: the same try, for real
+                if (pin_flags[0]) break;                                        // (the loop guard of the halving: handled below like an accepted step)
+                if (tries > 600) return fail(e, VGX_ERR_LOOP_GUARD, "vgx_simulate_tau: tau halving did not converge");
+                continue;                                                       // rejected: tau halved, the next try
+            }
+            a.phase = front_done ? 2 : 0;
+            front_done = false;
+            if (a.phase == 0) {
+                tries_total += 1;
+                if (a.use_list && a.front_on && a.sparse) tries_lists += 1;
+            }
             HIPCHECK(e, vgxi_tau_draw(&a, e->stream));
             HIPCHECK(e, vgxi_tau_draw_big(&a, e->stream));   // (+ the immunity transitions: extra blocks of the same launch)
             if (a.sparse) {
@@ -1933,7 +1956,7 @@ extern "C" int vgx_simulate_tau(vgx_engine *e, int64_t iterations, int64_t sampl
             }
             if (again & 2) dense_once = true;
             if (again) HIPCHECK(e, hipMemset(a.grow, 0, (size_t)R * 4));
-            if (tries > 300) return fail(e, VGX_ERR_LOOP_GUARD, "vgx_simulate_tau: tau halving did not converge");
+            if (tries > 600) return fail(e, VGX_ERR_LOOP_GUARD, "vgx_simulate_tau: tau halving did not converge");
         }
         HIPCHECK(e, vgxi_tau_finish(&a, e->stream));
         launches += 1;

@@ -209,7 +209,7 @@ struct VgxTauArgs {
     unsigned long long *big_n;  // [R]
     int64_t *res;        // [R][16] what the host reads after a step, packed by vgx_tau_finish_kernel: tau (bits),
                          // globalInfectious, counters[8], multievent row range of the step, error
-    int32_t *host_flags; // [2 R] accepted, grow as the decide kernel left them, in pinned HOST memory (or null)
+    int32_t *host_flags; // [3 R] accepted, grow as the decide kernel left them, and "the front pass alone found nothing", in pinned HOST memory (or null)
     int64_t *host_res;   // [R][16] the finish kernel's record per replicate, in pinned host memory (or null)
     int32_t *grow;       // [R] the try overflowed the cross-compartment list: the host enlarges it and the SAME try runs again
     int32_t *attempt;    // [R]
@@ -231,6 +231,8 @@ struct VgxTauArgs {
     int64_t *front;      // [R][P][front_cap] the front pass's lists: compartments that can fall below zero on their own in this try (vgx_tau_front_kernel)
     unsigned int *front_n;   // [R][P] their counts (may exceed front_cap: the rest is found by the try proper); cleared by vgx_tau_decide_kernel
     int32_t front_cap, front_on;
+    int32_t phase, phase_pad;   // of a try: 0 = front pass and try proper in one go; 1 = the front pass alone (the decide kernel rejects the try or
+                                // reports that the pass found nothing); 2 = the try proper after such a front pass (one replicate: vgx_api.hip)
     unsigned long long *cnt_pop;   // [R][P][8] the events kernel's share of them per population, folded into cnt_try by vgx_tau_decide_kernel
     int64_t *mev;        // [R][mev_cap][6]  num, type, hap, pop, newHap, newPop (rows with num > 0 only)
     int64_t mev_cap;

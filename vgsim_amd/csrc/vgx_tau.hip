@@ -3011,6 +3011,10 @@ extern "C" __global__ void __launch_bounds__(64) vgx_tau_decide_kernel(VgxTauArg
     int g = live ? a.grow[rep] : 0;
     if (live && a.mev_cap > 0 && (int64_t)a.mev_n[rep] > a.mev_cap) g |= 16;   // rows were lost: the host enlarges the buffer
     const bool ok = live && a.ok[rep];
+    if (a.phase == 1 && ok) {   // the front pass alone, and it found no failure: nothing is touched, the try proper comes next
+        if (threadIdx.x == 0 && a.host_flags) { a.host_flags[rep] = a.accepted[rep]; a.host_flags[a.R + rep] = 0; a.host_flags[2 * a.R + rep] = 1; }
+        return;
+    }
     const int again = (g & 29) ? (g & 29) : (ok ? (g & 2) : 0);
     const bool accept = live && ok && again == 0;
     if (live) {   // the events kernel's tallies, kept per population (vgx_tau_events_kernel's epilogue)
@@ -3040,7 +3044,7 @@ extern "C" __global__ void __launch_bounds__(64) vgx_tau_decide_kernel(VgxTauArg
     // what the host looks at after every try, written to its (pinned) memory as well: no copy to wait for
     struct Mirror {
         const VgxTauArgs &a; int rep;
-        __device__ ~Mirror() { if (a.host_flags) { a.host_flags[rep] = a.accepted[rep]; a.host_flags[a.R + rep] = a.grow[rep]; } }
+        __device__ ~Mirror() { if (a.host_flags) { a.host_flags[rep] = a.accepted[rep]; a.host_flags[a.R + rep] = a.grow[rep]; a.host_flags[2 * a.R + rep] = 0; } }
     } mirror{a, rep};
     a.deciding[rep] = 0;
     if (!live) return;
@@ -3270,7 +3274,9 @@ extern "C" __attribute__((visibility("hidden"))) hipError_t vgxi_tau_draw(const 
     egx = egx < 1u ? 1u : (egx > tau_draw_gx(a->p.H) ? tau_draw_gx(a->p.H) : egx);
     const dim3 egrid(egx * (unsigned)a->ev_split, (unsigned)a->p.P, (unsigned)a->R);
     const bool lists = a->use_list && a->front_on && a->sparse;
-    if (lists) {   // a sparse state: scan and front pass over the occupied compartments only
+    if (a->phase == 2) {
+        // the front pass of this try has run (and with the lists, so has its scan)
+    } else if (lists) {   // a sparse state: scan and front pass over the occupied compartments only
         const dim3 fgrid(1, (unsigned)a->p.P, (unsigned)a->R);
         hipLaunchKernelGGL(vgx_tau_listscan_kernel, grid, dim3(TB), 0, s, *a);
         if (tabs == 2) hipLaunchKernelGGL((vgx_tau_events_kernel<2, true>), fgrid, dim3(EB), lds, s, *a);
@@ -3283,6 +3289,7 @@ extern "C" __attribute__((visibility("hidden"))) hipError_t vgxi_tau_draw(const 
         else if (tabs == 1) hipLaunchKernelGGL((vgx_tau_events_kernel<1, true>), fgrid, dim3(EB), lds, s, *a);
         else hipLaunchKernelGGL((vgx_tau_events_kernel<0, true>), fgrid, dim3(EB), 16, s, *a);
     }
+    if (a->phase == 1) return hipGetLastError();   // the front pass alone
     if (lists) {
         // (the queue is there already)
     } else if (a->p.C <= 16 && a->p.CB <= 16 && (a->p.H & 15) == 0) {   // the usual shapes: thresholds tabulated
