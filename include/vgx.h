@@ -24,6 +24,7 @@
  *   VGX_TAU_NO_BYTE_DRIFT=1        tau: the two-pass drift instead of the pass on the one-byte counts
  *   VGX_TAU_NO_FRONT=1             tau: no front pass of a try (the compartments that can fall below zero on their own drawn first)
  *   VGX_TAU_NO_OCCLIST=1           tau: a try's scan and front pass always stream all compartments (no lists of the occupied ones)
+ *   VGX_TAU_NO_FRONT_ALONE=1       tau, one replicate: the front pass is enqueued together with the try proper, not ahead of it
  *   VGX_TAU_LARGE_MODEL_THRESHOLDS=1  tau: the draw thresholds of large models on a small one
  */
 #ifndef VGX_H
