@@ -10,9 +10,9 @@ LEGS = ("headline", "spread_occupancy", "spread_occupancy_fast", "tau_leap", "fa
 
 
 def one(pattern):
-    f = glob.glob(os.path.join(SRC, pattern))
+    f = sorted(glob.glob(os.path.join(SRC, pattern)), key=os.path.getmtime)
     assert f, pattern
-    return f[0]
+    return f[-1]      # (a leg collected twice: the later pass)
 
 
 def pmc(leg, counter, big=False):
