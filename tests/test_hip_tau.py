@@ -737,6 +737,39 @@ def test_tries_over_the_lists_of_occupied_compartments(monkeypatch, sites, P, S,
     assert a.bCounter > 0
 
 
+def test_lists_and_front_pass_with_several_replicates(monkeypatch):
+    """Three replicates of a sparse 8-site model on the step kernels (their tries end at different places: no front pass alone,
+    one list of occupied compartments per replicate): the runs with the lists and the front pass equal those without."""
+    import ctypes as C
+    from vgsim_amd import _capi
+
+    def run(plain):
+        for k in ("VGX_TAU_NO_FRONT", "VGX_TAU_NO_OCCLIST"):
+            if plain:
+                monkeypatch.setenv(k, "1")
+            else:
+                monkeypatch.delenv(k, raising=False)
+        s = _filled(8, 3, 2, 1234, _fill_sparse, True)
+        m = s.simulation
+        eng = _capi.HipEngine(m.sites, m.hapNum, m.popNum, m.susNum, n_replicates=3)
+        m.events.CreateEvents(6); m.events.CreateEvents(6)
+        eng.set_params(m); eng.set_state(m); eng.set_seeds(np.array([21, 22, 23], dtype=np.int64))
+        o = _capi.VgxRunOpts(); o.record_events = 0
+        eng._check(eng.lib.vgx_simulate_tau(eng.handle, 6, 10 ** 15, -1.0, 1, C.byref(o)))
+        out = []
+        for r in range(3):
+            c = eng.counters(r)
+            eng.get_state(m, r)
+            out.append((c.ev_ptr, c.loop_iterations, c.reserved[0], m.infectious.copy(), m.susceptible.copy(), m.currentTime))
+        eng.close()
+        return out
+    a, b = run(False), run(True)
+    for x, y in zip(a, b):
+        assert x[:3] == y[:3] and x[5] == y[5]
+        assert np.array_equal(x[3], y[3]) and np.array_equal(x[4], y[4])
+    assert a[0][2] > 0 and not np.array_equal(a[0][3], a[1][3])
+
+
 @pytest.mark.parametrize("sites,P,S", [(8, 3, 2), (2, 3, 1)])
 def test_staged_start_state_gives_the_same_run(sites, P, S):
     """vgx_stage_tau (snapshot, conversion and upload of the start state ahead of the call: the bench's hand-over) against

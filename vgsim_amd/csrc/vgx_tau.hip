@@ -3017,7 +3017,8 @@ extern "C" __global__ void __launch_bounds__(64) vgx_tau_decide_kernel(VgxTauArg
     }
     const int again = (g & 29) ? (g & 29) : (ok ? (g & 2) : 0);
     const bool accept = live && ok && again == 0;
-    if (live) {   // the events kernel's tallies, kept per population (vgx_tau_events_kernel's epilogue)
+    const bool front_alone = a.phase == 1;   // (rejected by its front pass alone: no tallies, and without the lists no queue either)
+    if (live && !front_alone) {   // the events kernel's tallies, kept per population (vgx_tau_events_kernel's epilogue)
         const int P = a.p.P;
         unsigned long long part[6] = {0, 0, 0, 0, 0, 0};
         for (int pn = threadIdx.x; pn < P; pn += 64) {
@@ -3036,7 +3037,8 @@ extern "C" __global__ void __launch_bounds__(64) vgx_tau_decide_kernel(VgxTauArg
     if (live && (!accept || !a.sparse))
         for (int i = threadIdx.x; i < a.inc_shards; i += 64) a.inc_n[(int64_t)rep * VGX_INC_SHARDS + i] = 0;
     if (live) {  // the queue of the try has been worked off
-        for (int64_t i = threadIdx.x; i < a.q_shards; i += 64) a.q_n[(int64_t)rep * a.q_shards + i] = 0;
+        if (!front_alone || a.use_list)
+            for (int64_t i = threadIdx.x; i < a.q_shards; i += 64) a.q_n[(int64_t)rep * a.q_shards + i] = 0;
         if (a.front_on)
             for (int i = threadIdx.x; i < a.p.P; i += 64) a.front_n[(int64_t)rep * a.p.P + i] = 0;
     }
