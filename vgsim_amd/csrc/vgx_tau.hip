@@ -899,6 +899,7 @@ static __device__ __forceinline__ void d8_cells(const D8Ctx &c, int lane, double
         const int h = (c.tl << (2 * c.low)) + 4 * q;          // first of the thread's four haplotypes
         const uint32_t own = c.tile32[q];
         if (c.occ_dst) {       // (wave-uniform) the occupied compartments among the wavefront's 256: listed, region by region
+            if (__any(own != 0u)) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const bool nz = ((own >> (8 * j)) & 255u) != 0u;
@@ -909,6 +910,7 @@ static __device__ __forceinline__ void d8_cells(const D8Ctx &c, int lane, double
                     if (pos < VGX_OCC_CAP) c.occ_dst[pos] = h + j;
                 }
                 occ_cnt += (int)__popcll(m);
+            }
             }
         } else {               // only counted (what decides whether the next step builds the lists)
             const uint32_t y = own;
