@@ -114,8 +114,26 @@ def test_random_model_tau_invariants(seed):
         return
     before = {k: getattr(m, k) for k in ("bCounter", "dCounter", "sCounter", "mCounter", "iCounter", "migPlus")}
     mv0 = m.multievents.ptr
-    with helpers.quiet():
-        sim.simulate(25, sample_size=10 ** 12, method="tau")
+    try:
+        with helpers.quiet():
+            sim.simulate(25, sample_size=10 ** 12, method="tau")
+    except Exception as ex:
+        if "tau underflow in the halving loop" not in str(ex) or m.popNum == 1:
+            raise
+        # Upstream's dead end: a source compartment that passed the check on the strength of its booked migrants (pyx:2473) was
+        # applied below zero (pyx:2548), after which no try can pass and upstream halves tau for ever; the engine gives up after
+        # 200 halvings.  That, and nothing else, must be what happened: the same call cut off after the steps it accepted (the
+        # error names the step that could not be drawn) ends with such a compartment.
+        import re
+        k = int(re.search(r"\(step (\d+),", str(ex)).group(1))
+        assert k > 0, "the halving loop gave up on the first step of the call: %s" % ex
+        sim2, _ = build(seed)
+        m2 = sim2.simulation
+        with helpers.quiet():
+            sim2.simulate(min(n, 600), sample_size=10 ** 9)
+            sim2.simulate(k, sample_size=10 ** 12, method="tau")
+        assert (m2.infectious < 0).any(), "the halving loop gave up although no compartment had been applied below zero"
+        pytest.skip("seed %d runs into upstream's dead end (a compartment applied below zero: pyx:2473 vs 2548)" % seed)
     # upstream books a migrant on its SOURCE compartment in the bounds check (pyx:2473) but applies it to the target
     # (pyx:2548), so with migration a source compartment can pass the check and still end below zero: faithfully
     # reproduced (the oracle is pinned draw-exact on it), hence non-negativity is only an invariant without migration
