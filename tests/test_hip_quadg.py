@@ -1,7 +1,7 @@
 """The GENERAL four-replicates-per-wavefront kernel (vgx_quadg.hip: several susceptibility groups, several rate classes,
 lockdown switches, up to 128 populations) against the CPU oracle and the reference's goldens, bit for bit: every direct case of
-the suite without recombination with the kernel forced (``kernel='quadg'``; ``'quad'`` takes it wherever the one-class form
-refuses), ensembles whose replicates must equal single seeded runs (the four rows of a wavefront take different branches:
+the suite with the kernel forced (``kernel='quadg'``; ``'quad'`` takes it wherever the one-class form refuses; models with a
+recombination probability run the instantiations that carry the recombination branch of Birth), ensembles whose replicates must equal single seeded runs (the four rows of a wavefront take different branches:
 immunity transitions, births, migrations, lockdown switches, restarts), and the model of the reference's published benchmark
 (data/Table 3)."""
 import numpy as np
@@ -13,7 +13,7 @@ import models
 pytestmark = pytest.mark.gpu
 
 DIRECT = [n for n, (_, ph) in models.CASES.items() if all(kw.get("method", "direct") == "direct" for _, kw in ph)]
-QUADG = [n for n in DIRECT if n not in models.RECOMBINATION_CASES]
+QUADG = [n for n in DIRECT if n not in models.RECOMBINATION_CASES]      # (those: test_recombinant_births_on_the_general_row_kernel)
 # the models the one-class form refuses (what `kernel='quad'` now hands to the general form)
 GENERAL_ONLY = ["g2", "g3", "g4", "g7", "g9", "example", "p70", "stress_h64", "stress_h256", "continuation", "cmd_example"]
 
@@ -31,10 +31,45 @@ def test_kernel_quad_takes_the_general_form_and_matches_the_goldens(name):
     helpers.check_against_golden(hip, name, exact_time=helpers.libm_matches_fixture_host(), rtol_time=1e-12, leftovers=False)
 
 
-def test_recombination_is_refused():
-    from vgsim_amd._capi import VgxError
-    with pytest.raises(VgxError), helpers.quiet():
-        helpers.run_case_hip("recomb_a", kernel="quadg")
+@pytest.mark.parametrize("name", models.RECOMBINATION_CASES)
+def test_recombinant_births_on_the_general_row_kernel(oracle_mod, name):
+    """The recombination branch of Birth (pyx:575-596) on the row-per-replicate layout (`vgx_quadg_kernel_*_rec`): the second parent
+    by fastChoose over birthInf in list order, breakpoint, the newborn's haplotype as a list operation, the forward records (kept
+    across Restarts like upstream's) — log, state and records equal the oracle's and the fixtures recorded from the reference."""
+    hip = helpers.run_case_hip(name, kernel="quadg").simulation
+    assert hip._engine.last_kernel == "quadg"
+    ref = helpers.run_case_oracle(oracle_mod, name).simulation
+    helpers.assert_models_equal(hip, ref, name)
+    assert len(hip.rec.his) > 0
+    helpers.check_against_golden(hip, name, exact_time=helpers.libm_matches_fixture_host(), rtol_time=1e-12, leftovers=False)
+
+
+@pytest.mark.parametrize("name,n_events", [("recomb_a", 3000), ("recomb_restart", 2500)])
+def test_recombination_in_an_ensemble_on_the_general_row_kernel(oracle_mod, name, n_events):
+    """Four rows of a wavefront with recombinant births at different events: every replicate equals its single seeded oracle run
+    (a recombinant birth's row names the second parent; the newborn's haplotype shows in the compartments)."""
+    from vgsim_amd import Simulator
+    from vgsim_amd.ensemble import Ensemble
+    R = 6
+    ctor, phases = models.CASES[name]
+    with helpers.quiet():
+        sim = Simulator(**ctor)
+    phases[0][0](sim)
+    seeds = np.array([3, 4, 2021, 99, 12345678901, 1], dtype=np.int64)
+    ens = Ensemble(sim, R, seeds=seeds)
+    res = ens.simulate(n_events, sample_size=10 ** 9, record_events=True, kernel="quadg")
+    assert ens.engine.last_kernel == "quadg"
+    for r in range(R):
+        m = _single(oracle_mod, name, seeds[r], n_events)
+        assert res.events[r] == m.events.ptr, "replicate %d" % r
+        chain = ens.replicate_events(r)
+        assert np.array_equal(chain, m.events.as_array()[:, :m.events.ptr]), "replicate %d: %s" % (
+            r, helpers.describe_first_diff(chain, m.events.as_array(), m.events.ptr))
+        st = ens.replicate_state(r)
+        assert np.array_equal(st.infectious, m.infectious) and np.array_equal(st.susceptible, m.susceptible)
+        for k in st.COUNTERS:
+            assert getattr(st, k) == getattr(m, k), k
+    ens.close()
 
 
 def _single(oracle_mod, name, seed, n_events):

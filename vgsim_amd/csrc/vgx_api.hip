@@ -943,8 +943,8 @@ static int direct_core(vgx_engine *e, int64_t iterations, int64_t sample_size, f
     // Kernel choice: small models run one replicate per LANE (vgx_lanes.hip: the reference's serial loops, dense state);
     // everything else one replicate per wavefront.  opts.kernel: 0 = automatic, 1 = wavefront, 2 = lane.
     const int64_t H = e->d.hapNum, S = e->d.susNum;
-    // Recombination (pyx:575-596), exact mode only: the lane kernel (serial, dense state) while the dense arrays fit, the
-    // wavefront kernel (occupancy lists) beyond that and whenever it is asked for.
+    // Recombination (pyx:575-596), exact mode only: the single-trajectory kernel, the general row kernel (its *_rec instantiations), the
+    // wavefront kernel (any shape), and — when asked for — the lane kernel (serial, dense state) while the dense arrays fit.
     const bool recomb = e->recombination != 0.0;
     const bool lane_ok = o.mode == 0 && (recomb ? P * H * std::max<int64_t>(S, 1) <= (1 << 24)
                                                 : (P * H <= 1024 && P <= 16 && S <= 8 && H <= e->cap));
@@ -969,8 +969,10 @@ static int direct_core(vgx_engine *e, int64_t iterations, int64_t sample_size, f
                                     "popNum <= 128, susNum <= 16 and a model that fits 160 KB of LDS");
     // measured (tools/probe_lanes.py): the lane kernel only wins for minimal models in very large ensembles (config 2 at
     // 262 144 replicates: 2.4e9 vs 7.0e8 events/s); its state lives in HBM/L2, so every other shape is latency-bound
-    // (recombination: the single-trajectory kernel where it takes the model, else the lane kernel, else the wavefront kernel)
-    const bool use_lanes = (recomb && lane_ok && o.kernel != 1 && o.kernel != 5 && !(o.kernel == 0 && solo_ok && R < 2048)) || o.kernel == 2 || (o.kernel == 0 && lane_ok && P * H * S <= 4 && R >= 65536);
+    // (recombination: the single-trajectory kernel for few replicates of a model it takes, else the general row kernel, else the wavefront kernel)
+    // (recombination, measured in round 4 — tools/probe_recomb_ens.py, 16 384 replicates of the recomb_a / recomb_pos models: the general row
+    // kernel 6.4-6.9e8 events/s, the wavefront kernel 3.1-3.4e8, the lane kernel 1.0-1.2e7: the lane kernel only when it is asked for)
+    const bool use_lanes = o.kernel == 2 || (o.kernel == 0 && !recomb && lane_ok && P * H * S <= 4 && R >= 65536);
     // Four replicates per wavefront, one per 16-lane DPP row (vgx_quad.hip): one rate class, one susceptibility group,
     // at most 64 populations, no population that can switch its lockdown state, exact mode.
     bool quad_shape = !recomb && P <= 64 && S == 1 && e->C == 1 && e->CB == 1 && !ld_possible &&
@@ -986,14 +988,14 @@ static int direct_core(vgx_engine *e, int64_t iterations, int64_t sample_size, f
     // The general form of that kernel (vgx_quadg.hip): several susceptibility groups and rate classes, lockdown switches,
     // up to 128 populations.
     const int64_t qg_W = 3 * S + e->CB;
-    const bool quadg_ok = o.mode == 0 && !recomb && P <= VGX_QG_MAX_P && S <= VGX_QG_MAX_S && e->C <= VGX_QG_MAX_C &&
+    const bool quadg_ok = o.mode == 0 && P <= VGX_QG_MAX_P && S <= VGX_QG_MAX_S && e->C <= VGX_QG_MAX_C &&
                           e->CB <= VGX_QG_MAX_CB && qg_W <= VGX_QG_MAX_W && (int64_t)e->h_seg_par.size() <= VGX_QG_MAX_SEG;
     if (o.kernel == 3 && !quad_ok && !quadg_ok && !quadf_ok)
         return fail(e, VGX_ERR_ARG, "vgx_simulate_direct: the four-replicates-per-wavefront kernels need exact mode, no recombination, "
                                     "popNum <= 128, susNum <= 8, at most 64 rate classes and 16 transmission/susceptibility classes");
     if (o.kernel == 4 && !quadg_ok)
-        return fail(e, VGX_ERR_ARG, "vgx_simulate_direct: the general four-replicates-per-wavefront kernel needs exact mode, no "
-                                    "recombination, popNum <= 128, susNum <= 8, at most 64 rate classes and 16 transmission/susceptibility classes");
+        return fail(e, VGX_ERR_ARG, "vgx_simulate_direct: the general four-replicates-per-wavefront kernel needs exact mode, "
+                                    "popNum <= 128, susNum <= 8, at most 64 rate classes and 16 transmission/susceptibility classes");
     // measured (tools/probe_single.py, round 3): the row kernels lead at every ensemble size, a single trajectory included —
     // config 2: 2.9e5 events/s against 2.0e5 on the one-replicate-per-wavefront kernel, config 3: 1.75e5 against 1.26e5; four
     // replicates in one wavefront: 1.1e6 / 5.9e5 against 7.9e5 / 4.9e5 in four wavefronts

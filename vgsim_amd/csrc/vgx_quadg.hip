@@ -4,7 +4,8 @@
 // leaves to the one-replicate-per-wavefront kernel of vgx_direct.hip.
 //
 // Same path, same contract as the other two: SimulatePopulation pyx:396-429 and everything it calls (SampleTime pyx:476,
-// GenerateEvent pyx:483, UpdateRates pyx:516, ImmunityTransition pyx:550, Birth pyx:568 without the recombination branch,
+// GenerateEvent pyx:483, UpdateRates pyx:516, ImmunityTransition pyx:550, Birth pyx:568 (the recombination branch pyx:575-596 in the
+// *_rec instantiations),
 // Death/Sampling pyx:616/630, Mutation pyx:640, GenerateMigration pyx:672, CheckLockdown pyx:698, Restart pyx:714,
 // UpdateAllRates pyx:279, fastChoose / fastChoose_skip fast_choose.pxi:18/36, Events.AddEvent events.pxi:37); every sum the
 // reference forms left to right is formed left to right, no contraction: event chains are bit-identical.
@@ -45,7 +46,8 @@ static __device__ __forceinline__ bool row_any(bool f) { return row_max(f ? 1 : 
 
 }  // namespace
 
-template <int NS>
+// RECOMB: the instantiations with the recombination branch of Birth (pyx:575-596); the others do not carry its code.
+template <int NS, bool RECOMB = false>
 static __device__ __forceinline__ void quadg_body(const VgxDirectArgs &a, const VgxQuadgArgs &qa) {
     const int lane = threadIdx.x, row = lane >> 4, rl = lane & 15;
     const VgxDevParams &p = a.p;
@@ -156,6 +158,7 @@ static __device__ __forceinline__ void quadg_body(const VgxDirectArgs &a, const 
 
     double t_now = sc->currentTime, totalRate = 0.0, totalMig = 0.0;
     int64_t gI = sc->globalInfectious, ev_ptr = sc->ev_ptr;
+    int64_t rec_n = 0;      // recombination records of this call (kept across Restarts like upstream's `rec`)
     int64_t cS = sc->sCounter;
     if (rl == 0) {
         s_cnt[GC_B] = sc->bCounter; s_cnt[GC_D] = sc->dCounter; s_cnt[GC_M] = sc->mCounter; s_cnt[GC_I] = sc->iCounter;
@@ -529,6 +532,7 @@ static __device__ __forceinline__ void quadg_body(const VgxDirectArgs &a, const 
                     double ws = 0.0;
                     for (int sn = 0; sn < S; ++sn) ws += (double)R_SNP(sn) * sg[sn];
                     int si = 0;
+                    double rnb = 0.0;       // (RECOMB) the random number after the group choice (fast_choose.pxi:31)
                     {
                         const double rq = ws * rn;
                         double total = (double)R_SNP(0) * sg[0], wi = total;
@@ -538,6 +542,60 @@ static __device__ __forceinline__ void quadg_body(const VgxDirectArgs &a, const 
                             if (!stop && total < rq) { si = j; total += wj; wi = wj; } else stop = true;
                         }
                         if (isB && wi == 0.0) err = G_ERR_ZERO_WEIGHT + 256 * 6;
+                        if (RECOMB) rnb = (rq - (total - wi)) / wi;
+                    }
+                    bool isR = false;       // a recombinant birth: second parent hi2, the newborn carries nhi
+                    int hi2 = 0, nhi = 0;
+                    if (RECOMB) {
+                        isR = isB && err == 0 && rnb < p.recombination && s_ti[pi] > 1;
+                        if (__builtin_expect(__ballot(isR) != 0, 0)) {
+                            // ---- pyx:575-596: the second parent by fastChoose over birthInf[hn] = eventHapPopRate[pi, hn, 0] *
+                            // infectious[pi, hn], one host of hi set aside; over the list in its (haplotype) order: the same additions ----
+                            double rr_ = rnb / p.recombination;
+                            auto weight = [&](int k) -> double {
+                                const int kk = min(k, last);
+                                return (isR && k < n_sel) ? R_BC(k_bidx[lc[kk]]) * (double)(ln[kk] - (kk == k_hit ? 1 : 0)) : 0.0;
+                            };
+                            const int maxr = rows_max(isR ? n_sel : 0);
+                            double hs = 0.0;
+                            for (int cb0 = 0; cb0 * 16 < maxr; ++cb0) hs = row_sum16(weight(cb0 * 16 + rl), hs);
+                            const double r_ = hs * rr_;
+                            if (isR && !(0.0 < r_) && !(n_sel > 0 && lh[0] == 0)) err = G_ERR_ZERO_WEIGHT + 256 * 15;   // the dense loop stops at haplotype 0
+                            double carry = 0.0, tot2 = 0.0, w2 = 0.0;
+                            int kq = -1;
+                            for (int cb0 = 0; cb0 * 16 < maxr; ++cb0) {
+                                const int k = cb0 * 16 + rl;
+                                const double w = weight(k);
+                                double tot_;
+                                const double pre = row_scan16(w, carry, tot_);
+                                const int q = row_min(kq < 0 && isR && k < n_sel && !(pre < r_) ? rl : 16);
+                                if (kq < 0 && q < 16) { kq = cb0 * 16 + q; tot2 = rowget_f64(pre, q); w2 = rowget_f64(w, q); }
+                                carry = tot_;
+                            }
+                            if (isR && err == 0 && kq < 0) {     // rounding left the total below r: the dense loop ends at haplotype H - 1
+                                if (n_sel > 0 && lh[last] == H - 1) { kq = last; w2 = rowget_f64(weight((last & ~15) + rl), last & 15); tot2 = carry; }
+                                else err = G_ERR_ZERO_WEIGHT + 256 * 16;
+                            }
+                            if (kq < 0) kq = 0;
+                            if (isR && err == 0 && w2 == 0.0) err = G_ERR_ZERO_WEIGHT + 256 * 17;
+                            rr_ = (r_ - (tot2 - w2)) / w2;
+                            hi2 = isR ? lh[min(kq, last)] : 0;
+                            const int64_t posRecomb = (int64_t)((double)p.genome_length * rr_);
+                            // pyx:586-591 as written: the recombinant carries only the last site of one parent
+                            nhi = sites > 0 ? ((p.sitesPosition[sites - 1] < posRecomb ? hap_hit : hi2) % 4) : 0;
+                            if (isR && err == 0 && live) {
+                                if (r.rec) {
+                                    if (rec_n < r.rec_cap) {
+                                        if (rl == 0) {
+                                            int64_t *o = r.rec + (rep * r.rec_cap + rec_n) * 5;
+                                            o[0] = ev_ptr; o[1] = hap_hit; o[2] = hi2; o[3] = nhi; o[4] = posRecomb;
+                                        }
+                                    } else err = G_ERR_CAPACITY;
+                                }
+                                rec_n += 1;
+                            }
+                            isR = isR && err == 0;
+                        }
                     }
                     WSYNC();
                     if (isB && err == 0) {
@@ -545,11 +603,12 @@ static __device__ __forceinline__ void quadg_body(const VgxDirectArgs &a, const 
                             R_SUS(si) -= 1;
                             R_IMS(si) = k_cumul[si] * (double)R_SUS(si);
                             s_ts[pi] -= 1; s_ti[pi] += 1;
-                            if (live) { ln[k_hit] = cnt_hit + 1; if (n_sel > 64) lt[k_hit >> 6] += 1; }
+                            if (live && !isR) { ln[k_hit] = cnt_hit + 1; if (n_sel > 64) lt[k_hit >> 6] += 1; }
                         }
-                        if (rl == k_hit) ch_cn += 1;
+                        if (isR) { op_n = 1; op_pi = pi; op_h0 = nhi; op_d0 = +1; ch_pi = -1; }     // the newborn's haplotype: a list operation
+                        else if (rl == k_hit) ch_cn += 1;
                         gI += 1; GBUMP(GC_B);
-                        e_type = GEV_BIRTH; e_hap = hap_hit; e_pop = pi; e_nh = si; e_np = H;
+                        e_type = GEV_BIRTH; e_hap = hap_hit; e_pop = pi; e_nh = si; e_np = isR ? hi2 : H;
                         u_pop = pi; u_inf = true; u_imm = true; u_mig = true;
                     }
                 }
@@ -1221,7 +1280,7 @@ static __device__ __forceinline__ void quadg_body(const VgxDirectArgs &a, const 
             sco->loc_n = loc_n; sco->error = err; sco->traj_next = traj_next;
             sco->last_attempt = last_att; sco->last_attempt_loops = att_loops;
             sco->fa_n = fa_n;
-            sco->rec_n = 0;
+            sco->rec_n = rec_n;
         }
     }
 }
@@ -1230,6 +1289,10 @@ extern "C" __global__ void __launch_bounds__(64, VGX_QUADG_WAVES) vgx_quadg_kern
 extern "C" __global__ void __launch_bounds__(64, VGX_QUADG_WAVES) vgx_quadg_kernel_p32(VgxDirectArgs a, VgxQuadgArgs qa) { quadg_body<2>(a, qa); }
 extern "C" __global__ void __launch_bounds__(64, VGX_QUADG_WAVES) vgx_quadg_kernel_p64(VgxDirectArgs a, VgxQuadgArgs qa) { quadg_body<4>(a, qa); }
 extern "C" __global__ void __launch_bounds__(64, VGX_QUADG_WAVES) vgx_quadg_kernel_p128(VgxDirectArgs a, VgxQuadgArgs qa) { quadg_body<8>(a, qa); }
+extern "C" __global__ void __launch_bounds__(64, VGX_QUADG_WAVES) vgx_quadg_kernel_p16_rec(VgxDirectArgs a, VgxQuadgArgs qa) { quadg_body<1, true>(a, qa); }
+extern "C" __global__ void __launch_bounds__(64, VGX_QUADG_WAVES) vgx_quadg_kernel_p32_rec(VgxDirectArgs a, VgxQuadgArgs qa) { quadg_body<2, true>(a, qa); }
+extern "C" __global__ void __launch_bounds__(64, VGX_QUADG_WAVES) vgx_quadg_kernel_p64_rec(VgxDirectArgs a, VgxQuadgArgs qa) { quadg_body<4, true>(a, qa); }
+extern "C" __global__ void __launch_bounds__(64, VGX_QUADG_WAVES) vgx_quadg_kernel_p128_rec(VgxDirectArgs a, VgxQuadgArgs qa) { quadg_body<8, true>(a, qa); }
 
 // ---- host-side launcher ----
 extern "C" __attribute__((visibility("hidden"))) hipError_t vgxi_launch_quadg(const VgxDirectArgs *a, const VgxQuadgArgs *qa,
@@ -1237,8 +1300,10 @@ extern "C" __attribute__((visibility("hidden"))) hipError_t vgxi_launch_quadg(co
     const int P = a->p.P;
     const int NS = P <= 16 ? 1 : P <= 32 ? 2 : P <= 64 ? 4 : 8;
     const VgxQuadgLayout L = vgx_quadg_layout(16 * NS, a->p.S, a->p.C, a->p.CB, qa->nseg);
-    void (*k)(VgxDirectArgs, VgxQuadgArgs) = NS == 1 ? vgx_quadg_kernel_p16 : NS == 2 ? vgx_quadg_kernel_p32 : NS == 4 ? vgx_quadg_kernel_p64
-                                                                                                                   : vgx_quadg_kernel_p128;
+    const bool rec = a->p.recombination != 0.0;
+    void (*k)(VgxDirectArgs, VgxQuadgArgs) =
+        rec ? (NS == 1 ? vgx_quadg_kernel_p16_rec : NS == 2 ? vgx_quadg_kernel_p32_rec : NS == 4 ? vgx_quadg_kernel_p64_rec : vgx_quadg_kernel_p128_rec)
+            : (NS == 1 ? vgx_quadg_kernel_p16 : NS == 2 ? vgx_quadg_kernel_p32 : NS == 4 ? vgx_quadg_kernel_p64 : vgx_quadg_kernel_p128);
     hipError_t err = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, L.total);
     if (err != hipSuccess) return err;
     const unsigned grid = (unsigned)((a->n_replicates + 3) / 4);
