@@ -935,9 +935,6 @@ static int direct_core(vgx_engine *e, int64_t iterations, int64_t sample_size, f
     a.ev_size = ev_size;
     a.max_loop = o.max_loop_factor * std::max<int64_t>(iterations, 1) + (1 << 20);
     a.record_events = o.record_events ? 1 : 0;
-    a.fast = o.mode >= 1 ? 1 : 0;
-    a.rng_philox = o.mode == 2 ? 1 : 0;
-    e->call_philox = o.mode == 2;
     a.lds_bytes = (int32_t)lds;
 
     // Kernel choice: small models run one replicate per LANE (vgx_lanes.hip: the reference's serial loops, dense state);
@@ -946,6 +943,20 @@ static int direct_core(vgx_engine *e, int64_t iterations, int64_t sample_size, f
     // Recombination (pyx:575-596), exact mode only: the single-trajectory kernel, the general row kernel (its *_rec instantiations), the
     // wavefront kernel (any shape), and — when asked for — the lane kernel (serial, dense state) while the dense arrays fit.
     const bool recomb = e->recombination != 0.0;
+    {
+        // FAST mode promises the exact mode's integer rows on the same seed and times within 1e-9 — which the exact mode delivers.  Its
+        // own row kernel (vgx_quadf.hip) takes one-class models; for every other model that the exact row kernels or the latency
+        // kernel take, those ARE the fast path (tools/probe_fast_general.py, 16 384 replicates of the Table-3 model: 1.4e9 / 1.1e9 /
+        // 4.2e8 events/s at 2 / 10 / 100 demes against 2.5e8 / 2.5e8 / 1.3e8 on the FAST form of the wavefront kernel).  The
+        // counter-based stream (mode 2) is another trajectory and stays where it is.
+        const bool one_class_shape = P <= 64 && S == 1 && e->C == 1 && e->CB == 1 && !ld_possible;
+        const bool general_shape = P <= VGX_QG_MAX_P && S <= VGX_QG_MAX_S && e->C <= VGX_QG_MAX_C && e->CB <= VGX_QG_MAX_CB &&
+                                   3 * S + e->CB <= VGX_QG_MAX_W && (int64_t)e->h_seg_par.size() <= VGX_QG_MAX_SEG;
+        if (o.mode == 1 && o.kernel == 0 && !recomb && !one_class_shape && general_shape) o.mode = 0;
+    }
+    a.fast = o.mode >= 1 ? 1 : 0;
+    a.rng_philox = o.mode == 2 ? 1 : 0;
+    e->call_philox = o.mode == 2;
     const bool lane_ok = o.mode == 0 && (recomb ? P * H * std::max<int64_t>(S, 1) <= (1 << 24)
                                                 : (P * H <= 1024 && P <= 16 && S <= 8 && H <= e->cap));
     if (recomb && o.mode != 0)
