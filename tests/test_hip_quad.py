@@ -27,12 +27,15 @@ def test_quad_kernel_vs_reference_goldens(name):
     helpers.check_against_golden(hip, name, exact_time=helpers.libm_matches_fixture_host(), leftovers=False)
 
 
-def test_quad_refuses_models_outside_its_scope():
-    """Models the one-class form does not take go to the general form (vgx_quadg.hip, tests/test_hip_quadg.py); recombination
-    is outside both."""
+def test_quad_hands_models_outside_its_scope_to_the_general_form(oracle_mod):
+    """Models the one-class form does not take go to the general form (vgx_quadg.hip, tests/test_hip_quadg.py) — since round 4 also
+    those with a recombination probability; FAST mode with recombination stays refused."""
     from vgsim_amd._capi import VgxError
+    hip = helpers.run_case_hip("recomb_pos", kernel="quad").simulation
+    assert hip._engine.last_kernel == "quadg"
+    helpers.assert_models_equal(hip, helpers.run_case_oracle(oracle_mod, "recomb_pos").simulation, "recomb_pos")
     with pytest.raises(VgxError), helpers.quiet():
-        helpers.run_case_hip("recomb_pos", kernel="quad")
+        helpers.run_case_hip("recomb_pos", mode="fast")
 
 
 def _single(oracle_mod, name, seed, n_events, mut=None):
