@@ -104,13 +104,16 @@ typedef struct vgx_run_opts {
                                 vgx_simulate_tau. */
     int64_t kernel;          /* direct path: 0 = automatic, 1 = one replicate per wavefront (vgx_direct.hip), 2 = one replicate
                                 per lane (vgx_lanes.hip; small models: popNum <= 16, popNum*hapNum <= 1024, susNum <= 8, EXACT),
-                                3 = four replicates per wavefront, one per 16-lane row (EXACT, no recombination): vgx_quad.hip
+                                3 = four replicates per wavefront, one per 16-lane row (EXACT): vgx_quad.hip
                                 for popNum <= 64, one susceptibility group, one rate class and no possible lockdown switch,
                                 else the general form vgx_quadg.hip (popNum <= 128, susNum <= 8, <= 64 rate classes, <= 16
-                                transmission/susceptibility classes); 4 = the general form even where 3 would take the other;
+                                transmission/susceptibility classes; also models with a recombination probability); 4 = the general
+                                form even where 3 would take the other;
                                 5 = one replicate per wavefront with the whole DENSE model in LDS and registers (vgx_solo.hip: the
-                                latency kernel of single trajectories; EXACT, no recombination, hapNum <= 64, popNum <= 128,
-                                susNum <= 16).  Automatic: 5 for fewer than 2048 replicates of a model it takes */
+                                latency kernel of single trajectories; EXACT, hapNum <= 64, popNum <= 128, susNum <= 16).
+                                Automatic: 5 for fewer than 2048 replicates of a model it takes (and for more where it beats 3 / 4);
+                                mode 1 on a model the FAST row kernel does not take runs the exact kernels 3 / 4 / 5 (their output
+                                is what FAST promises); 2 only when asked for */
     int64_t reserved[2];     /* [0] tau path: 1 = run every try of the halving loop (pyx:2316-2321) instead of starting at the
                                 first try that is not certain to be rejected (same accepted steps either way);
                                 [1] tau path, how a try's deltas are kept and checked (same draws and decisions in every mode):
