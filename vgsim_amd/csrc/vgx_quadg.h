@@ -37,7 +37,7 @@ struct VgxQuadgLayout {
 };
 
 // byte offsets of the LDS arrays (PL = 16 x slots); everything 8-byte aligned, the four replicates' blocks at `rows`
-static inline __host__ __device__ VgxQuadgLayout vgx_quadg_layout(int PL, int S, int C, int CB, int NSEG) {
+static inline __host__ __device__ VgxQuadgLayout vgx_quadg_layout(int PL, int S, int C, int CB, int NSEG, int W = VGX_QG_MAX_W) {
     VgxQuadgLayout L;
     int o = 0;
     L.k_as = o; o += 8 * PL;   L.k_thS = o; o += 8 * PL;   L.k_thE = o; o += 8 * PL;   L.k_mult = o; o += 8 * PL;
@@ -55,7 +55,7 @@ static inline __host__ __device__ VgxQuadgLayout vgx_quadg_layout(int PL, int S,
     L.s_pop = q; q += 8 * PL;  L.s_inf = q; q += 8 * PL;  L.s_imm = q; q += 8 * PL;  L.s_mebm = q; q += 8 * PL;  L.s_cd = q; q += 8 * PL;
     L.s_cc = q; q += 8 * 8;
     L.s_seg = q; q += 8 * (NSEG > 0 ? NSEG : 1);
-    L.s_rec = q; q += 8 * VGX_QG_MAX_W;
+    L.s_rec = q; q += 8 * W;     // (the model's own record length: at 64 populations the 192 bytes a row saves are the eighth wavefront of a CU)
     L.s_ts = q; q += 8 * PL;   L.s_ti = q; q += 8 * PL;
     L.s_cnt = q; q += 8 * 8;   L.s_inc = q; q += 8 * 2;
     L.s_nocc = q; q += 4 * PL; L.s_lock = q; q += 4 * PL;

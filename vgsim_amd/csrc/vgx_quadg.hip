@@ -60,7 +60,7 @@ static __device__ __forceinline__ void quadg_body(const VgxDirectArgs &a, const 
     const int64_t rep = live ? rep_raw : R - 1;   // idle rows shadow the last replicate read-only
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const VgxQuadgLayout L = vgx_quadg_layout(PL, S, C, CB, NSEG);
+    const VgxQuadgLayout L = vgx_quadg_layout(PL, S, C, CB, NSEG, W);
     double *k_as = (double *)(smem + L.k_as), *k_thS = (double *)(smem + L.k_thS), *k_thE = (double *)(smem + L.k_thE);
     double *k_mult = (double *)(smem + L.k_mult), *k_d = (double *)(smem + L.k_d), *k_s = (double *)(smem + L.k_s);
     double *k_tm = (double *)(smem + L.k_tm), *k_cbb = (double *)(smem + L.k_cbb), *k_sig = (double *)(smem + L.k_sig);
@@ -1299,7 +1299,7 @@ extern "C" __attribute__((visibility("hidden"))) hipError_t vgxi_launch_quadg(co
                                                                              hipStream_t stream) {
     const int P = a->p.P;
     const int NS = P <= 16 ? 1 : P <= 32 ? 2 : P <= 64 ? 4 : 8;
-    const VgxQuadgLayout L = vgx_quadg_layout(16 * NS, a->p.S, a->p.C, a->p.CB, qa->nseg);
+    const VgxQuadgLayout L = vgx_quadg_layout(16 * NS, a->p.S, a->p.C, a->p.CB, qa->nseg, qa->W);
     const bool rec = a->p.recombination != 0.0;
     void (*k)(VgxDirectArgs, VgxQuadgArgs) =
         rec ? (NS == 1 ? vgx_quadg_kernel_p16_rec : NS == 2 ? vgx_quadg_kernel_p32_rec : NS == 4 ? vgx_quadg_kernel_p64_rec : vgx_quadg_kernel_p128_rec)
