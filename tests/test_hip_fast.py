@@ -52,6 +52,32 @@ def test_fast_wave_kernel_integer_columns_match_oracle(oracle_mod, name):
     _assert_tier_b(hip, ref, name)
 
 
+@pytest.mark.parametrize("name", ["g9_short", "p70", "stress_h256"])
+def test_fast_request_on_a_general_model_runs_the_exact_fast_kernels(oracle_mod, name):
+    """A general model (several classes / groups / NPIs: what the FAST row kernel refuses) asked for in FAST mode: the exact row /
+    latency kernels run it — their output is what FAST promises, and they are the faster path (2.5e8 -> 1.4e9 events/s on the
+    Table-3 model; tools/probe_fast_general.py).  Here: the kernel that ran, and results equal to the exact oracle bit for bit."""
+    hip = helpers.run_case_hip(name, mode="fast").simulation
+    assert hip._engine.last_kernel in ("solo", "quadg"), hip._engine.last_kernel
+    helpers.assert_models_equal(hip, helpers.run_case_oracle(oracle_mod, name).simulation, name)
+
+
+def test_ensembles_with_recombination_do_not_take_the_lane_kernel():
+    """Round 3's automatic choice gave ensembles of models with recombination to the lane kernel (1.0e7 events/s at 16 384 replicates
+    against 7.5e8 on the latency kernel and 6.4e8 on the general row kernel: tools/probe_recomb_ens.py)."""
+    from vgsim_amd import Simulator
+    from vgsim_amd.ensemble import Ensemble
+    ctor, phases = models.CASES["recomb_a"]
+    with helpers.quiet():
+        sim = Simulator(**ctor)
+    phases[0][0](sim)
+    for R in (8, 4096):
+        ens = Ensemble(sim, R)
+        ens.simulate(500, sample_size=10 ** 9)
+        assert ens.engine.last_kernel in ("solo", "quadg"), (R, ens.engine.last_kernel)
+        ens.close()
+
+
 def test_fast_ensemble_matches_exact_ensemble():
     """Replicate ensembles: FAST and EXACT agree on every replicate's counters and final compartments."""
     from vgsim_amd import Simulator
