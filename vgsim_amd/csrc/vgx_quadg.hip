@@ -23,6 +23,8 @@
 // groups of zero susceptibility left out (they add +0.0) and common prefixes (sn, sigma) of different classes evaluated once:
 // same operations on the same operands in the same order, so every class gets the reference's bits.
 #include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <stdint.h>
 #include "vgx_dev.h"
 #include "vgx_rng.h"
@@ -1307,6 +1309,11 @@ extern "C" __attribute__((visibility("hidden"))) hipError_t vgxi_launch_quadg(co
     hipError_t err = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, L.total);
     if (err != hipSuccess) return err;
     const unsigned grid = (unsigned)((a->n_replicates + 3) / 4);
+    if (getenv("VGX_TIMING")) {   // diagnostics: how many of these wavefronts a CU holds (LDS and registers: a few hundred bytes decide)
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)k, 64, (size_t)L.total) == hipSuccess)
+            fprintf(stderr, "vgx_quadg: %d populations (%d slots), LDS %d B per wavefront, %d wavefronts per CU\n", P, NS, L.total, nb);
+    }
     hipLaunchKernelGGL(k, dim3(grid), dim3(64), (size_t)L.total, stream, *a, *qa);
     return hipGetLastError();
 }

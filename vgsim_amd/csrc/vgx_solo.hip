@@ -34,6 +34,8 @@
 // Exact mode.  Recombinant births (pyx:575-596) take the general path of event().  One wavefront per replicate: ensembles run as
 // independent wavefronts.
 #include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <stdint.h>
 #include "vgx_dev.h"
 #include "vgx_rng.h"
@@ -1448,6 +1450,11 @@ extern "C" __attribute__((visibility("hidden"))) hipError_t vgxi_launch_solo(con
     if (err != hipSuccess) return err;
     VgxSoloKArgs ka;
     ka.a = *a; ka.sa = *sa;
+    if (getenv("VGX_TIMING")) {   // diagnostics: wavefronts of this instantiation a CU holds
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)k, 64, (size_t)L.total) == hipSuccess)
+            fprintf(stderr, "vgx_solo: LDS %d B per wavefront, %d wavefronts per CU\n", (int)L.total, nb);
+    }
     hipLaunchKernelGGL(k, dim3((unsigned)a->n_replicates), dim3(64), (size_t)L.total, stream, ka);
     return hipGetLastError();
 }
