@@ -32,7 +32,7 @@ struct VgxQuadgLayout {
     int k_as, k_thS, k_thE, k_mult, k_d, k_s, k_tm, k_cbb, k_sig, k_cumul, k_trans, k_segsig, k_jump;
     int k_bidx, k_stype, k_segpar, k_segsn, k_cbseg;
     int rows, row_bytes;
-    int s_pop, s_inf, s_imm, s_mebm, s_cd, s_cc, s_seg, s_rec, s_ts, s_ti, s_cnt, s_inc, s_nocc, s_lock;   // inside a row's block
+    int s_inf, s_imm, s_mebm, s_cd, s_cc, s_seg, s_rec, s_ts, s_ti, s_cnt, s_inc, s_nocc, s_lock;   // inside a row's block
     int total;
 };
 
@@ -52,7 +52,7 @@ static inline __host__ __device__ VgxQuadgLayout vgx_quadg_layout(int PL, int S,
     o = (o + 15) & ~15;
     L.rows = o;
     int q = 0;
-    L.s_pop = q; q += 8 * PL;  L.s_inf = q; q += 8 * PL;  L.s_imm = q; q += 8 * PL;  L.s_mebm = q; q += 8 * PL;  L.s_cd = q; q += 8 * PL;
+    L.s_inf = q; q += 8 * PL;  L.s_imm = q; q += 8 * PL;  L.s_mebm = q; q += 8 * PL;  L.s_cd = q; q += 8 * PL;
     L.s_cc = q; q += 8 * 8;
     L.s_seg = q; q += 8 * (NSEG > 0 ? NSEG : 1);
     L.s_rec = q; q += 8 * W;     // (the model's own record length: at 64 populations the 192 bytes a row saves are the eighth wavefront of a CU)

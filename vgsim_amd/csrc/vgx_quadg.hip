@@ -71,7 +71,10 @@ static __device__ __forceinline__ void quadg_body(const VgxDirectArgs &a, const 
     int32_t *k_bidx = (int32_t *)(smem + L.k_bidx), *k_stype = (int32_t *)(smem + L.k_stype);
     int32_t *k_segpar = (int32_t *)(smem + L.k_segpar), *k_segsn = (int32_t *)(smem + L.k_segsn), *k_cbseg = (int32_t *)(smem + L.k_cbseg);
     unsigned char *blk = smem + L.rows + row * L.row_bytes;
-    double *s_pop = (double *)(blk + L.s_pop), *s_inf = (double *)(blk + L.s_inf), *s_imm = (double *)(blk + L.s_imm);
+    double *s_inf = (double *)(blk + L.s_inf), *s_imm = (double *)(blk + L.s_imm);
+    // popRate[pn] = infectPopRate[pn] + immunePopRate[pn] (pyx:534) is formed where it is read: the same addition, and the block of
+    // a wavefront at 97-112 populations stays within a fifth of a CU's LDS
+#define S_POP(i) (s_inf[(i)] + s_imm[(i)])
     double *s_mebm = (double *)(blk + L.s_mebm), *s_cd = (double *)(blk + L.s_cd), *s_cc = (double *)(blk + L.s_cc);
     double *s_seg = (double *)(blk + L.s_seg);
     double *s_recd = (double *)(blk + L.s_rec);
@@ -125,7 +128,7 @@ static __device__ __forceinline__ void quadg_body(const VgxDirectArgs &a, const 
         for (int s = 0; s < NS; ++s) {
             const int pq = s * 16 + rl;
             const bool ok = pq < P;
-            s_pop[pq] = 0.0; s_inf[pq] = 0.0; s_imm[pq] = 0.0;
+            s_inf[pq] = 0.0; s_imm[pq] = 0.0;
             s_mebm[pq] = ok ? qa.mebm0[pq] : 0.0;
             const double cdv = ok ? gD[PD_CD * P + pq] : 0.0;
             s_cd[pq] = cdv;
@@ -318,13 +321,13 @@ static __device__ __forceinline__ void quadg_body(const VgxDirectArgs &a, const 
                     if (!any && !(cs < rr_)) { any = true; slot = s; cin = clast; }
                     clast = cs;
                 }
-                const double w = s_pop[slot * 16 + rl];
+                const double w = S_POP(slot * 16 + rl);
                 double tot_;
                 const double pre = row_scan16(w, cin, tot_);
                 const int q = row_min(any && slot * 16 + rl < P && !(pre < rr_) ? rl : 16);
                 double total, wi;
                 if (q < 16) { pi = slot * 16 + q; total = rowget_f64(pre, q); wi = rowget_f64(w, q); }
-                else { pi = P - 1; total = clast; wi = s_pop[P - 1]; }       // clamp at n-1 (fc:26)
+                else { pi = P - 1; total = clast; wi = S_POP(P - 1); }       // clamp at n-1 (fc:26)
                 if (evn && wi == 0.0) err = G_ERR_ZERO_WEIGHT + 256 * 1;
                 rn = (rr_ - (total - wi)) / wi;
                 choose = rn * wi;                    // pyx:493: rn * popRate[pi]
@@ -1072,7 +1075,6 @@ static __device__ __forceinline__ void quadg_body(const VgxDirectArgs &a, const 
                 if (d_imm && rl == 0) s_imm[pu] = v;
             }
             WSYNC();
-            if (act && rl == 0) s_pop[pu] = s_inf[pu] + s_imm[pu];
             rec_store(pu, act);
         }
         if (maxu > 0) {
@@ -1081,7 +1083,7 @@ static __device__ __forceinline__ void quadg_body(const VgxDirectArgs &a, const 
                 double carry = 0.0, cend[NS];
 #pragma unroll
                 for (int s = 0; s < NS; ++s) {
-                    const double w = s_pop[s * 16 + rl];      // lanes beyond P hold +0.0
+                    const double w = S_POP(s * 16 + rl);      // lanes beyond P hold +0.0
                     if (s * 16 < P) carry = row_sum16(w, carry);
                     cend[s] = carry;
                 }
@@ -1246,7 +1248,7 @@ static __device__ __forceinline__ void quadg_body(const VgxDirectArgs &a, const 
         for (int s = 0; s < NS; ++s) {
             const int pn = s * 16 + rl;
             if (pn < P) {
-                gD[PD_POPRATE * P + pn] = s_pop[pn];
+                gD[PD_POPRATE * P + pn] = S_POP(pn);
                 gD[PD_INFECT * P + pn] = s_inf[pn];
                 gD[PD_IMMUNE * P + pn] = s_imm[pn];
                 gD[PD_MIG * P + pn] = s_mebm[pn] * (double)s_ts[pn] * (double)(gI - s_ti[pn]);
@@ -1287,25 +1289,34 @@ static __device__ __forceinline__ void quadg_body(const VgxDirectArgs &a, const 
     }
 }
 
-extern "C" __global__ void __launch_bounds__(64, VGX_QUADG_WAVES) vgx_quadg_kernel_p16(VgxDirectArgs a, VgxQuadgArgs qa) { quadg_body<1>(a, qa); }
-extern "C" __global__ void __launch_bounds__(64, VGX_QUADG_WAVES) vgx_quadg_kernel_p32(VgxDirectArgs a, VgxQuadgArgs qa) { quadg_body<2>(a, qa); }
-extern "C" __global__ void __launch_bounds__(64, VGX_QUADG_WAVES) vgx_quadg_kernel_p64(VgxDirectArgs a, VgxQuadgArgs qa) { quadg_body<4>(a, qa); }
-extern "C" __global__ void __launch_bounds__(64, VGX_QUADG_WAVES) vgx_quadg_kernel_p128(VgxDirectArgs a, VgxQuadgArgs qa) { quadg_body<8>(a, qa); }
-extern "C" __global__ void __launch_bounds__(64, VGX_QUADG_WAVES) vgx_quadg_kernel_p16_rec(VgxDirectArgs a, VgxQuadgArgs qa) { quadg_body<1, true>(a, qa); }
-extern "C" __global__ void __launch_bounds__(64, VGX_QUADG_WAVES) vgx_quadg_kernel_p32_rec(VgxDirectArgs a, VgxQuadgArgs qa) { quadg_body<2, true>(a, qa); }
-extern "C" __global__ void __launch_bounds__(64, VGX_QUADG_WAVES) vgx_quadg_kernel_p64_rec(VgxDirectArgs a, VgxQuadgArgs qa) { quadg_body<4, true>(a, qa); }
-extern "C" __global__ void __launch_bounds__(64, VGX_QUADG_WAVES) vgx_quadg_kernel_p128_rec(VgxDirectArgs a, VgxQuadgArgs qa) { quadg_body<8, true>(a, qa); }
+// one instantiation per number of 16-population slots (LDS and chain lengths follow the model's populations: 100 populations take seven
+// slots — five wavefronts per CU and seven chain rows where eight slots gave four and eight), each with and without recombination
+#define QUADG_KERNELS(NSLOT, PMAX)                                                                                                                  \
+    extern "C" __global__ void __launch_bounds__(64, VGX_QUADG_WAVES) vgx_quadg_kernel_p##PMAX(VgxDirectArgs a, VgxQuadgArgs qa) { quadg_body<NSLOT>(a, qa); } \
+    extern "C" __global__ void __launch_bounds__(64, VGX_QUADG_WAVES) vgx_quadg_kernel_p##PMAX##_rec(VgxDirectArgs a, VgxQuadgArgs qa) { quadg_body<NSLOT, true>(a, qa); }
+QUADG_KERNELS(1, 16)
+QUADG_KERNELS(2, 32)
+QUADG_KERNELS(3, 48)
+QUADG_KERNELS(4, 64)
+QUADG_KERNELS(5, 80)
+QUADG_KERNELS(6, 96)
+QUADG_KERNELS(7, 112)
+QUADG_KERNELS(8, 128)
 
 // ---- host-side launcher ----
 extern "C" __attribute__((visibility("hidden"))) hipError_t vgxi_launch_quadg(const VgxDirectArgs *a, const VgxQuadgArgs *qa,
                                                                              hipStream_t stream) {
     const int P = a->p.P;
-    const int NS = P <= 16 ? 1 : P <= 32 ? 2 : P <= 64 ? 4 : 8;
+    const int NS = (P + 15) / 16;
     const VgxQuadgLayout L = vgx_quadg_layout(16 * NS, a->p.S, a->p.C, a->p.CB, qa->nseg, qa->W);
     const bool rec = a->p.recombination != 0.0;
-    void (*k)(VgxDirectArgs, VgxQuadgArgs) =
-        rec ? (NS == 1 ? vgx_quadg_kernel_p16_rec : NS == 2 ? vgx_quadg_kernel_p32_rec : NS == 4 ? vgx_quadg_kernel_p64_rec : vgx_quadg_kernel_p128_rec)
-            : (NS == 1 ? vgx_quadg_kernel_p16 : NS == 2 ? vgx_quadg_kernel_p32 : NS == 4 ? vgx_quadg_kernel_p64 : vgx_quadg_kernel_p128);
+    typedef void (*Kern)(VgxDirectArgs, VgxQuadgArgs);
+    static const Kern plain[8] = {vgx_quadg_kernel_p16, vgx_quadg_kernel_p32, vgx_quadg_kernel_p48, vgx_quadg_kernel_p64,
+                                  vgx_quadg_kernel_p80, vgx_quadg_kernel_p96, vgx_quadg_kernel_p112, vgx_quadg_kernel_p128};
+    static const Kern with_rec[8] = {vgx_quadg_kernel_p16_rec, vgx_quadg_kernel_p32_rec, vgx_quadg_kernel_p48_rec, vgx_quadg_kernel_p64_rec,
+                                     vgx_quadg_kernel_p80_rec, vgx_quadg_kernel_p96_rec, vgx_quadg_kernel_p112_rec, vgx_quadg_kernel_p128_rec};
+    if (NS < 1 || NS > 8) return hipErrorInvalidValue;
+    const Kern k = rec ? with_rec[NS - 1] : plain[NS - 1];
     hipError_t err = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, L.total);
     if (err != hipSuccess) return err;
     const unsigned grid = (unsigned)((a->n_replicates + 3) / 4);
