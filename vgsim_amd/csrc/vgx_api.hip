@@ -103,7 +103,7 @@ struct vgx_engine {
         r_evrate, r_evcols, r_locrec, r_loctime, r_lociter, r_farate, r_fakey, r_traj, r_prof, r_qeff, r_qmebm, r_qflag;
     // tau-leaping (dense compartments)
     DevBuf t_I, t_S, t_dChk, t_dApp, t_dSi, t_dTot, t_totInf, t_gI, t_cd, t_lock, t_F, t_eff, t_Aeff, t_Gout, t_dS,
-        t_taubits, t_tau, t_time, t_flags, t_counters, t_cnttry, t_cntpop, t_front, t_frontn, t_occ, t_occn, t_occpop, t_mev, t_mevn, t_mevbase, t_locn, t_mutcum, t_migcdf, t_migIn, t_mutHi, t_colT, t_colTW, t_inc, t_incn, t_sieve, t_sieveskip, t_big, t_bign, t_res, t_susp, t_suspn, t_stkey, t_stval, t_dChkTot, t_q, t_qn, t_hist, t_I8, t_dSpart, t_tmax8, t_iI, t_iS, t_slog, t_sres;
+        t_taubits, t_tau, t_time, t_flags, t_counters, t_cnttry, t_cntpop, t_front, t_frontn, t_occ, t_occn, t_occpop, t_mev, t_mevn, t_mevbase, t_locn, t_mutcum, t_migcdf, t_migIn, t_mutHi, t_colT, t_colTW, t_inc, t_incn, t_sieve, t_sievepop, t_sieveskip, t_big, t_bign, t_res, t_susp, t_suspn, t_stkey, t_stval, t_dChkTot, t_q, t_qn, t_hist, t_I8, t_dSpart, t_tmax8, t_iI, t_iS, t_slog, t_sres;
     std::vector<int64_t> tau_sieve_skipped;   // [R] tries left out by the sieve in the last tau call
     bool last_was_tau = false;
     bool tau_staged = false;              // vgx_stage_tau put the current start state on the device in the tau kernels' layout
@@ -1420,6 +1420,7 @@ extern "C" int vgx_simulate_tau(vgx_engine *e, int64_t iterations, int64_t sampl
     rc |= ensure(e, e->t_stval, (size_t)(R * st_size) * 8);
     rc |= ensure(e, e->t_suspn, (size_t)R * 8);
     rc |= ensure(e, e->t_sieve, (size_t)R * VGX_SIEVE_K * 8);
+    rc |= ensure(e, e->t_sievepop, (size_t)(R * P) * VGX_SIEVE_K * 8);
     rc |= ensure(e, e->t_sieveskip, (size_t)R * 8);
     rc |= ensure(e, e->t_cnttry, (size_t)R * 8 * 8);
     rc |= ensure(e, e->t_cntpop, (size_t)(R * P) * 8 * 8);
@@ -1455,6 +1456,7 @@ extern "C" int vgx_simulate_tau(vgx_engine *e, int64_t iterations, int64_t sampl
     HIPCHECK(e, hipMemset(e->t_bign.p, 0, (size_t)R * 8));
     HIPCHECK(e, hipMemset(e->t_suspn.p, 0, (size_t)R * 8));
     HIPCHECK(e, hipMemset(e->t_sieve.p, 0, (size_t)R * VGX_SIEVE_K * 8));
+    HIPCHECK(e, hipMemset(e->t_sievepop.p, 0, (size_t)(R * P) * VGX_SIEVE_K * 8));
     HIPCHECK(e, hipMemset(e->t_sieveskip.p, 0, (size_t)R * 8));
     HIPCHECK(e, hipMemset(e->t_cnttry.p, 0, (size_t)R * 64));
     HIPCHECK(e, hipMemset(e->t_cntpop.p, 0, (size_t)(R * P) * 64));
@@ -1560,7 +1562,7 @@ extern "C" int vgx_simulate_tau(vgx_engine *e, int64_t iterations, int64_t sampl
     }
     // enough blocks of the events kernel to fill the chip whatever the number of shards (mid-size models have few)
     a.ev_split = (int32_t)std::max<int64_t>(1, std::min<int64_t>(q_shard_max / 64, 4096 / std::max<int64_t>(1, q_shards * R)));
-    a.sieve = (double *)e->t_sieve.p; a.sieve_skipped = (int64_t *)e->t_sieveskip.p;
+    a.sieve = (double *)e->t_sieve.p; a.sieve_pop = (double *)e->t_sievepop.p; a.sieve_skipped = (int64_t *)e->t_sieveskip.p;
     // vgx_run_opts.reserved[0] = 1: run every try of the halving loop; with few compartments no try is ever a certain rejection
     a.sieve_on = (o.reserved[0] == 1 || P * H < 32768) ? 0 : 1;
     {   // low sites (the last min(sites, 6)): equally likely derived states at each of them?  one common rate?

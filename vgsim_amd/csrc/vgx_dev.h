@@ -243,6 +243,7 @@ struct VgxTauArgs {
     double *loc_time;    // [R][VGX_LOC_CAP]
     // sieve of the halving loop (vgx_tau_sieve_kernel): lower bounds on the expected number of compartments that fail
     // the bounds check at tau * 2^-k, k = 0..VGX_SIEVE_K-1
+    double *sieve_pop;   // [R][P][VGX_SIEVE_K] the populations' parts of it (histogram form), summed by vgx_tau_sieve_pick_kernel
     double *sieve;       // [R][VGX_SIEVE_K]
     int64_t *sieve_skipped;  // [R] tries skipped so far in this call
     int32_t sieve_on;

@@ -1275,15 +1275,35 @@ extern "C" __global__ void __launch_bounds__(64) vgx_tau_sieve_hist_kernel(VgxTa
     for (int k = 0; k < VGX_SIEVE_K; ++k) {
         double v = acc[k];
         for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
-        if (threadIdx.x == 0 && v > 0.0) atomicAdd(&a.sieve[(int64_t)rep * VGX_SIEVE_K + k], v * 0.99);
+        // the population's part: summed over the populations by vgx_tau_sieve_pick_kernel in a fixed order (256 blocks adding to the
+        // same 16 doubles were worked off one after the other: 40 us per step, and the sum depended on the order)
+        if (threadIdx.x == 0) a.sieve_pop[((int64_t)rep * P + pn) * VGX_SIEVE_K + k] = v * 0.99;
     }
 }
 
 // Starts the halving loop of the step at the first try that is not certain to fail.  grid = R, one thread.
 extern "C" __global__ void __launch_bounds__(64) vgx_tau_sieve_pick_kernel(VgxTauArgs a) {
     const int rep = blockIdx.x;
-    if (threadIdx.x != 0 || !a.active[rep]) return;
+    if (!a.active[rep]) return;
     double *E = a.sieve + (int64_t)rep * VGX_SIEVE_K;
+    if (a.hist) {   // the populations' parts (vgx_tau_sieve_hist_kernel): lane-strided partial sums, then a tree — one order, always
+        const int P = a.p.P;
+        double acc[VGX_SIEVE_K];
+#pragma unroll
+        for (int k = 0; k < VGX_SIEVE_K; ++k) acc[k] = 0.0;
+        for (int pn = threadIdx.x; pn < P; pn += 64) {      // (a population's sixteen values: two cache lines, the loads independent)
+            const double *sp = a.sieve_pop + ((int64_t)rep * P + pn) * VGX_SIEVE_K;
+#pragma unroll
+            for (int k = 0; k < VGX_SIEVE_K; ++k) acc[k] += sp[k];
+        }
+#pragma unroll
+        for (int k = 0; k < VGX_SIEVE_K; ++k) {
+            double v = acc[k];
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+            if (threadIdx.x == 0) E[k] += v;
+        }
+    }
+    if (threadIdx.x != 0) return;
     int k0 = 0;
     while (k0 < VGX_SIEVE_K && E[k0] > VGX_SIEVE_MIN_FAILS) k0 += 1;
     for (int k = 0; k < VGX_SIEVE_K; ++k) E[k] = 0.0;
