@@ -1650,13 +1650,14 @@ extern "C" int vgx_simulate_tau(vgx_engine *e, int64_t iterations, int64_t sampl
     // Small models: the whole step loop on the device, one workgroup per replicate (vgx_taus.hip).  VGX_TAU_STEP_KERNELS=1 and the
     // test switches of the step kernels (dense validation modes, the large-model draw thresholds) keep the step kernels.
     const int64_t slog_cap = std::max<int64_t>(ev_size - ((ev_ptr_start <= 100 && iterations > 100) ? 0 : ev_ptr_start), 1);
-    // One workgroup (one CU) runs a replicate's whole loop: that wins where a step is launch-bound (few channels) or where there are
-    // replicates to fill the chip with; one replicate of a mid-size model (tens of thousands of channels, every draw a PTRS
-    // sample) is faster spread over the chip by the step kernels (256 haplotypes x 5 populations, 3e6 infected: 8.5e3 against
-    // 2.0e3 steps/s).
+    // One workgroup (one CU) runs a replicate's whole loop: that wins where a step is launch-bound (up to ~2000 compartments at any
+    // ensemble size) or where there are replicates to fill the chip with; few replicates of a larger model are faster spread over the
+    // chip by the step kernels.  Measured in round 4 (tools/probe_tau_single.py, steps/s of ONE trajectory, step kernels / loop):
+    // 256 compartments 8.9e3 / 5.3e4, 1280: 8.6e3 / 1.46e4 (1.2e6 infected: 7.1e3 / 6.5e3), 2048: 8.7e3 / 9.3e3, 4096: 8.3e3 / 3.9e3,
+    // 8192: 8.2e3 / 3.1e3; at 32 replicates 4096 compartments are level (1.4e5 / 1.2e5), from 128 on the loop leads everywhere.
     const int64_t n_channels = P * H * (2 + 3 * e->d.sites + S + (P - 1) * S) + P * S * S;
     bool use_small = P * H <= VGX_TAUS_MAX_CELLS && P <= VGX_TAUS_MAX_P && S <= VGX_TAUS_MAX_S && e->d.sites <= 15 && sparse_default &&
-                     e->C <= VGX_TAUS_MAX_C && e->CB <= VGX_TAUS_MAX_CB && (n_channels <= 4096 || R >= 32) &&
+                     e->C <= VGX_TAUS_MAX_C && e->CB <= VGX_TAUS_MAX_CB && (n_channels <= 4096 || P * H <= 2048 || R >= 32) &&
                      vgx_taus_lds_bytes(P, H, S, e->C, e->CB) <= 150 * 1024 && (double)R * (double)slog_cap * 24.0 <= 8e9;
     {
         const char *fs = getenv("VGX_TAU_STEP_KERNELS"), *th = getenv("VGX_TAU_LARGE_MODEL_THRESHOLDS");
