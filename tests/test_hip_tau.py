@@ -770,6 +770,39 @@ def test_lists_and_front_pass_with_several_replicates(monkeypatch):
     assert a[0][2] > 0 and not np.array_equal(a[0][3], a[1][3])
 
 
+@pytest.mark.parametrize("sites,pops", [(2, 3), (3, 4)])
+def test_small_model_loop_does_not_depend_on_the_workgroup_size(monkeypatch, sites, pops):
+    """vgx_taus.hip runs a replicate's step loop in one workgroup of 64, 256 or 512 threads (few replicates: many lanes per step; large
+    ensembles: many small workgroups per CU).  Streams are keyed by the channel and the sums are formed in one order, so the three
+    give the same runs: same states and times after 300 steps of three replicates of a model with two susceptibility groups."""
+    from vgsim_amd import Simulator
+    from vgsim_amd.ensemble import Ensemble
+
+    def run(tt):
+        monkeypatch.setenv("VGX_TAUS_THREADS", str(tt))
+        with helpers.quiet():
+            s = Simulator(number_of_sites=sites, populations_number=pops, number_of_susceptible_groups=2, seed=7)
+        s.set_transmission_rate(2.5); s.set_recovery_rate(0.9); s.set_sampling_rate(0.1); s.set_mutation_rate(0.05)
+        s.set_total_migration_probability(0.002); s.set_population_size(10 ** 6)
+        s.set_susceptibility_type(1); s.set_susceptibility(0.3, susceptibility_type=1); s.set_immunity_transition(0.02, source=1, target=0)
+        with helpers.quiet():
+            s.simulate(2000, sample_size=10 ** 12)
+        ens = Ensemble(s, 3)
+        ens.simulate_tau(300, sample_size=10 ** 15, seeds=np.array([5, 6, 7], dtype=np.int64))
+        out = []
+        for r in range(3):
+            st = ens.replicate_state(r)
+            out.append((st.infectious.copy(), st.susceptible.copy(), st.currentTime))
+        ens.close()
+        return out
+    ref = run(512)
+    for tt in (64, 256):
+        got = run(tt)
+        for x, y in zip(ref, got):
+            assert np.array_equal(x[0], y[0]) and np.array_equal(x[1], y[1]) and x[2] == y[2], tt
+    assert ref[0][2] > 0 and not np.array_equal(ref[0][0], ref[1][0])
+
+
 @pytest.mark.parametrize("sites,P,S", [(8, 3, 2), (2, 3, 1)])
 def test_staged_start_state_gives_the_same_run(sites, P, S):
     """vgx_stage_tau (snapshot, conversion and upload of the start state ahead of the call: the bench's hand-over) against

@@ -6,7 +6,9 @@
 #define VGX_TAUS_MAX_CELLS 8192    // popNum * hapNum: the compartments and their two delta arrays live in LDS (12 B each)
 #define VGX_TAUS_MAX_P 64
 #define VGX_TAUS_MAX_S 8
+#ifndef VGX_TAUS_TB
 #define VGX_TAUS_TB 512
+#endif
 
 struct VgxTausArgs {
     VgxDevParams p;

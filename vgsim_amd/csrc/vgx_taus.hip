@@ -17,13 +17,13 @@
 // (LDS atomics commute).  The bounds check books migrants on their SOURCE compartment as upstream does (pyx:2473 vs pyx:2548).
 // Distributional parity with the oracle: tests/test_hip_tau.py.
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include <stdint.h>
 #include "../../include/vgx.h"
 #include "vgx_dev.h"
 #include "vgx_taus.h"
 #include "vgx_tau_rng.h"
 
-#define TT VGX_TAUS_TB
 enum { TY_BIRTH = 0, TY_DEATH = 1, TY_SAMPLING = 2, TY_MUTATION = 3, TY_SUSCCHANGE = 4, TY_MIGRATION = 5 };
 
 // In-kernel stamps of the diagnostic build (-DVGX_PROFILE; tools/profile_taus.py): shader cycles per phase of the step loop, thread 0 of
@@ -43,7 +43,12 @@ extern "C" int vgx_taus_get_profile(unsigned long long *out, int clear) {
 #else
 #define TSPROF(i)
 #endif
-extern "C" __global__ void __launch_bounds__(TT) vgx_taus_kernel(VgxTausArgs a) {
+// TT = threads of the workgroup.  One trajectory (or a few) wants many lanes per step (512: two rounds of the 528 channels of the 16 x 3
+// model); ensembles that fill the chip want many small workgroups per CU instead — measured (tools/probe_taus_threads.py): 16 x 3,
+// 2048 replicates: 4.0e7 steps/s at 64 threads against 1.9e7 at 512; 64 x 4 and 256 x 5, 512 replicates: 1.0e7 / 2.65e6 at 256
+// against 8.4e6 / 2.4e6; one replicate alone: 7.1e4 / 3.4e4 / 9.6e3 at 512 against 2.6e4 / 8.5e3 / 2.0e3 at 64.
+template <int TT>
+static __device__ __forceinline__ void taus_body(const VgxTausArgs &a) {
     const VgxDevParams &p = a.p;
     const int rep = blockIdx.x;
     const int P = p.P, H = p.H, S = p.S, sites = p.sites, PH = P * H;
@@ -508,10 +513,20 @@ extern "C" __global__ void __launch_bounds__(TT) vgx_taus_kernel(VgxTausArgs a) 
     }
 }
 
+extern "C" __global__ void __launch_bounds__(64) vgx_taus_kernel_t64(VgxTausArgs a) { taus_body<64>(a); }
+extern "C" __global__ void __launch_bounds__(256) vgx_taus_kernel_t256(VgxTausArgs a) { taus_body<256>(a); }
+extern "C" __global__ void __launch_bounds__(512) vgx_taus_kernel(VgxTausArgs a) { taus_body<512>(a); }
+
 extern "C" __attribute__((visibility("hidden"))) hipError_t vgxi_launch_taus(const VgxTausArgs *a, hipStream_t s) {
     const size_t lds = vgx_taus_lds_bytes(a->p.P, a->p.H, a->p.S, a->p.C, a->p.CB);
-    hipError_t err = hipFuncSetAttribute((const void *)vgx_taus_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    // the workgroup size: see taus_body (VGX_TAUS_THREADS = 64 / 256 / 512 forces one, for comparisons)
+    const int64_t channels = (int64_t)a->p.P * a->p.H * (2 + 3 * a->p.sites + a->p.S + (a->p.P - 1) * a->p.S);
+    int tt = 512;
+    if (a->R >= 512) tt = channels <= 1024 ? 64 : 256;
+    if (const char *ft = getenv("VGX_TAUS_THREADS")) { const int v = atoi(ft); if (v == 64 || v == 256 || v == 512) tt = v; }
+    void (*k)(VgxTausArgs) = tt == 64 ? vgx_taus_kernel_t64 : tt == 256 ? vgx_taus_kernel_t256 : vgx_taus_kernel;
+    hipError_t err = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (err != hipSuccess) return err;
-    hipLaunchKernelGGL(vgx_taus_kernel, dim3((unsigned)a->R), dim3(TT), lds, s, *a);
+    hipLaunchKernelGGL(k, dim3((unsigned)a->R), dim3((unsigned)tt), lds, s, *a);
     return hipGetLastError();
 }
