@@ -44,9 +44,9 @@ extern "C" int vgx_taus_get_profile(unsigned long long *out, int clear) {
 #define TSPROF(i)
 #endif
 // TT = threads of the workgroup.  One trajectory (or a few) wants many lanes per step (512: two rounds of the 528 channels of the 16 x 3
-// model); ensembles that fill the chip want many small workgroups per CU instead — measured (tools/probe_taus_threads.py): 16 x 3,
-// 2048 replicates: 4.0e7 steps/s at 64 threads against 1.9e7 at 512; 64 x 4 and 256 x 5, 512 replicates: 1.0e7 / 2.65e6 at 256
-// against 8.4e6 / 2.4e6; one replicate alone: 7.1e4 / 3.4e4 / 9.6e3 at 512 against 2.6e4 / 8.5e3 / 2.0e3 at 64.
+// model); ensembles that fill the chip want many small workgroups per CU instead — measured (tools/probe_taus_threads.py, steps/s of all
+// replicates): 16 x 3, 2048 replicates: 6.2e7 at 64 threads, 3.6e7 at 256, 2.2e7 at 512; 512 replicates: 1.8e7 / 3.5e7 / 2.2e7; 64:
+// 2.3e6 / 5.0e6 / 5.5e6; the 64 x 4 and 256 x 5 models switch at the same ensemble sizes.
 template <int TT>
 static __device__ __forceinline__ void taus_body(const VgxTausArgs &a) {
     const VgxDevParams &p = a.p;
@@ -520,9 +520,16 @@ extern "C" __global__ void __launch_bounds__(512) vgx_taus_kernel(VgxTausArgs a)
 extern "C" __attribute__((visibility("hidden"))) hipError_t vgxi_launch_taus(const VgxTausArgs *a, hipStream_t s) {
     const size_t lds = vgx_taus_lds_bytes(a->p.P, a->p.H, a->p.S, a->p.C, a->p.CB);
     // the workgroup size: see taus_body (VGX_TAUS_THREADS = 64 / 256 / 512 forces one, for comparisons)
-    const int64_t channels = (int64_t)a->p.P * a->p.H * (2 + 3 * a->p.sites + a->p.S + (a->p.P - 1) * a->p.S);
-    int tt = 512;
-    if (a->R >= 512) tt = channels <= 1024 ? 64 : 256;
+    // (tools/probe_taus_threads.py, 16 x 3 / 64 x 4 / 256 x 5 models at 64 ... 4096 replicates: 512 threads lead below two workgroups per CU,
+    // 256 from two to eight, 64 from eight on — whatever the model's size)
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+        if (cus <= 0) cus = 256;
+    }
+    int tt = a->R >= 8 * (int64_t)cus ? 64 : a->R >= 2 * (int64_t)cus ? 256 : 512;
     if (const char *ft = getenv("VGX_TAUS_THREADS")) { const int v = atoi(ft); if (v == 64 || v == 256 || v == 512) tt = v; }
     void (*k)(VgxTausArgs) = tt == 64 ? vgx_taus_kernel_t64 : tt == 256 ? vgx_taus_kernel_t256 : vgx_taus_kernel;
     hipError_t err = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
