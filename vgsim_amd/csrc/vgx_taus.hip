@@ -17,6 +17,7 @@
 // (LDS atomics commute).  The bounds check books migrants on their SOURCE compartment as upstream does (pyx:2473 vs pyx:2548).
 // Distributional parity with the oracle: tests/test_hip_tau.py.
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <stdlib.h>
 #include <stdint.h>
 #include "../../include/vgx.h"
@@ -529,7 +530,10 @@ extern "C" __attribute__((visibility("hidden"))) hipError_t vgxi_launch_taus(con
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
         if (cus <= 0) cus = 256;
     }
-    int tt = a->R >= 8 * (int64_t)cus ? 64 : a->R >= 2 * (int64_t)cus ? 256 : 512;
+    // workgroups a CU will hold at once: what the launch offers, and what fits its LDS (a model of 8192 compartments fills it alone)
+    const int64_t fit = std::max<int64_t>(1, (int64_t)(160 * 1024) / (int64_t)std::max<size_t>(lds, 1));
+    const int64_t per_cu = std::min<int64_t>(std::max<int64_t>(a->R / cus, 1), fit);
+    int tt = per_cu >= 8 ? 64 : per_cu >= 2 ? 256 : 512;
     if (const char *ft = getenv("VGX_TAUS_THREADS")) { const int v = atoi(ft); if (v == 64 || v == 256 || v == 512) tt = v; }
     void (*k)(VgxTausArgs) = tt == 64 ? vgx_taus_kernel_t64 : tt == 256 ? vgx_taus_kernel_t256 : vgx_taus_kernel;
     hipError_t err = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
