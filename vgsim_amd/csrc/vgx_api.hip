@@ -983,7 +983,8 @@ static int direct_core(vgx_engine *e, int64_t iterations, int64_t sample_size, f
     // (recombination: the single-trajectory kernel for few replicates of a model it takes, else the general row kernel, else the wavefront kernel)
     // (recombination, measured in round 4 — tools/probe_recomb_ens.py, 16 384 replicates of the recomb_a / recomb_pos models: the general row
     // kernel 6.4-6.9e8 events/s, the wavefront kernel 3.1-3.4e8, the lane kernel 1.0-1.2e7: the lane kernel only when it is asked for)
-    const bool use_lanes = o.kernel == 2 || (o.kernel == 0 && !recomb && lane_ok && P * H * S <= 4 && R >= 65536);
+    // (config 2, tools/probe_config2.py: 65 536 replicates 1.8e9 events/s here against 2.0e9 on the row kernel, 262 144: 4.0e9 against 2.1e9)
+    const bool use_lanes = o.kernel == 2 || (o.kernel == 0 && !recomb && lane_ok && P * H * S <= 4 && R >= 131072);
     // Four replicates per wavefront, one per 16-lane DPP row (vgx_quad.hip): one rate class, one susceptibility group,
     // at most 64 populations, no population that can switch its lockdown state, exact mode.
     bool quad_shape = !recomb && P <= 64 && S == 1 && e->C == 1 && e->CB == 1 && !ld_possible &&
@@ -1016,6 +1017,12 @@ static int direct_core(vgx_engine *e, int64_t iterations, int64_t sample_size, f
     // wavefronts per SIMD of this kernel beat it too (tools/probe_solo_ens.py, 16 384 replicates of the Table-3 model: K = 2 1.68e9
     // against 1.09e9 events/s, K = 10 1.37e9 against 1.09e9; K = 100, general layout, 150 KB of LDS: 4.7e7 against 3.6e8)
     bool solo_many = false;
+    if (solo_ok && quad_ok) {
+        // One-class models the latency kernel takes too: the row kernel needs four replicates per wavefront, so below 8192 replicates it
+        // cannot give every SIMD its two wavefronts (tools/probe_oneclass_small.py, config 2 and the one-class goldens: 2048 replicates
+        // 1.3-1.6e9 events/s here against 5e8 there, 4096: 1.4-1.7e9 against 1.0e9; from 8192 on the row kernel leads, 1.8-1.9e9 against 1.5-1.7e9)
+        solo_many = R < 8192 && vgx_solo_layout((int)P, (int)H, (int)S, (int)e->d.sites, soa.mig_in_lds).total <= 20 * 1024;
+    }
     if (solo_ok && !quad_ok) {
         const bool compact = e->h_so_ncls <= VGX_SOLO_ROWS && S <= VGX_SOLO_MAX_S && P <= 64 && (int64_t)e->h_so_maxnnz * P <= 32;
         solo_many = compact && vgx_solo_layout((int)P, (int)H, (int)S, (int)e->d.sites, soa.mig_in_lds).total <= 20 * 1024;
