@@ -108,6 +108,37 @@ def test_solo_replicates_equal_single_runs(oracle_mod, name, n_events):
     ens.close()
 
 
+@pytest.mark.parametrize("name,n_events", [("g1", 800), ("g5", 800), ("g6_short", 800)])
+def test_one_class_ensembles_below_8192_replicates_take_the_latency_kernel(oracle_mod, name, n_events):
+    """The automatic choice (vgx_api.hip, direct dispatch): a one-class model both this kernel and the one-class row kernel take
+    runs here below 8192 replicates; a few replicates out of 4096 against single oracle runs, and the row kernel from 8192 on."""
+    from vgsim_amd import Simulator
+    from vgsim_amd.ensemble import Ensemble
+    R = 4096
+    ctor, phases = models.CASES[name] if name in models.CASES else models.ORACLE_ONLY_CASES[name]
+    with helpers.quiet():
+        sim = Simulator(**ctor)
+    phases[0][0](sim)
+    seeds = np.arange(R, dtype=np.int64) * 7919 + 11
+    ens = Ensemble(sim, R, seeds=seeds)
+    res = ens.simulate(n_events, sample_size=10 ** 9, record_events=True)
+    assert ens.engine.last_kernel == "solo"
+    for r in (0, 1, 63, 64, 2047, 4095):
+        m = _single(oracle_mod, name, seeds[r], n_events)
+        assert res.events[r] == m.events.ptr, "replicate %d" % r
+        chain = ens.replicate_events(r)
+        assert np.array_equal(chain, m.events.as_array()[:, :m.events.ptr]), "replicate %d: %s" % (
+            r, helpers.describe_first_diff(chain, m.events.as_array(), m.events.ptr))
+        st = ens.replicate_state(r)
+        assert np.array_equal(st.infectious, m.infectious) and np.array_equal(st.susceptible, m.susceptible)
+        assert st.currentTime == m.currentTime
+    ens.close()
+    ens = Ensemble(sim, 8192, seeds=np.arange(8192, dtype=np.int64) + 5)
+    ens.simulate(50, sample_size=10 ** 9)
+    assert ens.engine.last_kernel == "quad"
+    ens.close()
+
+
 def _table3(K, M, seed):
     import bench
     return bench.make_table3(K, M, seed)
