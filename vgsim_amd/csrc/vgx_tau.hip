@@ -28,6 +28,7 @@
 #include "vgx_dev.h"
 #include "vgx_rng.h"
 #include "vgx_wave.h"
+#include "vgx_tau_lf.h"
 #include "vgx_tau_rng.h"
 
 // The tau path is validated distributionally (different random streams anyway), so FMA contraction is allowed
@@ -971,6 +972,7 @@ static __device__ __forceinline__ void d8_cells(const D8Ctx &c, int lane, double
                 }
             }
         }
+        sumI += (MODE == 2) ? (long long)Iv[0] + (long long)Iv[1] + (long long)Iv[2] + (long long)Iv[3] : (long long)s4;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int32_t Icell = Iv[j];
@@ -984,14 +986,18 @@ static __device__ __forceinline__ void d8_cells(const D8Ctx &c, int lane, double
                 drift = __builtin_fma(c.Bsum, mgT, drift);
                 sumMg += mgT;
             }
-            sumI += Icell;
             // pyx:2440-2444: candidate max(eps * X / 2, 1) / |drift| with eps * X in single precision; the numerator is 1 up to 66
             // hosts ((double)(0.03f * (float)X) / 2 > 1 from X = 67 on), and the smallest of those candidates is 1 / (largest |drift|)
-            const double ad = fabs(drift);
-            const bool large = Icell > 66;
-            ad_max = fmax(ad_max, large ? 0.0 : ad);          // (|drift| < 1e-8 is sorted out at the end)
-            if (MODE != 0 && __any(large && ad >= 1e-8)) {
-                if (large && ad >= 1e-8) cand_min = fmin(cand_min, ((double)(0.03f * (float)Icell) / 2.0) / ad);
+            if (MODE == 0) {
+                // (no count above 66 here; one v_max_f64 with the |.| modifier: fmax() would first canonicalise both operands — three)
+                asm("v_max_f64 %0, %1, |%2|" : "=v"(ad_max) : "v"(ad_max), "v"(drift));
+            } else {
+                const double ad = fabs(drift);
+                const bool large = Icell > 66;
+                ad_max = fmax(ad_max, large ? 0.0 : ad);          // (|drift| < 1e-8 is sorted out at the end)
+                if (__any(large && ad >= 1e-8)) {
+                    if (large && ad >= 1e-8) cand_min = fmin(cand_min, ((double)(0.03f * (float)Icell) / 2.0) / ad);
+                }
             }
             if (c.do_hist && Icell >= 1 && Icell <= VGX_HIST_X) atomicAdd(&c.hist[(Icell - 1) * 16 + (lane & 15)], 1u);
         }
@@ -2076,7 +2082,7 @@ extern "C" __global__ void __launch_bounds__(TB) vgx_tau_front_kernel(VgxTauArgs
     // second Philox block and the bound are then paid by full wavefronts, not by the one lane in sixteen that holds such a bucket.
     __shared__ float s_lf[257];                     // log(n!)
     __shared__ int32_t s_c[TB / 64][64 + 1024];     // (a tile adds at most 1024)
-    for (int i = threadIdx.x; i < 257; i += TB) s_lf[i] = lgammaf((float)i + 1.0f);
+    for (int i = threadIdx.x; i < 257; i += TB) s_lf[i] = vgx_tau_logfact_f[i];
     __syncthreads();
     int nq = 0;                                     // wave-uniform
     auto look = [&](int base, int cnt) {            // `cnt` (<= 64) collected compartments from `base` on, one per lane
@@ -2181,7 +2187,7 @@ extern "C" __global__ void __launch_bounds__(TB) vgx_tau_listscan_kernel(VgxTauA
             const double r1 = s_rmig[cb] + p.c_d[i] + p.c_s[i] * p.sampMult[pn] + (a.mut_uniform ? a.mut_total : p.c_tm[i]) + s_rtr[cb];
             s_rt[i] = (float)(r1 * tau * (1.0 + 1.0 / 1048576.0)) * (1.0f + 1.0f / 1048576.0f);
         }
-        for (int i = threadIdx.x; i < 257; i += TB) s_lf[i] = lgammaf((float)i + 1.0f);
+        for (int i = threadIdx.x; i < 257; i += TB) s_lf[i] = vgx_tau_logfact_f[i];
         __syncthreads();
         for (int i = threadIdx.x; i < C * 256 && i < 16 * 256; i += TB) {
             const int X = i & 255;
