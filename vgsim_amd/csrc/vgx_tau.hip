@@ -890,14 +890,25 @@ struct D8Ctx {
     int tl, low, ntop, TSd, sites;
     bool use_col, use_tw, do_hist, one_rate;
     double kI, rate_lo, rate_hi, Bsum, c1, c2;
+    float kI_a, rlo_a, rhi_a, B_a;   // their magnitudes in single precision, rounded up: the screen of d8_cells
+    float kI_f, rlo_f, rhi_f, B_f;   // and the coefficients themselves (its second level)
+    bool opposed;                    // kI < 0 and every other coefficient >= 0: the own term and the arrivals have opposite signs
     unsigned int *hist;
     int32_t *occ_dst;      // this wavefront's region of the occupied-compartment lists, or null
 };
-template <int MODE>
+#ifdef VGX_D8_STATS
+__device__ unsigned long long vgx_d8_stats[8];   // diagnostic build: wave turns, turns past level 1, past level 2, sum of thr0 > 1.5
+#endif
+template <int MODE, bool USUAL>
 static __device__ __forceinline__ void d8_cells(const D8Ctx &c, int lane, double &cand_min, double &ad_max, long long &sumI, double &sumMg,
-                                                int &occ_cnt) {
-    for (int q = threadIdx.x; q < c.TSd; q += D8_TB) {
-        const int h = (c.tl << (2 * c.low)) + 4 * q;          // first of the thread's four haplotypes
+                                                int &occ_cnt, float thr) {
+    // USUAL: the shape of config 4 and of most models the kernel takes — eight sites inside the tile, uniform migration with one common
+    // weight, one mutation rate — with the switches below known at compile time (one straight-line turn: every neighbour read in flight
+    // together, no selects between forms that are not needed)
+    const int k_low = USUAL ? VGX_D8_LOW : c.low, k_TSd = USUAL ? (1 << (2 * VGX_D8_LOW - 2)) : c.TSd;
+    const bool k_col = USUAL ? true : c.use_col, k_tw = USUAL ? false : c.use_tw, k_one = USUAL ? true : c.one_rate;
+    for (int q = threadIdx.x; q < k_TSd; q += D8_TB) {
+        const int h = (c.tl << (2 * k_low)) + 4 * q;          // first of the thread's four haplotypes
         const uint32_t own = c.tile32[q];
         if (c.occ_dst) {       // (wave-uniform) the occupied compartments among the wavefront's 256: listed, region by region
             if (__any(own != 0u)) {
@@ -926,15 +937,15 @@ static __device__ __forceinline__ void d8_cells(const D8Ctx &c, int lane, double
             for (int x = 1; x < 4; ++x) {
                 const int k = g * 3 + x - 1;
                 hv[k] = 0;
-                if (g < c.ntop) hv[k] = c.row32[(int64_t)(c.tl ^ (x << (2 * g))) * c.TSd + q];
+                if (g < c.ntop) hv[k] = c.row32[(int64_t)(c.tl ^ (x << (2 * g))) * k_TSd + q];
             }
         double4 cT = {0.0, 0.0, 0.0, 0.0}, cTW = {0.0, 0.0, 0.0, 0.0};
-        if (c.use_col) cT = *(const double4 *)(c.cTP + h);
-        if (c.use_tw) cTW = *(const double4 *)(c.cTWP + h);
+        if (k_col) cT = *(const double4 *)(c.cTP + h);
+        if (k_tw) cTW = *(const double4 *)(c.cTWP + h);
         // inside the tile: digit g >= 1 of the cell index = two-bit group g - 1 of the dword index
 #pragma unroll
         for (int g = 1; g < VGX_D8_LOW; ++g) {
-            if (g < c.low) {
+            if (g < k_low) {
                 const int sh = 2 * g - 2;
                 const uint32_t x1 = c.tile32[q ^ (1 << sh)], x2 = c.tile32[q ^ (2 << sh)], x3 = c.tile32[q ^ (3 << sh)];
                 if (MODE == 2) bad |= d8_sat(x1) | d8_sat(x2) | d8_sat(x3);
@@ -973,38 +984,86 @@ static __device__ __forceinline__ void d8_cells(const D8Ctx &c, int lane, double
             }
         }
         sumI += (MODE == 2) ? (long long)Iv[0] + (long long)Iv[1] + (long long)Iv[2] + (long long)Iv[3] : (long long)s4;
+        // pyx:2440-2444: candidate max(eps * X / 2, 1) / |drift| with eps * X in single precision; the numerator is 1 up to 66
+        // hosts ((double)(0.03f * (float)X) / 2 > 1 from X = 67 on), and the smallest of those candidates is 1 / (largest |drift|).
+        // All the kernel keeps of the |drift| values is the launch's smallest candidate (tau_bits, an atomic minimum that starts
+        // at 1.0): a compartment of up to 66 hosts matters only if its |drift| exceeds 1 / (the smallest candidate anywhere so far).
+        // So the four compartments of a turn are first bounded together in single precision — |drift| <= |kI| max Ih + rate max n +
+        // B max |mg|, coefficients rounded up by 4e-6 (far above the roundings of the conversions and the three operations) — and
+        // only turns whose bound reaches thr (or that hold a large compartment) take the double-precision path; thr rises with what
+        // the wavefront finds.  Same minimum as without the screen, bit for bit; the kernel's vector pipes were two thirds busy
+        // with the fifteen double-precision instructions per compartment of this section.
+        double mg4[4] = {0.0, 0.0, 0.0, 0.0};
+        float mgmax = 0.0f;
+        if (k_col) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int32_t Icell = Iv[j];
-            const double Ih = (double)Icell;
-            double drift = c.kI * Ih;
-            if (c.one_rate) drift = __builtin_fma(c.rate_lo, (double)(nlo[j] + nhi[j]), drift);
-            else drift = __builtin_fma(c.rate_hi, (double)nhi[j], __builtin_fma(c.rate_lo, (double)nlo[j], drift));
-            if (c.use_col) {
+            for (int j = 0; j < 4; ++j) {
                 const double T = j == 0 ? cT.x : j == 1 ? cT.y : j == 2 ? cT.z : cT.w, TW = j == 0 ? cTW.x : j == 1 ? cTW.y : j == 2 ? cTW.z : cTW.w;
-                const double mgT = c.use_tw ? __builtin_fma(c.c2, TW, c.c1 * T) : c.c1 * T;     // (one common weight: c1 holds c1 + c2 w)
-                drift = __builtin_fma(c.Bsum, mgT, drift);
-                sumMg += mgT;
+                mg4[j] = k_tw ? __builtin_fma(c.c2, TW, c.c1 * T) : c.c1 * T;     // (one common weight: c1 holds c1 + c2 w)
+                sumMg += mg4[j];
             }
-            // pyx:2440-2444: candidate max(eps * X / 2, 1) / |drift| with eps * X in single precision; the numerator is 1 up to 66
-            // hosts ((double)(0.03f * (float)X) / 2 > 1 from X = 67 on), and the smallest of those candidates is 1 / (largest |drift|)
-            if (MODE == 0) {
-                // (no count above 66 here; one v_max_f64 with the |.| modifier: fmax() would first canonicalise both operands — three)
-                asm("v_max_f64 %0, %1, |%2|" : "=v"(ad_max) : "v"(ad_max), "v"(drift));
-            } else {
+            mgmax = fmaxf(fmaxf(fabsf((float)mg4[0]), fabsf((float)mg4[1])), fmaxf(fabsf((float)mg4[2]), fabsf((float)mg4[3])));
+        }
+        const int ihmax = max(max(Iv[0], Iv[1]), max(Iv[2], Iv[3]));
+        // (the arrivals' terms are not negative; with kI < 0 — the usual sign — the drift lies in [-|kI| max Ih, rate max n + B max mg])
+        const float Uneg = c.kI_a * (float)ihmax;
+        float Upos = k_col ? c.B_a * mgmax : 0.0f;
+        if (k_one) Upos = fmaf(c.rlo_a, (float)max(max(nlo[0] + nhi[0], nlo[1] + nhi[1]), max(nlo[2] + nhi[2], nlo[3] + nhi[3])), Upos);
+        else Upos = fmaf(c.rhi_a, (float)max(max(nhi[0], nhi[1]), max(nhi[2], nhi[3])), fmaf(c.rlo_a, (float)max(max(nlo[0], nlo[1]), max(nlo[2], nlo[3])), Upos));
+        const float U = c.opposed ? fmaxf(Upos, Uneg) : Upos + Uneg * (1.0f + 1e-6f);
+        unsigned int need = (U >= thr || (MODE != 0 && ihmax > 66) || !(U < 3.0e38f)) ? 15u : 0u;
+#ifdef VGX_D8_STATS
+        if (lane == 0) atomicAdd(&vgx_d8_stats[0], 1ull);
+        if (__any(need != 0u) && lane == 0) atomicAdd(&vgx_d8_stats[1], 1ull);
+        atomicAdd(&vgx_d8_stats[3], (unsigned long long)(need != 0u));
+        if (lane == 0 && q < D8_TB) { atomicAdd(&vgx_d8_stats[5], (unsigned long long)(thr > 1.5f)); atomicAdd(&vgx_d8_stats[6], (unsigned long long)thr); atomicAdd(&vgx_d8_stats[7], (unsigned long long)U); }
+#endif
+        if (c.do_hist) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (Iv[j] >= 1 && Iv[j] <= VGX_HIST_X) atomicAdd(&c.hist[(Iv[j] - 1) * 16 + (lane & 15)], 1u);
+        }
+        if (__any(need != 0u)) {
+            // second level, where the arrivals are nearly the same everywhere and the turn's bound says little: the compartments one
+            // by one in single precision — off the exact drift by less than 9 * 2^-24 * (sum of the terms' magnitudes) <= 6e-7 (Upos + Uneg)
+            const float cut = thr - 2e-6f * (Upos + Uneg);
+            unsigned int need2 = 0u;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float af = c.kI_f * (float)Iv[j];
+                if (k_one) af = fmaf(c.rlo_f, (float)(nlo[j] + nhi[j]), af);
+                else af = fmaf(c.rhi_f, (float)nhi[j], fmaf(c.rlo_f, (float)nlo[j], af));
+                if (k_col) af = fmaf(c.B_f, (float)mg4[j], af);
+                need2 |= ((fabsf(af) >= cut || (MODE != 0 && Iv[j] > 66) || !(U < 3.0e38f)) ? 1u : 0u) << j;
+            }
+            need &= need2;
+#ifdef VGX_D8_STATS
+            if (__any(need != 0u) && lane == 0) atomicAdd(&vgx_d8_stats[2], 1ull);
+            atomicAdd(&vgx_d8_stats[4], (unsigned long long)__popc(need));
+#endif
+        }
+        if (__any(need != 0u)) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (!((need >> j) & 1u)) continue;
+                const int32_t Icell = Iv[j];
+                double drift = c.kI * (double)Icell;
+                if (k_one) drift = __builtin_fma(c.rate_lo, (double)(nlo[j] + nhi[j]), drift);
+                else drift = __builtin_fma(c.rate_hi, (double)nhi[j], __builtin_fma(c.rate_lo, (double)nlo[j], drift));
+                if (k_col) drift = __builtin_fma(c.Bsum, mg4[j], drift);
                 const double ad = fabs(drift);
-                const bool large = Icell > 66;
+                const bool large = MODE != 0 && Icell > 66;
                 ad_max = fmax(ad_max, large ? 0.0 : ad);          // (|drift| < 1e-8 is sorted out at the end)
-                if (__any(large && ad >= 1e-8)) {
-                    if (large && ad >= 1e-8) cand_min = fmin(cand_min, ((double)(0.03f * (float)Icell) / 2.0) / ad);
-                }
+                if (large && ad >= 1e-8) cand_min = fmin(cand_min, ((double)(0.03f * (float)Icell) / 2.0) / ad);
             }
-            if (c.do_hist && Icell >= 1 && Icell <= VGX_HIST_X) atomicAdd(&c.hist[(Icell - 1) * 16 + (lane & 15)], 1u);
+            float m = (float)ad_max * (1.0f - 1e-6f);             // (below ad_max whatever the conversion's rounding)
+            for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+            thr = fmaxf(thr, m);
         }
     }
 }
 
-extern "C" __global__ void __launch_bounds__(D8_TB) vgx_tau_drift8_kernel(VgxTauArgs a) {
+extern "C" __global__ void __launch_bounds__(D8_TB, 4) vgx_tau_drift8_kernel(VgxTauArgs a) {   // (four wavefronts per SIMD = two blocks per CU: at most 128 VGPRs)
     const VgxDevParams &p = a.p;
     const int P = p.P, S = p.S, H = p.H, sites = p.sites;
     const int nt = a.nt8;
@@ -1069,14 +1128,27 @@ extern "C" __global__ void __launch_bounds__(D8_TB) vgx_tau_drift8_kernel(VgxTau
     const double kmig = mu.c1 + mu.c2 * mu.wt;         // mg = (c1 T + c2 TW) - kmig Ih
     c.kI = Bsum * F - (cd0 + cs0 + ctm0) - Bsum * kmig;
     c.hist = hist;
+    c.kI_a = fabsf((float)c.kI) * (1.0f + 4e-6f); c.rlo_a = fabsf((float)c.rate_lo) * (1.0f + 4e-6f); c.rhi_a = fabsf((float)c.rate_hi) * (1.0f + 4e-6f);
+    c.B_a = fabsf((float)c.Bsum) * (1.0f + 4e-6f);
+    c.kI_f = (float)c.kI; c.rlo_f = (float)c.rate_lo; c.rhi_f = (float)c.rate_hi; c.B_f = (float)c.Bsum;
+    c.opposed = c.kI < 0.0 && c.rate_lo >= 0.0 && c.rate_hi >= 0.0 && c.Bsum >= 0.0 && c.c1 >= 0.0 && (!c.use_tw || c.c2 >= 0.0);
+    // 1 / (the smallest candidate of the launch so far: the blocks that have finished), a little less; at least 1 - 1e-6
+    const float thr0 = (float)(1.0 / __longlong_as_double((long long)a.tau_bits[rep])) * (1.0f - 1e-6f);
     double cand_min = 1.0, ad_max = 0.0, sumMg = 0.0;
     long long sumI = 0;
     int occ_cnt = 0;       // listing: wave-uniform, entries of this wavefront's region; counting: the lane's occupied compartments
     const int64_t region = ((int64_t)rep * P + pn) * a.occ_nreg + (int64_t)tl * (D8_TB / 64) + wv;
     c.occ_dst = a.build_occ ? a.occ + region * VGX_OCC_CAP : nullptr;
-    if (mx <= 66u) d8_cells<0>(c, lane, cand_min, ad_max, sumI, sumMg, occ_cnt);
-    else if (mx < 255u) d8_cells<1>(c, lane, cand_min, ad_max, sumI, sumMg, occ_cnt);
-    else d8_cells<2>(c, lane, cand_min, ad_max, sumI, sumMg, occ_cnt);
+    const bool usual = low == VGX_D8_LOW && c.use_col && !c.use_tw && c.one_rate;
+    if (usual) {
+        if (mx <= 66u) d8_cells<0, true>(c, lane, cand_min, ad_max, sumI, sumMg, occ_cnt, thr0);
+        else if (mx < 255u) d8_cells<1, true>(c, lane, cand_min, ad_max, sumI, sumMg, occ_cnt, thr0);
+        else d8_cells<2, true>(c, lane, cand_min, ad_max, sumI, sumMg, occ_cnt, thr0);
+    } else {
+        if (mx <= 66u) d8_cells<0, false>(c, lane, cand_min, ad_max, sumI, sumMg, occ_cnt, thr0);
+        else if (mx < 255u) d8_cells<1, false>(c, lane, cand_min, ad_max, sumI, sumMg, occ_cnt, thr0);
+        else d8_cells<2, false>(c, lane, cand_min, ad_max, sumI, sumMg, occ_cnt, thr0);
+    }
     {
         int tot = occ_cnt;
         if (a.build_occ) { if (lane == 0) a.occ_n[region] = (unsigned int)occ_cnt; }
@@ -3242,6 +3314,15 @@ extern "C" __attribute__((visibility("hidden"))) hipError_t vgxi_tau_drift(const
         if (err != hipSuccess) return err;
         const dim3 grid((unsigned)(8 * ((a->p.P + 7) / 8) * a->nt8), (unsigned)a->R);
         hipLaunchKernelGGL(vgx_tau_drift8_kernel, grid, dim3(D8_TB), lds, s, *a);
+#ifdef VGX_D8_STATS
+        {
+            unsigned long long h[8];
+            hipStreamSynchronize(s);
+            hipMemcpyFromSymbol(h, HIP_SYMBOL(vgx_d8_stats), sizeof(h));
+            fprintf(stderr, "d8 stats (cumulative): wave turns %llu, past level 1 %llu, past level 2 %llu; lane turns past 1 %llu, compartments exact %llu; first turns with thr > 1.5: %llu, sum thr %llu, sum U %llu\n",
+                    h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7]);
+        }
+#endif
         return hipGetLastError();
     }
     if (a->has_mig && a->mig_uniform) {
