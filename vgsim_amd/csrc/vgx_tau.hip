@@ -947,7 +947,10 @@ static __device__ __forceinline__ void d8_cells(const D8Ctx &c, int lane, double
         for (int g = 1; g < VGX_D8_LOW; ++g) {
             if (g < k_low) {
                 const int sh = 2 * g - 2;
-                const uint32_t x1 = c.tile32[q ^ (1 << sh)], x2 = c.tile32[q ^ (2 << sh)], x3 = c.tile32[q ^ (3 << sh)];
+                // (the byte offset q * 4 is flipped, not the index: one v_xor per read, the tile's base in the read's offset field)
+                const char *tb = (const char *)c.tile32;
+                const uint32_t x1 = *(const uint32_t *)(tb + ((q << 2) ^ (4 << sh))), x2 = *(const uint32_t *)(tb + ((q << 2) ^ (8 << sh))),
+                               x3 = *(const uint32_t *)(tb + ((q << 2) ^ (12 << sh)));
                 if (MODE == 2) bad |= d8_sat(x1) | d8_sat(x2) | d8_sat(x3);
                 uint32_t e, o;
                 if (MODE == 0) { const uint32_t t = x1 + x2 + x3; e = d8_even(t); o = d8_odd(t); }
