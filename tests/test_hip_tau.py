@@ -607,9 +607,10 @@ def test_config4_kernel_instantiations_match_oracle_distribution(oracle_mod):
         assert abs(s1 ** 2 - s2 ** 2) <= tolv, "%s: variances %.6g vs %.6g (tolerance %.3g)" % (what, s1 ** 2, s2 ** 2, tolv)
 
 
-def _filled(sites, P, S, seed, fill, migration=True, classes=1):
+def _filled(sites, P, S, seed, fill, migration=True, classes=1, uneven=False):
     """A model whose compartments are written straight into the arrays (``fill(rng, shape) -> counts``); classes = 3: two
-    haplotypes with rates of their own (three rate classes)."""
+    haplotypes with rates of their own (three rate classes); uneven: one population of another size (the weights cd / actualSizes
+    of uniform migration then differ: the drift pass's second column sum)."""
     from vgsim_amd import Simulator
     with helpers.quiet():
         s = Simulator(number_of_sites=sites, populations_number=P, number_of_susceptible_groups=S, seed=seed)
@@ -621,6 +622,8 @@ def _filled(sites, P, S, seed, fill, migration=True, classes=1):
     if classes == 3:
         s.set_transmission_rate(3.1, haplotype=5); s.set_recovery_rate(0.5, haplotype=9)
     s.set_population_size(10 ** 8)
+    if uneven:
+        s.set_population_size(3 * 10 ** 7, population=1)
     m = s.simulation
     m.infectious[:] = fill(np.random.default_rng(seed), m.infectious.shape)
     m.susceptible[:, 0] -= m.infectious.sum(axis=1)
@@ -644,22 +647,35 @@ def _fill_saturated(rng, shape):      # mostly small counts, a few hundred compa
     return a
 
 
-@pytest.mark.parametrize("sites,P,S,fill,migration", [(7, 4, 1, _fill_small, True), (8, 3, 2, _fill_saturated, True), (9, 3, 1, _fill_saturated, True),
-                                                      (10, 2, 1, _fill_small, False), (10, 9, 2, _fill_saturated, True)])
-def test_byte_drift_pass_equals_the_two_pass_form(monkeypatch, sites, P, S, fill, migration):
+def _fill_sparse_mixed(rng, shape):    # 1 % occupied, from single hosts to counts far beyond a byte (the drift pass's screen: mostly empty turns)
+    a = np.zeros(shape, dtype=np.int64)
+    n = a.size // 100
+    idx = rng.choice(a.size, size=n, replace=False)
+    a.reshape(-1)[idx] = rng.choice([1, 1, 2, 3, 5, 40, 67, 254, 255, 300, 5000], size=n)
+    return a
+
+
+@pytest.mark.parametrize("sites,P,S,fill,migration,uneven", [
+    (7, 4, 1, _fill_small, True, False), (8, 3, 2, _fill_saturated, True, False), (9, 3, 1, _fill_saturated, True, False),
+    (10, 2, 1, _fill_small, False, False), (10, 9, 2, _fill_saturated, True, False),
+    (9, 2, 1, _fill_sparse_mixed, True, False), (10, 3, 2, _fill_sparse_mixed, True, False), (8, 4, 1, _fill_sparse_mixed, False, False),
+    (8, 3, 1, _fill_small, True, True), (9, 3, 2, _fill_sparse_mixed, True, True)])
+def test_byte_drift_pass_equals_the_two_pass_form(monkeypatch, sites, P, S, fill, migration, uneven):
     """vgx_tau_drift8_kernel (one read of the one-byte counts, neighbour sums inside a 4^8 tile and from the row's other tiles)
     against the two-pass form it replaces (VGX_TAU_NO_BYTE_DRIFT=1: column sums, high-site pass, low-site pass on the 4-byte
     counts).  The byte form collects the terms of a compartment's drift (fused multiply-adds) and sums the susceptible
     compartments' drift over another partition of the compartments: the leap lengths agree to 1e-12, and — a last-bit difference
     of tau moves no Poisson draw — the accepted steps, events and states are identical.  Also where bytes are saturated (counts of
     255 and more: flagged tiles, sums formed again from the 4-byte counts), with the one-byte copy kept in step by the apply pass
-    over several leaps."""
+    over several leaps.  Since round 4 the byte form screens the compartments in single precision before it forms a drift exactly
+    (only the launch's smallest candidate is kept): sparse states with counts of every size and populations of uneven size (the
+    form that is not compiled for the usual shape) are here for that."""
     def run(two_pass):
         if two_pass:
             monkeypatch.setenv("VGX_TAU_NO_BYTE_DRIFT", "1")
         else:
             monkeypatch.delenv("VGX_TAU_NO_BYTE_DRIFT", raising=False)
-        s = _filled(sites, P, S, 100 + sites, fill, migration)
+        s = _filled(sites, P, S, 100 + sites, fill, migration, uneven=uneven)
         with helpers.quiet():
             s.simulate(3, sample_size=10 ** 12, method="tau", record_multievents=False)
         return s.simulation
