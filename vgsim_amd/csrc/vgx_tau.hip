@@ -1014,7 +1014,12 @@ static __device__ __forceinline__ void d8_cells(const D8Ctx &c, int lane, double
         if (k_one) Upos = fmaf(c.rlo_a, (float)max(max(nlo[0] + nhi[0], nlo[1] + nhi[1]), max(nlo[2] + nhi[2], nlo[3] + nhi[3])), Upos);
         else Upos = fmaf(c.rhi_a, (float)max(max(nhi[0], nhi[1]), max(nhi[2], nhi[3])), fmaf(c.rlo_a, (float)max(max(nlo[0], nlo[1]), max(nlo[2], nlo[3])), Upos));
         const float U = c.opposed ? fmaxf(Upos, Uneg) : Upos + Uneg * (1.0f + 1e-6f);
+#ifdef VGX_D8_NOSCREEN      // (timing comparisons: every compartment takes the exact path)
+        unsigned int need = U > -1.0f ? 15u : 0u;
+        thr = -1.0f;
+#else
         unsigned int need = (U >= thr || (MODE != 0 && ihmax > 66) || !(U < 3.0e38f)) ? 15u : 0u;
+#endif
 #ifdef VGX_D8_STATS
         if (lane == 0) atomicAdd(&vgx_d8_stats[0], 1ull);
         if (__any(need != 0u) && lane == 0) atomicAdd(&vgx_d8_stats[1], 1ull);
