@@ -148,7 +148,8 @@ int vgx_set_params(vgx_engine *e, const vgx_params *p);
 /* Recombination branch of Birth (pyx:575-596): `recombination_probability` (pyx:93, set_coinfection_parameters
  * pyx:1422-1426), `genome_length` (pyx:1409-1417) and sitesPosition[sites] (pyx:98-101, set_mutation_position
  * pyx:1516-1524).  Optional: without this call the probability is 0 and the branch is never taken.  With a non-zero
- * probability direct runs use the lane-per-replicate kernel. */
+ * probability direct runs are exact mode only and take the single-trajectory kernel (few replicates of a small model), the general
+ * four-replicates-per-wavefront kernel (its *_rec instantiations) or the one-replicate-per-wavefront kernel (any shape). */
 int vgx_set_recombination(vgx_engine *e, double recombination_probability, int64_t genome_length,
                           const int64_t *sitesPosition /* [sites], may be NULL when the probability is 0 */);
 /* The same state is given to every replicate; replicates differ by their seed only. */

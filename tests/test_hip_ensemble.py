@@ -167,3 +167,48 @@ def test_continued_calls_keep_the_host_clock(oracle_mod, kernel):
         for k in range(5):
             assert np.array_equal(cols[k], ref[k + 1].astype(np.int64))
     eng.close()
+
+
+@pytest.mark.parametrize("kernel", ["auto", "solo", "wave"])
+def test_continued_call_after_a_slice_without_a_clock(oracle_mod, kernel):
+    """First slice: event log, NO time limit (the latency kernel then runs without its device clock); second slice on the
+    device-resident state WITH a time limit: it must start from the first slice's final time (the host clock's), stop where the
+    oracle stops and carry the oracle's times."""
+    import ctypes as C
+    from vgsim_amd import Simulator, _capi
+    ctor, phases = models.CASES["g5_short"]
+    seeds = np.array([5, 6, 2020], dtype=np.int64)
+    R, cap, s1, t2 = len(seeds), 30000, 40, 4.0
+    with helpers.quiet():
+        sim = Simulator(**ctor)
+    phases[0][0](sim)
+    m = sim.simulation
+    eng = _capi.HipEngine(m.sites, m.hapNum, m.popNum, m.susNum, n_replicates=R)
+    m.events.CreateEvents(cap)
+    eng.set_params(m); eng.set_state(m); eng.set_seeds(seeds)
+    o = _capi.VgxRunOpts(); o.record_events = 1
+    o.kernel = {"auto": 0, "wave": 1, "solo": 5}[kernel]
+    eng._check(eng.lib.vgx_simulate_direct(eng.handle, cap, s1, -1.0, 200, C.byref(o)))
+    if kernel != "wave":
+        assert eng.lib.vgx_last_direct_kernel(eng.handle) == 5
+    first_ptr = [eng.counters(r).ev_ptr for r in range(R)]
+    eng._check(eng.lib.vgx_simulate_direct(eng.handle, cap, 10 ** 9, t2, 200, C.byref(o)))
+    for r in range(R):
+        with helpers.quiet():
+            one = Simulator(**dict(ctor, seed=int(seeds[r])))
+        phases[0][0](one)
+        om = one.simulation
+        assert oracle_mod.run_direct(om, cap, s1, -1, 200) == 0
+        p1 = om.events.ptr
+        assert oracle_mod.run_direct(om, cap, 10 ** 9, t2, 200) == 0
+        c = eng.counters(r)
+        assert first_ptr[r] == p1 and c.ev_first_new == p1 and c.ev_ptr == om.events.ptr, (r, first_ptr[r], p1, c.ev_ptr, om.events.ptr)
+        n = c.ev_ptr - p1
+        assert n > 100
+        times = np.zeros(n); cols = [np.zeros(n, dtype=np.int64) for _ in range(5)]
+        eng._check(eng.lib.vgx_get_events(eng.handle, r, p1, n, _capi._p(times), *[_capi._p(x) for x in cols]))
+        ref = om.events.as_array()[:, p1:om.events.ptr]
+        assert np.array_equal(times, ref[0]), "replicate %d: times of the second slice" % r
+        for k in range(5):
+            assert np.array_equal(cols[k], ref[k + 1].astype(np.int64))
+    eng.close()

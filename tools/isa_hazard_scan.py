@@ -18,7 +18,27 @@ import sys
 import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+
+
+def _find_objdump():
+    """llvm-objdump of the ROCm installation that compiled the library: next to $HIPCC, under $ROCM_PATH, /opt/rocm, or on PATH."""
+    import shutil
+    cands = []
+    hipcc = os.environ.get("HIPCC") or shutil.which("hipcc")
+    if hipcc:
+        root = os.path.dirname(os.path.dirname(os.path.realpath(hipcc)))
+        cands += [os.path.join(root, "lib", "llvm", "bin", "llvm-objdump"), os.path.join(root, "llvm", "bin", "llvm-objdump")]
+    for root in (os.environ.get("ROCM_PATH"), "/opt/rocm"):
+        if root:
+            cands.append(os.path.join(root, "lib", "llvm", "bin", "llvm-objdump"))
+    for c in cands:
+        if os.path.isfile(c) and os.access(c, os.X_OK):
+            return c
+    return shutil.which("llvm-objdump")
+
+
+OBJDUMP = _find_objdump()
+TOOLS_MISSING = 3      # exit code: objcopy / llvm-objdump not found (the scan did not run; not a hazard)
 MAGIC = b"__CLANG_OFFLOAD_BUNDLE__"
 DPP_VGPR_WAIT, DPP_EXEC_WAIT = 2, 5
 
@@ -167,6 +187,11 @@ def scan(body):
 
 
 def main(lib):
+    import shutil
+    if not OBJDUMP or not shutil.which("objcopy"):
+        print("isa_hazard_scan: SKIPPED — %s not found (looked next to $HIPCC, under $ROCM_PATH, /opt/rocm and on PATH); the DPP hazards of "
+              "%s were NOT checked" % ("llvm-objdump" if not OBJDUMP else "objcopy (binutils)", os.path.relpath(lib, ROOT)), file=sys.stderr)
+        return TOOLS_MISSING
     total, viol = 0, []
     for img in code_objects(lib):
         with tempfile.NamedTemporaryFile(suffix=".co") as f:

@@ -152,6 +152,8 @@ struct vgx_engine {
     int h_so_ncls = 0, h_so_maxnnz = 0;
     DevBuf so_sn, so_sig, so_rcp, so_hapcls, so_nnz, so_tsn, so_tsig, so_clssig;
     bool last_used_solo = false;
+    bool dev_clock_stale = false;     // the last direct call ran without the device clock (vgx_solo.hip, CLOCK = false): r_sc[].currentTime is the
+                                      // time at that call's START; a continued call must take the host clock's final time instead
     int64_t last_ev_size = 0;
     std::vector<VgxRepScalars> sc_host;
     bool sc_host_valid = false;
@@ -865,14 +867,30 @@ static int direct_core(vgx_engine *e, int64_t iterations, int64_t sample_size, f
             // without an event log, from the device clock (vgx_log: < 1 ulp per step from the host's).
             int64_t work = 0;
             for (int64_t r = 0; r < R; r++) work += e->sc_host[(size_t)r].loop_iterations;
-            const bool rebuild = e->direct_logs_valid && work <= 50000000;
+            // After a call of the latency kernel without its device clock (event log, no time limit, no trajectories) the device's
+            // currentTime is still that call's START time: the rebuild is then not optional, whatever it costs, and its result goes
+            // back to the device before the continued call reads it (time limit, trajectory grid, calls without a log).
+            const bool stale = e->dev_clock_stale;
+            const bool rebuild = e->direct_logs_valid && (work <= 50000000 || stale);
+            if (stale && !rebuild)
+                return fail(e, VGX_ERR_ARG, "vgx_simulate_direct: the previous call ran without a device clock and left no event log to "
+                                            "rebuild it from: set the state again (vgx_set_state) before continuing");
             const int64_t mism = e->clock_mismatches;
             for (int64_t r = 0; r < R; r++) {
                 t0[(size_t)r] = e->sc_host[(size_t)r].currentTime;
-                if (rebuild && host_clock(e, r) == VGX_OK && e->hc.exact) t0[(size_t)r] = e->hc.final_time;
+                const bool ok = rebuild && host_clock(e, r) == VGX_OK && e->hc.exact;
+                if (ok) t0[(size_t)r] = e->hc.final_time;
+                else if (stale)
+                    return fail(e, VGX_ERR_ARG, "vgx_simulate_direct: cannot rebuild the clock of replicate " + std::to_string(r) +
+                                                " after a call without a device clock");
             }
             e->clock_mismatches = mism;   // (counted when a caller fetches the replicate)
             e->hc.rep = -1;
+            if (stale) {
+                for (int64_t r = 0; r < R; r++) e->sc_host[(size_t)r].currentTime = t0[(size_t)r];
+                HIPCHECK(e, hipMemcpy(e->r_sc.p, e->sc_host.data(), (size_t)R * sizeof(VgxRepScalars), hipMemcpyHostToDevice));
+                e->dev_clock_stale = false;
+            }
         }
     }
     // events.ptr / events.size as maintained by the caller's Events.CreateEvents (events.pxi:52-68)
@@ -938,11 +956,14 @@ static int direct_core(vgx_engine *e, int64_t iterations, int64_t sample_size, f
     a.lds_bytes = (int32_t)lds;
 
     // Kernel choice: small models run one replicate per LANE (vgx_lanes.hip: the reference's serial loops, dense state);
-    // everything else one replicate per wavefront.  opts.kernel: 0 = automatic, 1 = wavefront, 2 = lane.
+    // everything else one replicate per wavefront.  opts.kernel: 0 = automatic, 1 = wavefront, 2 = lane, 3 = four replicates per
+    // wavefront (whichever of its forms takes the model), 4 = its general form, 5 = single trajectory (vgx_solo.hip), 6 = single
+    // trajectory of a large haplotype space (vgx_lone.hip).
     const int64_t H = e->d.hapNum, S = e->d.susNum;
     // Recombination (pyx:575-596), exact mode only: the single-trajectory kernel, the general row kernel (its *_rec instantiations), the
     // wavefront kernel (any shape), and — when asked for — the lane kernel (serial, dense state) while the dense arrays fit.
     const bool recomb = e->recombination != 0.0;
+    bool fast_remapped = false;   // a FAST request that the exact row / latency kernels serve better (undone below if the call lands on neither)
     {
         // FAST mode promises the exact mode's integer rows on the same seed and times within 1e-9 — which the exact mode delivers.  Its
         // own row kernel (vgx_quadf.hip) takes one-class models; for every other model that the exact row kernels or the latency
@@ -952,7 +973,7 @@ static int direct_core(vgx_engine *e, int64_t iterations, int64_t sample_size, f
         const bool one_class_shape = P <= 64 && S == 1 && e->C == 1 && e->CB == 1 && !ld_possible;
         const bool general_shape = P <= VGX_QG_MAX_P && S <= VGX_QG_MAX_S && e->C <= VGX_QG_MAX_C && e->CB <= VGX_QG_MAX_CB &&
                                    3 * S + e->CB <= VGX_QG_MAX_W && (int64_t)e->h_seg_par.size() <= VGX_QG_MAX_SEG;
-        if (o.mode == 1 && o.kernel == 0 && !recomb && !one_class_shape && general_shape) o.mode = 0;
+        if (o.mode == 1 && o.kernel == 0 && !recomb && !one_class_shape && general_shape) { o.mode = 0; fast_remapped = true; }
     }
     a.fast = o.mode >= 1 ? 1 : 0;
     a.rng_philox = o.mode == 2 ? 1 : 0;
@@ -1003,7 +1024,7 @@ static int direct_core(vgx_engine *e, int64_t iterations, int64_t sample_size, f
     const bool quadg_ok = o.mode == 0 && P <= VGX_QG_MAX_P && S <= VGX_QG_MAX_S && e->C <= VGX_QG_MAX_C &&
                           e->CB <= VGX_QG_MAX_CB && qg_W <= VGX_QG_MAX_W && (int64_t)e->h_seg_par.size() <= VGX_QG_MAX_SEG;
     if (o.kernel == 3 && !quad_ok && !quadg_ok && !quadf_ok)
-        return fail(e, VGX_ERR_ARG, "vgx_simulate_direct: the four-replicates-per-wavefront kernels need exact mode, no recombination, "
+        return fail(e, VGX_ERR_ARG, "vgx_simulate_direct: the four-replicates-per-wavefront kernels need "
                                     "popNum <= 128, susNum <= 8, at most 64 rate classes and 16 transmission/susceptibility classes");
     if (o.kernel == 4 && !quadg_ok)
         return fail(e, VGX_ERR_ARG, "vgx_simulate_direct: the general four-replicates-per-wavefront kernel needs exact mode, "
@@ -1035,6 +1056,11 @@ static int direct_core(vgx_engine *e, int64_t iterations, int64_t sample_size, f
     // (tools/probe_single.py; at 64 populations the wave kernel leads, 1.25e5 against 0.94e5).
     const bool use_quadg = !use_solo && !use_quad && (o.kernel == 4 || (o.kernel == 3 && quadg_ok) ||
                                          (o.kernel == 0 && quadg_ok && !use_lanes && (R >= 2048 || (P <= 16 && (S > 1 || e->C > 1 || ld_possible)))));
+    if (fast_remapped && !use_solo && !use_quadg && !use_quad && !use_lanes) {
+        // (fewer than 2048 replicates of a model neither kernel takes there: the wavefront kernel's own FAST form is the faster one)
+        a.fast = 1;
+        o.mode = 1;
+    }
     VgxLaneWs ws{};
     a.r.rec = nullptr; a.r.rec_cap = 0;
     e->rec_cap = 0;
@@ -1109,7 +1135,8 @@ static int direct_core(vgx_engine *e, int64_t iterations, int64_t sample_size, f
     // (which copy of the counts the kernel leaves current is recorded once it has been enqueued: a failure before that leaves the flags
     // describing what is on the device; whatever a failed launch may have touched is rebuilt from the host state, below)
     HIPCHECK(e, hipEventRecord(e->ev0, e->stream));
-    if (use_solo) HIPCHECK(e, vgxi_launch_solo(&a, &soa, (e->call_has_tlimit || o.traj_points > 0 || !o.record_events) ? 1 : 0, e->stream));
+    const bool solo_clock = e->call_has_tlimit || o.traj_points > 0 || !o.record_events;
+    if (use_solo) HIPCHECK(e, vgxi_launch_solo(&a, &soa, solo_clock ? 1 : 0, e->stream));
     else if (use_lanes) HIPCHECK(e, vgxi_launch_lanes(&a, &ws, e->stream));
     else if (use_quad) HIPCHECK(e, vgxi_launch_quad(&a, (const double *)e->s_cd.p, (double *)e->r_qeff.p, (double *)e->r_qmebm.p,
                                                     (int32_t *)e->r_qflag.p, e->start_max_nocc > 64 ? 1 : 0, e->stream));
@@ -1123,6 +1150,7 @@ static int direct_core(vgx_engine *e, int64_t iterations, int64_t sample_size, f
     else HIPCHECK(e, vgxi_launch_direct(&a, lds, e->stream));
     e->counts32_valid = use_quad || use_quadf;
     if (leaves32) e->counts64_valid = false;
+    e->dev_clock_stale = use_solo && !solo_clock;
     HIPCHECK(e, hipEventRecord(e->ev1, e->stream));
     if (hipStreamSynchronize(e->stream) != hipSuccess) {
         e->dev_state_valid = false;     // a kernel that did not finish leaves no state to continue from

@@ -1470,6 +1470,7 @@ extern "C" __global__ void vgx_solo_divtest_kernel(const double *n, const double
 }
 extern "C" int vgx_test_div_by_const(const double *n, const double *b, int64_t count, double *q_seq, double *q_lean, double *q_div) {
     if (!n || !b || !q_seq || !q_lean || !q_div || count < 0) return 1;
+    if (count == 0) return 0;
     double *d = nullptr;
     const size_t c = (size_t)(count > 0 ? count : 1);
     if (hipMalloc((void **)&d, c * 40) != hipSuccess) return 2;
