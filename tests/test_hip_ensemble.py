@@ -178,7 +178,7 @@ def test_continued_call_after_a_slice_without_a_clock(oracle_mod, kernel):
     from vgsim_amd import Simulator, _capi
     ctor, phases = models.CASES["g5_short"]
     seeds = np.array([5, 6, 2020], dtype=np.int64)
-    R, cap, s1, t2 = len(seeds), 30000, 40, 4.0
+    R, cap, s1, t2 = len(seeds), 500000, 1, 7.5
     with helpers.quiet():
         sim = Simulator(**ctor)
     phases[0][0](sim)

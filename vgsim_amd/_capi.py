@@ -337,7 +337,7 @@ class HipEngine:
     @property
     def last_kernel(self):
         """Name of the kernel the last direct call ran on (vgx_run_opts.kernel)."""
-        return {1: "wave", 2: "lane", 3: "quad", 4: "quadg", 5: "solo"}[self.lib.vgx_last_direct_kernel(self.handle)]
+        return {1: "wave", 2: "lane", 3: "quad", 4: "quadg", 5: "solo", 6: "lone"}[self.lib.vgx_last_direct_kernel(self.handle)]
 
     @property
     def device_bytes(self):

@@ -330,13 +330,14 @@ class BirthDeathModel(ParameterTable, Reporting):
         order (bit-exact log); 'fast' = order-free sums (same random stream and event semantics; include/vgx.h
         vgx_run_opts.mode).  ``kernel``: 'auto', 'wave' (one replicate per wavefront), 'quad' (four per wavefront, one per
         16-lane row: the one-class form where the model allows it, the general form otherwise), 'quadg' (the general
-        four-per-wavefront form even for one-class models) or 'lane' (one replicate per lane, small models;
+        four-per-wavefront form even for one-class models), 'lane' (one replicate per lane, small models), 'solo' (one trajectory
+        of a small model: dense state in registers) or 'lone' (one trajectory of a large haplotype space: occupancy lists in LDS;
         vgx_run_opts.kernel)."""
         self._check_supported()
         if mode not in ('exact', 'fast', 'fast_philox'):
             raise ValueError("mode must be 'exact', 'fast' or 'fast_philox'")
-        if kernel not in ('auto', 'wave', 'lane', 'quad', 'quadg', 'solo'):
-            raise ValueError("kernel must be 'auto', 'wave', 'lane', 'quad', 'quadg' or 'solo'")
+        if kernel not in ('auto', 'wave', 'lane', 'quad', 'quadg', 'solo', 'lone'):
+            raise ValueError("kernel must be 'auto', 'wave', 'lane', 'quad', 'quadg', 'solo' or 'lone'")
         self.events.CreateEvents(iterations)
         self.CheckSizes()
         time = float(np.float32(time))  # `float time` in the reference signature
@@ -346,7 +347,7 @@ class BirthDeathModel(ParameterTable, Reporting):
             opts = _capi.VgxRunOpts()
             opts.record_events = 1
             opts.mode = {'exact': 0, 'fast': 1, 'fast_philox': 2}[mode]
-            opts.kernel = {'auto': 0, 'wave': 1, 'lane': 2, 'quad': 3, 'quadg': 4, 'solo': 5}[kernel]
+            opts.kernel = {'auto': 0, 'wave': 1, 'lane': 2, 'quad': 3, 'quadg': 4, 'solo': 5, 'lone': 6}[kernel]
         eng = self._get_engine()
         eng.simulate_direct(self, iterations, sample_size, time, attempts, opts)
         c = eng.last_counters

@@ -21,6 +21,7 @@
 #include "vgx_quadg.h"
 #include "vgx_taus.h"
 #include "vgx_solo.h"
+#include "vgx_lone.h"
 #include "vgx_rng.h"
 
 // launchers defined next to their kernels (vgx_direct.hip)
@@ -40,6 +41,7 @@ extern "C" hipError_t vgxi_launch_quadf(const VgxDirectArgs *a, const double *cd
 extern "C" hipError_t vgxi_launch_taus(const VgxTausArgs *a, hipStream_t s);
 extern "C" hipError_t vgxi_launch_quadg(const VgxDirectArgs *a, const VgxQuadgArgs *qa, hipStream_t stream);
 extern "C" hipError_t vgxi_launch_solo(const VgxDirectArgs *a, const VgxSoloArgs *sa, int clock, hipStream_t stream);
+extern "C" hipError_t vgxi_launch_lone(const VgxDirectArgs *a, const VgxLoneArgs *la, int clock, hipStream_t stream);
 extern "C" hipError_t vgxi_launch_counts32(const int64_t *c64, int32_t *c32, int64_t n, hipStream_t stream);
 extern "C" hipError_t vgxi_launch_init_reps(const VgxDevRep *r, int P, int S, int64_t R, const int32_t *s_nocc,
                                             const int32_t *s_hap, const int32_t *s_cls, const int64_t *s_cnt,
@@ -78,6 +80,7 @@ struct vgx_engine {
     bool have_params = false, have_state = false, dev_state_valid = false;
     bool call_philox = false;      // the last direct call drew from the counter-based stream (the host clock must too)
     int64_t start_max_nocc = 0;    // longest occupancy list of the state last uploaded
+    int64_t start_lone_rows = 0;   // heap rows of vgx_lone.hip that state (and the Restart snapshot) needs at least
     void *pin[2] = {nullptr, nullptr};   // pinned staging buffers of large uploads (VGX_PIN_BYTES each), allocated on first use
     void *pin_tau = nullptr;              // pinned mirror of what the tau step loop reads after every try and step (flags, the finish kernel's record)
     size_t pin_tau_bytes = 0;
@@ -152,6 +155,8 @@ struct vgx_engine {
     int h_so_ncls = 0, h_so_maxnnz = 0;
     DevBuf so_sn, so_sig, so_rcp, so_hapcls, so_nnz, so_tsn, so_tsig, so_clssig;
     bool last_used_solo = false;
+    bool last_used_lone = false;
+    int64_t lone_fallbacks = 0;       // calls that ran again on the row kernel because the LDS heap of vgx_lone.hip was full
     bool dev_clock_stale = false;     // the last direct call ran without the device clock (vgx_solo.hip, CLOCK = false): r_sc[].currentTime is the
                                       // time at that call's START; a continued call must take the host clock's final time instead
     int64_t last_ev_size = 0;
@@ -275,7 +280,7 @@ extern "C" double vgx_last_kernel_ms(const vgx_engine *e) { return e ? (double)e
 extern "C" int64_t vgx_last_kernel_launches(const vgx_engine *e) { return e ? e->last_launches : 0; }
 extern "C" int vgx_last_direct_kernel(const vgx_engine *e) {
     if (!e) return 0;
-    return e->last_used_solo ? 5 : e->last_used_quadg ? 4 : (e->last_used_quad || e->last_used_quadf) ? 3 : e->last_used_lanes ? 2 : 1;
+    return e->last_used_lone ? 6 : e->last_used_solo ? 5 : e->last_used_quadg ? 4 : (e->last_used_quad || e->last_used_quadf) ? 3 : e->last_used_lanes ? 2 : 1;
 }
 extern "C" int64_t vgx_device_bytes(const vgx_engine *e) { return e ? (int64_t)e->dev_bytes : 0; }
 
@@ -723,6 +728,11 @@ static int init_device_state(vgx_engine *e, int64_t traj_points) {
     HIPCHECK(e, hipMemGetInfo(&free_b, &total_b));
     int64_t need = std::max<int64_t>(std::max(s_cap, i_cap), 1);
     e->start_max_nocc = s_cap;
+    {
+        int64_t rows_s = 0, rows_i = 0;
+        for (int64_t pn = 0; pn < P; pn++) { rows_s += vgx_lone_min_rows(nocc[(size_t)pn]); rows_i += vgx_lone_min_rows(i_nocc[(size_t)pn]); }
+        e->start_lone_rows = std::max(rows_s, rows_i);
+    }
     // capacity per list: what fits 45 % of the free memory (buffers of an earlier state count as free: they are reused), at most
     // 32 GiB for all lists together (an ensemble of 16 384 x 64 lists still gets 1600 entries each; the rest of the memory
     // belongs to the event logs and trajectories), never below the start state's longest list + one tile.  Rounded down to a
@@ -982,7 +992,7 @@ static int direct_core(vgx_engine *e, int64_t iterations, int64_t sample_size, f
                                                 : (P * H <= 1024 && P <= 16 && S <= 8 && H <= e->cap));
     if (recomb && o.mode != 0)
         return fail(e, VGX_ERR_ARG, "vgx_simulate_direct: recombination runs in exact mode only");
-    if (o.kernel < 0 || o.kernel > 5) return fail(e, VGX_ERR_ARG, "vgx_simulate_direct: kernel must be 0..5");
+    if (o.kernel < 0 || o.kernel > 6) return fail(e, VGX_ERR_ARG, "vgx_simulate_direct: kernel must be 0..6");
     if (o.kernel == 2 && !lane_ok)
         return fail(e, VGX_ERR_ARG, "vgx_simulate_direct: the lane-per-replicate kernel needs exact mode, popNum <= 16, "
                                     "popNum * hapNum <= 1024 and susNum <= 8");
@@ -1016,6 +1026,18 @@ static int direct_core(vgx_engine *e, int64_t iterations, int64_t sample_size, f
     for (int64_t pn = 0; pn < P && quad_shape; pn++)
         if (h.totalSusceptible[(size_t)pn] != h.susceptible[(size_t)pn]) quad_shape = false;
     const bool quad_ok = o.mode == 0 && quad_shape;
+    // One trajectory (or a few hundred) of such a model with a LARGE haplotype space: the latency kernel on occupancy lists
+    // (vgx_lone.hip), every list resident in LDS.  One wavefront per CU with 160 KB each up to 256 replicates, two with 80 KB up to
+    // 512; beyond that the row kernel's four replicates per wavefront win.  Chosen by itself only for a state that came through
+    // vgx_set_state (when the lists outgrow the heap the call runs again from that state on the row kernel) whose lists leave half
+    // the heap free; opts.kernel = 6 forces it on any state (a full heap is then the call's error).
+    VgxLoneArgs loa{};
+    loa.lds_bytes = R <= 256 ? VGX_LONE_MAX_LDS : VGX_LONE_MAX_LDS / 2;
+    const int64_t lone_rows = vgx_lone_layout((int)P, loa.lds_bytes).nrows;
+    const bool lone_ok = quad_ok && lone_rows >= 2 * P;
+    if (o.kernel == 6 && !lone_ok)
+        return fail(e, VGX_ERR_ARG, "vgx_simulate_direct: the single-trajectory kernel for large haplotype spaces needs exact mode, one rate "
+                                    "class, one susceptibility group, popNum <= 64, no lockdown switches, no recombination");
     // FAST mode (order-free sums, PCG64 stream) on the same layout and scope: vgx_quadf.hip
     const bool quadf_ok = (o.mode == 1 || o.mode == 2) && quad_shape;     // FAST, with the PCG64 or the counter-based stream
     // The general form of that kernel (vgx_quadg.hip): several susceptibility groups and rate classes, lockdown switches,
@@ -1049,14 +1071,16 @@ static int direct_core(vgx_engine *e, int64_t iterations, int64_t sample_size, f
         solo_many = compact && vgx_solo_layout((int)P, (int)H, (int)S, (int)e->d.sites, soa.mig_in_lds).total <= 20 * 1024;
     }
     const bool use_solo = o.kernel == 5 || (o.kernel == 0 && solo_ok && !use_lanes && (R < 2048 || solo_many));
-    const bool use_quad = !use_solo && ((o.kernel == 3 && quad_ok) || (o.kernel == 0 && quad_ok && !use_lanes));
-    const bool use_quadf = !use_solo && ((o.kernel == 3 && quadf_ok) || (o.kernel == 0 && quadf_ok));
+    const bool use_lone = !use_solo && (o.kernel == 6 || (o.kernel == 0 && lone_ok && !use_lanes && fresh_state && R <= 512 &&
+                                                          2 * e->start_lone_rows <= lone_rows && !getenv("VGX_NO_LONE")));
+    const bool use_quad = !use_solo && !use_lone && ((o.kernel == 3 && quad_ok) || (o.kernel == 0 && quad_ok && !use_lanes));
+    const bool use_quadf = !use_solo && !use_lone && ((o.kernel == 3 && quadf_ok) || (o.kernel == 0 && quadf_ok));
     // The general form also for FEW replicates of models with up to 16 populations (one register slot): a wavefront running alone
     // does a Table-3 trajectory at 1.7e5 events/s there against 1.0e5 on the one-replicate-per-wavefront kernel
     // (tools/probe_single.py; at 64 populations the wave kernel leads, 1.25e5 against 0.94e5).
-    const bool use_quadg = !use_solo && !use_quad && (o.kernel == 4 || (o.kernel == 3 && quadg_ok) ||
+    const bool use_quadg = !use_solo && !use_lone && !use_quad && (o.kernel == 4 || (o.kernel == 3 && quadg_ok) ||
                                          (o.kernel == 0 && quadg_ok && !use_lanes && (R >= 2048 || (P <= 16 && (S > 1 || e->C > 1 || ld_possible)))));
-    if (fast_remapped && !use_solo && !use_quadg && !use_quad && !use_lanes) {
+    if (fast_remapped && !use_solo && !use_lone && !use_quadg && !use_quad && !use_lanes) {
         // (fewer than 2048 replicates of a model neither kernel takes there: the wavefront kernel's own FAST form is the faster one)
         a.fast = 1;
         o.mode = 1;
@@ -1089,6 +1113,7 @@ static int direct_core(vgx_engine *e, int64_t iterations, int64_t sample_size, f
     e->last_used_quadg = use_quadg;
     e->last_used_quadf = use_quadf;
     e->last_used_solo = use_solo;
+    e->last_used_lone = use_lone;
     if (use_solo) {
         soa.seg_sn = (const int32_t *)e->so_sn.p; soa.seg_sig = (const double *)e->so_sig.p; soa.nseg = (int32_t)e->h_so_sn.size();
         soa.rcpAs = (const double *)e->so_rcp.p;
@@ -1112,7 +1137,7 @@ static int direct_core(vgx_engine *e, int64_t iterations, int64_t sample_size, f
         qga.nseg = (int32_t)e->h_seg_par.size(); qga.W = (int32_t)qg_W;
         qga.cold = (int64_t *)e->r_cold.p;
     }
-    if (use_quad || use_quadg || use_quadf) {
+    if (use_quad || use_quadg || use_quadf || use_lone) {
         int rcq = 0;
         rcq |= ensure(e, e->r_qeff, (size_t)(P * P) * 8);
         rcq |= ensure(e, e->r_qmebm, (size_t)P * 8);
@@ -1137,6 +1162,14 @@ static int direct_core(vgx_engine *e, int64_t iterations, int64_t sample_size, f
     HIPCHECK(e, hipEventRecord(e->ev0, e->stream));
     const bool solo_clock = e->call_has_tlimit || o.traj_points > 0 || !o.record_events;
     if (use_solo) HIPCHECK(e, vgxi_launch_solo(&a, &soa, solo_clock ? 1 : 0, e->stream));
+    else if (use_lone) {
+        HIPCHECK(e, vgxi_launch_quad_prep(&a.p, (const double *)e->s_cd.p, (double *)e->r_qeff.p, (double *)e->r_qmebm.p,
+                                          (int32_t *)e->r_qflag.p, e->stream));
+        loa.effMig = (const double *)e->r_qeff.p; loa.maxEBM = (const double *)e->r_qmebm.p; loa.has_mig = (const int32_t *)e->r_qflag.p;
+        loa.rcpAs = (const double *)e->so_rcp.p;
+        loa.exact_rcp_div = getenv("VGX_SOLO_PLAIN_DIV") ? 0 : 1;
+        HIPCHECK(e, vgxi_launch_lone(&a, &loa, solo_clock ? 1 : 0, e->stream));
+    }
     else if (use_lanes) HIPCHECK(e, vgxi_launch_lanes(&a, &ws, e->stream));
     else if (use_quad) HIPCHECK(e, vgxi_launch_quad(&a, (const double *)e->s_cd.p, (double *)e->r_qeff.p, (double *)e->r_qmebm.p,
                                                     (int32_t *)e->r_qflag.p, e->start_max_nocc > 64 ? 1 : 0, e->stream));
@@ -1150,7 +1183,7 @@ static int direct_core(vgx_engine *e, int64_t iterations, int64_t sample_size, f
     else HIPCHECK(e, vgxi_launch_direct(&a, lds, e->stream));
     e->counts32_valid = use_quad || use_quadf;
     if (leaves32) e->counts64_valid = false;
-    e->dev_clock_stale = use_solo && !solo_clock;
+    e->dev_clock_stale = (use_solo || use_lone) && !solo_clock;
     HIPCHECK(e, hipEventRecord(e->ev1, e->stream));
     if (hipStreamSynchronize(e->stream) != hipSuccess) {
         e->dev_state_valid = false;     // a kernel that did not finish leaves no state to continue from
@@ -1162,6 +1195,21 @@ static int direct_core(vgx_engine *e, int64_t iterations, int64_t sample_size, f
     e->sc_host.resize((size_t)R);
     HIPCHECK(e, hipMemcpy(e->sc_host.data(), e->r_sc.p, (size_t)R * sizeof(VgxRepScalars), hipMemcpyDeviceToHost));
     e->sc_host_valid = true;
+    if (use_lone && o.kernel == 0) {
+        // The lists of some replicate outgrew the LDS heap: the call is a function of the state and the seeds, so it runs again from the
+        // state of vgx_set_state on the row kernel (the automatic choice takes this kernel only on such a state).
+        bool full = false;
+        for (int64_t r = 0; r < R; r++) full = full || e->sc_host[(size_t)r].error == (VGX_ERR_CAPACITY | (VGX_LONE_FULL_SITE << 8));
+        if (full) {
+            if (getenv("VGX_TIMING")) fprintf(stderr, "vgx_lone: LDS heap full, the call runs again on the row kernel\n");
+            e->dev_state_valid = false;
+            e->sc_host_valid = false;
+            vgx_run_opts o2 = o;
+            o2.kernel = 3;
+            e->lone_fallbacks += 1;
+            return direct_core(e, iterations, sample_size, time, attempts, &o2);
+        }
+    }
     e->direct_logs_valid = e->call_recorded;
     // the caller's next simulate continues from where replicate 0 stopped unless it sets a new state
     h.ev_ptr = e->sc_host[0].ev_ptr;

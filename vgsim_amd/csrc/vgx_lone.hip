@@ -1,0 +1,831 @@
+// vgx_lone.hip — direct Gillespie for ONE trajectory of a LARGE haplotype space: the latency kernel on occupancy lists.
+//
+// What `Simulator.simulate()` is upstream: one sequential event loop (src/_BirthDeath.pyx:396-429).  vgx_solo.hip runs that loop for
+// small models with the reference's dense arrays in registers; here the haplotype space is large (BASELINE config 3: 4^8 haplotypes x 64
+// populations) and the state is the ORDERED OCCUPANCY LISTS of vgx_dev.h — but resident in LDS for the whole call, one wavefront per
+// replicate, so that no memory round trip sits between two events:
+//   * a heap of list slots in LDS (rows of 16 slots; every population owns a contiguous run of rows, laid out again when one fills
+//     up): per slot the haplotype, its infectious count (4 bytes) and THE SERIAL PREFIX SUM OF hapPopRate as the population's last
+//     infect-update left it (pyx:519-528) — fastChoose(hapPopRate[pi], ...) (fast_choose.pxi:22-28) would form exactly those sums
+//     again, so the haplotype choice is a compare + ballot over them (first over the sums at the ends of the 64-entry tiles, then
+//     inside one tile) and the list is walked ONCE per event, by the refresh, not 1.5 times;
+//   * lane p <-> population p: popRate and its serial prefix sums (the partial sums of the totalRate loop, pyx:537-539), migPopRate and
+//     ITS prefix sums (fastChoose(migPopRate), pyx:676, is a ballot too), totals, BirthRate of the class, the list's place in the heap;
+//   * every sequential f64 sum of the reference is one v_fmac_f64 (DPP row_newbcast) per term (vgx_flat.h), in the reference's order;
+//   * migrationRates in LDS; uniforms 64 per refill by lane-parallel PCG64 jump-ahead; event records staged in LDS and written 64 at a
+//     time (2 KB bursts); the logarithm of SampleTime only in calls that need the device clock (vgx_solo.hip, vgx_api.hip host_clock).
+// Scope = the one-class row kernel's (vgx_quad.hip): popNum <= 64, one susceptibility group, one rate class, no population that can
+// switch its lockdown state, no recombination, population sizes < 2^31, exact mode.  With one group immunePopRate is +0.0 and popRate =
+// infectPopRate exactly; effectiveMigration / maxEffectiveBirthMigration come from vgx_quad_prep_kernel.
+// When the lists outgrow the heap the replicate ends with capacity | VGX_LONE_FULL_SITE << 8 and the host runs the call again on the
+// row kernel (the call is a function of state and seeds).  Start and end state are exchanged in the other kernels' layout.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <stdint.h>
+#include "vgx_dev.h"
+#include "vgx_rng.h"
+#include "vgx_wave.h"
+#include "vgx_flat.h"
+#include "vgx_lone.h"
+
+#ifdef VGX_PROFILE
+#define PROF(i)                                                                   \
+    do {                                                                          \
+        const unsigned long long prof_t1 = __builtin_readcyclecounter();          \
+        prof_acc += (lane == (i)) ? prof_t1 - prof_t0 : 0ull;                      \
+        prof_t0 = prof_t1;                                                        \
+    } while (0)
+#else
+#define PROF(i)
+#endif
+
+namespace {
+
+enum { ERR_ZERO_WEIGHT = 3, ERR_CAPACITY = 4, ERR_LOOP_GUARD = 5 };
+enum { EV_BIRTH = 0, EV_DEATH, EV_SAMPLING, EV_MUTATION, EV_SUSCCHANGE, EV_MIGRATION };
+// slots of the cold block (LDS): bookkeeping of the call that the event loop itself never reads
+enum { C_EV_PTR = 0, C_LOOPS, C_ATT_LOOPS, C_TRAJ_NEXT, C_RESTARTS, C_ATT, C_GOOD, C_LAST_ATT };
+enum { CNT_MIGN = 6 };
+#ifndef VGX_LONE_SEG
+#define VGX_LONE_SEG (1 << 30)   // iterations per segment of the event loop (32-bit countdowns; a test build shortens it)
+#endif
+#define LONE_BIG VGX_LONE_SEG
+// flags in the high word of zero_w (the low word: a fastChoose stopped on a zero weight)
+#define LONE_F_CAP (2ull << 32)      // event log / list capacity in HBM
+#define LONE_F_FULL (4ull << 32)     // the LDS heap is full
+
+struct VgxLoneKArgs { VgxDirectArgs a; VgxLoneArgs la; };
+typedef const VgxLoneKArgs __attribute__((address_space(4))) *LoneKA;
+static __device__ __forceinline__ LoneKA cold_args(LoneKA k) {
+    asm volatile("" : "+s"(k));
+    return k;
+}
+static __device__ __forceinline__ int lane_get(int v, int k) { return __builtin_amdgcn_readlane(v, k); }
+static __device__ __forceinline__ int wave_sum_i32(int v, int lane) { return (int)bcast_i64(iscan((int64_t)v, lane), 63); }
+
+template <bool CLOCK, bool RCPDIV>
+struct Lone {
+    int P, H, sites, lane;
+    int nrows;                    // rows of the heap
+    Masks M;
+    // LDS
+    double *ldCum, *ldTend, *ldMig, *ldRng;
+    int32_t *ldHap, *ldCnt;
+    uint32_t *ldStage;
+    uint64_t *ldRngK, *ldRngS;
+    int64_t *ldCold;
+    // the single rate class
+    double c_b, c_sig, c_d, c_tm;
+    // ---- population lanes ----
+    double popRate, cumPop, migR, cumMig, maxEBM, totS, totI, cd, asz, rcp, smul, bC;
+    int row0, rows, nocc;         // the population's list: first heap row, rows owned, entries
+    // ---- counters: lane t < 6 <-> events of type t, lane 6 rejected migrations ----
+    uint64_t cnt;
+    // ---- wave-uniform ----
+    double totalRate, totalMig, Rtot, currentTime, gI;
+    int has_mig;
+    unsigned long long zero_w;
+    int stage_n;
+    int pos;                      // iterations consumed from the current batch of 64 uniforms (32 = empty)
+    double u_pre, n_pre;
+    double tlimit, next_tg;
+    int ev_left, loop_left, s_left, ev_left0, loop_left0;
+    uint32_t iter_base;
+#ifdef VGX_PROFILE
+    unsigned long long prof_t0, prof_acc;
+#endif
+
+    __device__ __forceinline__ int64_t cold_get(int i) const { return ldCold[i]; }
+    __device__ __forceinline__ void cold_set(int i, int64_t v) {
+        if (lane == 0) ldCold[i] = v;
+        WSYNC();
+    }
+    __device__ __forceinline__ void prefetch_uniforms() {
+        const int q = min(pos, 31);
+        u_pre = ldRng[2 * q + 1];
+        if (CLOCK) n_pre = ldRng[2 * q];
+    }
+    __device__ __forceinline__ void zero_weight(bool c) { zero_w |= (__builtin_amdgcn_ballot_w64(c) ? 1ull : 0ull); }
+    static __device__ __forceinline__ int first_or(unsigned long long hit, int other) {
+        return uni_i32(hit ? (int)__builtin_ctzll(hit) : other);
+    }
+
+    // ---- the heap ---------------------------------------------------------------------------------------------------------
+    // A layout for the current lists (+ one entry for `need_pi`): every population its minimum of rows, the spare rows in proportion.
+    __device__ __forceinline__ bool plan(int need_pi, int &nr0, int &nrw) const {
+        const int nneed = lane < P ? nocc + (lane == need_pi ? 1 : 0) : 0;
+        const int mn = lane < P ? vgx_lone_min_rows(nneed) : 0;
+        const int tot = wave_sum_i32(mn, lane);
+        if (tot > nrows) return false;
+        const int spare = nrows - tot;
+        const int extra = lane < P ? (int)(((int64_t)spare * mn) / tot) : 0;
+        nrw = mn + extra;
+        nr0 = (int)iscan((int64_t)nrw, lane) - nrw;
+        return true;
+    }
+    // n list slots from slot `src` to slot `dst` (hap, cnt, cum); the ranges may overlap
+    __device__ __forceinline__ void move_slots(int src, int dst, int n) {
+        if (src == dst || n <= 0) return;
+        const int nt = (n + 63) >> 6;
+        for (int i = 0; i < nt; ++i) {
+            const int t = dst < src ? i : nt - 1 - i;     // towards lower slots: first tile first; towards higher: last tile first
+            const int idx = 64 * t + lane;
+            int h = 0, c = 0;
+            double q = 0.0;
+            if (idx < n) { h = ldHap[src + idx]; c = ldCnt[src + idx]; q = ldCum[src + idx]; }
+            WSYNC();
+            if (idx < n) { ldHap[dst + idx] = h; ldCnt[dst + idx] = c; ldCum[dst + idx] = q; }
+            WSYNC();
+        }
+    }
+    __device__ __forceinline__ void tile_ends(int p) {
+        const int n = uni_i32(lane_get(nocc, p)), r0 = uni_i32(lane_get(row0, p));
+        const int nt = (n + 63) >> 6;
+        if (lane < nt) ldTend[r0 + 4 * lane] = ldCum[16 * r0 + min(64 * lane + 63, n - 1)];
+    }
+    // room for one more entry in population pi's list: the lists move to a new layout; false: the heap is full
+    __device__ __forceinline__ bool relayout(int need_pi) {
+        int nr0, nrw;
+        if (!plan(need_pi, nr0, nrw)) return false;
+        const int mn = lane < P ? vgx_lone_min_rows(nocc) : 0;
+        const int cp = (int)iscan((int64_t)mn, lane) - mn;       // every list at its lowest place first ...
+        for (int p = 0; p < P; ++p)
+            move_slots(16 * uni_i32(lane_get(row0, p)), 16 * uni_i32(lane_get(cp, p)), uni_i32(lane_get(nocc, p)));
+        for (int p = P - 1; p >= 0; --p)                          // ... then up to its new one, the last population first
+            move_slots(16 * uni_i32(lane_get(cp, p)), 16 * uni_i32(lane_get(nr0, p)), uni_i32(lane_get(nocc, p)));
+        row0 = nr0; rows = nrw;
+        for (int p = 0; p < P; ++p) tile_ends(p);
+        WSYNC();
+        return true;
+    }
+    // the lists of a state in the other kernels' layout (occupancy lists in HBM) into the heap; false: they do not fit
+    __device__ __forceinline__ bool load_lists(const int32_t *gn, const int32_t *gh, const int64_t *gc, int64_t gcap) {
+        nocc = lane < P ? gn[lane] : 0;
+        int nr0, nrw;
+        if (!plan(-1, nr0, nrw)) return false;
+        row0 = nr0; rows = nrw;
+        double ti = 0.0;
+        for (int p = 0; p < P; ++p) {
+            const int n = uni_i32(lane_get(nocc, p)), base = 16 * uni_i32(lane_get(row0, p));
+            int64_t s = 0;
+            for (int k = lane; k < n; k += 64) {
+                const int64_t c = gc[(int64_t)p * gcap + k];
+                ldHap[base + k] = gh[(int64_t)p * gcap + k];
+                ldCnt[base + k] = (int)c;
+                ldCum[base + k] = 0.0;
+                s += c;
+            }
+            const double tp = (double)bcast_i64(iscan(s, lane), 63);
+            ti = lane == p ? tp : ti;
+        }
+        totI = ti;
+        WSYNC();
+        return true;
+    }
+
+    // first index whose haplotype is >= h in population's list (n entries from slot base); found: that entry holds h
+    __device__ __forceinline__ int lower_bound(int h, int n, int base, bool &found) const {
+        for (int t = 0; 64 * t < n; ++t) {
+            const int idx = 64 * t + lane;
+            const int hv = idx < n ? ldHap[base + idx] : 0x7fffffff;
+            const unsigned long long hit = __builtin_amdgcn_ballot_w64(hv >= h);
+            if (hit) {
+                const int l = (int)__builtin_ctzll(hit);
+                found = lane_get(hv, l) == h;
+                return uni_i32(64 * t + l);
+            }
+        }
+        found = false;
+        return n;
+    }
+    // entry k leaves the list: (k, n) one slot down, first tile first
+    __device__ __forceinline__ void list_remove(int pi, int k, int n, int base) {
+        for (int t = k >> 6; 64 * t < n - 1; ++t) {
+            const int idx = 64 * t + lane;
+            const bool mv = idx >= k && idx < n - 1;
+            int h = 0, c = 0;
+            if (mv) { h = ldHap[base + idx + 1]; c = ldCnt[base + idx + 1]; }
+            WSYNC();
+            if (mv) { ldHap[base + idx] = h; ldCnt[base + idx] = c; }
+            WSYNC();
+        }
+        nocc = lane == pi ? n - 1 : nocc;
+    }
+    // a new entry (hap, 1) at index k: [k, n) one slot up, last tile first.  The caller made room.
+    __device__ __forceinline__ void list_insert(int pi, int k, int hap, int n, int base) {
+        if (n > k)
+            for (int t = (n - 1) >> 6; t >= (k >> 6); --t) {
+                const int idx = 64 * t + lane;
+                const bool mv = idx >= k && idx < n;
+                int h = 0, c = 0;
+                if (mv) { h = ldHap[base + idx]; c = ldCnt[base + idx]; }
+                WSYNC();
+                if (mv) { ldHap[base + idx + 1] = h; ldCnt[base + idx + 1] = c; }
+                WSYNC();
+            }
+        if (lane == 0) { ldHap[base + k] = hap; ldCnt[base + k] = 1; }
+        WSYNC();
+        nocc = lane == pi ? n + 1 : nocc;
+    }
+    // infectious[pi, hap] += 1 (NewInfections of a mutant or a migrant, pyx:246-251 / 662)
+    __device__ __forceinline__ void list_add(int pi, int hap) {
+        int n = uni_i32(lane_get(nocc, pi)), base = 16 * uni_i32(lane_get(row0, pi));
+        bool found;
+        const int k = lower_bound(hap, n, base, found);
+        if (found) {
+            if (lane == 0) ldCnt[base + k] += 1;
+            WSYNC();
+            return;
+        }
+        if (n + 1 > 16 * uni_i32(lane_get(rows, pi))) {
+            if (!relayout(pi)) { zero_w |= LONE_F_FULL; return; }
+            base = 16 * uni_i32(lane_get(row0, pi));
+        }
+        list_insert(pi, k, hap, n, base);
+    }
+    // infectious[pi, entry k] -= 1; an entry that reaches 0 leaves the list
+    __device__ __forceinline__ void list_dec(int pi, int k, int cnt_k, int n, int base) {
+        if (cnt_k == 1) { list_remove(pi, k, n, base); return; }
+        if (lane == 0) ldCnt[base + k] = cnt_k - 1;
+        WSYNC();
+    }
+
+    // ---- UpdateRates, infect branch (pyx:518-528) ----
+    // BirthRate of the class in population pi (pyx:382-392): ps += ((x * m) * m * cd) / as over the source populations, in order
+    __device__ __forceinline__ double birth_rate(int pi) {
+        const double x = bcast(totS, pi) * c_sig;
+        const double m = lane < P ? ldMig[pi * P + lane] : 0.0;
+        const double t = x * m * m * cd;
+        double T = RCPDIV ? div_by_const(t, asz, rcp) : t / asz;
+        T = lane < P ? T : 0.0;
+        const double acc = flat_chain<false>(T, P, 0.0, M);
+        return c_b * bcast(acc, P - 1);
+    }
+    __device__ __forceinline__ double tE_of(double b, double sm) const { return ((b + c_d) + sm) + c_tm; }   // pyx:522-526
+    // hapPopRate = tE * infectious over the list in haplotype order, its serial prefix sums into the heap; returns infectPopRate[pi]
+    __device__ __forceinline__ double refresh(int pi, double tE) {
+        const int n = uni_i32(lane_get(nocc, pi)), r0 = uni_i32(lane_get(row0, pi)), base = 16 * r0;
+        double carry = 0.0;
+        int c = lane < n ? ldCnt[base + lane] : 0;
+        for (int t = 0; 64 * t < n; ++t) {
+            const int idx = 64 * t + lane;
+            const double w = idx < n ? tE * (double)c : 0.0;
+            c = idx + 64 < n ? ldCnt[base + idx + 64] : 0;        // the next tile's counts are on their way during this tile's chain
+            const int m = min(64, n - 64 * t);
+            const double cum = flat_chain<true>(w, m, carry, M);
+            if (idx < n) ldCum[base + idx] = cum;
+            carry = bcast(cum, m - 1);
+            if (lane == 0) ldTend[r0 + 4 * t] = carry;
+        }
+        WSYNC();
+        return carry;
+    }
+    // popRate changed: its serial prefix sums and totalRate (pyx:536-539)
+    __device__ __forceinline__ void rescan_pop() {
+        cumPop = flat_chain<true>(popRate, P, 0.0, M);
+        totalRate = bcast(cumPop, P - 1);
+    }
+    // migPopRate of every population, its prefix sums and totalMigrationRate (pyx:541-546)
+    __device__ __forceinline__ void remig() {
+        if (!has_mig) { totalMig = 0.0; return; }
+        migR = lane < P ? maxEBM * totS * (gI - totI) : 0.0;
+        cumMig = flat_chain<true>(migR, P, 0.0, M);
+        totalMig = bcast(cumMig, P - 1);
+    }
+    // UpdateAllRates (pyx:279-351) from the compartments; effectiveMigration and its maxima are parameters here
+    __device__ __forceinline__ void rebuild_all() {
+        for (int pn = 0; pn < P; ++pn) {
+            const double b = birth_rate(pn);
+            bC = lane == pn ? b : bC;
+            const double inP = refresh(pn, tE_of(b, bcast(smul, pn)));
+            popRate = lane == pn ? inP : popRate;
+        }
+        rescan_pop();
+        remig();
+        Rtot = totalRate + totalMig;
+    }
+
+    // ---- event log ----
+    __device__ __forceinline__ void stage_flush(LoneKA ka_, int64_t rep) {
+        if (stage_n > 0) {
+            const auto *a = &cold_args(ka_)->a;
+            WSYNC();
+            const int64_t ev_now = cold_get(C_EV_PTR) + (int64_t)(ev_left0 - ev_left);
+            const int64_t slot0 = ev_now - stage_n - a->r.ev_base;
+            if (slot0 < 0 || slot0 + stage_n > a->r.evcap) {
+                zero_w |= LONE_F_CAP;
+            } else if (lane < stage_n) {
+                const uint32_t *s = ldStage + lane * 8;
+                const int64_t slot = slot0 + lane;
+                int32_t *c = a->r.ev_cols + (rep * a->r.evcap + slot) * VGX_EV_COLS;
+                c[0] = (int32_t)s[0]; c[1] = (int32_t)s[1]; c[2] = (int32_t)s[2]; c[3] = (int32_t)s[3]; c[4] = (int32_t)s[4]; c[5] = (int32_t)s[5];
+                a->r.ev_rate[rep * a->r.evcap + slot] = __hiloint2double((int)s[7], (int)s[6]);
+            }
+            WSYNC();
+        }
+        stage_n = 0;
+    }
+    // AddEvent (events.pxi:37-44) into the LDS stage + the counters; type < 0: a rejected migration (counter only)
+    __device__ __forceinline__ void log_event(int type, int hap, int pop, int nh, int np, double den) {
+        const int ctr = type >= 0 ? type : CNT_MIGN;
+        cnt += (lane == ctr) ? 1u : 0u;
+        if (type >= 0) {
+            int v = __double2hiint(den);
+            const int it = uni_i32((int)(iter_base - (uint32_t)loop_left));
+            type = uni_i32(type); hap = uni_i32(hap); pop = uni_i32(pop); nh = uni_i32(nh); np = uni_i32(np);
+            SOLO_WRITELANE(v, type, 0); SOLO_WRITELANE(v, hap, 1); SOLO_WRITELANE(v, pop, 2); SOLO_WRITELANE(v, nh, 3);
+            SOLO_WRITELANE(v, np, 4); SOLO_WRITELANE(v, it, 5);
+            v = lane == 6 ? __double2loint(den) : v;
+            if (lane < 8) ldStage[stage_n * 8 + lane] = (uint32_t)v;
+            stage_n += 1;
+            ev_left -= 1;
+            s_left -= (type == EV_SAMPLING) ? 1 : 0;
+        }
+    }
+    __device__ __forceinline__ void traj_emit(LoneKA ka_, int64_t rep, double t_new, bool final_fill) {
+        const auto &r = cold_args(ka_)->a.r;
+        int64_t traj_next = cold_get(C_TRAJ_NEXT);
+        const int64_t n0 = traj_next;
+        while (traj_next < r.traj_points) {
+            const double tg = r.traj_t0 + (double)traj_next * r.traj_dt;
+            if (!final_fill && !(tg < t_new)) break;
+            double *o = r.traj + (rep * r.traj_points + traj_next) * (int64_t)P * 2;
+            if (lane < P) { o[lane * 2 + 0] = totI; o[lane * 2 + 1] = totS; }
+            traj_next += 1;
+        }
+        if (traj_next != n0) cold_set(C_TRAJ_NEXT, traj_next);
+        next_tg = traj_next < r.traj_points ? r.traj_t0 + (double)traj_next * r.traj_dt : __builtin_inf();
+    }
+
+    // ---- one iteration of the event loop (pyx:408-409): SampleTime, GenerateEvent with UpdateRates and AddEvent ----
+    __device__ __forceinline__ void iteration(LoneKA ka, int64_t rep) {
+        const double u = u_pre;
+        if (CLOCK) {
+            const double t_new = currentTime + (n_pre / Rtot);             // SampleTime pyx:476-478
+            if (any_lane(next_tg < t_new)) traj_emit(ka, rep, t_new, false);
+            currentTime = t_new;
+        }
+        loop_left -= 1;
+        pos += 1;
+        prefetch_uniforms();
+        PROF(0);
+        const double den = Rtot;
+        double choose = u * Rtot;                                          // GenerateEvent pyx:483-512
+        int u_pi = -1;                 // population whose infect rates change; its susceptible count changed too: f_birth
+        bool f_birth = false;
+        int ev_type = -1, ev_hap = 0, ev_pop = 0, ev_nh = 0, ev_np = 0;
+        if (any_lane(totalRate > choose)) {
+            double rn = fdiv(choose, totalRate);
+            const double r2 = totalRate * rn;
+            const int pi = first_or(__builtin_amdgcn_ballot_w64(lane < P && !(cumPop < r2)), P - 1);   // fastChoose(popRate), fc:18-31
+            const double W = bcast(popRate, pi), Cm = bcast(cumPop, pi);
+            zero_weight(W == 0.0);
+            rn = fdiv(r2 - (Cm - W), W);
+            choose = rn * W;
+            // immunePopRate[pi] = +0.0 is never > choose: the infect branch, rn = (choose - 0.0) / infectPopRate[pi] (pyx:499-500)
+            rn = fdiv(choose, W);
+            const double r4 = W * rn;
+            PROF(1);
+            // ---- haplotype: fastChoose(hapPopRate[pi], infectPopRate[pi], rn) on the list's stored prefix sums ----
+            const int n = uni_i32(lane_get(nocc, pi)), r0 = uni_i32(lane_get(row0, pi)), base = 16 * r0;
+            const int nt = (n + 63) >> 6;
+            int t = 0;
+            if (nt > 1) {
+                const double te = lane < nt ? ldTend[r0 + 4 * lane] : 0.0;
+                t = first_or(__builtin_amdgcn_ballot_w64(lane < nt && !(te < r4)), nt - 1);
+            }
+            const int idx = 64 * t + lane;
+            const bool in = idx < n;
+            const double cv = in ? ldCum[base + idx] : 0.0;
+            const int hv = in ? ldHap[base + idx] : 0, nv = in ? ldCnt[base + idx] : 0;
+            const double bpi = bcast(bC, pi), smpi = bcast(smul, pi);
+            const double e1 = bpi + c_d, e2 = e1 + smpi, tE = e2 + c_tm;
+            const unsigned long long hit = __builtin_amdgcn_ballot_w64(in && !(cv < r4));
+            const int kl = first_or(hit, (n - 1) & 63);
+            const int k = 64 * t + kl;
+            const double cum_k = bcast(cv, kl);
+            const int cnt_k = uni_i32(lane_get(nv, kl)), hap_k = uni_i32(lane_get(hv, kl));
+            // nothing reached r: the dense loop runs on to index H-1 (fc:26), a valid pick only if that haplotype is occupied
+            if (!hit && !(n > 0 && hap_k == H - 1)) zero_w |= 1ull;
+            const double hpr_k = tE * (double)cnt_k;
+            zero_weight(hpr_k == 0.0);
+            const double rn5 = fdiv(r4 - (cum_k - hpr_k), hpr_k);
+            // ---- event class: fastChoose(eventHapPopRate[pi, hi, 0..3], tEventHapPopRate[pi, hi], rn), pyx:503-511 ----
+            const double r6 = tE * rn5;
+            const int ei = uni_i32((any_lane(bpi < r6) ? 1 : 0) + (any_lane(e1 < r6) ? 1 : 0) + (any_lane(e2 < r6) ? 1 : 0));
+            const double w_ei = ei == 0 ? bpi : ei == 1 ? c_d : ei == 2 ? smpi : c_tm;
+            zero_weight(w_ei == 0.0);
+            PROF(2);
+            if (zero_w) return;          // (indices may be meaningless: the call ends with the error)
+            ev_hap = hap_k; ev_pop = pi;
+            if (ei < 3) {
+                // ---- Birth (pyx:568-605; one group: si = 0, weight S * sigma) / Death / Sampling (pyx:616-635) ----
+                const double sgn = ei == 0 ? 1.0 : -1.0;
+                if (ei == 0) {
+                    zero_weight(bcast(totS, pi) * c_sig == 0.0);
+                    if (zero_w) return;
+                    if (lane == 0) ldCnt[base + k] = cnt_k + 1;
+                    WSYNC();
+                } else {
+                    list_dec(pi, k, cnt_k, n, base);
+                }
+                const double d1 = lane == pi ? sgn : 0.0;
+                totS -= d1; totI += d1;
+                gI += sgn;
+                u_pi = pi; f_birth = true;
+                ev_type = ei; ev_nh = 0; ev_np = ei == 0 ? H : 0;
+            } else {
+                // ---- Mutation (pyx:640-667): site by mRate[h, :], derived state by hapMutType[h, site, :] ----
+                const auto &p = cold_args(ka)->a.p;
+                const double tmv = c_tm;
+                rn = (r6 - (tE - tmv)) / tmv;
+                int mi, DS;
+                {   // fastChoose(mRate[hi, :], tmRate[hi], rn)
+                    const double *w = p.mRate + (int64_t)hap_k * sites;
+                    const double r = tmv * rn;
+                    int i = 0;
+                    double total = w[0];
+                    while (any_lane(total < r) && i < sites - 1) { i += 1; total += w[i]; }
+                    const double wi = w[i];
+                    zero_weight(wi == 0.0);
+                    rn = (r - (total - wi)) / wi;
+                    mi = uni_i32(i);
+                }
+                {   // fastChoose(hapMutType[hi, mi, :], their sum, rn)
+                    const double *w = p.hapMutType + ((int64_t)hap_k * sites + mi) * 3;
+                    const double r = (w[0] + w[1] + w[2]) * rn;
+                    int i = 0;
+                    double total = w[0];
+                    while (any_lane(total < r) && i < 2) { i += 1; total += w[i]; }
+                    zero_weight(w[i] == 0.0);
+                    DS = uni_i32(i);
+                }
+                if (zero_w) return;
+                const int digit4 = 1 << (2 * (sites - mi - 1));      // Mutate, pyx:2420-2427
+                const int AS = (hap_k / digit4) % 4;
+                if (DS >= AS) DS += 1;
+                const int nhi = uni_i32(hap_k + (DS - AS) * digit4);
+                list_dec(pi, k, cnt_k, n, base);
+                list_add(pi, nhi);
+                if (zero_w) return;
+                u_pi = pi; f_birth = false;
+                ev_type = EV_MUTATION; ev_nh = nhi; ev_np = 0;
+            }
+        } else {
+            // ---- GenerateMigration (pyx:672-694) ----
+            double rn = (choose - totalRate) / totalMig;
+            int tpi;
+            {   // fastChoose(migPopRate, totalMigrationRate, rn) on the stored prefix sums
+                const double r = totalMig * rn;
+                tpi = first_or(__builtin_amdgcn_ballot_w64(lane < P && !(cumMig < r)), P - 1);
+                const double w = bcast(migR, tpi), tot = bcast(cumMig, tpi);
+                zero_weight(w == 0.0);
+                rn = (r - (tot - w)) / w;
+            }
+            int spi;
+            {   // fastChoose_skip(totalInfectious, globalInfectious - totalInfectious[tpi], rn, tpi), fc:36-52: integer weights
+                const int64_t wv = (lane == tpi || lane >= P) ? 0 : (int64_t)totI;
+                const int64_t pre = iscan(wv, lane);
+                const double r = (gI - bcast(totI, tpi)) * rn;
+                const int start = tpi == 0 ? 1 : 0;
+                const unsigned long long hit = __builtin_amdgcn_ballot_w64(lane < P && lane != tpi && lane >= start && !((double)pre < r));
+                spi = first_or(hit, P - 1);
+                // running total at the stop: every weight up to spi except the skipped one (also at a clamp on the skipped index)
+                const int64_t tot = bcast_i64(pre, spi), wi = (int64_t)bcast(totI, spi);
+                zero_weight(wi == 0);
+                rn = (r - (double)(tot - wi)) / (double)wi;
+            }
+            if (zero_w) return;
+            int hi;
+            {   // fastChoose(infectious[spi], totalInfectious[spi], rn): integer prefix sums over the list
+                const int n = uni_i32(lane_get(nocc, spi)), base = 16 * uni_i32(lane_get(row0, spi));
+                const double r = bcast(totI, spi) * rn;
+                int64_t carry = 0, tot = 0, wi = 0;
+                int hq = -1, hlast = -1;
+                bool got = false;
+                for (int t = 0; 64 * t < n; ++t) {
+                    const int idx = 64 * t + lane;
+                    const bool in = idx < n;
+                    const int c = in ? ldCnt[base + idx] : 0, hv = in ? ldHap[base + idx] : 0;
+                    const int64_t pre = iscan((int64_t)c, lane) + carry;
+                    const unsigned long long hit = __builtin_amdgcn_ballot_w64(in && !((double)pre < r));
+                    const int last = min(63, n - 1 - 64 * t);
+                    if (hit) {
+                        const int l = (int)__builtin_ctzll(hit);
+                        tot = bcast_i64(pre, l); wi = (int64_t)lane_get(c, l); hq = lane_get(hv, l);
+                        got = true;
+                        break;
+                    }
+                    carry = bcast_i64(pre, 63);
+                    hlast = lane_get(hv, last); wi = (int64_t)lane_get(c, last);
+                }
+                if (!got) {          // clamp at H-1 (fc:26)
+                    if (n > 0 && hlast == H - 1) { hq = hlast; tot = carry; } else { zero_w |= 1ull; hq = 0; wi = 1; }
+                }
+                zero_weight(wi == 0);
+                rn = (r - (double)(tot - wi)) / (double)wi;
+                hi = uni_i32(hq);
+            }
+            {   // fastChoose(susceptible[tpi], totalSusceptible[tpi], rn): one group
+                const double wi = bcast(totS, tpi);
+                const double r = wi * rn;
+                zero_weight(wi == 0.0);
+                rn = (r - (wi - wi)) / wi;
+            }
+            if (zero_w) return;
+            const auto &la = cold_args(ka)->la;
+            const double p_accept = la.effMig[spi * P + tpi] * c_b * c_sig / bcast(maxEBM, tpi);
+            ev_hap = hi; ev_pop = spi; ev_nh = 0; ev_np = tpi;
+            if (any_lane(rn < p_accept)) {
+                list_add(tpi, hi);                                   // NewInfections (pyx:246-251)
+                if (zero_w) return;
+                const double d1 = lane == tpi ? 1.0 : 0.0;
+                totS -= d1; totI += d1;
+                gI += 1.0;
+                u_pi = tpi; f_birth = true;
+                ev_type = EV_MIGRATION;
+            }
+        }
+        PROF(3);
+        // ---- UpdateRates(u_pi, ...) (pyx:516-546) ----
+        if (u_pi >= 0) {
+            double b = bcast(bC, u_pi);
+            if (f_birth) {
+                b = birth_rate(u_pi);
+                bC = lane == u_pi ? b : bC;
+            }
+            PROF(4);
+            if (f_birth) remig();
+            PROF(5);
+            const double inP = refresh(u_pi, tE_of(b, bcast(smul, u_pi)));
+            PROF(6);
+            popRate = lane == u_pi ? inP : popRate;
+            rescan_pop();
+            PROF(7);
+        }
+        Rtot = totalRate + totalMig;
+        log_event(ev_type, ev_hap, ev_pop, ev_nh, ev_np, den);
+        PROF(8);
+    }
+};
+
+template <bool CLOCK, bool RCPDIV>
+static __device__ __forceinline__ void lone_body() {
+    const LoneKA ka = (LoneKA)__builtin_amdgcn_kernarg_segment_ptr();
+    const auto &a = ka->a;
+    const auto &la = ka->la;
+    const int64_t rep = blockIdx.x;
+    if (rep >= a.n_replicates) return;
+    const int lane = threadIdx.x;
+    const auto &p = a.p;
+    const auto &r = a.r;
+    const int P = uni_i32(p.P), H = uni_i32(p.H), sites = uni_i32(p.sites);
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const VgxLoneLayout L = vgx_lone_layout(P, la.lds_bytes);
+
+    Lone<CLOCK, RCPDIV> c;
+    c.P = P; c.H = H; c.sites = sites; c.lane = lane;
+    c.nrows = uni_i32(L.nrows);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) c.M.m[k] = (lane & 15) >= k ? 1.0 : 0.0;
+    c.ldRng = (double *)(smem + L.rng); c.ldStage = (uint32_t *)(smem + L.stage);
+    c.ldRngK = (uint64_t *)(smem + L.rngk); c.ldRngS = (uint64_t *)(smem + L.rngs); c.ldCold = (int64_t *)(smem + L.cold);
+    c.ldMig = (double *)(smem + L.mig);
+    c.ldCum = (double *)(smem + L.cum); c.ldTend = (double *)(smem + L.tend);
+    c.ldHap = (int32_t *)(smem + L.hap); c.ldCnt = (int32_t *)(smem + L.cnt);
+    c.c_b = p.cb_b[0]; c.c_sig = p.cb_sigma[0]; c.c_d = p.c_d[0]; c.c_tm = p.c_tm[0];
+    const double c_s = p.c_s[0];
+    for (int i = lane; i < P * P; i += 64) c.ldMig[i] = p.mig[i];
+
+    // ---- start state from the layout of the other direct kernels (vgx_dev.h) ----
+    double *gD = r.popD + rep * PD_COUNT * P;
+    int64_t *gI = r.popI + rep * PI_COUNT * P;
+    int32_t *gN = r.nocc + rep * P;
+    {
+        const bool in = lane < P;
+        c.popRate = 0.0; c.cumPop = 0.0; c.migR = 0.0; c.cumMig = 0.0; c.bC = 0.0;
+        c.maxEBM = in ? la.maxEBM[lane] : 0.0;
+        c.cd = in ? gD[PD_CD * P + lane] : 0.0;
+        c.asz = in ? p.actualSizes[lane] : 1.0;
+        c.rcp = in ? la.rcpAs[lane] : 1.0;
+        c.smul = in ? c_s * p.sampMult[lane] : 0.0;
+        c.totS = in ? (double)gI[PI_TOTSUS * P + lane] : 0.0;
+        c.totI = 0.0;
+        c.row0 = 0; c.rows = 0; c.nocc = 0;
+    }
+    c.has_mig = uni_i32(la.has_mig[0] != 0 ? 1 : 0);
+    VgxRepScalars *sc = r.sc + rep;
+    c.currentTime = sc->currentTime; c.totalRate = 0.0; c.totalMig = 0.0; c.Rtot = 0.0;
+    c.gI = (double)uni_i64(sc->globalInfectious);
+    {
+        const int64_t v = lane == 0 ? sc->bCounter : lane == 1 ? sc->dCounter : lane == 2 ? sc->sCounter : lane == 3 ? sc->mCounter
+                        : lane == 4 ? sc->iCounter : lane == 5 ? sc->migPlus : lane == 6 ? sc->migNonPlus : lane == 7 ? sc->swapLockdown : 0;
+        c.cnt = (uint64_t)v;
+    }
+    c.zero_w = 0ull;
+#ifdef VGX_PROFILE
+    c.prof_acc = 0ull; c.prof_t0 = __builtin_readcyclecounter();
+#endif
+    c.stage_n = 0;
+    c.pos = 32; c.u_pre = 0.0; c.n_pre = 0.0;
+    c.ev_left = 0; c.loop_left = 0; c.s_left = 0; c.ev_left0 = 0; c.loop_left0 = 0; c.iter_base = 0u;
+    if (lane == 0) {
+        c.ldCold[C_EV_PTR] = sc->ev_ptr; c.ldCold[C_LOOPS] = 0; c.ldCold[C_ATT_LOOPS] = 0; c.ldCold[C_TRAJ_NEXT] = 0;
+        c.ldCold[C_RESTARTS] = 0; c.ldCold[C_ATT] = 0; c.ldCold[C_GOOD] = sc->good_attempt; c.ldCold[C_LAST_ATT] = -1;
+    }
+    {   // PCG64 jump constants of this lane: a^(lane+1), sum_{j<=lane} a^j
+        const uint64_t MH = 0x2360ED051FC65DA4ull, ML = 0x4385DF649FCCF645ull;
+        uint64_t Ah = MH, Al = ML, Gh = 0, Gl = 1;
+        for (int j = 1; j < 64; ++j) {
+            uint64_t nh, nl, gh, gl;
+            vgx_mul128(Ah, Al, MH, ML, nh, nl);
+            vgx_mul128(Gh, Gl, MH, ML, gh, gl);
+            vgx_add128(gh, gl, 0, 1);
+            if (j <= lane) { Ah = nh; Al = nl; Gh = gh; Gl = gl; }
+        }
+        c.ldRngK[lane * 4 + 0] = Ah; c.ldRngK[lane * 4 + 1] = Al; c.ldRngK[lane * 4 + 2] = Gh; c.ldRngK[lane * 4 + 3] = Gl;
+    }
+    WSYNC();
+    int error = 0;
+    if (!c.load_lists(gN, r.lhap + rep * P * r.cap, r.lcnt + rep * P * r.cap, r.cap)) c.zero_w |= LONE_F_FULL;
+
+    const bool has_tlimit = !(a.time == -1.0f);
+    const double tlimit = has_tlimit ? (double)a.time : __builtin_inf();
+    c.tlimit = tlimit;
+    const bool has_traj = r.traj != nullptr;
+    c.next_tg = (CLOCK && has_traj && r.traj_points > 0) ? r.traj_t0 : __builtin_inf();
+    const int record_events = a.record_events;
+
+    // PrepareParameters tail (pyx:451): UpdateAllRates
+    if (!c.zero_w) c.rebuild_all();
+
+    for (int64_t att = 0; att < a.attempts && !error && !c.zero_w; ++att) {   // pyx:399-418
+        {
+            VgxPcg64 s;
+            vgx_pcg64_seed(s, (uint64_t)r.seeds[rep], (uint32_t)att);
+            if (lane == 0) {
+                c.ldRngS[0] = s.sh; c.ldRngS[1] = s.sl; c.ldRngS[2] = s.ih; c.ldRngS[3] = s.il;
+                c.ldCold[C_ATT] = att; c.ldCold[C_LAST_ATT] = att; c.ldCold[C_ATT_LOOPS] = 0;
+            }
+            WSYNC();
+        }
+        c.pos = 32;
+        if (any_lane(c.Rtot != 0.0) && any_lane(c.gI != 0.0)) {
+            bool done = false;
+            while (!done) {
+                // ---- a segment of the event loop: at most 2^30 iterations on 32-bit countdowns ----
+                const int64_t ev_ptr = c.cold_get(C_EV_PTR), loops = c.cold_get(C_LOOPS), att_loops = c.cold_get(C_ATT_LOOPS);
+                {
+                    const int64_t cS = (int64_t)bcast_i64((int64_t)c.cnt, EV_SAMPLING);
+                    const bool go = ev_ptr < a.ev_size && (a.sample_size == -1 || cS <= a.sample_size) && (!has_tlimit || any_lane(c.currentTime < tlimit));
+                    if (!go) break;
+                    if (loops >= a.max_loop) { error = ERR_LOOP_GUARD; break; }
+                    c.ev_left0 = (int)min((int64_t)LONE_BIG, a.ev_size - ev_ptr);
+                    c.loop_left0 = (int)min((int64_t)LONE_BIG, a.max_loop - loops);
+                    c.s_left = a.sample_size == -1 ? LONE_BIG : (int)min((int64_t)LONE_BIG, a.sample_size - cS + 1);
+                    c.ev_left = c.ev_left0; c.loop_left = c.loop_left0;
+                    c.iter_base = (uint32_t)att_loops + (uint32_t)c.loop_left0;
+                }
+                for (;;) {
+                    if (min(min(c.ev_left, c.loop_left), c.s_left) <= 0) break;
+                    if (CLOCK && !any_lane(c.currentTime < tlimit)) break;
+                    if (c.pos == 32) {
+                        // 64 PCG64 outputs: lane k jumps the stream k + 1 steps ahead (exact 128-bit arithmetic); even outputs are the
+                        // uniforms of SampleTime (pyx:477), odd ones those of GenerateEvent (pyx:488)
+                        WSYNC();
+                        const uint64_t Ah = c.ldRngK[lane * 4 + 0], Al = c.ldRngK[lane * 4 + 1], Gh = c.ldRngK[lane * 4 + 2], Gl = c.ldRngK[lane * 4 + 3];
+                        const uint64_t sh = c.ldRngS[0], sl = c.ldRngS[1], ih = c.ldRngS[2], il = c.ldRngS[3];
+                        uint64_t h, l, ch, cl;
+                        vgx_mul128(Ah, Al, sh, sl, h, l);
+                        vgx_mul128(Gh, Gl, ih, il, ch, cl);
+                        vgx_add128(h, l, ch, cl);
+                        const double u = vgx_pcg64_output_double(h, l);
+                        WSYNC();
+                        c.ldRng[lane] = (CLOCK && !(lane & 1)) ? -vgx_log(u) : u;
+                        if (lane == 63) { c.ldRngS[0] = h; c.ldRngS[1] = l; }
+                        c.pos = 0;
+                        WSYNC();
+                        c.prefetch_uniforms();
+                    }
+                    c.iteration(ka, rep);
+                    // after an iteration: a full stage, an error, extinction (pyx:410-411)
+                    if (c.stage_n == 64) {
+                        if (record_events) c.stage_flush(ka, rep);
+                        c.stage_n = 0;
+                    }
+                    if (c.zero_w) { done = true; break; }
+                    if (any_lane(c.totalRate == 0.0) || any_lane(c.gI == 0.0)) { done = true; break; }
+                }
+                // ---- end of the segment: the 64-bit bookkeeping ----
+                if (record_events) c.stage_flush(ka, rep);
+                c.stage_n = 0;
+                if (lane == 0) {
+                    c.ldCold[C_EV_PTR] = ev_ptr + (c.ev_left0 - c.ev_left);
+                    c.ldCold[C_LOOPS] = loops + (c.loop_left0 - c.loop_left);
+                    c.ldCold[C_ATT_LOOPS] = att_loops + (c.loop_left0 - c.loop_left);
+                }
+                c.ev_left0 = 0; c.ev_left = 0; c.loop_left0 = 0; c.loop_left = 0;
+                WSYNC();
+            }
+        }
+        if (c.zero_w || error) break;
+        const int64_t ev_ptr = c.cold_get(C_EV_PTR);
+        if (ev_ptr <= 100 && a.iterations > 100) {
+            // Restart (pyx:714-738): compartments back to the initial snapshot, then UpdateAllRates
+            if (lane == 0) {
+                c.ldCold[C_EV_PTR] = 0; c.ldCold[C_TRAJ_NEXT] = 0;
+                c.ldCold[C_RESTARTS] = c.ldCold[C_RESTARTS] + 1;
+                c.ldCold[C_ATT] = att + 1; c.ldCold[C_ATT_LOOPS] = 0;
+            }
+            c.cnt = lane == 7 ? c.cnt : 0ull;
+            c.currentTime = 0.0;
+            c.next_tg = (CLOCK && has_traj && r.traj_points > 0) ? r.traj_t0 : __builtin_inf();
+            WSYNC();
+            if (!c.load_lists(r.i_nocc, r.i_hap, r.i_cnt, r.i_cap)) { c.zero_w |= LONE_F_FULL; break; }
+            c.totS = lane < P ? (double)r.i_sus[lane] : 0.0;
+            c.gI = (double)bcast_i64(iscan((int64_t)c.totI, lane), 63);
+            c.rebuild_all();
+        } else {
+            if (lane == 0) c.ldCold[C_GOOD] = att + 1;
+            WSYNC();
+            break;
+        }
+    }
+    if (c.zero_w) error = (c.zero_w >> 32) & 4ull ? (ERR_CAPACITY | (VGX_LONE_FULL_SITE << 8)) : (c.zero_w >> 32) & 2ull ? ERR_CAPACITY : ERR_ZERO_WEIGHT;
+    if (has_traj && !(c.zero_w & LONE_F_FULL)) c.traj_emit(ka, rep, 0.0, true);
+
+    // ---- end state back in the layout of the other direct kernels ----
+    if (!(c.zero_w & LONE_F_FULL)) {
+        for (int pn = 0; pn < P; ++pn) {
+            int32_t *lh = r.lhap + (rep * P + pn) * r.cap, *lc = r.lcls + (rep * P + pn) * r.cap;
+            int64_t *ln = r.lcnt + (rep * P + pn) * r.cap, *lt = r.ltsum + (rep * P + pn) * r.capT;
+            const int n = uni_i32(lane_get(c.nocc, pn)), base = 16 * uni_i32(lane_get(c.row0, pn));
+            if (n > r.cap) { error = ERR_CAPACITY; continue; }
+            for (int t = 0; 64 * t < n; ++t) {
+                const int idx = 64 * t + lane;
+                const int cv = idx < n ? c.ldCnt[base + idx] : 0;
+                if (idx < n) { lh[idx] = c.ldHap[base + idx]; lc[idx] = 0; ln[idx] = (int64_t)cv; }
+                const int64_t ts = bcast_i64(iscan((int64_t)cv, lane), 63);
+                if (lane == 0 && t < r.capT) lt[t] = ts;          // the tile sums of the row kernels (kept while a list is longer than a tile)
+            }
+            for (int j = ((n + 63) >> 6) + lane; j < r.capT; j += 64) lt[j] = 0;
+            if (n == 0 && lane == 0) lt[0] = 0;
+            if (lane == 0) gN[pn] = n;
+        }
+        if (lane < P) {
+            gD[PD_POPRATE * P + lane] = c.popRate;
+            gD[PD_INFECT * P + lane] = c.popRate;
+            gD[PD_IMMUNE * P + lane] = 0.0;
+            gD[PD_MIG * P + lane] = c.maxEBM * c.totS * (c.gI - c.totI);
+            gD[PD_MAXEBM * P + lane] = c.maxEBM;
+            gI[PI_TOTSUS * P + lane] = (int64_t)c.totS;
+            gI[PI_TOTINF * P + lane] = (int64_t)c.totI;
+            r.sus[rep * P + lane] = (int64_t)c.totS;
+            r.immSrc[rep * P + lane] = 0.0;
+        }
+    }
+#ifdef VGX_PROFILE
+    if (lane < VGX_PROF_SLOTS && r.prof) r.prof[rep * VGX_PROF_SLOTS + lane] = c.prof_acc;
+#endif
+    {
+        const int64_t cB = bcast_i64((int64_t)c.cnt, 0), cD = bcast_i64((int64_t)c.cnt, 1), cS = bcast_i64((int64_t)c.cnt, 2), cM = bcast_i64((int64_t)c.cnt, 3);
+        const int64_t cI = bcast_i64((int64_t)c.cnt, 4), cMigP = bcast_i64((int64_t)c.cnt, 5), cMigN = bcast_i64((int64_t)c.cnt, 6), cSwap = bcast_i64((int64_t)c.cnt, 7);
+        if (lane == 0) {
+            sc->currentTime = c.currentTime; sc->totalRate = c.totalRate; sc->totalMig = c.totalMig;
+            sc->globalInfectious = (int64_t)c.gI;
+            sc->bCounter = cB; sc->dCounter = cD; sc->sCounter = cS; sc->mCounter = cM; sc->iCounter = cI;
+            sc->swapLockdown = cSwap; sc->migPlus = cMigP; sc->migNonPlus = cMigN;
+            sc->good_attempt = c.ldCold[C_GOOD];
+            sc->ev_ptr = c.ldCold[C_EV_PTR]; sc->loop_iterations = c.ldCold[C_LOOPS]; sc->restarts = c.ldCold[C_RESTARTS];
+            sc->loc_n = 0; sc->error = error; sc->traj_next = c.ldCold[C_TRAJ_NEXT];
+            sc->last_attempt = c.ldCold[C_LAST_ATT]; sc->last_attempt_loops = c.ldCold[C_ATT_LOOPS];
+            sc->fa_n = 0;
+        }
+    }
+}
+
+}  // namespace
+
+#define LONE_KERNEL(name, CLOCK, RCPDIV) \
+    extern "C" __global__ void __launch_bounds__(64, 1) name(VgxLoneKArgs) { lone_body<CLOCK, RCPDIV>(); }
+LONE_KERNEL(vgx_lone_kernel, false, true)
+LONE_KERNEL(vgx_lone_kernel_clock, true, true)
+LONE_KERNEL(vgx_lone_kernel_plaindiv, false, false)      // validation: VGX_SOLO_PLAIN_DIV=1
+
+extern "C" __attribute__((visibility("hidden"))) hipError_t vgxi_launch_lone(const VgxDirectArgs *a, const VgxLoneArgs *la, int clock,
+                                                                            hipStream_t stream) {
+    void (*k)(VgxLoneKArgs) = clock ? vgx_lone_kernel_clock : la->exact_rcp_div ? vgx_lone_kernel : vgx_lone_kernel_plaindiv;
+    hipError_t err = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, la->lds_bytes);
+    if (err != hipSuccess) return err;
+    VgxLoneKArgs ka;
+    ka.a = *a; ka.la = *la;
+    if (getenv("VGX_TIMING")) {
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)k, 64, (size_t)la->lds_bytes) == hipSuccess)
+            fprintf(stderr, "vgx_lone: LDS %d B per wavefront (%d heap rows), %d wavefronts per CU\n", (int)la->lds_bytes,
+                    vgx_lone_layout(a->p.P, la->lds_bytes).nrows, nb);
+    }
+    hipLaunchKernelGGL(k, dim3((unsigned)a->n_replicates), dim3(64), (size_t)la->lds_bytes, stream, ka);
+    return hipGetLastError();
+}

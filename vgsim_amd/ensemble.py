@@ -75,7 +75,7 @@ class Ensemble:
         o.traj_points = int(traj_points)
         o.traj_t0, o.traj_t1 = float(traj_window[0]), float(traj_window[1])
         o.mode = {'exact': 0, 'fast': 1, 'fast_philox': 2}[mode]
-        o.kernel = {'auto': 0, 'wave': 1, 'lane': 2, 'quad': 3, 'quadg': 4, 'solo': 5}[kernel]
+        o.kernel = {'auto': 0, 'wave': 1, 'lane': 2, 'quad': 3, 'quadg': 4, 'solo': 5, 'lone': 6}[kernel]
         rc = eng.lib.vgx_simulate_direct(eng.handle, int(iterations), int(sample_size), float(np.float32(epidemic_time)),
                                          int(attempts), C.byref(o))
         eng._check(rc)
