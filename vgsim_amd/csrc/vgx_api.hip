@@ -1168,6 +1168,7 @@ static int direct_core(vgx_engine *e, int64_t iterations, int64_t sample_size, f
         loa.effMig = (const double *)e->r_qeff.p; loa.maxEBM = (const double *)e->r_qmebm.p; loa.has_mig = (const int32_t *)e->r_qflag.p;
         loa.rcpAs = (const double *)e->so_rcp.p;
         loa.exact_rcp_div = getenv("VGX_SOLO_PLAIN_DIV") ? 0 : 1;
+        loa.mut_uniform = (e->h_mut_uniform && !getenv("VGX_LONE_NO_MUTUNI")) ? 1 : 0;
         HIPCHECK(e, vgxi_launch_lone(&a, &loa, solo_clock ? 1 : 0, e->stream));
     }
     else if (use_lanes) HIPCHECK(e, vgxi_launch_lanes(&a, &ws, e->stream));

@@ -102,6 +102,48 @@ static __device__ __forceinline__ double flat_chain(double v, int n, double carr
     return acc;
 }
 
+// ---- whole rows, no way out ----------------------------------------------------------------------------------------------
+// The same chains in whole rows of 16 steps: `rows` (1..4, wave-uniform) rows run completely, entries beyond n MUST hold +0.0 (a row
+// that is partly beyond n adds zeros: x + 0.0 = x).  No compare-and-branch inside a row and one test for the usual case of four
+// rows: a wavefront that runs alone pays four to five cycles per INSTRUCTION whatever it is, and the early exits of flat_chain are
+// twelve scalar instructions per row.  Only the first row's statement carries the s_nop: between the rows nothing writes the chain's
+// DPP source (the value stays live in its register; tools/isa_hazard_scan.py checks the shipped code).
+#define FLAT_ROWSCAN(RM, NOP)                                                                                                  \
+    asm volatile(NOP SOLO_FM(0, "m0", RM) SOLO_FM(1, "m1", RM) SOLO_FM(2, "m2", RM) SOLO_FM(3, "m3", RM)                         \
+                 SOLO_FM(4, "m4", RM) SOLO_FM(5, "m5", RM) SOLO_FM(6, "m6", RM) SOLO_FM(7, "m7", RM)                             \
+                 SOLO_FM(8, "m8", RM) SOLO_FM(9, "m9", RM) SOLO_FM(10, "m10", RM) SOLO_FM(11, "m11", RM)                         \
+                 SOLO_FM(12, "m12", RM) SOLO_FM(13, "m13", RM) SOLO_FM(14, "m14", RM) SOLO_FM(15, "m15", RM)                     \
+                 : [acc] "+v"(acc)                                                                                               \
+                 : [v] "v"(v), [m0] "v"(M.m[0]), [m1] "v"(M.m[1]), [m2] "v"(M.m[2]), [m3] "v"(M.m[3]), [m4] "v"(M.m[4]),          \
+                   [m5] "v"(M.m[5]), [m6] "v"(M.m[6]), [m7] "v"(M.m[7]), [m8] "v"(M.m[8]), [m9] "v"(M.m[9]), [m10] "v"(M.m[10]),  \
+                   [m11] "v"(M.m[11]), [m12] "v"(M.m[12]), [m13] "v"(M.m[13]), [m14] "v"(M.m[14]), [m15] "v"(M.m[15]))
+#define FLAT_ROWSUM(RM, NOP)                                                                                                   \
+    asm volatile(NOP SOLO_FM(0, "mu", RM) SOLO_FM(1, "mu", RM) SOLO_FM(2, "mu", RM) SOLO_FM(3, "mu", RM)                         \
+                 SOLO_FM(4, "mu", RM) SOLO_FM(5, "mu", RM) SOLO_FM(6, "mu", RM) SOLO_FM(7, "mu", RM)                             \
+                 SOLO_FM(8, "mu", RM) SOLO_FM(9, "mu", RM) SOLO_FM(10, "mu", RM) SOLO_FM(11, "mu", RM)                           \
+                 SOLO_FM(12, "mu", RM) SOLO_FM(13, "mu", RM) SOLO_FM(14, "mu", RM) SOLO_FM(15, "mu", RM)                         \
+                 : [acc] "+v"(acc)                                                                                               \
+                 : [v] "v"(v), [mu] "v"(mu))
+#define FLAT_ROW(RM, NOP) do { if (SCAN) FLAT_ROWSCAN(RM, NOP); else FLAT_ROWSUM(RM, NOP); } while (0)
+// SCAN: lane l ends with carry + v[0] + ... + v[l] (lanes of rows that did not run keep the carry).  SUM: every lane of the last row
+// that ran ends with carry + v[0] + ... + v[16 rows - 1].
+template <bool SCAN>
+static __device__ __forceinline__ double flat_rows(double v, int rows, double carry, const Masks &M) {
+    double acc = carry;
+    const double mu = 1.0;
+    rows = uni_i32(rows);
+    FLAT_ROW("0x1", "s_nop 1\n\t");
+    if (rows == 4) {
+        acc = row_carry(acc, 1); FLAT_ROW("0x2", "");
+        acc = row_carry(acc, 2); FLAT_ROW("0x4", "");
+        acc = row_carry(acc, 3); FLAT_ROW("0x8", "");
+    } else if (rows > 1) {
+        acc = row_carry(acc, 1); FLAT_ROW("0x2", "");
+        if (rows > 2) { acc = row_carry(acc, 2); FLAT_ROW("0x4", ""); }
+    }
+    return acc;
+}
+
 // every lane: acc += mu * (v[lane 0 of its row] + ... in order ... + v[lane n-1 of its row]) term by term, mu = 1.0 or 0.0 per
 // lane; v must hold the same 16 values in every row (nn <= 16, entries beyond nn +0.0)
 template <bool TINY = false, bool UNIT = false>

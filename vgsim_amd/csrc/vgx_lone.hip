@@ -29,6 +29,11 @@
 #include "vgx_flat.h"
 #include "vgx_lone.h"
 
+#ifdef VGX_LONE_MARKS
+#define MARK(name) asm volatile("; MARK " name)
+#else
+#define MARK(name)
+#endif
 #ifdef VGX_PROFILE
 #define PROF(i)                                                                   \
     do {                                                                          \
@@ -67,6 +72,7 @@ static __device__ __forceinline__ int wave_sum_i32(int v, int lane) { return (in
 template <bool CLOCK, bool RCPDIV>
 struct Lone {
     int P, H, sites, lane;
+    int prow;                     // DPP rows of 16 lanes that hold populations
     int nrows;                    // rows of the heap
     Masks M;
     // LDS
@@ -80,6 +86,9 @@ struct Lone {
     // ---- population lanes ----
     double popRate, cumPop, migR, cumMig, maxEBM, totS, totI, cd, asz, rcp, smul, bC;
     int row0, rows, nocc;         // the population's list: first heap row, rows owned, entries
+    // ---- mutation lanes (sites <= 16): mRate[h, lane], hapMutType[h, lane / 3, lane % 3] of haplotype 0 when all haplotypes share them ----
+    double mut_m, mut_h;
+    int mut_uni;
     // ---- counters: lane t < 6 <-> events of type t, lane 6 rejected migrations ----
     uint64_t cnt;
     // ---- wave-uniform ----
@@ -96,6 +105,7 @@ struct Lone {
     unsigned long long prof_t0, prof_acc;
 #endif
 
+    __device__ __forceinline__ void prof(int i) { (void)i; PROF(i); }
     __device__ __forceinline__ int64_t cold_get(int i) const { return ldCold[i]; }
     __device__ __forceinline__ void cold_set(int i, int64_t v) {
         if (lane == 0) ldCold[i] = v;
@@ -259,7 +269,7 @@ struct Lone {
         const double t = x * m * m * cd;
         double T = RCPDIV ? div_by_const(t, asz, rcp) : t / asz;
         T = lane < P ? T : 0.0;
-        const double acc = flat_chain<false>(T, P, 0.0, M);
+        const double acc = flat_rows<false>(T, prow, 0.0, M);
         return c_b * bcast(acc, P - 1);
     }
     __device__ __forceinline__ double tE_of(double b, double sm) const { return ((b + c_d) + sm) + c_tm; }   // pyx:522-526
@@ -273,7 +283,7 @@ struct Lone {
             const double w = idx < n ? tE * (double)c : 0.0;
             c = idx + 64 < n ? ldCnt[base + idx + 64] : 0;        // the next tile's counts are on their way during this tile's chain
             const int m = min(64, n - 64 * t);
-            const double cum = flat_chain<true>(w, m, carry, M);
+            const double cum = flat_rows<true>(w, (m + 15) >> 4, carry, M);
             if (idx < n) ldCum[base + idx] = cum;
             carry = bcast(cum, m - 1);
             if (lane == 0) ldTend[r0 + 4 * t] = carry;
@@ -283,14 +293,14 @@ struct Lone {
     }
     // popRate changed: its serial prefix sums and totalRate (pyx:536-539)
     __device__ __forceinline__ void rescan_pop() {
-        cumPop = flat_chain<true>(popRate, P, 0.0, M);
+        cumPop = flat_rows<true>(popRate, prow, 0.0, M);
         totalRate = bcast(cumPop, P - 1);
     }
     // migPopRate of every population, its prefix sums and totalMigrationRate (pyx:541-546)
     __device__ __forceinline__ void remig() {
         if (!has_mig) { totalMig = 0.0; return; }
         migR = lane < P ? maxEBM * totS * (gI - totI) : 0.0;
-        cumMig = flat_chain<true>(migR, P, 0.0, M);
+        cumMig = flat_rows<true>(migR, prow, 0.0, M);
         totalMig = bcast(cumMig, P - 1);
     }
     // UpdateAllRates (pyx:279-351) from the compartments; effectiveMigration and its maxima are parameters here
@@ -358,7 +368,112 @@ struct Lone {
         next_tg = traj_next < r.traj_points ? r.traj_t0 + (double)traj_next * r.traj_dt : __builtin_inf();
     }
 
-    // ---- one iteration of the event loop (pyx:408-409): SampleTime, GenerateEvent with UpdateRates and AddEvent ----
+    // ---- the event loop proper: iterations whose event is a Birth, a Death or a Sampling that leaves its haplotype in the list
+    // (pyx:568-635: 95 % of the events of BASELINE config 3) run here back to back as ONE straight path; it returns when something else
+    // has to happen.  For FAST_SLOW nothing of the iteration is consumed yet: the general form below repeats its choices. ----
+    enum { FAST_END = 0, FAST_REFILL, FAST_SLOW, FAST_POST };
+    __device__ __forceinline__ int fast_loop() {
+        for (;;) {
+            PROF(9);
+            MARK("loop_top");
+            if (min(min(ev_left, loop_left), s_left) <= 0) return FAST_END;
+            if (CLOCK && !any_lane(currentTime < tlimit)) return FAST_END;
+            if (__builtin_expect(pos == 32, 0)) return FAST_REFILL;
+            const double u = u_pre;
+            double t_new = 0.0;
+            if (CLOCK) {
+                t_new = currentTime + (n_pre / Rtot);                      // SampleTime pyx:476-478
+                if (__builtin_expect(any_lane(next_tg < t_new), 0)) return FAST_SLOW;
+            }
+            PROF(0);
+            MARK("uniforms_done");
+            // GenerateEvent (pyx:483-512)
+            double choose = u * Rtot;
+            if (__builtin_expect(!any_lane(totalRate > choose), 0)) return FAST_SLOW;
+            double rn = fdiv(choose, totalRate);
+            const double r2 = totalRate * rn;
+            const int pi = first_or(__builtin_amdgcn_ballot_w64(lane < P && !(cumPop < r2)), P - 1);   // fastChoose(popRate), fc:18-31
+            const double W = bcast(popRate, pi), Cm = bcast(cumPop, pi);
+            const double yW = refined_rcp(W);
+            rn = fdiv_y(r2 - (Cm - W), W, yW);
+            choose = rn * W;
+            rn = fdiv_y(choose, W, yW);     // immunePopRate[pi] = +0.0: the infect branch, (choose - 0.0) / infectPopRate[pi] (pyx:499-500)
+            const double r4 = W * rn;
+            PROF(1);
+            MARK("pop_chosen");
+            // haplotype: fastChoose(hapPopRate[pi], infectPopRate[pi], rn) on the list's stored prefix sums
+            const int n = uni_i32(lane_get(nocc, pi)), r0 = uni_i32(lane_get(row0, pi)), base = 16 * r0;
+            const int nt = (n + 63) >> 6;
+            int t = 0;
+            if (nt > 1) {
+                const double te = ldTend[r0 + 4 * min(lane, nt - 1)];
+                t = first_or(__builtin_amdgcn_ballot_w64(lane < nt && !(te < r4)), nt - 1);
+            }
+            const int idx = 64 * t + lane;
+            const bool in = idx < n;
+            const int ic = base + max(min(idx, n - 1), 0);      // (unconditional loads on clamped indices: no EXEC juggling)
+            const double cv = ldCum[ic];
+            const int hv = ldHap[ic], nv = ldCnt[ic];
+            const double bpi = bcast(bC, pi), smpi = bcast(smul, pi);
+            const double e1 = bpi + c_d, e2 = e1 + smpi, tE = e2 + c_tm;
+            const unsigned long long hit = __builtin_amdgcn_ballot_w64(in && !(cv < r4));
+            const int kl = first_or(hit, (n - 1) & 63);
+            const double cum_k = bcast(cv, kl);
+            const int cnt_k = uni_i32(lane_get(nv, kl)), hap_k = uni_i32(lane_get(hv, kl));
+            const double hpr_k = tE * (double)cnt_k;
+            const double rn5 = fdiv(r4 - (cum_k - hpr_k), hpr_k);
+            // event class: fastChoose(eventHapPopRate[pi, hi, 0..3], tEventHapPopRate[pi, hi], rn), pyx:503-511
+            const double r6 = tE * rn5;
+            const bool is_b = !any_lane(bpi < r6);
+            const bool is_m = any_lane(e2 < r6);
+            const bool is_s = any_lane(e1 < r6);       // (with !is_m: Sampling)
+            // anything but the plain cases goes to the general form: a zero weight or the clamp at H-1 (fc:26-30), a mutation, the
+            // last carrier's death (its entry leaves the list), no susceptible host left
+            const double ts_pi = bcast(totS, pi);
+            const int w0 = is_b ? ((int)any_lane(bpi == 0.0) | (int)any_lane(ts_pi * c_sig == 0.0)) : is_s ? (int)any_lane(smpi == 0.0) : (int)any_lane(c_d == 0.0);
+            const int odd = (int)any_lane(W == 0.0) | (int)(hit == 0ull) | (int)any_lane(hpr_k == 0.0) | (int)is_m | ((int)!is_b & (int)(cnt_k == 1)) | w0;
+            if (__builtin_expect(odd != 0, 0)) return FAST_SLOW;
+            PROF(2);
+            MARK("class_chosen");
+            // ---- the iteration is this path's ----
+            loop_left -= 1;
+            pos += 1;
+            prefetch_uniforms();
+            if (CLOCK) currentTime = t_new;
+            const int ei = is_b ? EV_BIRTH : is_s ? EV_SAMPLING : EV_DEATH;
+            const double sgn = is_b ? 1.0 : -1.0;
+            if (lane == 0) ldCnt[base + 64 * t + kl] = cnt_k + (is_b ? 1 : -1);
+            const double d1 = lane == pi ? sgn : 0.0;            // NewInfections / NewRecoveries (pyx:246-260)
+            totS -= d1; totI += d1;
+            gI += sgn;
+            PROF(3);
+            MARK("event_applied");
+            // UpdateRates(pi, True, True, True), pyx:516-546
+            const double b = birth_rate(pi);
+            bC = lane == pi ? b : bC;
+            PROF(4);
+            MARK("birthrate_done");
+            remig();
+            PROF(5);
+            MARK("remig_done");
+            const double inP = refresh(pi, tE_of(b, smpi));
+            PROF(6);
+            MARK("refresh_done");
+            popRate = lane == pi ? inP : popRate;
+            rescan_pop();
+            PROF(7);
+            MARK("rescan_done");
+            const double den = Rtot;
+            Rtot = totalRate + totalMig;
+            log_event(ei, hap_k, pi, 0, is_b ? H : 0, den);
+            PROF(8);
+            MARK("logged");
+            // what ends the run of fast iterations: a full stage, extinction (pyx:410-411)
+            if (__builtin_expect(((int)any_lane(totalRate == 0.0) | (int)any_lane(gI == 0.0) | (int)(stage_n == 64)) != 0, 0)) return FAST_POST;
+        }
+    }
+
+    // ---- one iteration of the event loop in its general form (pyx:408-409): SampleTime, GenerateEvent with UpdateRates and AddEvent ----
     __device__ __forceinline__ void iteration(LoneKA ka, int64_t rep) {
         const double u = u_pre;
         if (CLOCK) {
@@ -369,7 +484,6 @@ struct Lone {
         loop_left -= 1;
         pos += 1;
         prefetch_uniforms();
-        PROF(0);
         const double den = Rtot;
         double choose = u * Rtot;                                          // GenerateEvent pyx:483-512
         int u_pi = -1;                 // population whose infect rates change; its susceptible count changed too: f_birth
@@ -386,7 +500,6 @@ struct Lone {
             // immunePopRate[pi] = +0.0 is never > choose: the infect branch, rn = (choose - 0.0) / infectPopRate[pi] (pyx:499-500)
             rn = fdiv(choose, W);
             const double r4 = W * rn;
-            PROF(1);
             // ---- haplotype: fastChoose(hapPopRate[pi], infectPopRate[pi], rn) on the list's stored prefix sums ----
             const int n = uni_i32(lane_get(nocc, pi)), r0 = uni_i32(lane_get(row0, pi)), base = 16 * r0;
             const int nt = (n + 63) >> 6;
@@ -416,7 +529,6 @@ struct Lone {
             const int ei = uni_i32((any_lane(bpi < r6) ? 1 : 0) + (any_lane(e1 < r6) ? 1 : 0) + (any_lane(e2 < r6) ? 1 : 0));
             const double w_ei = ei == 0 ? bpi : ei == 1 ? c_d : ei == 2 ? smpi : c_tm;
             zero_weight(w_ei == 0.0);
-            PROF(2);
             if (zero_w) return;          // (indices may be meaningless: the call ends with the error)
             ev_hap = hap_k; ev_pop = pi;
             if (ei < 3) {
@@ -441,6 +553,32 @@ struct Lone {
                 const double tmv = c_tm;
                 rn = (r6 - (tE - tmv)) / tmv;
                 int mi, DS;
+                if (sites <= 16) {
+                    // one site per lane, the three derived states of site s in lanes 3 s .. 3 s + 2: ONE round trip to memory for both
+                    // choices (none when every haplotype has the same rows: they then sit in registers since the start of the call)
+                    double wm = mut_m, wh = mut_h;
+                    if (!mut_uni) {
+                        wm = lane < sites ? p.mRate[(int64_t)hap_k * sites + lane] : 0.0;
+                        wh = lane < 3 * sites ? p.hapMutType[(int64_t)hap_k * sites * 3 + lane] : 0.0;
+                    }
+                    {   // fastChoose(mRate[hi, :], tmRate[hi], rn)
+                        const double cm = flat_rows<true>(wm, 1, 0.0, M);
+                        const double r = tmv * rn;
+                        mi = first_or(__builtin_amdgcn_ballot_w64(lane < sites && !(cm < r)), sites - 1);
+                        const double wi = bcast(wm, mi), total = bcast(cm, mi);
+                        zero_weight(wi == 0.0);
+                        rn = (r - (total - wi)) / wi;
+                    }
+                    {   // fastChoose(hapMutType[hi, mi, :], their sum, rn)
+                        const double w0 = bcast(wh, 3 * mi), w1 = bcast(wh, 3 * mi + 1), w2 = bcast(wh, 3 * mi + 2);
+                        const double r = (w0 + w1 + w2) * rn;
+                        int i = 0;
+                        double total = w0;
+                        if (any_lane(total < r)) { i = 1; total += w1; if (any_lane(total < r)) i = 2; }
+                        zero_weight((i == 0 ? w0 : i == 1 ? w1 : w2) == 0.0);
+                        DS = uni_i32(i);
+                    }
+                } else {
                 {   // fastChoose(mRate[hi, :], tmRate[hi], rn)
                     const double *w = p.mRate + (int64_t)hap_k * sites;
                     const double r = tmv * rn;
@@ -460,6 +598,7 @@ struct Lone {
                     while (any_lane(total < r) && i < 2) { i += 1; total += w[i]; }
                     zero_weight(w[i] == 0.0);
                     DS = uni_i32(i);
+                }
                 }
                 if (zero_w) return;
                 const int digit4 = 1 << (2 * (sites - mi - 1));      // Mutate, pyx:2420-2427
@@ -547,7 +686,6 @@ struct Lone {
                 ev_type = EV_MIGRATION;
             }
         }
-        PROF(3);
         // ---- UpdateRates(u_pi, ...) (pyx:516-546) ----
         if (u_pi >= 0) {
             double b = bcast(bC, u_pi);
@@ -555,18 +693,13 @@ struct Lone {
                 b = birth_rate(u_pi);
                 bC = lane == u_pi ? b : bC;
             }
-            PROF(4);
             if (f_birth) remig();
-            PROF(5);
             const double inP = refresh(u_pi, tE_of(b, bcast(smul, u_pi)));
-            PROF(6);
             popRate = lane == u_pi ? inP : popRate;
             rescan_pop();
-            PROF(7);
         }
         Rtot = totalRate + totalMig;
         log_event(ev_type, ev_hap, ev_pop, ev_nh, ev_np, den);
-        PROF(8);
     }
 };
 
@@ -586,6 +719,7 @@ static __device__ __forceinline__ void lone_body() {
 
     Lone<CLOCK, RCPDIV> c;
     c.P = P; c.H = H; c.sites = sites; c.lane = lane;
+    c.prow = uni_i32((P + 15) >> 4);
     c.nrows = uni_i32(L.nrows);
 #pragma unroll
     for (int k = 0; k < 16; ++k) c.M.m[k] = (lane & 15) >= k ? 1.0 : 0.0;
@@ -615,6 +749,9 @@ static __device__ __forceinline__ void lone_body() {
         c.row0 = 0; c.rows = 0; c.nocc = 0;
     }
     c.has_mig = uni_i32(la.has_mig[0] != 0 ? 1 : 0);
+    c.mut_uni = uni_i32((la.mut_uniform && sites >= 1 && sites <= 16) ? 1 : 0);
+    c.mut_m = (c.mut_uni && lane < sites) ? p.mRate[lane] : 0.0;
+    c.mut_h = (c.mut_uni && lane < 3 * sites) ? p.hapMutType[lane] : 0.0;
     VgxRepScalars *sc = r.sc + rep;
     c.currentTime = sc->currentTime; c.totalRate = 0.0; c.totalMig = 0.0; c.Rtot = 0.0;
     c.gI = (double)uni_i64(sc->globalInfectious);
@@ -688,9 +825,9 @@ static __device__ __forceinline__ void lone_body() {
                     c.iter_base = (uint32_t)att_loops + (uint32_t)c.loop_left0;
                 }
                 for (;;) {
-                    if (min(min(c.ev_left, c.loop_left), c.s_left) <= 0) break;
-                    if (CLOCK && !any_lane(c.currentTime < tlimit)) break;
-                    if (c.pos == 32) {
+                    const int why = c.fast_loop();
+                    if (why == c.FAST_END) break;
+                    if (why == c.FAST_REFILL) {
                         // 64 PCG64 outputs: lane k jumps the stream k + 1 steps ahead (exact 128-bit arithmetic); even outputs are the
                         // uniforms of SampleTime (pyx:477), odd ones those of GenerateEvent (pyx:488)
                         WSYNC();
@@ -707,8 +844,9 @@ static __device__ __forceinline__ void lone_body() {
                         c.pos = 0;
                         WSYNC();
                         c.prefetch_uniforms();
+                        continue;
                     }
-                    c.iteration(ka, rep);
+                    if (why == c.FAST_SLOW) c.iteration(ka, rep);
                     // after an iteration: a full stage, an error, extinction (pyx:410-411)
                     if (c.stage_n == 64) {
                         if (record_events) c.stage_flush(ka, rep);
