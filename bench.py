@@ -676,7 +676,7 @@ def config5_leg(device, world=1, rank=0, events=100000, traj_points=1001):
         elif err is not None:
             raise err
         t1 = time.perf_counter()
-        out = ens.gather_trajectories(dst=0)
+        out = ens.gather_trajectories(dst=0, device="cuda")     # (one rank: the result stays on the GPU, where an RCCL gather leaves it on rank 0)
         torch.cuda.synchronize()
         t_gather = time.perf_counter() - t1
     ev = float(res.total_events)
@@ -693,7 +693,12 @@ def config5_leg(device, world=1, rank=0, events=100000, traj_points=1001):
          "value": tot / tmax, "unit": "events/s (wall: simulate + gather, max over ranks)", "replicates_per_gpu": R,
          "kernel_ms_per_launch": res.kernel_ms, "simulate_s": t_sim, "gather_ms": 1e3 * t_gather,
          "gather_bytes_per_gpu": R * traj_points * POPS * 2 * 8, "gathered_shape_on_rank0": shape,
-         "collective": "torch.distributed.gather (RCCL)" if world > 1 else "none (one rank)"}
+         "collective": "torch.distributed.gather (RCCL)" if world > 1 else "none (one rank: device-to-device copy into the result tensor)",
+         "result_on": str(out.device) if out is not None else None,
+         "kernel": ens.engine.last_kernel,
+         "note": "256 replicates are 256 wavefronts: ONE GPU already runs them all concurrently (one per CU), so sharding them 32 per GPU "
+                 "cannot shorten any of them: this leg is latency-bound per trajectory and flat in the GPU count; the weak-scaling "
+                 "headline (16 384 replicates per GPU) is the curve that scales"}
     ens.close()
     return o
 

@@ -144,6 +144,33 @@ static __device__ __forceinline__ double flat_rows(double v, int rows, double ca
     return acc;
 }
 
+// ---- two independent chains of 64 steps, interleaved ----------------------------------------------------------------------------
+// A dependent v_fmac_f64 is ready after ~7 cycles, a lone wavefront can issue one every 4: two chains that do not depend on each other
+// (BirthRate's sum and the migPopRate prefix sums after a birth: vgx_lone.hip) run in the time of one when their steps alternate.  ONE
+// asm statement: the accumulators are fixed registers (the row-to-row moves address their halves, which an operand cannot), every DPP
+// read keeps its two wait states by construction (tools/isa_hazard_scan.py checks the shipped code).
+// A: every lane of row 3 ends with va[0] + ... + va[63] (SUM).  B: lane l ends with vb[0] + ... + vb[l] (SCAN).  Both from +0.0.
+#define FLAT2_A(K, RM) "v_fmac_f64_dpp v[200:201], %[va], %[mu] row_newbcast:" #K " row_mask:" RM " bank_mask:0xf\n\t"
+#define FLAT2_B(K, RM) "v_fmac_f64_dpp v[202:203], %[vb], %[m" #K "] row_newbcast:" #K " row_mask:" RM " bank_mask:0xf\n\t"
+#define FLAT2_S(K, RM) FLAT2_A(K, RM) FLAT2_B(K, RM)
+#define FLAT2_ROW(RM) FLAT2_S(0, RM) FLAT2_S(1, RM) FLAT2_S(2, RM) FLAT2_S(3, RM) FLAT2_S(4, RM) FLAT2_S(5, RM) FLAT2_S(6, RM) FLAT2_S(7, RM) \
+                      FLAT2_S(8, RM) FLAT2_S(9, RM) FLAT2_S(10, RM) FLAT2_S(11, RM) FLAT2_S(12, RM) FLAT2_S(13, RM) FLAT2_S(14, RM) FLAT2_S(15, RM)
+#define FLAT2_MV(R, RM) "v_mov_b32_dpp " R ", " R " row_bcast:15 row_mask:" RM " bank_mask:0xf\n\t"
+#define FLAT2_NEXT(RM) "s_nop 0\n\t" FLAT2_MV("v200", RM) FLAT2_MV("v201", RM) FLAT2_MV("v202", RM) FLAT2_MV("v203", RM)
+static __device__ __forceinline__ void flat_two64(double va, double vb, const Masks &M, double &sumA, double &scanB) {
+    const double mu = 1.0;
+    double oa, ob;
+    asm volatile("v_mov_b64 v[200:201], 0\n\tv_mov_b64 v[202:203], 0\n\ts_nop 1\n\t"
+                 FLAT2_ROW("0x1") FLAT2_NEXT("0x2") FLAT2_ROW("0x2") FLAT2_NEXT("0x4") FLAT2_ROW("0x4") FLAT2_NEXT("0x8") FLAT2_ROW("0x8")
+                 "v_mov_b64 %[oa], v[200:201]\n\tv_mov_b64 %[ob], v[202:203]\n\t"
+                 : [oa] "=&v"(oa), [ob] "=&v"(ob)
+                 : [va] "v"(va), [vb] "v"(vb), [mu] "v"(mu), [m0] "v"(M.m[0]), [m1] "v"(M.m[1]), [m2] "v"(M.m[2]), [m3] "v"(M.m[3]),
+                   [m4] "v"(M.m[4]), [m5] "v"(M.m[5]), [m6] "v"(M.m[6]), [m7] "v"(M.m[7]), [m8] "v"(M.m[8]), [m9] "v"(M.m[9]),
+                   [m10] "v"(M.m[10]), [m11] "v"(M.m[11]), [m12] "v"(M.m[12]), [m13] "v"(M.m[13]), [m14] "v"(M.m[14]), [m15] "v"(M.m[15])
+                 : "v200", "v201", "v202", "v203");
+    sumA = oa; scanB = ob;
+}
+
 // every lane: acc += mu * (v[lane 0 of its row] + ... in order ... + v[lane n-1 of its row]) term by term, mu = 1.0 or 0.0 per
 // lane; v must hold the same 16 values in every row (nn <= 16, entries beyond nn +0.0)
 template <bool TINY = false, bool UNIT = false>

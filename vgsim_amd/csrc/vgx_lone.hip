@@ -272,6 +272,24 @@ struct Lone {
         const double acc = flat_rows<false>(T, prow, 0.0, M);
         return c_b * bcast(acc, P - 1);
     }
+    // BirthRate of population pi and the migration rates after a birth / death there: the two sums do not depend on each other
+    __device__ __forceinline__ double birth_rate_and_remig(int pi) {
+        if (!(has_mig && prow == 4)) {
+            const double b = birth_rate(pi);
+            remig();
+            return b;
+        }
+        const double x = bcast(totS, pi) * c_sig;
+        const double m = ldMig[pi * P + min(lane, P - 1)];
+        const double t = x * m * m * cd;
+        double T = RCPDIV ? div_by_const(t, asz, rcp) : t / asz;
+        T = lane < P ? T : 0.0;
+        migR = lane < P ? maxEBM * totS * (gI - totI) : 0.0;
+        double acc;
+        flat_two64(T, migR, M, acc, cumMig);
+        totalMig = bcast(cumMig, P - 1);
+        return c_b * bcast(acc, P - 1);
+    }
     __device__ __forceinline__ double tE_of(double b, double sm) const { return ((b + c_d) + sm) + c_tm; }   // pyx:522-526
     // hapPopRate = tE * infectious over the list in haplotype order, its serial prefix sums into the heap; returns infectPopRate[pi]
     __device__ __forceinline__ double refresh(int pi, double tE) {
@@ -449,11 +467,10 @@ struct Lone {
             PROF(3);
             MARK("event_applied");
             // UpdateRates(pi, True, True, True), pyx:516-546
-            const double b = birth_rate(pi);
+            const double b = birth_rate_and_remig(pi);
             bC = lane == pi ? b : bC;
             PROF(4);
             MARK("birthrate_done");
-            remig();
             PROF(5);
             MARK("remig_done");
             const double inP = refresh(pi, tE_of(b, smpi));

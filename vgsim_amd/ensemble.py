@@ -173,7 +173,7 @@ class Ensemble:
         eng._check(eng.lib.vgx_get_trajectories(eng.handle, C.c_void_p(out.data_ptr()), 1 if out.is_cuda else 0))
         return out
 
-    def gather_trajectories(self, dst=0, out=None, async_op=False, wire_dtype=None):
+    def gather_trajectories(self, dst=0, out=None, async_op=False, wire_dtype=None, device=None):
         """One collective for the whole ensemble: every rank's ``[R, T, P, 2]`` block to rank ``dst``
         (``torch.distributed.gather``; backend nccl = RCCL over xGMI, gloo on CPU).  Returns the stacked
         ``[world, R, T, P, 2]`` tensor on ``dst`` and None elsewhere; ``out`` may be a preallocated result tensor on
@@ -181,7 +181,8 @@ class Ensemble:
         may overwrite them) and a :class:`PendingGather` is returned: the transfer overlaps the next step and
         ``.wait()`` gives the result.  ``wire_dtype=torch.int32`` sends the compartment totals as 32-bit integers (they are
         whole numbers; refused unless every population size is below 2^31): half the bytes on every xGMI link and in the
-        result on ``dst``, which then has that dtype."""
+        result on ``dst``, which then has that dtype.  Without a process group (one rank) the result is a host tensor, or — with
+        ``device='cuda'`` — a tensor on the engine's GPU, filled there: where an RCCL gather leaves it on rank ``dst``."""
         import torch
         import torch.distributed as dist
 
@@ -195,7 +196,11 @@ class Ensemble:
             return t.to(torch.int32)
 
         if not (dist.is_available() and dist.is_initialized()):
-            res = narrow(torch.from_numpy(self.trajectories()))[None]
+            if device is not None and str(device).startswith("cuda"):
+                dev = torch.device("cuda", torch.cuda.current_device()) if str(device) == "cuda" else torch.device(device)
+                res = narrow(self.trajectories(torch.empty(self.traj_shape, dtype=torch.float64, device=dev)))[None]
+            else:
+                res = narrow(torch.from_numpy(self.trajectories()))[None]
             return PendingGather(None, res, None) if async_op else res
         backend = dist.get_backend()
         if backend == "nccl":
