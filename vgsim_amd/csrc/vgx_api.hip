@@ -1451,7 +1451,7 @@ extern "C" int vgx_simulate_tau(vgx_engine *e, int64_t iterations, int64_t sampl
         ? std::max<int64_t>(1, std::min<int64_t>(mev_max / 2,
                                                  std::max<int64_t>((int64_t)1 << 22, std::min<int64_t>(iterations, 1 << 20) * rows_per_step)))
         : 0;   // doubled on demand (a try whose rows do not fit is run again), up to mev_max
-    const size_t nF = 10;  // int32 flag arrays
+    const size_t nF = 11;  // int32 flag arrays
     const int64_t Ppad = (P + 31) / 32 * 32;
     rc = 0;
     rc |= ensure(e, e->r_locrec, (size_t)(R * VGX_LOC_CAP * 2) * 4);
@@ -1589,6 +1589,7 @@ extern "C" int vgx_simulate_tau(vgx_engine *e, int64_t iterations, int64_t sampl
     const int32_t *pin_flags = (const int32_t *)e->pin_tau;
     const int64_t *pin_res = (const int64_t *)((const char *)e->pin_tau + (((size_t)R * 3 * 4 + 63) & ~(size_t)63));
     a.step = fl + 5 * R; a.error = fl + 6 * R; a.attempt = fl + 7 * R; a.eff_dirty = fl + 8 * R; a.deciding = fl + 9 * R;
+    a.spec = fl + 10 * R; a.gate = 0;
     a.Ppad = (int32_t)Ppad;
     {
         std::vector<int32_t> ones((size_t)R, 1);
@@ -1729,6 +1730,13 @@ extern "C" int vgx_simulate_tau(vgx_engine *e, int64_t iterations, int64_t sampl
     int64_t tries_total = 0, tries_lists = 0;
     const char *nfo = getenv("VGX_TAU_NO_FRONT_ALONE");
     const bool front_split = R == 1 && a.front_on && !(nfo && nfo[0] == '1');   // (several replicates: their tries end at different places)
+    // ... and whole rounds of a step without the host in between (VgxTauArgs.spec / gate); VGX_TAU_SPEC=0: one try per synchronisation as
+    // before, VGX_TAU_SPEC=k: k front passes per round
+    int spec_k = 6;
+    bool spec_adapt = true;      // the number of front passes per round follows the last step's (rejected tries + the one that ran + one to spare)
+    if (const char *sk = getenv("VGX_TAU_SPEC")) { spec_k = atoi(sk); spec_adapt = false; }
+    const bool spec_rounds = front_split && spec_k > 0;
+    int64_t host_syncs = 0;
     bool front_done = false;
     bool i8_dirty = true;    // I8 does not mirror I (start of the call, after a Restart's upload, after a dense try)
     // Small models: the whole step loop on the device, one workgroup per replicate (vgx_taus.hip).  VGX_TAU_STEP_KERNELS=1 and the
@@ -1934,78 +1942,8 @@ extern "C" int vgx_simulate_tau(vgx_engine *e, int64_t iterations, int64_t sampl
         launches += 4;
         if (a.sieve_on) { HIPCHECK(e, vgxi_tau_sieve(&a, e->stream)); launches += 2; }
         bool dense_once = false;   // the last try asked for dense delta arrays
-        for (int tries = 0;; tries++) {
-            a.sparse = (sparse_default && !dense_once) ? 1 : 0;
-            if (!a.sparse && !dense_ready) {
-                int rcd = ensure_dense();
-                if (rcd) return rcd;
-                a.dChk = (int32_t *)e->t_dChk.p; a.dApp = (int32_t *)e->t_dApp.p;
-            }
-            dense_once = false;
-            if (++a.gen >= (1u << 25)) {   // the table's try counter wraps: start over with an empty table
-                HIPCHECK(e, hipMemsetAsync(e->t_stkey.p, 0, (size_t)(R * st_size) * 8, e->stream));
-                a.gen = 1;
-            }
-            if (front_split && a.sparse && !front_done) {
-                // One replicate: the front pass of the try first, alone (most tries end there: three kernels and the host's turn instead
-                // of ten); if it finds nothing the try proper follows (phase 2), with the queue the list pass has already built.
-                a.phase = 1;
-                tries_total += 1;
-                if (a.use_list) tries_lists += 1;
-                HIPCHECK(e, vgxi_tau_draw(&a, e->stream));
-                HIPCHECK(e, vgxi_tau_decide(&a, e->stream));
-                launches += 3;
-                HIPCHECK(e, hipStreamSynchronize(e->stream));
-                a.phase = 0;
-                if (pin_flags[2 * R] == 1) { front_done = true; continue; }     // nothing found: the same try, for real
-                if (pin_flags[0]) break;                                        // (the loop guard of the halving: handled below like an accepted step)
-                if (tries > 600) return fail(e, VGX_ERR_LOOP_GUARD, "vgx_simulate_tau: tau halving did not converge");
-                continue;                                                       // rejected: tau halved, the next try
-            }
-            a.phase = front_done ? 2 : 0;
-            front_done = false;
-            if (a.phase == 0) {
-                tries_total += 1;
-                if (a.use_list && a.front_on && a.sparse) tries_lists += 1;
-            }
-            HIPCHECK(e, vgxi_tau_draw(&a, e->stream));
-            HIPCHECK(e, vgxi_tau_draw_big(&a, e->stream));   // (+ the immunity transitions: extra blocks of the same launch)
-            if (a.sparse) {
-                HIPCHECK(e, vgxi_tau_arrivals(&a, e->stream));
-                HIPCHECK(e, vgxi_tau_verdict(&a, e->stream));
-                HIPCHECK(e, vgxi_tau_decide(&a, e->stream));
-                HIPCHECK(e, vgxi_tau_apply(&a, e->stream));
-                if (a.use8) { HIPCHECK(e, vgxi_tau_sync8(&a, e->stream)); launches += 1; }
-            } else {
-                i8_dirty = true;     // (the dense commit pass changes the counts without the one-byte copy)
-                HIPCHECK(e, vgxi_tau_scatter(&a, e->stream));
-                HIPCHECK(e, vgxi_tau_suspect(&a, e->stream));
-                if (a.dense_check) HIPCHECK(e, vgxi_tau_check(&a, e->stream));
-                else if (suspect_cap < P * H) {
-                    // more compartments below zero on their own than the list holds (never at tries the sieve lets through; tiny
-                    // models list every compartment): the dense pass decides
-                    susp_h.resize((size_t)R);
-                    HIPCHECK(e, hipMemcpyAsync(susp_h.data(), a.suspect_n, (size_t)R * 8, hipMemcpyDeviceToHost, e->stream));
-                    HIPCHECK(e, hipStreamSynchronize(e->stream));
-                    bool over = false;
-                    for (int64_t r = 0; r < R; r++) over = over || (int64_t)susp_h[(size_t)r] > suspect_cap;
-                    if (over) { HIPCHECK(e, vgxi_tau_check(&a, e->stream)); launches += 1; }
-                }
-                HIPCHECK(e, vgxi_tau_decide(&a, e->stream));
-                HIPCHECK(e, vgxi_tau_commit(&a, e->stream));
-            }
-            launches += 8;
-            HIPCHECK(e, hipStreamSynchronize(e->stream));
-            acc_h.assign(pin_flags, pin_flags + (size_t)R * 2);   // accepted[R], grow[R]: the decide kernel's copy in pinned host memory
-            bool all = true;
-            for (int64_t r = 0; r < R; r++)
-                if (running[(size_t)r] && !acc_h[(size_t)r]) all = false;
-            if (all) break;
-            // a try that lost data (a full list) or that the sparse check could not decide was discarded by the decide kernel
-            // without touching tau or the try index: enlarge the list (it is empty now) / switch to the dense delta arrays
-            // and run the same try again
-            int again = 0;
-            for (int64_t r = 0; r < R; r++) again |= acc_h[(size_t)(R + r)];
+        // what a discarded try asks of the host (VgxTauArgs.grow): a larger list / buffer, or the dense delta arrays for the same try
+        auto handle_again = [&](int again) -> int {
             if (again & 1) {
                 if (inc_cap > ((int64_t)1 << 33) / std::max<int64_t>(R, 1))
                     return fail(e, VGX_ERR_CAPACITY, "vgx_simulate_tau: more than 2^33 individuals change compartment in one leap");
@@ -2056,12 +1994,144 @@ extern "C" int vgx_simulate_tau(vgx_engine *e, int64_t iterations, int64_t sampl
             }
             if (again & 2) dense_once = true;
             if (again) HIPCHECK(e, hipMemset(a.grow, 0, (size_t)R * 4));
+            return VGX_OK;
+        };
+        bool finished_on_device = false;
+        for (int tries = 0;; tries++) {
+            if (spec_rounds && sparse_default && !dense_once) {
+                // One replicate, ONE synchronisation per round: the front passes of `spec_k` tries back to back (each returns at once when
+                // an earlier one has found nothing: VgxTauArgs.spec), the try proper of that one, and the end of the step, all enqueued
+                // without a look from the host.  What the host reads afterwards: accepted / grow as the last decide kernel that ran left
+                // them.  (Tries that find a failure cost what they cost before; what goes is the host's turn between them.)
+                a.sparse = 1;
+                HIPCHECK(e, hipMemsetAsync(a.spec, 0, (size_t)R * 4, e->stream));
+                auto next_gen = [&]() -> int {
+                    if (++a.gen >= (1u << 25)) {   // the table's try counter wraps: start over with an empty table
+                        if (hipMemsetAsync(e->t_stkey.p, 0, (size_t)(R * st_size) * 8, e->stream) != hipSuccess) return VGX_ERR_HIP;
+                        a.gen = 1;
+                    }
+                    return VGX_OK;
+                };
+                for (int j = 0; j < spec_k; j++) {
+                    if (next_gen()) return fail(e, VGX_ERR_HIP, "vgx_simulate_tau: hipMemsetAsync failed");
+                    a.phase = 1; a.gate = 1;
+                    HIPCHECK(e, vgxi_tau_draw(&a, e->stream));
+                    HIPCHECK(e, vgxi_tau_decide(&a, e->stream));
+                    launches += 3;
+                }
+                if (next_gen()) return fail(e, VGX_ERR_HIP, "vgx_simulate_tau: hipMemsetAsync failed");
+                a.phase = 2; a.gate = 2;
+                HIPCHECK(e, vgxi_tau_draw(&a, e->stream));
+                HIPCHECK(e, vgxi_tau_draw_big(&a, e->stream));
+                HIPCHECK(e, vgxi_tau_arrivals(&a, e->stream));
+                HIPCHECK(e, vgxi_tau_verdict(&a, e->stream));
+                HIPCHECK(e, vgxi_tau_decide(&a, e->stream));
+                HIPCHECK(e, vgxi_tau_apply(&a, e->stream));
+                if (a.use8) { HIPCHECK(e, vgxi_tau_sync8(&a, e->stream)); launches += 1; }
+                a.gate = 3;
+                HIPCHECK(e, vgxi_tau_finish(&a, e->stream));
+                a.gate = 0; a.phase = 0;
+                launches += 8;
+                HIPCHECK(e, hipEventRecord(e->ev1, e->stream));
+                HIPCHECK(e, hipStreamSynchronize(e->stream));
+                host_syncs += 1;
+                tries += spec_k;
+                acc_h.assign(pin_flags, pin_flags + (size_t)R * 2);
+                if (acc_h[0]) { finished_on_device = true; break; }
+                const int again = acc_h[(size_t)R];
+                if (again) {   // (the rare cases: a list to enlarge, or the dense delta arrays — then the loop below runs this try)
+                    const int rca = handle_again(again);
+                    if (rca) return rca;
+                }
+                if (tries > 600) return fail(e, VGX_ERR_LOOP_GUARD, "vgx_simulate_tau: tau halving did not converge");
+                continue;
+            }
+            a.sparse = (sparse_default && !dense_once) ? 1 : 0;
+            if (!a.sparse && !dense_ready) {
+                int rcd = ensure_dense();
+                if (rcd) return rcd;
+                a.dChk = (int32_t *)e->t_dChk.p; a.dApp = (int32_t *)e->t_dApp.p;
+            }
+            dense_once = false;
+            if (++a.gen >= (1u << 25)) {   // the table's try counter wraps: start over with an empty table
+                HIPCHECK(e, hipMemsetAsync(e->t_stkey.p, 0, (size_t)(R * st_size) * 8, e->stream));
+                a.gen = 1;
+            }
+            if (front_split && a.sparse && !front_done) {
+                // One replicate: the front pass of the try first, alone (most tries end there: three kernels and the host's turn instead
+                // of ten); if it finds nothing the try proper follows (phase 2), with the queue the list pass has already built.
+                a.phase = 1;
+                tries_total += 1;
+                if (a.use_list) tries_lists += 1;
+                HIPCHECK(e, vgxi_tau_draw(&a, e->stream));
+                HIPCHECK(e, vgxi_tau_decide(&a, e->stream));
+                launches += 3;
+                HIPCHECK(e, hipStreamSynchronize(e->stream));
+                host_syncs += 1;
+                a.phase = 0;
+                if (pin_flags[2 * R] == 1) { front_done = true; continue; }     // nothing found: the same try, for real
+                if (pin_flags[0]) break;                                        // (the loop guard of the halving: handled below like an accepted step)
+                if (tries > 600) return fail(e, VGX_ERR_LOOP_GUARD, "vgx_simulate_tau: tau halving did not converge");
+                continue;                                                       // rejected: tau halved, the next try
+            }
+            a.phase = front_done ? 2 : 0;
+            front_done = false;
+            if (a.phase == 0) {
+                tries_total += 1;
+                if (a.use_list && a.front_on && a.sparse) tries_lists += 1;
+            }
+            HIPCHECK(e, vgxi_tau_draw(&a, e->stream));
+            HIPCHECK(e, vgxi_tau_draw_big(&a, e->stream));   // (+ the immunity transitions: extra blocks of the same launch)
+            if (a.sparse) {
+                HIPCHECK(e, vgxi_tau_arrivals(&a, e->stream));
+                HIPCHECK(e, vgxi_tau_verdict(&a, e->stream));
+                HIPCHECK(e, vgxi_tau_decide(&a, e->stream));
+                HIPCHECK(e, vgxi_tau_apply(&a, e->stream));
+                if (a.use8) { HIPCHECK(e, vgxi_tau_sync8(&a, e->stream)); launches += 1; }
+            } else {
+                i8_dirty = true;     // (the dense commit pass changes the counts without the one-byte copy)
+                HIPCHECK(e, vgxi_tau_scatter(&a, e->stream));
+                HIPCHECK(e, vgxi_tau_suspect(&a, e->stream));
+                if (a.dense_check) HIPCHECK(e, vgxi_tau_check(&a, e->stream));
+                else if (suspect_cap < P * H) {
+                    // more compartments below zero on their own than the list holds (never at tries the sieve lets through; tiny
+                    // models list every compartment): the dense pass decides
+                    susp_h.resize((size_t)R);
+                    HIPCHECK(e, hipMemcpyAsync(susp_h.data(), a.suspect_n, (size_t)R * 8, hipMemcpyDeviceToHost, e->stream));
+                    HIPCHECK(e, hipStreamSynchronize(e->stream));
+                    bool over = false;
+                    for (int64_t r = 0; r < R; r++) over = over || (int64_t)susp_h[(size_t)r] > suspect_cap;
+                    if (over) { HIPCHECK(e, vgxi_tau_check(&a, e->stream)); launches += 1; }
+                }
+                HIPCHECK(e, vgxi_tau_decide(&a, e->stream));
+                HIPCHECK(e, vgxi_tau_commit(&a, e->stream));
+            }
+            launches += 8;
+            HIPCHECK(e, hipStreamSynchronize(e->stream));
+            host_syncs += 1;
+            acc_h.assign(pin_flags, pin_flags + (size_t)R * 2);   // accepted[R], grow[R]: the decide kernel's copy in pinned host memory
+            bool all = true;
+            for (int64_t r = 0; r < R; r++)
+                if (running[(size_t)r] && !acc_h[(size_t)r]) all = false;
+            if (all) break;
+            // a try that lost data (a full list) or that the sparse check could not decide was discarded by the decide kernel
+            // without touching tau or the try index: enlarge the list (it is empty now) / switch to the dense delta arrays
+            // and run the same try again
+            int again = 0;
+            for (int64_t r = 0; r < R; r++) again |= acc_h[(size_t)(R + r)];
+            {
+                const int rca = handle_again(again);
+                if (rca) return rca;
+            }
             if (tries > 600) return fail(e, VGX_ERR_LOOP_GUARD, "vgx_simulate_tau: tau halving did not converge");
         }
-        HIPCHECK(e, vgxi_tau_finish(&a, e->stream));
-        launches += 1;
-        HIPCHECK(e, hipEventRecord(e->ev1, e->stream));
-        HIPCHECK(e, hipStreamSynchronize(e->stream));
+        if (!finished_on_device) {
+            HIPCHECK(e, vgxi_tau_finish(&a, e->stream));
+            launches += 1;
+            HIPCHECK(e, hipEventRecord(e->ev1, e->stream));
+            HIPCHECK(e, hipStreamSynchronize(e->stream));
+            host_syncs += 1;
+        }
         float ms = 0.f;
         HIPCHECK(e, hipEventElapsedTime(&ms, e->ev0, e->ev1));
         ms_total += ms;
@@ -2081,6 +2151,11 @@ extern "C" int vgx_simulate_tau(vgx_engine *e, int64_t iterations, int64_t sampl
             mevn[(size_t)r] = (unsigned long long)o[11];
             err_h[(size_t)r] = (int32_t)o[12];
             if (o[13] >= 0) occ_step = std::max<int64_t>(occ_step, o[13]);
+            if (spec_rounds && r == 0) {
+                tries_total += o[14] + 1;
+                if (a.use_list) tries_lists += o[14] + 1;
+                if (spec_adapt) spec_k = (int)std::min<int64_t>(std::max<int64_t>(o[14] + 2, 2), 8);
+            }
         }
         if (occ_step >= 0) occ_est = occ_step;
         for (int64_t r = 0; r < R; r++) {
@@ -2104,8 +2179,13 @@ extern "C" int vgx_simulate_tau(vgx_engine *e, int64_t iterations, int64_t sampl
     }
 
     lap("step loop");
-    if (timing) fprintf(stderr, "vgx_simulate_tau: %lld tries, %lld of them over the lists of occupied compartments%s\n", (long long)tries_total,
-                        (long long)tries_lists, "");
+    if (timing) {
+        int64_t st_all = 0;
+        for (int64_t r = 0; r < R; r++) st_all += steps_done[(size_t)r];
+        fprintf(stderr, "vgx_simulate_tau: %lld tries, %lld of them over the lists of occupied compartments; %lld host synchronisations in the step loop "
+                        "(%.2f per step)\n", (long long)tries_total, (long long)tries_lists, (long long)host_syncs,
+                (double)host_syncs / (double)std::max<int64_t>(st_all, 1));
+    }
     // ---- results ----
     std::vector<unsigned long long> locn((size_t)R);
     HIPCHECK(e, hipMemcpy(locn.data(), a.loc_n, (size_t)R * 8, hipMemcpyDeviceToHost));

@@ -231,6 +231,14 @@ struct VgxTauArgs {
     int64_t *front;      // [R][P][front_cap] the front pass's lists: compartments that can fall below zero on their own in this try (vgx_tau_front_kernel)
     unsigned int *front_n;   // [R][P] their counts (may exceed front_cap: the rest is found by the try proper); cleared by vgx_tau_decide_kernel
     int32_t front_cap, front_on;
+    // A whole ROUND of a step enqueued without the host in between (one replicate, vgx_api.hip): several tries' front passes back to
+    // back, the try proper of the first one that finds nothing, the end of the step.  `spec` says on the device how far the round is:
+    // 0 = front passes still look for a try that can succeed, 1 = one found nothing: its try proper runs, 2 = over (accepted, an error,
+    // or the host has to enlarge a list).  `gate` (set per launch by the host) says which of these states a launch belongs to: 0 = none
+    // (every launch runs: the host decides between them, as before), 1 = a front pass, 2 = the try proper, 3 = the end of the step
+    // (runs once the try is accepted).  A launch whose state has passed returns at once.
+    int32_t *spec;              // [R]
+    int32_t gate, gate_pad;
     int32_t phase, phase_pad;   // of a try: 0 = front pass and try proper in one go; 1 = the front pass alone (the decide kernel rejects the try or
                                 // reports that the pass found nothing); 2 = the try proper after such a front pass (one replicate: vgx_api.hip)
     unsigned long long *cnt_pop;   // [R][P][8] the events kernel's share of them per population, folded into cnt_try by vgx_tau_decide_kernel

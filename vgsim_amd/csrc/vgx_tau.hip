@@ -50,6 +50,13 @@ static __device__ __forceinline__ void atomic_min_pos_double(unsigned long long 
     atomicMin(addr, (unsigned long long)__double_as_longlong(v));
 }
 
+// a launch of a round whose state has passed (VgxTauArgs.gate / spec): nothing to do
+static __device__ __forceinline__ bool tau_gate_closed(const VgxTauArgs &a, int rep) {
+    if (a.gate == 0) return false;
+    const int st = a.spec[rep];
+    return a.gate == 1 ? st != 0 : a.gate == 2 ? st != 1 : false;
+}
+
 // ------------------------------------------------------------------------------------------------
 // effectiveMigration (pyx:327-338), its transposed/padded product with the diagonal, and the transmission factor,
 // rebuilt only when the contact densities changed (start of the call, lockdown switch).  grid = (P, R): one block
@@ -1813,7 +1820,7 @@ static __host__ __device__ inline int64_t tau_queue_shard_max(int64_t H) {
 // grid = (tau_draw_gx(H), P, R)
 extern "C" __global__ void __launch_bounds__(TB) vgx_tau_scan_kernel(VgxTauArgs a) {
     const int rep = blockIdx.z, pn = blockIdx.y;
-    if (!a.active[rep] || a.accepted[rep]) return;
+    if (!a.active[rep] || a.accepted[rep] || tau_gate_closed(a, rep)) return;
     const VgxDevParams &p = a.p;
     const int P = p.P, S = p.S, C = p.C, CB = p.CB, H = p.H;
     __shared__ float s_rt[256];
@@ -1959,7 +1966,7 @@ extern "C" __global__ void __launch_bounds__(TB) vgx_tau_scan_kernel(VgxTauArgs 
 template <bool C1, bool DENSE>
 __global__ void __launch_bounds__(TB) vgx_tau_scan_fast_kernel(VgxTauArgs a) {
     const int rep = blockIdx.z, pn = blockIdx.y;
-    if (!a.active[rep] || a.accepted[rep]) return;
+    if (!a.active[rep] || a.accepted[rep] || tau_gate_closed(a, rep)) return;
     if (a.front_on && a.ok[rep] == 0) return;   // the front pass found a failure: the try is lost, nothing of it is needed
     const VgxDevParams &p = a.p;
     const int P = p.P, S = p.S, C = p.C, CB = p.CB, H = p.H;
@@ -2123,7 +2130,7 @@ __global__ void __launch_bounds__(TB) vgx_tau_scan_fast_kernel(VgxTauArgs a) {
 // (at most 16 rate classes).
 extern "C" __global__ void __launch_bounds__(TB) vgx_tau_front_kernel(VgxTauArgs a) {
     const int rep = blockIdx.z, pn = blockIdx.y;
-    if (!a.active[rep] || a.accepted[rep]) return;
+    if (!a.active[rep] || a.accepted[rep] || tau_gate_closed(a, rep)) return;
     const VgxDevParams &p = a.p;
     const int P = p.P, S = p.S, H = p.H;
     const int C = p.C, CB = p.CB;
@@ -2244,7 +2251,7 @@ extern "C" __global__ void __launch_bounds__(TB) vgx_tau_front_kernel(VgxTauArgs
 // grid = (tau_draw_gx(H), P, R); the blocks' shards of the queue as in the scan.
 extern "C" __global__ void __launch_bounds__(TB) vgx_tau_listscan_kernel(VgxTauArgs a) {
     const int rep = blockIdx.z, pn = blockIdx.y;
-    if (!a.active[rep] || a.accepted[rep]) return;
+    if (!a.active[rep] || a.accepted[rep] || tau_gate_closed(a, rep)) return;
     const VgxDevParams &p = a.p;
     const int P = p.P, S = p.S, C = p.C, CB = p.CB, H = p.H;
     __shared__ float s_rt[16], s_lf[257];
@@ -2403,7 +2410,7 @@ extern "C" int vgx_tau_get_profile(unsigned long long *out, int clear) {
 template <int TABS, bool FRONT = false>
 __global__ void __launch_bounds__(EB, VGX_EV_WAVES) vgx_tau_events_kernel(VgxTauArgs a) {
     const int rep = blockIdx.z, pn = blockIdx.y;
-    if (!a.active[rep] || a.accepted[rep]) return;
+    if (!a.active[rep] || a.accepted[rep] || tau_gate_closed(a, rep)) return;
 #ifdef VGX_PROFILE
     long long pacc[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, prounds = 0;
     long long &pt = pacc[6];   // (tau_cell_events stamps through the same array: [6] = last stamp, [7..11] its phases)
@@ -2731,7 +2738,7 @@ static __device__ __forceinline__ void tau_suscep_draw(const VgxTauArgs &a, int 
 // of channel, ran one after the other), then book the result.
 extern "C" __global__ void __launch_bounds__(TB) vgx_tau_draw_big_kernel(VgxTauArgs a) {
     const int rep = blockIdx.y;
-    if (!a.active[rep] || a.accepted[rep]) return;
+    if (!a.active[rep] || a.accepted[rep] || tau_gate_closed(a, rep)) return;
     if (blockIdx.x >= VGX_BIG_BLOCKS) {   // the susceptible compartments' immunity transitions
         tau_suscep_draw(a, rep, (int)(blockIdx.x - VGX_BIG_BLOCKS) * TB + (int)threadIdx.x);
         return;
@@ -2962,7 +2969,7 @@ extern "C" __global__ void __launch_bounds__(TB) vgx_tau_suspect_kernel(VgxTauAr
 // grid = (inc_shards, R, VGX_INC_SHARDS / inc_shards) as for the scatter kernel.
 extern "C" __global__ void __launch_bounds__(64) vgx_tau_arrivals_kernel(VgxTauArgs a) {
     const int rep = blockIdx.y, shard = blockIdx.x;
-    if (!a.active[rep] || a.accepted[rep]) return;
+    if (!a.active[rep] || a.accepted[rep] || tau_gate_closed(a, rep)) return;
     const int64_t scap = a.inc_cap / a.inc_shards;
     unsigned long long n = a.inc_n[(int64_t)rep * VGX_INC_SHARDS + shard];
     if ((int64_t)n > scap) {  // shard overflow: entries were lost, nothing of this try counts
@@ -2986,7 +2993,7 @@ extern "C" __global__ void __launch_bounds__(64) vgx_tau_arrivals_kernel(VgxTauA
 // grid = (32, R).
 extern "C" __global__ void __launch_bounds__(TB) vgx_tau_verdict_kernel(VgxTauArgs a) {
     const int rep = blockIdx.y;
-    if (!a.active[rep] || a.accepted[rep]) return;
+    if (!a.active[rep] || a.accepted[rep] || tau_gate_closed(a, rep)) return;
     const VgxDevParams &p = a.p;
     const int P = p.P, S = p.S;
     unsigned long long n = a.suspect_n[rep];
@@ -3014,7 +3021,7 @@ extern "C" __global__ void __launch_bounds__(TB) vgx_tau_verdict_kernel(VgxTauAr
 // vgx_tau_commit_kernel.  grid = (inc_shards, R, VGX_INC_SHARDS / inc_shards).
 extern "C" __global__ void __launch_bounds__(64) vgx_tau_apply_kernel(VgxTauArgs a) {
     const int rep = blockIdx.y, shard = blockIdx.x;
-    if (!a.deciding[rep]) return;
+    if (!a.deciding[rep] || (a.gate == 2 && a.spec[rep] < 2)) return;   // (a round whose front passes found no try to run: nothing to apply or clear)
     const int P = a.p.P, S = a.p.S;
     const bool acc = a.accepted[rep] && !a.error[rep];
     if (acc) {
@@ -3047,7 +3054,7 @@ extern "C" __global__ void __launch_bounds__(64) vgx_tau_apply_kernel(VgxTauArgs
 // a compartment listed twice is written twice with the same, final, value).
 extern "C" __global__ void __launch_bounds__(64) vgx_tau_sync8_kernel(VgxTauArgs a) {
     const int rep = blockIdx.y, shard = blockIdx.x;
-    if (!a.deciding[rep] || !(a.accepted[rep] && !a.error[rep])) return;
+    if (!a.deciding[rep] || !(a.accepted[rep] && !a.error[rep]) || (a.gate == 2 && a.spec[rep] < 2)) return;
     const int P = a.p.P, H = a.p.H;
     const int64_t PH = (int64_t)P * H;
     const int64_t scap = a.inc_cap / a.inc_shards;
@@ -3115,12 +3122,14 @@ extern "C" __global__ void __launch_bounds__(TB) vgx_tau_check_kernel(VgxTauArgs
 // try was accepted or rejected.
 extern "C" __global__ void __launch_bounds__(64) vgx_tau_decide_kernel(VgxTauArgs a) {
     const int rep = blockIdx.x;
+    if (tau_gate_closed(a, rep)) return;     // (a round: this try's turn has passed; the flags the host reads stay the deciding try's)
     const bool live = a.active[rep] && !a.accepted[rep];
     int g = live ? a.grow[rep] : 0;
     if (live && a.mev_cap > 0 && (int64_t)a.mev_n[rep] > a.mev_cap) g |= 16;   // rows were lost: the host enlarges the buffer
     const bool ok = live && a.ok[rep];
     if (a.phase == 1 && ok) {   // the front pass alone, and it found no failure: nothing is touched, the try proper comes next
         if (threadIdx.x == 0 && a.host_flags) { a.host_flags[rep] = a.accepted[rep]; a.host_flags[a.R + rep] = 0; a.host_flags[2 * a.R + rep] = 1; }
+        if (threadIdx.x == 0) a.spec[rep] = 1;
         return;
     }
     const int again = (g & 29) ? (g & 29) : (ok ? (g & 2) : 0);
@@ -3163,6 +3172,7 @@ extern "C" __global__ void __launch_bounds__(64) vgx_tau_decide_kernel(VgxTauArg
     a.deciding[rep] = 1;
     a.grow[rep] = again;
     if (again) {   // discarded like a rejected try, but tau and the try index stay
+        a.spec[rep] = 2;
         a.ok[rep] = 1;
         for (int i = 0; i < 6; ++i) a.cnt_try[(int64_t)rep * 8 + i] = 0;
         a.mev_n[rep] = a.mev_base[rep];
@@ -3170,6 +3180,7 @@ extern "C" __global__ void __launch_bounds__(64) vgx_tau_decide_kernel(VgxTauArg
     }
     if (accept) {
         a.accepted[rep] = 1;
+        a.spec[rep] = 2;
         for (int i = 0; i < 6; ++i) { a.counters[(int64_t)rep * 8 + i] += a.cnt_try[(int64_t)rep * 8 + i]; }
         int64_t drawn = 0;
         for (int i = 0; i < 6; ++i) { drawn += a.cnt_try[(int64_t)rep * 8 + i]; a.cnt_try[(int64_t)rep * 8 + i] = 0; }
@@ -3180,7 +3191,8 @@ extern "C" __global__ void __launch_bounds__(64) vgx_tau_decide_kernel(VgxTauArg
         a.ok[rep] = 1;
         for (int i = 0; i < 6; ++i) a.cnt_try[(int64_t)rep * 8 + i] = 0;
         a.mev_n[rep] = a.mev_base[rep];
-        if (a.retry[rep] > 200) { a.accepted[rep] = 1; a.error[rep] = 5; }  // loop guard (tau underflow)
+        if (a.gate == 2) a.spec[rep] = 3;     // (a round: its try proper was rejected; the next round starts with front passes again)
+        if (a.retry[rep] > 200) { a.accepted[rep] = 1; a.error[rep] = 5; a.spec[rep] = 2; }  // loop guard (tau underflow)
     }
 }
 
@@ -3224,6 +3236,7 @@ extern "C" __global__ void __launch_bounds__(TB) vgx_tau_commit_kernel(VgxTauArg
 extern "C" __global__ void __launch_bounds__(64) vgx_tau_finish_kernel(VgxTauArgs a) {
     const int rep = blockIdx.x;
     if (!a.active[rep]) return;
+    if (a.gate == 3 && !a.accepted[rep]) return;     // (a round that did not end the step)
     const VgxDevParams &p = a.p;
     const int P = p.P;
     const int lane = threadIdx.x;
@@ -3274,8 +3287,9 @@ extern "C" __global__ void __launch_bounds__(64) vgx_tau_finish_kernel(VgxTauArg
         o[11] = (int64_t)a.mev_n[rep];
         o[12] = a.error[rep];
         o[13] = (a.occ_pop && a.use8) ? occ_sum : -1;   // occupied compartments at the start of this step (drift pass on the bytes), else -1
+        o[14] = a.retry[rep];                            // rejected tries of this step
         if (a.host_res)
-            for (int i = 0; i < 14; ++i) a.host_res[(int64_t)rep * 16 + i] = o[i];   // the host's (pinned) copy
+            for (int i = 0; i < 15; ++i) a.host_res[(int64_t)rep * 16 + i] = o[i];   // the host's (pinned) copy
         a.mev_base[rep] = a.mev_n[rep];          // rows of the accepted step stay (pyx:2325)
         a.time_now[rep] += a.tau[rep];           // pyx:2322
         a.step[rep] += 1;
