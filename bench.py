@@ -318,6 +318,23 @@ def table3_leg(device, cpu=True, replicates=16384, events=50000, single_events=3
                                          "s_per_1e8_iterations": 1e8 * res.kernel_ms * 1e-3 / max(it1, 1.0),
                                          "vs_baseline": (it1 / (res.kernel_ms * 1e-3)) / (1e8 / TABLE3_PUBLISHED_S[(M, K)])}
             ens.close()
+            # ... and what the published figure is: the wall clock of Simulator.simulate(N) (data/Table 3/Table 3.py:23-25), end to end
+            # through the facade: parameters and state to the device, the kernel, the event log back incl. the host clock (libm
+            # times), the counters, Stats.  The engine exists already (a first short call), as the reference's object does.
+            one = make_table3(K, M)
+            with contextlib.redirect_stdout(io.StringIO()):
+                one.simulate(1000, sample_size=10 ** 12)
+                m1 = one.simulation
+                ev0, it0 = m1.events.ptr, m1.events.ptr + m1.migNonPlus
+                t0 = time.perf_counter()
+                one.simulate(single_events, sample_size=10 ** 12)
+                tw = time.perf_counter() - t0
+            evw, itw = m1.events.ptr - ev0, m1.events.ptr + m1.migNonPlus - it0
+            cell["single_trajectory"]["wall"] = {
+                "what": "Simulator.simulate(%d) end to end (set_params, set_state, kernel, event log + host clock back, Stats); second call on the object" % single_events,
+                "seconds": tw, "kernel_ms": m1._engine.last_kernel_ms, "events_per_s": evw / tw, "iterations_per_s": itw / tw,
+                "s_per_1e8_iterations": 1e8 * tw / max(itw, 1), "vs_baseline": (itw / tw) / (1e8 / TABLE3_PUBLISHED_S[(M, K)]),
+                "kernel_share_of_wall": m1._engine.last_kernel_ms * 1e-3 / tw}
             R = replicates if K <= 16 else max(replicates // 4, 1024)
             ens = Ensemble(sim, R, device=device)
             for it in range(2):
@@ -645,7 +662,14 @@ def tau_leg(device, steps=20, per_cell=3, seed=2020, cpu=True, warm=True):
     return out
 
 
-def config5_leg(device, world=1, rank=0, events=100000, traj_points=1001):
+def config5_partition(world, rank, total=256, first_seed=2020):
+    """BASELINE config 5's replicates on `world` ranks: 256 / world consecutive seeds per rank, from 2020 on."""
+    import numpy as np
+    R = max(total // world, 1)
+    return R, first_seed + rank * R + np.arange(R, dtype=np.int64)
+
+
+def config5_leg(device, world=1, rank=0, events=100000, traj_points=1001, ens=None):
     """BASELINE config 5 as written: 256 independent seeded replicates of config 3 (seeds 2020..2275) sharded over the GPUs of the
     node (256 / world per GPU; all 256 on the one GPU at N = 1), one RCCL gather of the f64 epidemic trajectories
     [replicates, 1001, 64, 2] to rank 0 (32.8 MB per GPU at 8 GPUs).  Runs on every rank."""
@@ -653,12 +677,15 @@ def config5_leg(device, world=1, rank=0, events=100000, traj_points=1001):
     import torch
     import torch.distributed as dist
     from vgsim_amd.ensemble import Ensemble
-    R = max(256 // world, 1)
-    ens = Ensemble(make_simulator(2020), R, device=device)
-    seeds = 2020 + rank * R + np.arange(R, dtype=np.int64)
+    R, seeds = config5_partition(world, rank)
+    cuda = ens is None          # (tests hand in an engine stand-in and run the leg's own partition / gather / reduction on CPU ranks)
+    if ens is None:
+        ens = Ensemble(make_simulator(2020), R, device=device)
+    dev = "cuda" if cuda else "cpu"
+    sync = torch.cuda.synchronize if cuda else (lambda: None)
     res = None
     for it in range(2):      # the first launch is the warm-up
-        torch.cuda.synchronize()
+        sync()
         if world > 1:
             dist.barrier()
         t0 = time.perf_counter()
@@ -669,22 +696,22 @@ def config5_leg(device, world=1, rank=0, events=100000, traj_points=1001):
             err = ex
         t_sim = time.perf_counter() - t0
         if world > 1:
-            okv = torch.tensor([0.0 if err is not None else 1.0], dtype=torch.float64, device="cuda")
+            okv = torch.tensor([0.0 if err is not None else 1.0], dtype=torch.float64, device=dev)
             dist.all_reduce(okv, op=dist.ReduceOp.MIN)
             if okv.item() < 1.0:
                 raise RuntimeError("config5: a rank failed in simulate (%r on this rank)" % (err,))
         elif err is not None:
             raise err
         t1 = time.perf_counter()
-        out = ens.gather_trajectories(dst=0, device="cuda")     # (one rank: the result stays on the GPU, where an RCCL gather leaves it on rank 0)
-        torch.cuda.synchronize()
+        out = ens.gather_trajectories(dst=0, device=dev)     # (one rank: the result stays on the GPU, where an RCCL gather leaves it on rank 0)
+        sync()
         t_gather = time.perf_counter() - t1
     ev = float(res.total_events)
     tot, tmax = ev, t_sim + t_gather
     if world > 1:
-        v = torch.tensor([ev], dtype=torch.float64, device="cuda")
+        v = torch.tensor([ev], dtype=torch.float64, device=dev)
         dist.all_reduce(v, op=dist.ReduceOp.SUM)
-        m = torch.tensor([t_sim + t_gather, t_gather], dtype=torch.float64, device="cuda")
+        m = torch.tensor([t_sim + t_gather, t_gather], dtype=torch.float64, device=dev)
         dist.all_reduce(m, op=dist.ReduceOp.MAX)
         tot, tmax, t_gather = float(v.item()), float(m[0].item()), float(m[1].item())
     shape = list(out.shape) if out is not None else None
@@ -695,7 +722,7 @@ def config5_leg(device, world=1, rank=0, events=100000, traj_points=1001):
          "gather_bytes_per_gpu": R * traj_points * POPS * 2 * 8, "gathered_shape_on_rank0": shape,
          "collective": "torch.distributed.gather (RCCL)" if world > 1 else "none (one rank: device-to-device copy into the result tensor)",
          "result_on": str(out.device) if out is not None else None,
-         "kernel": ens.engine.last_kernel,
+         "kernel": getattr(getattr(ens, "engine", None), "last_kernel", None),
          "note": "256 replicates are 256 wavefronts: ONE GPU already runs them all concurrently (one per CU), so sharding them 32 per GPU "
                  "cannot shorten any of them: this leg is latency-bound per trajectory and flat in the GPU count; the weak-scaling "
                  "headline (16 384 replicates per GPU) is the curve that scales"}
@@ -968,6 +995,9 @@ def main():
                        "trajectory_points": a.traj_points, "loop_iterations_per_event": li},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         # what the memory system really moved (PMC bytes per launch / launch time / peak): `frac` above prices the
+                         # ALGORITHMIC list bytes, most of which are served by L2 / Infinity Cache — it is not HBM utilisation
+                         "hbm_frac": (traffic / launch_s / 1e9 / HBM_PEAK_GBS) if traffic else None,
                          "kernel": "vgx_quad_kernel" if R >= 2048 else "vgx_direct_kernel_p64s1c1",
                          "kernel_ms_per_launch": kernel_ms / max(a.steps, 1),
                          "bytes_per_event": bytes_per_event, "mean_occupancy_list_len": nocc_mean,
@@ -1052,6 +1082,7 @@ def main():
             return d
         line["summary"] = {
             "headline_events_per_s": line["value"], "headline_roofline_frac": pick(line, "roofline", "frac"),
+            "headline_hbm_frac": pick(line, "roofline", "hbm_frac"),
             "headline_chain_frac": pick(line, "chain_bound", "frac"),
             "tau_leap_ms_per_step": pick(line, "tau_leap", "ms_per_step"), "tau_leap_events_per_s": pick(line, "tau_leap", "value"),
             "tau_leap_roofline_frac": pick(line, "tau_leap", "roofline", "frac"), "tau_leap_wall_ms_per_step": pick(line, "tau_leap", "wall", "ms_per_step"),
@@ -1062,6 +1093,9 @@ def main():
             "single_trajectory_config3": pick(line, "single_trajectory", "config3"),
             "table3_K2_single_events_per_s": pick(line, "table3", "cells", "K=2,M=0.001", "single_trajectory", "events_per_s"),
             "table3_K2_single_vs_published": pick(line, "table3", "cells", "K=2,M=0.001", "single_trajectory", "vs_baseline"),
+            "table3_K2_single_wall_vs_published": pick(line, "table3", "cells", "K=2,M=0.001", "single_trajectory", "wall", "vs_baseline"),
+            "table3_K100_single_events_per_s": pick(line, "table3", "cells", "K=100,M=0.001", "single_trajectory", "events_per_s"),
+            "table3_K100_single_wall_vs_published": pick(line, "table3", "cells", "K=100,M=0.001", "single_trajectory", "wall", "vs_baseline"),
             "table3_K2_ensemble_events_per_s": pick(line, "table3", "cells", "K=2,M=0.001", "ensemble", "events_per_s"),
             "table3_K10_ensemble_events_per_s": pick(line, "table3", "cells", "K=10,M=0.001", "ensemble", "events_per_s"),
             "table3_K100_ensemble_events_per_s": pick(line, "table3", "cells", "K=100,M=0.001", "ensemble", "events_per_s"),

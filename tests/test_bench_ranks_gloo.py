@@ -105,3 +105,67 @@ def test_bench_gpus_n_starts_n_ranks_and_fails_loudly_without_gpus():
     assert r.returncode != 0
     assert '"metric"' not in r.stdout
     assert "2-rank launch failed" in r.stderr
+
+
+WORKER8 = textwrap.dedent("""
+    import os, sys
+    import numpy as np
+    import torch, torch.distributed as dist
+    sys.path.insert(0, %r)
+    import bench
+    from vgsim_amd.ensemble import Ensemble, EnsembleResult
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    T, P, N = 1001, bench.POPS, 100000
+
+    class StubEnsemble(Ensemble):     # engine stand-in: partition, error vote, gather and reductions are bench.py's / the product's own
+        def __init__(self, R):
+            self.R, self.traj_shape, self.seeds_seen = R, (R, T, P, 2), None
+            self.model = type("Model", (), {"sizes": np.full(P, 10 ** 7)})
+        def simulate(self, iterations, sample_size=None, record_events=False, traj_points=0, traj_window=(0.0, 1.0), seeds=None, **kw):
+            assert iterations == N and traj_points == T and len(seeds) == self.R
+            self.seeds_seen = np.asarray(seeds).copy()
+            res = EnsembleResult(self.R)
+            res.events[:] = N
+            res.kernel_ms = 1.0
+            return res
+        def trajectories(self, out=None):      # replicate r's block carries its seed: the gathered result says who sent what
+            return np.broadcast_to(self.seeds_seen[:, None, None, None].astype(np.float64), self.traj_shape).copy()
+        def close(self):
+            pass
+
+    R, seeds = bench.config5_partition(world, rank)
+    assert R == 32 and seeds[0] == 2020 + 32 * rank and seeds[-1] == 2020 + 32 * rank + 31
+    ens = StubEnsemble(R)
+    o = bench.config5_leg("cpu", world=world, rank=rank, events=N, traj_points=T, ens=ens)
+    assert o["replicates_per_gpu"] == 32 and o["gather_bytes_per_gpu"] == 32 * 1001 * 64 * 2 * 8
+    assert abs(o["value"] * (o["simulate_s"] + 1e-3 * o["gather_ms"]) - 256 * N) / (256 * N) < 0.5     # all ranks' events over the slowest rank's time
+    if rank == 0:
+        assert o["gathered_shape_on_rank0"] == [8, 32, 1001, 64, 2], o["gathered_shape_on_rank0"]
+        out = ens.gather_trajectories(dst=0)
+        got = out[:, :, 0, 0, 0].numpy().reshape(-1)
+        assert np.array_equal(got, 2020.0 + np.arange(256)), "rank k's block sits in row k, seeds 2020..2275 in order"
+        # the headline leg's memory plan of rank 0 at eight ranks on a 288 GB device: must fit (and say so) before anything is allocated
+        bench.memory_plan(16384, 100000, 1001, 8, 0, int(280e9), int(288e9))
+        print("CONFIG5_OK")
+    else:
+        assert o["gathered_shape_on_rank0"] is None
+        ens.gather_trajectories(dst=0)
+    dist.destroy_process_group()
+""")
+
+
+def test_config5_partition_and_gather_world_size_8(tmp_path):
+    """BASELINE config 5 as the driver will run it on a whole node — eight ranks, 32 replicates each, one gather of
+    [8, 32, 1001, 64, 2] to rank 0 — on eight CPU ranks (gloo) with an engine stand-in: bench.config5_leg's own partition,
+    error vote, gather and reductions, and rank 0's memory plan at 288 GB."""
+    script = tmp_path / "worker8.py"
+    script.write_text(WORKER8 % ROOT)
+    port = free_port()
+    procs = []
+    for rank in range(8):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="8", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    outs = [p.communicate(timeout=600)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert "CONFIG5_OK" in outs[0]
