@@ -190,6 +190,9 @@ int vgx_get_lockdowns(vgx_engine *e, int64_t replicate, int64_t cap, int64_t *st
 int vgx_get_recombinations(vgx_engine *e, int64_t replicate, int64_t cap, int64_t *idevents, int64_t *his,
                            int64_t *hi2s, int64_t *nhis, int64_t *posRecombs, int64_t *n);
 /* Tau multievents of the last call (events.pxi:105-152), rows with num > 0 only. */
+/* Rejected tries (halvings of tau_l, pyx:2316-2321) of steps [first, first + count) of the last vgx_simulate_tau call: the leap a step
+ * made times 2^tries is the tau ChooseTau (pyx:2432-2450) gave it. */
+int vgx_get_tau_tries(vgx_engine *e, int64_t replicate, int64_t first, int64_t count, int32_t *out);
 int vgx_get_multievents(vgx_engine *e, int64_t replicate, int64_t cap, int64_t *num, double *times, int64_t *types,
                         int64_t *haplotypes, int64_t *populations, int64_t *newHaplotypes,
                         int64_t *newPopulations, int64_t *n);

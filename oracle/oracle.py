@@ -297,6 +297,13 @@ def run_tau(model, iterations, sample_size, time, attempts, record_multievents=F
     return rc
 
 
+def tau_tries(step):
+    """Rejected tries (halvings, pyx:2316-2321) of step ``step`` of the last ``run_tau`` call (test hook)."""
+    f = lib().vgo_tau_tries
+    f.restype, f.argtypes = C.c_int64, [C.c_int64]
+    return int(f(int(step)))
+
+
 def prop_num(model):
     """propNum of SimulatePopulation_tau (pyx:2301): the channels the reference draws in every step."""
     st = get_state(model)

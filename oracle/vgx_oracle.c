@@ -1150,6 +1150,14 @@ static void UpdateCompartmentCounts_tau(vgo_model *m, tau_arrays *A) { /* pyx:25
     }
 }
 
+/* Test hook (not part of the restatement): rejected tries (halvings of tau_l, pyx:2316-2321) of the first steps of the last
+ * vgo_simulate_tau call, so that a test can compare the tau ChooseTau gave a step (leap * 2^tries) with another engine's. */
+#define VGO_TAU_TRIES_KEPT 4096
+static int64_t g_tau_tries[VGO_TAU_TRIES_KEPT];
+static int64_t g_tau_steps = 0;
+int64_t vgo_tau_tries(int64_t step) { return (step >= 0 && step < g_tau_steps && step < VGO_TAU_TRIES_KEPT) ? g_tau_tries[step] : -1; }
+
+
 int vgo_simulate_tau(vgo_model *m, int64_t iterations, int64_t sample_size, float time, int64_t attempts) { /* pyx:2293-2346 */
     rng_t r;
     r.philox = 0; r.seed = 0; r.n = 0; r.att = 0;   /* (tau draws from PCG64 through vgo_poisson) */
@@ -1167,6 +1175,7 @@ int vgo_simulate_tau(vgo_model *m, int64_t iterations, int64_t sample_size, floa
     A.pMigr = calloc(nMigr ? nMigr : 1, 8); A.eMigr = calloc(nMigr ? nMigr : 1, 8);
     A.pSuscep = calloc(nSus, 8); A.eSuscep = calloc(nSus, 8);
     A.pRec = calloc(nPH, 8); A.eRec = calloc(nPH, 8);
+    g_tau_steps = 0;
     A.pSamp = calloc(nPH, 8); A.eSamp = calloc(nPH, 8);
     A.pMut = calloc(nMut ? nMut : 1, 8); A.eMut = calloc(nMut ? nMut : 1, 8);
     A.pTrans = calloc(nTr, 8); A.eTrans = calloc(nTr, 8);
@@ -1178,10 +1187,14 @@ int vgo_simulate_tau(vgo_model *m, int64_t iterations, int64_t sample_size, floa
                    (time == -1 || m->currentTime < time)) {
                 Propensities(m, &A);
                 ChooseTau(m);
+                int64_t halvings = 0;
                 while (1) {
                     if (GenerateEvents_tau(m, &A, &r)) break;
                     m->tau_l /= 2;
+                    halvings += 1;
                 }
+                if (g_tau_steps < VGO_TAU_TRIES_KEPT) g_tau_tries[g_tau_steps] = halvings;   /* test hook: vgo_tau_tries */
+                g_tau_steps += 1;
                 m->currentTime += m->tau_l;
                 UpdateCompartmentCounts_tau(m, &A);
                 AddEvent(m, m->currentTime, VGO_MULTITYPE, m->mev_ptr - propNum, m->mev_ptr, 0, 0);

@@ -128,6 +128,9 @@ int vgo_simulate_tau(vgo_model *m, int64_t iterations, int64_t sample_size, floa
 void vgo_update_all_rates(vgo_model *m);
 /* pyx:2301 */
 int64_t vgo_prop_num(const vgo_model *m);
+/* test hook: rejected tries (halvings of tau_l, pyx:2316-2321) of step `step` (0-based, counted over all attempts) of the last
+ * vgo_simulate_tau call; -1 beyond the steps made (or the first 4096) */
+int64_t vgo_tau_tries(int64_t step);
 
 /* RNG restatement (mc_lib.rndm.RndmWrapper + numpy PCG64/SeedSequence). */
 typedef struct { uint64_t state_hi, state_lo, inc_hi, inc_lo; } vgo_pcg64;

@@ -90,6 +90,7 @@ SIGNATURES = {
     "vgx_get_counters_all": (C.c_int, [_H, _I]),
     "vgx_get_events": (C.c_int, [_H, C.c_int64, C.c_int64, C.c_int64, _F, _I, _I, _I, _I, _I]),
     "vgx_get_lockdowns": (C.c_int, [_H, C.c_int64, C.c_int64, _I, _I, _F, _I]),
+    "vgx_get_tau_tries": (C.c_int, [_H, C.c_int64, C.c_int64, C.c_int64, C.POINTER(C.c_int32)]),
     "vgx_get_multievents": (C.c_int, [_H, C.c_int64, C.c_int64, _I, _F, _I, _I, _I, _I, _I, _I]),
     "vgx_get_trajectories": (C.c_int, [_H, C.c_void_p, C.c_int]),
     "vgx_get_trajectories_int": (C.c_int, [_H, C.c_void_p]),
@@ -329,6 +330,12 @@ class HipEngine:
             for row in zip(*self.recombinations(replicate)):
                 m.rec.AddRecombination_forward(*row)
         self.last_counters = c
+
+    def tau_tries(self, replicate, first, count):
+        """Rejected tries (halvings of tau_l, pyx:2316-2321) of steps [first, first + count) of the last tau call."""
+        out = np.zeros(count, dtype=np.int32)
+        self._check(self.lib.vgx_get_tau_tries(self.handle, replicate, first, count, out.ctypes.data_as(C.POINTER(C.c_int32))))
+        return out
 
     @property
     def last_kernel_ms(self):

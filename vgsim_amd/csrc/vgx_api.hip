@@ -113,7 +113,7 @@ struct vgx_engine {
     int64_t tau_occupied = 0;             // ... and counted its occupied compartments
     bool direct_logs_valid = false;   // the rate / iteration logs of the last direct call are on the device (host_clock can run)
     int64_t tau_mev_cap = 0;
-    struct TauStep { double time; int64_t m0, m1; };
+    struct TauStep { double time; int64_t m0, m1; int32_t tries; };   // tries: rejected tries of the step's halving loop (pyx:2316-2321)
     std::vector<std::vector<TauStep>> tau_log;      // [R] MULTITYPE records of the last tau call
     std::vector<std::vector<double>> tau_loc_time;  // [R] lockdown log of the last tau call
     std::vector<std::vector<int64_t>> tau_loc_state, tau_loc_pop;
@@ -1822,7 +1822,7 @@ extern "C" int vgx_simulate_tau(vgx_engine *e, int64_t iterations, int64_t sampl
             for (int64_t k = 0; k < n; k++) {
                 double t;
                 memcpy(&t, &sl[(size_t)k * 3], 8);
-                e->tau_log[(size_t)r].push_back({t, sl[(size_t)k * 3 + 1], sl[(size_t)k * 3 + 2]});
+                e->tau_log[(size_t)r].push_back({t, sl[(size_t)k * 3 + 1] & (((int64_t)1 << 56) - 1), sl[(size_t)k * 3 + 2], (int32_t)((uint64_t)sl[(size_t)k * 3 + 1] >> 56)});
             }
         }
     } else
@@ -2168,7 +2168,7 @@ extern "C" int vgx_simulate_tau(vgx_engine *e, int64_t iterations, int64_t sampl
                                                      std::to_string(steps_done[(size_t)r] + 1) + " steps, room for " + std::to_string(mev_cap) +
                                                      "; pass record_events=0 for large runs)");
             tnow[(size_t)r] += tau_h[(size_t)r];                       // pyx:2322
-            e->tau_log[(size_t)r].push_back({tnow[(size_t)r], (int64_t)mevb[(size_t)r], (int64_t)mevn[(size_t)r]});  // pyx:2325
+            e->tau_log[(size_t)r].push_back({tnow[(size_t)r], (int64_t)mevb[(size_t)r], (int64_t)mevn[(size_t)r], (int32_t)res_h[(size_t)r * 16 + 14]});  // pyx:2325
             ev_ptr[(size_t)r] += 1;
             step_h[(size_t)r] += 1;
             steps_done[(size_t)r] += 1;
@@ -2449,6 +2449,15 @@ extern "C" int vgx_get_events(vgx_engine *e, int64_t replicate, int64_t first, i
     for (int c = 0; c < 5; c++)
         if (dst[c])
             for (int64_t i = 0; i < count; i++) dst[c][i] = cols[(size_t)(i * VGX_EV_COLS + c)];
+    return VGX_OK;
+}
+
+extern "C" int vgx_get_tau_tries(vgx_engine *e, int64_t replicate, int64_t first, int64_t count, int32_t *out) {
+    if (!e || !out || replicate < 0 || replicate >= e->R || first < 0 || count < 0) return VGX_ERR_ARG;
+    if (!e->last_was_tau || (size_t)replicate >= e->tau_log.size()) return fail(e, VGX_ERR_ARG, "vgx_get_tau_tries: the last call was not vgx_simulate_tau");
+    const auto &lg = e->tau_log[(size_t)replicate];
+    if (first + count > (int64_t)lg.size()) return fail(e, VGX_ERR_ARG, "vgx_get_tau_tries: the last call made fewer steps");
+    for (int64_t i = 0; i < count; i++) out[i] = lg[(size_t)(first + i)].tries;
     return VGX_OK;
 }
 

@@ -34,7 +34,7 @@ struct VgxTausArgs {
     double mutp[16][3];               // uniform mutation model: mRate[s] * w[s][i] / (w[s][0] + w[s][1] + w[s][2])
     int64_t *mev;                     // [R][mev_cap][6] multievent rows with num > 0: num, type, hap, pop, newHap, newPop
     int64_t mev_cap;
-    int64_t *slog;                    // [R][slog_cap][3] accepted steps: time (bits), first row, one past the last row
+    int64_t *slog;                    // [R][slog_cap][3] accepted steps: time (bits), first row (+ the step's rejected tries << 56), one past the last row
     int64_t slog_cap;
     int32_t *loc_rec;                 // [R][VGX_LOC_CAP][2]
     double *loc_time;                 // [R][VGX_LOC_CAP]

@@ -467,7 +467,7 @@ static __device__ __forceinline__ void taus_body(const VgxTausArgs &a) {
             const long long slot = ev_ptr - ev_ptr_start;
             if (slot >= 0 && slot < a.slog_cap) {
                 slog[slot * 3 + 0] = __double_as_longlong(tnow);
-                slog[slot * 3 + 1] = mev_base;
+                slog[slot * 3 + 1] = mev_base | ((long long)retry << 56);   // (+ the step's rejected tries, <= 200, in the top byte: vgx_get_tau_tries)
                 slog[slot * 3 + 2] = mev_base + nrows;
             }
         }
