@@ -49,11 +49,20 @@ static __device__ __forceinline__ bool row_any(bool f) { return row_max(f ? 1 : 
 }  // namespace
 
 // RECOMB: the instantiations with the recombination branch of Birth (pyx:575-596); the others do not carry its code.
+// The kernel's arguments are read through the kernarg segment pointer (constant address space: scalar loads where and when a value is
+// needed).  As by-value parameters whose fields are referenced all over the loop they were kept in scalar registers for the whole
+// kernel — 300 to 470 of them spilled to lanes of vector registers, every reload an instruction in the event loop (vgx_solo.hip).
+struct VgxQuadgKArgs { VgxDirectArgs a; VgxQuadgArgs qa; };
+typedef const VgxQuadgKArgs __attribute__((address_space(4))) *QuadgKA;
+
 template <int NS, bool RECOMB = false>
-static __device__ __forceinline__ void quadg_body(const VgxDirectArgs &a, const VgxQuadgArgs &qa) {
+static __device__ __forceinline__ void quadg_body() {
+    const QuadgKA ka = (QuadgKA)__builtin_amdgcn_kernarg_segment_ptr();
+    const auto &a = ka->a;
+    const auto &qa = ka->qa;
     const int lane = threadIdx.x, row = lane >> 4, rl = lane & 15;
-    const VgxDevParams &p = a.p;
-    const VgxDevRep &r = a.r;
+    const auto &p = a.p;
+    const auto &r = a.r;
     const int P = p.P, S = p.S, C = p.C, CB = p.CB, sites = p.sites, H = p.H, W = qa.W, NSEG = qa.nseg;
     constexpr int PL = 16 * NS;
     const int64_t R = a.n_replicates;
@@ -1292,8 +1301,8 @@ static __device__ __forceinline__ void quadg_body(const VgxDirectArgs &a, const 
 // one instantiation per number of 16-population slots (LDS and chain lengths follow the model's populations: 100 populations take seven
 // slots — five wavefronts per CU and seven chain rows where eight slots gave four and eight), each with and without recombination
 #define QUADG_KERNELS(NSLOT, PMAX)                                                                                                                  \
-    extern "C" __global__ void __launch_bounds__(64, VGX_QUADG_WAVES) vgx_quadg_kernel_p##PMAX(VgxDirectArgs a, VgxQuadgArgs qa) { quadg_body<NSLOT>(a, qa); } \
-    extern "C" __global__ void __launch_bounds__(64, VGX_QUADG_WAVES) vgx_quadg_kernel_p##PMAX##_rec(VgxDirectArgs a, VgxQuadgArgs qa) { quadg_body<NSLOT, true>(a, qa); }
+    extern "C" __global__ void __launch_bounds__(64, VGX_QUADG_WAVES) vgx_quadg_kernel_p##PMAX(VgxQuadgKArgs) { quadg_body<NSLOT>(); } \
+    extern "C" __global__ void __launch_bounds__(64, VGX_QUADG_WAVES) vgx_quadg_kernel_p##PMAX##_rec(VgxQuadgKArgs) { quadg_body<NSLOT, true>(); }
 QUADG_KERNELS(1, 16)
 QUADG_KERNELS(2, 32)
 QUADG_KERNELS(3, 48)
@@ -1310,7 +1319,7 @@ extern "C" __attribute__((visibility("hidden"))) hipError_t vgxi_launch_quadg(co
     const int NS = (P + 15) / 16;
     const VgxQuadgLayout L = vgx_quadg_layout(16 * NS, a->p.S, a->p.C, a->p.CB, qa->nseg, qa->W);
     const bool rec = a->p.recombination != 0.0;
-    typedef void (*Kern)(VgxDirectArgs, VgxQuadgArgs);
+    typedef void (*Kern)(VgxQuadgKArgs);
     static const Kern plain[8] = {vgx_quadg_kernel_p16, vgx_quadg_kernel_p32, vgx_quadg_kernel_p48, vgx_quadg_kernel_p64,
                                   vgx_quadg_kernel_p80, vgx_quadg_kernel_p96, vgx_quadg_kernel_p112, vgx_quadg_kernel_p128};
     static const Kern with_rec[8] = {vgx_quadg_kernel_p16_rec, vgx_quadg_kernel_p32_rec, vgx_quadg_kernel_p48_rec, vgx_quadg_kernel_p64_rec,
@@ -1325,6 +1334,8 @@ extern "C" __attribute__((visibility("hidden"))) hipError_t vgxi_launch_quadg(co
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)k, 64, (size_t)L.total) == hipSuccess)
             fprintf(stderr, "vgx_quadg: %d populations (%d slots), LDS %d B per wavefront, %d wavefronts per CU\n", P, NS, L.total, nb);
     }
-    hipLaunchKernelGGL(k, dim3(grid), dim3(64), (size_t)L.total, stream, *a, *qa);
+    VgxQuadgKArgs ka;
+    ka.a = *a; ka.qa = *qa;
+    hipLaunchKernelGGL(k, dim3(grid), dim3(64), (size_t)L.total, stream, ka);
     return hipGetLastError();
 }
