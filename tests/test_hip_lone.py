@@ -29,10 +29,33 @@ def test_lone_kernel_vs_reference_goldens(name):
     helpers.check_against_golden(hip, name, exact_time=helpers.libm_matches_fixture_host(), leftovers=False)
 
 
+DIRECT = [n for n, (_, ph) in models.CASES.items() if all(kw.get("method", "direct") == "direct" for _, kw in ph)]
+# the general form: every direct case of the suite without recombination at up to 64 populations (p70: outside)
+LONE_GENERAL = [n for n in DIRECT if n not in models.RECOMBINATION_CASES and n not in LONE_OK and n != "p70"]
+
+
+@pytest.mark.parametrize("name", LONE_GENERAL + [n for n in models.ORACLE_ONLY_CASES if n != "p70"])
+def test_lone_general_form_bit_exact_vs_oracle(oracle_mod, name):
+    """Several rate classes (the class rides in the list entry's haplotype word), several susceptibility groups (immunity transitions,
+    the stale susceptHapPopRate of Birth), lockdown switches with UpdateAllRates, Restarts that keep lockdown records."""
+    hip = helpers.run_case_hip(name, kernel="lone").simulation
+    assert hip._engine.last_kernel == "lone"
+    ref = helpers.run_case_oracle(oracle_mod, name).simulation
+    helpers.assert_models_equal(hip, ref, name)
+
+
+@pytest.mark.parametrize("name", ["g2", "g3", "g4", "g7", "g9", "example", "stress_h64", "stress_h256", "continuation", "cmd_example"])
+def test_lone_general_form_vs_reference_goldens(name):
+    hip = helpers.run_case_hip(name, kernel="lone").simulation
+    helpers.check_against_golden(hip, name, exact_time=helpers.libm_matches_fixture_host(), rtol_time=1e-12, leftovers=False)
+
+
 def test_lone_refuses_models_outside_its_scope():
     from vgsim_amd._capi import VgxError
     with pytest.raises(VgxError), helpers.quiet():
-        helpers.run_case_hip("g9_short", kernel="lone")
+        helpers.run_case_hip("p70", kernel="lone")
+    with pytest.raises(VgxError), helpers.quiet():
+        helpers.run_case_hip("recomb_a", kernel="lone")
 
 
 def _single(oracle_mod, name, seed, n_events, mut=None):

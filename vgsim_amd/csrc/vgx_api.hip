@@ -1031,13 +1031,20 @@ static int direct_core(vgx_engine *e, int64_t iterations, int64_t sample_size, f
     // 512; beyond that the row kernel's four replicates per wavefront win.  Chosen by itself only for a state that came through
     // vgx_set_state (when the lists outgrow the heap the call runs again from that state on the row kernel) whose lists leave half
     // the heap free; opts.kernel = 6 forces it on any state (a full heap is then the call's error).
+    // Its general form takes what the general row kernel takes at up to 64 populations: several rate classes (the class of a list entry
+    // rides in the top six bits of its haplotype word: hapNum <= 2^26), several susceptibility groups, lockdown switches.
     VgxLoneArgs loa{};
     loa.lds_bytes = R <= 256 ? VGX_LONE_MAX_LDS : VGX_LONE_MAX_LDS / 2;
-    const int64_t lone_rows = vgx_lone_layout((int)P, loa.lds_bytes).nrows;
-    const bool lone_ok = quad_ok && lone_rows >= 2 * P;
+    bool lone_gen_shape = o.mode == 0 && !recomb && P <= 64 && S <= VGX_LONE_MAX_S && e->C <= VGX_LONE_MAX_C && e->CB <= VGX_LONE_MAX_CB &&
+                          (int64_t)e->h_seg_par.size() <= VGX_LONE_MAX_SEG && H <= ((int64_t)1 << VGX_LONE_HAP_BITS);
+    for (int64_t pn = 0; pn < P && lone_gen_shape; pn++)
+        if (e->sizes[(size_t)pn] >= ((int64_t)1 << 31)) lone_gen_shape = false;   // 4-byte counts in the heap
+    loa.general = quad_ok ? 0 : 1;
+    const int64_t lone_rows = vgx_lone_layout((int)P, loa.lds_bytes, loa.general ? (int)S : 0, loa.general ? e->CB : 0).nrows;
+    const bool lone_ok = (quad_ok || lone_gen_shape) && lone_rows >= 2 * P;
     if (o.kernel == 6 && !lone_ok)
-        return fail(e, VGX_ERR_ARG, "vgx_simulate_direct: the single-trajectory kernel for large haplotype spaces needs exact mode, one rate "
-                                    "class, one susceptibility group, popNum <= 64, no lockdown switches, no recombination");
+        return fail(e, VGX_ERR_ARG, "vgx_simulate_direct: the single-trajectory kernel for large haplotype spaces needs exact mode, popNum <= 64, "
+                                    "susNum <= 16, at most 64 rate classes and 16 transmission/susceptibility classes, hapNum <= 2^26, no recombination");
     // FAST mode (order-free sums, PCG64 stream) on the same layout and scope: vgx_quadf.hip
     const bool quadf_ok = (o.mode == 1 || o.mode == 2) && quad_shape;     // FAST, with the PCG64 or the counter-based stream
     // The general form of that kernel (vgx_quadg.hip): several susceptibility groups and rate classes, lockdown switches,
@@ -1169,6 +1176,9 @@ static int direct_core(vgx_engine *e, int64_t iterations, int64_t sample_size, f
         loa.rcpAs = (const double *)e->so_rcp.p;
         loa.exact_rcp_div = getenv("VGX_SOLO_PLAIN_DIV") ? 0 : 1;
         loa.mut_uniform = (e->h_mut_uniform && !getenv("VGX_LONE_NO_MUTUNI")) ? 1 : 0;
+        loa.seg_par = (const int32_t *)e->q_segpar.p; loa.seg_sn = (const int32_t *)e->q_segsn.p;
+        loa.seg_sig = (const double *)e->q_segsig.p; loa.cb_seg = (const int32_t *)e->q_cbseg.p;
+        loa.nseg = (int32_t)e->h_seg_par.size();
         HIPCHECK(e, vgxi_launch_lone(&a, &loa, solo_clock ? 1 : 0, e->stream));
     }
     else if (use_lanes) HIPCHECK(e, vgxi_launch_lanes(&a, &ws, e->stream));
@@ -1206,7 +1216,7 @@ static int direct_core(vgx_engine *e, int64_t iterations, int64_t sample_size, f
             e->dev_state_valid = false;
             e->sc_host_valid = false;
             vgx_run_opts o2 = o;
-            o2.kernel = 3;
+            o2.kernel = (quad_ok || quadg_ok) ? 3 : 1;
             e->lone_fallbacks += 1;
             return direct_core(e, iterations, sample_size, time, attempts, &o2);
         }
