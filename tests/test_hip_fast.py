@@ -58,7 +58,7 @@ def test_fast_request_on_a_general_model_runs_the_exact_fast_kernels(oracle_mod,
     latency kernels run it — their output is what FAST promises, and they are the faster path (2.5e8 -> 1.4e9 events/s on the
     Table-3 model; tools/probe_fast_general.py).  Here: the kernel that ran, and results equal to the exact oracle bit for bit."""
     hip = helpers.run_case_hip(name, mode="fast").simulation
-    assert hip._engine.last_kernel in ("solo", "quadg"), hip._engine.last_kernel
+    assert hip._engine.last_kernel in ("solo", "quadg", "lone"), hip._engine.last_kernel
     helpers.assert_models_equal(hip, helpers.run_case_oracle(oracle_mod, name).simulation, name)
 
 
