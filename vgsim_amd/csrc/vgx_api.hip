@@ -1027,8 +1027,10 @@ static int direct_core(vgx_engine *e, int64_t iterations, int64_t sample_size, f
         if (h.totalSusceptible[(size_t)pn] != h.susceptible[(size_t)pn]) quad_shape = false;
     const bool quad_ok = o.mode == 0 && quad_shape;
     // One trajectory (or a few hundred) of such a model with a LARGE haplotype space: the latency kernel on occupancy lists
-    // (vgx_lone.hip), every list resident in LDS.  One wavefront per CU with 160 KB each up to 256 replicates, two with 80 KB up to
-    // 512; beyond that the row kernel's four replicates per wavefront win.  Chosen by itself only for a state that came through
+    // (vgx_lone.hip), every list resident in LDS.  One wavefront per CU with 160 KB each up to 256 replicates, two with 80 KB beyond
+    // (512 at a time).  The row kernels' four replicates per wavefront win from about 2000 replicates on (tools/probe_lone_crossover.py,
+    // config 3 / its general variant, events/s: 1536 replicates 2.6e8 / 1.6e8 here against 2.3e8 / 1.3e8 there, 2048: 2.6e8 / 1.6e8 against
+    // 3.1e8 / 1.8e8).  Chosen by itself only for a state that came through
     // vgx_set_state (when the lists outgrow the heap the call runs again from that state on the row kernel) whose lists leave half
     // the heap free; opts.kernel = 6 forces it on any state (a full heap is then the call's error).
     // Its general form takes what the general row kernel takes at up to 64 populations: several rate classes (the class of a list entry
@@ -1078,7 +1080,7 @@ static int direct_core(vgx_engine *e, int64_t iterations, int64_t sample_size, f
         solo_many = compact && vgx_solo_layout((int)P, (int)H, (int)S, (int)e->d.sites, soa.mig_in_lds).total <= 20 * 1024;
     }
     const bool use_solo = o.kernel == 5 || (o.kernel == 0 && solo_ok && !use_lanes && (R < 2048 || solo_many));
-    const bool use_lone = !use_solo && (o.kernel == 6 || (o.kernel == 0 && lone_ok && !use_lanes && fresh_state && R <= 512 &&
+    const bool use_lone = !use_solo && (o.kernel == 6 || (o.kernel == 0 && lone_ok && !use_lanes && fresh_state && R <= 1536 &&
                                                           2 * e->start_lone_rows <= lone_rows && !getenv("VGX_NO_LONE")));
     const bool use_quad = !use_solo && !use_lone && ((o.kernel == 3 && quad_ok) || (o.kernel == 0 && quad_ok && !use_lanes));
     const bool use_quadf = !use_solo && !use_lone && ((o.kernel == 3 && quadf_ok) || (o.kernel == 0 && quadf_ok));
