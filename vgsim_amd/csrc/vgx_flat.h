@@ -72,36 +72,6 @@ static __device__ __forceinline__ double row_carry(double acc, int which) {
     return __hiloint2double(hi, lo);
 }
 
-// SCAN: lane l < n ends with carry + v[0] + ... + v[l] (the serial prefix); lanes >= n-1 of the last row that ran hold the total.
-// SUM: every lane of the last row that ran ends with carry + v[0] + ... + v[n-1].  One value per lane, lanes >= n hold +0.0,
-// carry wave-uniform, n wave-uniform (1..64), all lanes active.
-template <bool SCAN, bool TINY = false, bool UNIT = false>
-static __device__ __forceinline__ double flat_chain(double v, int n, double carry, const Masks &M) {
-    if (UNIT) return carry + v;   // one term (lane 0 holds it; the other lanes' sums are never read)
-    double acc = carry;
-    const double mu = 1.0;
-    if (TINY) {   // n <= 4
-        if (SCAN) SOLO_SCAN4("0x1"); else SOLO_SUM4("0x1");
-        return acc;
-    }
-    n = uni_i32(n);
-    int nn = n;
-    if (SCAN) SOLO_SCAN16("0x1"); else SOLO_SUM16("0x1");
-    if (n > 16) {
-        acc = row_carry(acc, 1); nn = n - 16;
-        if (SCAN) SOLO_SCAN16("0x2"); else SOLO_SUM16("0x2");
-        if (n > 32) {
-            acc = row_carry(acc, 2); nn = n - 32;
-            if (SCAN) SOLO_SCAN16("0x4"); else SOLO_SUM16("0x4");
-            if (n > 48) {
-                acc = row_carry(acc, 3); nn = n - 48;
-                if (SCAN) SOLO_SCAN16("0x8"); else SOLO_SUM16("0x8");
-            }
-        }
-    }
-    return acc;
-}
-
 // ---- whole rows, no way out ----------------------------------------------------------------------------------------------
 // The same chains in whole rows of 16 steps: `rows` (1..4, wave-uniform) rows run completely, entries beyond n MUST hold +0.0 (a row
 // that is partly beyond n adds zeros: x + 0.0 = x).  No compare-and-branch inside a row and one test for the usual case of four
@@ -140,6 +110,36 @@ static __device__ __forceinline__ double flat_rows(double v, int rows, double ca
     } else if (rows > 1) {
         acc = row_carry(acc, 1); FLAT_ROW("0x2", "");
         if (rows > 2) { acc = row_carry(acc, 2); FLAT_ROW("0x4", ""); }
+    }
+    return acc;
+}
+
+// SCAN: lane l < n ends with carry + v[0] + ... + v[l] (the serial prefix); lanes >= n-1 of the last row that ran hold the total.
+// SUM: every lane of the last row that ran ends with carry + v[0] + ... + v[n-1].  One value per lane, lanes >= n hold +0.0,
+// carry wave-uniform, n wave-uniform (1..64), all lanes active.
+template <bool SCAN, bool TINY = false, bool UNIT = false>
+static __device__ __forceinline__ double flat_chain(double v, int n, double carry, const Masks &M) {
+    if (UNIT) return carry + v;   // one term (lane 0 holds it; the other lanes' sums are never read)
+    double acc = carry;
+    const double mu = 1.0;
+    if (TINY) {   // n <= 4
+        if (SCAN) SOLO_SCAN4("0x1"); else SOLO_SUM4("0x1");
+        return acc;
+    }
+    n = uni_i32(n);
+    int nn = n;
+    if (SCAN) SOLO_SCAN16("0x1"); else SOLO_SUM16("0x1");
+    if (n > 16) {
+        acc = row_carry(acc, 1); nn = n - 16;
+        if (SCAN) SOLO_SCAN16("0x2"); else SOLO_SUM16("0x2");
+        if (n > 32) {
+            acc = row_carry(acc, 2); nn = n - 32;
+            if (SCAN) SOLO_SCAN16("0x4"); else SOLO_SUM16("0x4");
+            if (n > 48) {
+                acc = row_carry(acc, 3); nn = n - 48;
+                if (SCAN) SOLO_SCAN16("0x8"); else SOLO_SUM16("0x8");
+            }
+        }
     }
     return acc;
 }
