@@ -241,8 +241,16 @@ def c4_direct_leg(device, replicates=1024, events=20000):
                            seeds=2020 + it * replicates + np.arange(replicates, dtype=np.int64))
     out = {"workload": "direct Gillespie at config 4's shape: 1048576 haplotypes x 256 populations, %d replicates x %d events, "
                        "exact mode, index-case start" % (replicates, events),
-           "value": res.total_events / (res.kernel_ms * 1e-3), "unit": "events/s (device time)", "kernel_ms_per_launch": res.kernel_ms}
+           "value": res.total_events / (res.kernel_ms * 1e-3), "unit": "events/s (device time)", "kernel_ms_per_launch": res.kernel_ms,
+           "kernel": ens.engine.last_kernel}
     ens.close()
+    # ... and ONE trajectory of that shape (256 populations: beyond the 64 of the list-resident latency kernel, so a lone wavefront of
+    # the general wave kernel runs it)
+    one = Ensemble(s, 1, device=device)
+    for it in range(2):
+        r1 = one.simulate(events // 2, sample_size=10 ** 12, record_events=True, seeds=np.array([2020 + it], dtype=np.int64))
+    out["single_trajectory"] = {"events_per_s": r1.total_events / (r1.kernel_ms * 1e-3), "kernel": one.engine.last_kernel, "events": int(r1.total_events)}
+    one.close()
     return out
 
 
