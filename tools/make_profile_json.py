@@ -6,7 +6,7 @@ TAG = os.environ.get("TAG", "r04")
 SRC = os.path.join(ROOT, "gpurun_out", "prof_" + TAG)
 DST = os.path.join(ROOT, "profiles")
 LEGS = ("headline", "spread_occupancy", "spread_occupancy_fast", "tau_leap", "fast_mode", "table3", "tau_small", "single_trajectory",
-        "config3_general", "propensity_scan")
+        "config3_general", "propensity_scan", "config5")
 
 
 def one(pattern):
