@@ -442,7 +442,34 @@ def rowscan_leg(device, rows=4096):
                          "bytes_per_row_visit": per_row, "bytes_by_array": exact,
                          "survey_formula": {"bytes_per_row_visit": survey_row, "GBs": rows * survey_row / (ms * 1e-3) / 1e9,
                                             "note": "SURVEY.md 8(d) counts the shared parameter arrays per row visit; they are "
-                                                    "cache-resident here, so this figure can exceed the HBM peak"}}}
+                                                    "cache-resident here, so this figure can exceed the HBM peak"},
+                         # what this box's memory system gives plain streams of the same size (the row pass reads and writes 1 : 1)
+                         "this_gpu_streams": stream_rates(device)}}
+
+
+def stream_rates(device):
+    """GB/s of three plain torch streams over 2 GiB arrays on this GPU (HIP events, 10 repeats): copy (read + write 1 : 1), sum (read
+    only), a += b (2 reads, 1 write) — the practical ceilings beside the 8 TB/s pin rate."""
+    import torch
+    n = 1 << 28
+    a = torch.empty(n, dtype=torch.float64, device="cuda")
+    b = torch.ones(n, dtype=torch.float64, device="cuda")
+
+    def t(f, reps=10):
+        f()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            f()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+    out = {"copy_GBs": 2 * n * 8 / t(lambda: a.copy_(b)) / 1e6, "read_only_sum_GBs": n * 8 / t(lambda: b.sum()) / 1e6,
+           "axpy_GBs": 3 * n * 8 / t(lambda: torch.add(a, b, out=a)) / 1e6}
+    del a, b
+    torch.cuda.empty_cache()
+    return out
 
 
 def fast_leg(device, replicates, events, traj_points):
