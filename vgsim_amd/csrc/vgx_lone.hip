@@ -344,15 +344,36 @@ struct Lone {
     __device__ __forceinline__ double refresh(int pi, double tE, double tEv = 0.0) {
         const int n = uni_i32(lane_get(nocc, pi)), r0 = uni_i32(lane_get(row0, pi)), base = 16 * r0;
         double carry = 0.0;
+        const int nfull = n >> 6;                  // tiles that lie inside the list: no bounds to look at, four rows each
         int c = lane < n ? ldCnt[base + lane] : 0;
         int hw = (GEN && lane < n) ? ldHap[base + lane] : 0;
-        for (int t = 0; 64 * t < n; ++t) {
-            const int idx = 64 * t + lane;
+        for (int t = 0; t < nfull; ++t) {
+            const int at = base + 64 * t + lane;
+            const double te = GEN ? bperm_f64(tEv, cls_of(hw)) : tE;
+            const double w = te * (double)c;
+            const int nx = 64 * t + 64 + lane;     // the next tile's counts are on their way during this tile's chain
+            c = nx < n ? ldCnt[base + nx] : 0;
+            if (GEN) hw = nx < n ? ldHap[base + nx] : 0;
+            double acc = carry;
+            const double mu = 1.0;
+            {
+                const double v = w;
+                constexpr bool SCAN = true;
+                FLAT_ROW("0x1", "s_nop 1\n\t");
+                acc = row_carry(acc, 1); FLAT_ROW("0x2", "");
+                acc = row_carry(acc, 2); FLAT_ROW("0x4", "");
+                acc = row_carry(acc, 3); FLAT_ROW("0x8", "");
+                (void)mu;
+            }
+            ldCum[at] = acc;
+            carry = bcast(acc, 63);
+            if (lane == 0) ldTend[r0 + 4 * t] = carry;
+        }
+        if (n & 63) {                              // the list's last, partial tile
+            const int t = nfull, idx = 64 * t + lane;
             const double te = GEN ? bperm_f64(tEv, cls_of(hw)) : tE;
             const double w = idx < n ? te * (double)c : 0.0;
-            c = idx + 64 < n ? ldCnt[base + idx + 64] : 0;        // the next tile's counts are on their way during this tile's chain
-            if (GEN) hw = idx + 64 < n ? ldHap[base + idx + 64] : 0;
-            const int m = min(64, n - 64 * t);
+            const int m = n - 64 * t;
             const double cum = flat_rows<true>(w, (m + 15) >> 4, carry, M);
             if (idx < n) ldCum[base + idx] = cum;
             carry = bcast(cum, m - 1);

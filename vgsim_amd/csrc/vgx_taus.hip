@@ -48,9 +48,13 @@ extern "C" int vgx_taus_get_profile(unsigned long long *out, int clear) {
 // model); ensembles that fill the chip want many small workgroups per CU instead — measured (tools/probe_taus_threads.py, steps/s of all
 // replicates): 16 x 3, 2048 replicates: 6.2e7 at 64 threads, 3.6e7 at 256, 2.2e7 at 512; 512 replicates: 1.8e7 / 3.5e7 / 2.2e7; 64:
 // 2.3e6 / 5.0e6 / 5.5e6; the 64 x 4 and 256 x 5 models switch at the same ensemble sizes.
+// (the arguments are read through the kernarg segment pointer, as in vgx_solo.hip / vgx_quadg.hip: by-value parameters referenced all over
+// the loop were held in scalar registers for the whole kernel, 330 of them spilled)
+typedef const VgxTausArgs __attribute__((address_space(4))) *TausKA;
 template <int TT>
-static __device__ __forceinline__ void taus_body(const VgxTausArgs &a) {
-    const VgxDevParams &p = a.p;
+static __device__ __forceinline__ void taus_body() {
+    const auto &a = *(TausKA)__builtin_amdgcn_kernarg_segment_ptr();
+    const auto &p = a.p;
     const int rep = blockIdx.x;
     const int P = p.P, H = p.H, S = p.S, sites = p.sites, PH = P * H;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -514,9 +518,9 @@ static __device__ __forceinline__ void taus_body(const VgxTausArgs &a) {
     }
 }
 
-extern "C" __global__ void __launch_bounds__(64) vgx_taus_kernel_t64(VgxTausArgs a) { taus_body<64>(a); }
-extern "C" __global__ void __launch_bounds__(256) vgx_taus_kernel_t256(VgxTausArgs a) { taus_body<256>(a); }
-extern "C" __global__ void __launch_bounds__(512) vgx_taus_kernel(VgxTausArgs a) { taus_body<512>(a); }
+extern "C" __global__ void __launch_bounds__(64) vgx_taus_kernel_t64(VgxTausArgs) { taus_body<64>(); }
+extern "C" __global__ void __launch_bounds__(256) vgx_taus_kernel_t256(VgxTausArgs) { taus_body<256>(); }
+extern "C" __global__ void __launch_bounds__(512) vgx_taus_kernel(VgxTausArgs) { taus_body<512>(); }
 
 extern "C" __attribute__((visibility("hidden"))) hipError_t vgxi_launch_taus(const VgxTausArgs *a, hipStream_t s) {
     const size_t lds = vgx_taus_lds_bytes(a->p.P, a->p.H, a->p.S, a->p.C, a->p.CB);
