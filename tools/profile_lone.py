@@ -16,7 +16,8 @@ eng = ens.engine
 out = np.zeros(16, dtype=np.int64)
 eng.lib.vgx_get_profile(eng.handle, 0, out.ctypes.data_as(C.POINTER(C.c_int64)))
 names = ["SampleTime, uniforms, loop counters", "population choice", "haplotype + class choice", "event: counts, list operations", "BirthRate",
-         "migration rates", "list refresh (prefix sums)", "popRate scan", "log + counters", "after event: flush, extinction, loop control"]
+         "migration rates", "list refresh (prefix sums)", "popRate scan", "log + counters", "after event: flush, extinction, loop control",
+         "general form: choices + event + list operations", "general form: UpdateRates + log"]
 iters = float(res.loop_iterations[0])
 print("%.3e ev/s, %.1f ms; stamped cycles per iteration: %.0f (stamps cost ~40 cycles each)" % (res.total_events / (res.kernel_ms * 1e-3), res.kernel_ms, out.sum() / iters))
 for n, v in zip(names, out):

@@ -721,6 +721,7 @@ struct Lone {
         pos += 1;
         prefetch_uniforms();
         const double den = Rtot;
+        PROF(9);
         double choose = u * Rtot;                                          // GenerateEvent pyx:483-512
         int u_pi = -1;                 // population whose rates change: UpdateRates(u_pi, f_infect, f_immune, f_birth)
         bool f_infect = false, f_birth = false, f_immune = false;   // f_birth: its susceptible counts changed too (BirthRate and the migration rates follow)
@@ -979,6 +980,7 @@ struct Lone {
                 ev_type = EV_MIGRATION;
             }
         }
+        PROF(10);
         // ---- UpdateRates(u_pi, ...) (pyx:516-546) ----
         if (u_pi >= 0) {
             if (GEN) {
@@ -1010,6 +1012,7 @@ struct Lone {
         }
         Rtot = totalRate + totalMig;
         log_event(ev_type, ev_hap, ev_pop, ev_nh, ev_np, den);
+        PROF(11);
         return ret_pi;
     }
 };
