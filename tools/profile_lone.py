@@ -1,5 +1,6 @@
 """Diagnostic: per-phase shader cycles of the latency kernel for large haplotype spaces (VGX_LIBRARY=vgsim_amd/libvgx_prof.so,
-`make -C vgsim_amd/csrc prof`):  python tools/profile_lone.py [events] [replicates]   (BASELINE config 3, seed 2020)"""
+`make -C vgsim_amd/csrc prof`):  python tools/profile_lone.py [events] [replicates] [model]   (model: c3 = BASELINE config 3 (default),
+c3g = bench.make_general_c3, tK = the Table-3 model with K demes, e.g. t10)"""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -7,7 +8,8 @@ import bench
 from vgsim_amd.ensemble import Ensemble
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
 R = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-sim = bench.make_simulator(2020)
+MODEL = sys.argv[3] if len(sys.argv) > 3 else "c3"
+sim = bench.make_simulator(2020) if MODEL == "c3" else bench.make_general_c3() if MODEL == "c3g" else bench.make_table3(int(MODEL[1:]), 0.001)
 ens = Ensemble(sim, R)
 res = None
 for it in range(2):

@@ -153,7 +153,9 @@ struct vgx_engine {
     std::vector<int32_t> h_so_sn, h_so_hapcls, h_so_nnz, h_so_tsn;
     std::vector<double> h_so_sig, h_so_tsig, h_so_clssig;
     int h_so_ncls = 0, h_so_maxnnz = 0;
-    DevBuf so_sn, so_sig, so_rcp, so_hapcls, so_nnz, so_tsn, so_tsig, so_clssig;
+    DevBuf so_sn, so_sig, so_rcp, so_hapcls, so_nnz, so_tsn, so_tsig, so_clssig, so_pass;
+    std::vector<int32_t> h_so_pass;
+    int h_so_npass0 = 0, h_so_npass1 = 0;
     bool last_used_solo = false;
     bool last_used_lone = false;
     int64_t lone_fallbacks = 0;       // calls that ran again on the row kernel because the LDS heap of vgx_lone.hip was full
@@ -380,6 +382,28 @@ extern "C" int vgx_set_params(vgx_engine *e, const vgx_params *p) {
             e->h_cb_seg[cb] = cur;
         }
     }
+    {   // the single-trajectory kernel runs that program two chains at a time (vgx_solo.h): a segment is ready when its parent is done,
+        // the sum of the migration rates (-2) from the start
+        e->h_so_pass.assign(4 * VGX_SOLO_MAX_PASS, -1);
+        const int ns = (int)e->h_seg_par.size();
+        for (int with_mig = 0; with_mig < 2; with_mig++) {
+            std::vector<char> done((size_t)ns, 0);
+            bool mig_done = !with_mig;
+            int left = ns, np = 0;
+            while ((left > 0 || !mig_done) && np < VGX_SOLO_MAX_PASS) {
+                int pick[2] = {-1, -1}, n = 0;
+                for (int sg = 0; sg < ns && n < 2; sg++)
+                    if (!done[(size_t)sg] && (e->h_seg_par[(size_t)sg] < 0 || done[(size_t)e->h_seg_par[(size_t)sg]])) pick[n++] = sg;
+                if (n < 2 && !mig_done) { pick[n++] = -2; mig_done = true; }
+                for (int k = 0; k < 2; k++)
+                    if (pick[k] >= 0) { done[(size_t)pick[k]] = 1; left--; }
+                e->h_so_pass[(size_t)((2 * with_mig + 0) * VGX_SOLO_MAX_PASS + np)] = pick[0];
+                e->h_so_pass[(size_t)((2 * with_mig + 1) * VGX_SOLO_MAX_PASS + np)] = pick[1];
+                np++;
+            }
+            (with_mig ? e->h_so_npass1 : e->h_so_npass0) = (left > 0 || !mig_done) ? -1 : np;   // -1: does not fit
+        }
+    }
     {   // segments of the single-trajectory kernel: for every group the distinct non-zero susceptibility values, in group order
         e->h_so_sn.clear(); e->h_so_sig.clear();
         for (int64_t sn = 0; sn < S; sn++) {
@@ -522,6 +546,7 @@ extern "C" int vgx_set_params(vgx_engine *e, const vgx_params *p) {
         rc |= upload(e, e->so_tsn, e->h_so_tsn.data(), e->h_so_tsn.size());
         rc |= upload(e, e->so_tsig, e->h_so_tsig.data(), e->h_so_tsig.size());
         rc |= upload(e, e->so_clssig, e->h_so_clssig.data(), e->h_so_clssig.size());
+        rc |= upload(e, e->so_pass, e->h_so_pass.data(), e->h_so_pass.size());
         if (rc == 0 && hipStreamSynchronize(e->stream) != hipSuccess) rc = VGX_ERR_HIP;   // rcp goes out of scope
     }
     rc |= upload(e, e->p_sizes, p->sizes, (size_t)P);
@@ -999,7 +1024,8 @@ static int direct_core(vgx_engine *e, int64_t iterations, int64_t sample_size, f
     // One trajectory (or a few) of a small model: the latency kernel (vgx_solo.hip), the whole model in LDS and registers.
     VgxSoloArgs soa{};
     bool solo_ok = o.mode == 0 && H <= VGX_SOLO_MAX_H && P <= VGX_SOLO_MAX_P && S <= VGX_SOLO_MAX_S &&
-                   (int64_t)e->h_so_sn.size() <= VGX_SOLO_MAX_SEG && H <= e->cap;
+                   (int64_t)e->h_so_sn.size() <= VGX_SOLO_MAX_SEG && H <= e->cap &&
+                   ((P <= 16 && H <= 16) || ((int64_t)e->h_seg_par.size() <= VGX_SOLO_MAX_TSEG && e->h_so_npass0 >= 0 && e->h_so_npass1 >= 0));
     for (int64_t pn = 0; pn < P && solo_ok; pn++)
         if (e->sizes[(size_t)pn] >= ((int64_t)1 << 52)) solo_ok = false;   // counts are kept as doubles
     if (solo_ok) {
@@ -1126,6 +1152,9 @@ static int direct_core(vgx_engine *e, int64_t iterations, int64_t sample_size, f
     if (use_solo) {
         soa.seg_sn = (const int32_t *)e->so_sn.p; soa.seg_sig = (const double *)e->so_sig.p; soa.nseg = (int32_t)e->h_so_sn.size();
         soa.rcpAs = (const double *)e->so_rcp.p;
+        soa.tseg_par = (const int32_t *)e->q_segpar.p; soa.tseg_sn = (const int32_t *)e->q_segsn.p; soa.tseg_sig = (const double *)e->q_segsig.p;
+        soa.cb_seg = (const int32_t *)e->q_cbseg.p; soa.pass = (const int32_t *)e->so_pass.p;
+        soa.tnseg = (int32_t)e->h_seg_par.size(); soa.npass0 = e->h_so_npass0; soa.npass1 = e->h_so_npass1;
         soa.exact_rcp_div = getenv("VGX_SOLO_PLAIN_DIV") ? 0 : 1;
         soa.hap_cls = (const int32_t *)e->so_hapcls.p; soa.cls_nnz = (const int32_t *)e->so_nnz.p; soa.cls_tsn = (const int32_t *)e->so_tsn.p;
         soa.cls_tsig = (const double *)e->so_tsig.p; soa.cls_sigma = (const double *)e->so_clssig.p;

@@ -171,6 +171,28 @@ static __device__ __forceinline__ void flat_two64(double va, double vb, const Ma
     sumA = oa; scanB = ob;
 }
 
+// The same for two SUMS over `rows` whole rows (1..4, wave-uniform) from wave-uniform carries: every lane of the last row that ran ends with
+// ca + va[0] + ... + va[16 rows - 1] / cb + vb[0] + ...; entries beyond the chains' lengths MUST hold +0.0.
+#define FLAT2S_B(K, RM) "v_fmac_f64_dpp v[202:203], %[vb], %[mu] row_newbcast:" #K " row_mask:" RM " bank_mask:0xf\n\t"
+#define FLAT2S_S(K, RM) FLAT2_A(K, RM) FLAT2S_B(K, RM)
+#define FLAT2S_ROW(RM) FLAT2S_S(0, RM) FLAT2S_S(1, RM) FLAT2S_S(2, RM) FLAT2S_S(3, RM) FLAT2S_S(4, RM) FLAT2S_S(5, RM) FLAT2S_S(6, RM) FLAT2S_S(7, RM) \
+                       FLAT2S_S(8, RM) FLAT2S_S(9, RM) FLAT2S_S(10, RM) FLAT2S_S(11, RM) FLAT2S_S(12, RM) FLAT2S_S(13, RM) FLAT2S_S(14, RM) FLAT2S_S(15, RM)
+#define FLAT2S_EXIT(N) "s_cmp_le_i32 %[rows], " #N "\n\ts_cbranch_scc1 .Lflat2s_done%=\n\t"
+static __device__ __forceinline__ void flat_two_sums(double va, double vb, int rows, double ca, double cb, double &sumA, double &sumB) {
+    const double mu = 1.0;
+    double oa, ob;
+    rows = uni_i32(rows);
+    asm volatile("v_mov_b64 v[200:201], %[ca]\n\tv_mov_b64 v[202:203], %[cb]\n\ts_nop 1\n\t"
+                 FLAT2S_ROW("0x1") FLAT2S_EXIT(1) FLAT2_NEXT("0x2") FLAT2S_ROW("0x2") FLAT2S_EXIT(2) FLAT2_NEXT("0x4") FLAT2S_ROW("0x4")
+                 FLAT2S_EXIT(3) FLAT2_NEXT("0x8") FLAT2S_ROW("0x8")
+                 ".Lflat2s_done%=:\n\t"
+                 "v_mov_b64 %[oa], v[200:201]\n\tv_mov_b64 %[ob], v[202:203]\n\t"
+                 : [oa] "=&v"(oa), [ob] "=&v"(ob)
+                 : [va] "v"(va), [vb] "v"(vb), [mu] "v"(mu), [ca] "v"(ca), [cb] "v"(cb), [rows] "s"(rows)
+                 : "v200", "v201", "v202", "v203", "scc");
+    sumA = oa; sumB = ob;
+}
+
 // every lane: acc += mu * (v[lane 0 of its row] + ... in order ... + v[lane n-1 of its row]) term by term, mu = 1.0 or 0.0 per
 // lane; v must hold the same 16 values in every row (nn <= 16, entries beyond nn +0.0)
 template <bool TINY = false, bool UNIT = false>

@@ -7,6 +7,8 @@
 #define VGX_SOLO_MAX_P 128     // populations: one lane each in up to two registers
 #define VGX_SOLO_MAX_S 16      // susceptibility groups: one lane each
 #define VGX_SOLO_MAX_SEG 32    // distinct (group, non-zero susceptibility) pairs: one bit of a lane's path word each
+#define VGX_SOLO_MAX_TSEG 64   // chain segments of the BirthRate program beyond 16 populations or haplotypes: one lane each
+#define VGX_SOLO_MAX_PASS 64   // passes of two chains each
 #define VGX_SOLO_MAX_LDS (160 * 1024)
 #define VGX_SOLO_COLD 16
 #define VGX_SOLO_ROWS 4        // 16-lane DPP rows of a wavefront
@@ -33,7 +35,18 @@ struct VgxSoloArgs {
     int32_t exact_rcp_div;     // 1: x / actualSizes through the reciprocal with two exact residual corrections (see vgx_solo.hip);
                                // 0: the compiler's division (validation: VGX_SOLO_PLAIN_DIV=1)
     int32_t mig_in_lds;        // migrationRates [P][P] fits the LDS budget
+    // General layout beyond 16 populations or 16 haplotypes: BirthRate per birth class as the program of chain segments of vgx_quadg.h
+    // (segment sg continues the sum of segment tseg_par[sg] with the P terms of group tseg_sn[sg] at susceptibility tseg_sig[sg]; birth
+    // class cb ends with segment cb_seg[cb]), each segment ONE chain over the population lanes for all haplotypes at once, and two chains
+    // that do not depend on each other per pass (vgx_flat.h flat_two_sums).  pass[0..1][k]: the two chains of pass k without the
+    // migration rates' sum, pass[2..3][k]: with it (-1: none, -2: the sum of migPopRate, pyx:541-546).
+    const int32_t *tseg_par, *tseg_sn;
+    const double *tseg_sig;
+    const int32_t *cb_seg;     // [CB]
+    const int32_t *pass;       // [4][VGX_SOLO_MAX_PASS]
+    int32_t tnseg, npass0, npass1, pad_;
 };
+
 
 struct VgxSoloLayout {
     int rowI, rowCum, rowHpr, rowBirth, rowTE;   // [P][H] f64: counts and rate caches of every population's row

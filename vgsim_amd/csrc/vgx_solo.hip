@@ -137,6 +137,9 @@ struct Solo {
     // ---- segment lanes (general layout) ----
     double Sseg, sgsig;
     int sgsn;
+    // general layout beyond 16 populations / haplotypes (vgx_solo.h): the segment lanes hold the program's segments; lane k the chains of pass k
+    int sgpar, hseg;             // parent segment of segment `lane`; haplotype `lane`'s last segment (-1: BirthRate's sum is +0.0)
+    int passA0, passB0, passA1, passB1, npass0, npass1;
     // ---- term lanes (compact layout): lane (c, j), register t <-> term 16 t + j of class c's BirthRate sum ----
     double tlS[NTT], tlSig[NTT], tlM[NTT], tlCd[NTT], tlAs[NTT], tlRcp[NTT];   // susceptible count of the term's group, its susceptibility,
                                                                             // migrationRates[cur][pn], contact density, actualSizes and 1 / it
@@ -239,7 +242,58 @@ struct Solo {
     // haplotype lane, then the rates, hapPopRate and its prefix sums; returns infectPopRate.  (Two halves so that the event loop can
     // put work that does not depend on the sum between them: the compact layout reads it across rows, an LDS round trip.) ----
     __device__ __forceinline__ double refresh_row() { return refresh_rates(birth_sums()); }
+    // the terms of one chain of a pass: segment j >= 0 (xs = S[cur, sn_j] * sigma_j), the migration rates (j = -2), nothing (j = -1)
+    __device__ __forceinline__ void pass_terms(int j, double xseg, double segv, double (&T)[NPR], double &carry) const {
+        carry = 0.0;
+        if (j >= 0) {
+            const double xs = bcast(xseg, j);
+            const int par = uni_i32(__builtin_amdgcn_readlane(sgpar, j));
+            if (par >= 0) carry = bcast(segv, par);
+#pragma unroll
+            for (int q = 0; q < NPR; ++q) {
+                const double t = xs * mrow[q] * mrow[q] * cd[q];
+                const double d = RCPDIV ? div_by_const(t, asz[q], rcp[q]) : t / asz[q];
+                T[q] = lane + 64 * q < P ? d : 0.0;
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < NPR; ++q) T[q] = j == -2 ? migR[q] : 0.0;
+        }
+    }
+    // BirthRate's sum for every haplotype lane by the program of chain segments, two chains per pass; MIG: the sum of the migration
+    // rates (remig) rides along as one of the chains
+    template <bool MIG>
+    __device__ __forceinline__ double birth_sums_program() {
+        Sst = Ssus;
+        const bool mig = MIG && has_mig;
+        if (MIG) {
+            if (mig) {
+#pragma unroll
+                for (int q = 0; q < NPR; ++q) migR[q] = maxEBM[q] * totS[q] * (gI - totI[q]);
+            } else {
+                totalMig = 0.0;
+            }
+        }
+        const double xseg = Sseg * sgsig;
+        double segv = 0.0;                          // lane sg: the sum at the end of segment sg
+        const int np = mig ? npass1 : npass0;
+        const int rows0 = (min(P, 64) + 15) >> 4, rows1 = (P - 64 + 15) >> 4, last = (P - 1) & 63;
+        for (int k = 0; k < np; ++k) {
+            const int ja = uni_i32(__builtin_amdgcn_readlane(mig ? passA1 : passA0, k)), jb = uni_i32(__builtin_amdgcn_readlane(mig ? passB1 : passB0, k));
+            double TA[NPR], TB[NPR], ca, cb, oa, ob;
+            pass_terms(ja, xseg, segv, TA, ca);
+            pass_terms(jb, xseg, segv, TB, cb);
+            flat_two_sums(TA[0], TB[0], rows0, ca, cb, oa, ob);
+            if (NPR > 1 && P > 64) flat_two_sums(TA[NPR - 1], TB[NPR - 1], rows1, bcast(oa, 63), bcast(ob, 63), oa, ob);
+            const double ta = bcast(oa, last), tb = bcast(ob, last);
+            if (ja >= 0) segv = lane == ja ? ta : segv; else if (ja == -2) totalMig = ta;
+            if (jb >= 0) segv = lane == jb ? tb : segv; else if (jb == -2) totalMig = tb;
+        }
+        const double ps = bperm_f64(segv, max(hseg, 0));
+        return hseg >= 0 ? ps : 0.0;
+    }
     __device__ __forceinline__ double birth_sums() {
+        if (NT == 0 && !small) return birth_sums_program<false>();
         Sst = Ssus;                                 // BirthRate stores susceptHapPopRate = S * sigma (pyx:385-386)
         double ps;
         if (NT > 0) {
@@ -601,10 +655,15 @@ struct Solo {
             imms = l15 == sidx ? cumul_l * Ssus : imms;
             PROF(6);
             // UpdateRates(pi, True, True, True), pyx:516-546
-            const double ps = birth_sums();
+            double ps;
+            if (NT == 0 && !small) {
+                ps = birth_sums_program<true>();    // (with the migration rates' sum)
+            } else {
+                ps = birth_sums();
+            }
             const double imP = immune_sum();
             PROF(10);
-            remig();
+            if (!(NT == 0 && !small)) remig();
             PROF(12);
             const double inP = refresh_rates(ps);
             PROF(9);
@@ -923,8 +982,18 @@ static __device__ __forceinline__ void solo_body() {
                 if (p.susc[lane * S + sa.seg_sn[s]] == sa.seg_sig[s]) c.path |= 1u << s;
         }
     }
-    c.sgsn = 0; c.sgsig = 0.0;
-    if (NT == 0 && lane < sa.nseg) { c.sgsn = sa.seg_sn[lane]; c.sgsig = sa.seg_sig[lane]; }
+    c.sgsn = 0; c.sgsig = 0.0; c.sgpar = -1; c.hseg = -1;
+    c.passA0 = -1; c.passB0 = -1; c.passA1 = -1; c.passB1 = -1; c.npass0 = 0; c.npass1 = 0;
+    if (NT == 0 && c.small) {
+        if (lane < sa.nseg) { c.sgsn = sa.seg_sn[lane]; c.sgsig = sa.seg_sig[lane]; }
+    } else if (NT == 0) {
+        c.nseg = uni_i32(sa.tnseg);
+        if (lane < sa.tnseg) { c.sgsn = sa.tseg_sn[lane]; c.sgsig = sa.tseg_sig[lane]; c.sgpar = sa.tseg_par[lane]; }
+        if (lane < H) c.hseg = sa.cb_seg[p.c_bidx[p.cls[lane]]];
+        c.passA0 = sa.pass[0 * VGX_SOLO_MAX_PASS + lane]; c.passB0 = sa.pass[1 * VGX_SOLO_MAX_PASS + lane];
+        c.passA1 = sa.pass[2 * VGX_SOLO_MAX_PASS + lane]; c.passB1 = sa.pass[3 * VGX_SOLO_MAX_PASS + lane];
+        c.npass0 = uni_i32(sa.npass0); c.npass1 = uni_i32(sa.npass1);
+    }
     c.cumul_l = c.l15 < S ? p.suscepCumul[c.l15] : 0.0;
     c.no_imm = any_lane(c.cumul_l != 0.0) ? 0 : 1;
     c.sigcs = 0.0;
