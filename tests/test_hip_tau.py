@@ -755,6 +755,41 @@ def test_tries_over_the_lists_of_occupied_compartments(monkeypatch, sites, P, S,
     assert a.bCounter > 0
 
 
+def _fill_heavy(rng, shape):           # sparse, with lineages of 10^5 .. 10^7 hosts: their EMPTY neighbours (mutants arriving) and the empty
+    a = _fill_sparse(rng, shape)       # compartments of their columns (migrants arriving) hold the smallest candidate of ChooseTau
+    a[0, 12345 % shape[1]] = 4 * 10 ** 6
+    a[shape[0] - 1, 777] = 10 ** 5
+    a[shape[0] - 1, 778] = 9 * 10 ** 6
+    return a
+
+
+@pytest.mark.parametrize("sites,P,S,fill,uneven", [(8, 3, 2, _fill_sparse, False), (9, 2, 1, _fill_sparse, False), (10, 3, 1, _fill_sparse_mixed, False),
+                                                    (8, 4, 1, _fill_heavy, False), (10, 2, 2, _fill_heavy, False), (9, 3, 1, _fill_heavy, True),
+                                                    (9, 2, 1, _fill_one_region, False), (7, 4, 1, _fill_sparse, False), (9, 3, 2, _fill_sparse_mixed, True)])
+def test_drift_over_the_lists_equals_the_dense_pass(monkeypatch, sites, P, S, fill, uneven):
+    """Sparse states with uniform migration: the column sums' pass lists the occupied compartments and the drift pass goes over the lists
+    (vgx_tau_drift8s_*: the occupied compartments, the empty neighbours of the large ones, the empty compartments of the columns with
+    large sums) instead of streaming every byte (VGX_TAU_DENSE_DRIFT=1: vgx_tau_drift8_kernel).  The compartments' candidates are the
+    same bit patterns; the susceptible compartments' drift is summed in another order: leap lengths to 1e-12, steps, events and states
+    identical.  `_fill_heavy`: the minimum is an EMPTY compartment's (next to a lineage of millions / in its column)."""
+    def run(dense):
+        if dense:
+            monkeypatch.setenv("VGX_TAU_DENSE_DRIFT", "1")
+        else:
+            monkeypatch.delenv("VGX_TAU_DENSE_DRIFT", raising=False)
+        s = _filled(sites, P, S, 1300 + sites, fill, True, uneven=uneven)
+        with helpers.quiet():
+            s.simulate(6, sample_size=10 ** 12, method="tau", record_multievents=False)
+        return s.simulation
+    a, b = run(False), run(True)
+    assert a.events.ptr == b.events.ptr == 12
+    np.testing.assert_allclose(a.events.times[:12], b.events.times[:12], rtol=1e-12, atol=0)
+    assert np.array_equal(a.infectious, b.infectious) and np.array_equal(a.susceptible, b.susceptible)
+    for k in a.COUNTERS:
+        assert getattr(a, k) == getattr(b, k), k
+    assert a.bCounter > 0
+
+
 def test_lists_and_front_pass_with_several_replicates(monkeypatch):
     """Three replicates of a sparse 8-site model on the step kernels (their tries end at different places: no front pass alone,
     one list of occupied compartments per replicate): the runs with the lists and the front pass equal those without."""

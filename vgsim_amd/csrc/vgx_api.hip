@@ -106,7 +106,7 @@ struct vgx_engine {
         r_evrate, r_evcols, r_locrec, r_loctime, r_lociter, r_farate, r_fakey, r_traj, r_prof, r_qeff, r_qmebm, r_qflag;
     // tau-leaping (dense compartments)
     DevBuf t_I, t_S, t_dChk, t_dApp, t_dSi, t_dTot, t_totInf, t_gI, t_cd, t_lock, t_F, t_eff, t_Aeff, t_Gout, t_dS,
-        t_taubits, t_tau, t_time, t_flags, t_counters, t_cnttry, t_cntpop, t_front, t_frontn, t_occ, t_occn, t_occpop, t_mev, t_mevn, t_mevbase, t_locn, t_mutcum, t_migcdf, t_migIn, t_mutHi, t_colT, t_colTW, t_inc, t_incn, t_sieve, t_sievepop, t_sieveskip, t_big, t_bign, t_res, t_susp, t_suspn, t_stkey, t_stval, t_dChkTot, t_q, t_qn, t_hist, t_I8, t_dSpart, t_tmax8, t_iI, t_iS, t_slog, t_sres;
+        t_taubits, t_tau, t_time, t_flags, t_counters, t_cnttry, t_cntpop, t_front, t_frontn, t_occ, t_occn, t_occpop, t_tIpt, t_d8spk, t_d8sbc, t_d8stile, t_d8sovf, t_d8smax, t_mev, t_mevn, t_mevbase, t_locn, t_mutcum, t_migcdf, t_migIn, t_mutHi, t_colT, t_colTW, t_inc, t_incn, t_sieve, t_sievepop, t_sieveskip, t_big, t_bign, t_res, t_susp, t_suspn, t_stkey, t_stval, t_dChkTot, t_q, t_qn, t_hist, t_I8, t_dSpart, t_tmax8, t_iI, t_iS, t_slog, t_sres;
     std::vector<int64_t> tau_sieve_skipped;   // [R] tries left out by the sieve in the last tau call
     bool last_was_tau = false;
     bool tau_staged = false;              // vgx_stage_tau put the current start state on the device in the tau kernels' layout
@@ -1721,6 +1721,16 @@ extern "C" int vgx_simulate_tau(vgx_engine *e, int64_t iterations, int64_t sampl
             if (rco) return rco;
             HIPCHECK(e, hipMemset(e->t_occpop.p, 0, (size_t)(R * P) * 8));
             a.occ = (int32_t *)e->t_occ.p; a.occ_n = (unsigned int *)e->t_occn.p; a.occ_pop = (unsigned long long *)e->t_occpop.p;
+            // the drift pass over those lists (vgx_tau_drift8s_*)
+            rco = ensure(e, e->t_tIpt, (size_t)(R * P * a.nt8) * 8 + 64);
+            if (!rco) rco = ensure(e, e->t_d8spk, (size_t)(R * P) * 64 + 64);
+            if (!rco) rco = ensure(e, e->t_d8sbc, (size_t)R * 64 + 64);
+            if (!rco) rco = ensure(e, e->t_d8sovf, (size_t)(R * P) * (size_t)a.occ_nreg * 4 + 64);
+            if (!rco) rco = ensure(e, e->t_d8smax, (size_t)(R * P) * (size_t)a.occ_nreg * 4 + 64);
+            if (!rco) rco = ensure(e, e->t_d8stile, (size_t)(R * 2 * a.nt8) * 8 + 64);
+            if (rco) return rco;
+            a.tI_pt = (unsigned long long *)e->t_tIpt.p; a.d8s_pk = (double *)e->t_d8spk.p; a.d8s_bc = (unsigned long long *)e->t_d8sbc.p;
+            a.d8s_tile = (double *)e->t_d8stile.p; a.d8s_ovf = (int32_t *)e->t_d8sovf.p; a.d8s_regmax = (int32_t *)e->t_d8smax.p;
         }
         a.hist = nullptr;
         if (flat && a.sieve_on && e->C <= 8) {   // (VGX_HIST_CMAX classes x 64 sizes per population)
@@ -1766,6 +1776,9 @@ extern "C" int vgx_simulate_tau(vgx_engine *e, int64_t iterations, int64_t sampl
     // uploaded state, then what the drift pass of the last step counted (the largest replicate)
     const char *nol = getenv("VGX_TAU_NO_OCCLIST");
     const bool occ_lists_ok = a.use8 && a.front_on && a.occ != nullptr && !(nol && nol[0] == '1');
+    const char *ddr = getenv("VGX_TAU_DENSE_DRIFT");     // comparisons: vgx_tau_drift8_kernel also on sparse states
+    const bool dense_drift = ddr && ddr[0] == '1';
+    int sparse_ban = 0;      // steps for which the drift pass stays dense
     const bool occ_lists_banned = false;
     int64_t occ_est = occupied;
     int64_t tries_total = 0, tries_lists = 0;
@@ -1976,6 +1989,11 @@ extern "C" int vgx_simulate_tau(vgx_engine *e, int64_t iterations, int64_t sampl
         // a sparse state (at most 1/32 of the compartments occupied when the last step began): the drift pass lists the occupied
         // compartments and the tries' scan and front pass go over the lists
         a.build_occ = a.use_list = (occ_lists_ok && !occ_lists_banned && occ_est >= 0 && occ_est * 32 <= P * H) ? 1 : 0;
+        // ... and with uniform migration (the column sums' pass is there to write the lists) the drift pass itself goes over them
+        // (unless the last such pass had to form the empty neighbours of too many compartments — a high mutation rate, or a smallest
+        // candidate far above what the lineages' mutants bring: the dense pass for a while, then another look)
+        if (sparse_ban > 0) sparse_ban -= 1;
+        a.drift_sparse = (a.build_occ && a.has_mig && a.mig_uniform && !dense_drift && sparse_ban == 0) ? 1 : 0;
         HIPCHECK(e, vgxi_tau_eff(&a, e->stream));
         HIPCHECK(e, vgxi_tau_prep(&a, e->stream));
         HIPCHECK(e, vgxi_tau_drift(&a, e->stream));
@@ -2192,6 +2210,7 @@ extern "C" int vgx_simulate_tau(vgx_engine *e, int64_t iterations, int64_t sampl
             mevn[(size_t)r] = (unsigned long long)o[11];
             err_h[(size_t)r] = (int32_t)o[12];
             if (o[13] >= 0) occ_step = std::max<int64_t>(occ_step, o[13]);
+            if (a.drift_sparse && o[15] >= 0 && (o[13] + 30 * o[15]) * 26 > P * H) sparse_ban = 32;
             if (spec_rounds && r == 0) {
                 tries_total += o[14] + 1;
                 if (a.use_list) tries_lists += o[14] + 1;

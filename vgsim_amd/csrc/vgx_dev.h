@@ -228,6 +228,17 @@ struct VgxTauArgs {
     unsigned int *occ_n;     // [R][P][occ_nreg] occupied compartments per region (beyond VGX_OCC_CAP the list is incomplete: the region is swept)
     unsigned long long *occ_pop;   // [R][P] occupied compartments of the population as the drift pass saw them (summed and cleared by the finish kernel)
     int32_t occ_nreg, build_occ, use_list, occ_pad;
+    // The drift pass over those lists (vgx_tau_drift8s_*: sparse states with uniform migration): the column sums' pass lists the occupied
+    // compartments, the drift of the listed ones is formed from their neighbours' bytes, and of the EMPTY compartments only those that a
+    // large neighbour or a large column sum could bring below the smallest candidate so far (ChooseTau's minimum is the same minimum).
+    int32_t drift_sparse, ds_pad;
+    unsigned long long *tI_pt;   // [R][P][nt8] infectious hosts per (population, tile): exact integer sums (any order)
+    double *d8s_pk;              // [R][P][8] per population: Bsum, c1, c2, kI, F, weight, kmig, -
+    unsigned long long *d8s_bc;  // [R][8] bit patterns of the largest |Bsum|, |c1|, |c2| of the populations (the bound of a column sum's term); [3]: compartments
+                                 // whose empty neighbours were formed in this step; [4]: regions on d8s_ovf
+    int32_t *d8s_ovf;            // [R][P * occ_nreg] the regions whose lists are incomplete (population * occ_nreg + region), d8s_bc[4] of them
+    int32_t *d8s_regmax;         // [R][P][occ_nreg] largest count of a region
+    double *d8s_tile;            // [R][2][nt8] hosts of all populations per tile of the rows, and weighted by cd / actualSizes
     int64_t *front;      // [R][P][front_cap] the front pass's lists: compartments that can fall below zero on their own in this try (vgx_tau_front_kernel)
     unsigned int *front_n;   // [R][P] their counts (may exceed front_cap: the rest is found by the try proper); cleared by vgx_tau_decide_kernel
     int32_t front_cap, front_on;

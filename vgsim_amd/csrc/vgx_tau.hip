@@ -895,7 +895,9 @@ struct D8Ctx {
     const int32_t *Irow;
     const double *cTP, *cTWP;
     int tl, low, ntop, TSd, sites;
-    bool use_col, use_tw, do_hist, one_rate;
+    bool use_col, use_tw, do_hist, one_rate, skip_empty, listed;
+    const uint16_t *queue;           // sparse states: the tile's dwords that hold a host (d8_scan), or null: all of them in order
+    int nq;
     double kI, rate_lo, rate_hi, Bsum, c1, c2;
     float kI_a, rlo_a, rhi_a, B_a;   // their magnitudes in single precision, rounded up: the screen of d8_cells
     float kI_f, rlo_f, rhi_f, B_f;   // and the coefficients themselves (its second level)
@@ -906,18 +908,65 @@ struct D8Ctx {
 #ifdef VGX_D8_STATS
 __device__ unsigned long long vgx_d8_stats[8];   // diagnostic build: wave turns, turns past level 1, past level 2, sum of thr0 > 1.5
 #endif
+// the coefficients of a compartment's drift in population pn (see D8Ctx): one function for the dense and the sparse form
+static __device__ __forceinline__ void d8_coeffs(const MigU &mu, bool use_tw, double Bsum, double F, double out_rate, double &c1, double &c2, double &kmig,
+                                                 double &kI) {
+    c1 = use_tw ? mu.c1 : mu.c1 + mu.c2 * mu.wt;
+    c2 = mu.c2;
+    kmig = mu.c1 + mu.c2 * mu.wt;
+    kI = Bsum * F - out_rate - Bsum * kmig;
+}
+// sparse states: the tile's occupied compartments listed region by region (as d8_cells lists them when it takes every dword in order) and
+// the dwords that hold a host gathered in LDS — d8_cells then takes only those, 64 per wavefront and turn whatever their place in the
+// tile (at SURVEY 8(d)'s start state six of ten turns of 256 compartments hold a host, one dword in seventy does).
+#define VGX_D8_QCAP 1024
+static __device__ __forceinline__ void d8_scan(const D8Ctx &c, int lane, int TSd, int low, int &occ_cnt, uint16_t *s_queue, int *s_nq) {
+    for (int q = threadIdx.x; q < TSd; q += D8_TB) {
+        const int h = (c.tl << (2 * low)) + 4 * q;
+        const uint32_t own = c.tile32[q];
+        if (!__any(own != 0u)) continue;
+        if (c.occ_dst) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool nz = ((own >> (8 * j)) & 255u) != 0u;
+                const unsigned long long m = __ballot(nz);
+                if (m == 0ull) continue;
+                if (nz) {
+                    const int pos = occ_cnt + (int)__popcll(m & ((1ull << lane) - 1ull));
+                    if (pos < VGX_OCC_CAP) c.occ_dst[pos] = h + j;
+                }
+                occ_cnt += (int)__popcll(m);
+            }
+        } else {
+            const uint32_t y = own;
+            const uint32_t zf = ~(((y & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | y | 0x7F7F7F7Fu);
+            occ_cnt += 4 - __popc(zf);
+        }
+        if (own != 0u) {
+            const int pos = atomicAdd(s_nq, 1);
+            if (pos < VGX_D8_QCAP) s_queue[pos] = (uint16_t)q;
+        }
+    }
+}
 template <int MODE, bool USUAL>
 static __device__ __forceinline__ void d8_cells(const D8Ctx &c, int lane, double &cand_min, double &ad_max, long long &sumI, double &sumMg,
-                                                int &occ_cnt, float thr) {
+                                                int &occ_cnt, float thr, int &imax) {
     // USUAL: the shape of config 4 and of most models the kernel takes — eight sites inside the tile, uniform migration with one common
     // weight, one mutation rate — with the switches below known at compile time (one straight-line turn: every neighbour read in flight
     // together, no selects between forms that are not needed)
     const int k_low = USUAL ? VGX_D8_LOW : c.low, k_TSd = USUAL ? (1 << (2 * VGX_D8_LOW - 2)) : c.TSd;
     const bool k_col = USUAL ? true : c.use_col, k_tw = USUAL ? false : c.use_tw, k_one = USUAL ? true : c.one_rate;
-    for (int q = threadIdx.x; q < k_TSd; q += D8_TB) {
+    const int bound = c.queue ? c.nq : k_TSd;
+    for (int it = threadIdx.x; (it & ~63) < bound; it += D8_TB) {      // (whole wavefronts: the turn's screen is a wavefront's)
+        const bool valid = it < bound;                                  // (beyond the gathered dwords: an empty dword that asks for nothing)
+        const int q = c.queue ? (valid ? (int)c.queue[it] : 0) : it;
         const int h = (c.tl << (2 * k_low)) + 4 * q;          // first of the thread's four haplotypes
-        const uint32_t own = c.tile32[q];
-        if (c.occ_dst) {       // (wave-uniform) the occupied compartments among the wavefront's 256: listed, region by region
+        const uint32_t own = valid ? c.tile32[q] : 0u;
+        // sparse states (VgxTauArgs.drift_sparse): a turn whose 256 compartments are all empty is left out — what arrives in an empty
+        // compartment is looked at by vgx_tau_drift8s_heavy_kernel / _col_kernel where it can matter
+        if (c.skip_empty && !__any(own != 0u)) continue;
+        if (c.listed) {
+        } else if (c.occ_dst) {       // (wave-uniform) the occupied compartments among the wavefront's 256: listed, region by region
             if (__any(own != 0u)) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -978,8 +1027,8 @@ static __device__ __forceinline__ void d8_cells(const D8Ctx &c, int lane, double
         const int s4 = Iv[0] + Iv[1] + Iv[2] + Iv[3];
         int nlo[4] = {(int)(loE & 0xFFFFu) + s4 - Iv[0], (int)(loO & 0xFFFFu) + s4 - Iv[1], (int)(loE >> 16) + s4 - Iv[2], (int)(loO >> 16) + s4 - Iv[3]};
         int nhi[4] = {(int)(hiE & 0xFFFFu), (int)(hiO & 0xFFFFu), (int)(hiE >> 16), (int)(hiO >> 16)};
-        if (MODE == 2 && __any(bad != 0u)) {
-            if (bad != 0u) {      // a count of 255 or more among the bytes added: the sums again from the 4-byte counts
+        if (MODE == 2 && __any(bad != 0u && valid)) {
+            if (bad != 0u && valid) {      // a count of 255 or more among the bytes added: the sums again from the 4-byte counts
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int hh = h + j;
@@ -994,6 +1043,7 @@ static __device__ __forceinline__ void d8_cells(const D8Ctx &c, int lane, double
             }
         }
         sumI += (MODE == 2) ? (long long)Iv[0] + (long long)Iv[1] + (long long)Iv[2] + (long long)Iv[3] : (long long)s4;
+        imax = max(imax, max(max(Iv[0], Iv[1]), max(Iv[2], Iv[3])));
         // pyx:2440-2444: candidate max(eps * X / 2, 1) / |drift| with eps * X in single precision; the numerator is 1 up to 66
         // hosts ((double)(0.03f * (float)X) / 2 > 1 from X = 67 on), and the smallest of those candidates is 1 / (largest |drift|).
         // All the kernel keeps of the |drift| values is the launch's smallest candidate (tau_bits, an atomic minimum that starts
@@ -1027,6 +1077,7 @@ static __device__ __forceinline__ void d8_cells(const D8Ctx &c, int lane, double
 #else
         unsigned int need = (U >= thr || (MODE != 0 && ihmax > 66) || !(U < 3.0e38f)) ? 15u : 0u;
 #endif
+        need = valid ? need : 0u;
 #ifdef VGX_D8_STATS
         if (lane == 0) atomicAdd(&vgx_d8_stats[0], 1ull);
         if (__any(need != 0u) && lane == 0) atomicAdd(&vgx_d8_stats[1], 1ull);
@@ -1101,8 +1152,11 @@ extern "C" __global__ void __launch_bounds__(D8_TB, 4) vgx_tau_drift8_kernel(Vgx
     __shared__ unsigned int hist[VGX_HIST_X * 16];
     __shared__ double s_wu[16];
     __shared__ unsigned int s_mx;
+    __shared__ uint16_t s_queue[VGX_D8_QCAP];
+    __shared__ int s_nq;
     const bool do_hist = a.hist != nullptr;
     if (threadIdx.x == 0) {
+        s_nq = 0;
         smin = (unsigned long long)__double_as_longlong(1.0);
         const unsigned int *tm = a.tmax8 + ((int64_t)rep * P + pn) * nt;
         unsigned int c = tm[tl];
@@ -1139,9 +1193,9 @@ extern "C" __global__ void __launch_bounds__(D8_TB, 4) vgx_tau_drift8_kernel(Vgx
     // digits 6.. and the tiles above
     c.rate_lo = a.mutp[sites - VGX_DRIFT_LOW][0]; c.rate_hi = a.mutHi_rate;
     c.one_rate = c.rate_lo == c.rate_hi;
-    c.Bsum = Bsum; c.c1 = c.use_tw ? mu.c1 : mu.c1 + mu.c2 * mu.wt; c.c2 = mu.c2;
-    const double kmig = mu.c1 + mu.c2 * mu.wt;         // mg = (c1 T + c2 TW) - kmig Ih
-    c.kI = Bsum * F - (cd0 + cs0 + ctm0) - Bsum * kmig;
+    double kmig;                                       // mg = (c1 T + c2 TW) - kmig Ih
+    c.Bsum = Bsum;
+    d8_coeffs(mu, c.use_tw, Bsum, F, cd0 + cs0 + ctm0, c.c1, c.c2, kmig, c.kI);
     c.hist = hist;
     c.kI_a = fabsf((float)c.kI) * (1.0f + 4e-6f); c.rlo_a = fabsf((float)c.rate_lo) * (1.0f + 4e-6f); c.rhi_a = fabsf((float)c.rate_hi) * (1.0f + 4e-6f);
     c.B_a = fabsf((float)c.Bsum) * (1.0f + 4e-6f);
@@ -1155,18 +1209,37 @@ extern "C" __global__ void __launch_bounds__(D8_TB, 4) vgx_tau_drift8_kernel(Vgx
     const int64_t region = ((int64_t)rep * P + pn) * a.occ_nreg + (int64_t)tl * (D8_TB / 64) + wv;
     c.occ_dst = a.build_occ ? a.occ + region * VGX_OCC_CAP : nullptr;
     const bool usual = low == VGX_D8_LOW && c.use_col && !c.use_tw && c.one_rate;
+    c.skip_empty = a.drift_sparse != 0;
+    c.listed = false; c.queue = nullptr; c.nq = 0;
+    int imax = 0;          // the lane's largest count
+    if (a.drift_sparse) {
+        d8_scan(c, lane, TSd, low, occ_cnt, s_queue, &s_nq);
+        __syncthreads();
+        c.listed = true;
+        if (s_nq <= VGX_D8_QCAP) { c.queue = s_queue; c.nq = s_nq; }      // (more: a tile in a large lineage's neighbourhood, every dword in order)
+    }
     if (usual) {
-        if (mx <= 66u) d8_cells<0, true>(c, lane, cand_min, ad_max, sumI, sumMg, occ_cnt, thr0);
-        else if (mx < 255u) d8_cells<1, true>(c, lane, cand_min, ad_max, sumI, sumMg, occ_cnt, thr0);
-        else d8_cells<2, true>(c, lane, cand_min, ad_max, sumI, sumMg, occ_cnt, thr0);
+        if (mx <= 66u) d8_cells<0, true>(c, lane, cand_min, ad_max, sumI, sumMg, occ_cnt, thr0, imax);
+        else if (mx < 255u) d8_cells<1, true>(c, lane, cand_min, ad_max, sumI, sumMg, occ_cnt, thr0, imax);
+        else d8_cells<2, true>(c, lane, cand_min, ad_max, sumI, sumMg, occ_cnt, thr0, imax);
     } else {
-        if (mx <= 66u) d8_cells<0, false>(c, lane, cand_min, ad_max, sumI, sumMg, occ_cnt, thr0);
-        else if (mx < 255u) d8_cells<1, false>(c, lane, cand_min, ad_max, sumI, sumMg, occ_cnt, thr0);
-        else d8_cells<2, false>(c, lane, cand_min, ad_max, sumI, sumMg, occ_cnt, thr0);
+        if (mx <= 66u) d8_cells<0, false>(c, lane, cand_min, ad_max, sumI, sumMg, occ_cnt, thr0, imax);
+        else if (mx < 255u) d8_cells<1, false>(c, lane, cand_min, ad_max, sumI, sumMg, occ_cnt, thr0, imax);
+        else d8_cells<2, false>(c, lane, cand_min, ad_max, sumI, sumMg, occ_cnt, thr0, imax);
     }
     {
         int tot = occ_cnt;
         if (a.build_occ) { if (lane == 0) a.occ_n[region] = (unsigned int)occ_cnt; }
+        if (a.drift_sparse) {      // the region's largest count; a region whose list is incomplete goes on the launch's list of such regions
+            for (int o = 32; o > 0; o >>= 1) imax = max(imax, __shfl_down(imax, o));
+            if (lane == 0) {
+                a.d8s_regmax[region] = imax;
+                if (occ_cnt > VGX_OCC_CAP) {
+                    const unsigned long long slot = atomicAdd(&a.d8s_bc[(int64_t)rep * 8 + 4], 1ull);
+                    a.d8s_ovf[(int64_t)rep * P * a.occ_nreg + (int64_t)slot] = pn * a.occ_nreg + (int)(region - ((int64_t)rep * P + pn) * a.occ_nreg);
+                }
+            }
+        }
         else for (int o = 32; o > 0; o >>= 1) tot += __shfl_down(tot, o);
         if (lane == 0 && tot != 0) atomicAdd(&a.occ_pop[(int64_t)rep * P + pn], (unsigned long long)tot);
     }
@@ -1192,7 +1265,10 @@ extern "C" __global__ void __launch_bounds__(D8_TB, 4) vgx_tau_drift8_kernel(Vgx
         const double mgsum = tM - kmig * tI;
         double v = -l_base[sn] * (F * tI + mgsum);
         if (sn == st0) v += (cd0 + cs0) * tI;
-        a.dS_part[(((int64_t)rep * P + pn) * a.ds_nb + tl) * S + sn] = v;
+        // (sparse: the sum over ALL compartments of the tile in mgsum is not formed — the turns left out — and the tile's hosts go to
+        // vgx_tau_drift8s_sus_kernel instead, which has it from the tiles' integer sums)
+        if (!a.drift_sparse) a.dS_part[(((int64_t)rep * P + pn) * a.ds_nb + tl) * S + sn] = v;
+        else if (sn == 0) a.tI_pt[((int64_t)rep * P + pn) * nt + tl] = (unsigned long long)tI;
     }
     if (threadIdx.x == 0) atomicMin(&a.tau_bits[rep], smin);
     if (do_hist)
@@ -1201,6 +1277,340 @@ extern "C" __global__ void __launch_bounds__(D8_TB, 4) vgx_tau_drift8_kernel(Vgx
             for (int k = 0; k < 16; ++k) v += hist[i * 16 + k];
             if (v) atomicAdd(&a.hist[((int64_t)rep * P + pn) * VGX_HIST_X + i], v);
         }
+}
+
+// ---- the drift pass over the lists of occupied compartments (sparse states: VgxTauArgs.drift_sparse) ---------------------------------
+// At natural occupancy (0.65 % of config 4's compartments after SURVEY 8(d)'s warm-up) vgx_tau_drift8_kernel spends its time finding
+// out that a turn's compartments are empty.  ChooseTau's minimum (pyx:2432-2450) needs
+//   (1) every OCCUPIED compartment's candidate — the lists (written here by vgx_tau_colsum8_kernel, which streams the bytes once for the
+//       column sums anyway) with the neighbours' bytes read where they lie;
+//   (2) of the EMPTY compartments, whose candidate is 1 / (their arrivals' rate), only those that can undercut the smallest candidate m
+//       of (1): an empty compartment's drift is rate * (its neighbours' hosts) + Bsum (c1 T + c2 TW) <= 3 sites rate max-neighbour +
+//       coefficient * column sum, so one whose neighbours all hold fewer than 0.49 / (m rate 3 sites) hosts and whose column's term is
+//       below 0.49 / m cannot: the neighbours of the larger compartments (vgx_tau_drift8s_heavy_kernel) and the columns with the larger
+//       sums (vgx_tau_drift8s_col_kernel) are formed exactly, the rest is provably above m.
+// Every drift that is formed is formed as vgx_tau_drift8_kernel forms it (same coefficients: d8_coeffs, same fused operations), so the
+// minimum is the same bit pattern; the susceptible compartments' drift (a sum over ALL compartments of a tile in the dense form) comes
+// from exact integer sums per (population, tile) and differs from the dense form's by rounding only
+// (tests/test_hip_tau.py::test_drift_over_the_lists_equals_the_dense_pass).
+struct D8S {
+    const uint8_t *I8row;
+    const int32_t *Irow;
+    const double *cT, *cTW;
+    int sites;
+    bool use_col, use_tw, one_rate;
+    double kI, rate_lo, rate_hi, Bsum, c1, c2;
+};
+static __device__ __forceinline__ int d8s_count(const D8S &c, int h) {
+    const int b = c.I8row[h];
+    return b < 255 ? b : c.Irow[h];
+}
+#define VGX_D8S_MAX_SITES 12
+static __device__ __forceinline__ double d8s_drift(const D8S &c, int h, int Icell) {
+    // the neighbours' bytes: every load of the compartment in flight before the first is used (the sites are wave-uniform)
+    int b[3 * VGX_D8S_MAX_SITES];
+#pragma unroll
+    for (int g = 0; g < VGX_D8S_MAX_SITES; ++g) {
+        if (g < c.sites) {
+#pragma unroll
+            for (int x = 1; x < 4; ++x) b[3 * g + x - 1] = c.I8row[h ^ (x << (2 * g))];
+        } else {
+            b[3 * g] = 0; b[3 * g + 1] = 0; b[3 * g + 2] = 0;
+        }
+    }
+    int nlo = 0, nhi = 0, sat = 0;
+#pragma unroll
+    for (int g = 0; g < VGX_D8S_MAX_SITES; ++g) {
+        const int v3 = b[3 * g] + b[3 * g + 1] + b[3 * g + 2];
+        sat |= (b[3 * g] == 255) | (b[3 * g + 1] == 255) | (b[3 * g + 2] == 255);
+        if (g < VGX_DRIFT_LOW) nlo += v3; else nhi += v3;
+    }
+    if (sat) {      // a byte of 255 stands for "255 or more": the sums again from the 4-byte counts
+        nlo = 0; nhi = 0;
+        for (int g = 0; g < c.sites; ++g) {
+            const int v3 = d8s_count(c, h ^ (1 << (2 * g))) + d8s_count(c, h ^ (2 << (2 * g))) + d8s_count(c, h ^ (3 << (2 * g)));
+            if (g < VGX_DRIFT_LOW) nlo += v3; else nhi += v3;
+        }
+    }
+    double drift = c.kI * (double)Icell;
+    if (c.one_rate) drift = __builtin_fma(c.rate_lo, (double)(nlo + nhi), drift);
+    else drift = __builtin_fma(c.rate_hi, (double)nhi, __builtin_fma(c.rate_lo, (double)nlo, drift));
+    if (c.use_col) {
+        const double T = c.cT[h];
+        const double mg = c.use_tw ? __builtin_fma(c.c2, c.cTW[h], c.c1 * T) : c.c1 * T;
+        drift = __builtin_fma(c.Bsum, mg, drift);
+    }
+    return drift;
+}
+static __device__ __forceinline__ void d8s_ctx(const VgxTauArgs &a, int rep, int pn, D8S &c) {
+    const VgxDevParams &p = a.p;
+    const int64_t rowoff = ((int64_t)rep * p.P + pn) * p.H;
+    const double *pk = a.d8s_pk + ((int64_t)rep * p.P + pn) * 8;
+    c.I8row = a.I8 + rowoff; c.Irow = a.I + rowoff;
+    c.cT = a.colT + (int64_t)rep * p.H; c.cTW = a.colTW + (int64_t)rep * p.H;
+    c.sites = p.sites;
+    c.use_col = a.has_mig && a.mig_uniform;
+    c.use_tw = pk[7] != 0.0;
+    c.rate_lo = a.mutp[p.sites - VGX_DRIFT_LOW][0]; c.rate_hi = a.mutHi_rate;
+    c.one_rate = c.rate_lo == c.rate_hi;
+    c.Bsum = pk[0]; c.c1 = pk[1]; c.c2 = pk[2]; c.kI = pk[3];
+}
+// a candidate of ChooseTau (pyx:2440-2444) into the lane's running values, as vgx_tau_drift8_kernel keeps them
+static __device__ __forceinline__ void d8s_candidate(int Icell, double drift, double &cand_min, double &ad_max) {
+    const double ad = fabs(drift);
+    const bool large = Icell > 66;
+    ad_max = fmax(ad_max, large ? 0.0 : ad);
+    if (large && ad >= 1e-8) cand_min = fmin(cand_min, ((double)(0.03f * (float)Icell) / 2.0) / ad);
+}
+static __device__ __forceinline__ void d8s_commit(const VgxTauArgs &a, int rep, double cand_min, double ad_max) {
+    if (ad_max >= 1e-8 && 1.0 / ad_max < cand_min) cand_min = 1.0 / ad_max;
+    for (int o = 32; o > 0; o >>= 1) {
+        const double other = __shfl_down(cand_min, o);
+        if (other < cand_min) cand_min = other;
+    }
+    // (a look before the atomic: tens of thousands of wavefronts on one address, and all but a few have nothing smaller to offer)
+    if ((threadIdx.x & 63) == 0 && cand_min < __longlong_as_double((long long)*(volatile unsigned long long *)&a.tau_bits[rep]))
+        atomic_min_pos_double(&a.tau_bits[rep], cand_min);
+}
+// A region whose list is complete: one wavefront, a compartment per lane and turn.  A region with more occupied compartments than its
+// list holds (the neighbourhood of a large lineage: four fifths of its 8192 compartments occupied at SURVEY 8(d)'s start state, in 16 of
+// 4096 tiles) is put on the launch's list of such regions instead and taken 256 compartments at a time by vgx_tau_drift8s_ovf_kernel.
+// what an empty compartment's arrivals must reach to matter: 1 / (the smallest candidate so far)
+static __device__ __forceinline__ double d8s_need(const VgxTauArgs &a, int rep) { return 1.0 / __longlong_as_double((long long)a.tau_bits[rep]); }
+
+// grid of the passes over the regions = (8 * ceil(P / 8) * ceil(occ_nreg / 4), R), flattened as vgx_tau_drift8_kernel's: the blocks of one
+// population on one XCD (workgroups go to the XCDs round-robin), so that a row's bytes are fetched into ONE L2
+static __device__ __forceinline__ void d8s_block(const VgxTauArgs &a, int &pn, int &bx) {
+    const unsigned nb = (unsigned)((a.occ_nreg + 3) / 4), f = blockIdx.x, sq = f >> 3;
+    pn = (int)(sq / nb) * 8 + (int)(f & 7u);
+    bx = (int)(sq % nb);
+}
+// the coefficients of every population (block = D8_TB threads as vgx_tau_drift8_kernel: tau_migu_setup's sum runs in the block's order).
+// grid = (P, R); d8s_bc zeroed before.
+extern "C" __global__ void __launch_bounds__(D8_TB) vgx_tau_drift8s_prep_kernel(VgxTauArgs a) {
+    const VgxDevParams &p = a.p;
+    const int P = p.P, S = p.S, pn = blockIdx.x, rep = blockIdx.y;
+    if (!a.active[rep]) return;
+    __shared__ double l_base[64];
+    __shared__ double s_wu[16];
+    const int64_t *Sus = a.S + (int64_t)rep * P * S + (int64_t)pn * S;
+    for (int i = threadIdx.x; i < S; i += D8_TB) l_base[i] = p.cb_b[0] * p.cb_sigma[i] * (double)Sus[i];
+    __syncthreads();
+    const bool use_col = a.has_mig && a.mig_uniform;
+    MigU mu = {0.0, 0.0, 0.0, true};
+    if (use_col) mu = tau_migu_setup(a, rep, pn, s_wu);
+    double Bsum = 0.0;
+    for (int sn = 0; sn < S; ++sn) Bsum += l_base[sn];
+    const double F = a.F[(int64_t)rep * P + pn];
+    const double cd0 = p.c_d[0], cs0 = p.c_s[0] * p.sampMult[pn], ctm0 = p.c_tm[0];
+    const bool use_tw = use_col && !mu.weq;
+    double c1, c2, kmig, kI;
+    d8_coeffs(mu, use_tw, Bsum, F, cd0 + cs0 + ctm0, c1, c2, kmig, kI);
+    if (threadIdx.x == 0) {
+        double *pk = a.d8s_pk + ((int64_t)rep * P + pn) * 8;
+        pk[0] = Bsum; pk[1] = c1; pk[2] = c2; pk[3] = kI; pk[4] = F; pk[5] = mu.wt; pk[6] = kmig; pk[7] = use_tw ? 1.0 : 0.0;
+        // upper bounds of |Bsum|, |c1|, |c2| over the populations (non-negative doubles order as their bit patterns)
+        atomicMax(&a.d8s_bc[(int64_t)rep * 8 + 0], (unsigned long long)__double_as_longlong(fabs(Bsum)));
+        atomicMax(&a.d8s_bc[(int64_t)rep * 8 + 1], (unsigned long long)__double_as_longlong(fabs(c1)));
+        atomicMax(&a.d8s_bc[(int64_t)rep * 8 + 2], (unsigned long long)__double_as_longlong(fabs(c2)));
+    }
+}
+
+// (1b) the regions on the list of that launch: a unit = the 256 compartments one wavefront of vgx_tau_drift8_kernel takes in a turn; four
+// units (of one region) per block and turn of the grid-stride loop.  HEAVY: pass (2a) for these regions instead.
+// grid = (VGX_D8S_OVF_BLOCKS, R), block = 256.
+#define VGX_D8S_OVF_BLOCKS 2048
+template <bool HEAVY>
+__global__ void __launch_bounds__(256) vgx_tau_drift8s_ovf_kernel(VgxTauArgs a) {
+    const VgxDevParams &p = a.p;
+    const int P = p.P, rep = blockIdx.y;
+    if (!a.active[rep]) return;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int novf = (int)a.d8s_bc[(int64_t)rep * 8 + 4];
+    if (novf == 0) return;
+    const int low = p.sites < VGX_D8_LOW ? p.sites : VGX_D8_LOW, TSd = 1 << (2 * low - 2), turns = TSd / D8_TB;   // (a multiple of four from seven sites on)
+    __shared__ unsigned int hist[VGX_HIST_X];
+    const bool do_hist = !HEAVY && a.hist != nullptr;
+    double need = 0.0;
+    if (HEAVY) need = d8s_need(a, rep);
+    for (int g = blockIdx.x; g < novf * (turns / 4); g += gridDim.x) {
+        const int ridx = a.d8s_ovf[(int64_t)rep * P * a.occ_nreg + g / (turns / 4)];
+        const int pn = ridx / a.occ_nreg, reg = ridx % a.occ_nreg, k = (g % (turns / 4)) * 4 + w;
+        const int64_t region = ((int64_t)rep * P + pn) * a.occ_nreg + reg;
+        D8S c;
+        d8s_ctx(a, rep, pn, c);
+        const int tl = reg / VGX_D8_WAVES, wv = reg % VGX_D8_WAVES;
+        const int h0 = (tl << (2 * low)) + 4 * (wv * 64 + lane + D8_TB * k);
+        const uint32_t own = *(const uint32_t *)(c.I8row + h0);
+        double cand_min = 1.0, ad_max = 0.0;
+        if (HEAVY) {
+            const double rate = fmax(fabs(c.rate_lo), fabs(c.rate_hi));
+            const double xpush = 0.49 * need / (rate * 3.0 * (double)p.sites);
+            if (!(rate > 0.0) || !((double)a.d8s_regmax[region] >= xpush)) continue;      // (block-uniform: one region per turn of the loop)
+            int nheavy = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (((own >> (8 * j)) & 255u) == 0u) continue;
+                const int h = h0 + j;
+                if (!((double)d8s_count(c, h) >= xpush)) continue;
+                nheavy += 1;
+                for (int q = 0; q < 3 * p.sites; ++q) {
+                    const int nb = h ^ ((q % 3 + 1) << (2 * (q / 3)));
+                    if (c.I8row[nb] == 0) d8s_candidate(0, d8s_drift(c, nb, 0), cand_min, ad_max);
+                }
+            }
+            d8s_commit(a, rep, cand_min, ad_max);
+            for (int o = 32; o > 0; o >>= 1) nheavy += __shfl_down(nheavy, o);
+            if (lane == 0 && nheavy != 0) atomicAdd(&a.d8s_bc[(int64_t)rep * 8 + 3], (unsigned long long)nheavy);
+            continue;
+        }
+        if (do_hist) {
+            for (int i = threadIdx.x; i < VGX_HIST_X; i += 256) hist[i] = 0;
+            __syncthreads();
+        }
+        long long sumI = 0;
+        int nocc = 0, imax = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (((own >> (8 * j)) & 255u) == 0u) continue;
+            const int h = h0 + j;
+            const int Icell = d8s_count(c, h);
+            nocc += 1;
+            sumI += Icell;
+            imax = max(imax, Icell);
+            if (do_hist && Icell <= VGX_HIST_X) atomicAdd(&hist[Icell - 1], 1u);
+            d8s_candidate(Icell, d8s_drift(c, h, Icell), cand_min, ad_max);
+        }
+        d8s_commit(a, rep, cand_min, ad_max);
+        for (int o = 32; o > 0; o >>= 1) { sumI += __shfl_down(sumI, o); nocc += __shfl_down(nocc, o); imax = max(imax, __shfl_down(imax, o)); }
+        if (lane == 0 && imax != 0) atomicMax(&a.d8s_regmax[region], imax);
+        if (lane == 0 && sumI != 0) atomicAdd(&a.tI_pt[((int64_t)rep * P + pn) * a.nt8 + tl], (unsigned long long)sumI);
+        if (lane == 0 && nocc != 0) atomicAdd(&a.occ_pop[(int64_t)rep * P + pn], (unsigned long long)nocc);
+        if (do_hist) {
+            __syncthreads();
+            for (int i = threadIdx.x; i < VGX_HIST_X; i += 256)
+                if (hist[i]) atomicAdd(&a.hist[((int64_t)rep * P + pn) * VGX_HIST_X + i], hist[i]);
+            __syncthreads();
+        }
+    }
+}
+
+// (2a) the empty neighbours of the larger compartments of the regions with complete lists: those whose largest count (kept by pass 1)
+// reaches the bound.  Same grid as pass 1.
+extern "C" __global__ void __launch_bounds__(256) vgx_tau_drift8s_heavy_kernel(VgxTauArgs a) {
+    const VgxDevParams &p = a.p;
+    const int rep = blockIdx.y;
+    int pn, bx;
+    d8s_block(a, pn, bx);
+    if (pn >= p.P || !a.active[rep]) return;
+    const int lane = threadIdx.x & 63, reg = bx * 4 + (threadIdx.x >> 6);
+    if (reg >= a.occ_nreg) return;
+    const int64_t region = ((int64_t)rep * p.P + pn) * a.occ_nreg + reg;
+    const int n = (int)a.occ_n[region];
+    if (n > VGX_OCC_CAP) return;
+    const double rate = fmax(fabs(a.mutp[p.sites - VGX_DRIFT_LOW][0]), fabs(a.mutHi_rate));
+    if (!(rate > 0.0)) return;
+    const double xpush = 0.49 * d8s_need(a, rep) / (rate * 3.0 * (double)p.sites);
+    if (!((double)a.d8s_regmax[region] >= xpush)) return;
+    D8S c;
+    d8s_ctx(a, rep, pn, c);
+    double cand_min = 1.0, ad_max = 0.0;
+    int nheavy = 0;
+    const int32_t *src = a.occ + region * VGX_OCC_CAP;
+    const int nnb = 3 * p.sites;
+    for (int i0 = 0; i0 < n; i0 += 64) {
+        // the turn's large compartments, then one (compartment, neighbour) pair per lane
+        const int h = i0 + lane < n ? src[i0 + lane] : 0;
+        const bool big = i0 + lane < n && (double)d8s_count(c, h) >= xpush;
+        unsigned long long m = __ballot(big);
+        nheavy += (int)__popcll(m);
+        while (m != 0ull) {
+            const int l = (int)__builtin_ctzll(m);
+            m &= m - 1ull;
+            const int hh = __shfl(h, l);
+            if (lane < nnb) {
+                const int nb = hh ^ ((lane % 3 + 1) << (2 * (lane / 3)));
+                if (c.I8row[nb] == 0) d8s_candidate(0, d8s_drift(c, nb, 0), cand_min, ad_max);
+            }
+        }
+    }
+    d8s_commit(a, rep, cand_min, ad_max);
+    // how many compartments took this path: the host goes back to the dense pass where it is no longer the few (vgx_api.hip)
+    if (lane == 0 && nheavy != 0) atomicAdd(&a.d8s_bc[(int64_t)rep * 8 + 3], (unsigned long long)nheavy);
+}
+
+// (2b) the empty compartments of the columns with the larger sums.  grid = (H / 256, R), block = 256: one haplotype per thread.
+extern "C" __global__ void __launch_bounds__(256) vgx_tau_drift8s_col_kernel(VgxTauArgs a) {
+    const VgxDevParams &p = a.p;
+    const int P = p.P, H = p.H, rep = blockIdx.y;
+    if (!a.active[rep]) return;
+    const int h = blockIdx.x * 256 + threadIdx.x;
+    const double Bm = __longlong_as_double((long long)a.d8s_bc[(int64_t)rep * 8 + 0]), c1m = __longlong_as_double((long long)a.d8s_bc[(int64_t)rep * 8 + 1]),
+                 c2m = __longlong_as_double((long long)a.d8s_bc[(int64_t)rep * 8 + 2]);
+    const double need = 0.49 * d8s_need(a, rep);
+    double cand_min = 1.0, ad_max = 0.0;
+    if (h < H) {
+        const double T = a.colT[(int64_t)rep * H + h];
+        // (the weighted sum is read only where the weights differ: d8s_pk[.][7] of every population then; its bound by the largest weight
+        // is not kept, so the column's own TW stands for it)
+        const bool tw = a.d8s_pk[((int64_t)rep * P) * 8 + 7] != 0.0;
+        const double TW = tw ? fabs(a.colTW[(int64_t)rep * H + h]) : 0.0;
+        if (T > 0.0 && Bm * (c1m * T + c2m * TW) >= need) {
+            for (int q = 0; q < P; ++q) {
+                if (a.I8[((int64_t)rep * P + q) * H + h] != 0) continue;
+                D8S c;
+                d8s_ctx(a, rep, q, c);
+                d8s_candidate(0, d8s_drift(c, h, 0), cand_min, ad_max);
+            }
+        }
+    }
+    d8s_commit(a, rep, cand_min, ad_max);
+}
+
+// per tile of the rows: the hosts of all populations and their weighted sum (the populations in a fixed order).  grid = (nt8, R), block = 256.
+extern "C" __global__ void __launch_bounds__(256) vgx_tau_drift8s_tiles_kernel(VgxTauArgs a) {
+    const int P = a.p.P, t = blockIdx.x, rep = blockIdx.y, nt = a.nt8;
+    if (!a.active[rep]) return;
+    __shared__ double sT[4], sW[4];
+    double T = 0.0, TW = 0.0;
+    for (int q = threadIdx.x; q < P; q += 256) {
+        const double v = (double)a.tI_pt[((int64_t)rep * P + q) * nt + t];
+        T += v;
+        TW += a.d8s_pk[((int64_t)rep * P + q) * 8 + 5] * v;
+    }
+    for (int o = 32; o > 0; o >>= 1) { T += __shfl_down(T, o); TW += __shfl_down(TW, o); }
+    if ((threadIdx.x & 63) == 0) { sT[threadIdx.x >> 6] = T; sW[threadIdx.x >> 6] = TW; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        a.d8s_tile[(int64_t)rep * 2 * nt + t] = (sT[0] + sT[1]) + (sT[2] + sT[3]);
+        a.d8s_tile[(int64_t)rep * 2 * nt + nt + t] = (sW[0] + sW[1]) + (sW[2] + sW[3]);
+    }
+}
+
+// the susceptible compartments' drift of (population, tile) from the integer sums, where vgx_tau_drift8_kernel's blocks leave theirs.
+// grid = (P, R), block = 64.
+extern "C" __global__ void __launch_bounds__(64) vgx_tau_drift8s_sus_kernel(VgxTauArgs a) {
+    const VgxDevParams &p = a.p;
+    const int P = p.P, S = p.S, pn = blockIdx.x, rep = blockIdx.y, nt = a.nt8;
+    if (!a.active[rep]) return;
+    const double *s_T = a.d8s_tile + (int64_t)rep * 2 * nt, *s_TW = s_T + nt;     // per tile: hosts of all populations, and weighted
+    const double *pk = a.d8s_pk + ((int64_t)rep * P + pn) * 8;
+    const double Bsum = pk[0], c1 = pk[1], c2 = pk[2], F = pk[4], kmig = pk[6];
+    const bool use_tw = pk[7] != 0.0;
+    (void)Bsum;
+    const int64_t *Sus = a.S + (int64_t)rep * P * S + (int64_t)pn * S;
+    const double cd0 = p.c_d[0], cs0 = p.c_s[0] * p.sampMult[pn];
+    const int st0 = p.c_stype[0];
+    for (int i = threadIdx.x; i < nt * S; i += 64) {
+        const int t = i / S, sn = i % S;
+        const double tI = (double)a.tI_pt[((int64_t)rep * P + pn) * nt + t];
+        const double tM = use_tw ? __builtin_fma(c2, s_TW[t], c1 * s_T[t]) : c1 * s_T[t];
+        const double mgsum = tM - kmig * tI;
+        const double base = p.cb_b[0] * p.cb_sigma[sn] * (double)Sus[sn];
+        double v = -base * (F * tI + mgsum);
+        if (sn == st0) v += (cd0 + cs0) * tI;
+        a.dS_part[(((int64_t)rep * P + pn) * a.ds_nb + t) * S + sn] = v;
+    }
 }
 
 // Susceptible compartments: immunity-transition drift (pyx:2374-2381), tau candidates (pyx:2445-2450),
@@ -3288,6 +3698,7 @@ extern "C" __global__ void __launch_bounds__(64) vgx_tau_finish_kernel(VgxTauArg
         o[12] = a.error[rep];
         o[13] = (a.occ_pop && a.use8) ? occ_sum : -1;   // occupied compartments at the start of this step (drift pass on the bytes), else -1
         o[14] = a.retry[rep];                            // rejected tries of this step
+        o[15] = (a.drift_sparse && a.d8s_bc) ? (int64_t)a.d8s_bc[(int64_t)rep * 8 + 3] : -1;   // compartments whose empty neighbours the sparse drift pass formed
         if (a.host_res)
             for (int i = 0; i < 15; ++i) a.host_res[(int64_t)rep * 16 + i] = o[i];   // the host's (pinned) copy
         a.mev_base[rep] = a.mev_n[rep];          // rows of the accepted step stay (pyx:2325)
@@ -3325,10 +3736,30 @@ extern "C" __attribute__((visibility("hidden"))) hipError_t vgxi_tau_conv8(const
 TAU_LAUNCH(tau_sync8, dim3((unsigned)a->inc_shards, (unsigned)a->R, (unsigned)(VGX_INC_SHARDS / a->inc_shards)), dim3(64))
 extern "C" __attribute__((visibility("hidden"))) hipError_t vgxi_tau_drift(const VgxTauArgs *a, hipStream_t s) {
     if (a->use8) {
+        if (a->drift_sparse) {     // (the host: lists wanted, uniform migration — the column sums' pass writes the lists)
+            hipError_t err = hipMemsetAsync(a->d8s_bc, 0, (size_t)a->R * 64, s);
+            if (err != hipSuccess) return err;
+        }
         if (a->has_mig) {     // (uniform: the condition of use8)
             hipLaunchKernelGGL(vgx_tau_colsum8_kernel, dim3((unsigned)((a->p.H + 4 * TB - 1) / (4 * TB)), (unsigned)a->R), dim3(TB), 0, s, *a);
             hipError_t err = hipGetLastError();
             if (err != hipSuccess) return err;
+        }
+        if (a->drift_sparse) {
+            hipError_t err;
+            const dim3 greg((unsigned)(8 * ((a->p.P + 7) / 8) * ((a->occ_nreg + 3) / 4)), (unsigned)a->R);
+            hipLaunchKernelGGL(vgx_tau_drift8s_prep_kernel, dim3((unsigned)a->p.P, (unsigned)a->R), dim3(D8_TB), 0, s, *a);
+            const int low = a->p.sites < VGX_D8_LOW ? a->p.sites : VGX_D8_LOW;
+            const size_t lds = (size_t)1 << (2 * low);
+            err = hipFuncSetAttribute((const void *)vgx_tau_drift8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (err != hipSuccess) return err;
+            hipLaunchKernelGGL(vgx_tau_drift8_kernel, dim3((unsigned)(8 * ((a->p.P + 7) / 8) * a->nt8), (unsigned)a->R), dim3(D8_TB), lds, s, *a);
+            hipLaunchKernelGGL(vgx_tau_drift8s_heavy_kernel, greg, dim3(256), 0, s, *a);
+            hipLaunchKernelGGL((vgx_tau_drift8s_ovf_kernel<true>), dim3(VGX_D8S_OVF_BLOCKS, (unsigned)a->R), dim3(256), 0, s, *a);
+            hipLaunchKernelGGL(vgx_tau_drift8s_col_kernel, dim3((unsigned)((a->p.H + 255) / 256), (unsigned)a->R), dim3(256), 0, s, *a);
+            hipLaunchKernelGGL(vgx_tau_drift8s_tiles_kernel, dim3((unsigned)a->nt8, (unsigned)a->R), dim3(256), 0, s, *a);
+            hipLaunchKernelGGL(vgx_tau_drift8s_sus_kernel, dim3((unsigned)a->p.P, (unsigned)a->R), dim3(64), 0, s, *a);
+            return hipGetLastError();
         }
         const int low = a->p.sites < VGX_D8_LOW ? a->p.sites : VGX_D8_LOW;
         const size_t lds = (size_t)1 << (2 * low);
