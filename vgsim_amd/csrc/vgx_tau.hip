@@ -1177,7 +1177,7 @@ extern "C" __global__ void __launch_bounds__(D8_TB, 4) vgx_tau_drift8_kernel(Vgx
     const double F = a.F[(int64_t)rep * P + pn];
     const bool use_col = a.has_mig && a.mig_uniform;
     MigU mu = {0.0, 0.0, 0.0, true};
-    if (use_col) mu = tau_migu_setup(a, rep, pn, s_wu);
+    if (use_col && !a.drift_sparse) mu = tau_migu_setup(a, rep, pn, s_wu);     // (sparse: from vgx_tau_drift8s_prep_kernel's record, below)
     double Bsum = 0.0;
     for (int sn = 0; sn < S; ++sn) Bsum += l_base[sn];
     const double cd0 = p.c_d[0], cs0 = p.c_s[0] * p.sampMult[pn], ctm0 = p.c_tm[0];
@@ -1196,6 +1196,10 @@ extern "C" __global__ void __launch_bounds__(D8_TB, 4) vgx_tau_drift8_kernel(Vgx
     double kmig;                                       // mg = (c1 T + c2 TW) - kmig Ih
     c.Bsum = Bsum;
     d8_coeffs(mu, c.use_tw, Bsum, F, cd0 + cs0 + ctm0, c.c1, c.c2, kmig, c.kI);
+    if (a.drift_sparse) {     // the same values, formed once per population by vgx_tau_drift8s_prep_kernel
+        const double *pk = a.d8s_pk + ((int64_t)rep * P + pn) * 8;
+        c.c1 = pk[1]; c.c2 = pk[2]; c.kI = pk[3]; kmig = pk[6]; c.use_tw = pk[7] != 0.0;
+    }
     c.hist = hist;
     c.kI_a = fabsf((float)c.kI) * (1.0f + 4e-6f); c.rlo_a = fabsf((float)c.rate_lo) * (1.0f + 4e-6f); c.rhi_a = fabsf((float)c.rate_hi) * (1.0f + 4e-6f);
     c.B_a = fabsf((float)c.Bsum) * (1.0f + 4e-6f);
@@ -1279,20 +1283,22 @@ extern "C" __global__ void __launch_bounds__(D8_TB, 4) vgx_tau_drift8_kernel(Vgx
         }
 }
 
-// ---- the drift pass over the lists of occupied compartments (sparse states: VgxTauArgs.drift_sparse) ---------------------------------
+// ---- the drift pass on sparse states (VgxTauArgs.drift_sparse) -----------------------------------------------------------------------
 // At natural occupancy (0.65 % of config 4's compartments after SURVEY 8(d)'s warm-up) vgx_tau_drift8_kernel spends its time finding
-// out that a turn's compartments are empty.  ChooseTau's minimum (pyx:2432-2450) needs
-//   (1) every OCCUPIED compartment's candidate — the lists (written here by vgx_tau_colsum8_kernel, which streams the bytes once for the
-//       column sums anyway) with the neighbours' bytes read where they lie;
+// out that compartments are empty.  ChooseTau's minimum (pyx:2432-2450) needs
+//   (1) every OCCUPIED compartment's candidate: vgx_tau_drift8_kernel still stages each tile's bytes, but gathers the dwords that hold a
+//       host (d8_scan) and forms the drifts of those only (their neighbours inside the tile from LDS as before);
 //   (2) of the EMPTY compartments, whose candidate is 1 / (their arrivals' rate), only those that can undercut the smallest candidate m
 //       of (1): an empty compartment's drift is rate * (its neighbours' hosts) + Bsum (c1 T + c2 TW) <= 3 sites rate max-neighbour +
 //       coefficient * column sum, so one whose neighbours all hold fewer than 0.49 / (m rate 3 sites) hosts and whose column's term is
-//       below 0.49 / m cannot: the neighbours of the larger compartments (vgx_tau_drift8s_heavy_kernel) and the columns with the larger
+//       below 0.49 / m cannot: the empty neighbours of the larger compartments (vgx_tau_drift8s_heavy_kernel over the lists,
+//       vgx_tau_drift8s_ovf_kernel for the regions whose lists are incomplete) and the empty compartments of the columns with the larger
 //       sums (vgx_tau_drift8s_col_kernel) are formed exactly, the rest is provably above m.
-// Every drift that is formed is formed as vgx_tau_drift8_kernel forms it (same coefficients: d8_coeffs, same fused operations), so the
-// minimum is the same bit pattern; the susceptible compartments' drift (a sum over ALL compartments of a tile in the dense form) comes
-// from exact integer sums per (population, tile) and differs from the dense form's by rounding only
-// (tests/test_hip_tau.py::test_drift_over_the_lists_equals_the_dense_pass).
+// Every drift that is formed is formed as the dense pass forms it (same coefficients: d8_coeffs, same fused operations), so the minimum
+// is the same bit pattern; the susceptible compartments' drift (in the dense form a sum over ALL compartments of a tile) comes from exact
+// integer sums per (population, tile) and differs from the dense form's by rounding only
+// (tests/test_hip_tau.py::test_drift_over_the_lists_equals_the_dense_pass).  Where the empty neighbours of too many compartments have
+// to be formed (a high mutation rate) the host goes back to the dense pass (vgx_api.hip: sparse_ban).
 struct D8S {
     const uint8_t *I8row;
     const int32_t *Irow;
@@ -1372,9 +1378,6 @@ static __device__ __forceinline__ void d8s_commit(const VgxTauArgs &a, int rep, 
     if ((threadIdx.x & 63) == 0 && cand_min < __longlong_as_double((long long)*(volatile unsigned long long *)&a.tau_bits[rep]))
         atomic_min_pos_double(&a.tau_bits[rep], cand_min);
 }
-// A region whose list is complete: one wavefront, a compartment per lane and turn.  A region with more occupied compartments than its
-// list holds (the neighbourhood of a large lineage: four fifths of its 8192 compartments occupied at SURVEY 8(d)'s start state, in 16 of
-// 4096 tiles) is put on the launch's list of such regions instead and taken 256 compartments at a time by vgx_tau_drift8s_ovf_kernel.
 // what an empty compartment's arrivals must reach to matter: 1 / (the smallest candidate so far)
 static __device__ __forceinline__ double d8s_need(const VgxTauArgs &a, int rep) { return 1.0 / __longlong_as_double((long long)a.tau_bits[rep]); }
 
@@ -1416,12 +1419,11 @@ extern "C" __global__ void __launch_bounds__(D8_TB) vgx_tau_drift8s_prep_kernel(
     }
 }
 
-// (1b) the regions on the list of that launch: a unit = the 256 compartments one wavefront of vgx_tau_drift8_kernel takes in a turn; four
-// units (of one region) per block and turn of the grid-stride loop.  HEAVY: pass (2a) for these regions instead.
+// (2a') the same for the regions whose lists are incomplete (vgx_tau_drift8_kernel puts them on the launch's list of such regions): a unit
+// = the 256 compartments one wavefront of that kernel takes in a turn, four units of one region per block and turn of the grid-stride loop.
 // grid = (VGX_D8S_OVF_BLOCKS, R), block = 256.
 #define VGX_D8S_OVF_BLOCKS 2048
-template <bool HEAVY>
-__global__ void __launch_bounds__(256) vgx_tau_drift8s_ovf_kernel(VgxTauArgs a) {
+extern "C" __global__ void __launch_bounds__(256) vgx_tau_drift8s_ovf_kernel(VgxTauArgs a) {
     const VgxDevParams &p = a.p;
     const int P = p.P, rep = blockIdx.y;
     if (!a.active[rep]) return;
@@ -1429,69 +1431,35 @@ __global__ void __launch_bounds__(256) vgx_tau_drift8s_ovf_kernel(VgxTauArgs a) 
     const int novf = (int)a.d8s_bc[(int64_t)rep * 8 + 4];
     if (novf == 0) return;
     const int low = p.sites < VGX_D8_LOW ? p.sites : VGX_D8_LOW, TSd = 1 << (2 * low - 2), turns = TSd / D8_TB;   // (a multiple of four from seven sites on)
-    __shared__ unsigned int hist[VGX_HIST_X];
-    const bool do_hist = !HEAVY && a.hist != nullptr;
-    double need = 0.0;
-    if (HEAVY) need = d8s_need(a, rep);
+    const double need = d8s_need(a, rep);
     for (int g = blockIdx.x; g < novf * (turns / 4); g += gridDim.x) {
         const int ridx = a.d8s_ovf[(int64_t)rep * P * a.occ_nreg + g / (turns / 4)];
         const int pn = ridx / a.occ_nreg, reg = ridx % a.occ_nreg, k = (g % (turns / 4)) * 4 + w;
         const int64_t region = ((int64_t)rep * P + pn) * a.occ_nreg + reg;
         D8S c;
         d8s_ctx(a, rep, pn, c);
+        const double rate = fmax(fabs(c.rate_lo), fabs(c.rate_hi));
+        const double xpush = 0.49 * need / (rate * 3.0 * (double)p.sites);
+        if (!(rate > 0.0) || !((double)a.d8s_regmax[region] >= xpush)) continue;
         const int tl = reg / VGX_D8_WAVES, wv = reg % VGX_D8_WAVES;
         const int h0 = (tl << (2 * low)) + 4 * (wv * 64 + lane + D8_TB * k);
         const uint32_t own = *(const uint32_t *)(c.I8row + h0);
         double cand_min = 1.0, ad_max = 0.0;
-        if (HEAVY) {
-            const double rate = fmax(fabs(c.rate_lo), fabs(c.rate_hi));
-            const double xpush = 0.49 * need / (rate * 3.0 * (double)p.sites);
-            if (!(rate > 0.0) || !((double)a.d8s_regmax[region] >= xpush)) continue;      // (block-uniform: one region per turn of the loop)
-            int nheavy = 0;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if (((own >> (8 * j)) & 255u) == 0u) continue;
-                const int h = h0 + j;
-                if (!((double)d8s_count(c, h) >= xpush)) continue;
-                nheavy += 1;
-                for (int q = 0; q < 3 * p.sites; ++q) {
-                    const int nb = h ^ ((q % 3 + 1) << (2 * (q / 3)));
-                    if (c.I8row[nb] == 0) d8s_candidate(0, d8s_drift(c, nb, 0), cand_min, ad_max);
-                }
-            }
-            d8s_commit(a, rep, cand_min, ad_max);
-            for (int o = 32; o > 0; o >>= 1) nheavy += __shfl_down(nheavy, o);
-            if (lane == 0 && nheavy != 0) atomicAdd(&a.d8s_bc[(int64_t)rep * 8 + 3], (unsigned long long)nheavy);
-            continue;
-        }
-        if (do_hist) {
-            for (int i = threadIdx.x; i < VGX_HIST_X; i += 256) hist[i] = 0;
-            __syncthreads();
-        }
-        long long sumI = 0;
-        int nocc = 0, imax = 0;
+        int nheavy = 0;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             if (((own >> (8 * j)) & 255u) == 0u) continue;
             const int h = h0 + j;
-            const int Icell = d8s_count(c, h);
-            nocc += 1;
-            sumI += Icell;
-            imax = max(imax, Icell);
-            if (do_hist && Icell <= VGX_HIST_X) atomicAdd(&hist[Icell - 1], 1u);
-            d8s_candidate(Icell, d8s_drift(c, h, Icell), cand_min, ad_max);
+            if (!((double)d8s_count(c, h) >= xpush)) continue;
+            nheavy += 1;
+            for (int q = 0; q < 3 * p.sites; ++q) {
+                const int nb = h ^ ((q % 3 + 1) << (2 * (q / 3)));
+                if (c.I8row[nb] == 0) d8s_candidate(0, d8s_drift(c, nb, 0), cand_min, ad_max);
+            }
         }
         d8s_commit(a, rep, cand_min, ad_max);
-        for (int o = 32; o > 0; o >>= 1) { sumI += __shfl_down(sumI, o); nocc += __shfl_down(nocc, o); imax = max(imax, __shfl_down(imax, o)); }
-        if (lane == 0 && imax != 0) atomicMax(&a.d8s_regmax[region], imax);
-        if (lane == 0 && sumI != 0) atomicAdd(&a.tI_pt[((int64_t)rep * P + pn) * a.nt8 + tl], (unsigned long long)sumI);
-        if (lane == 0 && nocc != 0) atomicAdd(&a.occ_pop[(int64_t)rep * P + pn], (unsigned long long)nocc);
-        if (do_hist) {
-            __syncthreads();
-            for (int i = threadIdx.x; i < VGX_HIST_X; i += 256)
-                if (hist[i]) atomicAdd(&a.hist[((int64_t)rep * P + pn) * VGX_HIST_X + i], hist[i]);
-            __syncthreads();
-        }
+        for (int o = 32; o > 0; o >>= 1) nheavy += __shfl_down(nheavy, o);
+        if (lane == 0 && nheavy != 0) atomicAdd(&a.d8s_bc[(int64_t)rep * 8 + 3], (unsigned long long)nheavy);
     }
 }
 
@@ -3755,7 +3723,7 @@ extern "C" __attribute__((visibility("hidden"))) hipError_t vgxi_tau_drift(const
             if (err != hipSuccess) return err;
             hipLaunchKernelGGL(vgx_tau_drift8_kernel, dim3((unsigned)(8 * ((a->p.P + 7) / 8) * a->nt8), (unsigned)a->R), dim3(D8_TB), lds, s, *a);
             hipLaunchKernelGGL(vgx_tau_drift8s_heavy_kernel, greg, dim3(256), 0, s, *a);
-            hipLaunchKernelGGL((vgx_tau_drift8s_ovf_kernel<true>), dim3(VGX_D8S_OVF_BLOCKS, (unsigned)a->R), dim3(256), 0, s, *a);
+            hipLaunchKernelGGL(vgx_tau_drift8s_ovf_kernel, dim3(VGX_D8S_OVF_BLOCKS, (unsigned)a->R), dim3(256), 0, s, *a);
             hipLaunchKernelGGL(vgx_tau_drift8s_col_kernel, dim3((unsigned)((a->p.H + 255) / 256), (unsigned)a->R), dim3(256), 0, s, *a);
             hipLaunchKernelGGL(vgx_tau_drift8s_tiles_kernel, dim3((unsigned)a->nt8, (unsigned)a->R), dim3(256), 0, s, *a);
             hipLaunchKernelGGL(vgx_tau_drift8s_sus_kernel, dim3((unsigned)a->p.P, (unsigned)a->R), dim3(64), 0, s, *a);
