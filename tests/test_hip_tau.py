@@ -790,6 +790,30 @@ def test_drift_over_the_lists_equals_the_dense_pass(monkeypatch, sites, P, S, fi
     assert a.bCounter > 0
 
 
+@pytest.mark.parametrize("sites,P,S,fill,uneven", [(8, 3, 1, _fill_heavy, False), (8, 2, 2, _fill_sparse, False), (9, 3, 1, _fill_heavy, True)])
+def test_sparse_drift_leap_length_matches_oracle(oracle_mod, sites, P, S, fill, uneven):
+    """The leap ChooseTau (pyx:2432-2450) gives a SPARSE state, formed by the drift pass that takes only the occupied dwords and the empty
+    compartments that can matter (vgx_tau_drift8s_*; from a call's second step on: the first one counts the occupied compartments),
+    against the oracle's on the same state: leap * 2^(rejected tries) to 1e-9.  `_fill_heavy`: the minimum is an empty compartment's."""
+    def start():
+        return _filled(sites, P, S, 1500 + sites, fill, True, uneven=uneven)
+    # (a call of n iterations makes 2 n steps: upstream's two CreateEvents calls, pyx:2298 / 2306)
+    one, two = start(), start()
+    with helpers.quiet():
+        one.simulate(1, sample_size=10 ** 12, method="tau", record_multievents=False)     # steps 1, 2
+        two.simulate(2, sample_size=10 ** 12, method="tau", record_multievents=False)     # the same two, then steps 3, 4
+    m1, m2 = one.simulation, two.simulation
+    assert m1.events.ptr == 2 and m2.events.ptr == 4 and np.array_equal(m1.events.times[:2], m2.events.times[:2])
+    dt_hip = float(m2.events.times[2] - m2.events.times[1])                               # step 3: chosen for the state after step 2
+    tries_hip = int(m2._engine.tau_tries(0, 2, 1)[0])
+    # the oracle's next step from that state
+    assert oracle_mod.run_tau(m1, 1, 10 ** 12, -1, 200) == 0
+    dt_ref = float(m1.events.times[2] - m1.events.times[1])
+    tries_ref = oracle_mod.tau_tries(0)
+    assert dt_hip > 0 and dt_ref > 0 and tries_ref >= 0
+    assert dt_hip * 2.0 ** tries_hip == pytest.approx(dt_ref * 2.0 ** tries_ref, rel=1e-9), (dt_hip, tries_hip, dt_ref, tries_ref)
+
+
 def test_lists_and_front_pass_with_several_replicates(monkeypatch):
     """Three replicates of a sparse 8-site model on the step kernels (their tries end at different places: no front pass alone,
     one list of occupied compartments per replicate): the runs with the lists and the front pass equal those without."""
