@@ -1155,6 +1155,17 @@ extern "C" __global__ void __launch_bounds__(D8_TB, 4) vgx_tau_drift8_kernel(Vgx
     __shared__ uint16_t s_queue[VGX_D8_QCAP];
     __shared__ int s_nq;
     const bool do_hist = a.hist != nullptr;
+    if (a.drift_sparse && a.tmax8[((int64_t)rep * P + pn) * nt + tl] == 0u) {
+        // sparse states: a tile that has held nobody since the bytes were last converted (the early epidemic: most of them) — nothing to
+        // list, no drift to form, no byte to load
+        if (threadIdx.x < VGX_D8_WAVES) {
+            const int64_t region = ((int64_t)rep * P + pn) * a.occ_nreg + (int64_t)tl * VGX_D8_WAVES + threadIdx.x;
+            if (a.build_occ) a.occ_n[region] = 0u;
+            a.d8s_regmax[region] = 0;
+        }
+        if (threadIdx.x == 0) a.tI_pt[((int64_t)rep * P + pn) * nt + tl] = 0ull;
+        return;
+    }
     if (threadIdx.x == 0) {
         s_nq = 0;
         smin = (unsigned long long)__double_as_longlong(1.0);
