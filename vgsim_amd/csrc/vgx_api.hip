@@ -1993,7 +1993,7 @@ extern "C" int vgx_simulate_tau(vgx_engine *e, int64_t iterations, int64_t sampl
         // (unless the last such pass had to form the empty neighbours of too many compartments — a high mutation rate, or a smallest
         // candidate far above what the lineages' mutants bring: the dense pass for a while, then another look)
         if (sparse_ban > 0) sparse_ban -= 1;
-        a.drift_sparse = (a.build_occ && a.has_mig && a.mig_uniform && !dense_drift && sparse_ban == 0) ? 1 : 0;
+        a.drift_sparse = (a.build_occ && a.has_mig && a.mig_uniform && !dense_drift && sparse_ban == 0 && e->d.sites <= 12) ? 1 : 0;   // (12: VGX_D8S_MAX_SITES)
         HIPCHECK(e, vgxi_tau_eff(&a, e->stream));
         HIPCHECK(e, vgxi_tau_prep(&a, e->stream));
         HIPCHECK(e, vgxi_tau_drift(&a, e->stream));
