@@ -397,12 +397,14 @@ def single_leg(device):
     with contextlib.redirect_stdout(io.StringIO()):
         c2 = Simulator(number_of_sites=0, populations_number=1, number_of_susceptible_groups=1, seed=2020)
     c2.set_transmission_rate(4.0); c2.set_recovery_rate(1.5); c2.set_sampling_rate(0.3)
-    for name, sim, n in (("config3", make_simulator(2020), 100000), ("config2", c2, 200000)):
+    out["kernel"] = {}
+    for name, sim, n in (("config3", make_simulator(2020), 100000), ("config2", c2, 200000), ("config3_general", make_general_c3(), 50000)):
         ens = Ensemble(sim, 1, device=device)
         res = None
         for it in range(2):
             res = ens.simulate(n, sample_size=10 ** 12, record_events=True, seeds=np.array([2020 + it], dtype=np.int64))
         out[name] = res.total_events / (res.kernel_ms * 1e-3)
+        out["kernel"][name] = ens.engine.last_kernel
         ens.close()
     return out
 
@@ -1126,6 +1128,7 @@ def main():
             "config5_events_per_s": pick(line, "config5", "value"), "fast_mode_events_per_s": pick(line, "fast_mode", "value"),
             "single_trajectory_config2": pick(line, "single_trajectory", "config2"),
             "single_trajectory_config3": pick(line, "single_trajectory", "config3"),
+            "single_trajectory_config3_general": pick(line, "single_trajectory", "config3_general"),
             "table3_K2_single_events_per_s": pick(line, "table3", "cells", "K=2,M=0.001", "single_trajectory", "events_per_s"),
             "table3_K2_single_vs_published": pick(line, "table3", "cells", "K=2,M=0.001", "single_trajectory", "vs_baseline"),
             "table3_K2_single_wall_vs_published": pick(line, "table3", "cells", "K=2,M=0.001", "single_trajectory", "wall", "vs_baseline"),
