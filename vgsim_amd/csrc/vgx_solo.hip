@@ -282,9 +282,15 @@ struct Solo {
             const int ja = uni_i32(__builtin_amdgcn_readlane(mig ? passA1 : passA0, k)), jb = uni_i32(__builtin_amdgcn_readlane(mig ? passB1 : passB0, k));
             double TA[NPR], TB[NPR], ca, cb, oa, ob;
             pass_terms(ja, xseg, segv, TA, ca);
-            pass_terms(jb, xseg, segv, TB, cb);
-            flat_two_sums(TA[0], TB[0], rows0, ca, cb, oa, ob);
-            if (NPR > 1 && P > 64) flat_two_sums(TA[NPR - 1], TB[NPR - 1], rows1, bcast(oa, 63), bcast(ob, 63), oa, ob);
+            if (jb == -1) {         // (a chain without a partner: alone — a lone wavefront pays per instruction, an idle second chain is not free)
+                oa = flat_chain<false>(TA[0], min(P, 64), ca, M);
+                if (NPR > 1 && P > 64) oa = flat_chain<false>(TA[NPR - 1], P - 64, bcast(oa, 63), M);
+                ob = 0.0;
+            } else {
+                pass_terms(jb, xseg, segv, TB, cb);
+                flat_two_sums(TA[0], TB[0], rows0, ca, cb, oa, ob);
+                if (NPR > 1 && P > 64) flat_two_sums(TA[NPR - 1], TB[NPR - 1], rows1, bcast(oa, 63), bcast(ob, 63), oa, ob);
+            }
             const double ta = bcast(oa, last), tb = bcast(ob, last);
             if (ja >= 0) segv = lane == ja ? ta : segv; else if (ja == -2) totalMig = ta;
             if (jb >= 0) segv = lane == jb ? tb : segv; else if (jb == -2) totalMig = tb;
