@@ -214,10 +214,16 @@ class HipEngine:
             setattr(s, c, int(getattr(m, c)))
         s.currentTime, s.totalRate, s.totalMigrationRate, s.tau_l = m.currentTime, m.totalRate, m.totalMigrationRate, m.tau_l
         s.ev_ptr, s.ev_size = m.events.ptr, m.events.size
+        self._first_call = bool(m.first_simulation)     # (the call after this snapshots the initial state: get_state reads it back then only)
         self._check(self.lib.vgx_set_state(self.handle, C.byref(s)))
 
     def get_state(self, m, replicate=0):
         s = self._state_struct(m)
+        if not getattr(self, "_first_call", True):
+            # the initial state is written by the first simulation's snapshot alone (pyx:419-424): at config 4's size copying it back
+            # after every call is 2 GB of memcpy for nothing
+            s.initial_susceptible = None
+            s.initial_infectious = None
         self._check(self.lib.vgx_get_state(self.handle, replicate, C.byref(s)))
         m.first_simulation = bool(s.first_simulation)
         m.globalInfectious = s.globalInfectious

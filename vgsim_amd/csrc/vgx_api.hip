@@ -1408,7 +1408,10 @@ extern "C" int vgx_simulate_tau(vgx_engine *e, int64_t iterations, int64_t sampl
     lap("count of occupied");
     bool rates_nonzero = false;
     int rc = 0;
-    if (occupied <= ((int64_t)1 << 18)) {
+    // (the device's UpdateAllRates for the start state — exact totalRate, lockdown switches — where building the direct kernels' occupancy
+    // lists from the dense host arrays is cheap: at config 4's size that scan of 2.7e8 compartments is 0.3 s per call, and the host form
+    // below — what a densely occupied state takes anyway — stands in)
+    if (occupied <= ((int64_t)1 << 18) && P * H <= ((int64_t)1 << 24)) {
         vgx_run_opts po{};
         po.record_events = 0;
         rc = direct_core(e, 0, -1, -1.0f, 0, &po);
