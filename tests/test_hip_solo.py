@@ -45,6 +45,44 @@ def test_solo_kernel_matches_the_goldens(name):
     helpers.check_against_golden(hip, name, exact_time=helpers.libm_matches_fixture_host(), rtol_time=1e-12, leftovers=False)
 
 
+def _program_model(P, S, migration, seed, per_hap):
+    """sites = 2 (16 haplotypes), P > 16 populations: BirthRate runs as the program of chain segments over the population lanes."""
+    from vgsim_amd import Simulator
+    with helpers.quiet():
+        s = Simulator(number_of_sites=2, populations_number=P, number_of_susceptible_groups=S, seed=seed)
+    s.set_transmission_rate(2.6); s.set_recovery_rate(0.8); s.set_sampling_rate(0.1); s.set_mutation_rate(0.05)
+    s.set_transmission_rate(3.4, haplotype="GG")
+    s.set_population_size(40000)
+    for g in range(1, S):
+        s.set_susceptibility(0.25 * g, susceptibility_type=g)
+        s.set_immunity_transition(0.01, source=g, target=0)
+    if S > 1:
+        s.set_susceptibility_type(1)
+    for h, g, v in per_hap:
+        s.set_susceptibility(v, susceptibility_type=g, haplotype=h)
+    if migration:
+        s.set_total_migration_probability(migration)
+    return s
+
+
+@pytest.mark.parametrize("P,S,migration,per_hap", [
+    (20, 2, 0.0, []),                                   # two segments in a row, no migration: every pass a chain alone
+    (20, 2, 0.05, []),                                  # the migration rates' sum beside the first segment, the second alone
+    (33, 3, 0.02, [("C*", 1, 0.6), ("G*", 2, 0.9)]),    # a tree of segments: siblings share a pass
+    (70, 3, 0.03, [("A*", 1, 0.0), ("T*", 2, 0.7)]),    # two registers of population lanes; a class without its group-1 segment
+    (100, 1, 0.01, []),                                 # one segment
+    (17, 4, 0.0, [("AC", 3, 1.0), ("GT", 2, 0.0)])])
+def test_birthrate_program_shapes_bit_exact_vs_oracle(oracle_mod, P, S, migration, per_hap):
+    """vgx_solo's BirthRate beyond 16 populations: the host's schedule of passes (two independent chains per pass, a chain alone where it
+    has no partner, the migration rates' sum riding along) on segment trees of several shapes, one trajectory against the oracle."""
+    hip, ref = _program_model(P, S, migration, 77 + P, per_hap), _program_model(P, S, migration, 77 + P, per_hap)
+    assert oracle_mod.run_direct(ref.simulation, 6000, 10 ** 9, -1, 200) == 0
+    with helpers.quiet():
+        hip.simulate(6000, sample_size=10 ** 9, kernel="solo")
+    assert hip.simulation._engine.last_kernel == "solo"
+    helpers.assert_models_equal(hip.simulation, ref.simulation, "program P=%d S=%d" % (P, S))
+
+
 def test_single_runs_take_the_solo_kernel_automatically():
     sim = helpers.run_case_hip("g9_short")
     assert sim.simulation._engine.last_kernel == "solo"
