@@ -353,6 +353,12 @@ def table3_leg(device, cpu=True, replicates=16384, events=50000, single_events=3
                                 "iterations_per_s": its / (res.kernel_ms * 1e-3), "kernel_ms_per_launch": res.kernel_ms,
                                 "rejected_migration_share": 1.0 - res.total_events / max(its, 1.0),
                                 "vs_baseline": (its / (res.kernel_ms * 1e-3)) / (1e8 / TABLE3_PUBLISHED_S[(M, K)])}
+            # the counter-based stream (mode='fast_philox', north_star's "Philox-style counter-based RNG"): the same kernels' exact arithmetic
+            # on that stream (every replicate = the oracle fed with it: tests/test_hip_quadg.py::test_counter_based_stream_on_the_general_row_kernel)
+            for it in range(2):
+                res = ens.simulate(events, sample_size=10 ** 12, record_events=True, mode="fast_philox",
+                                   seeds=2023 + it * R + np.arange(R, dtype=np.int64))
+            cell["ensemble_philox"] = {"replicates": R, "events_per_s": res.total_events / (res.kernel_ms * 1e-3), "kernel": ens.engine.last_kernel}
             ens.close()
             if cpu:
                 cell["cpu_baseline"] = table3_cpu(K, M)
@@ -1137,6 +1143,8 @@ def main():
             "table3_K2_ensemble_events_per_s": pick(line, "table3", "cells", "K=2,M=0.001", "ensemble", "events_per_s"),
             "table3_K10_ensemble_events_per_s": pick(line, "table3", "cells", "K=10,M=0.001", "ensemble", "events_per_s"),
             "table3_K100_ensemble_events_per_s": pick(line, "table3", "cells", "K=100,M=0.001", "ensemble", "events_per_s"),
+            "table3_K10_ensemble_philox_events_per_s": pick(line, "table3", "cells", "K=10,M=0.001", "ensemble_philox", "events_per_s"),
+            "table3_K100_ensemble_philox_events_per_s": pick(line, "table3", "cells", "K=100,M=0.001", "ensemble_philox", "events_per_s"),
             "spread_occupancy_events_per_s": pick(line, "spread_occupancy", "value"),
             "config3_general_events_per_s": pick(line, "config3_general", "value"),
             "propensity_scan_roofline_frac": pick(line, "propensity_scan", "roofline", "frac"),

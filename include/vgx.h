@@ -113,8 +113,11 @@ typedef struct vgx_run_opts {
                                 latency kernel of single trajectories; EXACT, hapNum <= 64, popNum <= 128, susNum <= 16).
                                 Automatic: 5 for fewer than 2048 replicates of a model it takes (and for more where it beats 3 / 4:
                                 small models with several classes, one-class models below 8192 replicates);
-                                mode 1 on a model the FAST row kernel does not take runs the exact kernels 3 / 4 / 5 (their output
-                                is what FAST promises); 2 for P*H*S <= 4 from 131072 replicates, or when asked for */
+                                6 = one replicate per wavefront with the occupancy LISTS in LDS (vgx_lone.hip: single trajectories of
+                                large haplotype spaces; EXACT, popNum <= 64; automatic up to 1536 replicates of models 5 does not take);
+                                mode 1 on a model the FAST row kernel does not take runs the exact kernels 3 / 4 / 5 / 6 (their output
+                                is what FAST promises), mode 2 likewise with those kernels' exact arithmetic on the counter-based
+                                stream (4, 5 and 6 take it); 2 for P*H*S <= 4 from 131072 replicates, or when asked for */
     int64_t reserved[2];     /* [0] tau path: 1 = run every try of the halving loop (pyx:2316-2321) instead of starting at the
                                 first try that is not certain to be rejected (same accepted steps either way);
                                 [1] tau path, how a try's deltas are kept and checked (same draws and decisions in every mode):

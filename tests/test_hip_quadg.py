@@ -112,6 +112,40 @@ def test_general_row_kernel_replicates_equal_single_runs(oracle_mod, name, n_eve
     ens.close()
 
 
+@pytest.mark.parametrize("name,n_events", [("g9_short", 4000), ("stress_h256", 2500), ("p70", 2000), ("lockdown_restart", 1500)])
+def test_counter_based_stream_on_the_general_row_kernel(oracle_mod, name, n_events):
+    """``mode='fast_philox'`` on a general model: the general row kernel's (or, for small models, the latency kernel's) exact arithmetic on the Philox stream (iteration i of an attempt
+    takes outputs 2 i and 2 i + 1 of the stream of (seed, attempt)) — every replicate equals the ORACLE fed with the same stream, integer
+    rows, counters and compartments bit for bit, times to 1e-9 (the device clock).  2048 replicates: the automatic choice."""
+    from vgsim_amd import Simulator
+    from vgsim_amd.ensemble import Ensemble
+    R = 2048
+    ctor, phases = models.CASES[name] if name in models.CASES else models.ORACLE_ONLY_CASES[name]
+    with helpers.quiet():
+        sim = Simulator(**ctor)
+    phases[0][0](sim)
+    seeds = 5000 + np.arange(R, dtype=np.int64)
+    ens = Ensemble(sim, R, seeds=seeds)
+    res = ens.simulate(n_events, sample_size=10 ** 9, record_events=True, mode="fast_philox")
+    assert ens.engine.last_kernel in ("quadg", "solo")      # (small models in the compact layout: two wavefronts per SIMD of the latency kernel)
+    for r in (0, 1, 777, R - 1):
+        with helpers.quiet():
+            one = Simulator(**dict(ctor, seed=int(seeds[r])))
+        phases[0][0](one)
+        m = one.simulation
+        assert oracle_mod.run_direct(m, n_events, 10 ** 9, -1, 200, log_mode=oracle_mod.RNG_PHILOX) == 0
+        assert res.events[r] == m.events.ptr, "replicate %d" % r
+        chain, want = ens.replicate_events(r), m.events.as_array()[:, :m.events.ptr]
+        assert np.array_equal(chain[1:], want[1:]), "replicate %d: %s" % (r, helpers.describe_first_diff(chain[1:], want[1:], m.events.ptr))
+        np.testing.assert_allclose(chain[0], want[0], rtol=1e-9, atol=0.0)
+        st = ens.replicate_state(r)
+        assert np.array_equal(st.infectious, m.infectious) and np.array_equal(st.susceptible, m.susceptible)
+        assert np.array_equal(st.lockdownON, m.lockdownON) and st.good_attempt == m.good_attempt
+        for k in st.COUNTERS:
+            assert getattr(st, k) == getattr(m, k), k
+    ens.close()
+
+
 def _table3(K, M, seed):
     """data/Table 3/Table 3.py:5-22 through today's setters (bench.py::make_table3)."""
     import bench

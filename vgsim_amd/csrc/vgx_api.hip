@@ -999,6 +999,7 @@ static int direct_core(vgx_engine *e, int64_t iterations, int64_t sample_size, f
     // wavefront kernel (any shape), and — when asked for — the lane kernel (serial, dense state) while the dense arrays fit.
     const bool recomb = e->recombination != 0.0;
     bool fast_remapped = false;   // a FAST request that the exact row / latency kernels serve better (undone below if the call lands on neither)
+    bool philox_remapped = false; // a counter-based request on a general model: the general row kernel's exact arithmetic on that stream
     {
         // FAST mode promises the exact mode's integer rows on the same seed and times within 1e-9 — which the exact mode delivers.  Its
         // own row kernel (vgx_quadf.hip) takes one-class models; for every other model that the exact row kernels or the latency
@@ -1009,11 +1010,19 @@ static int direct_core(vgx_engine *e, int64_t iterations, int64_t sample_size, f
         const bool general_shape = P <= VGX_QG_MAX_P && S <= VGX_QG_MAX_S && e->C <= VGX_QG_MAX_C && e->CB <= VGX_QG_MAX_CB &&
                                    3 * S + e->CB <= VGX_QG_MAX_W && (int64_t)e->h_seg_par.size() <= VGX_QG_MAX_SEG;
         if (o.mode == 1 && o.kernel == 0 && !recomb && !one_class_shape && general_shape) { o.mode = 0; fast_remapped = true; }
+        // The counter-based stream (mode 2) on such a model: the general row kernel's EXACT arithmetic on the Philox stream — the exact
+        // mode's rows for those random numbers (the oracle on the same stream agrees bit for bit), at that kernel's rate instead of the
+        // wavefront kernel's (16 384 replicates of the Table-3 model, K = 10: 1.3e9 against 2.5e8 events/s).  The latency kernels and the
+        // one-class exact row kernel draw from the PCG64 stream only.
+        // Likewise the latency kernels (one trajectory or a few: vgx_solo.hip, vgx_lone.hip), for every shape they take.
+        if (o.mode == 2 && (o.kernel == 0 || o.kernel == 3 || o.kernel == 4) && !recomb && !one_class_shape && general_shape) { o.mode = 0; philox_remapped = true; }
+        if (o.mode == 2 && (o.kernel == 0 || o.kernel == 5 || o.kernel == 6) && !recomb) { o.mode = 0; philox_remapped = true; }
     }
+    const bool philox = o.mode == 2 || philox_remapped;
     a.fast = o.mode >= 1 ? 1 : 0;
-    a.rng_philox = o.mode == 2 ? 1 : 0;
-    e->call_philox = o.mode == 2;
-    const bool lane_ok = o.mode == 0 && (recomb ? P * H * std::max<int64_t>(S, 1) <= (1 << 24)
+    a.rng_philox = philox ? 1 : 0;
+    e->call_philox = philox;
+    const bool lane_ok = o.mode == 0 && !philox_remapped && (recomb ? P * H * std::max<int64_t>(S, 1) <= (1 << 24)
                                                 : (P * H <= 1024 && P <= 16 && S <= 8 && H <= e->cap));
     if (recomb && o.mode != 0)
         return fail(e, VGX_ERR_ARG, "vgx_simulate_direct: recombination runs in exact mode only");
@@ -1051,7 +1060,7 @@ static int direct_core(vgx_engine *e, int64_t iterations, int64_t sample_size, f
         if (e->sizes[(size_t)pn] >= ((int64_t)1 << 31)) quad_shape = false;   // its streaming passes read 4-byte counts
     for (int64_t pn = 0; pn < P && quad_shape; pn++)
         if (h.totalSusceptible[(size_t)pn] != h.susceptible[(size_t)pn]) quad_shape = false;
-    const bool quad_ok = o.mode == 0 && quad_shape;
+    const bool quad_ok = o.mode == 0 && !philox_remapped && quad_shape;
     // One trajectory (or a few hundred) of such a model with a LARGE haplotype space: the latency kernel on occupancy lists
     // (vgx_lone.hip), every list resident in LDS.  One wavefront per CU with 160 KB each up to 256 replicates, two with 80 KB beyond
     // (512 at a time).  The row kernels' four replicates per wavefront win from about 2000 replicates on (tools/probe_lone_crossover.py,
@@ -1067,14 +1076,15 @@ static int direct_core(vgx_engine *e, int64_t iterations, int64_t sample_size, f
                           (int64_t)e->h_seg_par.size() <= VGX_LONE_MAX_SEG && H <= ((int64_t)1 << VGX_LONE_HAP_BITS);
     for (int64_t pn = 0; pn < P && lone_gen_shape; pn++)
         if (e->sizes[(size_t)pn] >= ((int64_t)1 << 31)) lone_gen_shape = false;   // 4-byte counts in the heap
-    loa.general = quad_ok ? 0 : 1;
+    const bool lone_one_class = o.mode == 0 && quad_shape;      // (its one-class form: the exact row kernel's scope, whatever the stream)
+    loa.general = lone_one_class ? 0 : 1;
     const int64_t lone_rows = vgx_lone_layout((int)P, loa.lds_bytes, loa.general ? (int)S : 0, loa.general ? e->CB : 0).nrows;
-    const bool lone_ok = (quad_ok || lone_gen_shape) && lone_rows >= 2 * P;
+    const bool lone_ok = (lone_one_class || lone_gen_shape) && lone_rows >= 2 * P;
     if (o.kernel == 6 && !lone_ok)
         return fail(e, VGX_ERR_ARG, "vgx_simulate_direct: the single-trajectory kernel for large haplotype spaces needs exact mode, popNum <= 64, "
                                     "susNum <= 16, at most 64 rate classes and 16 transmission/susceptibility classes, hapNum <= 2^26, no recombination");
     // FAST mode (order-free sums, PCG64 stream) on the same layout and scope: vgx_quadf.hip
-    const bool quadf_ok = (o.mode == 1 || o.mode == 2) && quad_shape;     // FAST, with the PCG64 or the counter-based stream
+    const bool quadf_ok = (o.mode == 1 || o.mode == 2 || philox_remapped) && quad_shape;     // FAST, with the PCG64 or the counter-based stream
     // The general form of that kernel (vgx_quadg.hip): several susceptibility groups and rate classes, lockdown switches,
     // up to 128 populations.
     const int64_t qg_W = 3 * S + e->CB;
@@ -1113,12 +1123,16 @@ static int direct_core(vgx_engine *e, int64_t iterations, int64_t sample_size, f
     // The general form also for FEW replicates of models with up to 16 populations (one register slot): a wavefront running alone
     // does a Table-3 trajectory at 1.7e5 events/s there against 1.0e5 on the one-replicate-per-wavefront kernel
     // (tools/probe_single.py; at 64 populations the wave kernel leads, 1.25e5 against 0.94e5).
-    const bool use_quadg = !use_solo && !use_lone && !use_quad && (o.kernel == 4 || (o.kernel == 3 && quadg_ok) ||
+    const bool use_quadg = !use_solo && !use_lone && !use_quad && !use_quadf && (o.kernel == 4 || (o.kernel == 3 && quadg_ok) ||
                                          (o.kernel == 0 && quadg_ok && !use_lanes && (R >= 2048 || (P <= 16 && (S > 1 || e->C > 1 || ld_possible)))));
     if (fast_remapped && !use_solo && !use_lone && !use_quadg && !use_quad && !use_lanes) {
         // (fewer than 2048 replicates of a model neither kernel takes there: the wavefront kernel's own FAST form is the faster one)
         a.fast = 1;
         o.mode = 1;
+    }
+    if (philox_remapped && !use_quadg && !use_solo && !use_lone) {   // (likewise: the FAST row kernel for one-class models, else the wavefront kernel's FAST form)
+        a.fast = 1;
+        o.mode = 2;
     }
     VgxLaneWs ws{};
     a.r.rec = nullptr; a.r.rec_cap = 0;
@@ -1247,7 +1261,8 @@ static int direct_core(vgx_engine *e, int64_t iterations, int64_t sample_size, f
             e->dev_state_valid = false;
             e->sc_host_valid = false;
             vgx_run_opts o2 = o;
-            o2.kernel = (quad_ok || quadg_ok) ? 3 : 1;
+            o2.kernel = (quad_ok || quadg_ok || quadf_ok) ? 3 : 1;
+            if (philox_remapped) o2.mode = 2;       // (the request as it came)
             e->lone_fallbacks += 1;
             return direct_core(e, iterations, sample_size, time, attempts, &o2);
         }

@@ -1190,7 +1190,12 @@ static __device__ __forceinline__ void lone_body() {
                         vgx_mul128(Ah, Al, sh, sl, h, l);
                         vgx_mul128(Gh, Gl, ih, il, ch, cl);
                         vgx_add128(h, l, ch, cl);
-                        const double u = vgx_pcg64_output_double(h, l);
+                        double u = vgx_pcg64_output_double(h, l);
+                        // the counter-based stream (vgx_run_opts.mode = 2: this kernel's exact arithmetic on other random numbers): iteration
+                        // i of the attempt takes outputs 2 i and 2 i + 1 of the stream of (seed, attempt), as the host clock reads them
+                        if (a.rng_philox)
+                            u = vgx_philox_stream_double((uint64_t)r.seeds[rep], (uint32_t)att,
+                                                         2 * (uint64_t)(att_loops + (int64_t)(c.loop_left0 - c.loop_left)) + (uint64_t)lane);
                         WSYNC();
                         c.ldRng[lane] = (CLOCK && !(lane & 1)) ? -vgx_log(u) : u;
                         if (lane == 63) { c.ldRngS[0] = h; c.ldRngS[1] = l; }

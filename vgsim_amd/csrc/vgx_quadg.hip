@@ -277,14 +277,23 @@ static __device__ __forceinline__ void quadg_body() {
             // ---- random numbers ----
             if (__builtin_expect(__ballot(ev && pos == 8) != 0, 0)) {
                 const bool fill = ev && pos == 8;
-                uint64_t h, l, ch, cl;
-                vgx_mul128(k_jump[0], k_jump[1], g_sh, g_sl, h, l);
-                vgx_mul128(k_jump[2], k_jump[3], s_inc[0], s_inc[1], ch, cl);
-                vgx_add128(h, l, ch, cl);
-                const double u = vgx_pcg64_output_double(h, l);
-                const double v = (rl & 1) ? u : -vgx_log(u);
-                const uint64_t nh = (uint64_t)rowget_i64((int64_t)h, 15), nl = (uint64_t)rowget_i64((int64_t)l, 15);
-                if (fill) { g_val = v; g_sh = nh; g_sl = nl; pos = 0; }
+                if (a.rng_philox) {
+                    // the counter-based stream (vgx_run_opts.mode = 2 on a general model: this kernel's exact arithmetic on other random
+                    // numbers): iteration i of the attempt takes outputs 2 i (time) and 2 i + 1 (event) of the stream of (seed, attempt),
+                    // as in vgx_quadf.hip and in the host clock
+                    const double u = vgx_philox_stream_double((uint64_t)r.seeds[rep], (uint32_t)last_att, 2 * (uint64_t)att_loops + (uint64_t)rl);
+                    const double v = (rl & 1) ? u : -vgx_log(u);
+                    if (fill) { g_val = v; pos = 0; }
+                } else {
+                    uint64_t h, l, ch, cl;
+                    vgx_mul128(k_jump[0], k_jump[1], g_sh, g_sl, h, l);
+                    vgx_mul128(k_jump[2], k_jump[3], s_inc[0], s_inc[1], ch, cl);
+                    vgx_add128(h, l, ch, cl);
+                    const double u = vgx_pcg64_output_double(h, l);
+                    const double v = (rl & 1) ? u : -vgx_log(u);
+                    const uint64_t nh = (uint64_t)rowget_i64((int64_t)h, 15), nl = (uint64_t)rowget_i64((int64_t)l, 15);
+                    if (fill) { g_val = v; g_sh = nh; g_sl = nl; pos = 0; }
+                }
             }
             const int pp = min(pos, 7);
             const double nlog = rowget_f64(g_val, 2 * pp), u2 = rowget_f64(g_val, 2 * pp + 1);
