@@ -1796,7 +1796,7 @@ extern "C" int vgx_simulate_tau(vgx_engine *e, int64_t iterations, int64_t sampl
     const bool occ_lists_ok = a.use8 && a.front_on && a.occ != nullptr && !(nol && nol[0] == '1');
     const char *ddr = getenv("VGX_TAU_DENSE_DRIFT");     // comparisons: vgx_tau_drift8_kernel also on sparse states
     const bool dense_drift = ddr && ddr[0] == '1';
-    int sparse_ban = 0;      // steps for which the drift pass stays dense
+    int sparse_ban = 0, sparse_ban_len = 32;      // steps for which the drift pass stays dense; the next such span
     const bool occ_lists_banned = false;
     int64_t occ_est = occupied;
     int64_t tries_total = 0, tries_lists = 0;
@@ -2228,7 +2228,11 @@ extern "C" int vgx_simulate_tau(vgx_engine *e, int64_t iterations, int64_t sampl
             mevn[(size_t)r] = (unsigned long long)o[11];
             err_h[(size_t)r] = (int32_t)o[12];
             if (o[13] >= 0) occ_step = std::max<int64_t>(occ_step, o[13]);
-            if (a.drift_sparse && o[15] >= 0 && (o[13] + 30 * o[15]) * 26 > P * H) sparse_ban = 32;
+            if (a.drift_sparse && o[15] >= 0) {
+                // (another look after 32 steps, then 64, ... 4096 while the answer stays the same: such a pass can be many times the dense one)
+                if ((o[13] + 30 * o[15]) * 26 > P * H) { sparse_ban = sparse_ban_len; sparse_ban_len = std::min(2 * sparse_ban_len, 4096); }
+                else sparse_ban_len = 32;
+            }
             if (spec_rounds && r == 0) {
                 tries_total += o[14] + 1;
                 if (a.use_list) tries_lists += o[14] + 1;
