@@ -693,6 +693,78 @@ struct Solo {
         }
     }
 
+    // ---- the same loop for ONE haplotype, ONE population, ONE group without immunity loss (BASELINE config 2; upstream's default model).
+    // There totalRate, popRate[0], infectPopRate[0] and hapPopRate[0, 0] are ONE number — popRate = infectPopRate + (+0.0), the prefix
+    // sums of one term are 0.0 + the term — so GenerateEvent's four rescalings (pyx:483-511, fc:18-31) divide by the same divisor: one
+    // refined reciprocal serves all four (fdiv_y: the quotients are the same correctly rounded ones), every index is 0 without a
+    // search, `x - (cum - w)` is `x - 0.0`, and no row is switched.  The apply / UpdateRates half is fast_loop's. ----
+    __device__ __forceinline__ int unit_fast_loop(double &u_slow, int &pi_post) {
+        for (;;) {
+            PROF(14);
+            if (min(min(ev_left, loop_left), s_left) <= 0) return FAST_END;
+            if (CLOCK && !any_lane(currentTime < tlimit)) return FAST_END;
+            if (pos == 32) return FAST_REFILL;
+            const double u = u_pre;
+            double t_new = 0.0;
+            if (CLOCK) {
+                t_new = currentTime + (n_pre / Rtot);
+                if (any_lane(next_tg < t_new)) { u_slow = u; return FAST_SLOW; }
+            }
+            PROF(0);
+            const double T = totalRate;
+            double choose = u * Rtot;
+            if (!any_lane(T > choose)) { u_slow = u; return FAST_SLOW; }
+            const double y = refined_rcp(T);
+            double rn = fdiv_y(choose, T, y);                              // choose / totalRate
+            zero_weight(T == 0.0);
+            rn = fdiv_y(T * rn - 0.0, T, y);                               // (r - (cumPop - popRate)) / popRate
+            choose = rn * T;                                               // (immunePopRate = +0.0 > choose: never)
+            rn = fdiv_y(choose - 0.0, T, y);                               // (choose - immunePopRate) / infectPopRate
+            const double rn5 = fdiv_y(T * rn - 0.0, T, y);                 // (r - (cum - hapPopRate)) / hapPopRate
+            const double r6 = tE * rn5;
+            const int eil = (birth < r6 ? 1 : 0) + (e1 < r6 ? 1 : 0) + (e2 < r6 ? 1 : 0);
+            const int ei = __builtin_amdgcn_readlane(eil, 0);
+            if (ei == 3 || (ei == 0 && recomb)) { u_slow = u; return FAST_SLOW; }
+            PROF(5);
+            loop_left -= 1;
+            pos += 1;
+            prefetch_uniforms();
+            if (CLOCK) currentTime = t_new;
+            zero_weight(lane == 0 && hpr == 0.0);
+            if (ei == 0) {
+                zero_weight(lane == 0 && birth == 0.0);
+                zero_w |= __builtin_amdgcn_ballot_w64(Sst * sigcs == 0.0) & 1ull;      // choose_group: susceptHapPopRate[0, 0, 0] == 0
+            }
+            const double sgn = ei == 0 ? 1.0 : -1.0;
+            sus_add(0, sgn);
+            const double d1 = lane == 0 ? sgn : 0.0;
+            I += d1;
+            totS[0] -= d1; totI[0] += d1;
+            gI += sgn;
+            imms = l15 == 0 ? cumul_l * Ssus : imms;
+            PROF(6);
+            const double ps = birth_sums();
+            PROF(10);
+            totalMig = 0.0;                                                // (one population: no migration)
+            PROF(12);
+            const double inP = refresh_rates(ps);
+            PROF(9);
+            infectP[0] = lane == 0 ? inP : infectP[0];
+            immuneP[0] = lane == 0 ? 0.0 : immuneP[0];
+            popRate[0] = lane == 0 ? inP + 0.0 : popRate[0];
+            cumPop[0] = 0.0 + popRate[0];
+            totalRate = bcast(cumPop[0], 0);
+            PROF(11);
+            const double den = Rtot;
+            Rtot = totalRate + totalMig;
+            log_event<true>(ei, 0, 0, 0, ei == 0 ? H : 0, den);
+            PROF(13);
+            const bool stop = (totalRate == 0.0) | (gI == 0.0) | ((lane == 0) & ((totI[0] - thrCur[0]) * sgnLD[0] > 0.0));
+            const unsigned long long post = __builtin_amdgcn_ballot_w64(stop) | zero_w | (unsigned long long)(stage_n >> 6);
+            if (post) { pi_post = 0; return FAST_POST; }
+        }
+    }
+
     // ---- one iteration of the event loop after SampleTime in its general form: GenerateEvent (pyx:483-512) with UpdateRates and
     // AddEvent; returns the population whose lockdown state has to be checked ----
     __device__ __forceinline__ int event(double u) {
@@ -1147,7 +1219,7 @@ static __device__ __forceinline__ void solo_body() {
                 for (;;) {
                     double u_slow = 0.0;
                     int pi = 0;
-                    const int why = c.fast_loop(u_slow, pi);
+                    const int why = (UNIT && c.no_imm && !c.has_mig && c.cur == 0) ? c.unit_fast_loop(u_slow, pi) : c.fast_loop(u_slow, pi);
                     if (why == c.FAST_END) break;
                     if (why == c.FAST_REFILL) {
                         // 64 PCG64 outputs: lane k jumps the stream k + 1 steps ahead (exact 128-bit arithmetic); even outputs are the
